@@ -1,0 +1,120 @@
+/*
+ * include/tf_msda.h -- C ABI of libtf_msda.so, the MI355X (gfx950) implementation of TrackFormer's
+ * multi-scale deformable attention operator.
+ *
+ * This is the drop-in boundary for the reference's native extension `MultiScaleDeformableAttention`:
+ *
+ *   reference interface (paths under /root/reference/src/trackformer/models/ops/)      replaced by
+ *   ---------------------------------------------------------------------------------  -----------------------
+ *   ms_deform_attn_forward(value, spatial_shapes, sampling_loc, attn_weight, step)      tf_msda_forward_{f32,f64}
+ *     src/vision.cpp:5, src/ms_deform_attn.h:10-28, src/cuda/ms_deform_attn_cuda.cu:19-86
+ *   ms_deform_attn_backward(value, spatial_shapes, sampling_loc, attn_weight,           tf_msda_backward_{f32,f64}
+ *                           grad_output, step)
+ *     src/vision.cpp:6, src/ms_deform_attn.h:30-49, src/cuda/ms_deform_attn_cuda.cu:89-168
+ *
+ * The binding that exposes these under the reference's Python names
+ * (`MultiScaleDeformableAttention.ms_deform_attn_forward/backward`) lives in
+ * trackformer_amd/dropin/MultiScaleDeformableAttention.py; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no torch / ATen types.  All data pointers are DEVICE pointers
+ *     on the current HIP device unless marked "host".  The caller owns every buffer.
+ *   - Tensors are dense row-major:
+ *       value        [N, S, M, D]          S = sum_l H_l*W_l; level l occupies rows start_l .. start_l+H_l*W_l
+ *       shapes       [L, 2] int64 (H_l, W_l)
+ *       loc          [N, Lq, M, L, P, 2]   (x, y) normalised to [0,1] over the level; pixel = loc*size - 0.5,
+ *                                          zero padding outside, in range iff -1 < pixel < size
+ *       attn         [N, Lq, M, L, P]
+ *       out/grad_out [N, Lq, M*D]
+ *   - Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and the
+ *     call returns without synchronising.  Re-entrant; no global state.  HIP-graph capturable.
+ *   - Return value: TF_MSDA_OK (0) or a negative tf_msda_status.  Never throws.
+ *   - im2col_step of the reference API only chunks the batch (cu:44-66) and does not change results;
+ *     this ABI has no such parameter.
+ */
+#ifndef TF_MSDA_H_
+#define TF_MSDA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TF_MSDA_ABI_VERSION 1
+#define TF_MSDA_MAX_LEVELS 16
+
+typedef enum tf_msda_status {
+    TF_MSDA_OK = 0,
+    TF_MSDA_ERR_NULL_POINTER = -1,  /* a required pointer was NULL */
+    TF_MSDA_ERR_BAD_DIMS = -2,      /* a dimension <= 0, L > TF_MSDA_MAX_LEVELS, or sizes overflow */
+    TF_MSDA_ERR_SHAPE_SUM = -3,     /* sum_l H_l*W_l != S (host-shape entry points only) */
+    TF_MSDA_ERR_LAUNCH = -4,        /* HIP reported an error enqueueing work (see tf_msda_last_hip_error) */
+    TF_MSDA_ERR_NO_DEVICE = -5      /* no HIP device available */
+} tf_msda_status;
+
+/* ABI version of the loaded library (== TF_MSDA_ABI_VERSION it was built with). */
+int tf_msda_abi_version(void);
+
+/* Human-readable text for a tf_msda_status. Never NULL. */
+const char *tf_msda_strerror(int status);
+
+/* hipError_t (as int) of the most recent failing HIP call on this thread, 0 if none. */
+int tf_msda_last_hip_error(void);
+
+/*
+ * Forward.  out[N,Lq,M*D] = sum_{l,p} attn * bilinear(value_l, loc)      (Appendix A of SURVEY.md)
+ *
+ * shapes_hw_host : HOST pointer to L*2 int64 (H_l, W_l).  Passed by value to the kernel; nothing is
+ *                  read from it after the call returns.
+ * replaces ms_deform_attn_cuda_forward (cu:19-86) + ms_deformable_im2col_gpu_kernel (cuh:165-237).
+ */
+int tf_msda_forward_f32(const float *value, const int64_t *shapes_hw_host, const float *loc,
+                        const float *attn, float *out, int N, int S, int M, int D, int L, int Lq,
+                        int P, void *stream);
+int tf_msda_forward_f64(const double *value, const int64_t *shapes_hw_host, const double *loc,
+                        const double *attn, double *out, int N, int S, int M, int D, int L, int Lq,
+                        int P, void *stream);
+
+/*
+ * Same, but the level shapes are read from DEVICE memory inside the kernel (what the reference does,
+ * cuh:194-196) -- for callers that only hold the reference's device-resident `spatial_shapes` tensor
+ * and must not synchronise.  sum_l H_l*W_l == S is the caller's responsibility (not checkable without a
+ * device->host copy).
+ */
+int tf_msda_forward_f32_dshapes(const float *value, const int64_t *shapes_hw_dev, const float *loc,
+                                const float *attn, float *out, int N, int S, int M, int D, int L,
+                                int Lq, int P, void *stream);
+int tf_msda_forward_f64_dshapes(const double *value, const int64_t *shapes_hw_dev,
+                                const double *loc, const double *attn, double *out, int N, int S,
+                                int M, int D, int L, int Lq, int P, void *stream);
+
+/*
+ * Backward.  Writes all three gradients; grad_value is zero-filled on `stream` by the library before
+ * accumulation (reference: at::zeros_like, cu:119-121), grad_loc / grad_attn are fully overwritten.
+ * grad_value accumulation uses hardware floating-point atomics, so its summation order (and therefore
+ * its last bits) is not deterministic -- as in the reference (cuh:301).
+ * replaces ms_deform_attn_cuda_backward (cu:89-168) + ms_deformable_col2im_gpu_kernel (cuh:239-306) +
+ * ms_deformable_col2im_coord_gpu_kernel (cuh:308-378).
+ */
+int tf_msda_backward_f32(const float *value, const int64_t *shapes_hw_host, const float *loc,
+                         const float *attn, const float *grad_out, float *grad_value,
+                         float *grad_loc, float *grad_attn, int N, int S, int M, int D, int L,
+                         int Lq, int P, void *stream);
+int tf_msda_backward_f64(const double *value, const int64_t *shapes_hw_host, const double *loc,
+                         const double *attn, const double *grad_out, double *grad_value,
+                         double *grad_loc, double *grad_attn, int N, int S, int M, int D, int L,
+                         int Lq, int P, void *stream);
+int tf_msda_backward_f32_dshapes(const float *value, const int64_t *shapes_hw_dev, const float *loc,
+                                 const float *attn, const float *grad_out, float *grad_value,
+                                 float *grad_loc, float *grad_attn, int N, int S, int M, int D,
+                                 int L, int Lq, int P, void *stream);
+int tf_msda_backward_f64_dshapes(const double *value, const int64_t *shapes_hw_dev,
+                                 const double *loc, const double *attn, const double *grad_out,
+                                 double *grad_value, double *grad_loc, double *grad_attn, int N,
+                                 int S, int M, int D, int L, int Lq, int P, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TF_MSDA_H_ */

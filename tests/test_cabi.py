@@ -1,0 +1,56 @@
+"""CPU: the C-ABI shared library loads and exports exactly what include/tf_msda.h declares;
+argument validation works without a GPU (no compute is launched here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from trackformer_amd import _cabi, build
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_all()
+    return _cabi.lib()
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "tf_msda.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tf_msda_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(_cabi.EXPORTED_SYMBOLS)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    raw = ctypes.CDLL(_cabi.LIB_PATH)
+    for name in _declared_symbols():
+        assert hasattr(raw, name), name
+
+
+def test_abi_version_and_strerror(lib):
+    assert lib.tf_msda_abi_version() == _cabi.ABI_VERSION
+    assert lib.tf_msda_strerror(0) == b"ok"
+    for code in (-1, -2, -3, -4, -5, -99):
+        assert len(lib.tf_msda_strerror(code)) > 0
+
+
+def test_null_and_bad_dims_are_rejected_before_any_gpu_work(lib):
+    shp = (ctypes.c_int64 * 2)(2, 2)
+    one = ctypes.c_void_p(16)  # never dereferenced: validation fails first
+    assert lib.tf_msda_forward_f32(None, shp, one, one, one, 1, 4, 1, 4, 1, 1, 1, None) == -1
+    assert lib.tf_msda_forward_f32(one, None, one, one, one, 1, 4, 1, 4, 1, 1, 1, None) == -1
+    assert lib.tf_msda_forward_f32(one, shp, one, one, one, 0, 4, 1, 4, 1, 1, 1, None) == -2
+    assert lib.tf_msda_forward_f32(one, shp, one, one, one, 1, 4, 1, 4, 17, 1, 1, None) == -2
+    assert lib.tf_msda_forward_f32(one, shp, one, one, one, 1, 5, 1, 4, 1, 1, 1, None) == -3
+    assert lib.tf_msda_backward_f64(one, shp, one, one, one, one, one, None, 1, 4, 1, 4, 1, 1, 1,
+                                    None) == -1
+    assert lib.tf_msda_backward_f32(one, shp, one, one, one, one, one, one, 1, 5, 1, 4, 1, 1, 1,
+                                    None) == -3
+    with pytest.raises(_cabi.MSDAError):
+        _cabi.check(-3, "unit test")

@@ -1,0 +1,72 @@
+"""ctypes binding of include/tf_msda.h (libtf_msda.so).
+
+This is the only place the package touches the native library.  There is deliberately no fallback:
+if the library is missing, `lib()` raises, and so does every operator built on it.
+"""
+import ctypes
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libtf_msda.so")
+
+# Every symbol include/tf_msda.h declares (tests/test_cabi.py checks the list against the header).
+EXPORTED_SYMBOLS = (
+    "tf_msda_abi_version",
+    "tf_msda_strerror",
+    "tf_msda_last_hip_error",
+    "tf_msda_forward_f32",
+    "tf_msda_forward_f64",
+    "tf_msda_forward_f32_dshapes",
+    "tf_msda_forward_f64_dshapes",
+    "tf_msda_backward_f32",
+    "tf_msda_backward_f64",
+    "tf_msda_backward_f32_dshapes",
+    "tf_msda_backward_f64_dshapes",
+)
+
+ABI_VERSION = 1
+
+_lib = None
+
+
+class MSDAError(RuntimeError):
+    """Raised when libtf_msda.so reports a non-zero status."""
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "trackformer_amd: native library %s not found. Build it with "
+            "`python -m trackformer_amd.build` (needs hipcc); there is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.tf_msda_abi_version.restype = ci
+    L.tf_msda_abi_version.argtypes = []
+    L.tf_msda_strerror.restype = ctypes.c_char_p
+    L.tf_msda_strerror.argtypes = [ci]
+    L.tf_msda_last_hip_error.restype = ci
+    L.tf_msda_last_hip_error.argtypes = []
+    for suf in ("f32", "f64"):
+        for tail in ("", "_dshapes"):
+            f = getattr(L, "tf_msda_forward_%s%s" % (suf, tail))
+            f.restype = ci
+            f.argtypes = [vp] * 5 + [ci] * 7 + [vp]
+            b = getattr(L, "tf_msda_backward_%s%s" % (suf, tail))
+            b.restype = ci
+            b.argtypes = [vp] * 8 + [ci] * 7 + [vp]
+    if L.tf_msda_abi_version() != ABI_VERSION:
+        raise RuntimeError("libtf_msda.so ABI version %d != expected %d (rebuild)" %
+                           (L.tf_msda_abi_version(), ABI_VERSION))
+    _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        L = lib()
+        msg = L.tf_msda_strerror(status).decode()
+        raise MSDAError("%s failed: %s (status %d, hipError %d)" %
+                        (what, msg, status, L.tf_msda_last_hip_error()))

@@ -1,0 +1,267 @@
+"""Multi-scale deformable attention: the operator, its autograd wrapper and the nn.Module.
+
+Host-side mirror of the reference's operator interface (names, argument meaning, error behaviour):
+
+    reference (under /root/reference/src/trackformer/models/ops/)          here
+    --------------------------------------------------------------------   ------------------------------
+    MSDA.ms_deform_attn_forward / _backward   src/vision.cpp:4-7            ms_deform_attn_forward / _backward
+    MSDeformAttnFunction                      functions/ms_deform_attn_func.py:14-31   MSDeformAttnFunction
+    MSDeformAttn                              modules/ms_deform_attn.py:16-89          MSDeformAttn
+
+All compute goes through the C ABI of libtf_msda.so (include/tf_msda.h) on the current HIP stream.
+There is no CPU implementation: CPU tensors raise "Not implemented on the CPU", exactly like the
+reference dispatcher (src/ms_deform_attn.h:27,48).
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.init import constant_, xavier_uniform_
+
+from . import _cabi
+
+_HOST_SHAPE_ATTR = "_tf_msda_host_shapes"
+_shape_array_cache = {}
+
+
+def attach_host_shapes(spatial_shapes, host_shapes):
+    """Remember the (H_l, W_l) list of a device-resident `spatial_shapes` tensor on the tensor object.
+
+    The reference keeps `spatial_shapes` only as an int64 device tensor (deformable_transformer.py:156)
+    and reads it inside the kernel.  Callers that know the shapes on the host (our transformer does)
+    attach them so that the operator can pass them by value and validate sum(H*W) == S without a
+    device->host copy.  Purely an optimisation: without the attribute the *_dshapes entry points are used.
+    """
+    setattr(spatial_shapes, _HOST_SHAPE_ATTR, tuple((int(h), int(w)) for h, w in host_shapes))
+    return spatial_shapes
+
+
+def _host_shapes_of(spatial_shapes):
+    hs = getattr(spatial_shapes, _HOST_SHAPE_ATTR, None)
+    if hs is not None:
+        return hs
+    if not spatial_shapes.is_cuda:
+        return tuple((int(h), int(w)) for h, w in spatial_shapes.tolist())
+    return None
+
+
+def _shape_array(host_shapes):
+    arr = _shape_array_cache.get(host_shapes)
+    if arr is None:
+        flat = [v for hw in host_shapes for v in hw]
+        arr = (ctypes.c_int64 * len(flat))(*flat)
+        _shape_array_cache[host_shapes] = arr
+    return arr
+
+
+def _suffix(dtype):
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise RuntimeError("ms_deform_attn: only float32 and float64 are supported, got %s" % dtype)
+
+
+def _check_inputs(value, spatial_shapes, sampling_loc, attn_weight, im2col_step):
+    if not value.is_cuda:
+        raise RuntimeError("Not implemented on the CPU")  # src/ms_deform_attn.h:27,48
+    if not value.is_contiguous():
+        raise RuntimeError("value tensor has to be contiguous")  # cu:29
+    for name, t in (("sampling_loc", sampling_loc), ("attn_weight", attn_weight)):
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)  # cu:33-34 (HIP device here)
+        if t.device != value.device:
+            raise RuntimeError("%s is on %s but value is on %s" % (name, t.device, value.device))
+        if t.dtype != value.dtype:
+            raise RuntimeError("%s has dtype %s but value has %s" % (name, t.dtype, value.dtype))
+    if value.dim() != 4 or sampling_loc.dim() != 6 or attn_weight.dim() != 5:
+        raise RuntimeError("ms_deform_attn: expected value[N,S,M,D], sampling_loc[N,Lq,M,L,P,2], "
+                           "attn_weight[N,Lq,M,L,P]")
+    N, S, M, D = value.shape
+    N2, Lq, M2, L, P, two = sampling_loc.shape
+    if (N2, M2, two) != (N, M, 2) or tuple(attn_weight.shape) != (N, Lq, M, L, P):
+        raise RuntimeError("ms_deform_attn: inconsistent tensor shapes")
+    if spatial_shapes.dim() != 2 or tuple(spatial_shapes.shape) != (L, 2) \
+            or spatial_shapes.dtype != torch.int64:
+        raise RuntimeError("spatial_shapes must be an int64 tensor of shape [L, 2]")
+    step = min(N, int(im2col_step))
+    if step <= 0 or N % step != 0:  # cu:44-48
+        raise RuntimeError("batch(%d) must divide im2col_step(%d)" % (N, step))
+    return N, S, M, D, L, Lq, P
+
+
+def _shape_args(spatial_shapes, value):
+    """Returns (tail, pointer-ish, keepalive) for the host- or device-shape entry point."""
+    hs = _host_shapes_of(spatial_shapes)
+    if hs is not None:
+        arr = _shape_array(hs)
+        return "", ctypes.cast(arr, ctypes.c_void_p), arr
+    if spatial_shapes.device != value.device:
+        raise RuntimeError("spatial_shapes must be a CUDA tensor")  # cu:32
+    ss = spatial_shapes.contiguous()
+    return "_dshapes", ctypes.c_void_p(ss.data_ptr()), ss
+
+
+def ms_deform_attn_forward(value, spatial_shapes, sampling_loc, attn_weight, im2col_step=64):
+    """value[N,S,M,D], spatial_shapes[L,2] i64, sampling_loc[N,Lq,M,L,P,2], attn_weight[N,Lq,M,L,P]
+    -> output[N,Lq,M*D].   Same contract as the reference's MSDA.ms_deform_attn_forward
+    (src/cuda/ms_deform_attn_cuda.cu:19-86); `im2col_step` is validated like the reference does and
+    otherwise ignored (it never changed results)."""
+    N, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, sampling_loc, attn_weight,
+                                         im2col_step)
+    suf = _suffix(value.dtype)
+    sampling_loc = sampling_loc.contiguous()
+    attn_weight = attn_weight.contiguous()
+    lib = _cabi.lib()
+    with torch.cuda.device(value.device):
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        tail, shp, keep = _shape_args(spatial_shapes, value)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(lib, "tf_msda_forward_%s%s" % (suf, tail))(
+            value.data_ptr(), shp, sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
+            N, S, M, D, L, Lq, P, stream)
+    del keep
+    _cabi.check(rc, "ms_deform_attn_forward")
+    return out
+
+
+def ms_deform_attn_backward(value, spatial_shapes, sampling_loc, attn_weight, grad_output,
+                            im2col_step=64):
+    """-> [grad_value, grad_sampling_loc, grad_attn_weight], shaped like the respective inputs
+    (reference: src/cuda/ms_deform_attn_cuda.cu:89-168)."""
+    N, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, sampling_loc, attn_weight,
+                                         im2col_step)
+    suf = _suffix(value.dtype)
+    if not grad_output.is_cuda or grad_output.dtype != value.dtype \
+            or grad_output.numel() != N * Lq * M * D:
+        raise RuntimeError("grad_output must be a CUDA tensor of shape [N, Lq, M*D] and value's dtype")
+    sampling_loc = sampling_loc.contiguous()
+    attn_weight = attn_weight.contiguous()
+    grad_output = grad_output.contiguous()  # autograd may hand over a strided view
+    lib = _cabi.lib()
+    with torch.cuda.device(value.device):
+        grad_value = torch.empty_like(value)  # zero-filled by the library on the stream
+        grad_loc = torch.empty_like(sampling_loc)
+        grad_attn = torch.empty_like(attn_weight)
+        tail, shp, keep = _shape_args(spatial_shapes, value)
+        stream = torch.cuda.current_stream().cuda_stream
+        rc = getattr(lib, "tf_msda_backward_%s%s" % (suf, tail))(
+            value.data_ptr(), shp, sampling_loc.data_ptr(), attn_weight.data_ptr(),
+            grad_output.data_ptr(), grad_value.data_ptr(), grad_loc.data_ptr(),
+            grad_attn.data_ptr(), N, S, M, D, L, Lq, P, stream)
+    del keep
+    _cabi.check(rc, "ms_deform_attn_backward")
+    return [grad_value, grad_loc, grad_attn]
+
+
+class MSDeformAttnFunction(Function):
+    """Autograd wrapper; mirrors functions/ms_deform_attn_func.py:14-31."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, sampling_locations, attention_weights,
+                im2col_step):
+        ctx.im2col_step = im2col_step
+        ctx.host_shapes = _host_shapes_of(value_spatial_shapes)
+        output = ms_deform_attn_forward(value, value_spatial_shapes, sampling_locations,
+                                        attention_weights, ctx.im2col_step)
+        ctx.save_for_backward(value, value_spatial_shapes, sampling_locations, attention_weights)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, value_spatial_shapes, sampling_locations, attention_weights = ctx.saved_tensors
+        if ctx.host_shapes is not None:
+            attach_host_shapes(value_spatial_shapes, ctx.host_shapes)
+        grad_value, grad_sampling_loc, grad_attn_weight = ms_deform_attn_backward(
+            value, value_spatial_shapes, sampling_locations, attention_weights, grad_output,
+            ctx.im2col_step)
+        return grad_value, None, grad_sampling_loc, grad_attn_weight, None
+
+
+class MSDeformAttn(nn.Module):
+    """Same constructor, parameters (state_dict keys) and forward contract as the reference module
+    (modules/ms_deform_attn.py:16-89)."""
+
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4, im2col_step=64):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, got %d and %d" %
+                             (d_model, n_heads))
+        self.im2col_step = im2col_step
+        self.d_model = d_model
+        self.n_levels = n_levels
+        self.n_heads = n_heads
+        self.n_points = n_points
+
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # modules/ms_deform_attn.py:34-47.  The 8-direction table of the reference is the set of
+        # unit steps ordered (-1,-1),(-1,0),(-1,1),(0,-1),(0,1),(1,-1),(1,0),(1,1); like the
+        # reference it only fits n_heads == 8.
+        constant_(self.sampling_offsets.weight.data, 0.)
+        dirs = [(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1) if (a, b) != (0, 0)]
+        if self.n_heads != len(dirs):
+            raise ValueError("MSDeformAttn bias initialisation requires n_heads == 8")
+        grid = torch.tensor(dirs, dtype=torch.float32).view(self.n_heads, 1, 1, 2)
+        grid = grid.repeat(1, self.n_levels, self.n_points, 1)
+        scale = torch.arange(1, self.n_points + 1, dtype=torch.float32).view(1, 1, -1, 1)
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter((grid * scale).reshape(-1))
+        constant_(self.attention_weights.weight.data, 0.)
+        constant_(self.attention_weights.bias.data, 0.)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
+                input_padding_mask=None, query_attn_mask=None):
+        """query[N,Lq,C], reference_points[N,Lq,L,2|4] in [0,1], input_flatten[N,S,C],
+        input_spatial_shapes[L,2] (H_l,W_l), input_padding_mask[N,S] (True = padding)
+        -> [N,Lq,C]   (modules/ms_deform_attn.py:49-89)."""
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        hs = _host_shapes_of(input_spatial_shapes)
+        if hs is not None:
+            if sum(h * w for h, w in hs) != Len_in:
+                raise AssertionError("sum of H_l*W_l does not match the flattened input length")
+        else:  # reference behaviour (one device sync), ms_deform_attn.py:62
+            assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+
+        M, L, P = self.n_heads, self.n_levels, self.n_points
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, M, self.d_model // M)
+
+        sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
+        attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
+        attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, M, L, P)
+        if query_attn_mask is not None:
+            attention_weights = attention_weights.masked_fill(
+                query_attn_mask[..., None, None, None], float(0))
+
+        if reference_points.shape[-1] == 2:
+            # NB: the divisor is (H_l, W_l) applied to (x, y) offsets, as written in the reference
+            # (ms_deform_attn.py:78-79); checkpoints were trained with it.
+            sampling_locations = reference_points[:, :, None, :, None, :] \
+                + sampling_offsets / input_spatial_shapes[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'
+                             .format(reference_points.shape[-1]))
+        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, sampling_locations,
+                                            attention_weights, self.im2col_step)
+        return self.output_proj(output)
