@@ -35,14 +35,14 @@ def _tol(dtype):
 
 def _fwd(value, shapes, loc, attn, host_shapes=True):
     from trackformer_amd import msda
-    if host_shapes:
+    if host_shapes and msda._host_shapes_of(shapes) is None:
         msda.attach_host_shapes(shapes, shapes.tolist())
     return msda.ms_deform_attn_forward(value, shapes, loc, attn, 64)
 
 
 def _bwd(value, shapes, loc, attn, grad_out, host_shapes=True):
     from trackformer_amd import msda
-    if host_shapes:
+    if host_shapes and msda._host_shapes_of(shapes) is None:
         msda.attach_host_shapes(shapes, shapes.tolist())
     return msda.ms_deform_attn_backward(value, shapes, loc, attn, grad_out, 64)
 

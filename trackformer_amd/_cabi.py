@@ -41,6 +41,10 @@ def lib():
         raise RuntimeError(
             "trackformer_amd: native library %s not found. Build it with "
             "`python -m trackformer_amd.build` (needs hipcc); there is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).
+    # It must be the one already mapped when libtf_msda.so is loaded, otherwise the process ends up
+    # with two HIP runtimes and torch's streams / device pointers mean nothing to ours.
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     vp, ci = ctypes.c_void_p, ctypes.c_int
     L.tf_msda_abi_version.restype = ci

@@ -103,17 +103,18 @@ __device__ __forceinline__ Tap<T> make_tap(T lx, T ly, int H, int W)
     Tap<T> t;
     // loc*size - 0.5 with a single rounding == the reference's double-literal expression narrowed
     // to T (cuh:227-228): the product is exact in double for any float loc and int size.
-    const T x = fma_t(lx, (T)W, (T)-0.5);
-    const T y = fma_t(ly, (T)H, (T)-0.5);
-    const bool in = (y > (T)-1) && (x > (T)-1) && (y < (T)H) && (x < (T)W);
+    const T xr = fma_t(lx, (T)W, (T)-0.5);
+    const T yr = fma_t(ly, (T)H, (T)-0.5);
+    const bool in = (yr > (T)-1) && (xr > (T)-1) && (yr < (T)H) && (xr < (T)W);
+    // Out-of-range samples may carry huge / non-finite coordinates: neutralise them so that every
+    // derived quantity stays finite (their taps are all invalid anyway).
+    const T x = in ? xr : (T)0, y = in ? yr : (T)0;
     const T xf = floor_t(x), yf = floor_t(y);
     t.fx = x - xf;
     t.fy = y - yf;
     t.gx = (T)1 - t.fx;
     t.gy = (T)1 - t.fy;
-    // Out-of-range samples may carry huge / non-finite coordinates: clamp in floating point first.
-    const T xc = in ? xf : (T)0, yc = in ? yf : (T)0;
-    const int x0 = (int)xc, y0 = (int)yc;
+    const int x0 = (int)xf, y0 = (int)yf;
     const int x1 = x0 + 1, y1 = y0 + 1;
     const bool kx0 = in && (x0 >= 0), kx1 = in && (x1 <= W - 1);
     const bool ky0 = in && (y0 >= 0), ky1 = in && (y1 <= H - 1);
@@ -128,6 +129,19 @@ __device__ __forceinline__ Tap<T> make_tap(T lx, T ly, int H, int W)
     t.k3 = ky1 && kx0;
     t.k4 = ky1 && kx1;
     return t;
+}
+
+// XCD-aware block order.  The dispatcher places workgroup i on XCD i % 8 (observed behaviour, used
+// for speed only).  Remapping i -> (i % 8) * ceil(n/8) + i / 8 hands each XCD one contiguous eighth
+// of the pair range, i.e. (for encoder self-attention, where consecutive queries are neighbouring
+// pixels) one band of rows per level, whose value rows then fit that XCD's private 4 MiB L2.
+// The launch grid is padded to a multiple of 8; returns -1 for the padding workgroups.
+constexpr int kXcds = 8;
+__device__ __forceinline__ long long logical_block(long long nblocks)
+{
+    const long long per = (nblocks + kXcds - 1) / kXcds;
+    const long long lb = (long long)(blockIdx.x % kXcds) * per + blockIdx.x / kXcds;
+    return (blockIdx.x / kXcds < per && lb < nblocks) ? lb : -1;
 }
 
 // Cooperative, coalesced copy of `n` elements global -> LDS (or LDS -> global).
@@ -158,7 +172,9 @@ msda_fwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
     T *s_loc = reinterpret_cast<T *>(smem + kLevelTableBytes);
     T *s_attn = s_loc + (size_t)ppb * LP * 2;
 
-    const long long pair0 = (long long)blockIdx.x * ppb;
+    const long long lblk = logical_block((total_pairs + ppb - 1) / ppb);
+    if (lblk < 0) return;
+    const long long pair0 = lblk * ppb;
     const int npairs = (int)min((long long)ppb, total_pairs - pair0);
 
     fill_level_table(s_tab, lt, dshapes, L);
@@ -215,6 +231,104 @@ msda_fwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, fp32 fast path: buffer loads with hardware bounds checking
+// ---------------------------------------------------------------------------------------------
+// Same pair/lane mapping as msda_fwd_rowgather, but every tap is a `buffer_load_dwordx4` through one
+// kernel-uniform buffer descriptor that spans the whole value tensor:
+//   * the per-lane address is a 32-bit byte offset (one v_mad_u32_u24 per tap instead of 64-bit
+//     multiply-adds);
+//   * an invalid tap (outside the level, or an out-of-range sample) gets an offset beyond
+//     num_records, for which the hardware returns 0 -- zero padding without selects, without
+//     clamping and without divergent code, and a 0*Inf can never be formed;
+//   * P is a template parameter so the 4*P loads of a level are issued back to back before the first
+//     use (the compiler cannot sink them into conditionals: there are none).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0xFFFFFFF0u;  // >= num_records for every supported tensor
+
+template <int PT>
+__global__ void __launch_bounds__(kThreads)
+msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
+                 const float *__restrict__ loc, const float *__restrict__ attn,
+                 float *__restrict__ out, const LevelTable lt, const int64_t *__restrict__ dshapes,
+                 int S, int M, int D, int L, int Lq, long long total_pairs, int ppb, int DV)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *s_tab = reinterpret_cast<int *>(smem);
+    const int LP = L * PT;
+    float *s_loc = reinterpret_cast<float *>(smem + kLevelTableBytes);
+    float *s_attn = s_loc + (size_t)ppb * LP * 2;
+
+    const long long lblk = logical_block((total_pairs + ppb - 1) / ppb);
+    if (lblk < 0) return;
+    const long long pair0 = lblk * ppb;
+    const int npairs = (int)min((long long)ppb, total_pairs - pair0);
+
+    fill_level_table(s_tab, lt, dshapes, L);
+    copy_in(s_loc, loc + pair0 * LP * 2, npairs * LP * 2);
+    copy_in(s_attn, attn + pair0 * LP, npairs * LP);
+    __syncthreads();
+
+    const int pl = threadIdx.x / DV;
+    const int dv = threadIdx.x - pl * DV;
+    if (pl >= npairs) return;
+
+    const long long pair = pair0 + pl;  // (b*Lq + q)*M + m
+    const int m = (int)(pair % M);
+    const int b = (int)((pair / M) / Lq);
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;                                // < 2^24
+    const unsigned lane_base = (unsigned)((((long long)b * S * M + m) * D + dv * 4) * 4);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, value_bytes, 0x00020000);
+    const float2 *sl = reinterpret_cast<const float2 *>(s_loc + (size_t)pl * LP * 2);
+    const float *sa = s_attn + (size_t)pl * LP;
+
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+        const int H = s_tab[l], W = s_tab[TF_MSDA_MAX_LEVELS + l];
+        const unsigned lvl_base = lane_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + l] * rowbytes;
+        const float Wf = (float)W, Hf = (float)H;
+        u32x4_t v[PT][4];
+        float w[PT][4];
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const float2 xy = sl[l * PT + p];
+            const float a = sa[l * PT + p];
+            const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);   // cuh:227-228, single rounding
+            const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
+            const bool in = (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);  // cuh:229
+            const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+            const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+            const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+            const int x0 = (int)xf, y0 = (int)yf;
+            const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
+            const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
+            const int r0 = y0 * W + x0;        // may be "negative": only used when the tap is valid
+            const int r1 = r0 + W;
+            const unsigned o1 = (ky0 && kx0) ? lvl_base + (unsigned)r0 * rowbytes : kOobOffset;
+            const unsigned o2 = (ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobOffset;
+            const unsigned o3 = (ky1 && kx0) ? lvl_base + (unsigned)r1 * rowbytes : kOobOffset;
+            const unsigned o4 = (ky1 && kx1) ? lvl_base + (unsigned)(r1 + 1) * rowbytes : kOobOffset;
+            v[p][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1, 0, 0);
+            v[p][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o2, 0, 0);
+            v[p][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o3, 0, 0);
+            v[p][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o4, 0, 0);
+            w[p][0] = gy * gx * a;
+            w[p][1] = gy * fx * a;
+            w[p][2] = fy * gx * a;
+            w[p][3] = fy * fx * a;
+        }
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                acc += __builtin_bit_cast(f32x4_t, v[p][t]) * w[p][t];
+        }
+    }
+    *reinterpret_cast<f32x4_t *>(out + pair * D + dv * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward (grad_value via atomics, grad_loc / grad_attn via wave reduction), fused
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC, bool POW2>
@@ -234,7 +348,9 @@ msda_bwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
     T *s_gloc = s_attn + (size_t)ppb * LP;
     T *s_gattn = s_gloc + (size_t)ppb * LP * 2;
 
-    const long long pair0 = (long long)blockIdx.x * ppb;
+    const long long lblk = logical_block((total_pairs + ppb - 1) / ppb);
+    if (lblk < 0) return;
+    const long long pair0 = lblk * ppb;
     const int npairs = (int)min((long long)ppb, total_pairs - pair0);
 
     fill_level_table(s_tab, lt, dshapes, L);
@@ -327,6 +443,13 @@ msda_bwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+template <typename... Args>
+hipError_t launch(const void *fn, unsigned grid, size_t lds, hipStream_t stream, Args... args)
+{
+    void *argv[] = {(void *)&args...};
+    return hipLaunchKernel(fn, dim3(grid), dim3(kThreads), argv, lds, stream);
+}
+
 int record_hip(hipError_t e)
 {
     if (e != hipSuccess) {
@@ -374,13 +497,27 @@ int make_plan(int N, int M, int D, int L, int Lq, int P, int lds_elems_per_sampl
     pl->ppb = (int)ppb;
     pl->lds = (size_t)kLevelTableBytes + (size_t)(ppb * bytes_per_pair);
     const long long total_pairs = (long long)N * Lq * M;
-    const long long grid = (total_pairs + ppb - 1) / ppb;
+    long long grid = (total_pairs + ppb - 1) / ppb;
+    grid = (grid + kXcds - 1) / kXcds * kXcds;  // see logical_block()
     if (grid > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
     pl->grid = (unsigned)grid;
     return TF_MSDA_OK;
 }
 
 bool is_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// fp32 fast path eligibility: everything addressable with 32-bit byte offsets / 24-bit multiplies.
+bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, int D, int L)
+{
+    const long long bytes = (long long)N * S * M * D * 4;
+    if (bytes >= (long long)kOobOffset) return false;
+    if ((long long)M * D * 4 >= (1 << 24)) return false;
+    if (S >= (1 << 24)) return false;   // also bounds every level's H*W (and start) below 2^24
+    if (host_shapes)
+        for (int l = 0; l < L; ++l)
+            if ((long long)lt.H[l] * lt.W[l] >= (1 << 24)) return false;
+    return true;
+}
 
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shapes_dev,
@@ -404,34 +541,25 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
     if (rc != TF_MSDA_OK) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     const long long total_pairs = (long long)N * Lq * M;
-    if (pl.vec == 4) {
-        hipLaunchKernelGGL((msda_fwd_rowgather<T, 4>), dim3(pl.grid), dim3(kThreads), pl.lds,
-                           stream, value, loc, attn, out, lt, shapes_dev, S, M, D, L, Lq, P,
-                           total_pairs, pl.ppb, pl.DV);
-    } else {
-        hipLaunchKernelGGL((msda_fwd_rowgather<T, 1>), dim3(pl.grid), dim3(kThreads), pl.lds,
-                           stream, value, loc, attn, out, lt, shapes_dev, S, M, D, L, Lq, P,
-                           total_pairs, pl.ppb, pl.DV);
+    hipError_t e;
+    if constexpr (sizeof(T) == 4) {
+        if (pl.vec == 4 && (P == 1 || P == 2 || P == 4 || P == 8) &&
+            buf_path_ok(lt, shapes_host != nullptr, N, S, M, D, L)) {
+            const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
+            const void *fn = P == 1   ? (const void *)&msda_fwd_f32_buf<1>
+                             : P == 2 ? (const void *)&msda_fwd_f32_buf<2>
+                             : P == 4 ? (const void *)&msda_fwd_f32_buf<4>
+                                      : (const void *)&msda_fwd_f32_buf<8>;
+            e = launch(fn, pl.grid, pl.lds, stream, value, vbytes, loc, attn, out, lt, shapes_dev,
+                       S, M, D, L, Lq, total_pairs, pl.ppb, pl.DV);
+            return record_hip(e);
+        }
     }
-    return record_hip(hipGetLastError());
-}
-
-template <typename T, int VEC>
-void launch_bwd(const Plan &pl, hipStream_t stream, const T *value, const T *loc, const T *attn,
-                const T *grad_out, T *grad_value, T *grad_loc, T *grad_attn, const LevelTable &lt,
-                const int64_t *shapes_dev, int S, int M, int D, int L, int Lq, int P,
-                long long total_pairs)
-{
-    const bool pow2 = (pl.DV & (pl.DV - 1)) == 0 && pl.DV <= 64;
-    if (pow2) {
-        hipLaunchKernelGGL((msda_bwd_rowgather<T, VEC, true>), dim3(pl.grid), dim3(kThreads),
-                           pl.lds, stream, value, loc, attn, grad_out, grad_value, grad_loc,
-                           grad_attn, lt, shapes_dev, S, M, D, L, Lq, P, total_pairs, pl.ppb, pl.DV);
-    } else {
-        hipLaunchKernelGGL((msda_bwd_rowgather<T, VEC, false>), dim3(pl.grid), dim3(kThreads),
-                           pl.lds, stream, value, loc, attn, grad_out, grad_value, grad_loc,
-                           grad_attn, lt, shapes_dev, S, M, D, L, Lq, P, total_pairs, pl.ppb, pl.DV);
-    }
+    const void *fn = pl.vec == 4 ? (const void *)&msda_fwd_rowgather<T, 4>
+                                 : (const void *)&msda_fwd_rowgather<T, 1>;
+    e = launch(fn, pl.grid, pl.lds, stream, value, loc, attn, out, lt, shapes_dev, S, M, D, L, Lq,
+               P, total_pairs, pl.ppb, pl.DV);
+    return record_hip(e);
 }
 
 template <typename T>
@@ -459,13 +587,18 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
     rc = record_hip(hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream));
     if (rc != TF_MSDA_OK) return rc;
     const long long total_pairs = (long long)N * Lq * M;
+    const bool pow2 = (pl.DV & (pl.DV - 1)) == 0 && pl.DV <= 64;
+    const void *fn;
     if (pl.vec == 4)
-        launch_bwd<T, 4>(pl, stream, value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, lt,
-                         shapes_dev, S, M, D, L, Lq, P, total_pairs);
+        fn = pow2 ? (const void *)&msda_bwd_rowgather<T, 4, true>
+                  : (const void *)&msda_bwd_rowgather<T, 4, false>;
     else
-        launch_bwd<T, 1>(pl, stream, value, loc, attn, grad_out, grad_value, grad_loc, grad_attn, lt,
-                         shapes_dev, S, M, D, L, Lq, P, total_pairs);
-    return record_hip(hipGetLastError());
+        fn = pow2 ? (const void *)&msda_bwd_rowgather<T, 1, true>
+                  : (const void *)&msda_bwd_rowgather<T, 1, false>;
+    const hipError_t e = launch(fn, pl.grid, pl.lds, stream, value, loc, attn, grad_out, grad_value,
+                                grad_loc, grad_attn, lt, shapes_dev, S, M, D, L, Lq, P, total_pairs,
+                                pl.ppb, pl.DV);
+    return record_hip(e);
 }
 
 }  // namespace
