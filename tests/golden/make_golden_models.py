@@ -1,0 +1,95 @@
+#!/usr/bin/env python
+"""Generate model- and tracker-level golden fixtures from the REFERENCE's own classes on CPU.
+
+    python tests/golden/make_golden_models.py      (build container only: needs /root/reference)
+
+For each case of tests/util_models.MODEL_CASES the reference `build_model` (models/__init__.py:16)
+is seeded (torch.manual_seed(42)), its weights perturbed by tests/util_weights.perturb_state_dict and
+the model run in tracking mode on seeded inputs with MSDeformAttn routed to the reference's pure-PyTorch
+path (oracle/reference_models.py).  Stored: logits, boxes, embeddings, a weight checksum -- not the
+weights (they are regenerated from the seeds, both here and on the GPU box).
+The tracker fixture runs the reference Tracker (models/tracker.py) for 6 synthetic frames and stores
+the per-frame track ids, boxes and scores.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from oracle import reference_models  # noqa: E402
+from tests import util_models as um  # noqa: E402
+from trackformer_amd import config  # noqa: E402
+
+
+def checksum(model):
+    return float(sum(float(v.double().abs().sum()) for v in model.state_dict().values()))
+
+
+def main():
+    ref = reference_models.load()
+    torch.set_num_threads(4)
+    for case in um.MODEL_CASES:
+        model, post, args = um.build(case, ref.models.build_model, config.make_args)
+        if hasattr(model, "tracking"):
+            model.tracking()
+        else:
+            model.eval()
+        img, prev, target = um.model_inputs(case, args.hidden_dim)
+        with torch.no_grad():
+            prev_features = None
+            if args.multi_frame_attention:
+                _, _, prev_features, _, _ = model(prev, None, None)
+            if case == "cfg1_plain_detr":
+                out, _, feats, memory, hs = model(img, target)
+            else:
+                out, _, feats, memory, hs = model(img, target, prev_features)
+            res = post['bbox'](out, torch.tensor([[480, 640]]))[0]
+        fix = dict(pred_logits=out['pred_logits'].numpy(), pred_boxes=out['pred_boxes'].numpy(),
+                   hs_embed=out['hs_embed'].numpy(), aux_boxes=np.stack(
+                       [a['pred_boxes'].numpy() for a in out['aux_outputs']]),
+                   scores=res['scores'].numpy(), labels=res['labels'].numpy(),
+                   boxes=res['boxes'].numpy(), weight_checksum=np.float64(checksum(model)),
+                   feat_last=feats[-1].tensors.numpy())
+        path = os.path.join(HERE, "model_%s.npz" % case)
+        np.savez_compressed(path, **fix)
+        print("%-28s logits%s boxes%s  -> %s (%d KB)" % (case, fix['pred_logits'].shape,
+              fix['pred_boxes'].shape, os.path.basename(path), os.path.getsize(path) // 1024))
+
+    # tracker sequence
+    model, post, args = um.build("cfg2_deformable_tracking", ref.models.build_model,
+                                 config.make_args)
+    model.tracking()
+    for reid in (False, True):
+        tracker = ref.tracker.Tracker(model, post, config.tracker_cfg(reid=reid), False)
+        tracker.reset()
+        per_frame = []
+        with torch.no_grad():
+            for blob in um.tracker_sequence():
+                tracker.step(blob)
+                per_frame.append((sorted(t.id for t in tracker.tracks),
+                                  sorted(t.id for t in tracker.inactive_tracks)))
+        results = tracker.get_results()
+        rows = []
+        for tid in sorted(results):
+            for f in sorted(results[tid]):
+                r = results[tid][f]
+                rows.append([tid, f, *r['bbox'].tolist(), float(r['score']), r['obj_ind']])
+        rows = np.array(rows, dtype=np.float64)
+        active = np.array([len(a) for a, _ in per_frame])
+        path = os.path.join(HERE, "tracker_cfg2_%s.npz" % ("reid" if reid else "default"))
+        np.savez_compressed(path, rows=rows, active_per_frame=active,
+                            inactive_per_frame=np.array([len(i) for _, i in per_frame]),
+                            num_tracks=np.int64(tracker.track_num),
+                            num_reids=np.int64(tracker.num_reids))
+        print("tracker reid=%s: %d track ids, active per frame %s, inactive %s, reids %d -> %s" % (
+            reid, tracker.track_num, active.tolist(), [len(i) for _, i in per_frame],
+            tracker.num_reids, os.path.basename(path)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+"""CPU (-m "not gpu"): host-side model + tracker logic against the reference goldens.
+
+The nn.Module graph, track-query handling, post-processing and the Tracker run on CPU with the C
+oracle standing in for the HIP operator (monkeypatched here, in the test only -- the product code has
+no CPU operator).  Goldens: tests/golden/model_*.npz, tracker_*.npz produced from the reference's own
+classes by tests/golden/make_golden_models.py.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import msda_oracle
+from tests import util_models as um
+from trackformer_amd import config, factory, msda
+from trackformer_amd.tracker import Tracker
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture()
+def oracle_op(monkeypatch):
+    monkeypatch.setattr(msda, "MSDeformAttnFunction", msda_oracle.make_torch_function())
+
+
+def _checksum(model):
+    return float(sum(float(v.double().abs().sum()) for v in model.state_dict().values()))
+
+
+def run_case(case, device="cpu"):
+    model, post, args = um.build(case, factory.build_model, config.make_args, device=device)
+    model.to(device)
+    if hasattr(model, "tracking"):
+        model.tracking()
+    else:
+        model.eval()
+    img, prev, target = um.model_inputs(case, args.hidden_dim)
+    img, prev, target = img.to(device), prev.to(device), um.to_device(target, device)
+    with torch.no_grad():
+        prev_features = None
+        if args.multi_frame_attention:
+            _, _, prev_features, _, _ = model(prev, None, None)
+        out, _, feats, memory, hs = model(img, target, prev_features)
+        res = post['bbox'](out, torch.tensor([[480, 640]], device=device))[0]
+    return model, out, res, feats
+
+
+def compare_to_golden(case, model, out, res, feats, box_tol, logit_tol):
+    z = np.load(os.path.join(GOLDEN, "model_%s.npz" % case))
+    assert abs(_checksum(model) - float(z["weight_checksum"])) < 1e-6 * float(z["weight_checksum"])
+    np.testing.assert_allclose(out['pred_boxes'].cpu().numpy(), z['pred_boxes'], atol=box_tol)
+    np.testing.assert_allclose(out['pred_logits'].cpu().numpy(), z['pred_logits'], atol=logit_tol)
+    np.testing.assert_allclose(out['hs_embed'].cpu().numpy(), z['hs_embed'], atol=logit_tol * 5)
+    aux = np.stack([a['pred_boxes'].cpu().numpy() for a in out['aux_outputs']])
+    np.testing.assert_allclose(aux, z['aux_boxes'], atol=box_tol)
+    np.testing.assert_array_equal(res['labels'].cpu().numpy(), z['labels'])
+    np.testing.assert_allclose(res['boxes'].cpu().numpy(), z['boxes'], atol=box_tol * 640)
+    f = feats[-1].tensors.cpu().numpy()
+    np.testing.assert_allclose(f, z['feat_last'], atol=1e-3 * max(1.0, np.abs(z['feat_last']).max()))
+
+
+@pytest.mark.parametrize("case", list(um.MODEL_CASES))
+def test_model_forward_matches_reference(case, oracle_op):
+    model, out, res, feats = run_case(case)
+    compare_to_golden(case, model, out, res, feats, box_tol=2e-5, logit_tol=1e-4)
+
+
+def run_tracker(reid, device="cpu"):
+    model, post, args = um.build("cfg2_deformable_tracking", factory.build_model,
+                                 config.make_args, device=device)
+    model.to(device)
+    model.tracking()
+    tracker = Tracker(model, post, config.tracker_cfg(reid=reid), False)
+    tracker.reset()
+    active, inactive = [], []
+    with torch.no_grad():
+        for blob in um.tracker_sequence():
+            tracker.step(blob)
+            active.append(len(tracker.tracks))
+            inactive.append(len(tracker.inactive_tracks))
+    rows = []
+    results = tracker.get_results()
+    for tid in sorted(results):
+        for f in sorted(results[tid]):
+            r = results[tid][f]
+            assert r['bbox'].shape == (4,) and r['bbox'].dtype == np.float32
+            assert isinstance(r['obj_ind'], int)
+            rows.append([tid, f, *r['bbox'].tolist(), float(r['score']), r['obj_ind']])
+    return tracker, np.array(rows, dtype=np.float64), active, inactive
+
+
+def compare_tracker_to_golden(reid, tracker, rows, active, inactive, box_tol_px):
+    z = np.load(os.path.join(GOLDEN, "tracker_cfg2_%s.npz" % ("reid" if reid else "default")))
+    # track-id assignment: bit-exact (ids, frames they are alive in, source object query)
+    assert int(z["num_tracks"]) == tracker.track_num
+    assert int(z["num_reids"]) == tracker.num_reids
+    assert z["active_per_frame"].tolist() == active
+    assert z["inactive_per_frame"].tolist() == inactive
+    assert rows.shape == z["rows"].shape
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
+    np.testing.assert_allclose(rows[:, 2:6], z["rows"][:, 2:6], atol=box_tol_px)
+    np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
+
+
+@pytest.mark.parametrize("reid", [False, True], ids=["default", "reid"])
+def test_tracker_sequence_matches_reference(reid, oracle_op):
+    tracker, rows, active, inactive = run_tracker(reid)
+    compare_tracker_to_golden(reid, tracker, rows, active, inactive, box_tol_px=0.05)
+
+
+def test_state_dict_layout_of_cfg2_model():
+    model, _, _ = factory.build_model(config.make_args('deformable', 'tracking', 'mot17',
+                                                       device='cpu'))
+    keys = list(model.state_dict().keys())
+    assert len(keys) == 597
+    for k in ("transformer.level_embed", "transformer.reference_points.weight",
+              "transformer.encoder.layers.0.self_attn.sampling_offsets.weight",
+              "transformer.decoder.layers.5.cross_attn.output_proj.bias",
+              "transformer.decoder.layers.0.self_attn.in_proj_weight",
+              "class_embed.5.bias", "bbox_embed.0.layers.2.weight", "query_embed.weight",
+              "input_proj.3.0.weight", "input_proj.0.1.bias", "backbone.0.body.conv1.weight",
+              "backbone.0.body.layer4.2.bn3.running_var",
+              "backbone.0.body.layer2.0.downsample.0.weight"):
+        assert k in keys, k
+    assert model.state_dict()["query_embed.weight"].shape == (300, 512)
+    assert model.num_queries == 300 and model.overflow_boxes and model.hidden_dim == 256
+    assert sum(p.numel() for p in model.parameters()) == 40740178
+
+
+def test_product_model_refuses_cpu_operator():
+    # without the test-only monkeypatch the model must fail loudly on CPU: no silent fallback
+    model, _, _ = factory.build_model(config.make_args('deformable', 'tracking', 'mot17',
+                                                       device='cpu'))
+    model.tracking()
+    with torch.no_grad(), pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        model(torch.zeros(1, 3, 64, 64), None, None)

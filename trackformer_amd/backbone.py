@@ -1,0 +1,291 @@
+"""ResNet backbone with frozen batch-norm, multi-level outputs and per-level position encodings.
+
+Covers models/backbone.py of the reference (FrozenBatchNorm2d :19-55, BackboneBase :58-88,
+Backbone :91-104, Joiner :107-122, build_backbone :125-134) plus the torchvision pieces it pulls in
+(torchvision.models.resnet50/101 "v1.5" and IntermediateLayerGetter), which are restated here from
+the published architecture because torchvision is not part of this build.  Module / parameter /
+buffer names are identical to torchvision's, so reference checkpoints (`backbone.0.body.layerX...`)
+load with strict=True.
+
+MI355X notes: in inference (eval mode, grad disabled) every conv + FrozenBN pair runs as ONE conv with
+the BN scale folded into the weights and the shift as its bias (the fold is cached and refreshed when
+the parameters change), ReLU is applied in place, and activations stay in channels_last so MIOpen
+picks NHWC kernels; that removes ~100 elementwise passes over the feature maps per frame.
+"""
+from collections import OrderedDict
+from typing import Dict, List
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .nested import NestedTensor, all_valid_mask, is_all_valid
+from .position_encoding import build_position_encoding
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """BatchNorm2d with fixed statistics and affine parameters, stored as buffers
+    (y = x * w * rsqrt(var + 1e-5) + (b - mean * w * rsqrt(var + 1e-5)), backbone.py:45-55)."""
+
+    def __init__(self, n):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
+                              unexpected_keys, error_msgs):
+        state_dict.pop(prefix + 'num_batches_tracked', None)  # plain BatchNorm checkpoints carry it
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
+                                      unexpected_keys, error_msgs)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + 1e-5).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+    def forward(self, x):
+        scale, shift = self.scale_shift()
+        return x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)
+
+
+class _FoldCache:
+    """conv weight with the following FrozenBN folded in; refreshed when any source tensor changes."""
+
+    def __init__(self):
+        self.key = None
+        self.weight = None
+        self.bias = None
+
+    def get(self, conv: nn.Conv2d, bn: FrozenBatchNorm2d):
+        srcs = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t.data_ptr(), t._version, t.device, t.dtype) for t in srcs)
+        if key != self.key:
+            with torch.no_grad():
+                scale, shift = bn.scale_shift()
+                w = conv.weight * scale.reshape(-1, 1, 1, 1)
+                self.weight = w.contiguous(memory_format=torch.channels_last)
+                self.bias = shift.contiguous()
+            self.key = key
+        return self.weight, self.bias
+
+
+def _inference_mode(module: nn.Module) -> bool:
+    return (not module.training) and (not torch.is_grad_enabled())
+
+
+def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, fold: bool):
+    if fold and isinstance(bn, FrozenBatchNorm2d):
+        w, b = cache.get(conv, bn)
+        x = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return F.relu_(x) if relu else x
+    x = bn(conv(x))
+    return F.relu(x) if relu else x
+
+
+class Bottleneck(nn.Module):
+    """ResNet v1.5 bottleneck: 1x1 reduce, 3x3 (carries the stride), 1x1 expand (x4), identity/projection."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None, dilation=1,
+                 norm_layer=FrozenBatchNorm2d):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = norm_layer(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=dilation,
+                               dilation=dilation, bias=False)
+        self.bn2 = norm_layer(planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, kernel_size=1, bias=False)
+        self.bn3 = norm_layer(planes * self.expansion)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+        self._folds = [_FoldCache() for _ in range(4)]
+
+    def forward(self, x):
+        fold = _inference_mode(self)
+        out = _conv_bn(x, self.conv1, self.bn1, self._folds[0], True, fold)
+        out = _conv_bn(out, self.conv2, self.bn2, self._folds[1], True, fold)
+        out = _conv_bn(out, self.conv3, self.bn3, self._folds[2], False, fold)
+        if self.downsample is not None:
+            x = _conv_bn(x, self.downsample[0], self.downsample[1], self._folds[3], False, fold)
+        if fold:
+            return F.relu_(out.add_(x))
+        return F.relu(out + x)
+
+
+class ResNet(nn.Module):
+    """torchvision-compatible ResNet trunk (conv1, bn1, relu, maxpool, layer1..4, avgpool, fc)."""
+
+    def __init__(self, layers, num_classes=1000, replace_stride_with_dilation=None,
+                 norm_layer=FrozenBatchNorm2d):
+        super().__init__()
+        if replace_stride_with_dilation is None:
+            replace_stride_with_dilation = [False, False, False]
+        if len(replace_stride_with_dilation) != 3:
+            raise ValueError("replace_stride_with_dilation should be None or a 3-element tuple")
+        self._norm_layer = norm_layer
+        self.inplanes = 64
+        self.dilation = 1
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = norm_layer(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], 2, replace_stride_with_dilation[0])
+        self.layer3 = self._make_layer(256, layers[2], 2, replace_stride_with_dilation[1])
+        self.layer4 = self._make_layer(512, layers[3], 2, replace_stride_with_dilation[2])
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(512 * Bottleneck.expansion, num_classes)
+        self._stem_fold = _FoldCache()
+        for m in self.modules():  # torchvision's default initialisation
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride=1, dilate=False):
+        norm_layer = self._norm_layer
+        previous_dilation = self.dilation
+        if dilate:
+            self.dilation *= stride
+            stride = 1
+        downsample = None
+        if stride != 1 or self.inplanes != planes * Bottleneck.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * Bottleneck.expansion, kernel_size=1, stride=stride,
+                          bias=False),
+                norm_layer(planes * Bottleneck.expansion))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample, previous_dilation, norm_layer)]
+        self.inplanes = planes * Bottleneck.expansion
+        for _ in range(1, blocks):
+            layers.append(Bottleneck(self.inplanes, planes, dilation=self.dilation,
+                                     norm_layer=norm_layer))
+        return nn.Sequential(*layers)
+
+    def stem(self, x):
+        x = _conv_bn(x, self.conv1, self.bn1, self._stem_fold, True, _inference_mode(self))
+        return self.maxpool(x)
+
+    def forward(self, x):
+        x = self.stem(x)
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+_RESNET_DEPTHS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3]}
+
+
+def resnet(name: str, replace_stride_with_dilation=None, norm_layer=FrozenBatchNorm2d) -> ResNet:
+    if name not in _RESNET_DEPTHS:
+        raise ValueError("unsupported backbone %r (have %s)" % (name, sorted(_RESNET_DEPTHS)))
+    return ResNet(_RESNET_DEPTHS[name], replace_stride_with_dilation=replace_stride_with_dilation,
+                  norm_layer=norm_layer)
+
+
+class IntermediateLayerGetter(nn.ModuleDict):
+    """Runs a model's children in order and returns the outputs of the named ones (torchvision's
+    models._utils.IntermediateLayerGetter): children after the last requested layer are dropped, so
+    `avgpool`/`fc` do not appear in the state dict."""
+
+    def __init__(self, model: nn.Module, return_layers: Dict[str, str]):
+        if not set(return_layers).issubset(name for name, _ in model.named_children()):
+            raise ValueError("return_layers are not present in model")
+        remaining = dict(return_layers)
+        kept = OrderedDict()
+        for name, module in model.named_children():
+            kept[name] = module
+            remaining.pop(name, None)
+            if not remaining:
+                break
+        super().__init__(kept)
+        self.return_layers = dict(return_layers)
+        self._fold = _FoldCache()
+
+    def forward(self, x):
+        out = OrderedDict()
+        fold = _inference_mode(self)
+        fused_stem = fold and all(k in self for k in ("conv1", "bn1", "relu"))
+        for name, module in self.items():
+            if fused_stem and name in ("bn1", "relu"):
+                continue
+            if fused_stem and name == "conv1":
+                x = _conv_bn(x, self["conv1"], self["bn1"], self._fold, True, True)
+            else:
+                x = module(x)
+            if name in self.return_layers:
+                out[self.return_layers[name]] = x
+        return out
+
+
+class BackboneBase(nn.Module):
+    def __init__(self, backbone: nn.Module, train_backbone: bool, return_interm_layers: bool):
+        super().__init__()
+        for name, parameter in backbone.named_parameters():
+            if not train_backbone or not any(k in name for k in ("layer2", "layer3", "layer4")):
+                parameter.requires_grad_(False)
+        if return_interm_layers:
+            return_layers = {"layer1": "0", "layer2": "1", "layer3": "2", "layer4": "3"}
+            self.strides = [4, 8, 16, 32]
+            self.num_channels = [256, 512, 1024, 2048]
+        else:
+            return_layers = {"layer4": "0"}
+            self.strides = [32]
+            self.num_channels = [2048]
+        self.body = IntermediateLayerGetter(backbone, return_layers=return_layers)
+
+    def forward(self, tensor_list: NestedTensor):
+        x = tensor_list.tensors
+        if _inference_mode(self) and x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
+        xs = self.body(x)
+        m = tensor_list.mask
+        assert m is not None
+        out: Dict[str, NestedTensor] = {}
+        for name, feat in xs.items():
+            if is_all_valid(m):  # nearest-downsampling an all-False mask: nothing to compute
+                mask = all_valid_mask((m.shape[0],) + tuple(feat.shape[-2:]), feat.device)
+            else:
+                mask = F.interpolate(m[None].float(), size=feat.shape[-2:]).to(torch.bool)[0]
+            out[name] = NestedTensor(feat, mask)
+        return out
+
+
+class Backbone(BackboneBase):
+    """ResNet backbone with frozen BatchNorm.  No pretrained download is attempted (there is no
+    network; the reference's `pretrained=is_main_process()` fetch, backbone.py:100, is out of scope):
+    weights come from a checkpoint or stay at their seeded initialisation."""
+
+    def __init__(self, name: str, train_backbone: bool, return_interm_layers: bool, dilation: bool):
+        backbone = resnet(name, replace_stride_with_dilation=[False, False, dilation],
+                          norm_layer=FrozenBatchNorm2d)
+        super().__init__(backbone, train_backbone, return_interm_layers)
+        if dilation:
+            self.strides[-1] = self.strides[-1] // 2
+
+
+class Joiner(nn.Sequential):
+    """[backbone, position_embedding] -> (list of NestedTensor features, list of position encodings)."""
+
+    def __init__(self, backbone, position_embedding):
+        super().__init__(backbone, position_embedding)
+        self.strides = backbone.strides
+        self.num_channels = backbone.num_channels
+
+    def forward(self, tensor_list: NestedTensor):
+        xs = self[0](tensor_list)
+        out: List[NestedTensor] = []
+        pos = []
+        for x in xs.values():
+            out.append(x)
+            pos.append(self[1](x).to(x.tensors.dtype))
+        return out, pos
+
+
+def build_backbone(args):
+    position_embedding = build_position_encoding(args)
+    train_backbone = args.lr_backbone > 0
+    return_interm_layers = args.masks or (args.num_feature_levels > 1)
+    backbone = Backbone(args.backbone, train_backbone, return_interm_layers, args.dilation)
+    return Joiner(backbone, position_embedding)

@@ -1,0 +1,191 @@
+"""Set-prediction loss of DETR / TrackFormer (training only; BASELINE cfg 3).
+
+Same surface as the reference's SetCriterion (models/detr.py:139-443) and its helper losses
+(util/misc.py:448-463 accuracy, :522-571 dice / sigmoid focal loss).
+"""
+import copy
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from . import box_ops
+from .nested import nested_tensor_from_tensor_list
+
+
+def _world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+@torch.no_grad()
+def accuracy(output, target, topk=(1,)):
+    """precision@k in percent."""
+    if target.numel() == 0:
+        return [torch.zeros([], device=output.device)]
+    pred = output.topk(max(topk), 1, True, True)[1].t()
+    correct = pred.eq(target.view(1, -1).expand_as(pred))
+    return [correct[:k].reshape(-1).float().sum(0) * (100.0 / target.size(0)) for k in topk]
+
+
+def dice_loss(inputs, targets, num_boxes):
+    inputs = inputs.sigmoid().flatten(1)
+    numerator = 2 * (inputs * targets).sum(1)
+    denominator = inputs.sum(-1) + targets.sum(-1)
+    return (1 - (numerator + 1) / (denominator + 1)).sum() / num_boxes
+
+
+def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: float = 2,
+                       query_mask=None, reduction=True):
+    prob = inputs.sigmoid()
+    ce_loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = prob * targets + (1 - prob) * (1 - targets)
+    loss = ce_loss * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    if not reduction:
+        return loss
+    if query_mask is not None:
+        loss = torch.stack([l[m].mean(0) for l, m in zip(loss, query_mask)])
+        return loss.sum() / num_boxes
+    return loss.mean(1).sum() / num_boxes
+
+
+class SetCriterion(nn.Module):
+    """1) Hungarian assignment of predictions to targets, 2) class / box (/ mask) losses on the pairs,
+    repeated for every auxiliary decoder output."""
+
+    def __init__(self, num_classes, matcher, weight_dict, eos_coef, losses, focal_loss,
+                 focal_alpha, focal_gamma, tracking, track_query_false_positive_eos_weight):
+        super().__init__()
+        self.num_classes = num_classes
+        self.matcher = matcher
+        self.weight_dict = weight_dict
+        self.eos_coef = eos_coef
+        self.losses = losses
+        empty_weight = torch.ones(self.num_classes + 1)
+        empty_weight[-1] = self.eos_coef
+        self.register_buffer('empty_weight', empty_weight)
+        self.focal_loss = focal_loss
+        self.focal_alpha = focal_alpha
+        self.focal_gamma = focal_gamma
+        self.tracking = tracking
+        self.track_query_false_positive_eos_weight = track_query_false_positive_eos_weight
+
+    # ------------------------------------------------------------------ helpers
+    def _get_src_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(src, i) for i, (src, _) in enumerate(indices)])
+        return batch_idx, torch.cat([src for (src, _) in indices])
+
+    def _get_tgt_permutation_idx(self, indices):
+        batch_idx = torch.cat([torch.full_like(tgt, i) for i, (_, tgt) in enumerate(indices)])
+        return batch_idx, torch.cat([tgt for (_, tgt) in indices])
+
+    def _target_classes(self, src_logits, targets, indices):
+        idx = self._get_src_permutation_idx(indices)
+        matched = torch.cat([t["labels"][J] for t, (_, J) in zip(targets, indices)])
+        classes = torch.full(src_logits.shape[:2], self.num_classes, dtype=torch.int64,
+                             device=src_logits.device)
+        classes[idx] = matched
+        return idx, matched, classes
+
+    # ------------------------------------------------------------------ losses
+    def loss_labels(self, outputs, targets, indices, _, log=True):
+        src_logits = outputs['pred_logits']
+        idx, matched, target_classes = self._target_classes(src_logits, targets, indices)
+        loss_ce = F.cross_entropy(src_logits.transpose(1, 2), target_classes,
+                                  weight=self.empty_weight, reduction='none')
+        if self.tracking and self.track_query_false_positive_eos_weight:
+            for i, target in enumerate(targets):
+                if 'track_query_boxes' in target:
+                    fp = target['track_queries_fal_pos_mask']
+                    loss_ce[i, fp] *= 1 / self.eos_coef       # undo the no-object down-weighting
+                    target_classes = target_classes.clone()
+                    target_classes[i, fp] = 0                  # ... also in the normaliser
+        losses = {'loss_ce': loss_ce.sum() / self.empty_weight[target_classes].sum()}
+        if log:
+            losses['class_error'] = 100 - accuracy(src_logits[idx], matched)[0]
+        return losses
+
+    def loss_labels_focal(self, outputs, targets, indices, num_boxes, log=True):
+        src_logits = outputs['pred_logits']
+        idx, matched, target_classes = self._target_classes(src_logits, targets, indices)
+        onehot = torch.zeros(src_logits.shape[0], src_logits.shape[1], src_logits.shape[2] + 1,
+                             dtype=src_logits.dtype, device=src_logits.device)
+        onehot.scatter_(2, target_classes.unsqueeze(-1), 1)
+        loss_ce = sigmoid_focal_loss(src_logits, onehot[:, :, :-1], num_boxes,
+                                     alpha=self.focal_alpha, gamma=self.focal_gamma)
+        losses = {'loss_ce': loss_ce * src_logits.shape[1]}
+        if log:
+            losses['class_error'] = 100 - accuracy(src_logits[idx], matched)[0]
+        return losses
+
+    @torch.no_grad()
+    def loss_cardinality(self, outputs, targets, indices, num_boxes):
+        pred_logits = outputs['pred_logits']
+        tgt_lengths = torch.as_tensor([len(v["labels"]) for v in targets],
+                                      device=pred_logits.device)
+        card_pred = (pred_logits.argmax(-1) != pred_logits.shape[-1] - 1).sum(1)
+        return {'cardinality_error': F.l1_loss(card_pred.float(), tgt_lengths.float())}
+
+    def loss_boxes(self, outputs, targets, indices, num_boxes):
+        idx = self._get_src_permutation_idx(indices)
+        src_boxes = outputs['pred_boxes'][idx]
+        target_boxes = torch.cat([t['boxes'][i] for t, (_, i) in zip(targets, indices)], dim=0)
+        loss_bbox = F.l1_loss(src_boxes, target_boxes, reduction='none')
+        loss_giou = 1 - torch.diag(box_ops.generalized_box_iou(
+            box_ops.box_cxcywh_to_xyxy(src_boxes), box_ops.box_cxcywh_to_xyxy(target_boxes)))
+        return {'loss_bbox': loss_bbox.sum() / num_boxes, 'loss_giou': loss_giou.sum() / num_boxes}
+
+    def loss_masks(self, outputs, targets, indices, num_boxes):
+        src_idx = self._get_src_permutation_idx(indices)
+        tgt_idx = self._get_tgt_permutation_idx(indices)
+        src_masks = outputs["pred_masks"]
+        target_masks, _ = nested_tensor_from_tensor_list([t["masks"] for t in targets]).decompose()
+        target_masks = target_masks.to(src_masks)
+        src_masks = F.interpolate(src_masks[src_idx][:, None], size=target_masks.shape[-2:],
+                                  mode="bilinear", align_corners=False)[:, 0].flatten(1)
+        target_masks = target_masks[tgt_idx].flatten(1)
+        return {"loss_mask": sigmoid_focal_loss(src_masks, target_masks, num_boxes),
+                "loss_dice": dice_loss(src_masks, target_masks, num_boxes)}
+
+    def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
+        loss_map = {'labels': self.loss_labels_focal if self.focal_loss else self.loss_labels,
+                    'cardinality': self.loss_cardinality, 'boxes': self.loss_boxes,
+                    'masks': self.loss_masks}
+        assert loss in loss_map, f'do you really want to compute {loss} loss?'
+        return loss_map[loss](outputs, targets, indices, num_boxes, **kwargs)
+
+    def _extra_losses(self, outputs, targets, num_boxes, suffix):
+        indices = self.matcher(outputs, targets)
+        out = {}
+        for loss in self.losses:
+            if loss == 'masks':  # too costly on intermediate outputs
+                continue
+            kwargs = {'log': False} if loss == 'labels' else {}
+            l_dict = self.get_loss(loss, outputs, targets, indices, num_boxes, **kwargs)
+            out.update({k + suffix: v for k, v in l_dict.items()})
+        return out
+
+    def forward(self, outputs, targets):
+        outputs_without_aux = {k: v for k, v in outputs.items() if k != 'aux_outputs'}
+        indices = self.matcher(outputs_without_aux, targets)
+
+        # number of target boxes averaged over all ranks (the one scalar all-reduce of the loss)
+        num_boxes = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float,
+                                    device=next(iter(outputs.values())).device)
+        if _world_size() > 1:
+            dist.all_reduce(num_boxes)
+        num_boxes = torch.clamp(num_boxes / _world_size(), min=1).item()
+
+        losses = {}
+        for loss in self.losses:
+            losses.update(self.get_loss(loss, outputs, targets, indices, num_boxes))
+        for i, aux_outputs in enumerate(outputs.get('aux_outputs', [])):
+            losses.update(self._extra_losses(aux_outputs, targets, num_boxes, f'_{i}'))
+        if 'enc_outputs' in outputs:
+            bin_targets = copy.deepcopy(targets)
+            for bt in bin_targets:
+                bt['labels'] = torch.zeros_like(bt['labels'])
+            losses.update(self._extra_losses(outputs['enc_outputs'], bin_targets, num_boxes, '_enc'))
+        return losses

@@ -1,0 +1,187 @@
+"""Deformable DETR detector (multi-level, optional multi-frame attention) and its post-processing.
+
+Same surface as the reference's models/deformable_detr.py: DeformableDETR (:29-283) -- constructor
+arguments, attributes, state_dict layout (`input_proj.L.{0,1}`, `class_embed.N`, `bbox_embed.N.layers.K`,
+`query_embed`, `transformer...`), forward(samples, targets, prev_features) ->
+(out, targets, features_all, memory, hs) -- and DeformablePostProcess (:286-334).
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import box_ops
+from .detr import DETR, PostProcess
+from .nested import (NestedTensor, all_valid_mask, inverse_sigmoid, is_all_valid,
+                     nested_tensor_from_tensor_list)
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+class DeformableDETR(DETR):
+    def __init__(self, backbone, transformer, num_classes, num_queries, num_feature_levels,
+                 aux_loss=True, with_box_refine=False, two_stage=False, overflow_boxes=False,
+                 multi_frame_attention=False, multi_frame_encoding=False,
+                 merge_frame_features=False):
+        super().__init__(backbone, transformer, num_classes, num_queries, aux_loss)
+        self.merge_frame_features = merge_frame_features
+        self.multi_frame_attention = multi_frame_attention
+        self.multi_frame_encoding = multi_frame_encoding
+        self.overflow_boxes = overflow_boxes
+        self.num_feature_levels = num_feature_levels
+        if not two_stage:
+            self.query_embed = nn.Embedding(num_queries, self.hidden_dim * 2)  # (query_pos | tgt)
+
+        def proj(in_ch, **conv_kw):
+            return nn.Sequential(nn.Conv2d(in_ch, self.hidden_dim, **conv_kw),
+                                 nn.GroupNorm(32, self.hidden_dim))
+
+        num_channels = backbone.num_channels[-3:]
+        if num_feature_levels > 1:
+            num_backbone_outs = len(backbone.strides) - 1  # layer2..layer4
+            projs = [proj(num_channels[i], kernel_size=1) for i in range(num_backbone_outs)]
+            in_ch = num_channels[num_backbone_outs - 1]
+            for _ in range(num_feature_levels - num_backbone_outs):  # extra stride-2 levels
+                projs.append(proj(in_ch, kernel_size=3, stride=2, padding=1))
+                in_ch = self.hidden_dim
+            self.input_proj = nn.ModuleList(projs)
+        else:
+            self.input_proj = nn.ModuleList([proj(num_channels[0], kernel_size=1)])
+        self.with_box_refine = with_box_refine
+        self.two_stage = two_stage
+
+        prior_prob = 0.01
+        self.class_embed.bias.data.fill_(-math.log((1 - prior_prob) / prior_prob))
+        nn.init.constant_(self.bbox_embed.layers[-1].weight.data, 0)
+        nn.init.constant_(self.bbox_embed.layers[-1].bias.data, 0)
+        for p in self.input_proj:
+            nn.init.xavier_uniform_(p[0].weight, gain=1)
+            nn.init.constant_(p[0].bias, 0)
+
+        # one head per decoder layer (+1 for the two-stage proposal head)
+        num_pred = transformer.decoder.num_layers + (1 if two_stage else 0)
+        if with_box_refine:
+            self.class_embed = _get_clones(self.class_embed, num_pred)
+            self.bbox_embed = _get_clones(self.bbox_embed, num_pred)
+            nn.init.constant_(self.bbox_embed[0].layers[-1].bias.data[2:], -2.0)
+            self.transformer.decoder.bbox_embed = self.bbox_embed  # iterative refinement
+        else:
+            nn.init.constant_(self.bbox_embed.layers[-1].bias.data[2:], -2.0)
+            self.class_embed = nn.ModuleList([self.class_embed for _ in range(num_pred)])
+            self.bbox_embed = nn.ModuleList([self.bbox_embed for _ in range(num_pred)])
+            self.transformer.decoder.bbox_embed = None
+        if two_stage:
+            self.transformer.decoder.class_embed = self.class_embed
+            for box_embed in self.bbox_embed:
+                nn.init.constant_(box_embed.layers[-1].bias.data[2:], 0.0)
+
+        if self.merge_frame_features:
+            merge = nn.Conv2d(self.hidden_dim * 2, self.hidden_dim, kernel_size=1)
+            self.merge_features = _get_clones(merge, num_feature_levels)
+
+    # ------------------------------------------------------------------------------------------
+    def _project(self, level, x, prev_x=None):
+        y = self.input_proj[level](x)
+        if self.merge_frame_features:
+            y = self.merge_features[level](torch.cat([y, self.input_proj[level](prev_x)], dim=1))
+        return y
+
+    def forward(self, samples: NestedTensor, targets: list = None, prev_features=None):
+        """samples: NestedTensor / list of images / [B,3,H,W] tensor.  targets (tracking): list of
+        dicts with `track_query_hs_embeds` [T,C] and `track_query_boxes` [T,4].  prev_features: the
+        `features_all` returned for the previous frame (multi-frame attention).
+
+        Returns (out, targets, features_all, memory, hs) as deformable_detr.py:275; `out` holds
+        pred_logits [B,Q,C], pred_boxes [B,Q,4] (cxcywh, [0,1]), hs_embed [B,Q,hidden], aux_outputs."""
+        if not isinstance(samples, NestedTensor):
+            samples = nested_tensor_from_tensor_list(samples)
+        features_all, pos = self.backbone(samples)
+        features = features_all[-3:]
+        prev_features = features if prev_features is None else prev_features[-3:]
+
+        frames = [prev_features, features] if self.multi_frame_attention else [features]
+        src_list, mask_list, pos_list = [], [], []
+        for frame, frame_feat in enumerate(frames):
+            per_frame_pos = self.multi_frame_attention and self.multi_frame_encoding
+            pos_list.extend([p[:, frame] for p in pos[-3:]] if per_frame_pos else pos[-3:])
+            for lvl, feat in enumerate(frame_feat):
+                src, mask = feat.decompose()
+                assert mask is not None
+                prev_src = prev_features[lvl].tensors if self.merge_frame_features else None
+                src_list.append(self._project(lvl, src, prev_src))
+                mask_list.append(mask)
+
+            for lvl in range(len(frame_feat), self.num_feature_levels):  # extra coarse levels
+                if lvl == len(frame_feat):
+                    src = self._project(lvl, frame_feat[-1].tensors,
+                                        prev_features[-1].tensors if self.merge_frame_features
+                                        else None)
+                else:
+                    src = self.input_proj[lvl](src_list[-1])
+                m = frame_feat[0].mask
+                if is_all_valid(m):
+                    mask = all_valid_mask((m.shape[0],) + tuple(src.shape[-2:]), src.device)
+                else:
+                    mask = F.interpolate(m[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
+                pos_l = self.backbone[1](NestedTensor(src, mask)).to(src.dtype)
+                src_list.append(src)
+                mask_list.append(mask)
+                pos_list.append(pos_l[:, frame] if per_frame_pos else pos_l)
+
+        query_embeds = None if self.two_stage else self.query_embed.weight
+        hs, memory, init_reference, inter_references, enc_outputs_class, enc_outputs_coord_unact = \
+            self.transformer(src_list, mask_list, pos_list, query_embeds, targets)
+
+        outputs_classes, outputs_coords = [], []
+        for lvl in range(hs.shape[0]):
+            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
+            outputs_classes.append(self.class_embed[lvl](hs[lvl]))
+            tmp = self.bbox_embed[lvl](hs[lvl])
+            if reference.shape[-1] == 4:
+                tmp += reference
+            else:
+                assert reference.shape[-1] == 2
+                tmp[..., :2] += reference
+            outputs_coords.append(tmp.sigmoid())
+        outputs_class = torch.stack(outputs_classes)
+        outputs_coord = torch.stack(outputs_coords)
+
+        out = {'pred_logits': outputs_class[-1], 'pred_boxes': outputs_coord[-1],
+               'hs_embed': hs[-1]}
+        if self.aux_loss:
+            out['aux_outputs'] = self._set_aux_loss(outputs_class, outputs_coord)
+        if self.two_stage:
+            out['enc_outputs'] = {'pred_logits': enc_outputs_class,
+                                  'pred_boxes': enc_outputs_coord_unact.sigmoid()}
+
+        # encoder memory re-sliced into per-level [B, C, H, W] views
+        batch_size, _, channels = memory.shape
+        memory_slices, offset = [], 0
+        for src in src_list:
+            h, w = src.shape[-2:]
+            memory_slices.append(memory[:, offset:offset + h * w].permute(0, 2, 1).view(
+                batch_size, channels, h, w))
+            offset += h * w
+        return out, targets, features_all, memory_slices, hs
+
+
+class DeformablePostProcess(PostProcess):
+    """Sigmoid scores: per query the best class and its score; boxes scaled to the image size."""
+
+    @torch.no_grad()
+    def forward(self, outputs, target_sizes, results_mask=None):
+        out_logits, out_bbox = outputs['pred_logits'], outputs['pred_boxes']
+        assert len(out_logits) == len(target_sizes)
+        assert target_sizes.shape[1] == 2
+        scores, labels = out_logits.sigmoid().max(-1)
+        boxes = self.process_boxes(out_bbox, target_sizes)
+        results = [{'scores': s, 'scores_no_object': 1 - s, 'labels': l, 'boxes': b}
+                   for s, l, b in zip(scores, labels, boxes)]
+        if results_mask is not None:
+            for i, mask in enumerate(results_mask):
+                results[i] = {k: v[mask] for k, v in results[i].items()}
+        return results

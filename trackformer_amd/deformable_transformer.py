@@ -1,0 +1,431 @@
+"""Deformable-DETR encoder/decoder with TrackFormer's track-query prepending.
+
+Same classes, constructor arguments, parameter names and forward contracts as the reference's
+models/deformable_transformer.py (DeformableTransformer :21-255, EncoderLayer :258-297,
+Encoder :300-327, DecoderLayer :330-383, Decoder :386-431, build_deforamble_transformer :434-454).
+
+What is different is host-side only: per-frame constants that depend just on the pyramid geometry
+(the `spatial_shapes` device tensor, valid ratios of an unpadded batch, encoder reference points)
+are cached instead of being rebuilt with dozens of tiny kernels every frame, and the host copy of
+the level shapes travels with the `spatial_shapes` tensor so the MSDeformAttn operator never has to
+read it back from the device.
+"""
+import copy
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.nn.init import constant_, normal_, xavier_uniform_
+
+from .msda import MSDeformAttn, attach_host_shapes
+from .nested import inverse_sigmoid, is_all_valid
+
+
+def _get_clones(module, N):
+    return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
+
+
+def _get_activation_fn(activation):
+    """String -> activation function (models/transformer.py:300-308)."""
+    if activation == "relu":
+        return F.relu
+    if activation == "gelu":
+        return F.gelu
+    if activation == "glu":
+        return F.glu
+    raise RuntimeError(F"activation should be relu/gelu, not {activation}.")
+
+
+class _GeometryCache:
+    """Device constants keyed by (level shapes, batch, device): spatial_shapes tensor, all-ones valid
+    ratios and the encoder's reference points for an unpadded batch."""
+
+    def __init__(self):
+        self._shapes = {}
+        self._ones = {}
+        self._enc_ref = {}
+
+    def spatial_shapes(self, shapes, device):
+        key = (tuple(shapes), device)
+        t = self._shapes.get(key)
+        if t is None:
+            t = torch.as_tensor(list(shapes), dtype=torch.long, device=device)
+            self._shapes[key] = attach_host_shapes(t, shapes)
+        return t
+
+    def unit_valid_ratios(self, bs, n_levels, device):
+        key = (bs, n_levels, device)
+        t = self._ones.get(key)
+        if t is None:
+            t = self._ones[key] = torch.ones(bs, n_levels, 2, dtype=torch.float32, device=device)
+        return t
+
+    def encoder_reference_points(self, shapes, valid_ratios, unit_ratios):
+        if not unit_ratios or torch.is_grad_enabled():
+            return DeformableTransformerEncoder.get_reference_points(shapes, valid_ratios,
+                                                                    valid_ratios.device)
+        key = (tuple(shapes), valid_ratios.shape[0], valid_ratios.device)
+        t = self._enc_ref.get(key)
+        if t is None:
+            t = self._enc_ref[key] = DeformableTransformerEncoder.get_reference_points(
+                shapes, valid_ratios, valid_ratios.device)
+        return t
+
+
+_GEOMETRY = _GeometryCache()
+
+
+def _host_shapes(spatial_shapes):
+    """(H, W) python ints of a spatial_shapes tensor (attached by DeformableTransformer.forward;
+    falls back to one device read for foreign callers)."""
+    hs = getattr(spatial_shapes, "_tf_msda_host_shapes", None)
+    if hs is None:
+        hs = tuple((int(h), int(w)) for h, w in spatial_shapes.tolist())
+        attach_host_shapes(spatial_shapes, hs)
+    return hs
+
+
+class DeformableTransformer(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, num_decoder_layers=6,
+                 dim_feedforward=1024, dropout=0.1, activation="relu",
+                 return_intermediate_dec=False, num_feature_levels=4, dec_n_points=4,
+                 enc_n_points=4, two_stage=False, two_stage_num_proposals=300,
+                 multi_frame_attention_separate_encoder=False):
+        super().__init__()
+        self.d_model = d_model
+        self.nhead = nhead
+        self.two_stage = two_stage
+        self.two_stage_num_proposals = two_stage_num_proposals
+        self.num_feature_levels = num_feature_levels
+        self.multi_frame_attention_separate_encoder = multi_frame_attention_separate_encoder
+
+        enc_levels = num_feature_levels // 2 if multi_frame_attention_separate_encoder \
+            else num_feature_levels
+        encoder_layer = DeformableTransformerEncoderLayer(
+            d_model, dim_feedforward, dropout, activation, enc_levels, nhead, enc_n_points)
+        self.encoder = DeformableTransformerEncoder(encoder_layer, num_encoder_layers)
+        decoder_layer = DeformableTransformerDecoderLayer(
+            d_model, dim_feedforward, dropout, activation, num_feature_levels, nhead, dec_n_points)
+        self.decoder = DeformableTransformerDecoder(decoder_layer, num_decoder_layers,
+                                                    return_intermediate_dec)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        if two_stage:
+            self.enc_output = nn.Linear(d_model, d_model)
+            self.enc_output_norm = nn.LayerNorm(d_model)
+            self.pos_trans = nn.Linear(d_model * 2, d_model * 2)
+            self.pos_trans_norm = nn.LayerNorm(d_model * 2)
+        else:
+            self.reference_points = nn.Linear(d_model, 2)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        if not self.two_stage:
+            xavier_uniform_(self.reference_points.weight.data, gain=1.0)
+            constant_(self.reference_points.bias.data, 0.)
+        normal_(self.level_embed)
+
+    # ------------------------------------------------------------------ two-stage helpers
+    def get_proposal_pos_embed(self, proposals):
+        """sine embedding of (logit) proposal boxes: [N, K, 4] -> [N, K, 512]."""
+        num_pos_feats, temperature, scale = 128, 10000, 2 * math.pi
+        i = torch.arange(num_pos_feats, dtype=torch.float32, device=proposals.device)
+        dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / num_pos_feats)
+        pos = (proposals.sigmoid() * scale)[:, :, :, None] / dim_t
+        return torch.stack((pos[..., 0::2].sin(), pos[..., 1::2].cos()), dim=4).flatten(2)
+
+    def gen_encoder_output_proposals(self, memory, memory_padding_mask, spatial_shapes):
+        """Per-token box proposals (logit space) + gated/normalised memory for the two-stage variant."""
+        n = memory.shape[0]
+        proposals = []
+        cur = 0
+        for lvl, (h, w) in enumerate(_host_shapes(spatial_shapes)):
+            m = memory_padding_mask[:, cur:cur + h * w].view(n, h, w, 1)
+            valid_h = torch.sum(~m[:, :, 0, 0], 1)
+            valid_w = torch.sum(~m[:, 0, :, 0], 1)
+            gy, gx = torch.meshgrid(
+                torch.linspace(0, h - 1, h, dtype=torch.float32, device=memory.device),
+                torch.linspace(0, w - 1, w, dtype=torch.float32, device=memory.device),
+                indexing="ij")
+            grid = torch.stack([gx, gy], -1)
+            scale = torch.stack([valid_w, valid_h], 1).view(n, 1, 1, 2)
+            grid = (grid[None].expand(n, -1, -1, -1) + 0.5) / scale
+            wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+            proposals.append(torch.cat((grid, wh), -1).view(n, -1, 4))
+            cur += h * w
+        out_prop = torch.cat(proposals, 1)
+        valid = ((out_prop > 0.01) & (out_prop < 0.99)).all(-1, keepdim=True)
+        out_prop = torch.log(out_prop / (1 - out_prop))
+        out_prop = out_prop.masked_fill(memory_padding_mask.unsqueeze(-1), float('inf'))
+        out_prop = out_prop.masked_fill(~valid, float('inf'))
+        out_mem = memory.masked_fill(memory_padding_mask.unsqueeze(-1), float(0))
+        out_mem = out_mem.masked_fill(~valid, float(0))
+        return self.enc_output_norm(self.enc_output(out_mem)), out_prop
+
+    def get_valid_ratio(self, mask):
+        """fraction of un-padded (width, height) per sample: [N, 2]."""
+        _, H, W = mask.shape
+        valid_h = torch.sum(~mask[:, :, 0], 1)
+        valid_w = torch.sum(~mask[:, 0, :], 1)
+        return torch.stack([valid_w.float() / W, valid_h.float() / H], -1)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, srcs, masks, pos_embeds, query_embed=None, targets=None):
+        assert self.two_stage or query_embed is not None
+
+        shapes = tuple((int(s.shape[2]), int(s.shape[3])) for s in srcs)
+        device = srcs[0].device
+        src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        lvl_pos_embed_flatten = torch.cat(
+            [p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
+             for lvl, p in enumerate(pos_embeds)], 1)
+        unpadded = all(is_all_valid(m) for m in masks)
+        if unpadded:
+            # nothing is padded: the flattened mask is all False -> skip it entirely (masked_fill with
+            # an all-False mask is the identity) and the valid ratios are exactly 1
+            mask_flatten = None
+            valid_ratios = _GEOMETRY.unit_valid_ratios(src_flatten.shape[0], len(shapes), device)
+        else:
+            mask_flatten = torch.cat([m.flatten(1) for m in masks], 1)
+            valid_ratios = torch.stack([self.get_valid_ratio(m) for m in masks], 1)
+        spatial_shapes = _GEOMETRY.spatial_shapes(shapes, device)
+
+        # encoder
+        if self.multi_frame_attention_separate_encoder:
+            half_t = src_flatten.shape[1] // 2
+            half_l = self.num_feature_levels // 2
+
+            def run(sl_t, sl_l):
+                return self.encoder(
+                    src_flatten[:, sl_t], _GEOMETRY.spatial_shapes(shapes[sl_l], device),
+                    valid_ratios[:, sl_l], lvl_pos_embed_flatten[:, sl_t],
+                    None if mask_flatten is None else mask_flatten[:, sl_t], unit_ratios=unpadded)
+            prev_memory = run(slice(0, half_t), slice(0, half_l))
+            memory = run(slice(half_t, None), slice(half_l, None))
+            memory = torch.cat([memory, prev_memory], 1)
+        else:
+            memory = self.encoder(src_flatten, spatial_shapes, valid_ratios, lvl_pos_embed_flatten,
+                                  mask_flatten, unit_ratios=unpadded)
+
+        # decoder inputs
+        bs, _, c = memory.shape
+        query_attn_mask = None
+        enc_outputs_class = enc_outputs_coord_unact = None
+        if self.two_stage:
+            pad = mask_flatten if mask_flatten is not None else \
+                torch.zeros(memory.shape[:2], dtype=torch.bool, device=device)
+            output_memory, output_proposals = self.gen_encoder_output_proposals(
+                memory, pad, spatial_shapes)
+            enc_outputs_class = self.decoder.class_embed[self.decoder.num_layers](output_memory)
+            enc_outputs_coord_unact = \
+                self.decoder.bbox_embed[self.decoder.num_layers](output_memory) + output_proposals
+            topk = self.two_stage_num_proposals
+            topk_proposals = torch.topk(enc_outputs_class[..., 0], topk, dim=1)[1]
+            topk_coords_unact = torch.gather(
+                enc_outputs_coord_unact, 1, topk_proposals.unsqueeze(-1).repeat(1, 1, 4)).detach()
+            reference_points = topk_coords_unact.sigmoid()
+            init_reference_out = reference_points
+            pos_trans_out = self.pos_trans_norm(
+                self.pos_trans(self.get_proposal_pos_embed(topk_coords_unact)))
+            query_embed, tgt = torch.split(pos_trans_out, c, dim=2)
+        else:
+            query_embed, tgt = torch.split(query_embed, c, dim=1)
+            query_embed = query_embed.unsqueeze(0).expand(bs, -1, -1)
+            tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
+            reference_points = self.reference_points(query_embed).sigmoid()
+
+            if targets is not None and 'track_query_hs_embeds' in targets[0]:
+                # TrackFormer: track queries go FIRST; their content is the previous frame's output
+                # embedding, their positional query is zero and their reference point is the centre
+                # of the previous box (deformable_transformer.py:202-225).
+                prev_hs_embed = torch.stack([t['track_query_hs_embeds'] for t in targets])
+                prev_boxes = torch.stack([t['track_query_boxes'] for t in targets])
+                query_embed = torch.cat([torch.zeros_like(prev_hs_embed), query_embed], dim=1)
+                tgt = torch.cat([prev_hs_embed, tgt], dim=1)
+                reference_points = torch.cat([prev_boxes[..., :2], reference_points], dim=1)
+            init_reference_out = reference_points
+
+        hs, inter_references = self.decoder(tgt, reference_points, memory, spatial_shapes,
+                                            valid_ratios, query_embed, mask_flatten,
+                                            query_attn_mask)
+        if self.two_stage:
+            return (hs, memory, init_reference_out, inter_references, enc_outputs_class,
+                    enc_outputs_coord_unact)
+        return hs, memory, init_reference_out, inter_references, None, None
+
+
+class DeformableTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4,
+                 n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, src):
+        src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
+        return self.norm2(src + self.dropout3(src2))
+
+    def forward(self, src, pos, reference_points, spatial_shapes, padding_mask=None):
+        src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
+                              padding_mask)
+        src = self.norm1(src + self.dropout1(src2))
+        return self.forward_ffn(src)
+
+
+class DeformableTransformerEncoder(nn.Module):
+    def __init__(self, encoder_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(encoder_layer, num_layers)
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        """Pixel centres of every level in normalised valid-image coordinates, broadcast over the
+        levels they will be sampled in: [N, S, L, 2] (deformable_transformer.py:307-319)."""
+        if torch.is_tensor(spatial_shapes):
+            spatial_shapes = _host_shapes(spatial_shapes)
+        per_level = []
+        for lvl, (h, w) in enumerate(spatial_shapes):
+            ys = torch.linspace(0.5, h - 0.5, h, dtype=torch.float32, device=device)
+            xs = torch.linspace(0.5, w - 0.5, w, dtype=torch.float32, device=device)
+            ref_y, ref_x = torch.meshgrid(ys, xs, indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * h)
+            ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * w)
+            per_level.append(torch.stack((ref_x, ref_y), -1))
+        reference_points = torch.cat(per_level, 1)
+        return reference_points[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, spatial_shapes, valid_ratios, pos=None, padding_mask=None,
+                unit_ratios=False):
+        reference_points = _GEOMETRY.encoder_reference_points(
+            _host_shapes(spatial_shapes), valid_ratios, unit_ratios)
+        output = src
+        for layer in self.layers:
+            output = layer(output, pos, reference_points, spatial_shapes, padding_mask)
+        return output
+
+
+class DeformableTransformerDecoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, activation="relu", n_levels=4,
+                 n_heads=8, n_points=4):
+        super().__init__()
+        self.cross_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.self_attn = nn.MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout2 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.activation = _get_activation_fn(activation)
+        self.dropout3 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout4 = nn.Dropout(dropout)
+        self.norm3 = nn.LayerNorm(d_model)
+
+    @staticmethod
+    def with_pos_embed(tensor, pos):
+        return tensor if pos is None else tensor + pos
+
+    def forward_ffn(self, tgt):
+        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
+        return self.norm3(tgt + self.dropout4(tgt2))
+
+    def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes,
+                src_padding_mask=None, query_attn_mask=None):
+        # self attention among the (track + object) queries
+        q = k = self.with_pos_embed(tgt, query_pos)
+        tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
+                              key_padding_mask=query_attn_mask)[0].transpose(0, 1)
+        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        # deformable cross attention into the encoder memory
+        tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src,
+                               src_spatial_shapes, src_padding_mask, query_attn_mask)
+        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        return self.forward_ffn(tgt)
+
+
+class DeformableTransformerDecoder(nn.Module):
+    def __init__(self, decoder_layer, num_layers, return_intermediate=False):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.return_intermediate = return_intermediate
+        # set by DeformableDETR for iterative box refinement / two-stage
+        self.bbox_embed = None
+        self.class_embed = None
+
+    def forward(self, tgt, reference_points, src, src_spatial_shapes, src_valid_ratios,
+                query_pos=None, src_padding_mask=None, query_attn_mask=None):
+        output = tgt
+        intermediate = []
+        intermediate_reference_points = []
+        for lid, layer in enumerate(self.layers):
+            if reference_points.shape[-1] == 4:
+                reference_points_input = reference_points[:, :, None] \
+                    * torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]
+            else:
+                assert reference_points.shape[-1] == 2
+                reference_points_input = reference_points[:, :, None] * src_valid_ratios[:, None]
+            output = layer(output, query_pos, reference_points_input, src, src_spatial_shapes,
+                           src_padding_mask, query_attn_mask)
+
+            if self.bbox_embed is not None:  # iterative bounding box refinement
+                tmp = self.bbox_embed[lid](output)
+                if reference_points.shape[-1] == 4:
+                    new_reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid()
+                else:
+                    assert reference_points.shape[-1] == 2
+                    new_reference_points = tmp
+                    new_reference_points[..., :2] = tmp[..., :2] + inverse_sigmoid(reference_points)
+                    new_reference_points = new_reference_points.sigmoid()
+                reference_points = new_reference_points.detach()
+
+            if self.return_intermediate:
+                intermediate.append(output)
+                intermediate_reference_points.append(reference_points)
+
+        if self.return_intermediate:
+            return torch.stack(intermediate), torch.stack(intermediate_reference_points)
+        return output, reference_points
+
+
+def build_deforamble_transformer(args):  # [sic] -- the reference's spelling, kept for drop-in use
+    num_feature_levels = args.num_feature_levels
+    if args.multi_frame_attention:
+        num_feature_levels *= 2
+    return DeformableTransformer(
+        d_model=args.hidden_dim,
+        nhead=args.nheads,
+        num_encoder_layers=args.enc_layers,
+        num_decoder_layers=args.dec_layers,
+        dim_feedforward=args.dim_feedforward,
+        dropout=args.dropout,
+        activation="relu",
+        return_intermediate_dec=True,
+        num_feature_levels=num_feature_levels,
+        dec_n_points=args.dec_n_points,
+        enc_n_points=args.enc_n_points,
+        two_stage=args.two_stage,
+        two_stage_num_proposals=args.num_queries,
+        multi_frame_attention_separate_encoder=(args.multi_frame_attention
+                                                and args.multi_frame_attention_separate_encoder))
+
+
+build_deformable_transformer = build_deforamble_transformer

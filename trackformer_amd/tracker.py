@@ -1,0 +1,437 @@
+"""Online multi-object tracker driving the detector frame by frame.
+
+Same API and decision logic as the reference's models/tracker.py -- Tracker(obj_detector,
+obj_detector_post, tracker_cfg, generate_attention_maps, logger, verbose), .reset(hard), .step(blob),
+.get_results(), and the Track state object (:557-583) -- so src/track.py can use it unchanged.
+
+What changed is WHERE the association logic runs.  The reference interleaves GPU tensors with Python
+control flow and pays one device->host sync per track and per decision (tracker.py:290, :346, :367,
+:400-402, :496, :530-541).  Here each frame does exactly ONE device->host copy (boxes, scores and
+labels of all queries packed into a [Lq, 6] tensor); every threshold, NMS, public-detection and
+bookkeeping decision is then taken on that host copy in the reference's order, and track positions /
+scores are kept as CPU tensors.  Only the per-query output embeddings stay on the GPU (they are fed
+back as track queries and never inspected on the host, except by the optional embedding re-ID).
+"""
+from collections import deque
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy.optimize import linear_sum_assignment
+
+from .box_ops import box_iou, box_xyxy_to_cxcywh, clip_boxes_to_image, nms
+
+
+class Tracker:
+    """Tracks objects through a sequence by re-feeding their output embeddings as track queries."""
+
+    def __init__(self, obj_detector, obj_detector_post, tracker_cfg, generate_attention_maps,
+                 logger=None, verbose=False):
+        self.obj_detector = obj_detector
+        self.obj_detector_post = obj_detector_post
+        self.detection_obj_score_thresh = tracker_cfg['detection_obj_score_thresh']
+        self.track_obj_score_thresh = tracker_cfg['track_obj_score_thresh']
+        self.detection_nms_thresh = tracker_cfg['detection_nms_thresh']
+        self.track_nms_thresh = tracker_cfg['track_nms_thresh']
+        self.public_detections = tracker_cfg['public_detections']
+        self.inactive_patience = float(tracker_cfg['inactive_patience'])
+        self.reid_sim_threshold = tracker_cfg['reid_sim_threshold']
+        self.reid_sim_only = tracker_cfg['reid_sim_only']
+        self.generate_attention_maps = generate_attention_maps
+        self.reid_score_thresh = tracker_cfg['reid_score_thresh']
+        self.reid_greedy_matching = tracker_cfg['reid_greedy_matching']
+        self.prev_frame_dist = tracker_cfg['prev_frame_dist']
+        self.steps_termination = tracker_cfg['steps_termination']
+
+        if self.generate_attention_maps:
+            last = self.obj_detector.transformer.decoder.layers[-1]
+            assert hasattr(last, 'multihead_attn'), \
+                'Generation of attention maps not possible for deformable DETR.'
+            attention_data = {'maps': None, 'conv_features': {}, 'hooks': []}
+
+            def keep_conv_features(module, inputs, output):
+                attention_data['conv_features'] = output
+
+            def keep_attention_map(module, inputs, output):
+                h, w = attention_data['conv_features']['3'].tensors.shape[-2:]
+                attention_data['maps'] = output[1].view(-1, h, w)
+
+            attention_data['hooks'].append(
+                self.obj_detector.backbone[-2].register_forward_hook(keep_conv_features))
+            attention_data['hooks'].append(
+                last.multihead_attn.register_forward_hook(keep_attention_map))
+            self.attention_data = attention_data
+
+        self._logger = logger if logger is not None else (lambda *log_strs: None)
+        self._verbose = verbose
+
+    # ------------------------------------------------------------------ state
+    @property
+    def num_object_queries(self):
+        return self.obj_detector.num_queries
+
+    @property
+    def device(self):
+        return next(self.obj_detector.parameters()).device
+
+    def reset(self, hard=True):
+        self.tracks = []
+        self.inactive_tracks = []
+        self._prev_features = deque([None], maxlen=self.prev_frame_dist)
+        if hard:
+            self.track_num = 0
+            self.results = {}
+            self.frame_index = 0
+            self.num_reids = 0
+
+    def tracks_to_inactive(self, tracks):
+        self.tracks = [t for t in self.tracks if t not in tracks]
+        for track in tracks:
+            track.pos = track.last_pos[-1]
+        self.inactive_tracks += tracks
+
+    def add_tracks(self, pos, scores, hs_embeds, indices, masks=None, attention_maps=None,
+                   aux_results=None):
+        """Creates Track objects with consecutive ids track_num, track_num+1, ... (tracker.py:93-122)."""
+        new_track_ids = []
+        for i in range(len(pos)):
+            self.tracks.append(Track(
+                pos[i], scores[i], self.track_num + i, hs_embeds[i], indices[i],
+                None if masks is None else masks[i],
+                None if attention_maps is None else attention_maps[i]))
+            new_track_ids.append(self.track_num + i)
+        self.track_num += len(new_track_ids)
+
+        if new_track_ids:
+            self._logger(
+                f'INIT TRACK IDS (detection_obj_score_thresh={self.detection_obj_score_thresh}): '
+                f'{new_track_ids}')
+            if aux_results is not None:
+                idx = torch.as_tensor(indices).reshape(-1).to(aux_results[0]['scores'].device)
+                aux_scores = torch.cat(
+                    [a['scores'][-self.num_object_queries:][idx][:, None] for a in aux_results]
+                    + [torch.as_tensor(scores).reshape(-1, 1).to(idx.device)], dim=-1)
+                for new_track_id, aux_score in zip(new_track_ids, aux_scores):
+                    self._logger(
+                        f"AUX SCORES ID {new_track_id}: {[f'{s:.2f}' for s in aux_score]}")
+        return new_track_ids
+
+    def public_detections_mask(self, new_det_boxes, public_det_boxes):
+        """Mask over the new detections that are backed by a provided public detection."""
+        n = new_det_boxes.size(0)
+        if not self.public_detections:
+            return torch.ones(n, dtype=torch.bool)
+        if not len(public_det_boxes) or not n:
+            return torch.zeros(n, dtype=torch.bool)
+        mask = torch.zeros(n, dtype=torch.bool)
+        public_det_boxes = public_det_boxes.detach().cpu().float()
+        if self.public_detections == 'center_distance':
+            item_size = ((new_det_boxes[:, 2] - new_det_boxes[:, 0])
+                         * (new_det_boxes[:, 3] - new_det_boxes[:, 1])).numpy().astype(np.float32)
+            det_c = box_xyxy_to_cxcywh(new_det_boxes).numpy()[:, :2]
+            pub_c = box_xyxy_to_cxcywh(public_det_boxes).numpy()[:, :2]
+            dist = ((det_c.reshape(-1, 1, 2) - pub_c.reshape(1, -1, 2)) ** 2).sum(axis=2)
+            for j in range(len(public_det_boxes)):
+                i = dist[:, j].argmin()
+                if dist[i, j] < item_size[i]:
+                    dist[i, :] = 1e18
+                    mask[i] = True
+        elif self.public_detections == 'min_iou_0_5':
+            iou = box_iou(new_det_boxes, public_det_boxes)
+            for j in range(len(public_det_boxes)):
+                i = iou[:, j].argmax()
+                if iou[i, j] >= 0.5:
+                    iou[i, :] = 0
+                    mask[i] = True
+        else:
+            raise NotImplementedError
+        return mask
+
+    def reid(self, new_det_boxes, new_det_scores, new_det_hs_embeds, new_det_masks=None,
+             new_det_attention_maps=None):
+        """Re-identify inactive tracks among the new detections; returns the mask of detections that
+        remain unassigned (tracker.py:167-264)."""
+        self.inactive_tracks = [
+            t for t in self.inactive_tracks
+            if t.has_positive_area() and t.count_inactive <= self.inactive_patience]
+        n = new_det_boxes.size(0)
+        if not self.inactive_tracks or not n:
+            return torch.ones(n, dtype=torch.bool)
+
+        if self.reid_greedy_matching:
+            det = box_xyxy_to_cxcywh(new_det_boxes).numpy()
+            inact = box_xyxy_to_cxcywh(torch.stack([t.pos for t in self.inactive_tracks])).numpy()
+            dist_mat = ((inact[:, :2].reshape(-1, 1, 2) - det[:, :2].reshape(1, -1, 2)) ** 2
+                        ).sum(axis=2)
+            track_size = inact[:, 2] * inact[:, 3]
+            item_size = det[:, 2] * det[:, 3]
+            invalid = ((dist_mat > track_size.reshape(-1, 1)) + (dist_mat > item_size.reshape(1, -1)))
+            dist_mat = dist_mat + invalid * 1e18
+            matched = []
+            if dist_mat.shape[1]:
+                for i in range(dist_mat.shape[0]):
+                    j = dist_mat[i].argmin()
+                    if dist_mat[i][j] < 1e16:
+                        dist_mat[:, j] = 1e18
+                        dist_mat[i, j] = 0.0
+                        matched.append([i, j])
+            matched = np.array(matched, np.int32).reshape(-1, 2)
+            row_indices, col_indices = matched[:, 0], matched[:, 1]
+        else:
+            track_sims = torch.stack([t.hs_embed[-1] for t in self.inactive_tracks])  # [I, C]
+            # F.pairwise_distance semantics (eps = 1e-6 added to the difference), one D2H for all
+            diff = track_sims[:, None, :] - new_det_hs_embeds[None, :, :] + 1e-6
+            dist_mat = diff.norm(p=2, dim=-1).cpu().numpy()
+            row_indices, col_indices = linear_sum_assignment(dist_mat)
+
+        assigned, revived = [], []
+        for row_ind, col_ind in zip(row_indices, col_indices):
+            if dist_mat[row_ind, col_ind] <= self.reid_sim_threshold:
+                track = self.inactive_tracks[row_ind]
+                self._logger(
+                    f'REID: track.id={track.id} - count_inactive={track.count_inactive} - '
+                    f'to_inactive_frame={self.frame_index - track.count_inactive}')
+                track.count_inactive = 0
+                track.pos = new_det_boxes[col_ind]
+                track.score = new_det_scores[col_ind]
+                track.hs_embed.append(new_det_hs_embeds[col_ind])
+                track.reset_last_pos()
+                if new_det_masks is not None:
+                    track.mask = new_det_masks[col_ind]
+                if new_det_attention_maps is not None:
+                    track.attention_map = new_det_attention_maps[col_ind]
+                assigned.append(col_ind)
+                revived.append(track)
+                self.tracks.append(track)
+                self.num_reids += 1
+        for track in revived:
+            self.inactive_tracks.remove(track)
+        reid_mask = torch.ones(n, dtype=torch.bool)
+        for ind in assigned:
+            reid_mask[ind] = False
+        return reid_mask
+
+    # ------------------------------------------------------------------ one frame
+    def step(self, blob):
+        """Process one frame.  blob: {'img' [1,3,H,W], 'orig_size' [1,2] (h,w), 'size' [1,2],
+        'dets' [1,K,4] xyxy public detections} as produced by the reference's sequence datasets."""
+        self.inactive_tracks = [
+            t for t in self.inactive_tracks
+            if t.has_positive_area() and t.count_inactive <= self.inactive_patience]
+
+        self._logger(f'FRAME: {self.frame_index + 1}')
+        if self.inactive_tracks:
+            self._logger(f'INACTIVE TRACK IDS: {[t.id for t in self.inactive_tracks]}')
+
+        for track in self.tracks:
+            track.last_pos.append(track.pos.clone())
+
+        device = self.device
+        img = blob['img'].to(device, non_blocking=True)
+        orig_size_host = blob['orig_size'].detach().cpu()
+        orig_size = orig_size_host.to(device, non_blocking=True)
+        orig_h, orig_w = int(orig_size_host[0, 0]), int(orig_size_host[0, 1])
+
+        target = None
+        prev_tracks = self.tracks + self.inactive_tracks
+        num_prev_track = len(prev_tracks)
+        if num_prev_track:
+            boxes_xyxy = torch.stack([t.pos for t in prev_tracks], dim=0)           # host
+            track_query_boxes = box_xyxy_to_cxcywh(boxes_xyxy) / torch.tensor(
+                [orig_w, orig_h, orig_w, orig_h], dtype=torch.float32)
+            target = [{
+                'track_query_boxes': track_query_boxes.to(device, non_blocking=True),
+                'image_id': torch.tensor([1], device=device),
+                'track_query_hs_embeds': torch.stack([t.hs_embed[-1] for t in prev_tracks], dim=0),
+            }]
+
+        outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
+        hs_embeds = outputs['hs_embed'][0]
+
+        results = self.obj_detector_post['bbox'](outputs, orig_size)
+        if "segm" in self.obj_detector_post:
+            results = self.obj_detector_post['segm'](
+                results, outputs, orig_size, blob["size"].to(device), return_probs=True)
+        result = results[0]
+        if 'masks' in result:
+            result['masks'] = result['masks'].squeeze(dim=1)
+
+        boxes_dev = result['boxes']
+        if not self.obj_detector.overflow_boxes:
+            boxes_dev = clip_boxes_to_image(boxes_dev, (orig_h, orig_w))
+
+        # the frame's single device -> host transfer
+        packed = torch.cat([boxes_dev, result['scores'][:, None],
+                            result['labels'][:, None].to(boxes_dev.dtype)], dim=1).cpu()
+        boxes = packed[:, :4]
+        scores = packed[:, 4]
+        is_person = packed[:, 5] == 0
+
+        nq = self.num_object_queries
+        # ---------------------------------------------------------------- existing tracks
+        if num_prev_track:
+            track_scores = scores[:-nq]
+            track_boxes = boxes[:-nq]
+            if 'masks' in result:
+                track_masks = result['masks'][:-nq]
+            if self.generate_attention_maps:
+                track_attention_maps = self.attention_data['maps'][:-nq]
+
+            track_keep = (track_scores > self.track_obj_score_thresh) & is_person[:-nq]
+            to_inactive, from_inactive = [], []
+            for i, track in enumerate(self.tracks):
+                if track_keep[i]:
+                    track.score = track_scores[i]
+                    track.hs_embed.append(hs_embeds[i])
+                    track.pos = track_boxes[i]
+                    track.count_termination = 0
+                    if 'masks' in result:
+                        track.mask = track_masks[i]
+                    if self.generate_attention_maps:
+                        track.attention_map = track_attention_maps[i]
+                else:
+                    track.count_termination += 1
+                    if track.count_termination >= self.steps_termination:
+                        to_inactive.append(track)
+
+            reid_keep = (track_scores > self.reid_score_thresh) & is_person[:-nq]
+            for i, track in enumerate(self.inactive_tracks, start=len(self.tracks)):
+                if reid_keep[i]:
+                    track.score = track_scores[i]
+                    track.hs_embed.append(hs_embeds[i])
+                    track.pos = track_boxes[i]
+                    if 'masks' in result:
+                        track.mask = track_masks[i]
+                    if self.generate_attention_maps:
+                        track.attention_map = track_attention_maps[i]
+                    from_inactive.append(track)
+
+            if to_inactive:
+                self._logger(
+                    f'NEW INACTIVE TRACK IDS (track_obj_score_thresh={self.track_obj_score_thresh}): '
+                    f'{[t.id for t in to_inactive]}')
+
+            self.num_reids += len(from_inactive)
+            for track in from_inactive:
+                self.inactive_tracks.remove(track)
+                self.tracks.append(track)
+            self.tracks_to_inactive(to_inactive)
+
+            if self.track_nms_thresh and self.tracks:
+                keep = set(nms(torch.stack([t.pos for t in self.tracks]),
+                               torch.stack([t.score for t in self.tracks]),
+                               self.track_nms_thresh).tolist())
+                remove_tracks = [t for i, t in enumerate(self.tracks) if i not in keep]
+                if remove_tracks:
+                    self._logger(f'REMOVE TRACK IDS (track_nms_thresh={self.track_nms_thresh}): '
+                                 f'{[t.id for t in remove_tracks]}')
+                self.tracks = [t for t in self.tracks if t not in remove_tracks]
+
+        # ---------------------------------------------------------------- new detections
+        new_det_keep = (scores[-nq:] > self.detection_obj_score_thresh) & is_person[-nq:]
+        new_det_indices = new_det_keep.float().nonzero()          # [K, 1] object-query indices
+        sel = new_det_indices[:, 0]
+        new_det_boxes = boxes[-nq:][sel]
+        new_det_scores = scores[-nq:][sel]
+        det_hs, det_masks, det_maps = hs_embeds[-nq:], None, None
+        if 'masks' in result:
+            det_masks = result['masks'][-nq:]
+        if self.generate_attention_maps:
+            det_maps = self.attention_data['maps'][-nq:]
+
+        def narrow(m):
+            return new_det_boxes[m], new_det_scores[m], new_det_indices[m], sel[m]
+
+        # public detections (tracker.py:438-449)
+        new_det_boxes, new_det_scores, new_det_indices, sel = narrow(
+            self.public_detections_mask(new_det_boxes, blob['dets'][0]))
+
+        # re-ID of inactive tracks (tracker.py:451-466)
+        gather = sel.to(device, non_blocking=True)
+        reid_mask = self.reid(new_det_boxes, new_det_scores, det_hs[gather],
+                              None if det_masks is None else det_masks[gather],
+                              None if det_maps is None else det_maps[gather])
+        new_det_boxes, new_det_scores, new_det_indices, sel = narrow(reid_mask)
+
+        gather = sel.to(device, non_blocking=True)
+        aux_results = None
+        if self._verbose:
+            aux_results = [self.obj_detector_post['bbox'](out, orig_size)[0]
+                           for out in outputs['aux_outputs']]
+        new_track_ids = self.add_tracks(
+            new_det_boxes, new_det_scores, det_hs[gather], new_det_indices,
+            None if det_masks is None else det_masks[gather],
+            None if det_maps is None else det_maps[gather], aux_results)
+
+        # ---------------------------------------------------------------- NMS new vs. existing
+        if self.detection_nms_thresh and self.tracks:
+            track_scores = torch.stack([t.score for t in self.tracks]).clone()
+            is_new = torch.tensor([t.id in new_track_ids for t in self.tracks])
+            track_scores[~is_new] = np.inf   # existing tracks always win against new detections
+            keep = set(nms(torch.stack([t.pos for t in self.tracks]), track_scores,
+                           self.detection_nms_thresh).tolist())
+            remove_tracks = [t for i, t in enumerate(self.tracks) if i not in keep]
+            if remove_tracks:
+                self._logger(
+                    f'REMOVE TRACK IDS (detection_nms_thresh={self.detection_nms_thresh}): '
+                    f'{[t.id for t in remove_tracks]}')
+            self.tracks = [t for t in self.tracks if t not in remove_tracks]
+
+        # ---------------------------------------------------------------- results
+        if 'masks' in result and self.tracks:
+            probs = torch.stack([t.mask for t in self.tracks])
+            index_map = torch.arange(probs.size(0), device=probs.device)[:, None, None]
+            track_masks = torch.logical_and(probs > 0.5,
+                                            index_map.expand_as(probs) == probs.argmax(dim=0))
+            for i, track in enumerate(self.tracks):
+                track.mask = track_masks[i]
+
+        for track in self.tracks:
+            entry = self.results.setdefault(track.id, {})[self.frame_index] = {}
+            pos = track.pos
+            if not self.obj_detector.overflow_boxes:
+                pos = clip_boxes_to_image(pos, (orig_h, orig_w))
+            entry['bbox'] = pos.numpy().copy()
+            entry['score'] = track.score.numpy().copy()
+            entry['obj_ind'] = int(track.obj_ind.reshape(-1)[0])
+            if track.mask is not None:
+                entry['mask'] = track.mask.cpu().numpy()
+            if track.attention_map is not None:
+                entry['attention_map'] = track.attention_map.cpu().numpy()
+
+        for t in self.inactive_tracks:
+            t.count_inactive += 1
+        self.frame_index += 1
+        self._prev_features.append(features)
+        if self.reid_sim_only:
+            self.tracks_to_inactive(self.tracks)
+
+    def get_results(self):
+        """{track_id: {frame_idx: {'bbox': xyxy px, 'score', 'obj_ind', ['mask'], ['attention_map']}}}"""
+        return self.results
+
+
+class Track(object):
+    """State of one track: last position / score (host tensors), the history of its output
+    embeddings (device tensors, the newest one is the next frame's track query) and counters."""
+
+    def __init__(self, pos, score, track_id, hs_embed, obj_ind, mask=None, attention_map=None):
+        self.id = track_id
+        self.pos = pos
+        self.last_pos = deque([pos.clone()])
+        self.score = score
+        self.ims = deque([])
+        self.count_inactive = 0
+        self.count_termination = 0
+        self.gt_id = None
+        self.hs_embed = [hs_embed]
+        self.mask = mask
+        self.attention_map = attention_map
+        self.obj_ind = obj_ind
+
+    def has_positive_area(self) -> bool:
+        return bool(self.pos[2] > self.pos[0] and self.pos[3] > self.pos[1])
+
+    def reset_last_pos(self) -> None:
+        self.last_pos.clear()
+        self.last_pos.append(self.pos.clone())
