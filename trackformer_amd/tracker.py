@@ -74,6 +74,12 @@ class Tracker:
     def device(self):
         return next(self.obj_detector.parameters()).device
 
+    def _image_id(self, device):
+        t = getattr(self, "_image_id_cache", None)
+        if t is None or t.device != device:
+            t = self._image_id_cache = torch.ones(1, dtype=torch.int64, device=device)
+        return t
+
     def reset(self, hard=True):
         self.tracks = []
         self.inactive_tracks = []
@@ -241,7 +247,7 @@ class Tracker:
                 [orig_w, orig_h, orig_w, orig_h], dtype=torch.float32)
             target = [{
                 'track_query_boxes': track_query_boxes.to(device, non_blocking=True),
-                'image_id': torch.tensor([1], device=device),
+                'image_id': self._image_id(device),
                 'track_query_hs_embeds': torch.stack([t.hs_embed[-1] for t in prev_tracks], dim=0),
             }]
 
