@@ -51,29 +51,25 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="run the detector eagerly (no HIP graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=3)
     return ap.parse_args()
 
 
 def init_distributed(n_gpus):
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from trackformer_amd import dist_utils as du
+    rank, local_rank, world = du.env_world()
     if world != n_gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
                          "--nproc-per-node %d" % (n_gpus, world, n_gpus))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        du.init_from_env(backend="nccl", device=torch.device("cuda", local_rank))  # nccl == RCCL
     return rank, local_rank, world
 
 
 def barrier(world):
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
+    from trackformer_amd import dist_utils as du
+    du.barrier()
 
 
 def build_tracker(device, use_graph):
@@ -236,11 +232,8 @@ def main():
         barrier(world)
         elapsed = time.perf_counter() - t0
 
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from trackformer_amd import dist_utils as du
+    elapsed = du.max_over_ranks(elapsed, device)
 
     roofline = cpu_baseline = None
     if rank == 0:
