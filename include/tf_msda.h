@@ -63,6 +63,14 @@ const char *tf_msda_strerror(int status);
 int tf_msda_last_hip_error(void);
 
 /*
+ * Kernel selection knob (process-wide, performance only -- results are identical): 1 enables the
+ * LDS-tiled forward kernel for encoder-shaped calls (Lq == S, fp32, D in {32, 36}, P == 4), 0 disables
+ * it, -1 restores the default (environment variable TF_MSDA_TILED, off when unset).  Returns the
+ * previous setting.
+ */
+int tf_msda_set_tiled(int mode);
+
+/*
  * Forward.  out[N,Lq,M*D] = sum_{l,p} attn * bilinear(value_l, loc)      (Appendix A of SURVEY.md)
  *
  * shapes_hw_host : HOST pointer to L*2 int64 (H_l, W_l).  Passed by value to the kernel; nothing is

@@ -79,10 +79,12 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_sequence_sharding_matches_single_process(tmp_path):
+def test_two_rank_sequence_sharding_matches_single_process(tmp_path, monkeypatch):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     from trackformer_amd import dist_utils as du
+    from trackformer_amd import msda
+    monkeypatch.setattr(msda, "MSDeformAttnFunction", msda.MSDeformAttnFunction)  # restored at teardown
     single = _flatten(du.track_sequences(_make_tracker, _make_sequences(), "cpu"))
     for rank in range(2):
         slow, total, n = open(tmp_path / ("rank%d.txt" % rank)).read().split()

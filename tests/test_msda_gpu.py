@@ -193,10 +193,16 @@ def test_full_size_properties(dev):
     assert torch.allclose(out2, out * 2.0, atol=1e-6, rtol=1e-6)
     out3 = _fwd(value, shapes, loc, attn * 0.5)
     assert torch.allclose(out3, out * 0.5, atol=1e-6, rtol=1e-6)
-    # query permutation equivariance: bitwise (each query is computed independently, same order)
+    # query permutation equivariance (the tiled encoder kernel sums staged and global taps in a
+    # different order when a query is not at its pyramid position, hence not bitwise)
     perm = torch.randperm(loc.shape[1], device=dev)
     outp = _fwd(value, shapes, loc[:, perm].contiguous(), attn[:, perm].contiguous())
-    assert torch.equal(outp, out[:, perm])
+    assert torch.allclose(outp, out[:, perm], atol=2e-6, rtol=1e-5)
+    # decoder shape (row-gather kernel): bitwise, each query is computed independently in one order
+    sub = perm[:400]
+    d1 = _fwd(value, shapes, loc[:, sub].contiguous(), attn[:, sub].contiguous())
+    d2 = _fwd(value, shapes, loc[:, sub.flip(0)].contiguous(), attn[:, sub.flip(0)].contiguous())
+    assert torch.equal(d1, d2.flip(1))
     # constant value + in-range samples + weights summing to 1 -> output == constant
     ones = torch.ones_like(value)
     loc_in = loc.clamp(0.2, 0.8)
@@ -363,3 +369,72 @@ def test_module_forward_matches_oracle_composition(dev):
         finally:
             msda.MSDeformAttnFunction = orig
         assert torch.allclose(out.cpu(), exp, atol=2e-4, rtol=1e-3)
+
+
+# ------------------------------------------------------------------ tiled / LDS-staged encoder kernel
+@pytest.fixture()
+def tiled(dev):
+    """Enable the opt-in LDS-tiled encoder kernel for the duration of a test."""
+    from trackformer_amd import _cabi
+    prev = _cabi.lib().tf_msda_set_tiled(1)
+    yield
+    _cabi.lib().tf_msda_set_tiled(prev)
+
+
+def _encoder_inputs(dev, shapes, mode, N=1, M=8, D=32, seed=0):
+    from tools.bench_msda import make_inputs
+    S = sum(h * w for h, w in shapes)
+    return make_inputs(N, M, D, S, 4, shapes, mode, dev, seed=seed, encoder_refs=True)
+
+
+TILED_CASES = [
+    ("cfg2_init", CFG2_SHAPES, "init", 1, 8, 32),
+    ("cfg2_local_n2", CFG2_SHAPES, "local", 2, 8, 32),
+    ("cfg2_uniform_all_fallback", CFG2_SHAPES, "uniform", 1, 8, 32),
+    ("mot17_750x1333", [(94, 167), (47, 84), (24, 42), (12, 21)], "local", 1, 8, 32),
+    ("small_pyramid", [(25, 42), (13, 21), (7, 11), (4, 6)], "init", 2, 8, 32),
+    ("tiny_levels", [(3, 5), (2, 3), (1, 2), (1, 1)], "local", 1, 8, 32),
+    ("one_level", [(37, 53)], "local", 1, 8, 32),
+    ("coarse_first_falls_back", [(13, 21), (100, 167)], "local", 1, 8, 32),
+    ("cfg4_d36_hidden288", CFG2_SHAPES, "local", 1, 8, 36),
+    ("d36_small_n2", [(30, 44), (15, 22), (8, 11)], "init", 2, 8, 36),
+    ("d64_m4", [(40, 60), (20, 30)], "local", 1, 4, 64),
+    ("d16_m8", [(40, 60), (20, 30)], "init", 1, 8, 16),
+]
+
+
+@pytest.mark.parametrize("name,shapes,mode,N,M,D", TILED_CASES, ids=[c[0] for c in TILED_CASES])
+def test_encoder_shape_tiled_kernel_vs_oracle(dev, tiled, name, shapes, mode, N, M, D):
+    """Lq == S selects the tiled kernel (when the plan fits); any input must still be exact."""
+    value, shp, loc, attn, _ = _encoder_inputs(dev, shapes, mode, N=N, M=M, D=D, seed=len(name))
+    out = _fwd(value, shp, loc, attn).cpu().numpy()
+    ref = msda_oracle.msda_forward(value.cpu().numpy(), shp.cpu().numpy(), loc.cpu().numpy(),
+                                   attn.cpu().numpy(), nthreads=8)
+    np.testing.assert_allclose(out, ref, atol=1e-5, rtol=1e-4)
+
+
+def test_tiled_kernel_with_shuffled_queries_and_mixed_windows(dev, tiled):
+    """Queries that are NOT at their pyramid position (a permutation) and samples that straddle the
+    window border: the heuristics are wrong for every tile, results must not change."""
+    value, shp, loc, attn, _ = _encoder_inputs(dev, CFG2_SHAPES, "local", seed=3)
+    base = _fwd(value, shp, loc, attn)
+    perm = torch.randperm(loc.shape[1], device=dev)
+    out = _fwd(value, shp, loc[:, perm].contiguous(), attn[:, perm].contiguous())
+    assert torch.allclose(out, base[:, perm], atol=1e-6, rtol=1e-6)
+    # push half of the points of every query ~12 px away: in-window and out-of-window taps mix
+    far = loc.clone()
+    far[:, :, :, :, ::2, 0] += 12.0 / 167
+    far[:, :, :, :, ::2, 1] -= 9.0 / 100
+    out = _fwd(value, shp, far, attn).cpu().numpy()
+    ref = msda_oracle.msda_forward(value.cpu().numpy(), shp.cpu().numpy(), far.cpu().numpy(),
+                                   attn.cpu().numpy(), nthreads=8)
+    np.testing.assert_allclose(out, ref, atol=1e-5, rtol=1e-4)
+
+
+def test_tiled_kernel_matches_rowgather_kernel(dev, tiled):
+    """Same inputs through the decoder-style kernel (Lq != S forces it) give the same numbers."""
+    value, shp, loc, attn, _ = _encoder_inputs(dev, CFG2_SHAPES, "init", seed=5)
+    tiled = _fwd(value, shp, loc, attn)
+    # drop the last query -> Lq = S - 1 -> row-gather kernel
+    rg = _fwd(value, shp, loc[:, :-1].contiguous(), attn[:, :-1].contiguous())
+    assert torch.allclose(tiled[:, :-1], rg, atol=2e-6, rtol=1e-5)

@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = (
     "tf_msda_abi_version",
     "tf_msda_strerror",
     "tf_msda_last_hip_error",
+    "tf_msda_set_tiled",
     "tf_msda_forward_f32",
     "tf_msda_forward_f64",
     "tf_msda_forward_f32_dshapes",
@@ -53,6 +54,8 @@ def lib():
     L.tf_msda_strerror.argtypes = [ci]
     L.tf_msda_last_hip_error.restype = ci
     L.tf_msda_last_hip_error.argtypes = []
+    L.tf_msda_set_tiled.restype = ci
+    L.tf_msda_set_tiled.argtypes = [ci]
     for suf in ("f32", "f64"):
         for tail in ("", "_dshapes"):
             f = getattr(L, "tf_msda_forward_%s%s" % (suf, tail))

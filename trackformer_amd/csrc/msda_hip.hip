@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "tf_msda.h"
 
@@ -329,6 +331,273 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, encoder self-attention shape (Lq == S): 2-D query tiles + LDS-staged sampling windows
+// ---------------------------------------------------------------------------------------------
+// In the encoder every pyramid pixel is a query and samples a small neighbourhood of its own position
+// in each level, so a value row is fetched ~64 times (16 samples x 4 taps per query and head).  Through
+// the vector-memory path that is 1.46 GB of 128-byte row gathers per launch at <= 64 B/clk/CU (measured:
+// TA busy 16 cycles per dwordx4 wave-load); LDS serves the same gathers at 256 B/clk/CU.  This kernel
+//   * forms 512-thread workgroups from 2-D tiles of queries: a tile is a TH x TW rectangle of level-0
+//     pixels together with the pixels of every other level whose centres fall into the same
+//     normalised rectangle (an exact partition of all S queries), for ONE head (blockIdx % M: with
+//     M == 8 each XCD serves one head, whose 2.8 MB of value rows stay in that XCD's 4 MiB L2);
+//   * ONE LANE = ONE (query, head) PAIR with all D channels in registers: the tap arithmetic is done
+//     once per sampling point (not once per 16-byte slice as in the row-gather kernels) and needs no
+//     cross-lane traffic; consecutive lanes are x-neighbours, so their taps are neighbouring rows;
+//   * walks the value levels; per level the tile's nominal window (tile extent mapped into the level
+//     plus a halo) is copied once, coalesced, into LDS with a row stride of an ODD number of 16-byte
+//     slots (144 B for D = 32), which makes ds_read_b128 of the same slice of 16 neighbouring rows
+//     conflict-free; the next level's window and sampling locations are requested before the current
+//     level is gathered, so their latency hides behind the gather;
+//   * taps outside the level read a zero row kept in LDS (zero padding with no selects); sampling
+//     points whose taps leave the staged window -- possible for any input, the window is only a
+//     guess -- take buffer loads under a wave-uniform branch.
+// Correctness never depends on the tile/window/halo heuristics (tests sweep adversarial inputs).
+constexpr int kV3Threads = 512;
+constexpr int kV3Waves = kV3Threads / 64;
+constexpr int kV3LinesPerWave = 3;     // window height  <= 8 * 3 lines
+constexpr int kV3ChunksPerLine = 5;    // window width x (D/4) <= 64 * 5 sixteen-byte chunks
+
+struct TileGeom {
+    int TH, TW;        // tile size in level-0 pixels
+    int HY, HX;        // window halo in pixels (every level)
+    int tiles_y, tiles_x;
+    int max_wh, max_ww;  // window size limits (LDS capacity and register staging)
+};
+
+template <int PT, int NCH>   // NCH = D / 4 sixteen-byte channel slices per row
+__global__ void __launch_bounds__(kV3Threads)
+msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
+                   const float *__restrict__ loc, const float *__restrict__ attn,
+                   float *__restrict__ out, const LevelTable lt,
+                   const int64_t *__restrict__ dshapes, int S, int M, int L, const TileGeom tg)
+{
+    constexpr int D = NCH * 4;
+    constexpr int kSlots = (NCH % 2) ? NCH : NCH + 1;      // odd number of 16-byte slots per LDS row
+    constexpr unsigned kStride = kSlots * 16u;             // LDS row stride in bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start   (192 B)
+    int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb | qoff(17)
+    constexpr int kQInts = 5 * TF_MSDA_MAX_LEVELS + 4;             // 84 ints -> header = 528 B
+    unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_q + kQInts);
+    // row 0 of s_rows is the zero row; the window starts at byte kStride
+
+    const int m = blockIdx.x % M;
+    int t = blockIdx.x / M;
+    const int tx = t % tg.tiles_x;
+    t /= tg.tiles_x;
+    const int ty = t % tg.tiles_y;
+    const int b = t / tg.tiles_y;
+
+    if (threadIdx.x == 0) {
+        if (dshapes != nullptr) {
+            int acc = 0;
+            for (int l = 0; l < L; ++l) {
+                const int h = (int)dshapes[2 * l], w = (int)dshapes[2 * l + 1];
+                s_tab[l] = h;
+                s_tab[TF_MSDA_MAX_LEVELS + l] = w;
+                s_tab[2 * TF_MSDA_MAX_LEVELS + l] = acc;
+                acc += h * w;
+            }
+        } else {
+            for (int l = 0; l < L; ++l) {
+                s_tab[l] = lt.H[l];
+                s_tab[TF_MSDA_MAX_LEVELS + l] = lt.W[l];
+                s_tab[2 * TF_MSDA_MAX_LEVELS + l] = lt.start[l];
+            }
+        }
+    }
+    if (threadIdx.x < kSlots * 4) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;
+    __syncthreads();
+
+    const int H0 = s_tab[0], W0 = s_tab[TF_MSDA_MAX_LEVELS];
+    const int y0t = ty * tg.TH, y1t = min(H0, y0t + tg.TH);
+    const int x0t = tx * tg.TW, x1t = min(W0, x0t + tg.TW);
+    if (threadIdx.x == 0) {
+        // pixels of level l whose centre lies in [y0t/H0, y1t/H0) x [x0t/W0, x1t/W0): integer exact
+        int acc = 0;
+        for (int l = 0; l < L; ++l) {
+            const int Hl = s_tab[l], Wl = s_tab[TF_MSDA_MAX_LEVELS + l];
+            const int ya = (int)((2LL * y0t * Hl + H0 - 1) / (2LL * H0));
+            const int yb = (int)((2LL * y1t * Hl + H0 - 1) / (2LL * H0));
+            const int xa = (int)((2LL * x0t * Wl + W0 - 1) / (2LL * W0));
+            const int xb = (int)((2LL * x1t * Wl + W0 - 1) / (2LL * W0));
+            s_q[l] = ya;
+            s_q[TF_MSDA_MAX_LEVELS + l] = yb;
+            s_q[2 * TF_MSDA_MAX_LEVELS + l] = xa;
+            s_q[3 * TF_MSDA_MAX_LEVELS + l] = xb;
+            s_q[4 * TF_MSDA_MAX_LEVELS + l] = acc;
+            acc += (yb - ya) * (xb - xa);
+        }
+        s_q[4 * TF_MSDA_MAX_LEVELS + L] = acc;
+    }
+    __syncthreads();
+    const int nq = s_q[4 * TF_MSDA_MAX_LEVELS + L];   // <= kV3Threads (host computed the maximum)
+
+    // this lane's query (tile-local index = thread index; level-major, row-major inside the tile)
+    int q = -1;
+    if ((int)threadIdx.x < nq) {
+        const int tq = threadIdx.x;
+        int l = 0;
+        while (l + 1 < L && tq >= s_q[4 * TF_MSDA_MAX_LEVELS + l + 1]) ++l;
+        const int r = tq - s_q[4 * TF_MSDA_MAX_LEVELS + l];
+        const int nx = s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l];
+        const int yy = s_q[l] + r / nx, xx = s_q[2 * TF_MSDA_MAX_LEVELS + l] + r % nx;
+        q = s_tab[2 * TF_MSDA_MAX_LEVELS + l] + yy * s_tab[TF_MSDA_MAX_LEVELS + l] + xx;
+    }
+    const long long pair = ((long long)b * S + max(q, 0)) * M + m;
+    const int LP = L * PT;
+    const float *lp_base = loc + pair * LP * 2;
+    const float *ap_base = attn + pair * LP;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;
+    const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, value_bytes, 0x00020000);
+
+    struct Geom {
+        int H, W, wy0, wx0, wy1, wx1, ww, wh;
+        unsigned lvl_base;
+    };
+    auto level_geom = [&](int l) {
+        Geom g;
+        g.H = s_tab[l];
+        g.W = s_tab[TF_MSDA_MAX_LEVELS + l];
+        int wy0 = (int)__builtin_floorf((float)y0t * g.H / H0 - 0.5f) - tg.HY;
+        int wy1 = (int)__builtin_floorf((float)y1t * g.H / H0 - 0.5f) + 1 + tg.HY;
+        int wx0 = (int)__builtin_floorf((float)x0t * g.W / W0 - 0.5f) - tg.HX;
+        int wx1 = (int)__builtin_floorf((float)x1t * g.W / W0 - 0.5f) + 1 + tg.HX;
+        g.wy0 = max(wy0, 0);
+        g.wx0 = max(wx0, 0);
+        wy1 = min(wy1, g.H - 1);
+        wx1 = min(wx1, g.W - 1);
+        g.ww = min(wx1 - g.wx0 + 1, tg.max_ww);
+        g.wh = min(wy1 - g.wy0 + 1, tg.max_wh);
+        g.wx1 = g.wx0 + g.ww - 1;
+        g.wy1 = g.wy0 + g.wh - 1;
+        g.lvl_base = head_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + l] * rowbytes;
+        return g;
+    };
+
+    // register staging: the window lines of this wave and this lane's sampling points, one level ahead
+    u32x4_t wreg[kV3LinesPerWave][kV3ChunksPerLine];
+    f32x4_t lxy0, lxy1, law;
+    auto issue_level_loads = [&](int l, const Geom &g) {
+#pragma unroll
+        for (int i = 0; i < kV3LinesPerWave; ++i) {
+            const int wy = wave + i * kV3Waves;
+            const unsigned line_base = g.lvl_base + (unsigned)((g.wy0 + wy) * g.W + g.wx0) * rowbytes;
+#pragma unroll
+            for (int j = 0; j < kV3ChunksPerLine; ++j) {
+                const int ch = lane + j * 64;
+                const int wx = ch / NCH, c = ch - wx * NCH;
+                const unsigned off = (wy < g.wh && wx < g.ww)
+                    ? line_base + (unsigned)wx * rowbytes + (unsigned)c * 16u : kOobOffset;
+                wreg[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+            }
+        }
+        lxy0 = *reinterpret_cast<const f32x4_t *>(lp_base + (size_t)l * PT * 2);
+        lxy1 = *reinterpret_cast<const f32x4_t *>(lp_base + (size_t)l * PT * 2 + 4);
+        law = *reinterpret_cast<const f32x4_t *>(ap_base + (size_t)l * PT);
+    };
+    auto commit_window = [&](const Geom &g) {
+#pragma unroll
+        for (int i = 0; i < kV3LinesPerWave; ++i) {
+            const int wy = wave + i * kV3Waves;
+#pragma unroll
+            for (int j = 0; j < kV3ChunksPerLine; ++j) {
+                const int ch = lane + j * 64;
+                const int wx = ch / NCH, c = ch - wx * NCH;
+                if (wy < g.wh && wx < g.ww)
+                    *reinterpret_cast<u32x4_t *>(s_rows + kStride +
+                        (unsigned)(wy * g.ww + wx) * kStride + (unsigned)c * 16u) = wreg[i][j];
+            }
+        }
+    };
+
+    f32x4_t acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    Geom gnext = level_geom(0);
+    issue_level_loads(0, gnext);
+    for (int l = 0; l < L; ++l) {
+        const Geom g = gnext;
+        __syncthreads();      // previous level's gathers are done with the window
+        commit_window(g);
+        const f32x4_t cxy0 = lxy0, cxy1 = lxy1, caw = law;
+        __syncthreads();
+        if (l + 1 < L) {      // next level's traffic flies while this level is gathered
+            gnext = level_geom(l + 1);
+            issue_level_loads(l + 1, gnext);
+        }
+        if (q < 0) continue;  // no barrier below this point inside the iteration
+
+        const float Wf = (float)g.W, Hf = (float)g.H;
+        const float lx[4] = {cxy0.x, cxy0.z, cxy1.x, cxy1.z};
+        const float ly[4] = {cxy0.y, cxy0.w, cxy1.y, cxy1.w};
+        const float aw[4] = {caw.x, caw.y, caw.z, caw.w};
+        static_assert(PT == 4, "tiled kernel is written for 4 sampling points per level");
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const float xr = __builtin_fmaf(lx[p], Wf, -0.5f);   // cuh:227-228, single rounding
+            const float yr = __builtin_fmaf(ly[p], Hf, -0.5f);
+            const bool in = (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);  // cuh:229
+            const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+            const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+            const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+            const int x0 = (int)xf, y0 = (int)yf;
+            const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= g.W - 1);
+            const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= g.H - 1);
+            // lowest / highest VALID tap coordinate must lie inside the staged window
+            const int xlo = kx0 ? x0 : x0 + 1, xhi = kx1 ? x0 + 1 : x0;
+            const int ylo = ky0 ? y0 : y0 + 1, yhi = ky1 ? y0 + 1 : y0;
+            const bool staged = !in || (xlo >= g.wx0 && xhi <= g.wx1 && ylo >= g.wy0 && yhi <= g.wy1);
+            const float w1 = gy * gx * aw[p], w2 = gy * fx * aw[p];
+            const float w3 = fy * gx * aw[p], w4 = fy * fx * aw[p];
+            const unsigned o = kStride + (unsigned)((y0 - g.wy0) * g.ww + (x0 - g.wx0)) * kStride;
+            const unsigned o1 = (staged && ky0 && kx0) ? o : 0u;                 // 0 = the zero row
+            const unsigned o2 = (staged && ky0 && kx1) ? o + kStride : 0u;
+            const unsigned o3 = (staged && ky1 && kx0) ? o + (unsigned)g.ww * kStride : 0u;
+            const unsigned o4 = (staged && ky1 && kx1) ? o + (unsigned)(g.ww + 1) * kStride : 0u;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const f32x4_t v1 = *reinterpret_cast<const f32x4_t *>(s_rows + o1 + c * 16);
+                const f32x4_t v2 = *reinterpret_cast<const f32x4_t *>(s_rows + o2 + c * 16);
+                const f32x4_t v3 = *reinterpret_cast<const f32x4_t *>(s_rows + o3 + c * 16);
+                const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(s_rows + o4 + c * 16);
+                acc[c] += v1 * w1;
+                acc[c] += v2 * w2;
+                acc[c] += v3 * w3;
+                acc[c] += v4 * w4;
+            }
+            if (__any(in && !staged)) {   // rare: the point left the window -> global gather for it
+                const bool gl = in && !staged;
+                const int r0 = y0 * g.W + x0;
+                const unsigned b1 = (gl && ky0 && kx0) ? g.lvl_base + (unsigned)r0 * rowbytes : kOobOffset;
+                const unsigned b2 = (gl && ky0 && kx1) ? g.lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobOffset;
+                const unsigned b3 = (gl && ky1 && kx0) ? g.lvl_base + (unsigned)(r0 + g.W) * rowbytes : kOobOffset;
+                const unsigned b4 = (gl && ky1 && kx1) ? g.lvl_base + (unsigned)(r0 + g.W + 1) * rowbytes : kOobOffset;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    // kOobOffset + c*16 stays out of range for every supported tensor (c*16 < 256)
+                    acc[c] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b1 == kOobOffset ? b1 : b1 + c * 16, 0, 0)) * w1;
+                    acc[c] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b2 == kOobOffset ? b2 : b2 + c * 16, 0, 0)) * w2;
+                    acc[c] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b3 == kOobOffset ? b3 : b3 + c * 16, 0, 0)) * w3;
+                    acc[c] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b4 == kOobOffset ? b4 : b4 + c * 16, 0, 0)) * w4;
+                }
+            }
+        }
+    }
+    if (q >= 0) {
+        float *op = out + pair * D;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *reinterpret_cast<f32x4_t *>(op + c * 4) = acc[c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward (grad_value via atomics, grad_loc / grad_attn via wave reduction), fused
 // ---------------------------------------------------------------------------------------------
 template <typename T, int VEC, bool POW2>
@@ -519,6 +788,78 @@ bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, in
     return true;
 }
 
+// The LDS-tiled encoder kernel is opt-in (tf_msda_set_tiled(1) or TF_MSDA_TILED=1): on MI355X it is
+// currently slower than the row-gather kernel (81 vs 58 us at the cfg-2 encoder shape).
+int g_tiled_mode = -1;   // -1: follow the environment, 0: off, 1: on
+bool tiled_enabled()
+{
+    if (g_tiled_mode >= 0) return g_tiled_mode != 0;
+    static const int env_on = [] { const char *e = getenv("TF_MSDA_TILED"); return (e && e[0] == '1') ? 1 : 0; }();
+    return env_on != 0;
+}
+
+// Tile / window plan of msda_fwd_f32_tiled.  Returns false when the shape does not suit the kernel
+// (then the row-gather kernels are used).  Everything here is a performance heuristic.
+constexpr size_t kTiledLdsBudget = 150 * 1024;   // one 512-thread workgroup per CU (160 KiB LDS)
+constexpr int kTiledHeaderBytes = kLevelTableBytes + (5 * TF_MSDA_MAX_LEVELS + 4) * (int)sizeof(int);
+
+bool plan_tiles(const LevelTable &lt, int L, int D, TileGeom *tg, size_t *lds)
+{
+    if (!tiled_enabled()) return false;
+    if (D != 32 && D != 36) return false;      // instantiated row widths (hidden 256 / 288, 8 heads)
+    const int nch = D / 4, slots = (nch % 2) ? nch : nch + 1;
+    int hy = 4, hx = 8;   // default halo: the (H,W)-divisor quirk stretches x offsets by W/H (~1.67)
+    int th = 14, tw = 16;
+    if (const char *e = getenv("TF_MSDA_HALO")) sscanf(e, "%d,%d", &hy, &hx);
+    if (const char *e = getenv("TF_MSDA_TILE")) sscanf(e, "%d,%d", &th, &tw);
+    if (hy < 0 || hx < 0 || th < 1 || tw < 1) return false;
+    const int H0 = lt.H[0], W0 = lt.W[0];
+    tg->TH = th;
+    tg->TW = tw;
+    tg->HY = hy;
+    tg->HX = hx;
+    tg->tiles_y = (H0 + th - 1) / th;
+    tg->tiles_x = (W0 + tw - 1) / tw;
+    // exact maximum number of queries of one tile (same integer partition as the kernel)
+    long long max_nq = 0;
+    for (int ty = 0; ty < tg->tiles_y; ++ty)
+        for (int tx = 0; tx < tg->tiles_x; ++tx) {
+            const int y0 = ty * th, y1 = (y0 + th < H0) ? y0 + th : H0;
+            const int x0 = tx * tw, x1 = (x0 + tw < W0) ? x0 + tw : W0;
+            long long nq = 0;
+            for (int l = 0; l < L; ++l) {
+                const long long Hl = lt.H[l], Wl = lt.W[l];
+                const long long ny = (2 * y1 * Hl + H0 - 1) / (2LL * H0) - (2 * y0 * Hl + H0 - 1) / (2LL * H0);
+                const long long nx = (2 * x1 * Wl + W0 - 1) / (2LL * W0) - (2 * x0 * Wl + W0 - 1) / (2LL * W0);
+                nq += ny * nx;
+            }
+            if (nq > max_nq) max_nq = nq;
+        }
+    if (max_nq < 1 || max_nq > kV3Threads) return false;   // e.g. level 0 is not the finest level
+    // window limits: register staging (lines per wave, chunks per line) and LDS capacity
+    int max_wh = kV3Waves * kV3LinesPerWave;
+    int max_ww = (64 * kV3ChunksPerLine) / nch;
+    const size_t row = (size_t)slots * 16;
+    while ((size_t)kTiledHeaderBytes + row * (1 + (size_t)max_wh * max_ww) > kTiledLdsBudget && max_wh > 1)
+        --max_wh;
+    if ((size_t)kTiledHeaderBytes + row * (1 + (size_t)max_wh * max_ww) > kTiledLdsBudget) return false;
+    tg->max_wh = max_wh;
+    tg->max_ww = max_ww;
+    // LDS actually needed: the largest nominal window over the levels (bounded by the limits)
+    long long want = 1;
+    for (int l = 0; l < L; ++l) {
+        long long wh = ((long long)th * lt.H[l] + H0 - 1) / H0 + 2 * hy + 3;
+        long long ww = ((long long)tw * lt.W[l] + W0 - 1) / W0 + 2 * hx + 3;
+        if (wh > lt.H[l]) wh = lt.H[l];
+        if (ww > lt.W[l]) ww = lt.W[l];
+        if (wh > max_wh) wh = max_wh;
+        if (ww > max_ww) ww = max_ww;
+        if (wh * ww > want) want = wh * ww;
+    }
+    *lds = (size_t)kTiledHeaderBytes + row * (size_t)(1 + want);
+    return true;
+}
+
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shapes_dev,
                  const T *loc, const T *attn, T *out, int N, int S, int M, int D, int L, int Lq,
@@ -546,6 +887,22 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
         if (pl.vec == 4 && (P == 1 || P == 2 || P == 4 || P == 8) &&
             buf_path_ok(lt, shapes_host != nullptr, N, S, M, D, L)) {
             const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
+            TileGeom tg;
+            size_t tiled_lds = 0;
+            if (shapes_host && Lq == S && P == 4 && is_aligned(loc, 16) && is_aligned(attn, 16) &&
+                plan_tiles(lt, L, D, &tg, &tiled_lds)) {
+                const long long grid = (long long)N * tg.tiles_y * tg.tiles_x * M;
+                if (grid <= 0x7fffffffLL) {
+                    const void *tfn = D == 32 ? (const void *)&msda_fwd_f32_tiled<4, 8>
+                                              : (const void *)&msda_fwd_f32_tiled<4, 9>;
+                    void *argv[] = {(void *)&value, (void *)&vbytes, (void *)&loc, (void *)&attn,
+                                    (void *)&out,   (void *)&lt,     (void *)&shapes_dev, (void *)&S,
+                                    (void *)&M,     (void *)&L,      (void *)&tg};
+                    e = hipLaunchKernel(tfn, dim3((unsigned)grid), dim3(kV3Threads), argv, tiled_lds,
+                                        stream);
+                    return record_hip(e);
+                }
+            }
             const void *fn = P == 1   ? (const void *)&msda_fwd_f32_buf<1>
                              : P == 2 ? (const void *)&msda_fwd_f32_buf<2>
                              : P == 4 ? (const void *)&msda_fwd_f32_buf<4>
@@ -624,6 +981,13 @@ const char *tf_msda_strerror(int status)
 }
 
 int tf_msda_last_hip_error(void) { return g_last_hip_error; }
+
+int tf_msda_set_tiled(int mode)
+{
+    const int prev = g_tiled_mode;
+    g_tiled_mode = mode < 0 ? -1 : (mode ? 1 : 0);
+    return prev;
+}
 
 int tf_msda_forward_f32(const float *value, const int64_t *shapes_hw_host, const float *loc,
                         const float *attn, float *out, int N, int S, int M, int D, int L, int Lq,
