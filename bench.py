@@ -208,6 +208,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    from trackformer_amd import runtime
+    runtime.configure_inference(tune=os.environ.get("TF_TUNE", "0") == "1",
+                                miopen_find=os.environ.get("TF_MIOPEN_FIND", "1") == "1",
+                                verbose=(rank == 0))
 
     from trackformer_amd import _cabi
     _cabi.lib()   # fail loudly if the HIP library is missing

@@ -18,9 +18,14 @@ def lib():
 
 
 def _declared_symbols():
-    text = open(os.path.join(REPO, "include", "tf_msda.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(tf_msda_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in sorted(os.listdir(os.path.join(REPO, "include"))):
+        if not header.endswith(".h"):
+            continue
+        text = open(os.path.join(REPO, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(tf_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_and_binding_agree():

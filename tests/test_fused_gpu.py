@@ -1,0 +1,75 @@
+"""GPU: fused element-wise HIP kernels against the plain PyTorch fp32 formulation they replace."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("shape", [(1, 64, 50, 84), (2, 256, 13, 21), (1, 2048, 25, 42),
+                                   (1, 8, 3, 5), (1, 256, 200, 334)])
+@pytest.mark.parametrize("with_res", [False, True])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bias_act_matches_torch(dev, shape, with_res, relu):
+    from trackformer_amd import fused
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(shape[1], generator=g).to(dev)
+    r = torch.randn(shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last) \
+        if with_res else None
+    ref = x + b.view(1, -1, 1, 1)
+    if r is not None:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    y = fused.bias_act_(x, b, r, relu)
+    assert y is x
+    assert torch.allclose(x, ref, atol=1e-6, rtol=1e-6)
+    assert x.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_bias_act_declines_unsuitable_layouts(dev):
+    from trackformer_amd import fused
+    x = torch.randn(1, 6, 4, 4, device=dev).contiguous(memory_format=torch.channels_last)
+    assert fused.bias_act_(x, torch.zeros(6, device=dev)) is None          # C % 4 != 0
+    x = torch.randn(1, 8, 4, 4, device=dev)                                  # NCHW storage
+    assert fused.bias_act_(x, torch.zeros(8, device=dev)) is None
+    assert fused.bias_act_(torch.randn(1, 8, 4, 4), torch.zeros(8)) is None  # CPU
+
+
+@pytest.mark.parametrize("rows,C", [(22223, 256), (400, 256), (800, 288), (7, 1024), (3, 4096),
+                                    (5, 8)])
+@pytest.mark.parametrize("with_res", [False, True])
+def test_add_layernorm_matches_torch(dev, rows, C, with_res):
+    from trackformer_amd import fused
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(1, rows, C, generator=g) * 3 + 0.5).to(dev)
+    r = torch.randn(1, rows, C, generator=g).to(dev) if with_res else None
+    ln = torch.nn.LayerNorm(C).to(dev)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.2)
+        ln.bias.normal_(0.0, 0.2)
+        ref = ln(x + r if with_res else x)
+        out = fused.add_layernorm(x, r, ln)
+    assert out is not None and out.shape == x.shape
+    assert torch.allclose(out, ref, atol=2e-5, rtol=1e-5)
+
+
+def test_residual_norm_dispatch(dev):
+    from trackformer_amd import fused
+    ln = torch.nn.LayerNorm(16).to(dev)
+    x, r = torch.randn(2, 3, 16, device=dev), torch.randn(2, 3, 16, device=dev)
+    with torch.no_grad():
+        a = fused.residual_norm(x, r, ln, inference=True)
+        b = fused.residual_norm(x, r, ln, inference=False)
+    assert torch.allclose(a, b, atol=1e-5)
+    # CPU tensors always take the PyTorch formulation
+    lc = torch.nn.LayerNorm(16)
+    assert fused.add_layernorm(torch.randn(2, 16), None, lc) is None

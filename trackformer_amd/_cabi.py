@@ -23,6 +23,9 @@ EXPORTED_SYMBOLS = (
     "tf_msda_backward_f64",
     "tf_msda_backward_f32_dshapes",
     "tf_msda_backward_f64_dshapes",
+    # include/tf_fused.h
+    "tf_bias_act_f32",
+    "tf_add_layernorm_f32",
 )
 
 ABI_VERSION = 1
@@ -64,6 +67,10 @@ def lib():
             b = getattr(L, "tf_msda_backward_%s%s" % (suf, tail))
             b.restype = ci
             b.argtypes = [vp] * 8 + [ci] * 7 + [vp]
+    L.tf_bias_act_f32.restype = ci
+    L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_add_layernorm_f32.restype = ci
+    L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     if L.tf_msda_abi_version() != ABI_VERSION:
         raise RuntimeError("libtf_msda.so ABI version %d != expected %d (rebuild)" %
                            (L.tf_msda_abi_version(), ABI_VERSION))

@@ -19,8 +19,15 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import fused
 from .nested import NestedTensor, all_valid_mask, is_all_valid
 from .position_encoding import build_position_encoding
+
+
+import os as _os
+
+# activations / folded weights in NHWC during inference (MIOpen's fp32 implicit-GEMM kernels are NHWC)
+CHANNELS_LAST = _os.environ.get("TF_BACKBONE_NCHW", "0") != "1"
 
 
 class FrozenBatchNorm2d(nn.Module):
@@ -64,7 +71,8 @@ class _FoldCache:
             with torch.no_grad():
                 scale, shift = bn.scale_shift()
                 w = conv.weight * scale.reshape(-1, 1, 1, 1)
-                self.weight = w.contiguous(memory_format=torch.channels_last)
+                self.weight = w.contiguous(memory_format=torch.channels_last) if CHANNELS_LAST \
+                    else w.contiguous()
                 self.bias = shift.contiguous()
             self.key = key
         return self.weight, self.bias
@@ -74,12 +82,25 @@ def _inference_mode(module: nn.Module) -> bool:
     return (not module.training) and (not torch.is_grad_enabled())
 
 
-def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, fold: bool):
+def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, fold: bool,
+             residual=None):
+    """conv -> frozen BN (-> + residual) (-> ReLU).  Inference on the GPU: one library convolution with
+    the BN scale folded into its weights, then ONE fused pass for shift / residual / ReLU."""
     if fold and isinstance(bn, FrozenBatchNorm2d):
         w, b = cache.get(conv, bn)
-        x = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
-        return F.relu_(x) if relu else x
+        if x.is_cuda:
+            y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            if fused.bias_act_(y, b, residual, relu) is not None:
+                return y
+            y = y + b.reshape(1, -1, 1, 1)
+        else:
+            y = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if residual is not None:
+            y = y.add_(residual)
+        return F.relu_(y) if relu else y
     x = bn(conv(x))
+    if residual is not None:
+        x = x + residual
     return F.relu(x) if relu else x
 
 
@@ -106,12 +127,9 @@ class Bottleneck(nn.Module):
         fold = _inference_mode(self)
         out = _conv_bn(x, self.conv1, self.bn1, self._folds[0], True, fold)
         out = _conv_bn(out, self.conv2, self.bn2, self._folds[1], True, fold)
-        out = _conv_bn(out, self.conv3, self.bn3, self._folds[2], False, fold)
         if self.downsample is not None:
             x = _conv_bn(x, self.downsample[0], self.downsample[1], self._folds[3], False, fold)
-        if fold:
-            return F.relu_(out.add_(x))
-        return F.relu(out + x)
+        return _conv_bn(out, self.conv3, self.bn3, self._folds[2], True, fold, residual=x)
 
 
 class ResNet(nn.Module):
@@ -237,7 +255,7 @@ class BackboneBase(nn.Module):
 
     def forward(self, tensor_list: NestedTensor):
         x = tensor_list.tensors
-        if _inference_mode(self) and x.is_cuda:
+        if _inference_mode(self) and x.is_cuda and CHANNELS_LAST:
             x = x.contiguous(memory_format=torch.channels_last)
         xs = self.body(x)
         m = tensor_list.mask

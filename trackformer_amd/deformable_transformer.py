@@ -18,8 +18,14 @@ import torch.nn.functional as F
 from torch import nn
 from torch.nn.init import constant_, normal_, xavier_uniform_
 
+from . import fused
 from .msda import MSDeformAttn, attach_host_shapes
 from .nested import inverse_sigmoid, is_all_valid
+
+
+def _inference(module) -> bool:
+    """eval mode with gradients disabled: the fused single-pass kernels may replace ATen chains."""
+    return (not module.training) and (not torch.is_grad_enabled())
 
 
 def _get_clones(module, N):
@@ -280,12 +286,12 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return self.norm2(src + self.dropout3(src2))
+        return fused.residual_norm(src, self.dropout3(src2), self.norm2, _inference(self))
 
     def forward(self, src, pos, reference_points, spatial_shapes, padding_mask=None):
         src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
                               padding_mask)
-        src = self.norm1(src + self.dropout1(src2))
+        src = fused.residual_norm(src, self.dropout1(src2), self.norm1, _inference(self))
         return self.forward_ffn(src)
 
 
@@ -345,7 +351,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return self.norm3(tgt + self.dropout4(tgt2))
+        return fused.residual_norm(tgt, self.dropout4(tgt2), self.norm3, _inference(self))
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes,
                 src_padding_mask=None, query_attn_mask=None):
@@ -353,11 +359,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
         q = k = self.with_pos_embed(tgt, query_pos)
         tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
                               key_padding_mask=query_attn_mask)[0].transpose(0, 1)
-        tgt = self.norm2(tgt + self.dropout2(tgt2))
+        tgt = fused.residual_norm(tgt, self.dropout2(tgt2), self.norm2, _inference(self))
         # deformable cross attention into the encoder memory
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src,
                                src_spatial_shapes, src_padding_mask, query_attn_mask)
-        tgt = self.norm1(tgt + self.dropout1(tgt2))
+        tgt = fused.residual_norm(tgt, self.dropout1(tgt2), self.norm1, _inference(self))
         return self.forward_ffn(tgt)
 
 

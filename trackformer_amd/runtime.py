@@ -1,0 +1,57 @@
+"""Process-wide inference setup for MI355X: library-kernel selection for the dense layers.
+
+The dense part of the path (ResNet-50 convolutions, the encoder/decoder linears) runs on MIOpen and
+hipBLASLt/rocBLAS through PyTorch-ROCm.  Their default heuristics leave a lot on the table at this
+model's shapes (fp32, M = 22 223 tokens, K,N in {128, 256, 1024}; batch-1 NHWC convolutions):
+
+  * `torch.backends.cudnn.benchmark = True` lets MIOpen time its solvers per convolution
+    configuration on first use instead of taking the immediate-mode guess (13.0 -> 11.0 ms/frame);
+  * PyTorch TunableOp picks the fastest hipBLASLt / rocBLAS solution per GEMM shape (53.6 -> 32 us for
+    the 22223x256x256 projections, 122 TFLOP/s fp32 on the FFN GEMMs; 13.0 -> 10.7 ms/frame).  The
+    selections for the BASELINE cfg-2 shapes, tuned on an MI355X with this image, ship in
+    trackformer_amd/tuning/ and are only looked up (no tuning at run time) unless `tune=True`.
+
+Numerics: every candidate is an fp32 kernel of the same library; results differ by summation order
+only (parity tests run with this setup enabled).
+"""
+import os
+
+import torch
+
+_TUNING_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
+_configured = False
+
+
+def configure_inference(tune=False, miopen_find=True, tunable_file=None, verbose=False):
+    """Idempotent.  Call once per process before the first forward."""
+    global _configured
+    if _configured:
+        return
+    _configured = True
+    if not torch.cuda.is_available():
+        return
+    if miopen_find:
+        torch.backends.cudnn.benchmark = True
+    try:
+        import torch.cuda.tunable as tunable
+    except ImportError:
+        return
+    path = tunable_file or os.path.join(_TUNING_DIR, "tunableop_gfx950_cfg2.csv")
+    tunable.enable(True)
+    tunable.tuning_enable(bool(tune))
+    if tune:
+        tunable.set_max_tuning_duration(30)
+        tunable.set_max_tuning_iterations(100)
+        out = os.environ.get("TF_TUNABLEOP_OUT")
+        if out:
+            tunable.set_filename(out, insert_device_ordinal=True)
+    elif hasattr(tunable, "write_file_on_exit"):
+        tunable.write_file_on_exit(False)
+    else:   # this PyTorch writes its (unchanged) table at exit: keep it out of the working directory
+        tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"),
+                                          "tf_tunableop_results.csv"), insert_device_ordinal=True)
+    if os.path.exists(path):
+        ok = tunable.read_file(path)
+        if verbose:
+            print("trackformer_amd: TunableOp selections %s from %s" %
+                  ("loaded" if ok else "REJECTED (validator mismatch)", path))
