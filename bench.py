@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--sequences", type=int, default=2,
+                    help="independent video sequences tracked concurrently per GPU (one host thread "
+                         "and HIP stream each); frames of one sequence stay strictly sequential")
     return ap.parse_args()
 
 
@@ -72,14 +75,17 @@ def barrier(world):
     du.barrier()
 
 
-def build_tracker(device, use_graph):
+def build_tracker(device, use_graph, model=None):
     from trackformer_amd import config, factory
+    from trackformer_amd.deformable_detr import DeformablePostProcess
     from trackformer_amd.tracker import Tracker
-    args = config.make_args('deformable', 'tracking', 'mot17', device=str(device))
-    torch.manual_seed(42)   # cfgs/train.yaml:112
-    model, _, post = factory.build_model(args)
-    model.to(device)
-    model.tracking()
+    post = {'bbox': DeformablePostProcess()}
+    if model is None:
+        args = config.make_args('deformable', 'tracking', 'mot17', device=str(device))
+        torch.manual_seed(42)   # cfgs/train.yaml:112
+        model, _, post = factory.build_model(args)
+        model.to(device)
+        model.tracking()
     detector = model
     if use_graph:
         from trackformer_amd.graphed import GraphedDetector
@@ -216,25 +222,47 @@ def main():
     from trackformer_amd import _cabi
     _cabi.lib()   # fail loudly if the HIP library is missing
 
-    tracker, model = build_tracker(device, use_graph=not args.no_graph)
+    import threading
+    n_seq = max(1, args.sequences)
+    steps_per_seq = [args.steps // n_seq + (1 if i < args.steps % n_seq else 0) for i in range(n_seq)]
+    warm_per_seq = max(3, (args.warmup + n_seq - 1) // n_seq)   # >= 3: HIP-graph capture happens here
+
+    # One tracker (own HIP stream, own graph buffers) per sequence; the detector weights are shared.
+    trackers, model = [], None
+    for i in range(n_seq):
+        tracker, m = build_tracker(device, use_graph=not args.no_graph, model=model)
+        model = m
+        trackers.append(tracker)
     seeder = TrackSeeder(device, model.hidden_dim)
     frames = make_frames(device)
+    streams = [torch.cuda.Stream(device) for _ in range(n_seq)]
 
-    def step(i):
-        seeder.seed(tracker)
-        tracker.step(frames[i % len(frames)])
+    def run(seq, n):
+        torch.cuda.set_device(device)
+        with torch.no_grad(), torch.cuda.stream(streams[seq]):
+            for i in range(n):
+                seeder.seed(trackers[seq])
+                trackers[seq].step(frames[(seq + i) % len(frames)])
+            streams[seq].synchronize()
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
-        torch.cuda.synchronize()
-        barrier(world)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
-        torch.cuda.synchronize()
-        barrier(world)
-        elapsed = time.perf_counter() - t0
+    # warm-up sequentially (MIOpen find, caches, graph capture are not re-entrant), then time
+    for seq in range(n_seq):
+        run(seq, warm_per_seq)
+    torch.cuda.synchronize()
+    barrier(world)
+    t0 = time.perf_counter()
+    if n_seq == 1:
+        run(0, steps_per_seq[0])
+    else:
+        threads = [threading.Thread(target=run, args=(seq, steps_per_seq[seq]))
+                   for seq in range(n_seq)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    torch.cuda.synchronize()
+    barrier(world)
+    elapsed = time.perf_counter() - t0
 
     from trackformer_amd import dist_utils as du
     elapsed = du.max_over_ranks(elapsed, device)
@@ -265,7 +293,7 @@ def main():
                                    "DeformableDETRTracking R50 4 levels, 300 obj + 100 track "
                                    "queries, seeded random-init weights, frames resident in HBM",
                        "global_batch": world, "parallelism": "sequence-sharded x%d" % world,
-                       "hip_graph": not args.no_graph},
+                       "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

@@ -229,8 +229,8 @@ class Tracker:
         if self.inactive_tracks:
             self._logger(f'INACTIVE TRACK IDS: {[t.id for t in self.inactive_tracks]}')
 
-        for track in self.tracks:
-            track.last_pos.append(track.pos.clone())
+        for track in self.tracks:   # host tensors are never modified in place: no clone needed
+            track.last_pos.append(track.pos)
 
         device = self.device
         img = blob['img'].to(device, non_blocking=True)
@@ -424,7 +424,7 @@ class Track(object):
     def __init__(self, pos, score, track_id, hs_embed, obj_ind, mask=None, attention_map=None):
         self.id = track_id
         self.pos = pos
-        self.last_pos = deque([pos.clone()])
+        self.last_pos = deque([pos])
         self.score = score
         self.ims = deque([])
         self.count_inactive = 0
@@ -436,8 +436,9 @@ class Track(object):
         self.obj_ind = obj_ind
 
     def has_positive_area(self) -> bool:
-        return bool(self.pos[2] > self.pos[0] and self.pos[3] > self.pos[1])
+        x0, y0, x1, y1 = self.pos.tolist()
+        return x1 > x0 and y1 > y0
 
     def reset_last_pos(self) -> None:
         self.last_pos.clear()
-        self.last_pos.append(self.pos.clone())
+        self.last_pos.append(self.pos)
