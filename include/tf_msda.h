@@ -98,6 +98,25 @@ int tf_msda_forward_f64_dshapes(const double *value, const int64_t *shapes_hw_de
                                 int M, int D, int L, int Lq, int P, void *stream);
 
 /*
+ * Forward with the operator's prologue fused in (fp32, inference): takes the RAW outputs of the query
+ * projections and the reference points and performs softmax + sampling-location arithmetic inside the
+ * kernel.  Replaces ops/modules/ms_deform_attn.py:69-86 (view / softmax / location arithmetic /
+ * MSDeformAttnFunction.apply) in one launch.
+ *   ref_points [N, Lq, L, ref_dim]   ref_dim 2: loc = ref + off / (H_l, W_l)   (x with H_l, y with W_l,
+ *                                               exactly as ms_deform_attn.py:78-79 is written)
+ *                                    ref_dim 4: loc = ref[:2] + off / P * ref[2:] * 0.5   (:81-82)
+ *   qproj      [N*Lq, ld] floats; row r holds the query's M*L*P*2 raw offsets (order m, l, p, xy) starting
+ *              at column off_col and its M*L*P attention logits (order m, l, p) at column logit_col
+ *              (e.g. one GEMM with the two Linear weights concatenated: ld = 3*M*L*P, off_col = 0,
+ *              logit_col = 2*M*L*P).  off_col and ld must be even.
+ * Requires D % 4 == 0, P in {1,2,4,8}, 16-byte aligned value/out, tensors < 4 GiB.
+ */
+int tf_msda_forward_fused_f32(const float *value, const int64_t *shapes_hw_host,
+                              const float *ref_points, int ref_dim, const float *qproj, int ld,
+                              int off_col, int logit_col, float *out, int N, int S, int M, int D,
+                              int L, int Lq, int P, void *stream);
+
+/*
  * Backward.  Writes all three gradients; grad_value is zero-filled on `stream` by the library before
  * accumulation (reference: at::zeros_like, cu:119-121), grad_loc / grad_attn are fully overwritten.
  * grad_value accumulation uses hardware floating-point atomics, so its summation order (and therefore

@@ -438,3 +438,59 @@ def test_tiled_kernel_matches_rowgather_kernel(dev, tiled):
     # drop the last query -> Lq = S - 1 -> row-gather kernel
     rg = _fwd(value, shp, loc[:, :-1].contiguous(), attn[:, :-1].contiguous())
     assert torch.allclose(tiled[:, :-1], rg, atol=2e-6, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ fused prologue (inference)
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("Lq,shapes_l,d_model", [(400, CFG2_SHAPES, 256), (1020, [(24, 32), (12, 16), (6, 8), (3, 4)], 256),
+                                                 (65, [(13, 21), (7, 11), (4, 6), (2, 3)] * 2, 288)])
+def test_fused_prologue_matches_unfused_module(dev, ref_dim, Lq, shapes_l, d_model):
+    """MSDeformAttn inference fast path (cat-projection GEMM + fused kernel prologue) vs the reference
+    formulation (separate Linears, softmax, location arithmetic, plain operator) on the same module."""
+    from trackformer_amd import msda
+    torch.manual_seed(1)
+    L = len(shapes_l)
+    m = msda.MSDeformAttn(d_model, L, 8, 4).to(dev).eval()
+    with torch.no_grad():
+        m.sampling_offsets.weight.normal_(0, 0.05)
+        m.attention_weights.weight.normal_(0, 0.3)
+        m.attention_weights.bias.normal_(0, 0.3)
+    S = sum(h * w for h, w in shapes_l)
+    shapes = msda.attach_host_shapes(torch.tensor(shapes_l, device=dev), shapes_l)
+    q = torch.randn(2, Lq, d_model, device=dev)
+    src = torch.randn(2, S, d_model, device=dev)
+    ref = torch.rand(2, Lq, L, ref_dim, device=dev) * (0.5 if ref_dim == 4 else 1.0) + 0.05
+    with torch.no_grad():
+        assert msda.FUSED_INFERENCE
+        fused_out = m(q, ref, src, shapes, None)
+        msda.FUSED_INFERENCE = False
+        try:
+            plain_out = m(q, ref, src, shapes, None)
+        finally:
+            msda.FUSED_INFERENCE = True
+    assert torch.allclose(fused_out, plain_out, atol=3e-5, rtol=1e-4)
+
+
+def test_fused_prologue_entry_point_vs_oracle(dev):
+    """C-ABI tf_msda_forward_fused_f32 against oracle(softmax / loc arithmetic done in torch fp32)."""
+    from trackformer_amd import msda
+    g = torch.Generator().manual_seed(7)
+    N, M, D, L, P, Lq = 1, 8, 32, 4, 4, 333
+    shapes_l = [(25, 42), (13, 21), (7, 11), (4, 6)]
+    S = sum(h * w for h, w in shapes_l)
+    value = torch.randn(N, S, M, D, generator=g)
+    qproj = torch.randn(N, Lq, 3 * M * L * P, generator=g)
+    shapes = torch.tensor(shapes_l)
+    for ref_dim in (2, 4):
+        ref = torch.rand(N, Lq, L, ref_dim, generator=g) * 0.6 + 0.1
+        off = qproj[..., :2 * M * L * P].view(N, Lq, M, L, P, 2)
+        attn = torch.softmax(qproj[..., 2 * M * L * P:].view(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+        if ref_dim == 2:
+            loc = ref[:, :, None, :, None, :] + off / shapes[None, None, None, :, None, :]
+        else:
+            loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+        expect = msda_oracle.msda_forward(value.numpy(), shapes.numpy(), loc.numpy(), attn.numpy())
+        dshapes = msda.attach_host_shapes(shapes.to(dev), shapes_l)
+        out = msda.ms_deform_attn_forward_fused(value.to(dev), dshapes, ref.to(dev), qproj.to(dev),
+                                                M, L, P)
+        np.testing.assert_allclose(out.cpu().numpy(), expect, atol=2e-5, rtol=1e-4)

@@ -15,6 +15,7 @@ EXPORTED_SYMBOLS = (
     "tf_msda_strerror",
     "tf_msda_last_hip_error",
     "tf_msda_set_tiled",
+    "tf_msda_forward_fused_f32",
     "tf_msda_forward_f32",
     "tf_msda_forward_f64",
     "tf_msda_forward_f32_dshapes",
@@ -67,6 +68,8 @@ def lib():
             b = getattr(L, "tf_msda_backward_%s%s" % (suf, tail))
             b.restype = ci
             b.argtypes = [vp] * 8 + [ci] * 7 + [vp]
+    L.tf_msda_forward_fused_f32.restype = ci
+    L.tf_msda_forward_fused_f32.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp] + [ci] * 7 + [vp]
     L.tf_bias_act_f32.restype = ci
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_add_layernorm_f32.restype = ci

@@ -248,12 +248,29 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobOffset = 0xFFFFFFF0u;  // >= num_records for every supported tensor
 
-template <int PT>
+// Optional fused prologue (FUSED = true): instead of reading finished sampling locations and softmaxed
+// attention weights, the kernel takes the raw outputs of the query projections and the reference
+// points and performs the arithmetic of MSDeformAttn.forward (ops/modules/ms_deform_attn.py:69-85) while
+// it stages the block's chunk in LDS:
+//     attn = softmax_{l,p}(logits[q, m, :])
+//     loc  = ref[q, l, :2] + off[q, m, l, p, :] / (H_l, W_l)                      (ref_dim == 2; the divisor
+//                                                  pairs x with H_l and y with W_l exactly as the reference)
+//     loc  = ref[q, l, :2] + off[q, m, l, p, :] / P * ref[q, l, 2:] * 0.5          (ref_dim == 4)
+// which removes the softmax, division, multiply and add kernels (and their ~100 MB of traffic per
+// encoder layer) that the reference runs between the projection GEMM and the operator.
+struct FusedArgs {
+    const float *ref;     // [N, Lq, L, ref_dim]
+    const float *qproj;   // [N*Lq, ld]: per query, M*L*P*2 raw offsets at off_col, M*L*P logits at logit_col
+    int ref_dim, ld, off_col, logit_col;
+};
+
+template <int PT, bool FUSED>
 __global__ void __launch_bounds__(kThreads)
 msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
                  const float *__restrict__ loc, const float *__restrict__ attn,
                  float *__restrict__ out, const LevelTable lt, const int64_t *__restrict__ dshapes,
-                 int S, int M, int D, int L, int Lq, long long total_pairs, int ppb, int DV)
+                 int S, int M, int D, int L, int Lq, long long total_pairs, int ppb, int DV,
+                 const FusedArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *s_tab = reinterpret_cast<int *>(smem);
@@ -267,9 +284,49 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
     const int npairs = (int)min((long long)ppb, total_pairs - pair0);
 
     fill_level_table(s_tab, lt, dshapes, L);
-    copy_in(s_loc, loc + pair0 * LP * 2, npairs * LP * 2);
-    copy_in(s_attn, attn + pair0 * LP, npairs * LP);
-    __syncthreads();
+    if constexpr (!FUSED) {
+        copy_in(s_loc, loc + pair0 * LP * 2, npairs * LP * 2);
+        copy_in(s_attn, attn + pair0 * LP, npairs * LP);
+        __syncthreads();
+    } else {
+        __syncthreads();   // level table visible
+        for (int sidx = threadIdx.x; sidx < npairs * LP; sidx += kThreads) {
+#pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
+            const int pp = sidx / LP, lp = sidx - pp * LP;
+            const int l = lp / PT;
+            const long long pr = pair0 + pp;
+            const long long bq = pr / M;
+            const int mm = (int)(pr - bq * M);
+            const float *row = fa.qproj + bq * fa.ld;
+            const float2 off = *reinterpret_cast<const float2 *>(row + fa.off_col + (mm * LP + lp) * 2);
+            const float *rp = fa.ref + (bq * L + l) * fa.ref_dim;
+            float x, y;
+            if (fa.ref_dim == 2) {
+                x = rp[0] + off.x / (float)s_tab[l];                           // x / H_l  (as written)
+                y = rp[1] + off.y / (float)s_tab[TF_MSDA_MAX_LEVELS + l];      // y / W_l
+            } else {
+                x = rp[0] + off.x / (float)PT * rp[2] * 0.5f;
+                y = rp[1] + off.y / (float)PT * rp[3] * 0.5f;
+            }
+            s_loc[2 * sidx] = x;
+            s_loc[2 * sidx + 1] = y;
+            s_attn[sidx] = row[fa.logit_col + mm * LP + lp];
+        }
+        __syncthreads();
+        for (int pp = threadIdx.x; pp < npairs; pp += kThreads) {   // softmax over the L*P logits
+            float *a = s_attn + (size_t)pp * LP;
+            float mx = a[0];
+            for (int i = 1; i < LP; ++i) mx = fmaxf(mx, a[i]);
+            float sum = 0.f;
+            for (int i = 0; i < LP; ++i) {
+                const float e = __expf(a[i] - mx);
+                a[i] = e;
+                sum += e;
+            }
+            for (int i = 0; i < LP; ++i) a[i] = a[i] / sum;
+        }
+        __syncthreads();
+    }
 
     const int pl = threadIdx.x / DV;
     const int dv = threadIdx.x - pl * DV;
@@ -903,12 +960,13 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                     return record_hip(e);
                 }
             }
-            const void *fn = P == 1   ? (const void *)&msda_fwd_f32_buf<1>
-                             : P == 2 ? (const void *)&msda_fwd_f32_buf<2>
-                             : P == 4 ? (const void *)&msda_fwd_f32_buf<4>
-                                      : (const void *)&msda_fwd_f32_buf<8>;
+            const void *fn = P == 1   ? (const void *)&msda_fwd_f32_buf<1, false>
+                             : P == 2 ? (const void *)&msda_fwd_f32_buf<2, false>
+                             : P == 4 ? (const void *)&msda_fwd_f32_buf<4, false>
+                                      : (const void *)&msda_fwd_f32_buf<8, false>;
+            const FusedArgs none{};
             e = launch(fn, pl.grid, pl.lds, stream, value, vbytes, loc, attn, out, lt, shapes_dev,
-                       S, M, D, L, Lq, total_pairs, pl.ppb, pl.DV);
+                       S, M, D, L, Lq, total_pairs, pl.ppb, pl.DV, none);
             return record_hip(e);
         }
     }
@@ -916,6 +974,43 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                                  : (const void *)&msda_fwd_rowgather<T, 1>;
     e = launch(fn, pl.grid, pl.lds, stream, value, loc, attn, out, lt, shapes_dev, S, M, D, L, Lq,
                P, total_pairs, pl.ppb, pl.DV);
+    return record_hip(e);
+}
+
+int forward_fused_impl(const float *value, const int64_t *shapes_host, const float *ref, int ref_dim,
+                       const float *qproj, int ld, int off_col, int logit_col, float *out, int N,
+                       int S, int M, int D, int L, int Lq, int P, void *stream_v)
+{
+    if (!value || !shapes_host || !ref || !qproj || !out) return TF_MSDA_ERR_NULL_POINTER;
+    if (N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0 ||
+        L > TF_MSDA_MAX_LEVELS || (ref_dim != 2 && ref_dim != 4))
+        return TF_MSDA_ERR_BAD_DIMS;
+    const int LP = L * P;
+    if (off_col < 0 || logit_col < 0 || (off_col & 1) || ld < off_col + M * LP * 2 ||
+        ld < logit_col + M * LP)
+        return TF_MSDA_ERR_BAD_DIMS;
+    if ((P != 1 && P != 2 && P != 4 && P != 8) || (D & 3)) return TF_MSDA_ERR_BAD_DIMS;
+    LevelTable lt{};
+    int rc = build_level_table(shapes_host, L, S, &lt);
+    if (rc != TF_MSDA_OK) return rc;
+    if (!is_aligned(value, 16) || !is_aligned(out, 16) || !is_aligned(qproj, 8) || (ld & 1) ||
+        !buf_path_ok(lt, true, N, S, M, D, L))
+        return TF_MSDA_ERR_BAD_DIMS;
+    Plan pl;
+    rc = make_plan<float>(N, M, D, L, Lq, P, 3, true, &pl);
+    if (rc != TF_MSDA_OK) return rc;
+    const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
+    const long long total_pairs = (long long)N * Lq * M;
+    const void *fn = P == 1   ? (const void *)&msda_fwd_f32_buf<1, true>
+                     : P == 2 ? (const void *)&msda_fwd_f32_buf<2, true>
+                     : P == 4 ? (const void *)&msda_fwd_f32_buf<4, true>
+                              : (const void *)&msda_fwd_f32_buf<8, true>;
+    const FusedArgs fa{ref, qproj, ref_dim, ld, off_col, logit_col};
+    const float *nul = nullptr;
+    const int64_t *nod = nullptr;
+    const hipError_t e = launch(fn, pl.grid, pl.lds, static_cast<hipStream_t>(stream_v), value,
+                                vbytes, nul, nul, out, lt, nod, S, M, D, L, Lq, total_pairs, pl.ppb,
+                                pl.DV, fa);
     return record_hip(e);
 }
 
@@ -987,6 +1082,15 @@ int tf_msda_set_tiled(int mode)
     const int prev = g_tiled_mode;
     g_tiled_mode = mode < 0 ? -1 : (mode ? 1 : 0);
     return prev;
+}
+
+int tf_msda_forward_fused_f32(const float *value, const int64_t *shapes_hw_host,
+                              const float *ref_points, int ref_dim, const float *qproj, int ld,
+                              int off_col, int logit_col, float *out, int N, int S, int M, int D,
+                              int L, int Lq, int P, void *stream)
+{
+    return forward_fused_impl(value, shapes_hw_host, ref_points, ref_dim, qproj, ld, off_col,
+                              logit_col, out, N, S, M, D, L, Lq, P, stream);
 }
 
 int tf_msda_forward_f32(const float *value, const int64_t *shapes_hw_host, const float *loc,

@@ -24,6 +24,11 @@ from torch.nn.init import constant_, xavier_uniform_
 
 from . import _cabi
 
+import os as _os
+
+# inference fast path of MSDeformAttn.forward (fused projections + fused operator prologue)
+FUSED_INFERENCE = _os.environ.get("TF_MSDA_FUSED", "1") != "0"
+
 _HOST_SHAPE_ATTR = "_tf_msda_host_shapes"
 _shape_array_cache = {}
 
@@ -158,6 +163,56 @@ def ms_deform_attn_backward(value, spatial_shapes, sampling_loc, attn_weight, gr
     return [grad_value, grad_loc, grad_attn]
 
 
+def ms_deform_attn_forward_fused(value, spatial_shapes, reference_points, qproj, n_heads, n_levels,
+                                 n_points):
+    """Inference-only fused operator: softmax + sampling-location arithmetic + sampling in one launch.
+
+    value [N,S,M,D]; reference_points [N,Lq,L,2|4]; qproj [N,Lq,3*M*L*P] = the query projected by the
+    concatenated (sampling_offsets | attention_weights) Linear.  Equivalent to
+    ms_deform_attn.py:69-86 followed by ms_deform_attn_forward; returns [N,Lq,M*D]."""
+    hs = _host_shapes_of(spatial_shapes)
+    if hs is None:
+        raise RuntimeError("ms_deform_attn_forward_fused needs host-side level shapes "
+                           "(attach_host_shapes)")
+    N, S, M, D = value.shape
+    Lq = qproj.shape[1]
+    L, P = n_levels, n_points
+    if M != n_heads or qproj.shape[-1] != 3 * M * L * P or reference_points.shape[:3] != (N, Lq, L):
+        raise RuntimeError("ms_deform_attn_forward_fused: inconsistent tensor shapes")
+    reference_points = reference_points.contiguous()
+    lib = _cabi.lib()
+    with torch.cuda.device(value.device):
+        out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
+        arr = _shape_array(hs)
+        rc = lib.tf_msda_forward_fused_f32(
+            value.data_ptr(), ctypes.cast(arr, ctypes.c_void_p), reference_points.data_ptr(),
+            reference_points.shape[-1], qproj.data_ptr(), qproj.shape[-1], 0, 2 * M * L * P,
+            out.data_ptr(), N, S, M, D, L, Lq, P, torch.cuda.current_stream().cuda_stream)
+    _cabi.check(rc, "ms_deform_attn_forward_fused")
+    return out
+
+
+class _CatProjection:
+    """(sampling_offsets | attention_weights) as ONE Linear: the two projections share their input, so
+    the inference path runs them as a single GEMM (refreshed when the parameters change)."""
+
+    def __init__(self):
+        self.key = None
+        self.weight = None
+        self.bias = None
+
+    def get(self, mod):
+        srcs = (mod.sampling_offsets.weight, mod.sampling_offsets.bias,
+                mod.attention_weights.weight, mod.attention_weights.bias)
+        key = tuple((t.data_ptr(), t._version, t.device, t.dtype) for t in srcs)
+        if key != self.key:
+            with torch.no_grad():
+                self.weight = torch.cat([srcs[0], srcs[2]], 0).contiguous()
+                self.bias = torch.cat([srcs[1], srcs[3]], 0).contiguous()
+            self.key = key
+        return self.weight, self.bias
+
+
 class MSDeformAttnFunction(Function):
     """Autograd wrapper; mirrors functions/ms_deform_attn_func.py:14-31."""
 
@@ -202,6 +257,7 @@ class MSDeformAttn(nn.Module):
         self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
+        self._cat_proj = _CatProjection()
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -243,6 +299,17 @@ class MSDeformAttn(nn.Module):
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
+
+        if (FUSED_INFERENCE and hs is not None and query_attn_mask is None and value.is_cuda
+                and value.dtype == torch.float32 and not self.training
+                and not torch.is_grad_enabled() and reference_points.shape[-1] in (2, 4)
+                and (self.d_model // M) % 4 == 0 and P in (1, 2, 4, 8)):
+            # inference: one GEMM for both query projections, prologue arithmetic inside the kernel
+            w, b = self._cat_proj.get(self)
+            qproj = F.linear(query, w, b)
+            output = ms_deform_attn_forward_fused(value, input_spatial_shapes, reference_points,
+                                                  qproj, M, L, P)
+            return self.output_proj(output)
 
         sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
         attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
