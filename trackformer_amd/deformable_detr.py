@@ -136,19 +136,32 @@ class DeformableDETR(DETR):
         hs, memory, init_reference, inter_references, enc_outputs_class, enc_outputs_coord_unact = \
             self.transformer(src_list, mask_list, pos_list, query_embeds, targets)
 
-        outputs_classes, outputs_coords = [], []
-        for lvl in range(hs.shape[0]):
-            reference = inverse_sigmoid(init_reference if lvl == 0 else inter_references[lvl - 1])
-            outputs_classes.append(self.class_embed[lvl](hs[lvl]))
-            tmp = self.bbox_embed[lvl](hs[lvl])
-            if reference.shape[-1] == 4:
-                tmp += reference
-            else:
-                assert reference.shape[-1] == 2
-                tmp[..., :2] += reference
-            outputs_coords.append(tmp.sigmoid())
-        outputs_class = torch.stack(outputs_classes)
-        outputs_coord = torch.stack(outputs_coords)
+        reuse_refinement = (self.with_box_refine and not self.two_stage and not self.training
+                            and not torch.is_grad_enabled()
+                            and inter_references.shape[0] == hs.shape[0])
+        if reuse_refinement:
+            # With iterative box refinement the decoder has already evaluated
+            # sigmoid(bbox_embed[l](hs[l]) + inverse_sigmoid(reference_l)) -- the very expression of
+            # the box head (deformable_transformer.py:412-422 vs deformable_detr.py:238-246, same
+            # modules, same inputs): the refined reference points ARE the per-layer box predictions.
+            outputs_coord = inter_references
+            outputs_class = torch.stack([self.class_embed[lvl](hs[lvl])
+                                         for lvl in range(hs.shape[0])])
+        else:
+            outputs_classes, outputs_coords = [], []
+            for lvl in range(hs.shape[0]):
+                reference = inverse_sigmoid(init_reference if lvl == 0
+                                            else inter_references[lvl - 1])
+                outputs_classes.append(self.class_embed[lvl](hs[lvl]))
+                tmp = self.bbox_embed[lvl](hs[lvl])
+                if reference.shape[-1] == 4:
+                    tmp += reference
+                else:
+                    assert reference.shape[-1] == 2
+                    tmp[..., :2] += reference
+                outputs_coords.append(tmp.sigmoid())
+            outputs_class = torch.stack(outputs_classes)
+            outputs_coord = torch.stack(outputs_coords)
 
         out = {'pred_logits': outputs_class[-1], 'pred_boxes': outputs_coord[-1],
                'hs_embed': hs[-1]}

@@ -28,6 +28,16 @@ def _inference(module) -> bool:
     return (not module.training) and (not torch.is_grad_enabled())
 
 
+def _ffn_hidden(linear, activation, x, inference):
+    """activation(linear(x)).  Inference on the GPU with ReLU: bias + ReLU run in the GEMM epilogue
+    (hipBLASLt) instead of a separate pass over the [tokens, d_ffn] activation."""
+    if inference and activation is F.relu and x.is_cuda and x.dtype == torch.float32:
+        x2 = x.reshape(-1, x.shape[-1])
+        y = torch._addmm_activation(linear.bias, x2, linear.weight.t(), use_gelu=False)
+        return y.view(*x.shape[:-1], y.shape[-1])
+    return activation(linear(x))
+
+
 def _get_clones(module, N):
     return nn.ModuleList([copy.deepcopy(module) for _ in range(N)])
 
@@ -285,8 +295,9 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, src):
-        src2 = self.linear2(self.dropout2(self.activation(self.linear1(src))))
-        return fused.residual_norm(src, self.dropout3(src2), self.norm2, _inference(self))
+        inf = _inference(self)
+        src2 = self.linear2(self.dropout2(_ffn_hidden(self.linear1, self.activation, src, inf)))
+        return fused.residual_norm(src, self.dropout3(src2), self.norm2, inf)
 
     def forward(self, src, pos, reference_points, spatial_shapes, padding_mask=None):
         src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
@@ -350,15 +361,35 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return tensor if pos is None else tensor + pos
 
     def forward_ffn(self, tgt):
-        tgt2 = self.linear2(self.dropout3(self.activation(self.linear1(tgt))))
-        return fused.residual_norm(tgt, self.dropout4(tgt2), self.norm3, _inference(self))
+        inf = _inference(self)
+        tgt2 = self.linear2(self.dropout3(_ffn_hidden(self.linear1, self.activation, tgt, inf)))
+        return fused.residual_norm(tgt, self.dropout4(tgt2), self.norm3, inf)
+
+    def _self_attention_inference(self, qk_in, v_in, key_padding_mask):
+        """nn.MultiheadAttention(q=k=qk_in, v=v_in) for batch-first inputs without materialising the
+        attention weights: one GEMM for the shared q/k input, one for v, fused SDPA, out_proj."""
+        mha = self.self_attn
+        E, H = mha.embed_dim, mha.num_heads
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        n, lq, _ = qk_in.shape
+        qk = F.linear(qk_in, w[:2 * E], b[:2 * E]).view(n, lq, 2, H, E // H)
+        v = F.linear(v_in, w[2 * E:], b[2 * E:]).view(n, lq, H, E // H)
+        q, k = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)      # [n, H, lq, d]
+        mask = None
+        if key_padding_mask is not None:
+            mask = ~key_padding_mask[:, None, None, :]                           # True = attend
+        o = F.scaled_dot_product_attention(q, k, v.transpose(1, 2), attn_mask=mask)
+        return mha.out_proj(o.transpose(1, 2).reshape(n, lq, E))
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes,
                 src_padding_mask=None, query_attn_mask=None):
         # self attention among the (track + object) queries
         q = k = self.with_pos_embed(tgt, query_pos)
-        tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
-                              key_padding_mask=query_attn_mask)[0].transpose(0, 1)
+        if _inference(self) and tgt.is_cuda and self.self_attn.in_proj_weight is not None:
+            tgt2 = self._self_attention_inference(q, tgt, query_attn_mask)
+        else:
+            tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
+                                  key_padding_mask=query_attn_mask)[0].transpose(0, 1)
         tgt = fused.residual_norm(tgt, self.dropout2(tgt2), self.norm2, _inference(self))
         # deformable cross attention into the encoder memory
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src,
