@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG_DIR, "lib", "libtf_msda.so")
+LIB_PATH = os.environ.get("TF_MSDA_LIB") or os.path.join(_PKG_DIR, "lib", "libtf_msda.so")
 
 # Every symbol include/tf_msda.h declares (tests/test_cabi.py checks the list against the header).
 EXPORTED_SYMBOLS = (

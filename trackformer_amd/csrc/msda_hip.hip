@@ -262,6 +262,7 @@ struct FusedArgs {
     const float *ref;     // [N, Lq, L, ref_dim]
     const float *qproj;   // [N*Lq, ld]: per query, M*L*P*2 raw offsets at off_col, M*L*P logits at logit_col
     int ref_dim, ld, off_col, logit_col;
+    int head_major;       // block -> pair mapping, see msda_fwd_f32_buf
 };
 
 template <int PT, bool FUSED>
@@ -278,15 +279,43 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
     float *s_loc = reinterpret_cast<float *>(smem + kLevelTableBytes);
     float *s_attn = s_loc + (size_t)ppb * LP * 2;
 
-    const long long lblk = logical_block((total_pairs + ppb - 1) / ppb);
-    if (lblk < 0) return;
-    const long long pair0 = lblk * ppb;
-    const int npairs = (int)min((long long)ppb, total_pairs - pair0);
+    // Block -> pairs.  head_major == 0: ppb consecutive pairs (all heads of a few queries), blocks in
+    // XCD-aware order.  head_major == 1: ppb consecutive QUERIES of ONE head, head = blockIdx % M: with
+    // M == 8 every XCD works on a single head, whose value rows (S*D*4 = 2.8 MB) fit its private L2.
+    long long pair0 = 0, q0 = 0;
+    int npairs = 0, head = 0;
+    const long long nlq = total_pairs / M;           // N * Lq
+    if (fa.head_major) {
+        head = blockIdx.x % M;
+        q0 = (long long)(blockIdx.x / M) * ppb;
+        if (q0 >= nlq) return;
+        npairs = (int)min((long long)ppb, nlq - q0);
+    } else {
+        const long long lblk = logical_block((total_pairs + ppb - 1) / ppb);
+        if (lblk < 0) return;
+        pair0 = lblk * ppb;
+        npairs = (int)min((long long)ppb, total_pairs - pair0);
+    }
+    auto pair_of = [&](int pp) -> long long {
+        return fa.head_major ? (q0 + pp) * M + head : pair0 + pp;
+    };
 
     fill_level_table(s_tab, lt, dshapes, L);
     if constexpr (!FUSED) {
-        copy_in(s_loc, loc + pair0 * LP * 2, npairs * LP * 2);
-        copy_in(s_attn, attn + pair0 * LP, npairs * LP);
+        if (fa.head_major) {
+            const int row = LP * 2;
+            for (int i = threadIdx.x; i < npairs * row; i += kThreads) {
+                const int pp = i / row, j = i - pp * row;
+                s_loc[i] = loc[pair_of(pp) * row + j];
+            }
+            for (int i = threadIdx.x; i < npairs * LP; i += kThreads) {
+                const int pp = i / LP, j = i - pp * LP;
+                s_attn[i] = attn[pair_of(pp) * LP + j];
+            }
+        } else {
+            copy_in(s_loc, loc + pair0 * LP * 2, npairs * LP * 2);
+            copy_in(s_attn, attn + pair0 * LP, npairs * LP);
+        }
         __syncthreads();
     } else {
         __syncthreads();   // level table visible
@@ -294,7 +323,7 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
 #pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
             const int pp = sidx / LP, lp = sidx - pp * LP;
             const int l = lp / PT;
-            const long long pr = pair0 + pp;
+            const long long pr = pair_of(pp);
             const long long bq = pr / M;
             const int mm = (int)(pr - bq * M);
             const float *row = fa.qproj + bq * fa.ld;
@@ -332,7 +361,7 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
     const int dv = threadIdx.x - pl * DV;
     if (pl >= npairs) return;
 
-    const long long pair = pair0 + pl;  // (b*Lq + q)*M + m
+    const long long pair = pair_of(pl);  // (b*Lq + q)*M + m
     const int m = (int)(pair % M);
     const int b = (int)((pair / M) / Lq);
     const unsigned rowbytes = (unsigned)(M * D) * 4u;                                // < 2^24
@@ -657,6 +686,12 @@ msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
 // ---------------------------------------------------------------------------------------------
 // backward (grad_value via atomics, grad_loc / grad_attn via wave reduction), fused
 // ---------------------------------------------------------------------------------------------
+#ifdef TF_EXPERIMENT_WG_SCOPE_ATOMICS
+#define ATOMIC_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+#else
+#define ATOMIC_ADD(p, v) unsafeAtomicAdd((p), (v))
+#endif
+
 template <typename T, int VEC, bool POW2>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
@@ -735,10 +770,10 @@ msda_bwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
                     dx = fma_t(gc, t.gy * (a2 - a1) + t.fy * (a4 - a3), dx);          // cuh:150-160
                     dy = fma_t(gc, t.gx * (a3 - a1) + t.fx * (a4 - a2), dy);          // cuh:139-149
                     const T top = gc * a;                                             // cuh:279
-                    if (t.k1) unsafeAtomicAdd(gvl + e1 + c, w1 * top);                // cuh:296-301
-                    if (t.k2) unsafeAtomicAdd(gvl + e2 + c, w2 * top);
-                    if (t.k3) unsafeAtomicAdd(gvl + e3 + c, w3 * top);
-                    if (t.k4) unsafeAtomicAdd(gvl + e4 + c, w4 * top);
+                    if (t.k1) ATOMIC_ADD(gvl + e1 + c, w1 * top);                // cuh:296-301
+                    if (t.k2) ATOMIC_ADD(gvl + e2 + c, w2 * top);
+                    if (t.k3) ATOMIC_ADD(gvl + e3 + c, w3 * top);
+                    if (t.k4) ATOMIC_ADD(gvl + e4 + c, w4 * top);
                 }
                 dx *= a * (T)W;  // cuh:371,373
                 dy *= a * (T)H;  // cuh:371,374
@@ -764,6 +799,153 @@ msda_bwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
     __syncthreads();
     copy_out(grad_loc + pair0 * LP * 2, s_gloc, npairs * LP * 2);
     copy_out(grad_attn + pair0 * LP, s_gattn, npairs * LP);
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward, fp32 fast path: buffer loads + buffer atomics with hardware bounds checking
+// ---------------------------------------------------------------------------------------------
+// Same pair / lane mapping as msda_fwd_f32_buf (head-major blocks).  Per sampling point a lane group
+//   * loads the 4 taps with buffer_load_dwordx4 (invalid taps: out-of-range offset -> 0),
+//   * forms its share of d(out)/d(attn), d(out)/d(x), d(out)/d(y) over its 4 channels and reduces
+//     them over the D/4 lanes of the pair with an xor butterfly (the reference loops serially over
+//     the channels, cuh:356-372),
+//   * scatters grad_value with buffer_atomic_add_f32: invalid taps get an out-of-range offset and
+//     are DROPPED by the hardware, so there is no divergent code around the 16 atomics of a point;
+//     for the atomics lane dv owns channels dv, dv+DV, dv+2DV, dv+3DV, so that one atomic
+//     instruction touches D/4 consecutive floats of each row instead of every fourth float.
+template <int PT>
+__global__ void __launch_bounds__(kThreads)
+msda_bwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
+                 const float *__restrict__ loc, const float *__restrict__ attn,
+                 const float *__restrict__ grad_out, float *__restrict__ grad_value,
+                 float *__restrict__ grad_loc, float *__restrict__ grad_attn, const LevelTable lt,
+                 const int64_t *__restrict__ dshapes, int S, int M, int D, int L, int Lq,
+                 long long total_pairs, int ppb, int DV)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *s_tab = reinterpret_cast<int *>(smem);
+    const int LP = L * PT;
+    float *s_loc = reinterpret_cast<float *>(smem + kLevelTableBytes);
+    float *s_attn = s_loc + (size_t)ppb * LP * 2;
+    float *s_gloc = s_attn + (size_t)ppb * LP;
+    float *s_gattn = s_gloc + (size_t)ppb * LP * 2;
+
+    const long long nlq = total_pairs / M;
+    const int head = blockIdx.x % M;
+    const long long q0 = (long long)(blockIdx.x / M) * ppb;
+    if (q0 >= nlq) return;
+    const int npairs = (int)min((long long)ppb, nlq - q0);
+    auto pair_of = [&](int pp) -> long long { return (q0 + pp) * M + head; };
+
+    fill_level_table(s_tab, lt, dshapes, L);
+    {
+        const int row = LP * 2;
+        for (int i = threadIdx.x; i < npairs * row; i += kThreads) {
+            const int pp = i / row, j = i - pp * row;
+            s_loc[i] = loc[pair_of(pp) * row + j];
+        }
+        for (int i = threadIdx.x; i < npairs * LP; i += kThreads) {
+            const int pp = i / LP, j = i - pp * LP;
+            s_attn[i] = attn[pair_of(pp) * LP + j];
+        }
+    }
+    __syncthreads();
+
+    const int pl = threadIdx.x / DV;
+    const int dv = threadIdx.x - pl * DV;
+    if (pl < npairs) {
+        const long long pair = pair_of(pl);
+        const int b = (int)((pair / M) / Lq);
+        const unsigned rowbytes = (unsigned)(M * D) * 4u;
+        const unsigned head_base = (unsigned)((((long long)b * S * M + head) * D) * 4);
+        const __amdgpu_buffer_rsrc_t rsrc_v =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, value_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_g =
+            __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, value_bytes, 0x00020000);
+        const float2 *sl = reinterpret_cast<const float2 *>(s_loc + (size_t)pl * LP * 2);
+        const float *sa = s_attn + (size_t)pl * LP;
+        float *sgl = s_gloc + (size_t)pl * LP * 2;
+        float *sga = s_gattn + (size_t)pl * LP;
+
+        const float *go = grad_out + pair * D;
+        const f32x4_t gA = *reinterpret_cast<const f32x4_t *>(go + dv * 4);   // channels 4dv..4dv+3
+        float gB[4];                                                           // channels dv + c*DV
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gB[c] = go[dv + c * DV];
+
+        for (int l = 0; l < L; ++l) {
+            const int H = s_tab[l], W = s_tab[TF_MSDA_MAX_LEVELS + l];
+            const unsigned lvl_base = head_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + l] * rowbytes;
+            const float Wf = (float)W, Hf = (float)H;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int s = l * PT + p;
+                const float2 xy = sl[s];
+                const float a = sa[s];
+                const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);   // cuh:350-351
+                const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
+                const bool in = (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);  // cuh:359
+                const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+                const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+                const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+                const int x0 = (int)xf, y0 = (int)yf;
+                const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
+                const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
+                const int r0 = y0 * W + x0;
+                const bool k1 = ky0 && kx0, k2 = ky0 && kx1, k3 = ky1 && kx0, k4 = ky1 && kx1;
+                const unsigned t1 = lvl_base + (unsigned)r0 * rowbytes;        // row byte offsets
+                const unsigned t2 = t1 + rowbytes;
+                const unsigned t3 = t1 + (unsigned)W * rowbytes;
+                const unsigned t4 = t3 + rowbytes;
+                const unsigned la = (unsigned)dv * 16u;
+                const f32x4_t v1 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k1 ? t1 + la : kOobOffset, 0, 0));
+                const f32x4_t v2 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k2 ? t2 + la : kOobOffset, 0, 0));
+                const f32x4_t v3 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k3 ? t3 + la : kOobOffset, 0, 0));
+                const f32x4_t v4 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k4 ? t4 + la : kOobOffset, 0, 0));
+                const float w1 = gy * gx, w2 = gy * fx, w3 = fy * gx, w4 = fy * fx;
+                // grad wrt value: cuh:279,296-301 with the weights of cuh:84-93
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned lb = (unsigned)(dv + c * DV) * 4u;
+                    const float top = gB[c] * a;
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w1 * top, rsrc_g, k1 ? t1 + lb : kOobOffset, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w2 * top, rsrc_g, k2 ? t2 + lb : kOobOffset, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w3 * top, rsrc_g, k3 ? t3 + lb : kOobOffset, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w4 * top, rsrc_g, k4 ? t4 + lb : kOobOffset, 0, 0);
+                }
+                // grad wrt attention weight / location: partial sums over this lane's 4 channels
+                const f32x4_t smp = v1 * w1 + v2 * w2 + v3 * w3 + v4 * w4;             // cuh:365
+                const f32x4_t ddx = (v2 - v1) * gy + (v4 - v3) * fy;                   // cuh:150-160
+                const f32x4_t ddy = (v3 - v1) * gx + (v4 - v2) * fx;                   // cuh:139-149
+                const f32x4_t pd = gA * smp, px = gA * ddx, py = gA * ddy;
+                float dot = (pd.x + pd.y) + (pd.z + pd.w);
+                float dx = (px.x + px.y) + (px.z + px.w);
+                float dy = (py.x + py.y) + (py.z + py.w);
+                for (int off = DV >> 1; off > 0; off >>= 1) {
+                    dot += __shfl_xor(dot, off);
+                    dx += __shfl_xor(dx, off);
+                    dy += __shfl_xor(dy, off);
+                }
+                if (dv == 0) {
+                    sgl[2 * s] = dx * a * Wf;       // cuh:371,373
+                    sgl[2 * s + 1] = dy * a * Hf;   // cuh:371,374
+                    sga[s] = dot;                   // cuh:376
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int row = LP * 2;
+        for (int i = threadIdx.x; i < npairs * row; i += kThreads) {
+            const int pp = i / row, j = i - pp * row;
+            grad_loc[pair_of(pp) * row + j] = s_gloc[i];
+        }
+        for (int i = threadIdx.x; i < npairs * LP; i += kThreads) {
+            const int pp = i / LP, j = i - pp * LP;
+            grad_attn[pair_of(pp) * LP + j] = s_gattn[i];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -831,6 +1013,18 @@ int make_plan(int N, int M, int D, int L, int Lq, int P, int lds_elems_per_sampl
 }
 
 bool is_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Block -> pair mapping of the buffer-load forward kernel (TF_MSDA_HEAD_MAJOR=0/1, default 1).
+bool head_major_enabled()
+{
+    static const int on = [] { const char *e = getenv("TF_MSDA_HEAD_MAJOR"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+unsigned head_major_grid(int N, int Lq, int M, int ppb)
+{
+    const long long chunks = ((long long)N * Lq + ppb - 1) / ppb;
+    return (unsigned)(chunks * M);
+}
 
 // fp32 fast path eligibility: everything addressable with 32-bit byte offsets / 24-bit multiplies.
 bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, int D, int L)
@@ -964,8 +1158,10 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                              : P == 2 ? (const void *)&msda_fwd_f32_buf<2, false>
                              : P == 4 ? (const void *)&msda_fwd_f32_buf<4, false>
                                       : (const void *)&msda_fwd_f32_buf<8, false>;
-            const FusedArgs none{};
-            e = launch(fn, pl.grid, pl.lds, stream, value, vbytes, loc, attn, out, lt, shapes_dev,
+            FusedArgs none{};
+            none.head_major = head_major_enabled() ? 1 : 0;
+            const unsigned grid = none.head_major ? head_major_grid(N, Lq, M, pl.ppb) : pl.grid;
+            e = launch(fn, grid, pl.lds, stream, value, vbytes, loc, attn, out, lt, shapes_dev,
                        S, M, D, L, Lq, total_pairs, pl.ppb, pl.DV, none);
             return record_hip(e);
         }
@@ -1005,10 +1201,12 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
                      : P == 2 ? (const void *)&msda_fwd_f32_buf<2, true>
                      : P == 4 ? (const void *)&msda_fwd_f32_buf<4, true>
                               : (const void *)&msda_fwd_f32_buf<8, true>;
-    const FusedArgs fa{ref, qproj, ref_dim, ld, off_col, logit_col};
+    const int hm = head_major_enabled() ? 1 : 0;
+    const FusedArgs fa{ref, qproj, ref_dim, ld, off_col, logit_col, hm};
     const float *nul = nullptr;
     const int64_t *nod = nullptr;
-    const hipError_t e = launch(fn, pl.grid, pl.lds, static_cast<hipStream_t>(stream_v), value,
+    const unsigned grid = hm ? head_major_grid(N, Lq, M, pl.ppb) : pl.grid;
+    const hipError_t e = launch(fn, grid, pl.lds, static_cast<hipStream_t>(stream_v), value,
                                 vbytes, nul, nul, out, lt, nod, S, M, D, L, Lq, total_pairs, pl.ppb,
                                 pl.DV, fa);
     return record_hip(e);
@@ -1040,6 +1238,21 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
     if (rc != TF_MSDA_OK) return rc;
     const long long total_pairs = (long long)N * Lq * M;
     const bool pow2 = (pl.DV & (pl.DV - 1)) == 0 && pl.DV <= 64;
+    if constexpr (sizeof(T) == 4) {
+        if (pl.vec == 4 && pow2 && (P == 1 || P == 2 || P == 4 || P == 8) &&
+            buf_path_ok(lt, shapes_host != nullptr, N, S, M, D, L) && is_aligned(grad_value, 16)) {
+            const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
+            const void *bfn = P == 1   ? (const void *)&msda_bwd_f32_buf<1>
+                              : P == 2 ? (const void *)&msda_bwd_f32_buf<2>
+                              : P == 4 ? (const void *)&msda_bwd_f32_buf<4>
+                                       : (const void *)&msda_bwd_f32_buf<8>;
+            const hipError_t be = launch(bfn, head_major_grid(N, Lq, M, pl.ppb), pl.lds, stream,
+                                         value, vbytes, loc, attn, grad_out, grad_value, grad_loc,
+                                         grad_attn, lt, shapes_dev, S, M, D, L, Lq, total_pairs,
+                                         pl.ppb, pl.DV);
+            return record_hip(be);
+        }
+    }
     const void *fn;
     if (pl.vec == 4)
         fn = pow2 ? (const void *)&msda_bwd_rowgather<T, 4, true>
