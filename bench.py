@@ -46,8 +46,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--no-graph", action="store_true", help="run the detector eagerly (no HIP graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -158,9 +158,17 @@ def measure_roofline(device, launches=50):
     us = start.elapsed_time(end) * 1e3 / launches
     alg = algorithmic_bytes(**dims)
     achieved = alg / (us * 1e-6) / 1e9
-    return {"bound": "hbm", "kernel": "msda_fwd_f32_buf<4> (encoder shape, Lq=S=22223)",
+    # HBM traffic of the same kernel/shape from the PMC counters: collected offline (rocprofv3 --pmc
+    # needs its own passes) and committed together with the method; see the file's "_how"
+    traffic = None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_msda_traffic.json")) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return {"bound": "hbm", "kernel": "msda_fwd_f32_buf<4,false> (encoder shape, Lq=S=22223)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": alg, "avg_launch_us": round(us, 2), "launches": launches}
 
 
