@@ -60,6 +60,19 @@ def main():
         print("%-28s logits%s boxes%s  -> %s (%d KB)" % (case, fix['pred_logits'].shape,
               fix['pred_boxes'].shape, os.path.basename(path), os.path.getsize(path) // 1024))
 
+    # one training step (cfg 3 path): losses and gradient norms of the reference on CPU
+    model, criterion, args = um.build_train(ref.models.build_model, config.make_args)
+    samples, targets = um.train_batch()
+    loss_dict, total, grads = um.train_step(model, criterion, samples, targets)
+    path = os.path.join(HERE, "train_cfg3_small.npz")
+    np.savez_compressed(path, loss_keys=np.array(sorted(loss_dict)),
+                        loss_vals=np.array([loss_dict[k] for k in sorted(loss_dict)]),
+                        total=np.float64(total), grad_keys=np.array(um.TRAIN_GRAD_KEYS),
+                        grad_norms=np.array([grads[k] for k in um.TRAIN_GRAD_KEYS]),
+                        num_grads=np.int64(len(grads)))
+    print("train step: total loss %.6f, %d losses, %d params with grad -> %s" % (
+        total, len(loss_dict), len(grads), os.path.basename(path)))
+
     # tracker sequence
     model, post, args = um.build("cfg2_deformable_tracking", ref.models.build_model,
                                  config.make_args)

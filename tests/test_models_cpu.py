@@ -135,3 +135,30 @@ def test_product_model_refuses_cpu_operator():
     model.tracking()
     with torch.no_grad(), pytest.raises(RuntimeError, match="Not implemented on the CPU"):
         model(torch.zeros(1, 3, 64, 64), None, None)
+
+
+# ------------------------------------------------------------------ one training step (cfg 3 path)
+def run_train_step(device="cpu"):
+    model, criterion, args = um.build_train(factory.build_model, config.make_args, device=device)
+    model.to(device)
+    criterion.to(device)
+    samples, targets = um.train_batch(device=device)
+    return um.train_step(model, criterion, samples, targets)
+
+
+def compare_train_to_golden(loss_dict, total, grads, rtol):
+    z = np.load(os.path.join(GOLDEN, "train_cfg3_small.npz"))
+    assert sorted(loss_dict) == z["loss_keys"].tolist()
+    got = np.array([loss_dict[k] for k in sorted(loss_dict)])
+    np.testing.assert_allclose(got, z["loss_vals"], rtol=rtol, atol=rtol)
+    assert abs(total - float(z["total"])) <= rtol * abs(float(z["total"]))
+    assert len(grads) == int(z["num_grads"])
+    gn = np.array([grads[k] for k in z["grad_keys"].tolist()])
+    np.testing.assert_allclose(gn, z["grad_norms"], rtol=max(rtol, 2e-3), atol=1e-6)
+
+
+def test_training_step_matches_reference(oracle_op):
+    """forward (padded batch, track-query augmentation, prev-frame pass) + SetCriterion + backward
+    through MSDeformAttnFunction.backward; losses and gradient norms vs the reference on CPU."""
+    loss_dict, total, grads = run_train_step()
+    compare_train_to_golden(loss_dict, total, grads, rtol=2e-4)

@@ -55,3 +55,69 @@ def to_device(target, device):
     if target is None:
         return None
     return [{k: v.to(device) for k, v in t.items()} for t in target]
+
+
+# ---------------------------------------------------------------------------------- training (cfg 3)
+TRAIN_OVERRIDES = dict(dropout=0.0, num_queries=40, enc_layers=2, dec_layers=3)
+
+
+def build_train(build_model_fn, make_args_fn, device="cpu", seed=42, weight_seed=2):
+    args = make_args_fn("deformable", "tracking", "mot17", device=str(device), **TRAIN_OVERRIDES)
+    torch.manual_seed(seed)
+    model, criterion, post = build_model_fn(args)
+    perturb_state_dict(model, weight_seed)
+    return model, criterion, args
+
+
+def train_batch(seed=9, device="cpu"):
+    """Two differently sized images (padding masks, valid ratios < 1) with previous-frame targets."""
+    g = torch.Generator().manual_seed(seed)
+    samples, targets = [], []
+    for i, (h, w) in enumerate([(128, 160), (112, 144)]):
+        img = torch.randn(3, h, w, generator=g)
+        n = 5 + i
+        cxcy = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+        wh = torch.rand(n, 2, generator=g) * 0.2 + 0.05
+        boxes = torch.cat([cxcy, wh], 1)
+        prev_boxes = (boxes + 0.01 * torch.randn(n, 4, generator=g)).clamp(0.02, 0.98)
+        ids = torch.arange(n) + 10 * i
+        prev_keep = torch.arange(n) != 1          # one object is new in the current frame
+        t = {'boxes': boxes.to(device), 'labels': torch.zeros(n, dtype=torch.long, device=device),
+             'track_ids': ids.to(device), 'image_id': torch.tensor([i], device=device),
+             'prev_image': (img + 0.05 * torch.randn(3, h, w, generator=g)).to(device),
+             'prev_target': {'boxes': prev_boxes[prev_keep].to(device),
+                             'labels': torch.zeros(int(prev_keep.sum()), dtype=torch.long,
+                                                   device=device),
+                             'track_ids': ids[prev_keep].to(device),
+                             'image_id': torch.tensor([i], device=device)}}
+        samples.append(img.to(device))
+        targets.append(t)
+    return samples, targets
+
+
+def train_step(model, criterion, samples, targets, rng_seed=7):
+    """One forward + loss + backward exactly as engine.py:126-148 does it (without the optimiser)."""
+    model.train()
+    criterion.train()
+    model.zero_grad()
+    torch.manual_seed(rng_seed)      # host RNG of the track-query augmentation
+    outputs, targets, *_ = model(samples, targets)
+    loss_dict = criterion(outputs, targets)
+    weight_dict = criterion.weight_dict
+    losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+    losses.backward()
+    grads = {n: float(p.grad.detach().double().norm()) for n, p in model.named_parameters()
+             if p.grad is not None}
+    return {k: float(v) for k, v in loss_dict.items()}, float(losses), grads
+
+
+TRAIN_GRAD_KEYS = [
+    "transformer.encoder.layers.0.self_attn.sampling_offsets.weight",
+    "transformer.encoder.layers.0.self_attn.value_proj.weight",
+    "transformer.encoder.layers.1.self_attn.attention_weights.bias",
+    "transformer.decoder.layers.0.cross_attn.sampling_offsets.bias",
+    "transformer.decoder.layers.2.cross_attn.output_proj.weight",
+    "transformer.level_embed", "input_proj.0.0.weight", "input_proj.3.0.weight",
+    "backbone.0.body.layer2.0.conv1.weight", "backbone.0.body.layer4.2.conv3.weight",
+    "class_embed.2.weight", "transformer.decoder.bbox_embed.0.layers.2.weight", "query_embed.weight",
+]

@@ -43,7 +43,10 @@ def add_track_queries_to_targets(targets, prev_indices, prev_out, add_false_pos=
         target['track_query_match_ids'] = match_matrix.nonzero()[:, 1]
 
         if add_false_pos:
-            prev_boxes_matched = prev_out['pred_boxes'][i, prev_out_ind[target_ind_matching]]
+            # (the matcher's indices live on the host, the id comparison on the device: PyTorch >= 1.8
+            # no longer mixes them implicitly as the reference's line 97 relies on)
+            prev_boxes_matched = prev_out['pred_boxes'][
+                i, prev_out_ind[target_ind_matching.to(prev_out_ind.device)]]
             free = torch.ones(num_prev_queries, dtype=torch.bool)
             free[prev_out_ind.cpu()] = False
             not_prev_out_ind = free.nonzero()[:, 0].tolist()
