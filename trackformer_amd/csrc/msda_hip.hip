@@ -247,6 +247,7 @@ msda_fwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobOffset = 0xFFFFFFF0u;  // >= num_records for every supported tensor
+constexpr unsigned kOobBase = 0xFFFFFF00u;    // ... and so is kOobBase + (lane slice offset < 0xF0)
 
 // Optional fused prologue (FUSED = true): instead of reading finished sampling locations and softmaxed
 // attention weights, the kernel takes the raw outputs of the query projections and the reference
@@ -263,6 +264,7 @@ struct FusedArgs {
     const float *qproj;   // [N*Lq, ld]: per query, M*L*P*2 raw offsets at off_col, M*L*P logits at logit_col
     int ref_dim, ld, off_col, logit_col;
     int head_major;       // block -> pair mapping, see msda_fwd_f32_buf
+    int debug;            // timing experiments only (wrong results), TF_MSDA_BUF_DEBUG
 };
 
 template <int PT, bool FUSED>
@@ -372,6 +374,71 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
     const float *sa = s_attn + (size_t)pl * LP;
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    if (fa.debug == 4) {   // timing experiment: prologue + store only
+        acc.x = sl[0].x + sa[0];
+    } else if (PT == 4 && DV == 8) {
+        // Shared tap arithmetic.  The 8 lanes of a pair need the same 4 offsets + 4 weights for each
+        // sampling point; instead of all 8 computing all of them, lane j computes ONE point per two
+        // levels (lanes 0-3: the 4 points of level l, lanes 4-7: those of level l+1) and the group
+        // exchanges the results with ds_bpermute -- the instruction count per wave halves, and this
+        // kernel is instruction-issue bound (profiles/r01_msda_fwd_pmc_counters.json).
+        const int sub = dv & 3, which = dv >> 2;
+        const int group = (threadIdx.x & 63) & ~7;
+        const unsigned dvb = (unsigned)dv * 16u;
+        const unsigned head_base = lane_base - dvb;
+        for (int l0 = 0; l0 < L; l0 += 2) {
+            const int ml = l0 + which;
+            const bool have = ml < L;
+            const int mlc = have ? ml : l0;
+            const int H = s_tab[mlc], W = s_tab[TF_MSDA_MAX_LEVELS + mlc];
+            const unsigned lvl_base = head_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + mlc] * rowbytes;
+            const float Wf = (float)W, Hf = (float)H;
+            const float2 xy = sl[mlc * 4 + sub];
+            const float a = have ? sa[mlc * 4 + sub] : 0.f;
+            const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);   // cuh:227-228, single rounding
+            const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
+            const bool in = have && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);  // cuh:229
+            const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+            const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+            const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+            const int x0 = (int)xf, y0 = (int)yf;
+            const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
+            const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
+            const int r0 = y0 * W + x0;
+            // invalid taps: kOobBase + dv*16 (<= 0xFFFFFFF0) is still out of range -> hardware zero
+            unsigned po[4];
+            po[0] = (ky0 && kx0) ? lvl_base + (unsigned)r0 * rowbytes : kOobBase;
+            po[1] = (ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase;
+            po[2] = (ky1 && kx0) ? lvl_base + (unsigned)(r0 + W) * rowbytes : kOobBase;
+            po[3] = (ky1 && kx1) ? lvl_base + (unsigned)(r0 + W + 1) * rowbytes : kOobBase;
+            float pw[4] = {gy * gx * a, gy * fx * a, fy * gx * a, fy * fx * a};
+#pragma unroll
+            for (int ll = 0; ll < 2; ++ll) {
+                if (l0 + ll >= L) break;                     // uniform
+                u32x4_t v[4][4];
+                float w[4][4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int src = group + ll * 4 + p;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        unsigned o = (unsigned)__shfl((int)po[t], src) + dvb;
+                        if (fa.debug == 1) o = dvb;                       // timing experiment: 100 % L1 hits
+                        if (fa.debug == 2) o = (o & 0x3FFFFu) + dvb;      // timing experiment: 256 KB footprint
+                        w[p][t] = __shfl(pw[t], src);
+                        if (fa.debug == 3) { v[p][t] = u32x4_t{o, o, o, o}; continue; }   // no loads at all
+                        v[p][t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc += __builtin_bit_cast(f32x4_t, v[p][t]) * w[p][t];
+                }
+            }
+        }
+    } else {
     for (int l = 0; l < L; ++l) {
         const int H = s_tab[l], W = s_tab[TF_MSDA_MAX_LEVELS + l];
         const unsigned lvl_base = lane_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + l] * rowbytes;
@@ -413,7 +480,181 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
                 acc += __builtin_bit_cast(f32x4_t, v[p][t]) * w[p][t];
         }
     }
+    }
     *reinterpret_cast<f32x4_t *>(out + pair * D + dv * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, fp32, D == 32, P == 4, L <= 8: register-only kernel (no LDS staging, no barriers after the
+// level table) with the tap arithmetic shared through DPP broadcasts
+// ---------------------------------------------------------------------------------------------
+// Ablations of msda_fwd_f32_buf at the cfg-2 encoder shape (64 us) showed where its time goes: ~22 us in
+// the prologue (loc/attn chunk -> LDS, barriers: every workgroup first waits a full memory round trip)
+// plus the store, ~31 us of VALU work that all 8 lanes of a pair repeat (tap arithmetic), and only
+// ~9 us for the 64 row gathers per pair, which hide behind the rest.  This kernel therefore
+//   * has every lane fetch just the two sampling points it is responsible for straight into
+//     registers at kernel entry (independent loads, nothing to wait for before issuing the gathers
+//     of other waves; no LDS round trip),
+//   * computes the tap arithmetic of a point ONCE per pair: per pair of levels, lanes 0-3 of the
+//     8-lane group take the 4 points of level l, lanes 4-7 those of level l+1, and the group
+//     exchanges the 4 offsets + 4 weights of each point with DPP row broadcasts (v_mov_b32_dpp
+//     row_newbcast + bank masks: VALU-only, the LDS pipe stays idle),
+//   * optionally (FUSED) performs MSDeformAttn.forward's softmax and sampling-location arithmetic
+//     on the fly (softmax statistics by xor butterflies over the 8 lanes).
+template <int K>
+__device__ __forceinline__ int bcast8_i(int v)
+{
+    // lanes 0-7 of each 16-lane row read lane K, lanes 8-15 read lane 8+K (bank = 4 lanes)
+    int r = __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xF, 0x3, false);
+    return __builtin_amdgcn_update_dpp(r, v, 0x150 + 8 + K, 0xF, 0xC, false);
+}
+template <int K>
+__device__ __forceinline__ float bcast8_f(float v)
+{
+    return __builtin_bit_cast(float, bcast8_i<K>(__builtin_bit_cast(int, v)));
+}
+
+struct DirectArgs {
+    const float *value;
+    unsigned value_bytes;
+    const float *loc, *attn;   // plain operator inputs (FUSED == false)
+    float *out;
+    FusedArgs fa;              // FUSED == true
+    int S, M, L, Lq;
+    long long nlq;             // N * Lq
+};
+
+template <int LPAIRS, bool FUSED>   // LPAIRS = ceil(L / 2)
+__global__ void __launch_bounds__(kThreads)
+msda_fwd_f32_direct(const DirectArgs da, const LevelTable lt, const int64_t *__restrict__ dshapes)
+{
+    constexpr int PT = 4, D = 32, DV = 8;
+    __shared__ int s_tab[3 * TF_MSDA_MAX_LEVELS];
+    const int L = da.L, M = da.M, LP = L * PT;
+    fill_level_table(s_tab, lt, dshapes, L);
+
+    const int head = blockIdx.x % M;                                   // one head per XCD when M == 8
+    const long long bq = (long long)(blockIdx.x / M) * (kThreads / DV) + threadIdx.x / DV;
+    const int dv = threadIdx.x & 7, sub = dv & 3, which = dv >> 2;
+    const bool live = bq < da.nlq;
+    const long long bqc = live ? bq : 0;
+    const long long pair = bqc * M + head;
+    const int b = (int)(bqc / da.Lq);
+
+    // ---- this lane's sampling points: (level 2i + which, point sub) for i < LPAIRS -------------
+    float sx[LPAIRS], sy[LPAIRS], sa[LPAIRS];
+    bool have[LPAIRS];
+#pragma unroll
+    for (int i = 0; i < LPAIRS; ++i) {
+        const int ml = 2 * i + which;
+        have[i] = ml < L;
+        const int s = (have[i] ? ml : 0) * PT + sub;
+        if constexpr (!FUSED) {
+            const float2 xy = *reinterpret_cast<const float2 *>(da.loc + (pair * LP + s) * 2);
+            sx[i] = xy.x;
+            sy[i] = xy.y;
+            sa[i] = da.attn[pair * LP + s];
+        } else {
+            const float *row = da.fa.qproj + bqc * da.fa.ld;
+            const float2 off = *reinterpret_cast<const float2 *>(row + da.fa.off_col + (head * LP + s) * 2);
+            sx[i] = off.x;
+            sy[i] = off.y;
+            sa[i] = have[i] ? row[da.fa.logit_col + head * LP + s] : -__builtin_inff();
+        }
+    }
+    __syncthreads();   // level table (the only LDS use; no memory latency in front of it)
+
+    if constexpr (FUSED) {
+#pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
+        // softmax over the pair's L*P logits: this lane holds LPAIRS of them, the group the rest
+        float mx = sa[0];
+#pragma unroll
+        for (int i = 1; i < LPAIRS; ++i) mx = fmaxf(mx, sa[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        mx = fmaxf(mx, __shfl_xor(mx, 4));
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < LPAIRS; ++i) {
+            sa[i] = have[i] ? __expf(sa[i] - mx) : 0.f;
+            sum += sa[i];
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        sum += __shfl_xor(sum, 4);
+#pragma unroll
+        for (int i = 0; i < LPAIRS; ++i) {
+            sa[i] = sa[i] / sum;
+            const int ml = have[i] ? 2 * i + which : 0;
+            const float *rp = da.fa.ref + (bqc * L + ml) * da.fa.ref_dim;
+            if (da.fa.ref_dim == 2) {
+                sx[i] = rp[0] + sx[i] / (float)s_tab[ml];                         // x / H_l (as written)
+                sy[i] = rp[1] + sy[i] / (float)s_tab[TF_MSDA_MAX_LEVELS + ml];    // y / W_l
+            } else {
+                sx[i] = rp[0] + sx[i] / (float)PT * rp[2] * 0.5f;
+                sy[i] = rp[1] + sy[i] / (float)PT * rp[3] * 0.5f;
+            }
+        }
+    }
+
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;
+    const unsigned head_base = (unsigned)((((long long)b * da.S * M + head) * D) * 4);
+    const unsigned dvb = (unsigned)dv * 16u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(da.value), 0, da.value_bytes, 0x00020000);
+
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < LPAIRS; ++i) {
+        // produce: taps of this lane's point of the level pair (2i, 2i+1)
+        const int ml = have[i] ? 2 * i + which : 0;
+        const int H = s_tab[ml], W = s_tab[TF_MSDA_MAX_LEVELS + ml];
+        const unsigned lvl_base = head_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + ml] * rowbytes;
+        const float Wf = (float)W, Hf = (float)H;
+        const float xr = __builtin_fmaf(sx[i], Wf, -0.5f);   // cuh:227-228, single rounding
+        const float yr = __builtin_fmaf(sy[i], Hf, -0.5f);
+        const bool in = have[i] && live && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
+        const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+        const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+        const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+        const int x0 = (int)xf, y0 = (int)yf;
+        const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
+        const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
+        const int r0 = y0 * W + x0;
+        // invalid taps: kOobBase + dv*16 (<= 0xFFFFFFF0) is still out of range -> hardware zero
+        const int po0 = (int)((ky0 && kx0) ? lvl_base + (unsigned)r0 * rowbytes : kOobBase);
+        const int po1 = (int)((ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase);
+        const int po2 = (int)((ky1 && kx0) ? lvl_base + (unsigned)(r0 + W) * rowbytes : kOobBase);
+        const int po3 = (int)((ky1 && kx1) ? lvl_base + (unsigned)(r0 + W + 1) * rowbytes : kOobBase);
+        const float a = in ? sa[i] : 0.f;
+        const float pw0 = gy * gx * a, pw1 = gy * fx * a, pw2 = fy * gx * a, pw3 = fy * fx * a;
+
+        // consume: the 8 points of the level pair, produced by lanes 0..7 of the group
+        u32x4_t v[8][4];
+        float w[8][4];
+#define TF_CONSUME(K)                                                                              \
+        {                                                                                          \
+            w[K][0] = bcast8_f<K>(pw0);                                                            \
+            w[K][1] = bcast8_f<K>(pw1);                                                            \
+            w[K][2] = bcast8_f<K>(pw2);                                                            \
+            w[K][3] = bcast8_f<K>(pw3);                                                            \
+            v[K][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)bcast8_i<K>(po0) + dvb, 0, 0); \
+            v[K][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)bcast8_i<K>(po1) + dvb, 0, 0); \
+            v[K][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)bcast8_i<K>(po2) + dvb, 0, 0); \
+            v[K][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)bcast8_i<K>(po3) + dvb, 0, 0); \
+        }
+        TF_CONSUME(0) TF_CONSUME(1) TF_CONSUME(2) TF_CONSUME(3)
+        const bool second = 2 * i + 1 < L;   // uniform
+        if (second) { TF_CONSUME(4) TF_CONSUME(5) TF_CONSUME(6) TF_CONSUME(7) }
+#undef TF_CONSUME
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (k >= 4 && !second) break;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc += __builtin_bit_cast(f32x4_t, v[k][t]) * w[k][t];
+        }
+    }
+    if (live) *reinterpret_cast<f32x4_t *>(da.out + pair * D + dv * 4) = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,32 +668,32 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
 //     pixels together with the pixels of every other level whose centres fall into the same
 //     normalised rectangle (an exact partition of all S queries), for ONE head (blockIdx % M: with
 //     M == 8 each XCD serves one head, whose 2.8 MB of value rows stay in that XCD's 4 MiB L2);
-//   * ONE LANE = ONE (query, head) PAIR with all D channels in registers: the tap arithmetic is done
-//     once per sampling point (not once per 16-byte slice as in the row-gather kernels) and needs no
-//     cross-lane traffic; consecutive lanes are x-neighbours, so their taps are neighbouring rows;
-//   * walks the value levels; per level the tile's nominal window (tile extent mapped into the level
-//     plus a halo) is copied once, coalesced, into LDS with a row stride of an ODD number of 16-byte
-//     slots (144 B for D = 32), which makes ds_read_b128 of the same slice of 16 neighbouring rows
-//     conflict-free; the next level's window and sampling locations are requested before the current
-//     level is gathered, so their latency hides behind the gather;
+//   * gives each (query, head) pair to TWO lanes (even / odd 16-byte channel slices): the tap
+//     arithmetic is done twice per sampling point instead of D/4 times as in the row-gather kernels,
+//     and 8 wavefronts per CU keep every SIMD two-deep;
+//   * walks the value levels with two LDS windows: while level l is gathered from one window the
+//     tile's nominal window of level l+1 (tile extent mapped into the level plus a halo) streams into
+//     the other one by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no LDS store
+//     instructions).  Rows are stored with a stride of an ODD number of 16-byte slots (144 B for
+//     D = 32) so that ds_read_b128 of one slice of neighbouring rows is bank-conflict free;
 //   * taps outside the level read a zero row kept in LDS (zero padding with no selects); sampling
 //     points whose taps leave the staged window -- possible for any input, the window is only a
 //     guess -- take buffer loads under a wave-uniform branch.
 // Correctness never depends on the tile/window/halo heuristics (tests sweep adversarial inputs).
-constexpr int kV3Threads = 512;
-constexpr int kV3Waves = kV3Threads / 64;
-constexpr int kV3LinesPerWave = 3;     // window height  <= 8 * 3 lines
-constexpr int kV3ChunksPerLine = 5;    // window width x (D/4) <= 64 * 5 sixteen-byte chunks
+constexpr int kV4Threads = 512;
+constexpr int kV4Waves = kV4Threads / 64;
+constexpr int kV4Pairs = kV4Threads / 2;     // queries per tile (two lanes each)
 
 struct TileGeom {
     int TH, TW;        // tile size in level-0 pixels
     int HY, HX;        // window halo in pixels (every level)
     int tiles_y, tiles_x;
-    int max_wh, max_ww;  // window size limits (LDS capacity and register staging)
+    int cap_even, cap_odd;   // LDS window capacities in rows: even levels use buffer A, odd ones B
+    int debug;               // timing experiments only (wrong results): 1 = skip staging, 2 = skip gather
 };
 
 template <int PT, int NCH>   // NCH = D / 4 sixteen-byte channel slices per row
-__global__ void __launch_bounds__(kV3Threads)
+__global__ void __launch_bounds__(kV4Threads)
 msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
                    const float *__restrict__ loc, const float *__restrict__ attn,
                    float *__restrict__ out, const LevelTable lt,
@@ -461,12 +702,14 @@ msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
     constexpr int D = NCH * 4;
     constexpr int kSlots = (NCH % 2) ? NCH : NCH + 1;      // odd number of 16-byte slots per LDS row
     constexpr unsigned kStride = kSlots * 16u;             // LDS row stride in bytes
+    constexpr int kMine = (NCH + 1) / 2;                   // slices per lane (even lane gets the extra one)
+    static_assert(PT == 4, "tiled kernel is written for 4 sampling points per level");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start   (192 B)
     int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb | qoff(17)
     constexpr int kQInts = 5 * TF_MSDA_MAX_LEVELS + 4;             // 84 ints -> header = 528 B
     unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_q + kQInts);
-    // row 0 of s_rows is the zero row; the window starts at byte kStride
+    // s_rows: [zero row][window A: cap_even rows][window B: cap_odd rows], all with stride kStride
 
     const int m = blockIdx.x % M;
     int t = blockIdx.x / M;
@@ -518,12 +761,12 @@ msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
         s_q[4 * TF_MSDA_MAX_LEVELS + L] = acc;
     }
     __syncthreads();
-    const int nq = s_q[4 * TF_MSDA_MAX_LEVELS + L];   // <= kV3Threads (host computed the maximum)
+    const int nq = s_q[4 * TF_MSDA_MAX_LEVELS + L];   // <= kV4Pairs (host computed the maximum)
 
-    // this lane's query (tile-local index = thread index; level-major, row-major inside the tile)
+    // this lane's query (tile-local index = thread / 2; level-major, row-major inside the tile)
+    const int tq = threadIdx.x >> 1, half = threadIdx.x & 1;
     int q = -1;
-    if ((int)threadIdx.x < nq) {
-        const int tq = threadIdx.x;
+    if (tq < nq) {
         int l = 0;
         while (l + 1 < L && tq >= s_q[4 * TF_MSDA_MAX_LEVELS + l + 1]) ++l;
         const int r = tq - s_q[4 * TF_MSDA_MAX_LEVELS + l];
@@ -536,15 +779,15 @@ msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
     const float *lp_base = loc + pair * LP * 2;
     const float *ap_base = attn + pair * LP;
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const unsigned rowbytes = (unsigned)(M * D) * 4u;
     const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, value_bytes, 0x00020000);
 
     struct Geom {
-        int H, W, wy0, wx0, wy1, wx1, ww, wh;
-        unsigned lvl_base;
+        int H, W, wy0, wx0, wy1, wx1, ww, nrows;
+        unsigned lvl_base, win_off;   // win_off: byte offset of the level's window inside s_rows
     };
     auto level_geom = [&](int l) {
         Geom g;
@@ -557,74 +800,67 @@ msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
         g.wy0 = max(wy0, 0);
         g.wx0 = max(wx0, 0);
         wy1 = min(wy1, g.H - 1);
-        wx1 = min(wx1, g.W - 1);
-        g.ww = min(wx1 - g.wx0 + 1, tg.max_ww);
-        g.wh = min(wy1 - g.wy0 + 1, tg.max_wh);
-        g.wx1 = g.wx0 + g.ww - 1;
-        g.wy1 = g.wy0 + g.wh - 1;
+        g.wx1 = min(wx1, g.W - 1);
+        g.ww = g.wx1 - g.wx0 + 1;
+        const int cap = (l & 1) ? tg.cap_odd : tg.cap_even;
+        int wh = wy1 - g.wy0 + 1;
+        if (wh * g.ww > cap) wh = cap / g.ww;            // cap >= ww is ensured by the host
+        g.wy1 = g.wy0 + wh - 1;
+        g.nrows = wh * g.ww;
         g.lvl_base = head_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + l] * rowbytes;
+        g.win_off = kStride * (1u + ((l & 1) ? (unsigned)tg.cap_even : 0u));
         return g;
     };
 
-    // register staging: the window lines of this wave and this lane's sampling points, one level ahead
-    u32x4_t wreg[kV3LinesPerWave][kV3ChunksPerLine];
-    f32x4_t lxy0, lxy1, law;
-    auto issue_level_loads = [&](int l, const Geom &g) {
-#pragma unroll
-        for (int i = 0; i < kV3LinesPerWave; ++i) {
-            const int wy = wave + i * kV3Waves;
-            const unsigned line_base = g.lvl_base + (unsigned)((g.wy0 + wy) * g.W + g.wx0) * rowbytes;
-#pragma unroll
-            for (int j = 0; j < kV3ChunksPerLine; ++j) {
-                const int ch = lane + j * 64;
-                const int wx = ch / NCH, c = ch - wx * NCH;
-                const unsigned off = (wy < g.wh && wx < g.ww)
-                    ? line_base + (unsigned)wx * rowbytes + (unsigned)c * 16u : kOobOffset;
-                wreg[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-            }
-        }
-        lxy0 = *reinterpret_cast<const f32x4_t *>(lp_base + (size_t)l * PT * 2);
-        lxy1 = *reinterpret_cast<const f32x4_t *>(lp_base + (size_t)l * PT * 2 + 4);
-        law = *reinterpret_cast<const f32x4_t *>(ap_base + (size_t)l * PT);
-    };
-    auto commit_window = [&](const Geom &g) {
-#pragma unroll
-        for (int i = 0; i < kV3LinesPerWave; ++i) {
-            const int wy = wave + i * kV3Waves;
-#pragma unroll
-            for (int j = 0; j < kV3ChunksPerLine; ++j) {
-                const int ch = lane + j * 64;
-                const int wx = ch / NCH, c = ch - wx * NCH;
-                if (wy < g.wh && wx < g.ww)
-                    *reinterpret_cast<u32x4_t *>(s_rows + kStride +
-                        (unsigned)(wy * g.ww + wx) * kStride + (unsigned)c * 16u) = wreg[i][j];
-            }
+    // window of level l -> LDS by LDS-DMA: one wave-instruction moves 64 sixteen-byte slots (1 KiB of
+    // LDS, contiguous) gathered from 64 lane-supplied global offsets; padding slots and slots past
+    // the window get an out-of-range offset (the hardware writes zeros).
+    auto issue_window_dma = [&](const Geom &g) {
+        if (tg.debug == 1) return;
+        const int nslots = g.nrows * kSlots;
+        const float inv_ww = 1.0f / (float)g.ww;
+        for (int chunk = wave; chunk * 64 < nslots; chunk += kV4Waves) {
+            const int sidx = chunk * 64 + lane;
+            const int row = sidx / kSlots, c = sidx - row * kSlots;
+            int wy = (int)(((float)row + 0.5f) * inv_ww);      // exact for row < 2^22
+            const int wx = row - wy * g.ww;
+            const unsigned off = (row < g.nrows && c < NCH)
+                ? g.lvl_base + (unsigned)((g.wy0 + wy) * g.W + g.wx0 + wx) * rowbytes + (unsigned)c * 16u
+                : kOobOffset;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsrc, (__attribute__((address_space(3))) void *)(s_rows + g.win_off + chunk * 1024),
+                16, off, 0, 0, 0);
         }
     };
 
-    f32x4_t acc[NCH];
+    f32x4_t acc[kMine];
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < kMine; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     Geom gnext = level_geom(0);
-    issue_level_loads(0, gnext);
+    f32x4_t lxy0 = *reinterpret_cast<const f32x4_t *>(lp_base);
+    f32x4_t lxy1 = *reinterpret_cast<const f32x4_t *>(lp_base + 4);
+    f32x4_t law = *reinterpret_cast<const f32x4_t *>(ap_base);
+    issue_window_dma(gnext);
     for (int l = 0; l < L; ++l) {
         const Geom g = gnext;
-        __syncthreads();      // previous level's gathers are done with the window
-        commit_window(g);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA + location loads landed
+        __syncthreads();      // ... everybody's; and everybody is done gathering level l-1
         const f32x4_t cxy0 = lxy0, cxy1 = lxy1, caw = law;
-        __syncthreads();
-        if (l + 1 < L) {      // next level's traffic flies while this level is gathered
+        if (l + 1 < L) {      // next level streams into the other window while this one is gathered
             gnext = level_geom(l + 1);
-            issue_level_loads(l + 1, gnext);
+            lxy0 = *reinterpret_cast<const f32x4_t *>(lp_base + (size_t)(l + 1) * PT * 2);
+            lxy1 = *reinterpret_cast<const f32x4_t *>(lp_base + (size_t)(l + 1) * PT * 2 + 4);
+            law = *reinterpret_cast<const f32x4_t *>(ap_base + (size_t)(l + 1) * PT);
+            issue_window_dma(gnext);
         }
-        if (q < 0) continue;  // no barrier below this point inside the iteration
+        if (q < 0 || tg.debug == 2) continue;  // no barrier below this point inside the iteration
 
         const float Wf = (float)g.W, Hf = (float)g.H;
         const float lx[4] = {cxy0.x, cxy0.z, cxy1.x, cxy1.z};
         const float ly[4] = {cxy0.y, cxy0.w, cxy1.y, cxy1.w};
         const float aw[4] = {caw.x, caw.y, caw.z, caw.w};
-        static_assert(PT == 4, "tiled kernel is written for 4 sampling points per level");
+        const unsigned char *rbase = s_rows + half * 16;
 #pragma unroll
         for (int p = 0; p < PT; ++p) {
             const float xr = __builtin_fmaf(lx[p], Wf, -0.5f);   // cuh:227-228, single rounding
@@ -642,44 +878,49 @@ msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
             const bool staged = !in || (xlo >= g.wx0 && xhi <= g.wx1 && ylo >= g.wy0 && yhi <= g.wy1);
             const float w1 = gy * gx * aw[p], w2 = gy * fx * aw[p];
             const float w3 = fy * gx * aw[p], w4 = fy * fx * aw[p];
-            const unsigned o = kStride + (unsigned)((y0 - g.wy0) * g.ww + (x0 - g.wx0)) * kStride;
+            const unsigned o = g.win_off + (unsigned)((y0 - g.wy0) * g.ww + (x0 - g.wx0)) * kStride;
             const unsigned o1 = (staged && ky0 && kx0) ? o : 0u;                 // 0 = the zero row
             const unsigned o2 = (staged && ky0 && kx1) ? o + kStride : 0u;
             const unsigned o3 = (staged && ky1 && kx0) ? o + (unsigned)g.ww * kStride : 0u;
             const unsigned o4 = (staged && ky1 && kx1) ? o + (unsigned)(g.ww + 1) * kStride : 0u;
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const f32x4_t v1 = *reinterpret_cast<const f32x4_t *>(s_rows + o1 + c * 16);
-                const f32x4_t v2 = *reinterpret_cast<const f32x4_t *>(s_rows + o2 + c * 16);
-                const f32x4_t v3 = *reinterpret_cast<const f32x4_t *>(s_rows + o3 + c * 16);
-                const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(s_rows + o4 + c * 16);
-                acc[c] += v1 * w1;
-                acc[c] += v2 * w2;
-                acc[c] += v3 * w3;
-                acc[c] += v4 * w4;
+            for (int k = 0; k < kMine; ++k) {
+                if (2 * k + 1 >= NCH && half) break;     // odd lane has one slice less when NCH is odd
+                const f32x4_t v1 = *reinterpret_cast<const f32x4_t *>(rbase + o1 + k * 32);
+                const f32x4_t v2 = *reinterpret_cast<const f32x4_t *>(rbase + o2 + k * 32);
+                const f32x4_t v3 = *reinterpret_cast<const f32x4_t *>(rbase + o3 + k * 32);
+                const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(rbase + o4 + k * 32);
+                acc[k] += v1 * w1;
+                acc[k] += v2 * w2;
+                acc[k] += v3 * w3;
+                acc[k] += v4 * w4;
             }
             if (__any(in && !staged)) {   // rare: the point left the window -> global gather for it
                 const bool gl = in && !staged;
                 const int r0 = y0 * g.W + x0;
-                const unsigned b1 = (gl && ky0 && kx0) ? g.lvl_base + (unsigned)r0 * rowbytes : kOobOffset;
-                const unsigned b2 = (gl && ky0 && kx1) ? g.lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobOffset;
-                const unsigned b3 = (gl && ky1 && kx0) ? g.lvl_base + (unsigned)(r0 + g.W) * rowbytes : kOobOffset;
-                const unsigned b4 = (gl && ky1 && kx1) ? g.lvl_base + (unsigned)(r0 + g.W + 1) * rowbytes : kOobOffset;
+                const unsigned hb = (unsigned)half * 16u;
+                const unsigned b1 = (gl && ky0 && kx0) ? g.lvl_base + (unsigned)r0 * rowbytes + hb : kOobOffset;
+                const unsigned b2 = (gl && ky0 && kx1) ? g.lvl_base + (unsigned)(r0 + 1) * rowbytes + hb : kOobOffset;
+                const unsigned b3 = (gl && ky1 && kx0) ? g.lvl_base + (unsigned)(r0 + g.W) * rowbytes + hb : kOobOffset;
+                const unsigned b4 = (gl && ky1 && kx1) ? g.lvl_base + (unsigned)(r0 + g.W + 1) * rowbytes + hb : kOobOffset;
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    // kOobOffset + c*16 stays out of range for every supported tensor (c*16 < 256)
-                    acc[c] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b1 == kOobOffset ? b1 : b1 + c * 16, 0, 0)) * w1;
-                    acc[c] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b2 == kOobOffset ? b2 : b2 + c * 16, 0, 0)) * w2;
-                    acc[c] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b3 == kOobOffset ? b3 : b3 + c * 16, 0, 0)) * w3;
-                    acc[c] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b4 == kOobOffset ? b4 : b4 + c * 16, 0, 0)) * w4;
+                for (int k = 0; k < kMine; ++k) {
+                    if (2 * k + 1 >= NCH && half) break;
+                    acc[k] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b1 == kOobOffset ? b1 : b1 + k * 32, 0, 0)) * w1;
+                    acc[k] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b2 == kOobOffset ? b2 : b2 + k * 32, 0, 0)) * w2;
+                    acc[k] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b3 == kOobOffset ? b3 : b3 + k * 32, 0, 0)) * w3;
+                    acc[k] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b4 == kOobOffset ? b4 : b4 + k * 32, 0, 0)) * w4;
                 }
             }
         }
     }
     if (q >= 0) {
-        float *op = out + pair * D;
+        float *op = out + pair * D + half * 4;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) *reinterpret_cast<f32x4_t *>(op + c * 4) = acc[c];
+        for (int k = 0; k < kMine; ++k) {
+            if (2 * k + 1 >= NCH && half) break;
+            *reinterpret_cast<f32x4_t *>(op + k * 8) = acc[k];
+        }
     }
 }
 
@@ -1030,7 +1271,7 @@ unsigned head_major_grid(int N, int Lq, int M, int ppb)
 bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, int D, int L)
 {
     const long long bytes = (long long)N * S * M * D * 4;
-    if (bytes >= (long long)kOobOffset) return false;
+    if (bytes >= (long long)kOobBase) return false;
     if ((long long)M * D * 4 >= (1 << 24)) return false;
     if (S >= (1 << 24)) return false;   // also bounds every level's H*W (and start) below 2^24
     if (host_shapes)
@@ -1051,32 +1292,16 @@ bool tiled_enabled()
 
 // Tile / window plan of msda_fwd_f32_tiled.  Returns false when the shape does not suit the kernel
 // (then the row-gather kernels are used).  Everything here is a performance heuristic.
-constexpr size_t kTiledLdsBudget = 150 * 1024;   // one 512-thread workgroup per CU (160 KiB LDS)
+constexpr size_t kTiledLdsBudget = 160 * 1024;   // one 512-thread workgroup per CU owns the whole LDS
 constexpr int kTiledHeaderBytes = kLevelTableBytes + (5 * TF_MSDA_MAX_LEVELS + 4) * (int)sizeof(int);
 
-bool plan_tiles(const LevelTable &lt, int L, int D, TileGeom *tg, size_t *lds)
+long long tile_max_queries(const LevelTable &lt, int L, int th, int tw)
 {
-    if (!tiled_enabled()) return false;
-    if (D != 32 && D != 36) return false;      // instantiated row widths (hidden 256 / 288, 8 heads)
-    const int nch = D / 4, slots = (nch % 2) ? nch : nch + 1;
-    int hy = 4, hx = 8;   // default halo: the (H,W)-divisor quirk stretches x offsets by W/H (~1.67)
-    int th = 14, tw = 16;
-    if (const char *e = getenv("TF_MSDA_HALO")) sscanf(e, "%d,%d", &hy, &hx);
-    if (const char *e = getenv("TF_MSDA_TILE")) sscanf(e, "%d,%d", &th, &tw);
-    if (hy < 0 || hx < 0 || th < 1 || tw < 1) return false;
     const int H0 = lt.H[0], W0 = lt.W[0];
-    tg->TH = th;
-    tg->TW = tw;
-    tg->HY = hy;
-    tg->HX = hx;
-    tg->tiles_y = (H0 + th - 1) / th;
-    tg->tiles_x = (W0 + tw - 1) / tw;
-    // exact maximum number of queries of one tile (same integer partition as the kernel)
-    long long max_nq = 0;
-    for (int ty = 0; ty < tg->tiles_y; ++ty)
-        for (int tx = 0; tx < tg->tiles_x; ++tx) {
-            const int y0 = ty * th, y1 = (y0 + th < H0) ? y0 + th : H0;
-            const int x0 = tx * tw, x1 = (x0 + tw < W0) ? x0 + tw : W0;
+    long long max_nq = 0;   // exact, same integer partition as the kernel
+    for (int y0 = 0; y0 < H0; y0 += th)
+        for (int x0 = 0; x0 < W0; x0 += tw) {
+            const int y1 = (y0 + th < H0) ? y0 + th : H0, x1 = (x0 + tw < W0) ? x0 + tw : W0;
             long long nq = 0;
             for (int l = 0; l < L; ++l) {
                 const long long Hl = lt.H[l], Wl = lt.W[l];
@@ -1086,28 +1311,83 @@ bool plan_tiles(const LevelTable &lt, int L, int D, TileGeom *tg, size_t *lds)
             }
             if (nq > max_nq) max_nq = nq;
         }
-    if (max_nq < 1 || max_nq > kV3Threads) return false;   // e.g. level 0 is not the finest level
-    // window limits: register staging (lines per wave, chunks per line) and LDS capacity
-    int max_wh = kV3Waves * kV3LinesPerWave;
-    int max_ww = (64 * kV3ChunksPerLine) / nch;
+    return max_nq;
+}
+
+bool plan_tiles(const LevelTable &lt, int L, int D, TileGeom *tg, size_t *lds)
+{
+    if (!tiled_enabled()) return false;
+    if (D != 32 && D != 36) return false;      // instantiated row widths (hidden 256 / 288, 8 heads)
+    const int nch = D / 4, slots = (nch % 2) ? nch : nch + 1;
     const size_t row = (size_t)slots * 16;
-    while ((size_t)kTiledHeaderBytes + row * (1 + (size_t)max_wh * max_ww) > kTiledLdsBudget && max_wh > 1)
-        --max_wh;
-    if ((size_t)kTiledHeaderBytes + row * (1 + (size_t)max_wh * max_ww) > kTiledLdsBudget) return false;
-    tg->max_wh = max_wh;
-    tg->max_ww = max_ww;
-    // LDS actually needed: the largest nominal window over the levels (bounded by the limits)
-    long long want = 1;
-    for (int l = 0; l < L; ++l) {
-        long long wh = ((long long)th * lt.H[l] + H0 - 1) / H0 + 2 * hy + 3;
-        long long ww = ((long long)tw * lt.W[l] + W0 - 1) / W0 + 2 * hx + 3;
-        if (wh > lt.H[l]) wh = lt.H[l];
-        if (ww > lt.W[l]) ww = lt.W[l];
-        if (wh > max_wh) wh = max_wh;
-        if (ww > max_ww) ww = max_ww;
-        if (wh * ww > want) want = wh * ww;
+    int hy = 3, hx = 7;   // default halo: the (H,W)-divisor quirk stretches x offsets by W/H (~1.67)
+    int th = 0, tw = 16;
+    if (const char *e = getenv("TF_MSDA_HALO")) sscanf(e, "%d,%d", &hy, &hx);
+    if (const char *e = getenv("TF_MSDA_TILE")) sscanf(e, "%d,%d", &th, &tw);
+    if (hy < 0 || hx < 0 || th < 0 || tw < 1) return false;
+    const int H0 = lt.H[0], W0 = lt.W[0];
+    // tallest tile (most queries per workgroup) whose queries fit the lanes and whose two largest
+    // windows (even / odd levels) fit the LDS
+    const int th_first = th ? th : 16, th_last = th ? th : 4;
+    for (int cand = th_first; cand >= th_last; --cand) {
+        const long long nq = tile_max_queries(lt, L, cand, tw);
+        if (nq < 1 || nq > kV4Pairs) continue;
+        long long cap[2] = {1, 1}, max_ww = 1;
+        for (int l = 0; l < L; ++l) {
+            long long wh = ((long long)cand * lt.H[l] + H0 - 1) / H0 + 2 * hy + 3;
+            long long ww = ((long long)tw * lt.W[l] + W0 - 1) / W0 + 2 * hx + 3;
+            if (wh > lt.H[l]) wh = lt.H[l];
+            if (ww > lt.W[l]) ww = lt.W[l];
+            if (wh * ww > cap[l & 1]) cap[l & 1] = wh * ww;
+            if (ww > max_ww) max_ww = ww;
+        }
+        // windows are filled in whole 1-KiB DMA chunks: round the capacities up to 64 slots
+        for (int k = 0; k < 2; ++k) cap[k] = ((cap[k] * slots + 63) / 64 * 64 + slots - 1) / slots;
+        const size_t need = (size_t)kTiledHeaderBytes + row * (size_t)(1 + cap[0] + cap[1]) + 1024;
+        if (need > kTiledLdsBudget) continue;
+        tg->TH = cand;
+        tg->TW = tw;
+        tg->HY = hy;
+        tg->HX = hx;
+        tg->tiles_y = (H0 + cand - 1) / cand;
+        tg->tiles_x = (W0 + tw - 1) / tw;
+        tg->cap_even = (int)cap[0];
+        tg->cap_odd = (int)cap[1];
+        tg->debug = 0;
+        if (const char *e = getenv("TF_MSDA_TILED_DEBUG")) tg->debug = atoi(e);
+        *lds = need;
+        return true;
     }
-    *lds = (size_t)kTiledHeaderBytes + row * (size_t)(1 + want);
+    return false;
+}
+
+// Launch msda_fwd_f32_direct when the shape qualifies (D == 32, P == 4, L <= 8).  Returns false if not.
+bool direct_enabled()
+{
+    static const int on = [] { const char *e = getenv("TF_MSDA_DIRECT"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
+bool launch_direct(bool fused, const DirectArgs &da, const LevelTable &lt, const int64_t *shapes_dev,
+                   int D, int P, hipStream_t stream, hipError_t *err)
+{
+    if (!direct_enabled() || D != 32 || P != 4 || da.L > 8) return false;
+    const int lpairs = (da.L + 1) / 2;
+    const void *fn = nullptr;
+    if (fused)
+        fn = lpairs == 1   ? (const void *)&msda_fwd_f32_direct<1, true>
+             : lpairs == 2 ? (const void *)&msda_fwd_f32_direct<2, true>
+             : lpairs == 3 ? (const void *)&msda_fwd_f32_direct<3, true>
+                           : (const void *)&msda_fwd_f32_direct<4, true>;
+    else
+        fn = lpairs == 1   ? (const void *)&msda_fwd_f32_direct<1, false>
+             : lpairs == 2 ? (const void *)&msda_fwd_f32_direct<2, false>
+             : lpairs == 3 ? (const void *)&msda_fwd_f32_direct<3, false>
+                           : (const void *)&msda_fwd_f32_direct<4, false>;
+    const long long chunks = (da.nlq + (kThreads / 8) - 1) / (kThreads / 8);
+    const long long grid = chunks * da.M;
+    if (grid > 0x7fffffffLL) return false;
+    *err = launch(fn, (unsigned)grid, 0, stream, da, lt, shapes_dev);
     return true;
 }
 
@@ -1149,10 +1429,25 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                     void *argv[] = {(void *)&value, (void *)&vbytes, (void *)&loc, (void *)&attn,
                                     (void *)&out,   (void *)&lt,     (void *)&shapes_dev, (void *)&S,
                                     (void *)&M,     (void *)&L,      (void *)&tg};
-                    e = hipLaunchKernel(tfn, dim3((unsigned)grid), dim3(kV3Threads), argv, tiled_lds,
+                    e = hipLaunchKernel(tfn, dim3((unsigned)grid), dim3(kV4Threads), argv, tiled_lds,
                                         stream);
                     return record_hip(e);
                 }
+            }
+            {
+                DirectArgs da{};
+                da.value = value;
+                da.value_bytes = vbytes;
+                da.loc = loc;
+                da.attn = attn;
+                da.out = out;
+                da.S = S;
+                da.M = M;
+                da.L = L;
+                da.Lq = Lq;
+                da.nlq = (long long)N * Lq;
+                if (is_aligned(loc, 8) && launch_direct(false, da, lt, shapes_dev, D, P, stream, &e))
+                    return record_hip(e);
             }
             const void *fn = P == 1   ? (const void *)&msda_fwd_f32_buf<1, false>
                              : P == 2 ? (const void *)&msda_fwd_f32_buf<2, false>
@@ -1160,6 +1455,7 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                                       : (const void *)&msda_fwd_f32_buf<8, false>;
             FusedArgs none{};
             none.head_major = head_major_enabled() ? 1 : 0;
+            if (const char *e = getenv("TF_MSDA_BUF_DEBUG")) none.debug = atoi(e);
             const unsigned grid = none.head_major ? head_major_grid(N, Lq, M, pl.ppb) : pl.grid;
             e = launch(fn, grid, pl.lds, stream, value, vbytes, loc, attn, out, lt, shapes_dev,
                        S, M, D, L, Lq, total_pairs, pl.ppb, pl.DV, none);
@@ -1197,12 +1493,27 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
     if (rc != TF_MSDA_OK) return rc;
     const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
     const long long total_pairs = (long long)N * Lq * M;
+    {
+        DirectArgs da{};
+        da.value = value;
+        da.value_bytes = vbytes;
+        da.out = out;
+        da.fa = FusedArgs{ref, qproj, ref_dim, ld, off_col, logit_col, 1, 0};
+        da.S = S;
+        da.M = M;
+        da.L = L;
+        da.Lq = Lq;
+        da.nlq = (long long)N * Lq;
+        hipError_t de;
+        if (launch_direct(true, da, lt, nullptr, D, P, static_cast<hipStream_t>(stream_v), &de))
+            return record_hip(de);
+    }
     const void *fn = P == 1   ? (const void *)&msda_fwd_f32_buf<1, true>
                      : P == 2 ? (const void *)&msda_fwd_f32_buf<2, true>
                      : P == 4 ? (const void *)&msda_fwd_f32_buf<4, true>
                               : (const void *)&msda_fwd_f32_buf<8, true>;
     const int hm = head_major_enabled() ? 1 : 0;
-    const FusedArgs fa{ref, qproj, ref_dim, ld, off_col, logit_col, hm};
+    const FusedArgs fa{ref, qproj, ref_dim, ld, off_col, logit_col, hm, 0};
     const float *nul = nullptr;
     const int64_t *nod = nullptr;
     const unsigned grid = hm ? head_major_grid(N, Lq, M, pl.ppb) : pl.grid;
