@@ -166,7 +166,7 @@ def measure_roofline(device, launches=50):
             traffic = json.load(f)["hbm_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "hbm", "kernel": "msda_fwd_f32_buf<4,false> (encoder shape, Lq=S=22223)",
+    return {"bound": "hbm", "kernel": "msda_fwd_f32_direct<2,false> (encoder shape, Lq=S=22223)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": alg, "avg_launch_us": round(us, 2), "launches": launches}

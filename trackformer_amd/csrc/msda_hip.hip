@@ -264,7 +264,6 @@ struct FusedArgs {
     const float *qproj;   // [N*Lq, ld]: per query, M*L*P*2 raw offsets at off_col, M*L*P logits at logit_col
     int ref_dim, ld, off_col, logit_col;
     int head_major;       // block -> pair mapping, see msda_fwd_f32_buf
-    int debug;            // timing experiments only (wrong results), TF_MSDA_BUF_DEBUG
 };
 
 template <int PT, bool FUSED>
@@ -374,71 +373,6 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
     const float *sa = s_attn + (size_t)pl * LP;
 
     f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    if (fa.debug == 4) {   // timing experiment: prologue + store only
-        acc.x = sl[0].x + sa[0];
-    } else if (PT == 4 && DV == 8) {
-        // Shared tap arithmetic.  The 8 lanes of a pair need the same 4 offsets + 4 weights for each
-        // sampling point; instead of all 8 computing all of them, lane j computes ONE point per two
-        // levels (lanes 0-3: the 4 points of level l, lanes 4-7: those of level l+1) and the group
-        // exchanges the results with ds_bpermute -- the instruction count per wave halves, and this
-        // kernel is instruction-issue bound (profiles/r01_msda_fwd_pmc_counters.json).
-        const int sub = dv & 3, which = dv >> 2;
-        const int group = (threadIdx.x & 63) & ~7;
-        const unsigned dvb = (unsigned)dv * 16u;
-        const unsigned head_base = lane_base - dvb;
-        for (int l0 = 0; l0 < L; l0 += 2) {
-            const int ml = l0 + which;
-            const bool have = ml < L;
-            const int mlc = have ? ml : l0;
-            const int H = s_tab[mlc], W = s_tab[TF_MSDA_MAX_LEVELS + mlc];
-            const unsigned lvl_base = head_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + mlc] * rowbytes;
-            const float Wf = (float)W, Hf = (float)H;
-            const float2 xy = sl[mlc * 4 + sub];
-            const float a = have ? sa[mlc * 4 + sub] : 0.f;
-            const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);   // cuh:227-228, single rounding
-            const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
-            const bool in = have && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);  // cuh:229
-            const float x = in ? xr : 0.f, y = in ? yr : 0.f;
-            const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
-            const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
-            const int x0 = (int)xf, y0 = (int)yf;
-            const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
-            const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
-            const int r0 = y0 * W + x0;
-            // invalid taps: kOobBase + dv*16 (<= 0xFFFFFFF0) is still out of range -> hardware zero
-            unsigned po[4];
-            po[0] = (ky0 && kx0) ? lvl_base + (unsigned)r0 * rowbytes : kOobBase;
-            po[1] = (ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase;
-            po[2] = (ky1 && kx0) ? lvl_base + (unsigned)(r0 + W) * rowbytes : kOobBase;
-            po[3] = (ky1 && kx1) ? lvl_base + (unsigned)(r0 + W + 1) * rowbytes : kOobBase;
-            float pw[4] = {gy * gx * a, gy * fx * a, fy * gx * a, fy * fx * a};
-#pragma unroll
-            for (int ll = 0; ll < 2; ++ll) {
-                if (l0 + ll >= L) break;                     // uniform
-                u32x4_t v[4][4];
-                float w[4][4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const int src = group + ll * 4 + p;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        unsigned o = (unsigned)__shfl((int)po[t], src) + dvb;
-                        if (fa.debug == 1) o = dvb;                       // timing experiment: 100 % L1 hits
-                        if (fa.debug == 2) o = (o & 0x3FFFFu) + dvb;      // timing experiment: 256 KB footprint
-                        w[p][t] = __shfl(pw[t], src);
-                        if (fa.debug == 3) { v[p][t] = u32x4_t{o, o, o, o}; continue; }   // no loads at all
-                        v[p][t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc += __builtin_bit_cast(f32x4_t, v[p][t]) * w[p][t];
-                }
-            }
-        }
-    } else {
     for (int l = 0; l < L; ++l) {
         const int H = s_tab[l], W = s_tab[TF_MSDA_MAX_LEVELS + l];
         const unsigned lvl_base = lane_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + l] * rowbytes;
@@ -480,40 +414,29 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
                 acc += __builtin_bit_cast(f32x4_t, v[p][t]) * w[p][t];
         }
     }
-    }
     *reinterpret_cast<f32x4_t *>(out + pair * D + dv * 4) = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, fp32, D == 32, P == 4, L <= 8: register-only kernel (no LDS staging, no barriers after the
-// level table) with the tap arithmetic shared through DPP broadcasts
+// forward, fp32, D == 32, P == 4, L <= 8: no staging prologue, tap arithmetic shared inside the wave
 // ---------------------------------------------------------------------------------------------
-// Ablations of msda_fwd_f32_buf at the cfg-2 encoder shape (64 us) showed where its time goes: ~22 us in
-// the prologue (loc/attn chunk -> LDS, barriers: every workgroup first waits a full memory round trip)
-// plus the store, ~31 us of VALU work that all 8 lanes of a pair repeat (tap arithmetic), and only
-// ~9 us for the 64 row gathers per pair, which hide behind the rest.  This kernel therefore
-//   * has every lane fetch just the two sampling points it is responsible for straight into
-//     registers at kernel entry (independent loads, nothing to wait for before issuing the gathers
-//     of other waves; no LDS round trip),
+// Ablations of msda_fwd_f32_buf at the cfg-2 encoder shape (64 us) showed where its time went: ~22 us
+// in the prologue (loc/attn chunk -> LDS, barriers: every workgroup first waits a full memory round
+// trip) plus the store, and ~31 us of vector-ALU work that all 8 lanes of a pair repeat (the tap
+// arithmetic) -- the kernel was instruction-issue bound, not memory bound.  This kernel
+//   * has every lane fetch just the sampling points it is responsible for straight into registers
+//     at kernel entry (no LDS round trip, no barrier behind a memory access),
 //   * computes the tap arithmetic of a point ONCE per pair: per pair of levels, lanes 0-3 of the
-//     8-lane group take the 4 points of level l, lanes 4-7 those of level l+1, and the group
-//     exchanges the 4 offsets + 4 weights of each point with DPP row broadcasts (v_mov_b32_dpp
-//     row_newbcast + bank masks: VALU-only, the LDS pipe stays idle),
+//     8-lane group take the 4 points of level l, lanes 4-7 those of level l+1; each lane publishes
+//     its 4 byte offsets + 4 weights in a per-wave LDS exchange buffer and the group reads them back
+//     with two broadcast ds_read_b128 per point (LDS operations of one wave execute in order, so a
+//     wave-scope fence is the only synchronisation).  The vector-ALU work per point drops from ~36 to
+//     ~12 instructions per wave; an all-DPP exchange (row_newbcast + bank masks, 16 v_mov_dpp per
+//     point) measured the same end-to-end time once the kernel had become vector-memory bound,
 //   * optionally (FUSED) performs MSDeformAttn.forward's softmax and sampling-location arithmetic
 //     on the fly (softmax statistics by xor butterflies over the 8 lanes).
-template <int K>
-__device__ __forceinline__ int bcast8_i(int v)
-{
-    // lanes 0-7 of each 16-lane row read lane K, lanes 8-15 read lane 8+K (bank = 4 lanes)
-    int r = __builtin_amdgcn_update_dpp(0, v, 0x150 + K, 0xF, 0x3, false);
-    return __builtin_amdgcn_update_dpp(r, v, 0x150 + 8 + K, 0xF, 0xC, false);
-}
-template <int K>
-__device__ __forceinline__ float bcast8_f(float v)
-{
-    return __builtin_bit_cast(float, bcast8_i<K>(__builtin_bit_cast(int, v)));
-}
-
+// What bounds it now is the vector-memory path itself: the 64 row gathers per pair move 1.46 GB per
+// launch through the texture-addresser / L1 at <= 64 B/clk/CU (TA_BUSY ~80 % of the kernel's cycles).
 struct DirectArgs {
     const float *value;
     unsigned value_bytes;
@@ -525,11 +448,15 @@ struct DirectArgs {
 };
 
 template <int LPAIRS, bool FUSED>   // LPAIRS = ceil(L / 2)
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads, 4)
 msda_fwd_f32_direct(const DirectArgs da, const LevelTable lt, const int64_t *__restrict__ dshapes)
 {
     constexpr int PT = 4, D = 32, DV = 8;
     __shared__ int s_tab[3 * TF_MSDA_MAX_LEVELS];
+    // per-wave exchange buffers, one 16-byte slot of offsets and one of weights per lane; a pad slot
+    // after every 8 lanes keeps the 8 groups of a wave on disjoint banks when they all read slot k
+    __shared__ u32x4_t s_xo[(kThreads / 64) * 72];
+    __shared__ f32x4_t s_xw[(kThreads / 64) * 72];
     const int L = da.L, M = da.M, LP = L * PT;
     fill_level_table(s_tab, lt, dshapes, L);
 
@@ -629,29 +556,39 @@ msda_fwd_f32_direct(const DirectArgs da, const LevelTable lt, const int64_t *__r
         const float a = in ? sa[i] : 0.f;
         const float pw0 = gy * gx * a, pw1 = gy * fx * a, pw2 = fy * gx * a, pw3 = fy * fx * a;
 
-        // consume: the 8 points of the level pair, produced by lanes 0..7 of the group
-        u32x4_t v[8][4];
-        float w[8][4];
-#define TF_CONSUME(K)                                                                              \
-        {                                                                                          \
-            w[K][0] = bcast8_f<K>(pw0);                                                            \
-            w[K][1] = bcast8_f<K>(pw1);                                                            \
-            w[K][2] = bcast8_f<K>(pw2);                                                            \
-            w[K][3] = bcast8_f<K>(pw3);                                                            \
-            v[K][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)bcast8_i<K>(po0) + dvb, 0, 0); \
-            v[K][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)bcast8_i<K>(po1) + dvb, 0, 0); \
-            v[K][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)bcast8_i<K>(po2) + dvb, 0, 0); \
-            v[K][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)bcast8_i<K>(po3) + dvb, 0, 0); \
-        }
-        TF_CONSUME(0) TF_CONSUME(1) TF_CONSUME(2) TF_CONSUME(3)
-        const bool second = 2 * i + 1 < L;   // uniform
-        if (second) { TF_CONSUME(4) TF_CONSUME(5) TF_CONSUME(6) TF_CONSUME(7) }
-#undef TF_CONSUME
+        // publish: LDS operations of a wave execute in order, so a wave-scope fence is all the
+        // synchronisation there is (it also orders the previous level pair's reads before this write)
+        const int lane = threadIdx.x & 63;
+        const int xbase = (threadIdx.x >> 6) * 72 + (lane >> 3) * 9;   // slot of lane 0 of this group
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        s_xo[xbase + dv] = u32x4_t{(unsigned)po0, (unsigned)po1, (unsigned)po2, (unsigned)po3};
+        s_xw[xbase + dv] = f32x4_t{pw0, pw1, pw2, pw3};
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // consume: the points of one level (produced by lanes 4*ll .. 4*ll+3 of the group) at a time,
+        // 16 row gathers in flight per lane
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (k >= 4 && !second) break;
+        for (int ll = 0; ll < 2; ++ll) {
+            if (2 * i + ll >= L) break;   // uniform
+            u32x4_t v[4][4];
+            f32x4_t w[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc += __builtin_bit_cast(f32x4_t, v[k][t]) * w[k][t];
+            for (int k = 0; k < 4; ++k) {
+                const u32x4_t o = s_xo[xbase + ll * 4 + k];
+                w[k] = s_xw[xbase + ll * 4 + k];
+                v[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + dvb, 0, 0);
+                v[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + dvb, 0, 0);
+                v[k][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + dvb, 0, 0);
+                v[k][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + dvb, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc += __builtin_bit_cast(f32x4_t, v[k][0]) * w[k].x;
+                acc += __builtin_bit_cast(f32x4_t, v[k][1]) * w[k].y;
+                acc += __builtin_bit_cast(f32x4_t, v[k][2]) * w[k].z;
+                acc += __builtin_bit_cast(f32x4_t, v[k][3]) * w[k].w;
+            }
         }
     }
     if (live) *reinterpret_cast<f32x4_t *>(da.out + pair * D + dv * 4) = acc;
@@ -1455,7 +1392,6 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                                       : (const void *)&msda_fwd_f32_buf<8, false>;
             FusedArgs none{};
             none.head_major = head_major_enabled() ? 1 : 0;
-            if (const char *e = getenv("TF_MSDA_BUF_DEBUG")) none.debug = atoi(e);
             const unsigned grid = none.head_major ? head_major_grid(N, Lq, M, pl.ppb) : pl.grid;
             e = launch(fn, grid, pl.lds, stream, value, vbytes, loc, attn, out, lt, shapes_dev,
                        S, M, D, L, Lq, total_pairs, pl.ppb, pl.DV, none);
@@ -1498,7 +1434,7 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
         da.value = value;
         da.value_bytes = vbytes;
         da.out = out;
-        da.fa = FusedArgs{ref, qproj, ref_dim, ld, off_col, logit_col, 1, 0};
+        da.fa = FusedArgs{ref, qproj, ref_dim, ld, off_col, logit_col, 1};
         da.S = S;
         da.M = M;
         da.L = L;
@@ -1513,7 +1449,7 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
                      : P == 4 ? (const void *)&msda_fwd_f32_buf<4, true>
                               : (const void *)&msda_fwd_f32_buf<8, true>;
     const int hm = head_major_enabled() ? 1 : 0;
-    const FusedArgs fa{ref, qproj, ref_dim, ld, off_col, logit_col, hm, 0};
+    const FusedArgs fa{ref, qproj, ref_dim, ld, off_col, logit_col, hm};
     const float *nul = nullptr;
     const int64_t *nod = nullptr;
     const unsigned grid = hm ? head_major_grid(N, Lq, M, pl.ppb) : pl.grid;
