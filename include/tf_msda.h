@@ -63,10 +63,10 @@ const char *tf_msda_strerror(int status);
 int tf_msda_last_hip_error(void);
 
 /*
- * Kernel selection knob (process-wide, performance only -- results are identical): 1 enables the
- * LDS-tiled forward kernel for encoder-shaped calls (Lq == S, fp32, D in {32, 36}, P == 4), 0 disables
- * it, -1 restores the default (environment variable TF_MSDA_TILED, off when unset).  Returns the
- * previous setting.
+ * Kernel selection knob (process-wide, performance only -- results are identical up to fp32 summation
+ * order): 1 enables the LDS-window forward kernel for encoder-shaped calls (Lq == S, fp32, D == 32,
+ * P == 4, L <= 4, host shapes), 0 disables it, -1 restores the default (environment variable
+ * TF_MSDA_TILED, off when unset).  Returns the previous setting.
  */
 int tf_msda_set_tiled(int mode);
 

@@ -374,7 +374,7 @@ def test_module_forward_matches_oracle_composition(dev):
 # ------------------------------------------------------------------ tiled / LDS-staged encoder kernel
 @pytest.fixture()
 def tiled(dev):
-    """Enable the opt-in LDS-tiled encoder kernel for the duration of a test."""
+    """Enable the opt-in LDS-window encoder kernel (msda_fwd_f32_win) for the duration of a test."""
     from trackformer_amd import _cabi
     prev = _cabi.lib().tf_msda_set_tiled(1)
     yield

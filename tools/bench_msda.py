@@ -72,17 +72,27 @@ def make_inputs(N, M, D, Lq, P, shapes, mode, device, seed=0, dtype=torch.float3
 
 
 def time_launches(fn, iters, warmup=5):
-    """Average duration (ms) of one launch: HIP events on the launch stream around `iters` launches."""
+    """Average duration (ms) of one launch: `iters` launches captured in ONE HIP graph (so that host
+    launch overhead cannot hide in the number), HIP events around the graph replay."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    start = torch.cuda.Event(enable_timing=True)
-    end = torch.cuda.Event(enable_timing=True)
-    start.record()
-    for _ in range(iters):
+    stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(stream):
         fn()
-    end.record()
-    end.synchronize()
+        stream.synchronize()
+        with torch.cuda.graph(graph, stream=stream):
+            for _ in range(iters):
+                fn()
+        graph.replay()
+        stream.synchronize()
+        start = torch.cuda.Event(enable_timing=True)
+        end = torch.cuda.Event(enable_timing=True)
+        start.record(stream)
+        graph.replay()
+        end.record(stream)
+        end.synchronize()
     return start.elapsed_time(end) / iters
 
 

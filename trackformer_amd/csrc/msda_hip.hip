@@ -13,29 +13,30 @@
 // the one written out in SURVEY.md Appendix A; the thread mapping, memory staging and reduction
 // scheme are designed for 64-wide wavefronts and are unrelated to the reference's.
 //
-// Kernel design (v1, "row gather"):
-//   * A "pair" is one (batch, query, head) triple: it owns L*P sampling points and one D-float
-//     output row.  pairs are contiguous in loc/attn/out memory, so a workgroup that owns
-//     `ppb` consecutive pairs reads ONE contiguous chunk of loc and attn (fully coalesced) into
-//     LDS and writes ONE contiguous chunk of out.
-//   * Inside a pair, D/VEC lanes each own VEC (=4) consecutive channels, so a bilinear tap is one
-//     16-byte load per lane and the D/VEC lanes of a pair together read one contiguous
-//     D*sizeof(T)-byte row of `value` (128 B for D=32: exactly one cache line).  With M=8, D=32 a
-//     64-lane wavefront is exactly one query (8 heads x 8 lanes).
-//   * Every tap address is clamped into the level, so all 4*L*P loads of a lane are unconditional
-//     and independent (deep memory-level parallelism, no divergent branches); validity is applied
-//     with selects on the loaded values (bit-exact zero padding, no 0*Inf leaks).
-//   * Level geometry lives in a 192-byte LDS table filled either from the kernel arguments
-//     (host-shape entry points) or from the reference's device-resident int64 tensor
-//     (..._dshapes entry points) -- never a host<->device sync.
-//   * Backward fuses the reference's two kernels: the D-reduction for grad_loc / grad_attn is a
-//     wave shuffle (xor butterfly over the D/VEC lanes of a pair) instead of a serial channel loop,
-//     results are staged in LDS and written back coalesced; grad_value uses hardware fp atomics.
+// Kernels in this file (a "pair" is one (batch, query, head) triple: L*P sampling points, one D-float
+// output row; the D/4 lanes of a pair each own 4 consecutive channels, so a bilinear tap is one 16-byte
+// load per lane and the lanes of a pair read one contiguous row of `value` -- 128 B for D = 32):
+//   msda_fwd_rowgather<T,VEC>   any dtype / shape; loc+attn chunk staged in LDS, clamped taps, selects.
+//   msda_fwd_f32_buf<P,FUSED>   fp32, D % 4 == 0: buffer loads whose out-of-range offsets give zero
+//                               padding in hardware; head-major workgroups (one head per XCD when
+//                               M == 8: that head's value rows stay in the XCD's 4 MiB L2).
+//   msda_fwd_f32_direct         fp32, D == 32, P == 4 (every TrackFormer config with hidden 256): no
+//                               staging prologue, tap arithmetic computed once per pair and shared
+//                               inside the wave.  THE DEFAULT for the hot path.
+//   msda_fwd_f32_win            encoder shape only, opt-in: data-adaptive LDS windows.
+//   msda_bwd_rowgather<T,...>   any dtype; fuses the reference's two backward kernels.
+//   msda_bwd_f32_buf<P>         fp32 fast path: buffer loads + buffer atomics.
+// Common rules: level geometry comes from the kernel arguments (host-shape entry points) or from the
+// reference's device-resident int64 tensor (..._dshapes) -- never a host<->device sync; no kernel
+// branches per tap; nothing depends on CUDA-style 32-wide warps.
+//
 #include <hip/hip_runtime.h>
 
+#include <limits.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "tf_msda.h"
 
@@ -595,269 +596,393 @@ msda_fwd_f32_direct(const DirectArgs da, const LevelTable lt, const int64_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, encoder self-attention shape (Lq == S): 2-D query tiles + LDS-staged sampling windows
+// forward, encoder shape, fp32, D == 32, P == 4, L <= 4: data-adaptive LDS windows (all levels resident)
 // ---------------------------------------------------------------------------------------------
-// In the encoder every pyramid pixel is a query and samples a small neighbourhood of its own position
-// in each level, so a value row is fetched ~64 times (16 samples x 4 taps per query and head).  Through
-// the vector-memory path that is 1.46 GB of 128-byte row gathers per launch at <= 64 B/clk/CU (measured:
-// TA busy 16 cycles per dwordx4 wave-load); LDS serves the same gathers at 256 B/clk/CU.  This kernel
-//   * forms 512-thread workgroups from 2-D tiles of queries: a tile is a TH x TW rectangle of level-0
-//     pixels together with the pixels of every other level whose centres fall into the same
-//     normalised rectangle (an exact partition of all S queries), for ONE head (blockIdx % M: with
-//     M == 8 each XCD serves one head, whose 2.8 MB of value rows stay in that XCD's 4 MiB L2);
-//   * gives each (query, head) pair to TWO lanes (even / odd 16-byte channel slices): the tap
-//     arithmetic is done twice per sampling point instead of D/4 times as in the row-gather kernels,
-//     and 8 wavefronts per CU keep every SIMD two-deep;
-//   * walks the value levels with two LDS windows: while level l is gathered from one window the
-//     tile's nominal window of level l+1 (tile extent mapped into the level plus a halo) streams into
-//     the other one by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no LDS store
-//     instructions).  Rows are stored with a stride of an ODD number of 16-byte slots (144 B for
-//     D = 32) so that ds_read_b128 of one slice of neighbouring rows is bank-conflict free;
-//   * taps outside the level read a zero row kept in LDS (zero padding with no selects); sampling
-//     points whose taps leave the staged window -- possible for any input, the window is only a
-//     guess -- take buffer loads under a wave-uniform branch.
-// Correctness never depends on the tile/window/halo heuristics (tests sweep adversarial inputs).
-constexpr int kV4Threads = 512;
-constexpr int kV4Waves = kV4Threads / 64;
-constexpr int kV4Pairs = kV4Threads / 2;     // queries per tile (two lanes each)
+// The row-gather kernels are bound by the vector-memory path (64 B/clk/CU for 1.46 GB of row gathers per
+// cfg-2 encoder launch); LDS serves ds_read_b128 at 256 B/clk/CU.  This kernel tiles the queries in 2-D,
+// keeps the wave-shared tap arithmetic of msda_fwd_f32_direct and sizes its LDS windows from the DATA
+// instead of from a guessed halo:
+//   * a workgroup (512 threads) owns the queries of one 2-D tile (TH x TW level-0 pixels plus the
+//     pixels of the other levels whose centres fall into the same normalised rectangle) for one head,
+//     and serves them in up to kWinPasses passes of 64 (query, head) pairs, 8 lanes per pair;
+//   * phase A: every lane computes the integer tap coordinates of the points it owns, and the
+//     workgroup reduces them to one bounding box per level (xor butterflies inside the wave, then
+//     ds_min / ds_max).  Attention heads sample along their own directions, so these boxes are much
+//     tighter than a symmetric halo around the tile;
+//   * phase B: the boxes (clamped to the tile footprint +- (HY, HX) pixels and to the LDS capacity)
+//     are streamed into LDS by LDS-DMA, all levels at once, rows unpadded (128 B);
+//   * phase C: as msda_fwd_f32_direct, but the taps are ds_read_b128 from the windows.  Taps outside
+//     the level read a zero row; points whose taps leave their window (clamped box) take buffer
+//     loads under a wave-uniform branch, so any input is handled exactly.
+constexpr int kWinThreads = 512;
+constexpr int kWinWaves = kWinThreads / 64;
+constexpr int kWinPasses = 2;
+constexpr int kWinPairs = kWinThreads / 8;               // (query, head) pairs per pass
+constexpr int kWinMaxQueries = kWinPasses * kWinPairs;   // queries per tile
+constexpr int kWinLevels = 4;
+constexpr int kWinHeaderBytes = 1664;                    // level table | query partition | boxes | geometry
+constexpr int kWinXchSlots = kWinWaves * 72;
+constexpr int kWinRowsOffset = kWinHeaderBytes + 3 * kWinXchSlots * 16;   // multiple of 128
 
-struct TileGeom {
+struct WinGeom {
     int TH, TW;        // tile size in level-0 pixels
-    int HY, HX;        // window halo in pixels (every level)
+    int HY, HX;        // the adaptive windows are clamped to the tile footprint +- this many pixels
     int tiles_y, tiles_x;
-    int cap_even, cap_odd;   // LDS window capacities in rows: even levels use buffer A, odd ones B
-    int debug;               // timing experiments only (wrong results): 1 = skip staging, 2 = skip gather
+    int cap_rows;      // LDS rows for windows, all levels together (multiple of 8)
 };
 
-template <int PT, int NCH>   // NCH = D / 4 sixteen-byte channel slices per row
-__global__ void __launch_bounds__(kV4Threads)
-msda_fwd_f32_tiled(const float *__restrict__ value, unsigned value_bytes,
-                   const float *__restrict__ loc, const float *__restrict__ attn,
-                   float *__restrict__ out, const LevelTable lt,
-                   const int64_t *__restrict__ dshapes, int S, int M, int L, const TileGeom tg)
+template <bool FUSED>
+__global__ void __launch_bounds__(kWinThreads, 4)
+msda_fwd_f32_win(const DirectArgs da, const LevelTable lt, const WinGeom wg)
 {
-    constexpr int D = NCH * 4;
-    constexpr int kSlots = (NCH % 2) ? NCH : NCH + 1;      // odd number of 16-byte slots per LDS row
-    constexpr unsigned kStride = kSlots * 16u;             // LDS row stride in bytes
-    constexpr int kMine = (NCH + 1) / 2;                   // slices per lane (even lane gets the extra one)
-    static_assert(PT == 4, "tiled kernel is written for 4 sampling points per level");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start   (192 B)
-    int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb | qoff(17)
-    constexpr int kQInts = 5 * TF_MSDA_MAX_LEVELS + 4;             // 84 ints -> header = 528 B
-    unsigned char *s_rows = reinterpret_cast<unsigned char *>(s_q + kQInts);
-    // s_rows: [zero row][window A: cap_even rows][window B: cap_odd rows], all with stride kStride
+    constexpr int PT = 4, D = 32, LPAIRS = kWinLevels / 2;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start          (48 ints)
+    int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb | qoff (84 ints)
+    int *s_bb = s_q + 5 * TF_MSDA_MAX_LEVELS + 4;                  // xmin xmax ymin ymax per level
+    // per-wave copy of the window geometry: wx0 wy0 wx1 wy1 | ww roff lvl_base -   (8 ints per level)
+    u32x4_t *s_geo = reinterpret_cast<u32x4_t *>(smem + 640);
+    u32x4_t *s_xo = reinterpret_cast<u32x4_t *>(smem + kWinHeaderBytes);
+    f32x4_t *s_xw = reinterpret_cast<f32x4_t *>(s_xo + kWinXchSlots);
+    u32x4_t *s_xg = reinterpret_cast<u32x4_t *>(s_xw + kWinXchSlots);
+    unsigned char *s_rows = smem + kWinRowsOffset;                 // row 0: zeros, then the windows
 
+    const int L = da.L, M = da.M, S = da.S, LP = L * PT;
     const int m = blockIdx.x % M;
     int t = blockIdx.x / M;
-    const int tx = t % tg.tiles_x;
-    t /= tg.tiles_x;
-    const int ty = t % tg.tiles_y;
-    const int b = t / tg.tiles_y;
+    const int tx = t % wg.tiles_x;
+    t /= wg.tiles_x;
+    const int ty = t % wg.tiles_y;
+    const int b = t / wg.tiles_y;
 
-    if (threadIdx.x == 0) {
-        if (dshapes != nullptr) {
-            int acc = 0;
-            for (int l = 0; l < L; ++l) {
-                const int h = (int)dshapes[2 * l], w = (int)dshapes[2 * l + 1];
-                s_tab[l] = h;
-                s_tab[TF_MSDA_MAX_LEVELS + l] = w;
-                s_tab[2 * TF_MSDA_MAX_LEVELS + l] = acc;
-                acc += h * w;
-            }
-        } else {
-            for (int l = 0; l < L; ++l) {
+    if (threadIdx.x < 4 * kWinLevels) {
+        // thread 4l+k: bound k (ya, yb, xa, xb) of the pixels of level l whose centre lies in the tile's
+        // normalised rectangle -- integer exact, so that the tiles partition every level
+        const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
+        if (l < L) {
+            const unsigned H0 = (unsigned)lt.H[0], W0 = (unsigned)lt.W[0];
+            const unsigned Hl = (unsigned)lt.H[l], Wl = (unsigned)lt.W[l];
+            const unsigned y0 = (unsigned)ty * wg.TH, y1 = min(H0, y0 + (unsigned)wg.TH);
+            const unsigned x0 = (unsigned)tx * wg.TW, x1 = min(W0, x0 + (unsigned)wg.TW);
+            const unsigned num = k == 0 ? 2u * y0 * Hl + H0 - 1u : k == 1 ? 2u * y1 * Hl + H0 - 1u
+                                 : k == 2 ? 2u * x0 * Wl + W0 - 1u : 2u * x1 * Wl + W0 - 1u;
+            s_q[k * TF_MSDA_MAX_LEVELS + l] = (int)(num / (k < 2 ? 2u * H0 : 2u * W0));   // host: < 2^31
+            if (k == 0) {
                 s_tab[l] = lt.H[l];
                 s_tab[TF_MSDA_MAX_LEVELS + l] = lt.W[l];
                 s_tab[2 * TF_MSDA_MAX_LEVELS + l] = lt.start[l];
             }
         }
     }
-    if (threadIdx.x < kSlots * 4) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;
+    if (threadIdx.x < 4 * kWinLevels) s_bb[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
+    if (threadIdx.x < D) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;
     __syncthreads();
 
-    const int H0 = s_tab[0], W0 = s_tab[TF_MSDA_MAX_LEVELS];
-    const int y0t = ty * tg.TH, y1t = min(H0, y0t + tg.TH);
-    const int x0t = tx * tg.TW, x1t = min(W0, x0t + tg.TW);
-    if (threadIdx.x == 0) {
-        // pixels of level l whose centre lies in [y0t/H0, y1t/H0) x [x0t/W0, x1t/W0): integer exact
-        int acc = 0;
-        for (int l = 0; l < L; ++l) {
-            const int Hl = s_tab[l], Wl = s_tab[TF_MSDA_MAX_LEVELS + l];
-            const int ya = (int)((2LL * y0t * Hl + H0 - 1) / (2LL * H0));
-            const int yb = (int)((2LL * y1t * Hl + H0 - 1) / (2LL * H0));
-            const int xa = (int)((2LL * x0t * Wl + W0 - 1) / (2LL * W0));
-            const int xb = (int)((2LL * x1t * Wl + W0 - 1) / (2LL * W0));
-            s_q[l] = ya;
-            s_q[TF_MSDA_MAX_LEVELS + l] = yb;
-            s_q[2 * TF_MSDA_MAX_LEVELS + l] = xa;
-            s_q[3 * TF_MSDA_MAX_LEVELS + l] = xb;
-            s_q[4 * TF_MSDA_MAX_LEVELS + l] = acc;
-            acc += (yb - ya) * (xb - xa);
-        }
-        s_q[4 * TF_MSDA_MAX_LEVELS + L] = acc;
-    }
-    __syncthreads();
-    const int nq = s_q[4 * TF_MSDA_MAX_LEVELS + L];   // <= kV4Pairs (host computed the maximum)
-
-    // this lane's query (tile-local index = thread / 2; level-major, row-major inside the tile)
-    const int tq = threadIdx.x >> 1, half = threadIdx.x & 1;
-    int q = -1;
-    if (tq < nq) {
-        int l = 0;
-        while (l + 1 < L && tq >= s_q[4 * TF_MSDA_MAX_LEVELS + l + 1]) ++l;
-        const int r = tq - s_q[4 * TF_MSDA_MAX_LEVELS + l];
-        const int nx = s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l];
-        const int yy = s_q[l] + r / nx, xx = s_q[2 * TF_MSDA_MAX_LEVELS + l] + r % nx;
-        q = s_tab[2 * TF_MSDA_MAX_LEVELS + l] + yy * s_tab[TF_MSDA_MAX_LEVELS + l] + xx;
-    }
-    const long long pair = ((long long)b * S + max(q, 0)) * M + m;
-    const int LP = L * PT;
-    const float *lp_base = loc + pair * LP * 2;
-    const float *ap_base = attn + pair * LP;
-
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const unsigned rowbytes = (unsigned)(M * D) * 4u;
-    const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(value), 0, value_bytes, 0x00020000);
-
-    struct Geom {
-        int H, W, wy0, wx0, wy1, wx1, ww, nrows;
-        unsigned lvl_base, win_off;   // win_off: byte offset of the level's window inside s_rows
-    };
-    auto level_geom = [&](int l) {
-        Geom g;
-        g.H = s_tab[l];
-        g.W = s_tab[TF_MSDA_MAX_LEVELS + l];
-        int wy0 = (int)__builtin_floorf((float)y0t * g.H / H0 - 0.5f) - tg.HY;
-        int wy1 = (int)__builtin_floorf((float)y1t * g.H / H0 - 0.5f) + 1 + tg.HY;
-        int wx0 = (int)__builtin_floorf((float)x0t * g.W / W0 - 0.5f) - tg.HX;
-        int wx1 = (int)__builtin_floorf((float)x1t * g.W / W0 - 0.5f) + 1 + tg.HX;
-        g.wy0 = max(wy0, 0);
-        g.wx0 = max(wx0, 0);
-        wy1 = min(wy1, g.H - 1);
-        g.wx1 = min(wx1, g.W - 1);
-        g.ww = g.wx1 - g.wx0 + 1;
-        const int cap = (l & 1) ? tg.cap_odd : tg.cap_even;
-        int wh = wy1 - g.wy0 + 1;
-        if (wh * g.ww > cap) wh = cap / g.ww;            // cap >= ww is ensured by the host
-        g.wy1 = g.wy0 + wh - 1;
-        g.nrows = wh * g.ww;
-        g.lvl_base = head_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + l] * rowbytes;
-        g.win_off = kStride * (1u + ((l & 1) ? (unsigned)tg.cap_even : 0u));
-        return g;
-    };
-
-    // window of level l -> LDS by LDS-DMA: one wave-instruction moves 64 sixteen-byte slots (1 KiB of
-    // LDS, contiguous) gathered from 64 lane-supplied global offsets; padding slots and slots past
-    // the window get an out-of-range offset (the hardware writes zeros).
-    auto issue_window_dma = [&](const Geom &g) {
-        if (tg.debug == 1) return;
-        const int nslots = g.nrows * kSlots;
-        const float inv_ww = 1.0f / (float)g.ww;
-        for (int chunk = wave; chunk * 64 < nslots; chunk += kV4Waves) {
-            const int sidx = chunk * 64 + lane;
-            const int row = sidx / kSlots, c = sidx - row * kSlots;
-            int wy = (int)(((float)row + 0.5f) * inv_ww);      // exact for row < 2^22
-            const int wx = row - wy * g.ww;
-            const unsigned off = (row < g.nrows && c < NCH)
-                ? g.lvl_base + (unsigned)((g.wy0 + wy) * g.W + g.wx0 + wx) * rowbytes + (unsigned)c * 16u
-                : kOobOffset;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsrc, (__attribute__((address_space(3))) void *)(s_rows + g.win_off + chunk * 1024),
-                16, off, 0, 0, 0);
-        }
-    };
-
-    f32x4_t acc[kMine];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dv = threadIdx.x & 7, sub = dv & 3, which = dv >> 2;
+    int qoff[kWinLevels + 1];   // first tile-local index of every level's queries
+    qoff[0] = 0;
 #pragma unroll
-    for (int k = 0; k < kMine; ++k) acc[k] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < kWinLevels; ++l)
+        qoff[l + 1] = qoff[l] + (l < L ? (s_q[TF_MSDA_MAX_LEVELS + l] - s_q[l]) *
+                                             (s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l])
+                                       : 0);
+    const int nq = qoff[kWinLevels];   // <= kWinMaxQueries (the host checked the maximum)
 
-    Geom gnext = level_geom(0);
-    f32x4_t lxy0 = *reinterpret_cast<const f32x4_t *>(lp_base);
-    f32x4_t lxy1 = *reinterpret_cast<const f32x4_t *>(lp_base + 4);
-    f32x4_t law = *reinterpret_cast<const f32x4_t *>(ap_base);
-    issue_window_dma(gnext);
-    for (int l = 0; l < L; ++l) {
-        const Geom g = gnext;
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA + location loads landed
-        __syncthreads();      // ... everybody's; and everybody is done gathering level l-1
-        const f32x4_t cxy0 = lxy0, cxy1 = lxy1, caw = law;
-        if (l + 1 < L) {      // next level streams into the other window while this one is gathered
-            gnext = level_geom(l + 1);
-            lxy0 = *reinterpret_cast<const f32x4_t *>(lp_base + (size_t)(l + 1) * PT * 2);
-            lxy1 = *reinterpret_cast<const f32x4_t *>(lp_base + (size_t)(l + 1) * PT * 2 + 4);
-            law = *reinterpret_cast<const f32x4_t *>(ap_base + (size_t)(l + 1) * PT);
-            issue_window_dma(gnext);
+    // ---- the queries of this lane's group, one per pass; their sampling points ------------------
+    long long bqs[kWinPasses];
+    bool live[kWinPasses];
+    float sx[kWinPasses][LPAIRS], sy[kWinPasses][LPAIRS], sa[kWinPasses][LPAIRS];
+#pragma unroll
+    for (int ps = 0; ps < kWinPasses; ++ps) {
+        const int tq = ps * kWinPairs + (threadIdx.x >> 3);
+        int q = 0;
+        live[ps] = tq < nq;
+        if (live[ps]) {
+            int l = 0, base = 0;
+#pragma unroll
+            for (int k = 1; k < kWinLevels; ++k)
+                if (tq >= qoff[k] && k < L) {
+                    l = k;
+                    base = qoff[k];
+                }
+            const int r = tq - base;
+            const int nx = s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l];
+            const int yy = r / nx, xx = r - yy * nx;
+            q = s_tab[2 * TF_MSDA_MAX_LEVELS + l] + (s_q[l] + yy) * s_tab[TF_MSDA_MAX_LEVELS + l] +
+                s_q[2 * TF_MSDA_MAX_LEVELS + l] + xx;
         }
-        if (q < 0 || tg.debug == 2) continue;  // no barrier below this point inside the iteration
-
-        const float Wf = (float)g.W, Hf = (float)g.H;
-        const float lx[4] = {cxy0.x, cxy0.z, cxy1.x, cxy1.z};
-        const float ly[4] = {cxy0.y, cxy0.w, cxy1.y, cxy1.w};
-        const float aw[4] = {caw.x, caw.y, caw.z, caw.w};
-        const unsigned char *rbase = s_rows + half * 16;
+        bqs[ps] = (long long)b * S + q;
+        const long long pair = bqs[ps] * M + m;
 #pragma unroll
-        for (int p = 0; p < PT; ++p) {
-            const float xr = __builtin_fmaf(lx[p], Wf, -0.5f);   // cuh:227-228, single rounding
-            const float yr = __builtin_fmaf(ly[p], Hf, -0.5f);
-            const bool in = (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);  // cuh:229
-            const float x = in ? xr : 0.f, y = in ? yr : 0.f;
-            const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
-            const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
-            const int x0 = (int)xf, y0 = (int)yf;
-            const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= g.W - 1);
-            const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= g.H - 1);
-            // lowest / highest VALID tap coordinate must lie inside the staged window
-            const int xlo = kx0 ? x0 : x0 + 1, xhi = kx1 ? x0 + 1 : x0;
-            const int ylo = ky0 ? y0 : y0 + 1, yhi = ky1 ? y0 + 1 : y0;
-            const bool staged = !in || (xlo >= g.wx0 && xhi <= g.wx1 && ylo >= g.wy0 && yhi <= g.wy1);
-            const float w1 = gy * gx * aw[p], w2 = gy * fx * aw[p];
-            const float w3 = fy * gx * aw[p], w4 = fy * fx * aw[p];
-            const unsigned o = g.win_off + (unsigned)((y0 - g.wy0) * g.ww + (x0 - g.wx0)) * kStride;
-            const unsigned o1 = (staged && ky0 && kx0) ? o : 0u;                 // 0 = the zero row
-            const unsigned o2 = (staged && ky0 && kx1) ? o + kStride : 0u;
-            const unsigned o3 = (staged && ky1 && kx0) ? o + (unsigned)g.ww * kStride : 0u;
-            const unsigned o4 = (staged && ky1 && kx1) ? o + (unsigned)(g.ww + 1) * kStride : 0u;
-#pragma unroll
-            for (int k = 0; k < kMine; ++k) {
-                if (2 * k + 1 >= NCH && half) break;     // odd lane has one slice less when NCH is odd
-                const f32x4_t v1 = *reinterpret_cast<const f32x4_t *>(rbase + o1 + k * 32);
-                const f32x4_t v2 = *reinterpret_cast<const f32x4_t *>(rbase + o2 + k * 32);
-                const f32x4_t v3 = *reinterpret_cast<const f32x4_t *>(rbase + o3 + k * 32);
-                const f32x4_t v4 = *reinterpret_cast<const f32x4_t *>(rbase + o4 + k * 32);
-                acc[k] += v1 * w1;
-                acc[k] += v2 * w2;
-                acc[k] += v3 * w3;
-                acc[k] += v4 * w4;
+        for (int i = 0; i < LPAIRS; ++i) {
+            const int ml = 2 * i + which;
+            const int s = (ml < L ? ml : 0) * PT + sub;
+            if constexpr (!FUSED) {
+                const float2 xy = *reinterpret_cast<const float2 *>(da.loc + (pair * LP + s) * 2);
+                sx[ps][i] = xy.x;
+                sy[ps][i] = xy.y;
+                sa[ps][i] = da.attn[pair * LP + s];
+            } else {
+                const float *row = da.fa.qproj + bqs[ps] * da.fa.ld;
+                const float2 off = *reinterpret_cast<const float2 *>(row + da.fa.off_col + (m * LP + s) * 2);
+                sx[ps][i] = off.x;
+                sy[ps][i] = off.y;
+                sa[ps][i] = ml < L ? row[da.fa.logit_col + m * LP + s] : -__builtin_inff();
             }
-            if (__any(in && !staged)) {   // rare: the point left the window -> global gather for it
-                const bool gl = in && !staged;
-                const int r0 = y0 * g.W + x0;
-                const unsigned hb = (unsigned)half * 16u;
-                const unsigned b1 = (gl && ky0 && kx0) ? g.lvl_base + (unsigned)r0 * rowbytes + hb : kOobOffset;
-                const unsigned b2 = (gl && ky0 && kx1) ? g.lvl_base + (unsigned)(r0 + 1) * rowbytes + hb : kOobOffset;
-                const unsigned b3 = (gl && ky1 && kx0) ? g.lvl_base + (unsigned)(r0 + g.W) * rowbytes + hb : kOobOffset;
-                const unsigned b4 = (gl && ky1 && kx1) ? g.lvl_base + (unsigned)(r0 + g.W + 1) * rowbytes + hb : kOobOffset;
+        }
+    }
+    if constexpr (FUSED) {
+#pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
 #pragma unroll
-                for (int k = 0; k < kMine; ++k) {
-                    if (2 * k + 1 >= NCH && half) break;
-                    acc[k] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b1 == kOobOffset ? b1 : b1 + k * 32, 0, 0)) * w1;
-                    acc[k] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b2 == kOobOffset ? b2 : b2 + k * 32, 0, 0)) * w2;
-                    acc[k] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b3 == kOobOffset ? b3 : b3 + k * 32, 0, 0)) * w3;
-                    acc[k] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc, b4 == kOobOffset ? b4 : b4 + k * 32, 0, 0)) * w4;
+        for (int ps = 0; ps < kWinPasses; ++ps) {
+            float mx = sa[ps][0];
+#pragma unroll
+            for (int i = 1; i < LPAIRS; ++i) mx = fmaxf(mx, sa[ps][i]);
+            mx = fmaxf(mx, __shfl_xor(mx, 1));
+            mx = fmaxf(mx, __shfl_xor(mx, 2));
+            mx = fmaxf(mx, __shfl_xor(mx, 4));
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < LPAIRS; ++i) {
+                sa[ps][i] = (2 * i + which < L) ? __expf(sa[ps][i] - mx) : 0.f;
+                sum += sa[ps][i];
+            }
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            sum += __shfl_xor(sum, 4);
+#pragma unroll
+            for (int i = 0; i < LPAIRS; ++i) {
+                sa[ps][i] = sa[ps][i] / sum;
+                const int ml = (2 * i + which < L) ? 2 * i + which : 0;
+                const float *rp = da.fa.ref + (bqs[ps] * L + ml) * da.fa.ref_dim;
+                if (da.fa.ref_dim == 2) {
+                    sx[ps][i] = rp[0] + sx[ps][i] / (float)s_tab[ml];                       // x / H_l
+                    sy[ps][i] = rp[1] + sy[ps][i] / (float)s_tab[TF_MSDA_MAX_LEVELS + ml];  // y / W_l
+                } else {
+                    sx[ps][i] = rp[0] + sx[ps][i] / (float)PT * rp[2] * 0.5f;
+                    sy[ps][i] = rp[1] + sy[ps][i] / (float)PT * rp[3] * 0.5f;
                 }
             }
         }
     }
-    if (q >= 0) {
-        float *op = out + pair * D + half * 4;
+
+    // ---- phase A: bounding box of the valid taps, per level ------------------------------------
+    {
+        int mnx[LPAIRS], mxx[LPAIRS], mny[LPAIRS], mxy[LPAIRS];
 #pragma unroll
-        for (int k = 0; k < kMine; ++k) {
-            if (2 * k + 1 >= NCH && half) break;
-            *reinterpret_cast<f32x4_t *>(op + k * 8) = acc[k];
+        for (int i = 0; i < LPAIRS; ++i) {
+            mnx[i] = INT_MAX, mny[i] = INT_MAX, mxx[i] = INT_MIN, mxy[i] = INT_MIN;
+            const int ml = (2 * i + which < L) ? 2 * i + which : 0;
+            const int H = s_tab[ml], W = s_tab[TF_MSDA_MAX_LEVELS + ml];
+            const float Wf = (float)W, Hf = (float)H;
+#pragma unroll
+            for (int ps = 0; ps < kWinPasses; ++ps) {
+                const float xr = __builtin_fmaf(sx[ps][i], Wf, -0.5f);
+                const float yr = __builtin_fmaf(sy[ps][i], Hf, -0.5f);
+                const bool in = live[ps] && (2 * i + which < L) && (yr > -1.f) && (xr > -1.f) &&
+                                (yr < Hf) && (xr < Wf);
+                const int x0 = (int)__builtin_floorf(in ? xr : 0.f), y0 = (int)__builtin_floorf(in ? yr : 0.f);
+                const int xlo = x0 >= 0 ? x0 : x0 + 1, xhi = (x0 + 1 <= W - 1) ? x0 + 1 : x0;
+                const int ylo = y0 >= 0 ? y0 : y0 + 1, yhi = (y0 + 1 <= H - 1) ? y0 + 1 : y0;
+                if (in) {
+                    mnx[i] = min(mnx[i], xlo);
+                    mxx[i] = max(mxx[i], xhi);
+                    mny[i] = min(mny[i], ylo);
+                    mxy[i] = max(mxy[i], yhi);
+                }
+            }
+            // lanes with the same `which` (bit 2 of the lane id) hold points of the same level: reduce
+            // over lane bits 0, 1 and 3 with DPP (quad_perm xor 1, xor 2, row_ror:8), then one LDS
+            // atomic per 16-lane row and level
+#define TF_DPP(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xF, 0xF, true)
+#pragma unroll
+            for (int st = 0; st < 3; ++st) {
+                const int c0 = 0xB1, c1 = 0x4E, c2 = 0x128;
+                mnx[i] = min(mnx[i], st == 0 ? TF_DPP(mnx[i], c0) : st == 1 ? TF_DPP(mnx[i], c1) : TF_DPP(mnx[i], c2));
+                mxx[i] = max(mxx[i], st == 0 ? TF_DPP(mxx[i], c0) : st == 1 ? TF_DPP(mxx[i], c1) : TF_DPP(mxx[i], c2));
+                mny[i] = min(mny[i], st == 0 ? TF_DPP(mny[i], c0) : st == 1 ? TF_DPP(mny[i], c1) : TF_DPP(mny[i], c2));
+                mxy[i] = max(mxy[i], st == 0 ? TF_DPP(mxy[i], c0) : st == 1 ? TF_DPP(mxy[i], c1) : TF_DPP(mxy[i], c2));
+            }
+#undef TF_DPP
+            if ((lane & 0xB) == 0 && 2 * i + which < L && mnx[i] != INT_MAX) {
+                const int l = 2 * i + which;
+                atomicMin(&s_bb[4 * l + 0], mnx[i]);
+                atomicMax(&s_bb[4 * l + 1], mxx[i]);
+                atomicMin(&s_bb[4 * l + 2], mny[i]);
+                atomicMax(&s_bb[4 * l + 3], mxy[i]);
+            }
         }
+    }
+    __syncthreads();
+
+    // ---- phase B: window geometry (wave-uniform) and LDS-DMA staging ---------------------------
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;
+    const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(da.value), 0, da.value_bytes, 0x00020000);
+    {
+        const int H0 = __builtin_amdgcn_readfirstlane(s_tab[0]);
+        const int W0 = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS]);
+        const float rH0 = __builtin_amdgcn_rcpf((float)H0), rW0 = __builtin_amdgcn_rcpf((float)W0);
+        const int y0t = ty * wg.TH, y1t = min(H0, y0t + wg.TH);
+        const int x0t = tx * wg.TW, x1t = min(W0, x0t + wg.TW);
+        int used = 0;
+        for (int l = 0; l < L; ++l) {
+            const int H = __builtin_amdgcn_readfirstlane(s_tab[l]);
+            const int W = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS + l]);
+            const unsigned lvl_base =
+                head_base + (unsigned)__builtin_amdgcn_readfirstlane(s_tab[2 * TF_MSDA_MAX_LEVELS + l]) * rowbytes;
+            const int bx0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 0]);
+            const int bx1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 1]);
+            const int by0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 2]);
+            const int by1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 3]);
+            // nominal footprint of the tile in this level (a clamp only: precision is irrelevant)
+            const int ny0 = (int)__builtin_floorf((float)y0t * (float)H * rH0 - 0.5f) - wg.HY;
+            const int ny1 = (int)__builtin_floorf((float)y1t * (float)H * rH0 - 0.5f) + 1 + wg.HY;
+            const int nx0 = (int)__builtin_floorf((float)x0t * (float)W * rW0 - 0.5f) - wg.HX;
+            const int nx1 = (int)__builtin_floorf((float)x1t * (float)W * rW0 - 0.5f) + 1 + wg.HX;
+            const int wx0 = max(max(bx0, nx0), 0), wx1 = min(min(bx1, nx1), W - 1);
+            const int wy0 = max(max(by0, ny0), 0), wy1 = min(min(by1, ny1), H - 1);
+            int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
+            if (ww <= 0 || wh <= 0 || bx0 == INT_MAX) {
+                ww = 1;
+                wh = 0;
+            }
+            const int avail = wg.cap_rows - used;
+            if (wh * ww > avail) wh = avail / ww;   // keep the top of the box
+            const int roff = 1 + used;              // LDS row index of the window (row 0 = zeros)
+            const int nrows = wh * ww;
+            const int nchunks = (nrows + 7) >> 3;   // one DMA wave-instruction = 8 rows of 128 B
+            used += nchunks * 8;
+            if (lane == 0) {
+                s_geo[(wave * kWinLevels + l) * 2] =
+                    u32x4_t{(unsigned)wx0, (unsigned)wy0, (unsigned)(wx0 + ww - 1), (unsigned)(wy0 + wh - 1)};
+                s_geo[(wave * kWinLevels + l) * 2 + 1] = u32x4_t{(unsigned)ww, (unsigned)roff, lvl_base, 0u};
+            }
+            const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
+            for (int c = wave; c < nchunks; c += kWinWaves) {
+                const int row = c * 8 + (lane >> 3), col = lane & 7;
+                int wy = (int)(((float)row + 0.5f) * inv_ww);
+                int wx = row - wy * ww;
+                if (wx < 0) { --wy; wx += ww; }             // rcp is approximate: fix up the quotient
+                if (wx >= ww) { ++wy; wx -= ww; }
+                const unsigned off = row < nrows
+                    ? lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)col * 16u
+                    : kOobOffset;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128),
+                    16, off, 0, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA landed
+    __syncthreads();                      // ... everybody's
+
+    // ---- phase C: gather -------------------------------------------------------------------------
+    const int xbase = wave * 72 + (lane >> 3) * 9;   // exchange slot of lane 0 of this group
+    const unsigned char *rb = s_rows + dv * 16;
+    const unsigned dvb = (unsigned)dv * 16u;
+#pragma unroll
+    for (int ps = 0; ps < kWinPasses; ++ps) {
+        if (ps * kWinPairs >= nq) break;   // uniform
+        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < LPAIRS; ++i) {
+            if (2 * i >= L) break;   // uniform
+            // produce: taps of this lane's point of the level pair (2i, 2i+1)
+            const bool have = 2 * i + which < L;
+            const int mlc = have ? 2 * i + which : 0;
+            const int H = s_tab[mlc], W = s_tab[TF_MSDA_MAX_LEVELS + mlc];
+            const u32x4_t ga = s_geo[(wave * kWinLevels + mlc) * 2], gb = s_geo[(wave * kWinLevels + mlc) * 2 + 1];
+            const int wx0 = (int)ga.x, wy0 = (int)ga.y, wx1 = (int)ga.z, wy1 = (int)ga.w;
+            const int ww = (int)gb.x, roff = (int)gb.y;
+            const unsigned lvl_base = gb.z;
+            const float Wf = (float)W, Hf = (float)H;
+            const float xr = __builtin_fmaf(sx[ps][i], Wf, -0.5f);   // cuh:227-228, single rounding
+            const float yr = __builtin_fmaf(sy[ps][i], Hf, -0.5f);
+            const bool in = have && live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
+            const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+            const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+            const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+            const int x0 = (int)xf, y0 = (int)yf;
+            const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
+            const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
+            // lowest / highest VALID tap coordinate must lie inside the staged window
+            const int xlo = kx0 ? x0 : x0 + 1, xhi = kx1 ? x0 + 1 : x0;
+            const int ylo = ky0 ? y0 : y0 + 1, yhi = ky1 ? y0 + 1 : y0;
+            const bool staged = in && xlo >= wx0 && xhi <= wx1 && ylo >= wy0 && yhi <= wy1;
+            const bool fb = in && !staged;
+            const unsigned lo = (unsigned)(roff + (y0 - wy0) * ww + (x0 - wx0)) * 128u;
+            const u32x4_t plo = {(staged && ky0 && kx0) ? lo : 0u,                          // 0 = zero row
+                                 (staged && ky0 && kx1) ? lo + 128u : 0u,
+                                 (staged && ky1 && kx0) ? lo + (unsigned)ww * 128u : 0u,
+                                 (staged && ky1 && kx1) ? lo + (unsigned)(ww + 1) * 128u : 0u};
+            const float a = in ? sa[ps][i] : 0.f;
+            const f32x4_t pw = {gy * gx * a, gy * fx * a, fy * gx * a, fy * fx * a};
+            const bool wave_fb = __any(fb);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            s_xo[xbase + dv] = plo;
+            s_xw[xbase + dv] = pw;
+            if (wave_fb) {
+                const int r0 = y0 * W + x0;
+                // staged / invalid taps: kOobBase + dv*16 is still out of range -> hardware zero
+                s_xg[xbase + dv] = u32x4_t{
+                    (fb && ky0 && kx0) ? lvl_base + (unsigned)r0 * rowbytes : kOobBase,
+                    (fb && ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase,
+                    (fb && ky1 && kx0) ? lvl_base + (unsigned)(r0 + W) * rowbytes : kOobBase,
+                    (fb && ky1 && kx1) ? lvl_base + (unsigned)(r0 + W + 1) * rowbytes : kOobBase};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+
+            // consume: the 8 points of the level pair, produced by lanes 0..7 of the group
+#pragma unroll
+            for (int ll = 0; ll < 2; ++ll) {
+                if (2 * i + ll >= L) break;   // uniform
+#pragma unroll
+                for (int kk = 0; kk < 4; kk += 2) {   // two points (8 taps) in flight per lane
+                    f32x4_t v[2][4];
+                    f32x4_t w[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const u32x4_t o = s_xo[xbase + ll * 4 + kk + k];
+                        w[k] = s_xw[xbase + ll * 4 + kk + k];
+                        v[k][0] = *reinterpret_cast<const f32x4_t *>(rb + o.x);
+                        v[k][1] = *reinterpret_cast<const f32x4_t *>(rb + o.y);
+                        v[k][2] = *reinterpret_cast<const f32x4_t *>(rb + o.z);
+                        v[k][3] = *reinterpret_cast<const f32x4_t *>(rb + o.w);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        acc += v[k][0] * w[k].x;
+                        acc += v[k][1] * w[k].y;
+                        acc += v[k][2] * w[k].z;
+                        acc += v[k][3] * w[k].w;
+                    }
+                    if (wave_fb) {   // some point of this wave left its window: global gather for those
+                        u32x4_t g[2][4];
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const u32x4_t o = s_xg[xbase + ll * 4 + kk + k];
+                            g[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + dvb, 0, 0);
+                            g[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + dvb, 0, 0);
+                            g[k][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + dvb, 0, 0);
+                            g[k][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + dvb, 0, 0);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            acc += __builtin_bit_cast(f32x4_t, g[k][0]) * w[k].x;
+                            acc += __builtin_bit_cast(f32x4_t, g[k][1]) * w[k].y;
+                            acc += __builtin_bit_cast(f32x4_t, g[k][2]) * w[k].z;
+                            acc += __builtin_bit_cast(f32x4_t, g[k][3]) * w[k].w;
+                        }
+                    }
+                }
+            }
+        }
+        if (live[ps]) *reinterpret_cast<f32x4_t *>(da.out + (bqs[ps] * M + m) * D + dv * 4) = acc;
     }
 }
 
@@ -1217,21 +1342,24 @@ bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, in
     return true;
 }
 
-// The LDS-tiled encoder kernel is opt-in (tf_msda_set_tiled(1) or TF_MSDA_TILED=1): on MI355X it is
-// currently slower than the row-gather kernel (81 vs 58 us at the cfg-2 encoder shape).
-int g_tiled_mode = -1;   // -1: follow the environment, 0: off, 1: on
-bool tiled_enabled()
+// The LDS-window encoder kernel is opt-in (tf_msda_set_tiled(1) or TF_MSDA_TILED=1).  Measured at the
+// cfg-2 encoder shape (HIP graph of 50 launches, us per launch; init / local / uniform sampling):
+//   msda_fwd_f32_direct (default)        53 / 61 / 66
+//   msda_fwd_f32_win                     48 / 73 / 103
+//   (earlier fixed-halo tiled kernel)    66 / 107 / 215   -- removed
+// DESIGN.md says where the time goes (LDS pipe + per-workgroup latencies at 2 workgroups per CU).
+int g_tiled_mode = -1;   // -1: follow the environment, 0: off, 1: msda_fwd_f32_win
+int tiled_mode()
 {
-    if (g_tiled_mode >= 0) return g_tiled_mode != 0;
-    static const int env_on = [] { const char *e = getenv("TF_MSDA_TILED"); return (e && e[0] == '1') ? 1 : 0; }();
-    return env_on != 0;
+    if (g_tiled_mode >= 0) return g_tiled_mode;
+    static const int env_mode = [] {
+        const char *e = getenv("TF_MSDA_TILED");
+        return (e && e[0] >= '1' && e[0] <= '9') ? 1 : 0;
+    }();
+    return env_mode;
 }
 
-// Tile / window plan of msda_fwd_f32_tiled.  Returns false when the shape does not suit the kernel
-// (then the row-gather kernels are used).  Everything here is a performance heuristic.
-constexpr size_t kTiledLdsBudget = 160 * 1024;   // one 512-thread workgroup per CU owns the whole LDS
-constexpr int kTiledHeaderBytes = kLevelTableBytes + (5 * TF_MSDA_MAX_LEVELS + 4) * (int)sizeof(int);
-
+// Largest number of queries any TH x TW tile holds (exact, same integer partition as the kernel).
 long long tile_max_queries(const LevelTable &lt, int L, int th, int tw)
 {
     const int H0 = lt.H[0], W0 = lt.W[0];
@@ -1251,51 +1379,85 @@ long long tile_max_queries(const LevelTable &lt, int L, int th, int tw)
     return max_nq;
 }
 
-bool plan_tiles(const LevelTable &lt, int L, int D, TileGeom *tg, size_t *lds)
+// Tile plan of msda_fwd_f32_win: the tile with the most queries that still fits kWinMaxQueries.
+bool plan_win(const LevelTable &lt, int L, int D, int P, WinGeom *wg, size_t *lds)
 {
-    if (!tiled_enabled()) return false;
-    if (D != 32 && D != 36) return false;      // instantiated row widths (hidden 256 / 288, 8 heads)
-    const int nch = D / 4, slots = (nch % 2) ? nch : nch + 1;
-    const size_t row = (size_t)slots * 16;
-    int hy = 3, hx = 7;   // default halo: the (H,W)-divisor quirk stretches x offsets by W/H (~1.67)
-    int th = 0, tw = 16;
+    if (tiled_mode() == 0 || D != 32 || P != 4 || L > kWinLevels) return false;
+    int hy = 6, hx = 10, th = 0, tw = 0, rows = 408;   // 408 rows (80 KB with the header): two workgroups per CU
     if (const char *e = getenv("TF_MSDA_HALO")) sscanf(e, "%d,%d", &hy, &hx);
     if (const char *e = getenv("TF_MSDA_TILE")) sscanf(e, "%d,%d", &th, &tw);
-    if (hy < 0 || hx < 0 || th < 0 || tw < 1) return false;
-    const int H0 = lt.H[0], W0 = lt.W[0];
-    // tallest tile (most queries per workgroup) whose queries fit the lanes and whose two largest
-    // windows (even / odd levels) fit the LDS
-    const int th_first = th ? th : 16, th_last = th ? th : 4;
-    for (int cand = th_first; cand >= th_last; --cand) {
-        const long long nq = tile_max_queries(lt, L, cand, tw);
-        if (nq < 1 || nq > kV4Pairs) continue;
-        long long cap[2] = {1, 1}, max_ww = 1;
-        for (int l = 0; l < L; ++l) {
-            long long wh = ((long long)cand * lt.H[l] + H0 - 1) / H0 + 2 * hy + 3;
-            long long ww = ((long long)tw * lt.W[l] + W0 - 1) / W0 + 2 * hx + 3;
-            if (wh > lt.H[l]) wh = lt.H[l];
-            if (ww > lt.W[l]) ww = lt.W[l];
-            if (wh * ww > cap[l & 1]) cap[l & 1] = wh * ww;
-            if (ww > max_ww) max_ww = ww;
-        }
-        // windows are filled in whole 1-KiB DMA chunks: round the capacities up to 64 slots
-        for (int k = 0; k < 2; ++k) cap[k] = ((cap[k] * slots + 63) / 64 * 64 + slots - 1) / slots;
-        const size_t need = (size_t)kTiledHeaderBytes + row * (size_t)(1 + cap[0] + cap[1]) + 1024;
-        if (need > kTiledLdsBudget) continue;
-        tg->TH = cand;
-        tg->TW = tw;
-        tg->HY = hy;
-        tg->HX = hx;
-        tg->tiles_y = (H0 + cand - 1) / cand;
-        tg->tiles_x = (W0 + tw - 1) / tw;
-        tg->cap_even = (int)cap[0];
-        tg->cap_odd = (int)cap[1];
-        tg->debug = 0;
-        if (const char *e = getenv("TF_MSDA_TILED_DEBUG")) tg->debug = atoi(e);
+    if (const char *e = getenv("TF_MSDA_WIN_ROWS")) rows = atoi(e);
+    rows &= ~7;
+    if (hy < 0 || hx < 0 || th < 0 || tw < 0 || rows < 8) return false;
+    for (int l = 0; l < L; ++l)
+        if (lt.H[l] >= 32768 || lt.W[l] >= 32768) return false;   // 32-bit tile arithmetic in the kernel
+    const size_t need = (size_t)kWinRowsOffset + (size_t)(1 + rows) * 128;
+    if (need > 160 * 1024) return false;
+    // the search below walks every tile of every candidate: remember the last plan of this thread
+    struct Memo {
+        bool valid = false, ok = false;
+        int L = 0;
+        LevelTable lt;
+        WinGeom wg;
+    };
+    static thread_local Memo memo;
+    if (memo.valid && memo.L == L && memcmp(&memo.lt, &lt, sizeof(lt)) == 0) {
+        *wg = memo.wg;
         *lds = need;
-        return true;
+        return memo.ok;
     }
-    return false;
+    memo.valid = true;
+    memo.ok = false;
+    memo.L = L;
+    memo.lt = lt;
+    long long best = 0;
+    int bth = 0, btw = 0;
+    const int tws[5] = {8, 16, 4, 2, 1};
+    for (int k = 0; k < 5; ++k) {
+        const int ctw = tw ? tw : tws[k];
+        for (int cth = th ? th : 16; cth >= (th ? th : 1); --cth) {
+            const long long nq = tile_max_queries(lt, L, cth, ctw);
+            if (nq >= 1 && nq <= kWinMaxQueries && nq > best) {
+                best = nq;
+                bth = cth;
+                btw = ctw;
+            }
+        }
+        if (tw || best >= kWinMaxQueries * 2 / 3) break;   // a row of 8 queries per wave is preferred
+    }
+    if (!best) return false;
+    wg->TH = bth;
+    wg->TW = btw;
+    wg->HY = hy;
+    wg->HX = hx;
+    wg->tiles_y = (lt.H[0] + bth - 1) / bth;
+    wg->tiles_x = (lt.W[0] + btw - 1) / btw;
+    wg->cap_rows = rows;
+    *lds = need;
+    memo.wg = *wg;
+    memo.ok = true;
+    return true;
+}
+
+// Launch msda_fwd_f32_win for encoder-shaped calls (Lq == S, host shapes).  Returns false if not taken.
+bool launch_win(bool fused, const DirectArgs &da, const LevelTable &lt, int N, int D, int P,
+                hipStream_t stream, hipError_t *err)
+{
+    if (da.Lq != da.S) return false;
+    WinGeom wg;
+    size_t lds = 0;
+    if (!plan_win(lt, da.L, D, P, &wg, &lds)) return false;
+    const long long grid = (long long)N * wg.tiles_y * wg.tiles_x * da.M;
+    if (grid > 0x7fffffffLL) return false;
+    const void *fn = fused ? (const void *)&msda_fwd_f32_win<true> : (const void *)&msda_fwd_f32_win<false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[fused ? 1 : 0]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        attr_set[fused ? 1 : 0] = true;
+    }
+    void *argv[] = {(void *)&da, (void *)&lt, (void *)&wg};
+    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kWinThreads), argv, lds, stream);
+    return true;
 }
 
 // Launch msda_fwd_f32_direct when the shape qualifies (D == 32, P == 4, L <= 8).  Returns false if not.
@@ -1355,22 +1517,6 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
         if (pl.vec == 4 && (P == 1 || P == 2 || P == 4 || P == 8) &&
             buf_path_ok(lt, shapes_host != nullptr, N, S, M, D, L)) {
             const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
-            TileGeom tg;
-            size_t tiled_lds = 0;
-            if (shapes_host && Lq == S && P == 4 && is_aligned(loc, 16) && is_aligned(attn, 16) &&
-                plan_tiles(lt, L, D, &tg, &tiled_lds)) {
-                const long long grid = (long long)N * tg.tiles_y * tg.tiles_x * M;
-                if (grid <= 0x7fffffffLL) {
-                    const void *tfn = D == 32 ? (const void *)&msda_fwd_f32_tiled<4, 8>
-                                              : (const void *)&msda_fwd_f32_tiled<4, 9>;
-                    void *argv[] = {(void *)&value, (void *)&vbytes, (void *)&loc, (void *)&attn,
-                                    (void *)&out,   (void *)&lt,     (void *)&shapes_dev, (void *)&S,
-                                    (void *)&M,     (void *)&L,      (void *)&tg};
-                    e = hipLaunchKernel(tfn, dim3((unsigned)grid), dim3(kV4Threads), argv, tiled_lds,
-                                        stream);
-                    return record_hip(e);
-                }
-            }
             {
                 DirectArgs da{};
                 da.value = value;
@@ -1383,6 +1529,8 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                 da.L = L;
                 da.Lq = Lq;
                 da.nlq = (long long)N * Lq;
+                if (is_aligned(loc, 8) && shapes_dev == nullptr && launch_win(false, da, lt, N, D, P, stream, &e))
+                    return record_hip(e);
                 if (is_aligned(loc, 8) && launch_direct(false, da, lt, shapes_dev, D, P, stream, &e))
                     return record_hip(e);
             }
@@ -1441,6 +1589,8 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
         da.Lq = Lq;
         da.nlq = (long long)N * Lq;
         hipError_t de;
+        if (launch_win(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
+            return record_hip(de);
         if (launch_direct(true, da, lt, nullptr, D, P, static_cast<hipStream_t>(stream_v), &de))
             return record_hip(de);
     }
