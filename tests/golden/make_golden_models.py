@@ -44,7 +44,9 @@ def main():
             prev_features = None
             if args.multi_frame_attention:
                 _, _, prev_features, _, _ = model(prev, None, None)
-            if case == "cfg1_plain_detr":
+            if case in um.MASK_CASES:   # the reference's mask mix-in takes two arguments only
+                out, _, feats, memory, hs = model(img, target)
+            elif case == "cfg1_plain_detr":
                 out, _, feats, memory, hs = model(img, target)
             else:
                 out, _, feats, memory, hs = model(img, target, prev_features)
@@ -55,6 +57,15 @@ def main():
                    scores=res['scores'].numpy(), labels=res['labels'].numpy(),
                    boxes=res['boxes'].numpy(), weight_checksum=np.float64(checksum(model)),
                    feat_last=feats[-1].tensors.numpy())
+        if case in um.MASK_CASES:
+            size, orig = um.MASK_SIZES[case]
+            with torch.no_grad():
+                res = post['bbox'](out, torch.tensor([list(orig)]))
+                res = post['segm'](res, out, torch.tensor([list(orig)]), torch.tensor([list(size)]),
+                                   return_probs=True)
+            fix['pred_masks'] = out['pred_masks'].numpy()
+            # post-processed probabilities of 3 queries (all of them would be ~1 MB)
+            fix['post_masks'] = res[0]['masks'][:3].numpy().astype(np.float32)
         path = os.path.join(HERE, "model_%s.npz" % case)
         np.savez_compressed(path, **fix)
         print("%-28s logits%s boxes%s  -> %s (%d KB)" % (case, fix['pred_logits'].shape,

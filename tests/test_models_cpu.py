@@ -43,6 +43,12 @@ def run_case(case, device="cpu"):
             _, _, prev_features, _, _ = model(prev, None, None)
         out, _, feats, memory, hs = model(img, target, prev_features)
         res = post['bbox'](out, torch.tensor([[480, 640]], device=device))[0]
+        if case in um.MASK_CASES:
+            size, orig = um.MASK_SIZES[case]
+            seg = post['bbox'](out, torch.tensor([list(orig)], device=device))
+            seg = post['segm'](seg, out, torch.tensor([list(orig)], device=device),
+                               torch.tensor([list(size)], device=device), return_probs=True)
+            res['post_masks'] = seg[0]['masks']
     return model, out, res, feats
 
 
@@ -58,6 +64,13 @@ def compare_to_golden(case, model, out, res, feats, box_tol, logit_tol):
     np.testing.assert_allclose(res['boxes'].cpu().numpy(), z['boxes'], atol=box_tol * 640)
     f = feats[-1].tensors.cpu().numpy()
     np.testing.assert_allclose(f, z['feat_last'], atol=1e-3 * max(1.0, np.abs(z['feat_last']).max()))
+    if case in um.MASK_CASES:   # mask logits [B,Q,H/4,W/4] and post-processed probabilities
+        scale = max(1.0, float(np.abs(z['pred_masks']).max()))
+        np.testing.assert_allclose(out['pred_masks'].cpu().numpy(), z['pred_masks'],
+                                   atol=logit_tol * scale)
+        assert res['post_masks'].shape[1:] == (1,) + um.MASK_SIZES[case][1]
+        np.testing.assert_allclose(res['post_masks'][:3].cpu().numpy(), z['post_masks'],
+                                   atol=logit_tol)
 
 
 @pytest.mark.parametrize("case", list(um.MODEL_CASES))
@@ -107,6 +120,33 @@ def compare_tracker_to_golden(reid, tracker, rows, active, inactive, box_tol_px)
 def test_tracker_sequence_matches_reference(reid, oracle_op):
     tracker, rows, active, inactive = run_tracker(reid)
     compare_tracker_to_golden(reid, tracker, rows, active, inactive, box_tol_px=0.05)
+
+
+def run_mask_tracker(device="cpu", frames=3):
+    """cfg-5 path: Tracker.step on the mask-head model; -> {track id: {frame: result dict}}."""
+    model, post, args = um.build("cfg5_segm_tracking", factory.build_model, config.make_args,
+                                 device=device)
+    model.to(device)
+    model.tracking()
+    tracker = Tracker(model, post, config.tracker_cfg(), False)
+    tracker.reset()
+    with torch.no_grad():
+        for blob in um.tracker_sequence()[:frames]:
+            tracker.step(blob)
+    return tracker.get_results()
+
+
+def test_tracker_with_mask_head_produces_per_track_masks(oracle_op):
+    results = run_mask_tracker()
+    assert results
+    per_frame = {}
+    for tid, frames in results.items():
+        for f, r in frames.items():
+            assert r['mask'].shape == um.TRACKER_ORIG and r['mask'].dtype == np.bool_
+            per_frame.setdefault(f, []).append(r['mask'])
+    for f, masks in per_frame.items():   # a pixel belongs to at most one track (tracker.py:521-532)
+        assert np.stack(masks).sum(0).max() <= 1
+    assert any(m.any() for masks in per_frame.values() for m in masks)
 
 
 def test_state_dict_layout_of_cfg2_model():

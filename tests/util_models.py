@@ -9,7 +9,15 @@ MODEL_CASES = {
     "cfg4_multi_frame_tracking": (("deformable", "tracking", "multi_frame", "mot17"),
                                   dict(num_queries=60), (160, 224), 5),
     "cfg1_plain_detr": ((), dict(dataset="coco"), (160, 192), 0),
+    # BASELINE cfg 5 model path: mask head on the tracking detector (MOTS20) ...
+    "cfg5_segm_tracking": (("deformable", "tracking", "mots20"), dict(num_queries=24),
+                           (128, 160), 4),
+    # ... and the plain-DETR flavour of the head (single feature level, dense attention)
+    "cfg1_plain_detr_masks": (("coco_person_masks",), dict(num_queries=12), (96, 128), 0),
 }
+MASK_CASES = ("cfg5_segm_tracking", "cfg1_plain_detr_masks")
+MASK_SIZES = {"cfg5_segm_tracking": ((128, 160), (200, 250)),      # (padded input size, original size)
+              "cfg1_plain_detr_masks": ((96, 128), (150, 200))}
 
 TRACKER_FRAMES = 6
 TRACKER_IMG = (192, 256)

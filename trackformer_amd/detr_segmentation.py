@@ -1,0 +1,302 @@
+"""Instance-mask head on top of the (Deformable) DETR detectors (BASELINE cfg 5: MOTS20).
+
+Same surface as the reference's models/detr_segmentation.py:
+    DETRSegmBase (:29-71), DETRSegm / DeformableDETRSegm / DETRSegmTracking / DeformableDETRSegmTracking
+    (:75-99) with the (mask_kwargs, [tracking_kwargs,] detr_kwargs) constructor convention of
+    build_model, MaskHeadSmallConv (:106-181), MHAttentionMap (:184-222), PostProcessSegm (:225-263),
+    PostProcessPanoptic (:266-388) -- same parameter names, so reference checkpoints load unchanged
+    (`bbox_attention.{q,k}_linear`, `mask_head.{lay1..5,gn1..5,out_lay,adapter1..3}`).
+
+Differences, all result-preserving:
+  * forward() takes the `prev_features` argument the tracker passes (tracker.py:307 calls the
+    detector with three arguments; the reference's DETRSegmBase.forward only accepts two and cannot
+    be driven by its own Tracker) and hands it through to the detector.
+  * MaskHeadSmallConv never materialises the per-query copies of the image features
+    (`_expand`, :102-103): the first convolution is linear, so its image part is evaluated once per
+    image and only the 8 attention-map channels are convolved per query (33x fewer flops in that
+    layer for hidden 256), and the FPN adapters are broadcast over the queries instead of repeated.
+  * PostProcessSegm keeps the masks on the device of the model outputs (the reference moves all
+    Q masks to the host before resizing them).
+"""
+import io
+from collections import defaultdict
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import box_ops
+from .deformable_detr import DeformableDETR
+from .detr import DETR
+from .detr_tracking import DETRTrackingBase
+from .nested import NestedTensor
+
+
+class DETRSegmBase(nn.Module):
+    """Mix-in: adds `bbox_attention` + `mask_head` to a detector and `pred_masks` [B,Q,H/4,W/4]
+    (deformable: stride of backbone layer1) to its outputs."""
+
+    def __init__(self, freeze_detr=False):
+        # like the reference this does not call nn.Module.__init__: the detector base class,
+        # initialised first by the concrete subclasses, already did
+        if freeze_detr:
+            for param in self.parameters():
+                param.requires_grad_(False)
+        nheads = self.transformer.nhead
+        self.bbox_attention = MHAttentionMap(self.hidden_dim, self.hidden_dim, nheads, dropout=0.0)
+        self.mask_head = MaskHeadSmallConv(self.hidden_dim + nheads, self.fpn_channels,
+                                           self.hidden_dim)
+
+    def forward(self, samples: NestedTensor, targets: list = None, prev_features=None):
+        out, targets, features, memory, hs = super().forward(samples, targets, prev_features)
+
+        if isinstance(memory, list):   # deformable: per-level encoder memory
+            src, mask = features[-2].decompose()
+            src = self.input_proj[-3](src)
+            mask = F.interpolate(mask[None].float(), size=src.shape[-2:]).to(torch.bool)[0]
+            fpns = [features[-2].tensors, features[-3].tensors, features[-4].tensors]
+            memory = memory[-3]
+        else:
+            src, mask = features[-1].decompose()
+            src = self.input_proj(src)
+            fpns = [features[2].tensors, features[1].tensors, features[0].tensors]
+
+        bbox_mask = self.bbox_attention(hs[-1], memory, mask=mask)     # [B, Q, heads, h, w]
+        seg_masks = self.mask_head(src, bbox_mask, fpns)               # [B*Q, 1, H, W]
+        out["pred_masks"] = seg_masks.view(src.shape[0], hs.shape[2], seg_masks.shape[-2],
+                                           seg_masks.shape[-1])
+        return out, targets, features, memory, hs
+
+
+class DETRSegm(DETRSegmBase, DETR):
+    def __init__(self, mask_kwargs, detr_kwargs):
+        DETR.__init__(self, **detr_kwargs)
+        DETRSegmBase.__init__(self, **mask_kwargs)
+
+
+class DeformableDETRSegm(DETRSegmBase, DeformableDETR):
+    def __init__(self, mask_kwargs, detr_kwargs):
+        DeformableDETR.__init__(self, **detr_kwargs)
+        DETRSegmBase.__init__(self, **mask_kwargs)
+
+
+class DETRSegmTracking(DETRSegmBase, DETRTrackingBase, DETR):
+    def __init__(self, mask_kwargs, tracking_kwargs, detr_kwargs):
+        DETR.__init__(self, **detr_kwargs)
+        DETRTrackingBase.__init__(self, **tracking_kwargs)
+        DETRSegmBase.__init__(self, **mask_kwargs)
+
+
+class DeformableDETRSegmTracking(DETRSegmBase, DETRTrackingBase, DeformableDETR):
+    def __init__(self, mask_kwargs, tracking_kwargs, detr_kwargs):
+        DeformableDETR.__init__(self, **detr_kwargs)
+        DETRTrackingBase.__init__(self, **tracking_kwargs)
+        DETRSegmBase.__init__(self, **mask_kwargs)
+
+
+class MaskHeadSmallConv(nn.Module):
+    """Small FPN-style convolutional head with GroupNorm: [image features | attention maps] at stride
+    16 (deformable; 32 for plain DETR) -> one mask logit map per query at the stride of fpns[2]."""
+
+    def __init__(self, dim, fpn_dims, context_dim):
+        super().__init__()
+        inter = [dim, context_dim // 2, context_dim // 4, context_dim // 8, context_dim // 16,
+                 context_dim // 64]
+        self.lay1 = nn.Conv2d(dim, dim, 3, padding=1)
+        self.gn1 = nn.GroupNorm(8, dim)
+        self.lay2 = nn.Conv2d(dim, inter[1], 3, padding=1)
+        self.gn2 = nn.GroupNorm(8, inter[1])
+        self.lay3 = nn.Conv2d(inter[1], inter[2], 3, padding=1)
+        self.gn3 = nn.GroupNorm(8, inter[2])
+        self.lay4 = nn.Conv2d(inter[2], inter[3], 3, padding=1)
+        self.gn4 = nn.GroupNorm(8, inter[3])
+        self.lay5 = nn.Conv2d(inter[3], inter[4], 3, padding=1)
+        self.gn5 = nn.GroupNorm(8, inter[4])
+        self.out_lay = nn.Conv2d(inter[4], 1, 3, padding=1)
+        self.dim = dim
+        self.adapter1 = nn.Conv2d(fpn_dims[0], inter[1], 1)
+        self.adapter2 = nn.Conv2d(fpn_dims[1], inter[2], 1)
+        self.adapter3 = nn.Conv2d(fpn_dims[2], inter[3], 1)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+
+    @staticmethod
+    def _merge(x, fpn, num_queries):
+        """fpn [B,C,H,W] (or already [B*Q,C,H,W]) + nearest-upsampled x [B*Q,C,h,w]; the adapter
+        output is broadcast over the queries (the reference repeats it, :154-156)."""
+        x = F.interpolate(x, size=fpn.shape[-2:], mode="nearest")
+        if fpn.size(0) == x.size(0):
+            return fpn + x
+        return (x.view(fpn.size(0), num_queries, *x.shape[1:]) + fpn[:, None]).flatten(0, 1)
+
+    def forward(self, x: Tensor, bbox_mask: Tensor, fpns: List[Tensor]):
+        """x [B,C,h,w] projected image features, bbox_mask [B,Q,heads,h,w], fpns 3 x [B,C_k,H_k,W_k]
+        (coarse to fine) -> [B*Q, 1, H_2, W_2]."""
+        num_queries = bbox_mask.shape[1]
+        c_img = x.shape[1]
+        # lay1 over cat([x repeated per query, attention maps]) == lay1_img(x) + lay1_att(maps):
+        # the image part (and the bias) once per image, the attention part per query
+        w = self.lay1.weight
+        y_img = F.conv2d(x, w[:, :c_img], self.lay1.bias, padding=1)                 # [B, dim, h, w]
+        y_att = F.conv2d(bbox_mask.flatten(0, 1), w[:, c_img:], None, padding=1)     # [B*Q, dim, h, w]
+        x = (y_att.view(x.shape[0], num_queries, *y_att.shape[1:]) + y_img[:, None]).flatten(0, 1)
+        x = F.relu(self.gn1(x))
+        x = F.relu(self.gn2(self.lay2(x)))
+
+        x = self._merge(x, self.adapter1(fpns[0]), num_queries)
+        x = F.relu(self.gn3(self.lay3(x)))
+        x = self._merge(x, self.adapter2(fpns[1]), num_queries)
+        x = F.relu(self.gn4(self.lay4(x)))
+        x = self._merge(x, self.adapter3(fpns[2]), num_queries)
+        x = F.relu(self.gn5(self.lay5(x)))
+        return self.out_lay(x)
+
+
+class MHAttentionMap(nn.Module):
+    """2-D multi-head attention that returns only the attention weights (softmax over heads x H x W
+    jointly, as the reference does at :219), no multiplication by a value."""
+
+    def __init__(self, query_dim, hidden_dim, num_heads, dropout=0.0, bias=True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.hidden_dim = hidden_dim
+        self.dropout = nn.Dropout(dropout)
+        self.q_linear = nn.Linear(query_dim, hidden_dim, bias=bias)
+        self.k_linear = nn.Linear(query_dim, hidden_dim, bias=bias)
+        nn.init.zeros_(self.k_linear.bias)
+        nn.init.zeros_(self.q_linear.bias)
+        nn.init.xavier_uniform_(self.k_linear.weight)
+        nn.init.xavier_uniform_(self.q_linear.weight)
+        self.normalize_fact = float(hidden_dim / self.num_heads) ** -0.5
+
+    def forward(self, q, k, mask: Optional[Tensor] = None):
+        """q [B,Q,C] decoder embeddings, k [B,C,h,w] encoder memory, mask [B,h,w] (True = padding)
+        -> [B,Q,heads,h,w]."""
+        B, Q = q.shape[:2]
+        h, w = k.shape[-2:]
+        dh = self.hidden_dim // self.num_heads
+        q = self.q_linear(q)
+        k = F.conv2d(k, self.k_linear.weight[:, :, None, None], self.k_linear.bias)
+        qh = (q * self.normalize_fact).view(B, Q, self.num_heads, dh).transpose(1, 2)   # [B,n,Q,dh]
+        kh = k.view(B, self.num_heads, dh, h * w)                                        # [B,n,dh,hw]
+        weights = torch.matmul(qh, kh).transpose(1, 2)                                   # [B,Q,n,hw]
+        if mask is not None:
+            weights = weights.masked_fill(mask.flatten(1)[:, None, None], float("-inf"))
+        weights = F.softmax(weights.flatten(2), dim=-1).view(B, Q, self.num_heads, h, w)
+        return self.dropout(weights)
+
+
+class PostProcessSegm(nn.Module):
+    """pred_masks -> per-image masks at the original image size: bilinear resize to the padded batch
+    size, sigmoid (threshold unless return_probs), crop the padding away, nearest resize."""
+
+    def __init__(self, threshold=0.5):
+        super().__init__()
+        self.threshold = threshold
+
+    @torch.no_grad()
+    def forward(self, results, outputs, orig_target_sizes, max_target_sizes, return_probs=False,
+                results_mask=None):
+        assert len(orig_target_sizes) == len(max_target_sizes)
+        sizes = torch.as_tensor(max_target_sizes).tolist()
+        orig = torch.as_tensor(orig_target_sizes).tolist()
+        max_h, max_w = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        masks_all = outputs["pred_masks"]
+        if masks_all.dim() == 5:
+            masks_all = masks_all.squeeze(2)
+        for i, ((img_h, img_w), out_size) in enumerate(zip(sizes, orig)):
+            cur = masks_all[i]
+            if results_mask is not None:   # resize only what is kept (the reference filters last)
+                cur = cur[results_mask[i]]
+            cur = F.interpolate(cur[None], size=(max_h, max_w), mode="bilinear",
+                                align_corners=False)[0].sigmoid()
+            if not return_probs:
+                cur = cur > self.threshold
+            cur = F.interpolate(cur[:, :img_h, :img_w].unsqueeze(1).float(), size=tuple(out_size),
+                                mode="nearest")
+            results[i]["masks"] = cur if return_probs else cur.byte()
+        return results
+
+
+class PostProcessPanoptic(nn.Module):
+    """Model outputs -> COCO-panoptic predictions (`png_string`, `segments_info`), reference :266-388.
+    Needs `panopticapi` and PIL at call time (neither is a dependency of the tracking path)."""
+
+    def __init__(self, is_thing_map, threshold=0.85):
+        super().__init__()
+        self.threshold = threshold
+        self.is_thing_map = is_thing_map
+
+    def forward(self, outputs, processed_sizes, target_sizes=None):
+        from panopticapi.utils import id2rgb, rgb2id   # noqa: import error = missing optional dep
+        from PIL import Image
+        import numpy as np
+
+        if target_sizes is None:
+            target_sizes = processed_sizes
+        assert len(processed_sizes) == len(target_sizes)
+        out_logits, raw_masks, raw_boxes = \
+            outputs["pred_logits"], outputs["pred_masks"], outputs["pred_boxes"]
+        assert len(out_logits) == len(raw_masks) == len(target_sizes)
+        no_object = out_logits.shape[-1] - 1
+
+        def as_tuple(t):
+            return t if isinstance(t, tuple) else tuple(torch.as_tensor(t).cpu().tolist())
+
+        preds = []
+        for logits, masks, boxes, size, target_size in zip(out_logits, raw_masks, raw_boxes,
+                                                           processed_sizes, target_sizes):
+            scores, classes = logits.softmax(-1).max(-1)
+            keep = classes.ne(no_object) & (scores > self.threshold)
+            scores, classes = scores[keep], classes[keep]
+            masks = F.interpolate(masks[keep][None], size=as_tuple(size), mode="bilinear",
+                                  align_corners=False)[0]
+            boxes = box_ops.box_cxcywh_to_xyxy(boxes[keep])
+            h, w = masks.shape[-2:]
+            assert len(boxes) == len(classes)
+            masks = masks.flatten(1)
+
+            # several predicted masks of one stuff class are merged into the first of them
+            stuff_equiv = defaultdict(list)
+            for k, label in enumerate(classes.tolist()):
+                if not self.is_thing_map[label]:
+                    stuff_equiv[label].append(k)
+            final_h, final_w = as_tuple(target_size)
+
+            def ids_and_areas(cur_masks, n, dedup=False):
+                if cur_masks.shape[0] == 0:
+                    m_id = torch.zeros((h, w), dtype=torch.long, device=cur_masks.device)
+                else:
+                    m_id = cur_masks.transpose(0, 1).softmax(-1).argmax(-1).view(h, w)
+                if dedup:
+                    for equiv in stuff_equiv.values():
+                        for eq_id in equiv[1:]:
+                            m_id.masked_fill_(m_id.eq(eq_id), equiv[0])
+                seg_img = Image.fromarray(id2rgb(m_id.cpu().numpy()))
+                seg_img = seg_img.resize(size=(final_w, final_h), resample=Image.NEAREST)
+                ids = torch.from_numpy(rgb2id(np.array(seg_img)))
+                return [int(ids.eq(i).sum()) for i in range(n)], seg_img
+
+            area, seg_img = ids_and_areas(masks, len(scores), dedup=True)
+            if classes.numel() > 0:
+                while True:   # drop empty (<= 4 px) segments until none is left
+                    small = torch.as_tensor([a <= 4 for a in area], dtype=torch.bool,
+                                            device=keep.device)
+                    if not small.any():
+                        break
+                    scores, classes, masks = scores[~small], classes[~small], masks[~small]
+                    area, seg_img = ids_and_areas(masks, len(scores))
+            else:
+                classes = torch.ones(1, dtype=torch.long, device=classes.device)
+
+            segments_info = [{"id": i, "isthing": self.is_thing_map[int(classes[i])],
+                              "category_id": int(classes[i]), "area": a}
+                             for i, a in enumerate(area)]
+            with io.BytesIO() as buf:
+                seg_img.save(buf, format="PNG")
+                preds.append({"png_string": buf.getvalue(), "segments_info": segments_info})
+        return preds
