@@ -33,7 +33,10 @@ def checksum(model):
 def main():
     ref = reference_models.load()
     torch.set_num_threads(4)
+    only = sys.argv[1:]   # optional: regenerate just the named cases
     for case in um.MODEL_CASES:
+        if only and case not in only:
+            continue
         model, post, args = um.build(case, ref.models.build_model, config.make_args)
         if hasattr(model, "tracking"):
             model.tracking()
@@ -71,6 +74,8 @@ def main():
         print("%-28s logits%s boxes%s  -> %s (%d KB)" % (case, fix['pred_logits'].shape,
               fix['pred_boxes'].shape, os.path.basename(path), os.path.getsize(path) // 1024))
 
+    if only:
+        return
     # one training step (cfg 3 path): losses and gradient norms of the reference on CPU
     model, criterion, args = um.build_train(ref.models.build_model, config.make_args)
     samples, targets = um.train_batch()

@@ -12,6 +12,8 @@ MODEL_CASES = {
     # BASELINE cfg 5 model path: mask head on the tracking detector (MOTS20) ...
     "cfg5_segm_tracking": (("deformable", "tracking", "mots20"), dict(num_queries=24),
                            (128, 160), 4),
+    # (the `multi_frame` overlay cannot be combined with masks in the reference either: hidden 288
+    #  gives the head a GroupNorm(8, 36) -- detr_segmentation.py:125 -- which torch rejects)
     # ... and the plain-DETR flavour of the head (single feature level, dense attention)
     "cfg1_plain_detr_masks": (("coco_person_masks",), dict(num_queries=12), (96, 128), 0),
 }
