@@ -1116,7 +1116,7 @@ msda_bwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
 //     are DROPPED by the hardware, so there is no divergent code around the 16 atomics of a point;
 //     for the atomics lane dv owns channels dv, dv+DV, dv+2DV, dv+3DV, so that one atomic
 //     instruction touches D/4 consecutive floats of each row instead of every fourth float.
-template <int PT>
+template <int PT, bool ROWATOM>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
                  const float *__restrict__ loc, const float *__restrict__ attn,
@@ -1132,6 +1132,9 @@ msda_bwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
     float *s_attn = s_loc + (size_t)ppb * LP * 2;
     float *s_gloc = s_attn + (size_t)ppb * LP;
     float *s_gattn = s_gloc + (size_t)ppb * LP * 2;
+    // ROWATOM: per (pair, point) the 4 row offsets and the 4 weights (x attention weight) of the taps
+    u32x4_t *s_tapo = reinterpret_cast<u32x4_t *>(s_gattn + (size_t)ppb * LP);
+    f32x4_t *s_tapw = reinterpret_cast<f32x4_t *>(s_tapo + (size_t)ppb * LP);
 
     const long long nlq = total_pairs / M;
     const int head = blockIdx.x % M;
@@ -1207,14 +1210,22 @@ msda_bwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
                 const f32x4_t v4 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k4 ? t4 + la : kOobOffset, 0, 0));
                 const float w1 = gy * gx, w2 = gy * fx, w3 = fy * gx, w4 = fy * fx;
                 // grad wrt value: cuh:279,296-301 with the weights of cuh:84-93
+                if constexpr (ROWATOM) {
+                    if (dv == 0) {   // scattered below, one full 128-byte row per half wave
+                        s_tapo[(size_t)pl * LP + s] = u32x4_t{k1 ? t1 : kOobBase, k2 ? t2 : kOobBase,
+                                                              k3 ? t3 : kOobBase, k4 ? t4 : kOobBase};
+                        s_tapw[(size_t)pl * LP + s] = f32x4_t{w1 * a, w2 * a, w3 * a, w4 * a};
+                    }
+                } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned lb = (unsigned)(dv + c * DV) * 4u;
-                    const float top = gB[c] * a;
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w1 * top, rsrc_g, k1 ? t1 + lb : kOobOffset, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w2 * top, rsrc_g, k2 ? t2 + lb : kOobOffset, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w3 * top, rsrc_g, k3 ? t3 + lb : kOobOffset, 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w4 * top, rsrc_g, k4 ? t4 + lb : kOobOffset, 0, 0);
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned lb = (unsigned)(dv + c * DV) * 4u;
+                        const float top = gB[c] * a;
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w1 * top, rsrc_g, k1 ? t1 + lb : kOobOffset, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w2 * top, rsrc_g, k2 ? t2 + lb : kOobOffset, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w3 * top, rsrc_g, k3 ? t3 + lb : kOobOffset, 0, 0);
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w4 * top, rsrc_g, k4 ? t4 + lb : kOobOffset, 0, 0);
+                    }
                 }
                 // grad wrt attention weight / location: partial sums over this lane's 4 channels
                 const f32x4_t smp = v1 * w1 + v2 * w2 + v3 * w3 + v4 * w4;             // cuh:365
@@ -1234,6 +1245,33 @@ msda_bwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
                     sgl[2 * s + 1] = dy * a * Hf;   // cuh:371,374
                     sga[s] = dot;                   // cuh:376
                 }
+            }
+        }
+    }
+    if constexpr (ROWATOM) {
+        // D == 32: a half wave (32 lanes = the 32 channels of one row) scatters the taps of one pair, so
+        // every atomic instruction adds to 2 complete 128-byte rows instead of 32-byte pieces of 8 rows
+        // (the L2 atomic units are occupied per cache line touched).  The 8 pairs a wave computed above
+        // are the ones it scatters: wave-scope ordering is enough.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int lane = threadIdx.x & 63, half = lane >> 5, ch = lane & 31;
+        const __amdgpu_buffer_rsrc_t rsrc_g =
+            __builtin_amdgcn_make_buffer_rsrc(grad_value, 0, value_bytes, 0x00020000);
+        const unsigned cb = (unsigned)ch * 4u;
+        for (int j = 0; j < 4; ++j) {
+            const int pp = (threadIdx.x >> 6) * 8 + 2 * j + half;
+            if (pp >= npairs) continue;
+            const float g = grad_out[pair_of(pp) * D + ch];
+            const u32x4_t *to = s_tapo + (size_t)pp * LP;
+            const f32x4_t *tw = s_tapw + (size_t)pp * LP;
+            for (int s = 0; s < LP; ++s) {
+                const u32x4_t o = to[s];
+                const f32x4_t w = tw[s];
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.x * g, rsrc_g, o.x + cb, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.y * g, rsrc_g, o.y + cb, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.z * g, rsrc_g, o.z + cb, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.w * g, rsrc_g, o.w + cb, 0, 0);
             }
         }
     }
@@ -1639,10 +1677,18 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
         if (pl.vec == 4 && pow2 && (P == 1 || P == 2 || P == 4 || P == 8) &&
             buf_path_ok(lt, shapes_host != nullptr, N, S, M, D, L) && is_aligned(grad_value, 16)) {
             const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
-            const void *bfn = P == 1   ? (const void *)&msda_bwd_f32_buf<1>
-                              : P == 2 ? (const void *)&msda_bwd_f32_buf<2>
-                              : P == 4 ? (const void *)&msda_bwd_f32_buf<4>
-                                       : (const void *)&msda_bwd_f32_buf<8>;
+            static const int rowatom_on = [] { const char *e = getenv("TF_MSDA_BWD_ROWATOM"); return (e && e[0] == '0') ? 0 : 1; }();
+            const bool rowatom = rowatom_on && D == 32 && pl.DV == 8 && pl.ppb == kThreads / 8;
+            const void *bfn =
+                rowatom ? (P == 1   ? (const void *)&msda_bwd_f32_buf<1, true>
+                           : P == 2 ? (const void *)&msda_bwd_f32_buf<2, true>
+                           : P == 4 ? (const void *)&msda_bwd_f32_buf<4, true>
+                                    : (const void *)&msda_bwd_f32_buf<8, true>)
+                        : (P == 1   ? (const void *)&msda_bwd_f32_buf<1, false>
+                           : P == 2 ? (const void *)&msda_bwd_f32_buf<2, false>
+                           : P == 4 ? (const void *)&msda_bwd_f32_buf<4, false>
+                                    : (const void *)&msda_bwd_f32_buf<8, false>);
+            if (rowatom) pl.lds = ((pl.lds + 15) & ~(size_t)15) + (size_t)pl.ppb * L * P * 32;
             const hipError_t be = launch(bfn, head_major_grid(N, Lq, M, pl.ppb), pl.lds, stream,
                                          value, vbytes, loc, attn, grad_out, grad_value, grad_loc,
                                          grad_attn, lt, shapes_dev, S, M, D, L, Lq, total_pairs,
