@@ -202,3 +202,28 @@ def test_training_step_matches_reference(oracle_op):
     through MSDeformAttnFunction.backward; losses and gradient norms vs the reference on CPU."""
     loss_dict, total, grads = run_train_step()
     compare_train_to_golden(loss_dict, total, grads, rtol=2e-4)
+
+
+def test_engine_train_step_reproduces_reference_loss_and_updates_weights(oracle_op):
+    """engine.train_step (engine.py:119-158 body) + build_optimizer (train.py:93-120 groups)."""
+    from trackformer_amd import engine
+    model, criterion, args = um.build_train(factory.build_model, config.make_args)
+    optimizer, scheduler = engine.build_optimizer(model, args)
+    lrs = [g['lr'] for g in optimizer.param_groups]
+    assert lrs == [args.lr, args.lr_backbone, args.lr * args.lr_linear_proj_mult]
+    names = dict(model.named_parameters())
+    in_proj_group = {id(p) for p in optimizer.param_groups[2]['params']}
+    assert id(names['transformer.reference_points.weight']) in in_proj_group
+    assert id(names['transformer.encoder.layers.0.self_attn.sampling_offsets.weight']) in in_proj_group
+    assert all(id(p) in {id(q) for q in optimizer.param_groups[1]['params']}
+               for n, p in names.items() if n.startswith('backbone.0') and p.requires_grad)
+    before = names['class_embed.0.weight'].detach().clone()
+    samples, targets = um.train_batch()
+    model.train()
+    criterion.train()
+    torch.manual_seed(7)
+    loss, loss_dict = engine.train_step(model, criterion, optimizer, samples, targets,
+                                        clip_max_norm=args.clip_max_norm)
+    z = np.load(os.path.join(GOLDEN, "train_cfg3_small.npz"))
+    assert abs(float(loss) - float(z["total"])) < 1e-3 * abs(float(z["total"]))
+    assert not torch.equal(before, names['class_embed.0.weight'].detach())

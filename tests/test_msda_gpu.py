@@ -440,6 +440,28 @@ def test_tiled_kernel_matches_rowgather_kernel(dev, tiled):
     assert torch.allclose(tiled[:, :-1], rg, atol=2e-6, rtol=1e-5)
 
 
+BWD_ENC_CASES = [c for c in TILED_CASES if c[0] in (
+    "cfg2_init", "cfg2_uniform_all_fallback", "mot17_750x1333", "small_pyramid", "tiny_levels",
+    "one_level", "coarse_first_falls_back", "cfg4_d36_hidden288")]
+
+
+@pytest.mark.parametrize("name,shapes,mode,N,M,D", BWD_ENC_CASES, ids=[c[0] for c in BWD_ENC_CASES])
+def test_encoder_shape_backward_vs_oracle(dev, name, shapes, mode, N, M, D):
+    """Backward at encoder shapes (Lq == S) incl. degenerate pyramids and far-away sampling points:
+    D == 32 runs the full-row atomic scatter (msda_bwd_f32_buf<P, true>), D == 36 the 32-byte one."""
+    value, shp, loc, attn, grad_out = _encoder_inputs(dev, shapes, mode, N=N, M=M, D=D, seed=len(name))
+    if name == "cfg2_init":   # mix in points far outside their windows
+        loc = loc.clone()
+        loc[:, :, :, :, ::2, 0] += 12.0 / 167
+        loc[:, :, :, :, ::2, 1] -= 9.0 / 100
+    gv, gl, ga = [t.cpu().numpy() for t in _bwd(value, shp, loc, attn, grad_out)]
+    rv, rl, ra = msda_oracle.msda_backward(value.cpu().numpy(), shp.cpu().numpy(), loc.cpu().numpy(),
+                                           attn.cpu().numpy(), grad_out.cpu().numpy())
+    np.testing.assert_allclose(gv, rv, atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(gl, rl, atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(ga, ra, atol=1e-4, rtol=1e-4)
+
+
 # ------------------------------------------------------------------ fused prologue (inference)
 @pytest.mark.parametrize("ref_dim", [2, 4])
 @pytest.mark.parametrize("Lq,shapes_l,d_model", [(400, CFG2_SHAPES, 256), (1020, [(24, 32), (12, 16), (6, 8), (3, 4)], 256),

@@ -1115,7 +1115,16 @@ msda_bwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
 //   * scatters grad_value with buffer_atomic_add_f32: invalid taps get an out-of-range offset and
 //     are DROPPED by the hardware, so there is no divergent code around the 16 atomics of a point;
 //     for the atomics lane dv owns channels dv, dv+DV, dv+2DV, dv+3DV, so that one atomic
-//     instruction touches D/4 consecutive floats of each row instead of every fourth float.
+//     instruction touches D/4 consecutive floats of each row instead of every fourth float;
+//   * ROWATOM (D == 32): the taps' row offsets and weights go through LDS and one HALF WAVE scatters a
+//     pair's contributions, lane = channel: every atomic instruction then adds to 2 complete 128-byte
+//     rows instead of 32-byte pieces of 8 rows, which halves the time (the L2 atomic units are
+//     occupied per cache line touched).
+// Tried and removed: pre-reducing grad_value in LDS windows (the tiling of msda_fwd_f32_win in reverse,
+// ds_add_f32 into zeroed windows, one flush per window row).  Correct, 15x fewer global atomics -- and
+// no faster: ds_add_f32 costs ~100 cycles per wave instruction on gfx950, which makes the LDS phase as
+// slow as the L2 atomics it replaces (1.9 ms vs 1.9 ms at the cfg-2 encoder shape, init pattern; the
+// kernel without its LDS atomics ran in 0.18 ms).
 template <int PT, bool ROWATOM>
 __global__ void __launch_bounds__(kThreads)
 msda_bwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
@@ -1268,10 +1277,13 @@ msda_bwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
             for (int s = 0; s < LP; ++s) {
                 const u32x4_t o = to[s];
                 const f32x4_t w = tw[s];
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.x * g, rsrc_g, o.x + cb, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.y * g, rsrc_g, o.y + cb, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.z * g, rsrc_g, o.z + cb, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.w * g, rsrc_g, o.w + cb, 0, 0);
+                // taps with an exactly zero weight add nothing (a default-initialised model samples at
+                // integer pixel offsets: 3 of 4 bilinear weights are 0): skip the instruction when that
+                // holds for both pairs of the wave
+                if (w.x != 0.f) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.x * g, rsrc_g, o.x + cb, 0, 0);
+                if (w.y != 0.f) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.y * g, rsrc_g, o.y + cb, 0, 0);
+                if (w.z != 0.f) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.z * g, rsrc_g, o.z + cb, 0, 0);
+                if (w.w != 0.f) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(w.w * g, rsrc_g, o.w + cb, 0, 0);
             }
         }
     }
