@@ -95,6 +95,42 @@ def test_two_rank_sequence_sharding_matches_single_process(tmp_path, monkeypatch
         np.testing.assert_allclose(got[:, 3:], single[:, 3:], atol=1e-4)
 
 
+def _train_worker(rank, world, port, out_dir):
+    """cfg-3 path at world size 2: DDP over gloo, each rank its own batch, one engine.train_step."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from oracle import msda_oracle
+    from tests import util_models as um
+    from trackformer_amd import config, dist_utils as du, engine, factory, msda
+    msda.MSDeformAttnFunction = msda_oracle.make_torch_function()  # CPU checker, tests only
+    du.init_from_env(backend="gloo")
+    model, criterion, args = um.build_train(factory.build_model, config.make_args)   # same seed: same weights
+    optimizer, _ = engine.build_optimizer(model, args)
+    ddp = engine.wrap_ddp(model, torch.device("cpu"))
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    samples, targets = um.train_batch(seed=9 + rank)        # different data per rank
+    ddp.train()
+    criterion.train()
+    torch.manual_seed(7)
+    loss, _ = engine.train_step(ddp, criterion, optimizer, samples, targets,
+                                clip_max_norm=args.clip_max_norm)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    np.save(os.path.join(out_dir, "train%d.npy" % rank),
+            np.array([float(loss), float(flat.double().sum()), float(flat.double().abs().sum())]))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_ddp_training_step_keeps_replicas_identical(tmp_path):
+    port = _free_port()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(tmp_path / ("train%d.npy" % r)) for r in range(2))
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert a[0] != b[0]                       # different batches -> different local losses
+    np.testing.assert_array_equal(a[1:], b[1:])   # averaged gradients -> identical weights after the step
+
+
 def test_single_process_helpers_are_noops():
     from trackformer_amd import dist_utils as du
     assert not du.is_distributed()
