@@ -15,6 +15,7 @@ Numerics: every candidate is an fp32 kernel of the same library; results differ 
 only (parity tests run with this setup enabled).
 """
 import os
+import sys
 
 import torch
 
@@ -54,4 +55,4 @@ def configure_inference(tune=False, miopen_find=True, tunable_file=None, verbose
         ok = tunable.read_file(path)
         if verbose:
             print("trackformer_amd: TunableOp selections %s from %s" %
-                  ("loaded" if ok else "REJECTED (validator mismatch)", path))
+                  ("loaded" if ok else "REJECTED (validator mismatch)", path), file=sys.stderr)
