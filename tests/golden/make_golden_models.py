@@ -118,7 +118,46 @@ def main():
         print("tracker reid=%s: %d track ids, active per frame %s, inactive %s, reids %d -> %s" % (
             reid, tracker.track_num, active.tolist(), [len(i) for _, i in per_frame],
             tracker.num_reids, os.path.basename(path)))
+    tracker_variants(ref)
+
+
+def tracker_variants(ref):
+    """Tracker configurations beyond cfgs/track.yaml / track_reid.yaml (tests/util_models.TRACKER_VARIANTS)."""
+    model, post, args = um.build("cfg2_deformable_tracking", ref.models.build_model,
+                                 config.make_args)
+    model.tracking()
+    frames = um.tracker_sequence()
+    dets = um.public_detections(model, post, frames)
+    for name, var in um.TRACKER_VARIANTS.items():
+        tracker = ref.tracker.Tracker(model, post, config.tracker_cfg(reid=var['reid'], **var['cfg']),
+                                      False)
+        tracker.reset()
+        active, inactive = [], []
+        with torch.no_grad():
+            for blob, d in zip(frames, dets):
+                blob = dict(blob, dets=d if var['dets'] else blob['dets'])
+                tracker.step(blob)
+                active.append(len(tracker.tracks))
+                inactive.append(len(tracker.inactive_tracks))
+        results = tracker.get_results()
+        rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']),
+                          results[tid][f]['obj_ind']]
+                         for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
+        path = os.path.join(HERE, "tracker_cfg2_%s.npz" % name)
+        extra = {"dets_f%d" % i: d.numpy() for i, d in enumerate(dets)} if var['dets'] else {}
+        np.savez_compressed(path, rows=rows, active_per_frame=np.array(active),
+                            inactive_per_frame=np.array(inactive),
+                            num_tracks=np.int64(tracker.track_num),
+                            num_reids=np.int64(tracker.num_reids), **extra)
+        print("tracker %s: %d track ids, active %s, inactive %s, reids %d, dets/frame %s -> %s" % (
+            name, tracker.track_num, active, inactive, tracker.num_reids,
+            [d.shape[1] for d in dets] if var['dets'] else "-", os.path.basename(path)))
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["tracker_variants"]:
+        ref_ = reference_models.load()
+        torch.set_num_threads(4)
+        tracker_variants(ref_)
+        sys.exit(0)
     main()

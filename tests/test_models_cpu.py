@@ -122,6 +122,50 @@ def test_tracker_sequence_matches_reference(reid, oracle_op):
     compare_tracker_to_golden(reid, tracker, rows, active, inactive, box_tol_px=0.05)
 
 
+def run_tracker_variant(name, device="cpu"):
+    """Tracker configurations of tests/util_models.TRACKER_VARIANTS (public detections come from the
+    fixture: they were generated with the reference model)."""
+    var = um.TRACKER_VARIANTS[name]
+    z = np.load(os.path.join(GOLDEN, "tracker_cfg2_%s.npz" % name))
+    model, post, args = um.build("cfg2_deformable_tracking", factory.build_model,
+                                 config.make_args, device=device)
+    model.to(device)
+    model.tracking()
+    tracker = Tracker(model, post, config.tracker_cfg(reid=var['reid'], **var['cfg']), False)
+    tracker.reset()
+    active, inactive = [], []
+    with torch.no_grad():
+        for i, blob in enumerate(um.tracker_sequence()):
+            if var['dets']:
+                blob = dict(blob, dets=torch.from_numpy(z["dets_f%d" % i]))
+            tracker.step(blob)
+            active.append(len(tracker.tracks))
+            inactive.append(len(tracker.inactive_tracks))
+    results = tracker.get_results()
+    rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']),
+                      results[tid][f]['obj_ind']]
+                     for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
+    return tracker, rows, active, inactive
+
+
+def compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px):
+    z = np.load(os.path.join(GOLDEN, "tracker_cfg2_%s.npz" % name))
+    assert int(z["num_tracks"]) == tracker.track_num
+    assert int(z["num_reids"]) == tracker.num_reids
+    assert z["active_per_frame"].tolist() == active
+    assert z["inactive_per_frame"].tolist() == inactive
+    assert rows.shape == z["rows"].shape
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])   # id, frame, query index
+    np.testing.assert_allclose(rows[:, 2:6], z["rows"][:, 2:6], atol=box_tol_px)
+    np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
+
+
+@pytest.mark.parametrize("name", list(um.TRACKER_VARIANTS))
+def test_tracker_variants_match_reference(name, oracle_op):
+    tracker, rows, active, inactive = run_tracker_variant(name)
+    compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.05)
+
+
 def run_mask_tracker(device="cpu", frames=3):
     """cfg-5 path: Tracker.step on the mask-head model; -> {track id: {frame: result dict}}."""
     model, post, args = um.build("cfg5_segm_tracking", factory.build_model, config.make_args,

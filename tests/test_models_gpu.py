@@ -33,6 +33,13 @@ def test_tracker_track_ids_bit_exact(dev, reid):
     shared.compare_tracker_to_golden(reid, tracker, rows, active, inactive, box_tol_px=0.64)
 
 
+@pytest.mark.parametrize("name", list(um.TRACKER_VARIANTS))
+def test_tracker_variants_track_ids_bit_exact(dev, name):
+    """Public detections (IoU / centre distance), NMS + termination counter, greedy re-identification."""
+    tracker, rows, active, inactive = shared.run_tracker_variant(name, device=dev)
+    shared.compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.64)
+
+
 def test_tracker_with_mask_head_matches_cpu_path(dev, monkeypatch):
     """cfg-5 path (mask head + Tracker) on the GPU against the same modules on the CPU with the C
     oracle as operator: same track ids in the same frames, same boxes.  (The mask numerics are pinned

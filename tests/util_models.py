@@ -61,6 +61,34 @@ def tracker_sequence(seed=11):
     return frames
 
 
+# extra Tracker configurations pinned against the reference (tracker.py:124-165 public detections,
+# :181-199 greedy re-identification, :356-360 termination counter, NMS thresholds)
+TRACKER_VARIANTS = {
+    "publicdet_iou": dict(cfg=dict(public_detections='min_iou_0_5'), reid=False, dets=True),
+    "publicdet_center": dict(cfg=dict(public_detections='center_distance'), reid=False, dets=True),
+    "nms_termination": dict(cfg=dict(detection_nms_thresh=0.5, track_nms_thresh=0.6, steps_termination=2,
+                                     detection_obj_score_thresh=0.5, track_obj_score_thresh=0.45),
+                            reid=False, dets=False),
+    "reid_greedy": dict(cfg=dict(reid_greedy_matching=True, reid_sim_threshold=2.0,
+                                 reid_score_thresh=0.45), reid=True, dets=False),
+}
+
+
+def public_detections(model, post, frames, every=3, seed=21):
+    """Synthetic public detections: every `every`-th confident detection of the detector on each
+    frame (no track queries), jittered by up to 2 px -- generated once with the reference model and
+    stored in the fixture."""
+    g = torch.Generator().manual_seed(seed)
+    dets = []
+    with torch.no_grad():
+        for blob in frames:
+            out, *_ = model(blob['img'], None, None)
+            res = post['bbox'](out, blob['orig_size'])[0]
+            boxes = res['boxes'][res['scores'] > 0.4][::every]
+            dets.append((boxes + (torch.rand(boxes.shape, generator=g) * 4 - 2)).clamp(min=0)[None])
+    return dets
+
+
 def to_device(target, device):
     if target is None:
         return None
