@@ -987,6 +987,357 @@ msda_fwd_f32_win(const DirectArgs da, const LevelTable lt, const WinGeom wg)
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, encoder shape, fp32, D == 32, P == 4, L <= 4: grad_value contributions sorted by row in LDS
+// ---------------------------------------------------------------------------------------------
+// msda_bwd_f32_buf is bound by the L2 atomic units, which are occupied ~25 cycles per cache line touched:
+// 64 taps per (query, head) pair = 11.4 M row updates per cfg-2 encoder launch.  Neighbouring queries
+// hit the same rows (~18 contributions per row inside a tile), so this kernel merges them BEFORE they
+// reach L2 -- without floating-point LDS atomics (ds_add_f32 costs ~100 cycles per wave instruction on
+// gfx950): per 2-D query tile, head and level the tap contributions (destination row, weight x
+// attention, source query) are counting-sorted by destination row with integer LDS atomics, then one
+// half wave per destination row sums its segment in registers (lane = channel, grad_out of the tile
+// staged in LDS) and issues ONE full-row global atomic.  Rows outside the binned window (bounding box
+// of the tile's taps, clamped; at most kSortRowsCap rows per level) are scattered directly, also as
+// full rows.  grad_loc / grad_attn as in the row kernels.
+constexpr int kSortRowsCap = 1024;                      // destination rows binned per level and tile
+constexpr int kSortItems = kWinMaxQueries * 4 * 4;      // taps per level: queries x points x taps
+constexpr unsigned kSortInvalid = 0xFFFFFFFFu;          // item key: [31] direct scatter, [30:24] query, [23:0] row
+constexpr int kSortOffCnt = 768;                                     // u32[kSortRowsCap]
+constexpr int kSortOffStart = kSortOffCnt + 4 * kSortRowsCap;        // u32[kSortRowsCap + 1]
+constexpr int kSortOffItem = kSortOffStart + 4224;                   // {key, weight}[kSortItems]
+constexpr int kSortOffSorted = kSortOffItem + 8 * kSortItems;        // the same, sorted by row
+constexpr int kSortOffGo = kSortOffSorted + 8 * kSortItems;          // grad_out of the tile [128][32]
+constexpr int kSortLdsBytes = kSortOffGo + kWinMaxQueries * 128;     // 58240: two workgroups per CU
+
+struct BwdSortArgs {
+    const float *value;
+    unsigned value_bytes;
+    const float *loc, *attn, *grad_out;
+    float *grad_value, *grad_loc, *grad_attn;
+    int S, M, L;
+};
+
+__global__ void __launch_bounds__(kWinThreads, 4)
+msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
+{
+    constexpr int PT = 4, D = 32, LPAIRS = kWinLevels / 2;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start          (48 ints)
+    int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb
+    int *s_bb = s_q + 5 * TF_MSDA_MAX_LEVELS + 4;                  // xmin xmax ymin ymax per level
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(smem + kSortOffCnt);
+    unsigned *s_start = reinterpret_cast<unsigned *>(smem + kSortOffStart);
+    uint2 *s_item = reinterpret_cast<uint2 *>(smem + kSortOffItem);
+    uint2 *s_sorted = reinterpret_cast<uint2 *>(smem + kSortOffSorted);
+    float *s_go = reinterpret_cast<float *>(smem + kSortOffGo);
+
+    const int L = ba.L, M = ba.M, S = ba.S, LP = L * PT;
+    const int m = blockIdx.x % M;
+    int t = blockIdx.x / M;
+    const int tx = t % wg.tiles_x;
+    t /= wg.tiles_x;
+    const int ty = t % wg.tiles_y;
+    const int b = t / wg.tiles_y;
+
+    if (threadIdx.x < 4 * kWinLevels) {   // as msda_fwd_f32_win: exact partition of every level
+        const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
+        if (l < L) {
+            const unsigned H0 = (unsigned)lt.H[0], W0 = (unsigned)lt.W[0];
+            const unsigned Hl = (unsigned)lt.H[l], Wl = (unsigned)lt.W[l];
+            const unsigned y0 = (unsigned)ty * wg.TH, y1 = min(H0, y0 + (unsigned)wg.TH);
+            const unsigned x0 = (unsigned)tx * wg.TW, x1 = min(W0, x0 + (unsigned)wg.TW);
+            const unsigned num = k == 0 ? 2u * y0 * Hl + H0 - 1u : k == 1 ? 2u * y1 * Hl + H0 - 1u
+                                 : k == 2 ? 2u * x0 * Wl + W0 - 1u : 2u * x1 * Wl + W0 - 1u;
+            s_q[k * TF_MSDA_MAX_LEVELS + l] = (int)(num / (k < 2 ? 2u * H0 : 2u * W0));
+            if (k == 0) {
+                s_tab[l] = lt.H[l];
+                s_tab[TF_MSDA_MAX_LEVELS + l] = lt.W[l];
+                s_tab[2 * TF_MSDA_MAX_LEVELS + l] = lt.start[l];
+            }
+        }
+        s_bb[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dv = threadIdx.x & 7, sub = dv & 3, which = dv >> 2;
+    const int pl = threadIdx.x >> 3;   // pair of this lane group inside a pass
+    int qoff[kWinLevels + 1];
+    qoff[0] = 0;
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l)
+        qoff[l + 1] = qoff[l] + (l < L ? (s_q[TF_MSDA_MAX_LEVELS + l] - s_q[l]) *
+                                             (s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l])
+                                       : 0);
+    const int nq = qoff[kWinLevels];
+
+    long long bqs[kWinPasses];
+    bool live[kWinPasses];
+    f32x4_t gA[kWinPasses];
+#pragma unroll
+    for (int ps = 0; ps < kWinPasses; ++ps) {
+        const int tq = ps * kWinPairs + pl;
+        int q = 0;
+        live[ps] = tq < nq;
+        if (live[ps]) {
+            int l = 0, base = 0;
+#pragma unroll
+            for (int k = 1; k < kWinLevels; ++k)
+                if (tq >= qoff[k] && k < L) {
+                    l = k;
+                    base = qoff[k];
+                }
+            const int r = tq - base;
+            const int nx = s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l];
+            const int yy = r / nx, xx = r - yy * nx;
+            q = s_tab[2 * TF_MSDA_MAX_LEVELS + l] + (s_q[l] + yy) * s_tab[TF_MSDA_MAX_LEVELS + l] +
+                s_q[2 * TF_MSDA_MAX_LEVELS + l] + xx;
+        }
+        bqs[ps] = (long long)b * S + q;
+        gA[ps] = *reinterpret_cast<const f32x4_t *>(ba.grad_out + (bqs[ps] * M + m) * D + dv * 4);
+        if (!live[ps]) gA[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4_t *>(s_go + (size_t)tq * D + dv * 4) = gA[ps];   // tile of grad_out
+    }
+
+    // ---- phase A: bounding box of the valid taps, per level (lane owns point `sub` of level 2i+which)
+#pragma unroll
+    for (int i = 0; i < LPAIRS; ++i) {
+        int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+        const bool have = 2 * i + which < L;
+        const int ml = have ? 2 * i + which : 0;
+        const int H = s_tab[ml], W = s_tab[TF_MSDA_MAX_LEVELS + ml];
+        const float Wf = (float)W, Hf = (float)H;
+#pragma unroll
+        for (int ps = 0; ps < kWinPasses; ++ps) {
+            const float2 xy = *reinterpret_cast<const float2 *>(
+                ba.loc + ((bqs[ps] * M + m) * LP + ml * PT + sub) * 2);
+            const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);
+            const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
+            const bool in = live[ps] && have && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
+            const int x0 = (int)__builtin_floorf(in ? xr : 0.f), y0 = (int)__builtin_floorf(in ? yr : 0.f);
+            if (in) {
+                mnx = min(mnx, x0 >= 0 ? x0 : x0 + 1);
+                mxx = max(mxx, (x0 + 1 <= W - 1) ? x0 + 1 : x0);
+                mny = min(mny, y0 >= 0 ? y0 : y0 + 1);
+                mxy = max(mxy, (y0 + 1 <= H - 1) ? y0 + 1 : y0);
+            }
+        }
+#define TF_DPP(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xF, 0xF, true)
+        mnx = min(mnx, TF_DPP(mnx, 0xB1)); mxx = max(mxx, TF_DPP(mxx, 0xB1));
+        mny = min(mny, TF_DPP(mny, 0xB1)); mxy = max(mxy, TF_DPP(mxy, 0xB1));
+        mnx = min(mnx, TF_DPP(mnx, 0x4E)); mxx = max(mxx, TF_DPP(mxx, 0x4E));
+        mny = min(mny, TF_DPP(mny, 0x4E)); mxy = max(mxy, TF_DPP(mxy, 0x4E));
+        mnx = min(mnx, TF_DPP(mnx, 0x128)); mxx = max(mxx, TF_DPP(mxx, 0x128));
+        mny = min(mny, TF_DPP(mny, 0x128)); mxy = max(mxy, TF_DPP(mxy, 0x128));
+#undef TF_DPP
+        if ((lane & 0xB) == 0 && have && mnx != INT_MAX) {
+            atomicMin(&s_bb[4 * ml + 0], mnx);
+            atomicMax(&s_bb[4 * ml + 1], mxx);
+            atomicMin(&s_bb[4 * ml + 2], mny);
+            atomicMax(&s_bb[4 * ml + 3], mxy);
+        }
+    }
+    __syncthreads();
+
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;
+    const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(ba.value), 0, ba.value_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_g =
+        __builtin_amdgcn_make_buffer_rsrc(ba.grad_value, 0, ba.value_bytes, 0x00020000);
+    const unsigned la = (unsigned)dv * 16u;
+    const int half = lane >> 5, ch = lane & 31;
+    const int H0 = __builtin_amdgcn_readfirstlane(s_tab[0]);
+    const int W0 = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS]);
+    const float rH0 = __builtin_amdgcn_rcpf((float)H0), rW0 = __builtin_amdgcn_rcpf((float)W0);
+    const int y0t = ty * wg.TH, y1t = min(H0, y0t + wg.TH);
+    const int x0t = tx * wg.TW, x1t = min(W0, x0t + wg.TW);
+    float rdx[kWinPasses][2], rdy[kWinPasses][2], rdot[kWinPasses][2];
+#pragma unroll
+    for (int ps = 0; ps < kWinPasses; ++ps)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rdx[ps][h] = rdy[ps][h] = rdot[ps][h] = 0.f;
+
+    for (int l = 0; l < L; ++l) {
+        // ---- window of this level: bounding box of the tile's taps, clamped to the tile footprint
+        //      +- (HY, HX) and to kSortRowsCap rows (wave-uniform)
+        const int H = __builtin_amdgcn_readfirstlane(s_tab[l]);
+        const int W = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS + l]);
+        const unsigned lvl_base =
+            head_base + (unsigned)__builtin_amdgcn_readfirstlane(s_tab[2 * TF_MSDA_MAX_LEVELS + l]) * rowbytes;
+        const int bx0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 0]);
+        const int bx1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 1]);
+        const int by0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 2]);
+        const int by1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 3]);
+        const int ny0 = (int)__builtin_floorf((float)y0t * (float)H * rH0 - 0.5f) - wg.HY;
+        const int ny1 = (int)__builtin_floorf((float)y1t * (float)H * rH0 - 0.5f) + 1 + wg.HY;
+        const int nx0 = (int)__builtin_floorf((float)x0t * (float)W * rW0 - 0.5f) - wg.HX;
+        const int nx1 = (int)__builtin_floorf((float)x1t * (float)W * rW0 - 0.5f) + 1 + wg.HX;
+        const int wx0 = max(max(bx0, nx0), 0), wy0 = max(max(by0, ny0), 0);
+        int ww = min(min(bx1, nx1), W - 1) - wx0 + 1, wh = min(min(by1, ny1), H - 1) - wy0 + 1;
+        if (ww <= 0 || wh <= 0 || bx0 == INT_MAX || ww > kSortRowsCap) {
+            ww = 1;
+            wh = 0;
+        }
+        if (wh * ww > kSortRowsCap) wh = kSortRowsCap / ww;
+        const int wx1 = wx0 + ww - 1, wy1 = wy0 + wh - 1, nrows = wh * ww;
+        const float Wf = (float)W, Hf = (float)H;
+
+        // ---- a. reset counters and items
+        for (int i = threadIdx.x; i < nrows; i += kWinThreads) s_cnt[i] = 0u;
+        for (int i = threadIdx.x; i < kSortItems; i += kWinThreads) s_item[i].x = kSortInvalid;
+        __syncthreads();
+
+        // ---- b. taps of this level: grad_loc / grad_attn, and the grad_value items
+#pragma unroll
+        for (int ps = 0; ps < kWinPasses; ++ps) {
+            if (ps * kWinPairs >= nq) break;   // uniform
+            const long long pair = bqs[ps] * M + m;
+            const int tq = ps * kWinPairs + pl;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int s = l * PT + p;
+                const float2 xy = *reinterpret_cast<const float2 *>(ba.loc + (pair * LP + s) * 2);
+                const float a = ba.attn[pair * LP + s];
+                const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);   // cuh:350-351
+                const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
+                const bool in = live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);   // cuh:359
+                const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+                const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+                const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+                const int x0 = (int)xf, y0 = (int)yf;
+                const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
+                const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
+                const bool k1 = ky0 && kx0, k2 = ky0 && kx1, k3 = ky1 && kx0, k4 = ky1 && kx1;
+                const int r0 = y0 * W + x0;
+                const unsigned t1 = lvl_base + (unsigned)r0 * rowbytes, t2 = t1 + rowbytes;
+                const unsigned t3 = t1 + (unsigned)W * rowbytes, t4 = t3 + rowbytes;
+                const f32x4_t v1 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k1 ? t1 + la : kOobOffset, 0, 0));
+                const f32x4_t v2 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k2 ? t2 + la : kOobOffset, 0, 0));
+                const f32x4_t v3 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k3 ? t3 + la : kOobOffset, 0, 0));
+                const f32x4_t v4 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k4 ? t4 + la : kOobOffset, 0, 0));
+                const float w1 = gy * gx, w2 = gy * fx, w3 = fy * gx, w4 = fy * fx;
+                if (dv < 4) {   // lane t of the group files tap t (cuh:279,296-301)
+                    const int tx_ = x0 + (dv & 1), ty_ = y0 + (dv >> 1);
+                    const bool kt = dv == 0 ? k1 : dv == 1 ? k2 : dv == 2 ? k3 : k4;
+                    const float wt = (dv == 0 ? w1 : dv == 1 ? w2 : dv == 2 ? w3 : w4) * a;
+                    if (kt && wt != 0.f) {
+                        const bool inside = tx_ >= wx0 && tx_ <= wx1 && ty_ >= wy0 && ty_ <= wy1;
+                        const unsigned row = inside ? (unsigned)((ty_ - wy0) * ww + (tx_ - wx0))
+                                                    : (0x80000000u | (unsigned)(ty_ * W + tx_));
+                        s_item[(tq * PT + p) * 4 + dv] =
+                            uint2{row | ((unsigned)tq << 24), __builtin_bit_cast(unsigned, wt)};
+                        if (inside) atomicAdd(&s_cnt[row], 1u);
+                    }
+                }
+                // grad wrt attention weight / location: partial sums over this lane's 4 channels
+                const f32x4_t smp = v1 * w1 + v2 * w2 + v3 * w3 + v4 * w4;             // cuh:365
+                const f32x4_t ddx = (v2 - v1) * gy + (v4 - v3) * fy;                   // cuh:150-160
+                const f32x4_t ddy = (v3 - v1) * gx + (v4 - v2) * fx;                   // cuh:139-149
+                const f32x4_t pd = gA[ps] * smp, px = gA[ps] * ddx, py = gA[ps] * ddy;
+                float dot = (pd.x + pd.y) + (pd.z + pd.w);
+                float dx = (px.x + px.y) + (px.z + px.w);
+                float dy = (py.x + py.y) + (py.z + py.w);
+#pragma unroll
+                for (int off = 4; off > 0; off >>= 1) {
+                    dot += __shfl_xor(dot, off);
+                    dx += __shfl_xor(dx, off);
+                    dy += __shfl_xor(dy, off);
+                }
+                if ((s & 7) == dv) {   // lane dv keeps points dv and dv + 8
+                    rdx[ps][s >> 3] = dx * a * Wf;      // cuh:371,373
+                    rdy[ps][s >> 3] = dy * a * Hf;      // cuh:371,374
+                    rdot[ps][s >> 3] = dot;             // cuh:376
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- c. exclusive prefix sum of the row counts (wave 0; 16 consecutive rows per lane)
+        if (wave == 0) {
+            unsigned c[16], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = lane * 16 + k;
+                c[k] = r < nrows ? s_cnt[r] : 0u;
+                sum += c[k];
+            }
+            unsigned incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, off);
+                if (lane >= off) incl += up;
+            }
+            unsigned run = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = lane * 16 + k;
+                if (r < nrows) {
+                    s_start[r] = run;
+                    s_cnt[r] = 0u;   // reused as the placement cursor
+                }
+                run += c[k];
+            }
+            if (lane == 63) s_start[nrows] = incl;   // number of binned items
+        }
+        __syncthreads();
+
+        // ---- d. place the binned items in row order
+        for (int i = threadIdx.x; i < kSortItems; i += kWinThreads) {
+            const uint2 it = s_item[i];
+            if (it.x != kSortInvalid && !(it.x & 0x80000000u)) {
+                const unsigned row = it.x & 0xFFFFFFu;
+                s_sorted[s_start[row] + atomicAdd(&s_cnt[row], 1u)] = it;
+            }
+        }
+        __syncthreads();
+
+        // ---- e. one half wave per destination row (lane = channel): sum the row's segment, one atomic
+        const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
+        for (int row = wave * 2 + half; row < nrows; row += 2 * kWinWaves) {
+            const unsigned beg = s_start[row], end = s_start[row + 1];
+            if (beg == end) continue;
+            float acc = 0.f;
+            for (unsigned k = beg; k < end; ++k) {
+                const uint2 it = s_sorted[k];
+                acc = __builtin_fmaf(__builtin_bit_cast(float, it.y), s_go[((it.x >> 24) & 0x7Fu) * D + ch], acc);
+            }
+            int wy = (int)(((float)row + 0.5f) * inv_ww);
+            int wx = row - wy * ww;
+            if (wx < 0) { --wy; wx += ww; }
+            if (wx >= ww) { ++wy; wx -= ww; }
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                acc, rsrc_g, lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)ch * 4u, 0, 0);
+        }
+        // ---- f. taps outside the window: scattered directly, still one full row per half wave
+        for (int i = wave * 2 + half; i < kSortItems; i += 2 * kWinWaves) {
+            const uint2 it = s_item[i];
+            if (it.x != kSortInvalid && (it.x & 0x80000000u)) {
+                const float v = __builtin_bit_cast(float, it.y) * s_go[((it.x >> 24) & 0x7Fu) * D + ch];
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                    v, rsrc_g, lvl_base + (it.x & 0xFFFFFFu) * rowbytes + (unsigned)ch * 4u, 0, 0);
+            }
+        }
+        __syncthreads();   // items / counters are reused by the next level
+    }
+
+#pragma unroll
+    for (int ps = 0; ps < kWinPasses; ++ps) {
+        if (!live[ps]) continue;
+        const long long pair = bqs[ps] * M + m;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = dv + 8 * h;
+            if (s < LP) {
+                *reinterpret_cast<float2 *>(ba.grad_loc + (pair * LP + s) * 2) = float2{rdx[ps][h], rdy[ps][h]};
+                ba.grad_attn[pair * LP + s] = rdot[ps][h];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward (grad_value via atomics, grad_loc / grad_attn via wave reduction), fused
 // ---------------------------------------------------------------------------------------------
 #ifdef TF_EXPERIMENT_WG_SCOPE_ATOMICS
@@ -1489,6 +1840,60 @@ bool plan_win(const LevelTable &lt, int L, int D, int P, WinGeom *wg, size_t *ld
     return true;
 }
 
+// Tile plan of msda_bwd_f32_sorted: the tile search of plan_win without its LDS-capacity terms.
+bool plan_sorted(const LevelTable &lt, int L, int D, int P, WinGeom *wg)
+{
+    static const int on = [] { const char *e = getenv("TF_MSDA_BWD_SORTED"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (!on || D != 32 || P != 4 || L > kWinLevels) return false;
+    for (int l = 0; l < L; ++l)
+        if (lt.H[l] >= 32768 || lt.W[l] >= 32768 || (long long)lt.H[l] * lt.W[l] >= (1 << 24)) return false;
+    struct Memo {
+        bool valid = false, ok = false;
+        int L = 0;
+        LevelTable lt;
+        WinGeom wg;
+    };
+    static thread_local Memo memo;
+    if (memo.valid && memo.L == L && memcmp(&memo.lt, &lt, sizeof(lt)) == 0) {
+        *wg = memo.wg;
+        return memo.ok;
+    }
+    memo.valid = true;
+    memo.ok = false;
+    memo.L = L;
+    memo.lt = lt;
+    int hy = 8, hx = 14, th = 0, tw = 0;
+    if (const char *e = getenv("TF_MSDA_BWD_HALO")) sscanf(e, "%d,%d", &hy, &hx);
+    if (const char *e = getenv("TF_MSDA_BWD_TILE")) sscanf(e, "%d,%d", &th, &tw);
+    if (hy < 0 || hx < 0 || th < 0 || tw < 0) return false;
+    long long best = 0;
+    int bth = 0, btw = 0;
+    const int tws[5] = {8, 16, 4, 2, 1};
+    for (int k = 0; k < 5; ++k) {
+        const int ctw = tw ? tw : tws[k];
+        for (int cth = th ? th : 16; cth >= (th ? th : 1); --cth) {
+            const long long nq = tile_max_queries(lt, L, cth, ctw);
+            if (nq >= 1 && nq <= kWinMaxQueries && nq > best) {
+                best = nq;
+                bth = cth;
+                btw = ctw;
+            }
+        }
+        if (tw || best >= kWinMaxQueries * 2 / 3) break;
+    }
+    if (!best) return false;
+    wg->TH = bth;
+    wg->TW = btw;
+    wg->HY = hy;
+    wg->HX = hx;
+    wg->tiles_y = (lt.H[0] + bth - 1) / bth;
+    wg->tiles_x = (lt.W[0] + btw - 1) / btw;
+    wg->cap_rows = kSortRowsCap;
+    memo.wg = *wg;
+    memo.ok = true;
+    return true;
+}
+
 // Launch msda_fwd_f32_win for encoder-shaped calls (Lq == S, host shapes).  Returns false if not taken.
 bool launch_win(bool fused, const DirectArgs &da, const LevelTable &lt, int N, int D, int P,
                 hipStream_t stream, hipError_t *err)
@@ -1689,6 +2094,17 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
         if (pl.vec == 4 && pow2 && (P == 1 || P == 2 || P == 4 || P == 8) &&
             buf_path_ok(lt, shapes_host != nullptr, N, S, M, D, L) && is_aligned(grad_value, 16)) {
             const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
+            WinGeom sgeom;
+            if (shapes_host && Lq == S && is_aligned(loc, 8) && is_aligned(grad_loc, 8) &&
+                plan_sorted(lt, L, D, P, &sgeom) &&
+                (long long)N * sgeom.tiles_y * sgeom.tiles_x * M <= 0x7fffffffLL) {
+                BwdSortArgs ba{value, vbytes, loc, attn, grad_out, grad_value, grad_loc, grad_attn, S, M, L};
+                const void *sfn = (const void *)&msda_bwd_f32_sorted;
+                void *argv[] = {(void *)&ba, (void *)&lt, (void *)&sgeom};
+                const unsigned sgrid = (unsigned)((long long)N * sgeom.tiles_y * sgeom.tiles_x * M);
+                return record_hip(hipLaunchKernel(sfn, dim3(sgrid), dim3(kWinThreads), argv,
+                                                  (size_t)kSortLdsBytes, stream));
+            }
             static const int rowatom_on = [] { const char *e = getenv("TF_MSDA_BWD_ROWATOM"); return (e && e[0] == '0') ? 0 : 1; }();
             const bool rowatom = rowatom_on && D == 32 && pl.DV == 8 && pl.ppb == kThreads / 8;
             const void *bfn =
