@@ -1025,6 +1025,7 @@ msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
     int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start          (48 ints)
     int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb
     int *s_bb = s_q + 5 * TF_MSDA_MAX_LEVELS + 4;                  // xmin xmax ymin ymax per level
+    int *s_direct = s_bb + 4 * kWinLevels;                         // per level: taps filed for direct scatter?
     unsigned *s_cnt = reinterpret_cast<unsigned *>(smem + kSortOffCnt);
     unsigned *s_start = reinterpret_cast<unsigned *>(smem + kSortOffStart);
     uint2 *s_item = reinterpret_cast<uint2 *>(smem + kSortOffItem);
@@ -1056,6 +1057,7 @@ msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
             }
         }
         s_bb[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
+        if (threadIdx.x < kWinLevels) s_direct[threadIdx.x] = 0;
     }
     __syncthreads();
 
@@ -1228,7 +1230,10 @@ msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
                                                     : (0x80000000u | (unsigned)(ty_ * W + tx_));
                         s_item[(tq * PT + p) * 4 + dv] =
                             uint2{row | ((unsigned)tq << 24), __builtin_bit_cast(unsigned, wt)};
-                        if (inside) atomicAdd(&s_cnt[row], 1u);
+                        if (inside)
+                            atomicAdd(&s_cnt[row], 1u);
+                        else
+                            s_direct[l] = 1;   // benign race: every writer stores the same value
                     }
                 }
                 // grad wrt attention weight / location: partial sums over this lane's 4 channels
@@ -1299,9 +1304,16 @@ msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
             const unsigned beg = s_start[row], end = s_start[row + 1];
             if (beg == end) continue;
             float acc = 0.f;
-            for (unsigned k = beg; k < end; ++k) {
-                const uint2 it = s_sorted[k];
-                acc = __builtin_fmaf(__builtin_bit_cast(float, it.y), s_go[((it.x >> 24) & 0x7Fu) * D + ch], acc);
+            for (unsigned k = beg; k < end; k += 4) {   // 4 independent LDS round trips in flight
+                uint2 it[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) it[j] = s_sorted[min(k + j, end - 1)];
+                float g[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = s_go[((it[j].x >> 24) & 0x7Fu) * D + ch];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (k + j < end) acc = __builtin_fmaf(__builtin_bit_cast(float, it[j].y), g[j], acc);
             }
             int wy = (int)(((float)row + 0.5f) * inv_ww);
             int wx = row - wy * ww;
@@ -1311,12 +1323,14 @@ msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
                 acc, rsrc_g, lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)ch * 4u, 0, 0);
         }
         // ---- f. taps outside the window: scattered directly, still one full row per half wave
-        for (int i = wave * 2 + half; i < kSortItems; i += 2 * kWinWaves) {
-            const uint2 it = s_item[i];
-            if (it.x != kSortInvalid && (it.x & 0x80000000u)) {
-                const float v = __builtin_bit_cast(float, it.y) * s_go[((it.x >> 24) & 0x7Fu) * D + ch];
-                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
-                    v, rsrc_g, lvl_base + (it.x & 0xFFFFFFu) * rowbytes + (unsigned)ch * 4u, 0, 0);
+        if (s_direct[l]) {
+            for (int i = wave * 2 + half; i < kSortItems; i += 2 * kWinWaves) {
+                const uint2 it = s_item[i];
+                if (it.x != kSortInvalid && (it.x & 0x80000000u)) {
+                    const float v = __builtin_bit_cast(float, it.y) * s_go[((it.x >> 24) & 0x7Fu) * D + ch];
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                        v, rsrc_g, lvl_base + (it.x & 0xFFFFFFu) * rowbytes + (unsigned)ch * 4u, 0, 0);
+                }
             }
         }
         __syncthreads();   // items / counters are reused by the next level
