@@ -25,7 +25,9 @@
 //                               inside the wave.  THE DEFAULT for the hot path.
 //   msda_fwd_f32_win            encoder shape only, opt-in: data-adaptive LDS windows.
 //   msda_bwd_rowgather<T,...>   any dtype; fuses the reference's two backward kernels.
-//   msda_bwd_f32_buf<P>         fp32 fast path: buffer loads + buffer atomics.
+//   msda_bwd_f32_buf<P,ROWATOM> fp32 fast path: buffer loads + buffer atomics (full-row scatter for D == 32).
+//   msda_bwd_f32_sorted         encoder shape, D == 32, P == 4: contributions counting-sorted by destination
+//                               row in LDS, one global atomic per row.  THE DEFAULT for encoder backward.
 // Common rules: level geometry comes from the kernel arguments (host-shape entry points) or from the
 // reference's device-resident int64 tensor (..._dshapes) -- never a host<->device sync; no kernel
 // branches per tap; nothing depends on CUDA-style 32-wide warps.
