@@ -32,6 +32,9 @@ import os
 import sys
 import time
 
+# RCCL / cross-process device memory on this stack need dmabuf IPC (see the environment notes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
