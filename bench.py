@@ -49,8 +49,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--no-graph", action="store_true", help="run the detector eagerly (no HIP graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument("--host-frames", action="store_true",
                     help="keep the frames in pinned host memory (PCIe copy inside the timed region); "
                          "the reported headline value always uses HBM-resident frames")
-    ap.add_argument("--sequences", type=int, default=2,
+    ap.add_argument("--sequences", type=int, default=4,
                     help="independent video sequences tracked concurrently per GPU (one host thread "
                          "and HIP stream each); frames of one sequence stay strictly sequential")
     return ap.parse_args()
