@@ -9,6 +9,13 @@ MODEL_CASES = {
     "cfg4_multi_frame_tracking": (("deformable", "tracking", "multi_frame", "mot17"),
                                   dict(num_queries=60), (160, 224), 5),
     "cfg1_plain_detr": ((), dict(dataset="coco"), (160, 192), 0),
+    # detector variants the overlays do not exercise (deformable_detr.py:96-122, deformable_transformer.py:
+    # 174-200,257-283): two-stage proposals, shared heads without box refinement, a single feature level
+    "deformable_two_stage": (("deformable", "mot17"), dict(two_stage=True, num_queries=30), (128, 160), 0),
+    "deformable_no_refine": (("deformable", "mot17"), dict(with_box_refine=False, num_queries=30),
+                             (128, 160), 0),
+    "deformable_one_level": (("deformable", "mot17"), dict(num_feature_levels=1, num_queries=30),
+                             (128, 160), 0),
     # BASELINE cfg 5 model path: mask head on the tracking detector (MOTS20) ...
     "cfg5_segm_tracking": (("deformable", "tracking", "mots20"), dict(num_queries=24),
                            (128, 160), 4),
