@@ -89,6 +89,19 @@ def main():
     print("train step: total loss %.6f, %d losses, %d params with grad -> %s" % (
         total, len(loss_dict), len(grads), os.path.basename(path)))
 
+    # the same with the mask head (loss_mask / loss_dice, gradients through MaskHeadSmallConv)
+    model, criterion, args = um.build_train(ref.models.build_model, config.make_args, masks=True)
+    samples, targets = um.train_batch(masks=True)
+    loss_dict, total, grads = um.train_step(model, criterion, samples, targets)
+    path = os.path.join(HERE, "train_cfg5_masks_small.npz")
+    np.savez_compressed(path, loss_keys=np.array(sorted(loss_dict)),
+                        loss_vals=np.array([loss_dict[k] for k in sorted(loss_dict)]),
+                        total=np.float64(total), grad_keys=np.array(um.TRAIN_MASK_GRAD_KEYS),
+                        grad_norms=np.array([grads[k] for k in um.TRAIN_MASK_GRAD_KEYS]),
+                        num_grads=np.int64(len(grads)))
+    print("mask train step: total loss %.6f, %d losses, %d params with grad -> %s" % (
+        total, len(loss_dict), len(grads), os.path.basename(path)))
+
     # tracker sequence
     model, post, args = um.build("cfg2_deformable_tracking", ref.models.build_model,
                                  config.make_args)
@@ -155,6 +168,20 @@ def tracker_variants(ref):
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["train_masks"]:
+        ref_ = reference_models.load()
+        torch.set_num_threads(4)
+        model, criterion, args = um.build_train(ref_.models.build_model, config.make_args, masks=True)
+        samples, targets = um.train_batch(masks=True)
+        loss_dict, total, grads = um.train_step(model, criterion, samples, targets)
+        np.savez_compressed(os.path.join(HERE, "train_cfg5_masks_small.npz"),
+                            loss_keys=np.array(sorted(loss_dict)),
+                            loss_vals=np.array([loss_dict[k] for k in sorted(loss_dict)]),
+                            total=np.float64(total), grad_keys=np.array(um.TRAIN_MASK_GRAD_KEYS),
+                            grad_norms=np.array([grads[k] for k in um.TRAIN_MASK_GRAD_KEYS]),
+                            num_grads=np.int64(len(grads)))
+        print("mask train step: total loss %.6f, losses %s" % (total, sorted(loss_dict)))
+        sys.exit(0)
     if sys.argv[1:] == ["tracker_variants"]:
         ref_ = reference_models.load()
         torch.set_num_threads(4)

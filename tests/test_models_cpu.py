@@ -222,16 +222,17 @@ def test_product_model_refuses_cpu_operator():
 
 
 # ------------------------------------------------------------------ one training step (cfg 3 path)
-def run_train_step(device="cpu"):
-    model, criterion, args = um.build_train(factory.build_model, config.make_args, device=device)
+def run_train_step(device="cpu", masks=False):
+    model, criterion, args = um.build_train(factory.build_model, config.make_args, device=device,
+                                            masks=masks)
     model.to(device)
     criterion.to(device)
-    samples, targets = um.train_batch(device=device)
+    samples, targets = um.train_batch(device=device, masks=masks)
     return um.train_step(model, criterion, samples, targets)
 
 
-def compare_train_to_golden(loss_dict, total, grads, rtol):
-    z = np.load(os.path.join(GOLDEN, "train_cfg3_small.npz"))
+def compare_train_to_golden(loss_dict, total, grads, rtol, fixture="train_cfg3_small.npz"):
+    z = np.load(os.path.join(GOLDEN, fixture))
     assert sorted(loss_dict) == z["loss_keys"].tolist()
     got = np.array([loss_dict[k] for k in sorted(loss_dict)])
     np.testing.assert_allclose(got, z["loss_vals"], rtol=rtol, atol=rtol)
@@ -246,6 +247,14 @@ def test_training_step_matches_reference(oracle_op):
     through MSDeformAttnFunction.backward; losses and gradient norms vs the reference on CPU."""
     loss_dict, total, grads = run_train_step()
     compare_train_to_golden(loss_dict, total, grads, rtol=2e-4)
+
+
+def test_training_step_with_mask_head_matches_reference(oracle_op):
+    """cfg-5 training path: + loss_mask (focal) / loss_dice (detr.py:330-358) and the gradients of
+    MHAttentionMap / MaskHeadSmallConv (incl. the split first convolution)."""
+    loss_dict, total, grads = run_train_step(masks=True)
+    assert "loss_mask" in loss_dict and "loss_dice" in loss_dict
+    compare_train_to_golden(loss_dict, total, grads, rtol=2e-4, fixture="train_cfg5_masks_small.npz")
 
 
 def test_engine_train_step_reproduces_reference_loss_and_updates_weights(oracle_op):

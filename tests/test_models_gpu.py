@@ -102,6 +102,13 @@ def test_training_step_matches_reference_cpu_path(dev):
     shared.compare_train_to_golden(loss_dict, total, grads, rtol=2e-3)
 
 
+def test_training_step_with_mask_head_matches_reference_cpu_path(dev):
+    """cfg 5 training path on the GPU (mask losses + mask-head gradients)."""
+    loss_dict, total, grads = shared.run_train_step(device=dev, masks=True)
+    shared.compare_train_to_golden(loss_dict, total, grads, rtol=2e-3,
+                                   fixture="train_cfg5_masks_small.npz")
+
+
 def test_graphed_detector_equals_eager(dev):
     """HIP-graph replay of the detector returns what the eager forward returns, frame after frame."""
     from trackformer_amd import config, factory

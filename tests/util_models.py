@@ -106,16 +106,18 @@ def to_device(target, device):
 TRAIN_OVERRIDES = dict(dropout=0.0, num_queries=40, enc_layers=2, dec_layers=3)
 
 
-def build_train(build_model_fn, make_args_fn, device="cpu", seed=42, weight_seed=2):
-    args = make_args_fn("deformable", "tracking", "mot17", device=str(device), **TRAIN_OVERRIDES)
+def build_train(build_model_fn, make_args_fn, device="cpu", seed=42, weight_seed=2, masks=False):
+    args = make_args_fn("deformable", "tracking", "mots20" if masks else "mot17", device=str(device),
+                        **TRAIN_OVERRIDES)
     torch.manual_seed(seed)
     model, criterion, post = build_model_fn(args)
     perturb_state_dict(model, weight_seed)
     return model, criterion, args
 
 
-def train_batch(seed=9, device="cpu"):
-    """Two differently sized images (padding masks, valid ratios < 1) with previous-frame targets."""
+def train_batch(seed=9, device="cpu", masks=False):
+    """Two differently sized images (padding masks, valid ratios < 1) with previous-frame targets;
+    masks=True adds box-shaped instance masks (the `masks` key loss_masks reads, detr.py:330-358)."""
     g = torch.Generator().manual_seed(seed)
     samples, targets = [], []
     for i, (h, w) in enumerate([(128, 160), (112, 144)]):
@@ -135,6 +137,15 @@ def train_batch(seed=9, device="cpu"):
                                                    device=device),
                              'track_ids': ids[prev_keep].to(device),
                              'image_id': torch.tensor([i], device=device)}}
+        if masks:
+            def box_masks(bx):
+                m = torch.zeros(len(bx), h, w, dtype=torch.bool)
+                for k, (cx, cy, bw, bh) in enumerate(bx.tolist()):
+                    m[k, max(0, int((cy - bh / 2) * h)):int((cy + bh / 2) * h) + 1,
+                      max(0, int((cx - bw / 2) * w)):int((cx + bw / 2) * w) + 1] = True
+                return m
+            t['masks'] = box_masks(boxes).to(device)
+            t['prev_target']['masks'] = box_masks(prev_boxes[prev_keep]).to(device)
         samples.append(img.to(device))
         targets.append(t)
     return samples, targets
@@ -155,6 +166,12 @@ def train_step(model, criterion, samples, targets, rng_seed=7):
              if p.grad is not None}
     return {k: float(v) for k, v in loss_dict.items()}, float(losses), grads
 
+
+TRAIN_MASK_GRAD_KEYS = [
+    "bbox_attention.q_linear.weight", "bbox_attention.k_linear.weight", "mask_head.lay1.weight",
+    "mask_head.gn3.weight", "mask_head.adapter2.weight", "mask_head.out_lay.weight",
+    "transformer.encoder.layers.0.self_attn.sampling_offsets.weight", "input_proj.1.0.weight",
+]
 
 TRAIN_GRAD_KEYS = [
     "transformer.encoder.layers.0.self_attn.sampling_offsets.weight",
