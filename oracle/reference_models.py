@@ -99,3 +99,22 @@ def load():
         transformer=ref_transformer, box_ops=ref_box_ops, misc=ref_misc,
         msda_module=ref_msda_module, core_pytorch=ms_deform_attn_core_pytorch)
     return _loaded
+
+
+def accept_prev_features():
+    """The reference's plain `DETR.forward(samples, targets)` cannot be called by its own
+    `DETRTrackingBase.forward` / `Tracker.step`, which pass `prev_features` as a third positional
+    argument (detr_tracking.py:275, tracker.py:307 vs detr.py:62).  For the goldens of the
+    dense-attention tracking model the harness widens the signature (the extra argument is ignored,
+    exactly as the deformable detector ignores it without multi-frame attention); nothing else of
+    the reference is touched."""
+    ref = load()
+    if getattr(ref.detr.DETR.forward, "_accepts_prev_features", False):
+        return
+    original = ref.detr.DETR.forward
+
+    def forward(self, samples, targets=None, prev_features=None):
+        return original(self, samples, targets)
+
+    forward._accepts_prev_features = True
+    ref.detr.DETR.forward = forward

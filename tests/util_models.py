@@ -16,6 +16,8 @@ MODEL_CASES = {
                              (128, 160), 0),
     "deformable_one_level": (("deformable", "mot17"), dict(num_feature_levels=1, num_queries=30),
                              (128, 160), 0),
+    # dense-attention tracking model (DETRTracking: transformer.py track-query prepend, detr.py focal off)
+    "plain_detr_tracking": (("tracking", "mot17"), dict(num_queries=20), (128, 160), 5),
     # BASELINE cfg 5 model path: mask head on the tracking detector (MOTS20) ...
     "cfg5_segm_tracking": (("deformable", "tracking", "mots20"), dict(num_queries=24),
                            (128, 160), 4),
