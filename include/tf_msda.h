@@ -65,10 +65,31 @@ int tf_msda_last_hip_error(void);
 /*
  * Kernel selection knob (process-wide, performance only -- results are identical up to fp32 summation
  * order): 1 enables the LDS-window forward kernel for encoder-shaped calls (Lq == S, fp32, D == 32,
- * P == 4, L <= 4, host shapes), 0 disables it, -1 restores the default (environment variable
- * TF_MSDA_TILED, off when unset).  Returns the previous setting.
+ * P == 4, L <= 4, host shapes), 2 selects msda_fwd_f32_quad for the same calls, 0 disables both, -1 restores
+ * the default (environment variable TF_MSDA_TILED, off when unset).  Returns the previous setting.
  */
 int tf_msda_set_tiled(int mode);
+
+/*
+ * Generic form of the knob above (process-wide, performance only).  Sets option `name` to `value` and
+ * returns the previous value, or INT_MIN for an unknown name.  Names:
+ *   "tiled"         0 / 1 / 2 / -1 as tf_msda_set_tiled (2 = the 4-lanes-per-pair LDS-window kernel
+ *                   msda_fwd_f32_quad, same eligibility as mode 1)
+ *   "quad_ta_mask"  bit l set: level l is gathered by buffer loads instead of an LDS window (0, 8 or 12)
+ *   "quad_waves"    wavefronts per workgroup (4 or 8);  "quad_npass"  passes of 16 pairs per wave (1 or 2)
+ *   "quad_lds_kb"   LDS per workgroup (decides the workgroups per CU and the window capacity)
+ *   "quad_halo_y" / "quad_halo_x"   clamp of the data-adaptive windows around the tile footprint
+ *   "quad_tile_h" / "quad_tile_w"   tile size in level-0 pixels (0 = search)
+ * Environment: TF_MSDA_TILED=2, TF_MSDA_QUAD="ta=12,waves=8,npass=1,lds=53,hy=6,hx=10,th=0,tw=0".
+ */
+int tf_msda_set_option(const char *name, int value);
+
+/*
+ * Debug aid of tools/msda_bench --trace (not part of the operator contract): while `device_buffer` is not
+ * NULL, every workgroup of msda_fwd_f32_quad writes 16 uint64 phase timestamps (s_memrealtime, 100 MHz) to
+ * device_buffer[16 * blockIdx + i].  The buffer must hold 16 * grid entries; pass NULL to switch it off.
+ */
+void tf_msda_debug_trace_buffer(void *device_buffer);
 
 /*
  * Forward.  out[N,Lq,M*D] = sum_{l,p} attn * bilinear(value_l, loc)      (Appendix A of SURVEY.md)

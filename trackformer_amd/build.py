@@ -41,6 +41,7 @@ def build_all(force=False, verbose=False):
     os.makedirs(LIB_DIR, exist_ok=True)
     built = []
     headers = [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    headers += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]   # kernel includes
     for out_name, srcs, extra in _TARGETS:
         out = os.path.join(LIB_DIR, out_name)
         src_paths = [os.path.join(CSRC, s) for s in srcs]
@@ -52,7 +53,28 @@ def build_all(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         built.append(out)
+    built += _build_tools(force, verbose)
     return built
+
+
+def _build_tools(force, verbose):
+    """tools/bin/msda_bench: standalone parity + timing harness of the forward kernels (no Python on the
+    GPU box).  Links against the in-tree libtf_msda.so through a relative rpath."""
+    src = os.path.join(REPO_DIR, "tools", "msda_bench.cpp")
+    if not os.path.exists(src):
+        return []
+    out_dir = os.path.join(REPO_DIR, "tools", "bin")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "msda_bench")
+    lib = os.path.join(LIB_DIR, "libtf_msda.so")
+    if not force and not _stale(out, [src, lib]):
+        return []
+    cmd = [_hipcc(), "--offload-arch=" + GFX_ARCH, "-O2", "-std=c++17", "-I" + INCLUDE, src,
+           "-L" + LIB_DIR, "-ltf_msda", "-Wl,-rpath,$ORIGIN/../../trackformer_amd/lib", "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return [out]
 
 
 if __name__ == "__main__":

@@ -1,0 +1,562 @@
+// trackformer_amd/csrc/msda_fwd_quad.h -- included by msda_hip.hip inside its anonymous namespace.
+//
+// msda_fwd_f32_quad: MSDeformAttn forward for encoder-shaped calls (Lq == S), fp32, D == 32, P == 4, L <= 4.
+//
+// Why another kernel.  msda_fwd_f32_direct moves 64 taps x 128 B per (query, head) pair through the
+// vector-memory path (64 B/clk/CU: 37-45 us at the cfg-2 encoder shape), msda_fwd_f32_win moves them
+// through LDS (256 B/clk/CU) but pays for it in instructions: 8 lanes per pair need the tap offsets and
+// weights of all 16 points of the pair, exchanged through LDS (1/3 of its LDS wave-instructions, 27 KB of
+// LDS), and every window tap carries its own validity test (1313 VALU instructions per wave, PMC).
+// This kernel removes both:
+//   * 4 lanes per pair (a DPP quad), 8 channels per lane.  Lane j of the quad owns point j of every level
+//     and computes its tap arithmetic ONCE; the other three lanes read the result with DPP quad_perm
+//     broadcasts that the compiler folds into the consuming v_add_u32 (addresses) or issues as one
+//     v_mov_b32_dpp per tap weight -- no LDS exchange, no fences, no exchange buffers.
+//   * Windows live in EXTENDED pixel coordinates (-1 .. size): pixels outside the level are staged as
+//     zeros by the LDS-DMA itself (out-of-range source offset), so a staged point is one box test and two
+//     row addresses (y0 and y0 + 1; the x0 + 1 taps are the +128 B immediates), not four guarded ones.
+//   * TA_MASK routes whole levels through buffer loads instead of LDS windows: the texture path and
+//     the LDS pipe are separate resources, the coarse levels' few rows stay in the vector L1, and their
+//     windows (halo-dominated) no longer occupy LDS, which buys workgroups per CU.
+//   * A lane reads its 8 channels as two 16-byte pieces from opposite 64-byte halves of the row, the
+//     half order alternating with bit 1 of the quad index: the four quads an LDS cycle serves then hit
+//     four disjoint bank groups when neighbouring queries read neighbouring rows (the encoder's pattern).
+// Points whose taps leave their window (clamped box, LDS capacity) take buffer loads under a wave-uniform
+// branch, so any input is handled exactly.  The tile / window geometry is in msda_quad_geom.h, shared
+// with the host emulation (tests/emu/quad_emu.cpp) that checks this logic against the oracle on the CPU.
+//
+// Arithmetic: SURVEY.md Appendix A; reference ms_deform_im2col_cuda.cuh:227-237 (pixel mapping, in-range
+// rule), :24-67 (bilinear taps with zero padding).
+
+constexpr int kQuadHdrBytes = 768;   // level table | query partition | bounding boxes | nominal footprints
+constexpr int kQuadLevels = 4;
+
+struct QuadGeom {
+    int TH, TW;        // tile size in level-0 pixels
+    int HY, HX;        // windows are clamped to the tile footprint +- this many pixels
+    int tiles_y, tiles_x;
+    int cap_rows;      // LDS rows available for windows, all levels together (multiple of 8)
+    unsigned long long *trace;   // debug: 16 timestamps (s_memrealtime, 100 MHz) per workgroup, or null
+};
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppQuadXor1 = 0xB1;   // quad_perm [1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;   // quad_perm [2,3,0,1]
+constexpr int kDppRowRor4 = 0x124;
+constexpr int kDppRowRor8 = 0x128;
+
+// One point's four taps from LDS windows.  a0 / a1: byte offsets (from the first LDS row) of the rows
+// (y0, x0) and (y0 + 1, x0) held by lane K of the quad; the x0 + 1 taps are the next 128-byte rows.
+// ldsA / ldsB: this lane's LDS byte addresses of its two 16-byte pieces of row 0 -- plain integers, so
+// that the quad broadcast folds into the address add (v_add_u32_dpp) and the + 128 becomes an immediate.
+typedef const __attribute__((address_space(3))) f32x4_t *lds_f32x4_ptr;
+__device__ __forceinline__ f32x4_t lds_read16(unsigned addr)
+{
+    return *reinterpret_cast<lds_f32x4_ptr>((size_t)addr);
+}
+template <int K>
+__device__ __forceinline__ void quad_taps_lds(unsigned a0, unsigned a1, const float (&w)[4], unsigned ldsA,
+                                              unsigned ldsB, f32x4_t &accA, f32x4_t &accB)
+{
+    constexpr int C = K * 0x55;   // quad_perm [K,K,K,K]
+    const unsigned p0a = dpp_u<C>(a0) + ldsA, p0b = dpp_u<C>(a0) + ldsB;
+    const unsigned p1a = dpp_u<C>(a1) + ldsA, p1b = dpp_u<C>(a1) + ldsB;
+    const float W0 = dpp_f<C>(w[0]), W1 = dpp_f<C>(w[1]), W2 = dpp_f<C>(w[2]), W3 = dpp_f<C>(w[3]);
+    const f32x4_t v00a = lds_read16(p0a), v01a = lds_read16(p0a + 128u);
+    const f32x4_t v00b = lds_read16(p0b), v01b = lds_read16(p0b + 128u);
+    const f32x4_t v10a = lds_read16(p1a), v11a = lds_read16(p1a + 128u);
+    const f32x4_t v10b = lds_read16(p1b), v11b = lds_read16(p1b + 128u);
+    accA += v00a * W0;
+    accB += v00b * W0;
+    accA += v01a * W1;
+    accB += v01b * W1;
+    accA += v10a * W2;
+    accB += v10b * W2;
+    accA += v11a * W3;
+    accB += v11b * W3;
+}
+
+// One point's four taps by buffer loads.  g[t]: byte offset of tap t's row (this head's 128 bytes) held
+// by lane K of the quad; invalid taps carry kOobBase, which stays out of range after + rbA / rbB.
+template <int K>
+__device__ __forceinline__ void quad_taps_global(const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&g)[4],
+                                                 const float (&w)[4], unsigned rbA, unsigned rbB,
+                                                 f32x4_t &accA, f32x4_t &accB)
+{
+    constexpr int C = K * 0x55;
+    u32x4_t va[4], vb[4];
+    float W[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned G = dpp_u<C>(g[t]);
+        W[t] = dpp_f<C>(w[t]);
+        va[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G + rbA, 0, 0);
+        vb[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G + rbB, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        accA += __builtin_bit_cast(f32x4_t, va[t]) * W[t];
+        accB += __builtin_bit_cast(f32x4_t, vb[t]) * W[t];
+    }
+}
+
+// 32-bit byte offsets from a kernel-uniform base: the compiler emits global_load ... v_off, s[base:base+1].
+__device__ __forceinline__ float ldg_f(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
+}
+__device__ __forceinline__ float2 ldg_f2(const float *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
+}
+
+// ROUND0: the levels whose windows are staged (and gathered) first; the remaining LDS levels reuse the same
+// LDS rows in a second round (0xF: one round, all windows resident at once).
+template <bool FUSED, int TA_MASK, int WAVES, int NPASS, int ROUND0>
+__global__ void __launch_bounds__(WAVES * 64, NPASS == 1 ? 6 : NPASS == 2 ? 5 : 4)
+msda_fwd_f32_quad(const DirectArgs da, const LevelTable lt, const QuadGeom qg)
+{
+    constexpr int PT = 4, D = 32, NL = kQuadLevels, THREADS = WAVES * 64, PAIRS = THREADS / 4;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    // header (ints): [0..3] H, [4..7] W, [8..11] start, [12..27] tile bounds ya | yb | xa | xb per level,
+    // [28..43] nominal footprint ny0 | ny1 | nx0 | nx1 per level; [64 + 16 w ..]: wave w's bounding boxes
+    int *s_hdr = reinterpret_cast<int *>(smem);
+    int *s_wbb = s_hdr + 64;
+    unsigned char *s_rows = smem + kQuadHdrBytes;     // rows 0, 1: zeros; the windows start at row 2
+
+    const int L = da.L, M = da.M, S = da.S, LP = L * PT;
+    const int m = blockIdx.x % M;                     // one head per XCD when M == 8
+    int t = blockIdx.x / M;
+    const int tx = t % qg.tiles_x;
+    t /= qg.tiles_x;
+    const int ty = t % qg.tiles_y;
+    const int b = t / qg.tiles_y;
+
+    if (threadIdx.x < 4 * NL) {
+        // thread 4l+k: bound k (ya, yb, xa, xb) of the pixels of level l whose centre lies in the tile's
+        // normalised rectangle, and bound k of the tile's nominal footprint in level l (window clamp)
+        const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
+        int bound = 0, nom = 0;
+        if (l < L) {
+            const unsigned H0 = (unsigned)lt.H[0], W0 = (unsigned)lt.W[0];
+            const unsigned Hl = (unsigned)lt.H[l], Wl = (unsigned)lt.W[l];
+            const unsigned y0 = (unsigned)ty * qg.TH, y1 = min(H0, y0 + (unsigned)qg.TH);
+            const unsigned x0 = (unsigned)tx * qg.TW, x1 = min(W0, x0 + (unsigned)qg.TW);
+            bound = k == 0   ? tfq_tile_bound(y0, Hl, H0)
+                    : k == 1 ? tfq_tile_bound(y1, Hl, H0)
+                    : k == 2 ? tfq_tile_bound(x0, Wl, W0)
+                             : tfq_tile_bound(x1, Wl, W0);
+            int lo, hi;
+            if (k < 2)
+                tfq_nominal((int)y0, (int)y1, (int)Hl, 1.f / (float)H0, qg.HY, &lo, &hi);
+            else
+                tfq_nominal((int)x0, (int)x1, (int)Wl, 1.f / (float)W0, qg.HX, &lo, &hi);
+            nom = (k & 1) ? hi : lo;
+        }
+        s_hdr[12 + 4 * k + l] = bound;
+        s_hdr[28 + 4 * k + l] = nom;
+        if (k < 3) {
+            const int lc = l < L ? l : 0;   // levels past L read as level 0: keeps every derived quantity sane
+            s_hdr[4 * k + l] = k == 0 ? lt.H[lc] : k == 1 ? lt.W[lc] : lt.start[lc];
+        }
+    }
+    if (threadIdx.x < 64) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;
+    // phase timestamps of wave 0 (tools/msda_bench --trace): where a workgroup's time goes
+    auto stamp = [&](int i) {
+        if (qg.trace != nullptr && threadIdx.x == 0)
+            qg.trace[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    __syncthreads();
+    stamp(1);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = threadIdx.x & 3;
+    const int quad = threadIdx.x >> 2;
+    const int hsel = (quad >> 1) & 1;
+    const unsigned rbA = (unsigned)(hsel * 64 + sub * 16), rbB = (unsigned)((1 - hsel) * 64 + sub * 16);
+    const unsigned lds_rows =
+        (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)s_rows);
+    const unsigned ldsA = lds_rows + rbA, ldsB = lds_rows + rbB;
+
+    // the whole header in ONE LDS read per wave, then v_readlane broadcasts into scalar registers
+    const int hv = s_hdr[lane];
+    int Hs[NL], Ws[NL], starts[NL], ya[NL], yb[NL], xa[NL], xb[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        Hs[l] = __builtin_amdgcn_readlane(hv, l);
+        Ws[l] = __builtin_amdgcn_readlane(hv, 4 + l);
+        starts[l] = __builtin_amdgcn_readlane(hv, 8 + l);
+        ya[l] = __builtin_amdgcn_readlane(hv, 12 + l);
+        yb[l] = __builtin_amdgcn_readlane(hv, 16 + l);
+        xa[l] = __builtin_amdgcn_readlane(hv, 20 + l);
+        xb[l] = __builtin_amdgcn_readlane(hv, 24 + l);
+    }
+    int qoff[NL + 1];   // first tile-local index of every level's queries (levels past L hold none)
+    qoff[0] = 0;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) qoff[l + 1] = qoff[l] + (yb[l] - ya[l]) * (xb[l] - xa[l]);
+    const int nq = qoff[NL];   // <= NPASS * PAIRS (the host checked the maximum)
+
+    // ---- the query of this lane's quad in every pass; the sampling points (l, sub) it owns --------
+    unsigned bq32[NPASS], pair32[NPASS];   // b * S + q, (b * S + q) * M + m: byte offsets fit 32 bits (host checked)
+    bool live[NPASS];
+    float sx[NPASS][NL], sy[NPASS][NL], sa[NPASS][NL];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        const int tq = ps * PAIRS + quad;
+        live[ps] = tq < nq;
+        // the level of the query and that level's tile bounds: per-lane selects from scalar registers
+        int base = 0, nx = xb[0] - xa[0], ya_l = ya[0], xa_l = xa[0], W_l = Ws[0], start_l = starts[0];
+#pragma unroll
+        for (int k = 1; k < NL; ++k) {
+            const bool ge = tq >= qoff[k] && qoff[k + 1] > qoff[k];
+            base = ge ? qoff[k] : base;
+            nx = ge ? xb[k] - xa[k] : nx;
+            ya_l = ge ? ya[k] : ya_l;
+            xa_l = ge ? xa[k] : xa_l;
+            W_l = ge ? Ws[k] : W_l;
+            start_l = ge ? starts[k] : start_l;
+        }
+        const int r = tq - base;   // < NPASS * PAIRS
+        // r / nx: (r + 0.5) / nx is at least 0.5 / nx away from an integer, far more than the float error
+        const int yy = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nx));
+        const int xx = r - yy * nx;
+        const int q = live[ps] ? start_l + (ya_l + yy) * W_l + xa_l + xx : 0;
+        const unsigned bq = (unsigned)b * (unsigned)S + (unsigned)q;
+        bq32[ps] = bq;
+        pair32[ps] = bq * (unsigned)M + (unsigned)m;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const unsigned s = (unsigned)((l < L ? l : 0) * PT + sub);
+            if constexpr (!FUSED) {
+                const float2 xy = ldg_f2(da.loc, (pair32[ps] * (unsigned)LP + s) * 8u);
+                sx[ps][l] = xy.x;
+                sy[ps][l] = xy.y;
+                sa[ps][l] = ldg_f(da.attn, (pair32[ps] * (unsigned)LP + s) * 4u);
+            } else {
+                const unsigned row = bq * (unsigned)da.fa.ld;
+                const float2 off = ldg_f2(da.fa.qproj, (row + (unsigned)da.fa.off_col + ((unsigned)(m * LP) + s) * 2u) * 4u);
+                sx[ps][l] = off.x;
+                sy[ps][l] = off.y;
+                sa[ps][l] = l < L ? ldg_f(da.fa.qproj, (row + (unsigned)da.fa.logit_col + (unsigned)(m * LP) + s) * 4u)
+                                  : -__builtin_inff();
+            }
+        }
+    }
+    stamp(12);   // point loads issued
+    if constexpr (FUSED) {
+#pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            // softmax over the pair's L*P logits: this lane holds L of them, the quad the rest
+            float mx = sa[ps][0];
+#pragma unroll
+            for (int l = 1; l < NL; ++l) mx = fmaxf(mx, sa[ps][l]);
+            mx = fmaxf(mx, dpp_f<kDppQuadXor1>(mx));
+            mx = fmaxf(mx, dpp_f<kDppQuadXor2>(mx));
+            float sum = 0.f;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                sa[ps][l] = l < L ? __expf(sa[ps][l] - mx) : 0.f;
+                sum += sa[ps][l];
+            }
+            sum += dpp_f<kDppQuadXor1>(sum);
+            sum += dpp_f<kDppQuadXor2>(sum);
+            const unsigned bq = bq32[ps];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                sa[ps][l] = sa[ps][l] / sum;
+                const int lc = l < L ? l : 0;
+                const float *rp = da.fa.ref + ((size_t)bq * L + lc) * da.fa.ref_dim;
+                if (da.fa.ref_dim == 2) {
+                    sx[ps][l] = rp[0] + sx[ps][l] / (float)Hs[l];   // x / H_l (as the reference writes it)
+                    sy[ps][l] = rp[1] + sy[ps][l] / (float)Ws[l];   // y / W_l
+                } else {
+                    sx[ps][l] = rp[0] + sx[ps][l] / (float)PT * rp[2] * 0.5f;
+                    sy[ps][l] = rp[1] + sy[ps][l] / (float)PT * rp[3] * 0.5f;
+                }
+            }
+        }
+    }
+
+    // ---- phase A: bounding box of the floor coordinates of the in-range points, per LDS level ---------
+    // Reduced over the wave by DPP (rows, then row_bcast), filed per wave in LDS, combined after the barrier:
+    // no LDS atomics.  `mine`: lane 4l+k collects bound k (min x0, max x0, min y0, max y0) of level l.
+    int mine = (lane & 1) ? INT_MIN : INT_MAX;
+    auto phase_a = [&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        if constexpr (((TA_MASK >> l) & 1) == 0) {
+            if (l < L) {
+                int v[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};   // min x0, max x0, min y0, max y0
+                const float Wf = (float)Ws[l], Hf = (float)Hs[l];
+#pragma unroll
+                for (int ps = 0; ps < NPASS; ++ps) {
+                    const float xr = __builtin_fmaf(sx[ps][l], Wf, -0.5f);
+                    const float yr = __builtin_fmaf(sy[ps][l], Hf, -0.5f);
+                    const bool in = live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
+                    const int x0 = (int)__builtin_floorf(in ? xr : 0.f), y0 = (int)__builtin_floorf(in ? yr : 0.f);
+                    v[0] = min(v[0], in ? x0 : INT_MAX);
+                    v[1] = max(v[1], in ? x0 : INT_MIN);
+                    v[2] = min(v[2], in ? y0 : INT_MAX);
+                    v[3] = max(v[3], in ? y0 : INT_MIN);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int x = v[k];
+                    const bool mx = (k & 1) != 0;
+                    // 16 lanes of a DPP row, then rows 0+1 / 2+3 (row_bcast15), then both halves (row_bcast31)
+                    x = mx ? max(x, dpp_i<kDppQuadXor1>(x)) : min(x, dpp_i<kDppQuadXor1>(x));
+                    x = mx ? max(x, dpp_i<kDppQuadXor2>(x)) : min(x, dpp_i<kDppQuadXor2>(x));
+                    x = mx ? max(x, dpp_i<kDppRowRor4>(x)) : min(x, dpp_i<kDppRowRor4>(x));
+                    x = mx ? max(x, dpp_i<kDppRowRor8>(x)) : min(x, dpp_i<kDppRowRor8>(x));
+                    const int b15 = __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false);
+                    x = mx ? max(x, b15) : min(x, b15);
+                    const int b31 = __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false);
+                    x = mx ? max(x, b31) : min(x, b31);
+                    // the wave's result must be read with every lane still active: the empty asm pins the
+                    // v_readlane here (the compiler otherwise sinks it, and the last min/max, into the
+                    // single-lane select below, where lane 63 no longer executes)
+                    int tot = __builtin_amdgcn_readlane(x, 63);
+                    asm volatile("" : "+s"(tot));
+                    mine = lane == 4 * l + k ? tot : mine;
+                }
+            }
+        }
+    };
+    phase_a(std::integral_constant<int, 0>{});
+    stamp(13);   // level 0's points arrived, its bounding box reduced
+    phase_a(std::integral_constant<int, 1>{});
+    phase_a(std::integral_constant<int, 2>{});
+    phase_a(std::integral_constant<int, 3>{});
+    if (lane < 16) s_wbb[wave * 16 + lane] = mine;
+    stamp(2);   // the sampling points have arrived, bounding boxes filed
+    __syncthreads();
+    stamp(3);
+    // combine the waves' boxes (lane 4l+k: bound k of level l) and broadcast them into scalar registers
+    int bbv = (lane & 1) ? INT_MIN : INT_MAX;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+        const int x = s_wbb[w * 16 + (lane & 15)];
+        bbv = (lane & 1) ? max(bbv, x) : min(bbv, x);
+    }
+    const int nomv = s_hdr[28 + (lane & 15)];   // lane 4k+l: nominal bound k of level l
+
+    // ---- phase B: window geometry (wave-uniform, kept in scalar registers) and LDS-DMA staging ---------
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;
+    const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(da.value), 0, da.value_bytes, 0x00020000);
+    int gwx0[NL], gwy0[NL], glimx[NL], glimy[NL], gww[NL], groff[NL];
+    unsigned glvl[NL];
+    bool by_loads[NL];   // the level is gathered by buffer loads (TA_MASK, or its window did not fit)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        glvl[l] = head_base + (unsigned)starts[l] * rowbytes;
+        gwx0[l] = kQuadFar;
+        gwy0[l] = kQuadFar;
+        glimx[l] = 0;
+        glimy[l] = 0;
+        gww[l] = 0;
+        groff[l] = 0;
+        by_loads[l] = true;
+    }
+    int used = 0;   // LDS rows taken by the windows of the current round
+    auto phase_b = [&](auto lc, auto rc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int RMASK = decltype(rc)::value;
+        {
+            if constexpr (((TA_MASK >> l) & 1) == 0 && ((RMASK >> l) & 1) != 0) {
+                if (l < L) {
+                    const int H = Hs[l], W = Ws[l];
+                    const int bx0 = __builtin_amdgcn_readlane(bbv, 4 * l + 0);
+                    const int bx1 = __builtin_amdgcn_readlane(bbv, 4 * l + 1);
+                    const int by0 = __builtin_amdgcn_readlane(bbv, 4 * l + 2);
+                    const int by1 = __builtin_amdgcn_readlane(bbv, 4 * l + 3);
+                    const int ny0 = __builtin_amdgcn_readlane(nomv, l);
+                    const int ny1 = __builtin_amdgcn_readlane(nomv, 4 + l);
+                    const int nx0 = __builtin_amdgcn_readlane(nomv, 8 + l);
+                    const int nx1 = __builtin_amdgcn_readlane(nomv, 12 + l);
+                    bool fits;
+                    const QuadWindow w = tfq_window(bx0, bx1, by0, by1, nx0, nx1, ny0, ny1, qg.cap_rows - used, 2 + used, &fits);
+                    by_loads[l] = !fits;
+                    const int ww = w.ww, wh = w.wh, wx0 = w.wx0, wy0 = w.wy0;
+                    const int roff = 2 + used;
+                    gwx0[l] = wx0;
+                    gwy0[l] = wy0;
+                    glimx[l] = w.limx;
+                    glimy[l] = w.limy;
+                    gww[l] = ww;
+                    groff[l] = roff;
+                    const int nrows = wh * ww;
+                    const int nchunks = (nrows + 7) >> 3;   // one DMA wave-instruction = 8 rows of 128 B
+                    used += nchunks * 8;
+                    if (nchunks > 0) {
+                        // lane (row r = 8 * chunk + lane / 8, 16-byte column lane % 8): window pixel (wy, wx) of
+                        // its row, advanced incrementally by 8 * WAVES rows per iteration
+                        const unsigned lvl_base = glvl[l];
+                        const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
+                        int r = wave * 8 + (lane >> 3);                       // < 64
+                        int wy = (int)(((float)r + 0.5f) * inv_ww);
+                        int wx = r - wy * ww;
+                        constexpr int STEP = 8 * WAVES;
+                        const int qstep = __builtin_amdgcn_readfirstlane((int)(((float)STEP + 0.5f) * inv_ww));
+                        const int rstep = STEP - qstep * ww;
+                        unsigned off = lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)(lane & 7) * 16u;
+                        const unsigned step_a = (unsigned)(qstep * W + rstep) * rowbytes;
+                        const unsigned step_b = (unsigned)(W - ww) * rowbytes;
+                        for (int c = wave; c < nchunks; c += WAVES) {
+                            const int py = wy0 + wy, px = wx0 + wx;   // extended coordinates: may be -1 or size
+                            const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128),
+                                16, ok ? off : kOobOffset /* hardware writes zeros */, 0, 0, 0);
+                            r += STEP;
+                            wy += qstep;
+                            wx += rstep;
+                            off += step_a;
+                            if (wx >= ww) {
+                                wx -= ww;
+                                wy += 1;
+                                off += step_b;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- phase C: gather.  Levels served by buffer loads first (they do not need the windows: the DMA is
+    // still landing), then -- behind the barrier -- the levels served from LDS --------------------------
+    f32x4_t accA[NPASS], accB[NPASS];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        accA[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        accB[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    auto level = [&](auto lc, auto psc, auto ldsc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int ps = decltype(psc)::value < NPASS ? decltype(psc)::value : 0;   // (never called out of range)
+        constexpr bool LDS_PHASE = decltype(ldsc)::value;
+        constexpr bool TA = ((TA_MASK >> l) & 1) != 0;
+        if (l >= L) return;                          // uniform
+        if constexpr (TA && LDS_PHASE) return;
+        if (!TA && by_loads[l] == LDS_PHASE) return;   // uniform: a level runs in exactly one of the two phases
+        if (ps * PAIRS >= nq) return;                // uniform
+        const int H = Hs[l], W = Ws[l];
+        const float Wf = (float)W, Hf = (float)H;
+        const float xr = __builtin_fmaf(sx[ps][l], Wf, -0.5f);   // cuh:227-228, single rounding
+        const float yr = __builtin_fmaf(sy[ps][l], Hf, -0.5f);
+        const bool in = live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
+        const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+        const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+        const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+        const int x0 = (int)xf, y0 = (int)yf;
+        const float a = in ? sa[ps][l] : 0.f;
+        const float w[4] = {gy * gx * a, gy * fx * a, fy * gx * a, fy * fx * a};
+        bool need_global = in;
+        if constexpr (LDS_PHASE) {
+            const int dx = x0 - gwx0[l], dy = y0 - gwy0[l];
+            const bool staged = in && (unsigned)dx <= (unsigned)glimx[l] && (unsigned)dy <= (unsigned)glimy[l];
+            const unsigned lo = (unsigned)(groff[l] + dy * gww[l] + dx) * 128u;
+            const unsigned a0 = staged ? lo : 0u;                            // rows 0, 1 are zeros
+            const unsigned a1 = staged ? lo + (unsigned)gww[l] * 128u : 0u;
+            quad_taps_lds<0>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+            quad_taps_lds<1>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+            quad_taps_lds<2>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+            quad_taps_lds<3>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+            need_global = in && !staged;
+            if (!__any(need_global)) return;   // wave-uniform: no point of this wave left its window
+        }
+        const bool kx0 = need_global && (x0 >= 0), kx1 = need_global && (x0 + 1 <= W - 1);
+        const bool ky0 = (y0 >= 0), ky1 = (y0 + 1 <= H - 1);
+        const int r0 = y0 * W + x0;
+        const unsigned lvl_base = glvl[l];
+        // staged / invalid taps: kOobBase + (lane offset < 128) is still out of range -> hardware zero
+        const unsigned g[4] = {(ky0 && kx0) ? lvl_base + (unsigned)r0 * rowbytes : kOobBase,
+                               (ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase,
+                               (ky1 && kx0) ? lvl_base + (unsigned)(r0 + W) * rowbytes : kOobBase,
+                               (ky1 && kx1) ? lvl_base + (unsigned)(r0 + W + 1) * rowbytes : kOobBase};
+        quad_taps_global<0>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+        quad_taps_global<1>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+        quad_taps_global<2>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+        quad_taps_global<3>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+    };
+    // one round: stage the windows of the levels in RMASK, gather the levels of the round that go by buffer
+    // loads while the DMA lands (round 0 also takes the TA_MASK levels), then the levels served from LDS
+    auto store = [&](auto psc) {
+        constexpr int ps = decltype(psc)::value < NPASS ? decltype(psc)::value : 0;   // (never called out of range)
+        if (live[ps]) {
+            float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(da.out) + (size_t)(pair32[ps] * (unsigned)(D * 4)));
+            *reinterpret_cast<f32x4_t *>(o + rbA / 4) = accA[ps];
+            *reinterpret_cast<f32x4_t *>(o + rbB / 4) = accB[ps];
+        }
+    };
+    auto round = [&](auto rc, auto firstc, auto lastc) {
+        constexpr int RMASK = decltype(rc)::value;
+        constexpr bool FIRST = decltype(firstc)::value;
+        constexpr bool LAST = decltype(lastc)::value;
+        constexpr int LOADS_MASK = FIRST ? (RMASK | TA_MASK) : (RMASK & ~TA_MASK);
+        if constexpr (!FIRST) __syncthreads();   // every wave is done reading the previous round's windows
+        used = 0;
+        phase_b(std::integral_constant<int, 0>{}, rc);
+        phase_b(std::integral_constant<int, 1>{}, rc);
+        phase_b(std::integral_constant<int, 2>{}, rc);
+        phase_b(std::integral_constant<int, 3>{}, rc);
+        stamp(FIRST ? 4 : 8);   // DMA issued
+        auto levels = [&](auto psc, auto ldsc) {
+            constexpr int MASK = decltype(ldsc)::value ? (RMASK & ~TA_MASK) : LOADS_MASK;
+            if constexpr (MASK & 1) level(std::integral_constant<int, 0>{}, psc, ldsc);
+            if constexpr (MASK & 2) level(std::integral_constant<int, 1>{}, psc, ldsc);
+            if constexpr (MASK & 4) level(std::integral_constant<int, 2>{}, psc, ldsc);
+            if constexpr (MASK & 8) level(std::integral_constant<int, 3>{}, psc, ldsc);
+        };
+        levels(std::integral_constant<int, 0>{}, std::false_type{});
+        if constexpr (NPASS > 1) levels(std::integral_constant<int, 1>{}, std::false_type{});
+        if constexpr (NPASS > 2) levels(std::integral_constant<int, 2>{}, std::false_type{});
+        stamp(FIRST ? 5 : 9);   // gathers by buffer loads done
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA landed
+        __syncthreads();                      // ... everybody's
+        stamp(FIRST ? 6 : 10);
+        // a pass's outputs are stored as soon as its last level is summed: the stores drain under the
+        // gathers of the next pass instead of all at the end
+        levels(std::integral_constant<int, 0>{}, std::true_type{});
+        if constexpr (LAST) store(std::integral_constant<int, 0>{});
+        if constexpr (NPASS > 1) levels(std::integral_constant<int, 1>{}, std::true_type{});
+        if constexpr (NPASS > 1 && LAST) store(std::integral_constant<int, 1>{});
+        if constexpr (NPASS > 2) levels(std::integral_constant<int, 2>{}, std::true_type{});
+        if constexpr (NPASS > 2 && LAST) store(std::integral_constant<int, 2>{});
+        stamp(FIRST ? 7 : 11);   // gathers from LDS done
+    };
+    constexpr int R1 = (0xF & ~ROUND0) & ~TA_MASK;   // the second round's levels
+    if constexpr (R1 == 0) {
+        round(std::integral_constant<int, ROUND0 & 0xF>{}, std::true_type{}, std::true_type{});
+    } else {
+        bool any = false;   // uniform: does any of the second round's levels exist?
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            if ((R1 >> l) & 1) any = any || (l < L);
+        if (any) {
+            round(std::integral_constant<int, ROUND0 & 0xF>{}, std::true_type{}, std::false_type{});
+            round(std::integral_constant<int, R1>{}, std::false_type{}, std::true_type{});
+        } else {
+            round(std::integral_constant<int, ROUND0 & 0xF>{}, std::true_type{}, std::true_type{});
+        }
+    }
+}

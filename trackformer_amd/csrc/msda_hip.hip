@@ -40,7 +40,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <type_traits>
+
 #include "tf_msda.h"
+#include "msda_quad_geom.h"
 
 namespace {
 
@@ -989,6 +993,11 @@ msda_fwd_f32_win(const DirectArgs da, const LevelTable lt, const WinGeom wg)
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, encoder shape, fp32, D == 32, P == 4, L <= 4: LDS windows, 4 lanes per pair (DPP quads)
+// ---------------------------------------------------------------------------------------------
+#include "msda_fwd_quad.h"
+
+// ---------------------------------------------------------------------------------------------
 // backward, encoder shape, fp32, D == 32, P == 4, L <= 4: grad_value contributions sorted by row in LDS
 // ---------------------------------------------------------------------------------------------
 // msda_bwd_f32_buf is bound by the L2 atomic units, which are occupied ~25 cycles per cache line touched:
@@ -1765,13 +1774,14 @@ bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, in
 //   msda_fwd_f32_win                     48 / 73 / 103
 //   (earlier fixed-halo tiled kernel)    66 / 107 / 215   -- removed
 // DESIGN.md says where the time goes (LDS pipe + per-workgroup latencies at 2 workgroups per CU).
-int g_tiled_mode = -1;   // -1: follow the environment, 0: off, 1: msda_fwd_f32_win
+std::atomic<int> g_tiled_mode{-1};   // -1: follow the environment, 0: off, 1: msda_fwd_f32_win, 2: msda_fwd_f32_quad
 int tiled_mode()
 {
-    if (g_tiled_mode >= 0) return g_tiled_mode;
+    const int g = g_tiled_mode.load(std::memory_order_relaxed);
+    if (g >= 0) return g;
     static const int env_mode = [] {
         const char *e = getenv("TF_MSDA_TILED");
-        return (e && e[0] >= '1' && e[0] <= '9') ? 1 : 0;
+        return (e && e[0] == '2') ? 2 : (e && e[0] >= '1' && e[0] <= '9') ? 1 : 0;
     }();
     return env_mode;
 }
@@ -1799,7 +1809,7 @@ long long tile_max_queries(const LevelTable &lt, int L, int th, int tw)
 // Tile plan of msda_fwd_f32_win: the tile with the most queries that still fits kWinMaxQueries.
 bool plan_win(const LevelTable &lt, int L, int D, int P, WinGeom *wg, size_t *lds)
 {
-    if (tiled_mode() == 0 || D != 32 || P != 4 || L > kWinLevels) return false;
+    if (tiled_mode() != 1 || D != 32 || P != 4 || L > kWinLevels) return false;
     int hy = 6, hx = 10, th = 0, tw = 0, rows = 408;   // 408 rows (80 KB with the header): two workgroups per CU
     if (const char *e = getenv("TF_MSDA_HALO")) sscanf(e, "%d,%d", &hy, &hx);
     if (const char *e = getenv("TF_MSDA_TILE")) sscanf(e, "%d,%d", &th, &tw);
@@ -1931,6 +1941,186 @@ bool launch_win(bool fused, const DirectArgs &da, const LevelTable &lt, int N, i
     return true;
 }
 
+// ---- msda_fwd_f32_quad: options, tile plan, launch ----------------------------------------------------
+// Performance knobs (process-wide; tf_msda_set_option / TF_MSDA_QUAD="ta=12,waves=8,npass=1,lds=53,...").
+enum QuadOpt { kQoTaMask, kQoWaves, kQoNpass, kQoLdsKb, kQoHaloY, kQoHaloX, kQoTileH, kQoTileW, kQoSplit, kQoCount };
+const char *const kQuadOptNames[kQoCount] = {"quad_ta_mask", "quad_waves", "quad_npass", "quad_lds_kb", "quad_halo_y",
+                                             "quad_halo_x",  "quad_tile_h", "quad_tile_w", "quad_split"};
+const char *const kQuadEnvKeys[kQoCount] = {"ta", "waves", "npass", "lds", "hy", "hx", "th", "tw", "split"};
+constexpr int kQuadOptDefaults[kQoCount] = {12, 4, 2, 40, 6, 10, 0, 0, 0};
+std::atomic<int> g_quad_opt[kQoCount];
+std::atomic<int> g_quad_epoch{0};   // bumped by every change: invalidates the per-thread tile plans
+std::atomic<unsigned long long *> g_quad_trace{nullptr};   // tf_msda_debug_trace_buffer
+
+void quad_opts_init()
+{
+    static const bool once = [] {
+        for (int i = 0; i < kQoCount; ++i) g_quad_opt[i].store(kQuadOptDefaults[i]);
+        if (const char *e = getenv("TF_MSDA_QUAD")) {
+            // comma-separated key=value list
+            const char *p = e;
+            while (*p) {
+                const char *eq = strchr(p, '=');
+                if (!eq) break;
+                for (int i = 0; i < kQoCount; ++i)
+                    if ((size_t)(eq - p) == strlen(kQuadEnvKeys[i]) && strncmp(p, kQuadEnvKeys[i], eq - p) == 0)
+                        g_quad_opt[i].store(atoi(eq + 1));
+                const char *c = strchr(eq, ',');
+                if (!c) break;
+                p = c + 1;
+            }
+        }
+        return true;
+    }();
+    (void)once;
+}
+
+struct QuadPlan {
+    QuadGeom geom;
+    size_t lds;
+    int ta_mask, waves, npass, split;
+};
+
+bool plan_quad(const LevelTable &lt, int L, int D, int P, QuadPlan *qp)
+{
+    if (tiled_mode() != 2 || D != 32 || P != 4 || L > kQuadLevels) return false;
+    quad_opts_init();
+    int o[kQoCount];
+    for (int i = 0; i < kQoCount; ++i) o[i] = g_quad_opt[i].load(std::memory_order_relaxed);
+    const int epoch = g_quad_epoch.load(std::memory_order_relaxed);
+    const int ta = o[kQoTaMask], waves = o[kQoWaves], npass = o[kQoNpass];
+    const int split = o[kQoSplit];
+    if ((ta != 0 && ta != 12) || (waves != 4 && waves != 8) || npass < 1 || npass > 3 ||
+        (waves == 8 && npass != 1) || (split != 0 && split != 1))
+        return false;
+    if (o[kQoLdsKb] < 8 || o[kQoLdsKb] > 160 || o[kQoHaloY] < 0 || o[kQoHaloX] < 0 || o[kQoTileH] < 0 || o[kQoTileW] < 0)
+        return false;
+    for (int l = 0; l < L; ++l)
+        if (lt.H[l] >= 32768 || lt.W[l] >= 32768) return false;   // 32-bit tile arithmetic in the kernel
+    const int cap_rows = (int)(((size_t)o[kQoLdsKb] * 1024 - kQuadHdrBytes) / 128 - 2) & ~7;
+    if (cap_rows < 8) return false;
+    const size_t need = (size_t)kQuadHdrBytes + (size_t)(2 + cap_rows) * 128;
+    struct Memo {
+        bool valid = false, ok = false;
+        int L = 0, epoch = -1;
+        LevelTable lt;
+        QuadPlan qp;
+    };
+    static thread_local Memo memo;
+    if (memo.valid && memo.L == L && memo.epoch == epoch && memcmp(&memo.lt, &lt, sizeof(lt)) == 0) {
+        *qp = memo.qp;
+        return memo.ok;
+    }
+    memo.valid = true;
+    memo.ok = false;
+    memo.L = L;
+    memo.epoch = epoch;
+    memo.lt = lt;
+    // tile: the most queries per (estimated) window row among the tiles that fill the workgroup
+    const long long cap_q = (long long)waves * 16 * npass;
+    int bth = 0, btw = 0;
+    if (o[kQoTileH] > 0 && o[kQoTileW] > 0) {
+        const long long nq = tile_max_queries(lt, L, o[kQoTileH], o[kQoTileW]);
+        if (nq >= 1 && nq <= cap_q) {
+            bth = o[kQoTileH];
+            btw = o[kQoTileW];
+        }
+    } else {
+        double best = 0.0;
+        long long best_nq = 0;
+        for (int pass = 0; pass < 2 && !bth; ++pass)
+            for (int th = 1; th <= 32; ++th)
+                for (int tw = 2; tw <= 32; tw += 2) {
+                    if ((long long)th * tw > cap_q) continue;
+                    const long long nq = tile_max_queries(lt, L, th, tw);
+                    if (nq < 1 || nq > cap_q) continue;
+                    if (pass == 0 && nq * 4 < cap_q * 3) continue;        // first pass: well-filled tiles only
+                    const double eff = (double)nq / ((double)(th + 4) * (double)(tw + 8));
+                    if (eff > best || (eff == best && nq > best_nq)) {
+                        best = eff;
+                        best_nq = nq;
+                        bth = th;
+                        btw = tw;
+                    }
+                }
+    }
+    if (!bth) return false;
+    QuadPlan r{};
+    r.geom.TH = bth;
+    r.geom.TW = btw;
+    r.geom.HY = o[kQoHaloY];
+    r.geom.HX = o[kQoHaloX];
+    r.geom.tiles_y = (lt.H[0] + bth - 1) / bth;
+    r.geom.tiles_x = (lt.W[0] + btw - 1) / btw;
+    r.geom.cap_rows = cap_rows;
+    r.lds = need;
+    r.ta_mask = ta;
+    r.waves = waves;
+    r.npass = npass;
+    r.split = split;
+    memo.qp = r;
+    memo.ok = true;
+    *qp = r;
+    static const bool verbose = getenv("TF_MSDA_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "[tf_msda] quad plan: tile %dx%d (%lld queries max of %lld), %dx%d tiles, ta_mask %d, %d waves x %d "
+                        "passes, split %d, %d window rows, %zu B LDS\n", bth, btw, tile_max_queries(lt, L, bth, btw), cap_q,
+                r.geom.tiles_y, r.geom.tiles_x, ta, waves, npass, split, cap_rows, need);
+    return true;
+}
+
+template <bool FUSED, int TA, int ROUND0>
+const void *quad_kernel_wn(int waves, int npass)
+{
+    if (waves == 8) return (const void *)&msda_fwd_f32_quad<FUSED, TA, 8, 1, ROUND0>;
+    return npass == 1   ? (const void *)&msda_fwd_f32_quad<FUSED, TA, 4, 1, ROUND0>
+           : npass == 2 ? (const void *)&msda_fwd_f32_quad<FUSED, TA, 4, 2, ROUND0>
+                        : (const void *)&msda_fwd_f32_quad<FUSED, TA, 4, 3, ROUND0>;
+}
+template <bool FUSED, int ROUND0>
+const void *quad_kernel_ta(int ta, int waves, int npass)
+{
+    return ta == 0 ? quad_kernel_wn<FUSED, 0, ROUND0>(waves, npass) : quad_kernel_wn<FUSED, 12, ROUND0>(waves, npass);
+}
+template <bool FUSED>
+const void *quad_kernel(int ta, int waves, int npass, int split)
+{
+    // split: level 0's window alone in a first round, the other levels' windows reuse its LDS rows
+    return split ? quad_kernel_ta<FUSED, 0x1>(ta, waves, npass) : quad_kernel_ta<FUSED, 0xF>(ta, waves, npass);
+}
+
+// Launch msda_fwd_f32_quad for encoder-shaped calls (Lq == S, host shapes).  Returns false if not taken.
+bool launch_quad(bool fused, const DirectArgs &da, const LevelTable &lt, int N, int D, int P,
+                 hipStream_t stream, hipError_t *err)
+{
+    if (da.Lq != da.S) return false;
+    // the kernel addresses loc / attn / qproj / out with 32-bit byte offsets
+    if (fused && (long long)N * da.Lq * da.fa.ld * 4 >= (1LL << 32)) return false;
+    QuadPlan qp;
+    if (!plan_quad(lt, da.L, D, P, &qp)) return false;
+    const long long grid = (long long)N * qp.geom.tiles_y * qp.geom.tiles_x * da.M;
+    if (grid > 0x7fffffffLL) return false;
+    const void *fn = fused ? quad_kernel<true>(qp.ta_mask, qp.waves, qp.npass, qp.split)
+                           : quad_kernel<false>(qp.ta_mask, qp.waves, qp.npass, qp.split);
+    // the dynamic-LDS limit is a per-function attribute: raise it once per function and device
+    static std::atomic<const void *> raised[64];
+    bool known = false;
+    int free_slot = -1;
+    for (int i = 0; i < 64; ++i) {
+        const void *f = raised[i].load(std::memory_order_acquire);
+        if (f == fn) { known = true; break; }
+        if (f == nullptr) { free_slot = i; break; }
+    }
+    if (!known) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+        if (free_slot >= 0) raised[free_slot].store(fn, std::memory_order_release);
+    }
+    qp.geom.trace = g_quad_trace.load(std::memory_order_relaxed);
+    void *argv[] = {(void *)&da, (void *)&lt, (void *)&qp.geom};
+    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(qp.waves * 64), argv, qp.lds, stream);
+    return true;
+}
+
 // Launch msda_fwd_f32_direct when the shape qualifies (D == 32, P == 4, L <= 8).  Returns false if not.
 bool direct_enabled()
 {
@@ -2000,6 +2190,8 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                 da.L = L;
                 da.Lq = Lq;
                 da.nlq = (long long)N * Lq;
+                if (is_aligned(loc, 8) && shapes_dev == nullptr && launch_quad(false, da, lt, N, D, P, stream, &e))
+                    return record_hip(e);
                 if (is_aligned(loc, 8) && shapes_dev == nullptr && launch_win(false, da, lt, N, D, P, stream, &e))
                     return record_hip(e);
                 if (is_aligned(loc, 8) && launch_direct(false, da, lt, shapes_dev, D, P, stream, &e))
@@ -2060,6 +2252,8 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
         da.Lq = Lq;
         da.nlq = (long long)N * Lq;
         hipError_t de;
+        if (launch_quad(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
+            return record_hip(de);
         if (launch_win(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
             return record_hip(de);
         if (launch_direct(true, da, lt, nullptr, D, P, static_cast<hipStream_t>(stream_v), &de))
@@ -2179,9 +2373,26 @@ int tf_msda_last_hip_error(void) { return g_last_hip_error; }
 
 int tf_msda_set_tiled(int mode)
 {
-    const int prev = g_tiled_mode;
-    g_tiled_mode = mode < 0 ? -1 : (mode ? 1 : 0);
-    return prev;
+    return g_tiled_mode.exchange(mode < 0 ? -1 : (mode == 2 ? 2 : (mode ? 1 : 0)));
+}
+
+void tf_msda_debug_trace_buffer(void *device_buffer)
+{
+    g_quad_trace.store(static_cast<unsigned long long *>(device_buffer));
+}
+
+int tf_msda_set_option(const char *name, int value)
+{
+    if (!name) return INT_MIN;
+    if (strcmp(name, "tiled") == 0) return tf_msda_set_tiled(value);
+    quad_opts_init();
+    for (int i = 0; i < kQoCount; ++i)
+        if (strcmp(name, kQuadOptNames[i]) == 0) {
+            const int prev = g_quad_opt[i].exchange(value);
+            g_quad_epoch.fetch_add(1);
+            return prev;
+        }
+    return INT_MIN;
 }
 
 int tf_msda_forward_fused_f32(const float *value, const int64_t *shapes_hw_host,
