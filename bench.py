@@ -167,13 +167,15 @@ def measure_roofline(device, launches=50):
     achieved = alg / (us * 1e-6) / 1e9
     # HBM traffic of the same kernel/shape from the PMC counters: collected offline (rocprofv3 --pmc
     # needs its own passes) and committed together with the method; see the file's "_how"
+    mode = os.environ.get("TF_MSDA_TILED", "2")[:1] or "2"   # the library's kernel choice for this shape
+    kernel = {"0": "msda_fwd_f32_direct", "1": "msda_fwd_f32_win"}.get(mode, "msda_fwd_f32_quad")
     traffic = None
     try:
-        with open(os.path.join(REPO, "profiles", "r01_msda_traffic.json")) as f:
-            traffic = json.load(f)["hbm_bytes_per_launch"]
+        with open(os.path.join(REPO, "profiles", "r01_msda_fwd_quad_traffic.json")) as f:
+            traffic = json.load(f)[kernel]["hbm_traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "hbm", "kernel": "msda_fwd_f32_direct<2,false> (encoder shape, Lq=S=22223)",
+    return {"bound": "hbm", "kernel": kernel + " (encoder shape, Lq=S=22223)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "algorithmic_bytes": alg, "avg_launch_us": round(us, 2), "launches": launches}

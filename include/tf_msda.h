@@ -64,9 +64,10 @@ int tf_msda_last_hip_error(void);
 
 /*
  * Kernel selection knob (process-wide, performance only -- results are identical up to fp32 summation
- * order): 1 enables the LDS-window forward kernel for encoder-shaped calls (Lq == S, fp32, D == 32,
- * P == 4, L <= 4, host shapes), 2 selects msda_fwd_f32_quad for the same calls, 0 disables both, -1 restores
- * the default (environment variable TF_MSDA_TILED, off when unset).  Returns the previous setting.
+ * order) for encoder-shaped forward calls (Lq == S, fp32, D == 32, P == 4, L <= 4, host shapes):
+ * 2 = msda_fwd_f32_quad (LDS windows, 4 lanes per pair; the default), 1 = msda_fwd_f32_win (LDS windows,
+ * 8 lanes per pair), 0 = msda_fwd_f32_direct (row gathers by buffer loads, what every other shape uses),
+ * -1 restores the default (environment variable TF_MSDA_TILED, 2 when unset).  Returns the previous setting.
  */
 int tf_msda_set_tiled(int mode);
 

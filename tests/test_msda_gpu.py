@@ -372,11 +372,12 @@ def test_module_forward_matches_oracle_composition(dev):
 
 
 # ------------------------------------------------------------------ tiled / LDS-staged encoder kernel
-@pytest.fixture()
-def tiled(dev):
-    """Enable the opt-in LDS-window encoder kernel (msda_fwd_f32_win) for the duration of a test."""
+@pytest.fixture(params=[1, 2], ids=["win", "quad"])
+def tiled(dev, request):
+    """Select an LDS-window encoder kernel (1: msda_fwd_f32_win, 2: msda_fwd_f32_quad -- the default for
+    encoder-shaped calls) for the duration of a test."""
     from trackformer_amd import _cabi
-    prev = _cabi.lib().tf_msda_set_tiled(1)
+    prev = _cabi.lib().tf_msda_set_tiled(request.param)
     yield
     _cabi.lib().tf_msda_set_tiled(prev)
 

@@ -144,7 +144,7 @@ static void apply(const Config &c)
 {
     static const char *names[] = {"quad_ta_mask", "quad_waves",  "quad_npass",  "quad_lds_kb", "quad_halo_y",
                                   "quad_halo_x",  "quad_tile_h", "quad_tile_w", "quad_split"};
-    static const int defaults[] = {12, 4, 2, 40, 6, 10, 0, 0, 0};
+    static const int defaults[] = {0, 4, 3, 40, 6, 10, 0, 0, 1};   // = kQuadOptDefaults of the library
     for (int i = 0; i < 9; ++i) tf_msda_set_option(names[i], defaults[i]);
     for (auto &o : c.opts) tf_msda_set_option(o.first.c_str(), o.second);
     tf_msda_set_option("tiled", c.tiled);

@@ -15,6 +15,8 @@ EXPORTED_SYMBOLS = (
     "tf_msda_strerror",
     "tf_msda_last_hip_error",
     "tf_msda_set_tiled",
+    "tf_msda_set_option",
+    "tf_msda_debug_trace_buffer",
     "tf_msda_forward_fused_f32",
     "tf_msda_forward_f32",
     "tf_msda_forward_f64",
@@ -60,6 +62,10 @@ def lib():
     L.tf_msda_last_hip_error.argtypes = []
     L.tf_msda_set_tiled.restype = ci
     L.tf_msda_set_tiled.argtypes = [ci]
+    L.tf_msda_set_option.restype = ci
+    L.tf_msda_set_option.argtypes = [ctypes.c_char_p, ci]
+    L.tf_msda_debug_trace_buffer.restype = None
+    L.tf_msda_debug_trace_buffer.argtypes = [vp]
     for suf in ("f32", "f64"):
         for tail in ("", "_dshapes"):
             f = getattr(L, "tf_msda_forward_%s%s" % (suf, tail))

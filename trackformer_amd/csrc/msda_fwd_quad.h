@@ -132,10 +132,10 @@ msda_fwd_f32_quad(const DirectArgs da, const LevelTable lt, const QuadGeom qg)
 {
     constexpr int PT = 4, D = 32, NL = kQuadLevels, THREADS = WAVES * 64, PAIRS = THREADS / 4;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
-    // header (ints): [0..3] H, [4..7] W, [8..11] start, [12..27] tile bounds ya | yb | xa | xb per level,
-    // [28..43] nominal footprint ny0 | ny1 | nx0 | nx1 per level; [64 + 16 w ..]: wave w's bounding boxes
-    int *s_hdr = reinterpret_cast<int *>(smem);
-    int *s_wbb = s_hdr + 64;
+    int *s_tab = reinterpret_cast<int *>(smem);       // H | W | start                          (3 x 16 ints)
+    int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;        // ya | yb | xa | xb per level             (4 x 16 ints)
+    int *s_bb = s_q + 4 * TF_MSDA_MAX_LEVELS;         // min x0, max x0, min y0, max y0 per level (16 ints)
+    int *s_nom = s_bb + 16;                           // nominal ny0 | ny1 | nx0 | nx1 per level  (4 x 16 ints)
     unsigned char *s_rows = smem + kQuadHdrBytes;     // rows 0, 1: zeros; the windows start at row 2
 
     const int L = da.L, M = da.M, S = da.S, LP = L * PT;
@@ -150,29 +150,28 @@ msda_fwd_f32_quad(const DirectArgs da, const LevelTable lt, const QuadGeom qg)
         // thread 4l+k: bound k (ya, yb, xa, xb) of the pixels of level l whose centre lies in the tile's
         // normalised rectangle, and bound k of the tile's nominal footprint in level l (window clamp)
         const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
-        int bound = 0, nom = 0;
         if (l < L) {
             const unsigned H0 = (unsigned)lt.H[0], W0 = (unsigned)lt.W[0];
             const unsigned Hl = (unsigned)lt.H[l], Wl = (unsigned)lt.W[l];
             const unsigned y0 = (unsigned)ty * qg.TH, y1 = min(H0, y0 + (unsigned)qg.TH);
             const unsigned x0 = (unsigned)tx * qg.TW, x1 = min(W0, x0 + (unsigned)qg.TW);
-            bound = k == 0   ? tfq_tile_bound(y0, Hl, H0)
-                    : k == 1 ? tfq_tile_bound(y1, Hl, H0)
-                    : k == 2 ? tfq_tile_bound(x0, Wl, W0)
-                             : tfq_tile_bound(x1, Wl, W0);
+            s_q[k * TF_MSDA_MAX_LEVELS + l] = k == 0   ? tfq_tile_bound(y0, Hl, H0)
+                                              : k == 1 ? tfq_tile_bound(y1, Hl, H0)
+                                              : k == 2 ? tfq_tile_bound(x0, Wl, W0)
+                                                       : tfq_tile_bound(x1, Wl, W0);
             int lo, hi;
             if (k < 2)
                 tfq_nominal((int)y0, (int)y1, (int)Hl, 1.f / (float)H0, qg.HY, &lo, &hi);
             else
                 tfq_nominal((int)x0, (int)x1, (int)Wl, 1.f / (float)W0, qg.HX, &lo, &hi);
-            nom = (k & 1) ? hi : lo;
+            s_nom[k * TF_MSDA_MAX_LEVELS + l] = (k & 1) ? hi : lo;
+            if (k == 0) {
+                s_tab[l] = lt.H[l];
+                s_tab[TF_MSDA_MAX_LEVELS + l] = lt.W[l];
+                s_tab[2 * TF_MSDA_MAX_LEVELS + l] = lt.start[l];
+            }
         }
-        s_hdr[12 + 4 * k + l] = bound;
-        s_hdr[28 + 4 * k + l] = nom;
-        if (k < 3) {
-            const int lc = l < L ? l : 0;   // levels past L read as level 0: keeps every derived quantity sane
-            s_hdr[4 * k + l] = k == 0 ? lt.H[lc] : k == 1 ? lt.W[lc] : lt.start[lc];
-        }
+        s_bb[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
     }
     if (threadIdx.x < 64) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;
     // phase timestamps of wave 0 (tools/msda_bench --trace): where a workgroup's time goes
@@ -194,23 +193,21 @@ msda_fwd_f32_quad(const DirectArgs da, const LevelTable lt, const QuadGeom qg)
         (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)s_rows);
     const unsigned ldsA = lds_rows + rbA, ldsB = lds_rows + rbB;
 
-    // the whole header in ONE LDS read per wave, then v_readlane broadcasts into scalar registers
-    const int hv = s_hdr[lane];
-    int Hs[NL], Ws[NL], starts[NL], ya[NL], yb[NL], xa[NL], xb[NL];
+    int Hs[NL], Ws[NL], starts[NL];
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        Hs[l] = __builtin_amdgcn_readlane(hv, l);
-        Ws[l] = __builtin_amdgcn_readlane(hv, 4 + l);
-        starts[l] = __builtin_amdgcn_readlane(hv, 8 + l);
-        ya[l] = __builtin_amdgcn_readlane(hv, 12 + l);
-        yb[l] = __builtin_amdgcn_readlane(hv, 16 + l);
-        xa[l] = __builtin_amdgcn_readlane(hv, 20 + l);
-        xb[l] = __builtin_amdgcn_readlane(hv, 24 + l);
+        const int lc = l < L ? l : 0;
+        Hs[l] = __builtin_amdgcn_readfirstlane(s_tab[lc]);
+        Ws[l] = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS + lc]);
+        starts[l] = __builtin_amdgcn_readfirstlane(s_tab[2 * TF_MSDA_MAX_LEVELS + lc]);
     }
-    int qoff[NL + 1];   // first tile-local index of every level's queries (levels past L hold none)
+    int qoff[NL + 1];   // first tile-local index of every level's queries
     qoff[0] = 0;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) qoff[l + 1] = qoff[l] + (yb[l] - ya[l]) * (xb[l] - xa[l]);
+    for (int l = 0; l < NL; ++l)
+        qoff[l + 1] = qoff[l] + (l < L ? (s_q[TF_MSDA_MAX_LEVELS + l] - s_q[l]) *
+                                             (s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l])
+                                       : 0);
     const int nq = qoff[NL];   // <= NPASS * PAIRS (the host checked the maximum)
 
     // ---- the query of this lane's quad in every pass; the sampling points (l, sub) it owns --------
@@ -220,24 +217,24 @@ msda_fwd_f32_quad(const DirectArgs da, const LevelTable lt, const QuadGeom qg)
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
         const int tq = ps * PAIRS + quad;
+        int q = 0;
         live[ps] = tq < nq;
-        // the level of the query and that level's tile bounds: per-lane selects from scalar registers
-        int base = 0, nx = xb[0] - xa[0], ya_l = ya[0], xa_l = xa[0], W_l = Ws[0], start_l = starts[0];
+        if (live[ps]) {
+            int l = 0, base = 0;
 #pragma unroll
-        for (int k = 1; k < NL; ++k) {
-            const bool ge = tq >= qoff[k] && qoff[k + 1] > qoff[k];
-            base = ge ? qoff[k] : base;
-            nx = ge ? xb[k] - xa[k] : nx;
-            ya_l = ge ? ya[k] : ya_l;
-            xa_l = ge ? xa[k] : xa_l;
-            W_l = ge ? Ws[k] : W_l;
-            start_l = ge ? starts[k] : start_l;
+            for (int k = 1; k < NL; ++k)
+                if (tq >= qoff[k] && k < L) {
+                    l = k;
+                    base = qoff[k];
+                }
+            const int r = tq - base;   // < NPASS * PAIRS <= 512
+            const int nx = s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l];
+            // r / nx: (r + 0.5) / nx is at least 0.5 / nx away from an integer, far more than the float error
+            const int yy = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nx));
+            const int xx = r - yy * nx;
+            q = s_tab[2 * TF_MSDA_MAX_LEVELS + l] + (s_q[l] + yy) * s_tab[TF_MSDA_MAX_LEVELS + l] +
+                s_q[2 * TF_MSDA_MAX_LEVELS + l] + xx;
         }
-        const int r = tq - base;   // < NPASS * PAIRS
-        // r / nx: (r + 0.5) / nx is at least 0.5 / nx away from an integer, far more than the float error
-        const int yy = (int)(((float)r + 0.5f) * __builtin_amdgcn_rcpf((float)nx));
-        const int xx = r - yy * nx;
-        const int q = live[ps] ? start_l + (ya_l + yy) * W_l + xa_l + xx : 0;
         const unsigned bq = (unsigned)b * (unsigned)S + (unsigned)q;
         bq32[ps] = bq;
         pair32[ps] = bq * (unsigned)M + (unsigned)m;
@@ -296,14 +293,11 @@ msda_fwd_f32_quad(const DirectArgs da, const LevelTable lt, const QuadGeom qg)
     }
 
     // ---- phase A: bounding box of the floor coordinates of the in-range points, per LDS level ---------
-    // Reduced over the wave by DPP (rows, then row_bcast), filed per wave in LDS, combined after the barrier:
-    // no LDS atomics.  `mine`: lane 4l+k collects bound k (min x0, max x0, min y0, max y0) of level l.
-    int mine = (lane & 1) ? INT_MIN : INT_MAX;
     auto phase_a = [&](auto lc) {
         constexpr int l = decltype(lc)::value;
         if constexpr (((TA_MASK >> l) & 1) == 0) {
             if (l < L) {
-                int v[4] = {INT_MAX, INT_MIN, INT_MAX, INT_MIN};   // min x0, max x0, min y0, max y0
+                int mnx = INT_MAX, mxx = INT_MIN, mny = INT_MAX, mxy = INT_MIN;
                 const float Wf = (float)Ws[l], Hf = (float)Hs[l];
 #pragma unroll
                 for (int ps = 0; ps < NPASS; ++ps) {
@@ -311,51 +305,46 @@ msda_fwd_f32_quad(const DirectArgs da, const LevelTable lt, const QuadGeom qg)
                     const float yr = __builtin_fmaf(sy[ps][l], Hf, -0.5f);
                     const bool in = live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
                     const int x0 = (int)__builtin_floorf(in ? xr : 0.f), y0 = (int)__builtin_floorf(in ? yr : 0.f);
-                    v[0] = min(v[0], in ? x0 : INT_MAX);
-                    v[1] = max(v[1], in ? x0 : INT_MIN);
-                    v[2] = min(v[2], in ? y0 : INT_MAX);
-                    v[3] = max(v[3], in ? y0 : INT_MIN);
+                    mnx = min(mnx, in ? x0 : INT_MAX);
+                    mxx = max(mxx, in ? x0 : INT_MIN);
+                    mny = min(mny, in ? y0 : INT_MAX);
+                    mxy = max(mxy, in ? y0 : INT_MIN);
                 }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int x = v[k];
-                    const bool mx = (k & 1) != 0;
-                    // 16 lanes of a DPP row, then rows 0+1 / 2+3 (row_bcast15), then both halves (row_bcast31)
-                    x = mx ? max(x, dpp_i<kDppQuadXor1>(x)) : min(x, dpp_i<kDppQuadXor1>(x));
-                    x = mx ? max(x, dpp_i<kDppQuadXor2>(x)) : min(x, dpp_i<kDppQuadXor2>(x));
-                    x = mx ? max(x, dpp_i<kDppRowRor4>(x)) : min(x, dpp_i<kDppRowRor4>(x));
-                    x = mx ? max(x, dpp_i<kDppRowRor8>(x)) : min(x, dpp_i<kDppRowRor8>(x));
-                    const int b15 = __builtin_amdgcn_update_dpp(x, x, 0x142, 0xA, 0xF, false);
-                    x = mx ? max(x, b15) : min(x, b15);
-                    const int b31 = __builtin_amdgcn_update_dpp(x, x, 0x143, 0xC, 0xF, false);
-                    x = mx ? max(x, b31) : min(x, b31);
-                    // the wave's result must be read with every lane still active: the empty asm pins the
-                    // v_readlane here (the compiler otherwise sinks it, and the last min/max, into the
-                    // single-lane select below, where lane 63 no longer executes)
-                    int tot = __builtin_amdgcn_readlane(x, 63);
-                    asm volatile("" : "+s"(tot));
-                    mine = lane == 4 * l + k ? tot : mine;
+                // every lane of the wave holds points of level l: reduce over the 16 lanes of a DPP row, then
+                // one LDS atomic per row and bound (the compiler folds the four rows of a wave into one)
+                mnx = min(mnx, dpp_i<kDppQuadXor1>(mnx));
+                mxx = max(mxx, dpp_i<kDppQuadXor1>(mxx));
+                mny = min(mny, dpp_i<kDppQuadXor1>(mny));
+                mxy = max(mxy, dpp_i<kDppQuadXor1>(mxy));
+                mnx = min(mnx, dpp_i<kDppQuadXor2>(mnx));
+                mxx = max(mxx, dpp_i<kDppQuadXor2>(mxx));
+                mny = min(mny, dpp_i<kDppQuadXor2>(mny));
+                mxy = max(mxy, dpp_i<kDppQuadXor2>(mxy));
+                mnx = min(mnx, dpp_i<kDppRowRor4>(mnx));
+                mxx = max(mxx, dpp_i<kDppRowRor4>(mxx));
+                mny = min(mny, dpp_i<kDppRowRor4>(mny));
+                mxy = max(mxy, dpp_i<kDppRowRor4>(mxy));
+                mnx = min(mnx, dpp_i<kDppRowRor8>(mnx));
+                mxx = max(mxx, dpp_i<kDppRowRor8>(mxx));
+                mny = min(mny, dpp_i<kDppRowRor8>(mny));
+                mxy = max(mxy, dpp_i<kDppRowRor8>(mxy));
+                if ((lane & 15) == 0 && mnx != INT_MAX) {
+                    atomicMin(&s_bb[4 * l + 0], mnx);
+                    atomicMax(&s_bb[4 * l + 1], mxx);
+                    atomicMin(&s_bb[4 * l + 2], mny);
+                    atomicMax(&s_bb[4 * l + 3], mxy);
                 }
             }
         }
     };
     phase_a(std::integral_constant<int, 0>{});
-    stamp(13);   // level 0's points arrived, its bounding box reduced
+    stamp(13);   // level 0's points arrived, its bounding box filed
     phase_a(std::integral_constant<int, 1>{});
     phase_a(std::integral_constant<int, 2>{});
     phase_a(std::integral_constant<int, 3>{});
-    if (lane < 16) s_wbb[wave * 16 + lane] = mine;
     stamp(2);   // the sampling points have arrived, bounding boxes filed
     __syncthreads();
     stamp(3);
-    // combine the waves' boxes (lane 4l+k: bound k of level l) and broadcast them into scalar registers
-    int bbv = (lane & 1) ? INT_MIN : INT_MAX;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-        const int x = s_wbb[w * 16 + (lane & 15)];
-        bbv = (lane & 1) ? max(bbv, x) : min(bbv, x);
-    }
-    const int nomv = s_hdr[28 + (lane & 15)];   // lane 4k+l: nominal bound k of level l
 
     // ---- phase B: window geometry (wave-uniform, kept in scalar registers) and LDS-DMA staging ---------
     const unsigned rowbytes = (unsigned)(M * D) * 4u;
@@ -384,14 +373,14 @@ msda_fwd_f32_quad(const DirectArgs da, const LevelTable lt, const QuadGeom qg)
             if constexpr (((TA_MASK >> l) & 1) == 0 && ((RMASK >> l) & 1) != 0) {
                 if (l < L) {
                     const int H = Hs[l], W = Ws[l];
-                    const int bx0 = __builtin_amdgcn_readlane(bbv, 4 * l + 0);
-                    const int bx1 = __builtin_amdgcn_readlane(bbv, 4 * l + 1);
-                    const int by0 = __builtin_amdgcn_readlane(bbv, 4 * l + 2);
-                    const int by1 = __builtin_amdgcn_readlane(bbv, 4 * l + 3);
-                    const int ny0 = __builtin_amdgcn_readlane(nomv, l);
-                    const int ny1 = __builtin_amdgcn_readlane(nomv, 4 + l);
-                    const int nx0 = __builtin_amdgcn_readlane(nomv, 8 + l);
-                    const int nx1 = __builtin_amdgcn_readlane(nomv, 12 + l);
+                    const int bx0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 0]);
+                    const int bx1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 1]);
+                    const int by0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 2]);
+                    const int by1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 3]);
+                    const int ny0 = __builtin_amdgcn_readfirstlane(s_nom[l]);
+                    const int ny1 = __builtin_amdgcn_readfirstlane(s_nom[TF_MSDA_MAX_LEVELS + l]);
+                    const int nx0 = __builtin_amdgcn_readfirstlane(s_nom[2 * TF_MSDA_MAX_LEVELS + l]);
+                    const int nx1 = __builtin_amdgcn_readfirstlane(s_nom[3 * TF_MSDA_MAX_LEVELS + l]);
                     bool fits;
                     const QuadWindow w = tfq_window(bx0, bx1, by0, by1, nx0, nx1, ny0, ny1, qg.cap_rows - used, 2 + used, &fits);
                     by_loads[l] = !fits;

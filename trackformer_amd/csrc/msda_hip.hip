@@ -1768,20 +1768,25 @@ bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, in
     return true;
 }
 
-// The LDS-window encoder kernel is opt-in (tf_msda_set_tiled(1) or TF_MSDA_TILED=1).  Measured at the
-// cfg-2 encoder shape (HIP graph of 50 launches, us per launch; init / local / uniform sampling):
-//   msda_fwd_f32_direct (default)        53 / 61 / 66
-//   msda_fwd_f32_win                     48 / 73 / 103
-//   (earlier fixed-halo tiled kernel)    66 / 107 / 215   -- removed
-// DESIGN.md says where the time goes (LDS pipe + per-workgroup latencies at 2 workgroups per CU).
+// Encoder-shaped calls (Lq == S, host shapes, D == 32, P == 4, L <= 4) run msda_fwd_f32_quad by default;
+// TF_MSDA_TILED=0 / tf_msda_set_tiled(0) selects msda_fwd_f32_direct, 1 the older msda_fwd_f32_win.  Measured
+// at the cfg-2 encoder shape (HIP graph of 20 launches, us per launch, plain / fused entry;
+// profiles/r01_msda_fwd_quad_harness.txt):
+//                                  init          local         uniform
+//   msda_fwd_f32_direct            51.8 / 54.4   62.1 / 65.9   66.6 / 73.6
+//   msda_fwd_f32_win               47.3 / 54.4   71.4 / 77.3   82.2 / 88.4
+//   msda_fwd_f32_quad (default)    36.0 / 44.4   60.0 / 70.4   76.4 / 89.5
+// init = what a default-initialised model produces (bench.py), local = reference point + N(0, 2 px),
+// uniform = rand over the level (no locality at all: every level falls back to buffer loads).
 std::atomic<int> g_tiled_mode{-1};   // -1: follow the environment, 0: off, 1: msda_fwd_f32_win, 2: msda_fwd_f32_quad
 int tiled_mode()
 {
     const int g = g_tiled_mode.load(std::memory_order_relaxed);
     if (g >= 0) return g;
     static const int env_mode = [] {
-        const char *e = getenv("TF_MSDA_TILED");
-        return (e && e[0] == '2') ? 2 : (e && e[0] >= '1' && e[0] <= '9') ? 1 : 0;
+        const char *e = getenv("TF_MSDA_TILED");   // unset: msda_fwd_f32_quad; 0: off; 1: msda_fwd_f32_win
+        if (!e || !e[0]) return 2;
+        return e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
     }();
     return env_mode;
 }
@@ -1947,7 +1952,7 @@ enum QuadOpt { kQoTaMask, kQoWaves, kQoNpass, kQoLdsKb, kQoHaloY, kQoHaloX, kQoT
 const char *const kQuadOptNames[kQoCount] = {"quad_ta_mask", "quad_waves", "quad_npass", "quad_lds_kb", "quad_halo_y",
                                              "quad_halo_x",  "quad_tile_h", "quad_tile_w", "quad_split"};
 const char *const kQuadEnvKeys[kQoCount] = {"ta", "waves", "npass", "lds", "hy", "hx", "th", "tw", "split"};
-constexpr int kQuadOptDefaults[kQoCount] = {12, 4, 2, 40, 6, 10, 0, 0, 0};
+constexpr int kQuadOptDefaults[kQoCount] = {0, 4, 3, 40, 6, 10, 0, 0, 1};
 std::atomic<int> g_quad_opt[kQoCount];
 std::atomic<int> g_quad_epoch{0};   // bumped by every change: invalidates the per-thread tile plans
 std::atomic<unsigned long long *> g_quad_trace{nullptr};   // tf_msda_debug_trace_buffer
