@@ -1,13 +1,15 @@
 // trackformer_amd/csrc/msda_fwd_quad.h -- included by msda_hip.hip inside its anonymous namespace.
 //
 // msda_fwd_f32_quad: MSDeformAttn forward for encoder-shaped calls (Lq == S), fp32, D == 32, P == 4, L <= 4.
+// THE DEFAULT for those calls (TF_MSDA_TILED unset): 36 us at the cfg-2 encoder shape against 52 us for
+// msda_fwd_f32_direct, HBM traffic 1.15x the algorithmic bytes (profiles/r01_msda_fwd_quad_*).
 //
 // Why another kernel.  msda_fwd_f32_direct moves 64 taps x 128 B per (query, head) pair through the
-// vector-memory path (64 B/clk/CU: 37-45 us at the cfg-2 encoder shape), msda_fwd_f32_win moves them
+// vector-memory path (64 B/clk/CU: the texture addresser is 85 % busy), msda_fwd_f32_win moves them
 // through LDS (256 B/clk/CU) but pays for it in instructions: 8 lanes per pair need the tap offsets and
 // weights of all 16 points of the pair, exchanged through LDS (1/3 of its LDS wave-instructions, 27 KB of
 // LDS), and every window tap carries its own validity test (1313 VALU instructions per wave, PMC).
-// This kernel removes both:
+// This kernel removes both and fixes the occupancy:
 //   * 4 lanes per pair (a DPP quad), 8 channels per lane.  Lane j of the quad owns point j of every level
 //     and computes its tap arithmetic ONCE; the other three lanes read the result with DPP quad_perm
 //     broadcasts that the compiler folds into the consuming v_add_u32 (addresses) or issues as one
@@ -15,15 +17,17 @@
 //   * Windows live in EXTENDED pixel coordinates (-1 .. size): pixels outside the level are staged as
 //     zeros by the LDS-DMA itself (out-of-range source offset), so a staged point is one box test and two
 //     row addresses (y0 and y0 + 1; the x0 + 1 taps are the +128 B immediates), not four guarded ones.
-//   * TA_MASK routes whole levels through buffer loads instead of LDS windows: the texture path and
-//     the LDS pipe are separate resources, the coarse levels' few rows stay in the vector L1, and their
-//     windows (halo-dominated) no longer occupy LDS, which buys workgroups per CU.
+//   * ROUND0 splits the staging: level 0's window first, then the windows of levels 1..3 in the SAME LDS rows.
+//     All taps go through LDS in 40 KB per workgroup (4 workgroups per CU) instead of 65 KB (2 per CU).
+//   * A window that does not fit is not staged at all and its level is gathered by buffer loads (before the
+//     barrier, while the other windows land); so is any level in TA_MASK (compile time: the texture path and
+//     the LDS pipe are separate resources; measured, the all-LDS split is faster).  Points whose taps leave
+//     their (clamped) window take buffer loads under a wave-uniform branch: any input is handled exactly.
 //   * A lane reads its 8 channels as two 16-byte pieces from opposite 64-byte halves of the row, the
 //     half order alternating with bit 1 of the quad index: the four quads an LDS cycle serves then hit
 //     four disjoint bank groups when neighbouring queries read neighbouring rows (the encoder's pattern).
-// Points whose taps leave their window (clamped box, LDS capacity) take buffer loads under a wave-uniform
-// branch, so any input is handled exactly.  The tile / window geometry is in msda_quad_geom.h, shared
-// with the host emulation (tests/emu/quad_emu.cpp) that checks this logic against the oracle on the CPU.
+// The tile / window geometry is in msda_quad_geom.h, shared with the host emulation (tests/emu/quad_emu.cpp,
+// tests/test_quad_emulation.py) that checks this logic against the oracle on the CPU.
 //
 // Arithmetic: SURVEY.md Appendix A; reference ms_deform_im2col_cuda.cuh:227-237 (pixel mapping, in-range
 // rule), :24-67 (bilinear taps with zero padding).

@@ -22,8 +22,10 @@
 //                               M == 8: that head's value rows stay in the XCD's 4 MiB L2).
 //   msda_fwd_f32_direct         fp32, D == 32, P == 4 (every TrackFormer config with hidden 256): no
 //                               staging prologue, tap arithmetic computed once per pair and shared
-//                               inside the wave.  THE DEFAULT for the hot path.
-//   msda_fwd_f32_win            encoder shape only, opt-in: data-adaptive LDS windows.
+//                               inside the wave.  THE DEFAULT for decoder-shaped calls.
+//   msda_fwd_f32_quad           encoder shape (Lq == S): data-adaptive LDS windows, 4 lanes per pair
+//                               (msda_fwd_quad.h).  THE DEFAULT for encoder-shaped calls.
+//   msda_fwd_f32_win            encoder shape only, opt-in: the first LDS-window kernel (8 lanes per pair).
 //   msda_bwd_rowgather<T,...>   any dtype; fuses the reference's two backward kernels.
 //   msda_bwd_f32_buf<P,ROWATOM> fp32 fast path: buffer loads + buffer atomics (full-row scatter for D == 32).
 //   msda_bwd_f32_sorted         encoder shape, D == 32, P == 4: contributions counting-sorted by destination
