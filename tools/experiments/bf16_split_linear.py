@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Feasibility experiment (CPU, no GPU needed): can the dense linears of the path run as bf16 split products on the
+matrix cores (fp32 = hi + mid + lo bf16 pieces, fp32 accumulation) without leaving the parity bar?
+
+    python tools/experiments/bf16_split_linear.py [x3|x6|x1]
+
+Every torch.nn.functional.linear / torch._addmm_activation of the model is replaced by an emulation of the split
+product -- the pieces are rounded to bf16 exactly as the hardware would see them, the partial products (exact in
+fp32, as on MFMA with fp32 accumulation) are summed in fp32 -- and the CPU parity tests that compare the model and
+the tracker with the reference goldens (boxes / logits <= 1e-3, track ids exact) are run on top of it.
+  x1: plain bf16 (1 MFMA pass)             -- what "just use bf16" would mean
+  x3: hi*hi + hi*mid + mid*hi              -- ~16 mantissa bits
+  x6: + mid*mid + hi*lo + lo*hi            -- ~fp32
+Result of the round-1 run: see DESIGN.md section 6 ("next").
+"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, REPO)
+MODE = sys.argv[1] if len(sys.argv) > 1 else "x3"
+_orig_linear = F.linear
+_orig_addmm_act = torch._addmm_activation
+
+
+def _pieces(t):
+    hi = t.to(torch.bfloat16).float()
+    mid = (t - hi).to(torch.bfloat16).float()
+    lo = (t - hi - mid).to(torch.bfloat16).float()
+    return hi, mid, lo
+
+
+def _split_mm(x, w_t):
+    """x [.., K] @ w_t [K, N] with bf16 pieces and fp32 accumulation."""
+    xh, xm, xl = _pieces(x)
+    wh, wm, wl = _pieces(w_t)
+    out = xh @ wh
+    if MODE in ("x3", "x6"):
+        out = out + xh @ wm + xm @ wh
+    if MODE == "x6":
+        out = out + xm @ wm + xh @ wl + xl @ wh
+    return out
+
+
+def linear(x, w, b=None):
+    if x.dtype != torch.float32 or x.is_cuda:
+        return _orig_linear(x, w, b)
+    y = _split_mm(x, w.t())
+    return y if b is None else y + b
+
+
+def addmm_activation(bias, x, w_t, *, beta=1, alpha=1, use_gelu=False):
+    y = _split_mm(x, w_t) + bias
+    return F.gelu(y) if use_gelu else torch.relu(y)
+
+
+if __name__ == "__main__":
+    F.linear = linear
+    torch.nn.functional.linear = linear
+    torch._addmm_activation = addmm_activation
+    sel = "model_forward_matches_reference or tracker_sequence_matches_reference or tracker_variants_match_reference"
+    sys.exit(pytest.main([os.path.join(REPO, "tests", "test_models_cpu.py"), "-q", "-x", "--no-header", "-k", sel]))
