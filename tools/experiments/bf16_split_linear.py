@@ -2,7 +2,7 @@
 """Feasibility experiment (CPU, no GPU needed): can the dense linears of the path run as bf16 split products on the
 matrix cores (fp32 = hi + mid + lo bf16 pieces, fp32 accumulation) without leaving the parity bar?
 
-    python tools/experiments/bf16_split_linear.py [x3|x6|x1]
+    python tools/experiments/bf16_split_linear.py [x3|x6|x1] [conv]
 
 Every torch.nn.functional.linear / torch._addmm_activation of the model is replaced by an emulation of the split
 product -- the pieces are rounded to bf16 exactly as the hardware would see them, the partial products (exact in
@@ -11,6 +11,7 @@ the tracker with the reference goldens (boxes / logits <= 1e-3, track ids exact)
   x1: plain bf16 (1 MFMA pass)             -- what "just use bf16" would mean
   x3: hi*hi + hi*mid + mid*hi              -- ~16 mantissa bits
   x6: + mid*mid + hi*lo + lo*hi            -- ~fp32
+With `conv` the convolutions (backbone, input projections, mask head) are split the same way.
 Result of the round-1 run: see DESIGN.md section 6 ("next").
 """
 import os
@@ -23,6 +24,8 @@ import torch.nn.functional as F
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 MODE = sys.argv[1] if len(sys.argv) > 1 else "x3"
+CONV = len(sys.argv) > 2 and sys.argv[2] == "conv"
+_orig_conv2d = F.conv2d
 _orig_linear = F.linear
 _orig_addmm_act = torch._addmm_activation
 
@@ -58,7 +61,24 @@ def addmm_activation(bias, x, w_t, *, beta=1, alpha=1, use_gelu=False):
     return F.gelu(y) if use_gelu else torch.relu(y)
 
 
+def conv2d(x, w, b=None, *args, **kw):
+    if x.dtype != torch.float32 or x.is_cuda:
+        return _orig_conv2d(x, w, b, *args, **kw)
+    xh, xm, xl = _pieces(x)
+    wh, wm, wl = _pieces(w)
+    c = lambda a, k: _orig_conv2d(a, k, None, *args, **kw)
+    out = c(xh, wh)
+    if MODE in ("x3", "x6"):
+        out = out + c(xh, wm) + c(xm, wh)
+    if MODE == "x6":
+        out = out + c(xm, wm) + c(xh, wl) + c(xl, wh)
+    return out if b is None else out + b.view(1, -1, 1, 1)
+
+
 if __name__ == "__main__":
+    if CONV:
+        F.conv2d = conv2d
+        torch.conv2d = conv2d
     F.linear = linear
     torch.nn.functional.linear = linear
     torch._addmm_activation = addmm_activation
