@@ -11,6 +11,9 @@
  *                          (reference: models/deformable_transformer.py:291-292, :285-286, :371-372, :378-379,
  *                          :360-361): residual add + LayerNorm in one pass
  *
+ *   tf_linear_split_f32    nn.Linear (+ ReLU) of the encoder / decoder (ms_deform_attn.py:64-88,
+ *                          deformable_transformer.py:282-297) as a bf16 split product on the matrix cores
+ *
  * Conventions as in tf_msda.h: device pointers, caller-owned buffers, work enqueued on `stream`
  * (hipStream_t as void*), no synchronisation, returns 0 or a negative tf_msda_status.
  */
@@ -38,6 +41,16 @@ int tf_bias_act_f32(float *x, const float *bias, const float *residual, int64_t 
  */
 int tf_add_layernorm_f32(const float *x, const float *res, const float *gamma, const float *beta,
                          float *out, int64_t rows, int C, float eps, void *stream);
+
+/*
+ * y[M, N] = x[M, K] . w[N, K]^T + bias[N] (bias may be NULL), ReLU if relu != 0; fp32 in and out, row-major.
+ * The weight arrives as TWO bf16 tensors [N, K]: w_hi = bf16(w), w_mid = bf16(w - float(w_hi)) (round to nearest
+ * even), split once by the caller; x is split the same way inside the kernel and the product is formed as
+ * x_hi.w_hi + x_hi.w_mid + x_mid.w_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error of a
+ * product below 2^-16; see trackformer_amd/csrc/linear_split.hip).  K % 32 == 0, 16-byte aligned x / w_hi / w_mid.
+ */
+int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
+                        int64_t M, int K, int N, int relu, void *stream);
 
 #ifdef __cplusplus
 }

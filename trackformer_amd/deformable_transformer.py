@@ -32,6 +32,10 @@ def _ffn_hidden(linear, activation, x, inference):
     """activation(linear(x)).  Inference on the GPU with ReLU: bias + ReLU run in the GEMM epilogue
     (hipBLASLt) instead of a separate pass over the [tokens, d_ffn] activation."""
     if inference and activation is F.relu and x.is_cuda and x.dtype == torch.float32:
+        if fused.split_linear_enabled():   # opt-in: bf16 split product on the matrix cores, ReLU in its epilogue
+            y = fused.linear(x, linear.weight, linear.bias, relu=True)
+            if y is not None:
+                return y
         x2 = x.reshape(-1, x.shape[-1])
         y = torch._addmm_activation(linear.bias, x2, linear.weight.t(), use_gelu=False)
         return y.view(*x.shape[:-1], y.shape[-1])
@@ -296,7 +300,7 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         inf = _inference(self)
-        src2 = self.linear2(self.dropout2(_ffn_hidden(self.linear1, self.activation, src, inf)))
+        src2 = fused.module_linear(self.linear2, self.dropout2(_ffn_hidden(self.linear1, self.activation, src, inf)), inf)
         return fused.residual_norm(src, self.dropout3(src2), self.norm2, inf)
 
     def forward(self, src, pos, reference_points, spatial_shapes, padding_mask=None):
@@ -362,7 +366,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         inf = _inference(self)
-        tgt2 = self.linear2(self.dropout3(_ffn_hidden(self.linear1, self.activation, tgt, inf)))
+        tgt2 = fused.module_linear(self.linear2, self.dropout3(_ffn_hidden(self.linear1, self.activation, tgt, inf)), inf)
         return fused.residual_norm(tgt, self.dropout4(tgt2), self.norm3, inf)
 
     def _self_attention_inference(self, qk_in, v_in, key_padding_mask):

@@ -2,6 +2,8 @@
 
 Used by the inference path only (eval mode, gradients disabled) on GPU tensors; everywhere else the
 callers keep the plain PyTorch formulation (these helpers return None when they do not apply)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -60,3 +62,71 @@ def residual_norm(x, res, norm, inference):
         if y is not None:
             return y
     return norm(x + res)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# nn.Linear as a bf16 split product on the matrix cores (include/tf_fused.h: tf_linear_split_f32).  OPT-IN:
+# TF_SPLIT_LINEAR=1 or set_split_linear(True); measured faster than the tuned fp32 library GEMMs at the encoder
+# shapes and inside the parity bar on the reference goldens, default off until the end-to-end numbers are in.
+_split_linear = os.environ.get("TF_SPLIT_LINEAR", "0") not in ("", "0")
+_split_cache = {}
+
+
+def split_linear_enabled():
+    return _split_linear
+
+
+def set_split_linear(on):
+    """Switch the split-product linears on or off (process-wide); returns the previous setting."""
+    global _split_linear
+    prev, _split_linear = _split_linear, bool(on)
+    return prev
+
+
+def _split_weight(weight):
+    """(w_hi, w_mid) bf16 pieces of an fp32 weight, cached per tensor version (weights are constants in inference)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
+    hit = _split_cache.get(key)
+    if hit is None:
+        if len(_split_cache) > 512:
+            _split_cache.clear()
+        w = weight.detach()
+        hi = w.to(torch.bfloat16)
+        mid = (w - hi.float()).to(torch.bfloat16)
+        hit = (hi.contiguous(), mid.contiguous())
+        _split_cache[key] = hit
+    return hit
+
+
+def linear(x, weight, bias=None, relu=False):
+    """act(x @ weight^T + bias) through tf_linear_split_f32 for fp32 GPU tensors with K % 32 == 0; returns None when
+    it does not apply (switched off, other dtype / device / shape): the caller keeps its PyTorch formulation."""
+    if not (_split_linear and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and weight.dim() == 2 and weight.is_contiguous() and weight.device == x.device):
+        return None
+    N, K = weight.shape
+    if x.shape[-1] != K or K % 32 or x.numel() == 0:
+        return None
+    if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N):
+        return None
+    x2 = x.reshape(-1, K)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    hi, mid = _split_weight(weight)
+    if (x2.data_ptr() | hi.data_ptr() | mid.data_ptr()) & 15:
+        return None
+    y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
+    rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(),
+                                         0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0], K, N,
+                                         1 if relu else 0, _stream())
+    _cabi.check(rc, "tf_linear_split_f32")
+    return y.view(*x.shape[:-1], N)
+
+
+def module_linear(module, x, inference):
+    """module(x) for an nn.Linear: the split product on the GPU inference path when enabled, else the module."""
+    if inference and _split_linear:
+        y = linear(x, module.weight, module.bias)
+        if y is not None:
+            return y
+    return module(x)

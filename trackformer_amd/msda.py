@@ -22,7 +22,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 from torch.nn.init import constant_, xavier_uniform_
 
-from . import _cabi
+from . import _cabi, fused
 
 import os as _os
 
@@ -295,7 +295,8 @@ class MSDeformAttn(nn.Module):
             assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
 
         M, L, P = self.n_heads, self.n_levels, self.n_points
-        value = self.value_proj(input_flatten)
+        inference = not self.training and not torch.is_grad_enabled()
+        value = fused.module_linear(self.value_proj, input_flatten, inference)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         value = value.view(N, Len_in, M, self.d_model // M)
@@ -306,10 +307,12 @@ class MSDeformAttn(nn.Module):
                 and (self.d_model // M) % 4 == 0 and P in (1, 2, 4, 8)):
             # inference: one GEMM for both query projections, prologue arithmetic inside the kernel
             w, b = self._cat_proj.get(self)
-            qproj = F.linear(query, w, b)
+            qproj = fused.linear(query, w, b) if fused.split_linear_enabled() else None
+            if qproj is None:
+                qproj = F.linear(query, w, b)
             output = ms_deform_attn_forward_fused(value, input_spatial_shapes, reference_points,
                                                   qproj, M, L, P)
-            return self.output_proj(output)
+            return fused.module_linear(self.output_proj, output, True)
 
         sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
         attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
