@@ -58,6 +58,10 @@ def parse_args():
     ap.add_argument("--host-frames", action="store_true",
                     help="keep the frames in pinned host memory (PCIe copy inside the timed region); "
                          "the reported headline value always uses HBM-resident frames")
+    ap.add_argument("--split-linear", action="store_true",
+                    help="encoder / decoder linears as bf16 split products on the matrix cores (tf_linear_split_f32; "
+                         "same as TF_SPLIT_LINEAR=1).  Verified against the goldens, off by default until measured "
+                         "end to end")
     ap.add_argument("--sequences", type=int, default=4,
                     help="independent video sequences tracked concurrently per GPU (one host thread "
                          "and HIP stream each); frames of one sequence stay strictly sequential")
@@ -236,8 +240,10 @@ def main():
                                 miopen_find=os.environ.get("TF_MIOPEN_FIND", "1") == "1",
                                 verbose=(rank == 0))
 
-    from trackformer_amd import _cabi
+    from trackformer_amd import _cabi, fused
     _cabi.lib()   # fail loudly if the HIP library is missing
+    if args.split_linear:
+        fused.set_split_linear(True)
 
     import threading
     n_seq = max(1, args.sequences)
@@ -320,7 +326,9 @@ def main():
                                    + ("in pinned host memory (PCIe copy timed)" if args.host_frames
                                       else "resident in HBM"),
                        "global_batch": world, "parallelism": "sequence-sharded x%d" % world,
-                       "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph},
+                       "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph,
+                       "linears": "bf16 split product (hi.hi + hi.mid + mid.hi, f32 accumulate)"
+                                  if fused.split_linear_enabled() else "f32 (hipBLASLt)"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

@@ -58,23 +58,27 @@ def build_all(force=False, verbose=False):
 
 
 def _build_tools(force, verbose):
-    """tools/bin/msda_bench: standalone parity + timing harness of the forward kernels (no Python on the
-    GPU box).  Links against the in-tree libtf_msda.so through a relative rpath."""
-    src = os.path.join(REPO_DIR, "tools", "msda_bench.cpp")
-    if not os.path.exists(src):
-        return []
+    """tools/bin/msda_bench, tools/bin/linear_bench: standalone parity + timing harnesses of the forward kernels and of
+    the split-product linear (no Python on the GPU box).  They link against the in-tree libtf_msda.so through a
+    relative rpath."""
     out_dir = os.path.join(REPO_DIR, "tools", "bin")
-    os.makedirs(out_dir, exist_ok=True)
-    out = os.path.join(out_dir, "msda_bench")
     lib = os.path.join(LIB_DIR, "libtf_msda.so")
-    if not force and not _stale(out, [src, lib]):
-        return []
-    cmd = [_hipcc(), "--offload-arch=" + GFX_ARCH, "-O2", "-std=c++17", "-I" + INCLUDE, src,
-           "-L" + LIB_DIR, "-ltf_msda", "-Wl,-rpath,$ORIGIN/../../trackformer_amd/lib", "-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return [out]
+    built = []
+    for name in ("msda_bench", "linear_bench"):
+        src = os.path.join(REPO_DIR, "tools", name + ".cpp")
+        if not os.path.exists(src):
+            continue
+        os.makedirs(out_dir, exist_ok=True)
+        out = os.path.join(out_dir, name)
+        if not force and not _stale(out, [src, lib]):
+            continue
+        cmd = [_hipcc(), "--offload-arch=" + GFX_ARCH, "-O2", "-std=c++17", "-I" + INCLUDE, src,
+               "-L" + LIB_DIR, "-ltf_msda", "-Wl,-rpath,$ORIGIN/../../trackformer_amd/lib", "-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        built.append(out)
+    return built
 
 
 if __name__ == "__main__":
