@@ -1,0 +1,67 @@
+"""CPU: the numerical claim behind tf_linear_split_f32 -- every linear of the path computed as the bf16 split product
+hi.hi + hi.mid + mid.hi (fp32 accumulation), emulated with PyTorch on the CPU, keeps the model and the tracker inside
+the tolerances of the CPU parity suite (boxes 2e-5, logits 1e-4, track ids exact), while plain bf16 does not.  (The HIP kernel itself is checked on the GPU:
+tests/test_linear_split_gpu.py; the full sweep over all goldens: tools/experiments/bf16_split_linear.py.)"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import test_models_cpu as shared
+from tests.test_models_cpu import oracle_op  # noqa: F401  (fixture: the C oracle as the MSDeformAttn operator)
+
+
+def _pieces(t):
+    hi = t.to(torch.bfloat16).float()
+    mid = (t - hi).to(torch.bfloat16).float()
+    return hi, mid
+
+
+def _patch(monkeypatch, passes):
+    def mm(x, w_t):
+        xh, xm = _pieces(x)
+        wh, wm = _pieces(w_t)
+        out = xh @ wh
+        if passes == 3:
+            out = out + xh @ wm + xm @ wh
+        return out
+
+    def linear(x, w, b=None):
+        y = mm(x, w.t())
+        return y if b is None else y + b
+
+    def addmm_activation(bias, x, w_t, *, beta=1, alpha=1, use_gelu=False):
+        y = mm(x, w_t) + bias
+        return F.gelu(y) if use_gelu else torch.relu(y)
+
+    monkeypatch.setattr(F, "linear", linear)
+    monkeypatch.setattr(torch, "_addmm_activation", addmm_activation)
+
+
+def test_weight_pieces_reconstruct_the_weight_to_16_bits():
+    from trackformer_amd import fused
+    w = torch.randn(64, 96) * 3
+    hi, mid = fused._split_weight(w)
+    assert hi.dtype == mid.dtype == torch.bfloat16
+    rel = ((hi.float() + mid.float() - w).abs() / w.abs().clamp_min(1e-30)).max()
+    assert float(rel) < 2.0 ** -15
+    assert fused._split_weight(w)[0] is hi      # cached per tensor version
+    w.add_(1.0)
+    assert fused._split_weight(w)[0] is not hi  # an in-place update invalidates the cache entry
+
+
+def test_split_product_linears_keep_model_and_tracker_parity(oracle_op, monkeypatch):
+    _patch(monkeypatch, passes=3)
+    case = "cfg2_deformable_tracking"
+    model, out, res, feats = shared.run_case(case, device="cpu")
+    # the CPU suite's own (tight) tolerances, 50x below the 1e-3 bar
+    shared.compare_to_golden(case, model, out, res, feats, box_tol=2e-5, logit_tol=1e-4)
+    tracker, rows, active, inactive = shared.run_tracker(False, device="cpu")
+    shared.compare_tracker_to_golden(False, tracker, rows, active, inactive, box_tol_px=0.05)
+
+
+def test_plain_bf16_linears_do_not(oracle_op, monkeypatch):
+    _patch(monkeypatch, passes=1)
+    case = "cfg2_deformable_tracking"
+    model, out, res, feats = shared.run_case(case, device="cpu")
+    with pytest.raises(AssertionError):   # one bf16 pass: boxes off by ~2e-4, ten times the tolerance above
+        shared.compare_to_golden(case, model, out, res, feats, box_tol=2e-5, logit_tol=1e-4)
