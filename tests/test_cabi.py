@@ -59,3 +59,19 @@ def test_null_and_bad_dims_are_rejected_before_any_gpu_work(lib):
                                     None) == -3
     with pytest.raises(_cabi.MSDAError):
         _cabi.check(-3, "unit test")
+
+
+def test_option_knobs_round_trip_without_a_gpu(lib):
+    """tf_msda_set_option / tf_msda_set_tiled only touch host state: names, previous values, unknown names."""
+    int_min = -2 ** 31
+    assert lib.tf_msda_set_option(b"no_such_option", 1) == int_min
+    assert lib.tf_msda_set_option(None, 1) == int_min
+    prev = lib.tf_msda_set_option(b"quad_lds_kb", 48)
+    assert prev == 40                                     # the shipped default (4 workgroups per CU)
+    assert lib.tf_msda_set_option(b"quad_lds_kb", prev) == 48
+    for name, default in ((b"quad_ta_mask", 0), (b"quad_waves", 4), (b"quad_npass", 3), (b"quad_split", 1)):
+        assert lib.tf_msda_set_option(name, default) == default
+    before = lib.tf_msda_set_tiled(0)
+    assert before == -1                                   # -1: follow TF_MSDA_TILED (unset: the quad kernel)
+    assert lib.tf_msda_set_option(b"tiled", 2) == 0
+    assert lib.tf_msda_set_tiled(-1) == 2
