@@ -1,0 +1,106 @@
+#!/usr/bin/env python
+"""BASELINE-size golden fixtures from the REFERENCE's own classes on CPU (build container only).
+
+    python tests/golden/make_golden_full.py [cfg2_full] [cfg4_full] [tracker]
+
+cfg2_full  reference `build_model('deformable','tracking','mot17')` (deformable_detr.py:124-275) on one
+           800x1333 frame with 300 object + 100 injected track queries
+cfg4_full  the `multi_frame` model (hidden 288, 500 object + 300 track queries, 8 decoder levels,
+           cfgs/train_multi_frame.yaml:1-5): previous frame, then current frame with prev_features
+tracker    reference `Tracker` (tracker.py:266-550) for 3 frames of 800x1333 with the cfg-2 model
+
+Weights and inputs are regenerated from seeds (tests/util_models, tests/util_weights) on the GPU box;
+the fixtures hold outputs only.  Large tensors are subsampled (encoder memory: every 89th token, last
+backbone level: every 32nd channel).  The script prints the smallest margin between a score and a
+tracker threshold, so that a fixture whose decisions sit on a knife edge is not committed.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+from oracle import reference_models  # noqa: E402
+from tests import util_models as um  # noqa: E402
+from trackformer_amd import config  # noqa: E402
+
+
+def checksum(model):
+    return float(sum(float(v.double().abs().sum()) for v in model.state_dict().values()))
+
+
+def model_case(ref, case):
+    model, post, args = um.build(case, ref.models.build_model, config.make_args)
+    model.tracking()
+    img, prev, target = um.model_inputs(case, args.hidden_dim)
+    t0 = time.time()
+    with torch.no_grad():
+        prev_features = None
+        if args.multi_frame_attention:
+            _, _, prev_features, _, _ = model(prev, None, None)
+        out, _, feats, memory, hs = model(img, target, prev_features)
+        res = post['bbox'](out, torch.tensor([list(um.FULL_ORIG)]))[0]
+    # memory: per-level [N, C, H, W] slices of the encoder output (deformable_detr.py:261-271);
+    # back to [N, S, C], keep every 89th token
+    mem = torch.cat([m.flatten(2) for m in memory], 2).transpose(1, 2)
+    fix = dict(pred_logits=out['pred_logits'].numpy(), pred_boxes=out['pred_boxes'].numpy(),
+               hs_embed=out['hs_embed'].numpy(),
+               aux_boxes=np.stack([a['pred_boxes'].numpy() for a in out['aux_outputs']]),
+               aux_logits=np.stack([a['pred_logits'].numpy() for a in out['aux_outputs']]),
+               scores=res['scores'].numpy(), labels=res['labels'].numpy(), boxes=res['boxes'].numpy(),
+               weight_checksum=np.float64(checksum(model)),
+               memory_rows=mem[0, ::um.FULL_MEMORY_ROW_STRIDE].numpy(),
+               memory_shape=np.array(mem.shape),
+               feat_last=feats[-1].tensors[0, ::um.FULL_FEAT_CH_STRIDE].numpy())
+    path = os.path.join(HERE, "full_%s.npz" % case)
+    np.savez_compressed(path, **fix)
+    print("%-10s %.0f s  logits%s boxes%s memory%s score range [%.3f, %.3f] -> %s (%d KB)" % (
+        case, time.time() - t0, fix['pred_logits'].shape, fix['pred_boxes'].shape, tuple(mem.shape),
+        fix['scores'].min(), fix['scores'].max(), os.path.basename(path),
+        os.path.getsize(path) // 1024), flush=True)
+
+
+def tracker_case(ref):
+    model, post, args = um.build("cfg2_full", ref.models.build_model, config.make_args)
+    model.tracking()
+    cfg = config.tracker_cfg()
+    tracker = ref.tracker.Tracker(model, post, cfg, False)
+    tracker.reset()
+    active = []
+    t0 = time.time()
+    with torch.no_grad():
+        for blob in um.full_tracker_sequence():
+            tracker.step(blob)
+            active.append(len(tracker.tracks))
+            print("  frame %d: %d active tracks (%.0f s)" % (len(active), active[-1], time.time() - t0),
+                  flush=True)
+    results = tracker.get_results()
+    rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']),
+                      results[tid][f]['obj_ind']]
+                     for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
+    margin = float(np.abs(rows[:, 6] - cfg['track_obj_score_thresh']).min())
+    path = os.path.join(HERE, "full_tracker_cfg2.npz")
+    np.savez_compressed(path, rows=rows, active_per_frame=np.array(active),
+                        num_tracks=np.int64(tracker.track_num), num_reids=np.int64(tracker.num_reids))
+    print("tracker: %d ids, active %s, smallest |score - threshold| of a kept track %.2e -> %s" % (
+        tracker.track_num, active, margin, os.path.basename(path)), flush=True)
+
+
+def main():
+    ref = reference_models.load()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["cfg2_full", "cfg4_full", "tracker"]
+    for case in which:
+        if case == "tracker":
+            tracker_case(ref)
+        else:
+            model_case(ref, case)
+
+
+if __name__ == "__main__":
+    main()

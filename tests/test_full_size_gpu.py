@@ -1,0 +1,149 @@
+"""GPU (-m gpu): the BASELINE-size configurations end to end against the reference CPU path.
+
+cfg 2 (800x1333, 300 object + 100 track queries) and cfg 4 (hidden 288, 500 + 300 queries, 8 decoder
+levels) through deformable_detr.py:124-275, and a 3-frame 800x1333 sequence through
+tracker.py:266-550, compared with goldens produced from the reference's own classes on CPU
+(tests/golden/make_golden_full.py).  The model runs in the set-ups `bench.py` times: eager with the
+library defaults, the tuned runtime (`runtime.configure_inference`: MIOpen find mode + shipped
+TunableOp selections) behind `GraphedDetector` (HIP-graph replay, fused MSDeformAttn entry -> the
+LDS-window encoder kernel at S = 22 223), and the same with the bf16 split-product linears.
+
+Tolerances are north_star's: boxes / logits within 1e-3 (fp32), track ids bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util_models as um
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    from trackformer_amd import _cabi
+    _cabi.lib()
+    return torch.device("cuda:0")
+
+
+def _checksum(model):
+    return float(sum(float(v.double().abs().sum()) for v in model.state_dict().values()))
+
+
+@pytest.fixture(scope="module")
+def models(dev):
+    """One model per full-size case, shared by the set-ups below (building + perturbing takes seconds)."""
+    from trackformer_amd import config, factory
+    cache = {}
+
+    def get(case):
+        if case not in cache:
+            model, post, args = um.build(case, factory.build_model, config.make_args, device=dev)
+            model.to(dev).tracking()
+            cache[case] = (model, post, args)
+        return cache[case]
+    return get
+
+
+def _forward(case, models, dev, setup):
+    from trackformer_amd import fused, runtime
+    from trackformer_amd.graphed import GraphedDetector
+    model, post, args = models(case)
+    img, prev, target = um.model_inputs(case, args.hidden_dim)
+    img, prev, target = img.to(dev), prev.to(dev), um.to_device(target, dev)
+    detector = model
+    prev_split = fused.set_split_linear(setup == "graph_split_linear")
+    try:
+        if setup != "eager":
+            runtime.configure_inference(verbose=False)
+            detector = GraphedDetector(model)
+        with torch.no_grad():
+            reps = 1 if setup == "eager" else 3     # call 1 eager, call 2 captures + replays, call 3 replays
+            for _ in range(reps):
+                prev_features = None
+                if args.multi_frame_attention:
+                    _, _, prev_features, _, _ = detector(prev, None, None)
+                out, _, feats, memory, hs = detector(img, [dict(t) for t in target], prev_features)
+            res = post['bbox'](out, torch.tensor([list(um.FULL_ORIG)], device=dev))[0]
+        if setup != "eager" and not args.multi_frame_attention:
+            assert len(detector._graphs) == 1, "the HIP-graph path was not taken"
+    finally:
+        fused.set_split_linear(prev_split)
+    return model, out, res, feats, memory
+
+
+def _compare(case, model, out, res, feats, memory, box_tol=1e-3, logit_tol=1e-3):
+    z = np.load(os.path.join(GOLDEN, "full_%s.npz" % case))
+    assert abs(_checksum(model) - float(z["weight_checksum"])) < 1e-6 * float(z["weight_checksum"])
+    np.testing.assert_allclose(out['pred_boxes'].cpu().numpy(), z['pred_boxes'], atol=box_tol)
+    np.testing.assert_allclose(out['pred_logits'].cpu().numpy(), z['pred_logits'], atol=logit_tol)
+    np.testing.assert_allclose(out['hs_embed'].cpu().numpy(), z['hs_embed'], atol=5 * logit_tol)
+    aux_b = np.stack([a['pred_boxes'].cpu().numpy() for a in out['aux_outputs']])
+    aux_l = np.stack([a['pred_logits'].cpu().numpy() for a in out['aux_outputs']])
+    np.testing.assert_allclose(aux_b, z['aux_boxes'], atol=box_tol)
+    np.testing.assert_allclose(aux_l, z['aux_logits'], atol=logit_tol)
+    np.testing.assert_array_equal(res['labels'].cpu().numpy(), z['labels'])
+    np.testing.assert_allclose(res['scores'].cpu().numpy(), z['scores'], atol=logit_tol)
+    np.testing.assert_allclose(res['boxes'].cpu().numpy(), z['boxes'], atol=box_tol * max(um.FULL_ORIG))
+    # encoder output (6 layers of the LDS-window kernel at S = 22 223): every 89th token
+    mem = torch.cat([m.flatten(2) for m in memory], 2).transpose(1, 2)
+    assert list(mem.shape) == z['memory_shape'].tolist()
+    rows = mem[0, ::um.FULL_MEMORY_ROW_STRIDE].cpu().numpy()
+    np.testing.assert_allclose(rows, z['memory_rows'], atol=logit_tol * max(1.0, np.abs(z['memory_rows']).max()))
+    f = feats[-1].tensors[0, ::um.FULL_FEAT_CH_STRIDE].cpu().numpy()
+    np.testing.assert_allclose(f, z['feat_last'], atol=1e-3 * max(1.0, np.abs(z['feat_last']).max()))
+    return float(np.abs(out['pred_boxes'].cpu().numpy() - z['pred_boxes']).max()), \
+        float(np.abs(out['pred_logits'].cpu().numpy() - z['pred_logits']).max())
+
+
+@pytest.mark.parametrize("setup", ["eager", "graph_tuned", "graph_split_linear"])
+@pytest.mark.parametrize("case", list(um.FULL_CASES))
+def test_full_size_model_matches_reference_cpu_path(dev, models, case, setup):
+    model, out, res, feats, memory = _forward(case, models, dev, setup)
+    dbox, dlogit = _compare(case, model, out, res, feats, memory)
+    print("%s / %s: max |d boxes| %.2e, max |d logits| %.2e" % (case, setup, dbox, dlogit))
+
+
+def _run_tracker(models, dev, setup):
+    from trackformer_amd import config, fused, runtime
+    from trackformer_amd.graphed import GraphedDetector
+    from trackformer_amd.tracker import Tracker
+    model, post, args = models("cfg2_full")
+    detector = model
+    prev_split = fused.set_split_linear(setup == "graph_split_linear")
+    try:
+        if setup != "eager":
+            runtime.configure_inference(verbose=False)
+            detector = GraphedDetector(model)
+        tracker = Tracker(detector, post, config.tracker_cfg(), False)
+        tracker.reset()
+        active = []
+        with torch.no_grad():
+            for blob in um.full_tracker_sequence():
+                tracker.step(dict(blob, img=blob['img'].to(dev)))
+                active.append(len(tracker.tracks))
+    finally:
+        fused.set_split_linear(prev_split)
+    results = tracker.get_results()
+    rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']),
+                      results[tid][f]['obj_ind']]
+                     for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
+    return tracker, rows, active
+
+
+@pytest.mark.parametrize("setup", ["eager", "graph_tuned", "graph_split_linear"])
+def test_full_size_tracker_track_ids_bit_exact(dev, models, setup):
+    tracker, rows, active = _run_tracker(models, dev, setup)
+    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
+    assert int(z["num_tracks"]) == tracker.track_num
+    assert int(z["num_reids"]) == tracker.num_reids
+    assert z["active_per_frame"].tolist() == active
+    assert rows.shape == z["rows"].shape
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])   # id, frame, source query
+    np.testing.assert_allclose(rows[:, 2:6], z["rows"][:, 2:6], atol=1e-3 * max(um.FULL_ORIG))
+    np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)

@@ -30,13 +30,27 @@ MASK_CASES = ("cfg5_segm_tracking", "cfg1_plain_detr_masks")
 MASK_SIZES = {"cfg5_segm_tracking": ((128, 160), (200, 250)),      # (padded input size, original size)
               "cfg1_plain_detr_masks": ((96, 128), (150, 200))}
 
+# BASELINE-size cases (800x1333; cfg 2: 300 object + 100 track queries, cfg 4: hidden 288, 500 + 300,
+# 8 decoder levels).  Goldens: tests/golden/full_*.npz from tests/golden/make_golden_full.py; the
+# tests run on the GPU only (the reference CPU path needs ~1 min per frame on 8 cores).
+FULL_CASES = {
+    "cfg2_full": (("deformable", "tracking", "mot17"), {}, (800, 1333), 100),
+    "cfg4_full": (("deformable", "tracking", "multi_frame", "mot17"), {}, (800, 1333), 300),
+}
+FULL_TRACKER_FRAMES = 3
+FULL_IMG = (800, 1333)
+FULL_ORIG = (1080, 1800)      # aspect of 800x1333 (datasets/transforms.py:115-146 resize)
+# rows / channels of the large tensors kept in the fixtures (full tensors would be tens of MB)
+FULL_MEMORY_ROW_STRIDE = 89
+FULL_FEAT_CH_STRIDE = 32
+
 TRACKER_FRAMES = 6
 TRACKER_IMG = (192, 256)
 TRACKER_ORIG = (480, 640)
 
 
 def build(case, build_model_fn, make_args_fn, device="cpu", seed=42, weight_seed=1):
-    overlays, overrides, _, _ = MODEL_CASES[case]
+    overlays, overrides, _, _ = (MODEL_CASES.get(case) or FULL_CASES[case])
     args = make_args_fn(*overlays, device=str(device), **overrides)
     torch.manual_seed(seed)
     model, criterion, post = build_model_fn(args)
@@ -45,7 +59,7 @@ def build(case, build_model_fn, make_args_fn, device="cpu", seed=42, weight_seed
 
 
 def model_inputs(case, hidden_dim, seed=5):
-    _, _, (h, w), n_track = MODEL_CASES[case]
+    _, _, (h, w), n_track = (MODEL_CASES.get(case) or FULL_CASES[case])
     g = torch.Generator().manual_seed(seed)
     img = torch.randn(1, 3, h, w, generator=g)
     prev = img + 0.05 * torch.randn(1, 3, h, w, generator=g)
@@ -57,17 +71,21 @@ def model_inputs(case, hidden_dim, seed=5):
     return img, prev, target
 
 
-def tracker_sequence(seed=11):
+def tracker_sequence(seed=11, img=None, orig=None, n_frames=None):
     """Synthetic sequence in the blob format of datasets/tracking/mot17_sequence.py:65-83."""
     g = torch.Generator().manual_seed(seed)
-    h, w = TRACKER_IMG
+    h, w = img or TRACKER_IMG
     base = torch.randn(1, 3, h, w, generator=g)
     frames = []
-    for _ in range(TRACKER_FRAMES):
+    for _ in range(n_frames or TRACKER_FRAMES):
         base = base + 0.15 * torch.randn(1, 3, h, w, generator=g)
-        frames.append({'img': base.clone(), 'orig_size': torch.tensor([list(TRACKER_ORIG)]),
+        frames.append({'img': base.clone(), 'orig_size': torch.tensor([list(orig or TRACKER_ORIG)]),
                        'size': torch.tensor([[h, w]]), 'dets': torch.zeros(1, 0, 4)})
     return frames
+
+
+def full_tracker_sequence(seed=31):
+    return tracker_sequence(seed, FULL_IMG, FULL_ORIG, FULL_TRACKER_FRAMES)
 
 
 # extra Tracker configurations pinned against the reference (tracker.py:124-165 public detections,

@@ -1,14 +1,20 @@
-"""Builds the native pieces in-tree (no JIT cache, so the .so files travel with the repo snapshot).
+"""Builds the native pieces in-tree (no JIT cache).
 
     python -m trackformer_amd.build          # compile everything for gfx950
     python -m trackformer_amd.build --force
 
-hipcc cross-compiles gfx950 code objects without a GPU present.
+hipcc cross-compiles gfx950 code objects without a GPU present.  The built .so / tools are git-ignored
+(the history stays source-only) but travel to the GPU box with the `gpurun` snapshot; a fresh clone
+has to run this once (`_cabi.lib()` has no fallback and does not build behind the caller's back).
+A target is rebuilt when the hash of its sources, headers, compiler flags and architecture differs
+from the stamp written next to it -- not by mtime, so a flag or arch change rebuilds too.
 """
+import hashlib
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
@@ -30,11 +36,33 @@ def _hipcc():
     return exe
 
 
-def _stale(out, deps):
-    if not os.path.exists(out):
+def _key(deps, flags):
+    h = hashlib.sha256()
+    h.update(("\0".join(flags) + "\0" + GFX_ARCH).encode())
+    for d in sorted(deps):
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(out, key):
+    stamp = out + ".stamp"
+    if not os.path.exists(out) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(out)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != key
+
+
+def _stamp(out, key):
+    with open(out + ".stamp", "w") as f:
+        f.write(key + "\n")
+
+
+def _run(cmd, verbose):
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
 
 
 def build_all(force=False, verbose=False):
@@ -45,13 +73,20 @@ def build_all(force=False, verbose=False):
     for out_name, srcs, extra in _TARGETS:
         out = os.path.join(LIB_DIR, out_name)
         src_paths = [os.path.join(CSRC, s) for s in srcs]
-        if not force and not _stale(out, src_paths + headers):
+        flags = ["--offload-arch=" + GFX_ARCH, "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE,
+                 "-Wno-pass-failed"] + extra
+        key = _key(src_paths + headers, flags)
+        if not force and not _stale(out, key):
             continue
-        cmd = [_hipcc(), "--offload-arch=" + GFX_ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
-               "-I" + INCLUDE, "-Wno-pass-failed"] + extra + src_paths + ["-o", out]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        # one hipcc per translation unit, in parallel, then one link
+        obj_dir = os.path.join(LIB_DIR, "obj")
+        os.makedirs(obj_dir, exist_ok=True)
+        objs = [os.path.join(obj_dir, os.path.splitext(s)[0] + ".o") for s in srcs]
+        with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
+            list(pool.map(lambda so: _run([_hipcc()] + flags + ["-c", so[0], "-o", so[1]], verbose),
+                          zip(src_paths, objs)))
+        _run([_hipcc(), "--offload-arch=" + GFX_ARCH, "-shared", "-fPIC"] + objs + ["-o", out], verbose)
+        _stamp(out, key)
         built.append(out)
     built += _build_tools(force, verbose)
     return built
@@ -70,13 +105,14 @@ def _build_tools(force, verbose):
             continue
         os.makedirs(out_dir, exist_ok=True)
         out = os.path.join(out_dir, name)
-        if not force and not _stale(out, [src, lib]):
+        flags = ["--offload-arch=" + GFX_ARCH, "-O2", "-std=c++17", "-I" + INCLUDE]
+        headers = [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+        key = _key([src] + headers, flags)
+        if not force and not _stale(out, key) and os.path.getmtime(out) >= os.path.getmtime(lib):
             continue
-        cmd = [_hipcc(), "--offload-arch=" + GFX_ARCH, "-O2", "-std=c++17", "-I" + INCLUDE, src,
-               "-L" + LIB_DIR, "-ltf_msda", "-Wl,-rpath,$ORIGIN/../../trackformer_amd/lib", "-o", out]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        _run([_hipcc()] + flags + [src, "-L" + LIB_DIR, "-ltf_msda",
+                                   "-Wl,-rpath,$ORIGIN/../../trackformer_amd/lib", "-o", out], verbose)
+        _stamp(out, key)
         built.append(out)
     return built
 
