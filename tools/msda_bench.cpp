@@ -11,7 +11,8 @@
 // reference; every other configuration is compared with it element-wise (max |diff|, number of
 // (query, head) pairs off by more than 1e-4, where they are) and timed: `iters` launches captured in one
 // HIP graph, HIP events around the replay.  Patterns as in tools/bench_msda.py: init = what a
-// default-initialised MSDeformAttn produces, local = reference point + N(0, 2 px), uniform = rand.
+// default-initialised MSDeformAttn produces, local = reference point + N(0, 2 px), uniform = rand; pert = the bias
+// grid + N(0, 0.8) raw offsets (what the perturbed-weight model of the parity tests produces).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -86,6 +87,10 @@ static Inputs make_inputs(const std::string &mode, int N, unsigned seed)
                                 if (mode == "init") {
                                     ox = (float)dirs[m][0] * (p + 1);
                                     oy = (float)dirs[m][1] * (p + 1);
+                                } else if (mode == "pert") {   // what tests/util_weights.perturb_state_dict makes of the
+                                    // model: the bias grid + a data-dependent part, N(0, 0.05 * sqrt(256)) = N(0, 0.8)
+                                    ox = (float)dirs[m][0] * (p + 1) + 0.8f * nrm(rng);
+                                    oy = (float)dirs[m][1] * (p + 1) + 0.8f * nrm(rng);
                                 } else if (mode == "local") {   // N(0, 2 px) in pixels of the sampled level
                                     ox = nrm(rng) * 2.f * kH[l] / kW[l];   // undo the (H, W) divisor quirk
                                     oy = nrm(rng) * 2.f * kW[l] / kH[l];
@@ -152,7 +157,7 @@ static void apply(const Config &c)
 
 int main(int argc, char **argv)
 {
-    int iters = 20, N = 1, fused = 1, trace = 0;
+    int iters = 20, N = 1, fused = 1, trace = 0, sets = 1;
     std::string patterns = "init,local,uniform";
     std::vector<Config> cfgs;
     for (int i = 1; i < argc; ++i) {
@@ -160,6 +165,8 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--n") && i + 1 < argc) N = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fused") && i + 1 < argc) fused = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--trace")) trace = 1;
+        else if (!strcmp(argv[i], "--sets") && i + 1 < argc) sets = std::max(1, atoi(argv[++i]));   // rotate over K copies of
+        // the tensors (K x 80..114 MB): with K >= 4 the working set exceeds the 256 MiB Infinity Cache, every launch reads HBM
         else if (!strcmp(argv[i], "--patterns") && i + 1 < argc) patterns = argv[++i];
         else cfgs.push_back(parse_config(argv[i]));
     }
@@ -187,16 +194,20 @@ int main(int argc, char **argv)
         const size_t n_out = (size_t)N * Lq * M * D;
         const double alg_bytes = 4.0 * ((double)N * S * M * D + 3.0 * N * Lq * M * LP + (double)n_out);
         float *d_value, *d_loc, *d_attn, *d_qproj, *d_ref, *d_out;
-        CK(hipMalloc(&d_value, in.value.size() * 4));
-        CK(hipMalloc(&d_loc, in.loc.size() * 4));
-        CK(hipMalloc(&d_attn, in.attn.size() * 4));
-        CK(hipMalloc(&d_qproj, in.qproj.size() * 4));
+        // `sets` copies of every tensor, back to back; set 0 is the one checked, the timed graph rotates over all
+        const size_t n_value = in.value.size(), n_loc = in.loc.size(), n_attn = in.attn.size(), n_qproj = in.qproj.size();
+        CK(hipMalloc(&d_value, n_value * 4 * sets));
+        CK(hipMalloc(&d_loc, n_loc * 4 * sets));
+        CK(hipMalloc(&d_attn, n_attn * 4 * sets));
+        CK(hipMalloc(&d_qproj, n_qproj * 4 * sets));
         CK(hipMalloc(&d_ref, in.ref.size() * 4));
-        CK(hipMalloc(&d_out, n_out * 4));
-        CK(hipMemcpy(d_value, in.value.data(), in.value.size() * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(d_loc, in.loc.data(), in.loc.size() * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(d_attn, in.attn.data(), in.attn.size() * 4, hipMemcpyHostToDevice));
-        CK(hipMemcpy(d_qproj, in.qproj.data(), in.qproj.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&d_out, n_out * 4 * sets));
+        for (int k = 0; k < sets; ++k) {
+            CK(hipMemcpy(d_value + k * n_value, in.value.data(), n_value * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_loc + k * n_loc, in.loc.data(), n_loc * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_attn + k * n_attn, in.attn.data(), n_attn * 4, hipMemcpyHostToDevice));
+            CK(hipMemcpy(d_qproj + k * n_qproj, in.qproj.data(), n_qproj * 4, hipMemcpyHostToDevice));
+        }
         CK(hipMemcpy(d_ref, in.ref.data(), in.ref.size() * 4, hipMemcpyHostToDevice));
 
         for (int fz = 0; fz <= (fused ? 1 : 0); ++fz) {
@@ -204,10 +215,12 @@ int main(int argc, char **argv)
             for (size_t ci = 0; ci < cfgs.size(); ++ci) {
                 const Config &c = cfgs[ci];
                 apply(c);
-                auto run = [&]() {
-                    return fz ? tf_msda_forward_fused_f32(d_value, shapes, d_ref, 2, d_qproj, 3 * M * LP, 0, 2 * M * LP,
-                                                          d_out, N, S, M, D, L, Lq, P, stream)
-                              : tf_msda_forward_f32(d_value, shapes, d_loc, d_attn, d_out, N, S, M, D, L, Lq, P, stream);
+                auto run = [&](int k = 0) {
+                    return fz ? tf_msda_forward_fused_f32(d_value + k * n_value, shapes, d_ref, 2, d_qproj + k * n_qproj,
+                                                          3 * M * LP, 0, 2 * M * LP, d_out + k * n_out, N, S, M, D, L, Lq, P,
+                                                          stream)
+                              : tf_msda_forward_f32(d_value + k * n_value, shapes, d_loc + k * n_loc, d_attn + k * n_attn,
+                                                    d_out + k * n_out, N, S, M, D, L, Lq, P, stream);
                 };
                 CK(hipMemsetAsync(d_out, 0xFF, n_out * 4, stream));   // NaN pattern: unwritten outputs show up
                 int rc = run();
@@ -306,7 +319,7 @@ int main(int argc, char **argv)
                 hipGraph_t graph;
                 hipGraphExec_t gexec;
                 CK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                for (int it = 0; it < iters; ++it) run();
+                for (int it = 0; it < iters; ++it) run(it % sets);
                 CK(hipStreamEndCapture(stream, &graph));
                 CK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
                 CK(hipGraphLaunch(gexec, stream));
