@@ -1,9 +1,21 @@
 #!/usr/bin/env python
 """bench.py -- TrackFormer-Deformable per-frame inference throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg1|cfg2|cfg3|cfg4|cfg5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    (`python bench.py --gpus N` with N > 1 outside a launcher re-executes itself under
+    torch.distributed.run on 127.0.0.1: one rank per GPU.)
+
+--config selects a BASELINE.json configuration (cfg2 -- the one the metric is quoted on -- is the
+default and the headline; the others print their own metric in the same JSON layout):
+  cfg1  plain DETR R50, one 480x640 frame, 100 object queries: forward + post-processing
+  cfg2  Deformable TrackFormer inference, 800x1333, 300 object + 100 track queries: Tracker.step
+  cfg3  Deformable TrackFormer training step, bs 2 per GPU, 800x1333 (fwd prev frame + match + fwd +
+        loss + bwd incl. the MSDeformAttn backward + gradient all-reduce over RCCL + AdamW)
+  cfg4  MOT20 crowded-scene model (multi_frame: hidden 288, 8 decoder levels), 500 + 300 queries
+  cfg5  MOTS20 mask head on the tracking detector (the buildable configuration: hidden 256, see
+        DESIGN.md section 2), Tracker.step incl. per-track masks
 
 Workload (BASELINE.json configs[1], SURVEY.md section 8d "cfg 2"): DeformableDETRTracking
 (ResNet-50, 4 feature levels, hidden 256, 6+6 layers), synthetic 800x1333 frames already resident in
@@ -17,14 +29,24 @@ Multi-GPU: the path shards by video sequence (engine.py:289-303 of the reference
 its own sequence on its own GPU, there is no collective in the data path ("scaling": "weak").  RCCL is
 used only for the barriers around the timed region and the max-over-ranks of the elapsed time.
 
+Timing: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides,
+max over ranks.  Because K steps of this workload are only ~0.1 s, that K-step set is repeated until at
+least --min-seconds (2 s) of timed work have accumulated; `value` is total steps / total time over all
+repetitions, `steps` stays K, `timed_repeats` / `steps_timed` say what was actually timed.
+
 The JSON line also carries
   roofline      -- the dominant custom kernel, MSDeformAttn forward at the encoder call shape
-                   (N=1, S=Lq=22223, M=8, D=32, L=4, P=4): algorithmic bytes (79.65 MB) /
-                   average launch duration measured here with HIP events on the launch stream
-                   (K launches replayed from one HIP graph so the host cannot be the bottleneck).
-  cpu_baseline  -- the same frame on the host CPU: identical nn.Modules on CPU with the C oracle
-                   (oracle/msda_ref.c, a port of the reference kernels' arithmetic) as the operator,
-                   rank 0, N=1 only, a bounded sample.
+                   (N=1, S=Lq=22223, M=8, D=32, L=4, P=4) THROUGH THE FUSED ENTRY the model calls:
+                   algorithmic bytes (79.65 MB) / average launch duration measured here with
+                   HIP events on the launch stream (launches replayed from one HIP graph, rotating over
+                   4 input sets so that the Infinity Cache is cold), on the perturbed-weight sampling
+                   pattern; the default-initialised and the wide pattern are reported beside it.
+  cpu_baseline  -- the same workload on the host CPU: identical nn.Modules on CPU with the reference's
+                   pure-CPU MSDeformAttn path (grid_sample, oracle/msda_grid_sample.py: "kind":
+                   "reference-restated"); the C port of the kernels' arithmetic (oracle/msda_ref.c)
+                   timed beside it; rank 0, N=1 only, a bounded sample.
+  single_sequence_fps -- cfg2/4/5: the same steps with ONE sequence per GPU (no overlap of one
+                   sequence's host-side association with another's forward).
 """
 import argparse
 import json
@@ -42,80 +64,131 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 IMG_H, IMG_W = 800, 1333
-NUM_TRACK_QUERIES = 100
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+# BASELINE.json configs: (config overlays, overrides, (H, W), track queries, what a step is)
+CONFIGS = {
+    "cfg1": dict(overlays=(), overrides=dict(dataset="coco"), size=(480, 640), tracks=0, kind="detect",
+                 name="BASELINE cfg 1: plain DETR R50, one 480x640 frame, 100 object queries, forward + PostProcess",
+                 metric="frames/sec, plain DETR (ResNet-50, 640x480, 100 queries) forward + post-processing",
+                 unit="frames/s"),
+    "cfg2": dict(overlays=("deformable", "tracking", "mot17"), overrides={}, size=(IMG_H, IMG_W), tracks=100,
+                 kind="track",
+                 name="BASELINE cfg 2: Tracker.step on 800x1333 synthetic frames, DeformableDETRTracking R50 4 "
+                      "levels, 300 obj + 100 track queries",
+                 metric="frames/sec, TrackFormer-Deformable inference (ResNet-50, 1333x800, 300 object + 100 "
+                        "track queries, bs 1 per GPU); roofline = ms_deform_attn HBM GB/s", unit="frames/s"),
+    "cfg3": dict(overlays=("deformable", "tracking", "mot17"), overrides={}, size=(IMG_H, IMG_W), tracks=0,
+                 kind="train",
+                 name="BASELINE cfg 3: training step (fwd prev frame + match + fwd + loss + bwd + all-reduce + "
+                      "AdamW), bs 2 per GPU, 800x1333, 30 boxes per image",
+                 metric="images/sec, Deformable TrackFormer training step, bs 2 per GPU, 1333x800", unit="images/s"),
+    "cfg4": dict(overlays=("deformable", "tracking", "multi_frame", "mot17"), overrides={}, size=(IMG_H, IMG_W),
+                 tracks=300, kind="track",
+                 name="BASELINE cfg 4: Tracker.step, multi-frame model (hidden 288, 8 decoder levels), 500 obj + "
+                      "300 track queries, 800x1333",
+                 metric="frames/sec, TrackFormer multi-frame (MOT20 config) inference, 1333x800, 500 + 300 queries",
+                 unit="frames/s"),
+    "cfg5": dict(overlays=("deformable", "tracking", "mots20"), overrides={}, size=(IMG_H, IMG_W), tracks=100,
+                 kind="track",
+                 name="BASELINE cfg 5: Tracker.step with the mask head (MOTS20: deformable + tracking + masks, "
+                      "hidden 256 -- the buildable configuration), 300 obj + 100 track queries, 800x1333",
+                 metric="frames/sec, TrackFormer MOTS20 (mask head) inference, 1333x800, 300 + 100 queries",
+                 unit="frames/s"),
+}
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=None, help="default: 120 (cfg 1/2/4/5), 6 (cfg 3)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 8 (cfg 1/2/4/5), 2 (cfg 3)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="repeat the K-step set until this much timed work has accumulated")
     ap.add_argument("--no-graph", action="store_true", help="run the detector eagerly (no HIP graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--no-single-sequence", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--host-frames", action="store_true",
                     help="keep the frames in pinned host memory (PCIe copy inside the timed region); "
                          "the reported headline value always uses HBM-resident frames")
-    ap.add_argument("--split-linear", action="store_true",
-                    help="encoder / decoder linears as bf16 split products on the matrix cores (tf_linear_split_f32; "
-                         "same as TF_SPLIT_LINEAR=1).  Verified against the goldens, off by default until measured "
-                         "end to end")
+    ap.add_argument("--split-linear", dest="split_linear", action="store_true", default=None,
+                    help="encoder / decoder linears as bf16 split products on the matrix cores "
+                         "(tf_linear_split_f32; same as TF_SPLIT_LINEAR=1)")
+    ap.add_argument("--no-split-linear", dest="split_linear", action="store_false")
     ap.add_argument("--sequences", type=int, default=4,
                     help="independent video sequences tracked concurrently per GPU (one host thread "
                          "and HIP stream each); frames of one sequence stay strictly sequential")
-    return ap.parse_args()
+    args = ap.parse_args()
+    train = CONFIGS[args.config]["kind"] == "train"
+    if args.steps is None:
+        args.steps = 6 if train else 120
+    if args.warmup is None:
+        args.warmup = 2 if train else 8
+    return args
 
 
-def init_distributed(n_gpus):
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: re-execute under torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1 (engine.py:289-303 shards sequences over ranks)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def init_distributed(args):
     from trackformer_amd import dist_utils as du
     rank, local_rank, world = du.env_world()
-    if world != n_gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run "
-                         "--nproc-per-node %d" % (n_gpus, world, n_gpus))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if world > 1:
         torch.cuda.set_device(local_rank)
         du.init_from_env(backend="nccl", device=torch.device("cuda", local_rank))  # nccl == RCCL
     return rank, local_rank, world
 
 
-def barrier(world):
-    from trackformer_amd import dist_utils as du
-    du.barrier()
-
-
-def build_tracker(device, use_graph, model=None):
+def build_model(cfg, device):
     from trackformer_amd import config, factory
-    from trackformer_amd.deformable_detr import DeformablePostProcess
+    margs = config.make_args(*cfg["overlays"], device=str(device), **cfg["overrides"])
+    torch.manual_seed(42)   # cfgs/train.yaml:112
+    model, criterion, post = factory.build_model(margs)
+    model.to(device)
+    return model, criterion, post, margs
+
+
+def build_tracker(model, post, use_graph):
+    from trackformer_amd import config
     from trackformer_amd.tracker import Tracker
-    post = {'bbox': DeformablePostProcess()}
-    if model is None:
-        args = config.make_args('deformable', 'tracking', 'mot17', device=str(device))
-        torch.manual_seed(42)   # cfgs/train.yaml:112
-        model, _, post = factory.build_model(args)
-        model.to(device)
-        model.tracking()
     detector = model
     if use_graph:
         from trackformer_amd.graphed import GraphedDetector
         detector = GraphedDetector(model)
     tracker = Tracker(detector, post, config.tracker_cfg(), False)
     tracker.reset()
-    return tracker, model
+    return tracker
 
 
 class TrackSeeder:
-    """Re-seeds the tracker with the same 100 synthetic tracks before every step."""
+    """Re-seeds the tracker with the same synthetic tracks before every step (exactly `n` track queries)."""
 
-    def __init__(self, device, hidden_dim, seed=0):
+    def __init__(self, device, hidden_dim, n, size, seed=0):
         from trackformer_amd.box_ops import box_cxcywh_to_xyxy
         g = torch.Generator().manual_seed(seed)
-        n = NUM_TRACK_QUERIES
+        h, w = size
+        self.n = n
         centres = torch.rand(n, 2, generator=g) * 0.8 + 0.1
         sizes = torch.rand(n, 2, generator=g) * 0.18 + 0.02
         self.pos = box_cxcywh_to_xyxy(torch.cat([centres, sizes], 1)) * torch.tensor(
-            [IMG_W, IMG_H, IMG_W, IMG_H], dtype=torch.float32)
+            [w, h, w, h], dtype=torch.float32)
         self.scores = torch.full((n,), 0.9)
         self.hs = torch.randn(n, hidden_dim, generator=g).to(device)
         self.obj_ind = torch.arange(n).view(n, 1)
@@ -123,143 +196,250 @@ class TrackSeeder:
     def seed(self, tracker):
         from trackformer_amd.tracker import Track
         tracker.tracks = [Track(self.pos[i], self.scores[i], i, self.hs[i], self.obj_ind[i])
-                          for i in range(NUM_TRACK_QUERIES)]
+                          for i in range(self.n)]
         tracker.inactive_tracks = []
-        tracker.track_num = NUM_TRACK_QUERIES
+        tracker.track_num = self.n
 
 
-def make_frames(device, n=4, host=False):
+def make_frames(device, size, n=4, host=False):
+    h, w = size
     frames = []
     for i in range(n):
         g = torch.Generator().manual_seed(i)
-        img = torch.randn(1, 3, IMG_H, IMG_W, generator=g)
+        img = torch.randn(1, 3, h, w, generator=g)
         img = img.pin_memory() if host else img.to(device)
-        frames.append({'img': img, 'orig_size': torch.tensor([[IMG_H, IMG_W]]),
-                       'size': torch.tensor([[IMG_H, IMG_W]]), 'dets': torch.zeros(1, 0, 4)})
+        frames.append({'img': img, 'orig_size': torch.tensor([[h, w]]),
+                       'size': torch.tensor([[h, w]]), 'dets': torch.zeros(1, 0, 4)})
     return frames
 
 
-def measure_roofline(device, launches=50):
-    """HIP-event timing of the MSDeformAttn forward kernel at the cfg-2 encoder shape."""
-    from tools.bench_msda import CFG2_SHAPES, algorithmic_bytes, make_inputs
+def _encoder_call_inputs(pattern, sets, device, seed=0, D=32):
+    """Inputs of the FUSED operator entry at the cfg-2 encoder call shape, `sets` independent copies:
+    value [1,S,8,32], qproj [1,S,384] (raw sampling offsets | attention logits, what the model's
+    concatenated projection GEMM hands to the kernel), encoder reference points [1,S,4,2].
+    pattern  init   the default-initialised module: zero offset weights, 8-direction bias grid
+             pert   the bias grid + N(0, 0.8) raw offsets: what the perturbed-weight model of the parity
+                    tests (tests/util_weights.py: sampling_offsets.weight ~ 0.05 * N(0,1), 256 inputs) produces
+             local  reference point + N(0, 2 px) in the sampled level (SURVEY 8d "realistic")"""
+    from tools.bench_msda import CFG2_SHAPES
+    M, L, P = 8, 4, 4
+    S = sum(h * w for h, w in CFG2_SHAPES)
+    g = torch.Generator(device=device).manual_seed(seed)
+    refs = []
+    for (h, w) in CFG2_SHAPES:
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32, device=device) + 0.5,
+                                torch.arange(w, dtype=torch.float32, device=device) + 0.5, indexing="ij")
+        refs.append(torch.stack([xs.reshape(-1) / w, ys.reshape(-1) / h], -1))
+    ref = torch.cat(refs, 0).view(1, S, 1, 2).expand(1, S, L, 2).contiguous()
+    dirs = torch.tensor([(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1) if (a, b) != (0, 0)],
+                        dtype=torch.float32, device=device).view(1, 1, M, 1, 1, 2)
+    k = torch.arange(1, P + 1, dtype=torch.float32, device=device).view(1, 1, 1, 1, P, 1)
+    hw = torch.tensor(CFG2_SHAPES, dtype=torch.float32, device=device).view(1, 1, 1, L, 1, 2)   # (H, W)
+    out = []
+    for _ in range(sets):
+        value = torch.randn(1, S, M, D, generator=g, device=device)
+        noise = torch.randn(1, S, M, L, P, 2, generator=g, device=device)
+        if pattern == "init":
+            off = (dirs * k).expand(1, S, M, L, P, 2)
+        elif pattern == "pert":
+            off = dirs * k + 0.8 * noise
+        elif pattern == "local":   # N(0, 2 px) of the sampled level; the module divides x by H_l and y by W_l
+            off = noise * 2.0 * hw / hw.flip(-1)
+        else:
+            raise ValueError(pattern)
+        logits = torch.randn(1, S, M * L * P, generator=g, device=device)
+        qproj = torch.cat([off.reshape(1, S, M * L * P * 2), logits], -1).contiguous()
+        out.append((value, qproj))
+    return out, ref, S
+
+
+def measure_roofline_backward(device, launches=10):
+    """cfg 3: the MSDeformAttn backward at the encoder call shape of a bs-2 training step (N = 2), wide
+    sampling pattern; 273 MB algorithmic bytes per launch (> the Infinity Cache with its outputs)."""
+    from tools.bench_msda import CFG2_SHAPES, algorithmic_bytes, make_inputs, time_launches
     from trackformer_amd import msda
     S = sum(h * w for h, w in CFG2_SHAPES)
-    dims = dict(N=1, S=S, M=8, D=32, L=4, Lq=S, P=4)
-    # sampling locations as the seeded default-initialised model produces them (zero offset weights,
-    # 8-direction bias grid; ms_deform_attn.py:34-41): reference point + k/(H_l, W_l)
-    value, shapes, loc, attn, _ = make_inputs(1, 8, 32, S, 4, CFG2_SHAPES, "init", device,
-                                              encoder_refs=True)
+    value, shapes, loc, attn, grad_out = make_inputs(2, 8, 32, S, 4, CFG2_SHAPES, "local", device,
+                                                     encoder_refs=True)
+    ms = time_launches(lambda: msda.ms_deform_attn_backward(value, shapes, loc, attn, grad_out, 64), launches)
+    alg = algorithmic_bytes(N=2, S=S, M=8, D=32, L=4, Lq=S, P=4, backward=True)
+    gbs = alg / ms / 1e6
+    return {"bound": "hbm", "kernel": "msda_bwd_f32_sorted (encoder call of a bs-2 training step, N=2, Lq=S=22223)",
+            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+            "traffic": None, "algorithmic_bytes": alg, "avg_launch_us": round(ms * 1e3, 2), "launches": launches,
+            "pattern": "local (reference point + N(0, 2 px))"}
+
+
+def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32):
+    """HIP-event timing of the MSDeformAttn forward kernel at the cfg-2 encoder call shape, THROUGH THE
+    FUSED ENTRY the model calls (tf_msda_forward_fused_f32), on the sampling pattern of the
+    perturbed-weight parity model, rotating over `sets` input sets (4 x 80 MB > the 256 MiB Infinity
+    Cache, so every launch reads HBM).  `launches` launches are captured in one HIP graph on the launch
+    stream.  The default-initialised (`init`) and the wide (`local`) pattern are reported next to it."""
+    if train:
+        return measure_roofline_backward(device)
+    from tools.bench_msda import CFG2_SHAPES, algorithmic_bytes
+    from trackformer_amd import msda
+    M, L, P, D = 8, 4, 4, head_dim
     stream = torch.cuda.Stream(device)
-    stream.wait_stream(torch.cuda.current_stream(device))
-    with torch.cuda.stream(stream):
-        for _ in range(3):
-            msda.ms_deform_attn_forward(value, shapes, loc, attn, 64)
-        graph = torch.cuda.CUDAGraph()
-        stream.synchronize()
-        with torch.cuda.graph(graph, stream=stream):
-            for _ in range(launches):
-                msda.ms_deform_attn_forward(value, shapes, loc, attn, 64)
-        graph.replay()
-        stream.synchronize()
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record(stream)
-        graph.replay()
-        end.record(stream)
-        end.synchronize()
-    us = start.elapsed_time(end) * 1e3 / launches
-    alg = algorithmic_bytes(**dims)
-    achieved = alg / (us * 1e-6) / 1e9
-    # HBM traffic of the same kernel/shape from the PMC counters: collected offline (rocprofv3 --pmc
-    # needs its own passes) and committed together with the method; see the file's "_how"
+    per_pattern = {}
+    alg = None
+    for pattern in ("pert", "init", "local"):
+        inputs, ref, S = _encoder_call_inputs(pattern, sets, device, D=D)
+        alg = algorithmic_bytes(N=1, S=S, M=M, D=D, L=L, Lq=S, P=P)
+        shapes = msda.attach_host_shapes(torch.tensor(CFG2_SHAPES, dtype=torch.long, device=device),
+                                         CFG2_SHAPES)
+        torch.cuda.synchronize(device)
+        stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(stream):
+            for value, qproj in inputs:
+                msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P)
+            graph = torch.cuda.CUDAGraph()
+            stream.synchronize()
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(launches):
+                    value, qproj = inputs[i % sets]
+                    msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P)
+            graph.replay()
+            stream.synchronize()
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record(stream)
+            graph.replay()
+            end.record(stream)
+            end.synchronize()
+        us = start.elapsed_time(end) * 1e3 / launches
+        per_pattern[pattern] = {"avg_launch_us": round(us, 2), "GBps": round(alg / (us * 1e-6) / 1e9, 1),
+                                "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        del graph, inputs
+    head = per_pattern["pert"]
+    # HBM traffic of the same kernel / shape / pattern from the PMC counters: collected offline (rocprofv3
+    # --pmc needs its own passes) and committed together with the method; see the file's "_how"
     mode = os.environ.get("TF_MSDA_TILED", "2")[:1] or "2"   # the library's kernel choice for this shape
-    kernel = {"0": "msda_fwd_f32_direct", "1": "msda_fwd_f32_win"}.get(mode, "msda_fwd_f32_quad")
+    kernel = {"0": "msda_fwd_f32_direct", "1": "msda_fwd_f32_win"}.get(mode, "msda_fwd_f32_pquad")
+    if D != 32:
+        kernel = "msda_fwd_f32_buf"   # head dimension 36 (hidden 288): no LDS-window kernel yet
     traffic = None
     try:
-        with open(os.path.join(REPO, "profiles", "r01_msda_fwd_quad_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r02_msda_fwd_pquad_traffic.json")) as f:
             traffic = json.load(f)[kernel]["hbm_traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "hbm", "kernel": kernel + " (encoder shape, Lq=S=22223)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "algorithmic_bytes": alg, "avg_launch_us": round(us, 2), "launches": launches}
+    return {"bound": "hbm", "kernel": kernel + " via tf_msda_forward_fused_f32 (encoder call, Lq=S=22223)",
+            "achieved": head["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
+            "traffic": traffic, "algorithmic_bytes": alg, "avg_launch_us": head["avg_launch_us"],
+            "launches": launches, "input_sets": sets,
+            "pattern": "pert (perturbed-weight model sampling), Infinity-Cache-cold",
+            "other_patterns": {k: v for k, v in per_pattern.items() if k != "pert"}}
 
 
-def measure_cpu_baseline(frames):
-    """The same frame on the host: identical modules on CPU, C oracle as the MSDeformAttn operator."""
+def cpu_operator(kind):
+    """MSDeformAttnFunction stand-ins for the CPU leg -- checkers used as the timed baseline, never shipped."""
+    if kind == "reference-restated":
+        from oracle import msda_grid_sample
+        return msda_grid_sample.make_torch_function()
     from oracle import msda_oracle
-    from trackformer_amd import config, factory, msda
-    from trackformer_amd.tracker import Tracker
-    cores = torch.get_num_threads()
     msda_oracle.build()
-    args = config.make_args('deformable', 'tracking', 'mot17', device='cpu')
-    torch.manual_seed(42)
-    model, _, post = factory.build_model(args)
-    model.tracking()
-    saved = msda.MSDeformAttnFunction
+    cores = torch.get_num_threads()
 
-    class HostOp(torch.autograd.Function):   # checker used as the timed CPU baseline, never shipped
+    class HostOp(torch.autograd.Function):
         @staticmethod
         def forward(ctx, value, shapes, loc, attn, step):
             out = msda_oracle.msda_forward(value.numpy(), shapes.numpy(), loc.numpy(),
                                            attn.numpy(), nthreads=cores)
             return torch.from_numpy(out)
+    return HostOp
 
-    msda.MSDeformAttnFunction = HostOp
+
+def measure_cpu_baseline(cfg, frames):
+    """The same workload on the host: identical modules on CPU; MSDeformAttn = the reference's pure-CPU
+    path restated (grid_sample), and, as a second figure, the C port of the kernels' arithmetic."""
+    from trackformer_amd import msda
+    cores = torch.get_num_threads()
+    cpu = torch.device("cpu")
+    model, criterion, post, margs = build_model(cfg, cpu)
+    saved = msda.MSDeformAttnFunction
+    results = {}
+    kinds = ("reference-restated", "port") if margs.deformable else ("port",)
     try:
-        tracker = Tracker(model, post, config.tracker_cfg(), False)
-        tracker.reset()
-        seeder = TrackSeeder(torch.device('cpu'), args.hidden_dim)
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            for i in range(frames):
-                seeder.seed(tracker)
-                g = torch.Generator().manual_seed(i)
-                blob = {'img': torch.randn(1, 3, IMG_H, IMG_W, generator=g),
-                        'orig_size': torch.tensor([[IMG_H, IMG_W]]),
-                        'size': torch.tensor([[IMG_H, IMG_W]]), 'dets': torch.zeros(1, 0, 4)}
-                tracker.step(blob)
-        dt = time.perf_counter() - t0
+        for kind in kinds:
+            msda.MSDeformAttnFunction = cpu_operator(kind)
+            if cfg["kind"] == "train":
+                from tools.bench_train import synthetic_batch
+                from trackformer_amd import engine
+                if kind == "port":
+                    continue   # the C port has no autograd
+                model.train()
+                criterion.train()
+                optimizer, _ = engine.build_optimizer(model, margs)
+                samples, targets = synthetic_batch(cpu, 1, *cfg["size"], seed=0)
+                t0 = time.perf_counter()
+                engine.train_step(model, criterion, optimizer, samples, targets,
+                                  clip_max_norm=margs.clip_max_norm)
+                dt = time.perf_counter() - t0
+                results[kind] = (1 / dt, "1 training step on 1 image (bs 1 instead of 2), %.1f s" % dt)
+                continue
+            if hasattr(model, "tracking"):
+                model.tracking()
+            else:
+                model.eval()
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                if cfg["kind"] == "detect":
+                    for i in range(frames):
+                        g = torch.Generator().manual_seed(i)
+                        out, *_ = model(torch.randn(1, 3, *cfg["size"], generator=g), None, None)
+                        post['bbox'](out, torch.tensor([list(cfg["size"])]))
+                else:
+                    tracker = build_tracker(model, post, use_graph=False)
+                    seeder = TrackSeeder(cpu, margs.hidden_dim, cfg["tracks"], cfg["size"])
+                    for blob in make_frames(cpu, cfg["size"], n=frames):
+                        seeder.seed(tracker)
+                        tracker.step(blob)
+            dt = time.perf_counter() - t0
+            results[kind] = (frames / dt, "%d frame(s), %.1f s" % (frames, dt))
     finally:
         msda.MSDeformAttnFunction = saved
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d frame(s) of the same workload (800x1333, 300+100 queries) through the "
-                      "same nn.Modules on CPU (torch CPU kernels, %d threads) with oracle/msda_ref.c "
-                      "as the MSDeformAttn operator; %.1f s" % (frames, cores, dt)}
+    head = kinds[0]
+    line = {"value": round(results[head][0], 4), "unit": cfg["unit"], "cores": cores, "kind": head,
+            "sample": "%s of the same workload through the same nn.Modules on CPU (torch CPU kernels, %d "
+                      "threads) with %s as the MSDeformAttn operator" % (
+                          results[head][1], cores,
+                          "the reference's pure-CPU path restated (grid_sample, oracle/msda_grid_sample.py)"
+                          if head == "reference-restated" else "no deformable attention in this model"
+                          if not margs.deformable else "oracle/msda_ref.c")}
+    if "port" in results and head != "port":
+        line["c_port"] = {"value": round(results["port"][0], 4), "kind": "port",
+                          "sample": results["port"][1] + ", oracle/msda_ref.c (OpenMP, %d threads) as the "
+                                                         "operator" % cores}
+    return line
 
 
-def main():
-    args = parse_args()
-    rank, local_rank, world = init_distributed(args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
-    from trackformer_amd import runtime
-    runtime.configure_inference(tune=os.environ.get("TF_TUNE", "0") == "1",
-                                miopen_find=os.environ.get("TF_MIOPEN_FIND", "1") == "1",
-                                verbose=(rank == 0))
+def timed_repeats(run_set, steps, world, device, min_seconds):
+    """EXACTLY `steps` steps per repetition, each bracketed by barrier + synchronize; repeated until
+    `min_seconds` of timed work; per-repetition time = max over ranks."""
+    from trackformer_amd import dist_utils as du
+    total, reps = 0.0, 0
+    while True:
+        torch.cuda.synchronize()
+        du.barrier()
+        t0 = time.perf_counter()
+        run_set(steps)
+        torch.cuda.synchronize()
+        du.barrier()
+        total += du.max_over_ranks(time.perf_counter() - t0, device)
+        reps += 1
+        if total >= min_seconds or reps >= 200:
+            return total, reps
 
-    from trackformer_amd import _cabi, fused
-    _cabi.lib()   # fail loudly if the HIP library is missing
-    if args.split_linear:
-        fused.set_split_linear(True)
 
+def run_tracking(cfg, args, device, world, model, post, margs, n_seq):
+    """cfg 2 / 4 / 5: `n_seq` trackers (own HIP stream + graph buffers each, shared weights) step through
+    synthetic frames; returns (elapsed, repeats)."""
     import threading
-    n_seq = max(1, args.sequences)
-    steps_per_seq = [args.steps // n_seq + (1 if i < args.steps % n_seq else 0) for i in range(n_seq)]
-    warm_per_seq = max(3, (args.warmup + n_seq - 1) // n_seq)   # >= 3: HIP-graph capture happens here
-
-    # One tracker (own HIP stream, own graph buffers) per sequence; the detector weights are shared.
-    trackers, model = [], None
-    for i in range(n_seq):
-        tracker, m = build_tracker(device, use_graph=not args.no_graph, model=model)
-        model = m
-        trackers.append(tracker)
-    seeder = TrackSeeder(device, model.hidden_dim)
-    frames = make_frames(device, host=args.host_frames)
+    trackers = [build_tracker(model, post, use_graph=not args.no_graph) for _ in range(n_seq)]
+    seeder = TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"])
+    frames = make_frames(device, cfg["size"], host=args.host_frames)
     streams = [torch.cuda.Stream(device) for _ in range(n_seq)]
-
     stagger = [0.0]
 
     def run(seq, n):
@@ -272,63 +452,138 @@ def main():
                 trackers[seq].step(frames[(seq + i) % len(frames)])
             streams[seq].synchronize()
 
-    # warm-up sequentially (MIOpen find, caches, graph capture are not re-entrant), then time
+    # warm-up sequentially (MIOpen find mode and the host-side caches are filled here), then time
+    warm_per_seq = max(4, (args.warmup + n_seq - 1) // n_seq)   # >= 4: both HIP graphs of a multi-frame model
     for seq in range(n_seq):
         run(seq, warm_per_seq)
     torch.cuda.synchronize()
     tw = time.perf_counter()
     run(0, 3)
     stagger[0] = (time.perf_counter() - tw) / 3 / n_seq if n_seq > 1 else 0.0
-    torch.cuda.synchronize()
-    barrier(world)
-    t0 = time.perf_counter()
-    if n_seq == 1:
-        run(0, steps_per_seq[0])
-    else:
-        threads = [threading.Thread(target=run, args=(seq, steps_per_seq[seq]))
-                   for seq in range(n_seq)]
+
+    def run_set(steps):
+        per_seq = [steps // n_seq + (1 if i < steps % n_seq else 0) for i in range(n_seq)]
+        if n_seq == 1:
+            run(0, per_seq[0])
+            return
+        threads = [threading.Thread(target=run, args=(seq, per_seq[seq])) for seq in range(n_seq)]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
-    torch.cuda.synchronize()
-    barrier(world)
-    elapsed = time.perf_counter() - t0
+    return timed_repeats(run_set, args.steps, world, device, args.min_seconds)
 
-    from trackformer_amd import dist_utils as du
-    elapsed = du.max_over_ranks(elapsed, device)
+
+def run_detect(cfg, args, device, world, model, post):
+    """cfg 1: forward + PostProcess of the plain DETR on one frame per step."""
+    detector = model
+    if not args.no_graph:
+        from trackformer_amd.graphed import GraphedDetector
+        detector = GraphedDetector(model)
+    frames = make_frames(device, cfg["size"])
+    sizes = torch.tensor([list(cfg["size"])], device=device)
+
+    def run_set(steps):
+        with torch.no_grad():
+            for i in range(steps):
+                out, *_ = detector(frames[i % len(frames)]['img'], None, None)
+                res = post['bbox'](out, sizes)
+            res[0]['scores'].cpu()   # the frame's result reaches the host
+    run_set(max(3, args.warmup))
+    return timed_repeats(run_set, args.steps, world, device, args.min_seconds)
+
+
+def run_training(cfg, args, device, world, rank, model, criterion, margs):
+    """cfg 3: engine.train_step on a fixed synthetic batch of 2 images per GPU (DDP over RCCL when world > 1)."""
+    from tools.bench_train import synthetic_batch
+    from trackformer_amd import engine
+    model.train()
+    criterion.train()
+    optimizer, _ = engine.build_optimizer(model, margs)
+    ddp = engine.wrap_ddp(model, device)
+    samples, targets = synthetic_batch(device, 2, *cfg["size"], seed=rank)
+
+    def run_set(steps):
+        for _ in range(steps):
+            tg = [dict(t, prev_target=dict(t['prev_target'])) for t in targets]   # forward mutates targets
+            engine.train_step(ddp, criterion, optimizer, samples, tg, clip_max_norm=margs.clip_max_norm)
+    run_set(args.warmup)
+    return timed_repeats(run_set, args.steps, world, device, args.min_seconds)
+
+
+def main():
+    args = parse_args()
+    rank, local_rank, world = init_distributed(args)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
+    cfg = CONFIGS[args.config]
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    from trackformer_amd import _cabi, fused, runtime
+    _cabi.lib()   # fail loudly if the HIP library is missing
+    train = cfg["kind"] == "train"
+    if train:
+        torch.backends.cudnn.benchmark = True
+    else:
+        runtime.configure_inference(tune=os.environ.get("TF_TUNE", "0") == "1",
+                                    miopen_find=os.environ.get("TF_MIOPEN_FIND", "1") == "1",
+                                    verbose=(rank == 0))
+    if args.split_linear is not None:
+        fused.set_split_linear(args.split_linear)
+
+    model, criterion, post, margs = build_model(cfg, device)
+    single = None
+    n_seq = 1
+    if cfg["kind"] == "track":
+        model.tracking()
+        n_seq = max(1, args.sequences)
+        elapsed, reps = run_tracking(cfg, args, device, world, model, post, margs, n_seq)
+        if n_seq > 1 and not args.no_single_sequence:
+            e1, r1 = run_tracking(cfg, args, device, world, model, post, margs, 1)
+            single = args.steps * r1 * world / e1
+    elif cfg["kind"] == "detect":
+        model.eval()
+        elapsed, reps = run_detect(cfg, args, device, world, model, post)
+    else:
+        elapsed, reps = run_training(cfg, args, device, world, rank, model, criterion, margs)
 
     roofline = cpu_baseline = None
     if rank == 0:
-        if not args.no_roofline:
-            roofline = measure_roofline(device)
+        if not args.no_roofline and margs.deformable:
+            roofline = measure_roofline(device, train=train, head_dim=margs.hidden_dim // margs.nheads)
         if world == 1 and not args.no_cpu_baseline:
-            cpu_baseline = measure_cpu_baseline(args.cpu_frames)
+            del model
+            torch.cuda.empty_cache()
+            cpu_baseline = measure_cpu_baseline(cfg, args.cpu_frames)
 
     if world > 1:
-        barrier(world)
+        from trackformer_amd import dist_utils as du
+        du.barrier()
         import torch.distributed as dist
         dist.destroy_process_group()
 
     if rank == 0:
-        total_frames = args.steps * world
-        value = total_frames / elapsed
+        units_per_step = 2 if train else 1   # cfg 3: 2 images per step and GPU
+        steps_timed = args.steps * reps
+        value = steps_timed * units_per_step * world / elapsed
         line = {
-            "metric": "frames/sec, TrackFormer-Deformable inference (ResNet-50, 1333x800, 300 object + "
-                      "100 track queries, bs 1 per GPU); roofline = ms_deform_attn HBM GB/s",
-            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "metric": cfg["metric"], "value": round(value, 3), "unit": cfg["unit"], "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / steps_timed, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if not fused.split_linear_enabled() or train
+                     else "f32 (transformer linears: 3-pass bf16 split product on MFMA, f32 accumulate)",
             "data": "synthetic", "per_gpu": round(value / world, 3),
-            "config": {"workload": "BASELINE cfg 2: Tracker.step on 800x1333 synthetic frames, "
-                                   "DeformableDETRTracking R50 4 levels, 300 obj + 100 track "
-                                   "queries, seeded random-init weights, frames "
+            "timed_repeats": reps, "steps_timed": steps_timed, "timed_seconds": round(elapsed, 3),
+            "config": {"workload": cfg["name"] + ", seeded random-init weights, frames "
                                    + ("in pinned host memory (PCIe copy timed)" if args.host_frames
                                       else "resident in HBM"),
-                       "global_batch": world, "parallelism": "sequence-sharded x%d" % world,
-                       "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph,
+                       "global_batch": world * (2 if train else 1),
+                       "parallelism": ("DDP x%d (RCCL all-reduce)" if train else "sequence-sharded x%d") % world,
+                       "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
                        "linears": "bf16 split product (hi.hi + hi.mid + mid.hi, f32 accumulate)"
-                                  if fused.split_linear_enabled() else "f32 (hipBLASLt)"},
+                                  if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)"},
+            "single_sequence_fps": None if single is None else round(single, 3),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

@@ -372,14 +372,17 @@ def test_module_forward_matches_oracle_composition(dev):
 
 
 # ------------------------------------------------------------------ tiled / LDS-staged encoder kernel
-@pytest.fixture(params=[1, 2], ids=["win", "quad"])
+@pytest.fixture(params=[1, 2, 3], ids=["win", "quad", "pquad"])
 def tiled(dev, request):
-    """Select an LDS-window encoder kernel (1: msda_fwd_f32_win, 2: msda_fwd_f32_quad -- the default for
-    encoder-shaped calls) for the duration of a test."""
+    """Select an LDS-window encoder kernel (1: msda_fwd_f32_win, 2: msda_fwd_f32_quad, 3: the persistent
+    msda_fwd_f32_pquad -- the default for encoder-shaped calls) for the duration of a test."""
     from trackformer_amd import _cabi
-    prev = _cabi.lib().tf_msda_set_tiled(request.param)
+    lib = _cabi.lib()
+    prev = lib.tf_msda_set_tiled(min(request.param, 2))
+    prev_pq = lib.tf_msda_set_option(b"pquad", 1 if request.param == 3 else 0)
     yield
-    _cabi.lib().tf_msda_set_tiled(prev)
+    lib.tf_msda_set_tiled(prev)
+    lib.tf_msda_set_option(b"pquad", prev_pq)
 
 
 def _encoder_inputs(dev, shapes, mode, N=1, M=8, D=32, seed=0):
@@ -439,6 +442,46 @@ def test_tiled_kernel_matches_rowgather_kernel(dev, tiled):
     # drop the last query -> Lq = S - 1 -> row-gather kernel
     rg = _fwd(value, shp, loc[:, :-1].contiguous(), attn[:, :-1].contiguous())
     assert torch.allclose(tiled[:, :-1], rg, atol=2e-6, rtol=1e-5)
+
+
+PQUAD_VARIANTS = [dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pquad_wg_per_cu=2),
+                  dict(pquad_prefetch=2, pquad_wg_per_cu=2), dict(pquad_wide=0), dict(pquad_lds_kb=24),
+                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1), dict(pquad_skew=100)]
+
+
+@pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items())
+                                                      for o in PQUAD_VARIANTS])
+def test_persistent_encoder_kernel_variants_vs_oracle(dev, opts):
+    """msda_fwd_f32_pquad with its knobs away from the defaults (passes per tile, register prefetch, narrow
+    loads, a small LDS budget, few workgroups = many tiles per workgroup, start-up skew), plain and fused entry,
+    N = 2: the tile loop, the double-buffered per-tile tables and the prefetch must not change a result."""
+    from trackformer_amd import _cabi, msda
+    lib = _cabi.lib()
+    prev = {k: lib.tf_msda_set_option(k.encode(), v) for k, v in opts.items()}
+    try:
+        shapes_l = [(40, 61), (20, 31), (10, 16), (5, 8)]
+        value, shp, loc, attn, _ = _encoder_inputs(dev, shapes_l, "local", N=2, seed=11)
+        out = _fwd(value, shp, loc, attn).cpu().numpy()
+        ref = msda_oracle.msda_forward(value.cpu().numpy(), shp.cpu().numpy(), loc.cpu().numpy(),
+                                       attn.cpu().numpy(), nthreads=8)
+        np.testing.assert_allclose(out, ref, atol=1e-5, rtol=1e-4)
+        # fused entry on the same geometry: raw offsets / logits + encoder reference points
+        N, S, M, D = value.shape
+        L, P = len(shapes_l), 4
+        g = torch.Generator().manual_seed(5)
+        qproj = torch.randn(N, S, 3 * M * L * P, generator=g)
+        qproj[..., :2 * M * L * P] *= 2.0
+        refp = loc.cpu()[:, :, 0, :, 0, :].contiguous() * 0 + torch.rand(N, S, L, 2, generator=g) * 0.8 + 0.1
+        off = qproj[..., :2 * M * L * P].view(N, S, M, L, P, 2)
+        a = torch.softmax(qproj[..., 2 * M * L * P:].view(N, S, M, L * P), -1).view(N, S, M, L, P)
+        hw = torch.tensor(shapes_l, dtype=torch.float32)[None, None, None, :, None, :]
+        floc = refp[:, :, None, :, None, :] + off / hw
+        expect = msda_oracle.msda_forward(value.cpu().numpy(), shp.cpu().numpy(), floc.numpy(), a.numpy(), nthreads=8)
+        got = msda.ms_deform_attn_forward_fused(value, shp, refp.to(dev), qproj.to(dev), M, L, P)
+        np.testing.assert_allclose(got.cpu().numpy(), expect.reshape(got.shape), atol=2e-5, rtol=1e-4)
+    finally:
+        for k, v in prev.items():
+            lib.tf_msda_set_option(k.encode(), v)
 
 
 BWD_ENC_CASES = [c for c in TILED_CASES if c[0] in (

@@ -53,3 +53,23 @@ def test_shape_sum_is_checked():
     bad[0, 0] += 1
     with pytest.raises(RuntimeError):
         msda_oracle.msda_forward(z["value"], bad, z["loc"], z["attn"])
+
+
+# ------------------------------------------------------------------ the restated grid_sample path
+@pytest.mark.parametrize("path", CASES, ids=lambda p: p.split("msda_")[-1][:-4])
+def test_grid_sample_restatement_matches_reference(path):
+    """oracle/msda_grid_sample.py (the reference's pure-CPU path restated, bench.py's cpu_baseline
+    operator) against outputs AND gradients of the reference's own ms_deform_attn_core_pytorch."""
+    import torch
+    from oracle.msda_grid_sample import msda_grid_sample
+    z = load_case(path)
+    value = torch.from_numpy(z["value"]).requires_grad_(True)
+    loc = torch.from_numpy(z["loc"]).requires_grad_(True)
+    attn = torch.from_numpy(z["attn"]).requires_grad_(True)
+    out = msda_grid_sample(value, torch.from_numpy(z["shapes"]), loc, attn)
+    atol, rtol = _tol(z["value"].dtype)
+    np.testing.assert_allclose(out.detach().numpy(), z["out"], atol=atol, rtol=rtol)
+    out.backward(torch.from_numpy(z["grad_out"]).reshape(out.shape))
+    np.testing.assert_allclose(value.grad.numpy(), z["grad_value"], atol=atol, rtol=rtol)
+    np.testing.assert_allclose(attn.grad.numpy(), z["grad_attn"], atol=atol * 10, rtol=rtol)
+    np.testing.assert_allclose(loc.grad.numpy(), z["grad_loc"], atol=atol * 10, rtol=rtol)

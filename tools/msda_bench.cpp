@@ -115,7 +115,7 @@ static Inputs make_inputs(const std::string &mode, int N, unsigned seed)
 
 struct Config {
     std::string name;
-    int tiled;                                            // 0 direct, 1 win, 2 quad
+    int tiled;                                            // 0 direct, 1 win, 2 quad, 3 pquad (tiled 2 + pquad on)
     std::vector<std::pair<std::string, int>> opts;        // quad_* options
 };
 
@@ -124,22 +124,28 @@ static Config parse_config(const std::string &arg)
     Config c;
     c.name = arg;
     const std::string kind = arg.substr(0, arg.find(':'));
-    c.tiled = kind == "direct" ? 0 : kind == "win" ? 1 : kind == "quad" ? 2 : -9;
+    c.tiled = kind == "direct" ? 0 : kind == "win" ? 1 : kind == "quad" ? 2 : kind == "pquad" ? 3 : -9;
     if (c.tiled == -9) {
         fprintf(stderr, "unknown configuration '%s'\n", arg.c_str());
         exit(2);
     }
-    static const char *keys[][2] = {{"ta", "quad_ta_mask"}, {"waves", "quad_waves"}, {"npass", "quad_npass"},
-                                    {"lds", "quad_lds_kb"}, {"hy", "quad_halo_y"}, {"hx", "quad_halo_x"},
-                                    {"th", "quad_tile_h"},  {"tw", "quad_tile_w"},  {"split", "quad_split"}};
+    static const char *qkeys[][2] = {{"ta", "quad_ta_mask"}, {"waves", "quad_waves"}, {"npass", "quad_npass"},
+                                     {"lds", "quad_lds_kb"}, {"hy", "quad_halo_y"}, {"hx", "quad_halo_x"},
+                                     {"th", "quad_tile_h"},  {"tw", "quad_tile_w"},  {"split", "quad_split"}};
+    static const char *pkeys[][2] = {{"wide", "pquad_wide"}, {"npass", "pquad_npass"}, {"lds", "pquad_lds_kb"},
+                                     {"hy", "pquad_halo_y"}, {"hx", "pquad_halo_x"}, {"th", "pquad_tile_h"},
+                                     {"tw", "pquad_tile_w"}, {"wgs", "pquad_wg_per_cu"}, {"pf", "pquad_prefetch"},
+                                     {"skew", "pquad_skew"}};
+    const size_t nkeys = c.tiled == 3 ? 10 : 9;
+    const char *(*keys)[2] = c.tiled == 3 ? pkeys : qkeys;
     size_t pos = arg.find(':');
     while (pos != std::string::npos && pos + 1 < arg.size()) {
         const size_t next = arg.find(',', pos + 1);
         const std::string kv = arg.substr(pos + 1, next == std::string::npos ? std::string::npos : next - pos - 1);
         const size_t eq = kv.find('=');
         if (eq != std::string::npos)
-            for (auto &k : keys)
-                if (kv.substr(0, eq) == k[0]) c.opts.push_back({k[1], atoi(kv.c_str() + eq + 1)});
+            for (size_t ki = 0; ki < nkeys; ++ki)
+                if (kv.substr(0, eq) == keys[ki][0]) c.opts.push_back({keys[ki][1], atoi(kv.c_str() + eq + 1)});
         pos = next;
     }
     return c;
@@ -150,9 +156,14 @@ static void apply(const Config &c)
     static const char *names[] = {"quad_ta_mask", "quad_waves",  "quad_npass",  "quad_lds_kb", "quad_halo_y",
                                   "quad_halo_x",  "quad_tile_h", "quad_tile_w", "quad_split"};
     static const int defaults[] = {0, 4, 3, 40, 6, 10, 0, 0, 1};   // = kQuadOptDefaults of the library
+    static const char *pnames[] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
+                                   "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew"};
+    static const int pdefaults[] = {1, 2, 48, 6, 10, 0, 0, 3, 0, 0};   // = kPqOptDefaults of the library
     for (int i = 0; i < 9; ++i) tf_msda_set_option(names[i], defaults[i]);
+    for (int i = 0; i < 10; ++i) tf_msda_set_option(pnames[i], pdefaults[i]);
     for (auto &o : c.opts) tf_msda_set_option(o.first.c_str(), o.second);
-    tf_msda_set_option("tiled", c.tiled);
+    tf_msda_set_option("pquad", c.tiled == 3 ? 1 : 0);
+    tf_msda_set_option("tiled", c.tiled == 3 ? 2 : c.tiled);
 }
 
 int main(int argc, char **argv)
@@ -267,7 +278,7 @@ int main(int argc, char **argv)
                         }
                     }
                 }
-                if (trace && c.tiled == 2) {
+                if (trace && c.tiled >= 2) {
                     // phase timestamps of every workgroup (wave 0): offsets from the earliest workgroup start
                     const size_t max_wg = 16384;
                     unsigned long long *d_tr;
@@ -287,12 +298,20 @@ int main(int argc, char **argv)
                             t0 = std::min(t0, tr[w * 16]);
                             nwg = w + 1;
                         }
-                    static const char *names[14] = {"entry", "setup barrier", "points+bbox", "barrier A", "DMA r0 issued",
-                                                    "load-gathers r0", "DMA r0 landed", "LDS gathers r0", "DMA r1 issued",
-                                                    "load-gathers r1", "DMA r1 landed", "LDS gathers r1 + stores",
-                                                    "(point loads issued)", "(level 0 bbox filed)"};
+                    static const char *qnames[14] = {"entry", "setup barrier", "points+bbox", "barrier A", "DMA r0 issued",
+                                                     "load-gathers r0", "DMA r0 landed", "LDS gathers r0", "DMA r1 issued",
+                                                     "load-gathers r1", "DMA r1 landed", "LDS gathers r1 + stores",
+                                                     "(point loads issued)", "(level 0 bbox filed)"};
+                    // msda_fwd_f32_pquad: first tile of every workgroup, then the end of its last tile
+                    static const char *pnames[14] = {"entry", "tile 0 loads issued", "tile 0 points+bbox", "B0", "B1 (L0 landed)",
+                                                     "(prefetch issued)", "L0 gathered", "B3 (L1-3 landed)", "stored",
+                                                     "tile 1 points+bbox", "end of last tile", "B2 (L0 window free)", "DMA L1-3 issued",
+                                                     "DMA L1-3 landed (own)"};
+                    const char **names = c.tiled == 3 ? pnames : qnames;
                     printf("  trace of %zu workgroups (us after the first workgroup's entry; 100 MHz clock):\n", nwg);
-                    static const int order[14] = {0, 1, 12, 13, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+                    static const int qorder[14] = {0, 1, 12, 13, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+                    static const int porder[14] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 7, 8, 9, 10};
+                    const int *order = c.tiled == 3 ? porder : qorder;
                     for (int oi = 0; oi < 14; ++oi) {
                         const int i = order[oi];
                         std::vector<double> v, dur;

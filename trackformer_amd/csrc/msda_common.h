@@ -1,0 +1,50 @@
+// trackformer_amd/csrc/msda_common.h -- types shared by the translation units of libtf_msda.so
+// (msda_hip.hip: every kernel but one + the C ABI; msda_pquad.hip: the persistent encoder forward kernel).
+#ifndef TF_MSDA_COMMON_H_
+#define TF_MSDA_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include "tf_msda.h"
+
+namespace tfm {
+
+struct LevelTable {
+    int H[TF_MSDA_MAX_LEVELS];
+    int W[TF_MSDA_MAX_LEVELS];
+    int start[TF_MSDA_MAX_LEVELS];
+};
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0xFFFFFFF0u;  // >= num_records for every supported tensor
+constexpr unsigned kOobBase = 0xFFFFFF00u;    // ... and so is kOobBase + (lane slice offset < 0xF0)
+
+// Fused prologue (ms_deform_attn.py:69-86 inside the kernel): raw projection outputs + reference points.
+struct FusedArgs {
+    const float *ref;     // [N, Lq, L, ref_dim]
+    const float *qproj;   // [N*Lq, ld]: per query, M*L*P*2 raw offsets at off_col, M*L*P logits at logit_col
+    int ref_dim, ld, off_col, logit_col;
+    int head_major;       // block -> pair mapping, see msda_fwd_f32_buf
+};
+
+struct DirectArgs {
+    const float *value;
+    unsigned value_bytes;
+    const float *loc, *attn;   // plain operator inputs (FUSED == false)
+    float *out;
+    FusedArgs fa;              // FUSED == true
+    int S, M, L, Lq;
+    long long nlq;             // N * Lq
+};
+
+// msda_pquad.hip: the persistent LDS-window encoder forward (msda_fwd_f32_pquad).  launch_pquad returns
+// false when the call does not qualify (the caller falls through to the next kernel).
+bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N, int D, int P, hipStream_t stream,
+                  hipError_t *err);
+int pquad_set_option(const char *name, int value);   // -1: unknown name, else the previous value
+void pquad_set_trace(unsigned long long *device_buffer);
+
+}  // namespace tfm
+
+#endif  // TF_MSDA_COMMON_H_

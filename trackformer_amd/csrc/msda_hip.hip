@@ -46,18 +46,15 @@
 #include <type_traits>
 
 #include "tf_msda.h"
+#include "msda_common.h"
 #include "msda_quad_geom.h"
 
 namespace {
+using namespace tfm;
 
 constexpr int kThreads = 256;          // 4 wavefronts per workgroup
 constexpr int kLdsChunkBudget = 48 * 1024;  // LDS bytes for the loc/attn (and grad) chunk
 
-struct LevelTable {
-    int H[TF_MSDA_MAX_LEVELS];
-    int W[TF_MSDA_MAX_LEVELS];
-    int start[TF_MSDA_MAX_LEVELS];
-};
 constexpr int kLevelTableBytes = 3 * TF_MSDA_MAX_LEVELS * (int)sizeof(int);  // 192, multiple of 16
 
 template <typename T, int VEC>
@@ -253,10 +250,7 @@ msda_fwd_rowgather(const T *__restrict__ value, const T *__restrict__ loc,
 //     clamping and without divergent code, and a 0*Inf can never be formed;
 //   * P is a template parameter so the 4*P loads of a level are issued back to back before the first
 //     use (the compiler cannot sink them into conditionals: there are none).
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr unsigned kOobOffset = 0xFFFFFFF0u;  // >= num_records for every supported tensor
-constexpr unsigned kOobBase = 0xFFFFFF00u;    // ... and so is kOobBase + (lane slice offset < 0xF0)
+// (u32x4_t / f32x4_t, kOobOffset / kOobBase: msda_common.h)
 
 // Optional fused prologue (FUSED = true): instead of reading finished sampling locations and softmaxed
 // attention weights, the kernel takes the raw outputs of the query projections and the reference
@@ -268,12 +262,7 @@ constexpr unsigned kOobBase = 0xFFFFFF00u;    // ... and so is kOobBase + (lane 
 //     loc  = ref[q, l, :2] + off[q, m, l, p, :] / P * ref[q, l, 2:] * 0.5          (ref_dim == 4)
 // which removes the softmax, division, multiply and add kernels (and their ~100 MB of traffic per
 // encoder layer) that the reference runs between the projection GEMM and the operator.
-struct FusedArgs {
-    const float *ref;     // [N, Lq, L, ref_dim]
-    const float *qproj;   // [N*Lq, ld]: per query, M*L*P*2 raw offsets at off_col, M*L*P logits at logit_col
-    int ref_dim, ld, off_col, logit_col;
-    int head_major;       // block -> pair mapping, see msda_fwd_f32_buf
-};
+// (struct FusedArgs: msda_common.h)
 
 template <int PT, bool FUSED>
 __global__ void __launch_bounds__(kThreads)
@@ -446,15 +435,7 @@ msda_fwd_f32_buf(const float *__restrict__ value, unsigned value_bytes,
 //     on the fly (softmax statistics by xor butterflies over the 8 lanes).
 // What bounds it now is the vector-memory path itself: the 64 row gathers per pair move 1.46 GB per
 // launch through the texture-addresser / L1 at <= 64 B/clk/CU (TA_BUSY ~80 % of the kernel's cycles).
-struct DirectArgs {
-    const float *value;
-    unsigned value_bytes;
-    const float *loc, *attn;   // plain operator inputs (FUSED == false)
-    float *out;
-    FusedArgs fa;              // FUSED == true
-    int S, M, L, Lq;
-    long long nlq;             // N * Lq
-};
+// (struct DirectArgs: msda_common.h)
 
 template <int LPAIRS, bool FUSED>   // LPAIRS = ceil(L / 2)
 __global__ void __launch_bounds__(kThreads, 4)
@@ -997,6 +978,7 @@ msda_fwd_f32_win(const DirectArgs da, const LevelTable lt, const WinGeom wg)
 // ---------------------------------------------------------------------------------------------
 // forward, encoder shape, fp32, D == 32, P == 4, L <= 4: LDS windows, 4 lanes per pair (DPP quads)
 // ---------------------------------------------------------------------------------------------
+#include "msda_quad_dev.h"
 #include "msda_fwd_quad.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -2197,6 +2179,9 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                 da.L = L;
                 da.Lq = Lq;
                 da.nlq = (long long)N * Lq;
+                if (is_aligned(loc, 8) && shapes_dev == nullptr && tiled_mode() == 2 &&
+                    launch_pquad(false, da, lt, N, D, P, stream, &e))
+                    return record_hip(e);
                 if (is_aligned(loc, 8) && shapes_dev == nullptr && launch_quad(false, da, lt, N, D, P, stream, &e))
                     return record_hip(e);
                 if (is_aligned(loc, 8) && shapes_dev == nullptr && launch_win(false, da, lt, N, D, P, stream, &e))
@@ -2259,6 +2244,8 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
         da.Lq = Lq;
         da.nlq = (long long)N * Lq;
         hipError_t de;
+        if (tiled_mode() == 2 && launch_pquad(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
+            return record_hip(de);
         if (launch_quad(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
             return record_hip(de);
         if (launch_win(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
@@ -2386,6 +2373,7 @@ int tf_msda_set_tiled(int mode)
 void tf_msda_debug_trace_buffer(void *device_buffer)
 {
     g_quad_trace.store(static_cast<unsigned long long *>(device_buffer));
+    pquad_set_trace(static_cast<unsigned long long *>(device_buffer));
 }
 
 int tf_msda_set_option(const char *name, int value)
@@ -2399,6 +2387,10 @@ int tf_msda_set_option(const char *name, int value)
             g_quad_epoch.fetch_add(1);
             return prev;
         }
+    if (strncmp(name, "pquad", 5) == 0) {
+        const int prev = pquad_set_option(name, value);
+        return prev == -1 ? INT_MIN : prev;
+    }
     return INT_MIN;
 }
 

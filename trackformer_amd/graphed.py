@@ -2,24 +2,44 @@
 
 At batch 1 the per-frame forward is ~900 small-to-medium kernels (53 convolutions, 12 attention
 layers of ~15 launches each, heads); launched eagerly from Python the host cannot feed an MI355X
-fast enough.  `GraphedDetector` captures `model(img, [track queries], None)` once per
-(image shape, number of track queries) into a HIP graph with static input/output buffers and replays
-it for every later frame of that shape: one graph launch instead of ~900 kernel launches, same kernels,
-same results.
+fast enough.  `GraphedDetector` captures `model(img, [track queries], prev_features)` once per
+(image shape, number of track queries, previous frame present) into a HIP graph with static
+input / output buffers and replays it for every later frame of that shape: one graph launch instead of
+~900 kernel launches, same kernels, same results.
 
 It is a drop-in for the `obj_detector` argument of Tracker: attribute access (num_queries,
 overflow_boxes, parameters(), ...) is forwarded to the wrapped model.  Calls it cannot replay --
-multi-frame attention (prev_features are per-frame inputs), training mode, gradients enabled -- run
-the wrapped model eagerly.
+training mode, gradients enabled, host images, batches -- run the wrapped model eagerly.
+
+Multi-frame attention (cfgs/train_multi_frame.yaml; deformable_detr.py:161-221): the previous
+frame's backbone features are an INPUT of the forward.  They live in static buffers owned by the graph
+entry; the captured graph ends with a copy of the new frame's features into those buffers, and the
+buffers are what the call returns as `features` -- so the tracker hands them back on the next frame
+and no copy is needed then (a caller that passes anything else gets a copy-in before the replay).
+
+Aliasing contract: `out['pred_logits' | 'pred_boxes' | 'hs_embed']` are cloned (the tracker keeps them
+across frames); `features` (see above), `memory`, `hs` and `out['aux_outputs']` alias static buffers of
+the entry and are valid until the next call with the same key.
+
+Threads: bench.py and INTEGRATION.md run one tracker thread (own HIP stream) per sequence against one
+shared model.  Captures are serialised by a process-wide lock and run in `thread_local` capture mode
+with a private memory pool, so other threads may keep replaying / running eagerly meanwhile.  The
+number of live graphs per wrapper is bounded (`max_graphs`, least-recently-used eviction): in real
+tracking the number of track queries changes from frame to frame, every new count is a new key.
 """
+import threading
+from collections import OrderedDict
+
 import torch
+
+_CAPTURE_LOCK = threading.Lock()
 
 
 class GraphedDetector:
-    def __init__(self, model, max_graphs=8):
+    def __init__(self, model, max_graphs=16):
         self.model = model
         self.max_graphs = max_graphs
-        self._graphs = {}
+        self._graphs = OrderedDict()
         self._seen = {}
 
     def __getattr__(self, name):  # only called for attributes GraphedDetector itself lacks
@@ -30,16 +50,23 @@ class GraphedDetector:
         m = self.model
         if torch.is_grad_enabled() or m.training or not getattr(m, "_tracking", True):
             return False
-        if getattr(m, "multi_frame_attention", False):
-            return False
-        if not torch.is_tensor(img) or not img.is_cuda or img.dim() != 4:
+        if not torch.is_tensor(img) or not img.is_cuda or img.dim() != 4 or img.shape[0] != 1:
             return False
         if target is not None and (len(target) != 1
                                    or 'track_query_hs_embeds' not in target[0]):
             return False
-        return True
+        return True   # prev_features: fed through static buffers (multi-frame models), ignored by the others
 
-    def _capture(self, img, target):
+    def _multi_frame(self):
+        return bool(getattr(self.model, "multi_frame_attention", False))
+
+    @staticmethod
+    def _clone_features(features):
+        from .nested import NestedTensor
+        return [NestedTensor(f.tensors.clone(), None if f.mask is None else f.mask.clone())
+                for f in features]
+
+    def _capture(self, img, target, prev_features):
         entry = {"img": img.clone()}
         static_target = None
         if target is not None:
@@ -49,39 +76,74 @@ class GraphedDetector:
                               'track_query_hs_embeds': entry["hs"],
                               'image_id': target[0].get('image_id')}]
         entry["target"] = static_target
-        # warm-up on a side stream (fills every host-side cache: folded conv weights, position
-        # encodings, geometry tensors), then capture
-        side = torch.cuda.Stream(img.device)
-        side.wait_stream(torch.cuda.current_stream(img.device))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self.model(entry["img"], static_target, None)
-        torch.cuda.current_stream(img.device).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            entry["out"] = self.model(entry["img"], static_target, None)
+        multi = self._multi_frame()
+        entry["prev"] = None
+        if multi and prev_features is not None:
+            entry["prev"] = self._clone_features(prev_features)
+        dev = img.device
+        with _CAPTURE_LOCK:
+            # warm-up on a side stream (fills every host-side cache: folded conv weights, position
+            # encodings, geometry tensors), then capture
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    warm = self.model(entry["img"], static_target, entry["prev"])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            if multi and entry["prev"] is None:
+                # first frame of a sequence: the model attends to the current frame twice; the buffers the
+                # NEXT frame will read its previous features from are created here
+                entry["prev_out"] = self._clone_features(warm[2])
+            del warm
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = self.model(entry["img"], static_target, entry["prev"])
+                if multi:
+                    dst = entry["prev"] if entry["prev"] is not None else entry["prev_out"]
+                    for d, s in zip(dst, out[2]):
+                        d.tensors.copy_(s.tensors)
+                        if d.mask is not None and s.mask is not None:
+                            d.mask.copy_(s.mask)
+                    out = (out[0], out[1], dst, out[3], out[4])
+                entry["out"] = out
         entry["graph"] = graph
         return entry
+
+    def _feed_prev(self, entry, prev_features):
+        """Copy-in of the previous frame's features unless they ARE the entry's static buffers."""
+        for d, s in zip(entry["prev"], prev_features):
+            if d.tensors.data_ptr() != s.tensors.data_ptr():
+                d.tensors.copy_(s.tensors, non_blocking=True)
+                if d.mask is not None and s.mask is not None:
+                    d.mask.copy_(s.mask, non_blocking=True)
 
     def __call__(self, img, target=None, prev_features=None):
         if not self._capturable(img, target, prev_features):
             return self.model(img, target, prev_features)
+        multi = self._multi_frame()
         n_track = 0 if target is None else int(target[0]['track_query_hs_embeds'].shape[0])
-        key = (tuple(img.shape), n_track, img.device)
+        key = (tuple(img.shape), n_track, img.device, bool(multi and prev_features is not None))
         entry = self._graphs.get(key)
         if entry is None:
             # capture a shape the second time it shows up (one-off shapes are not worth a graph)
             self._seen[key] = self._seen.get(key, 0) + 1
-            if self._seen[key] < 2 or len(self._graphs) >= self.max_graphs:
+            if self._seen[key] < 2:
                 return self.model(img, target, prev_features)
-            entry = self._graphs[key] = self._capture(img, target)
+            entry = self._capture(img, target, prev_features)
+            self._graphs[key] = entry
+            while len(self._graphs) > self.max_graphs:
+                self._graphs.popitem(last=False)   # least recently used
+        else:
+            self._graphs.move_to_end(key)
         entry["img"].copy_(img, non_blocking=True)
         if target is not None:
             entry["boxes"].copy_(target[0]['track_query_boxes'], non_blocking=True)
             entry["hs"].copy_(target[0]['track_query_hs_embeds'], non_blocking=True)
+        if entry["prev"] is not None:
+            self._feed_prev(entry, prev_features)
         entry["graph"].replay()
         out, tgt, features, memory, hs = entry["out"]
-        # everything the caller keeps across frames must not alias the static buffers
+        # what the tracker keeps across frames must not alias the static buffers (see the module docstring)
         out = dict(out)
         out['hs_embed'] = out['hs_embed'].clone()
         out['pred_logits'] = out['pred_logits'].clone()
