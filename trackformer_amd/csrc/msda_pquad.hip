@@ -551,7 +551,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
             if (ps * PAIRS >= cur.nq) return;            // uniform
             const int H = Hs[l], W = Ws[l];
             const float Wf = (float)W, Hf = (float)H;
-            const float xr = __builtin_fmaf(cur.sx[ps][l], Wf, -0.5f);   // cuh:227-228, single rounding
+            const float xr = __builtin_fmaf(cur.sx[ps][l], Wf, -0.5f);   // cuh:227-228 with one rounding (see make_tap, msda_hip.hip)
             const float yr = __builtin_fmaf(cur.sy[ps][l], Hf, -0.5f);
             const bool in = cur.live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
             const float x = in ? xr : 0.f, y = in ? yr : 0.f;

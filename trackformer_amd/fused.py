@@ -10,8 +10,14 @@ import torch.nn.functional as F
 from . import _cabi
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _param_ok(t, x):
+    """A parameter tensor the kernels can read next to `x`: same device, fp32, contiguous, 16-byte aligned."""
+    return (t.device == x.device and t.dtype == torch.float32 and t.is_contiguous()
+            and t.data_ptr() % 16 == 0)
 
 
 def bias_act_(x, bias, residual=None, relu=True):
@@ -21,14 +27,16 @@ def bias_act_(x, bias, residual=None, relu=True):
             and x.is_contiguous(memory_format=torch.channels_last)):
         return None
     C = x.shape[1]
-    if C % 4 or bias.dtype != torch.float32 or not bias.is_contiguous():
+    if C % 4 or not _param_ok(bias, x) or x.data_ptr() % 16:
         return None
     if residual is not None and not (residual.shape == x.shape and residual.dtype == x.dtype
+                                     and residual.device == x.device and residual.data_ptr() % 16 == 0
                                      and residual.is_contiguous(memory_format=torch.channels_last)):
         return None
-    rc = _cabi.lib().tf_bias_act_f32(x.data_ptr(), bias.data_ptr(),
-                                     0 if residual is None else residual.data_ptr(), x.numel(), C,
-                                     1 if relu else 0, _stream())
+    with torch.cuda.device(x.device):   # the launch goes to x's device and its current stream
+        rc = _cabi.lib().tf_bias_act_f32(x.data_ptr(), bias.data_ptr(),
+                                         0 if residual is None else residual.data_ptr(), x.numel(), C,
+                                         1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_bias_act_f32")
     return x
 
@@ -40,17 +48,22 @@ def add_layernorm(x, res, norm):
             and norm.elementwise_affine and len(norm.normalized_shape) == 1):
         return None
     C = norm.normalized_shape[0]
-    if x.shape[-1] != C or C % 4 or C > 4096:
+    if x.shape[-1] != C or C % 4 or C > 4096 or x.data_ptr() % 16:
+        return None
+    if not (_param_ok(norm.weight, x) and _param_ok(norm.bias, x)):
         return None
     if res is not None:
-        if res.shape != x.shape or res.dtype != x.dtype:
+        if res.shape != x.shape or res.dtype != x.dtype or res.device != x.device:
             return None
         res = res.contiguous()
-    out = torch.empty_like(x)
-    rc = _cabi.lib().tf_add_layernorm_f32(x.data_ptr(), 0 if res is None else res.data_ptr(),
-                                          norm.weight.data_ptr(), norm.bias.data_ptr(),
-                                          out.data_ptr(), x.numel() // C, C, float(norm.eps),
-                                          _stream())
+        if res.data_ptr() % 16:
+            return None
+    with torch.cuda.device(x.device):
+        out = torch.empty_like(x)
+        rc = _cabi.lib().tf_add_layernorm_f32(x.data_ptr(), 0 if res is None else res.data_ptr(),
+                                              norm.weight.data_ptr(), norm.bias.data_ptr(),
+                                              out.data_ptr(), x.numel() // C, C, float(norm.eps),
+                                              _stream(x.device))
     _cabi.check(rc, "tf_add_layernorm_f32")
     return out
 
@@ -65,10 +78,12 @@ def residual_norm(x, res, norm, inference):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# nn.Linear as a bf16 split product on the matrix cores (include/tf_fused.h: tf_linear_split_f32).  OPT-IN:
-# TF_SPLIT_LINEAR=1 or set_split_linear(True); measured faster than the tuned fp32 library GEMMs at the encoder
-# shapes and inside the parity bar on the reference goldens, default off until the end-to-end numbers are in.
-_split_linear = os.environ.get("TF_SPLIT_LINEAR", "0") not in ("", "0")
+# nn.Linear as a bf16 split product on the matrix cores (include/tf_fused.h: tf_linear_split_f32).  ON by default
+# in the GPU inference path (TF_SPLIT_LINEAR=0 / set_split_linear(False): the fp32 library GEMMs): faster than the
+# tuned hipBLASLt selections at the encoder shapes, 172.3 -> 173.2 frames/s end to end (4 sequences; 128.6 -> 131.3
+# with one), and inside the parity bar at the BASELINE sizes (tests/test_full_size_gpu.py: boxes 1e-6, logits 6e-5,
+# track ids exact).
+_split_linear = os.environ.get("TF_SPLIT_LINEAR", "1") not in ("", "0")
 _split_cache = {}
 
 
@@ -107,7 +122,8 @@ def linear(x, weight, bias=None, relu=False):
     N, K = weight.shape
     if x.shape[-1] != K or K % 32 or x.numel() == 0:
         return None
-    if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N):
+    if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
+                                 and bias.device == x.device):
         return None
     x2 = x.reshape(-1, K)
     if not x2.is_contiguous():
@@ -115,10 +131,11 @@ def linear(x, weight, bias=None, relu=False):
     hi, mid = _split_weight(weight)
     if (x2.data_ptr() | hi.data_ptr() | mid.data_ptr()) & 15:
         return None
-    y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
-    rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(),
-                                         0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0], K, N,
-                                         1 if relu else 0, _stream())
+    with torch.cuda.device(x.device):
+        y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
+        rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(),
+                                             0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0], K, N,
+                                             1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_linear_split_f32")
     return y.view(*x.shape[:-1], N)
 
