@@ -13,6 +13,8 @@
  *
  *   tf_linear_split_f32    nn.Linear (+ ReLU) of the encoder / decoder (ms_deform_attn.py:64-88,
  *                          deformable_transformer.py:282-297) as a bf16 split product on the matrix cores
+ *   tf_mha_core_f32        softmax(q k^T * scale) v of the decoder's query self-attention
+ *                          (deformable_transformer.py:364-383, nn.MultiheadAttention): one launch, fp32
  *
  * Conventions as in tf_msda.h: device pointers, caller-owned buffers, work enqueued on `stream`
  * (hipStream_t as void*), no synchronisation, returns 0 or a negative tf_msda_status.
@@ -51,6 +53,17 @@ int tf_add_layernorm_f32(const float *x, const float *res, const float *gamma, c
  */
 int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
                         int64_t M, int K, int N, int relu, void *stream);
+
+/*
+ * out[n, l, h, :] = sum_j softmax_j(scale * q[n, l, h, :] . k[n, j, h, :]) v[n, j, h, :]      (fp32)
+ * Element (n, l, h, c) of q / k / v / out lives at base + (n * L + l) * ld + h * D + c with ld in floats (so q and
+ * k may be the two halves of one projection output).  key_mask: [N, Lk] bytes, non-zero = the key is ignored
+ * (nn.MultiheadAttention's key_padding_mask), or NULL.  D % 4 == 0, D <= 64, ld % 4 == 0, 16-byte aligned
+ * pointers, Lk up to ~2500 (the 16 x Lk score tile lives in LDS).
+ */
+int tf_mha_core_f32(const float *q, const float *k, const float *v, float *out, const unsigned char *key_mask,
+                    int N, int Lq, int Lk, int H, int D, int ldq, int ldk, int ldv, int ldo, float scale,
+                    void *stream);
 
 #ifdef __cplusplus
 }

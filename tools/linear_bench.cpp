@@ -46,6 +46,7 @@ static float bf16_to_f32(unsigned short h)
 int main(int argc, char **argv)
 {
     const int M = argc > 3 ? atoi(argv[1]) : 22223, K = argc > 3 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 256;
+    if (argc > 4) tf_msda_set_option("linear_variant", atoi(argv[4]));   // block shape / pipelining variant
     if (K % 32) {
         fprintf(stderr, "K must be a multiple of 32\n");
         return 2;
@@ -99,7 +100,7 @@ int main(int argc, char **argv)
             ++checked;
         }
     }
-    printf("tf_linear_split_f32 M=%d K=%d N=%d: checked %lld outputs, max |err| %.3g (max |ref| %.3g), outside 1e-3: %lld\n", M, K, N,
+    printf("tf_linear_split_f32 variant %s M=%d K=%d N=%d: checked %lld outputs, max |err| %.3g (max |ref| %.3g), outside 1e-3: %lld\n", argc > 4 ? argv[4] : "default", M, K, N,
            checked, max_err, max_ref, bad);
     // ---- timing: 20 launches in one graph
     hipGraph_t graph;

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "tf_bias_act_f32",
     "tf_add_layernorm_f32",
     "tf_linear_split_f32",
+    "tf_mha_core_f32",
 )
 
 ABI_VERSION = 1
@@ -83,6 +84,8 @@ def lib():
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_linear_split_f32.restype = ci
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_mha_core_f32.restype = ci
+    L.tf_mha_core_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [ctypes.c_float, vp]
     if L.tf_msda_abi_version() != ABI_VERSION:
         raise RuntimeError("libtf_msda.so ABI version %d != expected %d (rebuild)" %
                            (L.tf_msda_abi_version(), ABI_VERSION))

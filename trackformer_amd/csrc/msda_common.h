@@ -45,6 +45,9 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
 int pquad_set_option(const char *name, int value);   // -1: unknown name, else the previous value
 void pquad_set_trace(unsigned long long *device_buffer);
 
+// linear_split.hip: block shape / pipelining variant of tf_linear_split_f32; returns the previous one
+int linear_set_variant(int v);
+
 }  // namespace tfm
 
 #endif  // TF_MSDA_COMMON_H_

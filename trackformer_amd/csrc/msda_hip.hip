@@ -2402,6 +2402,7 @@ int tf_msda_set_option(const char *name, int value)
             g_quad_epoch.fetch_add(1);
             return prev;
         }
+    if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);
     if (strncmp(name, "pquad", 5) == 0) {
         const int prev = pquad_set_option(name, value);
         return prev == -1 ? INT_MIN : prev;

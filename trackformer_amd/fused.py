@@ -147,3 +147,33 @@ def module_linear(module, x, inference):
         if y is not None:
             return y
     return module(x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def mha_core(qk, v, num_heads, key_padding_mask=None):
+    """softmax(q k^T / sqrt(d)) v for the decoder's query self-attention (include/tf_fused.h: tf_mha_core_f32).
+    qk [N, L, 2E]: the shared q | k projection of one GEMM; v [N, L, E]; key_padding_mask [N, L] bool (True = ignore)
+    or None.  Returns [N, L, E], or None when the kernel does not apply (the caller keeps torch's SDPA)."""
+    if not (qk.is_cuda and qk.dtype == torch.float32 and v.dtype == torch.float32 and v.device == qk.device
+            and qk.dim() == 3 and v.dim() == 3 and qk.is_contiguous() and v.is_contiguous()):
+        return None
+    n, length, e2 = qk.shape
+    e = e2 // 2
+    if e2 != 2 * e or v.shape != (n, length, e) or e % num_heads:
+        return None
+    d = e // num_heads
+    if d % 4 or d > 64 or e % 4 or length > 2400 or (qk.data_ptr() | v.data_ptr()) & 15 or (e * 4) % 16:
+        return None
+    mask_ptr = 0
+    if key_padding_mask is not None:
+        if key_padding_mask.shape != (n, length) or key_padding_mask.device != qk.device:
+            return None
+        key_padding_mask = key_padding_mask.to(torch.uint8).contiguous()
+        mask_ptr = key_padding_mask.data_ptr()
+    with torch.cuda.device(qk.device):
+        out = torch.empty((n, length, e), dtype=torch.float32, device=qk.device)
+        q_ptr = qk.data_ptr()
+        rc = _cabi.lib().tf_mha_core_f32(q_ptr, q_ptr + e * 4, v.data_ptr(), out.data_ptr(), mask_ptr, n, length, length,
+                                         num_heads, d, e2, e2, e, e, float(d) ** -0.5, _stream(qk.device))
+    _cabi.check(rc, "tf_mha_core_f32")
+    return out
