@@ -371,6 +371,17 @@ def test_module_forward_matches_oracle_composition(dev):
         assert torch.allclose(out.cpu(), exp, atol=2e-4, rtol=1e-3)
 
 
+@pytest.fixture(autouse=True)
+def _fp32_linears():
+    """This module tests the MSDeformAttn kernels and their fused prologue against fp32 compositions: the
+    split-product linears (default on in the inference path, tested in test_linear_split_gpu.py and
+    test_full_size_gpu.py) are switched off so that the projections are the same fp32 GEMMs on both sides."""
+    from trackformer_amd import fused
+    prev = fused.set_split_linear(False)
+    yield
+    fused.set_split_linear(prev)
+
+
 # ------------------------------------------------------------------ tiled / LDS-staged encoder kernel
 @pytest.fixture(params=[1, 2, 3], ids=["win", "quad", "pquad"])
 def tiled(dev, request):

@@ -64,7 +64,8 @@ constexpr int kML = TF_MSDA_MAX_LEVELS;
 constexpr int kPqOffQ = 3 * kML;
 constexpr int kPqOffNom = kPqOffQ + 2 * 4 * kML;
 constexpr int kPqOffBb = kPqOffNom + 2 * 4 * kML;
-constexpr int kPqHdrBytes = 1792;   // >= (kPqOffBb + 128) * 4 = 1728, multiple of 128
+constexpr int kPqOffGeo = kPqOffBb + 128;   // window table [2 parities][4 levels][8 ints]
+constexpr int kPqHdrBytes = 2048;   // >= (kPqOffGeo + 64) * 4 = 1984, multiple of 128
 
 struct PquadGeom {
     int TH, TW;        // tile size in level-0 pixels
@@ -136,6 +137,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
     int *s_q = s_tab + kPqOffQ;       // [parity][ya | yb | xa | xb][level]
     int *s_nom = s_tab + kPqOffNom;   // [parity][ny0 | ny1 | nx0 | nx1][level]
     int *s_bb = s_tab + kPqOffBb;     // [parity][wave][level][min x0, max x0, min y0, max y0]: no LDS atomics
+    int *s_geo = s_tab + kPqOffGeo;   // [parity][level][wx0, wy0, ww, wh, limx, limy, fits on its own, -]
     unsigned char *s_rows = smem + kPqHdrBytes;   // rows 0, 1: zeros; the windows start at row 2
 
     const int L = da.L, M = da.M, S = da.S, LP = L * PT;
@@ -213,6 +215,13 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         Hs[l] = __builtin_amdgcn_readfirstlane(s_tab[lc]);
         Ws[l] = __builtin_amdgcn_readfirstlane(s_tab[kML + lc]);
         starts[l] = __builtin_amdgcn_readfirstlane(s_tab[2 * kML + lc]);
+    }
+
+    float inv_h[NL], inv_w[NL];   // uniform
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        inv_h[l] = __builtin_amdgcn_rcpf((float)Hs[l]);
+        inv_w[l] = __builtin_amdgcn_rcpf((float)Ws[l]);
     }
 
     // ---- decode the queries of a tile and issue the loads of its sampling points ---------------------------
@@ -346,11 +355,14 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                 }
                 sum += dpp_f<kDppQuadXor1>(sum);
                 sum += dpp_f<kDppQuadXor2>(sum);
+                // reciprocals (v_rcp_f32, 1 ulp) instead of 12 IEEE divisions per pass (~10 instructions each): the
+                // normalised weights / locations move by <= 1 ulp, far below what the exp already differs by
+                const float inv_sum = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
-                    p.sa[ps][l] = p.sa[ps][l] / sum;
-                    p.sx[ps][l] = r.rx[ps][l] + p.sx[ps][l] / (float)Hs[l];   // x / H_l (as the reference writes it)
-                    p.sy[ps][l] = r.ry[ps][l] + p.sy[ps][l] / (float)Ws[l];   // y / W_l
+                    p.sa[ps][l] = p.sa[ps][l] * inv_sum;
+                    p.sx[ps][l] = r.rx[ps][l] + p.sx[ps][l] * inv_h[l];   // x / H_l (as the reference writes it)
+                    p.sy[ps][l] = r.ry[ps][l] + p.sy[ps][l] * inv_w[l];   // y / W_l
                 }
             }
         }
@@ -449,6 +461,45 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 
         __syncthreads();   // B0: the tile's bounding boxes are filed, its tables visible
         if (iter == 0) stamp(3);
+        // window geometry: wave l works out level l's window (bounding box over the four waves' boxes, clamped to the
+        // nominal footprint) and files it; every wave then only reads the table -- computing all four windows in
+        // every wave cost ~240 vector instructions per wave and tile
+        if (wave < NL) {
+            const int l = wave;
+            int *ge = s_geo + (par * 4 + l) * 8;
+            QuadWindow w;
+            w.wx0 = kQuadFar;
+            w.wy0 = kQuadFar;
+            w.ww = w.wh = w.limx = w.limy = 0;
+            bool fits = false;
+            if (l < L && ((TA_MASK >> l) & 1) == 0) {
+                const int *bb = s_bb + par * 64 + 4 * l;   // + 16 * wave
+                const int *nm4 = s_nom + par * 4 * kML;
+                int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
+#pragma unroll
+                for (int ww = 0; ww < kPqThreads / 64; ++ww) {
+                    bx0 = min(bx0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 0]));
+                    bx1 = max(bx1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 1]));
+                    by0 = min(by0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 2]));
+                    by1 = max(by1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 3]));
+                }
+                const int ny0 = __builtin_amdgcn_readfirstlane(nm4[l]);
+                const int ny1 = __builtin_amdgcn_readfirstlane(nm4[kML + l]);
+                const int nx0 = __builtin_amdgcn_readfirstlane(nm4[2 * kML + l]);
+                const int nx1 = __builtin_amdgcn_readfirstlane(nm4[3 * kML + l]);
+                w = tfq_window(bx0, bx1, by0, by1, nx0, nx1, ny0, ny1, pg.cap_rows, 2, &fits);
+            }
+            if (lane == 0) {
+                ge[0] = w.wx0;
+                ge[1] = w.wy0;
+                ge[2] = w.ww;
+                ge[3] = w.wh;
+                ge[4] = w.limx;
+                ge[5] = w.limy;
+                ge[6] = fits ? 1 : 0;
+            }
+        }
+        __syncthreads();   // B0': the window table is visible
 
         // window geometry (wave-uniform, scalar registers) of the current tile
         const unsigned head_base = (unsigned)((((long long)cur.b * S * M + cur.m) * D) * 4);
@@ -473,29 +524,17 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
             if constexpr (((TA_MASK >> l) & 1) == 0 && ((RMASK >> l) & 1) != 0) {
                 if (l < L) {
                     const int H = Hs[l], W = Ws[l];
-                    const int *bb = s_bb + par * 64 + 4 * l;   // + 16 * wave
-                    const int *nm4 = s_nom + par * 4 * kML;
-                    int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
-#pragma unroll
-                    for (int w = 0; w < kPqThreads / 64; ++w) {
-                        bx0 = min(bx0, __builtin_amdgcn_readfirstlane(bb[16 * w + 0]));
-                        bx1 = max(bx1, __builtin_amdgcn_readfirstlane(bb[16 * w + 1]));
-                        by0 = min(by0, __builtin_amdgcn_readfirstlane(bb[16 * w + 2]));
-                        by1 = max(by1, __builtin_amdgcn_readfirstlane(bb[16 * w + 3]));
-                    }
-                    const int ny0 = __builtin_amdgcn_readfirstlane(nm4[l]);
-                    const int ny1 = __builtin_amdgcn_readfirstlane(nm4[kML + l]);
-                    const int nx0 = __builtin_amdgcn_readfirstlane(nm4[2 * kML + l]);
-                    const int nx1 = __builtin_amdgcn_readfirstlane(nm4[3 * kML + l]);
-                    bool fits;
-                    const QuadWindow w = tfq_window(bx0, bx1, by0, by1, nx0, nx1, ny0, ny1, pg.cap_rows - used, 2 + used, &fits);
+                    const int *ge = s_geo + (par * 4 + l) * 8;   // this level's window, computed by wave l after B0
+                    const int ww = __builtin_amdgcn_readfirstlane(ge[2]), wh = __builtin_amdgcn_readfirstlane(ge[3]);
+                    const bool fits = __builtin_amdgcn_readfirstlane(ge[6]) != 0 && wh * ww <= pg.cap_rows - used;
                     by_loads[l] = !fits;
-                    const int ww = w.ww, wh = w.wh, wx0 = w.wx0, wy0 = w.wy0;
+                    if (!fits) return;   // all or nothing (msda_quad_geom.h): the level goes by buffer loads
+                    const int wx0 = __builtin_amdgcn_readfirstlane(ge[0]), wy0 = __builtin_amdgcn_readfirstlane(ge[1]);
                     const int roff = 2 + used;
                     gwx0[l] = wx0;
                     gwy0[l] = wy0;
-                    glimx[l] = w.limx;
-                    glimy[l] = w.limy;
+                    glimx[l] = __builtin_amdgcn_readfirstlane(ge[4]);
+                    glimy[l] = __builtin_amdgcn_readfirstlane(ge[5]);
                     gww[l] = ww;
                     groff[l] = roff;
                     const int nrows = wh * ww;

@@ -376,11 +376,15 @@ class DeformableTransformerDecoderLayer(nn.Module):
         E, H = mha.embed_dim, mha.num_heads
         w, b = mha.in_proj_weight, mha.in_proj_bias
         n, lq, _ = qk_in.shape
-        qk = F.linear(qk_in, w[:2 * E], b[:2 * E])
-        v = F.linear(v_in, w[2 * E:], b[2 * E:])
+        qk = fused.linear(qk_in, w[:2 * E], b[:2 * E])       # split product on the matrix cores when enabled
+        if qk is None:
+            qk = F.linear(qk_in, w[:2 * E], b[:2 * E])
+        v = fused.linear(v_in, w[2 * E:], b[2 * E:])
+        if v is None:
+            v = F.linear(v_in, w[2 * E:], b[2 * E:])
         o = fused.mha_core(qk, v, H, key_padding_mask)      # one fp32 launch: scores, softmax, P V
         if o is not None:
-            return mha.out_proj(o)
+            return fused.module_linear(mha.out_proj, o, True)
         qk = qk.view(n, lq, 2, H, E // H)
         v = v.view(n, lq, H, E // H)
         q, k = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)      # [n, H, lq, d]
