@@ -151,6 +151,11 @@ def init_distributed(args):
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if world > 1:
+        if os.environ.get("TF_BENCH_ONE_DEVICE") == "1":
+            # debugging aid for boxes with a single GPU: every rank uses cuda:0, the barriers go over gloo.
+            # Exercises the launcher / rank-0 reporting path; the numbers it prints mean nothing.
+            du.init_from_env(backend="gloo")
+            return rank, 0, world
         torch.cuda.set_device(local_rank)
         du.init_from_env(backend="nccl", device=torch.device("cuda", local_rank))  # nccl == RCCL
     return rank, local_rank, world
@@ -414,6 +419,11 @@ def measure_cpu_baseline(cfg, frames):
     return line
 
 
+def _reduce_device(device):
+    import torch.distributed as dist
+    return "cpu" if dist.is_initialized() and dist.get_backend() == "gloo" else device
+
+
 def timed_repeats(run_set, steps, world, device, min_seconds):
     """EXACTLY `steps` steps per repetition, each bracketed by barrier + synchronize; repeated until
     `min_seconds` of timed work; per-repetition time = max over ranks."""
@@ -426,7 +436,7 @@ def timed_repeats(run_set, steps, world, device, min_seconds):
         run_set(steps)
         torch.cuda.synchronize()
         du.barrier()
-        total += du.max_over_ranks(time.perf_counter() - t0, device)
+        total += du.max_over_ranks(time.perf_counter() - t0, _reduce_device(device))
         reps += 1
         if total >= min_seconds or reps >= 200:
             return total, reps

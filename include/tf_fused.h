@@ -58,8 +58,8 @@ int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, con
  * out[n, l, h, :] = sum_j softmax_j(scale * q[n, l, h, :] . k[n, j, h, :]) v[n, j, h, :]      (fp32)
  * Element (n, l, h, c) of q / k / v / out lives at base + (n * L + l) * ld + h * D + c with ld in floats (so q and
  * k may be the two halves of one projection output).  key_mask: [N, Lk] bytes, non-zero = the key is ignored
- * (nn.MultiheadAttention's key_padding_mask), or NULL.  D % 4 == 0, D <= 64, ld % 4 == 0, 16-byte aligned
- * pointers, Lk up to ~2500 (the 16 x Lk score tile lives in LDS).
+ * (nn.MultiheadAttention's key_padding_mask), or NULL.  D in {16, 32, 36, 64}, ld % 4 == 0, 16-byte aligned
+ * pointers, Lk up to ~2400 (the 16 x Lk score tile lives in LDS).
  */
 int tf_mha_core_f32(const float *q, const float *k, const float *v, float *out, const unsigned char *key_mask,
                     int N, int Lq, int Lk, int H, int D, int ldq, int ldk, int ldv, int ldo, float scale,

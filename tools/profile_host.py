@@ -15,9 +15,12 @@ from trackformer_amd import runtime  # noqa: E402
 
 runtime.configure_inference()
 dev = torch.device("cuda:0")
-tracker, model = bench.build_tracker(dev, use_graph=True)
-seeder = bench.TrackSeeder(dev, model.hidden_dim)
-frames = bench.make_frames(dev)
+cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+model, criterion, post, margs = bench.build_model(cfg, dev)
+model.tracking()
+tracker = bench.build_tracker(model, post, use_graph=True)
+seeder = bench.TrackSeeder(dev, margs.hidden_dim, cfg["tracks"], cfg["size"])
+frames = bench.make_frames(dev, cfg["size"])
 
 
 def step(i):
@@ -29,17 +32,22 @@ with torch.no_grad():
     for i in range(6):
         step(i)
     torch.cuda.synchronize()
-    # wall-clock split: time until the packed D2H returns vs the rest
     t0 = time.perf_counter()
-    for i in range(20):
+    for i in range(40):
         step(i)
     torch.cuda.synchronize()
-    print("ms/step", (time.perf_counter() - t0) / 20 * 1e3)
+    print("ms/step", (time.perf_counter() - t0) / 40 * 1e3)
+    # how long the GPU part alone takes: replay-only loop of the detector
+    img = frames[0]['img']
+    t0 = time.perf_counter()
+    for i in range(40):
+        seeder.seed(tracker)
+    print("ms/seed (bench artefact: 100 Track objects rebuilt per step)", (time.perf_counter() - t0) / 40 * 1e3)
     pr = cProfile.Profile()
     pr.enable()
-    for i in range(20):
+    for i in range(40):
         step(i)
     torch.cuda.synchronize()
     pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(22)
+st.sort_stats("tottime").print_stats(30)

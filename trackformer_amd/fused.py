@@ -162,7 +162,7 @@ def mha_core(qk, v, num_heads, key_padding_mask=None):
     if e2 != 2 * e or v.shape != (n, length, e) or e % num_heads:
         return None
     d = e // num_heads
-    if d % 4 or d > 64 or e % 4 or length > 2400 or (qk.data_ptr() | v.data_ptr()) & 15 or (e * 4) % 16:
+    if d not in (16, 32, 36, 64) or e % 4 or length > 2300 or (qk.data_ptr() | v.data_ptr()) & 15 or (e * 4) % 16:
         return None
     mask_ptr = 0
     if key_padding_mask is not None:
