@@ -168,6 +168,187 @@ split_gemm_kernel(const float *__restrict__ X, const unsigned short *__restrict_
         }
 }
 
+// ---- weight-stationary variant (variant 6; K == 256, many rows; an experiment that was run and measured, see above): the 128 x 256 weight block of a column block stays in LDS for the
+// whole workgroup (hi + mid pieces: 128 KB, 16-byte pieces XOR-swizzled by row & 15 so that the 16 lanes that read 16
+// different rows at one k hit 16 different bank groups; staged once by LDS-DMA), the activations stream from global memory
+// straight into MFMA fragment layout (lane = row, 8 consecutive k: two 16-byte loads), are split in registers and never
+// touch LDS: no barrier in the main loop, every wave walks its own 16-row tiles with the next tile's loads in flight.
+// v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as A and the activation fragment as B: D[n][m], a lane ends up with
+// 4 consecutive n of one row m -> one 16-byte store per tile and lane.
+typedef __attribute__((ext_vector_type(4))) float f32x4w;
+constexpr int WS_K = 256, WS_BN = 128, WS_KS = WS_K / 32, WS_NT = WS_BN / 16;
+constexpr unsigned kWsOob = 0xFFFFFFF0u;
+
+// NSPLIT: the block's 8 column tiles are shared out over NSPLIT groups of 4 waves (NSPLIT = 2: 8 waves, each wave 4 column
+// tiles of every row tile of its group; the activations of a row tile are then loaded by 2 waves, the second time from L1).
+template <bool RELU, int NSPLIT>
+__global__ void __launch_bounds__(NSPLIT * 256)
+split_gemm_ws_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
+                     const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y, int M,
+                     int N, int tiles_per_block, unsigned wbytes)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char s_w[];   // [hi | mid][128 rows][32 pieces of 16 B]
+    constexpr int TENSOR_BYTES = WS_BN * WS_K * 2;   // 65536
+    constexpr int WAVES = 4 * NSPLIT, NTW = WS_NT / NSPLIT;   // column tiles per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wrow = wave & 3, wcol = wave >> 2;   // row-tile lane of the wave, column group
+    const int n0 = blockIdx.x * WS_BN;
+    const int ntiles = (M + 15) >> 4;
+    const int tile0 = blockIdx.y * tiles_per_block;
+    if (tile0 >= ntiles) return;
+
+    const int lrow = lane & 15, kg = lane >> 4;
+    auto load_tile = [&](int tile, f32x4w (&xa)[WS_KS][2]) {
+        const int row = min(tile * 16 + lrow, M - 1);   // rows past M read the last row, never stored
+        const float *base = X + (size_t)row * WS_K + kg * 8;
+#pragma unroll
+        for (int ks = 0; ks < WS_KS; ++ks) {
+            xa[ks][0] = *reinterpret_cast<const f32x4w *>(base + ks * 32);
+            xa[ks][1] = *reinterpret_cast<const f32x4w *>(base + ks * 32 + 4);
+        }
+    };
+    f32x4w xa[WS_KS][2], xn[WS_KS][2];
+    int t = wrow;
+    const bool any = t < tiles_per_block && tile0 + t < ntiles;
+    if (any) load_tile(tile0 + t, xa);   // the first tile's activations travel while the weights are staged
+
+    // ---- stage the weight block: 64 DMA wave-instructions of 1 KB per tensor
+    {
+        const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Whi), 0, wbytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_mid = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Wmid), 0, wbytes, 0x00020000);
+        for (int c = wave; c < TENSOR_BYTES / 1024; c += WAVES) {
+            const int pp = c * 64 + lane;            // physical 16-byte piece of the LDS image
+            const int row = pp >> 5, q = pp & 31;
+            const int logical = q ^ (row & 15);      // which 8 k of the row live there
+            const int grow = n0 + row;
+            const unsigned off = grow < N ? (unsigned)((grow * WS_K + logical * 8) * 2) : kWsOob;   // rows past N: zeros
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_hi, (__attribute__((address_space(3))) void *)(s_w + c * 1024), 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_mid, (__attribute__((address_space(3))) void *)(s_w + TENSOR_BYTES + c * 1024), 16,
+                                                     off, 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+        __syncthreads();
+    }
+
+    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)s_w) +
+                              (unsigned)(wcol * NTW) * 8192u;
+    for (; t < tiles_per_block && tile0 + t < ntiles; t += 4) {
+        const int tile = tile0 + t;
+        const bool has_next = t + 4 < tiles_per_block && tile + 4 < ntiles;
+        if (has_next) load_tile(tile + 4, xn);   // in flight during the MFMAs below
+        f32x4w acc[NTW];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) acc[j] = f32x4w{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < WS_KS; ++ks) {
+            bf16x8 xh, xm;   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[e] = (__bf16)xa[ks][0][e];
+                xm[e] = (__bf16)(xa[ks][0][e] - (float)xh[e]);
+                xh[4 + e] = (__bf16)xa[ks][1][e];
+                xm[4 + e] = (__bf16)(xa[ks][1][e] - (float)xh[4 + e]);
+            }
+            // weight fragments of the wave's column tiles: row j * 16 + lrow, logical piece ks * 4 + kg, swizzled by the row
+            const unsigned a0 = lds_base + (unsigned)(lrow * 32 + ((ks * 4 + kg) ^ lrow)) * 16u;
+            bf16x8 wh[NTW], wm[NTW];
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                wh[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>((size_t)(a0 + j * 8192u));
+                wm[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>((size_t)(a0 + TENSOR_BYTES + j * 8192u));
+            }
+            // three passes over the column tiles: consecutive MFMAs never share an accumulator (smallest terms first)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[j], xh, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xm, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh, acc[j], 0, 0, 0);
+        }
+        // ---- epilogue: D[n][m]: lane holds n = 4 * kg + 0..3 of column m = lrow
+        const int m = tile * 16 + lrow;
+        if (m < M) {
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                const int n = n0 + (wcol * NTW + j) * 16 + kg * 4;
+                if (n < N) {   // N % 4 == 0 (host checked): the four columns exist together
+                    f32x4w v = acc[j];
+                    if (bias != nullptr) v += *reinterpret_cast<const f32x4w *>(bias + n);
+                    if (RELU) {
+                        v.x = fmaxf(v.x, 0.f);
+                        v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f);
+                        v.w = fmaxf(v.w, 0.f);
+                    }
+                    *reinterpret_cast<f32x4w *>(Y + (size_t)m * N + n) = v;
+                }
+            }
+        }
+        if (has_next) {
+#pragma unroll
+            for (int ks = 0; ks < WS_KS; ++ks) {
+                xa[ks][0] = xn[ks][0];
+                xa[ks][1] = xn[ks][1];
+            }
+        }
+    }
+}
+
+int ws_num_cus()
+{
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        return cus;
+    }();
+    return n;
+}
+
+int ws_nsplit()
+{
+    static const int v = [] { const char *e = getenv("TF_LINEAR_WS_SPLIT"); return e ? atoi(e) : 2; }();
+    return v == 1 ? 1 : 2;
+}
+
+// -> TF_MSDA_OK, an error, or 1 when the call does not qualify
+int launch_ws(const float *x, const unsigned short *wh, const unsigned short *wm, const float *bias, float *y, int M, int K, int N,
+              int relu, hipStream_t s)
+{
+    if (K != WS_K || (N & 3) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+        (long long)N * K * 2 >= (1LL << 31))
+        return 1;
+    const int nblk = (N + WS_BN - 1) / WS_BN;
+    const int ntiles = (M + 15) / 16;
+    int mblk = ws_num_cus() / nblk;
+    if (mblk < 1) mblk = 1;
+    if (mblk > ntiles) mblk = ntiles;
+    const int tpb = (ntiles + mblk - 1) / mblk;
+    mblk = (ntiles + tpb - 1) / tpb;
+    const bool eight = ws_nsplit() == 2;
+    const size_t lds = 2 * (size_t)WS_BN * WS_K * 2;
+    const void *fn = relu ? (eight ? (const void *)&split_gemm_ws_kernel<true, 2> : (const void *)&split_gemm_ws_kernel<true, 1>)
+                          : (eight ? (const void *)&split_gemm_ws_kernel<false, 2> : (const void *)&split_gemm_ws_kernel<false, 1>);
+    {
+        static std::atomic<unsigned> raised[4];   // bit per device, per kernel
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const int idx = (relu ? 2 : 0) + (eight ? 1 : 0);
+        if (dev >= 32 || !(raised[idx].load() & (1u << dev))) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+                return TF_MSDA_ERR_LAUNCH;
+            if (dev < 32) raised[idx].fetch_or(1u << dev);
+        }
+    }
+    unsigned wbytes = (unsigned)((long long)N * K * 2);
+    void *argv[] = {(void *)&x, (void *)&wh, (void *)&wm, (void *)&bias, (void *)&y, (void *)&M, (void *)&N, (void *)&tpb, (void *)&wbytes};
+    return hipLaunchKernel(fn, dim3((unsigned)nblk, (unsigned)mblk), dim3(eight ? 512 : 256), argv, lds, s) == hipSuccess
+               ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
 std::atomic<int> g_variant{-1};   // -1: TF_LINEAR_VARIANT or the default
 
 int variant()
@@ -220,10 +401,17 @@ extern "C" int tf_linear_split_f32(const float *x, const void *w_hi, const void 
     if (var < 0) {
         // per-shape choice from profiles/r02_split_gemm_variants.txt (22 223 x {256 -> 256, 256 -> 384, 256 -> 1024,
         // 1024 -> 256}, 400 x 256 -> 256): few rows want many small blocks, a long K a narrow N block
+        // (variant 6, the weight-stationary kernel, measured no faster than variant 2 / 3 at the encoder shapes:
+        //  22.6 vs 21.4 us at 256 -> 256, 73.0 vs 74.5 us at 256 -> 1024 -- selectable, not the default)
         if (M <= 4096) var = 5;
         else if (K >= 512 && N <= 256) var = 4;
         else if (N > 256 && N < 512) var = 3;
         else var = 2;
+    }
+    if (var == 6) {
+        const int rc = launch_ws(x, wh, wm, bias, y, (int)M, K, N, relu, s);
+        if (rc != 1) return rc;
+        var = 2;
     }
     switch (var) {
     case 0: return launch_variant<128, 128, false>(x, wh, wm, bias, y, (int)M, K, N, relu, s);   // round 1
