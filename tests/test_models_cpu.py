@@ -280,3 +280,18 @@ def test_engine_train_step_reproduces_reference_loss_and_updates_weights(oracle_
     z = np.load(os.path.join(GOLDEN, "train_cfg3_small.npz"))
     assert abs(float(loss) - float(z["total"])) < 1e-3 * abs(float(z["total"]))
     assert not torch.equal(before, names['class_embed.0.weight'].detach())
+
+
+def test_mask_postprocess_of_selected_queries_equals_rows_of_the_full_result():
+    """Tracker.step resizes only the masks its surviving tracks reference (tracker._resolve_masks); PostProcessSegm
+    on a subset of the queries must give exactly the rows it gives on all of them (detr_segmentation.py:297-334)."""
+    from trackformer_amd.detr_segmentation import PostProcessSegm
+    g = torch.Generator().manual_seed(0)
+    outputs = {"pred_masks": torch.randn(1, 12, 24, 32, generator=g)}
+    post = PostProcessSegm()
+    sizes, orig = torch.tensor([[90, 120]]), torch.tensor([[180, 250]])
+    full = post([{}], outputs, orig, sizes, return_probs=True)[0]["masks"]
+    keep = torch.zeros(12, dtype=torch.bool)
+    keep[[1, 4, 5, 11]] = True
+    part = post([{}], outputs, orig, sizes, return_probs=True, results_mask=[keep])[0]["masks"]
+    assert part.shape[0] == 4 and torch.equal(part, full[keep])

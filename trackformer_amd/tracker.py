@@ -255,12 +255,14 @@ class Tracker:
         hs_embeds = outputs['hs_embed'][0]
 
         results = self.obj_detector_post['bbox'](outputs, orig_size)
-        if "segm" in self.obj_detector_post:
-            results = self.obj_detector_post['segm'](
-                results, outputs, orig_size, blob["size"].to(device), return_probs=True)
         result = results[0]
-        if 'masks' in result:
-            result['masks'] = result['masks'].squeeze(dim=1)
+        if "segm" in self.obj_detector_post:
+            # The reference resizes the masks of ALL queries to the original image size here (tracker.py:315-319:
+            # 400 x 800 x 1333 floats per frame) and then keeps those of the surviving tracks.  A query's mask
+            # depends on nothing but that query, and no decision below looks at a mask, so the tracks get
+            # references (_MaskRef: the query's row) and only the referenced rows are resized, once, at the end of
+            # the step (_resolve_masks) -- same values, a fraction of the work.
+            result['masks'] = _MaskRows(len(result['scores']))
 
         boxes_dev = result['boxes']
         if not self.obj_detector.overflow_boxes:
@@ -384,6 +386,8 @@ class Tracker:
             self.tracks = [t for t in self.tracks if t not in remove_tracks]
 
         # ---------------------------------------------------------------- results
+        if 'masks' in result:
+            self._resolve_masks(outputs, results, orig_size, blob["size"].to(device))
         if 'masks' in result and self.tracks:
             probs = torch.stack([t.mask for t in self.tracks])
             index_map = torch.arange(probs.size(0), device=probs.device)[:, None, None]
@@ -412,9 +416,56 @@ class Tracker:
         if self.reid_sim_only:
             self.tracks_to_inactive(self.tracks)
 
+    def _resolve_masks(self, outputs, results, orig_size, size):
+        """Turn the _MaskRef placeholders of this frame into mask probabilities at the original image size:
+        PostProcessSegm (detr_segmentation.py:297-334 of the reference) on exactly the referenced queries."""
+        refs = sorted({t.mask.row for t in self.tracks if isinstance(t.mask, _MaskRef)})
+        if refs:
+            n = outputs['pred_masks'].shape[1]
+            keep = torch.zeros(n, dtype=torch.bool)
+            keep[refs] = True
+            keep = keep.to(outputs['pred_masks'].device)
+            seg = self.obj_detector_post['segm']([{}], outputs, orig_size, size, return_probs=True,
+                                                 results_mask=[keep])[0]['masks'].squeeze(dim=1)
+            by_row = {row: seg[k] for k, row in enumerate(refs)}
+            for t in self.tracks:
+                if isinstance(t.mask, _MaskRef):
+                    t.mask = by_row[t.mask.row]
+        for t in self.inactive_tracks:      # references of tracks that left the active set are never read
+            if isinstance(t.mask, _MaskRef):
+                t.mask = None
+
     def get_results(self):
         """{track_id: {frame_idx: {'bbox': xyxy px, 'score', 'obj_ind', ['mask'], ['attention_map']}}}"""
         return self.results
+
+
+class _MaskRef:
+    """Placeholder for "the mask of query row `row` of the current frame" (see Tracker.step)."""
+    __slots__ = ("row",)
+
+    def __init__(self, row):
+        self.row = int(row)
+
+
+class _MaskRows:
+    """Stands in for the [Q, H, W] mask tensor of a frame: indexing yields _MaskRef placeholders, with the
+    slicing / index-tensor forms Tracker.step uses on the real tensor."""
+
+    def __init__(self, n, rows=None):
+        self.rows = list(range(n)) if rows is None else rows
+
+    def __len__(self):
+        return len(self.rows)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return _MaskRows(0, self.rows[idx])
+        if torch.is_tensor(idx):
+            if idx.dim() == 0:
+                return _MaskRef(self.rows[int(idx)])
+            return [_MaskRef(self.rows[i]) for i in idx.reshape(-1).tolist()]
+        return _MaskRef(self.rows[int(idx)])
 
 
 class Track(object):
