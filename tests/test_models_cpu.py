@@ -294,4 +294,5 @@ def test_mask_postprocess_of_selected_queries_equals_rows_of_the_full_result():
     keep = torch.zeros(12, dtype=torch.bool)
     keep[[1, 4, 5, 11]] = True
     part = post([{}], outputs, orig, sizes, return_probs=True, results_mask=[keep])[0]["masks"]
-    assert part.shape[0] == 4 and torch.equal(part, full[keep])
+    # (the bilinear resize of a 4-channel and a 12-channel tensor may round differently in the last bit)
+    assert part.shape[0] == 4 and torch.allclose(part, full[keep], atol=1e-6, rtol=0)
