@@ -65,3 +65,18 @@ def test_plain_bf16_linears_do_not(oracle_op, monkeypatch):
     model, out, res, feats = shared.run_case(case, device="cpu")
     with pytest.raises(AssertionError):   # one bf16 pass: boxes off by ~2e-4, ten times the tolerance above
         shared.compare_to_golden(case, model, out, res, feats, box_tol=2e-5, logit_tol=1e-4)
+
+
+def test_split_pieces_are_cached_on_the_tensor_not_by_address():
+    """Two different weights that happen to live at the same address one after the other (the caching allocator hands a
+    freed parameter's memory to the next model) must not share split pieces."""
+    import torch
+    from trackformer_amd import fused
+    a = torch.randn(8, 32)
+    hi_a = fused._split_weight(a)[0].clone()
+    b = torch.empty(0)
+    b.set_(a.untyped_storage(), 0, a.shape, a.stride())     # a second tensor object over the same memory
+    with torch.no_grad():
+        a.mul_(0).add_(torch.randn(8, 32))                  # new values at the old address
+    hi_b = fused._split_weight(b)[0]
+    assert torch.equal(hi_b, b.to(torch.bfloat16)) and not torch.equal(hi_b, hi_a)

@@ -376,10 +376,10 @@ class DeformableTransformerDecoderLayer(nn.Module):
         E, H = mha.embed_dim, mha.num_heads
         w, b = mha.in_proj_weight, mha.in_proj_bias
         n, lq, _ = qk_in.shape
-        qk = fused.linear(qk_in, w[:2 * E], b[:2 * E])       # split product on the matrix cores when enabled
+        qk = fused.linear(qk_in, w, b[:2 * E], rows=(0, 2 * E))    # split product on the matrix cores when enabled
         if qk is None:
             qk = F.linear(qk_in, w[:2 * E], b[:2 * E])
-        v = fused.linear(v_in, w[2 * E:], b[2 * E:])
+        v = fused.linear(v_in, w, b[2 * E:], rows=(2 * E, 3 * E))
         if v is None:
             v = F.linear(v_in, w[2 * E:], b[2 * E:])
         o = fused.mha_core(qk, v, H, key_padding_mask)      # one fp32 launch: scores, softmax, P V

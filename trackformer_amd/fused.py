@@ -84,7 +84,6 @@ def residual_norm(x, res, norm, inference):
 # with one), and inside the parity bar at the BASELINE sizes (tests/test_full_size_gpu.py: boxes 1e-6, logits 6e-5,
 # track ids exact).
 _split_linear = os.environ.get("TF_SPLIT_LINEAR", "1") not in ("", "0")
-_split_cache = {}
 
 
 def split_linear_enabled():
@@ -99,27 +98,35 @@ def set_split_linear(on):
 
 
 def _split_weight(weight):
-    """(w_hi, w_mid) bf16 pieces of an fp32 weight, cached per tensor version (weights are constants in inference)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device)
-    hit = _split_cache.get(key)
-    if hit is None:
-        if len(_split_cache) > 512:
-            _split_cache.clear()
+    """(w_hi, w_mid) bf16 pieces of an fp32 weight.  Cached ON THE TENSOR OBJECT together with its version counter
+    (weights are constants in inference; an in-place update bumps the version).  Not keyed by data_ptr: a freed
+    parameter's address is handed to the next model's parameters by the caching allocator, and a pointer-keyed cache
+    then serves another tensor's pieces (seen as a golden failure when two test models were built one after the
+    other).  Callers pass persistent tensors (module parameters, _CatProjection's concatenation), and use `rows=` of
+    linear() for a row block instead of a temporary slice."""
+    hit = getattr(weight, "_tf_split", None)
+    if hit is None or hit[0] != weight._version:
         w = weight.detach()
         hi = w.to(torch.bfloat16)
         mid = (w - hi.float()).to(torch.bfloat16)
-        hit = (hi.contiguous(), mid.contiguous())
-        _split_cache[key] = hit
-    return hit
+        hit = (weight._version, hi.contiguous(), mid.contiguous())
+        weight._tf_split = hit
+    return hit[1], hit[2]
 
 
-def linear(x, weight, bias=None, relu=False):
+def linear(x, weight, bias=None, relu=False, rows=None):
     """act(x @ weight^T + bias) through tf_linear_split_f32 for fp32 GPU tensors with K % 32 == 0; returns None when
-    it does not apply (switched off, other dtype / device / shape): the caller keeps its PyTorch formulation."""
+    it does not apply (switched off, other dtype / device / shape): the caller keeps its PyTorch formulation.
+    rows = (a, b): use output features a..b of `weight` only (a row block of a packed projection such as
+    nn.MultiheadAttention.in_proj_weight); `bias` is then the matching slice."""
     if not (_split_linear and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
             and weight.dim() == 2 and weight.is_contiguous() and weight.device == x.device):
         return None
     N, K = weight.shape
+    if rows is not None:
+        if not (0 <= rows[0] < rows[1] <= N):
+            return None
+        N = rows[1] - rows[0]
     if x.shape[-1] != K or K % 32 or x.numel() == 0:
         return None
     if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
@@ -129,6 +136,8 @@ def linear(x, weight, bias=None, relu=False):
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     hi, mid = _split_weight(weight)
+    if rows is not None:
+        hi, mid = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]]   # views: a row block is contiguous
     if (x2.data_ptr() | hi.data_ptr() | mid.data_ptr()) & 15:
         return None
     with torch.cuda.device(x.device):
@@ -154,6 +163,8 @@ def mha_core(qk, v, num_heads, key_padding_mask=None):
     """softmax(q k^T / sqrt(d)) v for the decoder's query self-attention (include/tf_fused.h: tf_mha_core_f32).
     qk [N, L, 2E]: the shared q | k projection of one GEMM; v [N, L, E]; key_padding_mask [N, L] bool (True = ignore)
     or None.  Returns [N, L, E], or None when the kernel does not apply (the caller keeps torch's SDPA)."""
+    if os.environ.get("TF_NO_MHA") == "1":   # debugging aid: keep torch's SDPA
+        return None
     if not (qk.is_cuda and qk.dtype == torch.float32 and v.dtype == torch.float32 and v.device == qk.device
             and qk.dim() == 3 and v.dim() == 3 and qk.is_contiguous() and v.is_contiguous()):
         return None
