@@ -126,8 +126,14 @@ def test_graphed_detector_equals_eager(dev):
                        'image_id': torch.tensor([1], device=dev)}]
             eager, _, _, _, _ = model(img, [dict(target[0])], None)
             replay, _, _, _, _ = graphed(img, [dict(target[0])], None)
+            # Two forwards of the same frame are not bit-identical on this stack (the library convolutions that split
+            # K over workgroups accumulate with atomics: ~1 ulp of run-to-run noise in the backbone features), and the
+            # split-product linears turn a 1-ulp input change into a change at their own error level (2^-16 of the
+            # products: which bf16 `hi` an activation rounds to flips) -- measured 3e-5 on the logits between two EAGER
+            # runs (tools/debug_determinism.py), 5e-7 on the boxes.  Graph replay adds nothing to that.
+            tol = {'pred_logits': 2e-4, 'hs_embed': 2e-4, 'pred_boxes': 1e-5}
             for k in ('pred_logits', 'pred_boxes', 'hs_embed'):
-                assert torch.allclose(eager[k], replay[k], atol=1e-5, rtol=1e-5), (it, k)
+                assert torch.allclose(eager[k], replay[k], atol=tol[k], rtol=1e-5), (it, k)
     assert len(graphed._graphs) == 1
 
 
