@@ -110,6 +110,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-sequence", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="measure only the roofline kernel (headline pattern) and print its JSON object: the command "
+                         "profiles/r02_bench_roofline_kernel_stats.csv was collected with under rocprofv3 --stats")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--host-frames", action="store_true",
                     help="keep the frames in pinned host memory (PCIe copy inside the timed region); "
@@ -275,7 +278,7 @@ def measure_roofline_backward(device, launches=10):
             "pattern": "local (reference point + N(0, 2 px))"}
 
 
-def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32):
+def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patterns=("pert", "init", "local")):
     """HIP-event timing of the MSDeformAttn forward kernel at the cfg-2 encoder call shape, THROUGH THE
     FUSED ENTRY the model calls (tf_msda_forward_fused_f32), on the sampling pattern of the
     perturbed-weight parity model, rotating over `sets` input sets (4 x 80 MB > the 256 MiB Infinity
@@ -289,7 +292,7 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32):
     stream = torch.cuda.Stream(device)
     per_pattern = {}
     alg = None
-    for pattern in ("pert", "init", "local"):
+    for pattern in patterns:
         inputs, ref, S = _encoder_call_inputs(pattern, sets, device, D=D)
         alg = algorithmic_bytes(N=1, S=S, M=M, D=D, L=L, Lq=S, P=P)
         shapes = msda.attach_host_shapes(torch.tensor(CFG2_SHAPES, dtype=torch.long, device=device),
@@ -545,6 +548,10 @@ def main():
     if args.split_linear is not None:
         fused.set_split_linear(args.split_linear)
 
+    if args.roofline_only:
+        if rank == 0:
+            print(json.dumps(measure_roofline(device, patterns=("pert",))))
+        return
     model, criterion, post, margs = build_model(cfg, device)
     single = None
     n_seq = 1
