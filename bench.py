@@ -324,8 +324,8 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
     # --pmc needs its own passes) and committed together with the method; see the file's "_how"
     mode = os.environ.get("TF_MSDA_TILED", "2")[:1] or "2"   # the library's kernel choice for this shape
     kernel = {"0": "msda_fwd_f32_direct", "1": "msda_fwd_f32_win"}.get(mode, "msda_fwd_f32_pquad")
-    if D != 32:
-        kernel = "msda_fwd_f32_buf"   # head dimension 36 (hidden 288): no LDS-window kernel yet
+    if D != 32 and kernel == "msda_fwd_f32_pquad":
+        kernel = "msda_fwd_f32_pquad<D=36>"   # head dimension 36 (hidden 288): 144-byte rows, 3 lanes x 12 channels
     traffic = None
     try:
         with open(os.path.join(REPO, "profiles", "r02_msda_fwd_pquad_traffic.json")) as f:
@@ -550,7 +550,8 @@ def main():
 
     if args.roofline_only:
         if rank == 0:
-            print(json.dumps(measure_roofline(device, patterns=("pert",))))
+            hd = 36 if "multi_frame" in cfg["overlays"] else 32   # hidden 288 / 8 heads
+            print(json.dumps(measure_roofline(device, head_dim=hd, patterns=("pert", "init", "local"))))
         return
     model, criterion, post, margs = build_model(cfg, device)
     single = None

@@ -495,6 +495,39 @@ def test_persistent_encoder_kernel_variants_vs_oracle(dev, opts):
             lib.tf_msda_set_option(k.encode(), v)
 
 
+@pytest.mark.parametrize("shapes_l,N", [(CFG2_SHAPES, 1), ([(30, 44), (15, 22), (8, 11)], 2), ([(37, 53)], 1)],
+                         ids=["cfg4_encoder", "three_levels_n2", "one_level"])
+def test_persistent_encoder_kernel_head_dim_36(dev, shapes_l, N):
+    """hidden 288 (cfg 4: `multi_frame`, train_multi_frame.yaml:2): head dimension 36 through msda_fwd_f32_pquad's
+    144-byte-row variant (3 lanes x 12 channels, windows staged in 16-byte pieces), plain and fused entry."""
+    from trackformer_amd import _cabi, msda
+    lib = _cabi.lib()
+    prev_t = lib.tf_msda_set_tiled(2)
+    prev_p = lib.tf_msda_set_option(b"pquad", 1)
+    try:
+        value, shp, loc, attn, _ = _encoder_inputs(dev, shapes_l, "local", N=N, M=8, D=36, seed=7)
+        out = _fwd(value, shp, loc, attn).cpu().numpy()
+        ref = msda_oracle.msda_forward(value.cpu().numpy(), shp.cpu().numpy(), loc.cpu().numpy(),
+                                       attn.cpu().numpy(), nthreads=8)
+        np.testing.assert_allclose(out, ref, atol=1e-5, rtol=1e-4)
+        Nn, S, M, D = value.shape
+        L, P = len(shapes_l), 4
+        g = torch.Generator().manual_seed(9)
+        qproj = torch.randn(Nn, S, 3 * M * L * P, generator=g)
+        qproj[..., :2 * M * L * P] *= 2.0
+        refp = torch.rand(Nn, S, L, 2, generator=g) * 0.8 + 0.1
+        off = qproj[..., :2 * M * L * P].view(Nn, S, M, L, P, 2)
+        a = torch.softmax(qproj[..., 2 * M * L * P:].view(Nn, S, M, L * P), -1).view(Nn, S, M, L, P)
+        hw = torch.tensor(shapes_l, dtype=torch.float32)[None, None, None, :, None, :]
+        floc = refp[:, :, None, :, None, :] + off / hw
+        expect = msda_oracle.msda_forward(value.cpu().numpy(), shp.cpu().numpy(), floc.numpy(), a.numpy(), nthreads=8)
+        got = msda.ms_deform_attn_forward_fused(value, shp, refp.to(dev), qproj.to(dev), M, L, P)
+        np.testing.assert_allclose(got.cpu().numpy(), expect.reshape(got.shape), atol=5e-5, rtol=1e-4)
+    finally:
+        lib.tf_msda_set_tiled(prev_t)
+        lib.tf_msda_set_option(b"pquad", prev_p)
+
+
 BWD_ENC_CASES = [c for c in TILED_CASES if c[0] in (
     "cfg2_init", "cfg2_uniform_all_fallback", "mot17_750x1333", "small_pyramid", "tiny_levels",
     "one_level", "coarse_first_falls_back", "cfg4_d36_hidden288")]

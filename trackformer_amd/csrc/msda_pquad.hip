@@ -127,11 +127,16 @@ __device__ __forceinline__ f32x4_t ldg_f4(const float *base, unsigned byte_off)
     return *reinterpret_cast<const f32x4_t *>(reinterpret_cast<const char *>(base) + (size_t)byte_off);
 }
 
-template <bool FUSED, int TA_MASK, int NPASS, int PF, bool WIDE>
+// DH: head dimension, 32 (128-byte rows, 4 lanes x 8 channels) or 36 (hidden 288: 144-byte rows, 3 lanes x 12 channels,
+//     the window rows packed without padding and staged in 16-byte pieces; see msda_quad_dev.h).
+template <bool FUSED, int TA_MASK, int NPASS, int PF, bool WIDE, int DH>
 __global__ void __launch_bounds__(kPqThreads, (pq_min_waves<NPASS, PF>()))
 msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 {
-    constexpr int PT = 4, D = 32, NL = kPqLevels, PAIRS = kPqPairs;
+    constexpr int PT = 4, D = DH, NL = kPqLevels, PAIRS = kPqPairs;
+    constexpr bool D36 = DH == 36;
+    constexpr unsigned ROWB = D * 4;   // bytes of one (pixel, head) row
+    static_assert(DH == 32 || DH == 36, "head dimension 32 or 36");
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     int *s_tab = reinterpret_cast<int *>(smem);
     int *s_q = s_tab + kPqOffQ;       // [parity][ya | yb | xa | xb][level]
@@ -158,6 +163,9 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
     const unsigned rbA = (unsigned)(hsel * 64 + sub * 16), rbB = (unsigned)((1 - hsel) * 64 + sub * 16);
     const unsigned lds_rows = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)s_rows);
     const unsigned ldsA = lds_rows + rbA, ldsB = lds_rows + rbB;
+    // DH == 36: lanes 0..2 of the quad own 48 bytes of the row each; lane 3's global loads are sent out of range
+    const unsigned rbL = (unsigned)sub * 48u, ldsL = lds_rows + rbL;
+    const bool idle36 = sub == 3;
 
     auto stamp = [&](int i) {
         if (pg.trace != nullptr && threadIdx.x == 0 && i < 16)
@@ -201,7 +209,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         s_tab[kML + l] = l < L ? lt.W[l] : 1;
         s_tab[2 * kML + l] = l < L ? lt.start[l] : 0;
     }
-    if (threadIdx.x < 64) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;
+    if (threadIdx.x < 2 * D) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;   // rows 0, 1
     int cb, cty, ctx, cm;
     decode_item(item, cb, cty, ctx, cm);
     setup_tables(0, cty, ctx);
@@ -538,35 +546,58 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                     gww[l] = ww;
                     groff[l] = roff;
                     const int nrows = wh * ww;
-                    const int nchunks = (nrows + 7) >> 3;   // one DMA wave-instruction = 8 rows of 128 B
-                    used += nchunks * 8;
-                    if (nchunks > 0) {
+                    if constexpr (!D36) {
+                        const int nchunks = (nrows + 7) >> 3;   // one DMA wave-instruction = 8 rows of 128 B
+                        used += nchunks * 8;
+                        if (nchunks > 0) {
+                            const unsigned lvl_base = glvl[l];
+                            const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
+                            int r = wave * 8 + (lane >> 3);                       // < 64
+                            int wy = (int)(((float)r + 0.5f) * inv_ww);
+                            int wx = r - wy * ww;
+                            constexpr int STEP = 8 * (kPqThreads / 64);
+                            const int qstep = __builtin_amdgcn_readfirstlane((int)(((float)STEP + 0.5f) * inv_ww));
+                            const int rstep = STEP - qstep * ww;
+                            unsigned off = lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)(lane & 7) * 16u;
+                            const unsigned step_a = (unsigned)(qstep * W + rstep) * rowbytes;
+                            const unsigned step_b = (unsigned)(W - ww) * rowbytes;
+                            for (int c = wave; c < nchunks; c += kPqThreads / 64) {
+                                const int py = wy0 + wy, px = wx0 + wx;   // extended coordinates: may be -1 or size
+                                const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                    rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128),
+                                    16, ok ? off : kOobOffset /* hardware writes zeros */, 0, 0, 0);
+                                r += STEP;
+                                wy += qstep;
+                                wx += rstep;
+                                off += step_a;
+                                if (wx >= ww) {
+                                    wx -= ww;
+                                    wy += 1;
+                                    off += step_b;
+                                }
+                            }
+                        }
+                    } else {
+                        // 144-byte rows, packed: the window is nrows * 9 pieces of 16 bytes, one DMA wave-instruction
+                        // moves 64 consecutive pieces (7 rows and a piece); the next window starts on a row boundary
+                        const int npieces = nrows * 9;
+                        const int nchunks = (npieces + 63) >> 6;
+                        used += (nchunks * 64 + 8) / 9;
                         const unsigned lvl_base = glvl[l];
                         const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
-                        int r = wave * 8 + (lane >> 3);                       // < 64
-                        int wy = (int)(((float)r + 0.5f) * inv_ww);
-                        int wx = r - wy * ww;
-                        constexpr int STEP = 8 * (kPqThreads / 64);
-                        const int qstep = __builtin_amdgcn_readfirstlane((int)(((float)STEP + 0.5f) * inv_ww));
-                        const int rstep = STEP - qstep * ww;
-                        unsigned off = lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)(lane & 7) * 16u;
-                        const unsigned step_a = (unsigned)(qstep * W + rstep) * rowbytes;
-                        const unsigned step_b = (unsigned)(W - ww) * rowbytes;
                         for (int c = wave; c < nchunks; c += kPqThreads / 64) {
+                            const int pc = c * 64 + lane;
+                            const int r = (int)(((float)pc + 0.5f) * (1.f / 9.f));   // pc / 9 (pc < 2^16: exact)
+                            const int piece = pc - r * 9;
+                            const int wy = (int)(((float)r + 0.5f) * inv_ww);
+                            const int wx = r - wy * ww;
                             const int py = wy0 + wy, px = wx0 + wx;   // extended coordinates: may be -1 or size
                             const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
+                            const unsigned off = lvl_base + (unsigned)(py * W + px) * rowbytes + (unsigned)piece * 16u;
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                                rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128),
+                                rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)roff * ROWB + (size_t)c * 1024),
                                 16, ok ? off : kOobOffset /* hardware writes zeros */, 0, 0, 0);
-                            r += STEP;
-                            wy += qstep;
-                            wx += rstep;
-                            off += step_a;
-                            if (wx >= ww) {
-                                wx -= ww;
-                                wy += 1;
-                                off += step_b;
-                            }
                         }
                     }
                 }
@@ -574,10 +605,13 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         };
 
         f32x4_t accA[NPASS], accB[NPASS];
+        f32x4_t acc36[NPASS][3];   // DH == 36: 12 channels per lane
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             accA[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             accB[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc36[ps][c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
         auto level = [&](auto lc, auto psc, auto ldsc) {
             constexpr int l = decltype(lc)::value;
@@ -603,13 +637,20 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
             if constexpr (LDS_PHASE) {
                 const int dx = x0 - gwx0[l], dy = y0 - gwy0[l];
                 const bool staged = in && (unsigned)dx <= (unsigned)glimx[l] && (unsigned)dy <= (unsigned)glimy[l];
-                const unsigned lo = (unsigned)(groff[l] + dy * gww[l] + dx) * 128u;
+                const unsigned lo = (unsigned)(groff[l] + dy * gww[l] + dx) * ROWB;
                 const unsigned a0 = staged ? lo : 0u;                            // rows 0, 1 are zeros
-                const unsigned a1 = staged ? lo + (unsigned)gww[l] * 128u : 0u;
-                quad_taps_lds<0>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
-                quad_taps_lds<1>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
-                quad_taps_lds<2>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
-                quad_taps_lds<3>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+                const unsigned a1 = staged ? lo + (unsigned)gww[l] * ROWB : 0u;
+                if constexpr (!D36) {
+                    quad_taps_lds<0>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+                    quad_taps_lds<1>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+                    quad_taps_lds<2>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+                    quad_taps_lds<3>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
+                } else {
+                    quad_taps_lds36<0>(a0, a1, w, ldsL, acc36[ps]);
+                    quad_taps_lds36<1>(a0, a1, w, ldsL, acc36[ps]);
+                    quad_taps_lds36<2>(a0, a1, w, ldsL, acc36[ps]);
+                    quad_taps_lds36<3>(a0, a1, w, ldsL, acc36[ps]);
+                }
                 need_global = in && !staged;
                 if (!__any(need_global)) return;   // wave-uniform: no point of this wave left its window
             }
@@ -622,10 +663,17 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                                    (ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase,
                                    (ky1 && kx0) ? lvl_base + (unsigned)(r0 + W) * rowbytes : kOobBase,
                                    (ky1 && kx1) ? lvl_base + (unsigned)(r0 + W + 1) * rowbytes : kOobBase};
-            quad_taps_global<0>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
-            quad_taps_global<1>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
-            quad_taps_global<2>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
-            quad_taps_global<3>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+            if constexpr (!D36) {
+                quad_taps_global<0>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+                quad_taps_global<1>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+                quad_taps_global<2>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+                quad_taps_global<3>(rsrc, g, w, rbA, rbB, accA[ps], accB[ps]);
+            } else {
+                quad_taps_global36<0>(rsrc, g, w, rbL, idle36, acc36[ps]);
+                quad_taps_global36<1>(rsrc, g, w, rbL, idle36, acc36[ps]);
+                quad_taps_global36<2>(rsrc, g, w, rbL, idle36, acc36[ps]);
+                quad_taps_global36<3>(rsrc, g, w, rbL, idle36, acc36[ps]);
+            }
         };
         auto levels = [&](auto maskc, auto psc, auto ldsc) {
             constexpr int MASK = decltype(maskc)::value;
@@ -681,8 +729,13 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         for (int ps = 0; ps < NPASS; ++ps)
             if (cur.live[ps]) {
                 float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(da.out) + (size_t)(cur.pair32[ps] * (unsigned)(D * 4)));
-                *reinterpret_cast<f32x4_t *>(o + rbA / 4) = accA[ps];
-                *reinterpret_cast<f32x4_t *>(o + rbB / 4) = accB[ps];
+                if constexpr (!D36) {
+                    *reinterpret_cast<f32x4_t *>(o + rbA / 4) = accA[ps];
+                    *reinterpret_cast<f32x4_t *>(o + rbB / 4) = accB[ps];
+                } else if (!idle36) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) *reinterpret_cast<f32x4_t *>(o + rbL / 4 + 4 * c) = acc36[ps][c];
+                }
             }
         if (iter == 0) stamp(8);
         if (!has_next) break;
@@ -781,7 +834,7 @@ int pq_num_cus()
     return n;
 }
 
-bool pq_plan(const LevelTable &lt, int L, int M, int N, PqPlan *out)
+bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
 {
     pq_opts_init();
     int o[kPoCount];
@@ -795,16 +848,19 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, PqPlan *out)
         return false;
     for (int l = 0; l < L; ++l)
         if (lt.H[l] >= 32768 || lt.W[l] >= 32768) return false;   // 32-bit tile arithmetic in the kernel
-    const int cap_rows = (int)(((size_t)o[kPoLdsKb] * 1024 - kPqHdrBytes) / 128 - 2) & ~7;
+    const int rowb = D * 4;
+    // D == 36: one KB of slack behind the rows, the last DMA chunk of a window may end past its last row
+    int cap_rows = (int)(((size_t)o[kPoLdsKb] * 1024 - kPqHdrBytes - (D == 36 ? 1024 : 0)) / rowb - 2);
+    if (D == 32) cap_rows &= ~7;
     if (cap_rows < 8) return false;
     struct Memo {
         bool valid = false, ok = false;
-        int L = 0, M = 0, N = 0, epoch = -1;
+        int L = 0, M = 0, N = 0, D = 0, epoch = -1;
         LevelTable lt;
         PqPlan plan;
     };
     static thread_local Memo memo;
-    if (memo.valid && memo.L == L && memo.M == M && memo.N == N && memo.epoch == epoch &&
+    if (memo.valid && memo.L == L && memo.M == M && memo.N == N && memo.D == D && memo.epoch == epoch &&
         memcmp(&memo.lt, &lt, sizeof(lt)) == 0) {
         *out = memo.plan;
         return memo.ok;
@@ -814,6 +870,7 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, PqPlan *out)
     memo.L = L;
     memo.M = M;
     memo.N = N;
+    memo.D = D;
     memo.epoch = epoch;
     memo.lt = lt;
     const long long cap_q = (long long)kPqPairs * npass;
@@ -859,7 +916,7 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, PqPlan *out)
     if (items > 0x7fffffffLL) return false;
     r.geom.n_items = (int)items;
     r.geom.cap_rows = cap_rows;
-    r.lds = (size_t)kPqHdrBytes + (size_t)(2 + cap_rows) * 128;
+    r.lds = (size_t)kPqHdrBytes + (size_t)(2 + cap_rows) * rowb + (D == 36 ? 1024 : 0);
     r.geom.skew = o[kPoSkew];
     r.geom.cus = pq_num_cus();
     r.wide = o[kPoWide] != 0;
@@ -882,9 +939,16 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, PqPlan *out)
 template <bool FUSED, int PF, bool WIDE>
 const void *pq_kernel_n(int npass)
 {
-    return npass == 1   ? (const void *)&msda_fwd_f32_pquad<FUSED, 0, 1, PF, WIDE>
-           : npass == 2 ? (const void *)&msda_fwd_f32_pquad<FUSED, 0, 2, PF, WIDE>
-                        : (const void *)&msda_fwd_f32_pquad<FUSED, 0, 3, PF, WIDE>;
+    return npass == 1   ? (const void *)&msda_fwd_f32_pquad<FUSED, 0, 1, PF, WIDE, 32>
+           : npass == 2 ? (const void *)&msda_fwd_f32_pquad<FUSED, 0, 2, PF, WIDE, 32>
+                        : (const void *)&msda_fwd_f32_pquad<FUSED, 0, 3, PF, WIDE, 32>;
+}
+// head dimension 36: 2 passes, no register prefetch (the only variant built)
+template <bool FUSED>
+const void *pq_kernel_d36(bool wide)
+{
+    return wide ? (const void *)&msda_fwd_f32_pquad<FUSED, 0, 2, 0, true, 36>
+                : (const void *)&msda_fwd_f32_pquad<FUSED, 0, 2, 0, false, 36>;
 }
 template <bool FUSED, int PF>
 const void *pq_kernel_t(int npass, bool wide)
@@ -905,13 +969,14 @@ namespace tfm {
 bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N, int D, int P, hipStream_t stream,
                   hipError_t *err)
 {
-    if (da.Lq != da.S || D != 32 || P != 4 || da.L > kPqLevels) return false;
+    if (da.Lq != da.S || (D != 32 && D != 36) || P != 4 || da.L > kPqLevels) return false;
     if (fused && da.fa.ref_dim != 2) return false;
     // the kernel addresses loc / attn / qproj / ref / out with 32-bit byte offsets
     if (fused && (long long)N * da.Lq * da.fa.ld * 4 >= (1LL << 32)) return false;
     if ((long long)N * da.Lq * da.M * da.L * 4 * 8 >= (1LL << 32)) return false;
     PqPlan pl;
-    if (!pq_plan(lt, da.L, da.M, N, &pl)) return false;
+    if (!pq_plan(lt, da.L, da.M, N, D, &pl)) return false;
+    if (D == 36 && (pl.npass != 2 || pl.pf != 0)) return false;
     long long grid = (long long)pq_num_cus() * pl.wgs;
     if (grid > pl.geom.n_items) grid = pl.geom.n_items;
     // 16-byte loads of the points need 16-byte aligned rows
@@ -921,7 +986,8 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
                da.fa.logit_col % 4 == 0;
     else
         wide = wide && ((uintptr_t)da.loc % 16 == 0) && ((uintptr_t)da.attn % 16 == 0);
-    const void *fn = fused ? pq_kernel<true>(pl.npass, pl.pf, wide) : pq_kernel<false>(pl.npass, pl.pf, wide);
+    const void *fn = D == 36 ? (fused ? pq_kernel_d36<true>(wide) : pq_kernel_d36<false>(wide))
+                             : (fused ? pq_kernel<true>(pl.npass, pl.pf, wide) : pq_kernel<false>(pl.npass, pl.pf, wide));
     // the dynamic-LDS limit is a per-function, per-device attribute: cheap, set on every first (function, device)
     struct Raised { const void *fn; int dev; };
     static std::atomic<int> n_raised{0};

@@ -79,6 +79,48 @@ __device__ __forceinline__ void quad_taps_global(const __amdgpu_buffer_rsrc_t rs
     }
 }
 
+// ---- head dimension 36 (hidden 288: cfg 4).  A (pixel, head) row is 144 bytes = 9 pieces of 16 bytes; lanes 0..2 of
+// a quad take 3 pieces (12 channels) each, lane 3 only contributes its sampling point's tap arithmetic (what it reads and
+// sums is never stored).  ldsL: this lane's LDS byte address of its first piece of row 0; the x0 + 1 taps are + 144.
+template <int K>
+__device__ __forceinline__ void quad_taps_lds36(unsigned a0, unsigned a1, const float (&w)[4], unsigned ldsL,
+                                                f32x4_t (&acc)[3])
+{
+    constexpr int C = K * 0x55;   // quad_perm [K,K,K,K]
+    const unsigned p0 = dpp_u<C>(a0) + ldsL, p1 = dpp_u<C>(a1) + ldsL;
+    const float W0 = dpp_f<C>(w[0]), W1 = dpp_f<C>(w[1]), W2 = dpp_f<C>(w[2]), W3 = dpp_f<C>(w[3]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const f32x4_t v00 = lds_read16(p0 + 16u * c), v01 = lds_read16(p0 + 144u + 16u * c);
+        const f32x4_t v10 = lds_read16(p1 + 16u * c), v11 = lds_read16(p1 + 144u + 16u * c);
+        acc[c] += v00 * W0;
+        acc[c] += v01 * W1;
+        acc[c] += v10 * W2;
+        acc[c] += v11 * W3;
+    }
+}
+// g[t]: byte offset of tap t's 144-byte row; rbL = sub * 48; lane 3 (idle) loads from an out-of-range offset (zeros).
+template <int K>
+__device__ __forceinline__ void quad_taps_global36(const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&g)[4],
+                                                   const float (&w)[4], unsigned rbL, bool idle, f32x4_t (&acc)[3])
+{
+    constexpr int C = K * 0x55;
+    u32x4_t v[4][3];
+    float W[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned Gd = dpp_u<C>(g[t]);
+        const unsigned G = idle ? kOobBase : Gd;
+        W[t] = dpp_f<C>(w[t]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[t][c] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G + rbL + 16u * c, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += __builtin_bit_cast(f32x4_t, v[t][c]) * W[t];
+}
+
 // 32-bit byte offsets from a kernel-uniform base: the compiler emits global_load ... v_off, s[base:base+1].
 __device__ __forceinline__ float ldg_f(const float *base, unsigned byte_off)
 {
