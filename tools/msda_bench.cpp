@@ -158,7 +158,7 @@ static void apply(const Config &c)
     static const int defaults[] = {0, 4, 3, 40, 6, 10, 0, 0, 1};   // = kQuadOptDefaults of the library
     static const char *pnames[] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
                                    "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew"};
-    static const int pdefaults[] = {1, 2, 48, 6, 10, 0, 0, 3, 0, 0};   // = kPqOptDefaults of the library
+    static const int pdefaults[] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0};   // = kPqOptDefaults of the library
     for (int i = 0; i < 9; ++i) tf_msda_set_option(names[i], defaults[i]);
     for (int i = 0; i < 10; ++i) tf_msda_set_option(pnames[i], pdefaults[i]);
     for (auto &o : c.opts) tf_msda_set_option(o.first.c_str(), o.second);

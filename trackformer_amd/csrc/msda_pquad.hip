@@ -762,7 +762,7 @@ const char *const kPqOptNames[kPoCount] = {"pquad_wide", "pquad_npass", "pquad_l
                                            "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew",
                                            "pquad"};
 const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on"};
-constexpr int kPqOptDefaults[kPoCount] = {1, 2, 48, 6, 10, 0, 0, 3, 0, 0, 1};
+constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1};   // 3 x 52 KB = 156 KB of the CU's 160
 std::atomic<int> g_pq_opt[kPoCount];
 std::atomic<int> g_pq_epoch{0};
 std::atomic<unsigned long long *> g_pq_trace{nullptr};
