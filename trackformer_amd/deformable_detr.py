@@ -23,6 +23,9 @@ def _get_clones(module, N):
 
 
 class DeformableDETR(DETR):
+    # GraphedDetector may append filler track queries (masked as self-attention keys, deformable_transformer.py)
+    track_query_filler_ok = True
+
     def __init__(self, backbone, transformer, num_classes, num_queries, num_feature_levels,
                  aux_loss=True, with_box_refine=False, two_stage=False, overflow_boxes=False,
                  multi_frame_attention=False, multi_frame_encoding=False,

@@ -236,6 +236,7 @@ class DeformableTransformer(nn.Module):
         # decoder inputs
         bs, _, c = memory.shape
         query_attn_mask = None
+        filler_key_mask = None
         enc_outputs_class = enc_outputs_coord_unact = None
         if self.two_stage:
             pad = mask_flatten if mask_flatten is not None else \
@@ -269,11 +270,16 @@ class DeformableTransformer(nn.Module):
                 query_embed = torch.cat([torch.zeros_like(prev_hs_embed), query_embed], dim=1)
                 tgt = torch.cat([prev_hs_embed, tgt], dim=1)
                 reference_points = torch.cat([prev_boxes[..., :2], reference_points], dim=1)
+                if 'track_query_filler' in targets[0]:   # see DeformableTransformerDecoderLayer.forward
+                    filler = torch.stack([t['track_query_filler'] for t in targets])
+                    filler_key_mask = torch.cat(
+                        [filler, torch.zeros((bs, tgt.shape[1] - filler.shape[1]), dtype=torch.bool,
+                                             device=filler.device)], dim=1)
             init_reference_out = reference_points
 
         hs, inter_references = self.decoder(tgt, reference_points, memory, spatial_shapes,
                                             valid_ratios, query_embed, mask_flatten,
-                                            query_attn_mask)
+                                            query_attn_mask, filler_key_mask)
         if self.two_stage:
             return (hs, memory, init_reference_out, inter_references, enc_outputs_class,
                     enc_outputs_coord_unact)
@@ -395,14 +401,18 @@ class DeformableTransformerDecoderLayer(nn.Module):
         return mha.out_proj(o.transpose(1, 2).reshape(n, lq, E))
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes,
-                src_padding_mask=None, query_attn_mask=None):
+                src_padding_mask=None, query_attn_mask=None, filler_key_mask=None):
+        """filler_key_mask [N, Lq] (True = ignore as a KEY of the self-attention only): marks filler track queries
+        that GraphedDetector appends to reach a bucketed query count; their own outputs are dropped by the caller, so
+        nothing else needs to know about them (the cross-attention is per query)."""
         # self attention among the (track + object) queries
         q = k = self.with_pos_embed(tgt, query_pos)
+        key_mask = query_attn_mask if query_attn_mask is not None else filler_key_mask
         if _inference(self) and tgt.is_cuda and self.self_attn.in_proj_weight is not None:
-            tgt2 = self._self_attention_inference(q, tgt, query_attn_mask)
+            tgt2 = self._self_attention_inference(q, tgt, key_mask)
         else:
             tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
-                                  key_padding_mask=query_attn_mask)[0].transpose(0, 1)
+                                  key_padding_mask=key_mask)[0].transpose(0, 1)
         tgt = fused.residual_norm(tgt, self.dropout2(tgt2), self.norm2, _inference(self))
         # deformable cross attention into the encoder memory
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src,
@@ -422,7 +432,7 @@ class DeformableTransformerDecoder(nn.Module):
         self.class_embed = None
 
     def forward(self, tgt, reference_points, src, src_spatial_shapes, src_valid_ratios,
-                query_pos=None, src_padding_mask=None, query_attn_mask=None):
+                query_pos=None, src_padding_mask=None, query_attn_mask=None, filler_key_mask=None):
         output = tgt
         intermediate = []
         intermediate_reference_points = []
@@ -434,7 +444,7 @@ class DeformableTransformerDecoder(nn.Module):
                 assert reference_points.shape[-1] == 2
                 reference_points_input = reference_points[:, :, None] * src_valid_ratios[:, None]
             output = layer(output, query_pos, reference_points_input, src, src_spatial_shapes,
-                           src_padding_mask, query_attn_mask)
+                           src_padding_mask, query_attn_mask, filler_key_mask)
 
             if self.bbox_embed is not None:  # iterative bounding box refinement
                 tmp = self.bbox_embed[lid](output)

@@ -21,6 +21,13 @@ Aliasing contract: `out['pred_logits' | 'pred_boxes' | 'hs_embed']` are cloned (
 across frames); `features` (see above), `memory`, `hs` and `out['aux_outputs']` alias static buffers of
 the entry and are valid until the next call with the same key.
 
+Bucketed track-query count: in real tracking the number of track queries changes from frame to frame, and every
+count would be its own graph.  The wrapper therefore rounds the count up to a multiple of `bucket` (16) with FILLER
+track queries (zero embedding, a fixed box) that are masked out as keys of the decoder's query self-attention
+(`track_query_filler` -> `filler_key_mask`, deformable_transformer.py) -- their attention weight is exactly zero, so
+the real queries see what they would see without them (up to the summation order of the attention) -- and drops the
+fillers' rows from the outputs.  Everything else in the decoder is per query.  `bucket=1` switches it off.
+
 Threads: bench.py and INTEGRATION.md run one tracker thread (own HIP stream) per sequence against one
 shared model.  Captures are serialised by a process-wide lock and run in `thread_local` capture mode
 with a private memory pool, so other threads may keep replaying / running eagerly meanwhile.  The
@@ -36,9 +43,10 @@ _CAPTURE_LOCK = threading.Lock()
 
 
 class GraphedDetector:
-    def __init__(self, model, max_graphs=16):
+    def __init__(self, model, max_graphs=16, bucket=16):
         self.model = model
         self.max_graphs = max_graphs
+        self.bucket = max(1, int(bucket))
         self._graphs = OrderedDict()
         self._seen = {}
 
@@ -75,6 +83,9 @@ class GraphedDetector:
             static_target = [{'track_query_boxes': entry["boxes"],
                               'track_query_hs_embeds': entry["hs"],
                               'image_id': target[0].get('image_id')}]
+            if 'track_query_filler' in target[0]:
+                entry["filler"] = target[0]['track_query_filler'].clone()
+                static_target[0]['track_query_filler'] = entry["filler"]
         entry["target"] = static_target
         multi = self._multi_frame()
         entry["prev"] = None
@@ -117,18 +128,54 @@ class GraphedDetector:
                 if d.mask is not None and s.mask is not None:
                     d.mask.copy_(s.mask, non_blocking=True)
 
+    def _bucketed(self, target):
+        """-> (padded target, number of real track queries, padded number)."""
+        n_real = int(target[0]['track_query_hs_embeds'].shape[0])
+        n_pad = -(-n_real // self.bucket) * self.bucket
+        if self.bucket <= 1 or not getattr(self.model, "track_query_filler_ok", False) or n_real == 0:
+            return target, n_real, n_real
+        hs, boxes = target[0]['track_query_hs_embeds'], target[0]['track_query_boxes']
+        extra = n_pad - n_real
+        filler = torch.zeros(n_pad, dtype=torch.bool, device=hs.device)
+        if extra:
+            hs = torch.cat([hs, hs.new_zeros((extra, hs.shape[1]))])
+            boxes = torch.cat([boxes, boxes.new_tensor([0.5, 0.5, 0.1, 0.1]).expand(extra, 4)])
+            filler[n_real:] = True
+        padded = dict(target[0], track_query_hs_embeds=hs, track_query_boxes=boxes, track_query_filler=filler)
+        return [padded], n_real, n_pad
+
+    @staticmethod
+    def _strip(out, hs, n_real, n_pad):
+        """Drop the filler rows n_real .. n_pad of every per-query output."""
+        if n_pad == n_real:
+            return out, hs
+
+        def cut(t, dim):
+            return torch.cat([t.narrow(dim, 0, n_real), t.narrow(dim, n_pad, t.shape[dim] - n_pad)], dim)
+        out = dict(out)
+        for k in ('pred_logits', 'pred_boxes', 'hs_embed', 'pred_masks'):
+            if k in out:
+                out[k] = cut(out[k], 1)
+        if 'aux_outputs' in out:
+            out['aux_outputs'] = [{k: cut(v, 1) for k, v in a.items()} for a in out['aux_outputs']]
+        return out, cut(hs, 2)
+
     def __call__(self, img, target=None, prev_features=None):
         if not self._capturable(img, target, prev_features):
             return self.model(img, target, prev_features)
         multi = self._multi_frame()
-        n_track = 0 if target is None else int(target[0]['track_query_hs_embeds'].shape[0])
+        n_real = n_pad = 0
+        caller_target = target
+        if target is not None:
+            target, n_real, n_pad = self._bucketed(target)
+        n_track = n_pad
         key = (tuple(img.shape), n_track, img.device, bool(multi and prev_features is not None))
         entry = self._graphs.get(key)
         if entry is None:
             # capture a shape the second time it shows up (one-off shapes are not worth a graph)
             self._seen[key] = self._seen.get(key, 0) + 1
             if self._seen[key] < 2:
-                return self.model(img, target, prev_features)
+                return self.model(img, caller_target, prev_features)
             entry = self._capture(img, target, prev_features)
             self._graphs[key] = entry
             while len(self._graphs) > self.max_graphs:
@@ -139,13 +186,18 @@ class GraphedDetector:
         if target is not None:
             entry["boxes"].copy_(target[0]['track_query_boxes'], non_blocking=True)
             entry["hs"].copy_(target[0]['track_query_hs_embeds'], non_blocking=True)
+            if "filler" in entry:
+                entry["filler"].copy_(target[0]['track_query_filler'], non_blocking=True)
         if entry["prev"] is not None:
             self._feed_prev(entry, prev_features)
         entry["graph"].replay()
         out, tgt, features, memory, hs = entry["out"]
         # what the tracker keeps across frames must not alias the static buffers (see the module docstring)
         out = dict(out)
-        out['hs_embed'] = out['hs_embed'].clone()
-        out['pred_logits'] = out['pred_logits'].clone()
-        out['pred_boxes'] = out['pred_boxes'].clone()
-        return out, target, features, memory, hs
+        if n_pad != n_real:
+            out, hs = self._strip(out, hs, n_real, n_pad)   # torch.cat: fresh tensors, nothing aliases
+        else:
+            out['hs_embed'] = out['hs_embed'].clone()
+            out['pred_logits'] = out['pred_logits'].clone()
+            out['pred_boxes'] = out['pred_boxes'].clone()
+        return out, caller_target, features, memory, hs
