@@ -75,3 +75,16 @@ def test_option_knobs_round_trip_without_a_gpu(lib):
     assert before == -1                                   # -1: follow TF_MSDA_TILED (unset: the quad kernel)
     assert lib.tf_msda_set_option(b"tiled", 2) == 0
     assert lib.tf_msda_set_tiled(-1) == 2
+
+
+def test_pquad_and_linear_knobs_round_trip_without_a_gpu(lib):
+    """The persistent encoder kernel's options and the split GEMM's block-shape variant are host state as well."""
+    int_min = -2 ** 31
+    for name, default in ((b"pquad", 1), (b"pquad_wide", 1), (b"pquad_npass", 2), (b"pquad_lds_kb", 52),
+                          (b"pquad_halo_y", 6), (b"pquad_halo_x", 10), (b"pquad_wg_per_cu", 3),
+                          (b"pquad_prefetch", 0), (b"pquad_skew", 0)):
+        assert lib.tf_msda_set_option(name, default) == default, name
+    assert lib.tf_msda_set_option(b"pquad_no_such", 1) == int_min
+    prev = lib.tf_msda_set_option(b"linear_variant", 2)
+    assert prev in (-2, 2)                                # -2: per-shape choice (the default)
+    assert lib.tf_msda_set_option(b"linear_variant", prev) == 2

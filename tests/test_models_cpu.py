@@ -296,3 +296,26 @@ def test_mask_postprocess_of_selected_queries_equals_rows_of_the_full_result():
     part = post([{}], outputs, orig, sizes, return_probs=True, results_mask=[keep])[0]["masks"]
     # (the bilinear resize of a 4-channel and a 12-channel tensor may round differently in the last bit)
     assert part.shape[0] == 4 and torch.allclose(part, full[keep], atol=1e-6, rtol=0)
+
+
+def test_filler_track_queries_do_not_change_the_real_queries(oracle_op):
+    """GraphedDetector rounds the track-query count up with filler queries (`track_query_filler`, masked as keys of the
+    decoder's query self-attention) and drops their rows: on the CPU, through nn.MultiheadAttention's key_padding_mask,
+    the real rows must equal the unpadded forward."""
+    model, post, args = um.build("cfg2_deformable_tracking", factory.build_model, config.make_args)
+    model.tracking()
+    img, prev, target = um.model_inputs("cfg2_deformable_tracking", args.hidden_dim)
+    n = target[0]['track_query_hs_embeds'].shape[0]
+    extra = 16 - n
+    padded = [dict(target[0],
+                   track_query_hs_embeds=torch.cat([target[0]['track_query_hs_embeds'], torch.zeros(extra, args.hidden_dim)]),
+                   track_query_boxes=torch.cat([target[0]['track_query_boxes'],
+                                                torch.tensor([0.5, 0.5, 0.1, 0.1]).expand(extra, 4)]),
+                   track_query_filler=torch.arange(16) >= n)]
+    with torch.no_grad():
+        ref, *_ = model(img, [dict(target[0])], None)
+        out, *_ = model(img, padded, None)
+    keep = torch.cat([torch.arange(n), torch.arange(16, 16 + model.num_queries)])
+    for k in ('pred_logits', 'pred_boxes', 'hs_embed'):
+        assert out[k].shape[1] == 16 + model.num_queries
+        assert torch.allclose(out[k][:, keep], ref[k], atol=2e-5, rtol=1e-5), k
