@@ -13,6 +13,7 @@
  *
  *   tf_linear_split_f32    nn.Linear (+ ReLU) of the encoder / decoder (ms_deform_attn.py:64-88,
  *                          deformable_transformer.py:282-297) as a bf16 split product on the matrix cores
+ *   tf_linear_packed_f32   the same product with the weight packed once in fragment order (+ tf_linear_pack_weight_f32)
  *   tf_mha_core_f32        softmax(q k^T * scale) v of the decoder's query self-attention
  *                          (deformable_transformer.py:364-383, nn.MultiheadAttention): one launch, fp32
  *
@@ -53,6 +54,19 @@ int tf_add_layernorm_f32(const float *x, const float *res, const float *gamma, c
  */
 int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
                         int64_t M, int K, int N, int relu, void *stream);
+
+/*
+ * The same product with the weight in PACKED form (trackformer_amd/csrc/linear_stream.hip): the weight is split into
+ * bf16 (hi, mid) once and stored in matrix-core fragment order, so that the GEMM streams it from L2 into registers and
+ * only the activations pass through LDS.  Results are bit-identical to tf_linear_split_f32.
+ *   tf_linear_packed_bytes(K, N)          size of the packed buffer (N padded to a multiple of 256), or -1; K % 16 == 0
+ *   tf_linear_pack_weight_f32(w, packed)  w [N, K] fp32 row-major -> packed (16-byte aligned pointers); one small kernel
+ *   tf_linear_packed_f32                  y[M, N] = x[M, K] . w^T + bias, ReLU if relu != 0; K % 64 == 0, 16-byte aligned x
+ */
+int64_t tf_linear_packed_bytes(int K, int N);
+int tf_linear_pack_weight_f32(const float *w, void *packed, int K, int N, void *stream);
+int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias, float *y, int64_t M, int K, int N,
+                         int relu, void *stream);
 
 /*
  * out[n, l, h, :] = sum_j softmax_j(scale * q[n, l, h, :] . k[n, j, h, :]) v[n, j, h, :]      (fp32)

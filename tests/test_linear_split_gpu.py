@@ -63,6 +63,58 @@ def test_split_linear_matches_float64(dev, split_on, M, K, N, bias, relu):
         assert float(err.max()) < 0.05 * float((plain - ref).abs().max())
 
 
+PACKED_SHAPES = [   # M, K, N, bias, relu, row block of the weight or None, row tiles per block (0 = per shape)
+    (22223, 256, 1024, True, True, None, 0),        # FFN linear1 + ReLU at the cfg-2 encoder
+    (22223, 1024, 256, True, False, None, 0),       # FFN linear2
+    (22223, 256, 256, True, False, None, 0),        # (shapes the dispatcher keeps on the unpacked kernel run here through
+    (22223, 256, 384, True, False, None, 0),        #  the monkeypatched policy) N not a multiple of the 256-column block
+    (5000, 256, 1024, True, True, None, 2),
+    (5000, 1024, 256, True, False, None, 3),
+    (4500, 256, 256, False, False, None, 4),
+    (4100, 256, 1024, True, False, (128, 648), 0),  # a row block of a packed projection (in_proj_weight style)
+    (4097, 64, 40, True, True, None, 0),            # one row past a whole block, K of one unrolled pair of slices
+]
+
+
+@pytest.mark.parametrize("M,K,N,bias,relu,rows,ti", PACKED_SHAPES, ids=["%dx%dx%d" % s[:3] for s in PACKED_SHAPES])
+def test_packed_linear_is_bit_identical_to_the_unpacked_kernel(dev, split_on, monkeypatch, M, K, N, bias, relu, rows, ti):
+    """tf_linear_packed_f32 (weight packed once in fragment order, csrc/linear_stream.hip) accumulates in the order of
+    tf_linear_split_f32: same bits, for every block shape, at the edges of M and N, for row blocks of the weight."""
+    from trackformer_amd import _cabi
+    # every shape through the packed kernel, whatever the dispatcher would pick
+    monkeypatch.setattr(split_on, "_use_packed", lambda m, k, n: split_on._packed_linear and k % 64 == 0)
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    n_out = N if rows is None else rows[1] - rows[0]
+    b = torch.randn(n_out, generator=g).to(dev) if bias else None
+    prev_packed = split_on.set_packed_linear(False)
+    prev_ti = _cabi.lib().tf_msda_set_option(b"linear_stream_ti", ti)
+    try:
+        want = split_on.linear(x, w, b, relu=relu, rows=rows)
+        split_on.set_packed_linear(True)
+        got = split_on.linear(x, w, b, relu=relu, rows=rows)
+        assert getattr(w, "_tf_packed", None) is not None     # the packed path ran
+        again = split_on.linear(x, w, b, relu=relu, rows=rows)   # from the cached packed weight
+    finally:
+        split_on.set_packed_linear(prev_packed)
+        _cabi.lib().tf_msda_set_option(b"linear_stream_ti", prev_ti)
+    assert want is not None and got is not None and got.shape == (M, n_out)
+    assert torch.equal(got, want) and torch.equal(again, want)
+    w.mul_(2.0)                                                # an in-place update invalidates the cached image
+    split_on.set_packed_linear(True)
+    try:
+        doubled = split_on.linear(x, w, None, rows=rows)
+    finally:
+        split_on.set_packed_linear(prev_packed)
+    split_on.set_packed_linear(False)
+    try:
+        want2 = split_on.linear(x, w, None, rows=rows)
+    finally:
+        split_on.set_packed_linear(prev_packed)
+    assert torch.equal(doubled, want2)
+
+
 def test_split_linear_declines_what_it_cannot_do(dev, split_on):
     x = torch.randn(10, 48, device=dev)
     assert split_on.linear(x, torch.randn(8, 48, device=dev)) is None             # K % 32 != 0
@@ -85,3 +137,17 @@ def test_model_and_tracker_goldens_hold_with_split_linears(dev, split_on):
     shared.compare_to_golden(case, model, out, res, feats, box_tol=1e-3, logit_tol=1e-3)
     tracker, rows, active, inactive = shared.run_tracker(False, device=dev)
     shared.compare_tracker_to_golden(False, tracker, rows, active, inactive, box_tol_px=0.64)
+
+
+def test_packed_linear_dispatch(dev, split_on):
+    """Only the shapes the packed kernel measured faster on go to it (trackformer_amd/fused.py: _use_packed)."""
+    assert split_on._use_packed(22223, 256, 1024) and split_on._use_packed(22223, 1024, 256)
+    assert not split_on._use_packed(22223, 256, 256) and not split_on._use_packed(22223, 256, 384)
+    assert not split_on._use_packed(400, 256, 1024)            # decoder: few rows
+    assert not split_on._use_packed(30000, 288, 1024)          # hidden 288: K not a multiple of 64
+    assert not split_on._use_packed(30000, 1024, 288)          # second 256-column block nearly empty
+    prev = split_on.set_packed_linear(False)
+    try:
+        assert not split_on._use_packed(22223, 256, 1024)
+    finally:
+        split_on.set_packed_linear(prev)

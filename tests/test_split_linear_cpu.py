@@ -80,3 +80,20 @@ def test_split_pieces_are_cached_on_the_tensor_not_by_address():
         a.mul_(0).add_(torch.randn(8, 32))                  # new values at the old address
     hi_b = fused._split_weight(b)[0]
     assert torch.equal(hi_b, b.to(torch.bfloat16)) and not torch.equal(hi_b, hi_a)
+
+
+def test_packed_kernel_dispatch_policy():
+    """Which call shapes go to tf_linear_packed_f32 (fused._use_packed): many rows, K % 64 == 0, a wide output or a long K,
+    256-column blocks mostly full -- the FFN linears of the hidden-256 encoder, nothing else."""
+    from trackformer_amd import fused
+    prev = fused.set_packed_linear(True)
+    try:
+        assert fused._use_packed(22223, 256, 1024) and fused._use_packed(22223, 1024, 256)
+        assert not fused._use_packed(22223, 256, 256) and not fused._use_packed(22223, 256, 384)
+        assert not fused._use_packed(400, 256, 1024)       # decoder: few rows
+        assert not fused._use_packed(30000, 288, 1024)     # hidden 288: K not a multiple of 64
+        assert not fused._use_packed(30000, 1024, 288)     # second 256-column block nearly empty
+        fused.set_packed_linear(False)
+        assert not fused._use_packed(22223, 256, 1024)
+    finally:
+        fused.set_packed_linear(prev)

@@ -1,7 +1,10 @@
 // tools/linear_bench.cpp -- standalone (no Python, no torch) parity + timing harness for tf_linear_split_f32
 // (include/tf_fused.h): Y[M, N] = X[M, K] . W[N, K]^T + bias as a bf16 split product on the matrix cores.
 //
-//   tools/bin/linear_bench [M K N]     (built by trackformer_amd/build.py; default 22223 256 256)
+//   tools/bin/linear_bench [M K N [variant | packed | packedTI]]   (built by trackformer_amd/build.py; default 22223 256 256)
+//     variant: block shape of tf_linear_split_f32 (0..6); packed / packed2 / packed3 / packed4: tf_linear_packed_f32
+//     (weight packed once by tf_linear_pack_weight_f32; the digit forces the row tiles per block), whose output is
+//     also compared BIT FOR BIT with tf_linear_split_f32's
 //
 // Checks a sample of output rows (all columns, incl. the block edges) against a double-precision reference and
 // times 20 launches captured in one HIP graph.  Round-1 numbers: profiles/r01_split_gemm_experiment.txt.
@@ -46,7 +49,9 @@ static float bf16_to_f32(unsigned short h)
 int main(int argc, char **argv)
 {
     const int M = argc > 3 ? atoi(argv[1]) : 22223, K = argc > 3 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 256;
-    if (argc > 4) tf_msda_set_option("linear_variant", atoi(argv[4]));   // block shape / pipelining variant
+    const bool packed = argc > 4 && strncmp(argv[4], "packed", 6) == 0;
+    if (packed && argv[4][6]) tf_msda_set_option("linear_stream_ti", atoi(argv[4] + 6));
+    if (argc > 4 && !packed) tf_msda_set_option("linear_variant", atoi(argv[4]));   // block shape / pipelining variant
     if (K % 32) {
         fprintf(stderr, "K must be a multiple of 32\n");
         return 2;
@@ -76,10 +81,48 @@ int main(int argc, char **argv)
     CK(hipMemset(dY, 0xFF, Y.size() * 4));
     hipStream_t stream;
     CK(hipStreamCreate(&stream));
-    auto run = [&]() { return tf_linear_split_f32(dX, dWhi, dWmid, dB, dY, M, K, N, 0, stream); };
+    void *dWp = nullptr;
+    float *dW = nullptr;
+    long long not_identical = -1;
+    if (packed) {
+        const int64_t bytes = tf_linear_packed_bytes(K, N);
+        if (bytes <= 0 || (K % 64)) {
+            fprintf(stderr, "packed: K must be a multiple of 64\n");
+            return 2;
+        }
+        CK(hipMalloc(&dWp, (size_t)bytes));
+        CK(hipMalloc(&dW, W.size() * 4));
+        CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+        int prc = tf_linear_pack_weight_f32(dW, dWp, K, N, stream);
+        if (prc != 0) {
+            fprintf(stderr, "tf_linear_pack_weight_f32 failed: %s\n", tf_msda_strerror(prc));
+            return 2;
+        }
+        // the unpacked kernel's output first: the packed one must reproduce it bit for bit
+        prc = tf_linear_split_f32(dX, dWhi, dWmid, dB, dY, M, K, N, 0, stream);
+        if (prc != 0) return 2;
+        CK(hipStreamSynchronize(stream));
+        std::vector<float> Y0(Y.size());
+        CK(hipMemcpy(Y0.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemset(dY, 0xFF, Y.size() * 4));
+        prc = tf_linear_packed_f32(dX, dWp, dB, dY, M, K, N, 0, stream);
+        if (prc != 0) {
+            fprintf(stderr, "tf_linear_packed_f32 failed: %s\n", tf_msda_strerror(prc));
+            return 2;
+        }
+        CK(hipStreamSynchronize(stream));
+        CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
+        not_identical = 0;
+        for (size_t i = 0; i < Y.size(); ++i) not_identical += memcmp(&Y[i], &Y0[i], 4) != 0;
+        CK(hipMemset(dY, 0xFF, Y.size() * 4));
+    }
+    auto run = [&]() {
+        return packed ? tf_linear_packed_f32(dX, dWp, dB, dY, M, K, N, 0, stream)
+                      : tf_linear_split_f32(dX, dWhi, dWmid, dB, dY, M, K, N, 0, stream);
+    };
     int rc = run();
     if (rc != 0) {
-        fprintf(stderr, "tf_linear_split_f32 failed: %s\n", tf_msda_strerror(rc));
+        fprintf(stderr, "%s failed: %s\n", packed ? "tf_linear_packed_f32" : "tf_linear_split_f32", tf_msda_strerror(rc));
         return 2;
     }
     CK(hipStreamSynchronize(stream));
@@ -100,8 +143,13 @@ int main(int argc, char **argv)
             ++checked;
         }
     }
-    printf("tf_linear_split_f32 variant %s M=%d K=%d N=%d: checked %lld outputs, max |err| %.3g (max |ref| %.3g), outside 1e-3: %lld\n", argc > 4 ? argv[4] : "default", M, K, N,
-           checked, max_err, max_ref, bad);
+    printf("%s variant %s M=%d K=%d N=%d: checked %lld outputs, max |err| %.3g (max |ref| %.3g), outside 1e-3: %lld\n",
+           packed ? "tf_linear_packed_f32" : "tf_linear_split_f32", argc > 4 ? argv[4] : "default", M, K, N, checked, max_err,
+           max_ref, bad);
+    if (packed) {
+        printf("  outputs that differ from tf_linear_split_f32's bit pattern: %lld of %zu\n", not_identical, Y.size());
+        if (not_identical) bad += not_identical;
+    }
     // ---- timing: 20 launches in one graph
     hipGraph_t graph;
     hipGraphExec_t gexec;

@@ -30,6 +30,9 @@ EXPORTED_SYMBOLS = (
     "tf_bias_act_f32",
     "tf_add_layernorm_f32",
     "tf_linear_split_f32",
+    "tf_linear_packed_bytes",
+    "tf_linear_pack_weight_f32",
+    "tf_linear_packed_f32",
     "tf_mha_core_f32",
 )
 
@@ -84,6 +87,12 @@ def lib():
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_linear_split_f32.restype = ci
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_packed_bytes.restype = ctypes.c_int64
+    L.tf_linear_packed_bytes.argtypes = [ci, ci]
+    L.tf_linear_pack_weight_f32.restype = ci
+    L.tf_linear_pack_weight_f32.argtypes = [vp, vp, ci, ci, vp]
+    L.tf_linear_packed_f32.restype = ci
+    L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_mha_core_f32.restype = ci
     L.tf_mha_core_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [ctypes.c_float, vp]
     if L.tf_msda_abi_version() != ABI_VERSION:

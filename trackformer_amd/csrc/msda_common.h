@@ -47,6 +47,8 @@ void pquad_set_trace(unsigned long long *device_buffer);
 
 // linear_split.hip: block shape / pipelining variant of tf_linear_split_f32; returns the previous one
 int linear_set_variant(int v);
+// linear_stream.hip: row tiles per block of tf_linear_packed_f32 (2..4; 0 = per shape); returns the previous value
+int linear_stream_set_ti(int v);
 
 }  // namespace tfm
 

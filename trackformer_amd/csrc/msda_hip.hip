@@ -2403,6 +2403,7 @@ int tf_msda_set_option(const char *name, int value)
             return prev;
         }
     if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);
+    if (strcmp(name, "linear_stream_ti") == 0) return linear_stream_set_ti(value);
     if (strncmp(name, "pquad", 5) == 0) {
         const int prev = pquad_set_option(name, value);
         return prev == -1 ? INT_MIN : prev;

@@ -97,6 +97,55 @@ def set_split_linear(on):
     return prev
 
 
+# The same product with the weight packed once in matrix-core fragment order (tf_linear_packed_f32,
+# csrc/linear_stream.hip): bit-identical results.  Used where it measured faster (profiles/r02_split_gemm_packed.txt):
+# many rows and a wide output or a long K -- the FFN linears of the encoder (22 223 x 256 -> 1024: 76.2 -> 59.3 us,
+# 1024 -> 256: 63.6 -> 50.5 us).  TF_LINEAR_PACKED=0 / set_packed_linear(False): the unpacked kernel everywhere.
+_packed_linear = os.environ.get("TF_LINEAR_PACKED", "1") not in ("", "0")
+_PACKED_MIN_ROWS = 4096
+
+
+def _use_packed(M, K, N):
+    """Shapes tf_linear_packed_f32 is the faster kernel for: its 256-column blocks must be mostly full."""
+    if not _packed_linear or M <= _PACKED_MIN_ROWS or K % 64:
+        return False
+    tail = N % 256
+    return (N >= 512 or K >= 512) and (tail == 0 or tail > 128)
+
+
+def set_packed_linear(on):
+    """Switch the packed-weight kernel for the many-row linears on or off (process-wide); returns the previous setting."""
+    global _packed_linear
+    prev, _packed_linear = _packed_linear, bool(on)
+    return prev
+
+
+def _packed_weight(weight, rows):
+    """Fragment-order (hi, mid) image of `weight` (or of its row block `rows`), built by tf_linear_pack_weight_f32 and
+    cached on the tensor object with its version counter, like _split_weight below."""
+    cache = getattr(weight, "_tf_packed", None)
+    if cache is None or cache[0] != weight._version:
+        cache = (weight._version, {})
+        weight._tf_packed = cache
+    hit = cache[1].get(rows)
+    if hit is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None   # never build a cached buffer inside a graph's memory pool: this call takes the unpacked kernel
+        N, K = weight.shape
+        a, b = (0, N) if rows is None else rows
+        nbytes = _cabi.lib().tf_linear_packed_bytes(K, b - a)
+        if nbytes <= 0:
+            return None
+        w = weight.detach()
+        with torch.cuda.device(weight.device):
+            hit = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+            rc = _cabi.lib().tf_linear_pack_weight_f32(w.data_ptr() + a * K * 4, hit.data_ptr(), K, b - a,
+                                                       _stream(weight.device))
+        _cabi.check(rc, "tf_linear_pack_weight_f32")
+        cache[1][rows] = hit
+    return hit
+
+
 def _split_weight(weight):
     """(w_hi, w_mid) bf16 pieces of an fp32 weight.  Cached ON THE TENSOR OBJECT together with its version counter
     (weights are constants in inference; an in-place update bumps the version).  Not keyed by data_ptr: a freed
@@ -135,6 +184,16 @@ def linear(x, weight, bias=None, relu=False, rows=None):
     x2 = x.reshape(-1, K)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
+    if _use_packed(x2.shape[0], K, N) and not (x2.data_ptr() & 15):
+        packed = _packed_weight(weight, rows)
+        if packed is not None:
+            with torch.cuda.device(x.device):
+                y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
+                rc = _cabi.lib().tf_linear_packed_f32(x2.data_ptr(), packed.data_ptr(),
+                                                      0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0],
+                                                      K, N, 1 if relu else 0, _stream(x.device))
+            _cabi.check(rc, "tf_linear_packed_f32")
+            return y.view(*x.shape[:-1], N)
     hi, mid = _split_weight(weight)
     if rows is not None:
         hi, mid = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]]   # views: a row block is contiguous
