@@ -10,6 +10,7 @@
 // times 20 launches captured in one HIP graph.  Round-1 numbers: profiles/r01_split_gemm_experiment.txt.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -50,7 +51,8 @@ int main(int argc, char **argv)
 {
     const int M = argc > 3 ? atoi(argv[1]) : 22223, K = argc > 3 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 256;
     const bool packed = argc > 4 && strncmp(argv[4], "packed", 6) == 0;
-    if (packed && argv[4][6]) tf_msda_set_option("linear_stream_ti", atoi(argv[4] + 6));
+    if (packed && argv[4][6] == 'a') tf_msda_set_option("linear_astat", atoi(argv[4] + 7));   // packeda3: activation-stationary
+    else if (packed && argv[4][6]) tf_msda_set_option("linear_stream_ti", atoi(argv[4] + 6));
     if (argc > 4 && !packed) tf_msda_set_option("linear_variant", atoi(argv[4]));   // block shape / pipelining variant
     if (K % 32) {
         fprintf(stderr, "K must be a multiple of 32\n");
@@ -149,6 +151,46 @@ int main(int argc, char **argv)
     if (packed) {
         printf("  outputs that differ from tf_linear_split_f32's bit pattern: %lld of %zu\n", not_identical, Y.size());
         if (not_identical) bad += not_identical;
+    }
+    if (packed && getenv("LINEAR_BENCH_TRACE")) {   // phase timestamps of the activation-stationary kernel (one launch)
+        const int nb = 4096;
+        unsigned long long *d_tr;
+        CK(hipMalloc(&d_tr, (size_t)nb * 16 * 8));
+        CK(hipMemset(d_tr, 0, (size_t)nb * 16 * 8));
+        tf_msda_debug_trace_buffer(d_tr);
+        run();
+        CK(hipStreamSynchronize(stream));
+        tf_msda_debug_trace_buffer(nullptr);
+        std::vector<unsigned long long> tr((size_t)nb * 16);
+        CK(hipMemcpy(tr.data(), d_tr, tr.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        int used = 0;
+        for (int b = 0; b < nb; ++b)
+            if (tr[(size_t)b * 16]) {
+                t0 = std::min(t0, tr[(size_t)b * 16]);
+                used = b + 1;
+            }
+        static const char *names[14] = {"entry", "loads issued", "A converted", "barrier passed", "slice 0", "slice 1", "slice 3",
+                                        "slice 7 (col block 0)", "stores issued (col block 0)", "col block 1 done", "col block 2 done",
+                                        "col block 3 done", "all issued", "stores acknowledged"};
+        printf("  trace of %d blocks (us after the first block's entry; 100 MHz clock): mean / min / max over blocks\n", used);
+        for (int i = 0; i < 14; ++i) {
+            double sum = 0, mn = 1e30, mx = -1;
+            int n = 0;
+            for (int b = 0; b < used; ++b) {
+                const unsigned long long t = tr[(size_t)b * 16 + i];
+                if (!t) continue;
+                const double us = (double)(t - t0) * 0.01;
+                sum += us; mn = std::min(mn, us); mx = std::max(mx, us); ++n;
+            }
+            if (n) printf("    %-28s %7.2f %7.2f %7.2f   (%d blocks)\n", names[i], sum / n, mn, mx, n);
+        }
+        for (int b = 0; b < used; b += std::max(1, used / 6)) {
+            printf("    block %4d:", b);
+            for (int i = 0; i < 14; ++i) printf(" %6.2f", tr[(size_t)b * 16 + i] ? (double)(tr[(size_t)b * 16 + i] - t0) * 0.01 : -1.0);
+            printf("\n");
+        }
+        CK(hipFree(d_tr));
     }
     // ---- timing: 20 launches in one graph
     hipGraph_t graph;

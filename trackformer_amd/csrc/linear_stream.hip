@@ -236,6 +236,179 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
     }
 }
 
+// ---- activation-stationary variant for K == 256 (the encoder's hidden size): the block's whole activation tile
+// (32 TI rows x 256 k, split into bf16 hi / mid: 528-byte rows, conflict-free for the fragment reads) is staged in LDS
+// ONCE -- all of its global loads are issued back to back at kernel start, the most memory-level parallelism a block
+// can have -- and then every column block of the output is computed from it: no barrier after the staging one, the
+// waves run free, the only streams are the weight fragments (L2 -> registers, one K-slice ahead, across column-block
+// boundaries) and the output stores, which overlap with the next column block's matrix work.  For N = 1024 the
+// activations are read and split once instead of four times.  One block per CU (101 KB of LDS at TI = 3), one round:
+// 232 blocks for 22 223 rows.
+constexpr int kAK = 256, kAStride = kAK + 8, kASlices = kAK / kSlice;
+
+template <int TI, bool RELU>
+__global__ void __launch_bounds__(kThreads, 1)
+split_gemm_astat_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias,
+                        float *__restrict__ Y, int M, int N, int nblocks, unsigned long long *trace)
+{
+    // debug (tf_msda_debug_trace_buffer): 16 timestamps (s_memrealtime, 100 MHz) of wave 0 per block
+    auto stamp = [&](int i) {
+        if (trace != nullptr && threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    constexpr int BM = TI * 32, KQ = kAK >> 4;
+    constexpr int NV = BM * (kAK / 4) / kThreads;   // float4 per thread: a wave covers one row (1 KB) per step
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_a[];   // [hi | mid][BM][kAStride]
+    unsigned short *const sHi = s_a, *const sMid = s_a + BM * kAStride;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+
+    // ---- weights of the first slice first (they have the longest way), then the whole activation tile
+    auto wptr = [&](int nb, int j) { return Wp + ((size_t)(nb * 4 * kTJ + wave * kTJ + j) * KQ * 2) * 64 + lane; };
+    auto load_w = [&](int nb, int sl, WFrags &w) {
+#pragma unroll
+        for (int j = 0; j < kTJ; ++j) {
+            const u32x4 *base = wptr(nb, j) + (size_t)sl * 4 * 64;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) w.v[j][kk][p] = base[(kk * 2 + p) * 64];
+        }
+    };
+    // Weight fragments: a ring of 4 register sets, loaded 3 K-slices ahead of their use (across column-block boundaries).
+    // One slice of prefetch distance left the waves waiting on L2 for 2/3 of their time (profiles/r02_split_gemm_packed_pmc.txt:
+    // SQ_WAIT_ANY 65 % of SQ_WAVE_CYCLES, 24 M TCP_PENDING_STALL_CYCLES): with 4 waves per CU and 8 KB per wave in flight the
+    // L2 -> L1 stream is latency bound (Little's law), so keep 24 KB per wave in flight instead.
+    // The column blocks are visited in an order rotated by the block id, so that neighbouring CUs do not ask the same L2
+    // lines for the same weight slice at the same moment.
+    const int rot = blockIdx.x % nblocks;
+    auto nb_at = [&](int v) { int nb = v + rot; return nb >= nblocks ? nb - nblocks : nb; };   // v-th column block visited
+    WFrags w[4];
+    load_w(nb_at(0), 0, w[0]);
+    load_w(nb_at(0), 1, w[1]);
+    load_w(nb_at(0), 2, w[2]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        f32x4 xr[NV];
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int row = it * 4 + wave;
+            const int grow = min(m0 + row, M - 1);   // rows past M read the last row, never stored
+            xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * kAK + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all NV loads in flight before the first conversion waits
+        stamp(1);
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int row = it * 4 + wave;
+            bf16x4 hi, mid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = (__bf16)xr[it][e];
+                mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
+            }
+            *reinterpret_cast<bf16x4 *>(&sHi[row * kAStride + lane * 4]) = hi;
+            *reinterpret_cast<bf16x4 *>(&sMid[row * kAStride + lane * 4]) = mid;
+        }
+    }
+    stamp(2);
+    __syncthreads();
+    stamp(3);
+
+    const int arow = (lane & 31) * kAStride + (lane >> 5) * 8;
+    for (int v = 0; v < nblocks; ++v) {
+        const int nb = nb_at(v);
+        const int ncol0 = nb * kBN + wave * kTJ * 32;
+        f32x16 acc[TI][kTJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < kTJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int nb_next = nb_at(min(v + 1, nblocks - 1));   // after the last block: a harmless reload
+        auto slice = [&](auto slc) {
+            constexpr int sl = decltype(slc)::value;
+            constexpr int ahead = sl + 3;
+            if constexpr (ahead < kASlices) load_w(nb, ahead, w[ahead & 3]);
+            else load_w(nb_next, ahead - kASlices, w[ahead & 3]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the loads at the head of the slice (see split_gemm_stream_kernel)
+            const WFrags &cur = w[sl & 3];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int koff = sl * kSlice + kk * 16;
+                bf16x8 a_hi[TI], a_mid[TI], b_hi[kTJ], b_mid[kTJ];
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sHi[i * 32 * kAStride + arow + koff]);
+                    a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sMid[i * 32 * kAStride + arow + koff]);
+                }
+#pragma unroll
+                for (int j = 0; j < kTJ; ++j) {
+                    b_hi[j] = __builtin_bit_cast(bf16x8, cur.v[j][kk][0]);
+                    b_mid[j] = __builtin_bit_cast(bf16x8, cur.v[j][kk][1]);
+                }
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < kTJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid[i], b_hi[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < kTJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_mid[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TI; ++i)
+#pragma unroll
+                    for (int j = 0; j < kTJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        static_assert(kASlices == 8, "the slice loop is written out for K = 256");
+        slice(std::integral_constant<int, 0>{});
+        if (v == 0) stamp(4);
+        slice(std::integral_constant<int, 1>{});
+        if (v == 0) stamp(5);
+        slice(std::integral_constant<int, 2>{});
+        slice(std::integral_constant<int, 3>{});
+        if (v == 0) stamp(6);
+        slice(std::integral_constant<int, 4>{});
+        slice(std::integral_constant<int, 5>{});
+        slice(std::integral_constant<int, 6>{});
+        slice(std::integral_constant<int, 7>{});   // the ring now holds slices 0..2 of the next column block
+        if (v == 0) stamp(7);
+        if (v == 1) stamp(9);
+        if (v == 2) stamp(10);
+        if (v == 3) stamp(11);
+        if (ncol0 >= N) continue;   // a wave whose columns lie past N (N % 256 != 0) computed zeros: nothing to store
+#pragma unroll
+        for (int j = 0; j < kTJ; ++j) {
+            const int col = ncol0 + j * 32 + (lane & 31);
+            if (col >= N) continue;
+            const float b = bias ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (row < M) {
+                        float v = acc[i][j][e] + b;
+                        if (RELU) v = v > 0.f ? v : 0.f;
+                        Y[(size_t)row * N + col] = v;
+                    }
+                }
+        }
+        if (v == 0) stamp(8);
+    }
+    stamp(12);
+    if (trace != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the stores have been acknowledged
+        stamp(13);
+    }
+}
+
 int num_cus()
 {
     static const int n = [] {
@@ -250,6 +423,20 @@ int num_cus()
 }
 
 std::atomic<int> g_ti{-1};   // -1: TF_LINEAR_STREAM_TI or automatic (0)
+std::atomic<unsigned long long *> g_trace{nullptr};   // tf_msda_debug_trace_buffer
+std::atomic<int> g_astat{-1};   // -1: TF_LINEAR_ASTAT or the default (0: off, 2..4: on with that many row tiles)
+
+int astat_ti()
+{
+    int v = g_astat.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_LINEAR_ASTAT");
+        v = e ? atoi(e) : 0;
+        if (v < 2 || v > 4) v = 0;
+        g_astat.store(v);
+    }
+    return v;
+}
 
 int forced_ti()
 {
@@ -289,9 +476,36 @@ int launch_stream(const float *x, const u32x4 *wp, const float *bias, float *y, 
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
+template <int TI>
+int launch_astat(const float *x, const u32x4 *wp, const float *bias, float *y, int M, int N, int relu, hipStream_t s)
+{
+    const int mblocks = (M + 32 * TI - 1) / (32 * TI), nblocks = (N + kBN - 1) / kBN;
+    const size_t lds = 2 * (size_t)(32 * TI) * kAStride * 2;
+    const void *fn = relu ? (const void *)&split_gemm_astat_kernel<TI, true> : (const void *)&split_gemm_astat_kernel<TI, false>;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned> raised[2];   // bit per device, per kernel
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 32 || !(raised[relu ? 1 : 0].load() & (1u << dev))) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+            if (dev < 32) raised[relu ? 1 : 0].fetch_or(1u << dev);
+        }
+    }
+    unsigned long long *trace = g_trace.load(std::memory_order_relaxed);
+    void *argv[] = {(void *)&x, (void *)&wp, (void *)&bias, (void *)&y, (void *)&M, (void *)&N, (void *)&nblocks, (void *)&trace};
+    return hipLaunchKernel(fn, dim3((unsigned)mblocks), dim3(kThreads), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
 }  // namespace
 
 namespace tfm {
+void linear_set_trace(unsigned long long *device_buffer) { g_trace.store(device_buffer); }
+int linear_astat_set(int v)
+{
+    const int prev = astat_ti();
+    g_astat.store(v >= 2 && v <= 4 ? v : 0);
+    return prev;
+}
 int linear_stream_set_ti(int v)
 {
     const int prev = forced_ti();
@@ -329,6 +543,14 @@ extern "C" int tf_linear_packed_f32(const float *x, const void *w_packed, const 
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed)) & 15) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *wp = static_cast<const u32x4 *>(w_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (K == kAK) {
+        switch (astat_ti()) {
+        case 2: return launch_astat<2>(x, wp, bias, y, (int)M, N, relu, s);
+        case 3: return launch_astat<3>(x, wp, bias, y, (int)M, N, relu, s);
+        case 4: return launch_astat<4>(x, wp, bias, y, (int)M, N, relu, s);
+        default: break;
+        }
+    }
     switch (choose_ti(K)) {
     case 2: return launch_stream<2>(x, wp, bias, y, (int)M, K, N, relu, s);
     case 4: return launch_stream<4>(x, wp, bias, y, (int)M, K, N, relu, s);

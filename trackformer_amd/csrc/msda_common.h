@@ -49,6 +49,9 @@ void pquad_set_trace(unsigned long long *device_buffer);
 int linear_set_variant(int v);
 // linear_stream.hip: row tiles per block of tf_linear_packed_f32 (2..4; 0 = per shape); returns the previous value
 int linear_stream_set_ti(int v);
+// linear_stream.hip: activation-stationary kernel for K == 256 (0 = off, 2..4 = row tiles per block); returns the previous value
+int linear_astat_set(int v);
+void linear_set_trace(unsigned long long *device_buffer);   // debug timestamps of the activation-stationary kernel
 
 }  // namespace tfm
 

@@ -2389,6 +2389,7 @@ void tf_msda_debug_trace_buffer(void *device_buffer)
 {
     g_quad_trace.store(static_cast<unsigned long long *>(device_buffer));
     pquad_set_trace(static_cast<unsigned long long *>(device_buffer));
+    linear_set_trace(static_cast<unsigned long long *>(device_buffer));
 }
 
 int tf_msda_set_option(const char *name, int value)
@@ -2404,6 +2405,7 @@ int tf_msda_set_option(const char *name, int value)
         }
     if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);
     if (strcmp(name, "linear_stream_ti") == 0) return linear_stream_set_ti(value);
+    if (strcmp(name, "linear_astat") == 0) return linear_astat_set(value);
     if (strncmp(name, "pquad", 5) == 0) {
         const int prev = pquad_set_option(name, value);
         return prev == -1 ? INT_MIN : prev;
