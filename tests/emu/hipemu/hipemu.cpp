@@ -1,0 +1,507 @@
+// tests/emu/hipemu/hipemu.cpp -- the fiber engine of the SIMT emulator (see hipemu.h).  TEST INFRASTRUCTURE.
+#include "hipemu.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+
+#include <atomic>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+// ---- context switch (x86-64 System V): callee-saved registers on the old stack, swap stack pointers ------------
+extern "C" void hipemu_switch(void **save_sp, void *load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+
+namespace hipemu {
+
+namespace {
+
+enum State : int { kRunnable, kAtWaveOp, kAtBarrier, kDone };
+
+constexpr size_t kStackBytes = 512 * 1024;
+constexpr size_t kLdsBytes = 160 * 1024;
+constexpr int kWave = 64;
+
+struct PendingWrite {
+    void *dst;
+    unsigned char data[16];
+    int bytes;
+};
+
+}  // namespace
+
+struct Fiber {
+    void *sp = nullptr;
+    unsigned char *stack = nullptr;
+    Dim3 tid;
+    int lane = 0, wave = 0;
+    State state = kDone;
+    OpReq *req = nullptr;
+    std::vector<PendingWrite> pending;
+};
+
+namespace {
+
+struct Engine {
+    std::vector<Fiber> fibers;
+    unsigned char *stacks = nullptr;
+    size_t n_stacks = 0;
+    unsigned char *lds = nullptr;
+    void *sched_sp = nullptr;
+    Fiber *cur = nullptr;
+    Dim3 block_idx, block_dim, grid_dim;
+    const std::function<void()> *body = nullptr;
+    Stats st{};
+    // ds_read_b128 bank-conflict accounting: addresses of the current wave instruction
+    ~Engine()
+    {
+        if (stacks) munmap(stacks, n_stacks * kStackBytes);
+        if (lds) munmap(lds, kLdsBytes + 4096);
+    }
+};
+
+thread_local Engine *t_engine = nullptr;
+Stats g_stats{};
+std::mutex g_stats_mutex;
+
+void fiber_main()
+{
+    Engine *e = t_engine;
+    (*e->body)();
+    Fiber *f = e->cur;
+    for (auto &p : f->pending) memcpy(p.dst, p.data, p.bytes);
+    f->pending.clear();
+    f->state = kDone;
+    hipemu_switch(&f->sp, e->sched_sp);
+    abort();   // a finished fiber is never resumed
+}
+
+void prepare_fiber(Fiber &f)
+{
+    // stack image for hipemu_switch: r15 r14 r13 r12 rbx rbp | return address (fiber_main) | alignment slot
+    uintptr_t top = (uintptr_t)(f.stack + kStackBytes);
+    top &= ~(uintptr_t)15;
+    uint64_t *s = (uint64_t *)top;
+    *--s = 0;                           // keeps (rsp after `ret`) % 16 == 8, as after a call
+    *--s = (uint64_t)(uintptr_t)&fiber_main;
+    for (int i = 0; i < 6; ++i) *--s = 0;
+    f.sp = s;
+}
+
+void run_fiber(Engine *e, Fiber &f)
+{
+    e->cur = &f;
+    ++e->st.switches;
+    hipemu_switch(&e->sched_sp, f.sp);
+    e->cur = nullptr;
+}
+
+void yield_to_scheduler(Engine *e)
+{
+    Fiber *f = e->cur;
+    hipemu_switch(&f->sp, e->sched_sp);
+}
+
+float bf16_to_float(uint16_t b)
+{
+    uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+// Executes one wave operation for the lanes in `grp` (all at the same site and kind).
+void exec_group(Engine *e, Fiber **wave_lanes, int nlanes, const std::vector<int> &grp)
+{
+    ++e->st.wave_ops;
+    uint64_t exec = 0;
+    for (int l : grp) exec |= 1ull << l;
+    OpReq *first = wave_lanes[grp[0]]->req;
+    switch (first->kind) {
+    case kOpSync:
+        break;
+    case kOpShuffle: {
+        // read every source before writing any result (out may alias nothing of another lane, but keep it strict)
+        uint64_t vals[kWave] = {0};
+        for (int l : grp) {
+            OpReq *r = wave_lanes[l]->req;
+            uint64_t v = 0;
+            memcpy(&v, r->in, r->size);
+            vals[l] = v;
+        }
+        for (int l : grp) {
+            OpReq *r = wave_lanes[l]->req;
+            uint64_t v;
+            if (r->src < 0 || r->src >= kWave) {
+                v = r->aux;
+            } else if (!((exec >> r->src) & 1)) {
+                v = 0;   // a disabled source lane: bound_ctrl semantics; counted, the tests require none
+                ++e->st.inactive_reads;
+            } else {
+                v = vals[r->src];
+            }
+            memcpy(r->out, &v, r->size);
+        }
+        break;
+    }
+    case kOpFirstLane: {
+        uint64_t v = 0;
+        memcpy(&v, first->in, first->size);
+        for (int l : grp) memcpy(wave_lanes[l]->req->out, &v, wave_lanes[l]->req->size);
+        break;
+    }
+    case kOpVote: {
+        uint64_t mask = 0;
+        for (int l : grp)
+            if (*(const int *)wave_lanes[l]->req->in) mask |= 1ull << l;
+        for (int l : grp) {
+            *(uint64_t *)wave_lanes[l]->req->out = mask;
+            wave_lanes[l]->req->aux = exec;
+        }
+        break;
+    }
+    case kOpMfma32x32x16Bf16:
+    case kOpMfma16x16x32Bf16: {
+        // in: 8 bf16 of A, in2: 8 bf16 of B, in3: C (16 or 4 floats), out: D.  All 64 lanes must be active.
+        const bool big = first->kind == kOpMfma32x32x16Bf16;
+        const int MN = big ? 32 : 16, K = big ? 16 : 32, NR = big ? 16 : 4;
+        if ((int)grp.size() != kWave) {
+            fprintf(stderr, "hipemu: MFMA with %zu active lanes\n", grp.size());
+            abort();
+        }
+        static thread_local float A[32][32], B[32][32];   // [row][k], [col][k]
+        for (int l = 0; l < kWave; ++l) {
+            const uint16_t *a = (const uint16_t *)wave_lanes[l]->req->in;
+            const uint16_t *b = (const uint16_t *)wave_lanes[l]->req->in2;
+            const int rc = l % MN, k0 = 8 * (l / MN);
+            for (int i = 0; i < 8; ++i) {
+                A[rc][k0 + i] = bf16_to_float(a[i]);
+                B[rc][k0 + i] = bf16_to_float(b[i]);
+            }
+        }
+        for (int l = 0; l < kWave; ++l) {
+            const float *c = (const float *)wave_lanes[l]->req->in3;
+            float d[16];
+            const int col = l % MN;
+            for (int r = 0; r < NR; ++r) {
+                const int row = big ? (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) : 4 * (l >> 4) + r;
+                double acc = 0.0;   // products of bf16 pairs are exact in fp32; the sum is rounded once here
+                for (int k = 0; k < K; ++k) acc += (double)A[row][k] * (double)B[col][k];
+                d[r] = (float)((double)c[r] + acc);
+            }
+            memcpy(wave_lanes[l]->req->out, d, sizeof(float) * NR);
+        }
+        break;
+    }
+    case kOpLdsDma: {
+        // M0 (the LDS base) is wave-uniform: the first active lane's; lane l's data goes to base + l * size
+        unsigned char *base = (unsigned char *)(uintptr_t)first->aux;
+        for (int l : grp) {
+            OpReq *r = wave_lanes[l]->req;
+            Fiber *f = wave_lanes[l];
+            PendingWrite p;
+            p.dst = base + (size_t)l * r->size;
+            p.bytes = r->size;
+            memcpy(p.data, r->in, r->size);
+            f->pending.push_back(p);
+            e->st.lds_dma_bytes += r->size;
+        }
+        break;
+    }
+    default:
+        fprintf(stderr, "hipemu: unknown wave op %d\n", first->kind);
+        abort();
+    }
+    (void)nlanes;
+}
+
+// Runs one workgroup to completion.  Returns false on dead-lock.
+bool run_block(Engine *e, const Dim3 &bidx)
+{
+    const int nthreads = (int)(e->block_dim.x * e->block_dim.y * e->block_dim.z);
+    const int nwaves = (nthreads + kWave - 1) / kWave;
+    e->block_idx = bidx;
+    for (int t = 0; t < nthreads; ++t) {
+        Fiber &f = e->fibers[t];
+        f.tid = Dim3(t % e->block_dim.x, (t / e->block_dim.x) % e->block_dim.y, t / (e->block_dim.x * e->block_dim.y));
+        f.lane = t % kWave;
+        f.wave = t / kWave;
+        f.state = kRunnable;
+        f.req = nullptr;
+        f.pending.clear();
+        prepare_fiber(f);
+    }
+    ++e->st.blocks;
+    std::vector<int> grp;
+    for (;;) {
+        for (int w = 0; w < nwaves; ++w) {
+            Fiber *lanes[kWave] = {nullptr};
+            const int nl = (w + 1) * kWave <= nthreads ? kWave : nthreads - w * kWave;
+            for (int l = 0; l < nl; ++l) lanes[l] = &e->fibers[w * kWave + l];
+            for (;;) {
+                for (int l = 0; l < nl; ++l)
+                    if (lanes[l]->state == kRunnable) run_fiber(e, *lanes[l]);
+                // every lane is now at a wave op, at a barrier, or done
+                int first = -1, nops = 0;
+                for (int l = 0; l < nl; ++l)
+                    if (lanes[l]->state == kAtWaveOp) {
+                        ++nops;
+                        if (first < 0 || lanes[l]->req->site < lanes[first]->req->site) first = l;
+                    }
+                if (first < 0) break;
+                grp.clear();
+                const OpReq *fr = lanes[first]->req;
+                for (int l = 0; l < nl; ++l)
+                    if (lanes[l]->state == kAtWaveOp && lanes[l]->req->site == fr->site && lanes[l]->req->kind == fr->kind)
+                        grp.push_back(l);
+                if ((int)grp.size() != nops) {
+                    ++e->st.divergent_ops;
+                    static const bool debug = getenv("HIPEMU_DEBUG") != nullptr;
+                    if (debug && e->st.divergent_ops <= 5) {
+                        fprintf(stderr, "hipemu: divergent wave op: block %u wave %d, %zu lanes at line %u (kind %d) while",
+                                e->block_idx.x, w, grp.size(), fr->site, fr->kind);
+                        for (int l = 0; l < nl; ++l)
+                            if (lanes[l]->state == kAtWaveOp && lanes[l]->req->site != fr->site)
+                                fprintf(stderr, " lane %d at line %u (kind %d);", l, lanes[l]->req->site, lanes[l]->req->kind);
+                        fprintf(stderr, "\n");
+                    }
+                }
+                exec_group(e, lanes, nl, grp);
+                for (int l : grp) lanes[l]->state = kRunnable;
+            }
+        }
+        int at_barrier = 0, done = 0;
+        for (int t = 0; t < nthreads; ++t) {
+            at_barrier += e->fibers[t].state == kAtBarrier;
+            done += e->fibers[t].state == kDone;
+        }
+        if (done == nthreads) return true;
+        if (at_barrier + done != nthreads) return false;   // cannot happen: the loops above run every lane until it blocks
+        ++e->st.barriers;
+        for (int t = 0; t < nthreads; ++t)
+            if (e->fibers[t].state == kAtBarrier) e->fibers[t].state = kRunnable;
+        // work-items that ended while others still reach barriers are fine (as on the hardware)
+    }
+}
+
+Engine *make_engine(int nthreads)
+{
+    Engine *e = new Engine();
+    e->n_stacks = (size_t)nthreads;
+    e->stacks = (unsigned char *)mmap(nullptr, e->n_stacks * kStackBytes, PROT_READ | PROT_WRITE,
+                                      MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (e->stacks == MAP_FAILED) {
+        perror("hipemu: mmap stacks");
+        abort();
+    }
+    e->lds = (unsigned char *)mmap(nullptr, kLdsBytes + 4096, PROT_READ | PROT_WRITE,
+                                   MAP_PRIVATE | MAP_ANONYMOUS | MAP_32BIT, -1, 0);
+    if (e->lds == MAP_FAILED || (uintptr_t)e->lds + kLdsBytes + 4096 > 0xFFFFFFFFull) {
+        perror("hipemu: mmap LDS arena below 4 GiB");
+        abort();
+    }
+    e->fibers.resize(nthreads);
+    for (int t = 0; t < nthreads; ++t) e->fibers[t].stack = e->stacks + (size_t)t * kStackBytes;
+    return e;
+}
+
+}  // namespace
+
+Fiber *cur() { return t_engine->cur; }
+const Dim3 &thread_idx() { return t_engine->cur->tid; }
+const Dim3 &block_idx() { return t_engine->block_idx; }
+const Dim3 &block_dim() { return t_engine->block_dim; }
+const Dim3 &grid_dim() { return t_engine->grid_dim; }
+int lane_id() { return t_engine->cur->lane; }
+void *dynamic_lds() { return t_engine->lds; }
+
+void barrier()
+{
+    Engine *e = t_engine;
+    e->cur->state = kAtBarrier;
+    yield_to_scheduler(e);
+}
+
+void wave_op(OpReq &r)
+{
+    Engine *e = t_engine;
+    Fiber *f = e->cur;
+    f->req = &r;
+    f->state = kAtWaveOp;
+    yield_to_scheduler(e);
+    f->req = nullptr;
+}
+
+void waitcnt_vm(int vmcnt)
+{
+    Fiber *f = t_engine->cur;
+    if (vmcnt < 0) vmcnt = 0;
+    while ((int)f->pending.size() > vmcnt) {
+        PendingWrite &p = f->pending.front();
+        memcpy(p.dst, p.data, p.bytes);
+        f->pending.erase(f->pending.begin());
+    }
+}
+
+void defer_lds_write(void *dst, const void *src, int bytes)
+{
+    PendingWrite p;
+    p.dst = dst;
+    p.bytes = bytes;
+    memcpy(p.data, src, bytes);
+    t_engine->cur->pending.push_back(p);
+}
+
+uint64_t realtime()
+{
+    static std::atomic<uint64_t> t{0};
+    return t.fetch_add(1) + 1;
+}
+
+int num_cus()
+{
+    static const int n = [] {
+        const char *e = getenv("HIPEMU_CUS");
+        const int v = e ? atoi(e) : 4;
+        return v > 0 ? v : 4;
+    }();
+    return n;
+}
+
+Stats &stats() { return g_stats; }
+void reset_stats()
+{
+    std::lock_guard<std::mutex> g(g_stats_mutex);
+    memset(&g_stats, 0, sizeof(g_stats));
+}
+
+void track_lds_read16(unsigned) {}
+
+int dpp_source_lane(int lane, int ctrl)
+{
+    const int row = lane & ~15, in_row = lane & 15;
+    if (ctrl >= 0x000 && ctrl <= 0x0FF) return (lane & ~3) | ((ctrl >> (2 * (lane & 3))) & 3);
+    if (ctrl >= 0x101 && ctrl <= 0x10F) {   // row_shl:n -- lane i reads lane i + n of its row
+        const int s = in_row + (ctrl & 15);
+        return s < 16 ? row + s : -1;
+    }
+    if (ctrl >= 0x111 && ctrl <= 0x11F) {   // row_shr:n -- lane i reads lane i - n
+        const int s = in_row - (ctrl & 15);
+        return s >= 0 ? row + s : -1;
+    }
+    if (ctrl >= 0x121 && ctrl <= 0x12F) return row + ((in_row - (ctrl & 15)) & 15);   // row_ror:n
+    switch (ctrl) {
+    case 0x130: return lane + 1 < 64 ? lane + 1 : -1;   // wave_shl:1
+    case 0x134: return (lane + 1) & 63;                 // wave_rol:1
+    case 0x138: return lane - 1 >= 0 ? lane - 1 : -1;   // wave_shr:1
+    case 0x13C: return (lane - 1) & 63;                 // wave_ror:1
+    case 0x140: return row + 15 - in_row;               // row_mirror
+    case 0x141: return (lane & ~7) | (7 - (lane & 7));  // row_half_mirror
+    case 0x142: return row > 0 ? row - 1 : -1;          // row_bcast15
+    case 0x143: return lane >= 32 ? 31 : -1;            // row_bcast31
+    default: break;
+    }
+    if (ctrl >= 0x150 && ctrl <= 0x15F) return row + (ctrl & 15);   // row_newbcast:n (gfx90a+)
+    fprintf(stderr, "hipemu: unsupported DPP control 0x%x\n", ctrl);
+    abort();
+}
+
+int launch(Dim3 grid, Dim3 block, size_t dynamic_lds_bytes, const std::function<void()> &body)
+{
+    const int nthreads = (int)(block.x * block.y * block.z);
+    if (nthreads <= 0 || nthreads > 1024 || dynamic_lds_bytes > kLdsBytes) {
+        fprintf(stderr, "hipemu: bad launch (%d threads, %zu B of LDS)\n", nthreads, dynamic_lds_bytes);
+        return -1;
+    }
+    const uint64_t nblocks = (uint64_t)grid.x * grid.y * grid.z;
+    int nhost = 1;
+    if (const char *e = getenv("HIPEMU_THREADS")) nhost = atoi(e);
+    if (nhost < 1) nhost = 1;
+    if ((uint64_t)nhost > nblocks) nhost = (int)nblocks;
+    std::atomic<uint64_t> next{0};
+    std::atomic<int> failed{0};
+    auto worker = [&]() {
+        Engine *e = make_engine(nthreads);
+        t_engine = e;
+        e->block_dim = block;
+        e->grid_dim = grid;
+        e->body = &body;
+        for (;;) {
+            const uint64_t b = next.fetch_add(1);
+            if (b >= nblocks || failed.load()) break;
+            const Dim3 bidx((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((uint64_t)grid.x * grid.y)));
+            if (!run_block(e, bidx)) {
+                fprintf(stderr, "hipemu: workgroup (%u,%u,%u) dead-locked at a barrier\n", bidx.x, bidx.y, bidx.z);
+                failed.store(1);
+                break;
+            }
+        }
+        {
+            std::lock_guard<std::mutex> g(g_stats_mutex);
+            g_stats.wave_ops += e->st.wave_ops;
+            g_stats.barriers += e->st.barriers;
+            g_stats.divergent_ops += e->st.divergent_ops;
+            g_stats.inactive_reads += e->st.inactive_reads;
+            g_stats.lds_dma_bytes += e->st.lds_dma_bytes;
+            g_stats.blocks += e->st.blocks;
+            g_stats.switches += e->st.switches;
+        }
+        t_engine = nullptr;
+        delete e;
+    };
+    if (nhost == 1) {
+        Engine *outer = t_engine;   // (nested launches are not supported; keep the pointer sane anyway)
+        worker();
+        t_engine = outer;
+    } else {
+        std::vector<std::thread> th;
+        for (int i = 0; i < nhost; ++i) th.emplace_back(worker);
+        for (auto &t : th) t.join();
+    }
+    return failed.load() ? -1 : 0;
+}
+
+}  // namespace hipemu
+
+// ---- C entry points for the Python tests ---------------------------------------------------------------------
+extern "C" {
+// out[0..8]: wave_ops, barriers, divergent_ops, inactive_reads, lds_dma_bytes, blocks, switches, lds_b128_reads, lds_b128_cycles
+void hipemu_get_stats(uint64_t *out)
+{
+    const hipemu::Stats &s = hipemu::stats();
+    out[0] = s.wave_ops;
+    out[1] = s.barriers;
+    out[2] = s.divergent_ops;
+    out[3] = s.inactive_reads;
+    out[4] = s.lds_dma_bytes;
+    out[5] = s.blocks;
+    out[6] = s.switches;
+    out[7] = s.lds_b128_reads;
+    out[8] = s.lds_b128_cycles;
+}
+void hipemu_reset_stats(void) { hipemu::reset_stats(); }
+int hipemu_num_cus(void) { return hipemu::num_cus(); }
+}

@@ -1,0 +1,216 @@
+"""TEST INFRASTRUCTURE: numpy front-end over libtf_msda_emu.so -- the repo's HIP kernel sources compiled for the host and
+run under the SIMT emulator of tests/emu/hipemu/ (built by tests/emu/build_emu.py).  Same C ABI as libtf_msda.so
+(include/tf_msda.h, include/tf_fused.h) with host pointers in place of device pointers.  Used by tests/test_emu_*.py
+only; the product (trackformer_amd/) never loads it."""
+import ctypes
+
+import numpy as np
+
+from tests.emu import build_emu
+
+_lib = None
+
+STAT_NAMES = ("wave_ops", "barriers", "divergent_ops", "inactive_reads", "lds_dma_bytes", "blocks", "switches",
+              "lds_b128_reads", "lds_b128_cycles")
+
+
+def available():
+    return build_emu.find_compiler() is not None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = build_emu.build()
+    if so is None:
+        raise RuntimeError("no host clang++ to build the emulated library with")
+    L = ctypes.CDLL(so)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    L.tf_msda_set_tiled.restype = ci
+    L.tf_msda_set_tiled.argtypes = [ci]
+    L.tf_msda_set_option.restype = ci
+    L.tf_msda_set_option.argtypes = [ctypes.c_char_p, ci]
+    for suf in ("f32", "f64"):
+        for tail in ("", "_dshapes"):
+            f = getattr(L, "tf_msda_forward_%s%s" % (suf, tail))
+            f.restype = ci
+            f.argtypes = [vp] * 5 + [ci] * 7 + [vp]
+            b = getattr(L, "tf_msda_backward_%s%s" % (suf, tail))
+            b.restype = ci
+            b.argtypes = [vp] * 8 + [ci] * 7 + [vp]
+    L.tf_msda_forward_fused_f32.restype = ci
+    L.tf_msda_forward_fused_f32.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp] + [ci] * 7 + [vp]
+    L.tf_bias_act_f32.restype = ci
+    L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_add_layernorm_f32.restype = ci
+    L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
+    L.tf_linear_split_f32.restype = ci
+    L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_packed_bytes.restype = ctypes.c_int64
+    L.tf_linear_packed_bytes.argtypes = [ci, ci]
+    L.tf_linear_pack_weight_f32.restype = ci
+    L.tf_linear_pack_weight_f32.argtypes = [vp, vp, ci, ci, vp]
+    L.tf_linear_packed_f32.restype = ci
+    L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_mha_core_f32.restype = ci
+    L.tf_mha_core_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [ctypes.c_float, vp]
+    L.hipemu_get_stats.restype = None
+    L.hipemu_get_stats.argtypes = [vp]
+    L.hipemu_reset_stats.restype = None
+    L.hipemu_num_cus.restype = ci
+    _lib = L
+    return L
+
+
+def stats(reset=False):
+    buf = (ctypes.c_uint64 * len(STAT_NAMES))()
+    lib().hipemu_get_stats(buf)
+    if reset:
+        lib().hipemu_reset_stats()
+    return dict(zip(STAT_NAMES, (int(v) for v in buf)))
+
+
+def set_options(**opts):
+    """Sets tf_msda_set_option knobs; returns the previous values (pass them back to restore)."""
+    L = lib()
+    return {k: L.tf_msda_set_option(k.encode(), int(v)) for k, v in opts.items()}
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def msda_forward(value, shapes, loc, attn, dshapes=False):
+    dt = value.dtype
+    suf = "f32" if dt == np.float32 else "f64"
+    value, loc, attn = _c(value, dt), _c(loc, dt), _c(attn, dt)
+    shapes = _c(shapes, np.int64)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = np.full((N, Lq, M * D), np.nan, dt)
+    fn = getattr(lib(), "tf_msda_forward_%s%s" % (suf, "_dshapes" if dshapes else ""))
+    rc = fn(_p(value), _p(shapes), _p(loc), _p(attn), _p(out), N, S, M, D, L, Lq, P, None)
+    if rc != 0:
+        raise RuntimeError("tf_msda_forward_%s: status %d" % (suf, rc))
+    return out
+
+
+def msda_forward_fused(value, shapes, ref, qproj, M, L, P, off_col=0, logit_col=None):
+    value, ref, qproj = _c(value, np.float32), _c(ref, np.float32), _c(qproj, np.float32)
+    shapes = _c(shapes, np.int64)
+    N, S, _, D = value.shape
+    Lq = ref.shape[1]
+    ld = qproj.shape[-1]
+    if logit_col is None:
+        logit_col = 2 * M * L * P
+    out = np.full((N, Lq, M * D), np.nan, np.float32)
+    rc = lib().tf_msda_forward_fused_f32(_p(value), _p(shapes), _p(ref), ref.shape[-1], _p(qproj), ld, off_col, logit_col,
+                                         _p(out), N, S, M, D, L, Lq, P, None)
+    if rc != 0:
+        raise RuntimeError("tf_msda_forward_fused_f32: status %d" % rc)
+    return out
+
+
+def msda_backward(value, shapes, loc, attn, grad_out, dshapes=False):
+    dt = value.dtype
+    suf = "f32" if dt == np.float32 else "f64"
+    value, loc, attn, grad_out = _c(value, dt), _c(loc, dt), _c(attn, dt), _c(grad_out, dt)
+    shapes = _c(shapes, np.int64)
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    gv = np.full(value.shape, np.nan, dt)
+    gl = np.full(loc.shape, np.nan, dt)
+    ga = np.full(attn.shape, np.nan, dt)
+    fn = getattr(lib(), "tf_msda_backward_%s%s" % (suf, "_dshapes" if dshapes else ""))
+    rc = fn(_p(value), _p(shapes), _p(loc), _p(attn), _p(grad_out), _p(gv), _p(gl), _p(ga), N, S, M, D, L, Lq, P, None)
+    if rc != 0:
+        raise RuntimeError("tf_msda_backward_%s: status %d" % (suf, rc))
+    return gv, gl, ga
+
+
+def bf16_split(w):
+    """w (fp32) -> (hi, mid) as uint16 bit patterns of bf16, round to nearest even (what fused.py hands the kernel)."""
+    def to_bf16(x):
+        u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+        return r
+    hi = to_bf16(w)
+    hi_f = (hi.astype(np.uint32) << 16).view(np.float32)
+    mid = to_bf16(w - hi_f)
+    return hi, mid
+
+
+def linear_split(x, w, bias=None, relu=False):
+    x, w = _c(x, np.float32), _c(w, np.float32)
+    M, K = x.shape
+    N = w.shape[0]
+    hi, mid = bf16_split(w)
+    hi, mid = np.ascontiguousarray(hi), np.ascontiguousarray(mid)
+    b = _c(bias, np.float32) if bias is not None else None
+    y = np.full((M, N), np.nan, np.float32)
+    rc = lib().tf_linear_split_f32(_p(x), _p(hi), _p(mid), _p(b), _p(y), M, K, N, int(relu), None)
+    if rc != 0:
+        raise RuntimeError("tf_linear_split_f32: status %d" % rc)
+    return y
+
+
+def linear_packed(x, w, bias=None, relu=False):
+    x, w = _c(x, np.float32), _c(w, np.float32)
+    M, K = x.shape
+    N = w.shape[0]
+    nbytes = lib().tf_linear_packed_bytes(K, N)
+    if nbytes < 0:
+        raise RuntimeError("tf_linear_packed_bytes(%d, %d) < 0" % (K, N))
+    packed = np.zeros(nbytes + 16, np.uint8)
+    off = (-packed.ctypes.data) % 16
+    pk = packed[off:off + nbytes]
+    rc = lib().tf_linear_pack_weight_f32(_p(w), pk.ctypes.data, K, N, None)
+    if rc != 0:
+        raise RuntimeError("tf_linear_pack_weight_f32: status %d" % rc)
+    b = _c(bias, np.float32) if bias is not None else None
+    y = np.full((M, N), np.nan, np.float32)
+    rc = lib().tf_linear_packed_f32(_p(x), pk.ctypes.data, _p(b), _p(y), M, K, N, int(relu), None)
+    if rc != 0:
+        raise RuntimeError("tf_linear_packed_f32: status %d" % rc)
+    return y
+
+
+def mha_core(q, k, v, scale, key_mask=None):
+    """q [N, Lq, H, D], k / v [N, Lk, H, D] -> out [N, Lq, H, D]."""
+    q, k, v = _c(q, np.float32), _c(k, np.float32), _c(v, np.float32)
+    N, Lq, H, D = q.shape
+    Lk = k.shape[1]
+    out = np.full(q.shape, np.nan, np.float32)
+    km = np.ascontiguousarray(key_mask, dtype=np.uint8) if key_mask is not None else None
+    rc = lib().tf_mha_core_f32(_p(q), _p(k), _p(v), _p(out), _p(km), N, Lq, Lk, H, D, H * D, H * D, H * D, H * D,
+                               ctypes.c_float(scale), None)
+    if rc != 0:
+        raise RuntimeError("tf_mha_core_f32: status %d" % rc)
+    return out
+
+
+def bias_act(x, bias, residual=None, relu=True):
+    x = _c(x, np.float32).copy()
+    bias = _c(bias, np.float32)
+    r = _c(residual, np.float32) if residual is not None else None
+    rc = lib().tf_bias_act_f32(_p(x), _p(bias), _p(r), x.size, bias.size, int(relu), None)
+    if rc != 0:
+        raise RuntimeError("tf_bias_act_f32: status %d" % rc)
+    return x
+
+
+def add_layernorm(x, res, gamma, beta, eps=1e-5):
+    x = _c(x, np.float32)
+    r = _c(res, np.float32) if res is not None else None
+    gamma, beta = _c(gamma, np.float32), _c(beta, np.float32)
+    rows, C = x.shape
+    out = np.full(x.shape, np.nan, np.float32)
+    rc = lib().tf_add_layernorm_f32(_p(x), _p(r), _p(gamma), _p(beta), _p(out), rows, C, ctypes.c_float(eps), None)
+    if rc != 0:
+        raise RuntimeError("tf_add_layernorm_f32: status %d" % rc)
+    return out

@@ -1,0 +1,301 @@
+"""CPU: the repo's HIP kernel SOURCES (trackformer_amd/csrc/*.hip) compiled for the host and executed by the SIMT emulator
+of tests/emu/hipemu/ (fibers per work-item, wave operations executed in lock-step, LDS arena, buffer bounds checking,
+asynchronous LDS-DMA, MFMA fragment layouts), called through the same C ABI as libtf_msda.so and compared with the
+oracle / float64 references.  This is what lets kernel changes be checked without a GPU; the `-m gpu` tests remain the
+parity tests proper (same entry points on the real hardware).
+
+Every test also requires that no cross-lane read hit an inactive lane (inactive_reads); the LDS-window kernels, whose
+DPP / readlane exchanges are meant to run with full waves, additionally that no wave operation was reached by only a
+part of its wave (divergent_ops)."""
+import numpy as np
+import pytest
+
+from oracle import msda_oracle
+from tests import emu_lib
+from tests.test_quad_emulation import make_inputs as encoder_inputs
+from tests.util_msda import discontinuity_mask, golden_cases, load_case, rand_inputs
+
+pytestmark = pytest.mark.skipif(not emu_lib.available(), reason="needs a host clang++ (ROCm's llvm) to build the emulated library")
+
+
+@pytest.fixture(autouse=True)
+def _convergent():
+    emu_lib.lib()
+    emu_lib.stats(reset=True)
+    yield
+    st = emu_lib.stats()
+    assert st["inactive_reads"] == 0, st
+
+
+def _np(ts):
+    return [t.numpy() for t in ts]
+
+
+SMALL_GOLDEN = [p for p in golden_cases() if load_case(p)["value"].size <= 200_000]
+
+
+@pytest.mark.parametrize("path", SMALL_GOLDEN, ids=lambda p: p.split("msda_")[-1][:-4])
+def test_golden_vectors_forward_and_backward(path):
+    """The reference's own outputs (tests/golden/msda_*.npz) through the emulated kernels."""
+    z = load_case(path)
+    f64 = z["value"].dtype == np.float64
+    atol, rtol = (1e-12, 1e-10) if f64 else (1e-5, 1e-4)
+    out = emu_lib.msda_forward(z["value"], z["shapes"], z["loc"], z["attn"])
+    np.testing.assert_allclose(out, z["out"], atol=atol, rtol=rtol)
+    gv, gl, ga = emu_lib.msda_backward(z["value"], z["shapes"], z["loc"], z["attn"], z["grad_out"])
+    np.testing.assert_allclose(gv, z["grad_value"], atol=atol * 2, rtol=rtol)
+    np.testing.assert_allclose(ga, z["grad_attn"], atol=atol * 10, rtol=rtol)
+    keep = ~discontinuity_mask(z["loc"], z["shapes"])
+    np.testing.assert_allclose(gl[keep], z["grad_loc"][keep], atol=atol * 10, rtol=rtol)
+    assert np.all(gl[~keep] == 0)
+
+
+ORACLE_CASES = [
+    ("tiny", dict(N=2, M=2, D=4, Lq=3, P=2, shapes=[(8, 8), (4, 4), (2, 2)])),
+    ("ragged_levels", dict(N=1, M=3, D=8, Lq=65, P=3, shapes=[(1, 1), (1, 7), (9, 1), (3, 5)], loc_mode="wide")),
+    ("d5_scalar_path", dict(N=2, M=3, D=5, Lq=33, P=2, shapes=[(7, 3), (2, 2)], loc_mode="wide")),
+    ("d36_l8_buf", dict(N=1, M=8, D=36, Lq=70, P=4, shapes=[(13, 21), (7, 11), (4, 6), (2, 3)] * 2, loc_mode="wide")),
+    ("d32_l4_direct", dict(N=2, M=8, D=32, Lq=150, P=4, shapes=[(25, 42), (13, 21), (7, 11), (4, 6)], loc_mode="local")),
+    ("d64", dict(N=1, M=4, D=64, Lq=50, P=4, shapes=[(12, 10), (6, 5)], loc_mode="wide")),
+    ("levels16", dict(N=1, M=2, D=8, Lq=20, P=1, shapes=[(3, 2)] * 16, loc_mode="wide")),
+]
+
+
+@pytest.mark.parametrize("name,kw", ORACLE_CASES, ids=[c[0] for c in ORACLE_CASES])
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_forward_backward_vs_oracle(name, kw, dtype):
+    """Decoder-shaped calls: msda_fwd_f32_direct / _buf / the row-gather kernels and the atomic backward kernels."""
+    import torch
+    value, shapes, loc, attn, grad_out = _np(rand_inputs(seed=100 + len(name), dtype=torch.float32 if dtype == "f32" else torch.float64, **kw))
+    atol, rtol = (1e-5, 1e-4) if dtype == "f32" else (1e-12, 1e-10)
+    ref_out = msda_oracle.msda_forward(value, shapes, loc, attn)
+    rv, rl, ra = msda_oracle.msda_backward(value, shapes, loc, attn, grad_out)
+    np.testing.assert_allclose(emu_lib.msda_forward(value, shapes, loc, attn), ref_out, atol=atol, rtol=rtol)
+    np.testing.assert_allclose(emu_lib.msda_forward(value, shapes, loc, attn, dshapes=True), ref_out, atol=atol, rtol=rtol)
+    gv, gl, ga = emu_lib.msda_backward(value, shapes, loc, attn, grad_out)
+    np.testing.assert_allclose(gv, rv, atol=atol * 4, rtol=rtol)
+    np.testing.assert_allclose(gl, rl, atol=atol * 20, rtol=rtol)
+    np.testing.assert_allclose(ga, ra, atol=atol * 10, rtol=rtol)
+
+
+# ---- encoder-shaped calls: the LDS-window kernels ------------------------------------------------------------------
+PYR = [(25, 42), (13, 21), (7, 11), (4, 6)]
+ENC_CASES = [
+    ("pyramid_init", PYR, "init", 1, 32),
+    ("pyramid_local_n2", PYR, "local", 2, 32),
+    ("pyramid_uniform_fallbacks", PYR, "uniform", 1, 32),
+    ("pyramid_border", PYR, "border", 1, 32),
+    ("tiny_levels", [(3, 5), (2, 3), (1, 2), (1, 1)], "local", 1, 32),
+    ("one_level", [(19, 23)], "local", 1, 32),
+    ("coarse_first", [(7, 11), (25, 42)], "local", 1, 32),
+]
+
+
+def _with_d(value, D):
+    if value.shape[-1] == D:
+        return value
+    rng = np.random.default_rng(value.shape[1])
+    return rng.standard_normal(value.shape[:3] + (D,), dtype=np.float32)
+
+
+@pytest.fixture(params=["win", "quad", "pquad"])
+def tiled(request):
+    L = emu_lib.lib()
+    mode = {"win": 1, "quad": 2, "pquad": 2}[request.param]
+    prev_t = L.tf_msda_set_tiled(mode)
+    prev_p = L.tf_msda_set_option(b"pquad", 1 if request.param == "pquad" else 0)
+    yield request.param
+    L.tf_msda_set_tiled(prev_t)
+    L.tf_msda_set_option(b"pquad", prev_p)
+
+
+@pytest.mark.parametrize("name,shapes,mode,N,D", ENC_CASES, ids=[c[0] for c in ENC_CASES])
+def test_encoder_window_kernels_vs_oracle(tiled, name, shapes, mode, N, D):
+    value, loc, attn = encoder_inputs(shapes, mode, N=N, seed=len(name))
+    shp = np.array(shapes, np.int64)
+    out = emu_lib.msda_forward(value, shp, loc, attn)
+    ref = msda_oracle.msda_forward(value, shp, loc, attn, nthreads=4)
+    np.testing.assert_allclose(out, ref, atol=1e-5, rtol=1e-4)
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0, st
+    if tiled != "win" and mode in ("init", "local") and len(shapes) > 1 and shapes[0][0] > shapes[1][0]:
+        assert st["lds_dma_bytes"] > 0   # the windows were staged by LDS-DMA: it really was the window kernel
+
+
+def _fused_case(shapes, N, D, seed, M=8, P=4, spread=2.0):
+    rng = np.random.default_rng(seed)
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    value = rng.standard_normal((N, S, M, D), dtype=np.float32)
+    qproj = rng.standard_normal((N, S, 3 * M * L * P), dtype=np.float32)
+    qproj[..., :2 * M * L * P] *= spread
+    refp = np.concatenate([np.stack(np.meshgrid((np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h), -1).reshape(-1, 2)
+                           for h, w in shapes]).astype(np.float32)
+    refp = np.ascontiguousarray(np.broadcast_to(refp[None, :, None, :], (N, S, L, 2)))
+    off = qproj[..., :2 * M * L * P].reshape(N, S, M, L, P, 2)
+    logits = qproj[..., 2 * M * L * P:].reshape(N, S, M, L * P)
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    attn = (e / e.sum(-1, keepdims=True)).reshape(N, S, M, L, P).astype(np.float32)
+    hw = np.array(shapes, np.float32)[None, None, None, :, None, :]
+    loc = (refp[:, :, None, :, None, :] + off / hw).astype(np.float32)
+    return value, refp, qproj, loc, attn
+
+
+PQUAD_VARIANTS = [dict(), dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pquad_wg_per_cu=2),
+                  dict(pquad_prefetch=2, pquad_wg_per_cu=2), dict(pquad_wide=0), dict(pquad_lds_kb=24),
+                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1)]
+
+
+@pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items()) or "default"
+                                                      for o in PQUAD_VARIANTS])
+def test_persistent_encoder_kernel_variants(opts):
+    """msda_fwd_f32_pquad with its knobs away from the defaults, plain and fused entry, N = 2 (the GPU test of the same
+    name at a smaller size): the tile loop, the double-buffered per-tile tables and the prefetch must not change a result."""
+    prev = emu_lib.set_options(**opts)
+    try:
+        shapes = [(20, 31), (10, 16), (5, 8), (3, 4)]
+        shp = np.array(shapes, np.int64)
+        value, loc, attn = encoder_inputs(shapes, "local", N=2, seed=11)
+        np.testing.assert_allclose(emu_lib.msda_forward(value, shp, loc, attn),
+                                   msda_oracle.msda_forward(value, shp, loc, attn, nthreads=4), atol=1e-5, rtol=1e-4)
+        value, refp, qproj, floc, fattn = _fused_case(shapes, 2, 32, seed=5)
+        got = emu_lib.msda_forward_fused(value, shp, refp, qproj, 8, len(shapes), 4)
+        np.testing.assert_allclose(got, msda_oracle.msda_forward(value, shp, floc, fattn, nthreads=4), atol=2e-5, rtol=1e-4)
+        assert emu_lib.stats()["lds_dma_bytes"] > 0 and emu_lib.stats()["divergent_ops"] == 0
+    finally:
+        emu_lib.set_options(**prev)
+
+
+@pytest.mark.parametrize("shapes,N", [(PYR, 1), ([(15, 22), (8, 11), (4, 6)], 2), ([(19, 23)], 1)],
+                         ids=["four_levels", "three_levels_n2", "one_level"])
+def test_persistent_encoder_kernel_head_dim_36(shapes, N):
+    """hidden 288 (cfg 4): 144-byte rows packed in LDS, 3 lanes x 12 channels per pair; plain and fused entry."""
+    shp = np.array(shapes, np.int64)
+    value, loc, attn = encoder_inputs(shapes, "local", N=N, seed=7)
+    value = _with_d(value, 36)
+    np.testing.assert_allclose(emu_lib.msda_forward(value, shp, loc, attn),
+                               msda_oracle.msda_forward(value, shp, loc, attn, nthreads=4), atol=1e-5, rtol=1e-4)
+    assert emu_lib.stats()["lds_dma_bytes"] > 0
+    value, refp, qproj, floc, fattn = _fused_case(shapes, N, 36, seed=9)
+    got = emu_lib.msda_forward_fused(value, shp, refp, qproj, 8, len(shapes), 4)
+    np.testing.assert_allclose(got, msda_oracle.msda_forward(value, shp, floc, fattn, nthreads=4), atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("name,shapes,mode,N,D", [c for c in ENC_CASES if c[0] in ("pyramid_init", "pyramid_uniform_fallbacks",
+                                                                                    "tiny_levels", "one_level", "coarse_first")],
+                         ids=lambda v: v if isinstance(v, str) and "_" in v else None)
+def test_encoder_shape_backward_sorted_kernel(name, shapes, mode, N, D):
+    """msda_bwd_f32_sorted (counting sort of the taps by destination row in LDS, one full-row atomic per row)."""
+    value, loc, attn = encoder_inputs(shapes, mode, N=N, seed=len(name))
+    shp = np.array(shapes, np.int64)
+    rng = np.random.default_rng(3)
+    grad_out = rng.standard_normal((N, value.shape[1], value.shape[2] * value.shape[3]), dtype=np.float32)
+    if name == "pyramid_init":   # mix in points far outside their windows
+        loc = loc.copy()
+        loc[:, :, :, :, ::2, 0] += 12.0 / 42
+        loc[:, :, :, :, ::2, 1] -= 9.0 / 25
+    gv, gl, ga = emu_lib.msda_backward(value, shp, loc, attn, grad_out)
+    rv, rl, ra = msda_oracle.msda_backward(value, shp, loc, attn, grad_out)
+    np.testing.assert_allclose(gv, rv, atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(gl, rl, atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(ga, ra, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+@pytest.mark.parametrize("D,shapes", [(32, PYR), (36, [(13, 21), (7, 11), (4, 6), (2, 3)] * 2)], ids=["d32_direct", "d36_l8_buf"])
+def test_fused_prologue_decoder_shapes(ref_dim, D, shapes):
+    """tf_msda_forward_fused_f32 at decoder shapes (softmax + location arithmetic inside msda_fwd_f32_direct / _buf)."""
+    rng = np.random.default_rng(7)
+    N, M, L, P, Lq = 1, 8, len(shapes), 4, 77
+    S = sum(h * w for h, w in shapes)
+    value = rng.standard_normal((N, S, M, D), dtype=np.float32)
+    qproj = rng.standard_normal((N, Lq, 3 * M * L * P), dtype=np.float32)
+    ref = (rng.random((N, Lq, L, ref_dim), dtype=np.float32) * 0.6 + 0.1).astype(np.float32)
+    off = qproj[..., :2 * M * L * P].reshape(N, Lq, M, L, P, 2)
+    logits = qproj[..., 2 * M * L * P:].reshape(N, Lq, M, L * P)
+    e = np.exp(logits - logits.max(-1, keepdims=True))
+    attn = (e / e.sum(-1, keepdims=True)).reshape(N, Lq, M, L, P).astype(np.float32)
+    if ref_dim == 2:
+        loc = ref[:, :, None, :, None, :] + off / np.array(shapes, np.float32)[None, None, None, :, None, :]
+    else:
+        loc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+    shp = np.array(shapes, np.int64)
+    expect = msda_oracle.msda_forward(value, shp, loc.astype(np.float32), attn)
+    got = emu_lib.msda_forward_fused(value, shp, ref, qproj, M, L, P)
+    np.testing.assert_allclose(got, expect, atol=2e-5, rtol=1e-4)
+
+
+# ---- fused element-wise kernels, linears on the matrix cores, query self-attention ------------------------------------
+def test_bias_act_and_add_layernorm():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((37, 5, 64), dtype=np.float32)
+    b = rng.standard_normal(64, dtype=np.float32)
+    r = rng.standard_normal(x.shape, dtype=np.float32)
+    np.testing.assert_allclose(emu_lib.bias_act(x, b, r, relu=True), np.maximum(x + b + r, 0), atol=1e-6)
+    np.testing.assert_allclose(emu_lib.bias_act(x, b, None, relu=False), x + b, atol=1e-6)
+    for C in (256, 288, 1024):
+        x = rng.standard_normal((70, C), dtype=np.float32)
+        res = rng.standard_normal((70, C), dtype=np.float32)
+        g, be = rng.standard_normal(C, dtype=np.float32), rng.standard_normal(C, dtype=np.float32)
+        s = (x + res).astype(np.float64)
+        ref = (s - s.mean(-1, keepdims=True)) / np.sqrt(s.var(-1, keepdims=True) + 1e-5) * g + be
+        np.testing.assert_allclose(emu_lib.add_layernorm(x, res, g, be), ref, atol=2e-5, rtol=1e-5)
+
+
+LINEAR_SHAPES = [(200, 256, 256), (333, 256, 384), (130, 256, 1024), (130, 1024, 256), (400, 288, 288), (70, 64, 96)]
+
+
+@pytest.mark.parametrize("M,K,N", LINEAR_SHAPES, ids=["%dx%dx%d" % s for s in LINEAR_SHAPES])
+@pytest.mark.parametrize("relu", [False, True], ids=["plain", "relu"])
+def test_split_product_linear_on_emulated_matrix_cores(M, K, N, relu):
+    """tf_linear_split_f32 (LDS-staged operands, every block-shape variant the shape selects) and tf_linear_packed_f32
+    (weight fragments in MFMA order): hi.hi + hi.mid + mid.hi on the emulated v_mfma_f32_32x32x16_bf16 /
+    16x16x32 against a float64 product.  A wrong fragment layout anywhere gives errors of order 1."""
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N, dtype=np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if relu:
+        ref = np.maximum(ref, 0)
+    if K % 32 == 0:
+        y = emu_lib.linear_split(x, w, b, relu)
+        assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    if K % 64 == 0:
+        y2 = emu_lib.linear_packed(x, w, b, relu)
+        assert np.abs(y2 - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6])
+def test_split_product_linear_block_variants(variant):
+    prev = emu_lib.set_options(linear_variant=variant)
+    try:
+        rng = np.random.default_rng(variant)
+        x = rng.standard_normal((300, 256), dtype=np.float32)
+        w = (rng.standard_normal((256, 256), dtype=np.float32) / 16).astype(np.float32)
+        ref = x.astype(np.float64) @ w.astype(np.float64).T
+        assert np.abs(emu_lib.linear_split(x, w) - ref).max() < 1e-4 * np.abs(ref).max()
+    finally:
+        emu_lib.set_options(**prev)
+
+
+@pytest.mark.parametrize("Lq,Lk,H,D,masked", [(100, 100, 8, 32, False), (57, 130, 8, 36, True), (33, 33, 4, 16, True), (40, 40, 2, 64, False)])
+def test_query_self_attention_kernel(Lq, Lk, H, D, masked):
+    rng = np.random.default_rng(Lq + D)
+    N = 2
+    q = rng.standard_normal((N, Lq, H, D), dtype=np.float32)
+    k = rng.standard_normal((N, Lk, H, D), dtype=np.float32)
+    v = rng.standard_normal((N, Lk, H, D), dtype=np.float32)
+    mask = None
+    if masked:
+        mask = np.zeros((N, Lk), np.uint8)
+        mask[1, -7:] = 1
+        mask[0, 3] = 1
+    scale = 1.0 / np.sqrt(D)
+    s = np.einsum("nlhd,njhd->nhlj", q.astype(np.float64), k.astype(np.float64)) * scale
+    if masked:
+        s = np.where(mask[:, None, None, :] != 0, -np.inf, s)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("nhlj,njhd->nlhd", p, v.astype(np.float64))
+    np.testing.assert_allclose(emu_lib.mha_core(q, k, v, scale, mask), ref, atol=2e-5, rtol=1e-4)
