@@ -55,6 +55,16 @@ using namespace tfm;
 
 #include "msda_quad_dev.h"
 
+// Timing ablations for tools/msda_bench (tools/gpu_runs/: built into separate libraries, never into libtf_msda.so):
+// TF_PQUAD_ABLATE is a bit mask of phases to leave out, so that T(full) - T(without X) gives X's marginal cost under
+// the real overlap of the resident workgroups.  Results are WRONG by design with any bit set.
+//   1 no LDS gathers   2 no LDS-DMA staging   4 no bounding boxes (windows = the clamped nominal footprints)
+//   8 no output stores   16 no fused prologue arithmetic (softmax / locations)   32 no buffer-load fallback path
+#ifndef TF_PQUAD_ABLATE
+#define TF_PQUAD_ABLATE 0
+#endif
+constexpr int kPqAblate = TF_PQUAD_ABLATE;
+
 constexpr int kPqLevels = 4;
 constexpr int kPqThreads = 256;
 constexpr int kPqPairs = kPqThreads / 4;   // (query, head) pairs per pass
@@ -346,7 +356,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
     // ---- fused entry: softmax over the pair's L*P logits, sampling locations (ms_deform_attn.py:69-79) -----
     auto finish_points = [&](PqPoints<NPASS> &p, PqRefs<NPASS> &r) {
         transpose_points(p, r);
-        if constexpr (FUSED) {
+        if constexpr (FUSED && !(kPqAblate & 16)) {
 #pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
 #pragma unroll
             for (int ps = 0; ps < NPASS; ++ps) {
@@ -379,7 +389,15 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
     // ---- phase A: bounding box of the floor coordinates of the tile's in-range points, per LDS level -------
     auto bbox_level = [&](auto lc, const PqPoints<NPASS> &p, int par) {
         constexpr int l = decltype(lc)::value;
-        if constexpr (((TA_MASK >> l) & 1) == 0) {
+        if constexpr ((kPqAblate & 4) != 0) {
+            if (lane == 0) {   // the whole level: tfq_window clamps it to the nominal footprint
+                int *slot = s_bb + ((par * 4 + wave) * 4 + l) * 4;
+                slot[0] = -1;
+                slot[1] = l < L ? Ws[l < NL ? l : 0] : INT_MIN;
+                slot[2] = -1;
+                slot[3] = l < L ? Hs[l < NL ? l : 0] : INT_MIN;
+            }
+        } else if constexpr (((TA_MASK >> l) & 1) == 0) {
             if (l < L) {
                 int mnx = INT_MAX, mxx = INT_MIN, mny = INT_MAX, mxy = INT_MIN;
                 const float Wf = (float)Ws[l], Hf = (float)Hs[l];
@@ -564,9 +582,10 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                             for (int c = wave; c < nchunks; c += kPqThreads / 64) {
                                 const int py = wy0 + wy, px = wx0 + wx;   // extended coordinates: may be -1 or size
                                 const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                                    rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128),
-                                    16, ok ? off : kOobOffset /* hardware writes zeros */, 0, 0, 0);
+                                if constexpr (!(kPqAblate & 2))
+                                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                        rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128),
+                                        16, ok ? off : kOobOffset /* hardware writes zeros */, 0, 0, 0);
                                 r += STEP;
                                 wy += qstep;
                                 wx += rstep;
@@ -595,7 +614,8 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                             const int py = wy0 + wy, px = wx0 + wx;   // extended coordinates: may be -1 or size
                             const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
                             const unsigned off = lvl_base + (unsigned)(py * W + px) * rowbytes + (unsigned)piece * 16u;
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            if constexpr (!(kPqAblate & 2))
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(
                                 rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)roff * ROWB + (size_t)c * 1024),
                                 16, ok ? off : kOobOffset /* hardware writes zeros */, 0, 0, 0);
                         }
@@ -640,7 +660,9 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                 const unsigned lo = (unsigned)(groff[l] + dy * gww[l] + dx) * ROWB;
                 const unsigned a0 = staged ? lo : 0u;                            // rows 0, 1 are zeros
                 const unsigned a1 = staged ? lo + (unsigned)gww[l] * ROWB : 0u;
-                if constexpr (!D36) {
+                if constexpr ((kPqAblate & 1) != 0) {
+                    accA[ps].x += (float)(a0 + a1) * w[0];   // keeps the tap arithmetic alive
+                } else if constexpr (!D36) {
                     quad_taps_lds<0>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
                     quad_taps_lds<1>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
                     quad_taps_lds<2>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
@@ -652,6 +674,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                     quad_taps_lds36<3>(a0, a1, w, ldsL, acc36[ps]);
                 }
                 need_global = in && !staged;
+                if constexpr ((kPqAblate & 32) != 0) return;
                 if (!__any(need_global)) return;   // wave-uniform: no point of this wave left its window
             }
             const bool kx0 = need_global && (x0 >= 0), kx1 = need_global && (x0 + 1 <= W - 1);
@@ -727,7 +750,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         all_passes(std::integral_constant<int, R1>{}, std::true_type{});
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps)
-            if (cur.live[ps]) {
+            if (cur.live[ps] && (!(kPqAblate & 8) || accA[ps].x == 12345.678f)) {
                 float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(da.out) + (size_t)(cur.pair32[ps] * (unsigned)(D * 4)));
                 if constexpr (!D36) {
                     *reinterpret_cast<f32x4_t *>(o + rbA / 4) = accA[ps];
