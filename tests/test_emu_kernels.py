@@ -299,3 +299,39 @@ def test_query_self_attention_kernel(Lq, Lk, H, D, masked):
     p /= p.sum(-1, keepdims=True)
     ref = np.einsum("nhlj,njhd->nlhd", p, v.astype(np.float64))
     np.testing.assert_allclose(emu_lib.mha_core(q, k, v, scale, mask), ref, atol=2e-5, rtol=1e-4)
+
+
+# ---- opt-in kernels awaiting their first hardware run --------------------------------------------------------------
+@pytest.mark.parametrize("Lq,L,N", [(70, 8, 1), (29, 4, 2), (5, 3, 1), (800, 8, 1)], ids=["l8", "l4_n2", "l3_tiny", "cfg4_queries"])
+def test_direct9_decoder_kernel_head_dim_36(Lq, L, N):
+    """msda_fwd_f32_direct9 (9 lanes per pair, 7 pairs per wave; opt-in): plain entry (host and device shapes) and the
+    fused entry with 2-d and 4-d reference points against the oracle, and bit-for-bit against msda_fwd_f32_buf."""
+    shapes = ([(13, 21), (7, 11), (4, 6), (2, 3)] * 2)[:L]
+    import torch
+    value, shp, loc, attn, _ = _np(rand_inputs(seed=40 + Lq, N=N, M=8, D=36, Lq=Lq, P=4, shapes=shapes, loc_mode="wide"))
+    ref_out = msda_oracle.msda_forward(value, shp, loc, attn)
+    base = emu_lib.msda_forward(value, shp, loc, attn)
+    prev = emu_lib.set_options(direct9=1)
+    try:
+        out = emu_lib.msda_forward(value, shp, loc, attn)
+        np.testing.assert_allclose(out, ref_out, atol=1e-5, rtol=1e-4)
+        np.testing.assert_allclose(emu_lib.msda_forward(value, shp, loc, attn, dshapes=True), ref_out, atol=1e-5, rtol=1e-4)
+        assert np.abs(out - base).max() < 2e-6
+        rng = np.random.default_rng(Lq)
+        M, P = 8, 4
+        qproj = rng.standard_normal((N, Lq, 3 * M * L * P), dtype=np.float32)
+        for ref_dim in (2, 4):
+            ref = (rng.random((N, Lq, L, ref_dim), dtype=np.float32) * 0.6 + 0.1).astype(np.float32)
+            off = qproj[..., :2 * M * L * P].reshape(N, Lq, M, L, P, 2)
+            logits = qproj[..., 2 * M * L * P:].reshape(N, Lq, M, L * P)
+            e = np.exp(logits - logits.max(-1, keepdims=True))
+            a = (e / e.sum(-1, keepdims=True)).reshape(N, Lq, M, L, P).astype(np.float32)
+            if ref_dim == 2:
+                floc = ref[:, :, None, :, None, :] + off / np.array(shapes, np.float32)[None, None, None, :, None, :]
+            else:
+                floc = ref[:, :, None, :, None, :2] + off / P * ref[:, :, None, :, None, 2:] * 0.5
+            expect = msda_oracle.msda_forward(value, shp, floc.astype(np.float32), a)
+            got = emu_lib.msda_forward_fused(value, shp, ref, qproj, M, L, P)
+            np.testing.assert_allclose(got, expect, atol=2e-5, rtol=1e-4)
+    finally:
+        emu_lib.set_options(**prev)

@@ -590,6 +590,166 @@ msda_fwd_f32_direct(const DirectArgs da, const LevelTable lt, const int64_t *__r
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward, fp32, D == 36 (hidden 288: cfg 4), P == 4, L <= 8: msda_fwd_f32_direct's mapping with 9 lanes per pair
+// ---------------------------------------------------------------------------------------------
+// The decoder calls of the `multi_frame` model (D = 36, L = 8: two frames x 4 levels, 500 + 300 queries) ran
+// msda_fwd_f32_buf: every lane repeats the tap arithmetic (965 vector instructions per wave against 380 in
+// msda_fwd_f32_direct) behind a staging prologue.  This kernel keeps `direct`'s structure -- points fetched straight
+// into registers, the tap arithmetic of a point computed once per pair and published through a per-wave LDS
+// exchange, 16 row gathers in flight per lane -- for 144-byte rows: a (query, head) pair is served by NINE lanes
+// (4 channels each), seven pairs per wave (lane 63 idles), 28 pairs per 256-thread workgroup.  Lanes 0-7 of a group
+// produce (lanes 0-3: the points of level 2i, lanes 4-7: those of level 2i + 1), all nine consume.  The groups are
+// not aligned to DPP rows, so the softmax statistics of the fused entry go through wave shuffles (ds_bpermute).
+// OPT-IN until it has been timed on hardware: tf_msda_set_option("direct9", 1) / TF_MSDA_DIRECT9=1.
+template <int LPAIRS, bool FUSED>   // LPAIRS = ceil(L / 2)
+__global__ void __launch_bounds__(kThreads, 4)
+msda_fwd_f32_direct9(const DirectArgs da, const LevelTable lt, const int64_t *__restrict__ dshapes)
+{
+    constexpr int PT = 4, D = 36, GL = 9, GPW = 7;   // lanes per pair, pairs per wave
+    __shared__ int s_tab[3 * TF_MSDA_MAX_LEVELS];
+    __shared__ u32x4_t s_xo[(kThreads / 64) * 72];   // per wave: 7 groups x 9 slots (8 used) + padding
+    __shared__ f32x4_t s_xw[(kThreads / 64) * 72];
+    const int L = da.L, M = da.M, LP = L * PT;
+    fill_level_table(s_tab, lt, dshapes, L);
+
+    const int head = blockIdx.x % M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / GL, dv = lane - grp * GL;          // lane 63: grp 7, dv 0 (idle)
+    const long long bq = (long long)(blockIdx.x / M) * ((kThreads / 64) * GPW) + wave * GPW + grp;
+    const bool live = grp < GPW && bq < da.nlq;
+    const bool producer = dv < 8 && grp < GPW;
+    const int sub = dv & 3, which = (dv >> 2) & 1;
+    const long long bqc = live ? bq : 0;
+    const long long pair = bqc * M + head;
+    const int b = (int)(bqc / da.Lq);
+
+    // ---- this lane's sampling points: (level 2i + which, point sub) for i < LPAIRS (lanes 0-7 of a group) ----
+    float sx[LPAIRS], sy[LPAIRS], sa[LPAIRS];
+    bool have[LPAIRS];
+#pragma unroll
+    for (int i = 0; i < LPAIRS; ++i) {
+        const int ml = 2 * i + which;
+        have[i] = producer && ml < L;
+        const int s = (have[i] ? ml : 0) * PT + sub;
+        if constexpr (!FUSED) {
+            const float2 xy = *reinterpret_cast<const float2 *>(da.loc + (pair * LP + s) * 2);
+            sx[i] = xy.x;
+            sy[i] = xy.y;
+            sa[i] = da.attn[pair * LP + s];
+        } else {
+            const float *row = da.fa.qproj + bqc * da.fa.ld;
+            const float2 off = *reinterpret_cast<const float2 *>(row + da.fa.off_col + (head * LP + s) * 2);
+            sx[i] = off.x;
+            sy[i] = off.y;
+            sa[i] = have[i] ? row[da.fa.logit_col + head * LP + s] : -__builtin_inff();
+        }
+    }
+    __syncthreads();   // level table
+
+    if constexpr (FUSED) {
+#pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
+        // softmax over the pair's L*P logits: the eight producer lanes of the group hold LPAIRS of them each
+        const int gbase = grp * GL;
+        float mxl = sa[0];
+#pragma unroll
+        for (int i = 1; i < LPAIRS; ++i) mxl = fmaxf(mxl, sa[i]);
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx = fmaxf(mx, __shfl(mxl, gbase + k));
+        float suml = 0.f;
+#pragma unroll
+        for (int i = 0; i < LPAIRS; ++i) {
+            sa[i] = have[i] ? __expf(sa[i] - mx) : 0.f;
+            suml += sa[i];
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += __shfl(suml, gbase + k);
+#pragma unroll
+        for (int i = 0; i < LPAIRS; ++i) {
+            sa[i] = sa[i] / sum;
+            const int ml = have[i] ? 2 * i + which : 0;
+            const float *rp = da.fa.ref + (bqc * L + ml) * da.fa.ref_dim;
+            if (da.fa.ref_dim == 2) {
+                sx[i] = rp[0] + sx[i] / (float)s_tab[ml];                         // x / H_l (as written)
+                sy[i] = rp[1] + sy[i] / (float)s_tab[TF_MSDA_MAX_LEVELS + ml];    // y / W_l
+            } else {
+                sx[i] = rp[0] + sx[i] / (float)PT * rp[2] * 0.5f;
+                sy[i] = rp[1] + sy[i] / (float)PT * rp[3] * 0.5f;
+            }
+        }
+    }
+
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;
+    const unsigned head_base = (unsigned)((((long long)b * da.S * M + head) * D) * 4);
+    const unsigned dvb = (unsigned)dv * 16u;   // <= 128: kOobBase + dvb stays out of range
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(da.value), 0, da.value_bytes, 0x00020000);
+    // slot of lane 0 of this group; lane 63 reads along with group 6 (valid offsets, results never stored)
+    const int xbase = wave * 72 + (grp < GPW ? grp : GPW - 1) * GL;
+
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < LPAIRS; ++i) {
+        // produce: taps of this lane's point of the level pair (2i, 2i+1)
+        const int ml = have[i] ? 2 * i + which : 0;
+        const int H = s_tab[ml], W = s_tab[TF_MSDA_MAX_LEVELS + ml];
+        const unsigned lvl_base = head_base + (unsigned)s_tab[2 * TF_MSDA_MAX_LEVELS + ml] * rowbytes;
+        const float Wf = (float)W, Hf = (float)H;
+        const float xr = __builtin_fmaf(sx[i], Wf, -0.5f);   // cuh:227-228, single rounding
+        const float yr = __builtin_fmaf(sy[i], Hf, -0.5f);
+        const bool in = have[i] && live && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
+        const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+        const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+        const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+        const int x0 = (int)xf, y0 = (int)yf;
+        const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
+        const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
+        const int r0 = y0 * W + x0;
+        const int po0 = (int)((ky0 && kx0) ? lvl_base + (unsigned)r0 * rowbytes : kOobBase);
+        const int po1 = (int)((ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase);
+        const int po2 = (int)((ky1 && kx0) ? lvl_base + (unsigned)(r0 + W) * rowbytes : kOobBase);
+        const int po3 = (int)((ky1 && kx1) ? lvl_base + (unsigned)(r0 + W + 1) * rowbytes : kOobBase);
+        const float a = in ? sa[i] : 0.f;
+        const float pw0 = gy * gx * a, pw1 = gy * fx * a, pw2 = fy * gx * a, pw3 = fy * fx * a;
+
+        // publish (lanes 0-7 of the seven groups): wave-scope ordering as in `direct`
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (producer) {
+            s_xo[xbase + dv] = u32x4_t{(unsigned)po0, (unsigned)po1, (unsigned)po2, (unsigned)po3};
+            s_xw[xbase + dv] = f32x4_t{pw0, pw1, pw2, pw3};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // consume: one level at a time, 16 row gathers (16 bytes each) in flight per lane
+#pragma unroll
+        for (int ll = 0; ll < 2; ++ll) {
+            if (2 * i + ll >= L) break;   // uniform
+            u32x4_t v[4][4];
+            f32x4_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4_t o = s_xo[xbase + ll * 4 + k];
+                w[k] = s_xw[xbase + ll * 4 + k];
+                v[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + dvb, 0, 0);
+                v[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + dvb, 0, 0);
+                v[k][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + dvb, 0, 0);
+                v[k][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + dvb, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc += __builtin_bit_cast(f32x4_t, v[k][0]) * w[k].x;
+                acc += __builtin_bit_cast(f32x4_t, v[k][1]) * w[k].y;
+                acc += __builtin_bit_cast(f32x4_t, v[k][2]) * w[k].z;
+                acc += __builtin_bit_cast(f32x4_t, v[k][3]) * w[k].w;
+            }
+        }
+    }
+    if (live) *reinterpret_cast<f32x4_t *>(da.out + pair * D + dv * 4) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
 // forward, encoder shape, fp32, D == 32, P == 4, L <= 4: data-adaptive LDS windows (all levels resident)
 // ---------------------------------------------------------------------------------------------
 // The row-gather kernels are bound by the vector-memory path (64 B/clk/CU for 1.46 GB of row gathers per
@@ -2132,12 +2292,40 @@ bool direct_enabled()
     return on != 0;
 }
 
+std::atomic<int> g_direct9{-1};   // -1: environment (TF_MSDA_DIRECT9, default 0)
+bool direct9_enabled()
+{
+    const int v = g_direct9.load(std::memory_order_relaxed);
+    if (v >= 0) return v != 0;
+    static const int env = [] { const char *e = getenv("TF_MSDA_DIRECT9"); return (e && e[0] == '1') ? 1 : 0; }();
+    return env != 0;
+}
+
 bool launch_direct(bool fused, const DirectArgs &da, const LevelTable &lt, const int64_t *shapes_dev,
                    int D, int P, hipStream_t stream, hipError_t *err)
 {
-    if (!direct_enabled() || D != 32 || P != 4 || da.L > 8) return false;
+    if (!direct_enabled() || P != 4 || da.L > 8) return false;
     const int lpairs = (da.L + 1) / 2;
     const void *fn = nullptr;
+    if (D == 36) {   // 9 lanes per pair, 28 pairs per workgroup (opt-in until timed on hardware)
+        if (!direct9_enabled()) return false;
+        if (fused)
+            fn = lpairs == 1   ? (const void *)&msda_fwd_f32_direct9<1, true>
+                 : lpairs == 2 ? (const void *)&msda_fwd_f32_direct9<2, true>
+                 : lpairs == 3 ? (const void *)&msda_fwd_f32_direct9<3, true>
+                               : (const void *)&msda_fwd_f32_direct9<4, true>;
+        else
+            fn = lpairs == 1   ? (const void *)&msda_fwd_f32_direct9<1, false>
+                 : lpairs == 2 ? (const void *)&msda_fwd_f32_direct9<2, false>
+                 : lpairs == 3 ? (const void *)&msda_fwd_f32_direct9<3, false>
+                               : (const void *)&msda_fwd_f32_direct9<4, false>;
+        const long long ppb = (kThreads / 64) * 7;
+        const long long grid9 = (da.nlq + ppb - 1) / ppb * da.M;
+        if (grid9 > 0x7fffffffLL) return false;
+        *err = launch(fn, (unsigned)grid9, 0, stream, da, lt, shapes_dev);
+        return true;
+    }
+    if (D != 32) return false;
     if (fused)
         fn = lpairs == 1   ? (const void *)&msda_fwd_f32_direct<1, true>
              : lpairs == 2 ? (const void *)&msda_fwd_f32_direct<2, true>
@@ -2403,6 +2591,7 @@ int tf_msda_set_option(const char *name, int value)
             g_quad_epoch.fetch_add(1);
             return prev;
         }
+    if (strcmp(name, "direct9") == 0) return g_direct9.exchange(value < 0 ? -1 : (value ? 1 : 0));
     if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);
     if (strcmp(name, "linear_stream_ti") == 0) return linear_stream_set_ti(value);
     if (strcmp(name, "linear_astat") == 0) return linear_astat_set(value);
