@@ -335,3 +335,37 @@ def test_direct9_decoder_kernel_head_dim_36(Lq, L, N):
             np.testing.assert_allclose(got, expect, atol=2e-5, rtol=1e-4)
     finally:
         emu_lib.set_options(**prev)
+
+
+BWD2_CASES = [c for c in ENC_CASES if c[0] in ("pyramid_init", "pyramid_local_n2", "pyramid_uniform_fallbacks", "pyramid_border",
+                                               "tiny_levels", "one_level", "coarse_first")]
+
+
+@pytest.mark.parametrize("name,shapes,mode,N,D", BWD2_CASES, ids=[c[0] for c in BWD2_CASES])
+def test_encoder_shape_backward_sorted2_kernel(name, shapes, mode, N, D):
+    """msda_bwd_f32_sorted2 (opt-in): tap arithmetic once per pair through the per-wave LDS exchange, the channel sums as
+    four dot products + 8-lane DPP reductions, eight destination rows per wave in the row reduction."""
+    value, loc, attn = encoder_inputs(shapes, mode, N=N, seed=len(name))
+    shp = np.array(shapes, np.int64)
+    rng = np.random.default_rng(3)
+    grad_out = rng.standard_normal((N, value.shape[1], value.shape[2] * value.shape[3]), dtype=np.float32)
+    if name == "pyramid_init":   # mix in points far outside their windows
+        loc = loc.copy()
+        loc[:, :, :, :, ::2, 0] += 12.0 / 42
+        loc[:, :, :, :, ::2, 1] -= 9.0 / 25
+    rv, rl, ra = msda_oracle.msda_backward(value, shp, loc, attn, grad_out)
+    base = emu_lib.msda_backward(value, shp, loc, attn, grad_out)
+    prev = emu_lib.set_options(bwd_sorted2=1)
+    try:
+        emu_lib.stats(reset=True)
+        gv, gl, ga = emu_lib.msda_backward(value, shp, loc, attn, grad_out)
+        assert emu_lib.stats()["wave_ops"] > 0
+    finally:
+        emu_lib.set_options(**prev)
+    np.testing.assert_allclose(gv, rv, atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(gl, rl, atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(ga, ra, atol=1e-4, rtol=1e-4)
+    # and against the default kernel (same items, different summation order)
+    np.testing.assert_allclose(gv, base[0], atol=2e-4, rtol=1e-4)
+    np.testing.assert_allclose(gl, base[1], atol=2e-3, rtol=1e-4)
+    np.testing.assert_allclose(ga, base[2], atol=1e-4, rtol=1e-4)

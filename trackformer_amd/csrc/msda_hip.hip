@@ -1512,6 +1512,403 @@ msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
 }
 
 // ---------------------------------------------------------------------------------------------
+// msda_bwd_f32_sorted2: the same algorithm with ~half the vector instructions (OPT-IN until timed on hardware:
+// tf_msda_set_option("bwd_sorted2", 1) / TF_MSDA_BWD_SORTED2=1).  msda_bwd_f32_sorted is bound by vector-ALU issue
+// (profiles/r01_msda_bwd_sorted_pmc.json: 84 % of its cycles, 9.9 k instructions per wave), spent in phase b and e:
+//   * phase b: the tap arithmetic of a point was repeated by the 8 lanes of its pair.  Here the lane that loaded the
+//     point in phase A (level 2i + which, point sub) computes it once, files the point's four grad_value items, and
+//     publishes offsets / weights through a per-wave LDS exchange (as msda_fwd_f32_direct);
+//   * phase b: the three channel sums per point (cuh:365-376) are linear in s_t = <grad_out, value row of tap t>:
+//     grad_attn = sum_t w_t s_t,  d/dx = gy (s2 - s1) + fy (s4 - s3),  d/dy = gx (s3 - s1) + fx (s4 - s2).
+//     Four dot products of 4 channels per lane and four 8-lane DPP reductions replace three element-wise
+//     combinations of the four rows (60 -> 16 multiply-adds per lane and point);
+//   * phase e: eight destination rows per wave at a time, 8 lanes x 4 channels per row (one ds_read_b128 of the
+//     tile's grad_out per item instead of a ds_read_b32 per channel and half wave), items as {byte offset of the
+//     query's grad_out row, weight}; the sums are transposed through LDS so that the global atomics still add to
+//     complete 128-byte rows (two rows per instruction).
+// Same LDS layout as msda_bwd_f32_sorted plus 1.5 KB per wave (exchange / transposition buffer): 70 528 B.
+constexpr int kSort2XchPerWave = 1536;
+constexpr int kSort2OffXch = kSortLdsBytes;
+constexpr int kSort2LdsBytes = kSort2OffXch + kWinWaves * kSort2XchPerWave;
+
+__global__ void __launch_bounds__(kWinThreads, 4)
+msda_bwd_f32_sorted2(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
+{
+    constexpr int PT = 4, D = 32, LPAIRS = kWinLevels / 2;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start          (48 ints)
+    int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb
+    int *s_bb = s_q + 5 * TF_MSDA_MAX_LEVELS + 4;                  // xmin xmax ymin ymax per level
+    int *s_direct = s_bb + 4 * kWinLevels;                         // per level: taps filed for direct scatter?
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(smem + kSortOffCnt);
+    unsigned *s_start = reinterpret_cast<unsigned *>(smem + kSortOffStart);
+    uint2 *s_item = reinterpret_cast<uint2 *>(smem + kSortOffItem);
+    uint2 *s_sorted = reinterpret_cast<uint2 *>(smem + kSortOffSorted);
+    float *s_go = reinterpret_cast<float *>(smem + kSortOffGo);
+
+    const int L = ba.L, M = ba.M, S = ba.S, LP = L * PT;
+    const int m = blockIdx.x % M;
+    int t = blockIdx.x / M;
+    const int tx = t % wg.tiles_x;
+    t /= wg.tiles_x;
+    const int ty = t % wg.tiles_y;
+    const int b = t / wg.tiles_y;
+
+    if (threadIdx.x < 4 * kWinLevels) {   // as msda_fwd_f32_win: exact partition of every level
+        const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
+        if (l < L) {
+            const unsigned H0 = (unsigned)lt.H[0], W0 = (unsigned)lt.W[0];
+            const unsigned Hl = (unsigned)lt.H[l], Wl = (unsigned)lt.W[l];
+            const unsigned y0 = (unsigned)ty * wg.TH, y1 = min(H0, y0 + (unsigned)wg.TH);
+            const unsigned x0 = (unsigned)tx * wg.TW, x1 = min(W0, x0 + (unsigned)wg.TW);
+            const unsigned num = k == 0 ? 2u * y0 * Hl + H0 - 1u : k == 1 ? 2u * y1 * Hl + H0 - 1u
+                                 : k == 2 ? 2u * x0 * Wl + W0 - 1u : 2u * x1 * Wl + W0 - 1u;
+            s_q[k * TF_MSDA_MAX_LEVELS + l] = (int)(num / (k < 2 ? 2u * H0 : 2u * W0));
+            if (k == 0) {
+                s_tab[l] = lt.H[l];
+                s_tab[TF_MSDA_MAX_LEVELS + l] = lt.W[l];
+                s_tab[2 * TF_MSDA_MAX_LEVELS + l] = lt.start[l];
+            }
+        }
+        s_bb[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
+        if (threadIdx.x < kWinLevels) s_direct[threadIdx.x] = 0;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dv = threadIdx.x & 7, sub = dv & 3, which = dv >> 2;
+    const int pl = threadIdx.x >> 3;   // pair of this lane group inside a pass
+    int qoff[kWinLevels + 1];
+    qoff[0] = 0;
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l)
+        qoff[l + 1] = qoff[l] + (l < L ? (s_q[TF_MSDA_MAX_LEVELS + l] - s_q[l]) *
+                                             (s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l])
+                                       : 0);
+    const int nq = qoff[kWinLevels];
+
+    long long bqs[kWinPasses];
+    bool live[kWinPasses];
+    f32x4_t gA[kWinPasses];
+#pragma unroll
+    for (int ps = 0; ps < kWinPasses; ++ps) {
+        const int tq = ps * kWinPairs + pl;
+        int q = 0;
+        live[ps] = tq < nq;
+        if (live[ps]) {
+            int l = 0, base = 0;
+#pragma unroll
+            for (int k = 1; k < kWinLevels; ++k)
+                if (tq >= qoff[k] && k < L) {
+                    l = k;
+                    base = qoff[k];
+                }
+            const int r = tq - base;
+            const int nx = s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l];
+            const int yy = r / nx, xx = r - yy * nx;
+            q = s_tab[2 * TF_MSDA_MAX_LEVELS + l] + (s_q[l] + yy) * s_tab[TF_MSDA_MAX_LEVELS + l] +
+                s_q[2 * TF_MSDA_MAX_LEVELS + l] + xx;
+        }
+        bqs[ps] = (long long)b * S + q;
+        gA[ps] = *reinterpret_cast<const f32x4_t *>(ba.grad_out + (bqs[ps] * M + m) * D + dv * 4);
+        if (!live[ps]) gA[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4_t *>(s_go + (size_t)tq * D + dv * 4) = gA[ps];   // tile of grad_out
+    }
+
+    // ---- phase A: this lane's points (level 2i + which, point sub) stay in registers; bounding box of the valid
+    //      taps per level
+    float sx[LPAIRS][kWinPasses], sy[LPAIRS][kWinPasses], sa[LPAIRS][kWinPasses];
+#pragma unroll
+    for (int i = 0; i < LPAIRS; ++i) {
+        int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+        const bool have = 2 * i + which < L;
+        const int ml = have ? 2 * i + which : 0;
+        const int H = s_tab[ml], W = s_tab[TF_MSDA_MAX_LEVELS + ml];
+        const float Wf = (float)W, Hf = (float)H;
+#pragma unroll
+        for (int ps = 0; ps < kWinPasses; ++ps) {
+            const long long pi = (bqs[ps] * M + m) * LP + ml * PT + sub;
+            const float2 xy = *reinterpret_cast<const float2 *>(ba.loc + pi * 2);
+            sx[i][ps] = xy.x;
+            sy[i][ps] = xy.y;
+            sa[i][ps] = ba.attn[pi];
+            const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);
+            const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
+            const bool in = live[ps] && have && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
+            const int x0 = (int)__builtin_floorf(in ? xr : 0.f), y0 = (int)__builtin_floorf(in ? yr : 0.f);
+            if (in) {
+                mnx = min(mnx, x0 >= 0 ? x0 : x0 + 1);
+                mxx = max(mxx, (x0 + 1 <= W - 1) ? x0 + 1 : x0);
+                mny = min(mny, y0 >= 0 ? y0 : y0 + 1);
+                mxy = max(mxy, (y0 + 1 <= H - 1) ? y0 + 1 : y0);
+            }
+        }
+        mnx = min(mnx, dpp_i<kDppQuadXor1>(mnx)); mxx = max(mxx, dpp_i<kDppQuadXor1>(mxx));
+        mny = min(mny, dpp_i<kDppQuadXor1>(mny)); mxy = max(mxy, dpp_i<kDppQuadXor1>(mxy));
+        mnx = min(mnx, dpp_i<kDppQuadXor2>(mnx)); mxx = max(mxx, dpp_i<kDppQuadXor2>(mxx));
+        mny = min(mny, dpp_i<kDppQuadXor2>(mny)); mxy = max(mxy, dpp_i<kDppQuadXor2>(mxy));
+        mnx = min(mnx, dpp_i<kDppRowRor8>(mnx)); mxx = max(mxx, dpp_i<kDppRowRor8>(mxx));
+        mny = min(mny, dpp_i<kDppRowRor8>(mny)); mxy = max(mxy, dpp_i<kDppRowRor8>(mxy));
+        if ((lane & 0xB) == 0 && have && mnx != INT_MAX) {
+            atomicMin(&s_bb[4 * ml + 0], mnx);
+            atomicMax(&s_bb[4 * ml + 1], mxx);
+            atomicMin(&s_bb[4 * ml + 2], mny);
+            atomicMax(&s_bb[4 * ml + 3], mxy);
+        }
+    }
+    __syncthreads();
+
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;
+    const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(ba.value), 0, ba.value_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_g =
+        __builtin_amdgcn_make_buffer_rsrc(ba.grad_value, 0, ba.value_bytes, 0x00020000);
+    const unsigned la = (unsigned)dv * 16u;
+    const int half = lane >> 5, ch = lane & 31;
+    const int H0 = __builtin_amdgcn_readfirstlane(s_tab[0]);
+    const int W0 = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS]);
+    const float rH0 = __builtin_amdgcn_rcpf((float)H0), rW0 = __builtin_amdgcn_rcpf((float)W0);
+    const int y0t = ty * wg.TH, y1t = min(H0, y0t + wg.TH);
+    const int x0t = tx * wg.TW, x1t = min(W0, x0t + wg.TW);
+    float rdx[kWinPasses][2], rdy[kWinPasses][2], rdot[kWinPasses][2];
+#pragma unroll
+    for (int ps = 0; ps < kWinPasses; ++ps)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) rdx[ps][h] = rdy[ps][h] = rdot[ps][h] = 0.f;
+
+    // per-wave exchange buffer: [8 pairs of the wave][4 points][offsets | weights | fx fy a -]; later the
+    // transposition buffer of phase e: [8 rows][32 channels] floats + 8 item counts
+    unsigned char *xw = smem + kSort2OffXch + wave * kSort2XchPerWave;
+    u32x4_t *xch = reinterpret_cast<u32x4_t *>(xw) + (lane >> 3) * 12;
+    float *s_tr = reinterpret_cast<float *>(xw);
+    unsigned *s_trn = reinterpret_cast<unsigned *>(xw + 1024);
+    const unsigned char *s_gob = reinterpret_cast<const unsigned char *>(s_go);
+
+#pragma unroll
+    for (int l = 0; l < kWinLevels; ++l) {
+        if (l >= L) break;   // uniform
+        // ---- window of this level: bounding box of the tile's taps, clamped to the tile footprint
+        //      +- (HY, HX) and to kSortRowsCap rows (wave-uniform)
+        const int H = __builtin_amdgcn_readfirstlane(s_tab[l]);
+        const int W = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS + l]);
+        const unsigned lvl_base =
+            head_base + (unsigned)__builtin_amdgcn_readfirstlane(s_tab[2 * TF_MSDA_MAX_LEVELS + l]) * rowbytes;
+        const int bx0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 0]);
+        const int bx1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 1]);
+        const int by0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 2]);
+        const int by1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 3]);
+        const int ny0 = (int)__builtin_floorf((float)y0t * (float)H * rH0 - 0.5f) - wg.HY;
+        const int ny1 = (int)__builtin_floorf((float)y1t * (float)H * rH0 - 0.5f) + 1 + wg.HY;
+        const int nx0 = (int)__builtin_floorf((float)x0t * (float)W * rW0 - 0.5f) - wg.HX;
+        const int nx1 = (int)__builtin_floorf((float)x1t * (float)W * rW0 - 0.5f) + 1 + wg.HX;
+        const int wx0 = max(max(bx0, nx0), 0), wy0 = max(max(by0, ny0), 0);
+        int ww = min(min(bx1, nx1), W - 1) - wx0 + 1, wh = min(min(by1, ny1), H - 1) - wy0 + 1;
+        if (ww <= 0 || wh <= 0 || bx0 == INT_MAX || ww > kSortRowsCap) {
+            ww = 1;
+            wh = 0;
+        }
+        if (wh * ww > kSortRowsCap) wh = kSortRowsCap / ww;
+        const int wx1 = wx0 + ww - 1, wy1 = wy0 + wh - 1, nrows = wh * ww;
+        const float Wf = (float)W, Hf = (float)H;
+
+        // ---- a. reset counters and items
+        for (int i = threadIdx.x; i < nrows; i += kWinThreads) s_cnt[i] = 0u;
+        for (int i = threadIdx.x; i < kSortItems; i += kWinThreads) s_item[i].x = kSortInvalid;
+        __syncthreads();
+
+        // ---- b. taps of this level: grad_loc / grad_attn, and the grad_value items
+        const bool owner = which == (l & 1);   // this lane loaded point `sub` of level l in phase A
+#pragma unroll
+        for (int ps = 0; ps < kWinPasses; ++ps) {
+            if (ps * kWinPairs >= nq) break;   // uniform
+            const int tq = ps * kWinPairs + pl;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous round's reads are done
+            if (owner) {
+                const float a = sa[l >> 1][ps];
+                const float xr = __builtin_fmaf(sx[l >> 1][ps], Wf, -0.5f);   // cuh:350-351
+                const float yr = __builtin_fmaf(sy[l >> 1][ps], Hf, -0.5f);
+                const bool in = live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);   // cuh:359
+                const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+                const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+                const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+                const int x0 = (int)xf, y0 = (int)yf;
+                const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
+                const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
+                const bool kt[4] = {ky0 && kx0, ky0 && kx1, ky1 && kx0, ky1 && kx1};
+                const int r0 = y0 * W + x0;
+                const unsigned t1 = lvl_base + (unsigned)r0 * rowbytes, t2 = t1 + rowbytes;
+                const unsigned t3 = t1 + (unsigned)W * rowbytes, t4 = t3 + rowbytes;
+                const float w[4] = {gy * gx, gy * fx, fy * gx, fy * fx};
+                xch[sub * 3 + 0] = u32x4_t{kt[0] ? t1 : kOobBase, kt[1] ? t2 : kOobBase, kt[2] ? t3 : kOobBase,
+                                           kt[3] ? t4 : kOobBase};
+                xch[sub * 3 + 1] = __builtin_bit_cast(u32x4_t, f32x4_t{w[0], w[1], w[2], w[3]});
+                xch[sub * 3 + 2] = __builtin_bit_cast(u32x4_t, f32x4_t{fx, fy, in ? a : 0.f, 0.f});
+                // grad_value items of the point's four taps (cuh:279,296-301)
+#pragma unroll
+                for (int tp = 0; tp < 4; ++tp) {
+                    const int tx_ = x0 + (tp & 1), ty_ = y0 + (tp >> 1);
+                    const float wt = w[tp] * a;
+                    if (kt[tp] && wt != 0.f) {
+                        const bool inside = tx_ >= wx0 && tx_ <= wx1 && ty_ >= wy0 && ty_ <= wy1;
+                        const unsigned row = inside ? (unsigned)((ty_ - wy0) * ww + (tx_ - wx0))
+                                                    : (0x80000000u | (unsigned)(ty_ * W + tx_));
+                        s_item[(tq * PT + sub) * 4 + tp] =
+                            uint2{row | ((unsigned)tq << 24), __builtin_bit_cast(unsigned, wt)};
+                        if (inside)
+                            atomicAdd(&s_cnt[row], 1u);
+                        else
+                            s_direct[l] = 1;   // benign race: every writer stores the same value
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int s = l * PT + p;
+                const u32x4_t o = xch[p * 3 + 0];
+                const f32x4_t w = __builtin_bit_cast(f32x4_t, xch[p * 3 + 1]);
+                const f32x4_t f = __builtin_bit_cast(f32x4_t, xch[p * 3 + 2]);
+                const f32x4_t v1 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.x + la, 0, 0));
+                const f32x4_t v2 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.y + la, 0, 0));
+                const f32x4_t v3 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.z + la, 0, 0));
+                const f32x4_t v4 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.w + la, 0, 0));
+                // s_t = <grad_out, value row of tap t>: this lane's 4 channels, then the 8 lanes of the pair
+                const f32x4_t g = gA[ps];
+                float s1 = (g.x * v1.x + g.y * v1.y) + (g.z * v1.z + g.w * v1.w);
+                float s2 = (g.x * v2.x + g.y * v2.y) + (g.z * v2.z + g.w * v2.w);
+                float s3 = (g.x * v3.x + g.y * v3.y) + (g.z * v3.z + g.w * v3.w);
+                float s4 = (g.x * v4.x + g.y * v4.y) + (g.z * v4.z + g.w * v4.w);
+                s1 += dpp_f<kDppQuadXor1>(s1); s2 += dpp_f<kDppQuadXor1>(s2);
+                s3 += dpp_f<kDppQuadXor1>(s3); s4 += dpp_f<kDppQuadXor1>(s4);
+                s1 += dpp_f<kDppQuadXor2>(s1); s2 += dpp_f<kDppQuadXor2>(s2);
+                s3 += dpp_f<kDppQuadXor2>(s3); s4 += dpp_f<kDppQuadXor2>(s4);
+                s1 += dpp_f<kDppRowHalfMirror>(s1); s2 += dpp_f<kDppRowHalfMirror>(s2);
+                s3 += dpp_f<kDppRowHalfMirror>(s3); s4 += dpp_f<kDppRowHalfMirror>(s4);
+                const float fx = f.x, fy = f.y, a = f.z, gx = 1.f - fx, gy = 1.f - fy;
+                const float dot = (w.x * s1 + w.y * s2) + (w.z * s3 + w.w * s4);   // cuh:365,376
+                const float dx = (s2 - s1) * gy + (s4 - s3) * fy;                   // cuh:150-160
+                const float dy = (s3 - s1) * gx + (s4 - s2) * fx;                   // cuh:139-149
+                if ((s & 7) == dv) {   // lane dv keeps points dv and dv + 8
+                    rdx[ps][s >> 3] = dx * a * Wf;      // cuh:371,373
+                    rdy[ps][s >> 3] = dy * a * Hf;      // cuh:371,374
+                    rdot[ps][s >> 3] = dot;             // cuh:376
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- c. exclusive prefix sum of the row counts (wave 0; 16 consecutive rows per lane)
+        if (wave == 0) {
+            unsigned c[16], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = lane * 16 + k;
+                c[k] = r < nrows ? s_cnt[r] : 0u;
+                sum += c[k];
+            }
+            unsigned incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned up = (unsigned)__shfl_up((int)incl, off);
+                if (lane >= off) incl += up;
+            }
+            unsigned run = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = lane * 16 + k;
+                if (r < nrows) {
+                    s_start[r] = run;
+                    s_cnt[r] = 0u;   // reused as the placement cursor
+                }
+                run += c[k];
+            }
+            if (lane == 63) s_start[nrows] = incl;   // number of binned items
+        }
+        __syncthreads();
+
+        // ---- d. place the binned items in row order, as {byte offset of the query's grad_out row in s_go, weight}
+        for (int i = threadIdx.x; i < kSortItems; i += kWinThreads) {
+            const uint2 it = s_item[i];
+            if (it.x != kSortInvalid && !(it.x & 0x80000000u)) {
+                const unsigned row = it.x & 0xFFFFFFu;
+                s_sorted[s_start[row] + atomicAdd(&s_cnt[row], 1u)] = uint2{((it.x >> 24) & 0x7Fu) * (unsigned)(D * 4), it.y};
+            }
+        }
+        __syncthreads();
+
+        // ---- e. eight destination rows per wave at a time (8 lanes x 4 channels per row): sum each row's segment,
+        //         transpose through LDS, one atomic per complete 128-byte row
+        const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
+        const int rg = lane >> 3, cq = lane & 7;
+        for (int r0 = wave * 8; r0 < nrows; r0 += 8 * kWinWaves) {
+            const int row = r0 + rg;
+            unsigned beg = 0, n = 0;
+            if (row < nrows) {
+                beg = s_start[row];
+                n = s_start[row + 1] - beg;
+            }
+            if (!__any(n != 0u)) continue;   // wave-uniform: eight empty rows
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            for (unsigned k = 0; __any(k < n); k += 2) {   // two items in flight
+                const bool p0 = k < n, p1 = k + 1 < n;
+                const uint2 i0 = s_sorted[p0 ? beg + k : 0u], i1 = s_sorted[p1 ? beg + k + 1 : 0u];
+                const f32x4_t g0 = *reinterpret_cast<const f32x4_t *>(s_gob + (p0 ? i0.x : 0u) + (unsigned)cq * 16u);
+                const f32x4_t g1 = *reinterpret_cast<const f32x4_t *>(s_gob + (p1 ? i1.x : 0u) + (unsigned)cq * 16u);
+                acc += g0 * (p0 ? __builtin_bit_cast(float, i0.y) : 0.f);
+                acc += g1 * (p1 ? __builtin_bit_cast(float, i1.y) : 0.f);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous group's reads of s_tr are done
+            *reinterpret_cast<f32x4_t *>(s_tr + rg * D + cq * 4) = acc;
+            if (cq == 0) s_trn[rg] = n;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rr = 2 * j + half, rowj = r0 + rr;
+                const float v = s_tr[rr * D + ch];
+                if (rowj < nrows && s_trn[rr] != 0u) {
+                    int wy = (int)(((float)rowj + 0.5f) * inv_ww);
+                    int wx = rowj - wy * ww;
+                    if (wx < 0) { --wy; wx += ww; }
+                    if (wx >= ww) { ++wy; wx -= ww; }
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                        v, rsrc_g, lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)ch * 4u, 0, 0);
+                }
+            }
+        }
+        // ---- f. taps outside the window: scattered directly, still one full row per half wave
+        if (s_direct[l]) {
+            for (int i = wave * 2 + half; i < kSortItems; i += 2 * kWinWaves) {
+                const uint2 it = s_item[i];
+                if (it.x != kSortInvalid && (it.x & 0x80000000u)) {
+                    const float v = __builtin_bit_cast(float, it.y) * s_go[((it.x >> 24) & 0x7Fu) * D + ch];
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                        v, rsrc_g, lvl_base + (it.x & 0xFFFFFFu) * rowbytes + (unsigned)ch * 4u, 0, 0);
+                }
+            }
+        }
+        __syncthreads();   // items / counters / exchange buffers are reused by the next level
+    }
+
+#pragma unroll
+    for (int ps = 0; ps < kWinPasses; ++ps) {
+        if (!live[ps]) continue;
+        const long long pair = bqs[ps] * M + m;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = dv + 8 * h;
+            if (s < LP) {
+                *reinterpret_cast<float2 *>(ba.grad_loc + (pair * LP + s) * 2) = float2{rdx[ps][h], rdy[ps][h]};
+                ba.grad_attn[pair * LP + s] = rdot[ps][h];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward (grad_value via atomics, grad_loc / grad_attn via wave reduction), fused
 // ---------------------------------------------------------------------------------------------
 #ifdef TF_EXPERIMENT_WG_SCOPE_ATOMICS
@@ -2292,6 +2689,27 @@ bool direct_enabled()
     return on != 0;
 }
 
+std::atomic<int> g_bwd_sorted2{-1};   // -1: environment (TF_MSDA_BWD_SORTED2, default 0)
+bool bwd_sorted2_enabled()
+{
+    const int v = g_bwd_sorted2.load(std::memory_order_relaxed);
+    if (v >= 0) return v != 0;
+    static const int env = [] { const char *e = getenv("TF_MSDA_BWD_SORTED2"); return (e && e[0] == '1') ? 1 : 0; }();
+    return env != 0;
+}
+// dynamic LDS above 64 KB needs the per-function, per-device attribute: set once per device for msda_bwd_f32_sorted2
+bool raise_dynamic_lds(const void *fn)
+{
+    static std::atomic<unsigned long long> done{0};   // bit d: device d has the attribute
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
+
 std::atomic<int> g_direct9{-1};   // -1: environment (TF_MSDA_DIRECT9, default 0)
 bool direct9_enabled()
 {
@@ -2506,11 +2924,13 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
                 plan_sorted(lt, L, D, P, &sgeom) &&
                 (long long)N * sgeom.tiles_y * sgeom.tiles_x * M <= 0x7fffffffLL) {
                 BwdSortArgs ba{value, vbytes, loc, attn, grad_out, grad_value, grad_loc, grad_attn, S, M, L};
-                const void *sfn = (const void *)&msda_bwd_f32_sorted;
+                const bool v2 = bwd_sorted2_enabled();
+                const void *sfn = v2 ? (const void *)&msda_bwd_f32_sorted2 : (const void *)&msda_bwd_f32_sorted;
+                const size_t slds = v2 ? (size_t)kSort2LdsBytes : (size_t)kSortLdsBytes;
+                if (slds > 64 * 1024 && !raise_dynamic_lds(sfn)) return record_hip(hipErrorInvalidValue);
                 void *argv[] = {(void *)&ba, (void *)&lt, (void *)&sgeom};
                 const unsigned sgrid = (unsigned)((long long)N * sgeom.tiles_y * sgeom.tiles_x * M);
-                return record_hip(hipLaunchKernel(sfn, dim3(sgrid), dim3(kWinThreads), argv,
-                                                  (size_t)kSortLdsBytes, stream));
+                return record_hip(hipLaunchKernel(sfn, dim3(sgrid), dim3(kWinThreads), argv, slds, stream));
             }
             static const int rowatom_on = [] { const char *e = getenv("TF_MSDA_BWD_ROWATOM"); return (e && e[0] == '0') ? 0 : 1; }();
             const bool rowatom = rowatom_on && D == 32 && pl.DV == 8 && pl.ppb == kThreads / 8;
@@ -2591,6 +3011,7 @@ int tf_msda_set_option(const char *name, int value)
             g_quad_epoch.fetch_add(1);
             return prev;
         }
+    if (strcmp(name, "bwd_sorted2") == 0) return g_bwd_sorted2.exchange(value < 0 ? -1 : (value ? 1 : 0));
     if (strcmp(name, "direct9") == 0) return g_direct9.exchange(value < 0 ? -1 : (value ? 1 : 0));
     if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);
     if (strcmp(name, "linear_stream_ti") == 0) return linear_stream_set_ti(value);

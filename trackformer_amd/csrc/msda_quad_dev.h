@@ -23,6 +23,7 @@ constexpr int kDppQuadXor1 = 0xB1;   // quad_perm [1,0,3,2]
 constexpr int kDppQuadXor2 = 0x4E;   // quad_perm [2,3,0,1]
 constexpr int kDppRowRor4 = 0x124;
 constexpr int kDppRowRor8 = 0x128;
+constexpr int kDppRowHalfMirror = 0x141;   // lane i <- lane 7 - i of its group of 8
 
 // One point's four taps from LDS windows.  a0 / a1: byte offsets (from the first LDS row) of the rows
 // (y0, x0) and (y0 + 1, x0) held by lane K of the quad; the x0 + 1 taps are the next 128-byte rows.
