@@ -121,6 +121,9 @@ def parse_args():
                     help="encoder / decoder linears as bf16 split products on the matrix cores "
                          "(tf_linear_split_f32; same as TF_SPLIT_LINEAR=1)")
     ap.add_argument("--no-split-linear", dest="split_linear", action="store_false")
+    ap.add_argument("--conv1x1-split", dest="conv1x1_split", action="store_true", default=None,
+                    help="OPT-IN: the backbone's stride-1 1x1 convolutions through the split-product GEMM with the "
+                         "FrozenBN / identity / ReLU epilogue (same as TF_CONV1X1_SPLIT=1)")
     ap.add_argument("--sequences", type=int, default=4,
                     help="independent video sequences tracked concurrently per GPU (one host thread "
                          "and HIP stream each); frames of one sequence stay strictly sequential")
@@ -547,6 +550,9 @@ def main():
                                     verbose=(rank == 0))
     if args.split_linear is not None:
         fused.set_split_linear(args.split_linear)
+    from trackformer_amd import backbone as _backbone
+    if args.conv1x1_split is not None:
+        _backbone.set_conv1x1_split(args.conv1x1_split)
 
     if args.roofline_only:
         if rank == 0:
@@ -594,7 +600,9 @@ def main():
             "ms_per_step": round(1e3 * elapsed / steps_timed, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if not fused.split_linear_enabled() or train
-                     else "f32 (transformer linears: 3-pass bf16 split product on MFMA, f32 accumulate)",
+                     else ("f32 (transformer linears + backbone 1x1 convolutions: 3-pass bf16 split product on MFMA, f32 accumulate)"
+                           if _backbone._conv1x1_split else
+                           "f32 (transformer linears: 3-pass bf16 split product on MFMA, f32 accumulate)"),
             "data": "synthetic", "per_gpu": round(value / world, 3),
             "timed_repeats": reps, "steps_timed": steps_timed, "timed_seconds": round(elapsed, 3),
             "config": {"workload": cfg["name"] + ", seeded random-init weights, frames "

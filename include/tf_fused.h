@@ -56,6 +56,15 @@ int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, con
                         int64_t M, int K, int N, int relu, void *stream);
 
 /*
+ * The same product with a residual in the epilogue: y = act(x . w^T + bias + residual), residual [M, N] fp32 (may alias y).
+ * For the 1 x 1 convolutions that close a ResNet bottleneck (conv3 -> FrozenBatchNorm2d -> `out += identity` -> ReLU;
+ * reference: models/backbone.py:45-55 + torchvision's Bottleneck.forward): on channels_last activations a stride-1 1 x 1
+ * convolution IS this GEMM with M = N_img * H * W rows, the BN scale folded into w and its shift as bias.
+ */
+int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, const float *residual,
+                            float *y, int64_t M, int K, int N, int relu, void *stream);
+
+/*
  * The same product with the weight in PACKED form (trackformer_amd/csrc/linear_stream.hip): the weight is split into
  * bf16 (hi, mid) once and stored in matrix-core fragment order, so that the GEMM streams it from L2 into registers and
  * only the activations pass through LDS.  Results are bit-identical to tf_linear_split_f32.

@@ -47,6 +47,8 @@ def lib():
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_linear_split_f32.restype = ci
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_split_res_f32.restype = ci
+    L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_packed_bytes.restype = ctypes.c_int64
     L.tf_linear_packed_bytes.argtypes = [ci, ci]
     L.tf_linear_pack_weight_f32.restype = ci
@@ -145,7 +147,7 @@ def bf16_split(w):
     return hi, mid
 
 
-def linear_split(x, w, bias=None, relu=False):
+def linear_split(x, w, bias=None, relu=False, residual=None):
     x, w = _c(x, np.float32), _c(w, np.float32)
     M, K = x.shape
     N = w.shape[0]
@@ -153,7 +155,11 @@ def linear_split(x, w, bias=None, relu=False):
     hi, mid = np.ascontiguousarray(hi), np.ascontiguousarray(mid)
     b = _c(bias, np.float32) if bias is not None else None
     y = np.full((M, N), np.nan, np.float32)
-    rc = lib().tf_linear_split_f32(_p(x), _p(hi), _p(mid), _p(b), _p(y), M, K, N, int(relu), None)
+    if residual is not None:
+        r = _c(residual, np.float32)
+        rc = lib().tf_linear_split_res_f32(_p(x), _p(hi), _p(mid), _p(b), _p(r), _p(y), M, K, N, int(relu), None)
+    else:
+        rc = lib().tf_linear_split_f32(_p(x), _p(hi), _p(mid), _p(b), _p(y), M, K, N, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_linear_split_f32: status %d" % rc)
     return y

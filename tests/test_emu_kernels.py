@@ -369,3 +369,24 @@ def test_encoder_shape_backward_sorted2_kernel(name, shapes, mode, N, D):
     np.testing.assert_allclose(gv, base[0], atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(gl, base[1], atol=2e-3, rtol=1e-4)
     np.testing.assert_allclose(ga, base[2], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 64, 256), (130, 256, 64), (200, 512, 128), (70, 128, 512)], ids=lambda v: str(v))
+@pytest.mark.parametrize("relu", [False, True], ids=["plain", "relu"])
+def test_split_product_linear_with_residual_epilogue(M, K, N, relu):
+    """tf_linear_split_res_f32: y = act(x . w^T + bias + residual) -- the closing 1 x 1 convolution of a ResNet bottleneck
+    (FrozenBN shift as bias, identity branch as residual) at its channel counts; bit-identical to the plain kernel + add."""
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N, dtype=np.float32)
+    r = rng.standard_normal((M, N), dtype=np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b + r
+    if relu:
+        ref = np.maximum(ref, 0)
+    y = emu_lib.linear_split(x, w, b, relu, residual=r)
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    plain = emu_lib.linear_split(x, w, b, False) + r
+    if relu:
+        plain = np.maximum(plain, 0)
+    assert np.array_equal(y, plain.astype(np.float32))

@@ -147,3 +147,60 @@ def test_full_size_tracker_track_ids_bit_exact(dev, models, setup):
     np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])   # id, frame, source query
     np.testing.assert_allclose(rows[:, 2:6], z["rows"][:, 2:6], atol=1e-3 * max(um.FULL_ORIG))
     np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
+
+
+# ------------------------------------------------------------------ opt-in route (not a default; see test_msda_gpu.py)
+optin = pytest.mark.skipif(os.environ.get("TF_TEST_OPTIN") != "1", reason="opt-in kernels: set TF_TEST_OPTIN=1")
+
+
+@optin
+@pytest.mark.parametrize("case", list(um.FULL_CASES))
+def test_optin_conv1x1_split_route_full_size(dev, models, case):
+    """The stride-1 1 x 1 convolutions of the backbone through the split-product GEMM with the FrozenBN shift / identity /
+    ReLU epilogue (backbone.set_conv1x1_split): BASELINE-size model against the reference goldens, bench set-up."""
+    from trackformer_amd import backbone
+    prev = backbone.set_conv1x1_split(True)
+    try:
+        model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
+        dbox, dlogit = _compare(case, model, out, res, feats, memory)
+        print("%s / conv1x1 split: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+    finally:
+        backbone.set_conv1x1_split(prev)
+
+
+@optin
+def test_optin_conv1x1_split_route_tracker_ids(dev, models):
+    from trackformer_amd import backbone
+    prev = backbone.set_conv1x1_split(True)
+    try:
+        tracker, rows, active = _run_tracker(models, dev, "graph_split_linear")
+    finally:
+        backbone.set_conv1x1_split(prev)
+    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
+    assert int(z["num_tracks"]) == tracker.track_num and z["active_per_frame"].tolist() == active
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
+
+
+@optin
+def test_optin_conv1x1_split_backbone_layer_outputs(dev):
+    """Bottleneck by bottleneck: the split route against the library convolutions on the same weights (1e-3 relative to
+    the feature scale; the three-term product is ~2^-16 per layer)."""
+    from trackformer_amd import backbone
+    torch.manual_seed(0)
+    blk = backbone.Bottleneck(256, 64).to(dev).eval()
+    for m in blk.modules():
+        if isinstance(m, backbone.FrozenBatchNorm2d):
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.normal_(0, 0.1)
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(1, 256, 50, 84, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        ref = blk(x)
+        prev = backbone.set_conv1x1_split(True)
+        try:
+            got = blk(x)
+        finally:
+            backbone.set_conv1x1_split(prev)
+    assert got.is_contiguous(memory_format=torch.channels_last)
+    assert float((got - ref).abs().max()) < 1e-3 * float(ref.abs().max())

@@ -2,7 +2,7 @@
 """Feasibility experiment (CPU, no GPU needed): can the dense linears of the path run as bf16 split products on the
 matrix cores (fp32 = hi + mid + lo bf16 pieces, fp32 accumulation) without leaving the parity bar?
 
-    python tools/experiments/bf16_split_linear.py [x3|x6|x1] [conv]
+    python tools/experiments/bf16_split_linear.py [x3|x6|x1] [conv|conv1x1] [full]
 
 Every torch.nn.functional.linear / torch._addmm_activation of the model is replaced by an emulation of the split
 product -- the pieces are rounded to bf16 exactly as the hardware would see them, the partial products (exact in
@@ -11,7 +11,9 @@ the tracker with the reference goldens (boxes / logits <= 1e-3, track ids exact)
   x1: plain bf16 (1 MFMA pass)             -- what "just use bf16" would mean
   x3: hi*hi + hi*mid + mid*hi              -- ~16 mantissa bits
   x6: + mid*mid + hi*lo + lo*hi            -- ~fp32
-With `conv` the convolutions (backbone, input projections, mask head) are split the same way.
+With `conv` the convolutions (backbone, input projections, mask head) are split the same way; with `conv1x1` only the
+stride-1 1 x 1 convolutions (what trackformer_amd/backbone.py's opt-in TF_CONV1X1_SPLIT route sends through the split GEMM,
+plus the input projections).  `full` adds the BASELINE-size goldens (tests/test_full_size_cpu.py).
 Result of the round-1 run: see DESIGN.md section 6 ("next").
 """
 import os
@@ -24,7 +26,9 @@ import torch.nn.functional as F
 REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 MODE = sys.argv[1] if len(sys.argv) > 1 else "x3"
-CONV = len(sys.argv) > 2 and sys.argv[2] == "conv"
+CONV = len(sys.argv) > 2 and sys.argv[2] in ("conv", "conv1x1")
+ONLY_1X1 = len(sys.argv) > 2 and sys.argv[2] == "conv1x1"
+FULL = "full" in sys.argv[3:]
 _orig_conv2d = F.conv2d
 _orig_linear = F.linear
 _orig_addmm_act = torch._addmm_activation
@@ -64,6 +68,11 @@ def addmm_activation(bias, x, w_t, *, beta=1, alpha=1, use_gelu=False):
 def conv2d(x, w, b=None, *args, **kw):
     if x.dtype != torch.float32 or x.is_cuda:
         return _orig_conv2d(x, w, b, *args, **kw)
+    if ONLY_1X1:
+        stride = args[0] if len(args) > 0 else kw.get("stride", 1)
+        groups = args[3] if len(args) > 3 else kw.get("groups", 1)
+        if tuple(w.shape[2:]) != (1, 1) or stride not in (1, (1, 1), [1, 1]) or groups != 1:
+            return _orig_conv2d(x, w, b, *args, **kw)
     xh, xm, xl = _pieces(x)
     wh, wm, wl = _pieces(w)
     c = lambda a, k: _orig_conv2d(a, k, None, *args, **kw)
@@ -83,4 +92,8 @@ if __name__ == "__main__":
     torch.nn.functional.linear = linear
     torch._addmm_activation = addmm_activation
     sel = "model_forward_matches_reference or tracker_sequence_matches_reference or tracker_variants_match_reference"
-    sys.exit(pytest.main([os.path.join(REPO, "tests", "test_models_cpu.py"), "-q", "-x", "--no-header", "-k", sel]))
+    files = [os.path.join(REPO, "tests", "test_models_cpu.py")]
+    if FULL:
+        files.append(os.path.join(REPO, "tests", "test_full_size_cpu.py"))
+        sel += " or full_size_model_matches_reference"
+    sys.exit(pytest.main(files + ["-q", "--no-header", "-k", sel, "-s"]))

@@ -30,6 +30,42 @@ import os as _os
 CHANNELS_LAST = _os.environ.get("TF_BACKBONE_NCHW", "0") != "1"
 
 
+# OPT-IN (TF_CONV1X1_SPLIT=1 / set_conv1x1_split(True)), not yet timed on hardware: the stride-1 1 x 1 convolutions of the
+# bottlenecks (32 of ResNet-50's 53 convolutions, ~half of its flops) run as the library's own split-product GEMM
+# (fused.linear: hi.hi + hi.mid + mid.hi on the bf16 matrix cores, fp32 accumulate) with the FrozenBN shift, the
+# identity branch and the ReLU in its epilogue -- on channels_last activations such a convolution IS a GEMM over the
+# N*H*W pixels, and the separate bias_act pass disappears.  Three-term products leave the full-size model inside the
+# 1e-3 bar but not at fp32 agreement (tools/experiments/bf16_split_linear.py x3 conv: logits off by ~7e-5).
+_conv1x1_split = _os.environ.get("TF_CONV1X1_SPLIT", "0") == "1"
+
+
+def set_conv1x1_split(on):
+    """Route the stride-1 1 x 1 convolutions through the split-product GEMM (process-wide); returns the previous setting."""
+    global _conv1x1_split
+    prev, _conv1x1_split = _conv1x1_split, bool(on)
+    return prev
+
+
+def conv1x1_as_gemm(x, w2d, bias, residual, relu, linear_fn):
+    """1 x 1 stride-1 convolution of a channels_last activation as a GEMM over its pixels.
+    x [N, Cin, H, W] (channels_last), w2d [Cout, Cin], bias [Cout] or None, residual like the output or None;
+    linear_fn(x2, w2d, bias, relu, residual2) -> [N*H*W, Cout] or None.  Returns [N, Cout, H, W] (channels_last) or None."""
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        return None
+    n, cin, h, w = x.shape
+    cout = w2d.shape[0]
+    x2 = x.permute(0, 2, 3, 1).reshape(n * h * w, cin)          # a view: NHWC storage
+    r2 = None
+    if residual is not None:
+        if residual.shape != (n, cout, h, w) or not residual.is_contiguous(memory_format=torch.channels_last):
+            return None
+        r2 = residual.permute(0, 2, 3, 1).reshape(n * h * w, cout)
+    y2 = linear_fn(x2, w2d, bias, relu, r2)
+    if y2 is None:
+        return None
+    return y2.view(n, h, w, cout).permute(0, 3, 1, 2)            # NCHW shape over NHWC storage = channels_last
+
+
 class FrozenBatchNorm2d(nn.Module):
     """BatchNorm2d with fixed statistics and affine parameters, stored as buffers
     (y = x * w * rsqrt(var + 1e-5) + (b - mean * w * rsqrt(var + 1e-5)), backbone.py:45-55)."""
@@ -63,6 +99,7 @@ class _FoldCache:
         self.key = None
         self.weight = None
         self.bias = None
+        self.weight2d = None   # [Cout, Cin] of a 1 x 1 convolution (a persistent tensor: fused.linear caches its pieces on it)
 
     def get(self, conv: nn.Conv2d, bn: FrozenBatchNorm2d):
         srcs = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
@@ -74,6 +111,7 @@ class _FoldCache:
                 self.weight = w.contiguous(memory_format=torch.channels_last) if CHANNELS_LAST \
                     else w.contiguous()
                 self.bias = shift.contiguous()
+                self.weight2d = w.reshape(w.shape[0], w.shape[1]).contiguous() if w.shape[2:] == (1, 1) else None
             self.key = key
         return self.weight, self.bias
 
@@ -89,6 +127,12 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
     if fold and isinstance(bn, FrozenBatchNorm2d):
         w, b = cache.get(conv, bn)
         if x.is_cuda:
+            if (_conv1x1_split and cache.weight2d is not None and conv.stride == (1, 1) and conv.padding == (0, 0)
+                    and conv.groups == 1 and CHANNELS_LAST):
+                y = conv1x1_as_gemm(x, cache.weight2d, b, residual, relu,
+                                    lambda x2, w2, bb, act, r2: fused.linear(x2, w2, bb, relu=act, residual=r2))
+                if y is not None:
+                    return y
             y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
             if fused.bias_act_(y, b, residual, relu) is not None:
                 return y

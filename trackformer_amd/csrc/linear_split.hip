@@ -45,11 +45,13 @@ constexpr int LDS_STRIDE = BK + 8;   // bf16 elements per LDS row: 80 bytes, kee
 // PREFETCH: the global loads of K-slice s + 1 are issued before the MFMAs of slice s and written to LDS after them
 // (register double buffer), so a block's memory latency hides under its own matrix work instead of relying on a
 // second block on the CU being in the other phase.
-template <int BM, int BN, bool RELU, bool PREFETCH>
-__global__ void __launch_bounds__(THREADS)
-split_gemm_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                  const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
-                  int M, int K, int N)
+// RESID: Y = act(X . W^T + bias + R) with R [M, N] fp32 (the identity branch of a bottleneck: `out += identity` before
+// the ReLU, torchvision resnet.py Bottleneck.forward) -- only instantiated by split_gemm_res_kernel below.
+template <int BM, int BN, bool RELU, bool PREFETCH, bool RESID>
+__device__ __forceinline__ void
+split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
+                const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, const float *__restrict__ R,
+                float *__restrict__ Y, int M, int K, int N)
 {
     constexpr int TI = BM / 64, TJ = BN / 64;
     constexpr int XV = (BM * BK / 4) / THREADS;   // float4 of X per thread and slice
@@ -161,11 +163,30 @@ split_gemm_kernel(const float *__restrict__ X, const unsigned short *__restrict_
                 const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < M) {
                     float v = acc[i][j][r] + b;
+                    if constexpr (RESID) v += R[(size_t)row * N + col];
                     if (RELU) v = v > 0.f ? v : 0.f;
                     Y[(size_t)row * N + col] = v;
                 }
             }
         }
+}
+
+template <int BM, int BN, bool RELU, bool PREFETCH>
+__global__ void __launch_bounds__(THREADS)
+split_gemm_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
+                  const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
+                  int M, int K, int N)
+{
+    split_gemm_body<BM, BN, RELU, PREFETCH, false>(X, Whi, Wmid, bias, nullptr, Y, M, K, N);
+}
+
+template <int BM, int BN, bool RELU, bool PREFETCH>
+__global__ void __launch_bounds__(THREADS)
+split_gemm_res_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
+                      const unsigned short *__restrict__ Wmid, const float *__restrict__ bias,
+                      const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N)
+{
+    split_gemm_body<BM, BN, RELU, PREFETCH, true>(X, Whi, Wmid, bias, R, Y, M, K, N);
 }
 
 // ---- weight-stationary variant (variant 6; K == 256, many rows; an experiment that was run and measured, see above): the 128 x 256 weight block of a column block stays in LDS for the
@@ -363,11 +384,18 @@ int variant()
 }
 
 template <int BM, int BN, bool PREFETCH>
-int launch_variant(const float *x, const unsigned short *wh, const unsigned short *wm, const float *bias, float *y, int M, int K,
-                   int N, int relu, hipStream_t s)
+int launch_variant(const float *x, const unsigned short *wh, const unsigned short *wm, const float *bias, const float *res,
+                   float *y, int M, int K, int N, int relu, hipStream_t s)
 {
     const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
+    if (res) {
+        if (relu)
+            hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, true, PREFETCH>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
+        else
+            hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, false, PREFETCH>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
+        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    }
     if (relu)
         hipLaunchKernelGGL((split_gemm_kernel<BM, BN, true, PREFETCH>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, M, K, N);
     else
@@ -386,8 +414,27 @@ int linear_set_variant(int v)
 }
 }  // namespace tfm
 
+namespace {
+int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, const float *res, float *y,
+                      int64_t M, int K, int N, int relu, void *stream);
+}
+
 extern "C" int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
                                    int64_t M, int K, int N, int relu, void *stream)
+{
+    return linear_split_impl(x, w_hi, w_mid, bias, nullptr, y, M, K, N, relu, stream);
+}
+
+extern "C" int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias,
+                                       const float *residual, float *y, int64_t M, int K, int N, int relu, void *stream)
+{
+    if (!residual) return TF_MSDA_ERR_NULL_POINTER;
+    return linear_split_impl(x, w_hi, w_mid, bias, residual, y, M, K, N, relu, stream);
+}
+
+namespace {
+int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, const float *res, float *y,
+                      int64_t M, int K, int N, int relu, void *stream)
 {
     if (!x || !w_hi || !w_mid || !y) return TF_MSDA_ERR_NULL_POINTER;
     if (M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
@@ -409,16 +456,17 @@ extern "C" int tf_linear_split_f32(const float *x, const void *w_hi, const void 
         else var = 2;
     }
     if (var == 6) {
-        const int rc = launch_ws(x, wh, wm, bias, y, (int)M, K, N, relu, s);
+        const int rc = res ? 1 : launch_ws(x, wh, wm, bias, y, (int)M, K, N, relu, s);   // (no residual epilogue there)
         if (rc != 1) return rc;
         var = 2;
     }
     switch (var) {
-    case 0: return launch_variant<128, 128, false>(x, wh, wm, bias, y, (int)M, K, N, relu, s);   // round 1
-    case 1: return launch_variant<128, 128, true>(x, wh, wm, bias, y, (int)M, K, N, relu, s);
-    case 3: return launch_variant<64, 128, false>(x, wh, wm, bias, y, (int)M, K, N, relu, s);
-    case 4: return launch_variant<128, 64, true>(x, wh, wm, bias, y, (int)M, K, N, relu, s);
-    case 5: return launch_variant<64, 64, true>(x, wh, wm, bias, y, (int)M, K, N, relu, s);
-    default: return launch_variant<64, 128, true>(x, wh, wm, bias, y, (int)M, K, N, relu, s);
+    case 0: return launch_variant<128, 128, false>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);   // round 1
+    case 1: return launch_variant<128, 128, true>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
+    case 3: return launch_variant<64, 128, false>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
+    case 4: return launch_variant<128, 64, true>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
+    case 5: return launch_variant<64, 64, true>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
+    default: return launch_variant<64, 128, true>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
     }
 }
+}  // namespace

@@ -163,11 +163,12 @@ def _split_weight(weight):
     return hit[1], hit[2]
 
 
-def linear(x, weight, bias=None, relu=False, rows=None):
+def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
     """act(x @ weight^T + bias) through tf_linear_split_f32 for fp32 GPU tensors with K % 32 == 0; returns None when
     it does not apply (switched off, other dtype / device / shape): the caller keeps its PyTorch formulation.
     rows = (a, b): use output features a..b of `weight` only (a row block of a packed projection such as
-    nn.MultiheadAttention.in_proj_weight); `bias` is then the matching slice."""
+    nn.MultiheadAttention.in_proj_weight); `bias` is then the matching slice.
+    residual: fp32 [rows of x, N], added before the activation (tf_linear_split_res_f32)."""
     if not (_split_linear and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32
             and weight.dim() == 2 and weight.is_contiguous() and weight.device == x.device):
         return None
@@ -184,7 +185,10 @@ def linear(x, weight, bias=None, relu=False, rows=None):
     x2 = x.reshape(-1, K)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
-    if _use_packed(x2.shape[0], K, N) and not (x2.data_ptr() & 15):
+    if residual is not None and not (residual.dtype == torch.float32 and residual.is_contiguous() and residual.device == x.device
+                                     and residual.numel() == x2.shape[0] * N):
+        return None
+    if residual is None and _use_packed(x2.shape[0], K, N) and not (x2.data_ptr() & 15):
         packed = _packed_weight(weight, rows)
         if packed is not None:
             with torch.cuda.device(x.device):
@@ -201,9 +205,14 @@ def linear(x, weight, bias=None, relu=False, rows=None):
         return None
     with torch.cuda.device(x.device):
         y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
-        rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(),
-                                             0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0], K, N,
-                                             1 if relu else 0, _stream(x.device))
+        if residual is None:
+            rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(),
+                                                 0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0], K, N,
+                                                 1 if relu else 0, _stream(x.device))
+        else:
+            rc = _cabi.lib().tf_linear_split_res_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(),
+                                                     0 if bias is None else bias.data_ptr(), residual.data_ptr(),
+                                                     y.data_ptr(), x2.shape[0], K, N, 1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_linear_split_f32")
     return y.view(*x.shape[:-1], N)
 
