@@ -105,20 +105,23 @@ CONFIGS = [
 ]
 
 
-def run(iters=50, modes=("uniform", "local", "init"), device="cuda:0", backward=True):
+def run(iters=50, modes=("uniform", "local", "init"), device="cuda:0", backward=True, shapes=None, forward=True):
     rows = []
     for name, kw in CONFIGS:
+        if shapes and name not in shapes:
+            continue
         for mode in modes:
             S = sum(h * w for h, w in kw["shapes"])
             value, shapes, loc, attn, grad_out = make_inputs(
                 mode=mode, device=device, encoder_refs=(kw["Lq"] == S), **kw)
             dims = dict(N=kw["N"], S=S, M=kw["M"], D=kw["D"], L=len(kw["shapes"]), Lq=kw["Lq"],
                         P=kw["P"])
-            ms = time_launches(lambda: msda.ms_deform_attn_forward(value, shapes, loc, attn, 64),
-                               iters)
-            b = algorithmic_bytes(**dims)
-            rows.append(dict(shape=name, mode=mode, dir="fwd", ms=ms, alg_MB=b / 1e6,
-                             GBs=b / ms / 1e6, frac=b / ms / 1e6 / HBM_PEAK_GBS))
+            if forward:
+                ms = time_launches(lambda: msda.ms_deform_attn_forward(value, shapes, loc, attn, 64),
+                                   iters)
+                b = algorithmic_bytes(**dims)
+                rows.append(dict(shape=name, mode=mode, dir="fwd", ms=ms, alg_MB=b / 1e6,
+                                 GBs=b / ms / 1e6, frac=b / ms / 1e6 / HBM_PEAK_GBS))
             if backward:
                 ms = time_launches(lambda: msda.ms_deform_attn_backward(value, shapes, loc, attn,
                                                                         grad_out, 64), iters)
@@ -133,8 +136,18 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--json", default=None)
     ap.add_argument("--no-backward", action="store_true")
+    ap.add_argument("--no-forward", action="store_true")
+    ap.add_argument("--shapes", default=None, help="comma-separated subset of: " + ", ".join(n for n, _ in CONFIGS))
+    ap.add_argument("--modes", default="uniform,local,init")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="tf_msda_set_option before timing, e.g. --option direct9=1 --option bwd_sorted2=1")
     args = ap.parse_args()
-    rows = run(args.iters, backward=not args.no_backward)
+    from trackformer_amd import _cabi
+    for o in args.option:
+        k, v = o.split("=")
+        print("option %s: %d -> %s" % (k, _cabi.lib().tf_msda_set_option(k.encode(), int(v)), v))
+    rows = run(args.iters, modes=tuple(args.modes.split(",")), backward=not args.no_backward,
+               shapes=args.shapes.split(",") if args.shapes else None, forward=not args.no_forward)
     for r in rows:
         print("%-16s %-8s %s  %8.1f us  %7.2f MB  %8.1f GB/s  %5.1f%% of HBM peak" % (
             r["shape"], r["mode"], r["dir"], r["ms"] * 1e3, r["alg_MB"], r["GBs"],

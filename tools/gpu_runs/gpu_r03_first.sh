@@ -1,0 +1,44 @@
+# Round 3, FIRST GPU call (prepared at the end of round 2, when no GPU minutes were left): validates on hardware what
+# was written against the SIMT emulator and times it against the defaults.  Before calling:
+#     python -m trackformer_amd.build && python tools/build_ablations.py 1 2 4 8 16 32 7
+#     gpurun --timeout 1500 -- 'bash tools/gpu_runs/gpu_r03_first.sh'
+# Everything lands in gpurun_out/r03a/.  Nothing here changes a default: each result decides one.
+mkdir -p gpurun_out/r03a
+cd $GRAFT_REPO_ROOT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/trackformer_amd/lib:$LD_LIBRARY_PATH
+O=gpurun_out/r03a
+
+# 1. parity of the opt-in kernels / routes (direct9, bwd_sorted2, conv1x1 split) on the hardware
+TF_TEST_OPTIN=1 timeout 600 python -m pytest tests/test_msda_gpu.py tests/test_full_size_gpu.py -m gpu -q -s -k optin \
+    > $O/pytest_optin.txt 2>&1
+tail -3 $O/pytest_optin.txt
+
+# 2. kernel timings, default vs opt-in (HIP graph of 50 launches, HIP events)
+{
+echo "## cfg4 decoder forward: msda_fwd_f32_buf (default) vs msda_fwd_f32_direct9"
+timeout 200 python tools/bench_msda.py --shapes cfg4_decoder --no-backward
+timeout 200 python tools/bench_msda.py --shapes cfg4_decoder --no-backward --option direct9=1
+echo "## encoder backward: msda_bwd_f32_sorted (default) vs msda_bwd_f32_sorted2"
+timeout 300 python tools/bench_msda.py --shapes cfg2_encoder,cfg3_encoder_n2 --no-forward
+timeout 300 python tools/bench_msda.py --shapes cfg2_encoder,cfg3_encoder_n2 --no-forward --option bwd_sorted2=1
+} > $O/kernel_times.txt 2>&1
+
+# 3. frames/s: default vs the backbone's 1x1 convolutions through the split GEMM; cfg 4 with direct9
+timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_default.json 2> $O/bench_cfg2_default.err
+timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O/bench_cfg2_conv1x1.json 2> $O/bench_cfg2_conv1x1.err
+timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
+TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_direct9.json 2> $O/bench_cfg4_direct9.err
+cat $O/bench_cfg2_default.json $O/bench_cfg2_conv1x1.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
+
+# 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)
+{
+echo "## full kernel"
+timeout 120 tools/bin/msda_bench --iters 24 --sets 4 --patterns pert,init --fused 1 pquad
+for lib in tools/bin/ablate/libtf_msda_abl*.so; do
+    [ -e "$lib" ] || continue
+    echo "## $lib"
+    LD_PRELOAD=$lib timeout 120 tools/bin/msda_bench --iters 24 --sets 4 --patterns pert,init --fused 1 pquad 2>&1 | grep -E "fused +pquad|plain +pquad" | cut -c1-110
+done
+} > $O/pquad_ablations.txt 2>&1
+tail -30 $O/pquad_ablations.txt
