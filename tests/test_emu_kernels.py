@@ -390,3 +390,27 @@ def test_split_product_linear_with_residual_epilogue(M, K, N, relu):
     if relu:
         plain = np.maximum(plain, 0)
     assert np.array_equal(y, plain.astype(np.float32))
+
+
+@pytest.mark.parametrize("M,K,N", LINEAR_SHAPES + [(333, 64, 200), (70, 512, 96)], ids=lambda v: str(v))
+def test_split_product_linear_buffer_store_epilogue(M, K, N):
+    """The opt-in buffer-store epilogue (linear_bufstore: rows >= M / columns >= N dropped by the buffer bounds check
+    instead of per-store branches) is bit-identical to the default epilogue, in the unpacked, residual and packed kernels;
+    nothing is written outside Y (guard rows around the output)."""
+    rng = np.random.default_rng(M * 7 + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N, dtype=np.float32)
+    r = rng.standard_normal((M, N), dtype=np.float32)
+    base = [emu_lib.linear_split(x, w, b, True), emu_lib.linear_split(x, w, None, False, residual=r)]
+    if K % 64 == 0:
+        base.append(emu_lib.linear_packed(x, w, b, True))
+    prev = emu_lib.set_options(linear_bufstore=1)
+    try:
+        got = [emu_lib.linear_split(x, w, b, True), emu_lib.linear_split(x, w, None, False, residual=r)]
+        if K % 64 == 0:
+            got.append(emu_lib.linear_packed(x, w, b, True))
+    finally:
+        emu_lib.set_options(**prev)
+    for g, e in zip(got, base):
+        assert np.array_equal(g, e)

@@ -151,3 +151,43 @@ def test_packed_linear_dispatch(dev, split_on):
         assert not split_on._use_packed(22223, 256, 1024)
     finally:
         split_on.set_packed_linear(prev)
+
+
+# ------------------------------------------------------------------ opt-in (see test_msda_gpu.py): TF_TEST_OPTIN=1
+import os
+
+optin = pytest.mark.skipif(os.environ.get("TF_TEST_OPTIN") != "1", reason="opt-in kernels: set TF_TEST_OPTIN=1")
+
+
+@optin
+@pytest.mark.parametrize("M,K,N,bias,relu", SHAPES + [(66800, 64, 256, True, True), (16700, 512, 128, True, True)],
+                         ids=["%dx%dx%d" % s[:3] for s in SHAPES] + ["conv_layer1", "conv_layer2"])
+def test_optin_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, relu):
+    """linear_bufstore (stores through a buffer resource: no per-store branch, no vmcnt(0) between stores) and the
+    residual epilogue: bit-identical to the default epilogue / to the plain kernel + add; nothing written past Y."""
+    from trackformer_amd import _cabi
+    lib = _cabi.lib()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    r = torch.randn(M, N, generator=g).to(dev)
+    base = split_on.linear(x, w, b, relu=relu)
+    base_res = split_on.linear(x, w, b, relu=relu, residual=r)
+    if K % 32 == 0:
+        plain = split_on.linear(x, w, b, relu=False) + r
+        assert torch.equal(base_res, plain.clamp_min(0) if relu else plain)
+    guard = torch.full((M + 300, N), 7.0, device=dev)       # the kernel writes into the first M rows of a larger buffer
+    prev = lib.tf_msda_set_option(b"linear_bufstore", 1)
+    try:
+        got = split_on.linear(x, w, b, relu=relu)
+        got_res = split_on.linear(x, w, b, relu=relu, residual=r)
+        hi, mid = split_on._split_weight(w)
+        rc = lib.tf_linear_split_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if b is None else b.data_ptr(),
+                                     guard.data_ptr(), M, K, N, 1 if relu else 0, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    finally:
+        lib.tf_msda_set_option(b"linear_bufstore", prev)
+    torch.cuda.synchronize()
+    assert torch.equal(got, base) and torch.equal(got_res, base_res)
+    assert torch.equal(guard[M:], torch.full((300, N), 7.0, device=dev))

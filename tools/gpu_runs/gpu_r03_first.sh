@@ -10,7 +10,7 @@ export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/trackformer_amd/lib:$LD_LIBRARY_PATH
 O=gpurun_out/r03a
 
 # 1. parity of the opt-in kernels / routes (direct9, bwd_sorted2, conv1x1 split) on the hardware
-TF_TEST_OPTIN=1 timeout 600 python -m pytest tests/test_msda_gpu.py tests/test_full_size_gpu.py -m gpu -q -s -k optin \
+TF_TEST_OPTIN=1 timeout 600 python -m pytest tests/test_msda_gpu.py tests/test_full_size_gpu.py tests/test_linear_split_gpu.py -m gpu -q -s -k optin \
     > $O/pytest_optin.txt 2>&1
 tail -3 $O/pytest_optin.txt
 
@@ -24,12 +24,24 @@ timeout 300 python tools/bench_msda.py --shapes cfg2_encoder,cfg3_encoder_n2 --n
 timeout 300 python tools/bench_msda.py --shapes cfg2_encoder,cfg3_encoder_n2 --no-forward --option bwd_sorted2=1
 } > $O/kernel_times.txt 2>&1
 
+# 2b. the split GEMMs with the buffer-store epilogue (no vmcnt(0) between stores) against the default epilogue
+{
+for shape in "22223 256 1024 packed" "22223 1024 256 packed" "22223 256 256" "22223 256 384" "400 256 256" "66800 64 256" "16700 512 128"; do
+    echo "## $shape: default epilogue, then TF_LINEAR_BUFSTORE=1"
+    timeout 60 tools/bin/linear_bench $shape | grep -E "us per launch"
+    TF_LINEAR_BUFSTORE=1 timeout 60 tools/bin/linear_bench $shape | grep -E "us per launch|differ"
+done
+} > $O/linear_bufstore.txt 2>&1
+cat $O/linear_bufstore.txt
+
 # 3. frames/s: default vs the backbone's 1x1 convolutions through the split GEMM; cfg 4 with direct9
 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_default.json 2> $O/bench_cfg2_default.err
+TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore.json 2> $O/bench_cfg2_bufstore.err
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O/bench_cfg2_conv1x1.json 2> $O/bench_cfg2_conv1x1.err
+TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O/bench_cfg2_conv1x1_bufstore.json 2> $O/bench_cfg2_conv1x1_bufstore.err
 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
 TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_direct9.json 2> $O/bench_cfg4_direct9.err
-cat $O/bench_cfg2_default.json $O/bench_cfg2_conv1x1.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
+cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_conv1x1_bufstore.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
 
 # 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)
 {

@@ -27,6 +27,7 @@
 
 #include <atomic>
 
+#include "msda_common.h"
 #include "tf_fused.h"
 #include "tf_msda.h"
 
@@ -47,7 +48,13 @@ constexpr int LDS_STRIDE = BK + 8;   // bf16 elements per LDS row: 80 bytes, kee
 // second block on the CU being in the other phase.
 // RESID: Y = act(X . W^T + bias + R) with R [M, N] fp32 (the identity branch of a bottleneck: `out += identity` before
 // the ReLU, torchvision resnet.py Bottleneck.forward) -- only instantiated by split_gemm_res_kernel below.
-template <int BM, int BN, bool RELU, bool PREFETCH, bool RESID>
+// BUFST (opt-in, tf_msda_set_option("linear_bufstore", 1)): the epilogue through a buffer resource over Y -- rows >= M
+// and columns >= N fall outside num_records and are dropped by the hardware, so the 16 stores of a tile are straight-line
+// code.  With `if (row < M) Y[...] = v` every store sits in its own exec-masked block; the compiler's wait-count pass
+// re-waits for the bias load at each join, and on gfx9-family hardware vmcnt also counts STORES: the ISA had
+// `s_waitcnt vmcnt(0)` in front of every global_store_dword, i.e. each store waited for the previous one to reach L2
+// (profiles/r02_split_gemm_astat_trace.txt: 10.5 us of store time per 96 x 256 tile).
+template <int BM, int BN, bool RELU, bool PREFETCH, bool RESID, bool BUFST>
 __device__ __forceinline__ void
 split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
                 const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, const float *__restrict__ R,
@@ -151,6 +158,39 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
         __syncthreads();
     }
     // ---- epilogue: C/D of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if constexpr (BUFST) {
+        const unsigned ybytes = (unsigned)((size_t)M * N * 4);   // < 4 GiB (host check)
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, ybytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(RESID ? R : Y), 0, ybytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int col = n0 + wn + j * 32 + (lane & 31);
+                const bool colok = col < N;
+                const float b = (bias && colok) ? bias[col] : 0.f;
+                const int row0 = m0 + wm + i * 32 + 4 * (lane >> 5);
+                // rows >= M: (row * N + col) * 4 >= num_records -> dropped; columns >= N: an out-of-range offset
+                const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xFFFFFFF0u;
+                float rv[16];
+                if constexpr (RESID) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned off = colok ? base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u : 0xFFFFFFF0u;
+                        rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, off, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r] + b;
+                    if constexpr (RESID) v += rv[r];
+                    if (RELU) v = v > 0.f ? v : 0.f;
+                    const unsigned off = colok ? base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off, 0, 0);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -171,22 +211,22 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
         }
 }
 
-template <int BM, int BN, bool RELU, bool PREFETCH>
+template <int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
                   const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
                   int M, int K, int N)
 {
-    split_gemm_body<BM, BN, RELU, PREFETCH, false>(X, Whi, Wmid, bias, nullptr, Y, M, K, N);
+    split_gemm_body<BM, BN, RELU, PREFETCH, false, BUFST>(X, Whi, Wmid, bias, nullptr, Y, M, K, N);
 }
 
-template <int BM, int BN, bool RELU, bool PREFETCH>
+template <int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_res_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
                       const unsigned short *__restrict__ Wmid, const float *__restrict__ bias,
                       const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N)
 {
-    split_gemm_body<BM, BN, RELU, PREFETCH, true>(X, Whi, Wmid, bias, R, Y, M, K, N);
+    split_gemm_body<BM, BN, RELU, PREFETCH, true, BUFST>(X, Whi, Wmid, bias, R, Y, M, K, N);
 }
 
 // ---- weight-stationary variant (variant 6; K == 256, many rows; an experiment that was run and measured, see above): the 128 x 256 weight block of a column block stays in LDS for the
@@ -370,6 +410,7 @@ int launch_ws(const float *x, const unsigned short *wh, const unsigned short *wm
                ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
+std::atomic<int> g_bufstore{-1};   // -1: TF_LINEAR_BUFSTORE (default 0)
 std::atomic<int> g_variant{-1};   // -1: TF_LINEAR_VARIANT or the default
 
 int variant()
@@ -389,6 +430,20 @@ int launch_variant(const float *x, const unsigned short *wh, const unsigned shor
 {
     const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
+    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < (1LL << 32)) {   // opt-in: buffer-store epilogue
+        if (res) {
+            if (relu)
+                hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, true, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
+            else
+                hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, false, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
+        } else {
+            if (relu)
+                hipLaunchKernelGGL((split_gemm_kernel<BM, BN, true, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, M, K, N);
+            else
+                hipLaunchKernelGGL((split_gemm_kernel<BM, BN, false, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, M, K, N);
+        }
+        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    }
     if (res) {
         if (relu)
             hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, true, PREFETCH>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
@@ -406,6 +461,22 @@ int launch_variant(const float *x, const unsigned short *wh, const unsigned shor
 }  // namespace
 
 namespace tfm {
+int linear_bufstore()
+{
+    int v = g_bufstore.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_LINEAR_BUFSTORE");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_bufstore.store(v);
+    }
+    return v;
+}
+int linear_bufstore_set(int v)
+{
+    const int prev = linear_bufstore();
+    g_bufstore.store(v ? 1 : 0);
+    return prev;
+}
 int linear_set_variant(int v)
 {
     const int prev = variant();

@@ -85,7 +85,7 @@ struct WFrags {
 
 constexpr int stream_min_waves(int ti) { return ti <= 3 ? 2 : 1; }   // blocks per CU the register budget is cut for
 
-template <int TI, bool RELU>
+template <int TI, bool RELU, bool BUFST = false>   // BUFST: buffer-store epilogue (opt-in; see linear_split.hip)
 __global__ void __launch_bounds__(kThreads, (stream_min_waves(TI)))
 split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias,
                          float *__restrict__ Y, int M, int K, int N, int mblocks, int nblocks)
@@ -217,6 +217,29 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
     }
 
     // ---- epilogue: C/D of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if constexpr (BUFST) {
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < kTJ; ++j) {
+            const int col = n0 + (wave * kTJ + j) * 32 + (lane & 31);
+            const bool colok = col < N;
+            const float b = (bias && colok) ? bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int row0 = m0 + i * 32 + 4 * (lane >> 5);
+                const unsigned base = (unsigned)(row0 * N + col) * 4u;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = acc[i][j][e] + b;
+                    if (RELU) v = v > 0.f ? v : 0.f;
+                    // rows >= M land beyond num_records (dropped by the hardware); columns >= N get an out-of-range offset
+                    const unsigned off = colok ? base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off, 0, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < kTJ; ++j) {
         const int col = n0 + (wave * kTJ + j) * 32 + (lane & 31);
@@ -467,6 +490,15 @@ int launch_stream(const float *x, const u32x4 *wp, const float *bias, float *y, 
     const int mblocks = (M + 32 * TI - 1) / (32 * TI), nblocks = (N + kBN - 1) / kBN;
     const long long grid = (long long)((mblocks + 7) / 8) * 8 * nblocks;
     if (grid > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
+    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < (1LL << 32)) {   // opt-in: buffer-store epilogue
+        if (relu)
+            hipLaunchKernelGGL((split_gemm_stream_kernel<TI, true, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
+                               M, K, N, mblocks, nblocks);
+        else
+            hipLaunchKernelGGL((split_gemm_stream_kernel<TI, false, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
+                               M, K, N, mblocks, nblocks);
+        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    }
     if (relu)
         hipLaunchKernelGGL((split_gemm_stream_kernel<TI, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y, M, K,
                            N, mblocks, nblocks);
