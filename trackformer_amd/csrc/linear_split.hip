@@ -170,13 +170,14 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
                 const bool colok = col < N;
                 const float b = (bias && colok) ? bias[col] : 0.f;
                 const int row0 = m0 + wm + i * 32 + 4 * (lane >> 5);
-                // rows >= M: (row * N + col) * 4 >= num_records -> dropped; columns >= N: an out-of-range offset
-                const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xFFFFFFF0u;
+                // rows >= M: (row * N + col) * 4 >= num_records -> dropped; columns >= N start from 3 GiB, which stays out
+                // of range and does not wrap for any row delta (host: the tensor is < 3 GiB)
+                const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xC0000000u;
                 float rv[16];
                 if constexpr (RESID) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const unsigned off = colok ? base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u : 0xFFFFFFF0u;
+                        const unsigned off = base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u;
                         rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, off, 0, 0));
                     }
                 }
@@ -185,7 +186,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
                     float v = acc[i][j][r] + b;
                     if constexpr (RESID) v += rv[r];
                     if (RELU) v = v > 0.f ? v : 0.f;
-                    const unsigned off = colok ? base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u : 0xFFFFFFF0u;
+                    const unsigned off = base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off, 0, 0);
                 }
             }
@@ -430,7 +431,7 @@ int launch_variant(const float *x, const unsigned short *wh, const unsigned shor
 {
     const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
-    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < (1LL << 32)) {   // opt-in: buffer-store epilogue
+    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL) {   // opt-in: buffer-store epilogue
         if (res) {
             if (relu)
                 hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, true, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);

@@ -227,13 +227,14 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int row0 = m0 + i * 32 + 4 * (lane >> 5);
-                const unsigned base = (unsigned)(row0 * N + col) * 4u;
+                // rows >= M land beyond num_records (dropped by the hardware); columns >= N start from 3 GiB, which stays
+                // out of range and does not wrap for any row delta (host: the tensor is < 3 GiB)
+                const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xC0000000u;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float v = acc[i][j][e] + b;
                     if (RELU) v = v > 0.f ? v : 0.f;
-                    // rows >= M land beyond num_records (dropped by the hardware); columns >= N get an out-of-range offset
-                    const unsigned off = colok ? base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u : 0xFFFFFFF0u;
+                    const unsigned off = base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off, 0, 0);
                 }
             }
@@ -490,7 +491,7 @@ int launch_stream(const float *x, const u32x4 *wp, const float *bias, float *y, 
     const int mblocks = (M + 32 * TI - 1) / (32 * TI), nblocks = (N + kBN - 1) / kBN;
     const long long grid = (long long)((mblocks + 7) / 8) * 8 * nblocks;
     if (grid > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
-    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < (1LL << 32)) {   // opt-in: buffer-store epilogue
+    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL) {   // opt-in: buffer-store epilogue
         if (relu)
             hipLaunchKernelGGL((split_gemm_stream_kernel<TI, true, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
                                M, K, N, mblocks, nblocks);
