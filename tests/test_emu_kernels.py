@@ -143,7 +143,7 @@ def _fused_case(shapes, N, D, seed, M=8, P=4, spread=2.0):
 
 PQUAD_VARIANTS = [dict(), dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pquad_wg_per_cu=2),
                   dict(pquad_prefetch=2, pquad_wg_per_cu=2), dict(pquad_wide=0), dict(pquad_lds_kb=24),
-                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1)]
+                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1), dict(pquad_pipe=1)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items()) or "default"
@@ -414,3 +414,21 @@ def test_split_product_linear_buffer_store_epilogue(M, K, N):
         emu_lib.set_options(**prev)
     for g, e in zip(got, base):
         assert np.array_equal(g, e)
+
+
+def test_pipelined_gathers_are_bit_identical():
+    """pquad_pipe (opt-in): the LDS gathers with a rolling set of reads in flight -- same instructions, same summation
+    order per accumulator, so the output equals the default kernel's bit for bit (plain and fused entry)."""
+    shapes = PYR
+    shp = np.array(shapes, np.int64)
+    value, loc, attn = encoder_inputs(shapes, "local", N=1, seed=21)
+    fvalue, refp, qproj, _, _ = _fused_case(shapes, 1, 32, seed=22)
+    base = emu_lib.msda_forward(value, shp, loc, attn)
+    fbase = emu_lib.msda_forward_fused(fvalue, shp, refp, qproj, 8, len(shapes), 4)
+    prev = emu_lib.set_options(pquad_pipe=1)
+    try:
+        got = emu_lib.msda_forward(value, shp, loc, attn)
+        fgot = emu_lib.msda_forward_fused(fvalue, shp, refp, qproj, 8, len(shapes), 4)
+    finally:
+        emu_lib.set_options(**prev)
+    assert np.array_equal(got, base) and np.array_equal(fgot, fbase)

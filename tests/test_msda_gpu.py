@@ -670,3 +670,18 @@ def test_optin_backward_sorted2_kernel(dev, name, shapes, mode, N, M, D):
     np.testing.assert_allclose(gv, rv, atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(gl, rl, atol=2e-3, rtol=1e-4)
     np.testing.assert_allclose(ga, ra, atol=1e-4, rtol=1e-4)
+
+
+@optin
+def test_optin_pipelined_gathers_bit_identical(dev):
+    """pquad_pipe: the LDS gathers of msda_fwd_f32_pquad with a rolling set of reads in flight; bit-identical output."""
+    from trackformer_amd import _cabi
+    lib = _cabi.lib()
+    value, shp, loc, attn, _ = _encoder_inputs(dev, CFG2_SHAPES, "local", seed=3)
+    base = _fwd(value, shp, loc, attn)
+    prev = lib.tf_msda_set_option(b"pquad_pipe", 1)
+    try:
+        got = _fwd(value, shp, loc, attn)
+    finally:
+        lib.tf_msda_set_option(b"pquad_pipe", prev)
+    assert torch.equal(got, base)
