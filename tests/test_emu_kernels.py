@@ -432,3 +432,24 @@ def test_pipelined_gathers_are_bit_identical():
     finally:
         emu_lib.set_options(**prev)
     assert np.array_equal(got, base) and np.array_equal(fgot, fbase)
+
+
+@pytest.mark.parametrize("M,K,N", [(400, 256, 256), (130, 256, 384), (100, 288, 96), (70, 1024, 256), (65, 1152, 64), (200, 64, 64)],
+                         ids=lambda v: str(v))
+def test_deep_prefetch_linear_for_few_rows(M, K, N):
+    """Variant 7 (opt-in): ring of 8 K-slices in registers, all loads of a K = 256 block in flight at once; same arithmetic
+    and accumulation order as the default few-rows variant -> bit-identical (K / 32 outside {8, 9, 32, 36} falls back)."""
+    rng = np.random.default_rng(M + K)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N, dtype=np.float32)
+    base = [emu_lib.linear_split(x, w, b, True), emu_lib.linear_split(x, w, None, False)]
+    prev = emu_lib.set_options(linear_deep=1)
+    try:
+        got = [emu_lib.linear_split(x, w, b, True), emu_lib.linear_split(x, w, None, False)]
+    finally:
+        emu_lib.set_options(**prev)
+    for g, e in zip(got, base):
+        assert np.array_equal(g, e)
+    ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + b, 0)
+    assert np.abs(got[0] - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())

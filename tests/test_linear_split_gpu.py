@@ -191,3 +191,24 @@ def test_optin_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, 
     torch.cuda.synchronize()
     assert torch.equal(got, base) and torch.equal(got_res, base_res)
     assert torch.equal(guard[M:], torch.full((300, N), 7.0, device=dev))
+
+
+@optin
+@pytest.mark.parametrize("M,K,N,bias,relu", [(400, 256, 256, True, False), (400, 256, 1024, True, True), (400, 1024, 256, True, False),
+                                              (800, 288, 288, True, False), (800, 1152, 288, False, False), (400, 256, 384, True, False)],
+                         ids=lambda v: str(v))
+def test_optin_deep_prefetch_linear_bit_identical(dev, split_on, M, K, N, bias, relu):
+    """Variant 7 (ring of 8 K-slices in registers, for the decoder's few-row linears): bit-identical to the default."""
+    from trackformer_amd import _cabi
+    lib = _cabi.lib()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev) if bias else None
+    base = split_on.linear(x, w, b, relu=relu)
+    prev = lib.tf_msda_set_option(b"linear_deep", 1)
+    try:
+        got = split_on.linear(x, w, b, relu=relu)
+    finally:
+        lib.tf_msda_set_option(b"linear_deep", prev)
+    assert torch.equal(got, base)

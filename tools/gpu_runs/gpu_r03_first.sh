@@ -31,6 +31,10 @@ for shape in "22223 256 1024 packed" "22223 1024 256 packed" "22223 256 256" "22
     timeout 60 tools/bin/linear_bench $shape | grep -E "us per launch"
     TF_LINEAR_BUFSTORE=1 timeout 60 tools/bin/linear_bench $shape | grep -E "us per launch|differ"
 done
+echo "## few rows (decoder): default variant 5 vs the deep-prefetch variant 7 vs the weight-stationary variant 6"
+for shape in "400 256 256" "400 256 384" "400 256 1024" "400 1024 256" "800 288 288"; do
+    for v in 5 7 6; do timeout 60 tools/bin/linear_bench $shape $v | grep -E "us per launch"; done
+done
 } > $O/linear_bufstore.txt 2>&1
 cat $O/linear_bufstore.txt
 
@@ -39,9 +43,10 @@ timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_defa
 TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore.json 2> $O/bench_cfg2_bufstore.err
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O/bench_cfg2_conv1x1.json 2> $O/bench_cfg2_conv1x1.err
 TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O/bench_cfg2_conv1x1_bufstore.json 2> $O/bench_cfg2_conv1x1_bufstore.err
+TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore_deep.json 2> $O/bench_cfg2_bufstore_deep.err
 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
 TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_direct9.json 2> $O/bench_cfg4_direct9.err
-cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_conv1x1_bufstore.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
+cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_conv1x1_bufstore.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
 
 # 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)
 {

@@ -230,6 +230,157 @@ split_gemm_res_kernel(const float *__restrict__ X, const unsigned short *__restr
     split_gemm_body<BM, BN, RELU, PREFETCH, true, BUFST>(X, Whi, Wmid, bias, R, Y, M, K, N);
 }
 
+// ---- few rows (the decoder: 400 / 800 queries): a launch is 28-100 blocks, far fewer than CUs, and each block walks its
+// K-slices one memory round trip at a time -- 12 us per 400 x 256 -> 256 linear inside the model (36 such launches per
+// frame, profiles/r02_e2e_eager_per_frame.txt) for 0.16 GFLOP.  Variant 7 (OPT-IN: linear_variant = 7, or
+// tf_msda_set_option("linear_deep", 1) for every call with <= 4096 rows) keeps a RING OF 8 K-SLICES in registers: all
+// of a K = 256 block's global loads are in flight at once (one round trip instead of eight), the loop then only moves
+// registers -> LDS (double buffered, one barrier per slice) -> matrix cores; longer K refills the ring slot it has just
+// consumed.  64 x 64 blocks, 4 waves as 2 x 2; same arithmetic and accumulation order as split_gemm_kernel (bit-identical
+// results); buffer-store epilogue.
+// S = K / 32 is a template parameter (8, 9, 32, 36: hidden 256 / 288 and their FFN widths) so that the slice loop is
+// straight-line code: with run-time trip counts the compiler's wait-count pass loses track of how many loads are in
+// flight across the branches and falls back to vmcnt(0), which would wait for the refill just issued.
+template <bool RELU, int S>
+__global__ void __launch_bounds__(THREADS)
+split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
+                       const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
+                       int M, int K, int N)
+{
+    constexpr int BM = 64, BN = 64, PFD = 8;
+    constexpr int XV = (BM * BK / 4) / THREADS;   // 2 float4 of X per thread and slice
+    constexpr int WV = (BN * BK / 8) / THREADS;   // 1 16-byte piece of each weight tensor per thread and slice
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][2][BM * LDS_STRIDE];   // [buffer][hi | mid][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][2][BN * LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    f32x4 xr[PFD][XV];
+    u32x4 whr[PFD][WV], wmr[PFD][WV];
+    const float *xp[XV];
+    size_t wg[WV];
+#pragma unroll
+    for (int it = 0; it < XV; ++it) {
+        const int idx = it * THREADS + tid;
+        const int row = idx >> 3, c4 = idx & 7;
+        xp[it] = X + (size_t)min(m0 + row, M - 1) * K + c4 * 4;   // rows past M read the last row, never stored
+    }
+#pragma unroll
+    for (int it = 0; it < WV; ++it) {
+        const int idx = it * THREADS + tid;
+        const int row = idx >> 2, c8 = idx & 3;
+        wg[it] = (size_t)min(n0 + row, N - 1) * K + c8 * 8;
+    }
+    auto load_slice = [&](int s, auto slotc) {
+        constexpr int slot = decltype(slotc)::value;
+#pragma unroll
+        for (int it = 0; it < XV; ++it) xr[slot][it] = *reinterpret_cast<const f32x4 *>(xp[it] + s * BK);
+#pragma unroll
+        for (int it = 0; it < WV; ++it) {
+            whr[slot][it] = *reinterpret_cast<const u32x4 *>(Whi + wg[it] + s * BK);
+            wmr[slot][it] = *reinterpret_cast<const u32x4 *>(Wmid + wg[it] + s * BK);
+        }
+    };
+    auto store_slice = [&](auto slotc, int buf) {
+        constexpr int slot = decltype(slotc)::value;
+#pragma unroll
+        for (int it = 0; it < XV; ++it) {
+            const int idx = it * THREADS + tid;
+            const int row = idx >> 3, c4 = idx & 7;
+            bf16x4 hi, mid;   // v_cvt_pk_bf16_f32, round to nearest even
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = (__bf16)xr[slot][it][e];
+                mid[e] = (__bf16)(xr[slot][it][e] - (float)hi[e]);
+            }
+            *reinterpret_cast<bf16x4 *>(&sA[buf][0][row * LDS_STRIDE + c4 * 4]) = hi;
+            *reinterpret_cast<bf16x4 *>(&sA[buf][1][row * LDS_STRIDE + c4 * 4]) = mid;
+        }
+#pragma unroll
+        for (int it = 0; it < WV; ++it) {
+            const int idx = it * THREADS + tid;
+            const int row = idx >> 2, c8 = idx & 3;
+            *reinterpret_cast<u32x4 *>(&sB[buf][0][row * LDS_STRIDE + c8 * 8]) = whr[slot][it];
+            *reinterpret_cast<u32x4 *>(&sB[buf][1][row * LDS_STRIDE + c8 * 8]) = wmr[slot][it];
+        }
+    };
+    auto each_slot = [&](auto &&f) {
+        f(std::integral_constant<int, 0>{});
+        f(std::integral_constant<int, 1>{});
+        f(std::integral_constant<int, 2>{});
+        f(std::integral_constant<int, 3>{});
+        f(std::integral_constant<int, 4>{});
+        f(std::integral_constant<int, 5>{});
+        f(std::integral_constant<int, 6>{});
+        f(std::integral_constant<int, 7>{});
+    };
+
+    // ---- every load of the first 8 slices in flight at once
+    static_assert(S >= PFD, "at least one full ring");
+    each_slot([&](auto jc) { load_slice(decltype(jc)::value, jc); });
+    store_slice(std::integral_constant<int, 0>{}, 0);
+    __syncthreads();
+    auto step = [&](auto sc) {
+        constexpr int sidx = decltype(sc)::value;
+        if constexpr (sidx < S) {
+            constexpr int j = sidx % PFD, buf = sidx & 1;
+            // slice s + 1 -> the LDS buffer whose readers passed the previous barrier; slot j (consumed one step
+            // ago) takes slice s + 8
+            if constexpr (sidx + 1 < S) store_slice(std::integral_constant<int, (j + 1) % PFD>{}, buf ^ 1);
+            if constexpr (sidx + PFD < S) load_slice(sidx + PFD, std::integral_constant<int, j>{});
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 16) {
+                const int koff = kk + (lane >> 5) * 8;
+                const int ra = (wm + (lane & 31)) * LDS_STRIDE + koff, rb = (wn + (lane & 31)) * LDS_STRIDE + koff;
+                const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(&sA[buf][0][ra]);
+                const bf16x8 a_mid = *reinterpret_cast<const bf16x8 *>(&sA[buf][1][ra]);
+                const bf16x8 b_hi = *reinterpret_cast<const bf16x8 *>(&sB[buf][0][rb]);
+                const bf16x8 b_mid = *reinterpret_cast<const bf16x8 *>(&sB[buf][1][rb]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc, 0, 0, 0);   // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    };
+    auto steps4 = [&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        step(std::integral_constant<int, b>{});
+        step(std::integral_constant<int, b + 1>{});
+        step(std::integral_constant<int, b + 2>{});
+        step(std::integral_constant<int, b + 3>{});
+    };
+    static_assert(S <= 36, "unrolled for up to 36 slices");
+    steps4(std::integral_constant<int, 0>{});
+    steps4(std::integral_constant<int, 4>{});
+    steps4(std::integral_constant<int, 8>{});
+    steps4(std::integral_constant<int, 12>{});
+    steps4(std::integral_constant<int, 16>{});
+    steps4(std::integral_constant<int, 20>{});
+    steps4(std::integral_constant<int, 24>{});
+    steps4(std::integral_constant<int, 28>{});
+    steps4(std::integral_constant<int, 32>{});
+    // ---- epilogue (buffer stores: rows >= M fall outside num_records, columns >= N start at 3 GiB)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
+    const int col = n0 + wn + (lane & 31);
+    const bool colok = col < N;
+    const float b = (bias && colok) ? bias[col] : 0.f;
+    const int row0 = m0 + wm + 4 * (lane >> 5);
+    const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xC0000000u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = acc[r] + b;
+        if (RELU) v = v > 0.f ? v : 0.f;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                              base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
+    }
+}
+
 // ---- weight-stationary variant (variant 6; K == 256, many rows; an experiment that was run and measured, see above): the 128 x 256 weight block of a column block stays in LDS for the
 // whole workgroup (hi + mid pieces: 128 KB, 16-byte pieces XOR-swizzled by row & 15 so that the 16 lanes that read 16
 // different rows at one k hit 16 different bank groups; staged once by LDS-DMA), the activations stream from global memory
@@ -411,6 +562,7 @@ int launch_ws(const float *x, const unsigned short *wh, const unsigned short *wm
                ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
+std::atomic<int> g_deep{-1};       // -1: TF_LINEAR_DEEP (default 0): variant 7 for every call with <= 4096 rows
 std::atomic<int> g_bufstore{-1};   // -1: TF_LINEAR_BUFSTORE (default 0)
 std::atomic<int> g_variant{-1};   // -1: TF_LINEAR_VARIANT or the default
 
@@ -472,6 +624,22 @@ int linear_bufstore()
     }
     return v;
 }
+int linear_deep()
+{
+    int v = g_deep.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_LINEAR_DEEP");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_deep.store(v);
+    }
+    return v;
+}
+int linear_deep_set(int v)
+{
+    const int prev = linear_deep();
+    g_deep.store(v ? 1 : 0);
+    return prev;
+}
 int linear_bufstore_set(int v)
 {
     const int prev = linear_bufstore();
@@ -522,10 +690,28 @@ int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const
         // 1024 -> 256}, 400 x 256 -> 256): few rows want many small blocks, a long K a narrow N block
         // (variant 6, the weight-stationary kernel, measured no faster than variant 2 / 3 at the encoder shapes:
         //  22.6 vs 21.4 us at 256 -> 256, 73.0 vs 74.5 us at 256 -> 1024 -- selectable, not the default)
-        if (M <= 4096) var = 5;
+        if (M <= 4096) var = tfm::linear_deep() ? 7 : 5;
         else if (K >= 512 && N <= 256) var = 4;
         else if (N > 256 && N < 512) var = 3;
         else var = 2;
+    }
+    if (var == 7) {   // ring of 8 K-slices in registers (few rows); no residual epilogue, tensors below 3 GiB
+        if (!res && (long long)(M + 256) * N * 4 < 0xC0000000LL) {
+            const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
+            if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
+            const int slices = K / BK;
+#define TF_DEEP(SS)                                                                                                            \
+    if (slices == SS) {                                                                                                        \
+        if (relu)                                                                                                              \
+            hipLaunchKernelGGL((split_gemm_deep_kernel<true, SS>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, (int)M, K, N);  \
+        else                                                                                                                   \
+            hipLaunchKernelGGL((split_gemm_deep_kernel<false, SS>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, (int)M, K, N); \
+        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;                                              \
+    }
+            TF_DEEP(8) TF_DEEP(9) TF_DEEP(32) TF_DEEP(36)
+#undef TF_DEEP
+        }
+        var = 5;   // other K, a residual, or a tensor of 3 GiB: the default few-rows variant
     }
     if (var == 6) {
         const int rc = res ? 1 : launch_ws(x, wh, wm, bias, y, (int)M, K, N, relu, s);   // (no residual epilogue there)
