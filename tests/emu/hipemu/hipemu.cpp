@@ -255,6 +255,12 @@ bool run_block(Engine *e, const Dim3 &bidx)
         prepare_fiber(f);
     }
     ++e->st.blocks;
+    {
+        // LDS holds whatever the previous workgroup left behind; HIPEMU_POISON=1 makes that explicit (0xFF bytes = NaN
+        // patterns at every workgroup start), so that a kernel relying on zero-initialised LDS shows up in its results
+        static const bool poison = getenv("HIPEMU_POISON") != nullptr;
+        if (poison) memset(e->lds, 0xFF, kLdsBytes);
+    }
     std::vector<int> grp;
     for (;;) {
         for (int w = 0; w < nwaves; ++w) {

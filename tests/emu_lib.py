@@ -22,6 +22,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    import os
+    os.environ.setdefault("HIPEMU_POISON", "1")   # dynamic LDS starts as 0xFF bytes in every workgroup: nothing may rely on zeros
     so = build_emu.build()
     if so is None:
         raise RuntimeError("no host clang++ to build the emulated library with")
