@@ -262,14 +262,35 @@ bool run_block(Engine *e, const Dim3 &bidx)
         if (poison) memset(e->lds, 0xFF, kLdsBytes);
     }
     std::vector<int> grp;
+    // HIPEMU_SHUFFLE=<seed>: waves are visited in a pseudo-random order in every scheduling round and the lanes of a
+    // wave in a rotated / reversed order -- results must not depend on the (arbitrary) order in which the emulator runs
+    // work-items between synchronisation points, exactly as they must not depend on the hardware's timing
+    static const unsigned shuffle_seed = [] { const char *v = getenv("HIPEMU_SHUFFLE"); return v ? (unsigned)atoi(v) * 2654435761u + 1u : 0u; }();
+    unsigned rnd = shuffle_seed ? shuffle_seed ^ (bidx.x * 40503u + 977u) : 0u;
+    int worder[16];
+    for (int w = 0; w < nwaves; ++w) worder[w] = w;
     for (;;) {
-        for (int w = 0; w < nwaves; ++w) {
+        if (rnd)
+            for (int w = nwaves - 1; w > 0; --w) {
+                rnd = rnd * 1664525u + 1013904223u;
+                const int k = (int)((rnd >> 8) % (unsigned)(w + 1));
+                const int t = worder[w];
+                worder[w] = worder[k];
+                worder[k] = t;
+            }
+        for (int wi = 0; wi < nwaves; ++wi) {
+            const int w = worder[wi];
             Fiber *lanes[kWave] = {nullptr};
             const int nl = (w + 1) * kWave <= nthreads ? kWave : nthreads - w * kWave;
             for (int l = 0; l < nl; ++l) lanes[l] = &e->fibers[w * kWave + l];
             for (;;) {
-                for (int l = 0; l < nl; ++l)
+                rnd = rnd ? rnd * 1664525u + 1013904223u : 0u;
+                const int rot = rnd ? (int)((rnd >> 10) % (unsigned)nl) : 0;
+                const bool rev = rnd && ((rnd >> 20) & 1);
+                for (int li = 0; li < nl; ++li) {
+                    const int l = rev ? (rot + nl - li) % nl : (rot + li) % nl;
                     if (lanes[l]->state == kRunnable) run_fiber(e, *lanes[l]);
+                }
                 // every lane is now at a wave op, at a barrier, or done
                 int first = -1, nops = 0;
                 for (int l = 0; l < nl; ++l)
