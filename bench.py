@@ -124,6 +124,8 @@ def parse_args():
     ap.add_argument("--conv1x1-split", dest="conv1x1_split", action="store_true", default=None,
                     help="OPT-IN: the backbone's stride-1 1x1 convolutions through the split-product GEMM with the "
                          "FrozenBN / identity / ReLU epilogue (same as TF_CONV1X1_SPLIT=1)")
+    ap.add_argument("--conv3x3-split", dest="conv3x3_split", action="store_true", default=None,
+                    help="OPT-IN: the bottlenecks' 3x3 convolutions through the split-product implicit GEMM (TF_CONV3X3_SPLIT=1)")
     ap.add_argument("--sequences", type=int, default=4,
                     help="independent video sequences tracked concurrently per GPU (one host thread "
                          "and HIP stream each); frames of one sequence stay strictly sequential")
@@ -553,6 +555,8 @@ def main():
     from trackformer_amd import backbone as _backbone
     if args.conv1x1_split is not None:
         _backbone.set_conv1x1_split(args.conv1x1_split)
+    if args.conv3x3_split is not None:
+        _backbone.set_conv3x3_split(args.conv3x3_split)
 
     if args.roofline_only:
         if rank == 0:
@@ -600,8 +604,8 @@ def main():
             "ms_per_step": round(1e3 * elapsed / steps_timed, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if not fused.split_linear_enabled() or train
-                     else ("f32 (transformer linears + backbone 1x1 convolutions: 3-pass bf16 split product on MFMA, f32 accumulate)"
-                           if _backbone._conv1x1_split else
+                     else ("f32 (transformer linears + backbone bottleneck convolutions: 3-pass bf16 split product on MFMA, f32 accumulate)"
+                           if (_backbone._conv1x1_split or _backbone._conv3x3_split) else
                            "f32 (transformer linears: 3-pass bf16 split product on MFMA, f32 accumulate)"),
             "data": "synthetic", "per_gpu": round(value / world, 3),
             "timed_repeats": reps, "steps_timed": steps_timed, "timed_seconds": round(elapsed, 3),

@@ -65,6 +65,16 @@ int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid,
                             float *y, int64_t M, int K, int N, int relu, void *stream);
 
 /*
+ * 3 x 3 convolution (padding 1, stride 1 or 2, no groups / dilation) of a channels_last activation as the same split
+ * product (an implicit GEMM over the output pixels, K = 9 * Cin): y[n, ho, wo, :] = act(sum_taps x[n, hi, wi, :] . w[:, tap, :]^T
+ * + bias).  x [N, Hin, Win, Cin] and y [N, Hout, Wout, Cout] are NHWC (the storage of channels_last NCHW tensors); the weight
+ * arrives as bf16 (hi, mid) pieces of the [Cout, 3, 3, Cin] tensor (the storage of a channels_last OIHW weight), Cin % 32 == 0.
+ * For torchvision's Bottleneck.conv2 + FrozenBatchNorm2d + ReLU (BN scale folded into w, shift as bias).
+ */
+int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
+                         int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+
+/*
  * The same product with the weight in PACKED form (trackformer_amd/csrc/linear_stream.hip): the weight is split into
  * bf16 (hi, mid) once and stored in matrix-core fragment order, so that the GEMM streams it from L2 into registers and
  * only the activations pass through LDS.  Results are bit-identical to tf_linear_split_f32.

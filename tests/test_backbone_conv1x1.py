@@ -62,3 +62,24 @@ def test_fold_cache_keeps_a_persistent_2d_weight_for_1x1_convolutions():
     c3 = backbone._FoldCache()
     c3.get(conv3, bn)
     assert c3.weight2d is None
+
+
+def test_fold_cache_tap_major_weight_of_3x3_convolutions():
+    """weight_taps[o, (kh * 3 + kw) * Cin + c] == folded weight[o, c, kh, kw]: the K order tf_conv3x3_split_f32 expects."""
+    conv = torch.nn.Conv2d(8, 16, 3, padding=1, bias=False)
+    bn = backbone.FrozenBatchNorm2d(16)
+    bn.weight.uniform_(0.5, 1.5)
+    cache = backbone._FoldCache()
+    w, b = cache.get(conv, bn)
+    t = cache.weight_taps
+    assert t is not None and t.shape == (16, 72) and t.is_contiguous() and cache.weight2d is None
+    assert torch.equal(t.view(16, 3, 3, 8), w.permute(0, 2, 3, 1))
+    # and the implicit GEMM over those taps is the convolution (stride 1 and 2, padding 1)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 8, 7, 9, generator=g)
+    for stride in (1, 2):
+        ref = F.conv2d(x, w, b, stride=stride, padding=1)
+        cols = F.unfold(x, 3, padding=1, stride=stride)                      # [N, Cin * 9, L] with (c, kh, kw) order
+        cols = cols.view(2, 8, 9, -1).permute(0, 3, 2, 1).reshape(2, -1, 72)  # -> (tap, c) order
+        y = (cols @ t.t() + b).permute(0, 2, 1).reshape(ref.shape)
+        assert torch.allclose(y, ref, atol=1e-5)

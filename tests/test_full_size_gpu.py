@@ -154,28 +154,34 @@ optin = pytest.mark.skipif(os.environ.get("TF_TEST_OPTIN") != "1", reason="opt-i
 
 
 @optin
+@pytest.mark.parametrize("routes", [(True, False), (True, True)], ids=["conv1x1", "conv1x1_conv3x3"])
 @pytest.mark.parametrize("case", list(um.FULL_CASES))
-def test_optin_conv1x1_split_route_full_size(dev, models, case):
-    """The stride-1 1 x 1 convolutions of the backbone through the split-product GEMM with the FrozenBN shift / identity /
-    ReLU epilogue (backbone.set_conv1x1_split): BASELINE-size model against the reference goldens, bench set-up."""
+def test_optin_conv1x1_split_route_full_size(dev, models, case, routes):
+    """The bottleneck convolutions of the backbone through the split-product kernels with the FrozenBN shift / identity /
+    ReLU epilogue (backbone.set_conv1x1_split / set_conv3x3_split): BASELINE-size model against the reference goldens,
+    bench set-up."""
     from trackformer_amd import backbone
-    prev = backbone.set_conv1x1_split(True)
+    prev = backbone.set_conv1x1_split(routes[0])
+    prev3 = backbone.set_conv3x3_split(routes[1])
     try:
         model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
         dbox, dlogit = _compare(case, model, out, res, feats, memory)
-        print("%s / conv1x1 split: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+        print("%s / conv split %s: max |d boxes| %.2e, max |d logits| %.2e" % (case, routes, dbox, dlogit))
     finally:
         backbone.set_conv1x1_split(prev)
+        backbone.set_conv3x3_split(prev3)
 
 
 @optin
 def test_optin_conv1x1_split_route_tracker_ids(dev, models):
     from trackformer_amd import backbone
     prev = backbone.set_conv1x1_split(True)
+    prev3 = backbone.set_conv3x3_split(True)
     try:
         tracker, rows, active = _run_tracker(models, dev, "graph_split_linear")
     finally:
         backbone.set_conv1x1_split(prev)
+        backbone.set_conv3x3_split(prev3)
     z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
     assert int(z["num_tracks"]) == tracker.track_num and z["active_per_frame"].tolist() == active
     np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
@@ -197,10 +203,25 @@ def test_optin_conv1x1_split_backbone_layer_outputs(dev):
     x = torch.randn(1, 256, 50, 84, device=dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         ref = blk(x)
+        for both in (False, True):
+            prev = backbone.set_conv1x1_split(True)
+            prev3 = backbone.set_conv3x3_split(both)
+            try:
+                got = blk(x)
+            finally:
+                backbone.set_conv1x1_split(prev)
+                backbone.set_conv3x3_split(prev3)
+            assert got.is_contiguous(memory_format=torch.channels_last)
+            assert float((got - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+        # a strided bottleneck (3 x 3 with stride 2 + a strided projection that stays in the library)
+        ds = torch.nn.Sequential(torch.nn.Conv2d(256, 512, 1, stride=2, bias=False), backbone.FrozenBatchNorm2d(512)).to(dev)
+        blk2 = backbone.Bottleneck(256, 128, stride=2, downsample=ds).to(dev).eval()
+        ref2 = blk2(x)
         prev = backbone.set_conv1x1_split(True)
+        prev3 = backbone.set_conv3x3_split(True)
         try:
-            got = blk(x)
+            got2 = blk2(x)
         finally:
             backbone.set_conv1x1_split(prev)
-    assert got.is_contiguous(memory_format=torch.channels_last)
-    assert float((got - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+            backbone.set_conv3x3_split(prev3)
+        assert got2.shape == ref2.shape and float((got2 - ref2).abs().max()) < 1e-3 * float(ref2.abs().max())

@@ -39,6 +39,19 @@ CHANNELS_LAST = _os.environ.get("TF_BACKBONE_NCHW", "0") != "1"
 _conv1x1_split = _os.environ.get("TF_CONV1X1_SPLIT", "0") == "1"
 
 
+# OPT-IN as well (TF_CONV3X3_SPLIT=1 / set_conv3x3_split(True)): the bottlenecks' 3 x 3 convolutions (stride 1 and 2) as the
+# same split product, an implicit GEMM over the output pixels (fused.conv3x3 -> tf_conv3x3_split_f32), FrozenBN shift and
+# ReLU in its epilogue.  With both routes on, only the 7 x 7 stem and the three strided 1 x 1 projections stay in MIOpen.
+_conv3x3_split = _os.environ.get("TF_CONV3X3_SPLIT", "0") == "1"
+
+
+def set_conv3x3_split(on):
+    """Route the bottlenecks' 3 x 3 convolutions through the split-product kernel (process-wide); returns the previous setting."""
+    global _conv3x3_split
+    prev, _conv3x3_split = _conv3x3_split, bool(on)
+    return prev
+
+
 def set_conv1x1_split(on):
     """Route the stride-1 1 x 1 convolutions through the split-product GEMM (process-wide); returns the previous setting."""
     global _conv1x1_split
@@ -100,6 +113,7 @@ class _FoldCache:
         self.weight = None
         self.bias = None
         self.weight2d = None   # [Cout, Cin] of a 1 x 1 convolution (a persistent tensor: fused.linear caches its pieces on it)
+        self.weight_taps = None   # [Cout, 9 * Cin] of a 3 x 3 convolution, tap-major
 
     def get(self, conv: nn.Conv2d, bn: FrozenBatchNorm2d):
         srcs = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
@@ -112,6 +126,9 @@ class _FoldCache:
                     else w.contiguous()
                 self.bias = shift.contiguous()
                 self.weight2d = w.reshape(w.shape[0], w.shape[1]).contiguous() if w.shape[2:] == (1, 1) else None
+                # [Cout, 3, 3, Cin] -> [Cout, 9 * Cin]: the storage order of the channels_last weight (tap-major K)
+                self.weight_taps = (w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous()
+                                    if w.shape[2:] == (3, 3) else None)
             self.key = key
         return self.weight, self.bias
 
@@ -131,6 +148,11 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
                     and conv.groups == 1 and CHANNELS_LAST):
                 y = conv1x1_as_gemm(x, cache.weight2d, b, residual, relu,
                                     lambda x2, w2, bb, act, r2: fused.linear(x2, w2, bb, relu=act, residual=r2))
+                if y is not None:
+                    return y
+            if (_conv3x3_split and cache.weight_taps is not None and residual is None and conv.padding == (1, 1)
+                    and conv.dilation == (1, 1) and conv.groups == 1 and conv.stride in ((1, 1), (2, 2)) and CHANNELS_LAST):
+                y = fused.conv3x3(x, cache.weight_taps, b, relu, conv.stride[0])
                 if y is not None:
                     return y
             y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)

@@ -230,6 +230,158 @@ split_gemm_res_kernel(const float *__restrict__ X, const unsigned short *__restr
     split_gemm_body<BM, BN, RELU, PREFETCH, true, BUFST>(X, Whi, Wmid, bias, R, Y, M, K, N);
 }
 
+// ---- 3 x 3 convolution (padding 1, stride 1 or 2) on channels_last activations as the same split product: an
+// implicit GEMM with M = N * Hout * Wout pixels, K = 9 * Cin (tap-major: k = (kh * 3 + kw) * Cin + c -- exactly how a
+// channels_last OIHW weight lies in memory, so the folded FrozenBN weight is used as it is), N = Cout.  The only
+// difference from split_gemm_kernel is where a row of the A tile comes from: K-slice s lies inside ONE tap (Cin % 32 ==
+// 0), its rows are the input pixels shifted by that tap, zeros outside the image.  Register prefetch of the next
+// slice, buffer-store epilogue (bias = FrozenBN shift, ReLU).  OPT-IN route of trackformer_amd/backbone.py
+// (TF_CONV3X3_SPLIT=1): the bottlenecks' 3 x 3 convolutions (reference: torchvision Bottleneck.conv2 + bn2 + relu).
+struct Conv3Args {
+    int nimg, hin, win, cin, hout, wout, cout, stride;
+};
+
+template <int BM, int BN, bool RELU>
+__global__ void __launch_bounds__(THREADS)
+split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
+                   const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
+                   const Conv3Args ca)
+{
+    constexpr int TI = BM / 64, TJ = BN / 64;
+    constexpr int XV = (BM * BK / 4) / THREADS;
+    constexpr int WV = (BN * BK / 8) / THREADS;
+    static_assert(XV >= 1 && WV >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDS_STRIDE];   // [hi | mid][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int M = ca.nimg * ca.hout * ca.wout, K = 9 * ca.cin, N = ca.cout;
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // this thread's XV rows of the A tile: output pixel -> (image, top-left input pixel of its 3 x 3 window)
+    int ybase[XV], xbase[XV], ibase[XV];
+    bool rowok[XV];
+#pragma unroll
+    for (int it = 0; it < XV; ++it) {
+        const int idx = it * THREADS + tid;
+        const int row = m0 + (idx >> 3);
+        rowok[it] = row < M;
+        const int r = rowok[it] ? row : 0;
+        const int img = r / (ca.hout * ca.wout), rem = r - img * (ca.hout * ca.wout);
+        const int yo = rem / ca.wout, xo = rem - yo * ca.wout;
+        ybase[it] = yo * ca.stride - 1;
+        xbase[it] = xo * ca.stride - 1;
+        ibase[it] = img * ca.hin;
+    }
+    f32x4 xr[XV];
+    u32x4 whr[WV], wmr[WV];
+    auto load_slice = [&](int k0) {
+        const int tap = k0 / ca.cin, c0 = k0 - tap * ca.cin;   // uniform: the slice lies inside one tap
+        const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+        for (int it = 0; it < XV; ++it) {
+            const int idx = it * THREADS + tid;
+            const int c4 = idx & 7;
+            const int yi = ybase[it] + dy, xi = xbase[it] + dx;
+            const bool ok = rowok[it] && (unsigned)yi < (unsigned)ca.hin && (unsigned)xi < (unsigned)ca.win;
+            const size_t src = ((size_t)(ibase[it] + (ok ? yi : 0)) * ca.win + (ok ? xi : 0)) * ca.cin + c0 + c4 * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(X + src);   // (a valid address either way)
+            xr[it] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < WV; ++it) {
+            const int idx = it * THREADS + tid;
+            const int row = idx >> 2, c8 = idx & 3;
+            const int grow = min(n0 + row, N - 1);
+            const size_t g = (size_t)grow * K + k0 + c8 * 8;
+            whr[it] = *reinterpret_cast<const u32x4 *>(Whi + g);
+            wmr[it] = *reinterpret_cast<const u32x4 *>(Wmid + g);
+        }
+    };
+    auto store_slice = [&]() {
+#pragma unroll
+        for (int it = 0; it < XV; ++it) {
+            const int idx = it * THREADS + tid;
+            const int row = idx >> 3, c4 = idx & 7;
+            bf16x4 hi, mid;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = (__bf16)xr[it][e];
+                mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
+            }
+            *reinterpret_cast<bf16x4 *>(&sA[0][row * LDS_STRIDE + c4 * 4]) = hi;
+            *reinterpret_cast<bf16x4 *>(&sA[1][row * LDS_STRIDE + c4 * 4]) = mid;
+        }
+#pragma unroll
+        for (int it = 0; it < WV; ++it) {
+            const int idx = it * THREADS + tid;
+            const int row = idx >> 2, c8 = idx & 3;
+            *reinterpret_cast<u32x4 *>(&sB[0][row * LDS_STRIDE + c8 * 8]) = whr[it];
+            *reinterpret_cast<u32x4 *>(&sB[1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
+        }
+    };
+
+    load_slice(0);
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        store_slice();
+        __syncthreads();
+        if (k0 + BK < K) load_slice(k0 + BK);   // in flight during the MFMAs below
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            const int koff = kk + (lane >> 5) * 8;
+            bf16x8 a_hi[TI], a_mid[TI], b_hi[TJ], b_mid[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
+                a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[0][r]);
+                a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[1][r]);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
+                b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[0][r]);
+                b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[1][r]);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_mid[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: buffer stores (rows >= M beyond num_records, columns >= N from 3 GiB)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int col = n0 + wn + j * 32 + (lane & 31);
+            const bool colok = col < N;
+            const float b = (bias && colok) ? bias[col] : 0.f;
+            const int row0 = m0 + wm + i * 32 + 4 * (lane >> 5);
+            const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xC0000000u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[i][j][r] + b;
+                if (RELU) v = v > 0.f ? v : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
+                                                      base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
+            }
+        }
+}
+
 // ---- few rows (the decoder: 400 / 800 queries): a launch is 28-100 blocks, far fewer than CUs, and each block walks its
 // K-slices one memory round trip at a time -- 12 us per 400 x 256 -> 256 linear inside the model (36 such launches per
 // frame, profiles/r02_e2e_eager_per_frame.txt) for 0.16 GFLOP.  Variant 7 (OPT-IN: linear_variant = 7, or
@@ -728,3 +880,32 @@ int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const
     }
 }
 }  // namespace
+
+extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
+                                    int hin, int win, int cin, int cout, int stride, int relu, void *stream)
+{
+    if (!x || !w_hi || !w_mid || !y) return TF_MSDA_ERR_NULL_POINTER;
+    if (nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % BK) != 0 || (stride != 1 && stride != 2))
+        return TF_MSDA_ERR_BAD_DIMS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_mid)) & 15)
+        return TF_MSDA_ERR_BAD_DIMS;
+    Conv3Args ca{nimg, hin, win, cin, (hin + 2 - 3) / stride + 1, (win + 2 - 3) / stride + 1, cout, stride};
+    const long long M = (long long)nimg * ca.hout * ca.wout;
+    if (M <= 0 || (M + 256) * cout * 4 >= 0xC0000000LL || (long long)nimg * hin * win * cin * 4 >= (1LL << 40)) return TF_MSDA_ERR_BAD_DIMS;
+    const unsigned short *wh = static_cast<const unsigned short *>(w_hi), *wm = static_cast<const unsigned short *>(w_mid);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (cout >= 128) {
+        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + 127) / 128));
+        if (relu)
+            hipLaunchKernelGGL((split_conv3_kernel<64, 128, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, ca);
+        else
+            hipLaunchKernelGGL((split_conv3_kernel<64, 128, false>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, ca);
+    } else {
+        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + 63) / 64));
+        if (relu)
+            hipLaunchKernelGGL((split_conv3_kernel<64, 64, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, ca);
+        else
+            hipLaunchKernelGGL((split_conv3_kernel<64, 64, false>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, ca);
+    }
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
