@@ -126,6 +126,8 @@ def parse_args():
                          "FrozenBN / identity / ReLU epilogue (same as TF_CONV1X1_SPLIT=1)")
     ap.add_argument("--conv3x3-split", dest="conv3x3_split", action="store_true", default=None,
                     help="OPT-IN: the bottlenecks' 3x3 convolutions through the split-product implicit GEMM (TF_CONV3X3_SPLIT=1)")
+    ap.add_argument("--input-proj-fused", dest="input_proj_fused", action="store_true", default=None,
+                    help="OPT-IN: input_proj (1x1 convolution + GroupNorm) as split GEMM + own GroupNorm (TF_INPUT_PROJ_FUSED=1)")
     ap.add_argument("--sequences", type=int, default=4,
                     help="independent video sequences tracked concurrently per GPU (one host thread "
                          "and HIP stream each); frames of one sequence stay strictly sequential")
@@ -557,6 +559,8 @@ def main():
         _backbone.set_conv1x1_split(args.conv1x1_split)
     if args.conv3x3_split is not None:
         _backbone.set_conv3x3_split(args.conv3x3_split)
+    if args.input_proj_fused is not None:
+        fused.set_input_proj_fused(args.input_proj_fused)
 
     if args.roofline_only:
         if rank == 0:

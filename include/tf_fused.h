@@ -46,6 +46,16 @@ int tf_add_layernorm_f32(const float *x, const float *res, const float *gamma, c
                          float *out, int64_t rows, int C, float eps, void *stream);
 
 /*
+ * GroupNorm of a channels-innermost activation: x [N, HW, C] (row n starts at x + n * x_image_stride floats; the storage of
+ * a channels_last NCHW tensor or a token-major projection output), G groups of C / G consecutive channels, statistics
+ * per (image, group) with the biased variance and eps inside the square root (torch.nn.GroupNorm); out may alias x.
+ * workspace: 2 * N * G doubles (zeroed by the call).  C <= 1024, C % 4 == 0, 16-byte aligned pointers.
+ * For the reference's `input_proj` (models/deformable_detr.py:73-90: Conv2d -> GroupNorm(32, hidden_dim)).
+ */
+int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
+                          int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream);
+
+/*
  * y[M, N] = x[M, K] . w[N, K]^T + bias[N] (bias may be NULL), ReLU if relu != 0; fp32 in and out, row-major.
  * The weight arrives as TWO bf16 tensors [N, K]: w_hi = bf16(w), w_mid = bf16(w - float(w_hi)) (round to nearest
  * even), split once by the caller; x is split the same way inside the kernel and the product is formed as

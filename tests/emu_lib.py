@@ -47,6 +47,8 @@ def lib():
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_add_layernorm_f32.restype = ci
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
+    L.tf_groupnorm_nhwc_f32.restype = ci
+    L.tf_groupnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
     L.tf_linear_split_f32.restype = ci
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci
@@ -240,3 +242,15 @@ def conv3x3_split(x_nhwc, w_ohwi, bias=None, relu=False, stride=1):
     if rc != 0:
         raise RuntimeError("tf_conv3x3_split_f32: status %d" % rc)
     return y
+
+
+def groupnorm_nhwc(x, gamma, beta, G, eps=1e-5):
+    """x [N, HW, C] -> GroupNorm over (HW, C / G) per image and group."""
+    x, gamma, beta = _c(x, np.float32), _c(gamma, np.float32), _c(beta, np.float32)
+    n, hw, c = x.shape
+    out = np.full(x.shape, np.nan, np.float32)
+    ws = np.full(2 * n * G, np.nan, np.float64)
+    rc = lib().tf_groupnorm_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(out), _p(ws), n, hw, c, G, ctypes.c_float(eps), hw * c, hw * c, None)
+    if rc != 0:
+        raise RuntimeError("tf_groupnorm_nhwc_f32: status %d" % rc)
+    return out

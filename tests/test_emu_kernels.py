@@ -485,3 +485,16 @@ def test_conv3x3_as_split_product(n, h, w, cin, cout, stride):
     y = emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("n,hw,c,g", [(1, 300, 256, 32), (2, 77, 288, 32), (1, 1, 64, 8), (3, 129, 32, 4)], ids=lambda v: str(v))
+def test_groupnorm_nhwc(n, hw, c, g):
+    """tf_groupnorm_nhwc_f32 (statistics per image and group over HW x C / G, double accumulation) against numpy float64."""
+    rng = np.random.default_rng(hw + c)
+    x = (rng.standard_normal((n, hw, c), dtype=np.float32) * 3 + 1.5).astype(np.float32)
+    ga, be = rng.standard_normal(c, dtype=np.float32), rng.standard_normal(c, dtype=np.float32)
+    xr = x.astype(np.float64).reshape(n, hw, g, c // g)
+    mean = xr.mean(axis=(1, 3), keepdims=True)
+    var = xr.var(axis=(1, 3), keepdims=True)
+    ref = ((xr - mean) / np.sqrt(var + 1e-5)).reshape(n, hw, c) * ga + be
+    np.testing.assert_allclose(emu_lib.groupnorm_nhwc(x, ga, be, g), ref, atol=2e-5, rtol=1e-5)

@@ -225,3 +225,33 @@ def test_optin_conv1x1_split_backbone_layer_outputs(dev):
             backbone.set_conv1x1_split(prev)
             backbone.set_conv3x3_split(prev3)
         assert got2.shape == ref2.shape and float((got2 - ref2).abs().max()) < 1e-3 * float(ref2.abs().max())
+
+
+@optin
+@pytest.mark.parametrize("case", list(um.FULL_CASES))
+def test_optin_fused_input_proj_full_size(dev, models, case):
+    """input_proj's 1 x 1 levels as split GEMM + tf_groupnorm_nhwc_f32 (fused.set_input_proj_fused)."""
+    from trackformer_amd import fused
+    prev = fused.set_input_proj_fused(True)
+    try:
+        model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
+        dbox, dlogit = _compare(case, model, out, res, feats, memory)
+        print("%s / fused input_proj: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+    finally:
+        fused.set_input_proj_fused(prev)
+
+
+@optin
+@pytest.mark.parametrize("n,c,h,w,groups", [(1, 256, 50, 84, 32), (2, 288, 13, 21, 32), (1, 64, 7, 5, 8)])
+def test_optin_groupnorm_nhwc_matches_torch(dev, n, c, h, w, groups):
+    from trackformer_amd import fused
+    torch.manual_seed(0)
+    gn = torch.nn.GroupNorm(groups, c).to(dev)
+    with torch.no_grad():
+        gn.weight.normal_(1, 0.3)
+        gn.bias.normal_(0, 0.3)
+    x = (torch.randn(n, c, h, w, device=dev) * 3 + 1).contiguous(memory_format=torch.channels_last)
+    ref = gn(x)
+    got = fused.groupnorm_nhwc(x.permute(0, 2, 3, 1).reshape(n * h * w, c), n, gn)
+    assert got is not None
+    assert torch.allclose(got.view(n, h, w, c).permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)

@@ -92,9 +92,113 @@ add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ res,
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// ---- GroupNorm over channels-innermost activations: x [N, HW, C] (the storage of a channels_last NCHW tensor, or a
+// token-major projection output), statistics per (image, group) over HW x (C / G) elements.  Two passes:
+//   groupnorm_stats_kernel   partial sums per workgroup (fp32 over <= 64 rows per thread, then double), one double
+//                            atomic per group and workgroup into ws[n][g][sum | sum of squares]
+//   groupnorm_apply_kernel   y = (x - mean) * rstd * gamma + beta, mean / rstd from ws (double arithmetic, once per
+//                            workgroup into LDS), 16 bytes per lane
+// Replaces the ATen path behind the reference's `input_proj` (models/deformable_detr.py:73-90: Conv2d + GroupNorm(32, 256)),
+// which for channels_last inputs is a layout copy + RowwiseMoments over only N * 32 rows + a parameter kernel + an
+// element-wise kernel (0.2 ms per frame, profiles/r02_e2e_eager_per_frame.txt).
+constexpr int kGnRowsPerBlock = 128;
+
+__global__ void __launch_bounds__(256)
+groupnorm_stats_kernel(const float *__restrict__ x, double *__restrict__ ws, int HW, int C, int G, long long x_image_stride)
+{
+    __shared__ double s_stat[2 * 256];   // [group][sum | sumsq], G <= 256
+    const int C4 = C >> 2, cpg = C / G;
+    const int n = blockIdx.y;
+    const int r0 = blockIdx.x * kGnRowsPerBlock, r1 = min(HW, r0 + kGnRowsPerBlock);
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) s_stat[i] = 0.0;
+    __syncthreads();
+    const int nslots = 256 / C4;   // >= 1 (host: C <= 1024)
+    const int q = threadIdx.x % C4, rslot = threadIdx.x / C4;
+    if (rslot < nslots) {
+        const f32x4_t *xp = reinterpret_cast<const f32x4_t *>(x + (long long)n * x_image_stride);
+        f32x4_t sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+        for (int r = r0 + rslot; r < r1; r += nslots) {
+            const f32x4_t v = xp[(long long)r * C4 + q];
+            sum += v;
+            sq += v * v;
+        }
+        // the four channels of a quad may straddle two groups (hidden 288: 9 channels per group)
+        const int g0 = (q * 4) / cpg, g1 = (q * 4 + 1) / cpg, g2 = (q * 4 + 2) / cpg, g3 = (q * 4 + 3) / cpg;
+        if (g0 == g3) {
+            atomicAdd(&s_stat[2 * g0], (double)((sum.x + sum.y) + (sum.z + sum.w)));
+            atomicAdd(&s_stat[2 * g0 + 1], (double)((sq.x + sq.y) + (sq.z + sq.w)));
+        } else {
+            atomicAdd(&s_stat[2 * g0], (double)sum.x); atomicAdd(&s_stat[2 * g0 + 1], (double)sq.x);
+            atomicAdd(&s_stat[2 * g1], (double)sum.y); atomicAdd(&s_stat[2 * g1 + 1], (double)sq.y);
+            atomicAdd(&s_stat[2 * g2], (double)sum.z); atomicAdd(&s_stat[2 * g2 + 1], (double)sq.z);
+            atomicAdd(&s_stat[2 * g3], (double)sum.w); atomicAdd(&s_stat[2 * g3 + 1], (double)sq.w);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&ws[(long long)n * 2 * G + i], s_stat[i]);
+}
+
+__global__ void __launch_bounds__(256)
+groupnorm_apply_kernel(const float *__restrict__ x, const double *__restrict__ ws, const float *__restrict__ gamma,
+                       const float *__restrict__ beta, float *__restrict__ out, int HW, int C, int G, float eps,
+                       long long x_image_stride, long long out_image_stride)
+{
+    __shared__ float s_mean[256], s_rstd[256];
+    const int C4 = C >> 2, cpg = C / G;
+    const int n = blockIdx.y;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        const double cnt = (double)HW * (double)cpg;
+        const double mean = ws[(long long)n * 2 * G + 2 * g] / cnt;
+        double var = ws[(long long)n * 2 * G + 2 * g + 1] / cnt - mean * mean;   // biased, as torch.nn.GroupNorm
+        if (var < 0.0) var = 0.0;
+        s_mean[g] = (float)mean;
+        s_rstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const f32x4_t *xp = reinterpret_cast<const f32x4_t *>(x + (long long)n * x_image_stride);
+    f32x4_t *op = reinterpret_cast<f32x4_t *>(out + (long long)n * out_image_stride);
+    const long long n4 = (long long)HW * C4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const int q = (int)(i % C4);
+        const int g0 = (q * 4) / cpg, g1 = (q * 4 + 1) / cpg, g2 = (q * 4 + 2) / cpg, g3 = (q * 4 + 3) / cpg;
+        const f32x4_t v = xp[i];
+        const f32x4_t ga = reinterpret_cast<const f32x4_t *>(gamma)[q], be = reinterpret_cast<const f32x4_t *>(beta)[q];
+        f32x4_t y;
+        y.x = (v.x - s_mean[g0]) * s_rstd[g0] * ga.x + be.x;
+        y.y = (v.y - s_mean[g1]) * s_rstd[g1] * ga.y + be.y;
+        y.z = (v.z - s_mean[g2]) * s_rstd[g2] * ga.z + be.z;
+        y.w = (v.w - s_mean[g3]) * s_rstd[g3] * ga.w + be.w;
+        op[i] = y;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
+                          int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream)
+{
+    if (!x || !gamma || !beta || !out || !workspace) return TF_MSDA_ERR_NULL_POINTER;
+    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 256 || C > 1024 || (C % G) != 0 || (C & 3) || N > 65535)
+        return TF_MSDA_ERR_BAD_DIMS;
+    if (x_image_stride < (int64_t)HW * C || out_image_stride < (int64_t)HW * C || (x_image_stride & 3) || (out_image_stride & 3))
+        return TF_MSDA_ERR_BAD_DIMS;
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || !aligned16(out) || (reinterpret_cast<uintptr_t>(workspace) & 7))
+        return TF_MSDA_ERR_BAD_DIMS;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(workspace, 0, sizeof(double) * 2 * (size_t)N * G, s) != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    const unsigned sblocks = (unsigned)((HW + kGnRowsPerBlock - 1) / kGnRowsPerBlock);
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(sblocks, (unsigned)N), dim3(256), 0, s, x, workspace, HW, C, G,
+                       (long long)x_image_stride);
+    long long ablocks = ((long long)HW * (C / 4) + 255) / 256;
+    if (ablocks > 256 * 8) ablocks = 256 * 8;
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)ablocks, (unsigned)N), dim3(256), 0, s, x,
+                       (const double *)workspace, gamma, beta, out, HW, C, G, eps, (long long)x_image_stride,
+                       (long long)out_image_stride);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
 
 int tf_bias_act_f32(float *x, const float *bias, const float *residual, int64_t n, int C, int relu,
                     void *stream)

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import box_ops
+from . import box_ops, fused
 from .detr import DETR, PostProcess
 from .nested import (NestedTensor, all_valid_mask, inverse_sigmoid, is_all_valid,
                      nested_tensor_from_tensor_list)
@@ -87,10 +87,18 @@ class DeformableDETR(DETR):
             self.merge_features = _get_clones(merge, num_feature_levels)
 
     # ------------------------------------------------------------------------------------------
+    def _input_proj(self, level, x):
+        proj = self.input_proj[level]
+        if not self.training and not torch.is_grad_enabled() and x.is_cuda:
+            y = fused.input_proj_1x1(x, proj[0], proj[1])   # opt-in route; None = not applicable / switched off
+            if y is not None:
+                return y
+        return proj(x)
+
     def _project(self, level, x, prev_x=None):
-        y = self.input_proj[level](x)
+        y = self._input_proj(level, x)
         if self.merge_frame_features:
-            y = self.merge_features[level](torch.cat([y, self.input_proj[level](prev_x)], dim=1))
+            y = self.merge_features[level](torch.cat([y, self._input_proj(level, prev_x)], dim=1))
         return y
 
     def forward(self, samples: NestedTensor, targets: list = None, prev_features=None):

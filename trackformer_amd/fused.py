@@ -246,6 +246,62 @@ def conv3x3(x, w_taps, bias, relu, stride):
     return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
 
 
+# OPT-IN (TF_INPUT_PROJ_FUSED=1 / set_input_proj_fused(True)), not yet timed on hardware: the reference's `input_proj`
+# levels with a 1 x 1 convolution (models/deformable_detr.py:73-90: Conv2d(C, hidden, 1) -> GroupNorm(32, hidden)) as the
+# split-product GEMM over the pixels + the library's own channels-innermost GroupNorm (tf_groupnorm_nhwc_f32), instead
+# of a CK convolution, a layout copy and three ATen kernels per level.
+_input_proj_fused = os.environ.get("TF_INPUT_PROJ_FUSED", "0") == "1"
+
+
+def set_input_proj_fused(on):
+    global _input_proj_fused
+    prev, _input_proj_fused = _input_proj_fused, bool(on)
+    return prev
+
+
+def groupnorm_nhwc(x2, n_img, gn):
+    """GroupNorm of x2 [n_img * HW, C] (channels innermost) with nn.GroupNorm `gn`'s parameters; returns a new tensor of the
+    same shape or None when the kernel does not apply."""
+    if not (x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2 and x2.is_contiguous()
+            and gn.weight is not None and gn.bias is not None and gn.weight.device == x2.device):
+        return None
+    rows, c = x2.shape
+    if rows % n_img or c != gn.num_channels or c % 4 or c > 1024 or gn.num_groups > 256 or n_img > 65535 or (x2.data_ptr() & 15):
+        return None
+    hw = rows // n_img
+    with torch.cuda.device(x2.device):
+        out = torch.empty_like(x2)
+        ws = torch.empty(2 * n_img * gn.num_groups, dtype=torch.float64, device=x2.device)
+        rc = _cabi.lib().tf_groupnorm_nhwc_f32(x2.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(), out.data_ptr(),
+                                               ws.data_ptr(), n_img, hw, c, gn.num_groups, float(gn.eps), hw * c, hw * c,
+                                               _stream(x2.device))
+    _cabi.check(rc, "tf_groupnorm_nhwc_f32")
+    return out
+
+
+def input_proj_1x1(x, conv, gn):
+    """GroupNorm(conv1x1(x)) for a channels_last fp32 GPU activation x [N, Cin, H, W]; returns [N, Cout, H, W]
+    (channels_last) or None when the fused route does not apply (the caller keeps the nn.Sequential)."""
+    if not (_input_proj_fused and _split_linear and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
+            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1):
+        return None
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        x = x.contiguous(memory_format=torch.channels_last)
+    n, cin, h, w = x.shape
+    cout = conv.out_channels
+    hit = getattr(conv, "_tf_w2d", None)   # persistent [Cout, Cin] view: the split pieces are cached on it
+    if hit is None or hit[0] != conv.weight._version or hit[1].device != conv.weight.device:
+        hit = (conv.weight._version, conv.weight.detach().reshape(cout, cin).contiguous())
+        conv._tf_w2d = hit
+    y2 = linear(x.permute(0, 2, 3, 1).reshape(n * h * w, cin), hit[1], conv.bias)
+    if y2 is None:
+        return None
+    z2 = groupnorm_nhwc(y2.reshape(n * h * w, cout), n, gn)
+    if z2 is None:
+        return None
+    return z2.view(n, h, w, cout).permute(0, 3, 1, 2)
+
+
 def module_linear(module, x, inference):
     """module(x) for an nn.Linear: the split product on the GPU inference path when enabled, else the module."""
     if inference and _split_linear:
