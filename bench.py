@@ -561,6 +561,11 @@ def main():
         _backbone.set_conv3x3_split(args.conv3x3_split)
     if args.input_proj_fused is not None:
         fused.set_input_proj_fused(args.input_proj_fused)
+    if os.environ.get("TF_ALL_OPTIN") == "1":   # every opt-in route at once (round-3 measurement aid)
+        _backbone.set_conv1x1_split(True)
+        _backbone.set_conv3x3_split(True)
+        fused.set_input_proj_fused(True)
+        fused.set_box_refine_fused(True)
 
     if args.roofline_only:
         if rank == 0:

@@ -46,6 +46,14 @@ int tf_add_layernorm_f32(const float *x, const float *res, const float *gamma, c
                          float *out, int64_t rows, int C, float eps, void *stream);
 
 /*
+ * Iterative box refinement of the decoder in one pass (reference: models/deformable_transformer.py:331-343 +
+ * util/misc.py inverse_sigmoid): out[r, c] = sigmoid(delta[r, c] + (c < ref_dim ? logit_eps(ref[r, c]) : 0)),
+ * delta / out [rows, 4], ref [rows, ref_dim], ref_dim in {2, 4}, logit_eps(x) = log(max(x', eps) / max(1 - x', eps)) with
+ * x' = clamp(x, 0, 1).  out may alias delta.
+ */
+int tf_box_refine_f32(const float *delta, const float *ref, float *out, int64_t rows, int ref_dim, float eps, void *stream);
+
+/*
  * GroupNorm of a channels-innermost activation: x [N, HW, C] (row n starts at x + n * x_image_stride floats; the storage of
  * a channels_last NCHW tensor or a token-major projection output), G groups of C / G consecutive channels, statistics
  * per (image, group) with the biased variance and eps inside the square root (torch.nn.GroupNorm); out may alias x.

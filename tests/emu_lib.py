@@ -47,6 +47,8 @@ def lib():
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_add_layernorm_f32.restype = ci
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
+    L.tf_box_refine_f32.restype = ci
+    L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_groupnorm_nhwc_f32.restype = ci
     L.tf_groupnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
     L.tf_linear_split_f32.restype = ci
@@ -253,4 +255,14 @@ def groupnorm_nhwc(x, gamma, beta, G, eps=1e-5):
     rc = lib().tf_groupnorm_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(out), _p(ws), n, hw, c, G, ctypes.c_float(eps), hw * c, hw * c, None)
     if rc != 0:
         raise RuntimeError("tf_groupnorm_nhwc_f32: status %d" % rc)
+    return out
+
+
+def box_refine(delta, ref, eps=1e-5):
+    delta, ref = _c(delta, np.float32), _c(ref, np.float32)
+    rows = delta.shape[0]
+    out = np.full(delta.shape, np.nan, np.float32)
+    rc = lib().tf_box_refine_f32(_p(delta), _p(ref), _p(out), rows, ref.shape[1], ctypes.c_float(eps), None)
+    if rc != 0:
+        raise RuntimeError("tf_box_refine_f32: status %d" % rc)
     return out

@@ -498,3 +498,18 @@ def test_groupnorm_nhwc(n, hw, c, g):
     var = xr.var(axis=(1, 3), keepdims=True)
     ref = ((xr - mean) / np.sqrt(var + 1e-5)).reshape(n, hw, c) * ga + be
     np.testing.assert_allclose(emu_lib.groupnorm_nhwc(x, ga, be, g), ref, atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("ref_dim", [2, 4])
+def test_box_refine_fused(ref_dim):
+    """tf_box_refine_f32 against the reference's formulation in float64 (incl. references at / outside [0, 1])."""
+    rng = np.random.default_rng(ref_dim)
+    rows = 401
+    delta = rng.standard_normal((rows, 4)).astype(np.float32)
+    ref = rng.random((rows, ref_dim)).astype(np.float32)
+    ref[:5] = [[0.0, 1.0, -0.2, 1.3][:ref_dim]] * 5
+    x = np.clip(ref.astype(np.float64), 0, 1)
+    inv = np.log(np.maximum(x, 1e-5) / np.maximum(1 - x, 1e-5))
+    v = delta.astype(np.float64).copy()
+    v[:, :ref_dim] += inv
+    np.testing.assert_allclose(emu_lib.box_refine(delta, ref), 1 / (1 + np.exp(-v)), atol=1e-6, rtol=1e-5)

@@ -255,3 +255,29 @@ def test_optin_groupnorm_nhwc_matches_torch(dev, n, c, h, w, groups):
     got = fused.groupnorm_nhwc(x.permute(0, 2, 3, 1).reshape(n * h * w, c), n, gn)
     assert got is not None
     assert torch.allclose(got.view(n, h, w, c).permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)
+
+
+@optin
+@pytest.mark.parametrize("case", list(um.FULL_CASES))
+def test_optin_fused_box_refine_full_size(dev, models, case):
+    """The decoder's iterative box refinement as one launch per layer (fused.set_box_refine_fused)."""
+    from trackformer_amd import fused
+    from trackformer_amd.nested import inverse_sigmoid
+    g = torch.Generator().manual_seed(0)
+    for ref_dim in (2, 4):
+        delta = torch.randn(2, 400, 4, generator=g).to(dev)
+        ref = torch.rand(2, 400, ref_dim, generator=g).to(dev)
+        prev = fused.set_box_refine_fused(True)
+        try:
+            got = fused.box_refine(delta, ref)
+        finally:
+            fused.set_box_refine_fused(prev)
+        exp = delta.clone()
+        exp[..., :ref_dim] += inverse_sigmoid(ref)
+        assert got is not None and torch.allclose(got, exp.sigmoid(), atol=1e-6, rtol=1e-5)
+    prev = fused.set_box_refine_fused(True)
+    try:
+        model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
+        _compare(case, model, out, res, feats, memory)
+    finally:
+        fused.set_box_refine_fused(prev)

@@ -173,9 +173,43 @@ groupnorm_apply_kernel(const float *__restrict__ x, const double *__restrict__ w
     }
 }
 
+// ---- iterative box refinement of the decoder (models/deformable_transformer.py:331-343 of the reference):
+//   ref_dim 4: new = sigmoid(delta + inverse_sigmoid(ref))
+//   ref_dim 2: new[:2] = sigmoid(delta[:2] + inverse_sigmoid(ref)), new[2:] = sigmoid(delta[2:])
+// with inverse_sigmoid(x) = log(max(clamp(x, 0, 1), eps) / max(1 - clamp(x, 0, 1), eps)) (util/misc.py:inverse_sigmoid).
+// One launch instead of the ~12 element-wise ATen launches per decoder layer over [queries, 4] tensors.
+__global__ void __launch_bounds__(256)
+box_refine_kernel(const float *__restrict__ delta, const float *__restrict__ ref, float *__restrict__ out, long long rows,
+                  int ref_dim, float eps)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one component per thread
+    if (i >= rows * 4) return;
+    const long long r = i >> 2;
+    const int c = (int)(i & 3);
+    float v = delta[i];
+    if (c < ref_dim) {
+        float x = ref[r * ref_dim + c];
+        x = fminf(fmaxf(x, 0.f), 1.f);
+        const float x1 = fmaxf(x, eps), x2 = fmaxf(1.f - x, eps);
+        v += logf(x1 / x2);
+    }
+    out[i] = 1.f / (1.f + expf(-v));
+}
+
 }  // namespace
 
 extern "C" {
+
+int tf_box_refine_f32(const float *delta, const float *ref, float *out, int64_t rows, int ref_dim, float eps, void *stream)
+{
+    if (!delta || !ref || !out) return TF_MSDA_ERR_NULL_POINTER;
+    if (rows <= 0 || (ref_dim != 2 && ref_dim != 4) || rows > (1LL << 40)) return TF_MSDA_ERR_BAD_DIMS;
+    const long long blocks = (rows * 4 + 255) / 256;
+    if (blocks > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(box_refine_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), delta, ref,
+                       out, (long long)rows, ref_dim, eps);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
 
 int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
                           int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream)

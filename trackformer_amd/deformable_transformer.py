@@ -448,7 +448,11 @@ class DeformableTransformerDecoder(nn.Module):
 
             if self.bbox_embed is not None:  # iterative bounding box refinement
                 tmp = self.bbox_embed[lid](output)
-                if reference_points.shape[-1] == 4:
+                fused_ref = (fused.box_refine(tmp, reference_points)   # opt-in; None = not applicable / off
+                             if not self.training and not torch.is_grad_enabled() and tmp.is_cuda else None)
+                if fused_ref is not None:
+                    new_reference_points = fused_ref
+                elif reference_points.shape[-1] == 4:
                     new_reference_points = (tmp + inverse_sigmoid(reference_points)).sigmoid()
                 else:
                     assert reference_points.shape[-1] == 2

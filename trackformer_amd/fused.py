@@ -302,6 +302,33 @@ def input_proj_1x1(x, conv, gn):
     return z2.view(n, h, w, cout).permute(0, 3, 1, 2)
 
 
+# OPT-IN (TF_BOX_REFINE_FUSED=1 / set_box_refine_fused(True)): the decoder's iterative box refinement in one launch
+# (tf_box_refine_f32) instead of ~12 element-wise ATen launches per layer on [queries, 4] tensors.
+_box_refine_fused = os.environ.get("TF_BOX_REFINE_FUSED", "0") == "1"
+
+
+def set_box_refine_fused(on):
+    global _box_refine_fused
+    prev, _box_refine_fused = _box_refine_fused, bool(on)
+    return prev
+
+
+def box_refine(delta, reference_points):
+    """sigmoid(delta + inverse_sigmoid(reference_points)) (4-d references) / the 2-d variant of
+    deformable_transformer.py:331-343; delta [..., 4], reference_points [..., 2 or 4].  None when not applicable."""
+    if not (_box_refine_fused and delta.is_cuda and delta.dtype == torch.float32 and reference_points.dtype == torch.float32
+            and delta.shape[-1] == 4 and reference_points.shape[-1] in (2, 4)
+            and delta.shape[:-1] == reference_points.shape[:-1] and delta.is_contiguous()
+            and reference_points.is_contiguous() and reference_points.device == delta.device and delta.numel() > 0):
+        return None
+    with torch.cuda.device(delta.device):
+        out = torch.empty_like(delta)
+        rc = _cabi.lib().tf_box_refine_f32(delta.data_ptr(), reference_points.data_ptr(), out.data_ptr(), delta.numel() // 4,
+                                           reference_points.shape[-1], 1e-5, _stream(delta.device))
+    _cabi.check(rc, "tf_box_refine_f32")
+    return out
+
+
 def module_linear(module, x, inference):
     """module(x) for an nn.Linear: the split product on the GPU inference path when enabled, else the module."""
     if inference and _split_linear:
