@@ -1,7 +1,7 @@
 # Round 3, FIRST GPU call (prepared at the end of round 2, when no GPU minutes were left): validates on hardware what
 # was written against the SIMT emulator and times it against the defaults.  Before calling:
 #     python -m trackformer_amd.build && python tools/build_ablations.py 1 2 4 8 16 32 7
-#     gpurun --timeout 1500 -- 'bash tools/gpu_runs/gpu_r03_first.sh'
+#     gpurun --timeout 2400 -- 'bash tools/gpu_runs/gpu_r03_first.sh'
 # Everything lands in gpurun_out/r03a/.  Nothing here changes a default: each result decides one.
 mkdir -p gpurun_out/r03a
 cd $GRAFT_REPO_ROOT
@@ -43,13 +43,13 @@ timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_defa
 TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore.json 2> $O/bench_cfg2_bufstore.err
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O/bench_cfg2_conv1x1.json 2> $O/bench_cfg2_conv1x1.err
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --input-proj-fused > $O/bench_cfg2_input_proj.json 2> $O/bench_cfg2_input_proj.err
-TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O/bench_cfg2_conv1x1_bufstore.json 2> $O/bench_cfg2_conv1x1_bufstore.err
+timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split --conv3x3-split > $O/bench_cfg2_conv1x1_3x3.json 2> $O/bench_cfg2_conv1x1_3x3.err
 TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore_deep.json 2> $O/bench_cfg2_bufstore_deep.err
 TF_BOX_REFINE_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_box_refine.json 2> $O/bench_cfg2_box_refine.err
 TF_ALL_OPTIN=1 TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 TF_MSDA_PQUAD="pipe=1" timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_all_optin.json 2> $O/bench_cfg2_all_optin.err
 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
 TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_direct9.json 2> $O/bench_cfg4_direct9.err
-cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_bufstore.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
+cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
 
 # 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)
 {
