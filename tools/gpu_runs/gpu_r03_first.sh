@@ -54,7 +54,7 @@ cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstor
 # 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)
 {
 echo "## full kernel, and with the pipelined LDS gathers (pquad_pipe: bit-identical, rolling reads in flight)"
-timeout 180 tools/bin/msda_bench --iters 24 --sets 4 --patterns pert,init,local --fused 1 pquad pquad:pipe=1
+timeout 240 tools/bin/msda_bench --iters 24 --sets 4 --patterns pert,init,local --fused 1 pquad pquad:pipe=1 pquad:npass=1,wgs=4,lds=39 pquad:pipe=1,lds=48
 for lib in tools/bin/ablate/libtf_msda_abl*.so; do
     [ -e "$lib" ] || continue
     echo "## $lib"
