@@ -1,0 +1,75 @@
+"""CPU: the GPU INFERENCE PATH of the model -- backbone with folded FrozenBN + bias_act, input projections, the encoder
+with the fused MSDeformAttn entry and the LDS-window kernel, split-product linears, fused residual + LayerNorm, the
+decoder with its own attention kernel and box refinement -- executed on CPU tensors through the SIMT emulator's build of
+the kernel sources (tests/util_emu_gpu_path.py), against the goldens of the reference's own classes.  Once with the
+defaults (what `-m gpu` tests on hardware), once with every opt-in route switched on (what has not seen hardware yet)."""
+import numpy as np
+import pytest
+import torch
+
+from tests import emu_lib, test_models_cpu as shared
+from tests.util_emu_gpu_path import gpu_path_on_emulator
+
+pytestmark = pytest.mark.skipif(not emu_lib.available(), reason="needs a host clang++ (ROCm's llvm) to build the emulated library")
+
+
+def _run(case, optin, fn=None):
+    from trackformer_amd import backbone, fused
+    with gpu_path_on_emulator() as lib:
+        prev = []
+        if optin:
+            prev = [(backbone.set_conv1x1_split, backbone.set_conv1x1_split(True)),
+                    (backbone.set_conv3x3_split, backbone.set_conv3x3_split(True)),
+                    (fused.set_input_proj_fused, fused.set_input_proj_fused(True)),
+                    (fused.set_box_refine_fused, fused.set_box_refine_fused(True))]
+            opts = {b"linear_bufstore": 1, b"linear_deep": 1, b"pquad_pipe": 1, b"direct9": 1}
+            prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
+        try:
+            return (fn() if fn is not None else shared.run_case(case)) + (dict(lib.calls),)
+        finally:
+            for setter, value in prev:
+                setter(value)
+            if optin:
+                for k, v in prev_opts.items():
+                    lib.tf_msda_set_option(k, v)
+
+
+@pytest.mark.parametrize("optin", [False, True], ids=["defaults", "all_optin"])
+def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
+    case = "cfg2_deformable_tracking"
+    model, out, res, feats, calls = _run(case, optin)
+    # the GPU path really ran: 6 encoder + 6 decoder layers through the fused MSDeformAttn entry, the split-product linears,
+    # the fused LayerNorm and bias_act passes, the own attention kernel
+    assert calls.get("tf_msda_forward_fused_f32") == 12 and calls.get("tf_mha_core_f32") == 6
+    assert calls.get("tf_add_layernorm_f32", 0) >= 30 and calls.get("tf_linear_split_f32", 0) >= 60
+    routes = ("tf_conv3x3_split_f32", "tf_linear_split_res_f32", "tf_groupnorm_nhwc_f32", "tf_box_refine_f32")
+    if optin:   # ResNet-50: 16 bottlenecks (their 3 x 3 and closing 1 x 1 convolutions), 3 projection levels, 6 decoder layers
+        assert [calls.get(r) for r in routes] == [16, 16, 3, 6], calls
+        assert calls.get("tf_bias_act_f32", 0) <= 5          # the stem and the strided projections only
+    else:
+        assert all(calls.get(r) is None for r in routes), calls
+        assert calls.get("tf_bias_act_f32", 0) >= 50
+    # north_star's bar is 1e-3; the split products put the defaults at a few 1e-5 on the logits
+    shared.compare_to_golden(case, model, out, res, feats, box_tol=2e-4, logit_tol=1e-3)
+    z = np.load(shared.os.path.join(shared.GOLDEN, "model_%s.npz" % case))
+    print("max |d boxes| %.2e  max |d logits| %.2e" % (
+        float(np.abs(out['pred_boxes'].numpy() - z['pred_boxes']).max()),
+        float(np.abs(out['pred_logits'].numpy() - z['pred_logits']).max())))
+
+
+def test_multi_frame_model_hidden_288_on_the_emulator():
+    """cfg 4's model family (hidden 288: head dimension 36, two frames x 4 levels in the decoder, GroupNorm with 9 channels
+    per group) through the GPU path with every opt-in route: msda_fwd_f32_pquad<.., 36>, msda_fwd_f32_direct9, the
+    K = 288 / 1152 deep-prefetch linears."""
+    case = "cfg4_multi_frame_tracking"
+    model, out, res, feats, calls = _run(case, True)
+    shared.compare_to_golden(case, model, out, res, feats, box_tol=2e-4, logit_tol=1e-3)
+    assert calls.get("tf_msda_forward_fused_f32", 0) >= 12 and calls.get("tf_groupnorm_nhwc_f32", 0) >= 3
+
+
+def test_tracker_sequence_ids_on_the_emulator_with_every_opt_in_route():
+    """Six frames of Tracker.step through the emulated GPU path, all opt-in routes on: track ids / frames / source queries
+    equal the reference golden bit for bit (the decisions hang on scores next to thresholds)."""
+    tracker, rows, active, inactive, calls = _run("cfg2_deformable_tracking", True, fn=lambda: shared.run_tracker(False))
+    shared.compare_tracker_to_golden(False, tracker, rows, active, inactive, box_tol_px=0.05)
+    assert calls.get("tf_conv3x3_split_f32") == 16 * 6 and calls.get("tf_box_refine_f32") == 36
