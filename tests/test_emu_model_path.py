@@ -73,3 +73,41 @@ def test_tracker_sequence_ids_on_the_emulator_with_every_opt_in_route():
     tracker, rows, active, inactive, calls = _run("cfg2_deformable_tracking", True, fn=lambda: shared.run_tracker(False))
     shared.compare_tracker_to_golden(False, tracker, rows, active, inactive, box_tol_px=0.05)
     assert calls.get("tf_conv3x3_split_f32") == 16 * 6 and calls.get("tf_box_refine_f32") == 36
+
+
+@pytest.mark.parametrize("sorted2", [0, 1], ids=["bwd_sorted", "bwd_sorted2"])
+def test_training_step_through_the_emulated_kernels(sorted2):
+    """One training step (padded two-image batch, previous-frame pass, track-query augmentation, SetCriterion, backward)
+    with MSDeformAttnFunction running the HIP kernels under the emulator -- forward msda_fwd_f32_pquad / _direct, backward
+    msda_bwd_f32_sorted (or the opt-in _sorted2) / _buf -- against the reference's losses and gradient norms."""
+    from trackformer_amd import _cabi
+    with gpu_path_on_emulator() as lib:
+        prev = lib.tf_msda_set_option(b"bwd_sorted2", sorted2)
+        try:
+            loss_dict, total, grads = shared.run_train_step()
+            calls = dict(lib.calls)
+        finally:
+            lib.tf_msda_set_option(b"bwd_sorted2", prev)
+    shared.compare_train_to_golden(loss_dict, total, grads, rtol=2e-4)
+    assert calls.get("tf_msda_backward_f32", 0) >= 5 and calls.get("tf_msda_forward_f32", 0) >= 5
+
+
+def test_full_size_cfg2_model_on_the_emulator_with_every_opt_in_route():
+    """BASELINE cfg 2 (800 x 1333, 300 object + 100 track queries) through the emulated GPU path with every opt-in route
+    on, against the full-size golden of the reference's own classes -- tests/test_full_size_gpu.py's comparison without
+    a GPU (about two minutes on 8 cores; cfg 4 takes seven: tools/emu_full_size.py, profiles/r02_emulator_full_size_parity.txt)."""
+    from tests import test_full_size_gpu as full, util_models as um
+    from trackformer_amd import config, factory
+
+    def fn():
+        model, post, args = um.build("cfg2_full", factory.build_model, config.make_args)
+        model.tracking()
+        img, prev, target = um.model_inputs("cfg2_full", args.hidden_dim)
+        with torch.no_grad():
+            out, _, feats, memory, hs = model(img, target, None)
+            res = post['bbox'](out, torch.tensor([list(um.FULL_ORIG)]))[0]
+        return model, out, res, feats, memory
+    model, out, res, feats, memory, calls = _run("cfg2_full", True, fn=fn)
+    dbox, dlogit = full._compare("cfg2_full", model, out, res, feats, memory)
+    print("cfg2_full, every opt-in route, emulator: max |d boxes| %.2e, max |d logits| %.2e" % (dbox, dlogit))
+    assert calls.get("tf_conv3x3_split_f32") == 16 and calls.get("tf_linear_packed_f32", 0) >= 12
