@@ -91,6 +91,10 @@ int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid,
  */
 int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
                          int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+/* The same kernel for a strided 1 x 1 convolution without padding (w [Cout, Cin]): the projections of the identity branch
+ * (torchvision Bottleneck.downsample, stride 2) -- the rows of the GEMM are every stride-th pixel. */
+int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
+                                 int hin, int win, int cin, int cout, int stride, int relu, void *stream);
 
 /*
  * The same product with the weight in PACKED form (trackformer_amd/csrc/linear_stream.hip): the weight is split into

@@ -57,6 +57,8 @@ def lib():
     L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_conv3x3_split_f32.restype = ci
     L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv1x1_strided_split_f32.restype = ci
+    L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_linear_packed_bytes.restype = ctypes.c_int64
     L.tf_linear_packed_bytes.argtypes = [ci, ci]
     L.tf_linear_pack_weight_f32.restype = ci
@@ -231,16 +233,18 @@ def add_layernorm(x, res, gamma, beta, eps=1e-5):
 
 
 def conv3x3_split(x_nhwc, w_ohwi, bias=None, relu=False, stride=1):
-    """x [N, H, W, Cin] fp32, w [Cout, 3, 3, Cin] fp32 -> y [N, Hout, Wout, Cout] (padding 1)."""
+    """x [N, H, W, Cin] fp32, w [Cout, 3, 3, Cin] fp32 (padding 1) or [Cout, 1, 1, Cin] (no padding) -> y [N, Hout, Wout, Cout]."""
     x, w = _c(x_nhwc, np.float32), _c(w_ohwi, np.float32)
     n, h, wd, cin = x.shape
-    cout = w.shape[0]
-    hi, mid = bf16_split(w.reshape(cout, 9 * cin))
+    cout, ks = w.shape[0], w.shape[1]
+    hi, mid = bf16_split(w.reshape(cout, ks * ks * cin))
     hi, mid = np.ascontiguousarray(hi), np.ascontiguousarray(mid)
     b = _c(bias, np.float32) if bias is not None else None
-    ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    pad = 1 if ks == 3 else 0
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
     y = np.full((n, ho, wo, cout), np.nan, np.float32)
-    rc = lib().tf_conv3x3_split_f32(_p(x), _p(hi), _p(mid), _p(b), _p(y), n, h, wd, cin, cout, stride, int(relu), None)
+    fn = lib().tf_conv3x3_split_f32 if ks == 3 else lib().tf_conv1x1_strided_split_f32
+    rc = fn(_p(x), _p(hi), _p(mid), _p(b), _p(y), n, h, wd, cin, cout, stride, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_conv3x3_split_f32: status %d" % rc)
     return y

@@ -470,18 +470,19 @@ def test_opt_in_kernels_do_not_depend_on_the_scheduling_order():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("ks", [3, 1], ids=["3x3", "1x1_strided"])
 @pytest.mark.parametrize("n,h,w,cin,cout,stride", [(1, 9, 11, 64, 64, 1), (2, 8, 6, 32, 128, 1), (1, 10, 13, 64, 160, 2), (1, 7, 7, 128, 64, 2),
                                                     (1, 1, 1, 32, 32, 1)], ids=lambda v: str(v))
-def test_conv3x3_as_split_product(n, h, w, cin, cout, stride):
+def test_conv3x3_as_split_product(n, h, w, cin, cout, stride, ks):
     """tf_conv3x3_split_f32: the bottlenecks' 3 x 3 convolutions (padding 1, stride 1 / 2) as an implicit GEMM on the
     emulated matrix cores, against torch's convolution in float64."""
     import torch
     rng = np.random.default_rng(h * w + cin)
     x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
-    wt = (rng.standard_normal((cout, 3, 3, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    wt = (rng.standard_normal((cout, ks, ks, cin), dtype=np.float32) / np.sqrt(ks * ks * cin)).astype(np.float32)
     b = rng.standard_normal(cout, dtype=np.float32)
     ref = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double().permute(0, 3, 1, 2),
-                                     torch.from_numpy(b).double(), stride=stride, padding=1).clamp_min(0).permute(0, 2, 3, 1).numpy()
+                                     torch.from_numpy(b).double(), stride=stride, padding=1 if ks == 3 else 0).clamp_min(0).permute(0, 2, 3, 1).numpy()
     y = emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())

@@ -45,7 +45,8 @@ def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
     routes = ("tf_conv3x3_split_f32", "tf_linear_split_res_f32", "tf_groupnorm_nhwc_f32", "tf_box_refine_f32")
     if optin:   # ResNet-50: 16 bottlenecks (their 3 x 3 and closing 1 x 1 convolutions), 3 projection levels, 6 decoder layers
         assert [calls.get(r) for r in routes] == [16, 16, 3, 6], calls
-        assert calls.get("tf_bias_act_f32", 0) <= 5          # the stem and the strided projections only
+        assert calls.get("tf_conv1x1_strided_split_f32") == 3   # the strided projections of layer2..4
+        assert calls.get("tf_bias_act_f32", 0) <= 2          # the stem (and layer1's stride-1 projection goes through the GEMM)
     else:
         assert all(calls.get(r) is None for r in routes), calls
         assert calls.get("tf_bias_act_f32", 0) >= 50

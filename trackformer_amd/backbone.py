@@ -41,7 +41,8 @@ _conv1x1_split = _os.environ.get("TF_CONV1X1_SPLIT", "0") == "1"
 
 # OPT-IN as well (TF_CONV3X3_SPLIT=1 / set_conv3x3_split(True)): the bottlenecks' 3 x 3 convolutions (stride 1 and 2) as the
 # same split product, an implicit GEMM over the output pixels (fused.conv3x3 -> tf_conv3x3_split_f32), FrozenBN shift and
-# ReLU in its epilogue.  With both routes on, only the 7 x 7 stem and the three strided 1 x 1 projections stay in MIOpen.
+# ReLU in its epilogue.  (The three strided 1 x 1 projections of the identity branch go through the same kernel with a
+# 1 x 1 window under TF_CONV1X1_SPLIT.)  With both routes on, only the 7 x 7 stem stays in MIOpen.
 _conv3x3_split = _os.environ.get("TF_CONV3X3_SPLIT", "0") == "1"
 
 
@@ -148,6 +149,11 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
                     and conv.groups == 1 and CHANNELS_LAST):
                 y = conv1x1_as_gemm(x, cache.weight2d, b, residual, relu,
                                     lambda x2, w2, bb, act, r2: fused.linear(x2, w2, bb, relu=act, residual=r2))
+                if y is not None:
+                    return y
+            if (_conv1x1_split and cache.weight2d is not None and residual is None and conv.stride == (2, 2)
+                    and conv.padding == (0, 0) and conv.groups == 1 and CHANNELS_LAST):
+                y = fused.conv3x3(x, cache.weight2d, b, relu, 2)   # the strided projection of the identity branch
                 if y is not None:
                     return y
             if (_conv3x3_split and cache.weight_taps is not None and residual is None and conv.padding == (1, 1)

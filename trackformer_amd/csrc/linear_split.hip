@@ -239,6 +239,7 @@ split_gemm_res_kernel(const float *__restrict__ X, const unsigned short *__restr
 // (TF_CONV3X3_SPLIT=1): the bottlenecks' 3 x 3 convolutions (reference: torchvision Bottleneck.conv2 + bn2 + relu).
 struct Conv3Args {
     int nimg, hin, win, cin, hout, wout, cout, stride;
+    int ks, pad;   // 3 / 1 (the bottlenecks' 3 x 3 convolutions) or 1 / 0 (the strided 1 x 1 projections of the identity branch)
 };
 
 template <int BM, int BN, bool RELU>
@@ -256,7 +257,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-    const int M = ca.nimg * ca.hout * ca.wout, K = 9 * ca.cin, N = ca.cout;
+    const int M = ca.nimg * ca.hout * ca.wout, K = ca.ks * ca.ks * ca.cin, N = ca.cout;
 
     f32x16 acc[TI][TJ];
 #pragma unroll
@@ -277,15 +278,15 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         const int r = rowok[it] ? row : 0;
         const int img = r / (ca.hout * ca.wout), rem = r - img * (ca.hout * ca.wout);
         const int yo = rem / ca.wout, xo = rem - yo * ca.wout;
-        ybase[it] = yo * ca.stride - 1;
-        xbase[it] = xo * ca.stride - 1;
+        ybase[it] = yo * ca.stride - ca.pad;
+        xbase[it] = xo * ca.stride - ca.pad;
         ibase[it] = img * ca.hin;
     }
     f32x4 xr[XV];
     u32x4 whr[WV], wmr[WV];
     auto load_slice = [&](int k0) {
         const int tap = k0 / ca.cin, c0 = k0 - tap * ca.cin;   // uniform: the slice lies inside one tap
-        const int dy = tap / 3, dx = tap - dy * 3;
+        const int dy = tap / ca.ks, dx = tap - dy * ca.ks;
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
@@ -881,15 +882,34 @@ int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const
 }
 }  // namespace
 
+namespace {
+int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg, int hin, int win,
+                    int cin, int cout, int stride, int ks, int relu, void *stream);
+}
+
 extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
                                     int hin, int win, int cin, int cout, int stride, int relu, void *stream)
+{
+    return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream);
+}
+
+extern "C" int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
+                                            int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream)
+{
+    return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream);
+}
+
+namespace {
+int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg, int hin, int win,
+                    int cin, int cout, int stride, int ks, int relu, void *stream)
 {
     if (!x || !w_hi || !w_mid || !y) return TF_MSDA_ERR_NULL_POINTER;
     if (nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % BK) != 0 || (stride != 1 && stride != 2))
         return TF_MSDA_ERR_BAD_DIMS;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_mid)) & 15)
         return TF_MSDA_ERR_BAD_DIMS;
-    Conv3Args ca{nimg, hin, win, cin, (hin + 2 - 3) / stride + 1, (win + 2 - 3) / stride + 1, cout, stride};
+    const int pad = ks == 3 ? 1 : 0;
+    Conv3Args ca{nimg, hin, win, cin, (hin + 2 * pad - ks) / stride + 1, (win + 2 * pad - ks) / stride + 1, cout, stride, ks, pad};
     const long long M = (long long)nimg * ca.hout * ca.wout;
     if (M <= 0 || (M + 256) * cout * 4 >= 0xC0000000LL || (long long)nimg * hin * win * cin * 4 >= (1LL << 40)) return TF_MSDA_ERR_BAD_DIMS;
     const unsigned short *wh = static_cast<const unsigned short *>(w_hi), *wm = static_cast<const unsigned short *>(w_mid);
@@ -909,3 +929,4 @@ extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void
     }
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
+}  // namespace

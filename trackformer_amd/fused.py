@@ -218,7 +218,8 @@ def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
 
 
 def conv3x3(x, w_taps, bias, relu, stride):
-    """3 x 3 convolution (padding 1) of a channels_last fp32 GPU activation through tf_conv3x3_split_f32.
+    """3 x 3 convolution (padding 1) -- or, with a [Cout, Cin] weight, a strided 1 x 1 convolution without padding -- of a
+    channels_last fp32 GPU activation through tf_conv3x3_split_f32 / tf_conv1x1_strided_split_f32.
     x [N, Cin, H, W] (channels_last), w_taps [Cout, 9 * Cin] (the [Cout, 3, 3, Cin] storage of a channels_last weight, a
     persistent tensor: its bf16 pieces are cached on it), bias [Cout] or None.  Returns [N, Cout, Hout, Wout]
     (channels_last) or None when the kernel does not apply."""
@@ -228,7 +229,8 @@ def conv3x3(x, w_taps, bias, relu, stride):
         return None
     n, cin, h, w = x.shape
     cout = w_taps.shape[0]
-    if w_taps.shape[1] != 9 * cin or cin % 32 or stride not in (1, 2) or x.numel() == 0:
+    ks = 3 if w_taps.shape[1] == 9 * cin else 1   # [Cout, Cin]: a strided 1 x 1 projection (no padding)
+    if w_taps.shape[1] != ks * ks * cin or cin % 32 or stride not in (1, 2) or x.numel() == 0:
         return None
     if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
                                  and bias.device == x.device):
@@ -236,12 +238,13 @@ def conv3x3(x, w_taps, bias, relu, stride):
     hi, mid = _split_weight(w_taps)
     if (x.data_ptr() | hi.data_ptr() | mid.data_ptr()) & 15:
         return None
-    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    pad = 1 if ks == 3 else 0
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     with torch.cuda.device(x.device):
         y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
-        rc = _cabi.lib().tf_conv3x3_split_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(),
-                                              0 if bias is None else bias.data_ptr(), y.data_ptr(), n, h, w, cin, cout,
-                                              stride, 1 if relu else 0, _stream(x.device))
+        fn = _cabi.lib().tf_conv3x3_split_f32 if ks == 3 else _cabi.lib().tf_conv1x1_strided_split_f32
+        rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), n, h, w,
+                cin, cout, stride, 1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_conv3x3_split_f32")
     return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
 
