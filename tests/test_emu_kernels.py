@@ -514,3 +514,23 @@ def test_box_refine_fused(ref_dim):
     v = delta.astype(np.float64).copy()
     v[:, :ref_dim] += inv
     np.testing.assert_allclose(emu_lib.box_refine(delta, ref), 1 / (1 + np.exp(-v)), atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,K,N,bias", [(130, 256, 1024, True), (100, 1024, 256, True), (70, 64, 384, False), (65, 128, 200, True)],
+                         ids=lambda v: str(v))
+def test_packed_linear_transposed_accumulators_wide_stores(M, K, N, bias):
+    """linear_bufstore = 2 in the packed kernel: the weight fragment as the A operand (the accumulators hold the transposed
+    tile), 16-byte stores.  Same products; against float64 and (up to the rounding of the matrix-core sums) the default."""
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N, dtype=np.float32) if bias else None
+    base = emu_lib.linear_packed(x, w, b, True)
+    prev = emu_lib.set_options(linear_bufstore=2)
+    try:
+        got = emu_lib.linear_packed(x, w, b, True)
+    finally:
+        emu_lib.set_options(**prev)
+    ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + (b if bias else 0), 0)
+    assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    np.testing.assert_allclose(got, base, atol=1e-5, rtol=1e-5)

@@ -212,3 +212,24 @@ def test_optin_deep_prefetch_linear_bit_identical(dev, split_on, M, K, N, bias, 
     finally:
         lib.tf_msda_set_option(b"linear_deep", prev)
     assert torch.equal(got, base)
+
+
+@optin
+@pytest.mark.parametrize("M,K,N,relu", [(22223, 256, 1024, True), (22223, 1024, 256, False), (5000, 256, 1024, True)], ids=lambda v: str(v))
+def test_optin_packed_linear_wide_stores(dev, split_on, M, K, N, relu):
+    """linear_bufstore = 2: transposed accumulators + 16-byte stores in the packed kernel (same products; the matrix cores
+    may round the swapped-operand sums differently, hence a tolerance instead of bit identity -- reported either way)."""
+    from trackformer_amd import _cabi
+    lib = _cabi.lib()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    base = split_on.linear(x, w, b, relu=relu)
+    prev = lib.tf_msda_set_option(b"linear_bufstore", 2)
+    try:
+        got = split_on.linear(x, w, b, relu=relu)
+    finally:
+        lib.tf_msda_set_option(b"linear_bufstore", prev)
+    print("wide stores: %d of %d outputs differ in the last bits" % (int((got != base).sum()), got.numel()))
+    assert torch.allclose(got, base, atol=1e-5, rtol=1e-5)

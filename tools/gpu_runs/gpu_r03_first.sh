@@ -30,6 +30,7 @@ for shape in "22223 256 1024 packed" "22223 1024 256 packed" "22223 256 256" "22
     echo "## $shape: default epilogue, then TF_LINEAR_BUFSTORE=1"
     timeout 60 tools/bin/linear_bench $shape | grep -E "us per launch"
     TF_LINEAR_BUFSTORE=1 timeout 60 tools/bin/linear_bench $shape | grep -E "us per launch|differ"
+    case "$shape" in *packed*) TF_LINEAR_BUFSTORE=2 timeout 60 tools/bin/linear_bench $shape | grep -E "us per launch|differ";; esac
 done
 echo "## few rows (decoder): default variant 5 vs the deep-prefetch variant 7 vs the weight-stationary variant 6"
 for shape in "400 256 256" "400 256 384" "400 256 1024" "400 1024 256" "800 288 288"; do

@@ -772,7 +772,7 @@ int linear_bufstore()
     int v = g_bufstore.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("TF_LINEAR_BUFSTORE");
-        v = (e && e[0] == '1') ? 1 : 0;
+        v = (e && e[0] == '2') ? 2 : (e && e[0] == '1') ? 1 : 0;
         g_bufstore.store(v);
     }
     return v;
@@ -796,7 +796,7 @@ int linear_deep_set(int v)
 int linear_bufstore_set(int v)
 {
     const int prev = linear_bufstore();
-    g_bufstore.store(v ? 1 : 0);
+    g_bufstore.store(v == 2 ? 2 : (v ? 1 : 0));   // 2: + transposed accumulators / 16-byte stores in the packed kernel
     return prev;
 }
 int linear_set_variant(int v)
