@@ -298,7 +298,13 @@ def test_query_self_attention_kernel(Lq, Lk, H, D, masked):
     p = np.exp(s - s.max(-1, keepdims=True))
     p /= p.sum(-1, keepdims=True)
     ref = np.einsum("nhlj,njhd->nlhd", p, v.astype(np.float64))
-    np.testing.assert_allclose(emu_lib.mha_core(q, k, v, scale, mask), ref, atol=2e-5, rtol=1e-4)
+    base = emu_lib.mha_core(q, k, v, scale, mask)
+    np.testing.assert_allclose(base, ref, atol=2e-5, rtol=1e-4)
+    prev = emu_lib.set_options(mha_batch=1)   # opt-in: eight staging loads in flight per thread -- same data, same arithmetic
+    try:
+        assert np.array_equal(emu_lib.mha_core(q, k, v, scale, mask), base)
+    finally:
+        emu_lib.set_options(**prev)
 
 
 # ---- opt-in kernels awaiting their first hardware run --------------------------------------------------------------

@@ -22,7 +22,7 @@ def _run(case, optin, fn=None):
                     (backbone.set_conv3x3_split, backbone.set_conv3x3_split(True)),
                     (fused.set_input_proj_fused, fused.set_input_proj_fused(True)),
                     (fused.set_box_refine_fused, fused.set_box_refine_fused(True))]
-            opts = {b"linear_bufstore": 1, b"linear_deep": 1, b"pquad_pipe": 1, b"direct9": 1}
+            opts = {b"linear_bufstore": 2, b"linear_deep": 1, b"pquad_pipe": 1, b"direct9": 1, b"mha_batch": 1}
             prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
         try:
             return (fn() if fn is not None else shared.run_case(case)) + (dict(lib.calls),)

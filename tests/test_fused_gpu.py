@@ -127,3 +127,28 @@ def test_decoder_self_attention_uses_own_kernel_and_matches_module(dev):
         q = (tgt + pos).transpose(0, 1)
         ref = layer.self_attn(q, q, tgt.transpose(0, 1))[0].transpose(0, 1)
     assert torch.allclose(got, ref, atol=2e-5, rtol=1e-4)
+
+
+import os  # noqa: E402
+
+optin = pytest.mark.skipif(os.environ.get("TF_TEST_OPTIN") != "1", reason="opt-in kernels: set TF_TEST_OPTIN=1")
+
+
+@optin
+@pytest.mark.parametrize("length,heads,d", [(400, 8, 32), (800, 8, 36), (37, 4, 16)])
+def test_optin_mha_batched_staging_bit_identical(length, heads, d):
+    """mha_batch: eight staging loads in flight per thread in tf_mha_core_f32; same data, same arithmetic."""
+    from trackformer_amd import _cabi, fused
+    lib = _cabi.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(length)
+    e = heads * d
+    qk = torch.randn(2, length, 2 * e, generator=g).to(dev)
+    v = torch.randn(2, length, e, generator=g).to(dev)
+    base = fused.mha_core(qk, v, heads)
+    prev = lib.tf_msda_set_option(b"mha_batch", 1)
+    try:
+        got = fused.mha_core(qk, v, heads)
+    finally:
+        lib.tf_msda_set_option(b"mha_batch", prev)
+    assert base is not None and torch.equal(got, base)

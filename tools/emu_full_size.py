@@ -32,8 +32,8 @@ def main():
             backbone.set_conv3x3_split(True)
             fused.set_input_proj_fused(True)
             fused.set_box_refine_fused(True)
-            for k in (b"linear_bufstore", b"linear_deep", b"pquad_pipe", b"direct9"):
-                lib.tf_msda_set_option(k, 1)
+            for k, v in ((b"linear_bufstore", 2), (b"linear_deep", 1), (b"pquad_pipe", 1), (b"direct9", 1), (b"mha_batch", 1)):
+                lib.tf_msda_set_option(k, v)
         with torch.no_grad():
             prev_features = None
             if args.multi_frame_attention:

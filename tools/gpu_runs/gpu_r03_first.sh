@@ -10,7 +10,7 @@ export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/trackformer_amd/lib:$LD_LIBRARY_PATH
 O=gpurun_out/r03a
 
 # 1. parity of the opt-in kernels / routes (direct9, bwd_sorted2, conv1x1 split) on the hardware
-TF_TEST_OPTIN=1 timeout 600 python -m pytest tests/test_msda_gpu.py tests/test_full_size_gpu.py tests/test_linear_split_gpu.py -m gpu -q -s -k optin \
+TF_TEST_OPTIN=1 timeout 600 python -m pytest tests/test_msda_gpu.py tests/test_full_size_gpu.py tests/test_linear_split_gpu.py tests/test_fused_gpu.py -m gpu -q -s -k optin \
     > $O/pytest_optin.txt 2>&1
 tail -3 $O/pytest_optin.txt
 
@@ -22,6 +22,9 @@ timeout 200 python tools/bench_msda.py --shapes cfg4_decoder --no-backward --opt
 echo "## encoder backward: msda_bwd_f32_sorted (default) vs msda_bwd_f32_sorted2"
 timeout 300 python tools/bench_msda.py --shapes cfg2_encoder,cfg3_encoder_n2 --no-forward
 timeout 300 python tools/bench_msda.py --shapes cfg2_encoder,cfg3_encoder_n2 --no-forward --option bwd_sorted2=1
+echo "## decoder query self-attention: default staging vs TF_MHA_BATCH=1 (eight loads in flight per thread)"
+timeout 120 python tools/bench_mha.py
+TF_MHA_BATCH=1 timeout 120 python tools/bench_mha.py
 } > $O/kernel_times.txt 2>&1
 
 # 2b. the split GEMMs with the buffer-store epilogue (no vmcnt(0) between stores) against the default epilogue
@@ -47,7 +50,7 @@ timeout 240 python bench.py --no-cpu-baseline --no-roofline --input-proj-fused >
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split --conv3x3-split > $O/bench_cfg2_conv1x1_3x3.json 2> $O/bench_cfg2_conv1x1_3x3.err
 TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore_deep.json 2> $O/bench_cfg2_bufstore_deep.err
 TF_BOX_REFINE_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_box_refine.json 2> $O/bench_cfg2_box_refine.err
-TF_ALL_OPTIN=1 TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 TF_MSDA_PQUAD="pipe=1" timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_all_optin.json 2> $O/bench_cfg2_all_optin.err
+TF_ALL_OPTIN=1 TF_LINEAR_BUFSTORE=2 TF_LINEAR_DEEP=1 TF_MHA_BATCH=1 TF_MSDA_PQUAD="pipe=1" timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_all_optin.json 2> $O/bench_cfg2_all_optin.err
 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
 TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_direct9.json 2> $O/bench_cfg4_direct9.err
 cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260

@@ -50,6 +50,9 @@ int linear_set_variant(int v);
 // linear_split.hip: opt-in buffer-store epilogue of the split GEMMs (0 / 1); the setter returns the previous value
 int linear_bufstore();
 int linear_bufstore_set(int v);
+// mha_core.hip: opt-in batched staging loads of tf_mha_core_f32 (0 / 1)
+int mha_batch();
+int mha_batch_set(int v);
 // linear_split.hip: opt-in deep-prefetch kernel (variant 7) for calls with few rows (0 / 1)
 int linear_deep();
 int linear_deep_set(int v);
