@@ -233,6 +233,21 @@ def test_bias_act_and_add_layernorm():
     r = rng.standard_normal(x.shape, dtype=np.float32)
     np.testing.assert_allclose(emu_lib.bias_act(x, b, r, relu=True), np.maximum(x + b + r, 0), atol=1e-6)
     np.testing.assert_allclose(emu_lib.bias_act(x, b, None, relu=False), x + b, atol=1e-6)
+    prev = emu_lib.set_options(bias_act_batch=1)   # opt-in: loads batched, two grid strides per iteration; bit-identical
+    try:
+        for res in (r, None):
+            for relu in (True, False):
+                emu_lib.set_options(bias_act_batch=0)
+                base = emu_lib.bias_act(x, b, res, relu=relu)
+                emu_lib.set_options(bias_act_batch=1)
+                assert np.array_equal(emu_lib.bias_act(x, b, res, relu=relu), base)
+        big = rng.standard_normal((3000, 7, 64), dtype=np.float32)   # more float4s than the grid has threads: the strided loop
+        emu_lib.set_options(bias_act_batch=0)
+        base = emu_lib.bias_act(big, b, None, relu=True)
+        emu_lib.set_options(bias_act_batch=1)
+        assert np.array_equal(emu_lib.bias_act(big, b, None, relu=True), base)
+    finally:
+        emu_lib.set_options(**prev)
     for C in (256, 288, 1024):
         x = rng.standard_normal((70, C), dtype=np.float32)
         res = rng.standard_normal((70, C), dtype=np.float32)

@@ -152,3 +152,25 @@ def test_optin_mha_batched_staging_bit_identical(length, heads, d):
     finally:
         lib.tf_msda_set_option(b"mha_batch", prev)
     assert base is not None and torch.equal(got, base)
+
+
+@optin
+@pytest.mark.parametrize("shape,res,relu", [((1, 256, 200, 334), True, True), ((1, 64, 200, 334), False, True), ((2, 512, 25, 42), True, False)])
+def test_optin_bias_act_batched_bit_identical(shape, res, relu):
+    """bias_act_batch: the residual test as a template parameter, two grid strides per iteration, loads first."""
+    from trackformer_amd import _cabi, fused
+    lib = _cabi.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(shape[1])
+    x = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(shape[1], generator=g).to(dev)
+    r = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last) if res else None
+    base = x.clone()
+    assert fused.bias_act_(base, b, r, relu) is not None
+    got = x.clone()
+    prev = lib.tf_msda_set_option(b"bias_act_batch", 1)
+    try:
+        assert fused.bias_act_(got, b, r, relu) is not None
+    finally:
+        lib.tf_msda_set_option(b"bias_act_batch", prev)
+    assert torch.equal(got, base)

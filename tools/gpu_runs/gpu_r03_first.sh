@@ -49,7 +49,7 @@ timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --input-proj-fused > $O/bench_cfg2_input_proj.json 2> $O/bench_cfg2_input_proj.err
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split --conv3x3-split > $O/bench_cfg2_conv1x1_3x3.json 2> $O/bench_cfg2_conv1x1_3x3.err
 TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore_deep.json 2> $O/bench_cfg2_bufstore_deep.err
-TF_BOX_REFINE_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_box_refine.json 2> $O/bench_cfg2_box_refine.err
+TF_BOX_REFINE_FUSED=1 TF_MHA_BATCH=1 TF_BIAS_ACT_BATCH=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_box_refine.json 2> $O/bench_cfg2_box_refine.err
 TF_ALL_OPTIN=1 TF_LINEAR_BUFSTORE=2 TF_LINEAR_DEEP=1 TF_MHA_BATCH=1 TF_MSDA_PQUAD="pipe=1" timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_all_optin.json 2> $O/bench_cfg2_all_optin.err
 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
 TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_direct9.json 2> $O/bench_cfg4_direct9.err

@@ -5,7 +5,11 @@
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
+#include <stdlib.h>
 
+#include <atomic>
+
+#include "msda_common.h"
 #include "tf_fused.h"
 #include "tf_msda.h"
 
@@ -30,6 +34,52 @@ bias_act_kernel(float *__restrict__ x, const float *__restrict__ bias,
             v.w = fmaxf(v.w, 0.f);
         }
         reinterpret_cast<f32x4_t *>(x)[i] = v;
+    }
+}
+
+// OPT-IN variant (tf_msda_set_option("bias_act_batch", 1) / TF_BIAS_ACT_BATCH=1): the loop above compiles to load x, load
+// bias, s_waitcnt vmcnt(0), [branch] load residual, s_waitcnt vmcnt(0), store per iteration -- two sequential memory round
+// trips per 16 bytes and lane (tools/isa_audit.py --stream bias_act_kernel).  Here the residual test is a template
+// parameter and two grid strides are processed per iteration with all of their loads issued first.
+template <bool RES, bool RELU>
+__global__ void __launch_bounds__(256)
+bias_act_batched_kernel(float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ residual,
+                        long long n4, int C4)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // channel quad of element i: one 64-bit remainder up front, 32-bit increments with a wrap afterwards
+    const int step = (int)(stride % C4);
+    int q0 = (int)(first % C4);
+    for (long long i = first; i < n4; i += 2 * stride) {
+        const long long i1 = i + stride;
+        const bool two = i1 < n4;
+        const long long j1 = two ? i1 : i;   // a harmless reload when the second element does not exist
+        int q1 = q0 + step;
+        q1 = q1 >= C4 ? q1 - C4 : q1;
+        const f32x4_t b0 = reinterpret_cast<const f32x4_t *>(bias)[q0];
+        const f32x4_t b1 = reinterpret_cast<const f32x4_t *>(bias)[two ? q1 : q0];
+        f32x4_t v0 = reinterpret_cast<const f32x4_t *>(x)[i];
+        f32x4_t v1 = reinterpret_cast<const f32x4_t *>(x)[j1];
+        f32x4_t r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+        if constexpr (RES) {
+            r0 = reinterpret_cast<const f32x4_t *>(residual)[i];
+            r1 = reinterpret_cast<const f32x4_t *>(residual)[j1];
+        }
+        q0 = q1 + step;
+        q0 = q0 >= C4 ? q0 - C4 : q0;
+        v0 += b0;
+        v1 += b1;
+        if constexpr (RES) {
+            v0 += r0;
+            v1 += r1;
+        }
+        if constexpr (RELU) {
+            v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+            v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+        }
+        reinterpret_cast<f32x4_t *>(x)[i] = v0;
+        if (two) reinterpret_cast<f32x4_t *>(x)[i1] = v1;
     }
 }
 
@@ -88,6 +138,18 @@ add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ res,
             }
         }
     }
+}
+
+std::atomic<int> g_bias_act_batch{-1};   // -1: TF_BIAS_ACT_BATCH (default 0)
+int bias_act_batch()
+{
+    int v = g_bias_act_batch.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_BIAS_ACT_BATCH");
+        v = (e && e[0] == '1') ? 1 : 0;
+        g_bias_act_batch.store(v);
+    }
+    return v;
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -244,8 +306,19 @@ int tf_bias_act_f32(float *x, const float *bias, const float *residual, int64_t 
     const long long n4 = n / 4;
     long long blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond 16 workgroups per CU
-    hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), x, bias, residual, n4, C / 4, relu);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (bias_act_batch()) {   // opt-in variant: loads batched, two grid strides per iteration
+        if (residual && relu)
+            hipLaunchKernelGGL((bias_act_batched_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
+        else if (residual)
+            hipLaunchKernelGGL((bias_act_batched_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
+        else if (relu)
+            hipLaunchKernelGGL((bias_act_batched_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
+        else
+            hipLaunchKernelGGL((bias_act_batched_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
+        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4, relu);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
@@ -277,3 +350,12 @@ int tf_add_layernorm_f32(const float *x, const float *res, const float *gamma, c
 }
 
 }  // extern "C"
+
+namespace tfm {
+int bias_act_batch_set(int v)
+{
+    const int prev = bias_act_batch();
+    g_bias_act_batch.store(v ? 1 : 0);
+    return prev;
+}
+}  // namespace tfm

@@ -50,6 +50,8 @@ int linear_set_variant(int v);
 // linear_split.hip: opt-in buffer-store epilogue of the split GEMMs (0 / 1); the setter returns the previous value
 int linear_bufstore();
 int linear_bufstore_set(int v);
+// fused_ops.hip: opt-in batched-load variant of tf_bias_act_f32 (0 / 1); returns the previous value
+int bias_act_batch_set(int v);
 // mha_core.hip: opt-in batched staging loads of tf_mha_core_f32 (0 / 1)
 int mha_batch();
 int mha_batch_set(int v);
