@@ -625,7 +625,9 @@ def main():
                        "parallelism": ("DDP x%d (RCCL all-reduce)" if train else "sequence-sharded x%d") % world,
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
                        "linears": "bf16 split product (hi.hi + hi.mid + mid.hi, f32 accumulate)"
-                                  if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)"},
+                                  if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",
+                       **({"mask_head": "lazy: evaluated for the surviving tracks' queries only (TF_LAZY_MASKS=1)"}
+                          if os.environ.get("TF_LAZY_MASKS") == "1" and not train else {})},
             "single_sequence_fps": None if single is None else round(single, 3),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

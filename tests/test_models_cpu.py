@@ -166,13 +166,13 @@ def test_tracker_variants_match_reference(name, oracle_op):
     compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.05)
 
 
-def run_mask_tracker(device="cpu", frames=3):
+def run_mask_tracker(device="cpu", frames=3, lazy_masks=False):
     """cfg-5 path: Tracker.step on the mask-head model; -> {track id: {frame: result dict}}."""
     model, post, args = um.build("cfg5_segm_tracking", factory.build_model, config.make_args,
                                  device=device)
     model.to(device)
     model.tracking()
-    tracker = Tracker(model, post, config.tracker_cfg(), False)
+    tracker = Tracker(model, post, config.tracker_cfg(), False, lazy_masks=lazy_masks)
     tracker.reset()
     with torch.no_grad():
         for blob in um.tracker_sequence()[:frames]:
@@ -280,6 +280,50 @@ def test_engine_train_step_reproduces_reference_loss_and_updates_weights(oracle_
     z = np.load(os.path.join(GOLDEN, "train_cfg3_small.npz"))
     assert abs(float(loss) - float(z["total"])) < 1e-3 * abs(float(z["total"]))
     assert not torch.equal(before, names['class_embed.0.weight'].detach())
+
+
+def test_lazy_mask_head_gives_the_same_tracks_and_masks(oracle_op):
+    """Tracker(lazy_masks=True) (opt-in): the mask head runs only for the queries whose masks the step keeps
+    (DETRSegmBase.mask_rows on the frame's MaskContext) -- same track ids, boxes and scores, and the same masks up to the
+    convolution library's batch-size dependent summation order (probabilities next to 0.5 may flip a pixel)."""
+    full = run_mask_tracker()
+    lazy = run_mask_tracker(lazy_masks=True)
+    assert sorted(full) == sorted(lazy)
+    union_full, union_lazy = {}, {}
+    for tid in full:
+        assert sorted(full[tid]) == sorted(lazy[tid])
+        for f in full[tid]:
+            a, b = full[tid][f], lazy[tid][f]
+            np.testing.assert_array_equal(a['bbox'], b['bbox'])
+            np.testing.assert_array_equal(a['score'], b['score'])
+            assert a['obj_ind'] == b['obj_ind'] and a['mask'].shape == b['mask'].shape
+            union_full[f] = union_full.get(f, 0) | a['mask']
+            union_lazy[f] = union_lazy.get(f, 0) | b['mask']
+    # the random-init model's tracks produce near-identical probability maps, so WHICH track wins a pixel (the argmax of
+    # tracker.py:521-532) flips with the last bits; that a pixel is covered (max probability > 0.5) does not
+    n_px = sum(u.size for u in union_full.values())
+    n_diff = sum(int((union_full[f] != union_lazy[f]).sum()) for f in union_full)
+    assert n_px > 0 and n_diff <= 2e-3 * n_px, (n_diff, n_px)
+
+
+def test_mask_rows_equal_the_rows_of_the_full_head(oracle_op):
+    """DETRSegmBase.mask_rows(ctx, hs[:, rows]) == forward()'s pred_masks[:, rows]."""
+    model, post, args = um.build("cfg5_segm_tracking", factory.build_model, config.make_args)
+    model.tracking()
+    img, prev, target = um.model_inputs("cfg5_segm_tracking", args.hidden_dim)
+    with torch.no_grad():
+        out, *_ = model(img, target, None)
+        model.lazy_masks = True
+        try:
+            lazy_out, *_ = model(img, target, None)
+        finally:
+            model.lazy_masks = False
+        assert 'pred_masks' not in lazy_out and 'mask_context' in lazy_out
+        assert torch.equal(lazy_out['pred_logits'], out['pred_logits'])
+        rows = torch.tensor([0, 3, 7, out['pred_masks'].shape[1] - 1])
+        got = model.mask_rows(lazy_out['mask_context'], lazy_out['hs_embed'][:, rows])
+    scale = float(out['pred_masks'].abs().max())
+    assert torch.allclose(got, out['pred_masks'][:, rows], atol=1e-5 * max(1.0, scale))
 
 
 def test_mask_postprocess_of_selected_queries_equals_rows_of_the_full_result():

@@ -61,6 +61,28 @@ def test_tracker_with_mask_head_matches_cpu_path(dev, monkeypatch):
             assert a['mask'].shape == b['mask'].shape and a['mask'].dtype == b['mask'].dtype
 
 
+@pytest.mark.skipif(__import__("os").environ.get("TF_TEST_OPTIN") != "1", reason="opt-in paths: set TF_TEST_OPTIN=1")
+def test_optin_lazy_mask_head_gives_the_same_tracks(dev):
+    """Opt-in lazy mask head (Tracker(lazy_masks=True)): the head runs for the surviving tracks' queries only; same track
+    ids, boxes and scores as the full head, and the same covered pixels up to the random-weight model's ties."""
+    import numpy as np
+    full = shared.run_mask_tracker(device=dev)
+    lazy = shared.run_mask_tracker(device=dev, lazy_masks=True)
+    assert sorted(full) == sorted(lazy)
+    cover_full, cover_lazy = {}, {}
+    for tid in full:
+        assert sorted(full[tid]) == sorted(lazy[tid])
+        for f in full[tid]:
+            a, b = full[tid][f], lazy[tid][f]
+            np.testing.assert_array_equal(a['bbox'], b['bbox'])
+            np.testing.assert_array_equal(a['score'], b['score'])
+            cover_full[f] = cover_full.get(f, 0) | a['mask']
+            cover_lazy[f] = cover_lazy.get(f, 0) | b['mask']
+    n_px = sum(u.size for u in cover_full.values())
+    n_diff = sum(int((cover_full[f] != cover_lazy[f]).sum()) for f in cover_full)
+    assert n_px > 0 and n_diff <= 2e-3 * n_px, (n_diff, n_px)
+
+
 def test_tracker_step_does_one_device_to_host_sync_per_frame(dev):
     """The association logic runs on one packed host copy per frame (tracker)."""
     from trackformer_amd import config, factory

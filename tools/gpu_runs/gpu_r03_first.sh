@@ -53,6 +53,9 @@ TF_BOX_REFINE_FUSED=1 TF_MHA_BATCH=1 TF_BIAS_ACT_BATCH=1 timeout 240 python benc
 TF_ALL_OPTIN=1 TF_LINEAR_BUFSTORE=2 TF_LINEAR_DEEP=1 TF_MHA_BATCH=1 TF_MSDA_PQUAD="pipe=1" timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_all_optin.json 2> $O/bench_cfg2_all_optin.err
 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
 TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_direct9.json 2> $O/bench_cfg4_direct9.err
+timeout 300 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5_default.json 2> $O/bench_cfg5_default.err
+TF_LAZY_MASKS=1 timeout 300 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5_lazy_masks.json 2> $O/bench_cfg5_lazy_masks.err
+cat $O/bench_cfg5_default.json $O/bench_cfg5_lazy_masks.json | cut -c1-260
 cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
 
 # 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)

@@ -34,6 +34,17 @@ from .detr_tracking import DETRTrackingBase
 from .nested import NestedTensor
 
 
+class MaskContext:
+    """What the mask head needs besides the queries (all of it per image, none of it per query): the projected image
+    features, their padding mask, the FPN inputs and the encoder memory.  Returned under out["mask_context"] in place of
+    out["pred_masks"] when the detector runs with `lazy_masks` (DETRSegmBase.mask_rows evaluates the head later, for
+    the queries somebody actually wants)."""
+    __slots__ = ("src", "mask", "fpns", "memory")
+
+    def __init__(self, src, mask, fpns, memory):
+        self.src, self.mask, self.fpns, self.memory = src, mask, fpns, memory
+
+
 class DETRSegmBase(nn.Module):
     """Mix-in: adds `bbox_attention` + `mask_head` to a detector and `pred_masks` [B,Q,H/4,W/4]
     (deformable: stride of backbone layer1) to its outputs."""
@@ -63,11 +74,27 @@ class DETRSegmBase(nn.Module):
             src = self.input_proj(src)
             fpns = [features[2].tensors, features[1].tensors, features[0].tensors]
 
+        if self.lazy_masks and not self.training and not torch.is_grad_enabled():
+            # OPT-IN (Tracker(lazy_masks=True) / TF_LAZY_MASKS=1): a query's mask depends on that query alone (attention map
+            # and GroupNorm are per (image, query) sample), and the tracker only ever reads the masks of its surviving
+            # tracks -- the head (3.3 TFLOP for 400 queries at 800 x 1333, 41 of cfg 5's 47 ms) is evaluated for those rows
+            # only, by whoever holds the context.
+            out["mask_context"] = MaskContext(src, mask, fpns, memory)
+            return out, targets, features, memory, hs
         bbox_mask = self.bbox_attention(hs[-1], memory, mask=mask)     # [B, Q, heads, h, w]
         seg_masks = self.mask_head(src, bbox_mask, fpns)               # [B*Q, 1, H, W]
         out["pred_masks"] = seg_masks.view(src.shape[0], hs.shape[2], seg_masks.shape[-2],
                                            seg_masks.shape[-1])
         return out, targets, features, memory, hs
+
+    lazy_masks = False
+
+    def mask_rows(self, ctx: "MaskContext", hs_rows: Tensor) -> Tensor:
+        """pred_masks of the queries whose last-layer decoder outputs are hs_rows [B, n, C] -> [B, n, H, W]: the same
+        arithmetic as forward() on those rows (bbox_attention and mask_head treat every query independently)."""
+        bbox_mask = self.bbox_attention(hs_rows, ctx.memory, mask=ctx.mask)
+        seg = self.mask_head(ctx.src, bbox_mask, ctx.fpns)
+        return seg.view(ctx.src.shape[0], hs_rows.shape[1], seg.shape[-2], seg.shape[-1])
 
 
 class DETRSegm(DETRSegmBase, DETR):

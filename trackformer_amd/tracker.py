@@ -12,6 +12,7 @@ bookkeeping decision is then taken on that host copy in the reference's order, a
 scores are kept as CPU tensors.  Only the per-query output embeddings stay on the GPU (they are fed
 back as track queries and never inspected on the host, except by the optional embedding re-ID).
 """
+import os
 from collections import deque
 
 import numpy as np
@@ -26,9 +27,17 @@ class Tracker:
     """Tracks objects through a sequence by re-feeding their output embeddings as track queries."""
 
     def __init__(self, obj_detector, obj_detector_post, tracker_cfg, generate_attention_maps,
-                 logger=None, verbose=False):
+                 logger=None, verbose=False, lazy_masks=None):
         self.obj_detector = obj_detector
         self.obj_detector_post = obj_detector_post
+        # OPT-IN (lazy_masks=True / TF_LAZY_MASKS=1): with a mask head, run it only for the queries whose masks the step
+        # ends up keeping (DETRSegmBase.mask_rows) instead of for all of them inside the detector forward
+        if lazy_masks is None:
+            lazy_masks = os.environ.get("TF_LAZY_MASKS", "0") == "1"
+        module = getattr(obj_detector, "model", obj_detector)   # GraphedDetector wraps the nn.Module
+        self._lazy_masks = bool(lazy_masks) and "segm" in obj_detector_post and hasattr(module, "mask_rows")
+        if self._lazy_masks:
+            module.lazy_masks = True   # before the first forward: a captured HIP graph then leaves the head out
         self.detection_obj_score_thresh = tracker_cfg['detection_obj_score_thresh']
         self.track_obj_score_thresh = tracker_cfg['track_obj_score_thresh']
         self.detection_nms_thresh = tracker_cfg['detection_nms_thresh']
@@ -420,7 +429,20 @@ class Tracker:
         """Turn the _MaskRef placeholders of this frame into mask probabilities at the original image size:
         PostProcessSegm (detr_segmentation.py:297-334 of the reference) on exactly the referenced queries."""
         refs = sorted({t.mask.row for t in self.tracks if isinstance(t.mask, _MaskRef)})
-        if refs:
+        if refs and 'pred_masks' not in outputs:
+            # lazy mask head: evaluate it for the referenced queries now (the context aliases this frame's buffers)
+            module = getattr(self.obj_detector, "model", self.obj_detector)
+            hs = outputs['hs_embed']
+            idx = torch.tensor(refs, dtype=torch.long, device=hs.device)
+            with torch.no_grad():
+                rows = module.mask_rows(outputs['mask_context'], hs.index_select(1, idx))
+            seg = self.obj_detector_post['segm']([{}], {'pred_masks': rows}, orig_size, size,
+                                                 return_probs=True)[0]['masks'].squeeze(dim=1)
+            by_row = {row: seg[k] for k, row in enumerate(refs)}
+            for t in self.tracks:
+                if isinstance(t.mask, _MaskRef):
+                    t.mask = by_row[t.mask.row]
+        elif refs:
             n = outputs['pred_masks'].shape[1]
             keep = torch.zeros(n, dtype=torch.bool)
             keep[refs] = True
