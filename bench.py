@@ -566,6 +566,7 @@ def main():
         _backbone.set_conv3x3_split(True)
         fused.set_input_proj_fused(True)
         fused.set_box_refine_fused(True)
+        fused.set_ffn_fused(True)
 
     if args.roofline_only:
         if rank == 0:
@@ -626,6 +627,7 @@ def main():
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
                        "linears": "bf16 split product (hi.hi + hi.mid + mid.hi, f32 accumulate)"
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",
+                       **({"ffn": "one launch per feed-forward block (tf_ffn_fused_f32)"} if fused.ffn_fused_enabled() and not train else {}),
                        **({"mask_head": "lazy: evaluated for the surviving tracks' queries only (TF_LAZY_MASKS=1)"}
                           if os.environ.get("TF_LAZY_MASKS") == "1" and not train else {})},
             "single_sequence_fps": None if single is None else round(single, 3),

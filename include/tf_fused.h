@@ -14,6 +14,7 @@
  *   tf_linear_split_f32    nn.Linear (+ ReLU) of the encoder / decoder (ms_deform_attn.py:64-88,
  *                          deformable_transformer.py:282-297) as a bf16 split product on the matrix cores
  *   tf_linear_packed_f32   the same product with the weight packed once in fragment order (+ tf_linear_pack_weight_f32)
+ *   tf_ffn_fused_f32       linear1 -> ReLU -> linear2 -> + residual -> LayerNorm of a transformer layer in one launch
  *   tf_mha_core_f32        softmax(q k^T * scale) v of the decoder's query self-attention
  *                          (deformable_transformer.py:364-383, nn.MultiheadAttention): one launch, fp32
  *
@@ -108,6 +109,25 @@ int64_t tf_linear_packed_bytes(int K, int N);
 int tf_linear_pack_weight_f32(const float *w, void *packed, int K, int N, void *stream);
 int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias, float *y, int64_t M, int K, int N,
                          int relu, void *stream);
+
+/*
+ * The feed-forward block of a transformer layer in one launch (trackformer_amd/csrc/ffn_fused.hip):
+ *
+ *     y[M, d_model] = [LayerNorm]( residual + relu(x . w1^T + b1) . w2^T + b2 )
+ *
+ * (reference: models/deformable_transformer.py:282-297 forward_ffn + norm2 of the encoder layer, :371-379 of the decoder
+ * layer; inference: the dropouts are identities).  The d_ffn-wide intermediate stays on the CU.  Same three-term bf16 split
+ * product as tf_linear_packed_f32 for both GEMMs: without the LayerNorm the result is bit-identical to
+ * tf_linear_packed_f32(relu) -> tf_linear_packed_f32 -> + residual.
+ *   w1_packed, w2_packed   tf_linear_pack_weight_f32 of linear1.weight [d_ffn, d_model] (K = d_model, N = d_ffn) and of
+ *                          linear2.weight [d_model, d_ffn] (K = d_ffn, N = d_model)
+ *   b1 [d_ffn], b2 [d_model], residual [M, d_model]: each may be NULL;  ln_weight / ln_bias [d_model]: both or neither
+ *   (neither: no LayerNorm);  y must not alias x or residual.
+ * d_model == 256, d_ffn a multiple of 128, every pointer 16-byte aligned; anything else: TF_MSDA_ERR_BAD_DIMS.
+ */
+int tf_ffn_fused_f32(const float *x, const void *w1_packed, const float *b1, const void *w2_packed, const float *b2,
+                     const float *residual, const float *ln_weight, const float *ln_bias, float ln_eps, float *y, int64_t M,
+                     int d_model, int d_ffn, void *stream);
 
 /*
  * out[n, l, h, :] = sum_j softmax_j(scale * q[n, l, h, :] . k[n, j, h, :]) v[n, j, h, :]      (fp32)

@@ -51,6 +51,8 @@ def lib():
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_groupnorm_nhwc_f32.restype = ci
     L.tf_groupnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
+    L.tf_ffn_fused_f32.restype = ci
+    L.tf_ffn_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_linear_split_f32.restype = ci
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci
@@ -193,6 +195,50 @@ def linear_packed(x, w, bias=None, relu=False):
     rc = lib().tf_linear_packed_f32(_p(x), pk.ctypes.data, _p(b), _p(y), M, K, N, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_linear_packed_f32: status %d" % rc)
+    return y
+
+
+def _packed(w):
+    w = _c(w, np.float32)
+    N, K = w.shape
+    nbytes = lib().tf_linear_packed_bytes(K, N)
+    if nbytes < 0:
+        raise RuntimeError("tf_linear_packed_bytes(%d, %d) < 0" % (K, N))
+    buf = np.zeros(nbytes + 16, np.uint8)
+    off = (-buf.ctypes.data) % 16
+    pk = buf[off:off + nbytes]
+    rc = lib().tf_linear_pack_weight_f32(_p(w), pk.ctypes.data, K, N, None)
+    if rc != 0:
+        raise RuntimeError("tf_linear_pack_weight_f32: status %d" % rc)
+    return pk
+
+
+def _aligned(a):
+    """A 16-byte aligned contiguous fp32 copy (numpy only guarantees that for larger arrays)."""
+    if a is None:
+        return None
+    a = _c(a, np.float32)
+    buf = np.zeros(a.size * 4 + 16, np.uint8)
+    off = (-buf.ctypes.data) % 16
+    out = buf[off:off + a.size * 4].view(np.float32).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+def ffn_fused(x, w1, b1, w2, b2, residual=None, ln=None, eps=1e-5, guard_rows=0):
+    """tf_ffn_fused_f32: x [M, 256], w1 [F, 256], w2 [256, F]; ln = (weight, bias) or None.  guard_rows extra rows of NaN
+    behind y are returned too (nothing may be written there)."""
+    x = _aligned(x)
+    M, D = x.shape
+    F = w1.shape[0]
+    p1, p2 = _packed(w1), _packed(w2)
+    b1, b2, r = _aligned(b1), _aligned(b2), _aligned(residual)
+    g, be = (_aligned(ln[0]), _aligned(ln[1])) if ln is not None else (None, None)
+    y = _aligned(np.full((M + guard_rows, D), np.nan, np.float32))
+    rc = lib().tf_ffn_fused_f32(_p(x), p1.ctypes.data, _p(b1), p2.ctypes.data, _p(b2), _p(r), _p(g), _p(be),
+                                ctypes.c_float(eps), _p(y), M, D, F, None)
+    if rc != 0:
+        raise RuntimeError("tf_ffn_fused_f32: status %d" % rc)
     return y
 
 

@@ -485,7 +485,7 @@ def test_opt_in_kernels_do_not_depend_on_the_scheduling_order():
     import subprocess
     import sys
     env = dict(os.environ, HIPEMU_SHUFFLE="3")
-    sel = "direct9 or sorted2 or pipelined or deep_prefetch or buffer_store or residual_epilogue"
+    sel = "direct9 or sorted2 or pipelined or deep_prefetch or buffer_store or residual_epilogue or fused_ffn"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -555,3 +555,70 @@ def test_packed_linear_transposed_accumulators_wide_stores(M, K, N, bias):
     ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + (b if bias else 0), 0)
     assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
     np.testing.assert_allclose(got, base, atol=1e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ one-launch feed-forward block (opt-in, ffn_fused.hip)
+def _ffn_case(M, F, seed):
+    rng = np.random.default_rng(seed)
+    D = 256
+    x = rng.standard_normal((M, D), dtype=np.float32)
+    w1 = (rng.standard_normal((F, D), dtype=np.float32) / 16).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(F, dtype=np.float32)).astype(np.float32)
+    w2 = (rng.standard_normal((D, F), dtype=np.float32) / np.sqrt(F)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(D, dtype=np.float32)).astype(np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D, dtype=np.float32)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(D, dtype=np.float32)).astype(np.float32)
+    return x, w1, b1, w2, b2, g, be
+
+
+@pytest.mark.parametrize("M,F,ti", [(200, 1024, 3), (97, 1024, 3), (96, 256, 3), (130, 1024, 2), (33, 128, 1), (1, 1024, 3)])
+def test_fused_ffn_equals_the_two_packed_linears_bit_for_bit(M, F, ti):
+    """tf_ffn_fused_f32 without LayerNorm: linear1 -> ReLU -> linear2 -> + residual with the hidden activation kept in LDS
+    gives exactly what tf_linear_packed_f32 (relu) -> tf_linear_packed_f32 -> + residual gives (same split, same order of
+    the matrix-core sums); rows behind M (the last block's tail) are never written."""
+    x, w1, b1, w2, b2, _, _ = _ffn_case(M, F, M + F)
+    ref = emu_lib.linear_packed(emu_lib.linear_packed(x, w1, b1, relu=True), w2, b2) + x
+    prev = emu_lib.set_options(ffn_ti=ti)
+    try:
+        y = emu_lib.ffn_fused(x, w1, b1, w2, b2, residual=x, guard_rows=3)
+    finally:
+        emu_lib.set_options(**prev)
+    assert np.array_equal(y[:M], ref)
+    assert np.isnan(y[M:]).all()
+    f64 = np.maximum(x.astype(np.float64) @ w1.T + b1, 0) @ w2.T.astype(np.float64) + b2 + x
+    assert np.abs(ref - f64).max() < 1e-4 * max(1.0, np.abs(f64).max())
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+
+
+def test_fused_ffn_without_biases_and_residual():
+    x, w1, _, w2, _, _, _ = _ffn_case(70, 512, 5)
+    ref = emu_lib.linear_packed(emu_lib.linear_packed(x, w1, None, relu=True), w2, None)
+    assert np.array_equal(emu_lib.ffn_fused(x, w1, None, w2, None), ref)
+
+
+@pytest.mark.parametrize("M,ti", [(200, 3), (65, 2), (40, 1)])
+def test_fused_ffn_layernorm_epilogue(M, ti):
+    """The LayerNorm of the block (norm2 / norm3) in the epilogue: two-pass statistics over a row that is spread over two
+    half-waves and four waves; against float64 and against tf_add_layernorm_f32 on the un-normalised result."""
+    x, w1, b1, w2, b2, g, be = _ffn_case(M, 1024, 7 * M)
+    prev = emu_lib.set_options(ffn_ti=ti)
+    try:
+        pre = emu_lib.ffn_fused(x, w1, b1, w2, b2, residual=x)
+        y = emu_lib.ffn_fused(x, w1, b1, w2, b2, residual=x, ln=(g, be), eps=1e-5, guard_rows=2)
+    finally:
+        emu_lib.set_options(**prev)
+    assert np.isnan(y[M:]).all()
+    p64 = pre.astype(np.float64)
+    ln64 = (p64 - p64.mean(1, keepdims=True)) / np.sqrt(p64.var(1, keepdims=True) + 1e-5) * g + be
+    assert np.abs(y[:M] - ln64).max() < 5e-6 * max(1.0, np.abs(ln64).max())
+    sep = emu_lib.add_layernorm(pre, None, g, be, 1e-5)
+    assert np.abs(y[:M] - sep).max() < 5e-6
+
+
+def test_fused_ffn_rejects_what_it_does_not_cover():
+    x, w1, b1, w2, b2, _, _ = _ffn_case(10, 128, 1)
+    with pytest.raises(RuntimeError):   # d_model != 256
+        emu_lib.ffn_fused(x[:, :128].copy(), w1[:, :128].copy(), b1, w2[:128].copy(), b2[:128].copy())
+    with pytest.raises(RuntimeError):   # d_ffn not a multiple of 128
+        emu_lib.ffn_fused(x, w1[:64].copy(), b1[:64].copy(), w2[:, :64].copy(), b2)

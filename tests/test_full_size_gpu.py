@@ -281,3 +281,22 @@ def test_optin_fused_box_refine_full_size(dev, models, case):
         _compare(case, model, out, res, feats, memory)
     finally:
         fused.set_box_refine_fused(prev)
+
+
+@optin
+@pytest.mark.parametrize("case", [c for c in um.FULL_CASES if "cfg2" in c])
+def test_optin_fused_ffn_route_full_size(dev, models, case):
+    """The encoder's feed-forward blocks in one launch each (fused.set_ffn_fused; tf_ffn_fused_f32, hidden 256): BASELINE-size
+    model against the reference goldens and, separately, the tracker's ids."""
+    from trackformer_amd import fused
+    prev = fused.set_ffn_fused(True)
+    try:
+        model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
+        dbox, dlogit = _compare(case, model, out, res, feats, memory)
+        print("%s / fused ffn: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+        tracker, rows, active = _run_tracker(models, dev, "graph_split_linear")
+    finally:
+        fused.set_ffn_fused(prev)
+    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
+    assert int(z["num_tracks"]) == tracker.track_num and z["active_per_frame"].tolist() == active
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])

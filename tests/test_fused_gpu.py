@@ -174,3 +174,37 @@ def test_optin_bias_act_batched_bit_identical(shape, res, relu):
     finally:
         lib.tf_msda_set_option(b"bias_act_batch", prev)
     assert torch.equal(got, base)
+
+
+@optin
+@pytest.mark.parametrize("rows,ti", [(22223, 3), (4100, 2), (97, 1)])
+def test_optin_fused_ffn_block(rows, ti, monkeypatch):
+    """tf_ffn_fused_f32 (fused.ffn): linear1 -> ReLU -> linear2 -> + residual in one launch equals the separate packed
+    linears bit for bit (same split, same order of the matrix-core sums); with the LayerNorm in the epilogue it equals
+    torch's LayerNorm of that up to rounding."""
+    from trackformer_amd import _cabi, fused
+    lib = _cabi.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(rows)
+    l1, l2, norm = torch.nn.Linear(256, 1024).to(dev), torch.nn.Linear(1024, 256).to(dev), torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.add_(0.1 * torch.randn(256, device=dev))
+        norm.bias.add_(0.1 * torch.randn(256, device=dev))
+    x = torch.randn(1, rows, 256, device=dev)
+    monkeypatch.setattr(fused, "_FFN_FUSED_MIN_ROWS", 1)
+    monkeypatch.setattr(fused, "_PACKED_MIN_ROWS", 0)   # the reference below through tf_linear_packed_f32 at every size
+    prev_on, prev_ti = fused.set_ffn_fused(True), lib.tf_msda_set_option(b"ffn_ti", ti)
+    try:
+        with torch.no_grad():
+            h = fused.linear(x, l1.weight, l1.bias, relu=True)
+            ref = fused.linear(h, l2.weight, l2.bias) + x
+            got = fused.ffn(x, l1, l2, None, residual=x)
+            got_ln = fused.ffn(x, l1, l2, norm, residual=x)
+            exact = l2(torch.relu(l1(x))) + x   # hipBLASLt fp32
+    finally:
+        fused.set_ffn_fused(prev_on)
+        lib.tf_msda_set_option(b"ffn_ti", prev_ti)
+    assert got is not None and got_ln is not None
+    assert torch.equal(got, ref)
+    assert torch.allclose(got, exact, atol=2e-4, rtol=1e-4)
+    assert torch.allclose(got_ln, norm(ref), atol=1e-5, rtol=1e-5)

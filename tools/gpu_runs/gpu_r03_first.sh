@@ -10,7 +10,7 @@ export LD_LIBRARY_PATH=$GRAFT_REPO_ROOT/trackformer_amd/lib:$LD_LIBRARY_PATH
 O=gpurun_out/r03a
 
 # 1. parity of the opt-in kernels / routes (direct9, bwd_sorted2, conv1x1 split) on the hardware
-TF_TEST_OPTIN=1 timeout 600 python -m pytest tests/test_msda_gpu.py tests/test_full_size_gpu.py tests/test_linear_split_gpu.py tests/test_fused_gpu.py -m gpu -q -s -k optin \
+TF_TEST_OPTIN=1 timeout 900 python -m pytest tests/test_msda_gpu.py tests/test_full_size_gpu.py tests/test_linear_split_gpu.py tests/test_fused_gpu.py tests/test_models_gpu.py -m gpu -q -s -k optin \
     > $O/pytest_optin.txt 2>&1
 tail -3 $O/pytest_optin.txt
 
@@ -42,6 +42,15 @@ done
 } > $O/linear_bufstore.txt 2>&1
 cat $O/linear_bufstore.txt
 
+# 2c. the feed-forward block in one launch (tf_ffn_fused_f32) against linear1 + ReLU, linear2, residual + LayerNorm
+{
+for args in "22223 1024 3" "22223 1024 2" "22223 1024 1" "5600 1024 3"; do
+    echo "## ffn_bench $args"
+    timeout 120 tools/bin/ffn_bench $args
+done
+} > $O/ffn_fused.txt 2>&1
+cat $O/ffn_fused.txt
+
 # 3. frames/s: default vs the backbone's 1x1 convolutions through the split GEMM; cfg 4 with direct9
 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_default.json 2> $O/bench_cfg2_default.err
 TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore.json 2> $O/bench_cfg2_bufstore.err
@@ -49,6 +58,7 @@ timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split > $O
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --input-proj-fused > $O/bench_cfg2_input_proj.json 2> $O/bench_cfg2_input_proj.err
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split --conv3x3-split > $O/bench_cfg2_conv1x1_3x3.json 2> $O/bench_cfg2_conv1x1_3x3.err
 TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore_deep.json 2> $O/bench_cfg2_bufstore_deep.err
+TF_FFN_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_ffn_fused.json 2> $O/bench_cfg2_ffn_fused.err
 TF_BOX_REFINE_FUSED=1 TF_MHA_BATCH=1 TF_BIAS_ACT_BATCH=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_box_refine.json 2> $O/bench_cfg2_box_refine.err
 TF_ALL_OPTIN=1 TF_LINEAR_BUFSTORE=2 TF_LINEAR_DEEP=1 TF_MHA_BATCH=1 TF_MSDA_PQUAD="pipe=1" timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_all_optin.json 2> $O/bench_cfg2_all_optin.err
 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
@@ -56,7 +66,7 @@ TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --
 timeout 300 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5_default.json 2> $O/bench_cfg5_default.err
 TF_LAZY_MASKS=1 timeout 300 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5_lazy_masks.json 2> $O/bench_cfg5_lazy_masks.err
 cat $O/bench_cfg5_default.json $O/bench_cfg5_lazy_masks.json | cut -c1-260
-cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
+cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_ffn_fused.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
 
 # 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)
 {

@@ -25,7 +25,7 @@ GFX_ARCH = "gfx950"
 
 # (output, [sources], extra flags)
 _TARGETS = [
-    ("libtf_msda.so", ["msda_hip.hip", "msda_pquad.hip", "fused_ops.hip", "linear_split.hip", "linear_stream.hip", "mha_core.hip"], []),
+    ("libtf_msda.so", ["msda_hip.hip", "msda_pquad.hip", "fused_ops.hip", "linear_split.hip", "linear_stream.hip", "mha_core.hip", "ffn_fused.hip"], []),
 ]
 
 
@@ -99,7 +99,7 @@ def _build_tools(force, verbose):
     out_dir = os.path.join(REPO_DIR, "tools", "bin")
     lib = os.path.join(LIB_DIR, "libtf_msda.so")
     built = []
-    for name in ("msda_bench", "linear_bench"):
+    for name in ("msda_bench", "linear_bench", "ffn_bench"):
         src = os.path.join(REPO_DIR, "tools", name + ".cpp")
         if not os.path.exists(src):
             continue

@@ -1,0 +1,435 @@
+// trackformer_amd/csrc/ffn_fused.hip
+//
+// tf_ffn_fused_f32 (include/tf_fused.h): the feed-forward block of a transformer layer in ONE kernel,
+//
+//     y = [LayerNorm]( residual + linear2( relu( linear1(x) ) ) )
+//
+// (reference: models/deformable_transformer.py:282-297 DeformableTransformerEncoderLayer.forward_ffn -- `src2 =
+// linear2(dropout2(activation(linear1(src)))); src = src + dropout3(src2); src = norm2(src)`, and :371-379 for the decoder
+// layer).  OPT-IN (TF_FFN_FUSED=1 / fused.set_ffn_fused): written against the emulator, not yet run on hardware.
+//
+// Why: the two FFN GEMMs of an encoder layer (22 223 x 256 -> 1024 -> 256) take 59 + 51 us as separate launches, and the
+// phase trace of the first one (profiles/r02_split_gemm_astat_trace.txt) shows its matrix work done long before its
+// stores: 91 MB of fp32 intermediate go out at ~1.5 TB/s and come back in for linear2.  Here the 1024-wide intermediate
+// never leaves the CU.
+//
+//   * Same arithmetic as the separate kernels (linear_split.hip / linear_stream.hip): every product is the three-term
+//     bf16 split x_hi.w_hi + x_hi.w_mid + x_mid.w_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, per accumulator
+//     in the order mid.hi, hi.mid, hi.hi, k ascending; the intermediate is rounded to fp32 (bias, ReLU) and split again,
+//     exactly what linear2 does with linear1's stored output.  Without the LayerNorm the result is bit-identical to
+//     tf_linear_packed_f32 (relu) -> tf_linear_packed_f32 -> + residual.
+//   * A block owns 32 TI rows (TI = 3: 96 rows, 232 blocks for 22 223 rows: one round on 256 CUs).  Its activation tile
+//     is staged ONCE in LDS as bf16 hi / mid (96 x 264 x 2 x 2 B = 101 KB, all global loads of the tile in flight
+//     together).  The hidden dimension is processed in chunks of 128: GEMM 1 computes the chunk (each of the 4 waves
+//     32 hidden columns x 96 rows), bias + ReLU + split go to a second LDS tile (96 x 136 x 2 x 2 B = 52 KB), GEMM 2
+//     accumulates the chunk's contribution to the 96 x 256 output (each wave 64 output columns).  Two barriers per chunk.
+//   * Both weights are in the packed fragment form of tf_linear_pack_weight_f32 and are streamed L2 -> registers through
+//     one ring of eight 4 KB units per wave, six units (24 KB per wave) ahead of their use, ACROSS the GEMM 1 / GEMM 2 /
+//     chunk boundaries (the one-slice-ahead version of linear_stream.hip left the waves waiting on L2 for 2/3 of their
+//     time with one block per CU: profiles/r02_split_gemm_packed_pmc.txt).  A block streams both weights once (2 MB):
+//     232 x 2 MB = 464 MB from L2, what the two separate kernels read together.
+//   * The weight fragment is the A operand and the activation fragment B, so the accumulators hold the TRANSPOSED tile
+//     (see linear_stream.hip, BUFST = 2): a lane owns 4 consecutive columns of one row -- the intermediate goes to LDS
+//     with 8-byte writes, the output to HBM with 16-byte buffer stores (rows >= M fall outside the resource), the
+//     LayerNorm's row sums are 32 adds and one cross-half shuffle per lane, plus an LDS exchange between the 4 waves.
+//
+// Per block and wave: 8 chunks x (16 + 8) k-steps x 9 / 18 MFMAs = 2304 MFMAs of 32 cycles = 30.7 us at 2.4 GHz: the
+// kernel's floor is the matrix pipe (the three-term product costs 3x the bf16 flops); LDS reads (144 b128 per chunk and
+// wave) are half of that, the weight stream 28 B/clk/CU of the 64 the vector memory path has.
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+#include <stdlib.h>
+
+#include <atomic>
+#include <type_traits>
+
+#include "msda_common.h"
+#include "tf_fused.h"
+#include "tf_msda.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+constexpr int kThreads = 256;
+constexpr int kD = 256;               // d_model: K of GEMM 1, N of GEMM 2
+constexpr int kXStride = kD + 8;      // bf16 per LDS row of the activation tile: 528 B (conflict-free fragment reads)
+constexpr int kChunk = 128;           // hidden columns per chunk (4 waves x one 32-wide MFMA tile)
+constexpr int kHStride = kChunk + 8;  // 272 B
+constexpr int kKQ1 = kD / 16;         // k-steps of GEMM 1
+constexpr int kRing = 8, kAhead = 6;  // weight units (4 KB per wave each) in the ring / prefetch distance
+
+constexpr size_t ffn_lds_bytes(int ti) { return (size_t)(32 * ti) * (kXStride + kHStride) * 2 * 2; }
+
+template <int TI, bool LN>
+__global__ void __launch_bounds__(kThreads, 1)
+ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, const float *__restrict__ b1,
+                 const u32x4 *__restrict__ W2p, const float *__restrict__ b2, const float *R,
+                 const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *Y, int M, int F)
+{
+    constexpr int BM = TI * 32;
+    constexpr int NV = BM * (kD / 4) / kThreads;   // float4 of X per thread: a wave covers one row (1 KB) per step
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
+    unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * kXStride;
+    unsigned short *const sHhi = sXmid + BM * kXStride, *const sHmid = sHhi + BM * kHStride;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+    const int nchunks = F / kChunk, KQ2 = F >> 4;
+
+    // ---- the weight stream.  Unit u of chunk c (16 units per chunk, 4 x 16 bytes per lane each):
+    //   u < 8   GEMM 1: k-steps 2u, 2u + 1 (hi, mid each) of hidden n-tile 4c + wave of W1   [contiguous 4 KB]
+    //   u >= 8  GEMM 2: k-step 8c + (u - 8) (hi, mid) of the wave's two output n-tiles 2 wave, 2 wave + 1 of W2
+    // packed layout (linear_stream.hip pack_weight_kernel): piece (n-tile t, k-step q, part p) at ((t KQ + q) 2 + p) 64 + lane
+    u32x4 ring[kRing][4];
+    auto load_unit = [&](int c, auto uc, u32x4 (&dst)[4]) {
+        constexpr int u = decltype(uc)::value;
+        if constexpr (u < 8) {
+            const u32x4 *base = W1p + ((size_t)(c * 4 + wave) * kKQ1 * 2 + u * 4) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = base[i * 64];
+        } else {
+            const int q = c * 8 + (u - 8);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) dst[j * 2 + p] = W2p[(((size_t)(2 * wave + j) * KQ2 + q) * 2 + p) * 64 + lane];
+        }
+    };
+    // the first units first (they have the longest way), then the whole activation tile
+    load_unit(0, std::integral_constant<int, 0>{}, ring[0]);
+    load_unit(0, std::integral_constant<int, 1>{}, ring[1]);
+    load_unit(0, std::integral_constant<int, 2>{}, ring[2]);
+    load_unit(0, std::integral_constant<int, 3>{}, ring[3]);
+    load_unit(0, std::integral_constant<int, 4>{}, ring[4]);
+    load_unit(0, std::integral_constant<int, 5>{}, ring[5]);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        f32x4 xr[NV];
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int grow = min(m0 + it * 4 + wave, M - 1);   // rows past M read the last row, never stored
+            xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * kD + lane * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // all NV loads in flight before the first conversion waits
+#pragma unroll
+        for (int it = 0; it < NV; ++it) {
+            const int row = it * 4 + wave;
+            bf16x4 hi, mid;   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hi[e] = (__bf16)xr[it][e];
+                mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
+            }
+            *reinterpret_cast<bf16x4 *>(&sXhi[row * kXStride + lane * 4]) = hi;
+            *reinterpret_cast<bf16x4 *>(&sXmid[row * kXStride + lane * 4]) = mid;
+        }
+    }
+    __syncthreads();
+
+    f32x16 accy[TI][2];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accy[i][j][e] = 0.f;
+
+    const int frow = (lane & 31), fk = (lane >> 5) * 8;   // fragment: lane -> (row of the tile, first of 8 consecutive k)
+    const int xoff = frow * kXStride + fk, hoff = frow * kHStride + fk;
+
+    // every bias / LayerNorm vector through a buffer resource (NULL: zero records -> zeros, no branch around the load)
+    const __amdgpu_buffer_rsrc_t b1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b1 ? b1 : X), 0, b1 ? (unsigned)F * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b2 ? b2 : X), 0, b2 ? (unsigned)kD * 4u : 0u, 0x00020000);
+    const unsigned bytes = (unsigned)((size_t)M * kD * 4);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : X), 0, R ? bytes : 0u, 0x00020000);
+    const int cbase = wave * 64 + 4 * (lane >> 5);
+    f32x4 v[TI][2][4];   // the residual rows, then the output values
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int cn = min(c + 1, nchunks - 1);   // after the last chunk: a harmless reload
+        // this chunk's hidden bias, 4 consecutive columns per register group (transposed tile, see below)
+        f32x4 b1v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            b1v[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   b1rs, (unsigned)(c * kChunk + wave * 32 + 8 * g + 4 * (lane >> 5)) * 4u, 0, 0));
+        if (c == nchunks - 1) {
+            // the residual rows: in flight during the last chunk.  Lane -> output row m0 + 32 i + (lane & 31); registers
+            // 4 g .. 4 g + 3 of tile j -> columns 64 wave + 32 j + 8 g + 4 (lane >> 5) + 0..3; rows >= M return zeros
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        v[i][j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                   rrs, (unsigned)((m0 + i * 32 + frow) * kD + cbase + 32 * j + 8 * g) * 4u, 0, 0));
+        }
+        f32x16 acch[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acch[i][e] = 0.f;
+
+        auto prefetch = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int ahead = u + kAhead;
+            if constexpr (ahead < 16) load_unit(c, std::integral_constant<int, ahead>{}, ring[ahead & (kRing - 1)]);
+            else load_unit(cn, std::integral_constant<int, ahead - 16>{}, ring[ahead & (kRing - 1)]);
+        };
+        // ---- GEMM 1: hidden[32 of this wave][BM rows] (transposed) = W1 tile . x^T.  One block per CU means one wave per
+        // SIMD: nobody else covers the LDS latency, so the fragments of k-step st + 1 are read before the MFMAs of k-step st
+        bf16x8 xf[2][TI][2];   // [k-step parity][row tile][hi | mid]
+        auto read_x = [&](auto stc) {
+            constexpr int st = decltype(stc)::value;
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                xf[st & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sXhi[i * 32 * kXStride + xoff + st * 16]);
+                xf[st & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sXmid[i * 32 * kXStride + xoff + st * 16]);
+            }
+        };
+        auto gemm1 = [&](auto stc) {
+            constexpr int st = decltype(stc)::value;   // k-step 0..15; weight unit st / 2
+            if constexpr ((st & 1) == 0) prefetch(std::integral_constant<int, st / 2>{});
+            if constexpr (st + 1 < kKQ1) read_x(std::integral_constant<int, st + 1>{});
+            __builtin_amdgcn_sched_barrier(0);   // loads and reads stay at the head of the step (see linear_stream.hip)
+            const u32x4 (&cur)[4] = ring[(st / 2) & (kRing - 1)];
+            const bf16x8 w_hi = __builtin_bit_cast(bf16x8, cur[(st & 1) * 2 + 0]), w_mid = __builtin_bit_cast(bf16x8, cur[(st & 1) * 2 + 1]);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, xf[st & 1][i][1], acch[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid, xf[st & 1][i][0], acch[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, xf[st & 1][i][0], acch[i], 0, 0, 0);
+        };
+        read_x(std::integral_constant<int, 0>{});
+        gemm1(std::integral_constant<int, 0>{});
+        gemm1(std::integral_constant<int, 1>{});
+        gemm1(std::integral_constant<int, 2>{});
+        gemm1(std::integral_constant<int, 3>{});
+        gemm1(std::integral_constant<int, 4>{});
+        gemm1(std::integral_constant<int, 5>{});
+        gemm1(std::integral_constant<int, 6>{});
+        gemm1(std::integral_constant<int, 7>{});
+        gemm1(std::integral_constant<int, 8>{});
+        gemm1(std::integral_constant<int, 9>{});
+        gemm1(std::integral_constant<int, 10>{});
+        gemm1(std::integral_constant<int, 11>{});
+        gemm1(std::integral_constant<int, 12>{});
+        gemm1(std::integral_constant<int, 13>{});
+        gemm1(std::integral_constant<int, 14>{});
+        gemm1(std::integral_constant<int, 15>{});
+
+        // ---- bias + ReLU + split -> the hidden tile in LDS.  C/D of the 32 x 32 MFMA with the weight as A: lane -> row
+        // (lane & 31) of x, registers 4 g .. 4 g + 3 -> hidden columns 8 g + 4 (lane >> 5) + 0..3 of the wave's 32
+        __syncthreads();   // every wave is past GEMM 2 of the previous chunk: the hidden tile is free
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 hi, mid;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acch[i][4 * g + e] + b1v[g][e];
+                    t = t > 0.f ? t : 0.f;
+                    hi[e] = (__bf16)t;
+                    mid[e] = (__bf16)(t - (float)hi[e]);
+                }
+                const int o = (i * 32 + frow) * kHStride + wave * 32 + 8 * g + 4 * (lane >> 5);
+                *reinterpret_cast<bf16x4 *>(&sHhi[o]) = hi;
+                *reinterpret_cast<bf16x4 *>(&sHmid[o]) = mid;
+            }
+        __syncthreads();
+
+        // ---- GEMM 2: y[64 columns of this wave][BM rows] (transposed) += W2 tiles . hidden^T, k = this chunk
+        bf16x8 hf[2][TI][2];
+        auto read_h = [&](auto vc) {
+            constexpr int kv = decltype(vc)::value;   // k-step of the chunk, 0..7
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                hf[kv & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sHhi[i * 32 * kHStride + hoff + kv * 16]);
+                hf[kv & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sHmid[i * 32 * kHStride + hoff + kv * 16]);
+            }
+        };
+        auto gemm2 = [&](auto vc) {
+            constexpr int kv = decltype(vc)::value;   // weight unit 8 + kv
+            prefetch(std::integral_constant<int, 8 + kv>{});
+            if constexpr (kv + 1 < 8) read_h(std::integral_constant<int, kv + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 (&cur)[4] = ring[(8 + kv) & (kRing - 1)];
+            bf16x8 w_hi[2], w_mid[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                w_hi[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 0]);
+                w_mid[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 1]);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], hf[kv & 1][i][1], accy[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid[j], hf[kv & 1][i][0], accy[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], hf[kv & 1][i][0], accy[i][j], 0, 0, 0);
+        };
+        read_h(std::integral_constant<int, 0>{});
+        gemm2(std::integral_constant<int, 0>{});
+        gemm2(std::integral_constant<int, 1>{});
+        gemm2(std::integral_constant<int, 2>{});
+        gemm2(std::integral_constant<int, 3>{});
+        gemm2(std::integral_constant<int, 4>{});
+        gemm2(std::integral_constant<int, 5>{});
+        gemm2(std::integral_constant<int, 6>{});
+        gemm2(std::integral_constant<int, 7>{});
+    }
+
+    // ---- epilogue: + bias + residual [-> LayerNorm] -> Y (rows >= M: stores are dropped by the buffer resource)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b2rs, (unsigned)(cbase + 32 * j + 8 * g) * 4u, 0, 0));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][j][g][e] = (accy[i][j][4 * g + e] + b[e]) + v[i][j][g][e];
+        }
+    if constexpr (LN) {
+        // two-pass statistics over the 256 columns of a row: 32 values in this lane, 32 in lane ^ 32, the rest in the
+        // other three waves (through LDS: the hidden tile is free after the barrier)
+        float *const sRed = reinterpret_cast<float *>(sHhi);   // [2 passes][4 waves][BM]
+        float s[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a += (v[i][j][g].x + v[i][j][g].y) + (v[i][j][g].z + v[i][j][g].w);
+            s[i] = a + __shfl_xor(a, 32);
+        }
+        __syncthreads();   // all waves are past their last GEMM 2 reads of the hidden tile
+        if (lane < 32)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) sRed[wave * BM + i * 32 + lane] = s[i];
+        __syncthreads();
+        float mean[TI], rstd[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int r = i * 32 + frow;
+            mean[i] = ((sRed[r] + sRed[BM + r]) + (sRed[2 * BM + r] + sRed[3 * BM + r])) * (1.f / kD);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 d = v[i][j][g] - mean[i];
+                    a += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+            s[i] = a + __shfl_xor(a, 32);
+        }
+        if (lane < 32)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) sRed[(4 + wave) * BM + i * 32 + lane] = s[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int r = 4 * BM + i * 32 + frow;
+            rstd[i] = rsqrtf(((sRed[r] + sRed[BM + r]) + (sRed[2 * BM + r] + sRed[3 * BM + r])) * (1.f / kD) + eps);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + cbase + 32 * j + 8 * g);
+                const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + cbase + 32 * j + 8 * g);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) v[i][j][g] = (v[i][j][g] - mean[i]) * rstd[i] * ga + be;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i][j][g]), yrs,
+                                                       (unsigned)((m0 + i * 32 + frow) * kD + cbase + 32 * j + 8 * g) * 4u, 0, 0);
+}
+
+template <int TI>
+int launch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2, const float *b2, const float *res,
+               const float *gamma, const float *beta, float eps, float *y, int M, int F, hipStream_t s)
+{
+    const bool ln = gamma != nullptr;
+    const size_t lds = ffn_lds_bytes(TI);
+    const void *fn = ln ? (const void *)&ffn_fused_kernel<TI, true> : (const void *)&ffn_fused_kernel<TI, false>;
+    static std::atomic<unsigned> raised[2];   // bit per device, per kernel
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 32 || !(raised[ln ? 1 : 0].load() & (1u << dev))) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+        if (dev < 32) raised[ln ? 1 : 0].fetch_or(1u << dev);
+    }
+    const int blocks = (M + 32 * TI - 1) / (32 * TI);
+    void *argv[] = {(void *)&x, (void *)&w1, (void *)&b1, (void *)&w2, (void *)&b2, (void *)&res,
+                    (void *)&gamma, (void *)&beta, (void *)&eps, (void *)&y, (void *)&M, (void *)&F};
+    return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(kThreads), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+std::atomic<int> g_ffn_ti{-1};   // -1: TF_FFN_TI or the default (3)
+int ffn_ti()
+{
+    int v = g_ffn_ti.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_FFN_TI");
+        v = e ? atoi(e) : 3;
+        if (v < 1 || v > 3) v = 3;
+        g_ffn_ti.store(v);
+    }
+    return v;
+}
+
+}  // namespace
+
+namespace tfm {
+int ffn_set_ti(int v)
+{
+    const int prev = ffn_ti();
+    g_ffn_ti.store(v >= 1 && v <= 3 ? v : 3);
+    return prev;
+}
+}  // namespace tfm
+
+extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const float *b1, const void *w2_packed, const float *b2,
+                                const float *residual, const float *ln_weight, const float *ln_bias, float ln_eps, float *y,
+                                int64_t M, int d_model, int d_ffn, void *stream)
+{
+    if (!x || !w1_packed || !w2_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
+    if ((ln_weight == nullptr) != (ln_bias == nullptr)) return TF_MSDA_ERR_NULL_POINTER;
+    if (M <= 0 || d_model != kD || d_ffn < kChunk || (d_ffn % kChunk) != 0 ||
+        (M + 128) * (int64_t)kD * 4 > 0xFFFFFFFFLL)   // 32-bit buffer offsets, incl. the rows of the last block past M
+        return TF_MSDA_ERR_BAD_DIMS;
+    uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1_packed) | reinterpret_cast<uintptr_t>(w2_packed) |
+                   reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2) |
+                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(ln_weight) | reinterpret_cast<uintptr_t>(ln_bias);
+    if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
+    const u32x4 *w1 = static_cast<const u32x4 *>(w1_packed), *w2 = static_cast<const u32x4 *>(w2_packed);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    switch (ffn_ti()) {
+    case 1: return launch_ffn<1>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
+    case 2: return launch_ffn<2>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
+    default: return launch_ffn<3>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
+    }
+}

@@ -306,6 +306,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
 
     def forward_ffn(self, src):
         inf = _inference(self)
+        if inf and fused.ffn_fused_enabled() and self.activation is F.relu:   # opt-in: the whole block in one launch
+            out = fused.ffn(src, self.linear1, self.linear2, self.norm2, residual=src)
+            if out is not None:
+                return out
         src2 = fused.module_linear(self.linear2, self.dropout2(_ffn_hidden(self.linear1, self.activation, src, inf)), inf)
         return fused.residual_norm(src, self.dropout3(src2), self.norm2, inf)
 
@@ -372,6 +376,10 @@ class DeformableTransformerDecoderLayer(nn.Module):
 
     def forward_ffn(self, tgt):
         inf = _inference(self)
+        if inf and fused.ffn_fused_enabled() and self.activation is F.relu:   # opt-in; only with many rows (fused.ffn)
+            out = fused.ffn(tgt, self.linear1, self.linear2, self.norm3, residual=tgt)
+            if out is not None:
+                return out
         tgt2 = fused.module_linear(self.linear2, self.dropout3(_ffn_hidden(self.linear1, self.activation, tgt, inf)), inf)
         return fused.residual_norm(tgt, self.dropout4(tgt2), self.norm3, inf)
 

@@ -217,6 +217,71 @@ def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
     return y.view(*x.shape[:-1], N)
 
 
+# OPT-IN (TF_FFN_FUSED=1 / set_ffn_fused(True)): linear1 -> ReLU -> linear2 -> + residual -> LayerNorm of a transformer
+# layer in ONE launch (tf_ffn_fused_f32, csrc/ffn_fused.hip): the d_ffn-wide intermediate (91 MB per encoder layer at
+# 800 x 1333) never leaves the CU.  Same split products as linear(); written against the emulator, to be timed in round 3.
+_ffn_fused = os.environ.get("TF_FFN_FUSED", "0") == "1"
+_FFN_FUSED_MIN_ROWS = int(os.environ.get("TF_FFN_FUSED_MIN_ROWS", "4096"))   # below: too few 96-row blocks to fill the CUs
+
+
+def ffn_fused_enabled():
+    return _ffn_fused
+
+
+def set_ffn_fused(on):
+    """Switch the one-launch feed-forward block on or off (process-wide); returns the previous setting."""
+    global _ffn_fused
+    prev, _ffn_fused = _ffn_fused, bool(on)
+    return prev
+
+
+def ffn(x, linear1, linear2, norm=None, residual=None):
+    """[norm](residual + linear2(relu(linear1(x)))) through tf_ffn_fused_f32 (reference: deformable_transformer.py:282-297
+    forward_ffn + norm2).  x [..., 256] fp32 on the GPU; linear1 / linear2: nn.Linear; norm: nn.LayerNorm or None;
+    residual: like x or None.  Returns None when the kernel does not apply (the caller keeps the separate kernels)."""
+    if not (_ffn_fused and _split_linear and x.is_cuda and x.dtype == torch.float32):
+        return None
+    w1, w2 = linear1.weight, linear2.weight
+    F_, D = w1.shape
+    if D != 256 or x.shape[-1] != D or tuple(w2.shape) != (D, F_) or F_ % 128 or x.numel() == 0:
+        return None
+    if not all(w.dtype == torch.float32 and w.is_contiguous() and w.device == x.device for w in (w1, w2)):
+        return None
+    x2 = x.reshape(-1, D)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if M < _FFN_FUSED_MIN_ROWS or (M + 128) * D * 4 > 0xFFFFFFFF:
+        return None
+    vecs = [linear1.bias, linear2.bias]
+    if norm is not None:
+        if not (norm.elementwise_affine and tuple(norm.normalized_shape) == (D,)):
+            return None
+        vecs += [norm.weight, norm.bias]
+    if not all(v is None or _param_ok(v, x) for v in vecs):
+        return None
+    if residual is not None:
+        if residual.dtype != torch.float32 or residual.device != x.device or residual.numel() != x2.numel():
+            return None
+        residual = residual.reshape(-1, D)
+        if not residual.is_contiguous():
+            residual = residual.contiguous()
+    if (x2.data_ptr() | (0 if residual is None else residual.data_ptr())) & 15:
+        return None
+    p1, p2 = _packed_weight(w1, None), _packed_weight(w2, None)
+    if p1 is None or p2 is None:
+        return None
+    ptr = lambda t: 0 if t is None else t.data_ptr()
+    with torch.cuda.device(x.device):
+        y = torch.empty((M, D), dtype=torch.float32, device=x.device)
+        rc = _cabi.lib().tf_ffn_fused_f32(x2.data_ptr(), p1.data_ptr(), ptr(linear1.bias), p2.data_ptr(), ptr(linear2.bias),
+                                          ptr(residual), 0 if norm is None else norm.weight.data_ptr(),
+                                          0 if norm is None else norm.bias.data_ptr(), 0.0 if norm is None else float(norm.eps),
+                                          y.data_ptr(), M, D, F_, _stream(x.device))
+    _cabi.check(rc, "tf_ffn_fused_f32")
+    return y.view(x.shape)
+
+
 def conv3x3(x, w_taps, bias, relu, stride):
     """3 x 3 convolution (padding 1) -- or, with a [Cout, Cin] weight, a strided 1 x 1 convolution without padding -- of a
     channels_last fp32 GPU activation through tf_conv3x3_split_f32 / tf_conv1x1_strided_split_f32.
