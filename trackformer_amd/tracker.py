@@ -433,9 +433,12 @@ class Tracker:
             # lazy mask head: evaluate it for the referenced queries now (the context aliases this frame's buffers)
             module = getattr(self.obj_detector, "model", self.obj_detector)
             hs = outputs['hs_embed']
-            idx = torch.tensor(refs, dtype=torch.long, device=hs.device)
+            # the row count is rounded up to a multiple of 8 (the last row repeated): the convolution library tunes per
+            # shape, and the number of live tracks changes from frame to frame
+            padded = refs + [refs[-1]] * (-len(refs) % 8)
+            idx = torch.tensor(padded, dtype=torch.long, device=hs.device)
             with torch.no_grad():
-                rows = module.mask_rows(outputs['mask_context'], hs.index_select(1, idx))
+                rows = module.mask_rows(outputs['mask_context'], hs.index_select(1, idx))[:, :len(refs)]
             seg = self.obj_detector_post['segm']([{}], {'pred_masks': rows}, orig_size, size,
                                                  return_probs=True)[0]['masks'].squeeze(dim=1)
             by_row = {row: seg[k] for k, row in enumerate(refs)}
