@@ -567,6 +567,7 @@ def main():
         fused.set_input_proj_fused(True)
         fused.set_box_refine_fused(True)
         fused.set_ffn_fused(True)
+        fused.set_linear_ln_fused(True)
 
     if args.roofline_only:
         if rank == 0:
@@ -628,6 +629,8 @@ def main():
                        "linears": "bf16 split product (hi.hi + hi.mid + mid.hi, f32 accumulate)"
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",
                        **({"ffn": "one launch per feed-forward block (tf_ffn_fused_f32)"} if fused.ffn_fused_enabled() and not train else {}),
+                       **({"projection_norm": "output projection + residual + LayerNorm in one launch (tf_linear_res_ln_f32)"}
+                          if fused.linear_ln_fused_enabled() and not train else {}),
                        **({"mask_head": "lazy: evaluated for the surviving tracks' queries only (TF_LAZY_MASKS=1)"}
                           if os.environ.get("TF_LAZY_MASKS") == "1" and not train else {})},
             "single_sequence_fps": None if single is None else round(single, 3),

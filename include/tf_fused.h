@@ -15,6 +15,7 @@
  *                          deformable_transformer.py:282-297) as a bf16 split product on the matrix cores
  *   tf_linear_packed_f32   the same product with the weight packed once in fragment order (+ tf_linear_pack_weight_f32)
  *   tf_ffn_fused_f32       linear1 -> ReLU -> linear2 -> + residual -> LayerNorm of a transformer layer in one launch
+ *   tf_linear_res_ln_f32   linear (256 -> 256) -> + residual -> LayerNorm in one launch (output projection + norm1)
  *   tf_mha_core_f32        softmax(q k^T * scale) v of the decoder's query self-attention
  *                          (deformable_transformer.py:364-383, nn.MultiheadAttention): one launch, fp32
  *
@@ -125,6 +126,16 @@ int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias
  *   (neither: no LayerNorm);  y must not alias x or residual.
  * d_model == 256, d_ffn a multiple of 128, every pointer 16-byte aligned; anything else: TF_MSDA_ERR_BAD_DIMS.
  */
+/*
+ * y[M, 256] = [LayerNorm]( residual + x[M, 256] . w^T + bias ) in one launch: the attention's output projection with the
+ * layer's residual add and norm1 (reference: models/ops/modules/ms_deform_attn.py:87 output_proj +
+ * models/deformable_transformer.py:285-292).  Same split product as tf_linear_packed_f32 (bit-identical without the
+ * LayerNorm); w_packed: tf_linear_pack_weight_f32 of the [256, 256] weight.  K == N == 256, pointers 16-byte aligned,
+ * bias / residual may be NULL, ln_weight / ln_bias both or neither, y must not alias x or residual.
+ */
+int tf_linear_res_ln_f32(const float *x, const void *w_packed, const float *bias, const float *residual, const float *ln_weight,
+                         const float *ln_bias, float ln_eps, float *y, int64_t M, int K, int N, void *stream);
+
 int tf_ffn_fused_f32(const float *x, const void *w1_packed, const float *b1, const void *w2_packed, const float *b2,
                      const float *residual, const float *ln_weight, const float *ln_bias, float ln_eps, float *y, int64_t M,
                      int d_model, int d_ffn, void *stream);

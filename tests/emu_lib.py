@@ -51,6 +51,8 @@ def lib():
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_groupnorm_nhwc_f32.restype = ci
     L.tf_groupnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
+    L.tf_linear_res_ln_f32.restype = ci
+    L.tf_linear_res_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_ffn_fused_f32.restype = ci
     L.tf_ffn_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_linear_split_f32.restype = ci
@@ -239,6 +241,21 @@ def ffn_fused(x, w1, b1, w2, b2, residual=None, ln=None, eps=1e-5, guard_rows=0)
                                 ctypes.c_float(eps), _p(y), M, D, F, None)
     if rc != 0:
         raise RuntimeError("tf_ffn_fused_f32: status %d" % rc)
+    return y
+
+
+def linear_res_ln(x, w, bias=None, residual=None, ln=None, eps=1e-5, guard_rows=0):
+    """tf_linear_res_ln_f32: x [M, 256], w [256, 256]; ln = (weight, bias) or None."""
+    x = _aligned(x)
+    M, K = x.shape
+    pk = _packed(w)
+    b, r = _aligned(bias), _aligned(residual)
+    g, be = (_aligned(ln[0]), _aligned(ln[1])) if ln is not None else (None, None)
+    y = _aligned(np.full((M + guard_rows, w.shape[0]), np.nan, np.float32))
+    rc = lib().tf_linear_res_ln_f32(_p(x), pk.ctypes.data, _p(b), _p(r), _p(g), _p(be), ctypes.c_float(eps), _p(y), M, K,
+                                    w.shape[0], None)
+    if rc != 0:
+        raise RuntimeError("tf_linear_res_ln_f32: status %d" % rc)
     return y
 
 

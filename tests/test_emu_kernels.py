@@ -485,7 +485,7 @@ def test_opt_in_kernels_do_not_depend_on_the_scheduling_order():
     import subprocess
     import sys
     env = dict(os.environ, HIPEMU_SHUFFLE="3")
-    sel = "direct9 or sorted2 or pipelined or deep_prefetch or buffer_store or residual_epilogue or fused_ffn"
+    sel = "direct9 or sorted2 or pipelined or deep_prefetch or buffer_store or residual_epilogue or fused_ffn or residual_layernorm"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -622,3 +622,29 @@ def test_fused_ffn_rejects_what_it_does_not_cover():
         emu_lib.ffn_fused(x[:, :128].copy(), w1[:, :128].copy(), b1, w2[:128].copy(), b2[:128].copy())
     with pytest.raises(RuntimeError):   # d_ffn not a multiple of 128
         emu_lib.ffn_fused(x, w1[:64].copy(), b1[:64].copy(), w2[:, :64].copy(), b2)
+
+
+@pytest.mark.parametrize("M,ti", [(200, 0), (97, 3), (130, 2), (33, 1), (1, 0)])
+def test_linear_residual_layernorm_in_one_launch(M, ti):
+    """tf_linear_res_ln_f32 (opt-in): output projection + residual add (+ LayerNorm).  Without the norm bit-identical to
+    tf_linear_packed_f32 + residual; with it equal to tf_add_layernorm_f32 on that up to rounding; guard rows untouched."""
+    rng = np.random.default_rng(M)
+    x = rng.standard_normal((M, 256), dtype=np.float32)
+    w = (rng.standard_normal((256, 256), dtype=np.float32) / 16).astype(np.float32)
+    b = rng.standard_normal(256, dtype=np.float32)
+    r = rng.standard_normal((M, 256), dtype=np.float32)
+    g = (1 + 0.1 * rng.standard_normal(256, dtype=np.float32)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(256, dtype=np.float32)).astype(np.float32)
+    ref = emu_lib.linear_packed(x, w, b) + r
+    prev = emu_lib.set_options(linln_ti=ti)
+    try:
+        y = emu_lib.linear_res_ln(x, w, b, r, guard_rows=3)
+        yl = emu_lib.linear_res_ln(x, w, b, r, ln=(g, be), guard_rows=3)
+        y0 = emu_lib.linear_res_ln(x, w)
+    finally:
+        emu_lib.set_options(**prev)
+    assert np.array_equal(y[:M], ref) and np.isnan(y[M:]).all() and np.isnan(yl[M:]).all()
+    assert np.array_equal(y0, emu_lib.linear_packed(x, w))
+    assert np.abs(yl[:M] - emu_lib.add_layernorm(ref, None, g, be, 1e-5)).max() < 5e-6
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0

@@ -23,7 +23,10 @@ def _run(case, optin, fn=None):
                     (fused.set_input_proj_fused, fused.set_input_proj_fused(True)),
                     (fused.set_box_refine_fused, fused.set_box_refine_fused(True)),
                     (fused.set_ffn_fused, fused.set_ffn_fused(True)),
+                    (fused.set_linear_ln_fused, fused.set_linear_ln_fused(True)),
+                    (lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
                     (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
+            fused._LINLN_MIN_ROWS = 1
             fused._FFN_FUSED_MIN_ROWS = 1   # the test models have few tokens: the decoder's feed-forward blocks take it too
             opts = {b"linear_bufstore": 2, b"linear_deep": 1, b"pquad_pipe": 1, b"direct9": 1, b"mha_batch": 1}
             prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
@@ -44,9 +47,10 @@ def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
     # the GPU path really ran: 6 encoder + 6 decoder layers through the fused MSDeformAttn entry, the split-product linears,
     # the fused LayerNorm and bias_act passes, the own attention kernel
     assert calls.get("tf_msda_forward_fused_f32") == 12 and calls.get("tf_mha_core_f32") == 6
-    # 30 LayerNorms: 12 + 18; with the one-launch feed-forward block (opt-in) 12 of them and 24 linears move into it
-    assert calls.get("tf_add_layernorm_f32", 0) >= (18 if optin else 30) and calls.get("tf_linear_split_f32", 0) >= (36 if optin else 60)
-    assert calls.get("tf_ffn_fused_f32") == (12 if optin else None)
+    # 30 LayerNorms: 12 + 18.  Opt-in: the 12 feed-forward blocks are one launch each (12 norms, 24 linears inside), and so
+    # are the 18 output projections with their residual add and norm (6 encoder, 2 x 6 decoder): no separate LayerNorm left
+    assert calls.get("tf_add_layernorm_f32", 0) == (0 if optin else 30) and calls.get("tf_linear_split_f32", 0) >= (18 if optin else 60)
+    assert calls.get("tf_ffn_fused_f32") == (12 if optin else None) and calls.get("tf_linear_res_ln_f32") == (18 if optin else None)
     routes = ("tf_conv3x3_split_f32", "tf_linear_split_res_f32", "tf_groupnorm_nhwc_f32", "tf_box_refine_f32")
     if optin:   # ResNet-50: 16 bottlenecks (their 3 x 3 and closing 1 x 1 convolutions), 3 projection levels, 6 decoder layers
         assert [calls.get(r) for r in routes] == [16, 16, 3, 6], calls

@@ -119,7 +119,7 @@ def test_decoder_self_attention_uses_own_kernel_and_matches_module(dev):
     fused.mha_core = spy
     try:
         with torch.no_grad():
-            got = layer._self_attention_inference(tgt + pos, tgt, None)
+            got, _ = layer._self_attention_inference(tgt + pos, tgt, None)
     finally:
         fused.mha_core = orig
     assert calls == [True]
@@ -208,3 +208,30 @@ def test_optin_fused_ffn_block(rows, ti, monkeypatch):
     assert torch.equal(got, ref)
     assert torch.allclose(got, exact, atol=2e-4, rtol=1e-4)
     assert torch.allclose(got_ln, norm(ref), atol=1e-5, rtol=1e-5)
+
+
+@optin
+@pytest.mark.parametrize("rows,ti", [(22223, 0), (22223, 3), (400, 0), (97, 2)])
+def test_optin_linear_residual_layernorm(rows, ti, monkeypatch):
+    """tf_linear_res_ln_f32 (fused.linear_residual_norm): output projection + residual + LayerNorm in one launch against
+    the split-product linear followed by torch's add and LayerNorm."""
+    from trackformer_amd import _cabi, fused
+    lib = _cabi.lib()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(rows + ti)
+    lin, norm = torch.nn.Linear(256, 256).to(dev), torch.nn.LayerNorm(256).to(dev)
+    with torch.no_grad():
+        norm.weight.add_(0.1 * torch.randn(256, device=dev))
+        norm.bias.add_(0.1 * torch.randn(256, device=dev))
+    x, res = torch.randn(1, rows, 256, device=dev), torch.randn(1, rows, 256, device=dev)
+    monkeypatch.setattr(fused, "_LINLN_MIN_ROWS", 1)
+    prev_on, prev_ti = fused.set_linear_ln_fused(True), lib.tf_msda_set_option(b"linln_ti", ti)
+    try:
+        with torch.no_grad():
+            got = fused.linear_residual_norm(x, lin, res, norm)
+            ref = norm(res + fused.linear(x, lin.weight, lin.bias))
+    finally:
+        fused.set_linear_ln_fused(prev_on)
+        lib.tf_msda_set_option(b"linln_ti", prev_ti)
+    assert got is not None
+    assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)

@@ -7,7 +7,8 @@
 //    (the separate kernels of the default path), rows behind M checked untouched;
 // 2. with LayerNorm: a sample of rows against a double-precision reference;
 // 3. timing, 20 launches per HIP graph: the three launches of the default path (linear1 + ReLU, linear2, residual +
-//    LayerNorm) against the one fused launch.
+//    LayerNorm) against the one fused launch;
+// 4. the same for tf_linear_res_ln_f32 (256 -> 256 projection + residual + LayerNorm; TF_LINLN_TI forces its rows per block).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -165,6 +166,40 @@ int main(int argc, char **argv)
     });
     const double us_fused = time_graph([&] { tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, dG, dBe, 1e-5f, dY, M, D, F, s); });
     const double us_fused_noln = time_graph([&] { tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, F, s); });
+    // the output projection + residual + LayerNorm (tf_linear_res_ln_f32) against tf_linear_split_f32-class GEMM + tf_add_layernorm_f32
+    void *dPo;
+    float *dWo;
+    std::vector<float> Wo((size_t)D * D);
+    for (auto &v : Wo) v = nrm(rng) * 0.0625f;
+    up(&dWo, Wo);
+    CK(hipMalloc(&dPo, (size_t)tf_linear_packed_bytes(D, D)));
+    TF(tf_linear_pack_weight_f32(dWo, dPo, D, D, s));
+    TF(tf_linear_packed_f32(dX, dPo, dB2, dY0, M, D, D, 0, s));
+    CK(hipMemsetAsync(dY, 0xFF, (size_t)(M + guard) * D * 4, s));
+    TF(tf_linear_res_ln_f32(dX, dPo, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, D, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipMemcpy(Y0.data(), dY0, Y0.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
+    long long differ2 = 0, touched2 = 0;
+    for (size_t i = 0; i < Y0.size(); ++i) {
+        const float ref = Y0[i] + X[i];
+        differ2 += memcmp(&ref, &Y[i], 4) != 0;
+    }
+    for (size_t i = Y0.size(); i < Y.size(); ++i) {
+        unsigned u;
+        memcpy(&u, &Y[i], 4);
+        touched2 += u != 0xFFFFFFFFu;
+    }
+    const double us_lin_sep = time_graph([&] {
+        tf_linear_packed_f32(dX, dPo, dB2, dY0, M, D, D, 0, s);
+        tf_add_layernorm_f32(dX, dY0, dG, dBe, dY1, M, D, 1e-5f, s);
+    });
+    const double us_lin_fused = time_graph([&] { tf_linear_res_ln_f32(dX, dPo, dB2, dX, dG, dBe, 1e-5f, dY, M, D, D, s); });
+    printf("tf_linear_res_ln_f32 M=%d: outputs that differ from tf_linear_packed_f32 + x: %lld, words written behind row M: %lld\n"
+           "  separate (packed linear, residual + LayerNorm): %.2f us;  fused: %.2f us = %.0f GB/s of x + residual + y\n",
+           M, differ2, touched2, us_lin_sep, us_lin_fused, 3.0 * M * D * 4 / us_lin_fused * 1e-3);
+    differ += differ2;
+    touched += touched2;
     const double flop = 2.0 * 2.0 * M * D * F;   // fp32-equivalent; the three-term product issues 3x that in bf16
     printf("  separate (linear1 + ReLU, linear2, residual + LayerNorm): %.2f us;  fused: %.2f us (without LayerNorm %.2f us)\n"
            "  fused: %.1f TFLOP/s fp32-equivalent = %.1f TFLOP/s bf16 issued (dense bf16 MFMA peak ~2500)\n",

@@ -66,6 +66,117 @@ constexpr int kRing = 8, kAhead = 6;  // weight units (4 KB per wave each) in th
 
 constexpr size_t ffn_lds_bytes(int ti) { return (size_t)(32 * ti) * (kXStride + kHStride) * 2 * 2; }
 
+// ---- the block's activation tile (32 TI rows x 256 k) -> LDS as bf16 hi / mid.  All of its global loads are in flight
+// before the first conversion waits.  The caller issues the barrier.
+template <int TI>
+__device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, int m0, unsigned short *sXhi, unsigned short *sXmid,
+                                           int wave, int lane)
+{
+    constexpr int NV = TI * 32 * (kD / 4) / kThreads;   // float4 of X per thread: a wave covers one row (1 KB) per step
+    f32x4 xr[NV];
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int grow = min(m0 + it * 4 + wave, M - 1);   // rows past M read the last row, never stored
+        xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * kD + lane * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < NV; ++it) {
+        const int row = it * 4 + wave;
+        bf16x4 hi, mid;   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            hi[e] = (__bf16)xr[it][e];
+            mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
+        }
+        *reinterpret_cast<bf16x4 *>(&sXhi[row * kXStride + lane * 4]) = hi;
+        *reinterpret_cast<bf16x4 *>(&sXmid[row * kXStride + lane * 4]) = mid;
+    }
+}
+
+// ---- the epilogue both kernels share: + bias + residual [-> LayerNorm] -> Y.  accy: transposed 32 x 32 tiles (lane -> output
+// row m0 + 32 i + (lane & 31); registers 4 g .. 4 g + 3 of tile j -> columns 64 wave + 32 j + 8 g + 4 (lane >> 5) + 0..3);
+// v: the residual values in the same layout on entry.  sRed: [2 passes][4 waves][BM] floats of LDS that alias a tile every
+// wave has finished reading once it reaches the first barrier in here.  Rows >= M: stores are dropped by the buffer resource.
+template <int TI, bool LN>
+__device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][2], f32x4 (&v)[TI][2][4], const __amdgpu_buffer_rsrc_t b2rs,
+                                              const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                              const __amdgpu_buffer_rsrc_t yrs, float *sRed, int m0, int wave, int lane)
+{
+    constexpr int BM = TI * 32;
+    const int frow = lane & 31, cbase = wave * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b2rs, (unsigned)(cbase + 32 * j + 8 * g) * 4u, 0, 0));
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][j][g][e] = (accy[i][j][4 * g + e] + b[e]) + v[i][j][g][e];
+        }
+    if constexpr (LN) {
+        // two-pass statistics over the 256 columns of a row: 32 values in this lane, 32 in lane ^ 32, the rest in the
+        // other three waves (through LDS: the caller's scratch tile is free after the barrier)
+        float s[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a += (v[i][j][g].x + v[i][j][g].y) + (v[i][j][g].z + v[i][j][g].w);
+            s[i] = a + __shfl_xor(a, 32);
+        }
+        __syncthreads();   // all waves are past their last reads of the tile sRed aliases
+        if (lane < 32)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) sRed[wave * BM + i * 32 + lane] = s[i];
+        __syncthreads();
+        float mean[TI], rstd[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int r = i * 32 + frow;
+            mean[i] = ((sRed[r] + sRed[BM + r]) + (sRed[2 * BM + r] + sRed[3 * BM + r])) * (1.f / kD);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 d = v[i][j][g] - mean[i];
+                    a += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+                }
+            s[i] = a + __shfl_xor(a, 32);
+        }
+        if (lane < 32)
+#pragma unroll
+            for (int i = 0; i < TI; ++i) sRed[(4 + wave) * BM + i * 32 + lane] = s[i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int r = 4 * BM + i * 32 + frow;
+            rstd[i] = rsqrtf(((sRed[r] + sRed[BM + r]) + (sRed[2 * BM + r] + sRed[3 * BM + r])) * (1.f / kD) + eps);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + cbase + 32 * j + 8 * g);
+                const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + cbase + 32 * j + 8 * g);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) v[i][j][g] = (v[i][j][g] - mean[i]) * rstd[i] * ga + be;
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i][j][g]), yrs,
+                                                       (unsigned)((m0 + i * 32 + frow) * kD + cbase + 32 * j + 8 * g) * 4u, 0, 0);
+}
+
 template <int TI, bool LN>
 __global__ void __launch_bounds__(kThreads, 1)
 ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, const float *__restrict__ b1,
@@ -73,7 +184,6 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
                  const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *Y, int M, int F)
 {
     constexpr int BM = TI * 32;
-    constexpr int NV = BM * (kD / 4) / kThreads;   // float4 of X per thread: a wave covers one row (1 KB) per step
     extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
     unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * kXStride;
     unsigned short *const sHhi = sXmid + BM * kXStride, *const sHmid = sHhi + BM * kHStride;
@@ -109,27 +219,7 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
     load_unit(0, std::integral_constant<int, 4>{}, ring[4]);
     load_unit(0, std::integral_constant<int, 5>{}, ring[5]);
     __builtin_amdgcn_sched_barrier(0);
-    {
-        f32x4 xr[NV];
-#pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            const int grow = min(m0 + it * 4 + wave, M - 1);   // rows past M read the last row, never stored
-            xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * kD + lane * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // all NV loads in flight before the first conversion waits
-#pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            const int row = it * 4 + wave;
-            bf16x4 hi, mid;   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)xr[it][e];
-                mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
-            }
-            *reinterpret_cast<bf16x4 *>(&sXhi[row * kXStride + lane * 4]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sXmid[row * kXStride + lane * 4]) = mid;
-        }
-    }
+    stage_rows<TI>(X, M, m0, sXhi, sXmid, wave, lane);
     __syncthreads();
 
     f32x16 accy[TI][2];
@@ -294,78 +384,8 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
         gemm2(std::integral_constant<int, 7>{});
     }
 
-    // ---- epilogue: + bias + residual [-> LayerNorm] -> Y (rows >= M: stores are dropped by the buffer resource)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b2rs, (unsigned)(cbase + 32 * j + 8 * g) * 4u, 0, 0));
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][j][g][e] = (accy[i][j][4 * g + e] + b[e]) + v[i][j][g][e];
-        }
-    if constexpr (LN) {
-        // two-pass statistics over the 256 columns of a row: 32 values in this lane, 32 in lane ^ 32, the rest in the
-        // other three waves (through LDS: the hidden tile is free after the barrier)
-        float *const sRed = reinterpret_cast<float *>(sHhi);   // [2 passes][4 waves][BM]
-        float s[TI];
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) a += (v[i][j][g].x + v[i][j][g].y) + (v[i][j][g].z + v[i][j][g].w);
-            s[i] = a + __shfl_xor(a, 32);
-        }
-        __syncthreads();   // all waves are past their last GEMM 2 reads of the hidden tile
-        if (lane < 32)
-#pragma unroll
-            for (int i = 0; i < TI; ++i) sRed[wave * BM + i * 32 + lane] = s[i];
-        __syncthreads();
-        float mean[TI], rstd[TI];
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int r = i * 32 + frow;
-            mean[i] = ((sRed[r] + sRed[BM + r]) + (sRed[2 * BM + r] + sRed[3 * BM + r])) * (1.f / kD);
-            float a = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 d = v[i][j][g] - mean[i];
-                    a += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
-                }
-            s[i] = a + __shfl_xor(a, 32);
-        }
-        if (lane < 32)
-#pragma unroll
-            for (int i = 0; i < TI; ++i) sRed[(4 + wave) * BM + i * 32 + lane] = s[i];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int r = 4 * BM + i * 32 + frow;
-            rstd[i] = rsqrtf(((sRed[r] + sRed[BM + r]) + (sRed[2 * BM + r] + sRed[3 * BM + r])) * (1.f / kD) + eps);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + cbase + 32 * j + 8 * g);
-                const f32x4 be = *reinterpret_cast<const f32x4 *>(beta + cbase + 32 * j + 8 * g);
-#pragma unroll
-                for (int i = 0; i < TI; ++i) v[i][j][g] = (v[i][j][g] - mean[i]) * rstd[i] * ga + be;
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i][j][g]), yrs,
-                                                       (unsigned)((m0 + i * 32 + frow) * kD + cbase + 32 * j + 8 * g) * 4u, 0, 0);
+    // ---- epilogue (the LayerNorm's exchange buffer aliases the hidden tile)
+    rows_epilogue<TI, LN>(accy, v, b2rs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sHhi), m0, wave, lane);
 }
 
 template <int TI>
@@ -386,6 +406,159 @@ int launch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2
     void *argv[] = {(void *)&x, (void *)&w1, (void *)&b1, (void *)&w2, (void *)&b2, (void *)&res,
                     (void *)&gamma, (void *)&beta, (void *)&eps, (void *)&y, (void *)&M, (void *)&F};
     return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(kThreads), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+// ---- tf_linear_res_ln_f32: y = [LayerNorm](residual + x . w^T + bias) for a 256 x 256 weight -- the attention's output
+// projection with the layer's residual add and norm1 (deformable_transformer.py:285-292 / ms_deform_attn.py:87).  The GEMM 2
+// half of the kernel above with the activation tile as its operand: 16 k-steps, each wave 64 output columns.
+constexpr size_t linln_lds_bytes(int ti) { return (size_t)(32 * ti) * kXStride * 2 * 2; }
+constexpr int linln_min_blocks(int ti) { return ti <= 2 ? 2 : 1; }   // resident blocks per CU the register budget is cut for
+constexpr int linln_ring(int ti) { return ti <= 2 ? 4 : 8; }          // weight units in flight + 2 (16 registers each)
+
+template <int TI, bool LN>
+__global__ void __launch_bounds__(kThreads, (linln_min_blocks(TI)))
+linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R,
+                     const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *Y, int M)
+{
+    constexpr int BM = TI * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
+    unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * kXStride;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+    // weight unit u = k-step u (hi, mid) of the wave's two output n-tiles; a ring as above, RING - 2 units ahead
+    constexpr int RING = linln_ring(TI), AHEAD = RING - 2;
+    u32x4 ring[RING][4];
+    auto load_unit = [&](auto uc, u32x4 (&dst)[4]) {
+        constexpr int u = decltype(uc)::value;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) dst[j * 2 + p] = Wp[(((size_t)(2 * wave + j) * kKQ1 + u) * 2 + p) * 64 + lane];
+    };
+    load_unit(std::integral_constant<int, 0>{}, ring[0]);
+    load_unit(std::integral_constant<int, 1>{}, ring[1]);
+    if constexpr (AHEAD > 2) {
+        load_unit(std::integral_constant<int, 2>{}, ring[2]);
+        load_unit(std::integral_constant<int, 3>{}, ring[3]);
+        load_unit(std::integral_constant<int, 4>{}, ring[4]);
+        load_unit(std::integral_constant<int, 5>{}, ring[5]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bias ? bias : X), 0, bias ? (unsigned)kD * 4u : 0u, 0x00020000);
+    const unsigned bytes = (unsigned)((size_t)M * kD * 4);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : X), 0, R ? bytes : 0u, 0x00020000);
+    const int frow = lane & 31, cbase = wave * 64 + 4 * (lane >> 5);
+    f32x4 v[TI][2][4];   // the residual rows (rows >= M return zeros), then the output values
+    stage_rows<TI>(X, M, m0, sXhi, sXmid, wave, lane);
+    __syncthreads();
+
+    f32x16 accy[TI][2];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) accy[i][j][e] = 0.f;
+    const int xoff = frow * kXStride + (lane >> 5) * 8;
+    bf16x8 xf[2][TI][2];   // [k-step parity][row tile][hi | mid]: the fragments of step st + 1 are read before the MFMAs of st
+    auto read_x = [&](auto stc) {
+        constexpr int st = decltype(stc)::value;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            xf[st & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sXhi[i * 32 * kXStride + xoff + st * 16]);
+            xf[st & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sXmid[i * 32 * kXStride + xoff + st * 16]);
+        }
+    };
+    auto step = [&](auto stc) {
+        constexpr int st = decltype(stc)::value;
+        if constexpr (st + AHEAD < kKQ1) load_unit(std::integral_constant<int, st + AHEAD>{}, ring[(st + AHEAD) & (RING - 1)]);
+        if constexpr (st == kKQ1 - AHEAD) {   // the weight stream has ended: the residual rows take its place in the queue
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        v[i][j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                   rrs, (unsigned)((m0 + i * 32 + frow) * kD + cbase + 32 * j + 8 * g) * 4u, 0, 0));
+        }
+        if constexpr (st + 1 < kKQ1) read_x(std::integral_constant<int, st + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        const u32x4 (&cur)[4] = ring[st & (RING - 1)];
+        bf16x8 w_hi[2], w_mid[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            w_hi[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 0]);
+            w_mid[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 1]);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], xf[st & 1][i][1], accy[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid[j], xf[st & 1][i][0], accy[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], xf[st & 1][i][0], accy[i][j], 0, 0, 0);
+    };
+    read_x(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
+    step(std::integral_constant<int, 9>{});
+    step(std::integral_constant<int, 10>{});
+    step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{});
+    step(std::integral_constant<int, 13>{});
+    step(std::integral_constant<int, 14>{});
+    step(std::integral_constant<int, 15>{});
+    static_assert(kKQ1 == 16, "the k-step loop is written out for K = 256");
+    rows_epilogue<TI, LN>(accy, v, brs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sXhi), m0, wave, lane);
+}
+
+template <int TI>
+int launch_linln(const float *x, const u32x4 *w, const float *b, const float *res, const float *gamma, const float *beta, float eps,
+                 float *y, int M, hipStream_t s)
+{
+    const bool ln = gamma != nullptr;
+    const size_t lds = linln_lds_bytes(TI);
+    const void *fn = ln ? (const void *)&linear_res_ln_kernel<TI, true> : (const void *)&linear_res_ln_kernel<TI, false>;
+    if (lds > 64 * 1024) {
+        static std::atomic<unsigned> raised[2];   // bit per device, per kernel
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 32 || !(raised[ln ? 1 : 0].load() & (1u << dev))) {
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+            if (dev < 32) raised[ln ? 1 : 0].fetch_or(1u << dev);
+        }
+    }
+    const int blocks = (M + 32 * TI - 1) / (32 * TI);
+    void *argv[] = {(void *)&x, (void *)&w, (void *)&b, (void *)&res, (void *)&gamma, (void *)&beta, (void *)&eps, (void *)&y, (void *)&M};
+    return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(kThreads), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+std::atomic<int> g_linln_ti{-1};   // -1: TF_LINLN_TI or automatic (0)
+int linln_ti()
+{
+    int v = g_linln_ti.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_LINLN_TI");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 3) v = 0;
+        g_linln_ti.store(v);
+    }
+    return v;
 }
 
 std::atomic<int> g_ffn_ti{-1};   // -1: TF_FFN_TI or the default (3)
@@ -410,7 +583,35 @@ int ffn_set_ti(int v)
     g_ffn_ti.store(v >= 1 && v <= 3 ? v : 3);
     return prev;
 }
+int linln_set_ti(int v)
+{
+    const int prev = linln_ti();
+    g_linln_ti.store(v >= 1 && v <= 3 ? v : 0);
+    return prev;
+}
 }  // namespace tfm
+
+extern "C" int tf_linear_res_ln_f32(const float *x, const void *w_packed, const float *bias, const float *residual,
+                                    const float *ln_weight, const float *ln_bias, float ln_eps, float *y, int64_t M, int K, int N,
+                                    void *stream)
+{
+    if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
+    if ((ln_weight == nullptr) != (ln_bias == nullptr)) return TF_MSDA_ERR_NULL_POINTER;
+    if (M <= 0 || K != kD || N != kD || (M + 128) * (int64_t)kD * 4 > 0xFFFFFFFFLL) return TF_MSDA_ERR_BAD_DIMS;
+    uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y) |
+                   reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(ln_weight) |
+                   reinterpret_cast<uintptr_t>(ln_bias);
+    if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
+    const u32x4 *w = static_cast<const u32x4 *>(w_packed);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // rows per block = 32 TI; automatic: few rows -> 32-row blocks (more of them), many -> 64 (two resident per CU)
+    const int forced = linln_ti();
+    switch (forced ? forced : (M < 4096 ? 1 : 2)) {
+    case 1: return launch_linln<1>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
+    case 3: return launch_linln<3>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
+    default: return launch_linln<2>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
+    }
+}
 
 extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const float *b1, const void *w2_packed, const float *b2,
                                 const float *residual, const float *ln_weight, const float *ln_bias, float ln_eps, float *y,

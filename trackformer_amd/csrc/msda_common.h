@@ -60,6 +60,7 @@ int linear_deep();
 int linear_deep_set(int v);
 // ffn_fused.hip: row tiles per block of tf_ffn_fused_f32 (1..3, default 3); returns the previous value
 int ffn_set_ti(int v);
+int linln_set_ti(int v);   // tf_linear_res_ln_f32 (1..3; 0 = by row count)
 // linear_stream.hip: row tiles per block of tf_linear_packed_f32 (2..4; 0 = per shape); returns the previous value
 int linear_stream_set_ti(int v);
 // linear_stream.hip: activation-stationary kernel for K == 256 (0 = off, 2..4 = row tiles per block); returns the previous value

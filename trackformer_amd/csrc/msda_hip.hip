@@ -3018,6 +3018,7 @@ int tf_msda_set_option(const char *name, int value)
     if (strcmp(name, "mha_batch") == 0) return mha_batch_set(value);
     if (strcmp(name, "bias_act_batch") == 0) return bias_act_batch_set(value);
     if (strcmp(name, "ffn_ti") == 0) return ffn_set_ti(value);
+    if (strcmp(name, "linln_ti") == 0) return linln_set_ti(value);
     if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);
     if (strcmp(name, "linear_stream_ti") == 0) return linear_stream_set_ti(value);
     if (strcmp(name, "linear_astat") == 0) return linear_astat_set(value);

@@ -314,6 +314,10 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return fused.residual_norm(src, self.dropout3(src2), self.norm2, inf)
 
     def forward(self, src, pos, reference_points, spatial_shapes, padding_mask=None):
+        if _inference(self) and fused.linear_ln_fused_enabled():   # opt-in: output projection + add + norm1 in one launch
+            src = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes, padding_mask,
+                                 residual_norm=(src, self.norm1))
+            return self.forward_ffn(src)
         src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
                               padding_mask)
         src = fused.residual_norm(src, self.dropout1(src2), self.norm1, _inference(self))
@@ -383,9 +387,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
         tgt2 = fused.module_linear(self.linear2, self.dropout3(_ffn_hidden(self.linear1, self.activation, tgt, inf)), inf)
         return fused.residual_norm(tgt, self.dropout4(tgt2), self.norm3, inf)
 
-    def _self_attention_inference(self, qk_in, v_in, key_padding_mask):
+    def _self_attention_inference(self, qk_in, v_in, key_padding_mask, residual_norm=None):
         """nn.MultiheadAttention(q=k=qk_in, v=v_in) for batch-first inputs without materialising the
-        attention weights: one GEMM for the shared q/k input, one for v, fused SDPA, out_proj."""
+        attention weights: one GEMM for the shared q/k input, one for v, fused SDPA, out_proj.
+        residual_norm = (residual, norm): returns (norm(residual + attention), True) when the opt-in one-launch
+        projection + add + LayerNorm applied, else (attention, False)."""
         mha = self.self_attn
         E, H = mha.embed_dim, mha.num_heads
         w, b = mha.in_proj_weight, mha.in_proj_bias
@@ -398,7 +404,11 @@ class DeformableTransformerDecoderLayer(nn.Module):
             v = F.linear(v_in, w[2 * E:], b[2 * E:])
         o = fused.mha_core(qk, v, H, key_padding_mask)      # one fp32 launch: scores, softmax, P V
         if o is not None:
-            return fused.module_linear(mha.out_proj, o, True)
+            if residual_norm is not None and fused.linear_ln_fused_enabled():
+                y = fused.linear_residual_norm(o, mha.out_proj, residual_norm[0], residual_norm[1])
+                if y is not None:
+                    return y, True
+            return fused.module_linear(mha.out_proj, o, True), False
         qk = qk.view(n, lq, 2, H, E // H)
         v = v.view(n, lq, H, E // H)
         q, k = qk[:, :, 0].transpose(1, 2), qk[:, :, 1].transpose(1, 2)      # [n, H, lq, d]
@@ -406,7 +416,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         if key_padding_mask is not None:
             mask = ~key_padding_mask[:, None, None, :]                           # True = attend
         o = F.scaled_dot_product_attention(q, k, v.transpose(1, 2), attn_mask=mask)
-        return mha.out_proj(o.transpose(1, 2).reshape(n, lq, E))
+        return mha.out_proj(o.transpose(1, 2).reshape(n, lq, E)), False
 
     def forward(self, tgt, query_pos, reference_points, src, src_spatial_shapes,
                 src_padding_mask=None, query_attn_mask=None, filler_key_mask=None):
@@ -417,12 +427,17 @@ class DeformableTransformerDecoderLayer(nn.Module):
         q = k = self.with_pos_embed(tgt, query_pos)
         key_mask = query_attn_mask if query_attn_mask is not None else filler_key_mask
         if _inference(self) and tgt.is_cuda and self.self_attn.in_proj_weight is not None:
-            tgt2 = self._self_attention_inference(q, tgt, key_mask)
+            tgt2, normed = self._self_attention_inference(q, tgt, key_mask, residual_norm=(tgt, self.norm2))
         else:
+            normed = False
             tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
                                   key_padding_mask=key_mask)[0].transpose(0, 1)
-        tgt = fused.residual_norm(tgt, self.dropout2(tgt2), self.norm2, _inference(self))
+        tgt = tgt2 if normed else fused.residual_norm(tgt, self.dropout2(tgt2), self.norm2, _inference(self))
         # deformable cross attention into the encoder memory
+        if _inference(self) and fused.linear_ln_fused_enabled():   # opt-in, as in the encoder layer
+            tgt = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
+                                  src_padding_mask, query_attn_mask, residual_norm=(tgt, self.norm1))
+            return self.forward_ffn(tgt)
         tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src,
                                src_spatial_shapes, src_padding_mask, query_attn_mask)
         tgt = fused.residual_norm(tgt, self.dropout1(tgt2), self.norm1, _inference(self))

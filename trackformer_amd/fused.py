@@ -282,6 +282,62 @@ def ffn(x, linear1, linear2, norm=None, residual=None):
     return y.view(x.shape)
 
 
+# OPT-IN (TF_LINLN_FUSED=1 / set_linear_ln_fused(True)): a 256 -> 256 linear, the layer's residual add and its LayerNorm in
+# ONE launch (tf_linear_res_ln_f32, csrc/ffn_fused.hip) -- the attention's output projection + norm1.  Written against the
+# emulator, to be timed in round 3.
+_linln_fused = os.environ.get("TF_LINLN_FUSED", "0") == "1"
+_LINLN_MIN_ROWS = int(os.environ.get("TF_LINLN_MIN_ROWS", "256"))
+
+
+def linear_ln_fused_enabled():
+    return _linln_fused
+
+
+def set_linear_ln_fused(on):
+    """Switch the one-launch projection + residual + LayerNorm on or off (process-wide); returns the previous setting."""
+    global _linln_fused
+    prev, _linln_fused = _linln_fused, bool(on)
+    return prev
+
+
+def linear_residual_norm(x, linear, residual, norm):
+    """norm(residual + linear(x)) through tf_linear_res_ln_f32 for a 256 -> 256 nn.Linear (reference:
+    ms_deform_attn.py:87 output_proj + deformable_transformer.py:285-292).  Returns None when the kernel does not apply."""
+    if not (_linln_fused and _split_linear and x.is_cuda and x.dtype == torch.float32):
+        return None
+    w = linear.weight
+    if tuple(w.shape) != (256, 256) or x.shape[-1] != 256 or x.numel() == 0:
+        return None
+    if not (w.dtype == torch.float32 and w.is_contiguous() and w.device == x.device
+            and norm.elementwise_affine and tuple(norm.normalized_shape) == (256,)):
+        return None
+    x2 = x.reshape(-1, 256)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    M = x2.shape[0]
+    if M < _LINLN_MIN_ROWS or (M + 128) * 1024 > 0xFFFFFFFF:
+        return None
+    if not all(v is None or _param_ok(v, x) for v in (linear.bias, norm.weight, norm.bias)):
+        return None
+    if residual.dtype != torch.float32 or residual.device != x.device or residual.numel() != x2.numel():
+        return None
+    residual = residual.reshape(-1, 256)
+    if not residual.is_contiguous():
+        residual = residual.contiguous()
+    if (x2.data_ptr() | residual.data_ptr()) & 15:
+        return None
+    packed = _packed_weight(w, None)
+    if packed is None:
+        return None
+    with torch.cuda.device(x.device):
+        y = torch.empty((M, 256), dtype=torch.float32, device=x.device)
+        rc = _cabi.lib().tf_linear_res_ln_f32(x2.data_ptr(), packed.data_ptr(), 0 if linear.bias is None else linear.bias.data_ptr(),
+                                              residual.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
+                                              y.data_ptr(), M, 256, 256, _stream(x.device))
+    _cabi.check(rc, "tf_linear_res_ln_f32")
+    return y.view(x.shape)
+
+
 def conv3x3(x, w_taps, bias, relu, stride):
     """3 x 3 convolution (padding 1) -- or, with a [Cout, Cin] weight, a strided 1 x 1 convolution without padding -- of a
     channels_last fp32 GPU activation through tf_conv3x3_split_f32 / tf_conv1x1_strided_split_f32.

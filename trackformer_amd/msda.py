@@ -238,6 +238,14 @@ class MSDeformAttnFunction(Function):
         return grad_value, None, grad_sampling_loc, grad_attn_weight, None
 
 
+class _Normed:
+    """Marker: MSDeformAttn._forward already applied the caller's residual add and LayerNorm."""
+    __slots__ = ("value",)
+
+    def __init__(self, value):
+        self.value = value
+
+
 class MSDeformAttn(nn.Module):
     """Same constructor, parameters (state_dict keys) and forward contract as the reference module
     (modules/ms_deform_attn.py:16-89)."""
@@ -281,10 +289,22 @@ class MSDeformAttn(nn.Module):
         constant_(self.output_proj.bias.data, 0.)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_padding_mask=None, query_attn_mask=None):
+                input_padding_mask=None, query_attn_mask=None, residual_norm=None):
         """query[N,Lq,C], reference_points[N,Lq,L,2|4] in [0,1], input_flatten[N,S,C],
         input_spatial_shapes[L,2] (H_l,W_l), input_padding_mask[N,S] (True = padding)
-        -> [N,Lq,C]   (modules/ms_deform_attn.py:49-89)."""
+        -> [N,Lq,C]   (modules/ms_deform_attn.py:49-89).
+        residual_norm = (residual, nn.LayerNorm) (an extension used by the inference path of the layers): return
+        norm(residual + attention output) instead -- the output projection, the add and the norm can then be one launch."""
+        if residual_norm is not None:
+            out = self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask,
+                                query_attn_mask, residual_norm)
+            if isinstance(out, _Normed):
+                return out.value
+            return fused.residual_norm(residual_norm[0], out, residual_norm[1], True)
+        return self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask, query_attn_mask, None)
+
+    def _forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask, query_attn_mask,
+                 residual_norm):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         hs = _host_shapes_of(input_spatial_shapes)
@@ -312,6 +332,10 @@ class MSDeformAttn(nn.Module):
                 qproj = F.linear(query, w, b)
             output = ms_deform_attn_forward_fused(value, input_spatial_shapes, reference_points,
                                                   qproj, M, L, P)
+            if residual_norm is not None:
+                y = fused.linear_residual_norm(output, self.output_proj, residual_norm[0], residual_norm[1])
+                if y is not None:
+                    return _Normed(y)
             return fused.module_linear(self.output_proj, output, True)
 
         sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
