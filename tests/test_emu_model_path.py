@@ -102,7 +102,8 @@ def test_training_step_through_the_emulated_kernels(sorted2):
     assert calls.get("tf_msda_backward_f32", 0) >= 5 and calls.get("tf_msda_forward_f32", 0) >= 5
 
 
-@pytest.mark.skipif((shared.os.cpu_count() or 1) < 6, reason="two minutes on 8 cores; tools/emu_full_size.py runs it anywhere")
+@pytest.mark.skipif(shared.os.environ.get("TF_EMU_FULL") != "1",
+                    reason="two minutes on 8 cores: TF_EMU_FULL=1, or tools/emu_full_size.py (profiles/r02_emulator_full_size_parity.txt)")
 def test_full_size_cfg2_model_on_the_emulator_with_every_opt_in_route():
     """BASELINE cfg 2 (800 x 1333, 300 object + 100 track queries) through the emulated GPU path with every opt-in route
     on, against the full-size golden of the reference's own classes -- tests/test_full_size_gpu.py's comparison without
