@@ -648,3 +648,32 @@ def test_linear_residual_layernorm_in_one_launch(M, ti):
     assert np.abs(yl[:M] - emu_lib.add_layernorm(ref, None, g, be, 1e-5)).max() < 5e-6
     st = emu_lib.stats()
     assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+
+
+def test_one_launch_blocks_validate_their_arguments():
+    """tf_ffn_fused_f32 / tf_linear_res_ln_f32: NULL pointers, unsupported sizes, a LayerNorm weight without its bias and
+    misaligned pointers come back as status codes (tf_msda.h) before anything is launched."""
+    import ctypes
+    L = emu_lib.lib()
+    buf = emu_lib._aligned(np.zeros((64, 256), np.float32))
+    wp = emu_lib._packed(np.zeros((256, 256), np.float32))
+    w1 = emu_lib._packed(np.zeros((128, 256), np.float32))
+    w2 = emu_lib._packed(np.zeros((256, 128), np.float32))
+    y = emu_lib._aligned(np.zeros((64, 256), np.float32))
+    p, f0 = (lambda a: a.ctypes.data), ctypes.c_float(1e-5)
+    NULLP, BAD = -1, -2
+    lin = lambda x=p(buf), w=p(wp), b=None, r=None, g=None, be=None, out=p(y), M=64, K=256, N=256: \
+        L.tf_linear_res_ln_f32(x, w, b, r, g, be, f0, out, M, K, N, None)
+    assert lin() == 0
+    assert lin(x=None) == NULLP and lin(w=None) == NULLP and lin(out=None) == NULLP
+    assert lin(g=p(buf)) == NULLP                       # LayerNorm weight without bias
+    assert lin(M=0) == BAD and lin(K=288) == BAD and lin(N=128) == BAD
+    assert lin(x=p(buf) + 4) == BAD and lin(r=p(buf) + 8) == BAD   # not 16-byte aligned
+    assert lin(M=(1 << 22)) == BAD                      # 32-bit buffer offsets
+    ffn = lambda x=p(buf), a=p(w1), c=p(w2), out=p(y), M=64, D=256, F=128, g=None, be=None: \
+        L.tf_ffn_fused_f32(x, a, None, c, None, None, g, be, f0, out, M, D, F, None)
+    assert ffn() == 0
+    assert ffn(x=None) == NULLP and ffn(a=None) == NULLP and ffn(c=None) == NULLP and ffn(out=None) == NULLP
+    assert ffn(be=p(buf)) == NULLP
+    assert ffn(M=-1) == BAD and ffn(D=128) == BAD and ffn(F=64) == BAD and ffn(F=192) == BAD
+    assert ffn(out=p(y) + 4) == BAD

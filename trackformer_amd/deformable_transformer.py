@@ -196,15 +196,32 @@ class DeformableTransformer(nn.Module):
         return torch.stack([valid_w.float() / W, valid_h.float() / H], -1)
 
     # ------------------------------------------------------------------ forward
+    def _level_position_embedding(self, pos_embeds):
+        """cat_l(pos_l flattened + level_embed[l]) (deformable_transformer.py:139-156 of the reference).  In inference the
+        position encodings of an unpadded frame are cached tensors (position_encoding.py), so the result is a per-geometry
+        constant: it is kept as long as the very same tensors (and the same level_embed contents) come in."""
+        def compute():
+            return torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
+                              for lvl, p in enumerate(pos_embeds)], 1)
+        if self.training or torch.is_grad_enabled():
+            return compute()
+        key = tuple((id(p), p._version) for p in pos_embeds) + (self.level_embed._version, self.level_embed.data_ptr())
+        hit = self.__dict__.get("_lvl_pos_cache")
+        if hit is None or hit[0] != key:
+            if pos_embeds[0].is_cuda and torch.cuda.is_current_stream_capturing():
+                return compute()   # never keep a buffer of a graph's memory pool
+            # the inputs are kept alive next to the result: an id() in the key can then not be reused by another tensor
+            hit = (key, compute(), list(pos_embeds))
+            self.__dict__["_lvl_pos_cache"] = hit
+        return hit[1]
+
     def forward(self, srcs, masks, pos_embeds, query_embed=None, targets=None):
         assert self.two_stage or query_embed is not None
 
         shapes = tuple((int(s.shape[2]), int(s.shape[3])) for s in srcs)
         device = srcs[0].device
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
-        lvl_pos_embed_flatten = torch.cat(
-            [p.flatten(2).transpose(1, 2) + self.level_embed[lvl].view(1, 1, -1)
-             for lvl, p in enumerate(pos_embeds)], 1)
+        lvl_pos_embed_flatten = self._level_position_embedding(pos_embeds)
         unpadded = all(is_all_valid(m) for m in masks)
         if unpadded:
             # nothing is padded: the flattened mask is all False -> skip it entirely (masked_fill with
