@@ -568,6 +568,7 @@ def main():
         fused.set_box_refine_fused(True)
         fused.set_ffn_fused(True)
         fused.set_linear_ln_fused(True)
+        fused.set_stem_pool_fused(True)
 
     if args.roofline_only:
         if rank == 0:

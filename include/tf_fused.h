@@ -99,6 +99,15 @@ int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w
                                  int hin, int win, int cin, int cout, int stride, int relu, void *stream);
 
 /*
+ * out[n, oy, ox, c] = max over the 3 x 3 window (stride 2, padding 1) of relu(x[n, iy, ix, c] + bias[c]) on channels_last
+ * activations: FrozenBatchNorm2d shift + ReLU + MaxPool2d(3, 2, 1) after the backbone's first convolution (reference:
+ * models/backbone.py:45-55, torchvision ResNet.relu / .maxpool) in one pass.  x [N, H, W, C], out [N, (H - 1) / 2 + 1,
+ * (W - 1) / 2 + 1, C], C % 4 == 0, 16-byte aligned pointers.  Bit-identical to the separate passes (the shift and the ReLU
+ * are monotone per channel).
+ */
+int tf_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int N, int H, int W, int C, void *stream);
+
+/*
  * The same product with the weight in PACKED form (trackformer_amd/csrc/linear_stream.hip): the weight is split into
  * bf16 (hi, mid) once and stored in matrix-core fragment order, so that the GEMM streams it from L2 into registers and
  * only the activations pass through LDS.  Results are bit-identical to tf_linear_split_f32.

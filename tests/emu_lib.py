@@ -47,6 +47,8 @@ def lib():
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_add_layernorm_f32.restype = ci
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
+    L.tf_bias_relu_maxpool_f32.restype = ci
+    L.tf_bias_relu_maxpool_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_box_refine_f32.restype = ci
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_groupnorm_nhwc_f32.restype = ci
@@ -257,6 +259,17 @@ def linear_res_ln(x, w, bias=None, residual=None, ln=None, eps=1e-5, guard_rows=
     if rc != 0:
         raise RuntimeError("tf_linear_res_ln_f32: status %d" % rc)
     return y
+
+
+def bias_relu_maxpool(x_nhwc, bias):
+    """tf_bias_relu_maxpool_f32: x [N, H, W, C] -> [N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C]."""
+    x, b = _aligned(x_nhwc), _aligned(bias)
+    N, H, W, C = x.shape
+    out = _aligned(np.full((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), np.nan, np.float32))
+    rc = lib().tf_bias_relu_maxpool_f32(_p(x), _p(b), _p(out), N, H, W, C, None)
+    if rc != 0:
+        raise RuntimeError("tf_bias_relu_maxpool_f32: status %d" % rc)
+    return out
 
 
 def mha_core(q, k, v, scale, key_mask=None):

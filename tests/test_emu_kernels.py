@@ -677,3 +677,16 @@ def test_one_launch_blocks_validate_their_arguments():
     assert ffn(be=p(buf)) == NULLP
     assert ffn(M=-1) == BAD and ffn(D=128) == BAD and ffn(F=64) == BAD and ffn(F=192) == BAD
     assert ffn(out=p(y) + 4) == BAD
+
+
+@pytest.mark.parametrize("n,h,w,c", [(1, 20, 33, 64), (2, 7, 8, 8), (1, 1, 1, 4), (1, 2, 5, 12)], ids=lambda v: str(v))
+def test_bias_relu_maxpool_equals_the_separate_passes(n, h, w, c):
+    """tf_bias_relu_maxpool_f32 (opt-in stem route): bit-identical to relu(x + b) followed by torch's MaxPool2d(3, 2, 1)."""
+    import torch
+    rng = np.random.default_rng(h * w + c)
+    x = rng.standard_normal((n, h, w, c), dtype=np.float32)
+    b = rng.standard_normal(c, dtype=np.float32)
+    ref = torch.nn.functional.max_pool2d(torch.relu(torch.from_numpy(x).permute(0, 3, 1, 2) + torch.from_numpy(b).view(1, -1, 1, 1)),
+                                         3, 2, 1).permute(0, 2, 3, 1).numpy()
+    got = emu_lib.bias_relu_maxpool(x, b)
+    assert got.shape == ref.shape and np.array_equal(got, ref)

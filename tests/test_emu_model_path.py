@@ -24,6 +24,7 @@ def _run(case, optin, fn=None):
                     (fused.set_box_refine_fused, fused.set_box_refine_fused(True)),
                     (fused.set_ffn_fused, fused.set_ffn_fused(True)),
                     (fused.set_linear_ln_fused, fused.set_linear_ln_fused(True)),
+                    (fused.set_stem_pool_fused, fused.set_stem_pool_fused(True)),
                     (lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
                     (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
             fused._LINLN_MIN_ROWS = 1
@@ -55,7 +56,7 @@ def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
     if optin:   # ResNet-50: 16 bottlenecks (their 3 x 3 and closing 1 x 1 convolutions), 3 projection levels, 6 decoder layers
         assert [calls.get(r) for r in routes] == [16, 16, 3, 6], calls
         assert calls.get("tf_conv1x1_strided_split_f32") == 3   # the strided projections of layer2..4
-        assert calls.get("tf_bias_act_f32", 0) <= 2          # the stem (and layer1's stride-1 projection goes through the GEMM)
+        assert calls.get("tf_bias_act_f32", 0) <= 1 and calls.get("tf_bias_relu_maxpool_f32") == 1   # the stem: shift + ReLU + pooling in one pass
     else:
         assert all(calls.get(r) is None for r in routes), calls
         assert calls.get("tf_bias_act_f32", 0) >= 50

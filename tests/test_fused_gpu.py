@@ -235,3 +235,18 @@ def test_optin_linear_residual_layernorm(rows, ti, monkeypatch):
         lib.tf_msda_set_option(b"linln_ti", prev_ti)
     assert got is not None
     assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
+
+
+@optin
+@pytest.mark.parametrize("shape", [(1, 64, 400, 667), (2, 64, 33, 20), (1, 8, 7, 9)])
+def test_optin_bias_relu_maxpool_bit_identical(shape):
+    """tf_bias_relu_maxpool_f32 (stem route): one pass instead of bias_act_ + MaxPool2d(3, 2, 1); same bits."""
+    from trackformer_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(shape[1], generator=g).to(dev)
+    ref = torch.nn.functional.max_pool2d(torch.relu(x + b.view(1, -1, 1, 1)), 3, 2, 1)
+    got = fused.bias_relu_maxpool(x, b)
+    assert got is not None and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, ref)

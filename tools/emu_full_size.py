@@ -34,6 +34,7 @@ def main():
             fused.set_box_refine_fused(True)
             fused.set_ffn_fused(True)        # the row limits of fused.ffn / linear_residual_norm stay: what bench.py would run
             fused.set_linear_ln_fused(True)
+            fused.set_stem_pool_fused(True)
             for k, v in ((b"linear_bufstore", 2), (b"linear_deep", 1), (b"pquad_pipe", 1), (b"direct9", 1), (b"mha_batch", 1)):
                 lib.tf_msda_set_option(k, v)
         with torch.no_grad():

@@ -176,6 +176,24 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
     return F.relu(x) if relu else x
 
 
+def _stem_pooled(x, conv1, bn1, maxpool, cache: _FoldCache):
+    """OPT-IN (fused.set_stem_pool_fused / TF_STEM_POOL_FUSED=1): conv1 (BN scale folded in) and then BN shift + ReLU +
+    MaxPool2d(3, 2, 1) in ONE pass over the convolution's output (tf_bias_relu_maxpool_f32; bit-identical to the separate
+    passes).  Returns None when the route is off or does not apply."""
+    if not (fused.stem_pool_fused_enabled() and x.is_cuda and CHANNELS_LAST and isinstance(bn1, FrozenBatchNorm2d)
+            and isinstance(maxpool, nn.MaxPool2d) and maxpool.kernel_size == 3 and maxpool.stride == 2
+            and maxpool.padding == 1 and maxpool.dilation == 1 and not maxpool.ceil_mode):
+        return None
+    w, b = cache.get(conv1, bn1)
+    y = F.conv2d(x, w, None, conv1.stride, conv1.padding, conv1.dilation, conv1.groups)
+    pooled = fused.bias_relu_maxpool(y, b)
+    if pooled is None:   # not applicable after all: the separate passes on the same convolution output
+        if fused.bias_act_(y, b, None, True) is None:
+            y = F.relu_(y + b.reshape(1, -1, 1, 1))
+        pooled = maxpool(y)
+    return pooled
+
+
 class Bottleneck(nn.Module):
     """ResNet v1.5 bottleneck: 1x1 reduce, 3x3 (carries the stride), 1x1 expand (x4), identity/projection."""
     expansion = 4
@@ -255,6 +273,10 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def stem(self, x):
+        if _inference_mode(self):
+            pooled = _stem_pooled(x, self.conv1, self.bn1, self.maxpool, self._stem_fold)
+            if pooled is not None:
+                return pooled
         x = _conv_bn(x, self.conv1, self.bn1, self._stem_fold, True, _inference_mode(self))
         return self.maxpool(x)
 
@@ -297,10 +319,18 @@ class IntermediateLayerGetter(nn.ModuleDict):
         out = OrderedDict()
         fold = _inference_mode(self)
         fused_stem = fold and all(k in self for k in ("conv1", "bn1", "relu"))
+        # opt-in: the stem's shift + ReLU + pooling in one pass (only when nobody asked for the intermediate maps)
+        pooled_stem = (fused_stem and "maxpool" in self
+                       and not any(k in self.return_layers for k in ("conv1", "bn1", "relu", "maxpool")))
+        skip = ()
         for name, module in self.items():
-            if fused_stem and name in ("bn1", "relu"):
+            if name in skip or (fused_stem and name in ("bn1", "relu")):
                 continue
             if fused_stem and name == "conv1":
+                pooled = _stem_pooled(x, self["conv1"], self["bn1"], self["maxpool"], self._fold) if pooled_stem else None
+                if pooled is not None:
+                    x, skip = pooled, ("maxpool",)
+                    continue
                 x = _conv_bn(x, self["conv1"], self["bn1"], self._fold, True, True)
             else:
                 x = module(x)

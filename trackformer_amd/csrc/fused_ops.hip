@@ -258,9 +258,67 @@ box_refine_kernel(const float *__restrict__ delta, const float *__restrict__ ref
     out[i] = 1.f / (1.f + expf(-v));
 }
 
+// ---- out = maxpool3x3/s2/p1(relu(x + bias[c])) on channels_last activations: the stem of the backbone after its 7 x 7
+// convolution (reference: models/backbone.py:45-55 FrozenBatchNorm2d shift, torchvision ResNet.relu + .maxpool).  x + bias and
+// ReLU are monotone per channel, so max_i relu(x_i + b) == relu(max_i(x_i) + b) bit for bit: ONE pass reads the convolution's
+// output and writes the 4x smaller pooled map, instead of an in-place bias pass and a pooling pass.  One thread per (output
+// pixel, 4 channels); a wave covers whole pixels' channel vectors (coalesced 16-byte accesses).
+__global__ void __launch_bounds__(256)
+bias_relu_maxpool_kernel(const float *__restrict__ x, const float *__restrict__ bias, float *__restrict__ out, int H, int W,
+                         int C4, int Ho, int Wo, long long total)
+{
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = (int)(idx % C4);
+    long long p = idx / C4;
+    const int ox = (int)(p % Wo);
+    p /= Wo;
+    const int oy = (int)(p % Ho);
+    const long long n = p / Ho;
+    const f32x4_t *xi = reinterpret_cast<const f32x4_t *>(x) + n * (long long)H * W * C4 + c4;
+    const float ninf = -__builtin_inff();
+    f32x4_t m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int iy = 2 * oy + dy;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ix = 2 * ox + dx;
+            if (ix < 0 || ix >= W) continue;
+            const f32x4_t v = xi[((long long)iy * W + ix) * C4];
+            m.x = v.x > m.x ? v.x : m.x;
+            m.y = v.y > m.y ? v.y : m.y;
+            m.z = v.z > m.z ? v.z : m.z;
+            m.w = v.w > m.w ? v.w : m.w;
+        }
+    }
+    const f32x4_t b = reinterpret_cast<const f32x4_t *>(bias)[c4];
+    m += b;
+    m.x = m.x > 0.f ? m.x : 0.f;
+    m.y = m.y > 0.f ? m.y : 0.f;
+    m.z = m.z > 0.f ? m.z : 0.f;
+    m.w = m.w > 0.f ? m.w : 0.f;
+    reinterpret_cast<f32x4_t *>(out)[idx] = m;
+}
+
 }  // namespace
 
 extern "C" {
+
+int tf_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int N, int H, int W, int C, void *stream)
+{
+    if (!x || !bias || !out) return TF_MSDA_ERR_NULL_POINTER;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return TF_MSDA_ERR_BAD_DIMS;
+    if (!aligned16(x) || !aligned16(bias) || !aligned16(out)) return TF_MSDA_ERR_BAD_DIMS;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    const long long blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
+    hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias,
+                       out, H, W, C / 4, Ho, Wo, total);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
 
 int tf_box_refine_f32(const float *delta, const float *ref, float *out, int64_t rows, int ref_dim, float eps, void *stream)
 {

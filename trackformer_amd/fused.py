@@ -338,6 +338,37 @@ def linear_residual_norm(x, linear, residual, norm):
     return y.view(x.shape)
 
 
+# OPT-IN (TF_STEM_POOL_FUSED=1 / set_stem_pool_fused(True)): FrozenBN shift + ReLU + MaxPool2d(3, 2, 1) after the stem
+# convolution in one pass (tf_bias_relu_maxpool_f32) instead of bias_act_ + F.max_pool2d; bit-identical.
+_stem_pool_fused = os.environ.get("TF_STEM_POOL_FUSED", "0") == "1"
+
+
+def stem_pool_fused_enabled():
+    return _stem_pool_fused
+
+
+def set_stem_pool_fused(on):
+    global _stem_pool_fused
+    prev, _stem_pool_fused = _stem_pool_fused, bool(on)
+    return prev
+
+
+def bias_relu_maxpool(x, bias):
+    """maxpool3x3/s2/p1(relu(x + bias[c])) of a channels_last [N, C, H, W] fp32 GPU tensor -> channels_last
+    [N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1], or None when the kernel does not apply."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and x.numel() > 0 and x.shape[1] % 4 == 0 and _param_ok(bias, x) and bias.numel() == x.shape[1]
+            and x.data_ptr() % 16 == 0):
+        return None
+    n, c, h, w = x.shape
+    with torch.cuda.device(x.device):
+        out = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=torch.float32, device=x.device,
+                          memory_format=torch.channels_last)
+        rc = _cabi.lib().tf_bias_relu_maxpool_f32(x.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w, c, _stream(x.device))
+    _cabi.check(rc, "tf_bias_relu_maxpool_f32")
+    return out
+
+
 def conv3x3(x, w_taps, bias, relu, stride):
     """3 x 3 convolution (padding 1) -- or, with a [Cout, Cin] weight, a strided 1 x 1 convolution without padding -- of a
     channels_last fp32 GPU activation through tf_conv3x3_split_f32 / tf_conv1x1_strided_split_f32.
