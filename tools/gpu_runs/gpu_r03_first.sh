@@ -56,6 +56,10 @@ TF_LINLN_TI=1 timeout 120 tools/bin/ffn_bench 400 128 | grep -A1 "tf_linear_res_
 } > $O/ffn_fused.txt 2>&1
 cat $O/ffn_fused.txt
 
+# 2d. the backbone's bottleneck convolutions shape by shape: library convolution + bias_act against the split-product routes
+timeout 600 python tools/bench_conv.py > $O/conv_per_layer.txt 2>&1
+cat $O/conv_per_layer.txt
+
 # 3. frames/s: default vs the backbone's 1x1 convolutions through the split GEMM; cfg 4 with direct9
 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_default.json 2> $O/bench_cfg2_default.err
 TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore.json 2> $O/bench_cfg2_bufstore.err
