@@ -83,3 +83,28 @@ def test_fold_cache_tap_major_weight_of_3x3_convolutions():
         cols = cols.view(2, 8, 9, -1).permute(0, 3, 2, 1).reshape(2, -1, 72)  # -> (tap, c) order
         y = (cols @ t.t() + b).permute(0, 2, 1).reshape(ref.shape)
         assert torch.allclose(y, ref, atol=1e-5)
+
+
+def test_per_shape_skip_list_of_the_split_routes():
+    """TF_CONV_SPLIT_SKIP / set_conv_split_skip: listed (cin, cout, kernel, stride) shapes keep the library convolution."""
+    import torch
+    from torch import nn
+    from trackformer_amd import backbone
+    assert backbone._parse_skip("64x64x3x1, 256x64x1x1") == frozenset({(64, 64, 3, 1), (256, 64, 1, 1)})
+    assert backbone._parse_skip("") == frozenset()
+    import pytest
+    with pytest.raises(ValueError):
+        backbone._parse_skip("64x64x3")
+    prev = backbone.set_conv_split_skip([(64, 64, 3, 1)])
+    try:
+        assert not backbone._split_route_allowed(nn.Conv2d(64, 64, 3, stride=1, padding=1))
+        assert backbone._split_route_allowed(nn.Conv2d(64, 64, 3, stride=2, padding=1))
+        assert backbone._split_route_allowed(nn.Conv2d(64, 256, 1))
+    finally:
+        backbone.set_conv_split_skip(prev)
+    # the CPU path is untouched by any of it
+    conv, bn = nn.Conv2d(8, 8, 3, padding=1, bias=False), backbone.FrozenBatchNorm2d(8)
+    x = torch.randn(1, 8, 5, 5)
+    with torch.no_grad():
+        y = backbone._conv_bn(x, conv, bn, backbone._FoldCache(), True, True)
+    assert torch.allclose(y, torch.relu(bn(conv(x))), atol=1e-6)

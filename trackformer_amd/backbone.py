@@ -46,6 +46,33 @@ _conv1x1_split = _os.environ.get("TF_CONV1X1_SPLIT", "0") == "1"
 _conv3x3_split = _os.environ.get("TF_CONV3X3_SPLIT", "0") == "1"
 
 
+# Per-shape exceptions to the two routes above: "cin x cout x kernel x stride" entries (TF_CONV_SPLIT_SKIP="64x64x3x1,256x64x1x1"
+# / set_conv_split_skip) keep the library convolution -- tools/bench_conv.py times every bottleneck shape both ways.
+def _parse_skip(text):
+    out = set()
+    for item in text.replace(" ", "").split(","):
+        if item:
+            parts = item.lower().split("x")
+            if len(parts) != 4 or not all(p.isdigit() for p in parts):
+                raise ValueError("TF_CONV_SPLIT_SKIP entries are cin x cout x kernel x stride, e.g. 64x64x3x1: %r" % item)
+            out.add(tuple(int(p) for p in parts))
+    return frozenset(out)
+
+
+_conv_split_skip = _parse_skip(_os.environ.get("TF_CONV_SPLIT_SKIP", ""))
+
+
+def set_conv_split_skip(shapes):
+    """shapes: iterable of (cin, cout, kernel, stride) that keep the library convolution; returns the previous set."""
+    global _conv_split_skip
+    prev, _conv_split_skip = _conv_split_skip, frozenset(tuple(int(v) for v in s) for s in shapes)
+    return prev
+
+
+def _split_route_allowed(conv):
+    return (conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.stride[0]) not in _conv_split_skip
+
+
 def set_conv3x3_split(on):
     """Route the bottlenecks' 3 x 3 convolutions through the split-product kernel (process-wide); returns the previous setting."""
     global _conv3x3_split
@@ -145,18 +172,19 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
     if fold and isinstance(bn, FrozenBatchNorm2d):
         w, b = cache.get(conv, bn)
         if x.is_cuda:
-            if (_conv1x1_split and cache.weight2d is not None and conv.stride == (1, 1) and conv.padding == (0, 0)
+            split_ok = _split_route_allowed(conv)   # False: this shape keeps the library convolution (TF_CONV_SPLIT_SKIP)
+            if (split_ok and _conv1x1_split and cache.weight2d is not None and conv.stride == (1, 1) and conv.padding == (0, 0)
                     and conv.groups == 1 and CHANNELS_LAST):
                 y = conv1x1_as_gemm(x, cache.weight2d, b, residual, relu,
                                     lambda x2, w2, bb, act, r2: fused.linear(x2, w2, bb, relu=act, residual=r2))
                 if y is not None:
                     return y
-            if (_conv1x1_split and cache.weight2d is not None and residual is None and conv.stride == (2, 2)
+            if (split_ok and _conv1x1_split and cache.weight2d is not None and residual is None and conv.stride == (2, 2)
                     and conv.padding == (0, 0) and conv.groups == 1 and CHANNELS_LAST):
                 y = fused.conv3x3(x, cache.weight2d, b, relu, 2)   # the strided projection of the identity branch
                 if y is not None:
                     return y
-            if (_conv3x3_split and cache.weight_taps is not None and residual is None and conv.padding == (1, 1)
+            if (split_ok and _conv3x3_split and cache.weight_taps is not None and residual is None and conv.padding == (1, 1)
                     and conv.dilation == (1, 1) and conv.groups == 1 and conv.stride in ((1, 1), (2, 2)) and CHANNELS_LAST):
                 y = fused.conv3x3(x, cache.weight_taps, b, relu, conv.stride[0])
                 if y is not None:
