@@ -133,13 +133,14 @@ int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias
  *                          linear2.weight [d_model, d_ffn] (K = d_ffn, N = d_model)
  *   b1 [d_ffn], b2 [d_model], residual [M, d_model]: each may be NULL;  ln_weight / ln_bias [d_model]: both or neither
  *   (neither: no LayerNorm);  y must not alias x or residual.
- * d_model == 256, d_ffn a multiple of 128, every pointer 16-byte aligned; anything else: TF_MSDA_ERR_BAD_DIMS.
+ * d_model == 256 or 288 (the reference's hidden sizes), d_ffn a multiple of 16 and >= 128, every pointer 16-byte aligned;
+ * anything else: TF_MSDA_ERR_BAD_DIMS.
  */
 /*
- * y[M, 256] = [LayerNorm]( residual + x[M, 256] . w^T + bias ) in one launch: the attention's output projection with the
+ * y[M, D] = [LayerNorm]( residual + x[M, D] . w^T + bias ), D = 256 or 288, in one launch: the attention's output projection with the
  * layer's residual add and norm1 (reference: models/ops/modules/ms_deform_attn.py:87 output_proj +
  * models/deformable_transformer.py:285-292).  Same split product as tf_linear_packed_f32 (bit-identical without the
- * LayerNorm); w_packed: tf_linear_pack_weight_f32 of the [256, 256] weight.  K == N == 256, pointers 16-byte aligned,
+ * LayerNorm); w_packed: tf_linear_pack_weight_f32 of the [D, D] weight.  K == N == D, pointers 16-byte aligned,
  * bias / residual may be NULL, ln_weight / ln_bias both or neither, y must not alias x or residual.
  */
 int tf_linear_res_ln_f32(const float *x, const void *w_packed, const float *bias, const float *residual, const float *ln_weight,

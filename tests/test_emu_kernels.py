@@ -558,9 +558,8 @@ def test_packed_linear_transposed_accumulators_wide_stores(M, K, N, bias):
 
 
 # ------------------------------------------------------------------ one-launch feed-forward block (opt-in, ffn_fused.hip)
-def _ffn_case(M, F, seed):
+def _ffn_case(M, F, seed, D=256):
     rng = np.random.default_rng(seed)
-    D = 256
     x = rng.standard_normal((M, D), dtype=np.float32)
     w1 = (rng.standard_normal((F, D), dtype=np.float32) / 16).astype(np.float32)
     b1 = (0.1 * rng.standard_normal(F, dtype=np.float32)).astype(np.float32)
@@ -667,7 +666,7 @@ def test_one_launch_blocks_validate_their_arguments():
     assert lin() == 0
     assert lin(x=None) == NULLP and lin(w=None) == NULLP and lin(out=None) == NULLP
     assert lin(g=p(buf)) == NULLP                       # LayerNorm weight without bias
-    assert lin(M=0) == BAD and lin(K=288) == BAD and lin(N=128) == BAD
+    assert lin(M=0) == BAD and lin(K=320, N=320) == BAD and lin(N=128) == BAD and lin(K=288) == BAD   # square, 256 or 288
     assert lin(x=p(buf) + 4) == BAD and lin(r=p(buf) + 8) == BAD   # not 16-byte aligned
     assert lin(M=(1 << 22)) == BAD                      # 32-bit buffer offsets
     ffn = lambda x=p(buf), a=p(w1), c=p(w2), out=p(y), M=64, D=256, F=128, g=None, be=None: \
@@ -675,7 +674,7 @@ def test_one_launch_blocks_validate_their_arguments():
     assert ffn() == 0
     assert ffn(x=None) == NULLP and ffn(a=None) == NULLP and ffn(c=None) == NULLP and ffn(out=None) == NULLP
     assert ffn(be=p(buf)) == NULLP
-    assert ffn(M=-1) == BAD and ffn(D=128) == BAD and ffn(F=64) == BAD and ffn(F=192) == BAD
+    assert ffn(M=-1) == BAD and ffn(D=128) == BAD and ffn(F=64) == BAD and ffn(F=200) == BAD   # F: >= one chunk, multiple of 16
     assert ffn(out=p(y) + 4) == BAD
 
 
@@ -690,3 +689,49 @@ def test_bias_relu_maxpool_equals_the_separate_passes(n, h, w, c):
                                          3, 2, 1).permute(0, 2, 3, 1).numpy()
     got = emu_lib.bias_relu_maxpool(x, b)
     assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("D,M,F,ti", [(288, 150, 1024, 2), (288, 70, 1024, 1), (288, 97, 1024, 3), (288, 40, 96, 1), (288, 33, 160, 2),
+                                      (256, 50, 192, 2)])
+def test_fused_ffn_hidden_288_and_ragged_hidden_widths(D, M, F, ti):
+    """The multi-frame models' hidden size (288: three waves x three output tiles, hidden chunks of 96) and hidden widths
+    that are not a multiple of the chunk (1024 = 10 x 96 + 64: the last chunk runs over zero-padded weight columns and
+    clamped W2 k-steps).  Bit-identical to the two packed linears + residual; LayerNorm epilogue against float64."""
+    x, w1, b1, w2, b2, g, be = _ffn_case(M, F, D + M + F, D=D)
+    # tf_linear_split_f32 (any K % 32 == 0) gives the packed kernel's bits: the reference for K = 288 / ragged widths
+    ref = emu_lib.linear_split(emu_lib.linear_split(x, w1, b1, True), w2, b2) + x
+    prev = emu_lib.set_options(ffn_ti=ti)
+    try:
+        y = emu_lib.ffn_fused(x, w1, b1, w2, b2, residual=x, guard_rows=2)
+        yl = emu_lib.ffn_fused(x, w1, b1, w2, b2, residual=x, ln=(g, be), eps=1e-5, guard_rows=2)
+    finally:
+        emu_lib.set_options(**prev)
+    assert np.array_equal(y[:M], ref) and np.isnan(y[M:]).all() and np.isnan(yl[M:]).all()
+    p64 = ref.astype(np.float64)
+    ln64 = (p64 - p64.mean(1, keepdims=True)) / np.sqrt(p64.var(1, keepdims=True) + 1e-5) * g + be
+    assert np.abs(yl[:M] - ln64).max() < 5e-6 * max(1.0, np.abs(ln64).max())
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+
+
+@pytest.mark.parametrize("M,ti", [(150, 0), (70, 1), (97, 3), (64, 2)])
+def test_linear_residual_layernorm_hidden_288(M, ti):
+    rng = np.random.default_rng(M + 288)
+    D = 288
+    x = rng.standard_normal((M, D), dtype=np.float32)
+    w = (rng.standard_normal((D, D), dtype=np.float32) / 17).astype(np.float32)
+    b = rng.standard_normal(D, dtype=np.float32)
+    r = rng.standard_normal((M, D), dtype=np.float32)
+    g = (1 + 0.1 * rng.standard_normal(D, dtype=np.float32)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(D, dtype=np.float32)).astype(np.float32)
+    f64 = x.astype(np.float64) @ w.T.astype(np.float64) + b + r
+    prev = emu_lib.set_options(linln_ti=ti)
+    try:
+        y = emu_lib.linear_res_ln(x, w, b, r, guard_rows=3)
+        yl = emu_lib.linear_res_ln(x, w, b, r, ln=(g, be), guard_rows=3)
+    finally:
+        emu_lib.set_options(**prev)
+    ref = emu_lib.linear_split(x, w, b) + r        # K = 288 is not a multiple of 64: the unpacked kernel is the reference here
+    assert np.array_equal(y[:M], ref) and np.isnan(y[M:]).all() and np.isnan(yl[M:]).all()
+    assert np.abs(ref - f64).max() < 1e-4 * max(1.0, np.abs(f64).max())
+    assert np.abs(yl[:M] - emu_lib.add_layernorm(ref, None, g, be, 1e-5)).max() < 5e-6

@@ -71,11 +71,13 @@ def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
 def test_multi_frame_model_hidden_288_on_the_emulator():
     """cfg 4's model family (hidden 288: head dimension 36, two frames x 4 levels in the decoder, GroupNorm with 9 channels
     per group) through the GPU path with every opt-in route: msda_fwd_f32_pquad<.., 36>, msda_fwd_f32_direct9, the
-    K = 288 / 1152 deep-prefetch linears."""
+    K = 288 / 1152 deep-prefetch linears, ffn_fused_kernel<288, ..> / linear_res_ln_kernel<288, ..>."""
     case = "cfg4_multi_frame_tracking"
     model, out, res, feats, calls = _run(case, True)
     shared.compare_to_golden(case, model, out, res, feats, box_tol=2e-4, logit_tol=1e-3)
     assert calls.get("tf_msda_forward_fused_f32", 0) >= 12 and calls.get("tf_groupnorm_nhwc_f32", 0) >= 3
+    # hidden 288: the one-launch feed-forward blocks and projection + norm launches in their three-wave geometry
+    assert calls.get("tf_ffn_fused_f32", 0) >= 12 and calls.get("tf_linear_res_ln_f32", 0) >= 18 and calls.get("tf_add_layernorm_f32", 0) == 0
 
 
 def test_tracker_sequence_ids_on_the_emulator_with_every_opt_in_route():

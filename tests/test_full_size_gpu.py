@@ -284,19 +284,23 @@ def test_optin_fused_box_refine_full_size(dev, models, case):
 
 
 @optin
-@pytest.mark.parametrize("case", [c for c in um.FULL_CASES if "cfg2" in c])
+@pytest.mark.parametrize("case", list(um.FULL_CASES))
 def test_optin_fused_ffn_route_full_size(dev, models, case):
-    """The encoder's feed-forward blocks in one launch each (fused.set_ffn_fused; tf_ffn_fused_f32, hidden 256): BASELINE-size
-    model against the reference goldens and, separately, the tracker's ids."""
+    """The feed-forward blocks in one launch each (fused.set_ffn_fused; tf_ffn_fused_f32) and output projection + residual +
+    LayerNorm in one launch (fused.set_linear_ln_fused; tf_linear_res_ln_f32), hidden 256 (cfg 2) and 288 (cfg 4):
+    BASELINE-size model against the reference goldens and, for cfg 2, the tracker's ids."""
     from trackformer_amd import fused
-    prev = fused.set_ffn_fused(True)
+    prev, prev_ln = fused.set_ffn_fused(True), fused.set_linear_ln_fused(True)
     try:
         model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
         dbox, dlogit = _compare(case, model, out, res, feats, memory)
-        print("%s / fused ffn: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+        print("%s / fused ffn + projection norm: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+        if "cfg2" not in case:
+            return
         tracker, rows, active = _run_tracker(models, dev, "graph_split_linear")
     finally:
         fused.set_ffn_fused(prev)
+        fused.set_linear_ln_fused(prev_ln)
     z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
     assert int(z["num_tracks"]) == tracker.track_num and z["active_per_frame"].tolist() == active
     np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])

@@ -177,8 +177,8 @@ def test_optin_bias_act_batched_bit_identical(shape, res, relu):
 
 
 @optin
-@pytest.mark.parametrize("rows,ti", [(22223, 3), (4100, 2), (97, 1)])
-def test_optin_fused_ffn_block(rows, ti, monkeypatch):
+@pytest.mark.parametrize("rows,ti,d", [(22223, 3, 256), (4100, 2, 256), (97, 1, 256), (22223, 2, 288), (150, 1, 288)])
+def test_optin_fused_ffn_block(rows, ti, d, monkeypatch):
     """tf_ffn_fused_f32 (fused.ffn): linear1 -> ReLU -> linear2 -> + residual in one launch equals the separate packed
     linears bit for bit (same split, same order of the matrix-core sums); with the LayerNorm in the epilogue it equals
     torch's LayerNorm of that up to rounding."""
@@ -186,11 +186,11 @@ def test_optin_fused_ffn_block(rows, ti, monkeypatch):
     lib = _cabi.lib()
     dev = torch.device("cuda:0")
     torch.manual_seed(rows)
-    l1, l2, norm = torch.nn.Linear(256, 1024).to(dev), torch.nn.Linear(1024, 256).to(dev), torch.nn.LayerNorm(256).to(dev)
+    l1, l2, norm = torch.nn.Linear(d, 1024).to(dev), torch.nn.Linear(1024, d).to(dev), torch.nn.LayerNorm(d).to(dev)
     with torch.no_grad():
-        norm.weight.add_(0.1 * torch.randn(256, device=dev))
-        norm.bias.add_(0.1 * torch.randn(256, device=dev))
-    x = torch.randn(1, rows, 256, device=dev)
+        norm.weight.add_(0.1 * torch.randn(d, device=dev))
+        norm.bias.add_(0.1 * torch.randn(d, device=dev))
+    x = torch.randn(1, rows, d, device=dev)
     monkeypatch.setattr(fused, "_FFN_FUSED_MIN_ROWS", 1)
     monkeypatch.setattr(fused, "_PACKED_MIN_ROWS", 0)   # the reference below through tf_linear_packed_f32 at every size
     prev_on, prev_ti = fused.set_ffn_fused(True), lib.tf_msda_set_option(b"ffn_ti", ti)
@@ -211,19 +211,19 @@ def test_optin_fused_ffn_block(rows, ti, monkeypatch):
 
 
 @optin
-@pytest.mark.parametrize("rows,ti", [(22223, 0), (22223, 3), (400, 0), (97, 2)])
-def test_optin_linear_residual_layernorm(rows, ti, monkeypatch):
+@pytest.mark.parametrize("rows,ti,d", [(22223, 0, 256), (22223, 3, 256), (400, 0, 256), (97, 2, 256), (22223, 0, 288), (800, 0, 288)])
+def test_optin_linear_residual_layernorm(rows, ti, d, monkeypatch):
     """tf_linear_res_ln_f32 (fused.linear_residual_norm): output projection + residual + LayerNorm in one launch against
     the split-product linear followed by torch's add and LayerNorm."""
     from trackformer_amd import _cabi, fused
     lib = _cabi.lib()
     dev = torch.device("cuda:0")
     torch.manual_seed(rows + ti)
-    lin, norm = torch.nn.Linear(256, 256).to(dev), torch.nn.LayerNorm(256).to(dev)
+    lin, norm = torch.nn.Linear(d, d).to(dev), torch.nn.LayerNorm(d).to(dev)
     with torch.no_grad():
-        norm.weight.add_(0.1 * torch.randn(256, device=dev))
-        norm.bias.add_(0.1 * torch.randn(256, device=dev))
-    x, res = torch.randn(1, rows, 256, device=dev), torch.randn(1, rows, 256, device=dev)
+        norm.weight.add_(0.1 * torch.randn(d, device=dev))
+        norm.bias.add_(0.1 * torch.randn(d, device=dev))
+    x, res = torch.randn(1, rows, d, device=dev), torch.randn(1, rows, d, device=dev)
     monkeypatch.setattr(fused, "_LINLN_MIN_ROWS", 1)
     prev_on, prev_ti = fused.set_linear_ln_fused(True), lib.tf_msda_set_option(b"linln_ti", ti)
     try:

@@ -1,7 +1,8 @@
 // tools/ffn_bench.cpp -- standalone (no Python, no torch) parity + timing harness for tf_ffn_fused_f32 (include/tf_fused.h):
 // the feed-forward block of a transformer layer, y = LayerNorm(x + relu(x W1^T + b1) W2^T + b2), in one launch.
 //
-//   tools/bin/ffn_bench [M [d_ffn [TI]]]       (built by trackformer_amd/build.py; default 22223 1024 3: the cfg-2 encoder)
+//   tools/bin/ffn_bench [M [d_ffn [TI [d_model]]]]   (built by trackformer_amd/build.py; default 22223 1024 3 256: the cfg-2
+//   encoder; d_model 288: the multi-frame models, whose separate path is tf_linear_split_f32 -- K = 288 is not a multiple of 64)
 //
 // 1. without LayerNorm: compared BIT FOR BIT with tf_linear_packed_f32 (relu) -> tf_linear_packed_f32 -> + x
 //    (the separate kernels of the default path), rows behind M checked untouched;
@@ -42,7 +43,7 @@
 
 int main(int argc, char **argv)
 {
-    const int M = argc > 1 ? atoi(argv[1]) : 22223, F = argc > 2 ? atoi(argv[2]) : 1024, D = 256;
+    const int M = argc > 1 ? atoi(argv[1]) : 22223, F = argc > 2 ? atoi(argv[2]) : 1024, D = argc > 4 ? atoi(argv[4]) : 256;
     if (argc > 3) tf_msda_set_option("ffn_ti", atoi(argv[3]));
     const int guard = 128;   // rows behind M that nothing may write
     std::mt19937 rng(11);
@@ -73,9 +74,37 @@ int main(int argc, char **argv)
     TF(tf_linear_pack_weight_f32(dW1, dP1, D, F, s));
     TF(tf_linear_pack_weight_f32(dW2, dP2, F, D, s));
 
+    // the separate kernels: tf_linear_packed_f32 where it applies (K % 64 == 0), else tf_linear_split_f32 (same bits)
+    auto split_of = [&](const std::vector<float> &W, unsigned short **dhi, unsigned short **dmid) {
+        std::vector<unsigned short> hi(W.size()), mid(W.size());
+        for (size_t i = 0; i < W.size(); ++i) {
+            unsigned u;
+            float f = W[i];
+            memcpy(&u, &f, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            hi[i] = (unsigned short)(u >> 16);
+            unsigned hu = (unsigned)hi[i] << 16;
+            float hf;
+            memcpy(&hf, &hu, 4);
+            float r = W[i] - hf;
+            memcpy(&u, &r, 4);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            mid[i] = (unsigned short)(u >> 16);
+        }
+        CK(hipMalloc(dhi, W.size() * 2));
+        CK(hipMalloc(dmid, W.size() * 2));
+        CK(hipMemcpy(*dhi, hi.data(), W.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(*dmid, mid.data(), W.size() * 2, hipMemcpyHostToDevice));
+    };
+    unsigned short *dW1hi, *dW1mid, *dW2hi, *dW2mid;
+    split_of(W1, &dW1hi, &dW1mid);
+    split_of(W2, &dW2hi, &dW2mid);
+    auto lin1 = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dW1hi, dW1mid, dB1, dH, M, D, F, 1, s) : tf_linear_packed_f32(dX, dP1, dB1, dH, M, D, F, 1, s); };
+    auto lin2 = [&]() { return (F % 64) ? tf_linear_split_f32(dH, dW2hi, dW2mid, dB2, dY0, M, F, D, 0, s) : tf_linear_packed_f32(dH, dP2, dB2, dY0, M, F, D, 0, s); };
+
     // ---- 1. bit identity without the LayerNorm
-    TF(tf_linear_packed_f32(dX, dP1, dB1, dH, M, D, F, 1, s));
-    TF(tf_linear_packed_f32(dH, dP2, dB2, dY0, M, F, D, 0, s));
+    TF(lin1());
+    TF(lin2());
     CK(hipMemsetAsync(dY, 0xFF, (size_t)(M + guard) * D * 4, s));
     TF(tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, F, s));
     CK(hipStreamSynchronize(s));
@@ -160,8 +189,8 @@ int main(int argc, char **argv)
         return best * 1000.0 / iters;
     };
     const double us_sep = time_graph([&] {
-        tf_linear_packed_f32(dX, dP1, dB1, dH, M, D, F, 1, s);
-        tf_linear_packed_f32(dH, dP2, dB2, dY0, M, F, D, 0, s);
+        lin1();
+        lin2();
         tf_add_layernorm_f32(dX, dY0, dG, dBe, dY1, M, D, 1e-5f, s);
     });
     const double us_fused = time_graph([&] { tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, dG, dBe, 1e-5f, dY, M, D, F, s); });
@@ -174,7 +203,10 @@ int main(int argc, char **argv)
     up(&dWo, Wo);
     CK(hipMalloc(&dPo, (size_t)tf_linear_packed_bytes(D, D)));
     TF(tf_linear_pack_weight_f32(dWo, dPo, D, D, s));
-    TF(tf_linear_packed_f32(dX, dPo, dB2, dY0, M, D, D, 0, s));
+    unsigned short *dWohi, *dWomid;
+    split_of(Wo, &dWohi, &dWomid);
+    auto lino = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dWohi, dWomid, dB2, dY0, M, D, D, 0, s) : tf_linear_packed_f32(dX, dPo, dB2, dY0, M, D, D, 0, s); };
+    TF(lino());
     CK(hipMemsetAsync(dY, 0xFF, (size_t)(M + guard) * D * 4, s));
     TF(tf_linear_res_ln_f32(dX, dPo, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, D, s));
     CK(hipStreamSynchronize(s));
@@ -191,7 +223,7 @@ int main(int argc, char **argv)
         touched2 += u != 0xFFFFFFFFu;
     }
     const double us_lin_sep = time_graph([&] {
-        tf_linear_packed_f32(dX, dPo, dB2, dY0, M, D, D, 0, s);
+        lino();
         tf_add_layernorm_f32(dX, dY0, dG, dBe, dY1, M, D, 1e-5f, s);
     });
     const double us_lin_fused = time_graph([&] { tf_linear_res_ln_f32(dX, dPo, dB2, dX, dG, dBe, 1e-5f, dY, M, D, D, s); });

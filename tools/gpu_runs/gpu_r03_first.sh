@@ -53,6 +53,10 @@ for ti in 1 2 3; do
     TF_LINLN_TI=$ti timeout 120 tools/bin/ffn_bench 22223 128 | grep -A1 "tf_linear_res_ln_f32"
 done
 TF_LINLN_TI=1 timeout 120 tools/bin/ffn_bench 400 128 | grep -A1 "tf_linear_res_ln_f32"
+for ti in 1 2; do
+    echo "## hidden 288 (cfg 4), $ti row tiles per block"
+    TF_LINLN_TI=$ti timeout 120 tools/bin/ffn_bench 22223 1024 $ti 288
+done
 } > $O/ffn_fused.txt 2>&1
 cat $O/ffn_fused.txt
 
@@ -74,10 +78,11 @@ TF_BOX_REFINE_FUSED=1 TF_MHA_BATCH=1 TF_BIAS_ACT_BATCH=1 timeout 240 python benc
 TF_ALL_OPTIN=1 TF_LINEAR_BUFSTORE=2 TF_LINEAR_DEEP=1 TF_MHA_BATCH=1 TF_MSDA_PQUAD="pipe=1" timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_all_optin.json 2> $O/bench_cfg2_all_optin.err
 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_default.json 2> $O/bench_cfg4_default.err
 TF_MSDA_DIRECT9=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_direct9.json 2> $O/bench_cfg4_direct9.err
+TF_FFN_FUSED=1 TF_LINLN_FUSED=1 timeout 240 python bench.py --config cfg4 --no-cpu-baseline --no-roofline > $O/bench_cfg4_ffn_linln.json 2> $O/bench_cfg4_ffn_linln.err
 timeout 300 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5_default.json 2> $O/bench_cfg5_default.err
 TF_LAZY_MASKS=1 timeout 300 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5_lazy_masks.json 2> $O/bench_cfg5_lazy_masks.err
 cat $O/bench_cfg5_default.json $O/bench_cfg5_lazy_masks.json | cut -c1-260
-cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_ffn_fused.json $O/bench_cfg2_ffn_linln.json $O/bench_cfg2_stem_pool.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json | cut -c1-260
+cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_ffn_fused.json $O/bench_cfg2_ffn_linln.json $O/bench_cfg2_stem_pool.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json $O/bench_cfg4_ffn_linln.json | cut -c1-260
 
 # 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)
 {

@@ -33,7 +33,8 @@
 //     with 8-byte writes, the output to HBM with 16-byte buffer stores (rows >= M fall outside the resource), the
 //     LayerNorm's row sums are 32 adds and one cross-half shuffle per lane, plus an LDS exchange between the 4 waves.
 //
-// Per block and wave: 8 chunks x (16 + 8) k-steps x 9 / 18 MFMAs = 2304 MFMAs of 32 cycles = 30.7 us at 2.4 GHz: the
+// Hidden 288 (the multi-frame models) runs the same kernel in a three-wave geometry (struct Geo below); the numbers here are
+// for hidden 256.  Per block and wave: 8 chunks x (16 + 8) k-steps x 9 / 18 MFMAs = 2304 MFMAs of 32 cycles = 30.7 us at 2.4 GHz: the
 // kernel's floor is the matrix pipe (the three-term product costs 3x the bf16 flops); LDS reads (144 b128 per chunk and
 // wave) are half of that, the weight stream 28 B/clk/CU of the 64 the vector memory path has.
 #include <hip/hip_runtime.h>
@@ -56,57 +57,98 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-constexpr int kThreads = 256;
-constexpr int kD = 256;               // d_model: K of GEMM 1, N of GEMM 2
-constexpr int kXStride = kD + 8;      // bf16 per LDS row of the activation tile: 528 B (conflict-free fragment reads)
-constexpr int kChunk = 128;           // hidden columns per chunk (4 waves x one 32-wide MFMA tile)
-constexpr int kHStride = kChunk + 8;  // 272 B
-constexpr int kKQ1 = kD / 16;         // k-steps of GEMM 1
-constexpr int kRing = 8, kAhead = 6;  // weight units (4 KB per wave each) in the ring / prefetch distance
+// Geometry per hidden size.  256: four waves, each two of the eight output tiles, hidden chunks of 128.  288 (the multi-frame
+// models: 9 output tiles): THREE waves of three tiles, hidden chunks of 96 -- the last chunk of a hidden width that is not a
+// multiple of the chunk runs past it: the W1 tile index and the W2 k-step are clamped to the last ones the packed weights
+// hold, and the hidden values of columns >= d_ffn are set to zero before they are split (0 x finite weight = 0 in GEMM 2).
+template <int D>
+struct Geo {
+    static_assert(D == 256 || D == 288, "hidden sizes of the reference's configurations");
+    static constexpr int NW = D == 256 ? 4 : 3;        // waves per block
+    static constexpr int NT = NW * 64;                 // threads per block
+    static constexpr int TJ = D / 32 / NW;             // output tiles per wave
+    static constexpr int XS = D + 8;                   // bf16 per LDS row of the activation tile (528 / 592 B: 16-byte aligned)
+    static constexpr int CH = NW * 32;                 // hidden columns per chunk: one 32-wide MFMA tile per wave
+    static constexpr int HS = CH + 8;                  // bf16 per LDS row of the hidden tile
+    static constexpr int KQ1 = D / 16;                 // k-steps of GEMM 1
+    static constexpr int U1 = KQ1 / 2;                 // weight units of GEMM 1 per chunk (two k-steps of one tile each)
+    static constexpr int U2 = CH / 16;                 // weight units of GEMM 2 per chunk (one k-step of TJ tiles each)
+    static constexpr int UPC = U1 + U2;                // 16 / 15
+    static constexpr int US = 2 * TJ > 4 ? 2 * TJ : 4; // 16-byte pieces per lane and unit
+    static constexpr int RING = D == 256 ? 8 : 5;      // units in the ring (divides UPC: a unit's slot is a compile-time constant)
+    static constexpr int AHEAD = RING - 2;             // prefetch distance
+    static_assert(TJ * NW * 32 == D && KQ1 % 2 == 0 && UPC % RING == 0, "geometry");
+};
 
-constexpr size_t ffn_lds_bytes(int ti) { return (size_t)(32 * ti) * (kXStride + kHStride) * 2 * 2; }
-
-// ---- the block's activation tile (32 TI rows x 256 k) -> LDS as bf16 hi / mid.  All of its global loads are in flight
-// before the first conversion waits.  The caller issues the barrier.
-template <int TI>
-__device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, int m0, unsigned short *sXhi, unsigned short *sXmid,
-                                           int wave, int lane)
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f)
 {
-    constexpr int NV = TI * 32 * (kD / 4) / kThreads;   // float4 of X per thread: a wave covers one row (1 KB) per step
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f)   // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
+{
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int D>
+constexpr size_t ffn_lds_bytes(int ti) { return (size_t)(32 * ti) * (Geo<D>::XS + Geo<D>::HS) * 2 * 2; }
+
+// ---- the block's activation tile (32 TI rows x D) -> LDS as bf16 hi / mid.  All of its global loads are in flight before the
+// first conversion waits.  The caller issues the barrier.
+template <int D, int TI>
+__device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, int m0, unsigned short *sXhi, unsigned short *sXmid, int tid)
+{
+    using G = Geo<D>;
+    constexpr int C4 = D / 4, NV = TI * 32 * C4 / G::NT;   // float4 per row / per thread
+    static_assert(TI * 32 * C4 % G::NT == 0, "tile does not divide among the threads");
     f32x4 xr[NV];
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
-        const int grow = min(m0 + it * 4 + wave, M - 1);   // rows past M read the last row, never stored
-        xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * kD + lane * 4);
+        const int idx = it * G::NT + tid;
+        const int row = idx / C4, c4 = idx - row * C4;
+        const int grow = min(m0 + row, M - 1);   // rows past M read the last row, never stored
+        xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * D + c4 * 4);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = 0; it < NV; ++it) {
-        const int row = it * 4 + wave;
+        const int idx = it * G::NT + tid;
+        const int row = idx / C4, c4 = idx - row * C4;
         bf16x4 hi, mid;   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             hi[e] = (__bf16)xr[it][e];
             mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
         }
-        *reinterpret_cast<bf16x4 *>(&sXhi[row * kXStride + lane * 4]) = hi;
-        *reinterpret_cast<bf16x4 *>(&sXmid[row * kXStride + lane * 4]) = mid;
+        *reinterpret_cast<bf16x4 *>(&sXhi[row * G::XS + c4 * 4]) = hi;
+        *reinterpret_cast<bf16x4 *>(&sXmid[row * G::XS + c4 * 4]) = mid;
     }
 }
 
-// ---- the epilogue both kernels share: + bias + residual [-> LayerNorm] -> Y.  accy: transposed 32 x 32 tiles (lane -> output
-// row m0 + 32 i + (lane & 31); registers 4 g .. 4 g + 3 of tile j -> columns 64 wave + 32 j + 8 g + 4 (lane >> 5) + 0..3);
-// v: the residual values in the same layout on entry.  sRed: [2 passes][4 waves][BM] floats of LDS that alias a tile every
-// wave has finished reading once it reaches the first barrier in here.  Rows >= M: stores are dropped by the buffer resource.
-template <int TI, bool LN>
-__device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][2], f32x4 (&v)[TI][2][4], const __amdgpu_buffer_rsrc_t b2rs,
-                                              const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                              const __amdgpu_buffer_rsrc_t yrs, float *sRed, int m0, int wave, int lane)
+// sum of the NW waves' partial row sums, pairwise as ((0 + 1) + (2 + 3)) / ((0 + 1) + 2)
+template <int NW>
+__device__ __forceinline__ float wave_partials(const float *s, int stride)
 {
-    constexpr int BM = TI * 32;
-    const int frow = lane & 31, cbase = wave * 64 + 4 * (lane >> 5);
+    if constexpr (NW == 4) return (s[0] + s[stride]) + (s[2 * stride] + s[3 * stride]);
+    else return (s[0] + s[stride]) + s[2 * stride];
+}
+
+// ---- the epilogue both kernels share: + bias + residual [-> LayerNorm] -> Y.  accy: transposed 32 x 32 tiles (lane -> output
+// row m0 + 32 i + (lane & 31); registers 4 g .. 4 g + 3 of tile j -> columns 32 TJ wave + 32 j + 8 g + 4 (lane >> 5) + 0..3);
+// v: the residual values in the same layout on entry.  sRed: [2 passes][NW waves][BM] floats of LDS that alias a tile every
+// wave has finished reading once it reaches the first barrier in here.  Rows >= M: stores are dropped by the buffer resource.
+template <int D, int TI, bool LN>
+__device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][Geo<D>::TJ], f32x4 (&v)[TI][Geo<D>::TJ][4],
+                                              const __amdgpu_buffer_rsrc_t b2rs, const float *__restrict__ gamma,
+                                              const float *__restrict__ beta, float eps, const __amdgpu_buffer_rsrc_t yrs, float *sRed,
+                                              int m0, int wave, int lane)
+{
+    using G = Geo<D>;
+    constexpr int BM = TI * 32, TJ = G::TJ, NW = G::NW;
+    const int frow = lane & 31, cbase = wave * (32 * TJ) + 4 * (lane >> 5);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TJ; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b2rs, (unsigned)(cbase + 32 * j + 8 * g) * 4u, 0, 0));
@@ -116,14 +158,14 @@ __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][2], f32x4
                 for (int e = 0; e < 4; ++e) v[i][j][g][e] = (accy[i][j][4 * g + e] + b[e]) + v[i][j][g][e];
         }
     if constexpr (LN) {
-        // two-pass statistics over the 256 columns of a row: 32 values in this lane, 32 in lane ^ 32, the rest in the
-        // other three waves (through LDS: the caller's scratch tile is free after the barrier)
+        // two-pass statistics over the D columns of a row: 16 TJ values in this lane, as many in lane ^ 32, the rest in the
+        // other waves (through LDS: the caller's scratch tile is free after the barrier)
         float s[TI];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) a += (v[i][j][g].x + v[i][j][g].y) + (v[i][j][g].z + v[i][j][g].w);
             s[i] = a + __shfl_xor(a, 32);
@@ -136,11 +178,10 @@ __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][2], f32x4
         float mean[TI], rstd[TI];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const int r = i * 32 + frow;
-            mean[i] = ((sRed[r] + sRed[BM + r]) + (sRed[2 * BM + r] + sRed[3 * BM + r])) * (1.f / kD);
+            mean[i] = wave_partials<NW>(sRed + i * 32 + frow, BM) * (1.f / D);
             float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 d = v[i][j][g] - mean[i];
@@ -150,15 +191,12 @@ __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][2], f32x4
         }
         if (lane < 32)
 #pragma unroll
-            for (int i = 0; i < TI; ++i) sRed[(4 + wave) * BM + i * 32 + lane] = s[i];
+            for (int i = 0; i < TI; ++i) sRed[(NW + wave) * BM + i * 32 + lane] = s[i];
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int r = 4 * BM + i * 32 + frow;
-            rstd[i] = rsqrtf(((sRed[r] + sRed[BM + r]) + (sRed[2 * BM + r] + sRed[3 * BM + r])) * (1.f / kD) + eps);
-        }
+        for (int i = 0; i < TI; ++i) rstd[i] = rsqrtf(wave_partials<NW>(sRed + NW * BM + i * 32 + frow, BM) * (1.f / D) + eps);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 ga = *reinterpret_cast<const f32x4 *>(gamma + cbase + 32 * j + 8 * g);
@@ -170,77 +208,74 @@ __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][2], f32x4
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i][j][g]), yrs,
-                                                       (unsigned)((m0 + i * 32 + frow) * kD + cbase + 32 * j + 8 * g) * 4u, 0, 0);
+                                                       (unsigned)((m0 + i * 32 + frow) * D + cbase + 32 * j + 8 * g) * 4u, 0, 0);
 }
 
-template <int TI, bool LN>
-__global__ void __launch_bounds__(kThreads, 1)
+template <int D, int TI, bool LN>
+__global__ void __launch_bounds__(Geo<D>::NT, 1)
 ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, const float *__restrict__ b1,
                  const u32x4 *__restrict__ W2p, const float *__restrict__ b2, const float *R,
                  const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *Y, int M, int F)
 {
-    constexpr int BM = TI * 32;
+    using G = Geo<D>;
+    constexpr int BM = TI * 32, TJ = G::TJ, NW = G::NW, XS = G::XS, HS = G::HS, RING = G::RING, UPC = G::UPC, U1 = G::U1, U2 = G::U2;
     extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
-    unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * kXStride;
-    unsigned short *const sHhi = sXmid + BM * kXStride, *const sHmid = sHhi + BM * kHStride;
+    unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * XS;
+    unsigned short *const sHhi = sXmid + BM * XS, *const sHmid = sHhi + BM * HS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
-    const int nchunks = F / kChunk, KQ2 = F >> 4;
+    const int nchunks = (F + G::CH - 1) / G::CH, KQ2 = F >> 4;
+    const int ntiles1 = (F + 255) / 256 * 8;   // hidden n-tiles the packed W1 holds (zero columns up to a multiple of 256)
 
-    // ---- the weight stream.  Unit u of chunk c (16 units per chunk, 4 x 16 bytes per lane each):
-    //   u < 8   GEMM 1: k-steps 2u, 2u + 1 (hi, mid each) of hidden n-tile 4c + wave of W1   [contiguous 4 KB]
-    //   u >= 8  GEMM 2: k-step 8c + (u - 8) (hi, mid) of the wave's two output n-tiles 2 wave, 2 wave + 1 of W2
+    // ---- the weight stream.  Unit u of chunk c (UPC units per chunk, up to US x 16 bytes per lane each):
+    //   u < U1   GEMM 1: k-steps 2u, 2u + 1 (hi, mid each) of hidden n-tile NW c + wave of W1   [contiguous 4 KB]
+    //   u >= U1  GEMM 2: k-step U2 c + (u - U1) (hi, mid) of the wave's TJ output n-tiles of W2 (clamped to the last real one)
     // packed layout (linear_stream.hip pack_weight_kernel): piece (n-tile t, k-step q, part p) at ((t KQ + q) 2 + p) 64 + lane
-    u32x4 ring[kRing][4];
-    auto load_unit = [&](int c, auto uc, u32x4 (&dst)[4]) {
+    u32x4 ring[RING][G::US];
+    auto load_unit = [&](int c, auto uc, u32x4 (&dst)[G::US]) {
         constexpr int u = decltype(uc)::value;
-        if constexpr (u < 8) {
-            const u32x4 *base = W1p + ((size_t)(c * 4 + wave) * kKQ1 * 2 + u * 4) * 64 + lane;
+        if constexpr (u < U1) {
+            const u32x4 *base = W1p + ((size_t)min(c * NW + wave, ntiles1 - 1) * G::KQ1 * 2 + u * 4) * 64 + lane;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[i] = base[i * 64];
         } else {
-            const int q = c * 8 + (u - 8);
+            const int q = min(c * U2 + (u - U1), KQ2 - 1);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) dst[j * 2 + p] = W2p[(((size_t)(2 * wave + j) * KQ2 + q) * 2 + p) * 64 + lane];
+                for (int p = 0; p < 2; ++p) dst[j * 2 + p] = W2p[(((size_t)(TJ * wave + j) * KQ2 + q) * 2 + p) * 64 + lane];
         }
     };
     // the first units first (they have the longest way), then the whole activation tile
-    load_unit(0, std::integral_constant<int, 0>{}, ring[0]);
-    load_unit(0, std::integral_constant<int, 1>{}, ring[1]);
-    load_unit(0, std::integral_constant<int, 2>{}, ring[2]);
-    load_unit(0, std::integral_constant<int, 3>{}, ring[3]);
-    load_unit(0, std::integral_constant<int, 4>{}, ring[4]);
-    load_unit(0, std::integral_constant<int, 5>{}, ring[5]);
+    static_for<G::AHEAD>([&](auto uc) { load_unit(0, uc, ring[decltype(uc)::value]); });
     __builtin_amdgcn_sched_barrier(0);
-    stage_rows<TI>(X, M, m0, sXhi, sXmid, wave, lane);
+    stage_rows<D, TI>(X, M, m0, sXhi, sXmid, tid);
     __syncthreads();
 
-    f32x16 accy[TI][2];
+    f32x16 accy[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) accy[i][j][e] = 0.f;
 
     const int frow = (lane & 31), fk = (lane >> 5) * 8;   // fragment: lane -> (row of the tile, first of 8 consecutive k)
-    const int xoff = frow * kXStride + fk, hoff = frow * kHStride + fk;
+    const int xoff = frow * XS + fk, hoff = frow * HS + fk;
 
     // every bias / LayerNorm vector through a buffer resource (NULL: zero records -> zeros, no branch around the load)
     const __amdgpu_buffer_rsrc_t b1rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b1 ? b1 : X), 0, b1 ? (unsigned)F * 4u : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t b2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b2 ? b2 : X), 0, b2 ? (unsigned)kD * 4u : 0u, 0x00020000);
-    const unsigned bytes = (unsigned)((size_t)M * kD * 4);
+    const __amdgpu_buffer_rsrc_t b2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(b2 ? b2 : X), 0, b2 ? (unsigned)D * 4u : 0u, 0x00020000);
+    const unsigned bytes = (unsigned)((size_t)M * D * 4);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : X), 0, R ? bytes : 0u, 0x00020000);
-    const int cbase = wave * 64 + 4 * (lane >> 5);
-    f32x4 v[TI][2][4];   // the residual rows, then the output values
+    const int cbase = wave * (32 * TJ) + 4 * (lane >> 5);
+    f32x4 v[TI][TJ][4];   // the residual rows, then the output values
 
     for (int c = 0; c < nchunks; ++c) {
         const int cn = min(c + 1, nchunks - 1);   // after the last chunk: a harmless reload
@@ -249,18 +284,18 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             b1v[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                   b1rs, (unsigned)(c * kChunk + wave * 32 + 8 * g + 4 * (lane >> 5)) * 4u, 0, 0));
+                                                   b1rs, (unsigned)(c * G::CH + wave * 32 + 8 * g + 4 * (lane >> 5)) * 4u, 0, 0));
         if (c == nchunks - 1) {
             // the residual rows: in flight during the last chunk.  Lane -> output row m0 + 32 i + (lane & 31); registers
-            // 4 g .. 4 g + 3 of tile j -> columns 64 wave + 32 j + 8 g + 4 (lane >> 5) + 0..3; rows >= M return zeros
+            // 4 g .. 4 g + 3 of tile j -> columns 32 TJ wave + 32 j + 8 g + 4 (lane >> 5) + 0..3; rows >= M return zeros
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         v[i][j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                   rrs, (unsigned)((m0 + i * 32 + frow) * kD + cbase + 32 * j + 8 * g) * 4u, 0, 0));
+                                                                   rrs, (unsigned)((m0 + i * 32 + frow) * D + cbase + 32 * j + 8 * g) * 4u, 0, 0));
         }
         f32x16 acch[TI];
 #pragma unroll
@@ -269,10 +304,9 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
             for (int e = 0; e < 16; ++e) acch[i][e] = 0.f;
 
         auto prefetch = [&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            constexpr int ahead = u + kAhead;
-            if constexpr (ahead < 16) load_unit(c, std::integral_constant<int, ahead>{}, ring[ahead & (kRing - 1)]);
-            else load_unit(cn, std::integral_constant<int, ahead - 16>{}, ring[ahead & (kRing - 1)]);
+            constexpr int ahead = decltype(uc)::value + G::AHEAD;
+            if constexpr (ahead < UPC) load_unit(c, std::integral_constant<int, ahead>{}, ring[ahead % RING]);
+            else load_unit(cn, std::integral_constant<int, ahead - UPC>{}, ring[ahead % RING]);
         };
         // ---- GEMM 1: hidden[32 of this wave][BM rows] (transposed) = W1 tile . x^T.  One block per CU means one wave per
         // SIMD: nobody else covers the LDS latency, so the fragments of k-step st + 1 are read before the MFMAs of k-step st
@@ -281,16 +315,17 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
             constexpr int st = decltype(stc)::value;
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                xf[st & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sXhi[i * 32 * kXStride + xoff + st * 16]);
-                xf[st & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sXmid[i * 32 * kXStride + xoff + st * 16]);
+                xf[st & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sXhi[i * 32 * XS + xoff + st * 16]);
+                xf[st & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sXmid[i * 32 * XS + xoff + st * 16]);
             }
         };
-        auto gemm1 = [&](auto stc) {
-            constexpr int st = decltype(stc)::value;   // k-step 0..15; weight unit st / 2
+        read_x(std::integral_constant<int, 0>{});
+        static_for<G::KQ1>([&](auto stc) {
+            constexpr int st = decltype(stc)::value;   // k-step; weight unit st / 2
             if constexpr ((st & 1) == 0) prefetch(std::integral_constant<int, st / 2>{});
-            if constexpr (st + 1 < kKQ1) read_x(std::integral_constant<int, st + 1>{});
+            if constexpr (st + 1 < G::KQ1) read_x(std::integral_constant<int, st + 1>{});
             __builtin_amdgcn_sched_barrier(0);   // loads and reads stay at the head of the step (see linear_stream.hip)
-            const u32x4 (&cur)[4] = ring[(st / 2) & (kRing - 1)];
+            const u32x4 (&cur)[G::US] = ring[(st / 2) % RING];
             const bf16x8 w_hi = __builtin_bit_cast(bf16x8, cur[(st & 1) * 2 + 0]), w_mid = __builtin_bit_cast(bf16x8, cur[(st & 1) * 2 + 1]);
 #pragma unroll
             for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, xf[st & 1][i][1], acch[i], 0, 0, 0);
@@ -298,28 +333,12 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
             for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid, xf[st & 1][i][0], acch[i], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, xf[st & 1][i][0], acch[i], 0, 0, 0);
-        };
-        read_x(std::integral_constant<int, 0>{});
-        gemm1(std::integral_constant<int, 0>{});
-        gemm1(std::integral_constant<int, 1>{});
-        gemm1(std::integral_constant<int, 2>{});
-        gemm1(std::integral_constant<int, 3>{});
-        gemm1(std::integral_constant<int, 4>{});
-        gemm1(std::integral_constant<int, 5>{});
-        gemm1(std::integral_constant<int, 6>{});
-        gemm1(std::integral_constant<int, 7>{});
-        gemm1(std::integral_constant<int, 8>{});
-        gemm1(std::integral_constant<int, 9>{});
-        gemm1(std::integral_constant<int, 10>{});
-        gemm1(std::integral_constant<int, 11>{});
-        gemm1(std::integral_constant<int, 12>{});
-        gemm1(std::integral_constant<int, 13>{});
-        gemm1(std::integral_constant<int, 14>{});
-        gemm1(std::integral_constant<int, 15>{});
+        });
 
         // ---- bias + ReLU + split -> the hidden tile in LDS.  C/D of the 32 x 32 MFMA with the weight as A: lane -> row
         // (lane & 31) of x, registers 4 g .. 4 g + 3 -> hidden columns 8 g + 4 (lane >> 5) + 0..3 of the wave's 32
         __syncthreads();   // every wave is past GEMM 2 of the previous chunk: the hidden tile is free
+        const int hcol = c * G::CH + wave * 32 + 4 * (lane >> 5);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -328,73 +347,65 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float t = acch[i][4 * g + e] + b1v[g][e];
-                    t = t > 0.f ? t : 0.f;
+                    t = (t > 0.f && hcol + 8 * g < F) ? t : 0.f;   // columns past the hidden width (last chunk only): zero
                     hi[e] = (__bf16)t;
                     mid[e] = (__bf16)(t - (float)hi[e]);
                 }
-                const int o = (i * 32 + frow) * kHStride + wave * 32 + 8 * g + 4 * (lane >> 5);
+                const int o = (i * 32 + frow) * HS + wave * 32 + 8 * g + 4 * (lane >> 5);
                 *reinterpret_cast<bf16x4 *>(&sHhi[o]) = hi;
                 *reinterpret_cast<bf16x4 *>(&sHmid[o]) = mid;
             }
         __syncthreads();
 
-        // ---- GEMM 2: y[64 columns of this wave][BM rows] (transposed) += W2 tiles . hidden^T, k = this chunk
+        // ---- GEMM 2: y[32 TJ columns of this wave][BM rows] (transposed) += W2 tiles . hidden^T, k = this chunk
         bf16x8 hf[2][TI][2];
         auto read_h = [&](auto vc) {
-            constexpr int kv = decltype(vc)::value;   // k-step of the chunk, 0..7
+            constexpr int kv = decltype(vc)::value;   // k-step of the chunk
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                hf[kv & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sHhi[i * 32 * kHStride + hoff + kv * 16]);
-                hf[kv & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sHmid[i * 32 * kHStride + hoff + kv * 16]);
+                hf[kv & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sHhi[i * 32 * HS + hoff + kv * 16]);
+                hf[kv & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sHmid[i * 32 * HS + hoff + kv * 16]);
             }
         };
-        auto gemm2 = [&](auto vc) {
-            constexpr int kv = decltype(vc)::value;   // weight unit 8 + kv
-            prefetch(std::integral_constant<int, 8 + kv>{});
-            if constexpr (kv + 1 < 8) read_h(std::integral_constant<int, kv + 1>{});
+        read_h(std::integral_constant<int, 0>{});
+        static_for<U2>([&](auto vc) {
+            constexpr int kv = decltype(vc)::value;   // weight unit U1 + kv
+            prefetch(std::integral_constant<int, U1 + kv>{});
+            if constexpr (kv + 1 < U2) read_h(std::integral_constant<int, kv + 1>{});
             __builtin_amdgcn_sched_barrier(0);
-            const u32x4 (&cur)[4] = ring[(8 + kv) & (kRing - 1)];
-            bf16x8 w_hi[2], w_mid[2];
+            const u32x4 (&cur)[G::US] = ring[(U1 + kv) % RING];
+            bf16x8 w_hi[TJ], w_mid[TJ];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TJ; ++j) {
                 w_hi[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 0]);
                 w_mid[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 1]);
             }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], hf[kv & 1][i][1], accy[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], hf[kv & 1][i][1], accy[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid[j], hf[kv & 1][i][0], accy[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid[j], hf[kv & 1][i][0], accy[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], hf[kv & 1][i][0], accy[i][j], 0, 0, 0);
-        };
-        read_h(std::integral_constant<int, 0>{});
-        gemm2(std::integral_constant<int, 0>{});
-        gemm2(std::integral_constant<int, 1>{});
-        gemm2(std::integral_constant<int, 2>{});
-        gemm2(std::integral_constant<int, 3>{});
-        gemm2(std::integral_constant<int, 4>{});
-        gemm2(std::integral_constant<int, 5>{});
-        gemm2(std::integral_constant<int, 6>{});
-        gemm2(std::integral_constant<int, 7>{});
+                for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], hf[kv & 1][i][0], accy[i][j], 0, 0, 0);
+        });
     }
 
     // ---- epilogue (the LayerNorm's exchange buffer aliases the hidden tile)
-    rows_epilogue<TI, LN>(accy, v, b2rs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sHhi), m0, wave, lane);
+    rows_epilogue<D, TI, LN>(accy, v, b2rs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sHhi), m0, wave, lane);
 }
 
-template <int TI>
+template <int D, int TI>
 int launch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2, const float *b2, const float *res,
                const float *gamma, const float *beta, float eps, float *y, int M, int F, hipStream_t s)
 {
     const bool ln = gamma != nullptr;
-    const size_t lds = ffn_lds_bytes(TI);
-    const void *fn = ln ? (const void *)&ffn_fused_kernel<TI, true> : (const void *)&ffn_fused_kernel<TI, false>;
+    const size_t lds = ffn_lds_bytes<D>(TI);
+    const void *fn = ln ? (const void *)&ffn_fused_kernel<D, TI, true> : (const void *)&ffn_fused_kernel<D, TI, false>;
     static std::atomic<unsigned> raised[2];   // bit per device, per kernel
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -405,135 +416,113 @@ int launch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2
     const int blocks = (M + 32 * TI - 1) / (32 * TI);
     void *argv[] = {(void *)&x, (void *)&w1, (void *)&b1, (void *)&w2, (void *)&b2, (void *)&res,
                     (void *)&gamma, (void *)&beta, (void *)&eps, (void *)&y, (void *)&M, (void *)&F};
-    return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(kThreads), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(Geo<D>::NT), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-// ---- tf_linear_res_ln_f32: y = [LayerNorm](residual + x . w^T + bias) for a 256 x 256 weight -- the attention's output
+// ---- tf_linear_res_ln_f32: y = [LayerNorm](residual + x . w^T + bias) for a D x D weight -- the attention's output
 // projection with the layer's residual add and norm1 (deformable_transformer.py:285-292 / ms_deform_attn.py:87).  The GEMM 2
-// half of the kernel above with the activation tile as its operand: 16 k-steps, each wave 64 output columns.
-constexpr size_t linln_lds_bytes(int ti) { return (size_t)(32 * ti) * kXStride * 2 * 2; }
-constexpr int linln_min_blocks(int ti) { return ti <= 2 ? 2 : 1; }   // resident blocks per CU the register budget is cut for
-constexpr int linln_ring(int ti) { return ti <= 2 ? 4 : 8; }          // weight units in flight + 2 (16 registers each)
+// half of the kernel above with the activation tile as its operand: D / 16 k-steps, each wave 32 TJ output columns.
+template <int D>
+constexpr size_t linln_lds_bytes(int ti) { return (size_t)(32 * ti) * Geo<D>::XS * 2 * 2; }
+constexpr int linln_min_blocks(int d, int ti) { return (d == 256 ? ti <= 2 : ti <= 1) ? 2 : 1; }   // resident blocks per CU the register budget is cut for
+constexpr int linln_ring(int ti) { return ti <= 2 ? 4 : 8; }          // weight units in flight + 2
 
-template <int TI, bool LN>
-__global__ void __launch_bounds__(kThreads, (linln_min_blocks(TI)))
+template <int D, int TI, bool LN>
+__global__ void __launch_bounds__(Geo<D>::NT, (linln_min_blocks(D, TI)))
 linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R,
                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *Y, int M)
 {
-    constexpr int BM = TI * 32;
+    using G = Geo<D>;
+    constexpr int BM = TI * 32, TJ = G::TJ, XS = G::XS, KQ = G::KQ1;
     extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
-    unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * kXStride;
+    unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * XS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
-    // weight unit u = k-step u (hi, mid) of the wave's two output n-tiles; a ring as above, RING - 2 units ahead
+    // weight unit u = k-step u (hi, mid) of the wave's TJ output n-tiles; a ring as above, RING - 2 units ahead
     constexpr int RING = linln_ring(TI), AHEAD = RING - 2;
-    u32x4 ring[RING][4];
-    auto load_unit = [&](auto uc, u32x4 (&dst)[4]) {
+    u32x4 ring[RING][2 * TJ];
+    auto load_unit = [&](auto uc, u32x4 (&dst)[2 * TJ]) {
         constexpr int u = decltype(uc)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) dst[j * 2 + p] = Wp[(((size_t)(2 * wave + j) * kKQ1 + u) * 2 + p) * 64 + lane];
+            for (int p = 0; p < 2; ++p) dst[j * 2 + p] = Wp[(((size_t)(TJ * wave + j) * KQ + u) * 2 + p) * 64 + lane];
     };
-    load_unit(std::integral_constant<int, 0>{}, ring[0]);
-    load_unit(std::integral_constant<int, 1>{}, ring[1]);
-    if constexpr (AHEAD > 2) {
-        load_unit(std::integral_constant<int, 2>{}, ring[2]);
-        load_unit(std::integral_constant<int, 3>{}, ring[3]);
-        load_unit(std::integral_constant<int, 4>{}, ring[4]);
-        load_unit(std::integral_constant<int, 5>{}, ring[5]);
-    }
+    static_for<AHEAD>([&](auto uc) { load_unit(uc, ring[decltype(uc)::value]); });
     __builtin_amdgcn_sched_barrier(0);
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bias ? bias : X), 0, bias ? (unsigned)kD * 4u : 0u, 0x00020000);
-    const unsigned bytes = (unsigned)((size_t)M * kD * 4);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bias ? bias : X), 0, bias ? (unsigned)D * 4u : 0u, 0x00020000);
+    const unsigned bytes = (unsigned)((size_t)M * D * 4);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : X), 0, R ? bytes : 0u, 0x00020000);
-    const int frow = lane & 31, cbase = wave * 64 + 4 * (lane >> 5);
-    f32x4 v[TI][2][4];   // the residual rows (rows >= M return zeros), then the output values
-    stage_rows<TI>(X, M, m0, sXhi, sXmid, wave, lane);
+    const int frow = lane & 31, cbase = wave * (32 * TJ) + 4 * (lane >> 5);
+    f32x4 v[TI][TJ][4];   // the residual rows (rows >= M return zeros), then the output values
+    stage_rows<D, TI>(X, M, m0, sXhi, sXmid, tid);
     __syncthreads();
 
-    f32x16 accy[TI][2];
+    f32x16 accy[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) accy[i][j][e] = 0.f;
-    const int xoff = frow * kXStride + (lane >> 5) * 8;
+    const int xoff = frow * XS + (lane >> 5) * 8;
     bf16x8 xf[2][TI][2];   // [k-step parity][row tile][hi | mid]: the fragments of step st + 1 are read before the MFMAs of st
     auto read_x = [&](auto stc) {
         constexpr int st = decltype(stc)::value;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            xf[st & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sXhi[i * 32 * kXStride + xoff + st * 16]);
-            xf[st & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sXmid[i * 32 * kXStride + xoff + st * 16]);
+            xf[st & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sXhi[i * 32 * XS + xoff + st * 16]);
+            xf[st & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sXmid[i * 32 * XS + xoff + st * 16]);
         }
     };
-    auto step = [&](auto stc) {
+    read_x(std::integral_constant<int, 0>{});
+    static_for<KQ>([&](auto stc) {
         constexpr int st = decltype(stc)::value;
-        if constexpr (st + AHEAD < kKQ1) load_unit(std::integral_constant<int, st + AHEAD>{}, ring[(st + AHEAD) & (RING - 1)]);
-        if constexpr (st == kKQ1 - AHEAD) {   // the weight stream has ended: the residual rows take its place in the queue
+        if constexpr (st + AHEAD < KQ) load_unit(std::integral_constant<int, st + AHEAD>{}, ring[(st + AHEAD) % RING]);
+        if constexpr (st == KQ - AHEAD) {   // the weight stream has ended: the residual rows take its place in the queue
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TJ; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
                         v[i][j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                   rrs, (unsigned)((m0 + i * 32 + frow) * kD + cbase + 32 * j + 8 * g) * 4u, 0, 0));
+                                                                   rrs, (unsigned)((m0 + i * 32 + frow) * D + cbase + 32 * j + 8 * g) * 4u, 0, 0));
         }
-        if constexpr (st + 1 < kKQ1) read_x(std::integral_constant<int, st + 1>{});
+        if constexpr (st + 1 < KQ) read_x(std::integral_constant<int, st + 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        const u32x4 (&cur)[4] = ring[st & (RING - 1)];
-        bf16x8 w_hi[2], w_mid[2];
+        const u32x4 (&cur)[2 * TJ] = ring[st % RING];
+        bf16x8 w_hi[TJ], w_mid[TJ];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TJ; ++j) {
             w_hi[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 0]);
             w_mid[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 1]);
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], xf[st & 1][i][1], accy[i][j], 0, 0, 0);
+            for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], xf[st & 1][i][1], accy[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid[j], xf[st & 1][i][0], accy[i][j], 0, 0, 0);
+            for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid[j], xf[st & 1][i][0], accy[i][j], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], xf[st & 1][i][0], accy[i][j], 0, 0, 0);
-    };
-    read_x(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 0>{});
-    step(std::integral_constant<int, 1>{});
-    step(std::integral_constant<int, 2>{});
-    step(std::integral_constant<int, 3>{});
-    step(std::integral_constant<int, 4>{});
-    step(std::integral_constant<int, 5>{});
-    step(std::integral_constant<int, 6>{});
-    step(std::integral_constant<int, 7>{});
-    step(std::integral_constant<int, 8>{});
-    step(std::integral_constant<int, 9>{});
-    step(std::integral_constant<int, 10>{});
-    step(std::integral_constant<int, 11>{});
-    step(std::integral_constant<int, 12>{});
-    step(std::integral_constant<int, 13>{});
-    step(std::integral_constant<int, 14>{});
-    step(std::integral_constant<int, 15>{});
-    static_assert(kKQ1 == 16, "the k-step loop is written out for K = 256");
-    rows_epilogue<TI, LN>(accy, v, brs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sXhi), m0, wave, lane);
+            for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], xf[st & 1][i][0], accy[i][j], 0, 0, 0);
+    });
+    rows_epilogue<D, TI, LN>(accy, v, brs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sXhi), m0, wave, lane);
 }
 
-template <int TI>
+template <int D, int TI>
 int launch_linln(const float *x, const u32x4 *w, const float *b, const float *res, const float *gamma, const float *beta, float eps,
                  float *y, int M, hipStream_t s)
 {
     const bool ln = gamma != nullptr;
-    const size_t lds = linln_lds_bytes(TI);
-    const void *fn = ln ? (const void *)&linear_res_ln_kernel<TI, true> : (const void *)&linear_res_ln_kernel<TI, false>;
+    const size_t lds = linln_lds_bytes<D>(TI);
+    const void *fn = ln ? (const void *)&linear_res_ln_kernel<D, TI, true> : (const void *)&linear_res_ln_kernel<D, TI, false>;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned> raised[2];   // bit per device, per kernel
         int dev = 0;
@@ -545,7 +534,7 @@ int launch_linln(const float *x, const u32x4 *w, const float *b, const float *re
     }
     const int blocks = (M + 32 * TI - 1) / (32 * TI);
     void *argv[] = {(void *)&x, (void *)&w, (void *)&b, (void *)&res, (void *)&gamma, (void *)&beta, (void *)&eps, (void *)&y, (void *)&M};
-    return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(kThreads), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    return hipLaunchKernel(fn, dim3((unsigned)blocks), dim3(Geo<D>::NT), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
 std::atomic<int> g_linln_ti{-1};   // -1: TF_LINLN_TI or automatic (0)
@@ -591,26 +580,54 @@ int linln_set_ti(int v)
 }
 }  // namespace tfm
 
+namespace {
+
+template <int D>
+int dispatch_linln(const float *x, const u32x4 *w, const float *bias, const float *residual, const float *g, const float *b, float eps,
+                   float *y, int M, hipStream_t s)
+{
+    // rows per block = 32 TI; automatic: few rows -> 32-row blocks (more of them), many -> 64 (two resident per CU)
+    const int forced = linln_ti();
+    switch (forced ? forced : (M < 4096 ? 1 : 2)) {
+    case 1: return launch_linln<D, 1>(x, w, bias, residual, g, b, eps, y, M, s);
+    case 3:   // 96 rows per block: hidden 256 only (at 288 the accumulators of three row tiles do not fit the register file)
+        if constexpr (D == 256) return launch_linln<D, 3>(x, w, bias, residual, g, b, eps, y, M, s);
+        else return launch_linln<D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
+    default: return launch_linln<D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
+    }
+}
+
+template <int D>
+int dispatch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2, const float *b2, const float *residual,
+                 const float *g, const float *b, float eps, float *y, int M, int F, hipStream_t s)
+{
+    if (F < Geo<D>::CH || (F & 15)) return TF_MSDA_ERR_BAD_DIMS;   // at least one chunk; whole k-steps of GEMM 2
+    switch (ffn_ti()) {
+    case 1: return launch_ffn<D, 1>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    case 2: return launch_ffn<D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    default:   // 96 rows per block: hidden 256 only (see dispatch_linln)
+        if constexpr (D == 256) return launch_ffn<D, 3>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+        else return launch_ffn<D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    }
+}
+
+}  // namespace
+
 extern "C" int tf_linear_res_ln_f32(const float *x, const void *w_packed, const float *bias, const float *residual,
                                     const float *ln_weight, const float *ln_bias, float ln_eps, float *y, int64_t M, int K, int N,
                                     void *stream)
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return TF_MSDA_ERR_NULL_POINTER;
-    if (M <= 0 || K != kD || N != kD || (M + 128) * (int64_t)kD * 4 > 0xFFFFFFFFLL) return TF_MSDA_ERR_BAD_DIMS;
+    if (M <= 0 || K != N || (K != 256 && K != 288) || (M + 128) * (int64_t)K * 4 > 0xFFFFFFFFLL) return TF_MSDA_ERR_BAD_DIMS;
     uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y) |
                    reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(ln_weight) |
                    reinterpret_cast<uintptr_t>(ln_bias);
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *w = static_cast<const u32x4 *>(w_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // rows per block = 32 TI; automatic: few rows -> 32-row blocks (more of them), many -> 64 (two resident per CU)
-    const int forced = linln_ti();
-    switch (forced ? forced : (M < 4096 ? 1 : 2)) {
-    case 1: return launch_linln<1>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
-    case 3: return launch_linln<3>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
-    default: return launch_linln<2>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
-    }
+    return K == 256 ? dispatch_linln<256>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s)
+                    : dispatch_linln<288>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
 }
 
 extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const float *b1, const void *w2_packed, const float *b2,
@@ -619,8 +636,8 @@ extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const flo
 {
     if (!x || !w1_packed || !w2_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return TF_MSDA_ERR_NULL_POINTER;
-    if (M <= 0 || d_model != kD || d_ffn < kChunk || (d_ffn % kChunk) != 0 ||
-        (M + 128) * (int64_t)kD * 4 > 0xFFFFFFFFLL)   // 32-bit buffer offsets, incl. the rows of the last block past M
+    if (M <= 0 || (d_model != 256 && d_model != 288) || d_ffn <= 0 ||
+        (M + 128) * (int64_t)d_model * 4 > 0xFFFFFFFFLL)   // 32-bit buffer offsets, incl. the rows of the last block past M
         return TF_MSDA_ERR_BAD_DIMS;
     uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1_packed) | reinterpret_cast<uintptr_t>(w2_packed) |
                    reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b1) | reinterpret_cast<uintptr_t>(b2) |
@@ -628,9 +645,6 @@ extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const flo
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *w1 = static_cast<const u32x4 *>(w1_packed), *w2 = static_cast<const u32x4 *>(w2_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    switch (ffn_ti()) {
-    case 1: return launch_ffn<1>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
-    case 2: return launch_ffn<2>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
-    default: return launch_ffn<3>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
-    }
+    return d_model == 256 ? dispatch_ffn<256>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s)
+                          : dispatch_ffn<288>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
 }

@@ -237,13 +237,13 @@ def set_ffn_fused(on):
 
 def ffn(x, linear1, linear2, norm=None, residual=None):
     """[norm](residual + linear2(relu(linear1(x)))) through tf_ffn_fused_f32 (reference: deformable_transformer.py:282-297
-    forward_ffn + norm2).  x [..., 256] fp32 on the GPU; linear1 / linear2: nn.Linear; norm: nn.LayerNorm or None;
+    forward_ffn + norm2).  x [..., 256 | 288] fp32 on the GPU; linear1 / linear2: nn.Linear; norm: nn.LayerNorm or None;
     residual: like x or None.  Returns None when the kernel does not apply (the caller keeps the separate kernels)."""
     if not (_ffn_fused and _split_linear and x.is_cuda and x.dtype == torch.float32):
         return None
     w1, w2 = linear1.weight, linear2.weight
     F_, D = w1.shape
-    if D != 256 or x.shape[-1] != D or tuple(w2.shape) != (D, F_) or F_ % 128 or x.numel() == 0:
+    if D not in (256, 288) or x.shape[-1] != D or tuple(w2.shape) != (D, F_) or F_ % 16 or F_ < 128 or x.numel() == 0:
         return None
     if not all(w.dtype == torch.float32 and w.is_contiguous() and w.device == x.device for w in (w1, w2)):
         return None
@@ -301,27 +301,28 @@ def set_linear_ln_fused(on):
 
 
 def linear_residual_norm(x, linear, residual, norm):
-    """norm(residual + linear(x)) through tf_linear_res_ln_f32 for a 256 -> 256 nn.Linear (reference:
+    """norm(residual + linear(x)) through tf_linear_res_ln_f32 for a 256 -> 256 or 288 -> 288 nn.Linear (reference:
     ms_deform_attn.py:87 output_proj + deformable_transformer.py:285-292).  Returns None when the kernel does not apply."""
     if not (_linln_fused and _split_linear and x.is_cuda and x.dtype == torch.float32):
         return None
     w = linear.weight
-    if tuple(w.shape) != (256, 256) or x.shape[-1] != 256 or x.numel() == 0:
+    D = w.shape[0]
+    if D not in (256, 288) or tuple(w.shape) != (D, D) or x.shape[-1] != D or x.numel() == 0:
         return None
     if not (w.dtype == torch.float32 and w.is_contiguous() and w.device == x.device
-            and norm.elementwise_affine and tuple(norm.normalized_shape) == (256,)):
+            and norm.elementwise_affine and tuple(norm.normalized_shape) == (D,)):
         return None
-    x2 = x.reshape(-1, 256)
+    x2 = x.reshape(-1, D)
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     M = x2.shape[0]
-    if M < _LINLN_MIN_ROWS or (M + 128) * 1024 > 0xFFFFFFFF:
+    if M < _LINLN_MIN_ROWS or (M + 128) * D * 4 > 0xFFFFFFFF:
         return None
     if not all(v is None or _param_ok(v, x) for v in (linear.bias, norm.weight, norm.bias)):
         return None
     if residual.dtype != torch.float32 or residual.device != x.device or residual.numel() != x2.numel():
         return None
-    residual = residual.reshape(-1, 256)
+    residual = residual.reshape(-1, D)
     if not residual.is_contiguous():
         residual = residual.contiguous()
     if (x2.data_ptr() | residual.data_ptr()) & 15:
@@ -330,10 +331,10 @@ def linear_residual_norm(x, linear, residual, norm):
     if packed is None:
         return None
     with torch.cuda.device(x.device):
-        y = torch.empty((M, 256), dtype=torch.float32, device=x.device)
+        y = torch.empty((M, D), dtype=torch.float32, device=x.device)
         rc = _cabi.lib().tf_linear_res_ln_f32(x2.data_ptr(), packed.data_ptr(), 0 if linear.bias is None else linear.bias.data_ptr(),
                                               residual.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
-                                              y.data_ptr(), M, 256, 256, _stream(x.device))
+                                              y.data_ptr(), M, D, D, _stream(x.device))
     _cabi.check(rc, "tf_linear_res_ln_f32")
     return y.view(x.shape)
 
