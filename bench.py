@@ -569,6 +569,7 @@ def main():
         fused.set_ffn_fused(True)
         fused.set_linear_ln_fused(True)
         fused.set_stem_pool_fused(True)
+        fused.set_pos_add_fused(True)
 
     if args.roofline_only:
         if rank == 0:

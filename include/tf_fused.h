@@ -107,6 +107,12 @@ int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w
  */
 int tf_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int N, int H, int W, int C, void *stream);
 
+/* y[M, N] = (x + x2)[M, K] . w^T + bias: tf_linear_split_f32 with an element-wise add in front, done as the activation tile is
+ * staged -- `with_pos_embed(src, pos)` + a projection (models/deformable_transformer.py:279-283, ms_deform_attn.py:67-72)
+ * without a separate pass over the tokens.  Bit-identical to adding first. */
+int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const float *bias, float *y,
+                            int64_t M, int K, int N, void *stream);
+
 /*
  * The same product with the weight in PACKED form (trackformer_amd/csrc/linear_stream.hip): the weight is split into
  * bf16 (hi, mid) once and stored in matrix-core fragment order, so that the GEMM streams it from L2 into registers and

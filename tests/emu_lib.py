@@ -57,6 +57,8 @@ def lib():
     L.tf_linear_res_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_ffn_fused_f32.restype = ci
     L.tf_ffn_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_linear_split_add_f32.restype = ci
+    L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_linear_split_f32.restype = ci
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci
@@ -179,6 +181,30 @@ def linear_split(x, w, bias=None, relu=False, residual=None):
     if rc != 0:
         raise RuntimeError("tf_linear_split_f32: status %d" % rc)
     return y
+
+
+def linear_split_add(x, x2, w, bias=None):
+    """tf_linear_split_add_f32: (x + x2) @ w^T + bias."""
+    x, x2, w = _aligned(x), _aligned(x2), _c(w, np.float32)
+    M, K = x.shape
+    N = w.shape[0]
+    hi, mid = bf16_split(w)
+    hi, mid = _aligned16(np.ascontiguousarray(hi)), _aligned16(np.ascontiguousarray(mid))
+    b = _aligned(bias)
+    y = np.full((M, N), np.nan, np.float32)
+    rc = lib().tf_linear_split_add_f32(_p(x), _p(x2), _p(hi), _p(mid), _p(b), _p(y), M, K, N, None)
+    if rc != 0:
+        raise RuntimeError("tf_linear_split_add_f32: status %d" % rc)
+    return y
+
+
+def _aligned16(a):
+    """A 16-byte aligned copy of a contiguous array of any dtype."""
+    buf = np.zeros(a.nbytes + 16, np.uint8)
+    off = (-buf.ctypes.data) % 16
+    out = buf[off:off + a.nbytes].view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
 
 
 def linear_packed(x, w, bias=None, relu=False):

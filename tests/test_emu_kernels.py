@@ -735,3 +735,21 @@ def test_linear_residual_layernorm_hidden_288(M, ti):
     assert np.array_equal(y[:M], ref) and np.isnan(y[M:]).all() and np.isnan(yl[M:]).all()
     assert np.abs(ref - f64).max() < 1e-4 * max(1.0, np.abs(f64).max())
     assert np.abs(yl[:M] - emu_lib.add_layernorm(ref, None, g, be, 1e-5)).max() < 5e-6
+
+
+@pytest.mark.parametrize("M,K,N", [(300, 256, 384), (5000, 256, 384), (400, 256, 384), (4500, 256, 256), (130, 288, 288)])
+def test_linear_with_add_prologue_is_bit_identical(M, K, N):
+    """tf_linear_split_add_f32: (x + pos) . w^T with the add done while the activation tile is staged equals the separate
+    add followed by tf_linear_split_f32 bit for bit (the three block shapes it dispatches to)."""
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    pos = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N, dtype=np.float32)
+    ref = emu_lib.linear_split(x + pos, w, b)
+    assert np.array_equal(emu_lib.linear_split_add(x, pos, w, b), ref)
+    prev = emu_lib.set_options(linear_bufstore=1)
+    try:
+        assert np.array_equal(emu_lib.linear_split_add(x, pos, w, b), ref)
+    finally:
+        emu_lib.set_options(**prev)

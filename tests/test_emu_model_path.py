@@ -25,6 +25,7 @@ def _run(case, optin, fn=None):
                     (fused.set_ffn_fused, fused.set_ffn_fused(True)),
                     (fused.set_linear_ln_fused, fused.set_linear_ln_fused(True)),
                     (fused.set_stem_pool_fused, fused.set_stem_pool_fused(True)),
+                    (fused.set_pos_add_fused, fused.set_pos_add_fused(True)),
                     (lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
                     (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
             fused._LINLN_MIN_ROWS = 1
@@ -52,6 +53,7 @@ def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
     # are the 18 output projections with their residual add and norm (6 encoder, 2 x 6 decoder): no separate LayerNorm left
     assert calls.get("tf_add_layernorm_f32", 0) == (0 if optin else 30) and calls.get("tf_linear_split_f32", 0) >= (18 if optin else 60)
     assert calls.get("tf_ffn_fused_f32") == (12 if optin else None) and calls.get("tf_linear_res_ln_f32") == (18 if optin else None)
+    assert calls.get("tf_linear_split_add_f32") == (18 if optin else None)   # positional add inside the 6 + 2 x 6 attention projections
     routes = ("tf_conv3x3_split_f32", "tf_linear_split_res_f32", "tf_groupnorm_nhwc_f32", "tf_box_refine_f32")
     if optin:   # ResNet-50: 16 bottlenecks (their 3 x 3 and closing 1 x 1 convolutions), 3 projection levels, 6 decoder layers
         assert [calls.get(r) for r in routes] == [16, 16, 3, 6], calls

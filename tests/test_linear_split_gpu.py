@@ -233,3 +233,28 @@ def test_optin_packed_linear_wide_stores(dev, split_on, M, K, N, relu):
         lib.tf_msda_set_option(b"linear_bufstore", prev)
     print("wide stores: %d of %d outputs differ in the last bits" % (int((got != base).sum()), got.numel()))
     assert torch.allclose(got, base, atol=1e-5, rtol=1e-5)
+
+
+@optin
+@pytest.mark.parametrize("rows,n", [(22223, 384), (400, 384), (400, 512), (5000, 256)])
+def test_optin_linear_with_add_prologue(rows, n):
+    """tf_linear_split_add_f32 (fused.linear_add): (x + pos) @ w^T + b with the add done while the tile is staged; the same
+    bits as adding first and calling fused.linear."""
+    from trackformer_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows + n)
+    x = torch.randn(1, rows, 256, generator=g).to(dev)
+    pos = torch.randn(1, rows, 256, generator=g).to(dev)
+    w = (torch.randn(n, 256, generator=g) / 16).to(dev)
+    b = torch.randn(n, generator=g).to(dev)
+    prev = fused.set_pos_add_fused(True)
+    try:
+        got = fused.linear_add(x, pos, w, b)
+    finally:
+        fused.set_pos_add_fused(prev)
+    prev_packed = fused.set_packed_linear(False)   # the reference through the same (unpacked) kernel family
+    try:
+        ref = fused.linear(x + pos, w, b)
+    finally:
+        fused.set_packed_linear(prev_packed)
+    assert got is not None and ref is not None and torch.equal(got, ref)

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "tf_linear_packed_bytes",
     "tf_linear_pack_weight_f32",
     "tf_linear_packed_f32",
+    "tf_linear_split_add_f32",
     "tf_ffn_fused_f32",
     "tf_linear_res_ln_f32",
     "tf_mha_core_f32",
@@ -115,6 +116,8 @@ def lib():
     L.tf_linear_res_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_ffn_fused_f32.restype = ci
     L.tf_ffn_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_linear_split_add_f32.restype = ci
+    L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_linear_packed_f32.restype = ci
     L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_mha_core_f32.restype = ci

@@ -54,11 +54,13 @@ constexpr int LDS_STRIDE = BK + 8;   // bf16 elements per LDS row: 80 bytes, kee
 // re-waits for the bias load at each join, and on gfx9-family hardware vmcnt also counts STORES: the ISA had
 // `s_waitcnt vmcnt(0)` in front of every global_store_dword, i.e. each store waited for the previous one to reach L2
 // (profiles/r02_split_gemm_astat_trace.txt: 10.5 us of store time per 96 x 256 tile).
-template <int BM, int BN, bool RELU, bool PREFETCH, bool RESID, bool BUFST>
+// XADD (tf_linear_split_add_f32): the activation is X + X2, added element-wise as the tile is staged -- the layers'
+// `with_pos_embed(src, pos)` in front of a projection (deformable_transformer.py:279-283) without its own pass over the tokens.
+template <int BM, int BN, bool RELU, bool PREFETCH, bool RESID, bool BUFST, bool XADD = false>
 __device__ __forceinline__ void
 split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
                 const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, const float *__restrict__ R,
-                float *__restrict__ Y, int M, int K, int N)
+                float *__restrict__ Y, int M, int K, int N, const float *__restrict__ X2 = nullptr)
 {
     constexpr int TI = BM / 64, TJ = BN / 64;
     constexpr int XV = (BM * BK / 4) / THREADS;   // float4 of X per thread and slice
@@ -87,6 +89,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
             const int row = idx >> 3, c4 = idx & 7;
             const int grow = min(m0 + row, M - 1);       // rows past M read the last row, never stored
             xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * K + k0 + c4 * 4);
+            if constexpr (XADD) xr[it] += *reinterpret_cast<const f32x4 *>(X2 + (size_t)grow * K + k0 + c4 * 4);
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
@@ -228,6 +231,15 @@ split_gemm_res_kernel(const float *__restrict__ X, const unsigned short *__restr
                       const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N)
 {
     split_gemm_body<BM, BN, RELU, PREFETCH, true, BUFST>(X, Whi, Wmid, bias, R, Y, M, K, N);
+}
+
+template <int BM, int BN, bool PREFETCH, bool BUFST>
+__global__ void __launch_bounds__(THREADS)
+split_gemm_add_kernel(const float *__restrict__ X, const float *__restrict__ X2, const unsigned short *__restrict__ Whi,
+                      const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
+                      int M, int K, int N)
+{
+    split_gemm_body<BM, BN, false, PREFETCH, false, BUFST, true>(X, Whi, Wmid, bias, nullptr, Y, M, K, N, X2);
 }
 
 // ---- 3 x 3 convolution (padding 1, stride 1 or 2) on channels_last activations as the same split product: an
@@ -764,6 +776,19 @@ int launch_variant(const float *x, const unsigned short *wh, const unsigned shor
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
+template <int BM, int BN, bool PREFETCH>
+int launch_add(const float *x, const float *x2, const unsigned short *wh, const unsigned short *wm, const float *bias, float *y, int M,
+               int K, int N, hipStream_t s)
+{
+    const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+    if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
+    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL)
+        hipLaunchKernelGGL((split_gemm_add_kernel<BM, BN, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, x2, wh, wm, bias, y, M, K, N);
+    else
+        hipLaunchKernelGGL((split_gemm_add_kernel<BM, BN, PREFETCH, false>), grid, dim3(THREADS), 0, s, x, x2, wh, wm, bias, y, M, K, N);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
 }  // namespace
 
 namespace tfm {
@@ -881,6 +906,22 @@ int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const
     }
 }
 }  // namespace
+
+extern "C" int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const float *bias,
+                                       float *y, int64_t M, int K, int N, void *stream)
+{
+    if (!x || !x2 || !w_hi || !w_mid || !y) return TF_MSDA_ERR_NULL_POINTER;
+    if (M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(w_hi) |
+         reinterpret_cast<uintptr_t>(w_mid)) & 15)
+        return TF_MSDA_ERR_BAD_DIMS;
+    const unsigned short *wh = static_cast<const unsigned short *>(w_hi), *wm = static_cast<const unsigned short *>(w_mid);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // the block shapes tf_linear_split_f32 picks for these calls: few rows -> 64 x 64, else 64 x 128 (prefetch as there)
+    if (M <= 4096) return launch_add<64, 64, true>(x, x2, wh, wm, bias, y, (int)M, K, N, s);
+    if (N > 256 && N < 512) return launch_add<64, 128, false>(x, x2, wh, wm, bias, y, (int)M, K, N, s);
+    return launch_add<64, 128, true>(x, x2, wh, wm, bias, y, (int)M, K, N, s);
+}
 
 namespace {
 int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg, int hin, int win,

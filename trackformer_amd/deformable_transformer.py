@@ -331,12 +331,14 @@ class DeformableTransformerEncoderLayer(nn.Module):
         return fused.residual_norm(src, self.dropout3(src2), self.norm2, inf)
 
     def forward(self, src, pos, reference_points, spatial_shapes, padding_mask=None):
-        if _inference(self) and fused.linear_ln_fused_enabled():   # opt-in: output projection + add + norm1 in one launch
-            src = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes, padding_mask,
-                                 residual_norm=(src, self.norm1))
+        inf = _inference(self)
+        # opt-in (fused.set_pos_add_fused): the positional add rides in the attention's projection GEMM
+        q, q_pos = (src, pos) if (inf and pos is not None and fused.pos_add_fused_enabled()) else (self.with_pos_embed(src, pos), None)
+        if inf and fused.linear_ln_fused_enabled():   # opt-in: output projection + add + norm1 in one launch
+            src = self.self_attn(q, reference_points, src, spatial_shapes, padding_mask,
+                                 residual_norm=(src, self.norm1), query_pos=q_pos)
             return self.forward_ffn(src)
-        src2 = self.self_attn(self.with_pos_embed(src, pos), reference_points, src, spatial_shapes,
-                              padding_mask)
+        src2 = self.self_attn(q, reference_points, src, spatial_shapes, padding_mask, query_pos=q_pos)
         src = fused.residual_norm(src, self.dropout1(src2), self.norm1, _inference(self))
         return self.forward_ffn(src)
 
@@ -404,7 +406,7 @@ class DeformableTransformerDecoderLayer(nn.Module):
         tgt2 = fused.module_linear(self.linear2, self.dropout3(_ffn_hidden(self.linear1, self.activation, tgt, inf)), inf)
         return fused.residual_norm(tgt, self.dropout4(tgt2), self.norm3, inf)
 
-    def _self_attention_inference(self, qk_in, v_in, key_padding_mask, residual_norm=None):
+    def _self_attention_inference(self, qk_in, v_in, key_padding_mask, residual_norm=None, qk_pos=None):
         """nn.MultiheadAttention(q=k=qk_in, v=v_in) for batch-first inputs without materialising the
         attention weights: one GEMM for the shared q/k input, one for v, fused SDPA, out_proj.
         residual_norm = (residual, norm): returns (norm(residual + attention), True) when the opt-in one-launch
@@ -413,7 +415,13 @@ class DeformableTransformerDecoderLayer(nn.Module):
         E, H = mha.embed_dim, mha.num_heads
         w, b = mha.in_proj_weight, mha.in_proj_bias
         n, lq, _ = qk_in.shape
-        qk = fused.linear(qk_in, w, b[:2 * E], rows=(0, 2 * E))    # split product on the matrix cores when enabled
+        qk = None
+        if qk_pos is not None:   # opt-in: q = k = qk_in + qk_pos, the add inside the GEMM
+            qk = fused.linear_add(qk_in, qk_pos, w, b[:2 * E], rows=(0, 2 * E))
+            if qk is None:
+                qk_in = qk_in + qk_pos
+        if qk is None:
+            qk = fused.linear(qk_in, w, b[:2 * E], rows=(0, 2 * E))    # split product on the matrix cores when enabled
         if qk is None:
             qk = F.linear(qk_in, w[:2 * E], b[:2 * E])
         v = fused.linear(v_in, w, b[2 * E:], rows=(2 * E, 3 * E))
@@ -441,22 +449,29 @@ class DeformableTransformerDecoderLayer(nn.Module):
         that GraphedDetector appends to reach a bucketed query count; their own outputs are dropped by the caller, so
         nothing else needs to know about them (the cross-attention is per query)."""
         # self attention among the (track + object) queries
-        q = k = self.with_pos_embed(tgt, query_pos)
         key_mask = query_attn_mask if query_attn_mask is not None else filler_key_mask
         if _inference(self) and tgt.is_cuda and self.self_attn.in_proj_weight is not None:
-            tgt2, normed = self._self_attention_inference(q, tgt, key_mask, residual_norm=(tgt, self.norm2))
+            if query_pos is not None and fused.pos_add_fused_enabled():
+                tgt2, normed = self._self_attention_inference(tgt, tgt, key_mask, residual_norm=(tgt, self.norm2), qk_pos=query_pos)
+            else:
+                tgt2, normed = self._self_attention_inference(self.with_pos_embed(tgt, query_pos), tgt, key_mask,
+                                                              residual_norm=(tgt, self.norm2))
         else:
             normed = False
+            q = k = self.with_pos_embed(tgt, query_pos)
             tgt2 = self.self_attn(q.transpose(0, 1), k.transpose(0, 1), tgt.transpose(0, 1),
                                   key_padding_mask=key_mask)[0].transpose(0, 1)
         tgt = tgt2 if normed else fused.residual_norm(tgt, self.dropout2(tgt2), self.norm2, _inference(self))
         # deformable cross attention into the encoder memory
-        if _inference(self) and fused.linear_ln_fused_enabled():   # opt-in, as in the encoder layer
-            tgt = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src, src_spatial_shapes,
-                                  src_padding_mask, query_attn_mask, residual_norm=(tgt, self.norm1))
+        inf = _inference(self)
+        cq, cq_pos = (tgt, query_pos) if (inf and query_pos is not None and fused.pos_add_fused_enabled()) \
+            else (self.with_pos_embed(tgt, query_pos), None)
+        if inf and fused.linear_ln_fused_enabled():   # opt-in, as in the encoder layer
+            tgt = self.cross_attn(cq, reference_points, src, src_spatial_shapes, src_padding_mask, query_attn_mask,
+                                  residual_norm=(tgt, self.norm1), query_pos=cq_pos)
             return self.forward_ffn(tgt)
-        tgt2 = self.cross_attn(self.with_pos_embed(tgt, query_pos), reference_points, src,
-                               src_spatial_shapes, src_padding_mask, query_attn_mask)
+        tgt2 = self.cross_attn(cq, reference_points, src, src_spatial_shapes, src_padding_mask, query_attn_mask,
+                               query_pos=cq_pos)
         tgt = fused.residual_norm(tgt, self.dropout1(tgt2), self.norm1, _inference(self))
         return self.forward_ffn(tgt)
 

@@ -370,6 +370,55 @@ def bias_relu_maxpool(x, bias):
     return out
 
 
+# OPT-IN (TF_POS_ADD_FUSED=1 / set_pos_add_fused(True)): `with_pos_embed(x, pos)` in front of a projection is done inside the
+# GEMM while the activation tile is staged (tf_linear_split_add_f32) instead of as its own pass over the tokens; bit-identical.
+_pos_add_fused = os.environ.get("TF_POS_ADD_FUSED", "0") == "1"
+
+
+def pos_add_fused_enabled():
+    return _pos_add_fused
+
+
+def set_pos_add_fused(on):
+    global _pos_add_fused
+    prev, _pos_add_fused = _pos_add_fused, bool(on)
+    return prev
+
+
+def linear_add(x, x2, weight, bias=None, rows=None):
+    """(x + x2) @ weight^T + bias through tf_linear_split_add_f32 (same conditions and `rows` meaning as linear());
+    returns None when it does not apply."""
+    if not (_pos_add_fused and _split_linear and x.is_cuda and x.dtype == torch.float32 and x2.dtype == torch.float32
+            and x2.shape == x.shape and x2.device == x.device and weight.dtype == torch.float32 and weight.dim() == 2
+            and weight.is_contiguous() and weight.device == x.device):
+        return None
+    N, K = weight.shape
+    if rows is not None:
+        if not (0 <= rows[0] < rows[1] <= N):
+            return None
+        N = rows[1] - rows[0]
+    if x.shape[-1] != K or K % 32 or x.numel() == 0:
+        return None
+    if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N
+                                 and bias.device == x.device):
+        return None
+    a, b = x.reshape(-1, K), x2.reshape(-1, K)
+    a = a if a.is_contiguous() else a.contiguous()
+    b = b if b.is_contiguous() else b.contiguous()
+    hi, mid = _split_weight(weight)
+    if rows is not None:
+        hi, mid = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]]
+    if (a.data_ptr() | b.data_ptr() | hi.data_ptr() | mid.data_ptr()) & 15:
+        return None
+    with torch.cuda.device(x.device):
+        y = torch.empty((a.shape[0], N), dtype=torch.float32, device=x.device)
+        rc = _cabi.lib().tf_linear_split_add_f32(a.data_ptr(), b.data_ptr(), hi.data_ptr(), mid.data_ptr(),
+                                                 0 if bias is None else bias.data_ptr(), y.data_ptr(), a.shape[0], K, N,
+                                                 _stream(x.device))
+    _cabi.check(rc, "tf_linear_split_add_f32")
+    return y.view(*x.shape[:-1], N)
+
+
 def conv3x3(x, w_taps, bias, relu, stride):
     """3 x 3 convolution (padding 1) -- or, with a [Cout, Cin] weight, a strided 1 x 1 convolution without padding -- of a
     channels_last fp32 GPU activation through tf_conv3x3_split_f32 / tf_conv1x1_strided_split_f32.

@@ -289,22 +289,24 @@ class MSDeformAttn(nn.Module):
         constant_(self.output_proj.bias.data, 0.)
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes,
-                input_padding_mask=None, query_attn_mask=None, residual_norm=None):
+                input_padding_mask=None, query_attn_mask=None, residual_norm=None, query_pos=None):
         """query[N,Lq,C], reference_points[N,Lq,L,2|4] in [0,1], input_flatten[N,S,C],
         input_spatial_shapes[L,2] (H_l,W_l), input_padding_mask[N,S] (True = padding)
         -> [N,Lq,C]   (modules/ms_deform_attn.py:49-89).
         residual_norm = (residual, nn.LayerNorm) (an extension used by the inference path of the layers): return
-        norm(residual + attention output) instead -- the output projection, the add and the norm can then be one launch."""
+        norm(residual + attention output) instead -- the output projection, the add and the norm can then be one launch.
+        query_pos (extension, inference path): the query is `query + query_pos`; the add can then ride in the projection."""
         if residual_norm is not None:
             out = self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask,
-                                query_attn_mask, residual_norm)
+                                query_attn_mask, residual_norm, query_pos)
             if isinstance(out, _Normed):
                 return out.value
             return fused.residual_norm(residual_norm[0], out, residual_norm[1], True)
-        return self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask, query_attn_mask, None)
+        return self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask, query_attn_mask,
+                             None, query_pos)
 
     def _forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask, query_attn_mask,
-                 residual_norm):
+                 residual_norm, query_pos=None):
         N, Len_q, _ = query.shape
         N, Len_in, _ = input_flatten.shape
         hs = _host_shapes_of(input_spatial_shapes)
@@ -327,7 +329,13 @@ class MSDeformAttn(nn.Module):
                 and (self.d_model // M) % 4 == 0 and P in (1, 2, 4, 8)):
             # inference: one GEMM for both query projections, prologue arithmetic inside the kernel
             w, b = self._cat_proj.get(self)
-            qproj = fused.linear(query, w, b) if fused.split_linear_enabled() else None
+            qproj = None
+            if query_pos is not None:   # opt-in: the positional add inside the projection GEMM
+                qproj = fused.linear_add(query, query_pos, w, b)
+                if qproj is None:
+                    query = query + query_pos
+            if qproj is None:
+                qproj = fused.linear(query, w, b) if fused.split_linear_enabled() else None
             if qproj is None:
                 qproj = F.linear(query, w, b)
             output = ms_deform_attn_forward_fused(value, input_spatial_shapes, reference_points,
@@ -338,6 +346,8 @@ class MSDeformAttn(nn.Module):
                     return _Normed(y)
             return fused.module_linear(self.output_proj, output, True)
 
+        if query_pos is not None:
+            query = query + query_pos
         sampling_offsets = self.sampling_offsets(query).view(N, Len_q, M, L, P, 2)
         attention_weights = self.attention_weights(query).view(N, Len_q, M, L * P)
         attention_weights = F.softmax(attention_weights, -1).view(N, Len_q, M, L, P)
