@@ -753,3 +753,31 @@ def test_linear_with_add_prologue_is_bit_identical(M, K, N):
         assert np.array_equal(emu_lib.linear_split_add(x, pos, w, b), ref)
     finally:
         emu_lib.set_options(**prev)
+
+
+def test_lds_bank_conflict_model_on_the_encoder_kernel():
+    """HIPEMU_LDS_TRACK=1: the emulator's ds_read_b128 bank model (four fixed 16-lane groups, 64 banks, broadcast) counts the
+    LDS cycles of the LDS-window kernel's gathers.  Hardware counters of round 2 put 34 % of that kernel's LDS cycles down
+    to bank conflicts (profiles/r02_msda_fwd_pquad_pmc.json); the model gives 6.0 cycles per gather = 33 %
+    (tools/lds_conflict_study.py).  Here: a small pyramid in a fresh process, the ratio must lie between conflict-free
+    (4) and the two-way level (8), and the result must not depend on the accounting."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np\n"
+        "from tests import emu_lib\n"
+        "from tests.test_emu_kernels import _fused_case, PYR\n"
+        "value, refp, qproj, _, _ = _fused_case(PYR, 1, 32, seed=3, spread=0.8)\n"
+        "out = emu_lib.msda_forward_fused(value, np.array(PYR, np.int64), refp, qproj, 8, len(PYR), 4)\n"
+        "st = emu_lib.stats()\n"
+        "print('RESULT', st['lds_b128_reads'], st['lds_b128_cycles'], float(np.abs(out).sum()))\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for track in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_LDS_TRACK=track), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[track] = [float(v) for v in r.stdout.split("RESULT")[1].split()]
+    reads, cycles, checksum = res["1"]
+    assert reads > 1000 and 4.0 <= cycles / reads <= 8.0, (reads, cycles)
+    assert res["0"][0] == 0 and res["0"][2] == checksum
