@@ -70,3 +70,6 @@ TF_ALL_OPTIN=1 TF_LINEAR_BUFSTORE=2 TF_LINEAR_DEEP=1 TF_MHA_BATCH=1 TF_MSDA_PQUA
 TF_FFN_FUSED=1 TF_LINLN_FUSED=1 TF_LINEAR_BUFSTORE=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_ffn_linln_bufstore.json 2> $O/bench_cfg2_ffn_linln_bufstore.err
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split --conv3x3-split > $O/bench_cfg2_conv1x1_3x3.json 2> $O/bench_cfg2_conv1x1_3x3.err
 cat $O/bench_cfg2_default.json $O/bench_cfg2_all_optin.json $O/bench_cfg2_ffn_linln_bufstore.json $O/bench_cfg2_conv1x1_3x3.json | cut -c1-260
+
+# one table of every bench line of this call
+python tools/summarize_bench.py $O | tee $O/summary.txt

@@ -39,3 +39,6 @@ for lib in tools/bin/ablate/libtf_msda_abl*.so; do
 done
 } > $O/pquad_ablations.txt 2>&1
 tail -30 $O/pquad_ablations.txt
+
+# one table of every bench line of this call
+python tools/summarize_bench.py $O | tee $O/summary.txt
