@@ -485,7 +485,7 @@ def test_opt_in_kernels_do_not_depend_on_the_scheduling_order():
     import subprocess
     import sys
     env = dict(os.environ, HIPEMU_SHUFFLE="3")
-    sel = "direct9 or sorted2 or pipelined or deep_prefetch or buffer_store or residual_epilogue or fused_ffn or residual_layernorm"
+    sel = "direct9 or pipelined or deep_prefetch or buffer_store or residual_epilogue or fused_ffn or residual_layernorm or add_prologue"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel, "-p", "no:cacheprovider"],
                        env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
