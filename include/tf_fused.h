@@ -99,6 +99,18 @@ int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w
                                  int hin, int win, int cin, int cout, int stride, int relu, void *stream);
 
 /*
+ * The backbone's first convolution (7 x 7, stride 2, padding 3, 3 -> 64 channels; reference: models/backbone.py:93-104 ->
+ * torchvision resnet50.conv1) as a split product on the matrix cores (trackformer_amd/csrc/stem_conv.hip).
+ *   x         [N, 3, H, W] fp32, planar (NCHW)
+ *   w_packed  tf_linear_pack_weight_f32(K = 176, N = 64) of the [64, 176] matrix w2[o][(c * 7 + ky) * 8 + kx] = w[o][c][ky][kx]
+ *             (kx = 7 and k >= 168: zeros) -- with a following FrozenBatchNorm2d's scale folded in by the caller
+ *   bias      [64] or NULL (the FrozenBatchNorm2d shift), relu != 0: ReLU
+ *   y         [N, (H - 1) / 2 + 1, (W - 1) / 2 + 1, 64] fp32, channels_last
+ */
+int tf_stem_conv7x7_f32(const float *x, const void *w_packed, const float *bias, float *y, int N, int H, int W, int relu,
+                        void *stream);
+
+/*
  * out[n, oy, ox, c] = max over the 3 x 3 window (stride 2, padding 1) of relu(x[n, iy, ix, c] + bias[c]) on channels_last
  * activations: FrozenBatchNorm2d shift + ReLU + MaxPool2d(3, 2, 1) after the backbone's first convolution (reference:
  * models/backbone.py:45-55, torchvision ResNet.relu / .maxpool) in one pass.  x [N, H, W, C], out [N, (H - 1) / 2 + 1,

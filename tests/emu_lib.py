@@ -47,6 +47,8 @@ def lib():
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_add_layernorm_f32.restype = ci
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
+    L.tf_stem_conv7x7_f32.restype = ci
+    L.tf_stem_conv7x7_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_bias_relu_maxpool_f32.restype = ci
     L.tf_bias_relu_maxpool_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_box_refine_f32.restype = ci
@@ -284,6 +286,27 @@ def linear_res_ln(x, w, bias=None, residual=None, ln=None, eps=1e-5, guard_rows=
                                     w.shape[0], None)
     if rc != 0:
         raise RuntimeError("tf_linear_res_ln_f32: status %d" % rc)
+    return y
+
+
+def stem_weight_matrix(w):
+    """[64, 3, 7, 7] -> the [64, 176] matrix of tf_stem_conv7x7_f32: k = (c * 7 + ky) * 8 + kx, zero padded."""
+    w = _c(w, np.float32)
+    w2 = np.zeros((w.shape[0], 176), np.float32)
+    w2[:, :168] = np.pad(w, ((0, 0), (0, 0), (0, 0), (0, 1))).reshape(w.shape[0], 168)
+    return w2
+
+
+def stem_conv(x_nchw, w, bias=None, relu=False):
+    """tf_stem_conv7x7_f32: x [N, 3, H, W], w [64, 3, 7, 7] -> y [N, Ho, Wo, 64] (channels_last)."""
+    x = _c(x_nchw, np.float32)
+    N, _, H, W = x.shape
+    pk = _packed(stem_weight_matrix(w))
+    b = _aligned(bias)
+    y = _aligned(np.full((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), np.nan, np.float32))
+    rc = lib().tf_stem_conv7x7_f32(_p(x), pk.ctypes.data, _p(b), _p(y), N, H, W, int(relu), None)
+    if rc != 0:
+        raise RuntimeError("tf_stem_conv7x7_f32: status %d" % rc)
     return y
 
 

@@ -781,3 +781,24 @@ def test_lds_bank_conflict_model_on_the_encoder_kernel():
     reads, cycles, checksum = res["1"]
     assert reads > 1000 and 4.0 <= cycles / reads <= 8.0, (reads, cycles)
     assert res["0"][0] == 0 and res["0"][2] == checksum
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 37, 70), (2, 16, 19), (1, 8, 300), (1, 5, 5), (1, 1, 1)], ids=lambda v: str(v))
+def test_stem_convolution_as_split_product(n, h, w):
+    """tf_stem_conv7x7_f32: the 7 x 7 / stride 2 / padding 3 stem convolution (3 -> 64) as an implicit GEMM on the emulated
+    matrix cores -- K ordered (plane, kernel row, 8 padded taps), zero patch outside the image, ragged tile edges -- against
+    torch's convolution in float64, with and without the shift + ReLU epilogue."""
+    import torch
+    rng = np.random.default_rng(h * w)
+    x = rng.standard_normal((n, 3, h, w), dtype=np.float32)
+    wt = (rng.standard_normal((64, 3, 7, 7), dtype=np.float32) / 12).astype(np.float32)
+    b = rng.standard_normal(64, dtype=np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(wt).double(), None, stride=2, padding=3)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    y = emu_lib.stem_conv(x, wt)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    y2 = emu_lib.stem_conv(x, wt, b, relu=True)
+    assert np.abs(y2 - np.maximum(ref + b, 0)).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0

@@ -26,6 +26,7 @@ def _run(case, optin, fn=None):
                     (fused.set_linear_ln_fused, fused.set_linear_ln_fused(True)),
                     (fused.set_stem_pool_fused, fused.set_stem_pool_fused(True)),
                     (fused.set_pos_add_fused, fused.set_pos_add_fused(True)),
+                    (fused.set_stem_conv_split, fused.set_stem_conv_split(True)),
                     (lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
                     (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
             fused._LINLN_MIN_ROWS = 1
@@ -59,6 +60,7 @@ def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
         assert [calls.get(r) for r in routes] == [16, 16, 3, 6], calls
         assert calls.get("tf_conv1x1_strided_split_f32") == 3   # the strided projections of layer2..4
         assert calls.get("tf_bias_act_f32", 0) <= 1 and calls.get("tf_bias_relu_maxpool_f32") == 1   # the stem: shift + ReLU + pooling in one pass
+        assert calls.get("tf_stem_conv7x7_f32") == 1   # ... after the 7 x 7 convolution as a split product: all 53 ResNet convolutions on own kernels
     else:
         assert all(calls.get(r) is None for r in routes), calls
         assert calls.get("tf_bias_act_f32", 0) >= 50

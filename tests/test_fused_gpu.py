@@ -250,3 +250,27 @@ def test_optin_bias_relu_maxpool_bit_identical(shape):
     got = fused.bias_relu_maxpool(x, b)
     assert got is not None and got.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got, ref)
+
+
+@optin
+@pytest.mark.parametrize("shape", [(1, 3, 800, 1333), (2, 3, 97, 130), (1, 3, 9, 7)])
+def test_optin_stem_convolution_split(shape):
+    """tf_stem_conv7x7_f32 (fused.stem_conv): the 7 x 7 / stride 2 stem convolution as a split product against the library
+    convolution (1e-3 of the output scale: three-term bf16 products), channels_last output, optional shift + ReLU."""
+    from trackformer_amd import fused
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.randn(*shape, generator=g).to(dev)
+    w = (torch.randn(64, 3, 7, 7, generator=g) / 12).to(dev)
+    b = torch.randn(64, generator=g).to(dev)
+    prev = fused.set_stem_conv_split(True)
+    try:
+        got = fused.stem_conv(x, w)
+        got_b = fused.stem_conv(x, w, b, relu=True)
+    finally:
+        fused.set_stem_conv_split(prev)
+    ref = torch.nn.functional.conv2d(x, w, None, stride=2, padding=3)
+    assert got is not None and got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    scale = float(ref.abs().max())
+    assert float((got - ref).abs().max()) < 1e-3 * scale
+    assert float((got_b - torch.relu(ref + b.view(1, -1, 1, 1))).abs().max()) < 1e-3 * scale

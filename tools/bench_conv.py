@@ -95,6 +95,29 @@ def main():
             print("%-22s %5d %5d %d %d %4dx%-4d  %10.1f %10.1f  %6.2f  %d   max rel err %.1e" % (
                 name, cin, cout, ks, stride, h, w, t_lib, t_split, t_lib / t_split, times, err))
     print("per frame: library %.0f us, split routes %.0f us, best of both per shape %.0f us" % (total_lib, total_split, total_best))
+    # the stem: 7 x 7 convolution (+ shift, ReLU, pooling) through the library + bias_act + max_pool2d, and through the own kernels
+    from trackformer_amd import fused
+    with torch.no_grad():
+        conv, bn, pool = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False).to(dev), backbone.FrozenBatchNorm2d(64).to(dev), nn.MaxPool2d(3, 2, 1)
+        bn.weight.uniform_(0.5, 1.5)
+        bn.running_var.uniform_(0.5, 1.5)
+        x = torch.randn(1, 3, 800, 1333, device=dev)
+        cache = backbone._FoldCache()
+        lib = lambda: pool(backbone._conv_bn(x, conv, bn, cache, True, True))   # noqa: E731
+        own = lambda: backbone._stem_pooled(x, conv, bn, pool, cache)            # noqa: E731
+        t_lib = time_it(lib, args.iters)
+        res = []
+        for conv_split, pool_fused in ((False, True), (True, False), (True, True)):
+            p1, p2 = fused.set_stem_conv_split(conv_split), fused.set_stem_pool_fused(pool_fused)
+            try:
+                err = float((own() - lib()).abs().max())
+                res.append((conv_split, pool_fused, time_it(own, args.iters), err))
+            finally:
+                fused.set_stem_conv_split(p1)
+                fused.set_stem_pool_fused(p2)
+        print("stem (conv 7x7 + shift + ReLU + pooling): library + bias_act + max_pool2d %.1f us" % t_lib)
+        for conv_split, pool_fused, t, err in res:
+            print("  own convolution %s, fused pooling pass %s: %.1f us (max abs difference %.1e)" % (conv_split, pool_fused, t, err))
 
 
 if __name__ == "__main__":

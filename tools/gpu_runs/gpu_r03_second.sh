@@ -15,6 +15,7 @@ timeout 240 python bench.py --no-cpu-baseline --no-roofline --input-proj-fused >
 timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split --conv3x3-split > $O/bench_cfg2_conv1x1_3x3.json 2> $O/bench_cfg2_conv1x1_3x3.err
 TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore_deep.json 2> $O/bench_cfg2_bufstore_deep.err
 TF_FFN_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_ffn_fused.json 2> $O/bench_cfg2_ffn_fused.err
+TF_STEM_POOL_FUSED=1 TF_STEM_CONV_SPLIT=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_stem_conv.json 2> $O/bench_cfg2_stem_conv.err
 TF_POS_ADD_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_pos_add.json 2> $O/bench_cfg2_pos_add.err
 TF_STEM_POOL_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_stem_pool.json 2> $O/bench_cfg2_stem_pool.err
 TF_FFN_FUSED=1 TF_LINLN_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_ffn_linln.json 2> $O/bench_cfg2_ffn_linln.err
@@ -26,7 +27,7 @@ TF_FFN_FUSED=1 TF_LINLN_FUSED=1 timeout 240 python bench.py --config cfg4 --no-c
 timeout 300 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5_default.json 2> $O/bench_cfg5_default.err
 TF_LAZY_MASKS=1 timeout 300 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5_lazy_masks.json 2> $O/bench_cfg5_lazy_masks.err
 cat $O/bench_cfg5_default.json $O/bench_cfg5_lazy_masks.json | cut -c1-260
-cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_ffn_fused.json $O/bench_cfg2_ffn_linln.json $O/bench_cfg2_stem_pool.json $O/bench_cfg2_pos_add.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json $O/bench_cfg4_ffn_linln.json | cut -c1-260
+cat $O/bench_cfg2_default.json $O/bench_cfg2_bufstore.json $O/bench_cfg2_bufstore_deep.json $O/bench_cfg2_conv1x1.json $O/bench_cfg2_input_proj.json $O/bench_cfg2_conv1x1_3x3.json $O/bench_cfg2_ffn_fused.json $O/bench_cfg2_ffn_linln.json $O/bench_cfg2_stem_pool.json $O/bench_cfg2_stem_conv.json $O/bench_cfg2_pos_add.json $O/bench_cfg2_box_refine.json $O/bench_cfg2_all_optin.json $O/bench_cfg4_default.json $O/bench_cfg4_direct9.json $O/bench_cfg4_ffn_linln.json | cut -c1-260
 
 # 4. where the encoder kernel's time goes: the kernel without one phase at a time (results wrong by design)
 {

@@ -21,7 +21,7 @@ import tempfile
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(REPO, "trackformer_amd", "csrc")
-UNITS = ["msda_hip.hip", "msda_pquad.hip", "fused_ops.hip", "linear_split.hip", "linear_stream.hip", "mha_core.hip", "ffn_fused.hip"]
+UNITS = ["msda_hip.hip", "msda_pquad.hip", "fused_ops.hip", "linear_split.hip", "linear_stream.hip", "mha_core.hip", "ffn_fused.hip", "stem_conv.hip"]
 
 
 def assembly(unit, cache):

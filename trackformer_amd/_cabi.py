@@ -32,6 +32,7 @@ EXPORTED_SYMBOLS = (
     "tf_groupnorm_nhwc_f32",
     "tf_box_refine_f32",
     "tf_bias_relu_maxpool_f32",
+    "tf_stem_conv7x7_f32",
     "tf_linear_split_f32",
     "tf_linear_split_res_f32",
     "tf_conv3x3_split_f32",
@@ -94,6 +95,8 @@ def lib():
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_add_layernorm_f32.restype = ci
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
+    L.tf_stem_conv7x7_f32.restype = ci
+    L.tf_stem_conv7x7_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_bias_relu_maxpool_f32.restype = ci
     L.tf_bias_relu_maxpool_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_box_refine_f32.restype = ci

@@ -207,13 +207,26 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
 def _stem_pooled(x, conv1, bn1, maxpool, cache: _FoldCache):
     """OPT-IN (fused.set_stem_pool_fused / TF_STEM_POOL_FUSED=1): conv1 (BN scale folded in) and then BN shift + ReLU +
     MaxPool2d(3, 2, 1) in ONE pass over the convolution's output (tf_bias_relu_maxpool_f32; bit-identical to the separate
-    passes).  Returns None when the route is off or does not apply."""
-    if not (fused.stem_pool_fused_enabled() and x.is_cuda and CHANNELS_LAST and isinstance(bn1, FrozenBatchNorm2d)
+    passes); (fused.set_stem_conv_split / TF_STEM_CONV_SPLIT=1): conv1 itself as a split product (tf_stem_conv7x7_f32).
+    Returns None when both routes are off or do not apply."""
+    if not ((fused.stem_pool_fused_enabled() or fused.stem_conv_split_enabled()) and x.is_cuda and CHANNELS_LAST
+            and isinstance(bn1, FrozenBatchNorm2d)
             and isinstance(maxpool, nn.MaxPool2d) and maxpool.kernel_size == 3 and maxpool.stride == 2
             and maxpool.padding == 1 and maxpool.dilation == 1 and not maxpool.ceil_mode):
         return None
     w, b = cache.get(conv1, bn1)
-    y = F.conv2d(x, w, None, conv1.stride, conv1.padding, conv1.dilation, conv1.groups)
+    y = None
+    if (conv1.kernel_size == (7, 7) and conv1.stride == (2, 2) and conv1.padding == (3, 3) and conv1.dilation == (1, 1)
+            and conv1.groups == 1):
+        # opt-in (fused.set_stem_conv_split): the convolution itself on the matrix cores; shift + ReLU go to whichever pass follows
+        fuse_pool = fused.stem_pool_fused_enabled()
+        y = fused.stem_conv(x, w, None if fuse_pool else b, relu=not fuse_pool)
+        if y is not None and not fuse_pool:
+            return maxpool(y)
+    if y is None:
+        if not fused.stem_pool_fused_enabled():
+            return None
+        y = F.conv2d(x, w, None, conv1.stride, conv1.padding, conv1.dilation, conv1.groups)
     pooled = fused.bias_relu_maxpool(y, b)
     if pooled is None:   # not applicable after all: the separate passes on the same convolution output
         if fused.bias_act_(y, b, None, True) is None:

@@ -25,7 +25,7 @@ GFX_ARCH = "gfx950"
 
 # (output, [sources], extra flags)
 _TARGETS = [
-    ("libtf_msda.so", ["msda_hip.hip", "msda_pquad.hip", "fused_ops.hip", "linear_split.hip", "linear_stream.hip", "mha_core.hip", "ffn_fused.hip"], []),
+    ("libtf_msda.so", ["msda_hip.hip", "msda_pquad.hip", "fused_ops.hip", "linear_split.hip", "linear_stream.hip", "mha_core.hip", "ffn_fused.hip", "stem_conv.hip"], []),
 ]
 
 

@@ -354,6 +354,65 @@ def set_stem_pool_fused(on):
     return prev
 
 
+# OPT-IN (TF_STEM_CONV_SPLIT=1 / set_stem_conv_split(True)): the 7 x 7 stem convolution as a split product on the matrix cores
+# (tf_stem_conv7x7_f32, csrc/stem_conv.hip) instead of the library convolution.
+_stem_conv_split = os.environ.get("TF_STEM_CONV_SPLIT", "0") == "1"
+
+
+def stem_conv_split_enabled():
+    return _stem_conv_split
+
+
+def set_stem_conv_split(on):
+    global _stem_conv_split
+    prev, _stem_conv_split = _stem_conv_split, bool(on)
+    return prev
+
+
+def _stem_packed(weight):
+    """Packed [64, 176] image (k = (c * 7 + ky) * 8 + kx, zero padded) of a [64, 3, 7, 7] weight, cached on the tensor."""
+    hit = getattr(weight, "_tf_stem_packed", None)
+    if hit is None or hit[0] != weight._version:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        w = weight.detach()
+        w2 = torch.zeros((64, 176), dtype=torch.float32, device=w.device)
+        w2[:, :168] = F.pad(w, (0, 1)).reshape(64, 168)
+        nbytes = _cabi.lib().tf_linear_packed_bytes(176, 64)
+        with torch.cuda.device(w.device):
+            packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            rc = _cabi.lib().tf_linear_pack_weight_f32(w2.data_ptr(), packed.data_ptr(), 176, 64, _stream(w.device))
+        _cabi.check(rc, "tf_linear_pack_weight_f32")
+        hit = (weight._version, packed, w2)   # w2 is kept alive until the packing kernel has certainly run
+        weight._tf_stem_packed = hit
+    return hit[1]
+
+
+def stem_conv(x, weight, bias=None, relu=False):
+    """conv2d(x, weight, stride 2, padding 3) (+ bias, ReLU) for x [N, 3, H, W] fp32 on the GPU and a [64, 3, 7, 7] weight
+    (reference: torchvision resnet50.conv1 under models/backbone.py:93-104) -> channels_last [N, 64, Ho, Wo], or None."""
+    if not (_stem_conv_split and _split_linear and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
+            and tuple(weight.shape) == (64, 3, 7, 7) and weight.dtype == torch.float32 and weight.device == x.device
+            and x.numel() > 0):
+        return None
+    if bias is not None and not (_param_ok(bias, x) and bias.numel() == 64):
+        return None
+    x = x if x.is_contiguous() else x.contiguous()
+    n, _, h, w = x.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if n > 65535 or n * ho * wo * 256 >= 0xC0000000 or n * 3 * h * w >= 2 ** 31:
+        return None
+    packed = _stem_packed(weight)
+    if packed is None:
+        return None
+    with torch.cuda.device(x.device):
+        y = torch.empty((n, 64, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        rc = _cabi.lib().tf_stem_conv7x7_f32(x.data_ptr(), packed.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(),
+                                             n, h, w, 1 if relu else 0, _stream(x.device))
+    _cabi.check(rc, "tf_stem_conv7x7_f32")
+    return y
+
+
 def bias_relu_maxpool(x, bias):
     """maxpool3x3/s2/p1(relu(x + bias[c])) of a channels_last [N, C, H, W] fp32 GPU tensor -> channels_last
     [N, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1], or None when the kernel does not apply."""
