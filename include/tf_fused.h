@@ -93,6 +93,13 @@ int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid,
  */
 int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
                          int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+/* The same convolution with the K loop (9 Cin) cut into `ksplit` pieces that run as separate workgroups -- for few output
+ * pixels under a long K (the extra pyramid level of deformable_detr.py:55-79: 2048 -> 256 at 13 x 21; layer4's 3 x 3
+ * convolutions).  The pieces write partial sums to `workspace` (ksplit * N*Hout*Wout * cout floats, 16-byte aligned), a second
+ * launch adds them in a fixed order (deterministic, unlike atomics) and applies bias / ReLU.  ksplit in 1..64 (1: no workspace
+ * needed, identical to tf_conv3x3_split_f32); cout % 4 == 0 and 16-byte aligned y / bias when ksplit > 1. */
+int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, float *workspace,
+                          int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
 /* The same kernel for a strided 1 x 1 convolution without padding (w [Cout, Cin]): the projections of the identity branch
  * (torchvision Bottleneck.downsample, stride 2) -- the rows of the GEMM are every stride-th pixel. */
 int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,

@@ -65,6 +65,8 @@ def lib():
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci
     L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_conv3x3_splitk_f32.restype = ci
+    L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv3x3_split_f32.restype = ci
     L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_conv1x1_strided_split_f32.restype = ci
@@ -372,6 +374,23 @@ def conv3x3_split(x_nhwc, w_ohwi, bias=None, relu=False, stride=1):
     rc = fn(_p(x), _p(hi), _p(mid), _p(b), _p(y), n, h, wd, cin, cout, stride, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_conv3x3_split_f32: status %d" % rc)
+    return y
+
+
+def conv3x3_splitk(x_nhwc, w_ohwi, bias=None, relu=False, stride=1, ksplit=4):
+    """tf_conv3x3_splitk_f32: as conv3x3_split (3 x 3, padding 1) with the K loop cut into `ksplit` pieces."""
+    x, w = _aligned(x_nhwc), _c(w_ohwi, np.float32)
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    hi, mid = bf16_split(w.reshape(cout, 9 * cin))
+    hi, mid = _aligned16(np.ascontiguousarray(hi)), _aligned16(np.ascontiguousarray(mid))
+    b = _aligned(bias)
+    ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    y = _aligned(np.full((n, ho, wo, cout), np.nan, np.float32))
+    ws = _aligned(np.full((max(ksplit, 1), n * ho * wo * cout), np.nan, np.float32))
+    rc = lib().tf_conv3x3_splitk_f32(_p(x), _p(hi), _p(mid), _p(b), _p(y), _p(ws), ksplit, n, h, wd, cin, cout, stride, int(relu), None)
+    if rc != 0:
+        raise RuntimeError("tf_conv3x3_splitk_f32: status %d" % rc)
     return y
 
 

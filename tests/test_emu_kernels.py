@@ -802,3 +802,26 @@ def test_stem_convolution_as_split_product(n, h, w):
     assert np.abs(y2 - np.maximum(ref + b, 0)).max() < 1e-4 * max(1.0, np.abs(ref).max())
     st = emu_lib.stats()
     assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,stride,ksplit", [(1, 9, 11, 128, 64, 2, 4), (1, 7, 6, 256, 256, 2, 9), (2, 5, 5, 64, 128, 1, 18),
+                                                          (1, 6, 7, 96, 64, 1, 5), (1, 4, 4, 32, 64, 2, 1)], ids=lambda v: str(v))
+def test_conv3x3_split_k(n, h, w, cin, cout, stride, ksplit):
+    """tf_conv3x3_splitk_f32: the K loop of the 3 x 3 convolution cut into pieces (partial sums in a workspace, added in a
+    fixed order by a second launch, then bias / ReLU) -- the extra pyramid level's 2048 -> 256 projection at 13 x 21 and
+    layer4's convolutions have few output pixels under a long K.  Against torch float64 and against the unsplit kernel
+    (same products; the sum order differs, so up to rounding)."""
+    import torch
+    rng = np.random.default_rng(h * w + cin + ksplit)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, 3, 3, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double().permute(0, 3, 1, 2),
+                                     torch.from_numpy(b).double(), stride=stride, padding=1).clamp_min(0).permute(0, 2, 3, 1).numpy()
+    y = emu_lib.conv3x3_splitk(x, wt, b, relu=True, stride=stride, ksplit=ksplit)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    base = emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride)
+    assert np.abs(y - base).max() < 1e-5 * max(1.0, np.abs(ref).max())
+    if ksplit == 1:
+        assert np.array_equal(y, base)

@@ -304,3 +304,30 @@ def test_optin_fused_ffn_route_full_size(dev, models, case):
     z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
     assert int(z["num_tracks"]) == tracker.track_num and z["active_per_frame"].tolist() == active
     np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
+
+
+@optin
+@pytest.mark.parametrize("shape,cout,stride,ksplit", [((1, 2048, 25, 42), 256, 2, 36), ((1, 512, 25, 42), 512, 1, 5), ((1, 256, 100, 167), 256, 2, 2)])
+def test_optin_conv3x3_split_k(dev, shape, cout, stride, ksplit):
+    """tf_conv3x3_splitk_f32: the K loop cut into workgroups with a deterministic second pass, against the library
+    convolution (1e-3 of the output scale) and run twice (bit-identical: no atomics)."""
+    from trackformer_amd import _cabi, fused
+    g = torch.Generator().manual_seed(shape[1] + ksplit)
+    x = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, shape[1], 3, 3, generator=g) / (3 * shape[1] ** 0.5)).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    taps = w.permute(0, 2, 3, 1).reshape(cout, 9 * shape[1]).contiguous()
+    hi, mid = fused._split_weight(taps)
+    n, cin, h, wd = shape
+    ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+    outs = []
+    for _ in range(2):
+        y = torch.full((n, ho, wo, cout), float("nan"), device=dev)
+        ws = torch.empty((ksplit, n * ho * wo * cout), device=dev)
+        rc = _cabi.lib().tf_conv3x3_splitk_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                               ksplit, n, h, wd, cin, cout, stride, 1, fused._stream(dev))
+        _cabi.check(rc, "tf_conv3x3_splitk_f32")
+        outs.append(y)
+    ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)).permute(0, 2, 3, 1)
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - ref).abs().max()) < 1e-3 * float(ref.abs().max())

@@ -36,6 +36,7 @@ EXPORTED_SYMBOLS = (
     "tf_linear_split_f32",
     "tf_linear_split_res_f32",
     "tf_conv3x3_split_f32",
+    "tf_conv3x3_splitk_f32",
     "tf_conv1x1_strided_split_f32",
     "tf_linear_packed_bytes",
     "tf_linear_pack_weight_f32",
@@ -107,6 +108,8 @@ def lib():
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci
     L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_conv3x3_splitk_f32.restype = ci
+    L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv3x3_split_f32.restype = ci
     L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_conv1x1_strided_split_f32.restype = ci

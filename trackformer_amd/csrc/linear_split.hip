@@ -252,6 +252,8 @@ split_gemm_add_kernel(const float *__restrict__ X, const float *__restrict__ X2,
 struct Conv3Args {
     int nimg, hin, win, cin, hout, wout, cout, stride;
     int ks, pad;   // 3 / 1 (the bottlenecks' 3 x 3 convolutions) or 1 / 0 (the strided 1 x 1 projections of the identity branch)
+    int kslices;   // 0: a block walks the whole K; > 0 (split-K): block z walks K-slices z kslices .. and writes its partial
+                   // sums to Y + z M N (no bias / ReLU) -- few output pixels with a long K (the extra pyramid level, layer4)
 };
 
 template <int BM, int BN, bool RELU>
@@ -342,11 +344,14 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         }
     };
 
-    load_slice(0);
-    for (int k0 = 0; k0 < K; k0 += BK) {
+    const int kbeg = ca.kslices > 0 ? (int)blockIdx.z * ca.kslices * BK : 0;
+    const int kend = ca.kslices > 0 ? min(K, kbeg + ca.kslices * BK) : K;
+    if (ca.kslices > 0) Y += (size_t)blockIdx.z * M * N;   // this split's partial sums
+    load_slice(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
         store_slice();
         __syncthreads();
-        if (k0 + BK < K) load_slice(k0 + BK);   // in flight during the MFMAs below
+        if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int koff = kk + (lane >> 5) * 8;
@@ -393,6 +398,26 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
                                                       base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
             }
         }
+}
+
+// ---- split-K second pass: y = act(sum_z partial[z] + bias), the partials added in the order z = 0, 1, ... (a fixed order:
+// the result does not depend on scheduling, unlike atomic accumulation).  One thread per 4 consecutive outputs.
+__global__ void __launch_bounds__(256)
+conv_splitk_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias, float *__restrict__ y, long long mn4,
+                          int n4, int splits, int relu)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= mn4) return;
+    f32x4 acc = reinterpret_cast<const f32x4 *>(part)[i];
+    for (int z = 1; z < splits; ++z) acc += reinterpret_cast<const f32x4 *>(part)[(long long)z * mn4 + i];
+    if (bias != nullptr) acc += reinterpret_cast<const f32x4 *>(bias)[i % n4];
+    if (relu) {
+        acc.x = acc.x > 0.f ? acc.x : 0.f;
+        acc.y = acc.y > 0.f ? acc.y : 0.f;
+        acc.z = acc.z > 0.f ? acc.z : 0.f;
+        acc.w = acc.w > 0.f ? acc.w : 0.f;
+    }
+    reinterpret_cast<f32x4 *>(y)[i] = acc;
 }
 
 // ---- few rows (the decoder: 400 / 800 queries): a launch is 28-100 blocks, far fewer than CUs, and each block walks its
@@ -925,7 +950,15 @@ extern "C" int tf_linear_split_add_f32(const float *x, const float *x2, const vo
 
 namespace {
 int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg, int hin, int win,
-                    int cin, int cout, int stride, int ks, int relu, void *stream);
+                    int cin, int cout, int stride, int ks, int relu, void *stream, int ksplit = 1, float *workspace = nullptr);
+}
+
+extern "C" int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
+                                     float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+                                     void *stream)
+{
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && !workspace)) return ksplit > 1 && !workspace ? TF_MSDA_ERR_NULL_POINTER : TF_MSDA_ERR_BAD_DIMS;
+    return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream, ksplit, workspace);
 }
 
 extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
@@ -942,7 +975,7 @@ extern "C" int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, co
 
 namespace {
 int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg, int hin, int win,
-                    int cin, int cout, int stride, int ks, int relu, void *stream)
+                    int cin, int cout, int stride, int ks, int relu, void *stream, int ksplit, float *workspace)
 {
     if (!x || !w_hi || !w_mid || !y) return TF_MSDA_ERR_NULL_POINTER;
     if (nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % BK) != 0 || (stride != 1 && stride != 2))
@@ -950,24 +983,46 @@ int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const f
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_mid)) & 15)
         return TF_MSDA_ERR_BAD_DIMS;
     const int pad = ks == 3 ? 1 : 0;
-    Conv3Args ca{nimg, hin, win, cin, (hin + 2 * pad - ks) / stride + 1, (win + 2 * pad - ks) / stride + 1, cout, stride, ks, pad};
+    Conv3Args ca{nimg, hin, win, cin, (hin + 2 * pad - ks) / stride + 1, (win + 2 * pad - ks) / stride + 1, cout, stride, ks, pad, 0};
     const long long M = (long long)nimg * ca.hout * ca.wout;
     if (M <= 0 || (M + 256) * cout * 4 >= 0xC0000000LL || (long long)nimg * hin * win * cin * 4 >= (1LL << 40)) return TF_MSDA_ERR_BAD_DIMS;
     const unsigned short *wh = static_cast<const unsigned short *>(w_hi), *wm = static_cast<const unsigned short *>(w_mid);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (cout >= 128) {
-        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + 127) / 128));
-        if (relu)
-            hipLaunchKernelGGL((split_conv3_kernel<64, 128, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, ca);
-        else
-            hipLaunchKernelGGL((split_conv3_kernel<64, 128, false>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, ca);
-    } else {
-        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + 63) / 64));
-        if (relu)
-            hipLaunchKernelGGL((split_conv3_kernel<64, 64, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, ca);
-        else
-            hipLaunchKernelGGL((split_conv3_kernel<64, 64, false>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, ca);
+    // split-K: z-slices of the K loop write partial sums to the workspace [ksplit][M][cout], a second pass adds them in order
+    const int slices = ks * ks * cin / BK;
+    unsigned gz = 1;
+    float *out = y;
+    const float *kbias = bias;
+    int krelu = relu;
+    if (ksplit > 1) {
+        if ((cout & 3) || (reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15)
+            return TF_MSDA_ERR_BAD_DIMS;
+        ca.kslices = (slices + ksplit - 1) / ksplit;
+        gz = (unsigned)((slices + ca.kslices - 1) / ca.kslices);   // every z has at least one slice
+        out = workspace;
+        kbias = nullptr;
+        krelu = 0;
     }
-    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    if (cout >= 128) {
+        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + 127) / 128), gz);
+        if (krelu)
+            hipLaunchKernelGGL((split_conv3_kernel<64, 128, true>), grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
+        else
+            hipLaunchKernelGGL((split_conv3_kernel<64, 128, false>), grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
+    } else {
+        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + 63) / 64), gz);
+        if (krelu)
+            hipLaunchKernelGGL((split_conv3_kernel<64, 64, true>), grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
+        else
+            hipLaunchKernelGGL((split_conv3_kernel<64, 64, false>), grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
+    }
+    if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    if (ksplit > 1) {
+        const long long mn4 = M * cout / 4;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, s, workspace, bias, y, mn4,
+                           cout / 4, (int)gz, relu);
+        if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    }
+    return TF_MSDA_OK;
 }
 }  // namespace

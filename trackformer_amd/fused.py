@@ -501,13 +501,36 @@ def conv3x3(x, w_taps, bias, relu, stride):
         return None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    ksplit = _conv_ksplit(n * ho * wo, cin, cout) if ks == 3 else 1
     with torch.cuda.device(x.device):
         y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
-        fn = _cabi.lib().tf_conv3x3_split_f32 if ks == 3 else _cabi.lib().tf_conv1x1_strided_split_f32
-        rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), n, h, w,
-                cin, cout, stride, 1 if relu else 0, _stream(x.device))
+        if ksplit > 1:   # few output pixels under a long K: split the K loop over workgroups (deterministic second pass)
+            ws = torch.empty((ksplit, n * ho * wo * cout), dtype=torch.float32, device=x.device)
+            rc = _cabi.lib().tf_conv3x3_splitk_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(),
+                                                   y.data_ptr(), ws.data_ptr(), ksplit, n, h, w, cin, cout, stride,
+                                                   1 if relu else 0, _stream(x.device))
+        else:
+            fn = _cabi.lib().tf_conv3x3_split_f32 if ks == 3 else _cabi.lib().tf_conv1x1_strided_split_f32
+            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), n, h, w,
+                    cin, cout, stride, 1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_conv3x3_split_f32")
     return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
+
+
+_conv_splitk = os.environ.get("TF_CONV_SPLITK", "1") not in ("", "0")
+
+
+def _conv_ksplit(m, cin, cout):
+    """Pieces the K loop of a 3 x 3 split-product convolution is cut into: 1 unless the launch would have fewer workgroups
+    than the chip has CUs while every one of them walks a long K (layer3 / layer4 and the extra pyramid level at 800 x 1333:
+    132 / 68 / 10 workgroups of 72 / 144 / 576 K-slices)."""
+    if not _conv_splitk or cout % 4:
+        return 1
+    blocks = -(-m // 64) * -(-cout // (128 if cout >= 128 else 64))
+    slices = 9 * cin // 32
+    if blocks >= 160 or slices < 64:
+        return 1
+    return max(1, min(64, 384 // blocks, slices // 8))
 
 
 # OPT-IN (TF_INPUT_PROJ_FUSED=1 / set_input_proj_fused(True)), not yet timed on hardware: the reference's `input_proj`
@@ -544,10 +567,27 @@ def groupnorm_nhwc(x2, n_img, gn):
 
 
 def input_proj_1x1(x, conv, gn):
-    """GroupNorm(conv1x1(x)) for a channels_last fp32 GPU activation x [N, Cin, H, W]; returns [N, Cout, H, W]
+    """GroupNorm(conv(x)) for the input projections -- 1 x 1 convolutions, and the extra level's 3 x 3 / stride 2 one -- of a
+    channels_last fp32 GPU activation x [N, Cin, H, W]; returns [N, Cout, H', W']
     (channels_last) or None when the fused route does not apply (the caller keeps the nn.Sequential)."""
-    if not (_input_proj_fused and _split_linear and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32
-            and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1):
+    if not (_input_proj_fused and _split_linear and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and conv.groups == 1):
+        return None
+    if conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.padding == (1, 1) and conv.dilation == (1, 1):
+        # the extra pyramid level (deformable_detr.py:55-79: Conv2d(2048, hidden, 3, stride 2, padding 1) + GroupNorm)
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        cout, cin = conv.out_channels, conv.in_channels
+        hit = getattr(conv, "_tf_wtaps", None)   # persistent [Cout, 9 * Cin] tap-major image: the split pieces are cached on it
+        if hit is None or hit[0] != conv.weight._version or hit[1].device != conv.weight.device:
+            hit = (conv.weight._version, conv.weight.detach().permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous())
+            conv._tf_wtaps = hit
+        y = conv3x3(x, hit[1], conv.bias, False, 2)
+        if y is None:
+            return None
+        n, _, ho, wo = y.shape
+        z2 = groupnorm_nhwc(y.permute(0, 2, 3, 1).reshape(n * ho * wo, cout), n, gn)
+        return None if z2 is None else z2.view(n, ho, wo, cout).permute(0, 3, 1, 2)
+    if not (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0)):
         return None
     if not x.is_contiguous(memory_format=torch.channels_last):
         x = x.contiguous(memory_format=torch.channels_last)
