@@ -62,6 +62,7 @@ cat $O/ffn_fused.txt
 
 # 2d. the backbone's bottleneck convolutions shape by shape: library convolution + bias_act against the split-product routes
 timeout 600 python tools/bench_conv.py > $O/conv_per_layer.txt 2>&1
+TF_CONV_SPLITK=0 timeout 600 python tools/bench_conv.py > $O/conv_per_layer_no_splitk.txt 2>&1   # layer3 / layer4 3x3 rows without the split-K launch
 cat $O/conv_per_layer.txt
 
 # 3. frames/s: the defaults against every opt-in route at once (the per-option runs are in gpu_r03_second.sh)
