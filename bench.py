@@ -571,6 +571,7 @@ def main():
         fused.set_stem_pool_fused(True)
         fused.set_pos_add_fused(True)
         fused.set_stem_conv_split(True)
+        fused.set_heads_split(True)
 
     if args.roofline_only:
         if rank == 0:

@@ -27,6 +27,7 @@ def _run(case, optin, fn=None):
                     (fused.set_stem_pool_fused, fused.set_stem_pool_fused(True)),
                     (fused.set_pos_add_fused, fused.set_pos_add_fused(True)),
                     (fused.set_stem_conv_split, fused.set_stem_conv_split(True)),
+                    (fused.set_heads_split, fused.set_heads_split(True)),
                     (lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
                     (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
             fused._LINLN_MIN_ROWS = 1

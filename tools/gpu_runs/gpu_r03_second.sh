@@ -16,6 +16,7 @@ timeout 240 python bench.py --no-cpu-baseline --no-roofline --conv1x1-split --co
 TF_LINEAR_BUFSTORE=1 TF_LINEAR_DEEP=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_bufstore_deep.json 2> $O/bench_cfg2_bufstore_deep.err
 TF_FFN_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_ffn_fused.json 2> $O/bench_cfg2_ffn_fused.err
 TF_STEM_POOL_FUSED=1 TF_STEM_CONV_SPLIT=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_stem_conv.json 2> $O/bench_cfg2_stem_conv.err
+TF_HEADS_SPLIT=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_heads_split.json 2> $O/bench_cfg2_heads_split.err
 TF_POS_ADD_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_pos_add.json 2> $O/bench_cfg2_pos_add.err
 TF_STEM_POOL_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_stem_pool.json 2> $O/bench_cfg2_stem_pool.err
 TF_FFN_FUSED=1 TF_LINLN_FUSED=1 timeout 240 python bench.py --no-cpu-baseline --no-roofline > $O/bench_cfg2_ffn_linln.json 2> $O/bench_cfg2_ffn_linln.err

@@ -156,7 +156,7 @@ class DeformableDETR(DETR):
             # the box head (deformable_transformer.py:412-422 vs deformable_detr.py:238-246, same
             # modules, same inputs): the refined reference points ARE the per-layer box predictions.
             outputs_coord = inter_references
-            outputs_class = torch.stack([self.class_embed[lvl](hs[lvl])
+            outputs_class = torch.stack([fused.head_linear(self.class_embed[lvl], hs[lvl])
                                          for lvl in range(hs.shape[0])])
         else:
             outputs_classes, outputs_coords = [], []

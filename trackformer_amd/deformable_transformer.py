@@ -196,6 +196,23 @@ class DeformableTransformer(nn.Module):
         return torch.stack([valid_w.float() / W, valid_h.float() / H], -1)
 
     # ------------------------------------------------------------------ forward
+    def _object_reference_points(self, query_param, query_embed, bs):
+        """sigmoid(reference_points(query_embed)) of the object queries (deformable_transformer.py:199 of the reference).  In
+        inference it depends on parameters only: kept until one of them changes."""
+        if self.training or torch.is_grad_enabled():
+            return self.reference_points(query_embed).sigmoid()
+        lin = self.reference_points
+        key = (id(query_param), query_param._version, query_param.data_ptr(), lin.weight._version, lin.weight.data_ptr(),
+               lin.bias._version, bs, query_embed.device)
+        hit = self.__dict__.get("_ref_points_cache")
+        if hit is None or hit[0] != key:
+            value = lin(query_embed).sigmoid()
+            if query_embed.is_cuda and torch.cuda.is_current_stream_capturing():
+                return value   # never keep a buffer of a graph's memory pool
+            hit = (key, value, query_param)
+            self.__dict__["_ref_points_cache"] = hit
+        return hit[1]
+
     def _level_position_embedding(self, pos_embeds):
         """cat_l(pos_l flattened + level_embed[l]) (deformable_transformer.py:139-156 of the reference).  In inference the
         position encodings of an unpadded frame are cached tensors (position_encoding.py), so the result is a per-geometry
@@ -273,10 +290,11 @@ class DeformableTransformer(nn.Module):
                 self.pos_trans(self.get_proposal_pos_embed(topk_coords_unact)))
             query_embed, tgt = torch.split(pos_trans_out, c, dim=2)
         else:
+            query_param = query_embed
             query_embed, tgt = torch.split(query_embed, c, dim=1)
             query_embed = query_embed.unsqueeze(0).expand(bs, -1, -1)
             tgt = tgt.unsqueeze(0).expand(bs, -1, -1)
-            reference_points = self.reference_points(query_embed).sigmoid()
+            reference_points = self._object_reference_points(query_param, query_embed, bs)
 
             if targets is not None and 'track_query_hs_embeds' in targets[0]:
                 # TrackFormer: track queries go FIRST; their content is the previous frame's output

@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import box_ops
+from . import box_ops, fused
 from .nested import NestedTensor, nested_tensor_from_tensor_list
 
 
@@ -22,9 +22,7 @@ class MLP(nn.Module):
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
-            x = layer(x)
-            if i < self.num_layers - 1:
-                x = F.relu(x)
+            x = fused.head_linear(layer, x, relu=i < self.num_layers - 1)   # (the opt-in split product or layer(x) + ReLU)
         return x
 
 

@@ -429,6 +429,32 @@ def bias_relu_maxpool(x, bias):
     return out
 
 
+# OPT-IN (TF_HEADS_SPLIT=1 / set_heads_split(True)): the small head GEMMs (box-regression MLPs, class heads: 400 rows) through
+# the split-product kernels as well instead of hipBLASLt -- 24 launches per frame; the class logits then carry the three-term
+# product's ~1e-5 relative error like everything else (tools/experiments/bf16_split_linear.py: parity and track ids hold).
+_heads_split = os.environ.get("TF_HEADS_SPLIT", "0") == "1"
+
+
+def heads_split_enabled():
+    return _heads_split
+
+
+def set_heads_split(on):
+    global _heads_split
+    prev, _heads_split = _heads_split, bool(on)
+    return prev
+
+
+def head_linear(module, x, relu=False):
+    """act(module(x)) for a head's nn.Linear: the split product when the opt-in is on (inference on the GPU), else the module."""
+    if _heads_split and not module.training and not torch.is_grad_enabled():
+        y = linear(x, module.weight, module.bias, relu=relu)
+        if y is not None:
+            return y
+    y = module(x)
+    return F.relu(y) if relu else y
+
+
 # OPT-IN (TF_POS_ADD_FUSED=1 / set_pos_add_fused(True)): `with_pos_embed(x, pos)` in front of a projection is done inside the
 # GEMM while the activation tile is staged (tf_linear_split_add_f32) instead of as its own pass over the tokens; bit-identical.
 _pos_add_fused = os.environ.get("TF_POS_ADD_FUSED", "0") == "1"
