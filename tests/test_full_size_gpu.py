@@ -331,3 +331,33 @@ def test_optin_conv3x3_split_k(dev, shape, cout, stride, ksplit):
     ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)).permute(0, 2, 3, 1)
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0] - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+
+
+@optin
+@pytest.mark.parametrize("case", list(um.FULL_CASES))
+def test_optin_every_route_at_once_full_size(dev, models, case):
+    """Every opt-in switch of DESIGN.md section 4.3 at once (what `TF_ALL_OPTIN=1 bench.py` runs): BASELINE-size model
+    against the reference goldens and, for cfg 2, the tracker's ids.  On the emulator this configuration gives boxes 1.7e-6,
+    logits 6.6e-5 and exact ids (profiles/r02_emulator_full_size_parity.txt)."""
+    from trackformer_amd import _cabi, backbone, fused
+    lib = _cabi.lib()
+    setters = [backbone.set_conv1x1_split, backbone.set_conv3x3_split, fused.set_input_proj_fused, fused.set_box_refine_fused,
+               fused.set_ffn_fused, fused.set_linear_ln_fused, fused.set_stem_pool_fused, fused.set_pos_add_fused,
+               fused.set_stem_conv_split, fused.set_heads_split]
+    prev = [s(True) for s in setters]
+    opts = {b"linear_bufstore": 2, b"linear_deep": 1, b"pquad_pipe": 1, b"direct9": 1, b"mha_batch": 1, b"bias_act_batch": 1}
+    prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
+    try:
+        model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
+        dbox, dlogit = _compare(case, model, out, res, feats, memory)
+        print("%s / every opt-in route: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+        if "cfg2" in case:
+            tracker, rows, active = _run_tracker(models, dev, "graph_split_linear")
+            z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
+            assert int(z["num_tracks"]) == tracker.track_num and z["active_per_frame"].tolist() == active
+            np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
+    finally:
+        for s, p in zip(setters, prev):
+            s(p)
+        for k, v in prev_opts.items():
+            lib.tf_msda_set_option(k, v)
