@@ -171,6 +171,21 @@ def init_distributed(args):
     return rank, local_rank, world
 
 
+def _active_optins(backbone, fused):
+    """Names of the opt-in routes that are switched on in this process: recorded in the JSON line."""
+    flags = [("conv1x1_split", backbone._conv1x1_split), ("conv3x3_split", backbone._conv3x3_split),
+             ("input_proj_fused", fused._input_proj_fused), ("box_refine_fused", fused._box_refine_fused),
+             ("ffn_fused", fused.ffn_fused_enabled()), ("linln_fused", fused.linear_ln_fused_enabled()),
+             ("stem_pool_fused", fused.stem_pool_fused_enabled()), ("stem_conv_split", fused.stem_conv_split_enabled()),
+             ("pos_add_fused", fused.pos_add_fused_enabled()), ("heads_split", fused.heads_split_enabled())]
+    names = [n for n, on in flags if on]
+    for env in ("TF_LINEAR_BUFSTORE", "TF_LINEAR_DEEP", "TF_MHA_BATCH", "TF_BIAS_ACT_BATCH", "TF_MSDA_PQUAD", "TF_MSDA_DIRECT9",
+                "TF_CONV_SPLIT_SKIP", "TF_CONV_SPLITK", "TF_LAZY_MASKS"):
+        if os.environ.get(env):
+            names.append("%s=%s" % (env, os.environ[env]))
+    return names
+
+
 def build_model(cfg, device):
     from trackformer_amd import config, factory
     margs = config.make_args(*cfg["overlays"], device=str(device), **cfg["overrides"])
@@ -632,6 +647,7 @@ def main():
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
                        "linears": "bf16 split product (hi.hi + hi.mid + mid.hi, f32 accumulate)"
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",
+                       **({"optin": _active_optins(_backbone, fused)} if not train and _active_optins(_backbone, fused) else {}),
                        **({"ffn": "one launch per feed-forward block (tf_ffn_fused_f32)"} if fused.ffn_fused_enabled() and not train else {}),
                        **({"projection_norm": "output projection + residual + LayerNorm in one launch (tf_linear_res_ln_f32)"}
                           if fused.linear_ln_fused_enabled() and not train else {}),
