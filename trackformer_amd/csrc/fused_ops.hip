@@ -163,7 +163,7 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // Replaces the ATen path behind the reference's `input_proj` (models/deformable_detr.py:73-90: Conv2d + GroupNorm(32, 256)),
 // which for channels_last inputs is a layout copy + RowwiseMoments over only N * 32 rows + a parameter kernel + an
 // element-wise kernel (0.2 ms per frame, profiles/r02_e2e_eager_per_frame.txt).
-constexpr int kGnRowsPerBlock = 128;
+constexpr int kGnRowsPerBlock = 64;   // 261 workgroups for the largest level at 800 x 1333 (16 700 pixels)
 
 __global__ void __launch_bounds__(256)
 groupnorm_stats_kernel(const float *__restrict__ x, double *__restrict__ ws, int HW, int C, int G, long long x_image_stride)
@@ -179,7 +179,20 @@ groupnorm_stats_kernel(const float *__restrict__ x, double *__restrict__ ws, int
     if (rslot < nslots) {
         const f32x4_t *xp = reinterpret_cast<const f32x4_t *>(x + (long long)n * x_image_stride);
         f32x4_t sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
-        for (int r = r0 + rslot; r < r1; r += nslots) {
+        int r = r0 + rslot;
+        for (; r + 3 * nslots < r1; r += 4 * nslots) {   // four rows in flight per thread, accumulated in row order
+            const f32x4_t v0 = xp[(long long)r * C4 + q], v1 = xp[(long long)(r + nslots) * C4 + q];
+            const f32x4_t v2 = xp[(long long)(r + 2 * nslots) * C4 + q], v3 = xp[(long long)(r + 3 * nslots) * C4 + q];
+            sum += v0;
+            sq += v0 * v0;
+            sum += v1;
+            sq += v1 * v1;
+            sum += v2;
+            sq += v2 * v2;
+            sum += v3;
+            sq += v3 * v3;
+        }
+        for (; r < r1; r += nslots) {
             const f32x4_t v = xp[(long long)r * C4 + q];
             sum += v;
             sq += v * v;
@@ -267,31 +280,34 @@ __global__ void __launch_bounds__(256)
 bias_relu_maxpool_kernel(const float *__restrict__ x, const float *__restrict__ bias, float *__restrict__ out, int H, int W,
                          int C4, int Ho, int Wo, long long total)
 {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int c4 = (int)(idx % C4);
-    long long p = idx / C4;
-    const int ox = (int)(p % Wo);
-    p /= Wo;
-    const int oy = (int)(p % Ho);
-    const long long n = p / Ho;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;   // total < 2^31 (host): 32-bit index arithmetic, no division loops
+    if (idx >= (unsigned)total) return;
+    const unsigned c4 = idx % (unsigned)C4;
+    unsigned p = idx / (unsigned)C4;
+    const int ox = (int)(p % (unsigned)Wo);
+    p /= (unsigned)Wo;
+    const int oy = (int)(p % (unsigned)Ho);
+    const long long n = p / (unsigned)Ho;
     const f32x4_t *xi = reinterpret_cast<const f32x4_t *>(x) + n * (long long)H * W * C4 + c4;
-    const float ninf = -__builtin_inff();
-    f32x4_t m = {ninf, ninf, ninf, ninf};
+    // the nine loads first (clamped addresses: a window position outside the image re-reads an inside one, which cannot
+    // change a maximum), no branch between them
+    f32x4_t v[9];
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
-        const int iy = 2 * oy + dy;
-        if (iy < 0 || iy >= H) continue;
+        const int iy = min(max(2 * oy + dy, 0), H - 1);
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
-            const int ix = 2 * ox + dx;
-            if (ix < 0 || ix >= W) continue;
-            const f32x4_t v = xi[((long long)iy * W + ix) * C4];
-            m.x = v.x > m.x ? v.x : m.x;
-            m.y = v.y > m.y ? v.y : m.y;
-            m.z = v.z > m.z ? v.z : m.z;
-            m.w = v.w > m.w ? v.w : m.w;
+            const int ix = min(max(2 * ox + dx, 0), W - 1);
+            v[(dy + 1) * 3 + dx + 1] = xi[((long long)iy * W + ix) * C4];
         }
+    }
+    f32x4_t m = v[4];   // the window's centre (2 oy, 2 ox) always lies inside
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        m.x = v[k].x > m.x ? v[k].x : m.x;
+        m.y = v[k].y > m.y ? v[k].y : m.y;
+        m.z = v[k].z > m.z ? v[k].z : m.z;
+        m.w = v[k].w > m.w ? v[k].w : m.w;
     }
     const f32x4_t b = reinterpret_cast<const f32x4_t *>(bias)[c4];
     m += b;
@@ -314,7 +330,7 @@ int tf_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int 
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const long long total = (long long)N * Ho * Wo * (C / 4);
     const long long blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
+    if (total >= (1LL << 31)) return TF_MSDA_ERR_BAD_DIMS;
     hipLaunchKernelGGL(bias_relu_maxpool_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, bias,
                        out, H, W, C / 4, Ho, Wo, total);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;

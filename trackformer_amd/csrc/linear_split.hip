@@ -406,11 +406,20 @@ __global__ void __launch_bounds__(256)
 conv_splitk_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias, float *__restrict__ y, long long mn4,
                           int n4, int splits, int relu)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= mn4) return;
-    f32x4 acc = reinterpret_cast<const f32x4 *>(part)[i];
-    for (int z = 1; z < splits; ++z) acc += reinterpret_cast<const f32x4 *>(part)[(long long)z * mn4 + i];
-    if (bias != nullptr) acc += reinterpret_cast<const f32x4 *>(bias)[i % n4];
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;   // mn4 < 2^31 (the output is below 3 GiB): 32-bit index arithmetic
+    if (i >= (unsigned)mn4) return;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(part) + i;
+    f32x4 acc = p[0];
+    int z = 1;
+    for (; z + 3 < splits; z += 4) {   // four loads in flight, added in the order z, z + 1, ...
+        const f32x4 a = p[(long long)z * mn4], b = p[(long long)(z + 1) * mn4], c = p[(long long)(z + 2) * mn4], d = p[(long long)(z + 3) * mn4];
+        acc += a;
+        acc += b;
+        acc += c;
+        acc += d;
+    }
+    for (; z < splits; ++z) acc += p[(long long)z * mn4];
+    if (bias != nullptr) acc += reinterpret_cast<const f32x4 *>(bias)[i % (unsigned)n4];
     if (relu) {
         acc.x = acc.x > 0.f ? acc.x : 0.f;
         acc.y = acc.y > 0.f ? acc.y : 0.f;
