@@ -122,12 +122,15 @@ def parse_args():
                          "(tf_linear_split_f32; same as TF_SPLIT_LINEAR=1)")
     ap.add_argument("--no-split-linear", dest="split_linear", action="store_false")
     ap.add_argument("--conv1x1-split", dest="conv1x1_split", action="store_true", default=None,
-                    help="OPT-IN: the backbone's stride-1 1x1 convolutions through the split-product GEMM with the "
-                         "FrozenBN / identity / ReLU epilogue (same as TF_CONV1X1_SPLIT=1)")
+                    help="the backbone's stride-1 1x1 convolutions through the split-product GEMM with the "
+                         "FrozenBN / identity / ReLU epilogue (the default; --no-conv1x1-split = TF_CONV1X1_SPLIT=0)")
+    ap.add_argument("--no-conv1x1-split", dest="conv1x1_split", action="store_false")
     ap.add_argument("--conv3x3-split", dest="conv3x3_split", action="store_true", default=None,
-                    help="OPT-IN: the bottlenecks' 3x3 convolutions through the split-product implicit GEMM (TF_CONV3X3_SPLIT=1)")
+                    help="the bottlenecks' 3x3 convolutions through the split-product implicit GEMM (the default)")
+    ap.add_argument("--no-conv3x3-split", dest="conv3x3_split", action="store_false")
     ap.add_argument("--input-proj-fused", dest="input_proj_fused", action="store_true", default=None,
-                    help="OPT-IN: input_proj (1x1 convolution + GroupNorm) as split GEMM + own GroupNorm (TF_INPUT_PROJ_FUSED=1)")
+                    help="input_proj (1x1 convolution + GroupNorm) as split GEMM + own GroupNorm (the default)")
+    ap.add_argument("--no-input-proj-fused", dest="input_proj_fused", action="store_false")
     ap.add_argument("--sequences", type=int, default=4,
                     help="independent video sequences tracked concurrently per GPU (one host thread "
                          "and HIP stream each); frames of one sequence stay strictly sequential")
@@ -172,14 +175,15 @@ def init_distributed(args):
 
 
 def _active_optins(backbone, fused):
-    """Names of the opt-in routes that are switched on in this process: recorded in the JSON line."""
+    """Names of the fused routes (defaults since round 3) that are switched on in this process, plus any
+    off-switch set in the environment: recorded in the JSON line."""
     flags = [("conv1x1_split", backbone._conv1x1_split), ("conv3x3_split", backbone._conv3x3_split),
              ("input_proj_fused", fused._input_proj_fused), ("box_refine_fused", fused._box_refine_fused),
              ("ffn_fused", fused.ffn_fused_enabled()), ("linln_fused", fused.linear_ln_fused_enabled()),
              ("stem_pool_fused", fused.stem_pool_fused_enabled()), ("stem_conv_split", fused.stem_conv_split_enabled()),
              ("pos_add_fused", fused.pos_add_fused_enabled()), ("heads_split", fused.heads_split_enabled())]
     names = [n for n, on in flags if on]
-    for env in ("TF_LINEAR_BUFSTORE", "TF_LINEAR_DEEP", "TF_MHA_BATCH", "TF_BIAS_ACT_BATCH", "TF_MSDA_PQUAD", "TF_MSDA_DIRECT9",
+    for env in ("TF_LINEAR_BUFSTORE", "TF_LINEAR_DEEP", "TF_MSDA_PQUAD", "TF_MSDA_DIRECT9", "TF_MSDA_BWD_SORTED2",
                 "TF_CONV_SPLIT_SKIP", "TF_CONV_SPLITK", "TF_LAZY_MASKS"):
         if os.environ.get(env):
             names.append("%s=%s" % (env, os.environ[env]))
@@ -576,17 +580,17 @@ def main():
         _backbone.set_conv3x3_split(args.conv3x3_split)
     if args.input_proj_fused is not None:
         fused.set_input_proj_fused(args.input_proj_fused)
-    if os.environ.get("TF_ALL_OPTIN") == "1":   # every opt-in route at once (round-3 measurement aid)
-        _backbone.set_conv1x1_split(True)
-        _backbone.set_conv3x3_split(True)
-        fused.set_input_proj_fused(True)
-        fused.set_box_refine_fused(True)
-        fused.set_ffn_fused(True)
-        fused.set_linear_ln_fused(True)
-        fused.set_stem_pool_fused(True)
-        fused.set_pos_add_fused(True)
-        fused.set_stem_conv_split(True)
-        fused.set_heads_split(True)
+    if os.environ.get("TF_ROUND2_ROUTES") == "1":   # every round-3 route off at once (A/B aid: the round-2 defaults)
+        _backbone.set_conv1x1_split(False)
+        _backbone.set_conv3x3_split(False)
+        fused.set_input_proj_fused(False)
+        fused.set_box_refine_fused(False)
+        fused.set_ffn_fused(False)
+        fused.set_linear_ln_fused(False)
+        fused.set_stem_pool_fused(False)
+        fused.set_pos_add_fused(False)
+        fused.set_stem_conv_split(False)
+        fused.set_heads_split(False)
 
     if args.roofline_only:
         if rank == 0:
@@ -647,12 +651,12 @@ def main():
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
                        "linears": "bf16 split product (hi.hi + hi.mid + mid.hi, f32 accumulate)"
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",
-                       **({"optin": _active_optins(_backbone, fused)} if not train and _active_optins(_backbone, fused) else {}),
+                       **({"routes": _active_optins(_backbone, fused)} if not train and _active_optins(_backbone, fused) else {}),
                        **({"ffn": "one launch per feed-forward block (tf_ffn_fused_f32)"} if fused.ffn_fused_enabled() and not train else {}),
                        **({"projection_norm": "output projection + residual + LayerNorm in one launch (tf_linear_res_ln_f32)"}
                           if fused.linear_ln_fused_enabled() and not train else {}),
-                       **({"mask_head": "lazy: evaluated for the surviving tracks' queries only (TF_LAZY_MASKS=1)"}
-                          if os.environ.get("TF_LAZY_MASKS") == "1" and not train else {})},
+                       **({"mask_head": "lazy: evaluated for the surviving tracks' queries only (Tracker default)"}
+                          if "segm" in post and os.environ.get("TF_LAZY_MASKS", "1") != "0" and not train else {})},
             "single_sequence_fps": None if single is None else round(single, 3),
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -143,7 +143,7 @@ def _fused_case(shapes, N, D, seed, M=8, P=4, spread=2.0):
 
 PQUAD_VARIANTS = [dict(), dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pquad_wg_per_cu=2),
                   dict(pquad_prefetch=2, pquad_wg_per_cu=2), dict(pquad_wide=0), dict(pquad_lds_kb=24),
-                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1), dict(pquad_pipe=1)]
+                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items()) or "default"
@@ -233,21 +233,9 @@ def test_bias_act_and_add_layernorm():
     r = rng.standard_normal(x.shape, dtype=np.float32)
     np.testing.assert_allclose(emu_lib.bias_act(x, b, r, relu=True), np.maximum(x + b + r, 0), atol=1e-6)
     np.testing.assert_allclose(emu_lib.bias_act(x, b, None, relu=False), x + b, atol=1e-6)
-    prev = emu_lib.set_options(bias_act_batch=1)   # opt-in: loads batched, two grid strides per iteration; bit-identical
-    try:
-        for res in (r, None):
-            for relu in (True, False):
-                emu_lib.set_options(bias_act_batch=0)
-                base = emu_lib.bias_act(x, b, res, relu=relu)
-                emu_lib.set_options(bias_act_batch=1)
-                assert np.array_equal(emu_lib.bias_act(x, b, res, relu=relu), base)
-        big = rng.standard_normal((3000, 7, 64), dtype=np.float32)   # more float4s than the grid has threads: the strided loop
-        emu_lib.set_options(bias_act_batch=0)
-        base = emu_lib.bias_act(big, b, None, relu=True)
-        emu_lib.set_options(bias_act_batch=1)
-        assert np.array_equal(emu_lib.bias_act(big, b, None, relu=True), base)
-    finally:
-        emu_lib.set_options(**prev)
+    big = rng.standard_normal((3000, 7, 64), dtype=np.float32)   # more float4s than the grid has threads: the strided loop
+    assert np.array_equal(emu_lib.bias_act(big, b, None, relu=True), np.maximum(big + b, 0))
+    assert np.array_equal(emu_lib.bias_act(x, b, r, relu=False), (x + b) + r)
     for C in (256, 288, 1024):
         x = rng.standard_normal((70, C), dtype=np.float32)
         res = rng.standard_normal((70, C), dtype=np.float32)
@@ -315,14 +303,9 @@ def test_query_self_attention_kernel(Lq, Lk, H, D, masked):
     ref = np.einsum("nhlj,njhd->nlhd", p, v.astype(np.float64))
     base = emu_lib.mha_core(q, k, v, scale, mask)
     np.testing.assert_allclose(base, ref, atol=2e-5, rtol=1e-4)
-    prev = emu_lib.set_options(mha_batch=1)   # opt-in: eight staging loads in flight per thread -- same data, same arithmetic
-    try:
-        assert np.array_equal(emu_lib.mha_core(q, k, v, scale, mask), base)
-    finally:
-        emu_lib.set_options(**prev)
 
 
-# ---- opt-in kernels awaiting their first hardware run --------------------------------------------------------------
+# ---- kernels first written against this emulator (defaults since their hardware validation in round 3) --------------------------------------------------------------
 @pytest.mark.parametrize("Lq,L,N", [(70, 8, 1), (29, 4, 2), (5, 3, 1), (800, 8, 1)], ids=["l8", "l4_n2", "l3_tiny", "cfg4_queries"])
 def test_direct9_decoder_kernel_head_dim_36(Lq, L, N):
     """msda_fwd_f32_direct9 (9 lanes per pair, 7 pairs per wave; opt-in): plain entry (host and device shapes) and the
@@ -435,24 +418,6 @@ def test_split_product_linear_buffer_store_epilogue(M, K, N):
         emu_lib.set_options(**prev)
     for g, e in zip(got, base):
         assert np.array_equal(g, e)
-
-
-def test_pipelined_gathers_are_bit_identical():
-    """pquad_pipe (opt-in): the LDS gathers with a rolling set of reads in flight -- same instructions, same summation
-    order per accumulator, so the output equals the default kernel's bit for bit (plain and fused entry)."""
-    shapes = PYR
-    shp = np.array(shapes, np.int64)
-    value, loc, attn = encoder_inputs(shapes, "local", N=1, seed=21)
-    fvalue, refp, qproj, _, _ = _fused_case(shapes, 1, 32, seed=22)
-    base = emu_lib.msda_forward(value, shp, loc, attn)
-    fbase = emu_lib.msda_forward_fused(fvalue, shp, refp, qproj, 8, len(shapes), 4)
-    prev = emu_lib.set_options(pquad_pipe=1)
-    try:
-        got = emu_lib.msda_forward(value, shp, loc, attn)
-        fgot = emu_lib.msda_forward_fused(fvalue, shp, refp, qproj, 8, len(shapes), 4)
-    finally:
-        emu_lib.set_options(**prev)
-    assert np.array_equal(got, base) and np.array_equal(fgot, fbase)
 
 
 @pytest.mark.parametrize("M,K,N", [(400, 256, 256), (130, 256, 384), (100, 288, 96), (70, 1024, 256), (65, 1152, 64), (200, 64, 64)],

@@ -2,7 +2,7 @@
 with the fused MSDeformAttn entry and the LDS-window kernel, split-product linears, fused residual + LayerNorm, the
 decoder with its own attention kernel and box refinement -- executed on CPU tensors through the SIMT emulator's build of
 the kernel sources (tests/util_emu_gpu_path.py), against the goldens of the reference's own classes.  Once with the
-defaults (what `-m gpu` tests on hardware), once with every opt-in route switched on (what has not seen hardware yet)."""
+round-3 routes (the defaults since their hardware validation), once with every one of them switched off (the round-2 path)."""
 import numpy as np
 import pytest
 import torch
@@ -16,35 +16,27 @@ pytestmark = pytest.mark.skipif(not emu_lib.available(), reason="needs a host cl
 def _run(case, optin, fn=None):
     from trackformer_amd import backbone, fused
     with gpu_path_on_emulator() as lib:
-        prev = []
-        if optin:
-            prev = [(backbone.set_conv1x1_split, backbone.set_conv1x1_split(True)),
-                    (backbone.set_conv3x3_split, backbone.set_conv3x3_split(True)),
-                    (fused.set_input_proj_fused, fused.set_input_proj_fused(True)),
-                    (fused.set_box_refine_fused, fused.set_box_refine_fused(True)),
-                    (fused.set_ffn_fused, fused.set_ffn_fused(True)),
-                    (fused.set_linear_ln_fused, fused.set_linear_ln_fused(True)),
-                    (fused.set_stem_pool_fused, fused.set_stem_pool_fused(True)),
-                    (fused.set_pos_add_fused, fused.set_pos_add_fused(True)),
-                    (fused.set_stem_conv_split, fused.set_stem_conv_split(True)),
-                    (fused.set_heads_split, fused.set_heads_split(True)),
-                    (lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
-                    (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
-            fused._LINLN_MIN_ROWS = 1
-            fused._FFN_FUSED_MIN_ROWS = 1   # the test models have few tokens: the decoder's feed-forward blocks take it too
-            opts = {b"linear_bufstore": 2, b"linear_deep": 1, b"pquad_pipe": 1, b"direct9": 1, b"mha_batch": 1}
-            prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
+        setters = [backbone.set_conv1x1_split, backbone.set_conv3x3_split, fused.set_input_proj_fused, fused.set_box_refine_fused,
+                   fused.set_ffn_fused, fused.set_linear_ln_fused, fused.set_stem_pool_fused, fused.set_pos_add_fused,
+                   fused.set_stem_conv_split, fused.set_heads_split]
+        prev = [(s, s(bool(optin))) for s in setters]
+        prev += [(lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
+                 (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
+        fused._LINLN_MIN_ROWS = 1
+        fused._FFN_FUSED_MIN_ROWS = 1   # the test models have few tokens: the decoder's feed-forward blocks take it too
+        on = 1 if optin else 0
+        opts = {b"linear_bufstore": on, b"linear_deep": on, b"direct9": on}
+        prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
         try:
             return (fn() if fn is not None else shared.run_case(case)) + (dict(lib.calls),)
         finally:
             for setter, value in prev:
                 setter(value)
-            if optin:
-                for k, v in prev_opts.items():
-                    lib.tf_msda_set_option(k, v)
+            for k, v in prev_opts.items():
+                lib.tf_msda_set_option(k, v)
 
 
-@pytest.mark.parametrize("optin", [False, True], ids=["defaults", "all_optin"])
+@pytest.mark.parametrize("optin", [False, True], ids=["round2_routes", "defaults"])
 def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
     case = "cfg2_deformable_tracking"
     model, out, res, feats, calls = _run(case, optin)

@@ -149,14 +149,14 @@ def test_full_size_tracker_track_ids_bit_exact(dev, models, setup):
     np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
 
 
-# ------------------------------------------------------------------ opt-in route (not a default; see test_msda_gpu.py)
-optin = pytest.mark.skipif(os.environ.get("TF_TEST_OPTIN") != "1", reason="opt-in kernels: set TF_TEST_OPTIN=1")
+# ------------------------------------------------------------------ the round-3 routes (defaults since their hardware validation:
+# profiles/r03_optin_pytest_optin.txt).  "graph_split_linear" above runs ALL of them at once; below each family is also
+# switched off on its own (the off-switches stay honest) and unit-tested against PyTorch.
 
 
-@optin
-@pytest.mark.parametrize("routes", [(True, False), (True, True)], ids=["conv1x1", "conv1x1_conv3x3"])
+@pytest.mark.parametrize("routes", [(True, False), (False, True), (False, False)], ids=["conv1x1_only", "conv3x3_only", "library_convolutions"])
 @pytest.mark.parametrize("case", list(um.FULL_CASES))
-def test_optin_conv1x1_split_route_full_size(dev, models, case, routes):
+def test_conv_split_routes_full_size(dev, models, case, routes):
     """The bottleneck convolutions of the backbone through the split-product kernels with the FrozenBN shift / identity /
     ReLU epilogue (backbone.set_conv1x1_split / set_conv3x3_split): BASELINE-size model against the reference goldens,
     bench set-up."""
@@ -172,8 +172,7 @@ def test_optin_conv1x1_split_route_full_size(dev, models, case, routes):
         backbone.set_conv3x3_split(prev3)
 
 
-@optin
-def test_optin_conv1x1_split_route_tracker_ids(dev, models):
+def test_conv_split_route_tracker_ids(dev, models):
     from trackformer_amd import backbone
     prev = backbone.set_conv1x1_split(True)
     prev3 = backbone.set_conv3x3_split(True)
@@ -187,8 +186,7 @@ def test_optin_conv1x1_split_route_tracker_ids(dev, models):
     np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
 
 
-@optin
-def test_optin_conv1x1_split_backbone_layer_outputs(dev):
+def test_conv_split_backbone_layer_outputs(dev):
     """Bottleneck by bottleneck: the split route against the library convolutions on the same weights (1e-3 relative to
     the feature scale; the three-term product is ~2^-16 per layer)."""
     from trackformer_amd import backbone
@@ -202,7 +200,12 @@ def test_optin_conv1x1_split_backbone_layer_outputs(dev):
             m.running_var.uniform_(0.5, 1.5)
     x = torch.randn(1, 256, 50, 84, device=dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        ref = blk(x)
+        prev, prev3 = backbone.set_conv1x1_split(False), backbone.set_conv3x3_split(False)
+        try:
+            ref = blk(x)   # library convolutions
+        finally:
+            backbone.set_conv1x1_split(prev)
+            backbone.set_conv3x3_split(prev3)
         for both in (False, True):
             prev = backbone.set_conv1x1_split(True)
             prev3 = backbone.set_conv3x3_split(both)
@@ -216,7 +219,12 @@ def test_optin_conv1x1_split_backbone_layer_outputs(dev):
         # a strided bottleneck (3 x 3 with stride 2 + a strided projection that stays in the library)
         ds = torch.nn.Sequential(torch.nn.Conv2d(256, 512, 1, stride=2, bias=False), backbone.FrozenBatchNorm2d(512)).to(dev)
         blk2 = backbone.Bottleneck(256, 128, stride=2, downsample=ds).to(dev).eval()
-        ref2 = blk2(x)
+        prev, prev3 = backbone.set_conv1x1_split(False), backbone.set_conv3x3_split(False)
+        try:
+            ref2 = blk2(x)
+        finally:
+            backbone.set_conv1x1_split(prev)
+            backbone.set_conv3x3_split(prev3)
         prev = backbone.set_conv1x1_split(True)
         prev3 = backbone.set_conv3x3_split(True)
         try:
@@ -227,23 +235,22 @@ def test_optin_conv1x1_split_backbone_layer_outputs(dev):
         assert got2.shape == ref2.shape and float((got2 - ref2).abs().max()) < 1e-3 * float(ref2.abs().max())
 
 
-@optin
 @pytest.mark.parametrize("case", list(um.FULL_CASES))
-def test_optin_fused_input_proj_full_size(dev, models, case):
-    """input_proj's 1 x 1 levels as split GEMM + tf_groupnorm_nhwc_f32 (fused.set_input_proj_fused)."""
+def test_input_proj_library_route_full_size(dev, models, case):
+    """input_proj's 1 x 1 levels as split GEMM + tf_groupnorm_nhwc_f32 is the default (fused.set_input_proj_fused); here
+    switched off: library convolution + ATen GroupNorm."""
     from trackformer_amd import fused
-    prev = fused.set_input_proj_fused(True)
+    prev = fused.set_input_proj_fused(False)
     try:
         model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
         dbox, dlogit = _compare(case, model, out, res, feats, memory)
-        print("%s / fused input_proj: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+        print("%s / library input_proj: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
     finally:
         fused.set_input_proj_fused(prev)
 
 
-@optin
 @pytest.mark.parametrize("n,c,h,w,groups", [(1, 256, 50, 84, 32), (2, 288, 13, 21, 32), (1, 64, 7, 5, 8)])
-def test_optin_groupnorm_nhwc_matches_torch(dev, n, c, h, w, groups):
+def test_groupnorm_nhwc_matches_torch(dev, n, c, h, w, groups):
     from trackformer_amd import fused
     torch.manual_seed(0)
     gn = torch.nn.GroupNorm(groups, c).to(dev)
@@ -257,9 +264,8 @@ def test_optin_groupnorm_nhwc_matches_torch(dev, n, c, h, w, groups):
     assert torch.allclose(got.view(n, h, w, c).permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)
 
 
-@optin
 @pytest.mark.parametrize("case", list(um.FULL_CASES))
-def test_optin_fused_box_refine_full_size(dev, models, case):
+def test_fused_box_refine_full_size(dev, models, case):
     """The decoder's iterative box refinement as one launch per layer (fused.set_box_refine_fused)."""
     from trackformer_amd import fused
     from trackformer_amd.nested import inverse_sigmoid
@@ -275,7 +281,7 @@ def test_optin_fused_box_refine_full_size(dev, models, case):
         exp = delta.clone()
         exp[..., :ref_dim] += inverse_sigmoid(ref)
         assert got is not None and torch.allclose(got, exp.sigmoid(), atol=1e-6, rtol=1e-5)
-    prev = fused.set_box_refine_fused(True)
+    prev = fused.set_box_refine_fused(False)   # the element-wise ATen formulation
     try:
         model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
         _compare(case, model, out, res, feats, memory)
@@ -283,18 +289,17 @@ def test_optin_fused_box_refine_full_size(dev, models, case):
         fused.set_box_refine_fused(prev)
 
 
-@optin
 @pytest.mark.parametrize("case", list(um.FULL_CASES))
-def test_optin_fused_ffn_route_full_size(dev, models, case):
-    """The feed-forward blocks in one launch each (fused.set_ffn_fused; tf_ffn_fused_f32) and output projection + residual +
-    LayerNorm in one launch (fused.set_linear_ln_fused; tf_linear_res_ln_f32), hidden 256 (cfg 2) and 288 (cfg 4):
-    BASELINE-size model against the reference goldens and, for cfg 2, the tracker's ids."""
+def test_separate_ffn_route_full_size(dev, models, case):
+    """The feed-forward blocks in one launch each (tf_ffn_fused_f32) and output projection + residual + LayerNorm in one
+    launch (tf_linear_res_ln_f32) are the defaults; here switched off (separate linears + tf_add_layernorm_f32), hidden 256
+    (cfg 2) and 288 (cfg 4): BASELINE-size model against the reference goldens and, for cfg 2, the tracker's ids."""
     from trackformer_amd import fused
-    prev, prev_ln = fused.set_ffn_fused(True), fused.set_linear_ln_fused(True)
+    prev, prev_ln = fused.set_ffn_fused(False), fused.set_linear_ln_fused(False)
     try:
         model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
         dbox, dlogit = _compare(case, model, out, res, feats, memory)
-        print("%s / fused ffn + projection norm: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+        print("%s / separate ffn + projection norm: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
         if "cfg2" not in case:
             return
         tracker, rows, active = _run_tracker(models, dev, "graph_split_linear")
@@ -306,9 +311,8 @@ def test_optin_fused_ffn_route_full_size(dev, models, case):
     np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
 
 
-@optin
 @pytest.mark.parametrize("shape,cout,stride,ksplit", [((1, 2048, 25, 42), 256, 2, 36), ((1, 512, 25, 42), 512, 1, 5), ((1, 256, 100, 167), 256, 2, 2)])
-def test_optin_conv3x3_split_k(dev, shape, cout, stride, ksplit):
+def test_conv3x3_split_k(dev, shape, cout, stride, ksplit):
     """tf_conv3x3_splitk_f32: the K loop cut into workgroups with a deterministic second pass, against the library
     convolution (1e-3 of the output scale) and run twice (bit-identical: no atomics)."""
     from trackformer_amd import _cabi, fused
@@ -333,24 +337,23 @@ def test_optin_conv3x3_split_k(dev, shape, cout, stride, ksplit):
     assert float((outs[0] - ref).abs().max()) < 1e-3 * float(ref.abs().max())
 
 
-@optin
 @pytest.mark.parametrize("case", list(um.FULL_CASES))
-def test_optin_every_route_at_once_full_size(dev, models, case):
-    """Every opt-in switch of DESIGN.md section 4.3 at once (what `TF_ALL_OPTIN=1 bench.py` runs): BASELINE-size model
-    against the reference goldens and, for cfg 2, the tracker's ids.  On the emulator this configuration gives boxes 1.7e-6,
-    logits 6.6e-5 and exact ids (profiles/r02_emulator_full_size_parity.txt)."""
+def test_every_round3_route_switched_off_full_size(dev, models, case):
+    """Every switch of DESIGN.md section 4.3 OFF at once (the round-2 defaults: library convolutions, separate linears and
+    LayerNorms, plain-store GEMM epilogues, msda_fwd_f32_buf / msda_bwd_f32_sorted): BASELINE-size model against the
+    reference goldens and, for cfg 2, the tracker's ids."""
     from trackformer_amd import _cabi, backbone, fused
     lib = _cabi.lib()
     setters = [backbone.set_conv1x1_split, backbone.set_conv3x3_split, fused.set_input_proj_fused, fused.set_box_refine_fused,
                fused.set_ffn_fused, fused.set_linear_ln_fused, fused.set_stem_pool_fused, fused.set_pos_add_fused,
                fused.set_stem_conv_split, fused.set_heads_split]
-    prev = [s(True) for s in setters]
-    opts = {b"linear_bufstore": 2, b"linear_deep": 1, b"pquad_pipe": 1, b"direct9": 1, b"mha_batch": 1, b"bias_act_batch": 1}
+    prev = [s(False) for s in setters]
+    opts = {b"linear_bufstore": 0, b"linear_deep": 0, b"direct9": 0}
     prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
     try:
         model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
         dbox, dlogit = _compare(case, model, out, res, feats, memory)
-        print("%s / every opt-in route: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
+        print("%s / every round-3 route off: max |d boxes| %.2e, max |d logits| %.2e" % (case, dbox, dlogit))
         if "cfg2" in case:
             tracker, rows, active = _run_tracker(models, dev, "graph_split_linear")
             z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))

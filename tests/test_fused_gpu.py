@@ -129,56 +129,29 @@ def test_decoder_self_attention_uses_own_kernel_and_matches_module(dev):
     assert torch.allclose(got, ref, atol=2e-5, rtol=1e-4)
 
 
-import os  # noqa: E402
-
-optin = pytest.mark.skipif(os.environ.get("TF_TEST_OPTIN") != "1", reason="opt-in kernels: set TF_TEST_OPTIN=1")
 
 
-@optin
-@pytest.mark.parametrize("length,heads,d", [(400, 8, 32), (800, 8, 36), (37, 4, 16)])
-def test_optin_mha_batched_staging_bit_identical(length, heads, d):
-    """mha_batch: eight staging loads in flight per thread in tf_mha_core_f32; same data, same arithmetic."""
-    from trackformer_amd import _cabi, fused
-    lib = _cabi.lib()
-    dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(length)
-    e = heads * d
-    qk = torch.randn(2, length, 2 * e, generator=g).to(dev)
-    v = torch.randn(2, length, e, generator=g).to(dev)
-    base = fused.mha_core(qk, v, heads)
-    prev = lib.tf_msda_set_option(b"mha_batch", 1)
-    try:
-        got = fused.mha_core(qk, v, heads)
-    finally:
-        lib.tf_msda_set_option(b"mha_batch", prev)
-    assert base is not None and torch.equal(got, base)
-
-
-@optin
 @pytest.mark.parametrize("shape,res,relu", [((1, 256, 200, 334), True, True), ((1, 64, 200, 334), False, True), ((2, 512, 25, 42), True, False)])
-def test_optin_bias_act_batched_bit_identical(shape, res, relu):
-    """bias_act_batch: the residual test as a template parameter, two grid strides per iteration, loads first."""
-    from trackformer_amd import _cabi, fused
-    lib = _cabi.lib()
+def test_bias_act_matches_torch_bit_for_bit(shape, res, relu):
+    """tf_bias_act_f32 (two grid strides per iteration, loads first): (x + bias) (+ residual) (ReLU) in that order."""
+    from trackformer_amd import fused
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(shape[1])
     x = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     b = torch.randn(shape[1], generator=g).to(dev)
     r = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last) if res else None
-    base = x.clone()
-    assert fused.bias_act_(base, b, r, relu) is not None
+    base = x + b.view(1, -1, 1, 1)
+    if r is not None:
+        base = base + r
+    if relu:
+        base = base.clamp_min(0)
     got = x.clone()
-    prev = lib.tf_msda_set_option(b"bias_act_batch", 1)
-    try:
-        assert fused.bias_act_(got, b, r, relu) is not None
-    finally:
-        lib.tf_msda_set_option(b"bias_act_batch", prev)
+    assert fused.bias_act_(got, b, r, relu) is not None
     assert torch.equal(got, base)
 
 
-@optin
 @pytest.mark.parametrize("rows,ti,d", [(22223, 3, 256), (4100, 2, 256), (97, 1, 256), (22223, 2, 288), (150, 1, 288)])
-def test_optin_fused_ffn_block(rows, ti, d, monkeypatch):
+def test_fused_ffn_block(rows, ti, d, monkeypatch):
     """tf_ffn_fused_f32 (fused.ffn): linear1 -> ReLU -> linear2 -> + residual in one launch equals the separate packed
     linears bit for bit (same split, same order of the matrix-core sums); with the LayerNorm in the epilogue it equals
     torch's LayerNorm of that up to rounding."""
@@ -210,9 +183,8 @@ def test_optin_fused_ffn_block(rows, ti, d, monkeypatch):
     assert torch.allclose(got_ln, norm(ref), atol=1e-5, rtol=1e-5)
 
 
-@optin
 @pytest.mark.parametrize("rows,ti,d", [(22223, 0, 256), (22223, 3, 256), (400, 0, 256), (97, 2, 256), (22223, 0, 288), (800, 0, 288)])
-def test_optin_linear_residual_layernorm(rows, ti, d, monkeypatch):
+def test_linear_residual_layernorm(rows, ti, d, monkeypatch):
     """tf_linear_res_ln_f32 (fused.linear_residual_norm): output projection + residual + LayerNorm in one launch against
     the split-product linear followed by torch's add and LayerNorm."""
     from trackformer_amd import _cabi, fused
@@ -237,9 +209,8 @@ def test_optin_linear_residual_layernorm(rows, ti, d, monkeypatch):
     assert torch.allclose(got, ref, atol=1e-5, rtol=1e-5)
 
 
-@optin
 @pytest.mark.parametrize("shape", [(1, 64, 400, 667), (2, 64, 33, 20), (1, 8, 7, 9)])
-def test_optin_bias_relu_maxpool_bit_identical(shape):
+def test_bias_relu_maxpool_bit_identical(shape):
     """tf_bias_relu_maxpool_f32 (stem route): one pass instead of bias_act_ + MaxPool2d(3, 2, 1); same bits."""
     from trackformer_amd import fused
     dev = torch.device("cuda:0")
@@ -252,9 +223,8 @@ def test_optin_bias_relu_maxpool_bit_identical(shape):
     assert torch.equal(got, ref)
 
 
-@optin
 @pytest.mark.parametrize("shape", [(1, 3, 800, 1333), (2, 3, 97, 130), (1, 3, 9, 7)])
-def test_optin_stem_convolution_split(shape):
+def test_stem_convolution_split(shape):
     """tf_stem_conv7x7_f32 (fused.stem_conv): the 7 x 7 / stride 2 stem convolution as a split product against the library
     convolution (1e-3 of the output scale: three-term bf16 products), channels_last output, optional shift + ReLU."""
     from trackformer_amd import fused

@@ -153,16 +153,12 @@ def test_packed_linear_dispatch(dev, split_on):
         split_on.set_packed_linear(prev)
 
 
-# ------------------------------------------------------------------ opt-in (see test_msda_gpu.py): TF_TEST_OPTIN=1
-import os
-
-optin = pytest.mark.skipif(os.environ.get("TF_TEST_OPTIN") != "1", reason="opt-in kernels: set TF_TEST_OPTIN=1")
+# ------------------------------------------------------------------ epilogue / prefetch variants (defaults since round 3)
 
 
-@optin
 @pytest.mark.parametrize("M,K,N,bias,relu", SHAPES + [(66800, 64, 256, True, True), (16700, 512, 128, True, True)],
                          ids=["%dx%dx%d" % s[:3] for s in SHAPES] + ["conv_layer1", "conv_layer2"])
-def test_optin_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, relu):
+def test_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, relu):
     """linear_bufstore (stores through a buffer resource: no per-store branch, no vmcnt(0) between stores) and the
     residual epilogue: bit-identical to the default epilogue / to the plain kernel + add; nothing written past Y."""
     from trackformer_amd import _cabi
@@ -172,11 +168,15 @@ def test_optin_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, 
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev) if bias else None
     r = torch.randn(M, N, generator=g).to(dev)
-    base = split_on.linear(x, w, b, relu=relu)
-    base_res = split_on.linear(x, w, b, relu=relu, residual=r)
-    if K % 32 == 0:
-        plain = split_on.linear(x, w, b, relu=False) + r
-        assert torch.equal(base_res, plain.clamp_min(0) if relu else plain)
+    prev = lib.tf_msda_set_option(b"linear_bufstore", 0)   # the plain-store epilogue
+    try:
+        base = split_on.linear(x, w, b, relu=relu)
+        base_res = split_on.linear(x, w, b, relu=relu, residual=r)
+        if K % 32 == 0:
+            plain = split_on.linear(x, w, b, relu=False) + r
+            assert torch.equal(base_res, plain.clamp_min(0) if relu else plain)
+    finally:
+        lib.tf_msda_set_option(b"linear_bufstore", prev)
     guard = torch.full((M + 300, N), 7.0, device=dev)       # the kernel writes into the first M rows of a larger buffer
     prev = lib.tf_msda_set_option(b"linear_bufstore", 1)
     try:
@@ -193,19 +193,22 @@ def test_optin_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, 
     assert torch.equal(guard[M:], torch.full((300, N), 7.0, device=dev))
 
 
-@optin
 @pytest.mark.parametrize("M,K,N,bias,relu", [(400, 256, 256, True, False), (400, 256, 1024, True, True), (400, 1024, 256, True, False),
                                               (800, 288, 288, True, False), (800, 1152, 288, False, False), (400, 256, 384, True, False)],
                          ids=lambda v: str(v))
-def test_optin_deep_prefetch_linear_bit_identical(dev, split_on, M, K, N, bias, relu):
-    """Variant 7 (ring of 8 K-slices in registers, for the decoder's few-row linears): bit-identical to the default."""
+def test_deep_prefetch_linear_bit_identical(dev, split_on, M, K, N, bias, relu):
+    """Variant 7 (ring of 8 K-slices in registers, for the decoder's few-row linears): bit-identical to variant 5."""
     from trackformer_amd import _cabi
     lib = _cabi.lib()
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g).to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev) if bias else None
-    base = split_on.linear(x, w, b, relu=relu)
+    prev = lib.tf_msda_set_option(b"linear_deep", 0)
+    try:
+        base = split_on.linear(x, w, b, relu=relu)
+    finally:
+        lib.tf_msda_set_option(b"linear_deep", prev)
     prev = lib.tf_msda_set_option(b"linear_deep", 1)
     try:
         got = split_on.linear(x, w, b, relu=relu)
@@ -214,30 +217,8 @@ def test_optin_deep_prefetch_linear_bit_identical(dev, split_on, M, K, N, bias, 
     assert torch.equal(got, base)
 
 
-@optin
-@pytest.mark.parametrize("M,K,N,relu", [(22223, 256, 1024, True), (22223, 1024, 256, False), (5000, 256, 1024, True)], ids=lambda v: str(v))
-def test_optin_packed_linear_wide_stores(dev, split_on, M, K, N, relu):
-    """linear_bufstore = 2: transposed accumulators + 16-byte stores in the packed kernel (same products; the matrix cores
-    may round the swapped-operand sums differently, hence a tolerance instead of bit identity -- reported either way)."""
-    from trackformer_amd import _cabi
-    lib = _cabi.lib()
-    g = torch.Generator().manual_seed(M + K + N)
-    x = torch.randn(M, K, generator=g).to(dev)
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
-    b = torch.randn(N, generator=g).to(dev)
-    base = split_on.linear(x, w, b, relu=relu)
-    prev = lib.tf_msda_set_option(b"linear_bufstore", 2)
-    try:
-        got = split_on.linear(x, w, b, relu=relu)
-    finally:
-        lib.tf_msda_set_option(b"linear_bufstore", prev)
-    print("wide stores: %d of %d outputs differ in the last bits" % (int((got != base).sum()), got.numel()))
-    assert torch.allclose(got, base, atol=1e-5, rtol=1e-5)
-
-
-@optin
 @pytest.mark.parametrize("rows,n", [(22223, 384), (400, 384), (400, 512), (5000, 256)])
-def test_optin_linear_with_add_prologue(rows, n):
+def test_linear_with_add_prologue(rows, n):
     """tf_linear_split_add_f32 (fused.linear_add): (x + pos) @ w^T + b with the add done while the tile is staged; the same
     bits as adding first and calling fused.linear."""
     from trackformer_amd import fused

@@ -61,10 +61,11 @@ def test_tracker_with_mask_head_matches_cpu_path(dev, monkeypatch):
             assert a['mask'].shape == b['mask'].shape and a['mask'].dtype == b['mask'].dtype
 
 
-@pytest.mark.skipif(__import__("os").environ.get("TF_TEST_OPTIN") != "1", reason="opt-in paths: set TF_TEST_OPTIN=1")
-def test_optin_lazy_mask_head_gives_the_same_tracks(dev):
-    """Opt-in lazy mask head (Tracker(lazy_masks=True)): the head runs for the surviving tracks' queries only; same track
-    ids, boxes and scores as the full head, and the same covered pixels up to the random-weight model's ties."""
+def test_lazy_mask_head_gives_the_same_tracks(dev):
+    """Lazy mask head (Tracker's default; lazy_masks=False runs the head for every query inside the detector): the head runs
+    for the surviving tracks' queries only; same track ids as the full head, boxes and scores up to the run-to-run noise
+    of the library convolutions' atomics (seen on MI355X: 1.1e-4 px), and the same covered pixels up to the random-weight
+    model's ties."""
     import numpy as np
     full = shared.run_mask_tracker(device=dev)
     lazy = shared.run_mask_tracker(device=dev, lazy_masks=True)
@@ -74,8 +75,9 @@ def test_optin_lazy_mask_head_gives_the_same_tracks(dev):
         assert sorted(full[tid]) == sorted(lazy[tid])
         for f in full[tid]:
             a, b = full[tid][f], lazy[tid][f]
-            np.testing.assert_array_equal(a['bbox'], b['bbox'])
-            np.testing.assert_array_equal(a['score'], b['score'])
+            assert a['obj_ind'] == b['obj_ind']
+            np.testing.assert_allclose(a['bbox'], b['bbox'], atol=5e-3)
+            np.testing.assert_allclose(a['score'], b['score'], atol=1e-5)
             cover_full[f] = cover_full.get(f, 0) | a['mask']
             cover_lazy[f] = cover_lazy.get(f, 0) | b['mask']
     n_px = sum(u.size for u in cover_full.values())

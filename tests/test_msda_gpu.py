@@ -606,25 +606,24 @@ def test_fused_prologue_entry_point_vs_oracle(dev):
         np.testing.assert_allclose(out.cpu().numpy(), expect, atol=2e-5, rtol=1e-4)
 
 
-# ------------------------------------------------------------------ opt-in kernels (not yet defaults)
-# Written and checked in the SIMT emulator (tests/test_emu_kernels.py) while no GPU was available; they stay
-# opt-in -- and these tests stay skipped in the default `-m gpu` run -- until a hardware run has confirmed them:
-#     TF_TEST_OPTIN=1 python -m pytest tests/test_msda_gpu.py -m gpu -k optin
-import os
-
-optin = pytest.mark.skipif(os.environ.get("TF_TEST_OPTIN") != "1", reason="opt-in kernels: set TF_TEST_OPTIN=1")
+# ------------------------------------------------------------------ kernels promoted to defaults in round 3
+# Written and checked in the SIMT emulator (tests/test_emu_kernels.py) while no GPU was available, confirmed and timed on
+# MI355X at the start of round 3 (profiles/r03_optin_pytest_optin.txt, r03_optin_msda_variants.txt).
 
 
-@optin
 @pytest.mark.parametrize("Lq,L,N", [(800, 8, 1), (70, 8, 2), (29, 4, 2), (5, 3, 1)], ids=["cfg4_decoder", "l8_n2", "l4_n2", "l3_tiny"])
-def test_optin_direct9_decoder_kernel(dev, Lq, L, N):
+def test_direct9_decoder_kernel(dev, Lq, L, N):
     """msda_fwd_f32_direct9 (D = 36, 9 lanes per pair): plain + fused entry vs the oracle, and vs msda_fwd_f32_buf."""
     from trackformer_amd import _cabi, msda
     lib = _cabi.lib()
     shapes_l = (CFG2_SHAPES * 2)[:L] if Lq == 800 else ([(13, 21), (7, 11), (4, 6), (2, 3)] * 2)[:L]
     value, shapes, loc, attn, _ = rand_inputs(40 + Lq, N=N, M=8, D=36, Lq=Lq, P=4, shapes=shapes_l, loc_mode="wide", device=dev)
     ref = msda_oracle.msda_forward(value.cpu().numpy(), shapes.cpu().numpy(), loc.cpu().numpy(), attn.cpu().numpy(), nthreads=8)
-    base = _fwd(value, shapes, loc, attn)
+    prev = lib.tf_msda_set_option(b"direct9", 0)   # msda_fwd_f32_buf, the kernel direct9 replaced
+    try:
+        base = _fwd(value, shapes, loc, attn)
+    finally:
+        lib.tf_msda_set_option(b"direct9", prev)
     prev = lib.tf_msda_set_option(b"direct9", 1)
     try:
         out = _fwd(value, shapes, loc, attn)
@@ -649,10 +648,11 @@ def test_optin_direct9_decoder_kernel(dev, Lq, L, N):
         lib.tf_msda_set_option(b"direct9", prev)
 
 
-@optin
+@pytest.mark.parametrize("sorted2", [1, 0], ids=["sorted2", "sorted"])
 @pytest.mark.parametrize("name,shapes,mode,N,M,D", [c for c in BWD_ENC_CASES if c[5] == 32], ids=[c[0] for c in BWD_ENC_CASES if c[5] == 32])
-def test_optin_backward_sorted2_kernel(dev, name, shapes, mode, N, M, D):
-    """msda_bwd_f32_sorted2 at the encoder shapes of test_encoder_shape_backward_vs_oracle."""
+def test_backward_sorted_kernels(dev, name, shapes, mode, N, M, D, sorted2):
+    """msda_bwd_f32_sorted2 (the default) and msda_bwd_f32_sorted (bwd_sorted2 = 0) at the encoder shapes of
+    test_encoder_shape_backward_vs_oracle."""
     from trackformer_amd import _cabi
     lib = _cabi.lib()
     value, shp, loc, attn, grad_out = _encoder_inputs(dev, shapes, mode, N=N, M=M, D=D, seed=len(name))
@@ -662,7 +662,7 @@ def test_optin_backward_sorted2_kernel(dev, name, shapes, mode, N, M, D):
         loc[:, :, :, :, ::2, 1] -= 9.0 / 100
     rv, rl, ra = msda_oracle.msda_backward(value.cpu().numpy(), shp.cpu().numpy(), loc.cpu().numpy(),
                                            attn.cpu().numpy(), grad_out.cpu().numpy())
-    prev = lib.tf_msda_set_option(b"bwd_sorted2", 1)
+    prev = lib.tf_msda_set_option(b"bwd_sorted2", sorted2)
     try:
         gv, gl, ga = [t.cpu().numpy() for t in _bwd(value, shp, loc, attn, grad_out)]
     finally:
@@ -670,18 +670,3 @@ def test_optin_backward_sorted2_kernel(dev, name, shapes, mode, N, M, D):
     np.testing.assert_allclose(gv, rv, atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(gl, rl, atol=2e-3, rtol=1e-4)
     np.testing.assert_allclose(ga, ra, atol=1e-4, rtol=1e-4)
-
-
-@optin
-def test_optin_pipelined_gathers_bit_identical(dev):
-    """pquad_pipe: the LDS gathers of msda_fwd_f32_pquad with a rolling set of reads in flight; bit-identical output."""
-    from trackformer_amd import _cabi
-    lib = _cabi.lib()
-    value, shp, loc, attn, _ = _encoder_inputs(dev, CFG2_SHAPES, "local", seed=3)
-    base = _fwd(value, shp, loc, attn)
-    prev = lib.tf_msda_set_option(b"pquad_pipe", 1)
-    try:
-        got = _fwd(value, shp, loc, attn)
-    finally:
-        lib.tf_msda_set_option(b"pquad_pipe", prev)
-    assert torch.equal(got, base)

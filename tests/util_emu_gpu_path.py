@@ -27,6 +27,9 @@ class _NullDevice:
 class _Stream:
     cuda_stream = 0
 
+    def synchronize(self):   # the emulator runs every launch to completion before returning
+        pass
+
 
 @contextlib.contextmanager
 def gpu_path_on_emulator(host_threads=8):

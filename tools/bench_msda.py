@@ -105,10 +105,10 @@ CONFIGS = [
 ]
 
 
-def run(iters=50, modes=("uniform", "local", "init"), device="cuda:0", backward=True, shapes=None, forward=True):
+def run(iters=50, modes=("uniform", "local", "init"), device="cuda:0", backward=True, only=None, forward=True):
     rows = []
     for name, kw in CONFIGS:
-        if shapes and name not in shapes:
+        if only and name not in only:
             continue
         for mode in modes:
             S = sum(h * w for h, w in kw["shapes"])
@@ -147,7 +147,7 @@ def main():
         k, v = o.split("=")
         print("option %s: %d -> %s" % (k, _cabi.lib().tf_msda_set_option(k.encode(), int(v)), v))
     rows = run(args.iters, modes=tuple(args.modes.split(",")), backward=not args.no_backward,
-               shapes=args.shapes.split(",") if args.shapes else None, forward=not args.no_forward)
+               only=args.shapes.split(",") if args.shapes else None, forward=not args.no_forward)
     for r in rows:
         print("%-16s %-8s %s  %8.1f us  %7.2f MB  %8.1f GB/s  %5.1f%% of HBM peak" % (
             r["shape"], r["mode"], r["dir"], r["ms"] * 1e3, r["alg_MB"], r["GBs"],

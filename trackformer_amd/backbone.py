@@ -30,20 +30,22 @@ import os as _os
 CHANNELS_LAST = _os.environ.get("TF_BACKBONE_NCHW", "0") != "1"
 
 
-# OPT-IN (TF_CONV1X1_SPLIT=1 / set_conv1x1_split(True)), not yet timed on hardware: the stride-1 1 x 1 convolutions of the
+# DEFAULT since round 3 (TF_CONV1X1_SPLIT=0 / set_conv1x1_split(False) switches it off; measured per shape on MI355X in
+# profiles/r03_optin_conv_per_layer.txt: 1.03-1.99x the library convolution + bias_act on 22 of 23 bottleneck shapes, 2835 ->
+# 1973 us per 800 x 1333 frame with the 3 x 3 route below): the stride-1 1 x 1 convolutions of the
 # bottlenecks (32 of ResNet-50's 53 convolutions, ~half of its flops) run as the library's own split-product GEMM
 # (fused.linear: hi.hi + hi.mid + mid.hi on the bf16 matrix cores, fp32 accumulate) with the FrozenBN shift, the
 # identity branch and the ReLU in its epilogue -- on channels_last activations such a convolution IS a GEMM over the
 # N*H*W pixels, and the separate bias_act pass disappears.  Three-term products leave the full-size model inside the
 # 1e-3 bar but not at fp32 agreement (tools/experiments/bf16_split_linear.py x3 conv: logits off by ~7e-5).
-_conv1x1_split = _os.environ.get("TF_CONV1X1_SPLIT", "0") == "1"
+_conv1x1_split = _os.environ.get("TF_CONV1X1_SPLIT", "1") != "0"
 
 
-# OPT-IN as well (TF_CONV3X3_SPLIT=1 / set_conv3x3_split(True)): the bottlenecks' 3 x 3 convolutions (stride 1 and 2) as the
+# DEFAULT as well (TF_CONV3X3_SPLIT=0 / set_conv3x3_split(False) switches it off): the bottlenecks' 3 x 3 convolutions (stride 1 and 2) as the
 # same split product, an implicit GEMM over the output pixels (fused.conv3x3 -> tf_conv3x3_split_f32), FrozenBN shift and
 # ReLU in its epilogue.  (The three strided 1 x 1 projections of the identity branch go through the same kernel with a
 # 1 x 1 window under TF_CONV1X1_SPLIT.)  With both routes on, only the 7 x 7 stem stays in MIOpen.
-_conv3x3_split = _os.environ.get("TF_CONV3X3_SPLIT", "0") == "1"
+_conv3x3_split = _os.environ.get("TF_CONV3X3_SPLIT", "1") != "0"
 
 
 # Per-shape exceptions to the two routes above: "cin x cout x kernel x stride" entries (TF_CONV_SPLIT_SKIP="64x64x3x1,256x64x1x1"

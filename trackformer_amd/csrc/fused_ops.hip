@@ -17,33 +17,14 @@ namespace {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
-__global__ void __launch_bounds__(256)
-bias_act_kernel(float *__restrict__ x, const float *__restrict__ bias,
-                const float *__restrict__ residual, long long n4, int C4, int relu)
-{
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        f32x4_t v = reinterpret_cast<const f32x4_t *>(x)[i];
-        const f32x4_t b = reinterpret_cast<const f32x4_t *>(bias)[i % C4];
-        v += b;
-        if (residual != nullptr) v += reinterpret_cast<const f32x4_t *>(residual)[i];
-        if (relu) {
-            v.x = fmaxf(v.x, 0.f);
-            v.y = fmaxf(v.y, 0.f);
-            v.z = fmaxf(v.z, 0.f);
-            v.w = fmaxf(v.w, 0.f);
-        }
-        reinterpret_cast<f32x4_t *>(x)[i] = v;
-    }
-}
-
-// OPT-IN variant (tf_msda_set_option("bias_act_batch", 1) / TF_BIAS_ACT_BATCH=1): the loop above compiles to load x, load
-// bias, s_waitcnt vmcnt(0), [branch] load residual, s_waitcnt vmcnt(0), store per iteration -- two sequential memory round
-// trips per 16 bytes and lane (tools/isa_audit.py --stream bias_act_kernel).  Here the residual test is a template
-// parameter and two grid strides are processed per iteration with all of their loads issued first.
+// x += bias[channel] (+ residual) (ReLU), in place.  The residual / ReLU tests are template parameters and two grid strides
+// are processed per iteration with all of their loads issued first: the straightforward loop (one element per iteration, a
+// run-time residual pointer test) compiled to load x, load bias, s_waitcnt vmcnt(0), [branch] load residual, s_waitcnt
+// vmcnt(0), store -- two sequential memory round trips per 16 bytes and lane (tools/isa_audit.py --stream); bit-identical
+// results (round 3: the one-element kernel was removed after both were validated against each other on MI355X).
 template <bool RES, bool RELU>
 __global__ void __launch_bounds__(256)
-bias_act_batched_kernel(float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ residual,
+bias_act_kernel(float *__restrict__ x, const float *__restrict__ bias, const float *__restrict__ residual,
                         long long n4, int C4)
 {
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -138,18 +119,6 @@ add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ res,
             }
         }
     }
-}
-
-std::atomic<int> g_bias_act_batch{-1};   // -1: TF_BIAS_ACT_BATCH (default 0)
-int bias_act_batch()
-{
-    int v = g_bias_act_batch.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("TF_BIAS_ACT_BATCH");
-        v = (e && e[0] == '1') ? 1 : 0;
-        g_bias_act_batch.store(v);
-    }
-    return v;
 }
 
 bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -381,18 +350,14 @@ int tf_bias_act_f32(float *x, const float *bias, const float *residual, int64_t 
     long long blocks = (n4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;   // grid-stride beyond 16 workgroups per CU
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (bias_act_batch()) {   // opt-in variant: loads batched, two grid strides per iteration
-        if (residual && relu)
-            hipLaunchKernelGGL((bias_act_batched_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
-        else if (residual)
-            hipLaunchKernelGGL((bias_act_batched_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
-        else if (relu)
-            hipLaunchKernelGGL((bias_act_batched_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
-        else
-            hipLaunchKernelGGL((bias_act_batched_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
-        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
-    }
-    hipLaunchKernelGGL(bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4, relu);
+    if (residual && relu)
+        hipLaunchKernelGGL((bias_act_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
+    else if (residual)
+        hipLaunchKernelGGL((bias_act_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
+    else if (relu)
+        hipLaunchKernelGGL((bias_act_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
+    else
+        hipLaunchKernelGGL((bias_act_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, s, x, bias, residual, n4, C / 4);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
@@ -424,12 +389,3 @@ int tf_add_layernorm_f32(const float *x, const float *res, const float *gamma, c
 }
 
 }  // extern "C"
-
-namespace tfm {
-int bias_act_batch_set(int v)
-{
-    const int prev = bias_act_batch();
-    g_bias_act_batch.store(v ? 1 : 0);
-    return prev;
-}
-}  // namespace tfm

@@ -48,7 +48,9 @@ constexpr int LDS_STRIDE = BK + 8;   // bf16 elements per LDS row: 80 bytes, kee
 // second block on the CU being in the other phase.
 // RESID: Y = act(X . W^T + bias + R) with R [M, N] fp32 (the identity branch of a bottleneck: `out += identity` before
 // the ReLU, torchvision resnet.py Bottleneck.forward) -- only instantiated by split_gemm_res_kernel below.
-// BUFST (opt-in, tf_msda_set_option("linear_bufstore", 1)): the epilogue through a buffer resource over Y -- rows >= M
+// BUFST (the default since round 3 for tensors < 3 GiB; tf_msda_set_option("linear_bufstore", 0) / TF_LINEAR_BUFSTORE=0 keeps
+// the plain stores; 21.4 -> 18.1 us at 22 223 x 256 -> 256, 26.9 -> 18.9 us at 66 800 x 64 -> 256, bit-identical,
+// profiles/r03_optin_linear_bufstore.txt): the epilogue through a buffer resource over Y -- rows >= M
 // and columns >= N fall outside num_records and are dropped by the hardware, so the 16 stores of a tile are straight-line
 // code.  With `if (row < M) Y[...] = v` every store sits in its own exec-masked block; the compiler's wait-count pass
 // re-waits for the bias load at each join, and on gfx9-family hardware vmcnt also counts STORES: the ISA had
@@ -431,8 +433,9 @@ conv_splitk_reduce_kernel(const float *__restrict__ part, const float *__restric
 
 // ---- few rows (the decoder: 400 / 800 queries): a launch is 28-100 blocks, far fewer than CUs, and each block walks its
 // K-slices one memory round trip at a time -- 12 us per 400 x 256 -> 256 linear inside the model (36 such launches per
-// frame, profiles/r02_e2e_eager_per_frame.txt) for 0.16 GFLOP.  Variant 7 (OPT-IN: linear_variant = 7, or
-// tf_msda_set_option("linear_deep", 1) for every call with <= 4096 rows) keeps a RING OF 8 K-SLICES in registers: all
+// frame, profiles/r02_e2e_eager_per_frame.txt) for 0.16 GFLOP.  Variant 7 (the default for every call with <= 4096 rows
+// since round 3 -- 6.7 -> 4.9 us at 400 x 256 -> 256, 15.6 -> 12.3 us at 400 x 1024 -> 256, profiles/r03_optin_linear_bufstore.txt;
+// tf_msda_set_option("linear_deep", 0) / TF_LINEAR_DEEP=0 goes back to variant 5) keeps a RING OF 8 K-SLICES in registers: all
 // of a K = 256 block's global loads are in flight at once (one round trip instead of eight), the loop then only moves
 // registers -> LDS (double buffered, one barrier per slice) -> matrix cores; longer K refills the ring slot it has just
 // consumed.  64 x 64 blocks, 4 waves as 2 x 2; same arithmetic and accumulation order as split_gemm_kernel (bit-identical
@@ -761,8 +764,8 @@ int launch_ws(const float *x, const unsigned short *wh, const unsigned short *wm
                ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-std::atomic<int> g_deep{-1};       // -1: TF_LINEAR_DEEP (default 0): variant 7 for every call with <= 4096 rows
-std::atomic<int> g_bufstore{-1};   // -1: TF_LINEAR_BUFSTORE (default 0)
+std::atomic<int> g_deep{-1};       // -1: TF_LINEAR_DEEP (default 1 since round 3): variant 7 for every call with <= 4096 rows
+std::atomic<int> g_bufstore{-1};   // -1: TF_LINEAR_BUFSTORE (default 1 since round 3)
 std::atomic<int> g_variant{-1};   // -1: TF_LINEAR_VARIANT or the default
 
 int variant()
@@ -782,7 +785,7 @@ int launch_variant(const float *x, const unsigned short *wh, const unsigned shor
 {
     const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
-    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL) {   // opt-in: buffer-store epilogue
+    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL) {   // buffer-store epilogue (tensors < 3 GiB)
         if (res) {
             if (relu)
                 hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, true, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
@@ -831,7 +834,7 @@ int linear_bufstore()
     int v = g_bufstore.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("TF_LINEAR_BUFSTORE");
-        v = (e && e[0] == '2') ? 2 : (e && e[0] == '1') ? 1 : 0;
+        v = (e && e[0] == '0') ? 0 : 1;
         g_bufstore.store(v);
     }
     return v;
@@ -841,7 +844,7 @@ int linear_deep()
     int v = g_deep.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("TF_LINEAR_DEEP");
-        v = (e && e[0] == '1') ? 1 : 0;
+        v = (e && e[0] == '0') ? 0 : 1;
         g_deep.store(v);
     }
     return v;
@@ -855,7 +858,7 @@ int linear_deep_set(int v)
 int linear_bufstore_set(int v)
 {
     const int prev = linear_bufstore();
-    g_bufstore.store(v == 2 ? 2 : (v ? 1 : 0));   // 2: + transposed accumulators / 16-byte stores in the packed kernel
+    g_bufstore.store(v ? 1 : 0);
     return prev;
 }
 int linear_set_variant(int v)

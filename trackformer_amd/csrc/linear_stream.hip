@@ -85,11 +85,11 @@ struct WFrags {
 
 constexpr int stream_min_waves(int ti) { return ti <= 3 ? 2 : 1; }   // blocks per CU the register budget is cut for
 
-// BUFST (opt-in, linear_bufstore option; see linear_split.hip): 1 = the epilogue through a buffer resource (no per-store
-// branch / wait); 2 = additionally the accumulators hold the TRANSPOSED tile (the weight fragment goes in as the A
-// operand, the activation fragment as B: D[n][m], same fragments, same products), so a lane owns 4 consecutive output
-// columns of one row and stores 16 bytes at a time -- 4 store instructions per 32 x 32 tile instead of 16.
-template <int TI, bool RELU, int BUFST = 0>
+// BUFST (the default since round 3, linear_bufstore option; see linear_split.hip): the epilogue through a buffer resource
+// (no per-store branch / wait): 57.9 -> 44.1 us at 22 223 x 256 -> 1024, 52.1 -> 39.4 us at 1024 -> 256, bit-identical
+// (profiles/r03_optin_linear_bufstore.txt).  A variant with transposed accumulators and 16-byte stores measured slower on the
+// first shape (58.6 us) and was removed.
+template <int TI, bool RELU, bool BUFST = false>
 __global__ void __launch_bounds__(kThreads, (stream_min_waves(TI)))
 split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias,
                          float *__restrict__ Y, int M, int K, int N, int mblocks, int nblocks)
@@ -197,20 +197,17 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < kTJ; ++j)
-                    acc[i][j] = BUFST == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi[j], a_mid[i], acc[i][j], 0, 0, 0)
-                                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid[i], b_hi[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < kTJ; ++j)
-                    acc[i][j] = BUFST == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_mid[j], a_hi[i], acc[i][j], 0, 0, 0)
-                                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_mid[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_mid[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < kTJ; ++j)
-                    acc[i][j] = BUFST == 2 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_hi[j], a_hi[i], acc[i][j], 0, 0, 0)
-                                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
         }
         // slice s + 1 -> the LDS buffer nobody reads in this iteration (its readers passed the previous barrier),
         // then its registers take slice s + 3
@@ -224,46 +221,7 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
     }
 
     // ---- epilogue: C/D of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if constexpr (BUFST == 2) {
-        // transposed tile: lane -> output row m0 + i * 32 + (lane & 31); registers 4 g .. 4 g + 3 -> columns 8 g + 4 (lane >> 5) + 0..3
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
-        // the bias through a buffer resource too (no bias: zero records; columns >= N: out of range -> zeros): all of a
-        // wave's bias loads are issued together, in front of the stores
-        const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bias ? bias : Y), 0,
-                                                                             bias ? (unsigned)N * 4u : 0u, 0x00020000);
-        f32x4 bv[kTJ][4];
-#pragma unroll
-        for (int j = 0; j < kTJ; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                bv[j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                         brs, (unsigned)(n0 + (wave * kTJ + j) * 32 + 4 * (lane >> 5) + 8 * g) * 4u, 0, 0));
-#pragma unroll
-        for (int j = 0; j < kTJ; ++j) {
-            const int cbase = n0 + (wave * kTJ + j) * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = cbase + 8 * g;
-                const bool colok = col < N;   // N % 4 == 0 (host): the four columns are in or out together
-                const f32x4 b = bv[j][g];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    const int row = m0 + i * 32 + (lane & 31);
-                    f32x4 v = {acc[i][j][4 * g] + b.x, acc[i][j][4 * g + 1] + b.y, acc[i][j][4 * g + 2] + b.z, acc[i][j][4 * g + 3] + b.w};
-                    if (RELU) {
-                        v.x = v.x > 0.f ? v.x : 0.f;
-                        v.y = v.y > 0.f ? v.y : 0.f;
-                        v.z = v.z > 0.f ? v.z : 0.f;
-                        v.w = v.w > 0.f ? v.w : 0.f;
-                    }
-                    const unsigned off = colok ? (unsigned)(row * N + col) * 4u : 0xC0000000u;   // rows >= M: beyond num_records
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
-                }
-            }
-        }
-        return;
-    }
-    if constexpr (BUFST == 1) {
+    if constexpr (BUFST) {
         const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < kTJ; ++j) {
@@ -537,21 +495,12 @@ int launch_stream(const float *x, const u32x4 *wp, const float *bias, float *y, 
     const int mblocks = (M + 32 * TI - 1) / (32 * TI), nblocks = (N + kBN - 1) / kBN;
     const long long grid = (long long)((mblocks + 7) / 8) * 8 * nblocks;
     if (grid > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
-    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL) {   // opt-in: buffer-store epilogue
-        const bool wide = tfm::linear_bufstore() == 2 && (N & 3) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
-                          (reinterpret_cast<uintptr_t>(y) & 15) == 0;
-        if (wide) {
-            if (relu)
-                hipLaunchKernelGGL((split_gemm_stream_kernel<TI, true, 2>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
-                                   M, K, N, mblocks, nblocks);
-            else
-                hipLaunchKernelGGL((split_gemm_stream_kernel<TI, false, 2>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
-                                   M, K, N, mblocks, nblocks);
-        } else if (relu)
-            hipLaunchKernelGGL((split_gemm_stream_kernel<TI, true, 1>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
+    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL) {   // buffer-store epilogue (tensors < 3 GiB)
+        if (relu)
+            hipLaunchKernelGGL((split_gemm_stream_kernel<TI, true, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
                                M, K, N, mblocks, nblocks);
         else
-            hipLaunchKernelGGL((split_gemm_stream_kernel<TI, false, 1>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
+            hipLaunchKernelGGL((split_gemm_stream_kernel<TI, false, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
                                M, K, N, mblocks, nblocks);
         return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
     }

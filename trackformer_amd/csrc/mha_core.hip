@@ -48,11 +48,9 @@ __device__ __forceinline__ float row16_sum(float v)
 // K and V pass through LDS in chunks of 64 keys (coalesced 16-byte loads, rows padded by 4 floats so that the 16
 // lanes of a query, which read 16 different key rows at the same column, hit different banks); the 16 x Lk score
 // tile stays in LDS between the passes.
-// BATCH (opt-in: tf_msda_set_option("mha_batch", 1) / TF_MHA_BATCH=1): the staging loop issues EIGHT 16-byte loads per
-// thread before the first LDS write.  As written (`*lds = *global` per iteration) the compiler emits load, s_waitcnt
-// vmcnt(0), ds_write per iteration (tools/isa_audit.py --stream mha_core_kernel): 13 sequential L2 round trips per
-// staging pass of a 400-key head, twice per workgroup -- most of the kernel's 25 us.
-template <int D4, bool BATCH = false>
+// (A staging loop with eight 16-byte loads in flight per thread was measured in round 3: 23.3 -> 22.7 us at 400 keys, 67.4 ->
+// 76.7 us at 800 keys x 36 channels -- removed.)
+template <int D4>
 __global__ void __launch_bounds__(THREADS)
 mha_core_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                 float *__restrict__ out, const unsigned char *__restrict__ key_mask, int Lq, int Lk, int ldq,
@@ -77,28 +75,6 @@ mha_core_kernel(const float *__restrict__ q, const float *__restrict__ k, const 
         for (int c = 0; c < D4; ++c) qv[c] = *reinterpret_cast<const f32x4_t *>(qr + c * 4);
     }
     auto stage = [&](const float *base, int ld, int j0) {   // rows j0 .. j0 + kc of one head -> s_kv
-        if constexpr (BATCH) {
-            constexpr int UN = 8;
-            for (int i0 = tid; i0 < kc * D4; i0 += THREADS * UN) {
-                f32x4_t tmp[UN];
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int i = min(i0 + u * THREADS, kc * D4 - 1);   // past the end: a harmless reload of the last piece
-                    const int r = i / D4, c = i - r * D4;
-                    const int j = min(j0 + r, Lk - 1);
-                    tmp[u] = *reinterpret_cast<const f32x4_t *>(base + ((size_t)n * Lk + j) * ld + h * D + c * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < UN; ++u) {
-                    const int i = i0 + u * THREADS;
-                    if (i < kc * D4) {
-                        const int r = i / D4, c = i - r * D4;
-                        *reinterpret_cast<f32x4_t *>(s_kv + r * DP + c * 4) = tmp[u];
-                    }
-                }
-            }
-            return;
-        }
         for (int i = tid; i < kc * D4; i += THREADS) {
             const int r = i / D4, c = i - r * D4;
             const int j = min(j0 + r, Lk - 1);
@@ -180,28 +156,7 @@ mha_core_kernel(const float *__restrict__ q, const float *__restrict__ k, const 
         *reinterpret_cast<f32x4_t *>(out + ((size_t)n * Lq + q0 + qi) * ldo + h * D + kl * 4) = r * s_inv[qi];
 }
 
-std::atomic<int> g_mha_batch{-1};   // -1: TF_MHA_BATCH (default 0)
-
 }  // namespace
-
-namespace tfm {
-int mha_batch()
-{
-    int v = g_mha_batch.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("TF_MHA_BATCH");
-        v = (e && e[0] == '1') ? 1 : 0;
-        g_mha_batch.store(v);
-    }
-    return v;
-}
-int mha_batch_set(int v)
-{
-    const int prev = mha_batch();
-    g_mha_batch.store(v ? 1 : 0);
-    return prev;
-}
-}  // namespace tfm
 
 extern "C" int tf_mha_core_f32(const float *q, const float *k, const float *v, float *out, const unsigned char *key_mask,
                                int N, int Lq, int Lk, int H, int D, int ldq, int ldk, int ldv, int ldo, float scale,
@@ -227,19 +182,18 @@ extern "C" int tf_mha_core_f32(const float *q, const float *k, const float *v, f
     if ((long long)((Lq + TQ - 1) / TQ) * H * N > 256) kc = 64;
     const size_t lds = (size_t)kc * (D + 4) * sizeof(float) + fixed;
     const void *fn = nullptr;
-    const bool batch = tfm::mha_batch() != 0;
     switch (D / 4) {
-    case 4: fn = batch ? (const void *)&mha_core_kernel<4, true> : (const void *)&mha_core_kernel<4>; break;
-    case 8: fn = batch ? (const void *)&mha_core_kernel<8, true> : (const void *)&mha_core_kernel<8>; break;
-    case 9: fn = batch ? (const void *)&mha_core_kernel<9, true> : (const void *)&mha_core_kernel<9>; break;
-    case 16: fn = batch ? (const void *)&mha_core_kernel<16, true> : (const void *)&mha_core_kernel<16>; break;
+    case 4: fn = (const void *)&mha_core_kernel<4>; break;
+    case 8: fn = (const void *)&mha_core_kernel<8>; break;
+    case 9: fn = (const void *)&mha_core_kernel<9>; break;
+    case 16: fn = (const void *)&mha_core_kernel<16>; break;
     default: return TF_MSDA_ERR_BAD_DIMS;   // head dimensions 16, 32, 36, 64
     }
     if (lds > 64 * 1024) {
-        static int raised_dev_mask[34] = {0};   // per kernel (index D / 4, + 17 for the batched variant) and device; benign race
+        static int raised_dev_mask[17] = {0};   // per kernel (index D / 4) and device; benign race
         int dev = 0;
         (void)hipGetDevice(&dev);
-        int &mask = raised_dev_mask[D / 4 + (batch ? 17 : 0)];
+        int &mask = raised_dev_mask[D / 4];
         if (dev >= 31 || !(mask & (1 << dev))) {
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
                 return TF_MSDA_ERR_LAUNCH;

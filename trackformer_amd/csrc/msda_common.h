@@ -47,15 +47,10 @@ void pquad_set_trace(unsigned long long *device_buffer);
 
 // linear_split.hip: block shape / pipelining variant of tf_linear_split_f32; returns the previous one
 int linear_set_variant(int v);
-// linear_split.hip: opt-in buffer-store epilogue of the split GEMMs (0 / 1); the setter returns the previous value
+// linear_split.hip: buffer-store epilogue of the split GEMMs (0 / 1, default 1); the setter returns the previous value
 int linear_bufstore();
 int linear_bufstore_set(int v);
-// fused_ops.hip: opt-in batched-load variant of tf_bias_act_f32 (0 / 1); returns the previous value
-int bias_act_batch_set(int v);
-// mha_core.hip: opt-in batched staging loads of tf_mha_core_f32 (0 / 1)
-int mha_batch();
-int mha_batch_set(int v);
-// linear_split.hip: opt-in deep-prefetch kernel (variant 7) for calls with few rows (0 / 1)
+// linear_split.hip: deep-prefetch kernel (variant 7) for calls with few rows (0 / 1, default 1)
 int linear_deep();
 int linear_deep_set(int v);
 // ffn_fused.hip: row tiles per block of tf_ffn_fused_f32 (1..3, default 3); returns the previous value

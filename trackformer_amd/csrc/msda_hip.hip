@@ -2689,12 +2689,13 @@ bool direct_enabled()
     return on != 0;
 }
 
-std::atomic<int> g_bwd_sorted2{-1};   // -1: environment (TF_MSDA_BWD_SORTED2, default 0)
+std::atomic<int> g_bwd_sorted2{-1};   // -1: environment (TF_MSDA_BWD_SORTED2, default 1 since round 3: 292 -> 223 us `local`, 266 -> 255 us
+                                      // `init` at the cfg-2 encoder shape, profiles/r03_optin_msda_variants.txt)
 bool bwd_sorted2_enabled()
 {
     const int v = g_bwd_sorted2.load(std::memory_order_relaxed);
     if (v >= 0) return v != 0;
-    static const int env = [] { const char *e = getenv("TF_MSDA_BWD_SORTED2"); return (e && e[0] == '1') ? 1 : 0; }();
+    static const int env = [] { const char *e = getenv("TF_MSDA_BWD_SORTED2"); return (e && e[0] == '0') ? 0 : 1; }();
     return env != 0;
 }
 // dynamic LDS above 64 KB needs the per-function, per-device attribute: set once per device for msda_bwd_f32_sorted2
@@ -2710,12 +2711,13 @@ bool raise_dynamic_lds(const void *fn)
     return true;
 }
 
-std::atomic<int> g_direct9{-1};   // -1: environment (TF_MSDA_DIRECT9, default 0)
+std::atomic<int> g_direct9{-1};   // -1: environment (TF_MSDA_DIRECT9, default 1 since round 3: cfg-4 decoder forward 18.8-19.7 -> 12.7-14.0 us,
+                                  // profiles/r03_optin_msda_variants.txt)
 bool direct9_enabled()
 {
     const int v = g_direct9.load(std::memory_order_relaxed);
     if (v >= 0) return v != 0;
-    static const int env = [] { const char *e = getenv("TF_MSDA_DIRECT9"); return (e && e[0] == '1') ? 1 : 0; }();
+    static const int env = [] { const char *e = getenv("TF_MSDA_DIRECT9"); return (e && e[0] == '0') ? 0 : 1; }();
     return env != 0;
 }
 
@@ -2725,7 +2727,7 @@ bool launch_direct(bool fused, const DirectArgs &da, const LevelTable &lt, const
     if (!direct_enabled() || P != 4 || da.L > 8) return false;
     const int lpairs = (da.L + 1) / 2;
     const void *fn = nullptr;
-    if (D == 36) {   // 9 lanes per pair, 28 pairs per workgroup (opt-in until timed on hardware)
+    if (D == 36) {   // 9 lanes per pair, 28 pairs per workgroup
         if (!direct9_enabled()) return false;
         if (fused)
             fn = lpairs == 1   ? (const void *)&msda_fwd_f32_direct9<1, true>
@@ -3015,8 +3017,6 @@ int tf_msda_set_option(const char *name, int value)
     if (strcmp(name, "direct9") == 0) return g_direct9.exchange(value < 0 ? -1 : (value ? 1 : 0));
     if (strcmp(name, "linear_bufstore") == 0) return linear_bufstore_set(value);
     if (strcmp(name, "linear_deep") == 0) return linear_deep_set(value);
-    if (strcmp(name, "mha_batch") == 0) return mha_batch_set(value);
-    if (strcmp(name, "bias_act_batch") == 0) return bias_act_batch_set(value);
     if (strcmp(name, "ffn_ti") == 0) return ffn_set_ti(value);
     if (strcmp(name, "linln_ti") == 0) return linln_set_ti(value);
     if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);

@@ -139,8 +139,7 @@ __device__ __forceinline__ f32x4_t ldg_f4(const float *base, unsigned byte_off)
 
 // DH: head dimension, 32 (128-byte rows, 4 lanes x 8 channels) or 36 (hidden 288: 144-byte rows, 3 lanes x 12 channels,
 //     the window rows packed without padding and staged in 16-byte pieces; see msda_quad_dev.h).
-// PIPE (opt-in, pquad_pipe): the LDS gathers of a level with a rolling set of reads in flight (quad_level_lds_pipelined).
-template <bool FUSED, int TA_MASK, int NPASS, int PF, bool WIDE, int DH, bool PIPE = false>
+template <bool FUSED, int TA_MASK, int NPASS, int PF, bool WIDE, int DH>
 __global__ void __launch_bounds__(kPqThreads, (pq_min_waves<NPASS, PF>()))
 msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 {
@@ -663,8 +662,6 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                 const unsigned a1 = staged ? lo + (unsigned)gww[l] * ROWB : 0u;
                 if constexpr ((kPqAblate & 1) != 0) {
                     accA[ps].x += (float)(a0 + a1) * w[0];   // keeps the tap arithmetic alive
-                } else if constexpr (!D36 && PIPE) {
-                    quad_level_lds_pipelined(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
                 } else if constexpr (!D36) {
                     quad_taps_lds<0>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
                     quad_taps_lds<1>(a0, a1, w, ldsA, ldsB, accA[ps], accB[ps]);
@@ -783,12 +780,12 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 }
 
 // ---- options, tile plan, launch ------------------------------------------------------------------------------
-enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoPipe, kPoCount };
+enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoCount };
 const char *const kPqOptNames[kPoCount] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
                                            "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew",
-                                           "pquad", "pquad_pipe"};
-const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on", "pipe"};
-constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 0};   // 3 x 52 KB = 156 KB of the CU's 160
+                                           "pquad"};
+const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on"};
+constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1};   // 3 x 52 KB = 156 KB of the CU's 160
 std::atomic<int> g_pq_opt[kPoCount];
 std::atomic<int> g_pq_epoch{0};
 std::atomic<unsigned long long *> g_pq_trace{nullptr};
@@ -843,7 +840,7 @@ struct PqPlan {
     PquadGeom geom;
     size_t lds;
     int ta_mask, npass, wgs, pf;
-    bool wide, pipe;
+    bool wide;
 };
 
 int pq_num_cus()
@@ -946,7 +943,6 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     r.geom.skew = o[kPoSkew];
     r.geom.cus = pq_num_cus();
     r.wide = o[kPoWide] != 0;
-    r.pipe = o[kPoPipe] != 0;
     r.ta_mask = ta;
     r.npass = npass;
     r.wgs = wgs;
@@ -1015,9 +1011,6 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
         wide = wide && ((uintptr_t)da.loc % 16 == 0) && ((uintptr_t)da.attn % 16 == 0);
     const void *fn = D == 36 ? (fused ? pq_kernel_d36<true>(wide) : pq_kernel_d36<false>(wide))
                              : (fused ? pq_kernel<true>(pl.npass, pl.pf, wide) : pq_kernel<false>(pl.npass, pl.pf, wide));
-    if (pl.pipe && D == 32 && pl.npass == 2 && pl.pf == 0 && wide)   // the only configuration the pipelined gathers are built for
-        fn = fused ? (const void *)&msda_fwd_f32_pquad<true, 0, 2, 0, true, 32, true>
-                   : (const void *)&msda_fwd_f32_pquad<false, 0, 2, 0, true, 32, true>;
     // the dynamic-LDS limit is a per-function, per-device attribute: cheap, set on every first (function, device)
     struct Raised { const void *fn; int dev; };
     static std::atomic<int> n_raised{0};

@@ -56,78 +56,8 @@ __device__ __forceinline__ void quad_taps_lds(unsigned a0, unsigned a1, const fl
     accB += v11b * W3;
 }
 
-// The four points of one level (lanes 0..3 of the quad own one each) from LDS windows with a ROLLING set of reads in
-// flight: the two x-neighbour rows of point K + 1 (y0 taps) are requested as soon as point K's y0 taps have been
-// consumed, its y0 + 1 taps after point K's y0 + 1 taps -- 4..8 ds_read_b128 stay outstanding through the FMAs instead
-// of 8 -> 0 -> 8 per point.  Same instructions and the same summation order per accumulator as four quad_taps_lds<K>
-// calls (bit-identical results); __builtin_amdgcn_sched_barrier(0) pins the order.  Opt-in (pquad_pipe).
-__device__ __forceinline__ void quad_level_lds_pipelined(unsigned a0, unsigned a1, const float (&w)[4], unsigned ldsA,
-                                                         unsigned ldsB, f32x4_t &accA, f32x4_t &accB)
-{
-    f32x4_t r0[4], r1[4];   // y0 taps {x0 A, x0+1 A, x0 B, x0+1 B}, y0 + 1 taps likewise
-    auto issue0 = [&](auto kc) {
-        constexpr int C = decltype(kc)::value * 0x55;
-        const unsigned pa = dpp_u<C>(a0) + ldsA, pb = dpp_u<C>(a0) + ldsB;
-        r0[0] = lds_read16(pa);
-        r0[1] = lds_read16(pa + 128u);
-        r0[2] = lds_read16(pb);
-        r0[3] = lds_read16(pb + 128u);
-    };
-    auto issue1 = [&](auto kc) {
-        constexpr int C = decltype(kc)::value * 0x55;
-        const unsigned pa = dpp_u<C>(a1) + ldsA, pb = dpp_u<C>(a1) + ldsB;
-        r1[0] = lds_read16(pa);
-        r1[1] = lds_read16(pa + 128u);
-        r1[2] = lds_read16(pb);
-        r1[3] = lds_read16(pb + 128u);
-    };
-    auto fma0 = [&](auto kc) {
-        constexpr int C = decltype(kc)::value * 0x55;
-        const float W0 = dpp_f<C>(w[0]), W1 = dpp_f<C>(w[1]);
-        accA += r0[0] * W0;
-        accB += r0[2] * W0;
-        accA += r0[1] * W1;
-        accB += r0[3] * W1;
-    };
-    auto fma1 = [&](auto kc) {
-        constexpr int C = decltype(kc)::value * 0x55;
-        const float W2 = dpp_f<C>(w[2]), W3 = dpp_f<C>(w[3]);
-        accA += r1[0] * W2;
-        accB += r1[2] * W2;
-        accA += r1[1] * W3;
-        accB += r1[3] * W3;
-    };
-    using std::integral_constant;
-    issue0(integral_constant<int, 0>{});
-    issue1(integral_constant<int, 0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    fma0(integral_constant<int, 0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    issue0(integral_constant<int, 1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    fma1(integral_constant<int, 0>{});
-    __builtin_amdgcn_sched_barrier(0);
-    issue1(integral_constant<int, 1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    fma0(integral_constant<int, 1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    issue0(integral_constant<int, 2>{});
-    __builtin_amdgcn_sched_barrier(0);
-    fma1(integral_constant<int, 1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    issue1(integral_constant<int, 2>{});
-    __builtin_amdgcn_sched_barrier(0);
-    fma0(integral_constant<int, 2>{});
-    __builtin_amdgcn_sched_barrier(0);
-    issue0(integral_constant<int, 3>{});
-    __builtin_amdgcn_sched_barrier(0);
-    fma1(integral_constant<int, 2>{});
-    __builtin_amdgcn_sched_barrier(0);
-    issue1(integral_constant<int, 3>{});
-    __builtin_amdgcn_sched_barrier(0);
-    fma0(integral_constant<int, 3>{});
-    fma1(integral_constant<int, 3>{});
-}
+// (A variant with a rolling set of reads in flight -- the y0 taps of point K + 1 requested as soon as point K's were consumed,
+// bit-identical -- was measured on MI355X in round 3: 44.5 vs 44.4 us plain, 45.9 vs 47.2 us fused; removed.)
 
 // One point's four taps by buffer loads.  g[t]: byte offset of tap t's row (this head's 128 bytes) held
 // by lane K of the quad; invalid taps carry kOobBase, which stays out of range after + rbA / rbB.

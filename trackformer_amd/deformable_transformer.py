@@ -95,6 +95,12 @@ class _GeometryCache:
 
 _GEOMETRY = _GeometryCache()
 
+# per-module inference caches (_ref_points_cache, _lvl_pos_cache): a HIP graph captured after a cache hit has the cached
+# tensor's raw address baked in, so an entry must never be freed while such a graph can still be replayed.  The caches
+# are therefore keyed (one entry per geometry / parameter version) and never evict: once this many entries exist, new
+# keys are recomputed per call (inside a capture that lands in the graph's own pool) instead of displacing an old one.
+_KEEP_CACHE_ENTRIES = 64
+
 
 def _host_shapes(spatial_shapes):
     """(H, W) python ints of a spatial_shapes tensor (attached by DeformableTransformer.forward;
@@ -204,14 +210,15 @@ class DeformableTransformer(nn.Module):
         lin = self.reference_points
         key = (id(query_param), query_param._version, query_param.data_ptr(), lin.weight._version, lin.weight.data_ptr(),
                lin.bias._version, bs, query_embed.device)
-        hit = self.__dict__.get("_ref_points_cache")
-        if hit is None or hit[0] != key:
+        cache = self.__dict__.setdefault("_ref_points_cache", {})
+        hit = cache.get(key)
+        if hit is None:
             value = lin(query_embed).sigmoid()
-            if query_embed.is_cuda and torch.cuda.is_current_stream_capturing():
-                return value   # never keep a buffer of a graph's memory pool
-            hit = (key, value, query_param)
-            self.__dict__["_ref_points_cache"] = hit
-        return hit[1]
+            if (query_embed.is_cuda and torch.cuda.is_current_stream_capturing()) or len(cache) >= _KEEP_CACHE_ENTRIES:
+                return value   # never keep a buffer of a graph's memory pool; a full cache recomputes, it never evicts
+            hit = (value, query_param)
+            cache[key] = hit
+        return hit[0]
 
     def _level_position_embedding(self, pos_embeds):
         """cat_l(pos_l flattened + level_embed[l]) (deformable_transformer.py:139-156 of the reference).  In inference the
@@ -223,14 +230,15 @@ class DeformableTransformer(nn.Module):
         if self.training or torch.is_grad_enabled():
             return compute()
         key = tuple((id(p), p._version) for p in pos_embeds) + (self.level_embed._version, self.level_embed.data_ptr())
-        hit = self.__dict__.get("_lvl_pos_cache")
-        if hit is None or hit[0] != key:
-            if pos_embeds[0].is_cuda and torch.cuda.is_current_stream_capturing():
-                return compute()   # never keep a buffer of a graph's memory pool
+        cache = self.__dict__.setdefault("_lvl_pos_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if (pos_embeds[0].is_cuda and torch.cuda.is_current_stream_capturing()) or len(cache) >= _KEEP_CACHE_ENTRIES:
+                return compute()   # never keep a buffer of a graph's memory pool; a full cache recomputes, it never evicts
             # the inputs are kept alive next to the result: an id() in the key can then not be reused by another tensor
-            hit = (key, compute(), list(pos_embeds))
-            self.__dict__["_lvl_pos_cache"] = hit
-        return hit[1]
+            hit = (compute(), list(pos_embeds))
+            cache[key] = hit
+        return hit[0]
 
     def forward(self, srcs, masks, pos_embeds, query_embed=None, targets=None):
         assert self.two_stage or query_embed is not None

@@ -18,7 +18,9 @@ Differences, all result-preserving:
   * PostProcessSegm keeps the masks on the device of the model outputs (the reference moves all
     Q masks to the host before resizing them).
 """
+import contextlib
 import io
+import threading
 from collections import defaultdict
 from typing import List, Optional
 
@@ -43,6 +45,21 @@ class MaskContext:
 
     def __init__(self, src, mask, fpns, memory):
         self.src, self.mask, self.fpns, self.memory = src, mask, fpns, memory
+
+
+_LAZY_SCOPE = threading.local()
+
+
+@contextlib.contextmanager
+def lazy_mask_scope(on=True):
+    """Within the block (this thread only) a DETRSegm* forward under no_grad returns out["mask_context"] instead of
+    out["pred_masks"]; DETRSegmBase.mask_rows evaluates the head for chosen queries afterwards."""
+    prev = getattr(_LAZY_SCOPE, "on", False)
+    _LAZY_SCOPE.on = bool(on)
+    try:
+        yield
+    finally:
+        _LAZY_SCOPE.on = prev
 
 
 class DETRSegmBase(nn.Module):
@@ -74,7 +91,7 @@ class DETRSegmBase(nn.Module):
             src = self.input_proj(src)
             fpns = [features[2].tensors, features[1].tensors, features[0].tensors]
 
-        if self.lazy_masks and not self.training and not torch.is_grad_enabled():
+        if self.lazy_masks_active() and not self.training and not torch.is_grad_enabled():
             # OPT-IN (Tracker(lazy_masks=True) / TF_LAZY_MASKS=1): a query's mask depends on that query alone (attention map
             # and GroupNorm are per (image, query) sample), and the tracker only ever reads the masks of its surviving
             # tracks -- the head (3.3 TFLOP for 400 queries at 800 x 1333, 41 of cfg 5's 47 ms) is evaluated for those rows
@@ -87,7 +104,13 @@ class DETRSegmBase(nn.Module):
                                            seg_masks.shape[-1])
         return out, targets, features, memory, hs
 
-    lazy_masks = False
+    lazy_masks = False     # permanent opt-in of a model instance (every no_grad caller then gets `mask_context`)
+
+    def lazy_masks_active(self) -> bool:
+        """True when this call leaves the mask head to the caller: the instance switch, or the calling thread is inside
+        `lazy_mask_scope()` (what Tracker uses: the switch is scoped to its own detector call, a PostProcessSegm consumer
+        or a second tracker sharing the module is not affected)."""
+        return bool(self.lazy_masks or getattr(_LAZY_SCOPE, "on", False))
 
     def mask_rows(self, ctx: "MaskContext", hs_rows: Tensor) -> Tensor:
         """pred_masks of the queries whose last-layer decoder outputs are hs_rows [B, n, C] -> [B, n, H, W]: the same
@@ -232,6 +255,9 @@ class PostProcessSegm(nn.Module):
         sizes = torch.as_tensor(max_target_sizes).tolist()
         orig = torch.as_tensor(orig_target_sizes).tolist()
         max_h, max_w = max(s[0] for s in sizes), max(s[1] for s in sizes)
+        if "pred_masks" not in outputs and "mask_context" in outputs:
+            raise KeyError("pred_masks: the detector ran with lazy masks (DETRSegmBase.lazy_masks / lazy_mask_scope) and "
+                           "returned `mask_context`; evaluate model.mask_rows(context, hs_rows) or run it without the switch")
         masks_all = outputs["pred_masks"]
         if masks_all.dim() == 5:
             masks_all = masks_all.squeeze(2)

@@ -120,6 +120,14 @@ def set_packed_linear(on):
     return prev
 
 
+def _publish_barrier(device):
+    """Cached weight images are built on the caller's current stream and then published on the tensor for EVERY stream
+    (one tracker thread per sequence, each on its own HIP stream, share one model): wait for the building stream before
+    publishing, so that a second thread's first GEMM cannot read a half-written image.  Once per weight."""
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream(device).synchronize()
+
+
 def _packed_weight(weight, rows):
     """Fragment-order (hi, mid) image of `weight` (or of its row block `rows`), built by tf_linear_pack_weight_f32 and
     cached on the tensor object with its version counter, like _split_weight below."""
@@ -142,6 +150,7 @@ def _packed_weight(weight, rows):
             rc = _cabi.lib().tf_linear_pack_weight_f32(w.data_ptr() + a * K * 4, hit.data_ptr(), K, b - a,
                                                        _stream(weight.device))
         _cabi.check(rc, "tf_linear_pack_weight_f32")
+        _publish_barrier(weight.device)
         cache[1][rows] = hit
     return hit
 
@@ -159,6 +168,8 @@ def _split_weight(weight):
         hi = w.to(torch.bfloat16)
         mid = (w - hi.float()).to(torch.bfloat16)
         hit = (weight._version, hi.contiguous(), mid.contiguous())
+        if w.is_cuda:
+            _publish_barrier(w.device)
         weight._tf_split = hit
     return hit[1], hit[2]
 
@@ -217,10 +228,11 @@ def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
     return y.view(*x.shape[:-1], N)
 
 
-# OPT-IN (TF_FFN_FUSED=1 / set_ffn_fused(True)): linear1 -> ReLU -> linear2 -> + residual -> LayerNorm of a transformer
+# DEFAULT since round 3 (TF_FFN_FUSED=0 / set_ffn_fused(False) switches it off): linear1 -> ReLU -> linear2 -> + residual -> LayerNorm of a transformer
 # layer in ONE launch (tf_ffn_fused_f32, csrc/ffn_fused.hip): the d_ffn-wide intermediate (91 MB per encoder layer at
-# 800 x 1333) never leaves the CU.  Same split products as linear(); written against the emulator, to be timed in round 3.
-_ffn_fused = os.environ.get("TF_FFN_FUSED", "0") == "1"
+# 800 x 1333) never leaves the CU.  Same split products as linear(), bit-identical before the LayerNorm.  MI355X, 22 223 rows, d_ffn 1024: 72.3 us against
+# 116.0 us for linear1 + ReLU, linear2, residual + LayerNorm (profiles/r03_optin_ffn_fused.txt).
+_ffn_fused = os.environ.get("TF_FFN_FUSED", "1") != "0"
 _FFN_FUSED_MIN_ROWS = int(os.environ.get("TF_FFN_FUSED_MIN_ROWS", "4096"))   # below: too few 96-row blocks to fill the CUs
 
 
@@ -282,10 +294,10 @@ def ffn(x, linear1, linear2, norm=None, residual=None):
     return y.view(x.shape)
 
 
-# OPT-IN (TF_LINLN_FUSED=1 / set_linear_ln_fused(True)): a 256 -> 256 linear, the layer's residual add and its LayerNorm in
-# ONE launch (tf_linear_res_ln_f32, csrc/ffn_fused.hip) -- the attention's output projection + norm1.  Written against the
-# emulator, to be timed in round 3.
-_linln_fused = os.environ.get("TF_LINLN_FUSED", "0") == "1"
+# DEFAULT since round 3 (TF_LINLN_FUSED=0 / set_linear_ln_fused(False) switches it off): a 256 -> 256 linear, the layer's residual add and its LayerNorm in
+# ONE launch (tf_linear_res_ln_f32, csrc/ffn_fused.hip) -- the attention's output projection + norm1.  MI355X: 19.4-22.1 us
+# against 34.5 us at 22 223 rows, 6.9 against 17.1 us at 400 rows (profiles/r03_optin_ffn_fused.txt).
+_linln_fused = os.environ.get("TF_LINLN_FUSED", "1") != "0"
 _LINLN_MIN_ROWS = int(os.environ.get("TF_LINLN_MIN_ROWS", "256"))
 
 
@@ -339,9 +351,10 @@ def linear_residual_norm(x, linear, residual, norm):
     return y.view(x.shape)
 
 
-# OPT-IN (TF_STEM_POOL_FUSED=1 / set_stem_pool_fused(True)): FrozenBN shift + ReLU + MaxPool2d(3, 2, 1) after the stem
+# DEFAULT since round 3 (TF_STEM_POOL_FUSED=0 / set_stem_pool_fused(False) switches it off; stem 147.4 -> 66.4 us with the
+# convolution below, profiles/r03_optin_conv_per_layer.txt): FrozenBN shift + ReLU + MaxPool2d(3, 2, 1) after the stem
 # convolution in one pass (tf_bias_relu_maxpool_f32) instead of bias_act_ + F.max_pool2d; bit-identical.
-_stem_pool_fused = os.environ.get("TF_STEM_POOL_FUSED", "0") == "1"
+_stem_pool_fused = os.environ.get("TF_STEM_POOL_FUSED", "1") != "0"
 
 
 def stem_pool_fused_enabled():
@@ -354,9 +367,9 @@ def set_stem_pool_fused(on):
     return prev
 
 
-# OPT-IN (TF_STEM_CONV_SPLIT=1 / set_stem_conv_split(True)): the 7 x 7 stem convolution as a split product on the matrix cores
+# DEFAULT since round 3 (TF_STEM_CONV_SPLIT=0 / set_stem_conv_split(False) switches it off): the 7 x 7 stem convolution as a split product on the matrix cores
 # (tf_stem_conv7x7_f32, csrc/stem_conv.hip) instead of the library convolution.
-_stem_conv_split = os.environ.get("TF_STEM_CONV_SPLIT", "0") == "1"
+_stem_conv_split = os.environ.get("TF_STEM_CONV_SPLIT", "1") != "0"
 
 
 def stem_conv_split_enabled():
@@ -383,7 +396,8 @@ def _stem_packed(weight):
             packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
             rc = _cabi.lib().tf_linear_pack_weight_f32(w2.data_ptr(), packed.data_ptr(), 176, 64, _stream(w.device))
         _cabi.check(rc, "tf_linear_pack_weight_f32")
-        hit = (weight._version, packed, w2)   # w2 is kept alive until the packing kernel has certainly run
+        _publish_barrier(w.device)
+        hit = (weight._version, packed)
         weight._tf_stem_packed = hit
     return hit[1]
 
@@ -429,10 +443,11 @@ def bias_relu_maxpool(x, bias):
     return out
 
 
-# OPT-IN (TF_HEADS_SPLIT=1 / set_heads_split(True)): the small head GEMMs (box-regression MLPs, class heads: 400 rows) through
+# DEFAULT since round 3 (TF_HEADS_SPLIT=0 / set_heads_split(False) switches it off; +2.9 % frames/s on its own,
+# profiles/r03_optin_single_routes.txt): the small head GEMMs (box-regression MLPs, class heads: 400 rows) through
 # the split-product kernels as well instead of hipBLASLt -- 24 launches per frame; the class logits then carry the three-term
 # product's ~1e-5 relative error like everything else (tools/experiments/bf16_split_linear.py: parity and track ids hold).
-_heads_split = os.environ.get("TF_HEADS_SPLIT", "0") == "1"
+_heads_split = os.environ.get("TF_HEADS_SPLIT", "1") != "0"
 
 
 def heads_split_enabled():
@@ -455,9 +470,9 @@ def head_linear(module, x, relu=False):
     return F.relu(y) if relu else y
 
 
-# OPT-IN (TF_POS_ADD_FUSED=1 / set_pos_add_fused(True)): `with_pos_embed(x, pos)` in front of a projection is done inside the
+# DEFAULT since round 3 (TF_POS_ADD_FUSED=0 / set_pos_add_fused(False) switches it off): `with_pos_embed(x, pos)` in front of a projection is done inside the
 # GEMM while the activation tile is staged (tf_linear_split_add_f32) instead of as its own pass over the tokens; bit-identical.
-_pos_add_fused = os.environ.get("TF_POS_ADD_FUSED", "0") == "1"
+_pos_add_fused = os.environ.get("TF_POS_ADD_FUSED", "1") != "0"
 
 
 def pos_add_fused_enabled():
@@ -559,11 +574,12 @@ def _conv_ksplit(m, cin, cout):
     return max(1, min(64, 384 // blocks, slices // 8))
 
 
-# OPT-IN (TF_INPUT_PROJ_FUSED=1 / set_input_proj_fused(True)), not yet timed on hardware: the reference's `input_proj`
+# DEFAULT since round 3 (TF_INPUT_PROJ_FUSED=0 / set_input_proj_fused(False) switches it off; +4.3 % frames/s on its own,
+# profiles/r03_optin_single_routes.txt): the reference's `input_proj`
 # levels with a 1 x 1 convolution (models/deformable_detr.py:73-90: Conv2d(C, hidden, 1) -> GroupNorm(32, hidden)) as the
 # split-product GEMM over the pixels + the library's own channels-innermost GroupNorm (tf_groupnorm_nhwc_f32), instead
 # of a CK convolution, a layout copy and three ATen kernels per level.
-_input_proj_fused = os.environ.get("TF_INPUT_PROJ_FUSED", "0") == "1"
+_input_proj_fused = os.environ.get("TF_INPUT_PROJ_FUSED", "1") != "0"
 
 
 def set_input_proj_fused(on):
@@ -632,9 +648,10 @@ def input_proj_1x1(x, conv, gn):
     return z2.view(n, h, w, cout).permute(0, 3, 1, 2)
 
 
-# OPT-IN (TF_BOX_REFINE_FUSED=1 / set_box_refine_fused(True)): the decoder's iterative box refinement in one launch
+# DEFAULT since round 3 (TF_BOX_REFINE_FUSED=0 / set_box_refine_fused(False) switches it off; +5.1 % frames/s on its own):
+# the decoder's iterative box refinement in one launch
 # (tf_box_refine_f32) instead of ~12 element-wise ATen launches per layer on [queries, 4] tensors.
-_box_refine_fused = os.environ.get("TF_BOX_REFINE_FUSED", "0") == "1"
+_box_refine_fused = os.environ.get("TF_BOX_REFINE_FUSED", "1") != "0"
 
 
 def set_box_refine_fused(on):

@@ -43,6 +43,10 @@ _CAPTURE_LOCK = threading.Lock()
 
 
 class GraphedDetector:
+    # `features` of a multi-frame replay are the entry's static buffers (module docstring): a caller that keeps more than
+    # the latest set (Tracker with prev_frame_dist > 1) has to clone them -- Tracker.step checks this attribute
+    features_alias_static_buffers = True
+
     def __init__(self, model, max_graphs=16, bucket=16):
         self.model = model
         self.max_graphs = max_graphs
@@ -169,7 +173,9 @@ class GraphedDetector:
         if target is not None:
             target, n_real, n_pad = self._bucketed(target)
         n_track = n_pad
-        key = (tuple(img.shape), n_track, img.device, bool(multi and prev_features is not None))
+        lazy = getattr(self.model, "lazy_masks_active", None)
+        key = (tuple(img.shape), n_track, img.device, bool(multi and prev_features is not None),
+               bool(lazy()) if lazy is not None else False)   # a graph with and one without the mask head are different graphs
         entry = self._graphs.get(key)
         if entry is None:
             # capture a shape the second time it shows up (one-off shapes are not worth a graph)

@@ -30,14 +30,14 @@ class Tracker:
                  logger=None, verbose=False, lazy_masks=None):
         self.obj_detector = obj_detector
         self.obj_detector_post = obj_detector_post
-        # OPT-IN (lazy_masks=True / TF_LAZY_MASKS=1): with a mask head, run it only for the queries whose masks the step
-        # ends up keeping (DETRSegmBase.mask_rows) instead of for all of them inside the detector forward
+        # DEFAULT since round 3 (lazy_masks=False / TF_LAZY_MASKS=0 switches it off): with a mask head, run it only for the
+        # queries whose masks the step ends up keeping (DETRSegmBase.mask_rows) instead of for all of them inside the
+        # detector forward -- cfg 5 on MI355X: 21.3 -> 178.6 frames/s (profiles/r03_optin_summary.txt)
         if lazy_masks is None:
-            lazy_masks = os.environ.get("TF_LAZY_MASKS", "0") == "1"
+            lazy_masks = os.environ.get("TF_LAZY_MASKS", "1") != "0"
         module = getattr(obj_detector, "model", obj_detector)   # GraphedDetector wraps the nn.Module
+        # scoped to this tracker's own detector calls (detr_segmentation.lazy_mask_scope): the shared module is not modified
         self._lazy_masks = bool(lazy_masks) and "segm" in obj_detector_post and hasattr(module, "mask_rows")
-        if self._lazy_masks:
-            module.lazy_masks = True   # before the first forward: a captured HIP graph then leaves the head out
         self.detection_obj_score_thresh = tracker_cfg['detection_obj_score_thresh']
         self.track_obj_score_thresh = tracker_cfg['track_obj_score_thresh']
         self.detection_nms_thresh = tracker_cfg['detection_nms_thresh']
@@ -260,7 +260,12 @@ class Tracker:
                 'track_query_hs_embeds': torch.stack([t.hs_embed[-1] for t in prev_tracks], dim=0),
             }]
 
-        outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
+        if self._lazy_masks:
+            from .detr_segmentation import lazy_mask_scope
+            with lazy_mask_scope():
+                outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
+        else:
+            outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
         hs_embeds = outputs['hs_embed'][0]
 
         results = self.obj_detector_post['bbox'](outputs, orig_size)
@@ -421,6 +426,10 @@ class Tracker:
         for t in self.inactive_tracks:
             t.count_inactive += 1
         self.frame_index += 1
+        if self.prev_frame_dist != 1 and getattr(self.obj_detector, "features_alias_static_buffers", False):
+            # GraphedDetector hands back its static feature buffers (rewritten by every replay): with a distance of 1 they
+            # are exactly what the next call wants back; older slots of the deque must own their data
+            features = self.obj_detector._clone_features(features)
         self._prev_features.append(features)
         if self.reid_sim_only:
             self.tracks_to_inactive(self.tracks)
