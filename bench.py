@@ -50,6 +50,7 @@ The JSON line also carries
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -110,6 +111,12 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-sequence", action="store_true")
+    ap.add_argument("--no-fp32-exact", action="store_true",
+                    help="skip the second measurement with every matrix product in fp32 (hipBLASLt / library convolutions)")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the in-run parity check against the committed reference goldens (cfg 2 only)")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="keep the default-initialised class bias (-4.6: no query passes a score threshold, the association leg idles)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="measure only the roofline kernel (headline pattern) and print its JSON object: the command "
                          "profiles/r02_bench_roofline_kernel_stats.csv was collected with under rocprofv3 --stats")
@@ -214,18 +221,21 @@ def build_tracker(model, post, use_graph):
 class TrackSeeder:
     """Re-seeds the tracker with the same synthetic tracks before every step (exactly `n` track queries)."""
 
-    def __init__(self, device, hidden_dim, n, size, seed=0):
+    def __init__(self, device, hidden_dim, n, size, seed=0, seeds=None):
         from trackformer_amd.box_ops import box_cxcywh_to_xyxy
         g = torch.Generator().manual_seed(seed)
         h, w = size
         self.n = n
+        self.obj_ind = torch.arange(n).view(n, 1)
+        if seeds is not None:   # calibrate_association: the detector's own top-n outputs on frame 0
+            self.pos, self.scores, self.hs = seeds["pos"], seeds["scores"], seeds["hs"]
+            return
         centres = torch.rand(n, 2, generator=g) * 0.8 + 0.1
         sizes = torch.rand(n, 2, generator=g) * 0.18 + 0.02
         self.pos = box_cxcywh_to_xyxy(torch.cat([centres, sizes], 1)) * torch.tensor(
             [w, h, w, h], dtype=torch.float32)
         self.scores = torch.full((n,), 0.9)
         self.hs = torch.randn(n, hidden_dim, generator=g).to(device)
-        self.obj_ind = torch.arange(n).view(n, 1)
 
     def seed(self, tracker):
         from trackformer_amd.tracker import Track
@@ -233,6 +243,75 @@ class TrackSeeder:
                           for i in range(self.n)]
         tracker.inactive_tracks = []
         tracker.track_num = self.n
+
+
+def calibrate_association(model, frame, n_tracks, size, device):
+    """Give the association leg real work on random-init weights.  A default-initialised class head has bias
+    -4.6 (deformable_detr.py:60-61 of the reference): no query reaches detection_obj_score_thresh / track_obj_score_thresh
+    = 0.4, nothing is detected, every seeded track goes inactive.  Here the LAST class head's bias is shifted by one constant
+    so that the 1.5 n-th best query of frame 0 sits at 0.4 (about 1.5 n detections pass, the rest do not), and the n seeded
+    tracks are that frame's top-n outputs (boxes, scores, decoder embeddings): they come back as track queries with
+    realistic content, most of them survive, NMS and add_tracks have candidates every step.  Only a bias constant changes:
+    same kernels, same shapes, same arithmetic."""
+    from trackformer_amd.box_ops import box_cxcywh_to_xyxy
+    h, w = size
+    with torch.no_grad():
+        out, *_ = model(frame['img'].to(device), None, None)
+        logit = out['pred_logits'][0].max(-1).values
+        n_det = int(min(logit.numel() - 1, n_tracks + n_tracks // 2))
+        kth = float(logit.topk(n_det).values[-1])
+        delta = math.log(0.4 / 0.6) - kth + 1e-3
+        model.class_embed[-1].bias.add_(delta)
+        out, *_ = model(frame['img'].to(device), None, None)
+        scores = out['pred_logits'][0].sigmoid().max(-1).values
+        top = scores.topk(n_tracks).indices
+        pos = box_cxcywh_to_xyxy(out['pred_boxes'][0][top]) * torch.tensor([w, h, w, h], dtype=torch.float32, device=device)
+        return {"pos": pos.cpu(), "scores": scores[top].cpu(), "hs": out['hs_embed'][0][top].clone(),
+                "delta": round(delta, 4), "detections_above_0.4_frame0": int((scores > 0.4).sum())}
+
+
+def association_stats(model, post, seeder, frames, steps=4):
+    """What the association leg did in `steps` untimed steps of one (eager) tracker: tracks alive after the step, tracks
+    newly created by add_tracks, per step."""
+    tracker = build_tracker(model, post, use_graph=False)
+    alive, new = [], []
+    with torch.no_grad():
+        for i in range(steps):
+            seeder.seed(tracker)
+            tracker.step(frames[i % len(frames)])
+            alive.append(len(tracker.tracks))
+            new.append(tracker.track_num - seeder.n)
+    return {"seeded_tracks": seeder.n, "tracks_alive_after_step": alive, "new_tracks_per_step": new}
+
+
+def measure_parity(device):
+    """In-run parity of the product path against the committed goldens of the reference's own classes (tests/golden/
+    full_cfg2_full.npz, full_tracker_cfg2.npz; generated by tests/golden/make_golden_full.py from /root/reference on CPU): the
+    800 x 1333 cfg-2 model with the parity tests' perturbed weights in the bench set-up (tuned runtime, HIP graph, every
+    default route), one detector call and the 3-frame tracker sequence.  Same code as tests/test_full_size_gpu.py."""
+    import numpy as np
+    from tests import test_full_size_gpu as T, util_models as um
+    from trackformer_amd import config, factory
+    cache = {}
+
+    def models(case):
+        if case not in cache:
+            model, post, margs = um.build(case, factory.build_model, config.make_args, device=device)
+            model.to(device).tracking()
+            cache[case] = (model, post, margs)
+        return cache[case]
+    case = "cfg2_full"
+    model, out, res, feats, memory = T._forward(case, models, device, "graph_split_linear")
+    z = np.load(os.path.join(T.GOLDEN, "full_%s.npz" % case))
+    dbox = float(np.abs(out['pred_boxes'].cpu().numpy() - z['pred_boxes']).max())
+    dlogit = float(np.abs(out['pred_logits'].cpu().numpy() - z['pred_logits']).max())
+    tracker, rows, active = T._run_tracker(models, device, "graph_split_linear")
+    zt = np.load(os.path.join(T.GOLDEN, "full_tracker_cfg2.npz"))
+    ids_equal = bool(rows.shape == zt["rows"].shape and np.array_equal(rows[:, [0, 1, 7]], zt["rows"][:, [0, 1, 7]])
+                     and int(zt["num_tracks"]) == tracker.track_num and zt["active_per_frame"].tolist() == active)
+    return {"against": "reference CPU path goldens (tests/golden/full_cfg2_full.npz, full_tracker_cfg2.npz), perturbed weights, 800x1333",
+            "max_abs_boxes": dbox, "max_abs_logits": dlogit, "tolerance": 1e-3,
+            "ids_equal": ids_equal, "tracker_frames": int(len(active)), "track_rows": int(rows.shape[0])}
 
 
 def make_frames(device, size, n=4, host=False):
@@ -475,12 +554,12 @@ def timed_repeats(run_set, steps, world, device, min_seconds):
             return total, reps
 
 
-def run_tracking(cfg, args, device, world, model, post, margs, n_seq):
+def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None):
     """cfg 2 / 4 / 5: `n_seq` trackers (own HIP stream + graph buffers each, shared weights) step through
     synthetic frames; returns (elapsed, repeats)."""
     import threading
     trackers = [build_tracker(model, post, use_graph=not args.no_graph) for _ in range(n_seq)]
-    seeder = TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"])
+    seeder = TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds)
     frames = make_frames(device, cfg["size"], host=args.host_frames)
     streams = [torch.cuda.Stream(device) for _ in range(n_seq)]
     stagger = [0.0]
@@ -598,25 +677,43 @@ def main():
             print(json.dumps(measure_roofline(device, head_dim=hd, patterns=("pert", "init", "local"))))
         return
     model, criterion, post, margs = build_model(cfg, device)
-    single = None
+    single = fp32_exact = association = None
     n_seq = 1
     if cfg["kind"] == "track":
         model.tracking()
         n_seq = max(1, args.sequences)
-        elapsed, reps = run_tracking(cfg, args, device, world, model, post, margs, n_seq)
+        seeds = None
+        if not args.no_calibration and cfg["tracks"] > 0:
+            seeds = calibrate_association(model, make_frames(device, cfg["size"], n=1)[0], cfg["tracks"], cfg["size"], device)
+        elapsed, reps = run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds)
         if n_seq > 1 and not args.no_single_sequence:
-            e1, r1 = run_tracking(cfg, args, device, world, model, post, margs, 1)
+            e1, r1 = run_tracking(cfg, args, device, world, model, post, margs, 1, seeds)
             single = args.steps * r1 * world / e1
+        if seeds is not None and rank == 0:
+            association = association_stats(model, post, TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds),
+                                            make_frames(device, cfg["size"]))
+            association.update(class_bias_shift=seeds["delta"], detections_above_thresh_frame0=seeds["detections_above_0.4_frame0"])
+        if fused.split_linear_enabled() and not args.no_fp32_exact:
+            # the same measurement with every matrix product in fp32 (hipBLASLt linears, library convolutions): the number a
+            # reader who does not accept the 3-term bf16 products should take
+            prev_split = fused.set_split_linear(False)
+            try:
+                ef, rf = run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds)
+                fp32_exact = args.steps * rf * world / ef
+            finally:
+                fused.set_split_linear(prev_split)
     elif cfg["kind"] == "detect":
         model.eval()
         elapsed, reps = run_detect(cfg, args, device, world, model, post)
     else:
         elapsed, reps = run_training(cfg, args, device, world, rank, model, criterion, margs)
 
-    roofline = cpu_baseline = None
+    roofline = cpu_baseline = parity = None
     if rank == 0:
         if not args.no_roofline and margs.deformable:
             roofline = measure_roofline(device, train=train, head_dim=margs.hidden_dim // margs.nheads)
+        if args.config == "cfg2" and not args.no_parity and not args.no_graph:
+            parity = measure_parity(device)
         if world == 1 and not args.no_cpu_baseline:
             del model
             torch.cuda.empty_cache()
@@ -658,6 +755,8 @@ def main():
                        **({"mask_head": "lazy: evaluated for the surviving tracks' queries only (Tracker default)"}
                           if "segm" in post and os.environ.get("TF_LAZY_MASKS", "1") != "0" and not train else {})},
             "single_sequence_fps": None if single is None else round(single, 3),
+            "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
+            "association": association, "parity": parity,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

@@ -143,7 +143,8 @@ def _fused_case(shapes, N, D, seed, M=8, P=4, spread=2.0):
 
 PQUAD_VARIANTS = [dict(), dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pquad_wg_per_cu=2),
                   dict(pquad_prefetch=2, pquad_wg_per_cu=2), dict(pquad_wide=0), dict(pquad_lds_kb=24),
-                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1)]
+                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1),
+                  dict(pquad_threads=512, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items()) or "default"

@@ -66,16 +66,16 @@ using namespace tfm;
 constexpr int kPqAblate = TF_PQUAD_ABLATE;
 
 constexpr int kPqLevels = 4;
-constexpr int kPqThreads = 256;
-constexpr int kPqPairs = kPqThreads / 4;   // (query, head) pairs per pass
+constexpr int kPqThreads = 256;            // the default workgroup; THREADS = 512 (8 waves, one pass) is a template variant
+constexpr int kPqMaxWaves = 8;
 constexpr int kML = TF_MSDA_MAX_LEVELS;
 // LDS header: level table (3 x 16 ints) | query partition [2][4][16] | nominal footprints [2][4][16] |
 // per-wave bounding boxes [2][4 waves][4 levels][4]; then rows 0, 1 (zeros) and the window rows
 constexpr int kPqOffQ = 3 * kML;
 constexpr int kPqOffNom = kPqOffQ + 2 * 4 * kML;
 constexpr int kPqOffBb = kPqOffNom + 2 * 4 * kML;
-constexpr int kPqOffGeo = kPqOffBb + 128;   // window table [2 parities][4 levels][8 ints]
-constexpr int kPqHdrBytes = 2048;   // >= (kPqOffGeo + 64) * 4 = 1984, multiple of 128
+constexpr int kPqOffGeo = kPqOffBb + 2 * kPqMaxWaves * 16;   // window table [2 parities][4 levels][8 ints]
+constexpr int kPqHdrBytes = 2560;   // >= (kPqOffGeo + 64) * 4 = 2496, multiple of 128
 
 struct PquadGeom {
     int TH, TW;        // tile size in level-0 pixels
@@ -107,9 +107,10 @@ struct PqRefs {     // fused entry only: reference points of the pair's query, p
 // WIDE: the points are loaded as 16-byte pieces (lane j of a quad reads level j's four points: 2 + 1 loads per pass
 //     instead of 4 + 4, every cache line fetched once) and transposed inside the quad by DPP so that lane j ends
 //     up with point j of every level.  Needs 16-byte aligned rows (the host checks).
-template <int NPASS, int PF>
+template <int NPASS, int PF, int THREADS = kPqThreads>
 constexpr int pq_min_waves()
 {
+    if (THREADS == 512) return 4;   // two workgroups of eight waves per CU
     return PF == 2 ? (NPASS == 1 ? 3 : 2) : (NPASS == 1 ? 4 : NPASS == 2 ? 3 : 2);
 }
 
@@ -139,11 +140,13 @@ __device__ __forceinline__ f32x4_t ldg_f4(const float *base, unsigned byte_off)
 
 // DH: head dimension, 32 (128-byte rows, 4 lanes x 8 channels) or 36 (hidden 288: 144-byte rows, 3 lanes x 12 channels,
 //     the window rows packed without padding and staged in 16-byte pieces; see msda_quad_dev.h).
-template <bool FUSED, int TA_MASK, int NPASS, int PF, bool WIDE, int DH>
-__global__ void __launch_bounds__(kPqThreads, (pq_min_waves<NPASS, PF>()))
+// THREADS: 256 (four waves, NPASS passes of 64 pairs) or 512 (eight waves: the same tile in half the passes per wave).
+template <bool FUSED, int TA_MASK, int NPASS, int PF, bool WIDE, int DH, int THREADS = kPqThreads>
+__global__ void __launch_bounds__(THREADS, (pq_min_waves<NPASS, PF, THREADS>()))
 msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 {
-    constexpr int PT = 4, D = DH, NL = kPqLevels, PAIRS = kPqPairs;
+    constexpr int PT = 4, D = DH, NL = kPqLevels, PAIRS = THREADS / 4, WAVES = THREADS / 64;
+    static_assert(WAVES >= NL && WAVES <= kPqMaxWaves, "one wave per level for the window geometry");
     constexpr bool D36 = DH == 36;
     constexpr unsigned ROWB = D * 4;   // bytes of one (pixel, head) row
     static_assert(DH == 32 || DH == 36, "head dimension 32 or 36");
@@ -151,7 +154,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
     int *s_tab = reinterpret_cast<int *>(smem);
     int *s_q = s_tab + kPqOffQ;       // [parity][ya | yb | xa | xb][level]
     int *s_nom = s_tab + kPqOffNom;   // [parity][ny0 | ny1 | nx0 | nx1][level]
-    int *s_bb = s_tab + kPqOffBb;     // [parity][wave][level][min x0, max x0, min y0, max y0]: no LDS atomics
+    int *s_bb = s_tab + kPqOffBb;     // [parity][WAVES][level][min x0, max x0, min y0, max y0]: no LDS atomics
     int *s_geo = s_tab + kPqOffGeo;   // [parity][level][wx0, wy0, ww, wh, limx, limy, fits on its own, -]
     unsigned char *s_rows = smem + kPqHdrBytes;   // rows 0, 1: zeros; the windows start at row 2
 
@@ -391,7 +394,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         constexpr int l = decltype(lc)::value;
         if constexpr ((kPqAblate & 4) != 0) {
             if (lane == 0) {   // the whole level: tfq_window clamps it to the nominal footprint
-                int *slot = s_bb + ((par * 4 + wave) * 4 + l) * 4;
+                int *slot = s_bb + ((par * WAVES + wave) * 4 + l) * 4;
                 slot[0] = -1;
                 slot[1] = l < L ? Ws[l < NL ? l : 0] : INT_MIN;
                 slot[2] = -1;
@@ -441,14 +444,14 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                 const int wmnx = min(min(a0, a1), min(a2, a3)), wmxx = max(max(b0, b1), max(b2, b3));
                 const int wmny = min(min(c0, c1), min(c2, c3)), wmxy = max(max(d0, d1), max(d2, d3));
                 if (lane == 0) {
-                    int *slot = s_bb + ((par * 4 + wave) * 4 + l) * 4;
+                    int *slot = s_bb + ((par * WAVES + wave) * 4 + l) * 4;
                     slot[0] = wmnx;
                     slot[1] = wmxx;
                     slot[2] = wmny;
                     slot[3] = wmxy;
                 }
             } else if (l < NL && lane == 0) {   // levels the call does not have: an empty box
-                int *slot = s_bb + ((par * 4 + wave) * 4 + l) * 4;
+                int *slot = s_bb + ((par * WAVES + wave) * 4 + l) * 4;
                 slot[0] = INT_MAX;
                 slot[1] = INT_MIN;
                 slot[2] = INT_MAX;
@@ -499,11 +502,11 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
             w.ww = w.wh = w.limx = w.limy = 0;
             bool fits = false;
             if (l < L && ((TA_MASK >> l) & 1) == 0) {
-                const int *bb = s_bb + par * 64 + 4 * l;   // + 16 * wave
+                const int *bb = s_bb + par * (16 * WAVES) + 4 * l;   // + 16 * wave
                 const int *nm4 = s_nom + par * 4 * kML;
                 int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
 #pragma unroll
-                for (int ww = 0; ww < kPqThreads / 64; ++ww) {
+                for (int ww = 0; ww < WAVES; ++ww) {
                     bx0 = min(bx0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 0]));
                     bx1 = max(bx1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 1]));
                     by0 = min(by0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 2]));
@@ -573,13 +576,13 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                             int r = wave * 8 + (lane >> 3);                       // < 64
                             int wy = (int)(((float)r + 0.5f) * inv_ww);
                             int wx = r - wy * ww;
-                            constexpr int STEP = 8 * (kPqThreads / 64);
+                            constexpr int STEP = 8 * WAVES;
                             const int qstep = __builtin_amdgcn_readfirstlane((int)(((float)STEP + 0.5f) * inv_ww));
                             const int rstep = STEP - qstep * ww;
                             unsigned off = lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)(lane & 7) * 16u;
                             const unsigned step_a = (unsigned)(qstep * W + rstep) * rowbytes;
                             const unsigned step_b = (unsigned)(W - ww) * rowbytes;
-                            for (int c = wave; c < nchunks; c += kPqThreads / 64) {
+                            for (int c = wave; c < nchunks; c += WAVES) {
                                 const int py = wy0 + wy, px = wx0 + wx;   // extended coordinates: may be -1 or size
                                 const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
                                 if constexpr (!(kPqAblate & 2))
@@ -605,7 +608,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                         used += (nchunks * 64 + 8) / 9;
                         const unsigned lvl_base = glvl[l];
                         const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
-                        for (int c = wave; c < nchunks; c += kPqThreads / 64) {
+                        for (int c = wave; c < nchunks; c += WAVES) {
                             const int pc = c * 64 + lane;
                             const int r = (int)(((float)pc + 0.5f) * (1.f / 9.f));   // pc / 9 (pc < 2^16: exact)
                             const int piece = pc - r * 9;
@@ -780,12 +783,12 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 }
 
 // ---- options, tile plan, launch ------------------------------------------------------------------------------
-enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoCount };
+enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoThreads, kPoCount };
 const char *const kPqOptNames[kPoCount] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
                                            "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew",
-                                           "pquad"};
-const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on"};
-constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1};   // 3 x 52 KB = 156 KB of the CU's 160
+                                           "pquad", "pquad_threads"};
+const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on", "thr"};
+constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 256};   // 3 x 52 KB = 156 KB of the CU's 160
 std::atomic<int> g_pq_opt[kPoCount];
 std::atomic<int> g_pq_epoch{0};
 std::atomic<unsigned long long *> g_pq_trace{nullptr};
@@ -839,7 +842,7 @@ long long pq_tile_max_queries(const LevelTable &lt, int L, int th, int tw)
 struct PqPlan {
     PquadGeom geom;
     size_t lds;
-    int ta_mask, npass, wgs, pf;
+    int ta_mask, npass, wgs, pf, threads;
     bool wide;
 };
 
@@ -866,7 +869,11 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     const int epoch = g_pq_epoch.load(std::memory_order_relaxed);
     const int ta = 0, npass = o[kPoNpass], pf = o[kPoPrefetch];
     if (npass < 1 || npass > 3 || (pf != 0 && pf != 2) || o[kPoWgPerCu] < 1 || o[kPoSkew] < 0) return false;
-    const int wgs = o[kPoWgPerCu] < pq_max_wgs(npass, pf) ? o[kPoWgPerCu] : pq_max_wgs(npass, pf);
+    const int threads = o[kPoThreads];
+    if (threads != 256 && threads != 512) return false;
+    if (threads == 512 && (npass != 1 || pf != 0 || D != 32)) return false;   // the only eight-wave variant built
+    const int max_wgs = threads == 512 ? 2 : pq_max_wgs(npass, pf);
+    const int wgs = o[kPoWgPerCu] < max_wgs ? o[kPoWgPerCu] : max_wgs;
     if (o[kPoLdsKb] < 8 || o[kPoLdsKb] > 160 || o[kPoHaloY] < 0 || o[kPoHaloX] < 0 || o[kPoTileH] < 0 || o[kPoTileW] < 0)
         return false;
     for (int l = 0; l < L; ++l)
@@ -896,7 +903,7 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     memo.D = D;
     memo.epoch = epoch;
     memo.lt = lt;
-    const long long cap_q = (long long)kPqPairs * npass;
+    const long long cap_q = (long long)(threads / 4) * npass;
     const long long slots = (long long)pq_num_cus() * wgs;
     int bth = 0, btw = 0;
     if (o[kPoTileH] > 0 && o[kPoTileW] > 0) {
@@ -945,6 +952,7 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     r.wide = o[kPoWide] != 0;
     r.ta_mask = ta;
     r.npass = npass;
+    r.threads = threads;
     r.wgs = wgs;
     r.pf = pf;
     memo.plan = r;
@@ -1011,6 +1019,11 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
         wide = wide && ((uintptr_t)da.loc % 16 == 0) && ((uintptr_t)da.attn % 16 == 0);
     const void *fn = D == 36 ? (fused ? pq_kernel_d36<true>(wide) : pq_kernel_d36<false>(wide))
                              : (fused ? pq_kernel<true>(pl.npass, pl.pf, wide) : pq_kernel<false>(pl.npass, pl.pf, wide));
+    if (pl.threads == 512) {
+        if (!wide) return false;
+        fn = fused ? (const void *)&msda_fwd_f32_pquad<true, 0, 1, 0, true, 32, 512>
+                   : (const void *)&msda_fwd_f32_pquad<false, 0, 1, 0, true, 32, 512>;
+    }
     // the dynamic-LDS limit is a per-function, per-device attribute: cheap, set on every first (function, device)
     struct Raised { const void *fn; int dev; };
     static std::atomic<int> n_raised{0};
@@ -1034,7 +1047,7 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
     }
     pl.geom.trace = g_pq_trace.load(std::memory_order_relaxed);
     void *argv[] = {(void *)&da, (void *)&lt, (void *)&pl.geom};
-    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kPqThreads), argv, pl.lds, stream);
+    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3((unsigned)pl.threads), argv, pl.lds, stream);
     return true;
 }
 
