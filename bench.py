@@ -177,6 +177,7 @@ def init_distributed(args):
             du.init_from_env(backend="gloo")
             return rank, 0, world
         torch.cuda.set_device(local_rank)
+        du.pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         du.init_from_env(backend="nccl", device=torch.device("cuda", local_rank))  # nccl == RCCL
     return rank, local_rank, world
 
@@ -245,43 +246,67 @@ class TrackSeeder:
         tracker.track_num = self.n
 
 
-def calibrate_association(model, frame, n_tracks, size, device):
+def calibrate_association(model, frame, n_tracks, size, device, spread=1.5, frac=0.5):
     """Give the association leg real work on random-init weights.  A default-initialised class head has bias
-    -4.6 (deformable_detr.py:60-61 of the reference): no query reaches detection_obj_score_thresh / track_obj_score_thresh
-    = 0.4, nothing is detected, every seeded track goes inactive.  Here the LAST class head's bias is shifted by one constant
-    so that the 1.5 n-th best query of frame 0 sits at 0.4 (about 1.5 n detections pass, the rest do not), and the n seeded
-    tracks are that frame's top-n outputs (boxes, scores, decoder embeddings): they come back as track queries with
-    realistic content, most of them survive, NMS and add_tracks have candidates every step.  Only a bias constant changes:
-    same kernels, same shapes, same arithmetic."""
-    from trackformer_amd.box_ops import box_cxcywh_to_xyxy
+    -4.6 (deformable_detr.py:60-61 of the reference) and a random-init decoder spreads the logits of its queries over a few
+    hundredths: no query reaches detection_obj_score_thresh / track_obj_score_thresh = 0.4, nothing is detected, every
+    seeded track goes inactive.  Here the "person" output (class 0, the only label the tracker keeps: tracker.py:340 of the
+    reference) of the LAST class head is rescaled and shifted by two constants, logit' = a * logit + b,
+    chosen on frame 0 IN THE TRACKING CONTEXT (n seeded track queries + the object queries) so that the scores' logits
+    have a standard deviation of `spread` and the fraction `frac` of all queries passes 0.4: about half of the seeded
+    tracks survive each step, about half of the object queries are detections that go through NMS against them and
+    through add_tracks.  The n seeded tracks are frame 0's top-n outputs (boxes, scores, decoder embeddings), so they
+    come back as track queries with realistic content.  Only two constants of one Linear change: same kernels, same
+    shapes, same arithmetic."""
+    from trackformer_amd.box_ops import box_cxcywh_to_xyxy, box_xyxy_to_cxcywh
     h, w = size
-    with torch.no_grad():
-        out, *_ = model(frame['img'].to(device), None, None)
-        logit = out['pred_logits'][0].max(-1).values
-        n_det = int(min(logit.numel() - 1, n_tracks + n_tracks // 2))
-        kth = float(logit.topk(n_det).values[-1])
-        delta = math.log(0.4 / 0.6) - kth + 1e-3
-        model.class_embed[-1].bias.add_(delta)
-        out, *_ = model(frame['img'].to(device), None, None)
+    wh = torch.tensor([w, h, w, h], dtype=torch.float32, device=device)
+    head = model.class_embed[-1]
+
+    def seeds_from(out):
         scores = out['pred_logits'][0].sigmoid().max(-1).values
         top = scores.topk(n_tracks).indices
-        pos = box_cxcywh_to_xyxy(out['pred_boxes'][0][top]) * torch.tensor([w, h, w, h], dtype=torch.float32, device=device)
-        return {"pos": pos.cpu(), "scores": scores[top].cpu(), "hs": out['hs_embed'][0][top].clone(),
-                "delta": round(delta, 4), "detections_above_0.4_frame0": int((scores > 0.4).sum())}
+        return {"pos": (box_cxcywh_to_xyxy(out['pred_boxes'][0][top]) * wh).cpu(), "scores": scores[top].cpu(),
+                "hs": out['hs_embed'][0][top].clone()}
+    with torch.no_grad():
+        img = frame['img'].to(device)
+        out, *_ = model(img, None, None)
+        seeds = seeds_from(out)
+        target = [{'track_query_boxes': box_xyxy_to_cxcywh(seeds["pos"].to(device)) / wh, 'image_id': torch.ones(1, dtype=torch.int64, device=device),
+                   'track_query_hs_embeds': seeds["hs"]}]
+        out, *_ = model(img, [dict(t) for t in target], None)
+        logit = out['pred_logits'][0][:, 0]
+        a = spread / max(float(logit.std()), 1e-6)
+        head.weight[0].mul_(a)
+        head.bias[0].mul_(a)
+        k = max(1, int(frac * logit.numel()))
+        kth = float((logit * a).topk(k).values[-1])
+        b = math.log(0.4 / 0.6) - kth + 1e-3
+        head.bias[0].add_(b)
+        out, *_ = model(img, None, None)     # the seeds' scores under the calibrated head
+        seeds = seeds_from(out)
+        out, *_ = model(img, [dict(t, track_query_hs_embeds=seeds["hs"]) for t in target], None)
+        scores = out['pred_logits'][0].sigmoid().max(-1).values
+    seeds.update(scale=round(a, 3), shift=round(b, 4), queries_above_0p4_frame0=int((scores > 0.4).sum()),
+                 track_queries_above_0p4_frame0=int((scores[:n_tracks] > 0.4).sum()))
+    return seeds
 
 
 def association_stats(model, post, seeder, frames, steps=4):
-    """What the association leg did in `steps` untimed steps of one (eager) tracker: tracks alive after the step, tracks
-    newly created by add_tracks, per step."""
+    """What the association leg did in `steps` untimed steps of one (eager) tracker, per step: seeded tracks that survived
+    (score threshold + track NMS), tracks newly initialised by add_tracks, tracks alive after the NMS of new against
+    existing."""
     tracker = build_tracker(model, post, use_graph=False)
-    alive, new = [], []
+    survived, created, alive = [], [], []
     with torch.no_grad():
         for i in range(steps):
             seeder.seed(tracker)
             tracker.step(frames[i % len(frames)])
+            survived.append(sum(1 for t in tracker.tracks if t.id < seeder.n))
+            created.append(tracker.track_num - seeder.n)
             alive.append(len(tracker.tracks))
-            new.append(tracker.track_num - seeder.n)
-    return {"seeded_tracks": seeder.n, "tracks_alive_after_step": alive, "new_tracks_per_step": new}
+    return {"seeded_tracks": seeder.n, "seeded_tracks_surviving": survived, "new_tracks_initialised": created,
+            "tracks_alive_after_step": alive}
 
 
 def measure_parity(device):
@@ -388,7 +413,10 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
     FUSED ENTRY the model calls (tf_msda_forward_fused_f32), on the sampling pattern of the
     perturbed-weight parity model, rotating over `sets` input sets (4 x 80 MB > the 256 MiB Infinity
     Cache, so every launch reads HBM).  `launches` launches are captured in one HIP graph on the launch
-    stream.  The default-initialised (`init`) and the wide (`local`) pattern are reported next to it."""
+    stream.  The default-initialised (`init`) and the wide (`local`) pattern are reported next to it.
+    The call carries ONE window-hint table (tf_msda_forward_fused_hint_f32), as a layer of the model does: every launch is
+    hinted by what the previous launch -- a different input set, i.e. "the previous frame" with independent noise -- measured.
+    `no_hints` is the same measurement through the unhinted entry."""
     if train:
         return measure_roofline_backward(device)
     from tools.bench_msda import CFG2_SHAPES, algorithmic_bytes
@@ -404,26 +432,33 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
                                          CFG2_SHAPES)
         torch.cuda.synchronize(device)
         stream.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(stream):
-            for value, qproj in inputs:
-                msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P)
-            graph = torch.cuda.CUDAGraph()
-            stream.synchronize()
-            with torch.cuda.graph(graph, stream=stream):
-                for i in range(launches):
-                    value, qproj = inputs[i % sets]
-                    msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P)
-            graph.replay()
-            stream.synchronize()
-            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            start.record(stream)
-            graph.replay()
-            end.record(stream)
-            end.synchronize()
-        us = start.elapsed_time(end) * 1e3 / launches
-        per_pattern[pattern] = {"avg_launch_us": round(us, 2), "GBps": round(alg / (us * 1e-6) / 1e9, 1),
-                                "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-        del graph, inputs
+        table = msda.window_hints(shapes, 1, S, M, D, L, S, P, device) if msda.WINDOW_HINTS else None
+        for hint in ((table, None) if table is not None else (None,)):
+            with torch.cuda.stream(stream):
+                for value, qproj in inputs:
+                    msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P, hint=hint)
+                graph = torch.cuda.CUDAGraph()
+                stream.synchronize()
+                with torch.cuda.graph(graph, stream=stream):
+                    for i in range(launches):
+                        value, qproj = inputs[i % sets]
+                        msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P, hint=hint)
+                graph.replay()
+                stream.synchronize()
+                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                start.record(stream)
+                graph.replay()
+                end.record(stream)
+                end.synchronize()
+            us = start.elapsed_time(end) * 1e3 / launches
+            row = {"avg_launch_us": round(us, 2), "GBps": round(alg / (us * 1e-6) / 1e9, 1),
+                   "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            if hint is table:
+                per_pattern[pattern] = row
+            else:
+                per_pattern[pattern]["no_hints"] = row
+            del graph
+        del inputs
     head = per_pattern["pert"]
     # HBM traffic of the same kernel / shape / pattern from the PMC counters: collected offline (rocprofv3
     # --pmc needs its own passes) and committed together with the method; see the file's "_how"
@@ -437,11 +472,12 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
             traffic = json.load(f)[kernel]["hbm_traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "hbm", "kernel": kernel + " via tf_msda_forward_fused_f32 (encoder call, Lq=S=22223)",
+    return {"bound": "hbm", "kernel": kernel + " via tf_msda_forward_fused%s_f32 (encoder call, Lq=S=22223)" % ("_hint" if msda.WINDOW_HINTS and D == 32 else ""),
             "achieved": head["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
             "traffic": traffic, "algorithmic_bytes": alg, "avg_launch_us": head["avg_launch_us"],
             "launches": launches, "input_sets": sets,
             "pattern": "pert (perturbed-weight model sampling), Infinity-Cache-cold",
+            "no_hints": head.get("no_hints"),
             "other_patterns": {k: v for k, v in per_pattern.items() if k != "pert"}}
 
 
@@ -692,7 +728,9 @@ def main():
         if seeds is not None and rank == 0:
             association = association_stats(model, post, TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds),
                                             make_frames(device, cfg["size"]))
-            association.update(class_bias_shift=seeds["delta"], detections_above_thresh_frame0=seeds["detections_above_0.4_frame0"])
+            association.update(class_head_scale=seeds["scale"], class_head_shift=seeds["shift"],
+                               queries_above_thresh_frame0=seeds["queries_above_0p4_frame0"],
+                               track_queries_above_thresh_frame0=seeds["track_queries_above_0p4_frame0"])
         if fused.split_linear_enabled() and not args.no_fp32_exact:
             # the same measurement with every matrix product in fp32 (hipBLASLt linears, library convolutions): the number a
             # reader who does not accept the 3-term bf16 products should take
@@ -719,8 +757,13 @@ def main():
             torch.cuda.empty_cache()
             cpu_baseline = measure_cpu_baseline(cfg, args.cpu_frames)
 
+    ranks = None
     if world > 1:
         from trackformer_amd import dist_utils as du
+        seen = du.ranks_seen(device)   # over the job's backend (RCCL): one entry per process
+        ranks = {"world": world, "backend": seen[0].get("backend"), "distinct_devices": len({(r.get("uuid"), r.get("pci_bus_id"), r.get("device")) for r in seen}),
+                 "distinct_processes": len({r["pid"] for r in seen}), "cpus_per_rank": [r.get("cpus") for r in seen],
+                 "devices": [r.get("name") for r in seen]}
         du.barrier()
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -756,7 +799,7 @@ def main():
                           if "segm" in post and os.environ.get("TF_LAZY_MASKS", "1") != "0" and not train else {})},
             "single_sequence_fps": None if single is None else round(single, 3),
             "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
-            "association": association, "parity": parity,
+            "association": association, "parity": parity, "ranks": ranks,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

@@ -64,8 +64,16 @@ def _worker(rank, world, port, out_dir):
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     from trackformer_amd import dist_utils as du
+    before = sorted(os.sched_getaffinity(0))
+    share = du.pin_rank_to_cpus(rank, world, max_threads=2)   # what bench.py does per rank at N > 1
+    if len(before) >= world:
+        assert share == before[len(before) * rank // world:len(before) * (rank + 1) // world]
+        assert sorted(os.sched_getaffinity(0)) == share and torch.get_num_threads() <= 2
     r, lr, w = du.init_from_env(backend="gloo")
     assert (r, w) == (rank, world) and du.is_distributed()
+    seen = du.ranks_seen()
+    assert [e["rank"] for e in seen] == list(range(world)) and len({e["pid"] for e in seen}) == world
+    assert all(e["backend"] == "gloo" for e in seen)
     assert du.shard_sequences(list(range(5))) == ([0, 2, 4] if rank == 0 else [1, 3])
     du.barrier()
     slow = du.max_over_ranks(1.0 + rank)          # rank 1 is "slower"

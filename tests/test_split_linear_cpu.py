@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 from tests import test_models_cpu as shared
-from tests.test_models_cpu import oracle_op  # noqa: F401  (fixture: the C oracle as the MSDeformAttn operator)
+from tests.test_models_cpu import host_op  # noqa: F401  (fixture: the product's host operator for CPU tensors)
 
 
 def _pieces(t):
@@ -49,7 +49,7 @@ def test_weight_pieces_reconstruct_the_weight_to_16_bits():
     assert fused._split_weight(w)[0] is not hi  # an in-place update invalidates the cache entry
 
 
-def test_split_product_linears_keep_model_and_tracker_parity(oracle_op, monkeypatch):
+def test_split_product_linears_keep_model_and_tracker_parity(host_op, monkeypatch):
     _patch(monkeypatch, passes=3)
     case = "cfg2_deformable_tracking"
     model, out, res, feats = shared.run_case(case, device="cpu")
@@ -59,7 +59,7 @@ def test_split_product_linears_keep_model_and_tracker_parity(oracle_op, monkeypa
     shared.compare_tracker_to_golden(False, tracker, rows, active, inactive, box_tol_px=0.05)
 
 
-def test_plain_bf16_linears_do_not(oracle_op, monkeypatch):
+def test_plain_bf16_linears_do_not(host_op, monkeypatch):
     _patch(monkeypatch, passes=1)
     case = "cfg2_deformable_tracking"
     model, out, res, feats = shared.run_case(case, device="cpu")

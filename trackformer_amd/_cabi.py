@@ -26,6 +26,13 @@ EXPORTED_SYMBOLS = (
     "tf_msda_backward_f64",
     "tf_msda_backward_f32_dshapes",
     "tf_msda_backward_f64_dshapes",
+    "tf_msda_window_hint_words",
+    "tf_msda_forward_fused_hint_f32",
+    "tf_msda_forward_hint_f32",
+    "tf_msda_forward_host_f32",
+    "tf_msda_forward_host_f64",
+    "tf_msda_backward_host_f32",
+    "tf_msda_backward_host_f64",
     # include/tf_fused.h
     "tf_bias_act_f32",
     "tf_add_layernorm_f32",
@@ -90,7 +97,20 @@ def lib():
             b = getattr(L, "tf_msda_backward_%s%s" % (suf, tail))
             b.restype = ci
             b.argtypes = [vp] * 8 + [ci] * 7 + [vp]
+    for suf in ("f32", "f64"):   # host tensors: no stream argument, synchronous
+        f = getattr(L, "tf_msda_forward_host_" + suf)
+        f.restype = ci
+        f.argtypes = [vp] * 5 + [ci] * 7
+        b = getattr(L, "tf_msda_backward_host_" + suf)
+        b.restype = ci
+        b.argtypes = [vp] * 8 + [ci] * 7
     L.tf_msda_forward_fused_f32.restype = ci
+    L.tf_msda_window_hint_words.restype = ctypes.c_int64
+    L.tf_msda_window_hint_words.argtypes = [vp] + [ci] * 7
+    L.tf_msda_forward_fused_hint_f32.restype = ci
+    L.tf_msda_forward_fused_hint_f32.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp] + [ci] * 7 + [vp, ctypes.c_int64, vp]
+    L.tf_msda_forward_hint_f32.restype = ci
+    L.tf_msda_forward_hint_f32.argtypes = [vp] * 5 + [ci] * 7 + [vp, ctypes.c_int64, vp]
     L.tf_msda_forward_fused_f32.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp] + [ci] * 7 + [vp]
     L.tf_bias_act_f32.restype = ci
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]

@@ -25,7 +25,7 @@ GFX_ARCH = "gfx950"
 
 # (output, [sources], extra flags)
 _TARGETS = [
-    ("libtf_msda.so", ["msda_hip.hip", "msda_pquad.hip", "fused_ops.hip", "linear_split.hip", "linear_stream.hip", "mha_core.hip", "ffn_fused.hip", "stem_conv.hip"], []),
+    ("libtf_msda.so", ["msda_hip.hip", "msda_pquad.hip", "fused_ops.hip", "linear_split.hip", "linear_stream.hip", "mha_core.hip", "ffn_fused.hip", "stem_conv.hip", "msda_host.cpp"], []),
 ]
 
 
@@ -85,7 +85,7 @@ def build_all(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=len(srcs)) as pool:
             list(pool.map(lambda so: _run([_hipcc()] + flags + ["-c", so[0], "-o", so[1]], verbose),
                           zip(src_paths, objs)))
-        _run([_hipcc(), "--offload-arch=" + GFX_ARCH, "-shared", "-fPIC"] + objs + ["-o", out], verbose)
+        _run([_hipcc(), "--offload-arch=" + GFX_ARCH, "-shared", "-fPIC", "-pthread"] + objs + ["-o", out], verbose)
         _stamp(out, key)
         built.append(out)
     built += _build_tools(force, verbose)

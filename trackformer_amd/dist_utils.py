@@ -32,6 +32,68 @@ def init_from_env(backend=None, device=None):
     return rank, local_rank, world
 
 
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _gpu_numa_cpus(local_rank):
+    """CPUs of the NUMA node the rank's GPU hangs off (sysfs), or None when the platform does not say."""
+    try:
+        props = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            return _parse_cpulist(f.read())
+    except (OSError, AttributeError, ValueError, RuntimeError, AssertionError):
+        return None
+
+
+def pin_rank_to_cpus(local_rank, local_world, max_threads=16):
+    """One process per GPU on one host: give every rank its own slice of the host cores, on its GPU's NUMA node where
+    sysfs knows it -- at 8 ranks x (tracker threads + MIOpen find + the matcher's scipy) an unpinned host oversubscribes
+    its cores and the slowest rank sets the job's time.  Caps torch's intra-op threads to the slice.  Returns the CPU list
+    (empty: the platform has no sched_setaffinity, nothing was changed)."""
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return []
+    allowed = sorted(os.sched_getaffinity(0))
+    node = _gpu_numa_cpus(local_rank) if torch.cuda.is_available() else None
+    pool = sorted(set(allowed) & node) if node else allowed
+    if node and len(pool) * 2 >= len(allowed) // max(1, local_world):
+        # ranks that share the node split it: rank order inside the node = local_rank order (even split assumed)
+        nodes = max(1, round(len(allowed) / max(1, len(pool))))
+        per_node = max(1, local_world // nodes)
+        k = local_rank % per_node
+        share = pool[len(pool) * k // per_node:len(pool) * (k + 1) // per_node]
+    else:
+        share = allowed[len(allowed) * local_rank // local_world:len(allowed) * (local_rank + 1) // local_world]
+    if not share:
+        return []
+    os.sched_setaffinity(0, share)
+    torch.set_num_threads(max(1, min(max_threads, len(share))))
+    return share
+
+
+def ranks_seen(device=None):
+    """What every rank of the job runs on, gathered over the job's own backend (RCCL for "nccl"): the N > 1 bench line
+    carries it so that a scaling run verifies itself (N distinct devices, one process each)."""
+    info = {"rank": dist.get_rank() if is_distributed() else 0, "pid": os.getpid(),
+            "backend": dist.get_backend() if is_distributed() else None, "cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    if device is not None and torch.cuda.is_available() and torch.device(device).type == "cuda":
+        props = torch.cuda.get_device_properties(device)
+        info.update(device=str(device), name=props.name, uuid=str(getattr(props, "uuid", "")),
+                    pci_bus_id=getattr(props, "pci_bus_id", None))
+    return gather_results(info)
+
+
 def is_distributed():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
