@@ -8,6 +8,7 @@ cfg2_full  reference `build_model('deformable','tracking','mot17')` (deformable_
 cfg4_full  the `multi_frame` model (hidden 288, 500 object + 300 track queries, 8 decoder levels,
            cfgs/train_multi_frame.yaml:1-5): previous frame, then current frame with prev_features
 tracker    reference `Tracker` (tracker.py:266-550) for 3 frames of 800x1333 with the cfg-2 model
+tracker64  the same for 64 frames, with the score margins to the thresholds recorded
 
 Weights and inputs are regenerated from seeds (tests/util_models, tests/util_weights) on the GPU box;
 the fixtures hold outputs only.  Large tensors are subsampled (encoder memory: every 89th token, last
@@ -65,16 +66,29 @@ def model_case(ref, case):
         os.path.getsize(path) // 1024), flush=True)
 
 
-def tracker_case(ref):
+def tracker_case(ref, n_frames=None):
+    """n_frames None: the 3-frame fixture; 64: SURVEY 8(d)'s "64-frame synthetic sequence for the track-ID parity check"
+    (full_tracker_cfg2_64.npz), which also records how far every score of every frame stays from the two score
+    thresholds -- a fixture whose decisions sit within the 1e-3 box / logit tolerance of a threshold would not pin ids."""
     model, post, args = um.build("cfg2_full", ref.models.build_model, config.make_args)
     model.tracking()
     cfg = config.tracker_cfg()
+    all_scores = []
+    bbox_post = post['bbox']
+
+    class Recording(torch.nn.Module):   # the tracker's own post-processor, with every frame's scores kept
+        def forward(self, outputs, sizes, *a, **k):
+            res = bbox_post(outputs, sizes, *a, **k)
+            all_scores.append(res[0]['scores'].detach().clone())
+            return res
+    post = dict(post, bbox=Recording())
     tracker = ref.tracker.Tracker(model, post, cfg, False)
     tracker.reset()
     active = []
     t0 = time.time()
+    frames = um.full_tracker_sequence() if n_frames is None else um.full_tracker_sequence(n_frames=n_frames)
     with torch.no_grad():
-        for blob in um.full_tracker_sequence():
+        for blob in frames:
             tracker.step(blob)
             active.append(len(tracker.tracks))
             print("  frame %d: %d active tracks (%.0f s)" % (len(active), active[-1], time.time() - t0),
@@ -84,9 +98,14 @@ def tracker_case(ref):
                       results[tid][f]['obj_ind']]
                      for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
     margin = float(np.abs(rows[:, 6] - cfg['track_obj_score_thresh']).min())
-    path = os.path.join(HERE, "full_tracker_cfg2.npz")
+    sc = torch.cat(all_scores).numpy().astype(np.float64)
+    thresholds = sorted({cfg['track_obj_score_thresh'], cfg['detection_obj_score_thresh'], cfg['reid_score_thresh']})
+    min_margin = float(min(np.abs(sc - t).min() for t in thresholds))
+    path = os.path.join(HERE, "full_tracker_cfg2.npz" if n_frames is None else "full_tracker_cfg2_%d.npz" % n_frames)
     np.savez_compressed(path, rows=rows, active_per_frame=np.array(active),
-                        num_tracks=np.int64(tracker.track_num), num_reids=np.int64(tracker.num_reids))
+                        num_tracks=np.int64(tracker.track_num), num_reids=np.int64(tracker.num_reids),
+                        min_score_margin=np.float64(min_margin), score_thresholds=np.array(thresholds))
+    print("smallest |score - threshold| over every query of every frame: %.3e (thresholds %s)" % (min_margin, thresholds))
     print("tracker: %d ids, active %s, smallest |score - threshold| of a kept track %.2e -> %s" % (
         tracker.track_num, active, margin, os.path.basename(path)), flush=True)
 
@@ -98,6 +117,8 @@ def main():
     for case in which:
         if case == "tracker":
             tracker_case(ref)
+        elif case.startswith("tracker") and case[7:].isdigit():   # e.g. tracker64
+            tracker_case(ref, int(case[7:]))
         else:
             model_case(ref, case)
 

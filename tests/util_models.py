@@ -84,8 +84,8 @@ def tracker_sequence(seed=11, img=None, orig=None, n_frames=None):
     return frames
 
 
-def full_tracker_sequence(seed=31):
-    return tracker_sequence(seed, FULL_IMG, FULL_ORIG, FULL_TRACKER_FRAMES)
+def full_tracker_sequence(seed=31, n_frames=None):
+    return tracker_sequence(seed, FULL_IMG, FULL_ORIG, n_frames or FULL_TRACKER_FRAMES)
 
 
 # extra Tracker configurations pinned against the reference (tracker.py:124-165 public detections,

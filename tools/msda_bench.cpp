@@ -321,16 +321,16 @@ int main(int argc, char **argv)
                                                      "load-gathers r1", "DMA r1 landed", "LDS gathers r1 + stores",
                                                      "(point loads issued)", "(level 0 bbox filed)"};
                     // msda_fwd_f32_pquad: first tile of every workgroup, then the end of its last tile
-                    static const char *pnames[14] = {"entry", "tile 0 loads issued", "tile 0 points+bbox", "B0", "B1 (L0 landed)",
+                    static const char *pnames[16] = {"entry", "tile 0 loads issued", "tile 0 points+bbox", "B0", "B1 (L0 landed)",
                                                      "(prefetch issued)", "L0 gathered", "B3 (L1-3 landed)", "stored",
                                                      "tile 1 points+bbox", "end of last tile", "B2 (L0 window free)", "DMA L1-3 issued",
-                                                     "DMA L1-3 landed (own)"};
+                                                     "DMA L1-3 landed (own)", "hinted: L0 DMA issued", "hinted: points+bbox done"};
                     const char **names = c.tiled == 3 ? pnames : qnames;
                     printf("  trace of %zu workgroups (us after the first workgroup's entry; 100 MHz clock):\n", nwg);
                     static const int qorder[14] = {0, 1, 12, 13, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-                    static const int porder[14] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 7, 8, 9, 10};
+                    static const int porder[16] = {0, 1, 2, 3, 14, 15, 4, 5, 6, 11, 12, 13, 7, 8, 9, 10};
                     const int *order = c.tiled == 3 ? porder : qorder;
-                    for (int oi = 0; oi < 14; ++oi) {
+                    for (int oi = 0; oi < (c.tiled == 3 ? 16 : 14); ++oi) {
                         const int i = order[oi];
                         std::vector<double> v, dur;
                         for (size_t w = 0; w < nwg; ++w)

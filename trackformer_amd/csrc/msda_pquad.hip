@@ -115,11 +115,15 @@ struct PqRefs {     // fused entry only: reference points of the pair's query, p
 // WIDE: the points are loaded as 16-byte pieces (lane j of a quad reads level j's four points: 2 + 1 loads per pass
 //     instead of 4 + 4, every cache line fetched once) and transposed inside the quad by DPP so that lane j ends
 //     up with point j of every level.  Needs 16-byte aligned rows (the host checks).
+// experiment knob of tools/build_ablations.py (never set in libtf_msda.so): waves per SIMD the two-pass kernel is compiled for
+#ifndef TF_PQUAD_NPASS2_WAVES
+#define TF_PQUAD_NPASS2_WAVES 3
+#endif
 template <int NPASS, int PF, int THREADS = kPqThreads>
 constexpr int pq_min_waves()
 {
     if (THREADS == 512) return 4;   // two workgroups of eight waves per CU
-    return PF == 2 ? (NPASS == 1 ? 3 : 2) : (NPASS == 1 ? 4 : NPASS == 2 ? 3 : 2);
+    return PF == 2 ? (NPASS == 1 ? 3 : 2) : (NPASS == 1 ? 4 : NPASS == 2 ? TF_PQUAD_NPASS2_WAVES : 2);
 }
 
 // 4 x 4 transpose across the lanes of a quad: in v[p] = element (row = this lane, column p), out v[l] = element
@@ -830,8 +834,10 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         phase_b(std::integral_constant<int, 0>{}, std::integral_constant<int, R0>{});
         if constexpr (HINT)
             if (hinted) {   // the points land while the window streams in; their boxes are filed for levels 1..3 / the hint
+                if (iter == 0) stamp(14);   // level 0's DMA issued
                 finish_points(cur, nref);
                 bbox(cur, par);
+                if (iter == 0) stamp(15);   // points finished, boxes filed
             }
         all_passes(std::integral_constant<int, (0x1 | TA_MASK)>{}, std::false_type{});   // by buffer loads
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA landed
@@ -921,7 +927,7 @@ std::atomic<unsigned long long *> g_pq_trace{nullptr};
 
 int pq_max_wgs(int npass, int pf)   // = pq_min_waves<NPASS, PF>(): workgroups per CU the register budget admits
 {
-    return pf == 2 ? (npass == 1 ? 3 : 2) : (npass == 1 ? 4 : npass == 2 ? 3 : 2);
+    return pf == 2 ? (npass == 1 ? 3 : 2) : (npass == 1 ? 4 : npass == 2 ? TF_PQUAD_NPASS2_WAVES : 2);
 }
 
 void pq_opts_init()
