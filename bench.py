@@ -138,9 +138,9 @@ def parse_args():
     ap.add_argument("--input-proj-fused", dest="input_proj_fused", action="store_true", default=None,
                     help="input_proj (1x1 convolution + GroupNorm) as split GEMM + own GroupNorm (the default)")
     ap.add_argument("--no-input-proj-fused", dest="input_proj_fused", action="store_false")
-    ap.add_argument("--sequences", type=int, default=4,
-                    help="independent video sequences tracked concurrently per GPU (one host thread "
-                         "and HIP stream each); frames of one sequence stay strictly sequential")
+    ap.add_argument("--sequences", type=int, default=3,
+                    help="independent video sequences interleaved per GPU (one HIP stream each, one host thread in all: "
+                         "Tracker.step_async / step_finish); frames of one sequence stay strictly sequential")
     args = ap.parse_args()
     train = CONFIGS[args.config]["kind"] == "train"
     if args.steps is None:
@@ -240,8 +240,10 @@ class TrackSeeder:
 
     def seed(self, tracker):
         from trackformer_amd.tracker import Track
-        tracker.tracks = [Track(self.pos[i], self.scores[i], i, self.hs[i], self.obj_ind[i])
-                          for i in range(self.n)]
+        rows = zip(self.pos.unbind(0), self.scores.unbind(0), self.hs.unbind(0), self.obj_ind.unbind(0))
+        tracker.tracks = [Track(p, sc, i, hs, ind) for i, (p, sc, hs, ind) in enumerate(rows)]
+        for i, t in enumerate(tracker.tracks):
+            t.__dict__["_obj_index"] = i
         tracker.inactive_tracks = []
         tracker.track_num = self.n
 
@@ -413,10 +415,7 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
     FUSED ENTRY the model calls (tf_msda_forward_fused_f32), on the sampling pattern of the
     perturbed-weight parity model, rotating over `sets` input sets (4 x 80 MB > the 256 MiB Infinity
     Cache, so every launch reads HBM).  `launches` launches are captured in one HIP graph on the launch
-    stream.  The default-initialised (`init`) and the wide (`local`) pattern are reported next to it.
-    The call carries ONE window-hint table (tf_msda_forward_fused_hint_f32), as a layer of the model does: every launch is
-    hinted by what the previous launch -- a different input set, i.e. "the previous frame" with independent noise -- measured.
-    `no_hints` is the same measurement through the unhinted entry."""
+    stream.  The default-initialised (`init`) and the wide (`local`) pattern are reported next to it."""
     if train:
         return measure_roofline_backward(device)
     from tools.bench_msda import CFG2_SHAPES, algorithmic_bytes
@@ -432,33 +431,26 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
                                          CFG2_SHAPES)
         torch.cuda.synchronize(device)
         stream.wait_stream(torch.cuda.current_stream(device))
-        table = msda.window_hints(shapes, 1, S, M, D, L, S, P, device) if msda.WINDOW_HINTS else None
-        for hint in ((table, None) if table is not None else (None,)):
-            with torch.cuda.stream(stream):
-                for value, qproj in inputs:
-                    msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P, hint=hint)
-                graph = torch.cuda.CUDAGraph()
-                stream.synchronize()
-                with torch.cuda.graph(graph, stream=stream):
-                    for i in range(launches):
-                        value, qproj = inputs[i % sets]
-                        msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P, hint=hint)
-                graph.replay()
-                stream.synchronize()
-                start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                start.record(stream)
-                graph.replay()
-                end.record(stream)
-                end.synchronize()
-            us = start.elapsed_time(end) * 1e3 / launches
-            row = {"avg_launch_us": round(us, 2), "GBps": round(alg / (us * 1e-6) / 1e9, 1),
-                   "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
-            if hint is table:
-                per_pattern[pattern] = row
-            else:
-                per_pattern[pattern]["no_hints"] = row
-            del graph
-        del inputs
+        with torch.cuda.stream(stream):
+            for value, qproj in inputs:
+                msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P)
+            graph = torch.cuda.CUDAGraph()
+            stream.synchronize()
+            with torch.cuda.graph(graph, stream=stream):
+                for i in range(launches):
+                    value, qproj = inputs[i % sets]
+                    msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P)
+            graph.replay()
+            stream.synchronize()
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record(stream)
+            graph.replay()
+            end.record(stream)
+            end.synchronize()
+        us = start.elapsed_time(end) * 1e3 / launches
+        per_pattern[pattern] = {"avg_launch_us": round(us, 2), "GBps": round(alg / (us * 1e-6) / 1e9, 1),
+                                "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        del graph, inputs
     head = per_pattern["pert"]
     # HBM traffic of the same kernel / shape / pattern from the PMC counters: collected offline (rocprofv3
     # --pmc needs its own passes) and committed together with the method; see the file's "_how"
@@ -472,12 +464,11 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
             traffic = json.load(f)[kernel]["hbm_traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"bound": "hbm", "kernel": kernel + " via tf_msda_forward_fused%s_f32 (encoder call, Lq=S=22223)" % ("_hint" if msda.WINDOW_HINTS and D == 32 else ""),
+    return {"bound": "hbm", "kernel": kernel + " via tf_msda_forward_fused_f32 (encoder call, Lq=S=22223)",
             "achieved": head["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
             "traffic": traffic, "algorithmic_bytes": alg, "avg_launch_us": head["avg_launch_us"],
             "launches": launches, "input_sets": sets,
             "pattern": "pert (perturbed-weight model sampling), Infinity-Cache-cold",
-            "no_hints": head.get("no_hints"),
             "other_patterns": {k: v for k, v in per_pattern.items() if k != "pert"}}
 
 
@@ -503,6 +494,8 @@ def measure_cpu_baseline(cfg, frames):
     """The same workload on the host: identical modules on CPU; MSDeformAttn = the reference's pure-CPU
     path restated (grid_sample), and, as a second figure, the C port of the kernels' arithmetic."""
     from trackformer_amd import msda
+    # every host core for the CPU leg (the inference set-up capped torch's intra-op threads for the association leg)
+    torch.set_num_threads(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     cores = torch.get_num_threads()
     cpu = torch.device("cpu")
     model, criterion, post, margs = build_model(cfg, cpu)
@@ -591,44 +584,39 @@ def timed_repeats(run_set, steps, world, device, min_seconds):
 
 
 def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None):
-    """cfg 2 / 4 / 5: `n_seq` trackers (own HIP stream + graph buffers each, shared weights) step through
-    synthetic frames; returns (elapsed, repeats)."""
-    import threading
+    """cfg 2 / 4 / 5: `n_seq` trackers (own HIP stream + graph buffers each, shared weights) step through synthetic frames;
+    returns (elapsed, repeats).  Several sequences are interleaved in ONE thread (Tracker.step_async / step_finish): while
+    one sequence's forward runs on the GPU the host does another one's association; frames of one sequence stay strictly
+    sequential.  (Round 2 used one thread per sequence: with the association leg at work they serialise on the GIL and
+    four threads are slower than one, profiles/r03_sequences_sweep.txt.)"""
     trackers = [build_tracker(model, post, use_graph=not args.no_graph) for _ in range(n_seq)]
     seeder = TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds)
     frames = make_frames(device, cfg["size"], host=args.host_frames)
     streams = [torch.cuda.Stream(device) for _ in range(n_seq)]
-    stagger = [0.0]
-
-    def run(seq, n):
-        torch.cuda.set_device(device)
-        with torch.no_grad(), torch.cuda.stream(streams[seq]):
-            if stagger[0]:   # de-phase the sequences: one does host-side association while the
-                time.sleep(seq * stagger[0])   # other's forward occupies the GPU
-            for i in range(n):
-                seeder.seed(trackers[seq])
-                trackers[seq].step(frames[(seq + i) % len(frames)])
-            streams[seq].synchronize()
-
-    # warm-up sequentially (MIOpen find mode and the host-side caches are filled here), then time
-    warm_per_seq = max(4, (args.warmup + n_seq - 1) // n_seq)   # >= 4: both HIP graphs of a multi-frame model
-    for seq in range(n_seq):
-        run(seq, warm_per_seq)
-    torch.cuda.synchronize()
-    tw = time.perf_counter()
-    run(0, 3)
-    stagger[0] = (time.perf_counter() - tw) / 3 / n_seq if n_seq > 1 else 0.0
 
     def run_set(steps):
         per_seq = [steps // n_seq + (1 if i < steps % n_seq else 0) for i in range(n_seq)]
-        if n_seq == 1:
-            run(0, per_seq[0])
-            return
-        threads = [threading.Thread(target=run, args=(seq, per_seq[seq])) for seq in range(n_seq)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        handles, issued, done = [None] * n_seq, [0] * n_seq, [0] * n_seq
+        torch.cuda.set_device(device)
+        with torch.no_grad():
+            while any(done[s] < per_seq[s] for s in range(n_seq)):
+                for s in range(n_seq):
+                    with torch.cuda.stream(streams[s]):
+                        if handles[s] is not None:
+                            trackers[s].step_finish(handles[s])
+                            handles[s] = None
+                            done[s] += 1
+                        if issued[s] < per_seq[s]:
+                            seeder.seed(trackers[s])
+                            handles[s] = trackers[s].step_async(frames[(s + issued[s]) % len(frames)])
+                            issued[s] += 1
+        for st in streams:
+            st.synchronize()
+
+    # warm-up (MIOpen find mode and the host-side caches are filled here; >= 4 steps per sequence: both HIP graphs of a
+    # multi-frame model), then time
+    run_set(n_seq * max(4, (args.warmup + n_seq - 1) // n_seq))
+    torch.cuda.synchronize()
     return timed_repeats(run_set, args.steps, world, device, args.min_seconds)
 
 
@@ -722,9 +710,15 @@ def main():
         if not args.no_calibration and cfg["tracks"] > 0:
             seeds = calibrate_association(model, make_frames(device, cfg["size"], n=1)[0], cfg["tracks"], cfg["size"], device)
         elapsed, reps = run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds)
+        multi = None
         if n_seq > 1 and not args.no_single_sequence:
             e1, r1 = run_tracking(cfg, args, device, world, model, post, margs, 1, seeds)
             single = args.steps * r1 * world / e1
+            multi = args.steps * reps * world / elapsed
+            if e1 / r1 < elapsed / reps:
+                # the headline is the faster set-up, the other one is reported next to it (same K steps, same barriers; the
+                # all-reduced times are identical on every rank)
+                elapsed, reps, n_seq = e1, r1, 1
         if seeds is not None and rank == 0:
             association = association_stats(model, post, TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds),
                                             make_frames(device, cfg["size"]))
@@ -798,6 +792,7 @@ def main():
                        **({"mask_head": "lazy: evaluated for the surviving tracks' queries only (Tracker default)"}
                           if "segm" in post and os.environ.get("TF_LAZY_MASKS", "1") != "0" and not train else {})},
             "single_sequence_fps": None if single is None else round(single, 3),
+            "multi_sequence_fps": None if multi is None else {"sequences_per_gpu": max(1, args.sequences), "value": round(multi, 3)},
             "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
             "association": association, "parity": parity, "ranks": ranks,
             "roofline": roofline, "cpu_baseline": cpu_baseline,

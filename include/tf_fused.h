@@ -186,6 +186,14 @@ int tf_mha_core_f32(const float *q, const float *k, const float *v, float *out, 
                     int N, int Lq, int Lk, int H, int D, int ldq, int ldk, int ldv, int ldo, float scale,
                     void *stream);
 
+/*
+ * Greedy non-maximum suppression on HOST boxes (all pointers host; synchronous): torchvision.ops.nms semantics, which the
+ * reference's tracker calls twice per frame (tracker.py:399,495).  boxes [n, 4] xyxy, scores [n]; boxes are visited in
+ * stable descending-score order; keep [n] receives the indices of the kept boxes in that order, *n_keep their number.
+ * IoU arithmetic: fp32, inter / (area_i + area_j - inter), as box_ops.box_iou.
+ */
+int tf_nms_host_f32(const float *boxes, const float *scores, int n, float iou_threshold, int64_t *keep, int *n_keep);
+
 #ifdef __cplusplus
 }
 #endif

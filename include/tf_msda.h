@@ -139,26 +139,6 @@ int tf_msda_forward_fused_f32(const float *value, const int64_t *shapes_hw_host,
                               int L, int Lq, int P, void *stream);
 
 /*
- * The two forward entry points above with WINDOW HINTS (performance only; results never depend on the table).
- * Encoder-shaped calls (Lq == S) run a kernel that stages data-dependent windows of the feature pyramid in LDS.  Which
- * window a tile needs is only known once its sampling points have been read; a hint table remembers, per tile and
- * head, the level-0 window the PREVIOUS call with this table needed, so that the staging of the next call's tile can
- * start together with its point loads (consecutive frames of a video / consecutive calls of one layer sample alike).
- * Points outside a hinted window take the exact path; entries that were never written (a zero-initialised table) make
- * their tile run the unhinted chain.  One table per call site that is called with similar inputs (a layer of a model);
- * device memory, 16-byte aligned, tf_msda_window_hint_words() 32-bit words (0: this call shape uses no hints, pass NULL),
- * zero-initialised by the caller once, read and rewritten by every call.  Concurrent calls on one table are safe
- * (entries are single 16-byte words).  NULL / too small a table: same as the unhinted entry points.
- */
-int64_t tf_msda_window_hint_words(const int64_t *shapes_hw_host, int N, int S, int M, int D, int L, int Lq, int P);
-int tf_msda_forward_fused_hint_f32(const float *value, const int64_t *shapes_hw_host, const float *ref_points, int ref_dim,
-                                   const float *qproj, int ld, int off_col, int logit_col, float *out, int N, int S,
-                                   int M, int D, int L, int Lq, int P, int32_t *hint, int64_t hint_words, void *stream);
-int tf_msda_forward_hint_f32(const float *value, const int64_t *shapes_hw_host, const float *loc, const float *attn,
-                             float *out, int N, int S, int M, int D, int L, int Lq, int P, int32_t *hint,
-                             int64_t hint_words, void *stream);
-
-/*
  * Backward.  Writes all three gradients; grad_value is zero-filled on `stream` by the library before
  * accumulation (reference: at::zeros_like, cu:119-121), grad_loc / grad_attn are fully overwritten.
  * grad_value accumulation uses hardware floating-point atomics, so its summation order (and therefore

@@ -43,12 +43,6 @@ def lib():
             b.argtypes = [vp] * 8 + [ci] * 7 + [vp]
     L.tf_msda_forward_fused_f32.restype = ci
     L.tf_msda_forward_fused_f32.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp] + [ci] * 7 + [vp]
-    L.tf_msda_window_hint_words.restype = ctypes.c_int64
-    L.tf_msda_window_hint_words.argtypes = [vp] + [ci] * 7
-    L.tf_msda_forward_fused_hint_f32.restype = ci
-    L.tf_msda_forward_fused_hint_f32.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp] + [ci] * 7 + [vp, ctypes.c_int64, vp]
-    L.tf_msda_forward_hint_f32.restype = ci
-    L.tf_msda_forward_hint_f32.argtypes = [vp] * 5 + [ci] * 7 + [vp, ctypes.c_int64, vp]
     L.tf_bias_act_f32.restype = ci
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_add_layernorm_f32.restype = ci
@@ -115,13 +109,7 @@ def _c(a, dt):
     return np.ascontiguousarray(a, dtype=dt)
 
 
-def window_hint_words(shapes, N, S, M, D, L, Lq, P):
-    shapes = _c(shapes, np.int64)
-    return int(lib().tf_msda_window_hint_words(_p(shapes), N, S, M, D, L, Lq, P))
-
-
-def msda_forward(value, shapes, loc, attn, dshapes=False, hint=None):
-    """hint: int32 array (tf_msda_window_hint_words entries), read and rewritten in place (fp32, host shapes only)."""
+def msda_forward(value, shapes, loc, attn, dshapes=False):
     dt = value.dtype
     suf = "f32" if dt == np.float32 else "f64"
     value, loc, attn = _c(value, dt), _c(loc, dt), _c(attn, dt)
@@ -129,12 +117,6 @@ def msda_forward(value, shapes, loc, attn, dshapes=False, hint=None):
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = loc.shape
     out = np.full((N, Lq, M * D), np.nan, dt)
-    if hint is not None:
-        assert dt == np.float32 and not dshapes and hint.dtype == np.int32 and hint.flags.c_contiguous
-        rc = lib().tf_msda_forward_hint_f32(_p(value), _p(shapes), _p(loc), _p(attn), _p(out), N, S, M, D, L, Lq, P, _p(hint), hint.size, None)
-        if rc != 0:
-            raise RuntimeError("tf_msda_forward_hint_f32: status %d" % rc)
-        return out
     fn = getattr(lib(), "tf_msda_forward_%s%s" % (suf, "_dshapes" if dshapes else ""))
     rc = fn(_p(value), _p(shapes), _p(loc), _p(attn), _p(out), N, S, M, D, L, Lq, P, None)
     if rc != 0:
@@ -142,7 +124,7 @@ def msda_forward(value, shapes, loc, attn, dshapes=False, hint=None):
     return out
 
 
-def msda_forward_fused(value, shapes, ref, qproj, M, L, P, off_col=0, logit_col=None, hint=None):
+def msda_forward_fused(value, shapes, ref, qproj, M, L, P, off_col=0, logit_col=None):
     value, ref, qproj = _c(value, np.float32), _c(ref, np.float32), _c(qproj, np.float32)
     shapes = _c(shapes, np.int64)
     N, S, _, D = value.shape
@@ -151,13 +133,6 @@ def msda_forward_fused(value, shapes, ref, qproj, M, L, P, off_col=0, logit_col=
     if logit_col is None:
         logit_col = 2 * M * L * P
     out = np.full((N, Lq, M * D), np.nan, np.float32)
-    if hint is not None:
-        assert hint.dtype == np.int32 and hint.flags.c_contiguous
-        rc = lib().tf_msda_forward_fused_hint_f32(_p(value), _p(shapes), _p(ref), ref.shape[-1], _p(qproj), ld, off_col, logit_col,
-                                                  _p(out), N, S, M, D, L, Lq, P, _p(hint), hint.size, None)
-        if rc != 0:
-            raise RuntimeError("tf_msda_forward_fused_hint_f32: status %d" % rc)
-        return out
     rc = lib().tf_msda_forward_fused_f32(_p(value), _p(shapes), _p(ref), ref.shape[-1], _p(qproj), ld, off_col, logit_col,
                                          _p(out), N, S, M, D, L, Lq, P, None)
     if rc != 0:

@@ -134,6 +134,49 @@ def main():
             reid, tracker.track_num, active.tolist(), [len(i) for _, i in per_frame],
             tracker.num_reids, os.path.basename(path)))
     tracker_variants(ref)
+    mask_tracker(ref)
+
+
+def mask_tracker(ref, frames=3):
+    """cfg-5 path: the reference Tracker (tracker.py:266-550, masks: :315-319, :521-532) on the mask-head model for three
+    synthetic frames -> tracker_cfg5_masks.npz: ids / frames / boxes / scores / source queries and, per result row, the
+    number of mask pixels the track owns (the per-pixel argmax over random-weight tracks is not a stable quantity to pin
+    pixel by pixel; its area per track is compared with a tolerance)."""
+    model, post, args = um.build("cfg5_segm_tracking", ref.models.build_model, config.make_args)
+    model.tracking()
+
+    class ThreeArgs:
+        """The reference's Tracker calls obj_detector(img, target, prev_features) (tracker.py:305) but its DETRSegmBase.forward
+        takes (samples, targets) only (detr_segmentation.py:41): the unmodified pair cannot run.  The third
+        argument is not used by this single-frame model (multi_frame_attention off); this adapter drops it and forwards
+        everything else."""
+        def __init__(self, m):
+            self.m = m
+
+        def __call__(self, img, target=None, prev_features=None):
+            return self.m(img, target)
+
+        def __getattr__(self, name):
+            return getattr(self.m, name)
+    tracker = ref.tracker.Tracker(ThreeArgs(model), post, config.tracker_cfg(), False)
+    tracker.reset()
+    active = []
+    with torch.no_grad():
+        for blob in um.tracker_sequence()[:frames]:
+            tracker.step(blob)
+            active.append(len(tracker.tracks))
+    results = tracker.get_results()
+    rows, areas = [], []
+    for tid in sorted(results):
+        for f in sorted(results[tid]):
+            r = results[tid][f]
+            rows.append([tid, f, *r['bbox'].tolist(), float(r['score']), r['obj_ind']])
+            areas.append(int(np.asarray(r['mask']).sum()))
+    path = os.path.join(HERE, "tracker_cfg5_masks.npz")
+    np.savez_compressed(path, rows=np.array(rows, dtype=np.float64), mask_areas=np.array(areas), active_per_frame=np.array(active),
+                        num_tracks=np.int64(tracker.track_num), mask_shape=np.array(np.asarray(r['mask']).shape))
+    print("mask tracker: %d track ids, active %s, %d rows, mask pixels owned %d -> %s" % (
+        tracker.track_num, active, len(rows), sum(areas), os.path.basename(path)))
 
 
 def tracker_variants(ref):
@@ -183,6 +226,11 @@ if __name__ == "__main__":
                             grad_norms=np.array([grads[k] for k in um.TRAIN_MASK_GRAD_KEYS]),
                             num_grads=np.int64(len(grads)))
         print("mask train step: total loss %.6f, losses %s" % (total, sorted(loss_dict)))
+        sys.exit(0)
+    if sys.argv[1:] == ["mask_tracker"]:
+        ref_ = reference_models.load()
+        torch.set_num_threads(8)
+        mask_tracker(ref_)
         sys.exit(0)
     if sys.argv[1:] == ["tracker_variants"]:
         ref_ = reference_models.load()

@@ -128,3 +128,21 @@ def test_resnet50_layout_matches_the_published_definition():
         out = getter(torch.zeros(1, 3, 64, 96))
     assert list(out) == ["0", "1", "2", "3"]
     assert [tuple(v.shape[1:]) for v in out.values()] == [(256, 16, 24), (512, 8, 12), (1024, 4, 6), (2048, 2, 3)]
+
+
+def test_host_nms_in_the_library_equals_the_matrix_sweep():
+    """box_ops.nms on host boxes runs tf_nms_host_f32 (csrc/msda_host.cpp); nms_keep_mask is the K x K IoU matrix + sweep it
+    replaced in the tracker's association leg: same kept set, same order, incl. +inf scores, ties, degenerate boxes."""
+    g = torch.Generator().manual_seed(0)
+    for n, thr in [(1, 0.5), (7, 0.3), (250, 0.9), (250, 0.5), (400, 0.1)]:
+        c = torch.rand(n, 2, generator=g) * 100
+        wh = torch.rand(n, 2, generator=g) * 30
+        boxes = torch.cat([c - wh / 2, c + wh / 2], 1)
+        boxes[::17, 2:] = boxes[::17, :2]                      # zero-area boxes: IoU 0 / 0 = NaN never suppresses
+        boxes[5 % n] = boxes[0]                                # an exact duplicate
+        scores = torch.rand(n, generator=g)
+        scores[::11] = float("inf")                            # tracker.py:493: existing tracks win
+        scores[3 % n] = scores[2 % n]                          # a tie keeps the input order
+        order = torch.sort(scores, descending=True, stable=True)[1]
+        expect = order[box_ops.nms_keep_mask(boxes, scores, thr)[order]]
+        assert box_ops.nms(boxes, scores, thr).tolist() == expect.tolist()

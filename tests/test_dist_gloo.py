@@ -78,7 +78,7 @@ def _worker(rank, world, port, out_dir):
     du.barrier()
     slow = du.max_over_ranks(1.0 + rank)          # rank 1 is "slower"
     total = du.sum_over_ranks(10.0)
-    merged = du.track_sequences(_make_tracker, _make_sequences(), "cpu")
+    merged = du.track_sequences(_make_tracker, _make_sequences(), "cpu", interleave=2)   # two sequences in flight per rank
     du.barrier()
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), _flatten(merged))
     with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:

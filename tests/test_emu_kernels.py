@@ -142,9 +142,8 @@ def _fused_case(shapes, N, D, seed, M=8, P=4, spread=2.0):
 
 
 PQUAD_VARIANTS = [dict(), dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pquad_wg_per_cu=2),
-                  dict(pquad_prefetch=2, pquad_wg_per_cu=2), dict(pquad_wide=0), dict(pquad_lds_kb=24),
-                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1),
-                  dict(pquad_threads=512, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78)]
+                  dict(pquad_wide=0), dict(pquad_lds_kb=24),
+                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items()) or "default"
@@ -165,50 +164,6 @@ def test_persistent_encoder_kernel_variants(opts):
         assert emu_lib.stats()["lds_dma_bytes"] > 0 and emu_lib.stats()["divergent_ops"] == 0
     finally:
         emu_lib.set_options(**prev)
-
-
-@pytest.mark.parametrize("shapes,N,mode", [(PYR, 1, "local"), ([(20, 31), (10, 16), (5, 8), (3, 4)], 2, "local"), (PYR, 1, "uniform"),
-                                           ([(19, 23)], 1, "local"), ([(15, 22), (8, 11), (4, 6)], 1, "border")],
-                         ids=["pyramid", "n2", "uniform_fallbacks", "one_level", "three_levels_border"])
-def test_hinted_encoder_kernel_results_never_depend_on_the_hint_table(shapes, N, mode):
-    """msda_fwd_f32_pquad<..., HINT> (tf_msda_forward_hint_f32 / _fused_hint_f32): level 0's window of a tile comes from what
-    the previous call on the same table measured.  Whatever the table holds -- zeros (never written: the exact chain), the
-    previous call's boxes (the hinted chain), the boxes of DIFFERENT inputs (points outside the hinted window take the exact
-    buffer-load path), garbage -- the output is the unhinted kernel's: bit for bit while every point lies inside its hinted
-    window, and up to the fp32 summation order otherwise (a point outside its window is added after the staged ones of its
-    level instead of in point order; 1e-6 here) -- plain and fused entry."""
-    shp = np.array(shapes, np.int64)
-    L = len(shapes)
-    S = sum(h * w for h, w in shapes)
-    words = emu_lib.window_hint_words(shp, N, S, 8, 32, L, S, 4)
-    assert words > 0 and words % 4 == 0
-    assert emu_lib.window_hint_words(shp, N, S, 8, 32, L, S - 1, 4) == 0     # not encoder-shaped: no hints
-    value, loc, attn = encoder_inputs(shapes, mode, N=N, seed=31)
-    value2, loc2, attn2 = encoder_inputs(shapes, mode, N=N, seed=32)        # "the next frame"
-    base, base2 = emu_lib.msda_forward(value, shp, loc, attn), emu_lib.msda_forward(value2, shp, loc2, attn2)
-    np.testing.assert_allclose(base, msda_oracle.msda_forward(value, shp, loc, attn, nthreads=4), atol=1e-5, rtol=1e-4)
-    hint = np.zeros(words, np.int32)
-    assert np.array_equal(emu_lib.msda_forward(value, shp, loc, attn, hint=hint), base)       # cold table
-    assert np.all(hint.reshape(-1, 4)[:, 0] != 0), "every item files its level-0 box"
-    first = hint.copy()
-    assert np.array_equal(emu_lib.msda_forward(value, shp, loc, attn, hint=hint), base)       # hinted, same inputs
-    assert np.array_equal(hint, first), "the same points give the same boxes"
-    got2 = emu_lib.msda_forward(value2, shp, loc2, attn2, hint=hint)                          # hinted by other inputs' boxes
-    np.testing.assert_allclose(got2, base2, atol=2e-6, rtol=1e-5)
-    rng = np.random.default_rng(5)
-    junk = rng.integers(-2 ** 31, 2 ** 31 - 1, words, dtype=np.int64).astype(np.int32)
-    np.testing.assert_allclose(emu_lib.msda_forward(value, shp, loc, attn, hint=junk), base, atol=2e-6, rtol=1e-5)   # garbage
-    assert np.array_equal(junk, first), "... and is replaced by the measured boxes"
-    small = np.zeros(words - 4, np.int32)                                                     # too small a table: ignored
-    assert np.array_equal(emu_lib.msda_forward(value, shp, loc, attn, hint=small), base) and not small.any()
-    # fused entry
-    fvalue, refp, qproj, floc, fattn = _fused_case(shapes, N, 32, seed=33)
-    fbase = emu_lib.msda_forward_fused(fvalue, shp, refp, qproj, 8, L, 4)
-    fh = np.zeros(words, np.int32)
-    for _ in range(3):
-        assert np.array_equal(emu_lib.msda_forward_fused(fvalue, shp, refp, qproj, 8, L, 4, hint=fh), fbase)
-    np.testing.assert_allclose(emu_lib.msda_forward_fused(fvalue, shp, refp, qproj, 8, L, 4, hint=hint), fbase,
-                               atol=2e-6, rtol=1e-5)   # the plain call's boxes
 
 
 @pytest.mark.parametrize("shapes,N", [(PYR, 1), ([(15, 22), (8, 11), (4, 6)], 2), ([(19, 23)], 1)],

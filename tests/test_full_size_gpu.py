@@ -149,6 +149,41 @@ def test_full_size_tracker_track_ids_bit_exact(dev, models, setup):
     np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
 
 
+def test_full_size_tracker_64_frames_track_ids_bit_exact(dev, models):
+    """a 64-frame 800x1333 sequence through Tracker.step in the bench set-up (tuned runtime, HIP graphs with
+    the bucketed track-query count, every default route) against the reference's own Tracker on CPU
+    (tests/golden/make_golden_full.py tracker64): 9 514 track ids over 64 frames, up to 1 980 simultaneous track queries.
+    The fixture records that no score of any query in any frame comes closer than `min_score_margin` to a score threshold
+    -- 0.35 here, against the 1e-3 logit tolerance: no decision sits on a knife edge."""
+    from trackformer_amd import config, fused, runtime
+    from trackformer_amd.graphed import GraphedDetector
+    from trackformer_amd.tracker import Tracker
+    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2_64.npz"))
+    assert float(z["min_score_margin"]) > 1e-2
+    model, post, args = models("cfg2_full")
+    runtime.configure_inference(verbose=False)
+    prev_split = fused.set_split_linear(True)
+    try:
+        tracker = Tracker(GraphedDetector(model), post, config.tracker_cfg(), False)
+        tracker.reset()
+        active = []
+        with torch.no_grad():
+            for blob in um.full_tracker_sequence(n_frames=64):
+                tracker.step(dict(blob, img=blob['img'].to(dev)))
+                active.append(len(tracker.tracks))
+    finally:
+        fused.set_split_linear(prev_split)
+    results = tracker.get_results()
+    rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']), results[tid][f]['obj_ind']]
+                     for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
+    assert z["active_per_frame"].tolist() == active
+    assert int(z["num_tracks"]) == tracker.track_num and int(z["num_reids"]) == tracker.num_reids
+    assert rows.shape == z["rows"].shape
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])   # id, frame, source query
+    np.testing.assert_allclose(rows[:, 2:6], z["rows"][:, 2:6], atol=1e-3 * max(um.FULL_ORIG))
+    np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
+
+
 # ------------------------------------------------------------------ the round-3 routes (defaults since their hardware validation:
 # profiles/r03_optin_pytest_optin.txt).  "graph_split_linear" above runs ALL of them at once; below each family is also
 # switched off on its own (the off-switches stay honest) and unit-tested against PyTorch.

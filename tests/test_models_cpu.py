@@ -192,6 +192,32 @@ def run_mask_tracker(device="cpu", frames=3, lazy_masks=False):
     return tracker.get_results()
 
 
+def compare_mask_tracker_to_golden(results, box_tol_px=0.05, area_tol=0.02):
+    """results of run_mask_tracker against tests/golden/tracker_cfg5_masks.npz (the reference's own Tracker + mask head +
+    PostProcessSegm on CPU, tests/golden/make_golden_models.py mask_tracker): ids / frames / source queries exact, boxes and
+    scores within tolerance, the number of mask pixels every track owns within `area_tol` of the image (the per-pixel argmax
+    over random-weight tracks near 0.5 is compared by area, not pixel by pixel)."""
+    z = np.load(os.path.join(GOLDEN, "tracker_cfg5_masks.npz"))
+    rows, areas = [], []
+    for tid in sorted(results):
+        for f in sorted(results[tid]):
+            r = results[tid][f]
+            rows.append([tid, f, *r['bbox'].tolist(), float(r['score']), r['obj_ind']])
+            areas.append(int(np.asarray(r['mask']).sum()))
+            assert list(np.asarray(r['mask']).shape) == z["mask_shape"].tolist()
+    rows = np.array(rows, dtype=np.float64)
+    assert rows.shape == z["rows"].shape
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
+    np.testing.assert_allclose(rows[:, 2:6], z["rows"][:, 2:6], atol=box_tol_px)
+    np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
+    n_px = int(np.prod(z["mask_shape"]))
+    assert np.abs(np.array(areas) - z["mask_areas"]).max() <= area_tol * n_px, (areas, z["mask_areas"].tolist())
+
+
+def test_tracker_with_mask_head_matches_reference(host_op):
+    compare_mask_tracker_to_golden(run_mask_tracker())
+
+
 def test_tracker_with_mask_head_produces_per_track_masks(host_op):
     results = run_mask_tracker()
     assert results

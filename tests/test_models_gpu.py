@@ -40,25 +40,13 @@ def test_tracker_variants_track_ids_bit_exact(dev, name):
     shared.compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.64)
 
 
-def test_tracker_with_mask_head_matches_cpu_path(dev, monkeypatch):
-    """cfg-5 path (mask head + Tracker) on the GPU against the same modules on the CPU with the C
-    oracle as operator: same track ids in the same frames, same boxes.  (The mask numerics are pinned
-    by the model-level golden; the per-pixel argmax over ~130 random-weight tracks whose probabilities
-    all sit near 0.5 is not a stable quantity to compare.)"""
-    import numpy as np
-    gpu = shared.run_mask_tracker(device=dev)
-    from oracle import msda_oracle
-    from trackformer_amd import msda
-    monkeypatch.setattr(msda, "MSDeformAttnFunction", msda_oracle.make_torch_function())
-    cpu = shared.run_mask_tracker(device="cpu")
-    assert sorted(gpu) == sorted(cpu)
-    for tid in cpu:
-        assert sorted(gpu[tid]) == sorted(cpu[tid])
-        for f in cpu[tid]:
-            a, b = gpu[tid][f], cpu[tid][f]
-            assert a['obj_ind'] == b['obj_ind']
-            np.testing.assert_allclose(a['bbox'], b['bbox'], atol=0.64)
-            assert a['mask'].shape == b['mask'].shape and a['mask'].dtype == b['mask'].dtype
+@pytest.mark.parametrize("lazy", [False, True], ids=["full_head", "lazy_head"])
+def test_tracker_with_mask_head_matches_reference(dev, lazy):
+    """cfg-5 path (mask head + Tracker) on the GPU against the reference's own Tracker / mask head / PostProcessSegm on CPU
+    (tests/golden/tracker_cfg5_masks.npz): same track ids in the same frames from the same queries, boxes, scores, and the
+    mask area every track owns.  Both mask-head schedules: inside the detector for every query, and the Tracker's default
+    (for the surviving tracks' queries only)."""
+    shared.compare_mask_tracker_to_golden(shared.run_mask_tracker(device=dev, lazy_masks=lazy), box_tol_px=0.64)
 
 
 def test_lazy_mask_head_gives_the_same_tracks(dev):
@@ -86,7 +74,9 @@ def test_lazy_mask_head_gives_the_same_tracks(dev):
 
 
 def test_tracker_step_does_one_device_to_host_sync_per_frame(dev):
-    """The association logic runs on one packed host copy per frame (tracker)."""
+    """The association logic runs on ONE packed host copy per frame (tracker): step_async enqueues it into pinned
+    memory without waiting, step_finish waits for its event -- the frame's only synchronisation (any implicit one raises
+    under the sync debug mode, no .cpu() of a device tensor is left)."""
     from trackformer_amd import config, factory
     from trackformer_amd.tracker import Tracker
     model, post, args = um.build("cfg2_deformable_tracking", factory.build_model,
@@ -98,26 +88,29 @@ def test_tracker_step_does_one_device_to_host_sync_per_frame(dev):
     with torch.no_grad():
         tracker.step(frames[0])
         torch.cuda.synchronize()
-        torch.cuda.set_sync_debug_mode("error")   # any further implicit sync raises
+        torch.cuda.set_sync_debug_mode("error")   # any implicit sync raises
+        orig_cpu, orig_sync = torch.Tensor.cpu, torch.cuda.Event.synchronize
+        cpu_calls, event_syncs = [], []
         try:
-            orig_cpu = torch.Tensor.cpu
-            calls = []
-
             def counting_cpu(self, *a, **k):
                 if self.is_cuda:
-                    calls.append(tuple(self.shape))
-                    torch.cuda.set_sync_debug_mode("default")
-                    try:
-                        return orig_cpu(self, *a, **k)
-                    finally:
-                        torch.cuda.set_sync_debug_mode("error")
+                    cpu_calls.append(tuple(self.shape))
                 return orig_cpu(self, *a, **k)
+
+            def counting_sync(self):
+                event_syncs.append(1)
+                return orig_sync(self)
             torch.Tensor.cpu = counting_cpu
-            tracker.step(frames[1])
+            torch.cuda.Event.synchronize = counting_sync
+            handle = tracker.step_async(frames[1])
+            assert not event_syncs and not cpu_calls          # nothing waited for yet
+            assert handle["host"].is_pinned() and handle["packed_dev"].shape[1] == 6
+            tracker.step_finish(handle)
         finally:
             torch.Tensor.cpu = orig_cpu
+            torch.cuda.Event.synchronize = orig_sync
             torch.cuda.set_sync_debug_mode("default")
-    assert len(calls) == 1 and calls[0][1] == 6, calls
+    assert len(event_syncs) == 1 and not cpu_calls, (event_syncs, cpu_calls)
 
 
 def test_training_step_matches_reference_cpu_path(dev):

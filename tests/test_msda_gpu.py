@@ -671,38 +671,3 @@ def test_backward_sorted_kernels(dev, name, shapes, mode, N, M, D, sorted2):
     np.testing.assert_allclose(gl, rl, atol=2e-3, rtol=1e-4)
     np.testing.assert_allclose(ga, ra, atol=1e-4, rtol=1e-4)
 
-
-@pytest.mark.parametrize("mode", ["local", "uniform"])
-def test_hinted_encoder_kernel_results_do_not_depend_on_the_hint_table(dev, mode):
-    """msda_fwd_f32_pquad<..., HINT> at the cfg-2 encoder shape (tf_msda_forward_hint_f32 / _fused_hint_f32; the emulator
-    test of the same name covers the small shapes): cold table = the exact chain, bit-identical; the same inputs again =
-    the hinted chain, bit-identical and the table unchanged; the table of OTHER inputs or garbage: the oracle's result up
-    to the fp32 summation order of the points that fall outside their hinted window."""
-    from trackformer_amd import msda
-    value, shp, loc, attn, _ = _encoder_inputs(dev, CFG2_SHAPES, mode, seed=5)
-    value2, _, loc2, attn2, _ = _encoder_inputs(dev, CFG2_SHAPES, mode, seed=6)
-    N, S, M, D = value.shape
-    hint = msda.window_hints(shp, N, S, M, D, 4, S, 4, dev)
-    assert hint is not None and hint.numel() % 4 == 0 and int(hint.abs().sum()) == 0
-    base, base2 = _fwd(value, shp, loc, attn), _fwd(value2, shp, loc2, attn2)
-    assert torch.equal(msda.ms_deform_attn_forward(value, shp, loc, attn, 64, hint=hint), base)
-    first = hint.clone()
-    assert bool((first.view(-1, 4)[:, 0] != 0).all())
-    assert torch.equal(msda.ms_deform_attn_forward(value, shp, loc, attn, 64, hint=hint), base)
-    assert torch.equal(hint, first)
-    got2 = msda.ms_deform_attn_forward(value2, shp, loc2, attn2, 64, hint=hint)
-    assert torch.allclose(got2, base2, atol=5e-6, rtol=1e-5)
-    junk = torch.randint(-2 ** 31, 2 ** 31 - 1, hint.shape, dtype=torch.int64, device=dev).to(torch.int32)
-    assert torch.allclose(msda.ms_deform_attn_forward(value, shp, loc, attn, 64, hint=junk), base, atol=5e-6, rtol=1e-5)
-    assert torch.equal(junk, first)
-    # fused entry: three calls on one table (cold, hinted, hinted) against the unhinted call
-    g = torch.Generator().manual_seed(9)
-    qproj = torch.randn(N, S, 3 * M * 16, generator=g)
-    qproj[..., :2 * M * 16] *= 2.0
-    qproj = qproj.to(dev)
-    refp = torch.cat([torch.stack(torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij"), -1)
-                      .flip(-1).reshape(-1, 2) for h, w in CFG2_SHAPES]).view(1, S, 1, 2).expand(N, S, 4, 2).contiguous().to(dev)
-    fbase = msda.ms_deform_attn_forward_fused(value, shp, refp, qproj, M, 4, 4)
-    fh = torch.zeros_like(hint)
-    for _ in range(3):
-        assert torch.equal(msda.ms_deform_attn_forward_fused(value, shp, refp, qproj, M, 4, 4, hint=fh), fbase)

@@ -22,7 +22,7 @@ from trackformer_amd import build as tfbuild  # noqa: E402
 
 
 def main():
-    masks = [int(a) for a in sys.argv[1:] if a.isdigit()] or ([] if "w4" in sys.argv[1:] else [1, 2, 3, 4, 8, 16, 32, 7, 47])
+    masks = [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4, 8, 16, 32, 7, 47]
     tfbuild.build_all()                      # the other translation units' objects
     out_dir = os.path.join(REPO, "tools", "bin", "ablate")
     os.makedirs(out_dir, exist_ok=True)
@@ -35,22 +35,11 @@ def main():
         obj = os.path.join(out_dir, "msda_pquad_abl%d.o" % mask)
         so = os.path.join(out_dir, "libtf_msda_abl%d.so" % mask)
         subprocess.check_call([hipcc] + flags + ["-DTF_PQUAD_ABLATE=%d" % mask, "-c", os.path.join(tfbuild.CSRC, "msda_pquad.hip"), "-o", obj])
-        subprocess.check_call([hipcc, "--offload-arch=" + tfbuild.GFX_ARCH, "-shared", "-fPIC", "-pthread", obj] + others + ["-o", so])
+        subprocess.check_call([hipcc, "--offload-arch=" + tfbuild.GFX_ARCH, "-shared", "-fPIC", obj] + others + ["-o", so])
         os.remove(obj)
         return so
 
-    def waves4():
-        """The two-pass kernel compiled for four waves per SIMD (<= 128 VGPRs): four workgroups per CU at 39 KB of LDS."""
-        obj = os.path.join(out_dir, "msda_pquad_w4.o")
-        so = os.path.join(out_dir, "libtf_msda_w4.so")
-        subprocess.check_call([hipcc] + flags + ["-DTF_PQUAD_NPASS2_WAVES=4", "-c", os.path.join(tfbuild.CSRC, "msda_pquad.hip"), "-o", obj])
-        subprocess.check_call([hipcc, "--offload-arch=" + tfbuild.GFX_ARCH, "-shared", "-fPIC", "-pthread", obj] + others + ["-o", so])
-        os.remove(obj)
-        return so
-
-    if "w4" in sys.argv[1:]:
-        print("built", os.path.relpath(waves4(), REPO))
-    with ThreadPoolExecutor(max_workers=min(max(1, len(masks)), os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(len(masks), os.cpu_count() or 1)) as ex:
         for so in ex.map(one, masks):
             print("built", os.path.relpath(so, REPO))
 

@@ -117,7 +117,6 @@ struct Config {
     std::string name;
     int tiled;                                            // 0 direct, 1 win, 2 quad, 3 pquad (tiled 2 + pquad on)
     std::vector<std::pair<std::string, int>> opts;        // quad_* options
-    bool hint = false;                                    // "hint=1": the *_hint_f32 entry points with one window-hint table
 };
 
 static Config parse_config(const std::string &arg)
@@ -136,15 +135,14 @@ static Config parse_config(const std::string &arg)
     static const char *pkeys[][2] = {{"wide", "pquad_wide"}, {"npass", "pquad_npass"}, {"lds", "pquad_lds_kb"},
                                      {"hy", "pquad_halo_y"}, {"hx", "pquad_halo_x"}, {"th", "pquad_tile_h"},
                                      {"tw", "pquad_tile_w"}, {"wgs", "pquad_wg_per_cu"}, {"pf", "pquad_prefetch"},
-                                     {"skew", "pquad_skew"}, {"thr", "pquad_threads"}};
-    const size_t nkeys = c.tiled == 3 ? 11 : 9;
+                                     {"skew", "pquad_skew"}};
+    const size_t nkeys = c.tiled == 3 ? 10 : 9;
     const char *(*keys)[2] = c.tiled == 3 ? pkeys : qkeys;
     size_t pos = arg.find(':');
     while (pos != std::string::npos && pos + 1 < arg.size()) {
         const size_t next = arg.find(',', pos + 1);
         const std::string kv = arg.substr(pos + 1, next == std::string::npos ? std::string::npos : next - pos - 1);
         const size_t eq = kv.find('=');
-        if (eq != std::string::npos && kv.substr(0, eq) == "hint") c.hint = atoi(kv.c_str() + eq + 1) != 0;
         if (eq != std::string::npos)
             for (size_t ki = 0; ki < nkeys; ++ki)
                 if (kv.substr(0, eq) == keys[ki][0]) c.opts.push_back({keys[ki][1], atoi(kv.c_str() + eq + 1)});
@@ -159,11 +157,10 @@ static void apply(const Config &c)
                                   "quad_halo_x",  "quad_tile_h", "quad_tile_w", "quad_split"};
     static const int defaults[] = {0, 4, 3, 40, 6, 10, 0, 0, 1};   // = kQuadOptDefaults of the library
     static const char *pnames[] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
-                                   "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew",
-                                   "pquad_threads"};
-    static const int pdefaults[] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 256};   // = kPqOptDefaults of the library
+                                   "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew"};
+    static const int pdefaults[] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0};   // = kPqOptDefaults of the library
     for (int i = 0; i < 9; ++i) tf_msda_set_option(names[i], defaults[i]);
-    for (int i = 0; i < 11; ++i) tf_msda_set_option(pnames[i], pdefaults[i]);
+    for (int i = 0; i < 10; ++i) tf_msda_set_option(pnames[i], pdefaults[i]);
     for (auto &o : c.opts) tf_msda_set_option(o.first.c_str(), o.second);
     tf_msda_set_option("pquad", c.tiled == 3 ? 1 : 0);
     tf_msda_set_option("tiled", c.tiled == 3 ? 2 : c.tiled);
@@ -229,22 +226,7 @@ int main(int argc, char **argv)
             for (size_t ci = 0; ci < cfgs.size(); ++ci) {
                 const Config &c = cfgs[ci];
                 apply(c);
-                int32_t *d_hint = nullptr;
-                int64_t hint_words = 0;
-                if (c.hint) {   // one table for all input sets (zeroed: the first launch runs the exact chain and fills it)
-                    hint_words = tf_msda_window_hint_words(shapes, N, S, M, D, L, Lq, P);
-                    if (hint_words > 0) {
-                        CK(hipMalloc(&d_hint, hint_words * 4));
-                        CK(hipMemset(d_hint, 0, hint_words * 4));
-                    }
-                }
                 auto run = [&](int k = 0) {
-                    if (d_hint)
-                        return fz ? tf_msda_forward_fused_hint_f32(d_value + k * n_value, shapes, d_ref, 2, d_qproj + k * n_qproj,
-                                                                   3 * M * LP, 0, 2 * M * LP, d_out + k * n_out, N, S, M, D, L,
-                                                                   Lq, P, d_hint, hint_words, stream)
-                                  : tf_msda_forward_hint_f32(d_value + k * n_value, shapes, d_loc + k * n_loc, d_attn + k * n_attn,
-                                                             d_out + k * n_out, N, S, M, D, L, Lq, P, d_hint, hint_words, stream);
                     return fz ? tf_msda_forward_fused_f32(d_value + k * n_value, shapes, d_ref, 2, d_qproj + k * n_qproj,
                                                           3 * M * LP, 0, 2 * M * LP, d_out + k * n_out, N, S, M, D, L, Lq, P,
                                                           stream)
@@ -321,16 +303,16 @@ int main(int argc, char **argv)
                                                      "load-gathers r1", "DMA r1 landed", "LDS gathers r1 + stores",
                                                      "(point loads issued)", "(level 0 bbox filed)"};
                     // msda_fwd_f32_pquad: first tile of every workgroup, then the end of its last tile
-                    static const char *pnames[16] = {"entry", "tile 0 loads issued", "tile 0 points+bbox", "B0", "B1 (L0 landed)",
+                    static const char *pnames[14] = {"entry", "tile 0 loads issued", "tile 0 points+bbox", "B0", "B1 (L0 landed)",
                                                      "(prefetch issued)", "L0 gathered", "B3 (L1-3 landed)", "stored",
                                                      "tile 1 points+bbox", "end of last tile", "B2 (L0 window free)", "DMA L1-3 issued",
-                                                     "DMA L1-3 landed (own)", "hinted: L0 DMA issued", "hinted: points+bbox done"};
+                                                     "DMA L1-3 landed (own)"};
                     const char **names = c.tiled == 3 ? pnames : qnames;
                     printf("  trace of %zu workgroups (us after the first workgroup's entry; 100 MHz clock):\n", nwg);
                     static const int qorder[14] = {0, 1, 12, 13, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
-                    static const int porder[16] = {0, 1, 2, 3, 14, 15, 4, 5, 6, 11, 12, 13, 7, 8, 9, 10};
+                    static const int porder[14] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 7, 8, 9, 10};
                     const int *order = c.tiled == 3 ? porder : qorder;
-                    for (int oi = 0; oi < (c.tiled == 3 ? 16 : 14); ++oi) {
+                    for (int oi = 0; oi < 14; ++oi) {
                         const int i = order[oi];
                         std::vector<double> v, dur;
                         for (size_t w = 0; w < nwg; ++w)

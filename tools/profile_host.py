@@ -15,12 +15,15 @@ from trackformer_amd import runtime  # noqa: E402
 
 runtime.configure_inference()
 dev = torch.device("cuda:0")
-cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+cfg = bench.CONFIGS[sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "cfg2"]
 model, criterion, post, margs = bench.build_model(cfg, dev)
 model.tracking()
 tracker = bench.build_tracker(model, post, use_graph=True)
-seeder = bench.TrackSeeder(dev, margs.hidden_dim, cfg["tracks"], cfg["size"])
 frames = bench.make_frames(dev, cfg["size"])
+seeds = None
+if "--no-calibration" not in sys.argv:   # bench.py's default: the association leg has ~100 surviving tracks and ~150 detections
+    seeds = bench.calibrate_association(model, frames[0], cfg["tracks"], cfg["size"], dev)
+seeder = bench.TrackSeeder(dev, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds)
 
 
 def step(i):
@@ -51,3 +54,4 @@ with torch.no_grad():
     pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(30)
+st.sort_stats("cumulative").print_stats(25)

@@ -26,9 +26,6 @@ EXPORTED_SYMBOLS = (
     "tf_msda_backward_f64",
     "tf_msda_backward_f32_dshapes",
     "tf_msda_backward_f64_dshapes",
-    "tf_msda_window_hint_words",
-    "tf_msda_forward_fused_hint_f32",
-    "tf_msda_forward_hint_f32",
     "tf_msda_forward_host_f32",
     "tf_msda_forward_host_f64",
     "tf_msda_backward_host_f32",
@@ -52,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "tf_ffn_fused_f32",
     "tf_linear_res_ln_f32",
     "tf_mha_core_f32",
+    "tf_nms_host_f32",
 )
 
 ABI_VERSION = 1
@@ -104,13 +102,9 @@ def lib():
         b = getattr(L, "tf_msda_backward_host_" + suf)
         b.restype = ci
         b.argtypes = [vp] * 8 + [ci] * 7
+    L.tf_nms_host_f32.restype = ci
+    L.tf_nms_host_f32.argtypes = [vp, vp, ci, ctypes.c_float, vp, vp]
     L.tf_msda_forward_fused_f32.restype = ci
-    L.tf_msda_window_hint_words.restype = ctypes.c_int64
-    L.tf_msda_window_hint_words.argtypes = [vp] + [ci] * 7
-    L.tf_msda_forward_fused_hint_f32.restype = ci
-    L.tf_msda_forward_fused_hint_f32.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp] + [ci] * 7 + [vp, ctypes.c_int64, vp]
-    L.tf_msda_forward_hint_f32.restype = ci
-    L.tf_msda_forward_hint_f32.argtypes = [vp] * 5 + [ci] * 7 + [vp, ctypes.c_int64, vp]
     L.tf_msda_forward_fused_f32.argtypes = [vp, vp, vp, ci, vp, ci, ci, ci, vp] + [ci] * 7 + [vp]
     L.tf_bias_act_f32.restype = ci
     L.tf_bias_act_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ci, vp]

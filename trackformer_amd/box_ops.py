@@ -107,6 +107,17 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
     """torchvision.ops.nms semantics: indices of kept boxes, sorted by decreasing score."""
     if boxes.shape[0] == 0:
         return torch.zeros(0, dtype=torch.int64, device=boxes.device)
+    if boxes.device.type == "cpu" and boxes.dtype == torch.float32 and scores.dtype == torch.float32:
+        # host boxes (the tracker's association leg): the library's C sweep -- same arithmetic, same visiting order
+        import ctypes
+        from . import _cabi
+        b, s = boxes.contiguous(), scores.contiguous()
+        keep = torch.empty(b.shape[0], dtype=torch.int64)
+        n_keep = ctypes.c_int(0)
+        rc = _cabi.lib().tf_nms_host_f32(b.data_ptr(), s.data_ptr(), b.shape[0], float(iou_threshold), keep.data_ptr(),
+                                         ctypes.addressof(n_keep))
+        _cabi.check(rc, "tf_nms_host_f32")
+        return keep[:n_keep.value]
     order = torch.sort(scores, descending=True, stable=True)[1]
     keep = nms_keep_mask(boxes, scores, iou_threshold)
     return order[keep[order]]

@@ -36,8 +36,6 @@ struct DirectArgs {
     FusedArgs fa;              // FUSED == true
     int S, M, L, Lq;
     long long nlq;             // N * Lq
-    int *hint;                 // optional window-hint table of the encoder kernel (tf_msda_*_hint_f32), or null
-    long long hint_words;      // its size in 32-bit words
 };
 
 // msda_pquad.hip: the persistent LDS-window encoder forward (msda_fwd_f32_pquad).  launch_pquad returns
@@ -45,8 +43,6 @@ struct DirectArgs {
 bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N, int D, int P, hipStream_t stream,
                   hipError_t *err);
 int pquad_set_option(const char *name, int value);   // -1: unknown name, else the previous value
-// 32-bit words of window hints launch_pquad would use for this call shape (0: it would not take the call / no hints)
-long long pquad_hint_words(const LevelTable &lt, int L, int M, int N, int D, int P, int S, int Lq);
 void pquad_set_trace(unsigned long long *device_buffer);
 
 // linear_split.hip: block shape / pipelining variant of tf_linear_split_f32; returns the previous one

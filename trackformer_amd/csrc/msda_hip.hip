@@ -2763,9 +2763,6 @@ bool launch_direct(bool fused, const DirectArgs &da, const LevelTable &lt, const
     return true;
 }
 
-thread_local int *t_hint = nullptr;           // window hints of the call in progress (tf_msda_*_hint_f32), else null
-thread_local long long t_hint_words = 0;
-
 template <typename T>
 int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shapes_dev,
                  const T *loc, const T *attn, T *out, int N, int S, int M, int D, int L, int Lq,
@@ -2805,8 +2802,6 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                 da.L = L;
                 da.Lq = Lq;
                 da.nlq = (long long)N * Lq;
-                da.hint = t_hint;
-                da.hint_words = t_hint_words;
                 if (is_aligned(loc, 8) && shapes_dev == nullptr && tiled_mode() == 2 &&
                     launch_pquad(false, da, lt, N, D, P, stream, &e))
                     return record_hip(e);
@@ -2871,8 +2866,6 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
         da.L = L;
         da.Lq = Lq;
         da.nlq = (long long)N * Lq;
-        da.hint = t_hint;
-        da.hint_words = t_hint_words;
         hipError_t de;
         if (tiled_mode() == 2 && launch_pquad(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
             return record_hip(de);
@@ -3043,47 +3036,6 @@ int tf_msda_forward_fused_f32(const float *value, const int64_t *shapes_hw_host,
 {
     return forward_fused_impl(value, shapes_hw_host, ref_points, ref_dim, qproj, ld, off_col,
                               logit_col, out, N, S, M, D, L, Lq, P, stream);
-}
-
-namespace {
-struct HintScope {   // the optional hint table travels to launch_pquad through the calling thread
-    HintScope(int32_t *h, int64_t words)
-    {
-        t_hint = reinterpret_cast<int *>(h);
-        t_hint_words = h ? (long long)words : 0;
-    }
-    ~HintScope()
-    {
-        t_hint = nullptr;
-        t_hint_words = 0;
-    }
-};
-}  // namespace
-
-int64_t tf_msda_window_hint_words(const int64_t *shapes_hw_host, int N, int S, int M, int D, int L, int Lq, int P)
-{
-    if (!shapes_hw_host || N <= 0 || S <= 0 || M <= 0 || D <= 0 || L <= 0 || Lq <= 0 || P <= 0 || L > TF_MSDA_MAX_LEVELS) return 0;
-    LevelTable lt{};
-    if (build_level_table(shapes_hw_host, L, S, &lt) != TF_MSDA_OK) return 0;
-    if (tiled_mode() != 2) return 0;
-    return (int64_t)pquad_hint_words(lt, L, M, N, D, P, S, Lq);
-}
-
-int tf_msda_forward_fused_hint_f32(const float *value, const int64_t *shapes_hw_host, const float *ref_points, int ref_dim,
-                                   const float *qproj, int ld, int off_col, int logit_col, float *out, int N, int S, int M,
-                                   int D, int L, int Lq, int P, int32_t *hint, int64_t hint_words, void *stream)
-{
-    HintScope scope(hint, hint_words);
-    return forward_fused_impl(value, shapes_hw_host, ref_points, ref_dim, qproj, ld, off_col, logit_col, out, N, S, M, D, L,
-                              Lq, P, stream);
-}
-
-int tf_msda_forward_hint_f32(const float *value, const int64_t *shapes_hw_host, const float *loc, const float *attn, float *out,
-                             int N, int S, int M, int D, int L, int Lq, int P, int32_t *hint, int64_t hint_words, void *stream)
-{
-    if (!shapes_hw_host) return TF_MSDA_ERR_NULL_POINTER;
-    HintScope scope(hint, hint_words);
-    return forward_impl<float>(value, shapes_hw_host, nullptr, loc, attn, out, N, S, M, D, L, Lq, P, stream);
 }
 
 int tf_msda_forward_f32(const float *value, const int64_t *shapes_hw_host, const float *loc,

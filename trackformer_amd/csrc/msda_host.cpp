@@ -214,3 +214,41 @@ int tf_msda_backward_host_f64(const double *value, const int64_t *shapes_hw, con
 }
 
 }  // extern "C"
+
+// ---- greedy non-maximum suppression on host boxes (torchvision.ops.nms semantics; reference call sites tracker.py:399,495).
+// The association leg of Tracker.step runs it twice per frame on a few hundred host boxes; as a K x K IoU matrix plus a
+// Python sweep it cost ~0.35 ms per call.  Same arithmetic as box_ops.box_iou in the same order (fp32, no contraction),
+// same visiting order as torch.sort(descending=True, stable=True): the kept set is identical.
+#pragma STDC FP_CONTRACT OFF
+extern "C" int tf_nms_host_f32(const float *boxes, const float *scores, int n, float iou_threshold, int64_t *keep, int *n_keep)
+{
+    if (!boxes || !scores || !keep || !n_keep) return TF_MSDA_ERR_NULL_POINTER;
+    if (n < 0) return TF_MSDA_ERR_BAD_DIMS;
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+    std::vector<float> area((size_t)n);
+    for (int i = 0; i < n; ++i) area[(size_t)i] = (boxes[4 * i + 2] - boxes[4 * i]) * (boxes[4 * i + 3] - boxes[4 * i + 1]);
+    std::vector<char> dead((size_t)n, 0);
+    int kept = 0;
+    for (int a = 0; a < n; ++a) {
+        const int i = order[(size_t)a];
+        if (dead[(size_t)a]) continue;
+        keep[kept++] = i;
+        const float *bi = boxes + 4 * i;
+        for (int b = a + 1; b < n; ++b) {
+            if (dead[(size_t)b]) continue;
+            const int j = order[(size_t)b];
+            const float *bj = boxes + 4 * j;
+            const float ltx = std::max(bi[0], bj[0]), lty = std::max(bi[1], bj[1]);
+            const float rbx = std::min(bi[2], bj[2]), rby = std::min(bi[3], bj[3]);
+            const float w = std::max(rbx - ltx, 0.f), h = std::max(rby - lty, 0.f);
+            const float inter = w * h;
+            const float uni = area[(size_t)i] + area[(size_t)j] - inter;
+            const float iou = inter / uni;
+            if (iou > iou_threshold) dead[(size_t)b] = 1;
+        }
+    }
+    *n_keep = kept;
+    return TF_MSDA_OK;
+}

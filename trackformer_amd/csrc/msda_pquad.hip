@@ -66,17 +66,16 @@ using namespace tfm;
 constexpr int kPqAblate = TF_PQUAD_ABLATE;
 
 constexpr int kPqLevels = 4;
-constexpr int kPqThreads = 256;            // the default workgroup; THREADS = 512 (8 waves, one pass) is a template variant
-constexpr int kPqMaxWaves = 8;
+constexpr int kPqThreads = 256;
+constexpr int kPqPairs = kPqThreads / 4;   // (query, head) pairs per pass
 constexpr int kML = TF_MSDA_MAX_LEVELS;
 // LDS header: level table (3 x 16 ints) | query partition [2][4][16] | nominal footprints [2][4][16] |
 // per-wave bounding boxes [2][4 waves][4 levels][4]; then rows 0, 1 (zeros) and the window rows
 constexpr int kPqOffQ = 3 * kML;
 constexpr int kPqOffNom = kPqOffQ + 2 * 4 * kML;
 constexpr int kPqOffBb = kPqOffNom + 2 * 4 * kML;
-constexpr int kPqOffGeo = kPqOffBb + 2 * kPqMaxWaves * 16;   // window table [2 parities][4 levels][8 ints]
-constexpr int kPqOffHint = kPqOffGeo + 64;   // HINT: the next tile's hint words (4 ints), landed by LDS-DMA
-constexpr int kPqHdrBytes = 2560;   // >= (kPqOffHint + 4) * 4 = 2512, multiple of 128
+constexpr int kPqOffGeo = kPqOffBb + 128;   // window table [2 parities][4 levels][8 ints]
+constexpr int kPqHdrBytes = 2048;   // >= (kPqOffGeo + 64) * 4 = 1984, multiple of 128
 
 struct PquadGeom {
     int TH, TW;        // tile size in level-0 pixels
@@ -87,14 +86,7 @@ struct PquadGeom {
     int skew;          // start-up skew between the workgroups of a CU, in 10 ns units (0: none)
     int cus;           // compute units of the device (workgroup b is the (b / cus)-th of its CU)
     unsigned long long *trace;   // debug: 16 timestamps (s_memrealtime, 100 MHz) per workgroup, or null
-    int *hint;         // HINT kernels: [n_items][4 ints] level-0 window hints, read and rewritten by the launch
 };
-
-// A window hint = the bounding box {min x0, max x0, min y0, max y0} of the floor coordinates of the item's in-range LEVEL-0
-// points AS THE PREVIOUS LAUNCH ON THIS TABLE SAW THEM, stored biased so that a zero-initialised table reads as "never
-// written": word 0 == 0 -> invalid; otherwise {bx0 + kPqHintBias, bx1 + kPqHintBias, by0 + ..., by1 + ...} (coordinates are
-// >= -1), an empty box (no point of the level in range) as {kPqHintEmpty, 1, kPqHintEmpty, 1}.
-constexpr int kPqHintBias = 2, kPqHintEmpty = 1 << 20;
 
 template <int NPASS>
 struct PqPoints {   // one tile's sampling points as the gathers need them + where its outputs go
@@ -108,22 +100,19 @@ struct PqRefs {     // fused entry only: reference points of the pair's query, p
     float rx[NPASS][kPqLevels], ry[NPASS][kPqLevels];
 };
 
-// PF: 2 = the next tile's sampling points are prefetched into REGISTERS (loads issued before the gathers of the
-//     current tile, consumed after them; ~23 VGPRs per pass: 3 or 2 waves per SIMD); 0 = they are loaded at the
-//     end of the current tile.  (An L2 prefetch by LDS-DMA into a sink was measured: no effect, removed -- the
-//     point loads are bound by L2 -> L1 fill bandwidth, not by HBM latency; that is what WIDE addresses.)
+// PF: always 0.  (Register prefetch of the next tile's points, PF = 2: +23 VGPRs per pass -> two workgroups per CU, 50 vs
+//     43 us, removed in round 3.  An L2 prefetch by LDS-DMA into a sink: no effect, removed.  Round 3 also measured, and
+//     did not keep: window hints from the previous call with the level-0 DMA issued next to the point loads (two barriers
+//     fewer per tile, 47.0 vs 46.0 us), eight-wave workgroups (53 vs 47 us), four workgroups per CU at 128 VGPRs
+//     (55 vs 44 us) -- profiles/r03_pquad_experiments.txt.  The kernel's time does not follow the latency chain of a
+//     tile: it follows the ~3700 instructions a wave executes per tile.)
 // WIDE: the points are loaded as 16-byte pieces (lane j of a quad reads level j's four points: 2 + 1 loads per pass
 //     instead of 4 + 4, every cache line fetched once) and transposed inside the quad by DPP so that lane j ends
 //     up with point j of every level.  Needs 16-byte aligned rows (the host checks).
-// experiment knob of tools/build_ablations.py (never set in libtf_msda.so): waves per SIMD the two-pass kernel is compiled for
-#ifndef TF_PQUAD_NPASS2_WAVES
-#define TF_PQUAD_NPASS2_WAVES 3
-#endif
-template <int NPASS, int PF, int THREADS = kPqThreads>
+template <int NPASS, int PF>
 constexpr int pq_min_waves()
 {
-    if (THREADS == 512) return 4;   // two workgroups of eight waves per CU
-    return PF == 2 ? (NPASS == 1 ? 3 : 2) : (NPASS == 1 ? 4 : NPASS == 2 ? TF_PQUAD_NPASS2_WAVES : 2);
+    return NPASS == 1 ? 4 : NPASS == 2 ? 3 : 2;
 }
 
 // 4 x 4 transpose across the lanes of a quad: in v[p] = element (row = this lane, column p), out v[l] = element
@@ -152,21 +141,12 @@ __device__ __forceinline__ f32x4_t ldg_f4(const float *base, unsigned byte_off)
 
 // DH: head dimension, 32 (128-byte rows, 4 lanes x 8 channels) or 36 (hidden 288: 144-byte rows, 3 lanes x 12 channels,
 //     the window rows packed without padding and staged in 16-byte pieces; see msda_quad_dev.h).
-// THREADS: 256 (four waves, NPASS passes of 64 pairs) or 512 (eight waves: the same tile in half the passes per wave).
-// HINT: the LEVEL-0 window of a tile comes from pg.hint (what the previous launch on the same table measured for this item,
-//     widened by one pixel) instead of from the tile's own points: it is known before the points have been loaded, so the
-//     LDS-DMA of level 0 is issued together with the point loads, and the bounding boxes / window geometry / two barriers
-//     leave the tile's critical path.  The boxes are still computed: level 0's is the next launch's hint, levels 1..3 get
-//     their exact windows from them as before -- but that geometry now runs under the level-0 gathers (its windows are
-//     only staged in round 1).  Points outside the hinted window take the exact buffer-load path like any point outside
-//     its window, an item without a valid hint runs the exact chain: results never depend on the table's contents.
-template <bool FUSED, int TA_MASK, int NPASS, int PF, bool WIDE, int DH, int THREADS = kPqThreads, bool HINT = false>
-__global__ void __launch_bounds__(THREADS, (pq_min_waves<NPASS, PF, THREADS>()))
+template <bool FUSED, int TA_MASK, int NPASS, int PF, bool WIDE, int DH>
+__global__ void __launch_bounds__(kPqThreads, (pq_min_waves<NPASS, PF>()))
 msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 {
-    constexpr int PT = 4, D = DH, NL = kPqLevels, PAIRS = THREADS / 4, WAVES = THREADS / 64;
-    static_assert(PF == 0, "the register-prefetch variant (PF = 2) measured slower (50 vs 43 us) and was removed in round 3");
-    static_assert(WAVES >= NL && WAVES <= kPqMaxWaves, "one wave per level for the window geometry");
+    constexpr int PT = 4, D = DH, NL = kPqLevels, PAIRS = kPqPairs;
+    static_assert(PF == 0, "the register-prefetch variant (PF = 2) measured slower (50 vs 43 us, round 2) and was removed in round 3");
     constexpr bool D36 = DH == 36;
     constexpr unsigned ROWB = D * 4;   // bytes of one (pixel, head) row
     static_assert(DH == 32 || DH == 36, "head dimension 32 or 36");
@@ -174,7 +154,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
     int *s_tab = reinterpret_cast<int *>(smem);
     int *s_q = s_tab + kPqOffQ;       // [parity][ya | yb | xa | xb][level]
     int *s_nom = s_tab + kPqOffNom;   // [parity][ny0 | ny1 | nx0 | nx1][level]
-    int *s_bb = s_tab + kPqOffBb;     // [parity][WAVES][level][min x0, max x0, min y0, max y0]: no LDS atomics
+    int *s_bb = s_tab + kPqOffBb;     // [parity][wave][level][min x0, max x0, min y0, max y0]: no LDS atomics
     int *s_geo = s_tab + kPqOffGeo;   // [parity][level][wx0, wy0, ww, wh, limx, limy, fits on its own, -]
     unsigned char *s_rows = smem + kPqHdrBytes;   // rows 0, 1: zeros; the windows start at row 2
 
@@ -414,7 +394,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         constexpr int l = decltype(lc)::value;
         if constexpr ((kPqAblate & 4) != 0) {
             if (lane == 0) {   // the whole level: tfq_window clamps it to the nominal footprint
-                int *slot = s_bb + ((par * WAVES + wave) * 4 + l) * 4;
+                int *slot = s_bb + ((par * 4 + wave) * 4 + l) * 4;
                 slot[0] = -1;
                 slot[1] = l < L ? Ws[l < NL ? l : 0] : INT_MIN;
                 slot[2] = -1;
@@ -464,14 +444,14 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                 const int wmnx = min(min(a0, a1), min(a2, a3)), wmxx = max(max(b0, b1), max(b2, b3));
                 const int wmny = min(min(c0, c1), min(c2, c3)), wmxy = max(max(d0, d1), max(d2, d3));
                 if (lane == 0) {
-                    int *slot = s_bb + ((par * WAVES + wave) * 4 + l) * 4;
+                    int *slot = s_bb + ((par * 4 + wave) * 4 + l) * 4;
                     slot[0] = wmnx;
                     slot[1] = wmxx;
                     slot[2] = wmny;
                     slot[3] = wmxy;
                 }
             } else if (l < NL && lane == 0) {   // levels the call does not have: an empty box
-                int *slot = s_bb + ((par * WAVES + wave) * 4 + l) * 4;
+                int *slot = s_bb + ((par * 4 + wave) * 4 + l) * 4;
                 slot[0] = INT_MAX;
                 slot[1] = INT_MIN;
                 slot[2] = INT_MAX;
@@ -496,130 +476,8 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
     decode_queries(0, cb, cm, cur);
     issue_loads(cur, nref);
     stamp(1);
-
-    // ---- window geometry of one level from the tile's own bounding boxes (wave l -> level l): the box over the waves'
-    // boxes, clamped to the nominal footprint, filed in the window table; every wave then only reads the table --
-    // computing all four windows in every wave cost ~240 vector instructions per wave and tile
-    auto exact_geometry = [&](int par_, int l) {
-        int *ge = s_geo + (par_ * 4 + l) * 8;
-        QuadWindow w;
-        w.wx0 = kQuadFar;
-        w.wy0 = kQuadFar;
-        w.ww = w.wh = w.limx = w.limy = 0;
-        bool fits = false;
-        if (l < L && ((TA_MASK >> l) & 1) == 0) {
-            const int *bb = s_bb + par_ * (16 * WAVES) + 4 * l;   // + 16 * wave
-            const int *nm4 = s_nom + par_ * 4 * kML;
-            int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
-#pragma unroll
-            for (int ww = 0; ww < WAVES; ++ww) {
-                bx0 = min(bx0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 0]));
-                bx1 = max(bx1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 1]));
-                by0 = min(by0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 2]));
-                by1 = max(by1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 3]));
-            }
-            const int ny0 = __builtin_amdgcn_readfirstlane(nm4[l]);
-            const int ny1 = __builtin_amdgcn_readfirstlane(nm4[kML + l]);
-            const int nx0 = __builtin_amdgcn_readfirstlane(nm4[2 * kML + l]);
-            const int nx1 = __builtin_amdgcn_readfirstlane(nm4[3 * kML + l]);
-            w = tfq_window(bx0, bx1, by0, by1, nx0, nx1, ny0, ny1, pg.cap_rows, 2, &fits);
-        }
-        if (lane == 0) {
-            ge[0] = w.wx0;
-            ge[1] = w.wy0;
-            ge[2] = w.ww;
-            ge[3] = w.wh;
-            ge[4] = w.limx;
-            ge[5] = w.limy;
-            ge[6] = fits ? 1 : 0;
-            ge[7] = 0;   // not a hinted window
-        }
-    };
-    // ---- HINT: level 0's window of item `it` from the hint table (wave 0) -> window table of parity par_; [7] = valid.
-    // hint_load issues the 16-byte load (held in four registers until hint_file), hint_store files the tile's exact box.
-    int *s_hint = s_tab + kPqOffHint;
-    auto hint_load = [&](int it, int (&h)[4]) {
-        const int4 v = *reinterpret_cast<const int4 *>(pg.hint + (size_t)it * 4);
-        h[0] = v.x;
-        h[1] = v.y;
-        h[2] = v.z;
-        h[3] = v.w;
-    };
-    // the same 16 bytes by LDS-DMA into s_hint (lanes 0..3 of the calling wave, one dword each): nothing is held in
-    // registers while the words are in flight; the wave's next vmcnt(0) -- before B3 -- covers them
-    const __amdgpu_buffer_rsrc_t hrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        pg.hint, 0, HINT ? (unsigned)pg.n_items * 16u : 0u, 0x00020000);
-    auto hint_dma = [&](int it) {
-        if (lane < 4)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(hrsrc, (__attribute__((address_space(3))) void *)s_hint, 4,
-                                                     (unsigned)it * 16u + (unsigned)lane * 4u, 0, 0, 0);
-    };
-    auto hint_file = [&](int par_, const int (&h)[4]) {
-        int *ge = s_geo + (par_ * 4 + 0) * 8;
-        QuadWindow w;
-        w.wx0 = kQuadFar;
-        w.wy0 = kQuadFar;
-        w.ww = w.wh = w.limx = w.limy = 0;
-        bool fits = true;
-        const int h0 = __builtin_amdgcn_readfirstlane(h[0]), h1 = __builtin_amdgcn_readfirstlane(h[1]);
-        const int h2 = __builtin_amdgcn_readfirstlane(h[2]), h3 = __builtin_amdgcn_readfirstlane(h[3]);
-        const bool valid = h0 != 0;
-        if (valid && h0 != kPqHintEmpty && (TA_MASK & 1) == 0) {
-            const int *nm4 = s_nom + par_ * 4 * kML;
-            const int ny0 = __builtin_amdgcn_readfirstlane(nm4[0]), ny1 = __builtin_amdgcn_readfirstlane(nm4[kML]);
-            const int nx0 = __builtin_amdgcn_readfirstlane(nm4[2 * kML]), nx1 = __builtin_amdgcn_readfirstlane(nm4[3 * kML]);
-            // any table contents are safe: the box is clamped to +-2^24 before the margin, tfq_window clamps it to the
-            // nominal footprint and to the LDS capacity
-            const int lim = 1 << 24;
-            const int bx0 = max(-lim, min(lim, h0 - kPqHintBias)), bx1 = max(-lim, min(lim, h1 - kPqHintBias));
-            const int by0 = max(-lim, min(lim, h2 - kPqHintBias)), by1 = max(-lim, min(lim, h3 - kPqHintBias));
-            w = tfq_window(bx0 - 1, bx1 + 1, by0 - 1, by1 + 1, nx0, nx1, ny0, ny1, pg.cap_rows, 2, &fits);
-            if (!fits) w = tfq_window(bx0, bx1, by0, by1, nx0, nx1, ny0, ny1, pg.cap_rows, 2, &fits);   // without the margin
-        }
-        if (lane == 0) {
-            ge[0] = w.wx0;
-            ge[1] = w.wy0;
-            ge[2] = w.ww;
-            ge[3] = w.wh;
-            ge[4] = w.limx;
-            ge[5] = w.limy;
-            ge[6] = fits ? 1 : 0;
-            ge[7] = valid ? 1 : 0;
-        }
-    };
-    auto hint_store = [&](int par_, int it) {   // the tile's exact level-0 box -> the next launch's hint
-        const int *bb = s_bb + par_ * (16 * WAVES);
-        int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
-#pragma unroll
-        for (int ww = 0; ww < WAVES; ++ww) {
-            bx0 = min(bx0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 0]));
-            bx1 = max(bx1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 1]));
-            by0 = min(by0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 2]));
-            by1 = max(by1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 3]));
-        }
-        const bool empty = bx0 > bx1 || by0 > by1;
-        if (lane == 0) {
-            int4 v;
-            v.x = empty ? kPqHintEmpty : bx0 + kPqHintBias;
-            v.y = empty ? 1 : bx1 + kPqHintBias;
-            v.z = empty ? kPqHintEmpty : by0 + kPqHintBias;
-            v.w = empty ? 1 : by1 + kPqHintBias;
-            *reinterpret_cast<int4 *>(pg.hint + (size_t)it * 4) = v;
-        }
-    };
-
-    if constexpr (HINT) {
-        // the first tile's hinted window (its tables are visible since the barrier above); the points stay in flight
-        if (wave == 0) {
-            int h[4];
-            hint_load(item, h);
-            hint_file(0, h);
-        }
-        __syncthreads();
-    } else {
-        finish_points(cur, nref);
-        bbox(cur, 0);
-    }
+    finish_points(cur, nref);
+    bbox(cur, 0);
     stamp(2);
 
     int par = 0;
@@ -630,19 +488,47 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         int nb = 0, nty = 0, ntx = 0, nm = 0;
         if (has_next) decode_item(next_item, nb, nty, ntx, nm);
 
-        // HINT: is this tile's level-0 window a hinted one (filed by wave 0 during the previous tile / the prologue)?
-        bool hinted = false;
-        if constexpr (HINT) hinted = __builtin_amdgcn_readfirstlane(s_geo[(par * 4 + 0) * 8 + 7]) != 0;
-        if (!hinted) {
-            if constexpr (HINT) {   // no valid hint: the exact chain (the points were only issued so far)
-                finish_points(cur, nref);
-                bbox(cur, par);
+        __syncthreads();   // B0: the tile's bounding boxes are filed, its tables visible
+        if (iter == 0) stamp(3);
+        // window geometry: wave l works out level l's window (bounding box over the four waves' boxes, clamped to the
+        // nominal footprint) and files it; every wave then only reads the table -- computing all four windows in
+        // every wave cost ~240 vector instructions per wave and tile
+        if (wave < NL) {
+            const int l = wave;
+            int *ge = s_geo + (par * 4 + l) * 8;
+            QuadWindow w;
+            w.wx0 = kQuadFar;
+            w.wy0 = kQuadFar;
+            w.ww = w.wh = w.limx = w.limy = 0;
+            bool fits = false;
+            if (l < L && ((TA_MASK >> l) & 1) == 0) {
+                const int *bb = s_bb + par * 64 + 4 * l;   // + 16 * wave
+                const int *nm4 = s_nom + par * 4 * kML;
+                int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
+#pragma unroll
+                for (int ww = 0; ww < kPqThreads / 64; ++ww) {
+                    bx0 = min(bx0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 0]));
+                    bx1 = max(bx1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 1]));
+                    by0 = min(by0, __builtin_amdgcn_readfirstlane(bb[16 * ww + 2]));
+                    by1 = max(by1, __builtin_amdgcn_readfirstlane(bb[16 * ww + 3]));
+                }
+                const int ny0 = __builtin_amdgcn_readfirstlane(nm4[l]);
+                const int ny1 = __builtin_amdgcn_readfirstlane(nm4[kML + l]);
+                const int nx0 = __builtin_amdgcn_readfirstlane(nm4[2 * kML + l]);
+                const int nx1 = __builtin_amdgcn_readfirstlane(nm4[3 * kML + l]);
+                w = tfq_window(bx0, bx1, by0, by1, nx0, nx1, ny0, ny1, pg.cap_rows, 2, &fits);
             }
-            __syncthreads();   // B0: the tile's bounding boxes are filed, its tables visible
-            if (iter == 0) stamp(3);
-            if (wave < NL) exact_geometry(par, wave);
-            __syncthreads();   // B0': the window table is visible
+            if (lane == 0) {
+                ge[0] = w.wx0;
+                ge[1] = w.wy0;
+                ge[2] = w.ww;
+                ge[3] = w.wh;
+                ge[4] = w.limx;
+                ge[5] = w.limy;
+                ge[6] = fits ? 1 : 0;
+            }
         }
+        __syncthreads();   // B0': the window table is visible
 
         // window geometry (wave-uniform, scalar registers) of the current tile
         const unsigned head_base = (unsigned)((((long long)cur.b * S * M + cur.m) * D) * 4);
@@ -690,13 +576,13 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                             int r = wave * 8 + (lane >> 3);                       // < 64
                             int wy = (int)(((float)r + 0.5f) * inv_ww);
                             int wx = r - wy * ww;
-                            constexpr int STEP = 8 * WAVES;
+                            constexpr int STEP = 8 * (kPqThreads / 64);
                             const int qstep = __builtin_amdgcn_readfirstlane((int)(((float)STEP + 0.5f) * inv_ww));
                             const int rstep = STEP - qstep * ww;
                             unsigned off = lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)(lane & 7) * 16u;
                             const unsigned step_a = (unsigned)(qstep * W + rstep) * rowbytes;
                             const unsigned step_b = (unsigned)(W - ww) * rowbytes;
-                            for (int c = wave; c < nchunks; c += WAVES) {
+                            for (int c = wave; c < nchunks; c += kPqThreads / 64) {
                                 const int py = wy0 + wy, px = wx0 + wx;   // extended coordinates: may be -1 or size
                                 const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
                                 if constexpr (!(kPqAblate & 2))
@@ -722,7 +608,7 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
                         used += (nchunks * 64 + 8) / 9;
                         const unsigned lvl_base = glvl[l];
                         const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
-                        for (int c = wave; c < nchunks; c += WAVES) {
+                        for (int c = wave; c < nchunks; c += kPqThreads / 64) {
                             const int pc = c * 64 + lane;
                             const int r = (int)(((float)pc + 0.5f) * (1.f / 9.f));   // pc / 9 (pc < 2^16: exact)
                             const int piece = pc - r * 9;
@@ -832,28 +718,12 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         // ---- round 0: level 0 ----
         used = 0;
         phase_b(std::integral_constant<int, 0>{}, std::integral_constant<int, R0>{});
-        if constexpr (HINT)
-            if (hinted) {   // the points land while the window streams in; their boxes are filed for levels 1..3 / the hint
-                if (iter == 0) stamp(14);   // level 0's DMA issued
-                finish_points(cur, nref);
-                bbox(cur, par);
-                if (iter == 0) stamp(15);   // points finished, boxes filed
-            }
         all_passes(std::integral_constant<int, (0x1 | TA_MASK)>{}, std::false_type{});   // by buffer loads
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA landed
-        __syncthreads();                      // B1: ... everybody's; (HINT) the tile's bounding boxes are filed
+        __syncthreads();                      // B1: ... everybody's; the next tile's tables are visible
         if (iter == 0) stamp(4);
         PqRefs<NPASS> rr;
         if (has_next) setup_tables(par ^ 1, nty, ntx);   // off the staging path; visible after the barriers below
-        if constexpr (HINT) {
-            // under the level-0 gathers: the exact windows of levels 1..3 (waves 1..3; visible after B2, staged in round 1);
-            // wave 0 files the tile's level-0 box as the next launch's hint and requests the next tile's
-            if (hinted && wave >= 1 && wave < NL) exact_geometry(par, wave);
-            if (wave == 0) {
-                hint_store(par, item);
-                if (has_next) hint_dma(next_item);
-            }
-        }
         if (iter == 0) stamp(5);
         all_passes(std::integral_constant<int, R0>{}, std::true_type{});
         if (iter == 0) stamp(6);
@@ -871,11 +741,6 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         if (iter == 0) stamp(13);
         __syncthreads();   // B3
         if (iter == 0) stamp(7);
-        if constexpr (HINT)
-            if (has_next && wave == 0) {   // the next tile's tables are visible since B2, its hint words landed before B3
-                const int hraw[4] = {s_hint[0], s_hint[1], s_hint[2], s_hint[3]};
-                hint_file(par ^ 1, hraw);
-            }
         all_passes(std::integral_constant<int, R1>{}, std::true_type{});
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps)
@@ -893,20 +758,12 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
         if (!has_next) break;
 
         // ---- the next tile: prologue arithmetic and bounding boxes (its points arrived during the gathers) ----
-        if constexpr (HINT) {
-            // the next tile's points are requested and stay in flight over the loop edge (straight into `cur`: no copy that
-            // would wait for them); the barrier frees the window rows for its level-0 DMA and publishes its window table
-            decode_queries(par ^ 1, nb, nm, cur);
-            issue_loads(cur, nref);
-            __syncthreads();   // Bs
-        } else {
-            decode_queries(par ^ 1, nb, nm, nxt);
-            issue_loads(nxt, rr);
-            finish_points(nxt, rr);
-            bbox(nxt, par ^ 1);
-            cur = nxt;
-        }
+        decode_queries(par ^ 1, nb, nm, nxt);
+        issue_loads(nxt, rr);
+        finish_points(nxt, rr);
+        bbox(nxt, par ^ 1);
         if (iter == 0) stamp(9);
+        cur = nxt;
         item = next_item;
         par ^= 1;
         ++iter;
@@ -915,19 +772,20 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 }
 
 // ---- options, tile plan, launch ------------------------------------------------------------------------------
-enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoThreads, kPoHint, kPoCount };
+enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoCount };
 const char *const kPqOptNames[kPoCount] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
                                            "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew",
-                                           "pquad", "pquad_threads", "pquad_hint"};
-const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on", "thr", "hint"};
-constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 256, 1};   // 3 x 52 KB = 156 KB of the CU's 160
+                                           "pquad"};
+const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on"};
+constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1};   // 3 x 52 KB = 156 KB of the CU's 160
 std::atomic<int> g_pq_opt[kPoCount];
 std::atomic<int> g_pq_epoch{0};
 std::atomic<unsigned long long *> g_pq_trace{nullptr};
 
 int pq_max_wgs(int npass, int pf)   // = pq_min_waves<NPASS, PF>(): workgroups per CU the register budget admits
 {
-    return pf == 2 ? (npass == 1 ? 3 : 2) : (npass == 1 ? 4 : npass == 2 ? TF_PQUAD_NPASS2_WAVES : 2);
+    (void)pf;
+    return npass == 1 ? 4 : npass == 2 ? 3 : 2;
 }
 
 void pq_opts_init()
@@ -974,7 +832,7 @@ long long pq_tile_max_queries(const LevelTable &lt, int L, int th, int tw)
 struct PqPlan {
     PquadGeom geom;
     size_t lds;
-    int ta_mask, npass, wgs, pf, threads;
+    int ta_mask, npass, wgs, pf;
     bool wide;
 };
 
@@ -1000,12 +858,8 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     if (!o[kPoEnable]) return false;
     const int epoch = g_pq_epoch.load(std::memory_order_relaxed);
     const int ta = 0, npass = o[kPoNpass], pf = o[kPoPrefetch];
-    if (npass < 1 || npass > 3 || pf != 0 || o[kPoWgPerCu] < 1 || o[kPoSkew] < 0) return false;   // pf = 2 (register prefetch): removed
-    const int threads = o[kPoThreads];
-    if (threads != 256 && threads != 512) return false;
-    if (threads == 512 && (npass != 1 || pf != 0 || D != 32)) return false;   // the only eight-wave variant built
-    const int max_wgs = threads == 512 ? 2 : pq_max_wgs(npass, pf);
-    const int wgs = o[kPoWgPerCu] < max_wgs ? o[kPoWgPerCu] : max_wgs;
+    if (npass < 1 || npass > 3 || pf != 0 || o[kPoWgPerCu] < 1 || o[kPoSkew] < 0) return false;   // pquad_prefetch = 2: removed
+    const int wgs = o[kPoWgPerCu] < pq_max_wgs(npass, pf) ? o[kPoWgPerCu] : pq_max_wgs(npass, pf);
     if (o[kPoLdsKb] < 8 || o[kPoLdsKb] > 160 || o[kPoHaloY] < 0 || o[kPoHaloX] < 0 || o[kPoTileH] < 0 || o[kPoTileW] < 0)
         return false;
     for (int l = 0; l < L; ++l)
@@ -1035,7 +889,7 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     memo.D = D;
     memo.epoch = epoch;
     memo.lt = lt;
-    const long long cap_q = (long long)(threads / 4) * npass;
+    const long long cap_q = (long long)kPqPairs * npass;
     const long long slots = (long long)pq_num_cus() * wgs;
     int bth = 0, btw = 0;
     if (o[kPoTileH] > 0 && o[kPoTileW] > 0) {
@@ -1084,7 +938,6 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     r.wide = o[kPoWide] != 0;
     r.ta_mask = ta;
     r.npass = npass;
-    r.threads = threads;
     r.wgs = wgs;
     r.pf = pf;
     memo.plan = r;
@@ -1145,18 +998,6 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
         wide = wide && ((uintptr_t)da.loc % 16 == 0) && ((uintptr_t)da.attn % 16 == 0);
     const void *fn = D == 36 ? (fused ? pq_kernel_d36<true>(wide) : pq_kernel_d36<false>(wide))
                              : (fused ? pq_kernel<true>(pl.npass, wide) : pq_kernel<false>(pl.npass, wide));
-    if (pl.threads == 512) {
-        if (!wide) return false;
-        fn = fused ? (const void *)&msda_fwd_f32_pquad<true, 0, 1, 0, true, 32, 512>
-                   : (const void *)&msda_fwd_f32_pquad<false, 0, 1, 0, true, 32, 512>;
-    }
-    pl.geom.hint = nullptr;
-    if (da.hint != nullptr && g_pq_opt[kPoHint].load(std::memory_order_relaxed) != 0 && D == 32 && pl.npass == 2 &&
-        pl.threads == 256 && wide && da.hint_words >= 4LL * pl.geom.n_items && ((uintptr_t)da.hint & 15) == 0) {
-        pl.geom.hint = da.hint;   // the hinted level-0 windows (the only configuration built)
-        fn = fused ? (const void *)&msda_fwd_f32_pquad<true, 0, 2, 0, true, 32, 256, true>
-                   : (const void *)&msda_fwd_f32_pquad<false, 0, 2, 0, true, 32, 256, true>;
-    }
     // the dynamic-LDS limit is a per-function, per-device attribute: cheap, set on every first (function, device)
     struct Raised { const void *fn; int dev; };
     static std::atomic<int> n_raised{0};
@@ -1180,16 +1021,8 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
     }
     pl.geom.trace = g_pq_trace.load(std::memory_order_relaxed);
     void *argv[] = {(void *)&da, (void *)&lt, (void *)&pl.geom};
-    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3((unsigned)pl.threads), argv, pl.lds, stream);
+    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kPqThreads), argv, pl.lds, stream);
     return true;
-}
-
-long long pquad_hint_words(const LevelTable &lt, int L, int M, int N, int D, int P, int S, int Lq)
-{
-    if (Lq != S || D != 32 || P != 4 || L > kPqLevels) return 0;
-    PqPlan pl;
-    if (!pq_plan(lt, L, M, N, D, &pl) || pl.npass != 2 || pl.threads != 256) return 0;
-    return 4LL * pl.geom.n_items;
 }
 
 int pquad_set_option(const char *name, int value)

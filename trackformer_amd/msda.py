@@ -30,8 +30,6 @@ import os as _os
 
 # inference fast path of MSDeformAttn.forward (fused projections + fused operator prologue)
 FUSED_INFERENCE = _os.environ.get("TF_MSDA_FUSED", "1") != "0"
-# window hints of the encoder kernel (tf_msda_forward_fused_hint_f32): one small table per layer and geometry
-WINDOW_HINTS = _os.environ.get("TF_MSDA_HINTS", "1") != "0"
 
 _HOST_SHAPE_ATTR = "_tf_msda_host_shapes"
 _shape_array_cache = {}
@@ -120,12 +118,11 @@ def _shape_args(spatial_shapes, value):
     return "_dshapes", ctypes.c_void_p(ss.data_ptr()), ss
 
 
-def ms_deform_attn_forward(value, spatial_shapes, sampling_loc, attn_weight, im2col_step=64, hint=None):
+def ms_deform_attn_forward(value, spatial_shapes, sampling_loc, attn_weight, im2col_step=64):
     """value[N,S,M,D], spatial_shapes[L,2] i64, sampling_loc[N,Lq,M,L,P,2], attn_weight[N,Lq,M,L,P]
     -> output[N,Lq,M*D].   Same contract as the reference's MSDA.ms_deform_attn_forward
     (src/cuda/ms_deform_attn_cuda.cu:19-86); `im2col_step` is validated like the reference does and
-    otherwise ignored (it never changed results).  hint (not in the reference): an int32 table from window_hints()
-    for repeated encoder-shaped fp32 calls -- performance only, see include/tf_msda.h."""
+    otherwise ignored (it never changed results)."""
     N, S, M, D, L, Lq, P = _check_inputs(value, spatial_shapes, sampling_loc, attn_weight,
                                          im2col_step)
     suf = _suffix(value.dtype)
@@ -144,14 +141,9 @@ def ms_deform_attn_forward(value, spatial_shapes, sampling_loc, attn_weight, im2
         out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         tail, shp, keep = _shape_args(spatial_shapes, value)
         stream = torch.cuda.current_stream().cuda_stream
-        if hint is not None and suf == "f32" and tail == "":
-            rc = lib.tf_msda_forward_hint_f32(
-                value.data_ptr(), shp, sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
-                N, S, M, D, L, Lq, P, hint.data_ptr(), hint.numel(), stream)
-        else:
-            rc = getattr(lib, "tf_msda_forward_%s%s" % (suf, tail))(
-                value.data_ptr(), shp, sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
-                N, S, M, D, L, Lq, P, stream)
+        rc = getattr(lib, "tf_msda_forward_%s%s" % (suf, tail))(
+            value.data_ptr(), shp, sampling_loc.data_ptr(), attn_weight.data_ptr(), out.data_ptr(),
+            N, S, M, D, L, Lq, P, stream)
     del keep
     _cabi.check(rc, "ms_deform_attn_forward")
     return out
@@ -194,22 +186,9 @@ def ms_deform_attn_backward(value, spatial_shapes, sampling_loc, attn_weight, gr
     return [grad_value, grad_loc, grad_attn]
 
 
-def window_hints(spatial_shapes, N, S, M, D, L, Lq, P, device):
-    """A zero-initialised window-hint table for calls of this shape (include/tf_msda.h: tf_msda_window_hint_words), or None
-    when the call shape uses none.  The caller keeps it per call site (a layer) and hands it to every call."""
-    hs = _host_shapes_of(spatial_shapes)
-    if hs is None:
-        return None
-    words = int(_cabi.lib().tf_msda_window_hint_words(ctypes.cast(_shape_array(hs), ctypes.c_void_p), N, S, M, D, L, Lq, P))
-    if words <= 0:
-        return None
-    return torch.zeros(words, dtype=torch.int32, device=device)
-
-
 def ms_deform_attn_forward_fused(value, spatial_shapes, reference_points, qproj, n_heads, n_levels,
-                                 n_points, hint=None):
+                                 n_points):
     """Inference-only fused operator: softmax + sampling-location arithmetic + sampling in one launch.
-    hint: optional int32 device tensor from window_hints() -- performance only, read and rewritten by the call.
 
     value [N,S,M,D]; reference_points [N,Lq,L,2|4]; qproj [N,Lq,3*M*L*P] = the query projected by the
     concatenated (sampling_offsets | attention_weights) Linear.  Equivalent to
@@ -228,16 +207,10 @@ def ms_deform_attn_forward_fused(value, spatial_shapes, reference_points, qproj,
     with torch.cuda.device(value.device):
         out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
         arr = _shape_array(hs)
-        if hint is not None:
-            rc = lib.tf_msda_forward_fused_hint_f32(
-                value.data_ptr(), ctypes.cast(arr, ctypes.c_void_p), reference_points.data_ptr(),
-                reference_points.shape[-1], qproj.data_ptr(), qproj.shape[-1], 0, 2 * M * L * P,
-                out.data_ptr(), N, S, M, D, L, Lq, P, hint.data_ptr(), hint.numel(), torch.cuda.current_stream().cuda_stream)
-        else:
-            rc = lib.tf_msda_forward_fused_f32(
-                value.data_ptr(), ctypes.cast(arr, ctypes.c_void_p), reference_points.data_ptr(),
-                reference_points.shape[-1], qproj.data_ptr(), qproj.shape[-1], 0, 2 * M * L * P,
-                out.data_ptr(), N, S, M, D, L, Lq, P, torch.cuda.current_stream().cuda_stream)
+        rc = lib.tf_msda_forward_fused_f32(
+            value.data_ptr(), ctypes.cast(arr, ctypes.c_void_p), reference_points.data_ptr(),
+            reference_points.shape[-1], qproj.data_ptr(), qproj.shape[-1], 0, 2 * M * L * P,
+            out.data_ptr(), N, S, M, D, L, Lq, P, torch.cuda.current_stream().cuda_stream)
     _cabi.check(rc, "ms_deform_attn_forward_fused")
     return out
 
@@ -355,26 +328,6 @@ class MSDeformAttn(nn.Module):
         return self._forward(query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask, query_attn_mask,
                              None, query_pos)
 
-    def _window_hints(self, hs, N, Len_in, Len_q, value):
-        """This layer's window-hint table for the call shape (encoder self-attention only: Lq == S), created on first use
-        outside a HIP-graph capture (a captured graph keeps its address: entries are never evicted, they are 16 bytes per
-        tile and head).  One table per calling THREAD: a tracker thread steps through one sequence, so its tables follow
-        that sequence's frames, and what another sequence does never changes this one's results (the table steers when
-        staging starts, and with that the fp32 summation order of the few points that fall outside a hinted window)."""
-        if Len_q != Len_in or not WINDOW_HINTS:
-            return None
-        import threading
-        key = (hs, N, value.device, threading.get_ident())
-        cache = self.__dict__.setdefault("_window_hint_tables", {})
-        if key not in cache:
-            if torch.cuda.is_current_stream_capturing() or len(cache) >= 64:
-                return None
-            M = self.n_heads
-            probe = torch.empty(0, device=value.device)
-            attach_host_shapes(probe, hs)
-            cache[key] = window_hints(probe, N, Len_in, M, self.d_model // M, self.n_levels, Len_q, self.n_points, value.device)
-        return cache[key]
-
     def _forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_padding_mask, query_attn_mask,
                  residual_norm, query_pos=None):
         N, Len_q, _ = query.shape
@@ -409,7 +362,7 @@ class MSDeformAttn(nn.Module):
             if qproj is None:
                 qproj = F.linear(query, w, b)
             output = ms_deform_attn_forward_fused(value, input_spatial_shapes, reference_points,
-                                                  qproj, M, L, P, hint=self._window_hints(hs, N, Len_in, Len_q, value))
+                                                  qproj, M, L, P)
             if residual_norm is not None:
                 y = fused.linear_residual_norm(output, self.output_proj, residual_norm[0], residual_norm[1])
                 if y is not None:

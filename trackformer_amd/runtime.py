@@ -23,12 +23,18 @@ _TUNING_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
 _configured = False
 
 
-def configure_inference(tune=False, miopen_find=True, tunable_file=None, verbose=False):
-    """Idempotent.  Call once per process before the first forward."""
+def configure_inference(tune=False, miopen_find=True, tunable_file=None, verbose=False, host_threads=4):
+    """Idempotent.  Call once per process before the first forward.
+    host_threads: cap of torch's intra-op CPU threads (None: leave it).  The association leg of Tracker.step works on host
+    tensors of a few hundred boxes (NMS masks, IoU matrices, the packed copy); with torch's default of one thread per
+    core a 250 x 250 `triu` pays the fork / join of 128 threads: measured on the MI355X box with ~100 live tracks and
+    ~150 detections per frame, 52 ms per step at the default against the GPU forward's 3 ms (profiles/r03_host_profile_*)."""
     global _configured
     if _configured:
         return
     _configured = True
+    if host_threads is not None and torch.get_num_threads() > host_threads:
+        torch.set_num_threads(int(host_threads))
     if not torch.cuda.is_available():
         return
     if miopen_find:

