@@ -302,7 +302,7 @@ class Tracker:
         packed_dev = torch.cat([boxes_dev, result['scores'][:, None],
                                 result['labels'][:, None].to(boxes_dev.dtype)], dim=1)
         event = host = None
-        if packed_dev.is_cuda:
+        if packed_dev.device.type == "cuda":
             host = self.__dict__.get("_packed_host")
             if host is None or host.shape[0] < packed_dev.shape[0]:
                 host = self.__dict__["_packed_host"] = torch.empty((max(1024, 2 * packed_dev.shape[0]), 6), dtype=torch.float32,
@@ -386,7 +386,7 @@ class Tracker:
                 if remove_tracks:
                     self._logger(f'REMOVE TRACK IDS (track_nms_thresh={self.track_nms_thresh}): '
                                  f'{[t.id for t in remove_tracks]}')
-                self.tracks = [t for t in self.tracks if t not in remove_tracks]
+                self.tracks = [t for i, t in enumerate(self.tracks) if i in keep]   # (a list membership test per track was O(n^2))
 
         # ---------------------------------------------------------------- new detections
         new_det_keep = (scores[-nq:] > self.detection_obj_score_thresh) & is_person[-nq:]
@@ -427,7 +427,8 @@ class Tracker:
         # ---------------------------------------------------------------- NMS new vs. existing
         if self.detection_nms_thresh and self.tracks:
             track_scores = torch.stack([t.score for t in self.tracks]).clone()
-            is_new = torch.tensor([t.id in new_track_ids for t in self.tracks])
+            new_ids = set(new_track_ids)
+            is_new = torch.tensor([t.id in new_ids for t in self.tracks])
             track_scores[~is_new] = np.inf   # existing tracks always win against new detections
             keep = set(nms(torch.stack([t.pos for t in self.tracks]), track_scores,
                            self.detection_nms_thresh).tolist())
@@ -436,7 +437,7 @@ class Tracker:
                 self._logger(
                     f'REMOVE TRACK IDS (detection_nms_thresh={self.detection_nms_thresh}): '
                     f'{[t.id for t in remove_tracks]}')
-            self.tracks = [t for t in self.tracks if t not in remove_tracks]
+            self.tracks = [t for i, t in enumerate(self.tracks) if i in keep]
 
         # ---------------------------------------------------------------- results
         if 'masks' in result:
