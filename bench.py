@@ -102,13 +102,16 @@ CONFIGS = {
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 120 (cfg 1/2/4/5), 6 (cfg 3)")
+    ap.add_argument("--steps", type=int, default=None, help="default: 120 (cfg 1/2/4), 24 (cfg 5), 6 (cfg 3)")
     ap.add_argument("--warmup", type=int, default=None, help="default: 8 (cfg 1/2/4/5), 2 (cfg 3)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="repeat the K-step set until this much timed work has accumulated")
     ap.add_argument("--no-graph", action="store_true", help="run the detector eagerly (no HIP graph)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true",
+                    help="(internal) time the CPU leg of --config and print its JSON object: the main run starts this in a "
+                         "fresh process so that the leg gets torch's default one-thread-per-core set-up")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-sequence", action="store_true")
     ap.add_argument("--no-fp32-exact", action="store_true",
@@ -143,10 +146,11 @@ def parse_args():
                          "Tracker.step_async / step_finish); frames of one sequence stay strictly sequential")
     args = ap.parse_args()
     train = CONFIGS[args.config]["kind"] == "train"
+    heavy = args.config == "cfg5"   # ~100 full-size masks per frame reach the host: tens of ms per step
     if args.steps is None:
-        args.steps = 6 if train else 120
+        args.steps = 6 if train else 24 if heavy else 120
     if args.warmup is None:
-        args.warmup = 2 if train else 8
+        args.warmup = 2 if train else 4 if heavy else 8
     return args
 
 
@@ -490,13 +494,26 @@ def cpu_operator(kind):
     return HostOp
 
 
+def cpu_baseline_in_fresh_process(args):
+    """The CPU leg in its own interpreter: this process has capped torch's intra-op threads for the association leg, holds a
+    HIP context and pinned buffers; re-raising the thread count here left the leg ~10x slower on the MI355X box than in
+    a process that never touched it (round 3, gpu_r03_16.sh).  A fresh process is what a CPU-only user would run."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""     # the leg must not touch the GPU
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config, "--cpu-frames", str(args.cpu_frames)]
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, check=True, text=True).stdout
+        return json.loads(out.strip().splitlines()[-1])
+    except (subprocess.SubprocessError, ValueError, IndexError) as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+
+
 def measure_cpu_baseline(cfg, frames):
     """The same workload on the host: identical modules on CPU; MSDeformAttn = the reference's pure-CPU
     path restated (grid_sample), and, as a second figure, the C port of the kernels' arithmetic."""
     from trackformer_amd import msda
-    # every host core for the CPU leg (the inference set-up capped torch's intra-op threads for the association leg)
-    torch.set_num_threads(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    cores = torch.get_num_threads()
+    cores = torch.get_num_threads()   # a fresh process (cpu_baseline_in_fresh_process): torch's default, one thread per core
     cpu = torch.device("cpu")
     model, criterion, post, margs = build_model(cfg, cpu)
     saved = msda.MSDeformAttnFunction
@@ -658,7 +675,13 @@ def run_training(cfg, args, device, world, rank, model, criterion, margs):
 
 
 def main():
+    if os.environ.get("TF_BENCH_WATCHDOG"):   # debugging aid: dump every thread's stack after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["TF_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     args = parse_args()
+    if args.cpu_baseline_only:   # no GPU, no process group: the host leg alone
+        print(json.dumps(measure_cpu_baseline(CONFIGS[args.config], args.cpu_frames)))
+        return
     rank, local_rank, world = init_distributed(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the product path)")
@@ -701,7 +724,7 @@ def main():
             print(json.dumps(measure_roofline(device, head_dim=hd, patterns=("pert", "init", "local"))))
         return
     model, criterion, post, margs = build_model(cfg, device)
-    single = fp32_exact = association = None
+    single = fp32_exact = association = multi = None
     n_seq = 1
     if cfg["kind"] == "track":
         model.tracking()
@@ -710,7 +733,6 @@ def main():
         if not args.no_calibration and cfg["tracks"] > 0:
             seeds = calibrate_association(model, make_frames(device, cfg["size"], n=1)[0], cfg["tracks"], cfg["size"], device)
         elapsed, reps = run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds)
-        multi = None
         if n_seq > 1 and not args.no_single_sequence:
             e1, r1 = run_tracking(cfg, args, device, world, model, post, margs, 1, seeds)
             single = args.steps * r1 * world / e1
@@ -749,7 +771,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del model
             torch.cuda.empty_cache()
-            cpu_baseline = measure_cpu_baseline(cfg, args.cpu_frames)
+            cpu_baseline = cpu_baseline_in_fresh_process(args)
 
     ranks = None
     if world > 1:

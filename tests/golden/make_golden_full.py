@@ -82,6 +82,17 @@ def tracker_case(ref, n_frames=None):
             all_scores.append(res[0]['scores'].detach().clone())
             return res
     post = dict(post, bbox=Recording())
+    # ... and how close any pair of boxes an NMS pass looks at comes to its IoU threshold, per frame
+    nms_margin = []
+    real_nms = ref.tracker.nms
+
+    def recording_nms(boxes, scores, thr):
+        if boxes.shape[0] > 1:
+            iou = ref.tracker.box_iou(boxes, boxes)
+            iou = iou[~torch.eye(len(iou), dtype=torch.bool)]
+            nms_margin[-1] = min(nms_margin[-1], float((iou - thr).abs().min()))
+        return real_nms(boxes, scores, thr)
+    ref.tracker.nms = recording_nms
     tracker = ref.tracker.Tracker(model, post, cfg, False)
     tracker.reset()
     active = []
@@ -89,6 +100,7 @@ def tracker_case(ref, n_frames=None):
     frames = um.full_tracker_sequence() if n_frames is None else um.full_tracker_sequence(n_frames=n_frames)
     with torch.no_grad():
         for blob in frames:
+            nms_margin.append(float("inf"))
             tracker.step(blob)
             active.append(len(tracker.tracks))
             print("  frame %d: %d active tracks (%.0f s)" % (len(active), active[-1], time.time() - t0),
@@ -104,7 +116,10 @@ def tracker_case(ref, n_frames=None):
     path = os.path.join(HERE, "full_tracker_cfg2.npz" if n_frames is None else "full_tracker_cfg2_%d.npz" % n_frames)
     np.savez_compressed(path, rows=rows, active_per_frame=np.array(active),
                         num_tracks=np.int64(tracker.track_num), num_reids=np.int64(tracker.num_reids),
-                        min_score_margin=np.float64(min_margin), score_thresholds=np.array(thresholds))
+                        min_score_margin=np.float64(min_margin), score_thresholds=np.array(thresholds),
+                        nms_iou_margin_per_frame=np.array(nms_margin))
+    ref.tracker.nms = real_nms
+    print("smallest |IoU - NMS threshold| per frame:", ["%.1e" % m for m in nms_margin])
     print("smallest |score - threshold| over every query of every frame: %.3e (thresholds %s)" % (min_margin, thresholds))
     print("tracker: %d ids, active %s, smallest |score - threshold| of a kept track %.2e -> %s" % (
         tracker.track_num, active, margin, os.path.basename(path)), flush=True)

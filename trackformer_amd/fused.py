@@ -713,5 +713,7 @@ def mha_core(qk, v, num_heads, key_padding_mask=None):
         q_ptr = qk.data_ptr()
         rc = _cabi.lib().tf_mha_core_f32(q_ptr, q_ptr + e * 4, v.data_ptr(), out.data_ptr(), mask_ptr, n, length, length,
                                          num_heads, d, e2, e2, e, e, float(d) ** -0.5, _stream(qk.device))
+    if rc == -2:   # TF_MSDA_ERR_BAD_DIMS: more keys than the score tile has LDS for -> the caller keeps torch's SDPA
+        return None
     _cabi.check(rc, "tf_mha_core_f32")
     return out

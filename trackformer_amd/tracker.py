@@ -442,6 +442,7 @@ class Tracker:
         # ---------------------------------------------------------------- results
         if 'masks' in result:
             self._resolve_masks(outputs, results, orig_size, blob["size"].to(device))
+        masks_host = None
         if 'masks' in result and self.tracks:
             probs = torch.stack([t.mask for t in self.tracks])
             index_map = torch.arange(probs.size(0), device=probs.device)[:, None, None]
@@ -449,6 +450,7 @@ class Tracker:
                                             index_map.expand_as(probs) == probs.argmax(dim=0))
             for i, track in enumerate(self.tracks):
                 track.mask = track_masks[i]
+            masks_host = track_masks.cpu().numpy()   # ONE copy for all tracks (the results hold a full-size mask per track)
 
         if self.tracks:   # one stack + one numpy view for all tracks instead of three conversions per track
             all_pos = torch.stack([t.pos for t in self.tracks])
@@ -462,7 +464,7 @@ class Tracker:
             entry['score'] = all_scores[i:i + 1].reshape(()).copy()   # 0-d array, as tensor.numpy().copy() gives
             entry['obj_ind'] = track.obj_index
             if track.mask is not None:
-                entry['mask'] = track.mask.cpu().numpy()
+                entry['mask'] = masks_host[i] if masks_host is not None else track.mask.cpu().numpy()
             if track.attention_map is not None:
                 entry['attention_map'] = track.attention_map.cpu().numpy()
 
@@ -485,9 +487,9 @@ class Tracker:
             # lazy mask head: evaluate it for the referenced queries now (the context aliases this frame's buffers)
             module = getattr(self.obj_detector, "model", self.obj_detector)
             hs = outputs['hs_embed']
-            # the row count is rounded up to a multiple of 8 (the last row repeated): the convolution library tunes per
-            # shape, and the number of live tracks changes from frame to frame
-            padded = refs + [refs[-1]] * (-len(refs) % 8)
+            # the row count is rounded up to a multiple of 32 (the last row repeated): the convolution library tunes per
+            # shape (seconds per new shape in find mode), and the number of live tracks changes from frame to frame
+            padded = refs + [refs[-1]] * (-len(refs) % 32)
             idx = torch.tensor(padded, dtype=torch.long, device=hs.device)
             with torch.no_grad():
                 rows = module.mask_rows(outputs['mask_context'], hs.index_select(1, idx))[:, :len(refs)]
