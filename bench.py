@@ -464,7 +464,7 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
         kernel = "msda_fwd_f32_pquad<D=36>"   # head dimension 36 (hidden 288): 144-byte rows, 3 lanes x 12 channels
     traffic = None
     try:
-        with open(os.path.join(REPO, "profiles", "r02_msda_fwd_pquad_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r03_msda_fwd_pquad_traffic.json")) as f:
             traffic = json.load(f)[kernel]["hbm_traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
@@ -474,6 +474,23 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
             "launches": launches, "input_sets": sets,
             "pattern": "pert (perturbed-weight model sampling), Infinity-Cache-cold",
             "other_patterns": {k: v for k, v in per_pattern.items() if k != "pert"}}
+
+
+def committed_mfma_utilisation():
+    """Matrix-core utilisation of the dense kernels, from the committed counter pass of this round: PMC counters
+    need their own rocprofv3 run (profiles/r03_mfma_utilisation.json, tools/gpu_runs/gpu_r03_15.sh).  Utilisation =
+    SQ_VALU_MFMA_BUSY_CYCLES (summed over all SIMDs) / (dispatch duration x 2.4 GHz x 1024 SIMDs): it cannot exceed 1."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r03_mfma_utilisation.json")) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    frame = {k: round(v["mfma_util"], 3) for k, v in d.get("mfma_frame", {}).items() if "mfma_util" in v}
+    return {"source": "profiles/r03_mfma_utilisation.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, own pass)",
+            "per_kernel_in_an_eager_cfg2_frame": frame,
+            "harness": {"tf_ffn_fused_f32 22223x256x1024": round(d["mfma_ffn"]["ffn_fused_kernel"]["mfma_util"], 3),
+                        "tf_linear_packed_f32 22223x256->1024": round(d["mfma_lin1"]["split_gemm_stream_kernel"]["mfma_util"], 3),
+                        "tf_linear_split_f32 22223x256->256": round(d["mfma_lin2"]["split_gemm_kernel"]["mfma_util"], 3)}}
 
 
 def cpu_operator(kind):
@@ -762,12 +779,14 @@ def main():
     else:
         elapsed, reps = run_training(cfg, args, device, world, rank, model, criterion, margs)
 
-    roofline = cpu_baseline = parity = None
+    roofline = cpu_baseline = parity = mfma = None
     if rank == 0:
         if not args.no_roofline and margs.deformable:
             roofline = measure_roofline(device, train=train, head_dim=margs.hidden_dim // margs.nheads)
         if args.config == "cfg2" and not args.no_parity and not args.no_graph:
             parity = measure_parity(device)
+        if not train and margs.deformable:
+            mfma = committed_mfma_utilisation()
         if world == 1 and not args.no_cpu_baseline:
             del model
             torch.cuda.empty_cache()
@@ -816,7 +835,7 @@ def main():
             "single_sequence_fps": None if single is None else round(single, 3),
             "multi_sequence_fps": None if multi is None else {"sequences_per_gpu": max(1, args.sequences), "value": round(multi, 3)},
             "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
-            "association": association, "parity": parity, "ranks": ranks,
+            "association": association, "parity": parity, "ranks": ranks, "mfma_utilisation": mfma,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line))

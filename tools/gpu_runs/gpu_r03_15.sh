@@ -47,11 +47,19 @@ PY
 head -12 $O/bench_kernel_stats_top45.csv | cut -c1-200
 # 5. backward kernel: tile / halo sweep of msda_bwd_f32_sorted2 at the encoder shapes
 {
-for tile in "" "8,8" "6,16" "12,8" "16,8" "10,16" "4,16"; do
-  for halo in "" "6,10" "5,8"; do
+for tile in "" "8,8" "12,8" "6,16"; do
+  for halo in "" "6,10"; do
     echo "## TF_MSDA_BWD_TILE='$tile' TF_MSDA_BWD_HALO='$halo'"
     env ${tile:+TF_MSDA_BWD_TILE=$tile} ${halo:+TF_MSDA_BWD_HALO=$halo} timeout 100 python tools/bench_msda.py --shapes cfg3_encoder_n2 --no-forward --modes local,init 2>&1 | grep -v amdgpu
   done
 done
 } > $O/bwd_sweep.txt 2>&1
 cat $O/bwd_sweep.txt
+
+# 6. the 64-frame tracker fixture, cfg 5 line
+cd $R
+timeout 300 python -m pytest tests/test_full_size_gpu.py -m gpu -q -x -s -k "64_frame" > $O/pytest64.txt 2>&1
+grep -E "64-frame fixture|passed|failed" $O/pytest64.txt | cut -c1-300
+TF_BENCH_WATCHDOG=120 timeout 240 python bench.py --config cfg5 --no-cpu-baseline --no-roofline > $O/bench_cfg5.json 2> $O/bench_cfg5.err
+echo "cfg5 rc $?"; grep -v amdgpu $O/bench_cfg5.err | tail -12 | cut -c1-160
+python tools/summarize_bench.py $O
