@@ -23,7 +23,12 @@ HBM, 300 object queries + exactly 100 track queries per frame, batch 1, fp32, we
 initialisation (no checkpoints / datasets exist offline).  One step = one `Tracker.step(blob)`:
 detector forward, post-processing, the single packed device->host copy and the host-side association
 (thresholds, NMS, id bookkeeping).  Before every step the tracker is re-seeded with the same 100
-synthetic tracks so that each step has exactly 300+100 queries.
+tracks so that each step has exactly 300+100 queries.  Since round 3 the association leg has work to do: the "person"
+output of the last class head is rescaled / shifted on frame 0 (calibrate_association) so that about half of the 400 queries
+pass the 0.4 thresholds and the seeded tracks are that frame's top-100 outputs -- ~98 seeded tracks survive a step, ~150
+detections go through NMS and add_tracks (`association` in the line; --no-calibration: the default-initialised head, no
+query passes, the leg idles as in rounds 1-2).  Several sequences per GPU are interleaved in ONE host thread
+(Tracker.step_async / step_finish); `value` is the faster of --sequences (3) and one sequence, both are in the line.
 
 Multi-GPU: the path shards by video sequence (engine.py:289-303 of the reference); every rank tracks
 its own sequence on its own GPU, there is no collective in the data path ("scaling": "weak").  RCCL is
@@ -45,8 +50,13 @@ The JSON line also carries
                    pure-CPU MSDeformAttn path (grid_sample, oracle/msda_grid_sample.py: "kind":
                    "reference-restated"); the C port of the kernels' arithmetic (oracle/msda_ref.c)
                    timed beside it; rank 0, N=1 only, a bounded sample.
-  single_sequence_fps -- cfg2/4/5: the same steps with ONE sequence per GPU (no overlap of one
-                   sequence's host-side association with another's forward).
+  single_sequence_fps / multi_sequence_fps -- cfg2/4/5: the same steps with ONE sequence per GPU (no overlap of one
+                   sequence's host-side association with another's forward) / with --sequences interleaved.
+  fp32_exact_fps -- the same measurement with every matrix product in fp32 (hipBLASLt linears, library convolutions).
+  association   -- what the association leg did in four untimed steps (survivors, initialised, alive).
+  parity        -- cfg2: in-run check against the committed reference goldens (max |d boxes|, max |d logits|, ids equal).
+  mfma_utilisation -- matrix-core utilisation of the dense kernels from this round's committed counter pass.
+  ranks         -- N > 1: what every rank runs on, gathered over the job's own backend.
 """
 import argparse
 import json
