@@ -95,7 +95,8 @@ class Tracker:
         self._prev_features = deque([None], maxlen=self.prev_frame_dist)
         if hard:
             self.track_num = 0
-            self.results = {}
+            self._results = {}
+            self._pending_results = []
             self.frame_index = 0
             self.num_reids = 0
 
@@ -458,15 +459,18 @@ class Tracker:
                 all_pos = clip_boxes_to_image(all_pos, (orig_h, orig_w))
             all_pos = all_pos.numpy()
             all_scores = torch.stack([t.score for t in self.tracks]).numpy()
-        for i, track in enumerate(self.tracks):
-            entry = self.results.setdefault(track.id, {})[self.frame_index] = {}
-            entry['bbox'] = all_pos[i].copy()
-            entry['score'] = all_scores[i:i + 1].reshape(()).copy()   # 0-d array, as tensor.numpy().copy() gives
-            entry['obj_ind'] = track.obj_index
-            if track.mask is not None:
-                entry['mask'] = masks_host[i] if masks_host is not None else track.mask.cpu().numpy()
-            if track.attention_map is not None:
-                entry['attention_map'] = track.attention_map.cpu().numpy()
+        if self.tracks:
+            # the frame's rows are filed as arrays; the reference's {track id: {frame: {...}}} layout is built from them when
+            # somebody reads `results` / get_results() (per track and frame that is a dict and three objects: ~0.3 ms per
+            # frame at 150 live tracks, off the per-frame path now)
+            extras = None
+            if any(t.mask is not None or t.attention_map is not None for t in self.tracks):
+                extras = [(masks_host[i] if (masks_host is not None and t.mask is not None) else
+                           (t.mask.cpu().numpy() if t.mask is not None else None),
+                           t.attention_map.cpu().numpy() if t.attention_map is not None else None)
+                          for i, t in enumerate(self.tracks)]
+            self._pending_results.append((self.frame_index, [t.id for t in self.tracks], all_pos, all_scores,
+                                          [t.obj_index for t in self.tracks], extras))
 
         for t in self.inactive_tracks:
             t.count_inactive += 1
@@ -513,6 +517,30 @@ class Tracker:
         for t in self.inactive_tracks:      # references of tracks that left the active set are never read
             if isinstance(t.mask, _MaskRef):
                 t.mask = None
+
+    @property
+    def results(self):
+        """{track_id: {frame_idx: {'bbox': xyxy px, 'score', 'obj_ind', ['mask'], ['attention_map']}}} (tracker.py:523-541 of
+        the reference): the frames filed since the last access are merged in here."""
+        pending, self._pending_results = self._pending_results, []
+        for frame, ids, pos, scores, obj_inds, extras in pending:
+            for i, tid in enumerate(ids):
+                entry = self._results.setdefault(tid, {})[frame] = {}
+                entry['bbox'] = pos[i].copy()
+                entry['score'] = scores[i:i + 1].reshape(()).copy()   # 0-d array, as tensor.numpy().copy() gives
+                entry['obj_ind'] = obj_inds[i]
+                if extras is not None:
+                    mask, amap = extras[i]
+                    if mask is not None:
+                        entry['mask'] = mask
+                    if amap is not None:
+                        entry['attention_map'] = amap
+        return self._results
+
+    @results.setter
+    def results(self, value):
+        self._results = value
+        self._pending_results = []
 
     def get_results(self):
         """{track_id: {frame_idx: {'bbox': xyxy px, 'score', 'obj_ind', ['mask'], ['attention_map']}}}"""
