@@ -52,12 +52,18 @@ def test_fold_cache_keeps_a_persistent_2d_weight_for_1x1_convolutions():
     bn = backbone.FrozenBatchNorm2d(16)
     bn.weight.uniform_(0.5, 1.5)
     cache = backbone._FoldCache()
-    w, b = cache.get(conv, bn)
+    b = cache.get(conv, bn)
+    assert cache._weight is None and cache._weight2d is None      # nothing is materialised before a route asks for it
     w2 = cache.weight2d
     assert w2 is not None and w2.shape == (16, 8) and w2.is_contiguous()
-    assert torch.equal(w2, w.reshape(16, 8))
+    assert cache._weight is None                       # the split route never pays for the 4-d image
+    assert torch.equal(w2, cache.weight.reshape(16, 8))
     cache.get(conv, bn)
     assert cache.weight2d is w2                        # same object: the split pieces cached on it stay valid
+    with torch.no_grad():
+        bn.weight.mul_(2.0)                            # a source tensor changed: every image is rebuilt
+    cache.get(conv, bn)
+    assert cache.weight2d is not w2 and torch.allclose(cache.weight2d, 2.0 * w2)
     conv3 = torch.nn.Conv2d(8, 16, 3, bias=False)
     c3 = backbone._FoldCache()
     c3.get(conv3, bn)
@@ -70,7 +76,8 @@ def test_fold_cache_tap_major_weight_of_3x3_convolutions():
     bn = backbone.FrozenBatchNorm2d(16)
     bn.weight.uniform_(0.5, 1.5)
     cache = backbone._FoldCache()
-    w, b = cache.get(conv, bn)
+    b = cache.get(conv, bn)
+    w = cache.weight
     t = cache.weight_taps
     assert t is not None and t.shape == (16, 72) and t.is_contiguous() and cache.weight2d is None
     assert torch.equal(t.view(16, 3, 3, 8), w.permute(0, 2, 3, 1))

@@ -136,31 +136,58 @@ class FrozenBatchNorm2d(nn.Module):
 
 
 class _FoldCache:
-    """conv weight with the following FrozenBN folded in; refreshed when any source tensor changes."""
+    """conv weight with the following FrozenBN folded in; refreshed when any source tensor changes.  Only the image the
+    active route needs is materialised: the [Cout, Cin] / tap-major [Cout, 9 Cin] matrix of the split-product routes (the
+    defaults), or the 4-d weight of the library convolution when a layer takes that path (route switched off, shape on the
+    skip list, CPU tensors) -- not all of them for every layer (~90 MB of copies for ResNet-50 otherwise)."""
 
     def __init__(self):
         self.key = None
-        self.weight = None
         self.bias = None
-        self.weight2d = None   # [Cout, Cin] of a 1 x 1 convolution (a persistent tensor: fused.linear caches its pieces on it)
-        self.weight_taps = None   # [Cout, 9 * Cin] of a 3 x 3 convolution, tap-major
+        self._conv = self._bn = None
+        self._weight = None        # 4-d, library path
+        self._weight2d = None      # [Cout, Cin] of a 1 x 1 convolution (a persistent tensor: fused.linear caches its pieces on it)
+        self._weight_taps = None   # [Cout, 9 * Cin] of a 3 x 3 convolution, tap-major
+
+    def _scaled(self):
+        with torch.no_grad():
+            scale, _ = self._bn.scale_shift()
+            return self._conv.weight * scale.reshape(-1, 1, 1, 1)
+
+    @property
+    def weight(self):
+        if self._weight is None:
+            w = self._scaled()
+            self._weight = w.contiguous(memory_format=torch.channels_last) if CHANNELS_LAST else w.contiguous()
+        return self._weight
+
+    @property
+    def weight2d(self):
+        if self._weight2d is None and self._conv.kernel_size == (1, 1):
+            w = self._scaled()
+            self._weight2d = w.reshape(w.shape[0], w.shape[1]).contiguous()
+        return self._weight2d
+
+    @property
+    def weight_taps(self):
+        if self._weight_taps is None and self._conv.kernel_size == (3, 3):
+            w = self._scaled()
+            # [Cout, 3, 3, Cin] -> [Cout, 9 * Cin]: the storage order of the channels_last weight (tap-major K)
+            self._weight_taps = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous()
+        return self._weight_taps
 
     def get(self, conv: nn.Conv2d, bn: FrozenBatchNorm2d):
+        """-> the folded shift (bias); the weight images are the properties above."""
         srcs = (conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var)
         key = tuple((t.data_ptr(), t._version, t.device, t.dtype) for t in srcs)
         if key != self.key:
             with torch.no_grad():
-                scale, shift = bn.scale_shift()
-                w = conv.weight * scale.reshape(-1, 1, 1, 1)
-                self.weight = w.contiguous(memory_format=torch.channels_last) if CHANNELS_LAST \
-                    else w.contiguous()
+                _, shift = bn.scale_shift()
                 self.bias = shift.contiguous()
-                self.weight2d = w.reshape(w.shape[0], w.shape[1]).contiguous() if w.shape[2:] == (1, 1) else None
-                # [Cout, 3, 3, Cin] -> [Cout, 9 * Cin]: the storage order of the channels_last weight (tap-major K)
-                self.weight_taps = (w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous()
-                                    if w.shape[2:] == (3, 3) else None)
+            self._conv, self._bn = conv, bn
+            self._weight = self._weight2d = self._weight_taps = None
             self.key = key
-        return self.weight, self.bias
+        return self.bias
 
 
 def _inference_mode(module: nn.Module) -> bool:
@@ -172,7 +199,7 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
     """conv -> frozen BN (-> + residual) (-> ReLU).  Inference on the GPU: one library convolution with
     the BN scale folded into its weights, then ONE fused pass for shift / residual / ReLU."""
     if fold and isinstance(bn, FrozenBatchNorm2d):
-        w, b = cache.get(conv, bn)
+        b = cache.get(conv, bn)
         if x.is_cuda:
             split_ok = _split_route_allowed(conv)   # False: this shape keeps the library convolution (TF_CONV_SPLIT_SKIP)
             if (split_ok and _conv1x1_split and cache.weight2d is not None and conv.stride == (1, 1) and conv.padding == (0, 0)
@@ -191,12 +218,12 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
                 y = fused.conv3x3(x, cache.weight_taps, b, relu, conv.stride[0])
                 if y is not None:
                     return y
-            y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+            y = F.conv2d(x, cache.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
             if fused.bias_act_(y, b, residual, relu) is not None:
                 return y
             y = y + b.reshape(1, -1, 1, 1)
         else:
-            y = F.conv2d(x, w, b, conv.stride, conv.padding, conv.dilation, conv.groups)
+            y = F.conv2d(x, cache.weight, b, conv.stride, conv.padding, conv.dilation, conv.groups)
         if residual is not None:
             y = y.add_(residual)
         return F.relu_(y) if relu else y
@@ -207,16 +234,17 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
 
 
 def _stem_pooled(x, conv1, bn1, maxpool, cache: _FoldCache):
-    """OPT-IN (fused.set_stem_pool_fused / TF_STEM_POOL_FUSED=1): conv1 (BN scale folded in) and then BN shift + ReLU +
-    MaxPool2d(3, 2, 1) in ONE pass over the convolution's output (tf_bias_relu_maxpool_f32; bit-identical to the separate
-    passes); (fused.set_stem_conv_split / TF_STEM_CONV_SPLIT=1): conv1 itself as a split product (tf_stem_conv7x7_f32).
-    Returns None when both routes are off or do not apply."""
+    """Defaults since round 3 (fused.set_stem_pool_fused / TF_STEM_POOL_FUSED=0 switches it off): conv1 (BN scale folded in)
+    and then BN shift + ReLU + MaxPool2d(3, 2, 1) in ONE pass over the convolution's output (tf_bias_relu_maxpool_f32;
+    bit-identical to the separate passes); (fused.set_stem_conv_split / TF_STEM_CONV_SPLIT=0): conv1 itself as a split
+    product (tf_stem_conv7x7_f32).  Returns None when both routes are off or do not apply."""
     if not ((fused.stem_pool_fused_enabled() or fused.stem_conv_split_enabled()) and x.is_cuda and CHANNELS_LAST
             and isinstance(bn1, FrozenBatchNorm2d)
             and isinstance(maxpool, nn.MaxPool2d) and maxpool.kernel_size == 3 and maxpool.stride == 2
             and maxpool.padding == 1 and maxpool.dilation == 1 and not maxpool.ceil_mode):
         return None
-    w, b = cache.get(conv1, bn1)
+    b = cache.get(conv1, bn1)
+    w = cache.weight   # the stem's packed image (fused.stem_conv) is cached on this tensor
     y = None
     if (conv1.kernel_size == (7, 7) and conv1.stride == (2, 2) and conv1.padding == (3, 3) and conv1.dilation == (1, 1)
             and conv1.groups == 1):

@@ -258,7 +258,16 @@ struct Conv3Args {
                    // sums to Y + z M N (no bias / ReLU) -- few output pixels with a long K (the extra pyramid level, layer4)
 };
 
-template <int BM, int BN, bool RELU>
+//
+// BUFLD (the default for inputs < 3 GiB; tf_msda_set_option("conv3_bufload", 0) / TF_CONV3_BUFLOAD=0 keeps the pointer loads):
+// the A rows and the weight pieces are fetched through buffer resources with 32-bit offsets.  A tap that falls outside the
+// image gets an offset beyond num_records and the hardware returns zeros, so nothing is selected AFTER the load: with
+// `v = *p; x = ok ? v : 0` the compiler placed the v_cndmask right behind each global_load (s_waitcnt vmcnt(0) between the
+// first A load and the remaining five of the slice, vmcnt(4) behind the second), i.e. the prefetch of slice s + 1 waited
+// for its own data BEFORE the MFMAs of slice s that were meant to cover it -- two exposed memory latencies per K-slice
+// (the ISA is quoted in DESIGN.md section 4.4).  The 64-bit address arithmetic (v_mad_i64 / v_mad_u64 chains per load)
+// goes away with it: per slice one uniform tap offset is added to per-thread constants.
+template <int BM, int BN, bool RELU, bool BUFLD, int NBUF = 1>
 __global__ void __launch_bounds__(THREADS)
 split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
                    const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
@@ -268,8 +277,9 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
     constexpr int XV = (BM * BK / 4) / THREADS;
     constexpr int WV = (BN * BK / 8) / THREADS;
     static_assert(XV >= 1 && WV >= 1, "tile too small for 256 threads");
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDS_STRIDE];   // [hi | mid][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDS_STRIDE];
+    static_assert(NBUF == 1 || NBUF == 2, "one LDS stage, or two (one barrier per slice)");
+    __shared__ __attribute__((aligned(16))) unsigned short sA[NBUF][2][BM * LDS_STRIDE];   // [stage][hi | mid][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[NBUF][2][BN * LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -300,7 +310,53 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
     }
     f32x4 xr[XV];
     u32x4 whr[WV], wmr[WV];
+    // BUFLD: byte offsets of this thread's pieces at tap (0, 0), channel 0 / at k = 0 (wrap-around arithmetic: a border
+    // pixel's window starts in front of the image, the sum with a valid tap's offset is back inside)
+    constexpr unsigned OOB = 0xC0000000u;   // >= num_records of every resource below (sizes are checked by the host)
+    unsigned xoff[XV], woff[WV];
+    __amdgpu_buffer_rsrc_t xrs, whrs, wmrs;
+    if constexpr (BUFLD) {
+        xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0,
+                                                (unsigned)((size_t)ca.nimg * ca.hin * ca.win * ca.cin * 4), 0x00020000);
+        whrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Whi), 0, (unsigned)((size_t)N * K * 2), 0x00020000);
+        wmrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Wmid), 0, (unsigned)((size_t)N * K * 2), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < XV; ++it)
+            xoff[it] = ((unsigned)((ibase[it] + ybase[it]) * ca.win + xbase[it]) * (unsigned)ca.cin
+                        + (unsigned)(((it * THREADS + tid) & 7) * 4)) * 4u;
+#pragma unroll
+        for (int it = 0; it < WV; ++it) {
+            const int idx = it * THREADS + tid;
+            woff[it] = ((unsigned)min(n0 + (idx >> 2), N - 1) * (unsigned)K + (unsigned)((idx & 3) * 8)) * 2u;
+        }
+    }
+    // BUFLD walks the slices in order and steps (channel, dx, dy) of the NEXT slice instead of dividing k0 per slice
+    int nc0 = 0, ndx = 0, ndy = 0;
     auto load_slice = [&](int k0) {
+        if constexpr (BUFLD) {
+            const int c0 = nc0, dx = ndx, dy = ndy;
+            nc0 += BK;
+            if (nc0 == ca.cin) {
+                nc0 = 0;
+                if (++ndx == ca.ks) {
+                    ndx = 0;
+                    ++ndy;
+                }
+            }
+            const unsigned tapoff = (unsigned)((dy * ca.win + dx) * ca.cin + c0) * 4u;   // uniform
+#pragma unroll
+            for (int it = 0; it < XV; ++it) {
+                const bool ok = rowok[it] && (unsigned)(ybase[it] + dy) < (unsigned)ca.hin
+                                && (unsigned)(xbase[it] + dx) < (unsigned)ca.win;
+                xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xoff[it] + tapoff : OOB, 0, 0));
+            }
+#pragma unroll
+            for (int it = 0; it < WV; ++it) {
+                whr[it] = __builtin_amdgcn_raw_buffer_load_b128(whrs, woff[it] + (unsigned)k0 * 2u, 0, 0);
+                wmr[it] = __builtin_amdgcn_raw_buffer_load_b128(wmrs, woff[it] + (unsigned)k0 * 2u, 0, 0);
+            }
+            return;
+        }
         const int tap = k0 / ca.cin, c0 = k0 - tap * ca.cin;   // uniform: the slice lies inside one tap
         const int dy = tap / ca.ks, dx = tap - dy * ca.ks;
 #pragma unroll
@@ -323,7 +379,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
             wmr[it] = *reinterpret_cast<const u32x4 *>(Wmid + g);
         }
     };
-    auto store_slice = [&]() {
+    auto store_slice = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
@@ -334,26 +390,28 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
                 hi[e] = (__bf16)xr[it][e];
                 mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
             }
-            *reinterpret_cast<bf16x4 *>(&sA[0][row * LDS_STRIDE + c4 * 4]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sA[1][row * LDS_STRIDE + c4 * 4]) = mid;
+            *reinterpret_cast<bf16x4 *>(&sA[buf][0][row * LDS_STRIDE + c4 * 4]) = hi;
+            *reinterpret_cast<bf16x4 *>(&sA[buf][1][row * LDS_STRIDE + c4 * 4]) = mid;
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = idx >> 2, c8 = idx & 3;
-            *reinterpret_cast<u32x4 *>(&sB[0][row * LDS_STRIDE + c8 * 8]) = whr[it];
-            *reinterpret_cast<u32x4 *>(&sB[1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
+            *reinterpret_cast<u32x4 *>(&sB[buf][0][row * LDS_STRIDE + c8 * 8]) = whr[it];
+            *reinterpret_cast<u32x4 *>(&sB[buf][1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
         }
     };
 
     const int kbeg = ca.kslices > 0 ? (int)blockIdx.z * ca.kslices * BK : 0;
     const int kend = ca.kslices > 0 ? min(K, kbeg + ca.kslices * BK) : K;
     if (ca.kslices > 0) Y += (size_t)blockIdx.z * M * N;   // this split's partial sums
-    load_slice(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        store_slice();
-        __syncthreads();
-        if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
+    if constexpr (BUFLD) {
+        const int tap = kbeg / ca.cin;
+        nc0 = kbeg - tap * ca.cin;
+        ndy = tap / ca.ks;
+        ndx = tap - ndy * ca.ks;
+    }
+    auto mfma_slice = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int koff = kk + (lane >> 5) * 8;
@@ -361,14 +419,14 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
-                a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[0][r]);
-                a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[1][r]);
+                a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[buf][0][r]);
+                a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[buf][1][r]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
-                b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[0][r]);
-                b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[1][r]);
+                b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[buf][0][r]);
+                b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[buf][1][r]);
             }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -379,7 +437,30 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    load_slice(kbeg);
+    if constexpr (NBUF == 2) {
+        // two LDS stages: slice s + 1 is written to the stage whose readers passed the previous barrier while the other
+        // waves may still be in the MFMAs of slice s -- ONE barrier per slice, same accumulation order
+        store_slice(0);
         __syncthreads();
+        int cur = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            const bool more = k0 + BK < kend;
+            if (more) load_slice(k0 + BK);
+            mfma_slice(cur);
+            if (more) store_slice(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            store_slice(0);
+            __syncthreads();
+            if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
+            mfma_slice(0);
+            __syncthreads();
+        }
     }
     // ---- epilogue: buffer stores (rows >= M beyond num_records, columns >= N from 3 GiB)
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
@@ -766,6 +847,7 @@ int launch_ws(const float *x, const unsigned short *wh, const unsigned short *wm
 
 std::atomic<int> g_deep{-1};       // -1: TF_LINEAR_DEEP (default 1 since round 3): variant 7 for every call with <= 4096 rows
 std::atomic<int> g_bufstore{-1};   // -1: TF_LINEAR_BUFSTORE (default 1 since round 3)
+std::atomic<int> g_conv3_bufload{-1};   // -1: TF_CONV3_BUFLOAD (default 1): buffer loads in split_conv3_kernel
 std::atomic<int> g_variant{-1};   // -1: TF_LINEAR_VARIANT or the default
 
 int variant()
@@ -848,6 +930,22 @@ int linear_deep()
         g_deep.store(v);
     }
     return v;
+}
+int conv3_bufload()
+{
+    int v = g_conv3_bufload.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_CONV3_BUFLOAD");
+        v = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
+        g_conv3_bufload.store(v);
+    }
+    return v;
+}
+int conv3_bufload_set(int v)
+{
+    const int prev = conv3_bufload();
+    g_conv3_bufload.store(v < 0 ? 0 : v > 2 ? 2 : v);
+    return prev;
 }
 int linear_deep_set(int v)
 {
@@ -1015,18 +1113,22 @@ int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const f
         kbias = nullptr;
         krelu = 0;
     }
-    if (cout >= 128) {
-        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + 127) / 128), gz);
-        if (krelu)
-            hipLaunchKernelGGL((split_conv3_kernel<64, 128, true>), grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
-        else
-            hipLaunchKernelGGL((split_conv3_kernel<64, 128, false>), grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
+    // buffer loads need every offset below the out-of-range marker (3 GiB); larger inputs keep the pointer loads
+    const bool bufld = tfm::conv3_bufload() && (long long)nimg * hin * win * cin * 4 < 0xC0000000LL
+                       && (long long)cout * ks * ks * cin * 2 < 0xC0000000LL;
+    auto launch = [&](auto kern, unsigned bn) {
+        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + bn - 1) / bn), gz);
+        hipLaunchKernelGGL(kern, grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
+    };
+    const bool two = bufld && tfm::conv3_bufload() == 2;   // + two LDS stages
+    if (cout >= 128) {   // output tile 64 x 128 for the wide layers
+        if (two) krelu ? launch(split_conv3_kernel<64, 128, true, true, 2>, 128) : launch(split_conv3_kernel<64, 128, false, true, 2>, 128);
+        else if (bufld) krelu ? launch(split_conv3_kernel<64, 128, true, true>, 128) : launch(split_conv3_kernel<64, 128, false, true>, 128);
+        else krelu ? launch(split_conv3_kernel<64, 128, true, false>, 128) : launch(split_conv3_kernel<64, 128, false, false>, 128);
     } else {
-        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + 63) / 64), gz);
-        if (krelu)
-            hipLaunchKernelGGL((split_conv3_kernel<64, 64, true>), grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
-        else
-            hipLaunchKernelGGL((split_conv3_kernel<64, 64, false>), grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
+        if (two) krelu ? launch(split_conv3_kernel<64, 64, true, true, 2>, 64) : launch(split_conv3_kernel<64, 64, false, true, 2>, 64);
+        else if (bufld) krelu ? launch(split_conv3_kernel<64, 64, true, true>, 64) : launch(split_conv3_kernel<64, 64, false, true>, 64);
+        else krelu ? launch(split_conv3_kernel<64, 64, true, false>, 64) : launch(split_conv3_kernel<64, 64, false, false>, 64);
     }
     if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
     if (ksplit > 1) {

@@ -53,6 +53,10 @@ int linear_bufstore_set(int v);
 // linear_split.hip: deep-prefetch kernel (variant 7) for calls with few rows (0 / 1, default 1)
 int linear_deep();
 int linear_deep_set(int v);
+// linear_split.hip: buffer loads (out-of-image taps read zeros from beyond num_records) in the 3 x 3 / strided 1 x 1
+// split-product convolution (0 / 1, default 1)
+int conv3_bufload();
+int conv3_bufload_set(int v);
 // ffn_fused.hip: row tiles per block of tf_ffn_fused_f32 (1..3, default 3); returns the previous value
 int ffn_set_ti(int v);
 int linln_set_ti(int v);   // tf_linear_res_ln_f32 (1..3; 0 = by row count)

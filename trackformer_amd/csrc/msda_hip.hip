@@ -3017,6 +3017,7 @@ int tf_msda_set_option(const char *name, int value)
     if (strcmp(name, "direct9") == 0) return g_direct9.exchange(value < 0 ? -1 : (value ? 1 : 0));
     if (strcmp(name, "linear_bufstore") == 0) return linear_bufstore_set(value);
     if (strcmp(name, "linear_deep") == 0) return linear_deep_set(value);
+    if (strcmp(name, "conv3_bufload") == 0) return conv3_bufload_set(value);
     if (strcmp(name, "ffn_ti") == 0) return ffn_set_ti(value);
     if (strcmp(name, "linln_ti") == 0) return linln_set_ti(value);
     if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);
