@@ -42,6 +42,16 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 constexpr int BK = 32, THREADS = 256;
 constexpr int LDS_STRIDE = BK + 8;   // bf16 elements per LDS row: 80 bytes, keeps 16-byte alignment, spreads banks
 
+// Which tile row the q-th group of staging lanes (8 lanes x 8 B of an A row, 4 lanes x 16 B of a weight row) carries:
+// within every 8 rows the order 0 4 1 5 2 6 3 7.  An LDS store is serviced in groups of 16 (b64) / 8 (b128) consecutive
+// lanes against 32 banks, i.e. two staging groups at a time; with 80-byte rows, rows r and r + 1 share 4 banks (dwords
+// 0..15 and 20..35 mod 32) -- every store of the kernels below was a 2-way conflict, SQ_LDS_BANK_CONFLICT = 32 cycles per
+// wave and K-slice = a third of SQ_LDS_IDX_ACTIVE (profiles/r03_conv3_pmc.txt) -- while rows r and r + 4 (dwords
+// 0..15 and 80..95 = 16..31 mod 32) cover the 32 banks exactly.  Only the lane -> row assignment of the staging loads
+// and stores changes; the LDS layout, the fragment reads and the arithmetic do not (bit-identical results).  Time per
+// layer: unchanged within noise (profiles/r03_bench_conv_stage_rows.txt) -- the stores were not what the kernels wait for.
+__device__ __forceinline__ int stage_row(int q) { return (q & ~7) | ((q & 1) << 2) | ((q & 7) >> 1); }
+
 // BM x BN output block, 4 waves as 2 x 2, each wave (BM / 2) x (BN / 2) = TI x TJ MFMA tiles of 32 x 32.
 // PREFETCH: the global loads of K-slice s + 1 are issued before the MFMAs of slice s and written to LDS after them
 // (register double buffer), so a block's memory latency hides under its own matrix work instead of relying on a
@@ -88,7 +98,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;          // float4 index: 8 per row
-            const int row = idx >> 3, c4 = idx & 7;
+            const int row = stage_row(idx >> 3), c4 = idx & 7;
             const int grow = min(m0 + row, M - 1);       // rows past M read the last row, never stored
             xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * K + k0 + c4 * 4);
             if constexpr (XADD) xr[it] += *reinterpret_cast<const f32x4 *>(X2 + (size_t)grow * K + k0 + c4 * 4);
@@ -96,7 +106,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;          // 16-byte index: 4 per row
-            const int row = idx >> 2, c8 = idx & 3;
+            const int row = stage_row(idx >> 2), c8 = idx & 3;
             const int grow = min(n0 + row, N - 1);
             const size_t g = (size_t)grow * K + k0 + c8 * 8;
             whr[it] = *reinterpret_cast<const u32x4 *>(Whi + g);
@@ -107,7 +117,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
-            const int row = idx >> 3, c4 = idx & 7;
+            const int row = stage_row(idx >> 3), c4 = idx & 7;
             bf16x4 hi, mid;   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -120,7 +130,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
-            const int row = idx >> 2, c8 = idx & 3;
+            const int row = stage_row(idx >> 2), c8 = idx & 3;
             *reinterpret_cast<u32x4 *>(&sB[0][row * LDS_STRIDE + c8 * 8]) = whr[it];
             *reinterpret_cast<u32x4 *>(&sB[1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
         }
@@ -267,7 +277,7 @@ struct Conv3Args {
 // for its own data BEFORE the MFMAs of slice s that were meant to cover it -- two exposed memory latencies per K-slice
 // (the ISA is quoted in DESIGN.md section 4.4).  The 64-bit address arithmetic (v_mad_i64 / v_mad_u64 chains per load)
 // goes away with it: per slice one uniform tap offset is added to per-thread constants.
-template <int BM, int BN, bool RELU, bool BUFLD, int NBUF = 1>
+template <int BM, int BN, bool RELU, bool BUFLD>
 __global__ void __launch_bounds__(THREADS)
 split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
                    const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
@@ -277,9 +287,8 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
     constexpr int XV = (BM * BK / 4) / THREADS;
     constexpr int WV = (BN * BK / 8) / THREADS;
     static_assert(XV >= 1 && WV >= 1, "tile too small for 256 threads");
-    static_assert(NBUF == 1 || NBUF == 2, "one LDS stage, or two (one barrier per slice)");
-    __shared__ __attribute__((aligned(16))) unsigned short sA[NBUF][2][BM * LDS_STRIDE];   // [stage][hi | mid][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[NBUF][2][BN * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDS_STRIDE];   // [hi | mid][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -299,7 +308,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
 #pragma unroll
     for (int it = 0; it < XV; ++it) {
         const int idx = it * THREADS + tid;
-        const int row = m0 + (idx >> 3);
+        const int row = m0 + (stage_row(idx >> 3));
         rowok[it] = row < M;
         const int r = rowok[it] ? row : 0;
         const int img = r / (ca.hout * ca.wout), rem = r - img * (ca.hout * ca.wout);
@@ -327,7 +336,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
-            woff[it] = ((unsigned)min(n0 + (idx >> 2), N - 1) * (unsigned)K + (unsigned)((idx & 3) * 8)) * 2u;
+            woff[it] = ((unsigned)min(n0 + (stage_row(idx >> 2)), N - 1) * (unsigned)K + (unsigned)((idx & 3) * 8)) * 2u;
         }
     }
     // BUFLD walks the slices in order and steps (channel, dx, dy) of the NEXT slice instead of dividing k0 per slice
@@ -372,33 +381,33 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
-            const int row = idx >> 2, c8 = idx & 3;
+            const int row = stage_row(idx >> 2), c8 = idx & 3;
             const int grow = min(n0 + row, N - 1);
             const size_t g = (size_t)grow * K + k0 + c8 * 8;
             whr[it] = *reinterpret_cast<const u32x4 *>(Whi + g);
             wmr[it] = *reinterpret_cast<const u32x4 *>(Wmid + g);
         }
     };
-    auto store_slice = [&](int buf) {
+    auto store_slice = [&]() {
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
-            const int row = idx >> 3, c4 = idx & 7;
+            const int row = stage_row(idx >> 3), c4 = idx & 7;
             bf16x4 hi, mid;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 hi[e] = (__bf16)xr[it][e];
                 mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
             }
-            *reinterpret_cast<bf16x4 *>(&sA[buf][0][row * LDS_STRIDE + c4 * 4]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sA[buf][1][row * LDS_STRIDE + c4 * 4]) = mid;
+            *reinterpret_cast<bf16x4 *>(&sA[0][row * LDS_STRIDE + c4 * 4]) = hi;
+            *reinterpret_cast<bf16x4 *>(&sA[1][row * LDS_STRIDE + c4 * 4]) = mid;
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
-            const int row = idx >> 2, c8 = idx & 3;
-            *reinterpret_cast<u32x4 *>(&sB[buf][0][row * LDS_STRIDE + c8 * 8]) = whr[it];
-            *reinterpret_cast<u32x4 *>(&sB[buf][1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
+            const int row = stage_row(idx >> 2), c8 = idx & 3;
+            *reinterpret_cast<u32x4 *>(&sB[0][row * LDS_STRIDE + c8 * 8]) = whr[it];
+            *reinterpret_cast<u32x4 *>(&sB[1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
         }
     };
 
@@ -411,7 +420,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         ndy = tap / ca.ks;
         ndx = tap - ndy * ca.ks;
     }
-    auto mfma_slice = [&](int buf) {
+    auto mfma_slice = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int koff = kk + (lane >> 5) * 8;
@@ -419,14 +428,14 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
-                a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[buf][0][r]);
-                a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[buf][1][r]);
+                a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[0][r]);
+                a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[1][r]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
-                b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[buf][0][r]);
-                b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[buf][1][r]);
+                b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[0][r]);
+                b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[1][r]);
             }
 #pragma unroll
             for (int i = 0; i < TI; ++i)
@@ -439,28 +448,15 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         }
     };
     load_slice(kbeg);
-    if constexpr (NBUF == 2) {
-        // two LDS stages: slice s + 1 is written to the stage whose readers passed the previous barrier while the other
-        // waves may still be in the MFMAs of slice s -- ONE barrier per slice, same accumulation order
-        store_slice(0);
+    // Measured and NOT kept (profiles/r03_conv3_bufload.txt, r03_conv3_ksplit.txt, r03_conv3_tile128.txt, r03_conv3_ahead2.txt):
+    // a second LDS stage with one barrier per slice (1-10 % slower at every layer), 128-row output tiles (+3 %), the
+    // loads issued two slices ahead with a second register set (+1.5 %).
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        store_slice();
         __syncthreads();
-        int cur = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            const bool more = k0 + BK < kend;
-            if (more) load_slice(k0 + BK);
-            mfma_slice(cur);
-            if (more) store_slice(cur ^ 1);
-            __syncthreads();
-            cur ^= 1;
-        }
-    } else {
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            store_slice(0);
-            __syncthreads();
-            if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
-            mfma_slice(0);
-            __syncthreads();
-        }
+        if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
+        mfma_slice();
+        __syncthreads();
     }
     // ---- epilogue: buffer stores (rows >= M beyond num_records, columns >= N from 3 GiB)
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
@@ -550,13 +546,13 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
 #pragma unroll
     for (int it = 0; it < XV; ++it) {
         const int idx = it * THREADS + tid;
-        const int row = idx >> 3, c4 = idx & 7;
+        const int row = stage_row(idx >> 3), c4 = idx & 7;
         xp[it] = X + (size_t)min(m0 + row, M - 1) * K + c4 * 4;   // rows past M read the last row, never stored
     }
 #pragma unroll
     for (int it = 0; it < WV; ++it) {
         const int idx = it * THREADS + tid;
-        const int row = idx >> 2, c8 = idx & 3;
+        const int row = stage_row(idx >> 2), c8 = idx & 3;
         wg[it] = (size_t)min(n0 + row, N - 1) * K + c8 * 8;
     }
     auto load_slice = [&](int s, auto slotc) {
@@ -574,7 +570,7 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
-            const int row = idx >> 3, c4 = idx & 7;
+            const int row = stage_row(idx >> 3), c4 = idx & 7;
             bf16x4 hi, mid;   // v_cvt_pk_bf16_f32, round to nearest even
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -587,7 +583,7 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
-            const int row = idx >> 2, c8 = idx & 3;
+            const int row = stage_row(idx >> 2), c8 = idx & 3;
             *reinterpret_cast<u32x4 *>(&sB[buf][0][row * LDS_STRIDE + c8 * 8]) = whr[slot][it];
             *reinterpret_cast<u32x4 *>(&sB[buf][1][row * LDS_STRIDE + c8 * 8]) = wmr[slot][it];
         }
@@ -936,7 +932,7 @@ int conv3_bufload()
     int v = g_conv3_bufload.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("TF_CONV3_BUFLOAD");
-        v = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
+        v = (e && e[0] == '0') ? 0 : 1;
         g_conv3_bufload.store(v);
     }
     return v;
@@ -944,7 +940,7 @@ int conv3_bufload()
 int conv3_bufload_set(int v)
 {
     const int prev = conv3_bufload();
-    g_conv3_bufload.store(v < 0 ? 0 : v > 2 ? 2 : v);
+    g_conv3_bufload.store(v ? 1 : 0);
     return prev;
 }
 int linear_deep_set(int v)
@@ -1120,14 +1116,11 @@ int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const f
         const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + bn - 1) / bn), gz);
         hipLaunchKernelGGL(kern, grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
     };
-    const bool two = bufld && tfm::conv3_bufload() == 2;   // + two LDS stages
     if (cout >= 128) {   // output tile 64 x 128 for the wide layers
-        if (two) krelu ? launch(split_conv3_kernel<64, 128, true, true, 2>, 128) : launch(split_conv3_kernel<64, 128, false, true, 2>, 128);
-        else if (bufld) krelu ? launch(split_conv3_kernel<64, 128, true, true>, 128) : launch(split_conv3_kernel<64, 128, false, true>, 128);
+        if (bufld) krelu ? launch(split_conv3_kernel<64, 128, true, true>, 128) : launch(split_conv3_kernel<64, 128, false, true>, 128);
         else krelu ? launch(split_conv3_kernel<64, 128, true, false>, 128) : launch(split_conv3_kernel<64, 128, false, false>, 128);
     } else {
-        if (two) krelu ? launch(split_conv3_kernel<64, 64, true, true, 2>, 64) : launch(split_conv3_kernel<64, 64, false, true, 2>, 64);
-        else if (bufld) krelu ? launch(split_conv3_kernel<64, 64, true, true>, 64) : launch(split_conv3_kernel<64, 64, false, true>, 64);
+        if (bufld) krelu ? launch(split_conv3_kernel<64, 64, true, true>, 64) : launch(split_conv3_kernel<64, 64, false, true>, 64);
         else krelu ? launch(split_conv3_kernel<64, 64, true, false>, 64) : launch(split_conv3_kernel<64, 64, false, false>, 64);
     }
     if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;

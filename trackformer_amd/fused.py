@@ -561,17 +561,33 @@ def conv3x3(x, w_taps, bias, relu, stride):
 _conv_splitk = os.environ.get("TF_CONV_SPLITK", "1") not in ("", "0")
 
 
+# Split-K policy of the 3 x 3 convolutions: (workgroups aimed at, launches with at least this many blocks are left alone,
+# fewest K-slices a piece may have, fewest K-slices a layer must have).  Swept on the MI355X at the 800 x 1333 frame
+# (profiles/r03_conv3_ksplit.txt; us of backbone convolutions per frame): 384,160,8,64 (rounds 2-3) 1473, 768,300,8,32 1396,
+# 1024,300,6,32 1409, 1024,600,4,16 1418, 2048,600,4,16 1493.
+_KSPLIT_POLICY = tuple(int(v) for v in os.environ.get("TF_CONV_KSPLIT_POLICY", "768,300,8,32").split(","))
+
+
+def set_conv_ksplit_policy(target_blocks, leave_alone_blocks, min_slices_per_piece, min_slices):
+    """-> the previous policy tuple."""
+    global _KSPLIT_POLICY
+    prev, _KSPLIT_POLICY = _KSPLIT_POLICY, (int(target_blocks), int(leave_alone_blocks), int(min_slices_per_piece), int(min_slices))
+    return prev
+
+
 def _conv_ksplit(m, cin, cout):
-    """Pieces the K loop of a 3 x 3 split-product convolution is cut into: 1 unless the launch would have fewer workgroups
-    than the chip has CUs while every one of them walks a long K (layer3 / layer4 and the extra pyramid level at 800 x 1333:
-    132 / 68 / 10 workgroups of 72 / 144 / 576 K-slices)."""
+    """Pieces the K loop of a 3 x 3 split-product convolution is cut into: 1 unless the launch would leave most of the chip
+    with one workgroup or none while every one of them walks a long K (at 800 x 1333: layer2's stride-1 layers 261
+    workgroups of 36 K-slices -> 2 pieces, layer3 132 of 72 -> 5, layer4 68 of 144 -> 11, the extra pyramid level 10 of
+    576 -> 64)."""
     if not _conv_splitk or cout % 4:
         return 1
+    target, alone, per_piece, min_slices = _KSPLIT_POLICY
     blocks = -(-m // 64) * -(-cout // (128 if cout >= 128 else 64))
     slices = 9 * cin // 32
-    if blocks >= 160 or slices < 64:
+    if blocks >= alone or slices < min_slices:
         return 1
-    return max(1, min(64, 384 // blocks, slices // 8))
+    return max(1, min(64, target // blocks, slices // per_piece))
 
 
 # DEFAULT since round 3 (TF_INPUT_PROJ_FUSED=0 / set_input_proj_fused(False) switches it off; +4.3 % frames/s on its own,
