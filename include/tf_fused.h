@@ -104,6 +104,11 @@ int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, c
  * (torchvision Bottleneck.downsample, stride 2) -- the rows of the GEMM are every stride-th pixel. */
 int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
                                  int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+/* The 1 x 1 convolution (stride 1 or 2, w [Cout, Cin]) with the K loop (Cin) cut into `ksplit` pieces, as tf_conv3x3_splitk_f32:
+ * ResNet-50's reducing 1 x 1 convolutions of layer3 / layer4 (torchvision Bottleneck.conv1: 1024 -> 256 at 50 x 84, 2048 -> 512 at
+ * 25 x 42 for an 800 x 1333 frame) are 132 / 68 workgroups of 32 / 64 K-slices -- fewer than the chip has CUs. */
+int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, float *workspace,
+                          int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
 
 /*
  * The backbone's first convolution (7 x 7, stride 2, padding 3, 3 -> 64 channels; reference: models/backbone.py:93-104 ->

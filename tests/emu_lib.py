@@ -69,6 +69,8 @@ def lib():
     L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv3x3_split_f32.restype = ci
     L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv1x1_splitk_f32.restype = ci
+    L.tf_conv1x1_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv1x1_strided_split_f32.restype = ci
     L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_linear_packed_bytes.restype = ctypes.c_int64
@@ -378,19 +380,22 @@ def conv3x3_split(x_nhwc, w_ohwi, bias=None, relu=False, stride=1):
 
 
 def conv3x3_splitk(x_nhwc, w_ohwi, bias=None, relu=False, stride=1, ksplit=4):
-    """tf_conv3x3_splitk_f32: as conv3x3_split (3 x 3, padding 1) with the K loop cut into `ksplit` pieces."""
+    """tf_conv3x3_splitk_f32 / tf_conv1x1_splitk_f32: as conv3x3_split (3 x 3 with padding 1, or 1 x 1 without: by the
+    weight's shape) with the K loop cut into `ksplit` pieces."""
     x, w = _aligned(x_nhwc), _c(w_ohwi, np.float32)
     n, h, wd, cin = x.shape
-    cout = w.shape[0]
-    hi, mid = bf16_split(w.reshape(cout, 9 * cin))
+    cout, ks = w.shape[0], w.shape[1]
+    hi, mid = bf16_split(w.reshape(cout, ks * ks * cin))
     hi, mid = _aligned16(np.ascontiguousarray(hi)), _aligned16(np.ascontiguousarray(mid))
     b = _aligned(bias)
-    ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    pad = 1 if ks == 3 else 0
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
     y = _aligned(np.full((n, ho, wo, cout), np.nan, np.float32))
     ws = _aligned(np.full((max(ksplit, 1), n * ho * wo * cout), np.nan, np.float32))
-    rc = lib().tf_conv3x3_splitk_f32(_p(x), _p(hi), _p(mid), _p(b), _p(y), _p(ws), ksplit, n, h, wd, cin, cout, stride, int(relu), None)
+    fn = lib().tf_conv3x3_splitk_f32 if ks == 3 else lib().tf_conv1x1_splitk_f32
+    rc = fn(_p(x), _p(hi), _p(mid), _p(b), _p(y), _p(ws), ksplit, n, h, wd, cin, cout, stride, int(relu), None)
     if rc != 0:
-        raise RuntimeError("tf_conv3x3_splitk_f32: status %d" % rc)
+        raise RuntimeError("tf_conv%dx%d_splitk_f32: status %d" % (ks, ks, rc))
     return y
 
 

@@ -779,6 +779,25 @@ def test_stem_convolution_as_split_product(n, h, w):
     assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,stride,ksplit", [(1, 9, 11, 256, 64, 1, 4), (2, 7, 5, 160, 128, 2, 3), (1, 6, 6, 64, 192, 1, 2)], ids=lambda v: str(v))
+def test_conv1x1_split_k(n, h, w, cin, cout, stride, ksplit):
+    """tf_conv1x1_splitk_f32: the reducing 1 x 1 convolutions of layer3 / layer4 (few output pixels under K = 1024 / 2048) with
+    the K loop cut into pieces -- against torch float64 and against the unsplit kernel (same products, another sum order)."""
+    import torch
+    rng = np.random.default_rng(h * w + cin + ksplit)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, 1, 1, cin), dtype=np.float32) / np.sqrt(cin)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double().permute(0, 3, 1, 2),
+                                     torch.from_numpy(b).double(), stride=stride).clamp_min(0).permute(0, 2, 3, 1).numpy()
+    y = emu_lib.conv3x3_splitk(x, wt, b, relu=True, stride=stride, ksplit=ksplit)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    base = emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride)
+    assert np.abs(y - base).max() < 1e-5 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(emu_lib.conv3x3_splitk(x, wt, b, relu=True, stride=stride, ksplit=1), base)
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,stride,ksplit", [(1, 9, 11, 128, 64, 2, 4), (1, 7, 6, 256, 256, 2, 9), (2, 5, 5, 64, 128, 1, 18),
                                                           (1, 6, 7, 96, 64, 1, 5), (1, 4, 4, 32, 64, 2, 1)], ids=lambda v: str(v))
 def test_conv3x3_split_k(n, h, w, cin, cout, stride, ksplit):

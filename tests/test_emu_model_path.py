@@ -53,7 +53,10 @@ def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
         # 3 x 3 convolutions: the 16 bottlenecks' + the extra pyramid level's, the small ones with their K loop split
         assert calls.get("tf_conv3x3_split_f32", 0) + calls.get("tf_conv3x3_splitk_f32", 0) == 17, calls
         assert [calls.get(r) for r in routes[1:]] == [16, 4, 6], calls
-        assert calls.get("tf_conv1x1_strided_split_f32") == 3   # the strided projections of layer2..4
+        # the strided projections of layer2..4 (3) and, at this small test frame, the few-pixel 1 x 1 convolutions with a long
+        # K: their K loop split (tf_conv1x1_splitk_f32)
+        assert calls.get("tf_conv1x1_strided_split_f32", 0) + calls.get("tf_conv1x1_splitk_f32", 0) >= 3, calls
+        assert calls.get("tf_conv1x1_splitk_f32", 0) >= 1, calls
         assert calls.get("tf_bias_act_f32", 0) <= 1 and calls.get("tf_bias_relu_maxpool_f32") == 1   # the stem: shift + ReLU + pooling in one pass
         assert calls.get("tf_stem_conv7x7_f32") == 1   # ... after the 7 x 7 convolution as a split product: all 53 ResNet convolutions on own kernels
     else:

@@ -387,6 +387,63 @@ def test_conv3x3_split_k(dev, shape, cout, stride, ksplit):
     assert float((outs[0] - ref).abs().max()) < 1e-3 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("shape,cout,stride", [((1, 1024, 50, 84), 256, 1), ((1, 2048, 25, 42), 512, 1), ((1, 2048, 25, 42), 256, 1),
+                                               ((1, 1024, 50, 84), 2048, 2)])
+def test_conv1x1_split_k(dev, shape, cout, stride):
+    """The few-pixel 1 x 1 convolutions under a long K (layer3 / layer4 conv1, the coarse input projections) take the
+    convolution kernel with their K loop cut (tf_conv1x1_splitk_f32): against the uncut kernel (same products, another sum
+    order), the library convolution, and run twice (bit-identical: no atomics)."""
+    from trackformer_amd import fused
+    g = torch.Generator().manual_seed(shape[1] + cout)
+    x = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, shape[1], generator=g) / shape[1] ** 0.5).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    m = shape[0] * ((shape[2] - 1) // stride + 1) * ((shape[3] - 1) // stride + 1)
+    cut = fused._conv_ksplit(m, shape[1], cout)
+    y1, y2 = fused.conv3x3(x, w, b, True, stride), fused.conv3x3(x, w, b, True, stride)
+    prev = fused.set_conv1x1_splitk(False)
+    try:
+        y0 = fused.conv3x3(x, w, b, True, stride)
+    finally:
+        fused.set_conv1x1_splitk(prev)
+    ref = torch.relu(torch.nn.functional.conv2d(x, w[:, :, None, None], b, stride=stride))
+    scale = float(ref.abs().max())
+    assert torch.equal(y1, y2)
+    assert float((y1 - y0).abs().max()) < 1e-5 * scale and float((y1 - ref).abs().max()) < 1e-3 * scale
+    if cut >= 3:
+        assert fused.conv1x1_wants_split_k(m, shape[1], cout)
+    else:
+        assert torch.equal(y1, y0)                     # two pieces do not pay for a 1 x 1 convolution: left alone
+
+
+@pytest.mark.parametrize("shape,cout,ks,stride", [((1, 64, 200, 334), 64, 3, 1), ((1, 256, 100, 167), 256, 3, 2), ((1, 512, 25, 42), 512, 3, 1),
+                                                  ((2, 128, 37, 53), 160, 3, 1), ((1, 1024, 50, 84), 2048, 1, 2)])
+def test_conv3x3_buffer_loads_equal_pointer_loads(dev, shape, cout, ks, stride):
+    """split_conv3_kernel fetches through buffer resources by default (a tap outside the image reads zeros from beyond
+    num_records); conv3_bufload = 0 keeps the pointer loads + select.  Same products in the same
+    order: bit-identical at ResNet-50's shapes of the 800 x 1333 frame (borders on all four sides, the last row block
+    partial, the split-K pieces fused.conv3x3 chooses), and within 1e-3 of the library convolution."""
+    from trackformer_amd import _cabi, fused
+    g = torch.Generator().manual_seed(shape[1] + cout)
+    x = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, shape[1], ks, ks, generator=g) / (ks * shape[1] ** 0.5)).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    taps = w.permute(0, 2, 3, 1).reshape(cout, ks * ks * shape[1]).contiguous()
+    lib = _cabi.lib()
+    outs = {}
+    for mode in (1, 0):
+        prev = lib.tf_msda_set_option(b"conv3_bufload", mode)
+        try:
+            outs[mode] = fused.conv3x3(x, taps, b, True, stride)
+            torch.cuda.synchronize()
+        finally:
+            lib.tf_msda_set_option(b"conv3_bufload", prev)
+    assert prev == 1 or mode == 1                      # buffer loads are the default
+    assert outs[1] is not None and torch.equal(outs[0], outs[1])
+    ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=ks // 2))
+    assert float((outs[1] - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("case", list(um.FULL_CASES))
 def test_every_round3_route_switched_off_full_size(dev, models, case):
     """Every switch of DESIGN.md section 4.3 OFF at once (the round-2 defaults: library convolutions, separate linears and

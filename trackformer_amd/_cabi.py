@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "tf_conv3x3_split_f32",
     "tf_conv3x3_splitk_f32",
     "tf_conv1x1_strided_split_f32",
+    "tf_conv1x1_splitk_f32",
     "tf_linear_packed_bytes",
     "tf_linear_pack_weight_f32",
     "tf_linear_packed_f32",
@@ -126,6 +127,8 @@ def lib():
     L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv3x3_split_f32.restype = ci
     L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv1x1_splitk_f32.restype = ci
+    L.tf_conv1x1_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv1x1_strided_split_f32.restype = ci
     L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_linear_packed_bytes.restype = ctypes.c_int64

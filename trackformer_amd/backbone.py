@@ -202,6 +202,12 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
         b = cache.get(conv, bn)
         if x.is_cuda:
             split_ok = _split_route_allowed(conv)   # False: this shape keeps the library convolution (TF_CONV_SPLIT_SKIP)
+            if (split_ok and _conv1x1_split and cache.weight2d is not None and residual is None and conv.stride == (1, 1)
+                    and conv.padding == (0, 0) and conv.groups == 1 and CHANNELS_LAST
+                    and fused.conv1x1_wants_split_k(x.shape[0] * x.shape[2] * x.shape[3], conv.in_channels, conv.out_channels)):
+                y = fused.conv3x3(x, cache.weight2d, b, relu, 1)   # few pixels under a long K (layer3 / layer4 conv1): split-K
+                if y is not None:
+                    return y
             if (split_ok and _conv1x1_split and cache.weight2d is not None and conv.stride == (1, 1) and conv.padding == (0, 0)
                     and conv.groups == 1 and CHANNELS_LAST):
                 y = conv1x1_as_gemm(x, cache.weight2d, b, residual, relu,

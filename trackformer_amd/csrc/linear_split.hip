@@ -1067,6 +1067,14 @@ extern "C" int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const voi
     return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream, ksplit, workspace);
 }
 
+extern "C" int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
+                                     float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+                                     void *stream)
+{
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && !workspace)) return ksplit > 1 && !workspace ? TF_MSDA_ERR_NULL_POINTER : TF_MSDA_ERR_BAD_DIMS;
+    return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream, ksplit, workspace);
+}
+
 extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
                                     int hin, int win, int cin, int cout, int stride, int relu, void *stream)
 {

@@ -542,14 +542,16 @@ def conv3x3(x, w_taps, bias, relu, stride):
         return None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
-    ksplit = _conv_ksplit(n * ho * wo, cin, cout) if ks == 3 else 1
+    ksplit = _conv_ksplit(n * ho * wo, ks * ks * cin, cout)
+    if ks == 1 and (ksplit < _CONV1X1_MIN_PIECES or not _conv1x1_splitk):
+        ksplit = 1
     with torch.cuda.device(x.device):
         y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
         if ksplit > 1:   # few output pixels under a long K: split the K loop over workgroups (deterministic second pass)
             ws = torch.empty((ksplit, n * ho * wo * cout), dtype=torch.float32, device=x.device)
-            rc = _cabi.lib().tf_conv3x3_splitk_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(),
-                                                   y.data_ptr(), ws.data_ptr(), ksplit, n, h, w, cin, cout, stride,
-                                                   1 if relu else 0, _stream(x.device))
+            fn = _cabi.lib().tf_conv3x3_splitk_f32 if ks == 3 else _cabi.lib().tf_conv1x1_splitk_f32
+            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                    ksplit, n, h, w, cin, cout, stride, 1 if relu else 0, _stream(x.device))
         else:
             fn = _cabi.lib().tf_conv3x3_split_f32 if ks == 3 else _cabi.lib().tf_conv1x1_strided_split_f32
             rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), n, h, w,
@@ -575,8 +577,28 @@ def set_conv_ksplit_policy(target_blocks, leave_alone_blocks, min_slices_per_pie
     return prev
 
 
-def _conv_ksplit(m, cin, cout):
-    """Pieces the K loop of a 3 x 3 split-product convolution is cut into: 1 unless the launch would leave most of the chip
+def conv1x1_wants_split_k(m, cin, cout):
+    """True when a stride-1 1 x 1 convolution over m pixels is better off in the convolution kernel with its K loop cut
+    (tf_conv1x1_splitk_f32) than in the plain split GEMM: few workgroups, each walking a long K.  Default since round 3
+    (TF_CONV1X1_SPLITK=0 / set_conv1x1_splitk(False) switches it off), measured at the 800 x 1333 frame
+    (profiles/r03_conv1x1_splitk.txt): layer3.1-5.conv1 (1024 -> 256 at 50 x 84, 4 pieces) 30.2 -> 21.8 us, layer4.1-2.conv1
+    (2048 -> 512 at 25 x 42, 8 pieces) 40.1 -> 23.9 us; two pieces did not pay (layer4.0.conv1 31.1 -> 32.5 us, the strided
+    projection of layer4 33.6 -> 34.0 us): a 1 x 1 convolution is only cut into three pieces or more."""
+    return _conv1x1_splitk and _conv_ksplit(m, cin, cout) >= _CONV1X1_MIN_PIECES
+
+
+_conv1x1_splitk = os.environ.get("TF_CONV1X1_SPLITK", "1") not in ("", "0")
+_CONV1X1_MIN_PIECES = 3
+
+
+def set_conv1x1_splitk(on):
+    global _conv1x1_splitk
+    prev, _conv1x1_splitk = _conv1x1_splitk, bool(on)
+    return prev
+
+
+def _conv_ksplit(m, k, cout):
+    """Pieces the K loop (k = 9 Cin or Cin) of a split-product convolution is cut into: 1 unless the launch would leave most of the chip
     with one workgroup or none while every one of them walks a long K (at 800 x 1333: layer2's stride-1 layers 261
     workgroups of 36 K-slices -> 2 pieces, layer3 132 of 72 -> 5, layer4 68 of 144 -> 11, the extra pyramid level 10 of
     576 -> 64)."""
@@ -584,7 +606,7 @@ def _conv_ksplit(m, cin, cout):
         return 1
     target, alone, per_piece, min_slices = _KSPLIT_POLICY
     blocks = -(-m // 64) * -(-cout // (128 if cout >= 128 else 64))
-    slices = 9 * cin // 32
+    slices = k // 32
     if blocks >= alone or slices < min_slices:
         return 1
     return max(1, min(64, target // blocks, slices // per_piece))
@@ -655,7 +677,12 @@ def input_proj_1x1(x, conv, gn):
     if hit is None or hit[0] != conv.weight._version or hit[1].device != conv.weight.device:
         hit = (conv.weight._version, conv.weight.detach().reshape(cout, cin).contiguous())
         conv._tf_w2d = hit
-    y2 = linear(x.permute(0, 2, 3, 1).reshape(n * h * w, cin), hit[1], conv.bias)
+    y2 = None
+    if conv1x1_wants_split_k(n * h * w, cin, cout):   # the coarse levels: 1050 / 4200 pixels under K = 2048 / 1024
+        y = conv3x3(x, hit[1], conv.bias, False, 1)
+        y2 = None if y is None else y.permute(0, 2, 3, 1)
+    if y2 is None:
+        y2 = linear(x.permute(0, 2, 3, 1).reshape(n * h * w, cin), hit[1], conv.bias)
     if y2 is None:
         return None
     z2 = groupnorm_nhwc(y2.reshape(n * h * w, cout), n, gn)
