@@ -254,10 +254,10 @@ class TrackSeeder:
 
     def seed(self, tracker):
         from trackformer_amd.tracker import Track
-        rows = zip(self.pos.unbind(0), self.scores.unbind(0), self.hs.unbind(0), self.obj_ind.unbind(0))
-        tracker.tracks = [Track(p, sc, i, hs, ind) for i, (p, sc, hs, ind) in enumerate(rows)]
-        for i, t in enumerate(tracker.tracks):
-            t.__dict__["_obj_index"] = i
+        # the embeddings as (frame embeddings, row) references, which is how the tracker itself files them: in a running
+        # sequence every live track points into the previous frame's output (tracker._HsHistory)
+        rows = zip(self.pos.unbind(0), self.scores.unbind(0))
+        tracker.tracks = [Track(p, sc, i, (self.hs, i), i) for i, (p, sc) in enumerate(rows)]
         tracker.inactive_tracks = []
         tracker.track_num = self.n
 
@@ -665,6 +665,8 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
     # multi-frame model), then time
     run_set(n_seq * max(4, (args.warmup + n_seq - 1) // n_seq))
     torch.cuda.synchronize()
+    from trackformer_amd import runtime
+    runtime.settle_heap()   # model, trackers and graphs exist: the cyclic collector need not walk them again
     return timed_repeats(run_set, args.steps, world, device, args.min_seconds)
 
 

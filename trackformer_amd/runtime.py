@@ -62,3 +62,16 @@ def configure_inference(tune=False, miopen_find=True, tunable_file=None, verbose
         if verbose:
             print("trackformer_amd: TunableOp selections %s from %s" %
                   ("loaded" if ok else "REJECTED (validator mismatch)", path), file=sys.stderr)
+
+
+def settle_heap():
+    """Call once the model, the trackers and the HIP graphs exist (after the warm-up frames).  The association leg creates and
+    drops a few hundred small objects per frame (Track, deque, per-row tensors), which makes CPython's cyclic collector run
+    every few frames; its older-generation passes walk EVERY tracked object of the process -- with a model in memory that is
+    the whole module / parameter graph, for nothing.  gc.freeze() moves what is alive now into the permanent generation:
+    later collections only look at what the frames themselves allocate.  (tools/profile_host_cpu.py --gc: the collector is
+    ~7 % of the association leg even without a model in the process.)"""
+    import gc
+    gc.collect()
+    gc.freeze()
+

@@ -89,6 +89,20 @@ class Tracker:
             t = self._image_id_cache = torch.ones(1, dtype=torch.int64, device=device)
         return t
 
+    @staticmethod
+    def _track_query_embeds(prev_tracks, device):
+        """[n, C]: every track's newest output embedding (tracker.py:290-297 of the reference stacks them).  When all of them
+        are rows of one frame's embeddings -- the usual case: the tracks were updated or created by the previous frame -- that
+        is one index_select; any other mix falls back to the stack."""
+        items = [t.hs_embed._items[-1] for t in prev_tracks]
+        first = items[0]
+        if type(first) is tuple:
+            src = first[0]
+            if all(type(it) is tuple and it[0] is src for it in items):
+                idx = torch.tensor([it[1] for it in items], dtype=torch.long)
+                return src.index_select(0, idx.to(src.device, non_blocking=True))
+        return torch.stack([_HsHistory._row(it) for it in items], dim=0)
+
     def reset(self, hard=True):
         self.tracks = []
         self.inactive_tracks = []
@@ -100,6 +114,19 @@ class Tracker:
             self.frame_index = 0
             self.num_reids = 0
 
+    def _keep_after_nms(self, pos, scores, rank, thresh, name):
+        """NMS over self.tracks (pos [n, 4] / scores [n] in list order, suppression order by `rank`): drops the suppressed
+        tracks from the list and returns (pos, scores) of the survivors, still in list order."""
+        keep = torch.zeros(pos.shape[0], dtype=torch.bool)
+        keep[nms(pos, rank, thresh)] = True
+        flags = keep.tolist()
+        if not all(flags):
+            self._logger(f'REMOVE TRACK IDS ({name}={thresh}): '
+                         f'{[t.id for t, k in zip(self.tracks, flags) if not k]}')
+            self.tracks = [t for t, k in zip(self.tracks, flags) if k]
+            return pos[keep], scores[keep]
+        return pos, scores
+
     def tracks_to_inactive(self, tracks):
         self.tracks = [t for t in self.tracks if t not in tracks]
         for track in tracks:
@@ -107,21 +134,27 @@ class Tracker:
         self.inactive_tracks += tracks
 
     def add_tracks(self, pos, scores, hs_embeds, indices, masks=None, attention_maps=None,
-                   aux_results=None):
-        """Creates Track objects with consecutive ids track_num, track_num+1, ... (tracker.py:93-122)."""
+                   aux_results=None, hs_rows=None):
+        """Creates Track objects with consecutive ids track_num, track_num+1, ... (tracker.py:93-122).  hs_rows = (frame
+        embeddings [Q, C], [row per new track]) may stand in for hs_embeds [n, C]: the tracks then reference their rows
+        (_HsHistory) instead of holding n gathered copies."""
         n = len(pos)
         new_track_ids = list(range(self.track_num, self.track_num + n))
         if n:
             # one unbind per tensor instead of four Python-level indexings per track (150 new tracks: 0.8 -> 0.2 ms)
             indices = torch.as_tensor(indices)
             ints = indices.reshape(n, -1)[:, 0].tolist()   # the results of every later frame carry obj_ind as an int
-            rows = zip(pos.unbind(0), scores.unbind(0), hs_embeds.unbind(0), indices.unbind(0))
-            for i, (p, sc, hs, ind) in enumerate(rows):
-                track = Track(p, sc, self.track_num + i, hs, ind,
-                              None if masks is None else masks[i],
-                              None if attention_maps is None else attention_maps[i])
-                track.__dict__["_obj_index"] = ints[i]
-                self.tracks.append(track)
+            if hs_rows is not None:
+                src, src_rows = hs_rows
+                hs_iter = [(src, r) for r in src_rows]
+            else:
+                hs_iter = hs_embeds.unbind(0)
+            rows = zip(pos.unbind(0), scores.unbind(0), hs_iter, ints)
+            append = self.tracks.append
+            for i, (p, sc, hs, ind) in enumerate(rows):   # obj_ind as an int: Track.obj_ind gives the [1] tensor on demand
+                append(Track(p, sc, self.track_num + i, hs, ind,
+                             None if masks is None else masks[i],
+                             None if attention_maps is None else attention_maps[i]))
         self.track_num += n
 
         if new_track_ids:
@@ -274,7 +307,7 @@ class Tracker:
             target = [{
                 'track_query_boxes': track_query_boxes.to(device, non_blocking=True),
                 'image_id': self._image_id(device),
-                'track_query_hs_embeds': torch.stack([t.hs_embed[-1] for t in prev_tracks], dim=0),
+                'track_query_hs_embeds': self._track_query_embeds(prev_tracks, device),
             }]
 
         if self._lazy_masks:
@@ -330,6 +363,10 @@ class Tracker:
         is_person = packed[:, 5] == 0
 
         nq = self.num_object_queries
+        # `cur`: (positions [n, 4], scores [n]) of self.tracks in list order while that is known from the arrays at hand --
+        # the NMS passes and the results then take them from there instead of stacking ~200 per-track tensors three more
+        # times per frame; None = not known (any path that reorders / revives tracks), the consumers stack as before.
+        cur = None
         # ---------------------------------------------------------------- existing tracks
         if num_prev_track:
             track_scores = scores[:-nq]
@@ -339,13 +376,14 @@ class Tracker:
             if self.generate_attention_maps:
                 track_attention_maps = self.attention_data['maps'][:-nq]
 
-            track_keep = (track_scores > self.track_obj_score_thresh) & is_person[:-nq]
+            track_keep = ((track_scores > self.track_obj_score_thresh) & is_person[:-nq]).tolist()
+            score_rows, box_rows = track_scores.unbind(0), track_boxes.unbind(0)   # one unbind each, not an indexing per track
             to_inactive, from_inactive = [], []
             for i, track in enumerate(self.tracks):
                 if track_keep[i]:
-                    track.score = track_scores[i]
-                    track.hs_embed.append(hs_embeds[i])
-                    track.pos = track_boxes[i]
+                    track.score = score_rows[i]
+                    track.hs_embed.append_row(hs_embeds, i)
+                    track.pos = box_rows[i]
                     track.count_termination = 0
                     if 'masks' in result:
                         track.mask = track_masks[i]
@@ -356,12 +394,12 @@ class Tracker:
                     if track.count_termination >= self.steps_termination:
                         to_inactive.append(track)
 
-            reid_keep = (track_scores > self.reid_score_thresh) & is_person[:-nq]
+            reid_keep = ((track_scores > self.reid_score_thresh) & is_person[:-nq]).tolist()
             for i, track in enumerate(self.inactive_tracks, start=len(self.tracks)):
                 if reid_keep[i]:
-                    track.score = track_scores[i]
-                    track.hs_embed.append(hs_embeds[i])
-                    track.pos = track_boxes[i]
+                    track.score = score_rows[i]
+                    track.hs_embed.append_row(hs_embeds, i)
+                    track.pos = box_rows[i]
                     if 'masks' in result:
                         track.mask = track_masks[i]
                     if self.generate_attention_maps:
@@ -380,14 +418,9 @@ class Tracker:
             self.tracks_to_inactive(to_inactive)
 
             if self.track_nms_thresh and self.tracks:
-                keep = set(nms(torch.stack([t.pos for t in self.tracks]),
-                               torch.stack([t.score for t in self.tracks]),
-                               self.track_nms_thresh).tolist())
-                remove_tracks = [t for i, t in enumerate(self.tracks) if i not in keep]
-                if remove_tracks:
-                    self._logger(f'REMOVE TRACK IDS (track_nms_thresh={self.track_nms_thresh}): '
-                                 f'{[t.id for t in remove_tracks]}')
-                self.tracks = [t for i, t in enumerate(self.tracks) if i in keep]   # (a list membership test per track was O(n^2))
+                pos_all = torch.stack([t.pos for t in self.tracks])
+                score_all = torch.stack([t.score for t in self.tracks])
+                cur = self._keep_after_nms(pos_all, score_all, score_all, self.track_nms_thresh, 'track_nms_thresh')
 
         # ---------------------------------------------------------------- new detections
         new_det_keep = (scores[-nq:] > self.detection_obj_score_thresh) & is_person[-nq:]
@@ -408,37 +441,44 @@ class Tracker:
         new_det_boxes, new_det_scores, new_det_indices, sel = narrow(
             self.public_detections_mask(new_det_boxes, blob['dets'][0]))
 
-        # re-ID of inactive tracks (tracker.py:451-466)
-        gather = sel.to(device, non_blocking=True)
-        reid_mask = self.reid(new_det_boxes, new_det_scores, det_hs[gather],
-                              None if det_masks is None else det_masks[gather],
-                              None if det_maps is None else det_maps[gather])
+        # re-ID of inactive tracks (tracker.py:451-466); without inactive tracks reid() returns at once and the gathered
+        # embeddings / masks / maps of the detections are never looked at
+        if self.inactive_tracks and len(sel):
+            gather = sel.to(device, non_blocking=True)
+            reid_mask = self.reid(new_det_boxes, new_det_scores, det_hs[gather],
+                                  None if det_masks is None else det_masks[gather],
+                                  None if det_maps is None else det_maps[gather])
+        else:
+            reid_mask = self.reid(new_det_boxes, new_det_scores, None)
         new_det_boxes, new_det_scores, new_det_indices, sel = narrow(reid_mask)
+        n_before_new = len(self.tracks)
+        if cur is not None and cur[0].shape[0] != n_before_new:
+            cur = None                                   # re-identification moved tracks back into the active list
 
-        gather = sel.to(device, non_blocking=True)
+        gather = sel.to(device, non_blocking=True) if (det_masks is not None or det_maps is not None) else None
         aux_results = None
         if self._verbose:
             aux_results = [self.obj_detector_post['bbox'](out, orig_size)[0]
                            for out in outputs['aux_outputs']]
+        first_obj_row = hs_embeds.shape[0] - nq          # the new tracks reference their rows of this frame's embeddings
         new_track_ids = self.add_tracks(
-            new_det_boxes, new_det_scores, det_hs[gather], new_det_indices,
+            new_det_boxes, new_det_scores, None, new_det_indices,
             None if det_masks is None else det_masks[gather],
-            None if det_maps is None else det_maps[gather], aux_results)
+            None if det_maps is None else det_maps[gather], aux_results,
+            hs_rows=(hs_embeds, [first_obj_row + r for r in sel.tolist()]))
+
+        if cur is not None:                               # the new tracks were appended in the detections' order
+            cur = (torch.cat([cur[0], new_det_boxes]), torch.cat([cur[1], new_det_scores]))
+        elif n_before_new == 0:
+            cur = (new_det_boxes, new_det_scores)
 
         # ---------------------------------------------------------------- NMS new vs. existing
         if self.detection_nms_thresh and self.tracks:
-            track_scores = torch.stack([t.score for t in self.tracks]).clone()
-            new_ids = set(new_track_ids)
-            is_new = torch.tensor([t.id in new_ids for t in self.tracks])
-            track_scores[~is_new] = np.inf   # existing tracks always win against new detections
-            keep = set(nms(torch.stack([t.pos for t in self.tracks]), track_scores,
-                           self.detection_nms_thresh).tolist())
-            remove_tracks = [t for i, t in enumerate(self.tracks) if i not in keep]
-            if remove_tracks:
-                self._logger(
-                    f'REMOVE TRACK IDS (detection_nms_thresh={self.detection_nms_thresh}): '
-                    f'{[t.id for t in remove_tracks]}')
-            self.tracks = [t for i, t in enumerate(self.tracks) if i in keep]
+            if cur is None:
+                cur = (torch.stack([t.pos for t in self.tracks]), torch.stack([t.score for t in self.tracks]))
+            rank = cur[1].clone()
+            rank[:len(self.tracks) - len(new_track_ids)] = np.inf   # existing tracks (everything in front of the new ones)
+            cur = self._keep_after_nms(cur[0], cur[1], rank, self.detection_nms_thresh, 'detection_nms_thresh')   # always win
 
         # ---------------------------------------------------------------- results
         if 'masks' in result:
@@ -454,11 +494,13 @@ class Tracker:
             masks_host = track_masks.cpu().numpy()   # ONE copy for all tracks (the results hold a full-size mask per track)
 
         if self.tracks:   # one stack + one numpy view for all tracks instead of three conversions per track
-            all_pos = torch.stack([t.pos for t in self.tracks])
+            if cur is None or cur[0].shape[0] != len(self.tracks):
+                cur = (torch.stack([t.pos for t in self.tracks]), torch.stack([t.score for t in self.tracks]))
+            all_pos = cur[0]
             if not self.obj_detector.overflow_boxes:
                 all_pos = clip_boxes_to_image(all_pos, (orig_h, orig_w))
             all_pos = all_pos.numpy()
-            all_scores = torch.stack([t.score for t in self.tracks]).numpy()
+            all_scores = cur[1].numpy()
         if self.tracks:
             # the frame's rows are filed as arrays; the reference's {track id: {frame: {...}}} layout is built from them when
             # somebody reads `results` / get_results() (per track and frame that is a dict and three objects: ~0.3 ms per
@@ -575,9 +617,46 @@ class _MaskRows:
         return _MaskRef(self.rows[int(idx)])
 
 
+class _HsHistory(object):
+    """Track.hs_embed: the output embeddings a track has had, newest last (a list of [C] device tensors in the reference,
+    models/tracker.py:557-583; the newest one is the next frame's track query).  An entry filed by the tracker is a
+    (frame embeddings [Q, C], row) reference: no per-track device view is created per frame (they were ~300 tensor objects
+    per frame at 100 tracks + 100 detections), and the next frame's queries are ONE index_select when every track points
+    into the same frame (Tracker._track_query_embeds).  Reading an entry gives the [C] row, as the reference's list does."""
+    __slots__ = ("_items",)
+
+    def __init__(self, first):
+        self._items = [first]
+
+    def append(self, row_tensor):
+        self._items.append(row_tensor)
+
+    def append_row(self, frame_embeds, row):
+        self._items.append((frame_embeds, row))
+
+    def __len__(self):
+        return len(self._items)
+
+    @staticmethod
+    def _row(item):
+        return item[0][item[1]] if type(item) is tuple else item
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._row(it) for it in self._items[i]]
+        return self._row(self._items[i])
+
+    def __iter__(self):
+        return (self._row(it) for it in self._items)
+
+
 class Track(object):
     """State of one track: last position / score (host tensors), the history of its output
     embeddings (device tensors, the newest one is the next frame's track query) and counters."""
+    # slots for the fields every frame touches (100 tracks are created and ~200 updated per frame in bench.py's association
+    # leg); __dict__ stays available for whatever a caller wants to hang on a track
+    __slots__ = ("id", "pos", "last_pos", "score", "ims", "count_inactive", "count_termination", "gt_id", "hs_embed", "mask",
+                 "attention_map", "_obj_ind", "_obj_index", "__dict__")
 
     def __init__(self, pos, score, track_id, hs_embed, obj_ind, mask=None, attention_map=None):
         self.id = track_id
@@ -588,17 +667,31 @@ class Track(object):
         self.count_inactive = 0
         self.count_termination = 0
         self.gt_id = None
-        self.hs_embed = [hs_embed]
+        self.hs_embed = _HsHistory(hs_embed)   # a [C] tensor or a (frame embeddings, row) reference
         self.mask = mask
         self.attention_map = attention_map
-        self.obj_ind = obj_ind
+        if type(obj_ind) is int:                 # the tracker's own tracks: no per-track index tensor until somebody asks
+            self._obj_ind, self._obj_index = None, obj_ind
+        else:
+            self._obj_ind, self._obj_index = obj_ind, None
+
+    @property
+    def obj_ind(self):
+        """Index of the object query that started the track: the [1] int64 tensor the reference keeps (tracker.py:557-583)."""
+        if self._obj_ind is None:
+            self._obj_ind = torch.tensor([self._obj_index], dtype=torch.int64)
+        return self._obj_ind
+
+    @obj_ind.setter
+    def obj_ind(self, value):
+        self._obj_ind, self._obj_index = value, None
 
     @property
     def obj_index(self) -> int:
         """obj_ind as a Python int (computed once; the results of every frame carry it)."""
-        v = self.__dict__.get("_obj_index")
+        v = self._obj_index
         if v is None:
-            v = self.__dict__["_obj_index"] = int(torch.as_tensor(self.obj_ind).reshape(-1)[0])
+            v = self._obj_index = int(torch.as_tensor(self._obj_ind).reshape(-1)[0])
         return v
 
     def has_positive_area(self) -> bool:
