@@ -254,10 +254,10 @@ class TrackSeeder:
 
     def seed(self, tracker):
         from trackformer_amd.tracker import Track
-        # the embeddings as (frame embeddings, row) references, which is how the tracker itself files them: in a running
-        # sequence every live track points into the previous frame's output (tracker._HsHistory)
-        rows = zip(self.pos.unbind(0), self.scores.unbind(0))
-        tracker.tracks = [Track(p, sc, i, (self.hs, i), i) for i, (p, sc) in enumerate(rows)]
+        # positions, scores and embeddings as (frame array, row) references, which is how the tracker itself files them: in a
+        # running sequence every live track points into the previous frame's arrays (tracker._HsHistory, Track.pos)
+        pos, scores, hs = self.pos, self.scores, self.hs
+        tracker.tracks = [Track((pos, i), (scores, i), i, (hs, i), i) for i in range(self.n)]
         tracker.inactive_tracks = []
         tracker.track_num = self.n
 

@@ -69,3 +69,41 @@ def test_keep_after_nms_filters_list_and_arrays_together():
     assert torch.equal(pos, boxes[[2, 3]]) and torch.equal(sc, scores[[2, 3]])
     pos2, sc2 = tr._keep_after_nms(pos, sc, sc, 0.5, "track_nms_thresh")
     assert pos2 is pos and [t.id for t in tr.tracks] == [2, 3]   # nothing suppressed: nothing rebuilt
+
+
+def test_positions_and_scores_as_row_references_read_like_tensors():
+    from trackformer_amd.tracker import _LastPos, _gather_rows
+    boxes, scores = torch.rand(6, 4), torch.rand(6)
+    t = Track((boxes, 2), (scores, 2), 0, torch.zeros(8), 1)
+    assert type(t._pos) is tuple                                   # nothing built yet
+    assert torch.equal(t.pos, boxes[2]) and torch.equal(t.score, scores[2]) and t.score.dim() == 0
+    assert torch.is_tensor(t._pos)                                 # built once, then kept
+    assert isinstance(t.last_pos, _LastPos) and torch.equal(t.last_pos[-1], boxes[2]) and len(t.last_pos) == 1
+    t.pos = boxes[4]
+    t.last_pos.append(t._pos)
+    t.last_pos.append((boxes, 5))
+    assert [p.tolist() for p in t.last_pos] == [boxes[2].tolist(), boxes[4].tolist(), boxes[5].tolist()]
+    assert torch.equal(t.last_pos.pop(), boxes[5]) and torch.equal(t.last_pos.popleft(), boxes[2])
+    t.reset_last_pos()
+    assert len(t.last_pos) == 1 and torch.equal(t.last_pos[0], boxes[4])
+    assert t.has_positive_area() == bool(boxes[4, 2] > boxes[4, 0] and boxes[4, 3] > boxes[4, 1])
+
+
+def test_gather_rows_equals_the_stack_for_every_mix_of_sources():
+    from trackformer_amd.tracker import _gather_rows
+    g = torch.Generator().manual_seed(0)
+    srcs = [torch.rand(9, 4, generator=g) for _ in range(6)]
+    plain = [torch.rand(4, generator=g) for _ in range(3)]
+    cases = {
+        "one source": [(srcs[0], r) for r in (3, 0, 8, 3)],
+        "two sources": [(srcs[0], 1), (srcs[1], 7), (srcs[0], 2), (srcs[1], 0)],
+        "sources and tensors": [plain[0], (srcs[2], 4), plain[1], (srcs[0], 4), (srcs[2], 5), plain[2]],
+        "tensors only": plain,
+        "many sources": [(s, i) for i, s in enumerate(srcs)],
+        "tensor first": [plain[0], (srcs[0], 1), (srcs[0], 2)],
+    }
+    for name, items in cases.items():
+        want = torch.stack([it[0][it[1]] if type(it) is tuple else it for it in items])
+        assert torch.equal(_gather_rows(items), want), name
+    scores = torch.rand(5, generator=g)
+    assert torch.equal(_gather_rows([(scores, 4), (scores, 0)]), scores[[4, 0]])     # 1-d sources: the scores

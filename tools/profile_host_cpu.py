@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--profile", action="store_true")
     ap.add_argument("--gc", choices=["default", "off", "freeze"], default="default")
     args = ap.parse_args()
-    torch.set_num_threads(4)
+    torch.set_num_threads(1)   # the shared CPU of the build container: one thread, CPU time instead of wall time
     det = StandInDetector(args.detections)
     tracker = Tracker(det, {'bbox': PostProcess()}, config.tracker_cfg(), False)
     tracker.reset()
@@ -75,7 +75,7 @@ def main():
     scores, hs, ind = torch.full((n,), 0.9), torch.randn(n, 256, generator=g), torch.arange(n).view(n, 1)
 
     def seed():   # bench.py's TrackSeeder: the same n tracks before every step (a steady state)
-        tracker.tracks = [Track(p, sc, i, (hs, i), i) for i, (p, sc) in enumerate(zip(pos.unbind(0), scores.unbind(0)))]
+        tracker.tracks = [Track((pos, i), (scores, i), i, (hs, i), i) for i in range(n)]
         tracker.inactive_tracks = []
         tracker.track_num = n
 
@@ -85,11 +85,11 @@ def main():
     def run(frames):
         t_seed = t_step = 0.0
         for _ in range(frames):
-            t0 = time.perf_counter()
+            t0 = time.process_time()
             seed()
-            t1 = time.perf_counter()
+            t1 = time.process_time()
             tracker.step(blob)
-            t_step += time.perf_counter() - t1
+            t_step += time.process_time() - t1
             t_seed += t1 - t0
         return t_seed / frames * 1e3, t_step / frames * 1e3
 
@@ -102,9 +102,9 @@ def main():
     with torch.no_grad():
         run(20)
         alive = len(tracker.tracks)
-        runs = [run(args.frames) for _ in range(5)]
+        runs = [run(args.frames) for _ in range(9)]
         s, t = min(r[0] for r in runs), min(r[1] for r in runs)
-        print("host ms per frame (best of 5 x %d frames): step %.3f (+ seeding %.3f, bench artefact); %d tracks alive after a step"
+        print("host ms per frame (CPU time, best of 9 x %d frames): step %.3f (+ seeding %.3f, bench artefact); %d tracks alive after a step"
               % (args.frames, t, s, alive))
         if args.profile:
             pr = cProfile.Profile()

@@ -149,10 +149,9 @@ class Tracker:
                 hs_iter = [(src, r) for r in src_rows]
             else:
                 hs_iter = hs_embeds.unbind(0)
-            rows = zip(pos.unbind(0), scores.unbind(0), hs_iter, ints)
             append = self.tracks.append
-            for i, (p, sc, hs, ind) in enumerate(rows):   # obj_ind as an int: Track.obj_ind gives the [1] tensor on demand
-                append(Track(p, sc, self.track_num + i, hs, ind,
+            for i, (hs, ind) in enumerate(zip(hs_iter, ints)):   # rows of `pos` / `scores` as references, obj_ind as an int
+                append(Track((pos, i), (scores, i), self.track_num + i, hs, ind,
                              None if masks is None else masks[i],
                              None if attention_maps is None else attention_maps[i]))
         self.track_num += n
@@ -215,7 +214,7 @@ class Tracker:
 
         if self.reid_greedy_matching:
             det = box_xyxy_to_cxcywh(new_det_boxes).numpy()
-            inact = box_xyxy_to_cxcywh(torch.stack([t.pos for t in self.inactive_tracks])).numpy()
+            inact = box_xyxy_to_cxcywh(_gather_rows([t._pos for t in self.inactive_tracks])).numpy()
             dist_mat = ((inact[:, :2].reshape(-1, 1, 2) - det[:, :2].reshape(1, -1, 2)) ** 2
                         ).sum(axis=2)
             track_size = inact[:, 2] * inact[:, 3]
@@ -288,8 +287,8 @@ class Tracker:
         if self.inactive_tracks:
             self._logger(f'INACTIVE TRACK IDS: {[t.id for t in self.inactive_tracks]}')
 
-        for track in self.tracks:   # host tensors are never modified in place: no clone needed
-            track.last_pos.append(track.pos)
+        for track in self.tracks:   # host tensors are never modified in place: no clone needed; a reference is filed as it is
+            track.last_pos.append(track._pos)
 
         device = self.device
         img = blob['img'].to(device, non_blocking=True)
@@ -301,7 +300,7 @@ class Tracker:
         prev_tracks = self.tracks + self.inactive_tracks
         num_prev_track = len(prev_tracks)
         if num_prev_track:
-            boxes_xyxy = torch.stack([t.pos for t in prev_tracks], dim=0)           # host
+            boxes_xyxy = _gather_rows([t._pos for t in prev_tracks])                # host
             track_query_boxes = box_xyxy_to_cxcywh(boxes_xyxy) / torch.tensor(
                 [orig_w, orig_h, orig_w, orig_h], dtype=torch.float32)
             target = [{
@@ -377,13 +376,14 @@ class Tracker:
                 track_attention_maps = self.attention_data['maps'][:-nq]
 
             track_keep = ((track_scores > self.track_obj_score_thresh) & is_person[:-nq]).tolist()
-            score_rows, box_rows = track_scores.unbind(0), track_boxes.unbind(0)   # one unbind each, not an indexing per track
+            # a track's new position / score / embedding are filed as (this frame's array, row) references: no tensor per
+            # track and frame (Track.pos / .score build it when somebody reads one)
             to_inactive, from_inactive = [], []
             for i, track in enumerate(self.tracks):
                 if track_keep[i]:
-                    track.score = score_rows[i]
+                    track._score = (track_scores, i)
                     track.hs_embed.append_row(hs_embeds, i)
-                    track.pos = box_rows[i]
+                    track._pos = (track_boxes, i)
                     track.count_termination = 0
                     if 'masks' in result:
                         track.mask = track_masks[i]
@@ -397,9 +397,9 @@ class Tracker:
             reid_keep = ((track_scores > self.reid_score_thresh) & is_person[:-nq]).tolist()
             for i, track in enumerate(self.inactive_tracks, start=len(self.tracks)):
                 if reid_keep[i]:
-                    track.score = score_rows[i]
+                    track._score = (track_scores, i)
                     track.hs_embed.append_row(hs_embeds, i)
-                    track.pos = box_rows[i]
+                    track._pos = (track_boxes, i)
                     if 'masks' in result:
                         track.mask = track_masks[i]
                     if self.generate_attention_maps:
@@ -418,8 +418,8 @@ class Tracker:
             self.tracks_to_inactive(to_inactive)
 
             if self.track_nms_thresh and self.tracks:
-                pos_all = torch.stack([t.pos for t in self.tracks])
-                score_all = torch.stack([t.score for t in self.tracks])
+                pos_all = _gather_rows([t._pos for t in self.tracks])
+                score_all = _gather_rows([t._score for t in self.tracks])
                 cur = self._keep_after_nms(pos_all, score_all, score_all, self.track_nms_thresh, 'track_nms_thresh')
 
         # ---------------------------------------------------------------- new detections
@@ -475,7 +475,7 @@ class Tracker:
         # ---------------------------------------------------------------- NMS new vs. existing
         if self.detection_nms_thresh and self.tracks:
             if cur is None:
-                cur = (torch.stack([t.pos for t in self.tracks]), torch.stack([t.score for t in self.tracks]))
+                cur = (_gather_rows([t._pos for t in self.tracks]), _gather_rows([t._score for t in self.tracks]))
             rank = cur[1].clone()
             rank[:len(self.tracks) - len(new_track_ids)] = np.inf   # existing tracks (everything in front of the new ones)
             cur = self._keep_after_nms(cur[0], cur[1], rank, self.detection_nms_thresh, 'detection_nms_thresh')   # always win
@@ -495,12 +495,18 @@ class Tracker:
 
         if self.tracks:   # one stack + one numpy view for all tracks instead of three conversions per track
             if cur is None or cur[0].shape[0] != len(self.tracks):
-                cur = (torch.stack([t.pos for t in self.tracks]), torch.stack([t.score for t in self.tracks]))
+                cur = (_gather_rows([t._pos for t in self.tracks]), _gather_rows([t._score for t in self.tracks]))
             all_pos = cur[0]
             if not self.obj_detector.overflow_boxes:
                 all_pos = clip_boxes_to_image(all_pos, (orig_h, orig_w))
             all_pos = all_pos.numpy()
             all_scores = cur[1].numpy()
+            # every live track now points into these two arrays: the next frame's track-query boxes and its NMS inputs are
+            # one gather from one source again, whatever mix of updated / revived / new tracks this frame left behind
+            pos_arr, score_arr = cur
+            for i, t in enumerate(self.tracks):
+                t._pos = (pos_arr, i)
+                t._score = (score_arr, i)
         if self.tracks:
             # the frame's rows are filed as arrays; the reference's {track id: {frame: {...}}} layout is built from them when
             # somebody reads `results` / get_results() (per track and frame that is a dict and three objects: ~0.3 ms per
@@ -617,6 +623,69 @@ class _MaskRows:
         return _MaskRef(self.rows[int(idx)])
 
 
+def _row(item):
+    """A (frame array, row) reference or a tensor -> the tensor."""
+    return item[0][item[1]] if type(item) is tuple else item
+
+
+def _gather_rows(items):
+    """[n, ...]: the rows a list of tensors / (frame array, row) references stands for, in list order -- torch.stack of the
+    reference's per-track tensors.  References into ONE array are one gather; a few arrays (the tracks the previous frame
+    updated, the ones it created, an inactive one from earlier) are one gather each and a permutation."""
+    first = items[0]
+    if type(first) is tuple:
+        src, rows = first[0], []
+        for it in items:
+            if type(it) is not tuple or it[0] is not src:
+                break
+            rows.append(it[1])
+        else:
+            return src[rows]
+    groups, plain, plain_at = {}, [], []
+    for k, it in enumerate(items):
+        if type(it) is tuple:
+            g = groups.get(id(it[0]))
+            if g is None:
+                g = groups[id(it[0])] = (it[0], [], [])
+            g[1].append(k)
+            g[2].append(it[1])
+        else:
+            plain.append(it)
+            plain_at.append(k)
+    if len(groups) > 4:                         # many sources: nothing to gain over the plain stack
+        return torch.stack([_row(it) for it in items])
+    parts, at = [], []
+    for src, ks, rows in groups.values():
+        parts.append(src[rows])
+        at += ks
+    if plain:
+        parts.append(torch.stack(plain))
+        at += plain_at
+    out = torch.cat(parts)
+    inverse = [0] * len(at)
+    for j, k in enumerate(at):
+        inverse[k] = j
+    return out[inverse]
+
+
+class _LastPos(deque):
+    """Track.last_pos: the deque of past positions of the reference (tracker.py:557-583).  The tracker files an entry per
+    track and frame; it files the track's (frame boxes, row) reference as it is, and the [4] tensor is built when an entry
+    is read."""
+
+    def __getitem__(self, i):
+        return _row(deque.__getitem__(self, i))
+
+    def __iter__(self):
+        return (_row(it) for it in deque.__iter__(self))
+
+    def pop(self):
+        return _row(deque.pop(self))
+
+    def popleft(self):
+        return _row(deque.popleft(self))
+
+
 class _HsHistory(object):
     """Track.hs_embed: the output embeddings a track has had, newest last (a list of [C] device tensors in the reference,
     models/tracker.py:557-583; the newest one is the next frame's track query).  An entry filed by the tracker is a
@@ -655,14 +724,14 @@ class Track(object):
     embeddings (device tensors, the newest one is the next frame's track query) and counters."""
     # slots for the fields every frame touches (100 tracks are created and ~200 updated per frame in bench.py's association
     # leg); __dict__ stays available for whatever a caller wants to hang on a track
-    __slots__ = ("id", "pos", "last_pos", "score", "ims", "count_inactive", "count_termination", "gt_id", "hs_embed", "mask",
+    __slots__ = ("id", "_pos", "last_pos", "_score", "ims", "count_inactive", "count_termination", "gt_id", "hs_embed", "mask",
                  "attention_map", "_obj_ind", "_obj_index", "__dict__")
 
     def __init__(self, pos, score, track_id, hs_embed, obj_ind, mask=None, attention_map=None):
         self.id = track_id
-        self.pos = pos
-        self.last_pos = deque([pos])
-        self.score = score
+        self._pos = pos              # a [4] tensor, or a (frame boxes [n, 4], row) reference: `pos` builds the tensor when read
+        self.last_pos = _LastPos([pos])
+        self._score = score          # a 0-d tensor, or a (frame scores [n], row) reference
         self.ims = deque([])
         self.count_inactive = 0
         self.count_termination = 0
@@ -674,6 +743,29 @@ class Track(object):
             self._obj_ind, self._obj_index = None, obj_ind
         else:
             self._obj_ind, self._obj_index = obj_ind, None
+
+    @property
+    def pos(self):
+        """Last position, xyxy in pixels of the original image: the [4] host tensor of the reference."""
+        v = self._pos
+        if type(v) is tuple:
+            v = self._pos = v[0][v[1]]
+        return v
+
+    @pos.setter
+    def pos(self, value):
+        self._pos = value
+
+    @property
+    def score(self):
+        v = self._score
+        if type(v) is tuple:
+            v = self._score = v[0][v[1]]
+        return v
+
+    @score.setter
+    def score(self, value):
+        self._score = value
 
     @property
     def obj_ind(self):
@@ -700,4 +792,4 @@ class Track(object):
 
     def reset_last_pos(self) -> None:
         self.last_pos.clear()
-        self.last_pos.append(self.pos)
+        self.last_pos.append(self._pos)
