@@ -206,7 +206,7 @@ def _active_optins(backbone, fused):
              ("pos_add_fused", fused.pos_add_fused_enabled()), ("heads_split", fused.heads_split_enabled())]
     names = [n for n, on in flags if on]
     for env in ("TF_LINEAR_BUFSTORE", "TF_LINEAR_DEEP", "TF_MSDA_PQUAD", "TF_MSDA_DIRECT9", "TF_MSDA_BWD_SORTED2",
-                "TF_CONV_SPLIT_SKIP", "TF_CONV_SPLITK", "TF_LAZY_MASKS"):
+                "TF_CONV_SPLIT_SKIP", "TF_CONV_SPLITK", "TF_CONV1X1_SPLITK", "TF_CONV3_BUFLOAD", "TF_CONV_KSPLIT_POLICY", "TF_LAZY_MASKS"):
         if os.environ.get(env):
             names.append("%s=%s" % (env, os.environ[env]))
     return names
