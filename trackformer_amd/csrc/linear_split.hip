@@ -94,6 +94,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
 
     f32x4 xr[XV];
     u32x4 whr[WV], wmr[WV];
+    f32x4 xr2[XADD ? XV : 1];
     auto load_slice = [&](int k0) {
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
@@ -101,7 +102,11 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
             const int row = stage_row(idx >> 3), c4 = idx & 7;
             const int grow = min(m0 + row, M - 1);       // rows past M read the last row, never stored
             xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * K + k0 + c4 * 4);
-            if constexpr (XADD) xr[it] += *reinterpret_cast<const f32x4 *>(X2 + (size_t)grow * K + k0 + c4 * 4);
+            // XADD: the second operand stays in its own registers and is added when the slice is staged (store_slice).
+            // Written as `xr += load` here, hipcc put the v_pk_add -- and with it `s_waitcnt vmcnt` for BOTH loads --
+            // right behind the loads: the prefetch of slice s + 1 was waited for before the MFMAs of slice s (the defect
+            // of DESIGN.md section 4.4 again; found by tools/isa_wait_audit.py)
+            if constexpr (XADD) xr2[it] = *reinterpret_cast<const f32x4 *>(X2 + (size_t)grow * K + k0 + c4 * 4);
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
@@ -119,10 +124,12 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
             bf16x4 hi, mid;   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
+            f32x4 xv = xr[it];
+            if constexpr (XADD) xv += xr2[it];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)xr[it][e];
-                mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
+                hi[e] = (__bf16)xv[e];
+                mid[e] = (__bf16)(xv[e] - (float)hi[e]);
             }
             *reinterpret_cast<bf16x4 *>(&sA[0][row * LDS_STRIDE + c4 * 4]) = hi;
             *reinterpret_cast<bf16x4 *>(&sA[1][row * LDS_STRIDE + c4 * 4]) = mid;
