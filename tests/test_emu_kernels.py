@@ -461,9 +461,10 @@ def test_opt_in_kernels_do_not_depend_on_the_scheduling_order():
                                                     (1, 1, 1, 32, 32, 1)], ids=lambda v: str(v))
 def test_conv3x3_as_split_product(n, h, w, cin, cout, stride, ks):
     """tf_conv3x3_split_f32: the bottlenecks' 3 x 3 convolutions (padding 1, stride 1 / 2) as an implicit GEMM on the
-    emulated matrix cores, against torch's convolution in float64 -- and the two fetch schedules of the kernel
-    (conv3_bufload 1, the default: buffer loads, taps outside the image read zeros from beyond num_records; 0: pointer loads
-    + select) bit-identical to each other."""
+    emulated matrix cores, against torch's convolution in float64 -- and the schedules of the kernel (conv3_bufload 1, the
+    default: buffer loads, taps outside the image read zeros from beyond num_records; 0: pointer loads + select; 2, an
+    experiment not timed yet: two LDS stages with the operands read one k-step ahead of their MFMAs) bit-identical to
+    each other."""
     import torch
     rng = np.random.default_rng(h * w + cin)
     x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
@@ -474,12 +475,13 @@ def test_conv3x3_as_split_product(n, h, w, cin, cout, stride, ks):
     y = emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
-    prev = emu_lib.set_options(conv3_bufload=0)
-    try:
-        assert prev["conv3_bufload"] == 1            # the default
-        assert np.array_equal(emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride), y)
-    finally:
-        emu_lib.set_options(**prev)
+    for mode in (0, 2):                              # pointer loads + select; operands read one k-step ahead (experiment)
+        prev = emu_lib.set_options(conv3_bufload=mode)
+        try:
+            assert prev["conv3_bufload"] == 1            # the default
+            assert np.array_equal(emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride), y), mode
+        finally:
+            emu_lib.set_options(**prev)
     st = emu_lib.stats()
     assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
 
@@ -819,8 +821,9 @@ def test_conv3x3_split_k(n, h, w, cin, cout, stride, ksplit):
     assert np.abs(y - base).max() < 1e-5 * max(1.0, np.abs(ref).max())
     if ksplit == 1:
         assert np.array_equal(y, base)
-    prev = emu_lib.set_options(conv3_bufload=0)          # pointer loads + select: same products in the same order
-    try:
-        assert np.array_equal(emu_lib.conv3x3_splitk(x, wt, b, relu=True, stride=stride, ksplit=ksplit), y)
-    finally:
-        emu_lib.set_options(**prev)
+    for mode in (0, 2):                                  # the other fetch / operand schedules: same products in the same order
+        prev = emu_lib.set_options(conv3_bufload=mode)
+        try:
+            assert np.array_equal(emu_lib.conv3x3_splitk(x, wt, b, relu=True, stride=stride, ksplit=ksplit), y), mode
+        finally:
+            emu_lib.set_options(**prev)

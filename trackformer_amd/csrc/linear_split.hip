@@ -284,7 +284,7 @@ struct Conv3Args {
 // for its own data BEFORE the MFMAs of slice s that were meant to cover it -- two exposed memory latencies per K-slice
 // (the ISA is quoted in DESIGN.md section 4.4).  The 64-bit address arithmetic (v_mad_i64 / v_mad_u64 chains per load)
 // goes away with it: per slice one uniform tap offset is added to per-thread constants.
-template <int BM, int BN, bool RELU, bool BUFLD>
+template <int BM, int BN, bool RELU, bool BUFLD, bool PIPE = false>
 __global__ void __launch_bounds__(THREADS)
 split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
                    const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
@@ -294,8 +294,10 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
     constexpr int XV = (BM * BK / 4) / THREADS;
     constexpr int WV = (BN * BK / 8) / THREADS;
     static_assert(XV >= 1 && WV >= 1, "tile too small for 256 threads");
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDS_STRIDE];   // [hi | mid][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDS_STRIDE];
+    static_assert(!PIPE || BUFLD, "the pipelined schedule uses the buffer loads (dead loads past the last slice)");
+    constexpr int NST = PIPE ? 2 : 1;   // LDS stages
+    __shared__ __attribute__((aligned(16))) unsigned short sA[NST][2][BM * LDS_STRIDE];   // [stage][hi | mid][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[NST][2][BN * LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -348,7 +350,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
     }
     // BUFLD walks the slices in order and steps (channel, dx, dy) of the NEXT slice instead of dividing k0 per slice
     int nc0 = 0, ndx = 0, ndy = 0;
-    auto load_slice = [&](int k0) {
+    auto load_slice = [&](int k0, bool live = true) {   // !live (PIPE): past the last slice, every offset out of range
         if constexpr (BUFLD) {
             const int c0 = nc0, dx = ndx, dy = ndy;
             nc0 += BK;
@@ -360,16 +362,18 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
                 }
             }
             const unsigned tapoff = (unsigned)((dy * ca.win + dx) * ca.cin + c0) * 4u;   // uniform
+            const unsigned dead = live ? 0u : OOB;   // OR-ed into every offset (all of them < OOB): straight-line code
 #pragma unroll
             for (int it = 0; it < XV; ++it) {
                 const bool ok = rowok[it] && (unsigned)(ybase[it] + dy) < (unsigned)ca.hin
                                 && (unsigned)(xbase[it] + dx) < (unsigned)ca.win;
-                xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xoff[it] + tapoff : OOB, 0, 0));
+                xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (ok ? xoff[it] + tapoff : OOB) | dead, 0, 0));
             }
 #pragma unroll
             for (int it = 0; it < WV; ++it) {
-                whr[it] = __builtin_amdgcn_raw_buffer_load_b128(whrs, woff[it] + (unsigned)k0 * 2u, 0, 0);
-                wmr[it] = __builtin_amdgcn_raw_buffer_load_b128(wmrs, woff[it] + (unsigned)k0 * 2u, 0, 0);
+                const unsigned o = (woff[it] + (unsigned)k0 * 2u) | dead;
+                whr[it] = __builtin_amdgcn_raw_buffer_load_b128(whrs, o, 0, 0);
+                wmr[it] = __builtin_amdgcn_raw_buffer_load_b128(wmrs, o, 0, 0);
             }
             return;
         }
@@ -395,7 +399,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
             wmr[it] = *reinterpret_cast<const u32x4 *>(Wmid + g);
         }
     };
-    auto store_slice = [&]() {
+    auto store_slice = [&](int st = 0) {
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
@@ -406,15 +410,15 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
                 hi[e] = (__bf16)xr[it][e];
                 mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
             }
-            *reinterpret_cast<bf16x4 *>(&sA[0][row * LDS_STRIDE + c4 * 4]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sA[1][row * LDS_STRIDE + c4 * 4]) = mid;
+            *reinterpret_cast<bf16x4 *>(&sA[st][0][row * LDS_STRIDE + c4 * 4]) = hi;
+            *reinterpret_cast<bf16x4 *>(&sA[st][1][row * LDS_STRIDE + c4 * 4]) = mid;
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 2), c8 = idx & 3;
-            *reinterpret_cast<u32x4 *>(&sB[0][row * LDS_STRIDE + c8 * 8]) = whr[it];
-            *reinterpret_cast<u32x4 *>(&sB[1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
+            *reinterpret_cast<u32x4 *>(&sB[st][0][row * LDS_STRIDE + c8 * 8]) = whr[it];
+            *reinterpret_cast<u32x4 *>(&sB[st][1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
         }
     };
 
@@ -427,43 +431,86 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         ndy = tap / ca.ks;
         ndx = tap - ndy * ca.ks;
     }
+    struct Frags {
+        bf16x8 a_hi[TI], a_mid[TI], b_hi[TJ], b_mid[TJ];
+    };
+    auto read_frags = [&](Frags &f, int st, int kk) {   // the wave's operands of one 16-wide k-step from LDS stage `st`
+        const int koff = kk + (lane >> 5) * 8;
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
+            f.a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[st][0][r]);
+            f.a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[st][1][r]);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
+            f.b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[st][0][r]);
+            f.b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[st][1][r]);
+        }
+    };
+    auto mfma_frags = [&](const Frags &f) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a_mid[i], f.b_hi[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a_hi[i], f.b_mid[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a_hi[i], f.b_hi[j], acc[i][j], 0, 0, 0);
+            }
+    };
     auto mfma_slice = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
-            const int koff = kk + (lane >> 5) * 8;
-            bf16x8 a_hi[TI], a_mid[TI], b_hi[TJ], b_mid[TJ];
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
-                a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[0][r]);
-                a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[1][r]);
-            }
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
-                b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[0][r]);
-                b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[1][r]);
-            }
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid[i], b_hi[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_mid[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
-                }
+            Frags f;
+            read_frags(f, 0, kk);
+            mfma_frags(f);
         }
     };
     load_slice(kbeg);
-    // Measured and NOT kept (profiles/r03_conv3_bufload.txt, r03_conv3_ksplit.txt, r03_conv3_tile128.txt, r03_conv3_ahead2.txt):
-    // a second LDS stage with one barrier per slice (1-10 % slower at every layer), 128-row output tiles (+3 %), the
-    // loads issued two slices ahead with a second register set (+1.5 %).
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        store_slice();
+    if constexpr (PIPE) {
+        // EXPERIMENT (tf_msda_set_option("conv3_bufload", 2) / TF_CONV3_BUFLOAD=2; written after the last GPU minute of round 3,
+        // bit-identical on the emulator, NOT timed yet): the operands of a k-step are read from LDS one k-step AHEAD of
+        // the MFMAs that use them, into a second register set -- the counters of the default schedule show the waves a third
+        // of their time in s_waitcnt with neither memory latency, barrier count nor LDS store conflicts to blame
+        // (DESIGN.md section 4.4), which leaves the ds_read -> MFMA dependency inside the k-step.  Two LDS stages, ONE
+        // barrier per slice, placed between the two k-steps:
+        //     read (s, k-step 1) | MFMA (s, k-step 0) | stage slice s + 1 | issue the loads of s + 2 | barrier |
+        //     read (s + 1, k-step 0) | MFMA (s, k-step 1)
+        // Past the last slice the loads are dead (out-of-range offsets, zeros) and a stage of zeros is written: no branch
+        // in the loop, exact wait counts.  Same products in the same order per accumulator.
+        store_slice(0);
+        load_slice(kbeg + BK, kbeg + BK < kend);
         __syncthreads();
-        if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
-        mfma_slice();
-        __syncthreads();
+        Frags f0, f1;
+        read_frags(f0, 0, 0);
+        int st = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            // (the sched_barriers pin the order: left alone, the scheduler sinks every ds_read to right in front of the
+            // MFMA that uses it -- shorter live ranges, and the schedule this variant exists to get away from)
+            read_frags(f1, st, 16);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_frags(f0);
+            store_slice(st ^ 1);
+            load_slice(k0 + 2 * BK, k0 + 2 * BK < kend);
+            __syncthreads();
+            read_frags(f0, st ^ 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_frags(f1);
+            __builtin_amdgcn_sched_barrier(0);
+            st ^= 1;
+        }
+    } else {
+        // Measured and NOT kept (profiles/r03_conv3_bufload.txt, r03_conv3_ksplit.txt, r03_conv3_tile128.txt, r03_conv3_ahead2.txt):
+        // a second LDS stage with one barrier per slice (1-10 % slower at every layer), 128-row output tiles (+3 %), the
+        // loads issued two slices ahead with a second register set (+1.5 %).
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            store_slice();
+            __syncthreads();
+            if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
+            mfma_slice();
+            __syncthreads();
+        }
     }
     // ---- epilogue: buffer stores (rows >= M beyond num_records, columns >= N from 3 GiB)
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
@@ -939,7 +986,7 @@ int conv3_bufload()
     int v = g_conv3_bufload.load(std::memory_order_relaxed);
     if (v < 0) {
         const char *e = getenv("TF_CONV3_BUFLOAD");
-        v = (e && e[0] == '0') ? 0 : 1;
+        v = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
         g_conv3_bufload.store(v);
     }
     return v;
@@ -947,7 +994,7 @@ int conv3_bufload()
 int conv3_bufload_set(int v)
 {
     const int prev = conv3_bufload();
-    g_conv3_bufload.store(v ? 1 : 0);
+    g_conv3_bufload.store(v < 0 ? 0 : v > 2 ? 2 : v);
     return prev;
 }
 int linear_deep_set(int v)
@@ -1131,11 +1178,14 @@ int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const f
         const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + bn - 1) / bn), gz);
         hipLaunchKernelGGL(kern, grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
     };
+    const bool pipe = bufld && tfm::conv3_bufload() == 2;   // experiment: operands read one k-step ahead (see the kernel)
     if (cout >= 128) {   // output tile 64 x 128 for the wide layers
-        if (bufld) krelu ? launch(split_conv3_kernel<64, 128, true, true>, 128) : launch(split_conv3_kernel<64, 128, false, true>, 128);
+        if (pipe) krelu ? launch(split_conv3_kernel<64, 128, true, true, true>, 128) : launch(split_conv3_kernel<64, 128, false, true, true>, 128);
+        else if (bufld) krelu ? launch(split_conv3_kernel<64, 128, true, true>, 128) : launch(split_conv3_kernel<64, 128, false, true>, 128);
         else krelu ? launch(split_conv3_kernel<64, 128, true, false>, 128) : launch(split_conv3_kernel<64, 128, false, false>, 128);
     } else {
-        if (bufld) krelu ? launch(split_conv3_kernel<64, 64, true, true>, 64) : launch(split_conv3_kernel<64, 64, false, true>, 64);
+        if (pipe) krelu ? launch(split_conv3_kernel<64, 64, true, true, true>, 64) : launch(split_conv3_kernel<64, 64, false, true, true>, 64);
+        else if (bufld) krelu ? launch(split_conv3_kernel<64, 64, true, true>, 64) : launch(split_conv3_kernel<64, 64, false, true>, 64);
         else krelu ? launch(split_conv3_kernel<64, 64, true, false>, 64) : launch(split_conv3_kernel<64, 64, false, false>, 64);
     }
     if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
