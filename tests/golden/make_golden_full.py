@@ -1,8 +1,15 @@
 #!/usr/bin/env python
 """BASELINE-size golden fixtures from the REFERENCE's own classes on CPU (build container only).
 
-    python tests/golden/make_golden_full.py [cfg2_full] [cfg4_full] [tracker]
+    python tests/golden/make_golden_full.py [cfg1_full] [cfg2_full] [cfg3_full] [cfg4_full] [cfg5_full] [tracker] [tracker64] [tracker_cfg5]
 
+cfg1_full  reference plain `DETR` (detr.py:62-128; coco classes, 100 object queries, ffn 2048) on one 480x640 frame
+cfg3_full  one TRAINING step of the cfg-2 model at batch 2 (800x1333 + 768x1280, 30 boxes per image, previous-frame pass,
+           track-query augmentation, SetCriterion, backward through the reference's pure-PyTorch MSDeformAttn;
+           engine.py:119-158, detr_tracking.py:39-183): losses, total, gradient norms of EVERY parameter
+cfg5_full  the mask-head model (detr_segmentation.py:41-71 on the tracking detector, MOTS20 overlay) on one 800x1333 frame
+           with 300 object + 100 track queries: detector outputs + pred_masks of every 50th query + post-processed masks
+tracker_cfg5  the reference `Tracker` driving that model for 3 frames of 800x1333 (masks per track: tracker.py:521-547)
 cfg2_full  reference `build_model('deformable','tracking','mot17')` (deformable_detr.py:124-275) on one
            800x1333 frame with 300 object + 100 injected track queries
 cfg4_full  the `multi_frame` model (hidden 288, 500 object + 300 track queries, 8 decoder levels,
@@ -37,18 +44,24 @@ def checksum(model):
 
 def model_case(ref, case):
     model, post, args = um.build(case, ref.models.build_model, config.make_args)
-    model.tracking()
+    plain = not hasattr(model, "tracking")            # cfg 1: plain DETR has no tracking mix-in
+    masks = case == "cfg5_full"
+    model.eval() if plain else model.tracking()
     img, prev, target = um.model_inputs(case, args.hidden_dim)
+    orig = um.FULL_IMG_CFG1 if plain else um.FULL_ORIG
     t0 = time.time()
     with torch.no_grad():
         prev_features = None
         if args.multi_frame_attention:
             _, _, prev_features, _, _ = model(prev, None, None)
-        out, _, feats, memory, hs = model(img, target, prev_features)
-        res = post['bbox'](out, torch.tensor([list(um.FULL_ORIG)]))[0]
-    # memory: per-level [N, C, H, W] slices of the encoder output (deformable_detr.py:261-271);
-    # back to [N, S, C], keep every 89th token
-    mem = torch.cat([m.flatten(2) for m in memory], 2).transpose(1, 2)
+        if plain or masks:   # two-argument forward (detr.py:62, detr_segmentation.py:41)
+            out, _, feats, memory, hs = model(img, target)
+        else:
+            out, _, feats, memory, hs = model(img, target, prev_features)
+        res = post['bbox'](out, torch.tensor([list(orig)]))[0]
+    # memory: per-level [N, C, H, W] slices of the encoder output (deformable_detr.py:261-271) or the one [N, C, H, W]
+    # map of the dense transformer (transformer.py:60-61); back to [N, S, C], keep every 89th token
+    mem = (torch.cat([m.flatten(2) for m in memory], 2) if isinstance(memory, (list, tuple)) else memory.flatten(2)).transpose(1, 2)
     fix = dict(pred_logits=out['pred_logits'].numpy(), pred_boxes=out['pred_boxes'].numpy(),
                hs_embed=out['hs_embed'].numpy(),
                aux_boxes=np.stack([a['pred_boxes'].numpy() for a in out['aux_outputs']]),
@@ -58,12 +71,73 @@ def model_case(ref, case):
                memory_rows=mem[0, ::um.FULL_MEMORY_ROW_STRIDE].numpy(),
                memory_shape=np.array(mem.shape),
                feat_last=feats[-1].tensors[0, ::um.FULL_FEAT_CH_STRIDE].numpy())
+    if masks:
+        with torch.no_grad():
+            resm = post['segm'](post['bbox'](out, torch.tensor([list(orig)])), out, torch.tensor([list(orig)]),
+                                torch.tensor([list(um.FULL_IMG)]), return_probs=True)
+        fix['pred_masks'] = out['pred_masks'][:, ::um.FULL_MASK_QUERY_STRIDE].numpy()
+        fix['pred_masks_shape'] = np.array(out['pred_masks'].shape)
+        # post-processed probabilities of 3 queries at a quarter of the rows / columns (the full maps are 7.8 MB each)
+        fix['post_masks'] = resm[0]['masks'][:3, :, ::4, ::4].numpy().astype(np.float32)
     path = os.path.join(HERE, "full_%s.npz" % case)
     np.savez_compressed(path, **fix)
     print("%-10s %.0f s  logits%s boxes%s memory%s score range [%.3f, %.3f] -> %s (%d KB)" % (
         case, time.time() - t0, fix['pred_logits'].shape, fix['pred_boxes'].shape, tuple(mem.shape),
         fix['scores'].min(), fix['scores'].max(), os.path.basename(path),
         os.path.getsize(path) // 1024), flush=True)
+
+
+def train_case(ref):
+    """BASELINE cfg 3 on CPU: um.train_step (= engine.py:126-148 without the optimiser) on the full model at batch 2."""
+    model, criterion, args = um.build_train(ref.models.build_model, config.make_args, full=True)
+    samples, targets = um.train_batch(full=True)
+    t0 = time.time()
+    loss_dict, total, grads = um.train_step(model, criterion, samples, targets)
+    keys = sorted(grads)
+    path = os.path.join(HERE, "full_cfg3_full.npz")
+    np.savez_compressed(path, loss_keys=np.array(sorted(loss_dict)), loss_vals=np.array([loss_dict[k] for k in sorted(loss_dict)]),
+                        total=np.float64(total), grad_keys=np.array(keys), grad_norms=np.array([grads[k] for k in keys]),
+                        num_grads=np.int64(len(grads)), weight_checksum=np.float64(checksum(model)))
+    print("cfg3_full  %.0f s  total loss %.6f, %d losses, %d parameters with a gradient -> %s" % (
+        time.time() - t0, total, len(loss_dict), len(grads), os.path.basename(path)), flush=True)
+
+
+def mask_tracker_case(ref, frames=3):
+    """BASELINE cfg 5 through the reference Tracker at 800x1333 (the adapter of make_golden_models.mask_tracker: the
+    reference's mask mix-in takes two arguments, its Tracker passes three)."""
+    model, post, args = um.build("cfg5_full", ref.models.build_model, config.make_args)
+    model.tracking()
+
+    class ThreeArgs:
+        def __init__(self, m):
+            self.m = m
+
+        def __call__(self, img, target=None, prev_features=None):
+            return self.m(img, target)
+
+        def __getattr__(self, name):
+            return getattr(self.m, name)
+    tracker = ref.tracker.Tracker(ThreeArgs(model), post, config.tracker_cfg(), False)
+    tracker.reset()
+    active = []
+    t0 = time.time()
+    with torch.no_grad():
+        for blob in um.full_tracker_sequence(n_frames=frames):
+            tracker.step(blob)
+            active.append(len(tracker.tracks))
+            print("  frame %d: %d active tracks (%.0f s)" % (len(active), active[-1], time.time() - t0), flush=True)
+    results = tracker.get_results()
+    rows, areas = [], []
+    for tid in sorted(results):
+        for f in sorted(results[tid]):
+            r = results[tid][f]
+            rows.append([tid, f, *r['bbox'].tolist(), float(r['score']), r['obj_ind']])
+            areas.append(int(np.asarray(r['mask']).sum()))
+    path = os.path.join(HERE, "full_tracker_cfg5.npz")
+    np.savez_compressed(path, rows=np.array(rows, dtype=np.float64), mask_areas=np.array(areas), active_per_frame=np.array(active),
+                        num_tracks=np.int64(tracker.track_num), mask_shape=np.array(np.asarray(r['mask']).shape))
+    print("tracker_cfg5: %d ids, active %s, %d rows, mask pixels owned %d -> %s" % (
+        tracker.track_num, active, len(rows), sum(areas), os.path.basename(path)), flush=True)
 
 
 def tracker_case(ref, n_frames=None):
@@ -132,6 +206,10 @@ def main():
     for case in which:
         if case == "tracker":
             tracker_case(ref)
+        elif case == "cfg3_full":
+            train_case(ref)
+        elif case == "tracker_cfg5":
+            mask_tracker_case(ref)
         elif case.startswith("tracker") and case[7:].isdigit():   # e.g. tracker64
             tracker_case(ref, int(case[7:]))
         else:

@@ -34,12 +34,25 @@ MASK_SIZES = {"cfg5_segm_tracking": ((128, 160), (200, 250)),      # (padded inp
 # 8 decoder levels).  Goldens: tests/golden/full_*.npz from tests/golden/make_golden_full.py; the
 # tests run on the GPU only (the reference CPU path needs ~1 min per frame on 8 cores).
 FULL_CASES = {
+    # BASELINE cfg 1: plain DETR, one 480x640 frame, 100 object queries, coco classes (detr.py:62-128)
+    "cfg1_full": ((), dict(dataset="coco"), (480, 640), 0),
     "cfg2_full": (("deformable", "tracking", "mot17"), {}, (800, 1333), 100),
+    # BASELINE cfg 3: one training step at bs 2 (engine.py:119-158): not a forward case -- see FULL_TRAIN / train_batch(full=True)
+    "cfg3_full": (("deformable", "tracking", "mot17"), dict(dropout=0.0), (800, 1333), 0),
     "cfg4_full": (("deformable", "tracking", "multi_frame", "mot17"), {}, (800, 1333), 300),
+    # BASELINE cfg 5: mask head on the tracking detector (the buildable MOTS20 model, hidden 256: DESIGN.md section 2)
+    "cfg5_full": (("deformable", "tracking", "mots20"), {}, (800, 1333), 100),
 }
+# the detector-forward cases every route / set-up test of tests/test_full_size_gpu.py is parametrised over
+FULL_DETECTOR_CASES = ("cfg2_full", "cfg4_full")
+FULL_TRAIN_SIZES = ((800, 1333), (768, 1280))   # cfg 3: two images of one batch (the second one padded: masks, valid ratios < 1)
+FULL_TRAIN_BOXES = 30                           # 30 boxes per image
+# cfg 5 fixture: pred_masks of every FULL_MASK_QUERY_STRIDE-th query, post-processed probabilities of the first 3
+FULL_MASK_QUERY_STRIDE = 50
 FULL_TRACKER_FRAMES = 3
 FULL_IMG = (800, 1333)
 FULL_ORIG = (1080, 1800)      # aspect of 800x1333 (datasets/transforms.py:115-146 resize)
+FULL_IMG_CFG1 = (480, 640)    # cfg 1 is quoted on a 480x640 frame (no resize)
 # rows / channels of the large tensors kept in the fixtures (full tensors would be tens of MB)
 FULL_MEMORY_ROW_STRIDE = 89
 FULL_FEAT_CH_STRIDE = 32
@@ -126,23 +139,25 @@ def to_device(target, device):
 TRAIN_OVERRIDES = dict(dropout=0.0, num_queries=40, enc_layers=2, dec_layers=3)
 
 
-def build_train(build_model_fn, make_args_fn, device="cpu", seed=42, weight_seed=2, masks=False):
+def build_train(build_model_fn, make_args_fn, device="cpu", seed=42, weight_seed=2, masks=False, full=False):
+    """full=True: the BASELINE cfg-3 model (300 queries, 6 + 6 layers); dropout stays 0 so that the step is deterministic."""
     args = make_args_fn("deformable", "tracking", "mots20" if masks else "mot17", device=str(device),
-                        **TRAIN_OVERRIDES)
+                        **(dict(dropout=0.0) if full else TRAIN_OVERRIDES))
     torch.manual_seed(seed)
     model, criterion, post = build_model_fn(args)
     perturb_state_dict(model, weight_seed)
     return model, criterion, args
 
 
-def train_batch(seed=9, device="cpu", masks=False):
+def train_batch(seed=9, device="cpu", masks=False, full=False):
     """Two differently sized images (padding masks, valid ratios < 1) with previous-frame targets;
-    masks=True adds box-shaped instance masks (the `masks` key loss_masks reads, detr.py:330-358)."""
+    masks=True adds box-shaped instance masks (the `masks` key loss_masks reads, detr.py:330-358).
+    full=True: BASELINE cfg 3 -- 800x1333 + 768x1280, 30 boxes per image."""
     g = torch.Generator().manual_seed(seed)
     samples, targets = [], []
-    for i, (h, w) in enumerate([(128, 160), (112, 144)]):
+    for i, (h, w) in enumerate(FULL_TRAIN_SIZES if full else [(128, 160), (112, 144)]):
         img = torch.randn(3, h, w, generator=g)
-        n = 5 + i
+        n = FULL_TRAIN_BOXES if full else 5 + i
         cxcy = torch.rand(n, 2, generator=g) * 0.6 + 0.2
         wh = torch.rand(n, 2, generator=g) * 0.2 + 0.05
         boxes = torch.cat([cxcy, wh], 1)
