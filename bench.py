@@ -52,10 +52,18 @@ The JSON line also carries
                    timed beside it; rank 0, N=1 only, a bounded sample.
   single_sequence_fps / multi_sequence_fps -- cfg2/4/5: the same steps with ONE sequence per GPU (no overlap of one
                    sequence's host-side association with another's forward) / with --sequences interleaved.
-  fp32_exact_fps -- the same measurement with every matrix product in fp32 (hipBLASLt linears, library convolutions).
+  precision     -- `value` is measured with the DEFAULT arithmetic: every dense layer as the SIX-term bf16 split product on the
+                   matrix cores (operands cut into hi / mid / lo bf16 pieces = all 24 significand bits, dropped terms < 2^-24 of a
+                   product, fp32 accumulation: fp32 arithmetic in another summation order; include/tf_fused.h).  Beside it:
+                   fp32_exact_fps / single_sequence_fp32_exact_fps (every matrix product in the fp32 LIBRARIES: hipBLASLt linears,
+                   MIOpen convolutions; 3 sequences / one sequence) and split3_fps (the three-term fast mode, products good to 2^-16:
+                   NOT the reference's precision -- it loses the reference's track ids at frame 14 of the 64-frame fixture where
+                   fp32 holds 59, profiles/r04_id_parity_64.txt -- reported, never the headline).
   association   -- what the association leg did in four untimed steps (survivors, initialised, alive).
   parity        -- cfg2: in-run check against the committed reference goldens (max |d boxes|, max |d logits|, ids equal).
-  mfma_utilisation -- matrix-core utilisation of the dense kernels from this round's committed counter pass.
+  mfma_utilisation -- "live": the dense kernels of the frame timed HERE with HIP events at their cfg-2 shapes, as fp32-equivalent
+                   TFLOP/s and as matrix-pipe utilisation = flops x terms / (2.5 PFLOP/s x time); "pmc": the committed counter
+                   pass (rocprofv3 --pmc needs its own run), with the commit it was taken at.
   ranks         -- N > 1: what every rank runs on, gathered over the job's own backend.
 """
 import argparse
@@ -141,6 +149,9 @@ def parse_args():
                     help="encoder / decoder linears as bf16 split products on the matrix cores "
                          "(tf_linear_split_f32; same as TF_SPLIT_LINEAR=1)")
     ap.add_argument("--no-split-linear", dest="split_linear", action="store_false")
+    ap.add_argument("--split-terms", type=int, choices=(3, 6), default=None,
+                    help="terms per split product: 6 (default; fp32-accurate) or 3 (fast mode, products good to 2^-16)")
+    ap.add_argument("--no-split3", action="store_true", help="skip the extra measurement in the three-term fast mode")
     ap.add_argument("--conv1x1-split", dest="conv1x1_split", action="store_true", default=None,
                     help="the backbone's stride-1 1x1 convolutions through the split-product GEMM with the "
                          "FrozenBN / identity / ReLU epilogue (the default; --no-conv1x1-split = TF_CONV1X1_SPLIT=0)")
@@ -205,8 +216,8 @@ def _active_optins(backbone, fused):
              ("stem_pool_fused", fused.stem_pool_fused_enabled()), ("stem_conv_split", fused.stem_conv_split_enabled()),
              ("pos_add_fused", fused.pos_add_fused_enabled()), ("heads_split", fused.heads_split_enabled())]
     names = [n for n, on in flags if on]
-    for env in ("TF_LINEAR_BUFSTORE", "TF_LINEAR_DEEP", "TF_MSDA_PQUAD", "TF_MSDA_DIRECT9", "TF_MSDA_BWD_SORTED2",
-                "TF_CONV_SPLIT_SKIP", "TF_CONV_SPLITK", "TF_CONV1X1_SPLITK", "TF_CONV3_BUFLOAD", "TF_CONV_KSPLIT_POLICY", "TF_LAZY_MASKS"):
+    for env in ("TF_SPLIT_TERMS", "TF_MSDA_PQUAD", "TF_MSDA_DIRECT9", "TF_MSDA_BWD_SORTED2",
+                "TF_CONV_SPLIT_SKIP", "TF_CONV_SPLITK", "TF_CONV1X1_SPLITK", "TF_CONV_KSPLIT_POLICY", "TF_LAZY_MASKS"):
         if os.environ.get(env):
             names.append("%s=%s" % (env, os.environ[env]))
     return names
@@ -490,21 +501,90 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
             "other_patterns": {k: v for k, v in per_pattern.items() if k != "pert"}}
 
 
+MFMA_PEAK_BF16 = 2.5e15   # dense bf16 flop/s of the matrix cores (MI355X_MICROARCH.md)
+
+
+def measure_dense_kernels(device, hidden=256):
+    """The dense kernels of a cfg-2 frame, timed HERE (HIP events around 20 launches replayed from one HIP graph on the launch
+    stream) at the shapes the frame runs them: fp32-equivalent TFLOP/s and matrix-pipe utilisation = 2 M K N x terms /
+    (2.5 PFLOP/s x time) -- the share of the run the matrix cores spend on this kernel's MFMAs if nothing else ran on them.
+    Live, unlike the PMC figures next to it (which need their own rocprofv3 pass and are committed with their commit)."""
+    import torch.nn as nn
+    from trackformer_amd import fused
+    terms = fused.split_terms()
+    g = torch.Generator().manual_seed(0)
+    rows = 22223
+    out = {}
+
+    def timed(fn, flop):
+        stream = torch.cuda.Stream(device)
+        with torch.cuda.stream(stream):
+            fn()                                   # weight images built outside the capture
+            stream.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                for _ in range(20):
+                    fn()
+            graph.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            graph.replay()
+            e1.record(stream)
+            e1.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        return {"us": round(us, 2), "tflops_fp32_equivalent": round(flop / us * 1e-6, 1),
+                "mfma_util": round(flop * terms / MFMA_PEAK_BF16 / (us * 1e-6), 3)}
+    with torch.no_grad():
+        x = torch.randn(rows, hidden, generator=g).to(device)
+        lin1, lin2, norm = nn.Linear(hidden, 1024).to(device), nn.Linear(1024, hidden).to(device), nn.LayerNorm(hidden).to(device)
+        if fused.ffn(x, lin1, lin2, norm, x) is not None:
+            out["ffn_fused 22223 x %d x 1024" % hidden] = timed(lambda: fused.ffn(x, lin1, lin2, norm, x), 4.0 * rows * hidden * 1024)
+        proj = nn.Linear(hidden, hidden).to(device)
+        if fused.linear(x, proj.weight, proj.bias) is not None:
+            out["linear 22223 x %d -> %d" % (hidden, hidden)] = timed(lambda: fused.linear(x, proj.weight, proj.bias), 2.0 * rows * hidden * hidden)
+        if fused.linear_residual_norm(x, proj, x, norm) is not None:
+            out["linear + residual + LayerNorm 22223 x %d" % hidden] = timed(lambda: fused.linear_residual_norm(x, proj, x, norm),
+                                                                             2.0 * rows * hidden * hidden)
+        # ResNet-50 at 800 x 1333: layer2's 3 x 3 convolution (128 -> 128 at 100 x 167) and layer1's closing 1 x 1 (64 -> 256 at 200 x 334)
+        xc = torch.randn(1, 128, 100, 167, generator=g).to(device).contiguous(memory_format=torch.channels_last)
+        taps = (torch.randn(128, 9 * 128, generator=g) / 34).to(device)
+        bias = torch.zeros(128, device=device)
+        if fused.conv3x3(xc, taps, bias, True, 1) is not None:
+            out["conv 3x3 128 -> 128 at 100 x 167"] = timed(lambda: fused.conv3x3(xc, taps, bias, True, 1), 2.0 * 16700 * 1152 * 128)
+        x1 = torch.randn(66800, 64, generator=g).to(device)
+        w1 = (torch.randn(256, 64, generator=g) / 8).to(device)
+        r1 = torch.randn(66800, 256, generator=g).to(device)
+        if fused.linear(x1, w1, None, relu=True, residual=r1) is not None:
+            out["conv 1x1 64 -> 256 + identity + ReLU at 200 x 334"] = timed(lambda: fused.linear(x1, w1, None, relu=True, residual=r1),
+                                                                             2.0 * 66800 * 64 * 256)
+    return {"terms": terms, "peak": "2.5 PFLOP/s dense bf16", "kernels": out}
+
+
 def committed_mfma_utilisation():
-    """Matrix-core utilisation of the dense kernels, from the committed counter pass of this round: PMC counters
-    need their own rocprofv3 run (profiles/r03_mfma_utilisation.json, tools/gpu_runs/gpu_r03_15.sh).  Utilisation =
-    SQ_VALU_MFMA_BUSY_CYCLES (summed over all SIMDs) / (dispatch duration x 2.4 GHz x 1024 SIMDs): it cannot exceed 1."""
+    """Matrix-core utilisation of the dense kernels from a committed counter pass: PMC counters need their own
+    rocprofv3 run.  Utilisation = SQ_VALU_MFMA_BUSY_CYCLES (summed over all SIMDs) / (dispatch duration x 2.4 GHz x 1024 SIMDs):
+    it cannot exceed 1.  The newest profiles/r*_mfma_utilisation.json is used; `source_commit` / `terms` say what it describes."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_mfma_utilisation.json")))
+    if not files:
+        return None
     try:
-        with open(os.path.join(REPO, "profiles", "r03_mfma_utilisation.json")) as f:
+        with open(files[-1]) as f:
             d = json.load(f)
     except (OSError, ValueError):
         return None
     frame = {k: round(v["mfma_util"], 3) for k, v in d.get("mfma_frame", {}).items() if "mfma_util" in v}
-    return {"source": "profiles/r03_mfma_utilisation.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, own pass)",
-            "per_kernel_in_an_eager_cfg2_frame": frame,
-            "harness": {"tf_ffn_fused_f32 22223x256x1024": round(d["mfma_ffn"]["ffn_fused_kernel"]["mfma_util"], 3),
-                        "tf_linear_packed_f32 22223x256->1024": round(d["mfma_lin1"]["split_gemm_stream_kernel"]["mfma_util"], 3),
-                        "tf_linear_split_f32 22223x256->256": round(d["mfma_lin2"]["split_gemm_kernel"]["mfma_util"], 3)}}
+    harness = {}
+    for key, kern, label in (("mfma_ffn", "ffn_fused_kernel", "tf_ffn_fused_f32 22223x256x1024"),
+                             ("mfma_lin1", "split_gemm_stream_kernel", "tf_linear_packed_f32 22223x256->1024"),
+                             ("mfma_lin2", "split_gemm_kernel", "tf_linear_split_f32 22223x256->256")):
+        try:
+            harness[label] = round(d[key][kern]["mfma_util"], 3)
+        except (KeyError, TypeError):
+            pass
+    return {"source": "profiles/%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, own pass)" % os.path.basename(files[-1]),
+            "source_commit": d.get("_commit", "before round 4 (three-term kernels of round 3)"), "terms": d.get("_terms", 3),
+            "per_kernel_in_an_eager_cfg2_frame": frame, "harness": harness}
 
 
 def cpu_operator(kind):
@@ -732,6 +812,8 @@ def main():
                                     verbose=(rank == 0))
     if args.split_linear is not None:
         fused.set_split_linear(args.split_linear)
+    if args.split_terms is not None:
+        fused.set_split_terms(args.split_terms)
     from trackformer_amd import backbone as _backbone
     if args.conv1x1_split is not None:
         _backbone.set_conv1x1_split(args.conv1x1_split)
@@ -757,7 +839,7 @@ def main():
             print(json.dumps(measure_roofline(device, head_dim=hd, patterns=("pert", "init", "local"))))
         return
     model, criterion, post, margs = build_model(cfg, device)
-    single = fp32_exact = association = multi = None
+    single = fp32_exact = fp32_exact_single = split3 = association = multi = None
     n_seq = 1
     if cfg["kind"] == "track":
         model.tracking()
@@ -781,14 +863,28 @@ def main():
                                queries_above_thresh_frame0=seeds["queries_above_0p4_frame0"],
                                track_queries_above_thresh_frame0=seeds["track_queries_above_0p4_frame0"])
         if fused.split_linear_enabled() and not args.no_fp32_exact:
-            # the same measurement with every matrix product in fp32 (hipBLASLt linears, library convolutions): the number a
-            # reader who does not accept the 3-term bf16 products should take
+            # the same measurement with every matrix product in the fp32 libraries (hipBLASLt linears, MIOpen convolutions), with
+            # --sequences and with one sequence
             prev_split = fused.set_split_linear(False)
             try:
-                ef, rf = run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds)
+                ef, rf = run_tracking(cfg, args, device, world, model, post, margs, max(1, args.sequences), seeds)
                 fp32_exact = args.steps * rf * world / ef
+                if args.sequences > 1 and not args.no_single_sequence:
+                    ef, rf = run_tracking(cfg, args, device, world, model, post, margs, 1, seeds)
+                    fp32_exact_single = args.steps * rf * world / ef
             finally:
                 fused.set_split_linear(prev_split)
+        if fused.split_linear_enabled() and fused.split_terms() == 6 and not args.no_split3:
+            # ... and in the three-term fast mode (reported beside the headline, never as the headline)
+            prev_terms = fused.set_split_terms(3)
+            try:
+                e3, r3 = run_tracking(cfg, args, device, world, model, post, margs, max(1, args.sequences), seeds)
+                split3 = {"sequences_per_gpu": max(1, args.sequences), "value": round(args.steps * r3 * world / e3, 3)}
+                if args.sequences > 1 and not args.no_single_sequence:
+                    e3, r3 = run_tracking(cfg, args, device, world, model, post, margs, 1, seeds)
+                    split3["single_sequence"] = round(args.steps * r3 * world / e3, 3)
+            finally:
+                fused.set_split_terms(prev_terms)
     elif cfg["kind"] == "detect":
         model.eval()
         elapsed, reps = run_detect(cfg, args, device, world, model, post)
@@ -802,7 +898,8 @@ def main():
         if args.config == "cfg2" and not args.no_parity and not args.no_graph:
             parity = measure_parity(device)
         if not train and margs.deformable:
-            mfma = committed_mfma_utilisation()
+            mfma = {"live": measure_dense_kernels(device, margs.hidden_dim) if fused.split_linear_enabled() else None,
+                    "pmc": committed_mfma_utilisation()}
         if world == 1 and not args.no_cpu_baseline:
             del model
             torch.cuda.empty_cache()
@@ -829,9 +926,11 @@ def main():
             "ms_per_step": round(1e3 * elapsed / steps_timed, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if not fused.split_linear_enabled() or train
-                     else ("f32 (transformer linears + backbone bottleneck convolutions: 3-pass bf16 split product on MFMA, f32 accumulate)"
-                           if (_backbone._conv1x1_split or _backbone._conv3x3_split) else
-                           "f32 (transformer linears: 3-pass bf16 split product on MFMA, f32 accumulate)"),
+                     else ("f32 (dense layers as the six-term bf16 split product on MFMA: hi / mid / lo pieces carry all 24 significand "
+                           "bits, dropped terms < 2^-24 of a product, f32 accumulate -- fp32 arithmetic in another summation order)"
+                           if fused.split_terms() == 6 else
+                           "f32 storage, products good to 2^-16 (three-term bf16 split product on MFMA, f32 accumulate): the fast mode, "
+                           "NOT the reference's precision"),
             "data": "synthetic", "per_gpu": round(value / world, 3),
             "timed_repeats": reps, "steps_timed": steps_timed, "timed_seconds": round(elapsed, 3),
             "config": {"workload": cfg["name"] + ", seeded random-init weights, frames "
@@ -840,7 +939,7 @@ def main():
                        "global_batch": world * (2 if train else 1),
                        "parallelism": ("DDP x%d (RCCL all-reduce)" if train else "sequence-sharded x%d") % world,
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
-                       "linears": "bf16 split product (hi.hi + hi.mid + mid.hi, f32 accumulate)"
+                       "linears": ("bf16 split product, %d terms, f32 accumulate (own kernels)" % fused.split_terms())
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",
                        **({"routes": _active_optins(_backbone, fused)} if not train and _active_optins(_backbone, fused) else {}),
                        **({"ffn": "one launch per feed-forward block (tf_ffn_fused_f32)"} if fused.ffn_fused_enabled() and not train else {}),
@@ -851,6 +950,15 @@ def main():
             "single_sequence_fps": None if single is None else round(single, 3),
             "multi_sequence_fps": None if multi is None else {"sequences_per_gpu": max(1, args.sequences), "value": round(multi, 3)},
             "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
+            "single_sequence_fp32_exact_fps": None if fp32_exact_single is None else round(fp32_exact_single, 3),
+            "split3_fps": split3,
+            "precision": None if train else {
+                "value_measured_with": ("six-term split product (fp32-accurate), own kernels" if fused.split_terms() == 6 else
+                                        "three-term split product (2^-16 per product), own kernels") if fused.split_linear_enabled()
+                                       else "fp32 libraries (hipBLASLt, MIOpen)",
+                "fp32_exact_fps": "fp32 libraries (hipBLASLt linears, MIOpen convolutions), --sequences per GPU",
+                "single_sequence_fp32_exact_fps": "the same with one sequence per GPU",
+                "split3_fps": "three-term fast mode; not the reference's precision (profiles/r04_id_parity_64.txt)"},
             "association": association, "parity": parity, "ranks": ranks, "mfma_utilisation": mfma,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -12,7 +12,8 @@
  *                          :360-361): residual add + LayerNorm in one pass
  *
  *   tf_linear_split_f32    nn.Linear (+ ReLU) of the encoder / decoder (ms_deform_attn.py:64-88,
- *                          deformable_transformer.py:282-297) as a bf16 split product on the matrix cores
+ *                          deformable_transformer.py:282-297) as a bf16 split product on the matrix cores (six terms:
+ *                          fp32-accurate, the default; three terms: the fast mode -- THE SPLIT PRODUCT below)
  *   tf_linear_packed_f32   the same product with the weight packed once in fragment order (+ tf_linear_pack_weight_f32)
  *   tf_ffn_fused_f32       linear1 -> ReLU -> linear2 -> + residual -> LayerNorm of a transformer layer in one launch
  *   tf_linear_res_ln_f32   linear (256 -> 256) -> + residual -> LayerNorm in one launch (output projection + norm1)
@@ -66,13 +67,26 @@ int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta,
                           int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream);
 
 /*
- * y[M, N] = x[M, K] . w[N, K]^T + bias[N] (bias may be NULL), ReLU if relu != 0; fp32 in and out, row-major.
- * The weight arrives as TWO bf16 tensors [N, K]: w_hi = bf16(w), w_mid = bf16(w - float(w_hi)) (round to nearest
- * even), split once by the caller; x is split the same way inside the kernel and the product is formed as
- * x_hi.w_hi + x_hi.w_mid + x_mid.w_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (relative error of a
- * product below 2^-16; see trackformer_amd/csrc/linear_split.hip).  K % 32 == 0, 16-byte aligned x / w_hi / w_mid.
+ * THE SPLIT PRODUCT (every matrix-core kernel below).  fp32 operands are cut into bf16 pieces (round to nearest even):
+ *   hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)          (the residuals are exact in fp32)
+ * and a product x . w is formed from v_mfma_f32_32x32x16_bf16 terms with fp32 accumulation, smallest terms first:
+ *   six terms   (pieces hi, mid, lo):  x_lo.w_hi + x_hi.w_lo + x_mid.w_mid + x_mid.w_hi + x_hi.w_mid + x_hi.w_hi
+ *               The three pieces carry all 24 significand bits; the dropped terms are below 2^-24 |x||w| -- the arithmetic of the
+ *               reference (fp32 nn.Linear / Conv2d; models/ops/src/cuda/ms_deform_attn_cuda.cu:69 dispatches on fp32) in another
+ *               summation order.  THE DEFAULT of trackformer_amd (fused.set_split_terms(6)).
+ *   three terms (pieces hi, mid):      x_mid.w_hi + x_hi.w_mid + x_hi.w_hi      relative error of a product < 2^-16: boxes / logits
+ *               stay inside the 1e-3 parity bar, but track ids leave the reference's earlier than fp32 does (frame 14 instead of
+ *               59 of the 64-frame fixture, profiles/r04_id_parity_64.txt): the opt-in fast mode.
+ * Entry points that take the weight as separate piece tensors (`w_hi`, `w_mid`, `w_lo`: bf16 [N, K] each, split once by the
+ * caller) select by `w_lo`: NULL -> three terms, else six.  Entry points that take a PACKED weight select by `terms` (3 or 6),
+ * which must be the value the weight was packed with.  x is split the same way inside the kernels.
  */
-int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
+
+/*
+ * y[M, N] = x[M, K] . w[N, K]^T + bias[N] (bias may be NULL), ReLU if relu != 0; fp32 in and out, row-major.
+ * K % 32 == 0, 16-byte aligned x / w_hi / w_mid / w_lo.  (trackformer_amd/csrc/linear_split.hip)
+ */
+int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
                         int64_t M, int K, int N, int relu, void *stream);
 
 /*
@@ -81,46 +95,49 @@ int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, con
  * reference: models/backbone.py:45-55 + torchvision's Bottleneck.forward): on channels_last activations a stride-1 1 x 1
  * convolution IS this GEMM with M = N_img * H * W rows, the BN scale folded into w and its shift as bias.
  */
-int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, const float *residual,
-                            float *y, int64_t M, int K, int N, int relu, void *stream);
+int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias,
+                            const float *residual, float *y, int64_t M, int K, int N, int relu, void *stream);
 
 /*
  * 3 x 3 convolution (padding 1, stride 1 or 2, no groups / dilation) of a channels_last activation as the same split
  * product (an implicit GEMM over the output pixels, K = 9 * Cin): y[n, ho, wo, :] = act(sum_taps x[n, hi, wi, :] . w[:, tap, :]^T
  * + bias).  x [N, Hin, Win, Cin] and y [N, Hout, Wout, Cout] are NHWC (the storage of channels_last NCHW tensors); the weight
- * arrives as bf16 (hi, mid) pieces of the [Cout, 3, 3, Cin] tensor (the storage of a channels_last OIHW weight), Cin % 32 == 0.
- * For torchvision's Bottleneck.conv2 + FrozenBatchNorm2d + ReLU (BN scale folded into w, shift as bias).
+ * arrives as bf16 pieces of the [Cout, 3, 3, Cin] tensor (the storage of a channels_last OIHW weight), Cin % 32 == 0.
+ * For torchvision's Bottleneck.conv2 + FrozenBatchNorm2d + ReLU (BN scale folded into w, shift as bias).  Input, output and
+ * weight pieces below 3 GiB each (buffer-resource offsets), else TF_MSDA_ERR_BAD_DIMS.
  */
-int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
-                         int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
+                         int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
 /* The same convolution with the K loop (9 Cin) cut into `ksplit` pieces that run as separate workgroups -- for few output
  * pixels under a long K (the extra pyramid level of deformable_detr.py:55-79: 2048 -> 256 at 13 x 21; layer4's 3 x 3
  * convolutions).  The pieces write partial sums to `workspace` (ksplit * N*Hout*Wout * cout floats, 16-byte aligned), a second
  * launch adds them in a fixed order (deterministic, unlike atomics) and applies bias / ReLU.  ksplit in 1..64 (1: no workspace
  * needed, identical to tf_conv3x3_split_f32); cout % 4 == 0 and 16-byte aligned y / bias when ksplit > 1. */
-int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, float *workspace,
-                          int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
+                          float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+                          void *stream);
 /* The same kernel for a strided 1 x 1 convolution without padding (w [Cout, Cin]): the projections of the identity branch
  * (torchvision Bottleneck.downsample, stride 2) -- the rows of the GEMM are every stride-th pixel. */
-int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
-                                 int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
+                                 int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
 /* The 1 x 1 convolution (stride 1 or 2, w [Cout, Cin]) with the K loop (Cin) cut into `ksplit` pieces, as tf_conv3x3_splitk_f32:
  * ResNet-50's reducing 1 x 1 convolutions of layer3 / layer4 (torchvision Bottleneck.conv1: 1024 -> 256 at 50 x 84, 2048 -> 512 at
  * 25 x 42 for an 800 x 1333 frame) are 132 / 68 workgroups of 32 / 64 K-slices -- fewer than the chip has CUs. */
-int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, float *workspace,
-                          int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
+                          float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+                          void *stream);
 
 /*
  * The backbone's first convolution (7 x 7, stride 2, padding 3, 3 -> 64 channels; reference: models/backbone.py:93-104 ->
  * torchvision resnet50.conv1) as a split product on the matrix cores (trackformer_amd/csrc/stem_conv.hip).
  *   x         [N, 3, H, W] fp32, planar (NCHW)
- *   w_packed  tf_linear_pack_weight_f32(K = 176, N = 64) of the [64, 176] matrix w2[o][(c * 7 + ky) * 8 + kx] = w[o][c][ky][kx]
+ *   w_packed  tf_linear_pack_weight_f32(K = 176, N = 64, terms) of the [64, 176] matrix w2[o][(c * 7 + ky) * 8 + kx] = w[o][c][ky][kx]
  *             (kx = 7 and k >= 168: zeros) -- with a following FrozenBatchNorm2d's scale folded in by the caller
  *   bias      [64] or NULL (the FrozenBatchNorm2d shift), relu != 0: ReLU
  *   y         [N, (H - 1) / 2 + 1, (W - 1) / 2 + 1, 64] fp32, channels_last
  */
 int tf_stem_conv7x7_f32(const float *x, const void *w_packed, const float *bias, float *y, int N, int H, int W, int relu,
-                        void *stream);
+                        int terms, void *stream);
 
 /*
  * out[n, oy, ox, c] = max over the 3 x 3 window (stride 2, padding 1) of relu(x[n, iy, ix, c] + bias[c]) on channels_last
@@ -134,21 +151,22 @@ int tf_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int 
 /* y[M, N] = (x + x2)[M, K] . w^T + bias: tf_linear_split_f32 with an element-wise add in front, done as the activation tile is
  * staged -- `with_pos_embed(src, pos)` + a projection (models/deformable_transformer.py:279-283, ms_deform_attn.py:67-72)
  * without a separate pass over the tokens.  Bit-identical to adding first. */
-int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const float *bias, float *y,
-                            int64_t M, int K, int N, void *stream);
+int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const void *w_lo,
+                            const float *bias, float *y, int64_t M, int K, int N, void *stream);
 
 /*
  * The same product with the weight in PACKED form (trackformer_amd/csrc/linear_stream.hip): the weight is split into
- * bf16 (hi, mid) once and stored in matrix-core fragment order, so that the GEMM streams it from L2 into registers and
- * only the activations pass through LDS.  Results are bit-identical to tf_linear_split_f32.
- *   tf_linear_packed_bytes(K, N)          size of the packed buffer (N padded to a multiple of 256), or -1; K % 16 == 0
- *   tf_linear_pack_weight_f32(w, packed)  w [N, K] fp32 row-major -> packed (16-byte aligned pointers); one small kernel
- *   tf_linear_packed_f32                  y[M, N] = x[M, K] . w^T + bias, ReLU if relu != 0; K % 64 == 0, 16-byte aligned x
+ * its bf16 pieces once and stored in matrix-core fragment order, so that the GEMM streams it from L2 into registers and
+ * only the activations pass through LDS.  Results are bit-identical to tf_linear_split_f32 with the same number of terms.
+ *   tf_linear_packed_bytes(K, N, terms)          size of the packed buffer (N padded to a multiple of 256), or -1; K % 16 == 0
+ *   tf_linear_pack_weight_f32(w, packed, ...)    w [N, K] fp32 row-major -> packed (16-byte aligned pointers); one small kernel
+ *   tf_linear_packed_f32                         y[M, N] = x[M, K] . w^T + bias, ReLU if relu != 0; K % 64 == 0, 16-byte aligned x
+ * terms: 3 or 6 (see THE SPLIT PRODUCT above); a weight packed for 6 terms holds three pieces per fragment.
  */
-int64_t tf_linear_packed_bytes(int K, int N);
-int tf_linear_pack_weight_f32(const float *w, void *packed, int K, int N, void *stream);
+int64_t tf_linear_packed_bytes(int K, int N, int terms);
+int tf_linear_pack_weight_f32(const float *w, void *packed, int K, int N, int terms, void *stream);
 int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias, float *y, int64_t M, int K, int N,
-                         int relu, void *stream);
+                         int relu, int terms, void *stream);
 
 /*
  * The feed-forward block of a transformer layer in one launch (trackformer_amd/csrc/ffn_fused.hip):
@@ -156,8 +174,8 @@ int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias
  *     y[M, d_model] = [LayerNorm]( residual + relu(x . w1^T + b1) . w2^T + b2 )
  *
  * (reference: models/deformable_transformer.py:282-297 forward_ffn + norm2 of the encoder layer, :371-379 of the decoder
- * layer; inference: the dropouts are identities).  The d_ffn-wide intermediate stays on the CU.  Same three-term bf16 split
- * product as tf_linear_packed_f32 for both GEMMs: without the LayerNorm the result is bit-identical to
+ * layer; inference: the dropouts are identities).  The d_ffn-wide intermediate stays on the CU.  Same split
+ * product as tf_linear_packed_f32 (same `terms`) for both GEMMs: without the LayerNorm the result is bit-identical to
  * tf_linear_packed_f32(relu) -> tf_linear_packed_f32 -> + residual.
  *   w1_packed, w2_packed   tf_linear_pack_weight_f32 of linear1.weight [d_ffn, d_model] (K = d_model, N = d_ffn) and of
  *                          linear2.weight [d_model, d_ffn] (K = d_ffn, N = d_model)
@@ -174,11 +192,11 @@ int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias
  * bias / residual may be NULL, ln_weight / ln_bias both or neither, y must not alias x or residual.
  */
 int tf_linear_res_ln_f32(const float *x, const void *w_packed, const float *bias, const float *residual, const float *ln_weight,
-                         const float *ln_bias, float ln_eps, float *y, int64_t M, int K, int N, void *stream);
+                         const float *ln_bias, float ln_eps, float *y, int64_t M, int K, int N, int terms, void *stream);
 
 int tf_ffn_fused_f32(const float *x, const void *w1_packed, const float *b1, const void *w2_packed, const float *b2,
                      const float *residual, const float *ln_weight, const float *ln_bias, float ln_eps, float *y, int64_t M,
-                     int d_model, int d_ffn, void *stream);
+                     int d_model, int d_ffn, int terms, void *stream);
 
 /*
  * out[n, l, h, :] = sum_j softmax_j(scale * q[n, l, h, :] . k[n, j, h, :]) v[n, j, h, :]      (fp32)

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define TF_MSDA_ABI_VERSION 1
+#define TF_MSDA_ABI_VERSION 2
 #define TF_MSDA_MAX_LEVELS 16
 
 typedef enum tf_msda_status {

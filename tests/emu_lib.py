@@ -48,7 +48,7 @@ def lib():
     L.tf_add_layernorm_f32.restype = ci
     L.tf_add_layernorm_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_stem_conv7x7_f32.restype = ci
-    L.tf_stem_conv7x7_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp]
+    L.tf_stem_conv7x7_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.tf_bias_relu_maxpool_f32.restype = ci
     L.tf_bias_relu_maxpool_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_box_refine_f32.restype = ci
@@ -56,29 +56,29 @@ def lib():
     L.tf_groupnorm_nhwc_f32.restype = ci
     L.tf_groupnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
     L.tf_linear_res_ln_f32.restype = ci
-    L.tf_linear_res_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_linear_res_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_ffn_fused_f32.restype = ci
-    L.tf_ffn_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_ffn_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_add_f32.restype = ci
-    L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_linear_split_f32.restype = ci
-    L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci
-    L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_conv3x3_splitk_f32.restype = ci
-    L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv3x3_split_f32.restype = ci
-    L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_conv1x1_splitk_f32.restype = ci
-    L.tf_conv1x1_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.tf_conv1x1_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv1x1_strided_split_f32.restype = ci
-    L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_linear_packed_bytes.restype = ctypes.c_int64
-    L.tf_linear_packed_bytes.argtypes = [ci, ci]
+    L.tf_linear_packed_bytes.argtypes = [ci, ci, ci]
     L.tf_linear_pack_weight_f32.restype = ci
-    L.tf_linear_pack_weight_f32.argtypes = [vp, vp, ci, ci, vp]
+    L.tf_linear_pack_weight_f32.argtypes = [vp, vp, ci, ci, ci, vp]
     L.tf_linear_packed_f32.restype = ci
-    L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, ci, vp]
     L.tf_mha_core_f32.restype = ci
     L.tf_mha_core_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [ctypes.c_float, vp]
     L.hipemu_get_stats.restype = None
@@ -159,31 +159,52 @@ def msda_backward(value, shapes, loc, attn, grad_out, dshapes=False):
     return gv, gl, ga
 
 
-def bf16_split(w):
-    """w (fp32) -> (hi, mid) as uint16 bit patterns of bf16, round to nearest even (what fused.py hands the kernel)."""
+TERMS = 6   # terms per split product of the wrappers below (include/tf_fused.h: 6 = the default, 3 = the fast mode)
+
+
+def set_terms(n):
+    """3 or 6; returns the previous value."""
+    global TERMS
+    assert n in (3, 6)
+    prev, TERMS = TERMS, n
+    return prev
+
+
+def bf16_split(w, terms=None):
+    """w (fp32) -> (hi, mid, lo) as uint16 bit patterns of bf16, round to nearest even at every step (what fused.py hands the
+    kernel); lo is None for three terms."""
     def to_bf16(x):
         u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
         r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
         return r
+
+    def to_f32(h):
+        return (h.astype(np.uint32) << 16).view(np.float32)
+    w = w.astype(np.float32)
     hi = to_bf16(w)
-    hi_f = (hi.astype(np.uint32) << 16).view(np.float32)
-    mid = to_bf16(w - hi_f)
-    return hi, mid
+    r = w - to_f32(hi)
+    mid = to_bf16(r)
+    lo = to_bf16(r - to_f32(mid)) if (terms or TERMS) == 6 else None
+    return hi, mid, lo
+
+
+def _pieces(w2d, terms=None):
+    """16-byte aligned contiguous piece arrays of a [N, K] weight."""
+    return tuple(None if p is None else _aligned16(np.ascontiguousarray(p)) for p in bf16_split(w2d, terms))
 
 
 def linear_split(x, w, bias=None, relu=False, residual=None):
     x, w = _c(x, np.float32), _c(w, np.float32)
     M, K = x.shape
     N = w.shape[0]
-    hi, mid = bf16_split(w)
-    hi, mid = np.ascontiguousarray(hi), np.ascontiguousarray(mid)
+    hi, mid, lo = _pieces(w)
     b = _c(bias, np.float32) if bias is not None else None
     y = np.full((M, N), np.nan, np.float32)
     if residual is not None:
         r = _c(residual, np.float32)
-        rc = lib().tf_linear_split_res_f32(_p(x), _p(hi), _p(mid), _p(b), _p(r), _p(y), M, K, N, int(relu), None)
+        rc = lib().tf_linear_split_res_f32(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(r), _p(y), M, K, N, int(relu), None)
     else:
-        rc = lib().tf_linear_split_f32(_p(x), _p(hi), _p(mid), _p(b), _p(y), M, K, N, int(relu), None)
+        rc = lib().tf_linear_split_f32(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(y), M, K, N, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_linear_split_f32: status %d" % rc)
     return y
@@ -194,11 +215,10 @@ def linear_split_add(x, x2, w, bias=None):
     x, x2, w = _aligned(x), _aligned(x2), _c(w, np.float32)
     M, K = x.shape
     N = w.shape[0]
-    hi, mid = bf16_split(w)
-    hi, mid = _aligned16(np.ascontiguousarray(hi)), _aligned16(np.ascontiguousarray(mid))
+    hi, mid, lo = _pieces(w)
     b = _aligned(bias)
     y = np.full((M, N), np.nan, np.float32)
-    rc = lib().tf_linear_split_add_f32(_p(x), _p(x2), _p(hi), _p(mid), _p(b), _p(y), M, K, N, None)
+    rc = lib().tf_linear_split_add_f32(_p(x), _p(x2), _p(hi), _p(mid), _p(lo), _p(b), _p(y), M, K, N, None)
     if rc != 0:
         raise RuntimeError("tf_linear_split_add_f32: status %d" % rc)
     return y
@@ -217,18 +237,10 @@ def linear_packed(x, w, bias=None, relu=False):
     x, w = _c(x, np.float32), _c(w, np.float32)
     M, K = x.shape
     N = w.shape[0]
-    nbytes = lib().tf_linear_packed_bytes(K, N)
-    if nbytes < 0:
-        raise RuntimeError("tf_linear_packed_bytes(%d, %d) < 0" % (K, N))
-    packed = np.zeros(nbytes + 16, np.uint8)
-    off = (-packed.ctypes.data) % 16
-    pk = packed[off:off + nbytes]
-    rc = lib().tf_linear_pack_weight_f32(_p(w), pk.ctypes.data, K, N, None)
-    if rc != 0:
-        raise RuntimeError("tf_linear_pack_weight_f32: status %d" % rc)
+    pk = _packed(w)
     b = _c(bias, np.float32) if bias is not None else None
     y = np.full((M, N), np.nan, np.float32)
-    rc = lib().tf_linear_packed_f32(_p(x), pk.ctypes.data, _p(b), _p(y), M, K, N, int(relu), None)
+    rc = lib().tf_linear_packed_f32(_p(x), pk.ctypes.data, _p(b), _p(y), M, K, N, int(relu), TERMS, None)
     if rc != 0:
         raise RuntimeError("tf_linear_packed_f32: status %d" % rc)
     return y
@@ -237,13 +249,13 @@ def linear_packed(x, w, bias=None, relu=False):
 def _packed(w):
     w = _c(w, np.float32)
     N, K = w.shape
-    nbytes = lib().tf_linear_packed_bytes(K, N)
+    nbytes = lib().tf_linear_packed_bytes(K, N, TERMS)
     if nbytes < 0:
         raise RuntimeError("tf_linear_packed_bytes(%d, %d) < 0" % (K, N))
     buf = np.zeros(nbytes + 16, np.uint8)
     off = (-buf.ctypes.data) % 16
     pk = buf[off:off + nbytes]
-    rc = lib().tf_linear_pack_weight_f32(_p(w), pk.ctypes.data, K, N, None)
+    rc = lib().tf_linear_pack_weight_f32(_p(w), pk.ctypes.data, K, N, TERMS, None)
     if rc != 0:
         raise RuntimeError("tf_linear_pack_weight_f32: status %d" % rc)
     return pk
@@ -272,7 +284,7 @@ def ffn_fused(x, w1, b1, w2, b2, residual=None, ln=None, eps=1e-5, guard_rows=0)
     g, be = (_aligned(ln[0]), _aligned(ln[1])) if ln is not None else (None, None)
     y = _aligned(np.full((M + guard_rows, D), np.nan, np.float32))
     rc = lib().tf_ffn_fused_f32(_p(x), p1.ctypes.data, _p(b1), p2.ctypes.data, _p(b2), _p(r), _p(g), _p(be),
-                                ctypes.c_float(eps), _p(y), M, D, F, None)
+                                ctypes.c_float(eps), _p(y), M, D, F, TERMS, None)
     if rc != 0:
         raise RuntimeError("tf_ffn_fused_f32: status %d" % rc)
     return y
@@ -287,7 +299,7 @@ def linear_res_ln(x, w, bias=None, residual=None, ln=None, eps=1e-5, guard_rows=
     g, be = (_aligned(ln[0]), _aligned(ln[1])) if ln is not None else (None, None)
     y = _aligned(np.full((M + guard_rows, w.shape[0]), np.nan, np.float32))
     rc = lib().tf_linear_res_ln_f32(_p(x), pk.ctypes.data, _p(b), _p(r), _p(g), _p(be), ctypes.c_float(eps), _p(y), M, K,
-                                    w.shape[0], None)
+                                    w.shape[0], TERMS, None)
     if rc != 0:
         raise RuntimeError("tf_linear_res_ln_f32: status %d" % rc)
     return y
@@ -308,7 +320,7 @@ def stem_conv(x_nchw, w, bias=None, relu=False):
     pk = _packed(stem_weight_matrix(w))
     b = _aligned(bias)
     y = _aligned(np.full((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 64), np.nan, np.float32))
-    rc = lib().tf_stem_conv7x7_f32(_p(x), pk.ctypes.data, _p(b), _p(y), N, H, W, int(relu), None)
+    rc = lib().tf_stem_conv7x7_f32(_p(x), pk.ctypes.data, _p(b), _p(y), N, H, W, int(relu), TERMS, None)
     if rc != 0:
         raise RuntimeError("tf_stem_conv7x7_f32: status %d" % rc)
     return y
@@ -366,14 +378,14 @@ def conv3x3_split(x_nhwc, w_ohwi, bias=None, relu=False, stride=1):
     x, w = _c(x_nhwc, np.float32), _c(w_ohwi, np.float32)
     n, h, wd, cin = x.shape
     cout, ks = w.shape[0], w.shape[1]
-    hi, mid = bf16_split(w.reshape(cout, ks * ks * cin))
-    hi, mid = np.ascontiguousarray(hi), np.ascontiguousarray(mid)
+    x = _aligned(x)
+    hi, mid, lo = _pieces(w.reshape(cout, ks * ks * cin))
     b = _c(bias, np.float32) if bias is not None else None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
     y = np.full((n, ho, wo, cout), np.nan, np.float32)
     fn = lib().tf_conv3x3_split_f32 if ks == 3 else lib().tf_conv1x1_strided_split_f32
-    rc = fn(_p(x), _p(hi), _p(mid), _p(b), _p(y), n, h, wd, cin, cout, stride, int(relu), None)
+    rc = fn(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(y), n, h, wd, cin, cout, stride, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_conv3x3_split_f32: status %d" % rc)
     return y
@@ -385,15 +397,14 @@ def conv3x3_splitk(x_nhwc, w_ohwi, bias=None, relu=False, stride=1, ksplit=4):
     x, w = _aligned(x_nhwc), _c(w_ohwi, np.float32)
     n, h, wd, cin = x.shape
     cout, ks = w.shape[0], w.shape[1]
-    hi, mid = bf16_split(w.reshape(cout, ks * ks * cin))
-    hi, mid = _aligned16(np.ascontiguousarray(hi)), _aligned16(np.ascontiguousarray(mid))
+    hi, mid, lo = _pieces(w.reshape(cout, ks * ks * cin))
     b = _aligned(bias)
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
     y = _aligned(np.full((n, ho, wo, cout), np.nan, np.float32))
     ws = _aligned(np.full((max(ksplit, 1), n * ho * wo * cout), np.nan, np.float32))
     fn = lib().tf_conv3x3_splitk_f32 if ks == 3 else lib().tf_conv1x1_splitk_f32
-    rc = fn(_p(x), _p(hi), _p(mid), _p(b), _p(y), _p(ws), ksplit, n, h, wd, cin, cout, stride, int(relu), None)
+    rc = fn(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(y), _p(ws), ksplit, n, h, wd, cin, cout, stride, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_conv%dx%d_splitk_f32: status %d" % (ks, ks, rc))
     return y

@@ -1,0 +1,38 @@
+"""GPU (-m gpu): the N > 1 path of bench.py end to end on a ONE-GPU box -- `python bench.py --gpus 2` re-executes itself under
+torch.distributed.run (one process per rank, rendezvous on 127.0.0.1), shards the sequences over the ranks as
+engine.py:289-303 of the reference does, brackets the timed region with barriers, takes the max over ranks and lets rank 0
+print the ONE JSON line.  With TF_BENCH_ONE_DEVICE=1 both ranks use cuda:0 and the barriers go over gloo: the numbers mean
+nothing, but the launcher, the rank environment, the pinning call, the gathered `ranks` block and the rank-0 report are the
+code the driver's 8-GPU scaling run executes -- so that run is not the first time they execute on hardware."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_report_themselves():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU")
+    env = dict(os.environ, TF_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--min-seconds", "0.2",
+           "--sequences", "1", "--no-cpu-baseline", "--no-roofline", "--no-parity", "--no-fp32-exact", "--no-split3",
+           "--no-single-sequence"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line: %r" % lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["value"] > 0
+    assert d["config"]["parallelism"] == "sequence-sharded x2" and d["config"]["global_batch"] == 2
+    ranks = d["ranks"]
+    assert ranks["world"] == 2 and ranks["distinct_processes"] == 2 and ranks["backend"] == "gloo"
+    assert len(ranks["devices"]) == 2 and len(ranks["cpus_per_rank"]) == 2
+    assert abs(d["per_gpu"] * 2 - d["value"]) < 1e-2 * d["value"]     # value = whole job, per_gpu = value / N

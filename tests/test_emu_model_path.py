@@ -25,7 +25,7 @@ def _run(case, optin, fn=None):
         fused._LINLN_MIN_ROWS = 1
         fused._FFN_FUSED_MIN_ROWS = 1   # the test models have few tokens: the decoder's feed-forward blocks take it too
         on = 1 if optin else 0
-        opts = {b"linear_bufstore": on, b"linear_deep": on, b"direct9": on}
+        opts = {b"direct9": on}
         prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
         try:
             return (fn() if fn is not None else shared.run_case(case)) + (dict(lib.calls),)

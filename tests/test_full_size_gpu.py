@@ -57,7 +57,8 @@ def _forward(case, models, dev, setup):
     img, prev, target = um.model_inputs(case, args.hidden_dim)
     img, prev, target = img.to(dev), prev.to(dev), um.to_device(target, dev)
     detector = model
-    prev_split = fused.set_split_linear(setup == "graph_split_linear")
+    prev_split = fused.set_split_linear(setup in ("graph_split_linear", "graph_split3"))
+    prev_terms = fused.set_split_terms(3 if setup == "graph_split3" else 6)
     try:
         if setup != "eager":
             runtime.configure_inference(verbose=False)
@@ -74,10 +75,12 @@ def _forward(case, models, dev, setup):
             assert len(detector._graphs) == 1, "the HIP-graph path was not taken"
     finally:
         fused.set_split_linear(prev_split)
+        fused.set_split_terms(prev_terms)
     return model, out, res, feats, memory
 
 
-def _compare(case, model, out, res, feats, memory, box_tol=1e-3, logit_tol=1e-3):
+def _compare(case, model, out, res, feats, memory, box_tol=1e-3, logit_tol=1e-3, orig=None):
+    orig = orig or um.FULL_ORIG
     z = np.load(os.path.join(GOLDEN, "full_%s.npz" % case))
     assert abs(_checksum(model) - float(z["weight_checksum"])) < 1e-6 * float(z["weight_checksum"])
     np.testing.assert_allclose(out['pred_boxes'].cpu().numpy(), z['pred_boxes'], atol=box_tol)
@@ -89,9 +92,9 @@ def _compare(case, model, out, res, feats, memory, box_tol=1e-3, logit_tol=1e-3)
     np.testing.assert_allclose(aux_l, z['aux_logits'], atol=logit_tol)
     np.testing.assert_array_equal(res['labels'].cpu().numpy(), z['labels'])
     np.testing.assert_allclose(res['scores'].cpu().numpy(), z['scores'], atol=logit_tol)
-    np.testing.assert_allclose(res['boxes'].cpu().numpy(), z['boxes'], atol=box_tol * max(um.FULL_ORIG))
+    np.testing.assert_allclose(res['boxes'].cpu().numpy(), z['boxes'], atol=box_tol * max(orig))
     # encoder output (6 layers of the LDS-window kernel at S = 22 223): every 89th token
-    mem = torch.cat([m.flatten(2) for m in memory], 2).transpose(1, 2)
+    mem = (torch.cat([m.flatten(2) for m in memory], 2) if isinstance(memory, (list, tuple)) else memory.flatten(2)).transpose(1, 2)
     assert list(mem.shape) == z['memory_shape'].tolist()
     rows = mem[0, ::um.FULL_MEMORY_ROW_STRIDE].cpu().numpy()
     np.testing.assert_allclose(rows, z['memory_rows'], atol=logit_tol * max(1.0, np.abs(z['memory_rows']).max()))
@@ -101,8 +104,8 @@ def _compare(case, model, out, res, feats, memory, box_tol=1e-3, logit_tol=1e-3)
         float(np.abs(out['pred_logits'].cpu().numpy() - z['pred_logits']).max())
 
 
-@pytest.mark.parametrize("setup", ["eager", "graph_tuned", "graph_split_linear"])
-@pytest.mark.parametrize("case", list(um.FULL_CASES))
+@pytest.mark.parametrize("setup", ["eager", "graph_tuned", "graph_split_linear", "graph_split3"])
+@pytest.mark.parametrize("case", um.FULL_DETECTOR_CASES)
 def test_full_size_model_matches_reference_cpu_path(dev, models, case, setup):
     model, out, res, feats, memory = _forward(case, models, dev, setup)
     dbox, dlogit = _compare(case, model, out, res, feats, memory)
@@ -115,7 +118,8 @@ def _run_tracker(models, dev, setup):
     from trackformer_amd.tracker import Tracker
     model, post, args = models("cfg2_full")
     detector = model
-    prev_split = fused.set_split_linear(setup == "graph_split_linear")
+    prev_split = fused.set_split_linear(setup in ("graph_split_linear", "graph_split3"))
+    prev_terms = fused.set_split_terms(3 if setup == "graph_split3" else 6)
     try:
         if setup != "eager":
             runtime.configure_inference(verbose=False)
@@ -129,6 +133,7 @@ def _run_tracker(models, dev, setup):
                 active.append(len(tracker.tracks))
     finally:
         fused.set_split_linear(prev_split)
+        fused.set_split_terms(prev_terms)
     results = tracker.get_results()
     rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']),
                       results[tid][f]['obj_ind']]
@@ -136,7 +141,7 @@ def _run_tracker(models, dev, setup):
     return tracker, rows, active
 
 
-@pytest.mark.parametrize("setup", ["eager", "graph_tuned", "graph_split_linear"])
+@pytest.mark.parametrize("setup", ["eager", "graph_tuned", "graph_split_linear", "graph_split3"])
 def test_full_size_tracker_track_ids_bit_exact(dev, models, setup):
     tracker, rows, active = _run_tracker(models, dev, setup)
     z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
@@ -205,7 +210,7 @@ def test_full_size_tracker_64_frame_sequence_against_reference(dev, models):
 
 
 @pytest.mark.parametrize("routes", [(True, False), (False, True), (False, False)], ids=["conv1x1_only", "conv3x3_only", "library_convolutions"])
-@pytest.mark.parametrize("case", list(um.FULL_CASES))
+@pytest.mark.parametrize("case", um.FULL_DETECTOR_CASES)
 def test_conv_split_routes_full_size(dev, models, case, routes):
     """The bottleneck convolutions of the backbone through the split-product kernels with the FrozenBN shift / identity /
     ReLU epilogue (backbone.set_conv1x1_split / set_conv3x3_split): BASELINE-size model against the reference goldens,
@@ -285,7 +290,7 @@ def test_conv_split_backbone_layer_outputs(dev):
         assert got2.shape == ref2.shape and float((got2 - ref2).abs().max()) < 1e-3 * float(ref2.abs().max())
 
 
-@pytest.mark.parametrize("case", list(um.FULL_CASES))
+@pytest.mark.parametrize("case", um.FULL_DETECTOR_CASES)
 def test_input_proj_library_route_full_size(dev, models, case):
     """input_proj's 1 x 1 levels as split GEMM + tf_groupnorm_nhwc_f32 is the default (fused.set_input_proj_fused); here
     switched off: library convolution + ATen GroupNorm."""
@@ -314,7 +319,7 @@ def test_groupnorm_nhwc_matches_torch(dev, n, c, h, w, groups):
     assert torch.allclose(got.view(n, h, w, c).permute(0, 3, 1, 2), ref, atol=2e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("case", list(um.FULL_CASES))
+@pytest.mark.parametrize("case", um.FULL_DETECTOR_CASES)
 def test_fused_box_refine_full_size(dev, models, case):
     """The decoder's iterative box refinement as one launch per layer (fused.set_box_refine_fused)."""
     from trackformer_amd import fused
@@ -339,7 +344,7 @@ def test_fused_box_refine_full_size(dev, models, case):
         fused.set_box_refine_fused(prev)
 
 
-@pytest.mark.parametrize("case", list(um.FULL_CASES))
+@pytest.mark.parametrize("case", um.FULL_DETECTOR_CASES)
 def test_separate_ffn_route_full_size(dev, models, case):
     """The feed-forward blocks in one launch each (tf_ffn_fused_f32) and output projection + residual + LayerNorm in one
     launch (tf_linear_res_ln_f32) are the defaults; here switched off (separate linears + tf_add_layernorm_f32), hidden 256
@@ -371,15 +376,15 @@ def test_conv3x3_split_k(dev, shape, cout, stride, ksplit):
     w = (torch.randn(cout, shape[1], 3, 3, generator=g) / (3 * shape[1] ** 0.5)).to(dev)
     b = torch.randn(cout, generator=g).to(dev)
     taps = w.permute(0, 2, 3, 1).reshape(cout, 9 * shape[1]).contiguous()
-    hi, mid = fused._split_weight(taps)
+    hi, mid, lo = fused._split_weight(taps)
     n, cin, h, wd = shape
     ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
     outs = []
     for _ in range(2):
         y = torch.full((n, ho, wo, cout), float("nan"), device=dev)
         ws = torch.empty((ksplit, n * ho * wo * cout), device=dev)
-        rc = _cabi.lib().tf_conv3x3_splitk_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(),
-                                               ksplit, n, h, wd, cin, cout, stride, 1, fused._stream(dev))
+        rc = _cabi.lib().tf_conv3x3_splitk_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if lo is None else lo.data_ptr(),
+                                               b.data_ptr(), y.data_ptr(), ws.data_ptr(), ksplit, n, h, wd, cin, cout, stride, 1, fused._stream(dev))
         _cabi.check(rc, "tf_conv3x3_splitk_f32")
         outs.append(y)
     ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)).permute(0, 2, 3, 1)
@@ -416,38 +421,42 @@ def test_conv1x1_split_k(dev, shape, cout, stride):
         assert torch.equal(y1, y0)                     # two pieces do not pay for a 1 x 1 convolution: left alone
 
 
+@pytest.mark.parametrize("terms", [6, 3], ids=["six_terms", "three_terms"])
 @pytest.mark.parametrize("shape,cout,ks,stride", [((1, 64, 200, 334), 64, 3, 1), ((1, 256, 100, 167), 256, 3, 2), ((1, 512, 25, 42), 512, 3, 1),
                                                   ((2, 128, 37, 53), 160, 3, 1), ((1, 1024, 50, 84), 2048, 1, 2)])
-def test_conv3x3_buffer_loads_equal_pointer_loads(dev, shape, cout, ks, stride):
-    """split_conv3_kernel fetches through buffer resources by default (a tap outside the image reads zeros from beyond
-    num_records); conv3_bufload = 0 keeps the pointer loads + select.  Same products in the same
-    order: bit-identical at ResNet-50's shapes of the 800 x 1333 frame (borders on all four sides, the last row block
-    partial, the split-K pieces fused.conv3x3 chooses), and within 1e-3 of the library convolution."""
-    from trackformer_amd import _cabi, fused
+def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
+    """split_conv3_kernel (buffer-resource fetches: a tap outside the image reads zeros from beyond num_records; DESIGN.md
+    section 4.4) at ResNet-50's shapes of the 800 x 1333 frame -- borders on all four sides, the last row block partial, the
+    split-K pieces fused.conv3x3 chooses -- against a float64 convolution: six terms at fp32 round-off (the library's fp32
+    convolution is no closer), three terms at 2^-16 per product."""
+    from trackformer_amd import fused
     g = torch.Generator().manual_seed(shape[1] + cout)
     x = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
     w = (torch.randn(cout, shape[1], ks, ks, generator=g) / (ks * shape[1] ** 0.5)).to(dev)
     b = torch.randn(cout, generator=g).to(dev)
     taps = w.permute(0, 2, 3, 1).reshape(cout, ks * ks * shape[1]).contiguous()
-    lib = _cabi.lib()
-    outs = {}
-    for mode in (1, 0):
-        prev = lib.tf_msda_set_option(b"conv3_bufload", mode)
-        try:
-            outs[mode] = fused.conv3x3(x, taps, b, True, stride)
-            torch.cuda.synchronize()
-        finally:
-            lib.tf_msda_set_option(b"conv3_bufload", prev)
-    assert prev == 1 or mode == 1                      # buffer loads are the default
-    assert outs[1] is not None and torch.equal(outs[0], outs[1])
-    ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=ks // 2))
-    assert float((outs[1] - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+    prev = fused.set_split_terms(terms)
+    try:
+        y = fused.conv3x3(x, taps, b, True, stride)
+        torch.cuda.synchronize()
+    finally:
+        fused.set_split_terms(prev)
+    assert y is not None
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2))
+    lib32 = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=ks // 2))
+    scale = float(ref.abs().max())
+    err, err_lib = float((y.double() - ref).abs().max()) / scale, float((lib32.double() - ref).abs().max()) / scale
+    print("conv %s -> %d, %d x %d / %d, %d terms: max err / max |y| %.2e (library fp32 convolution: %.2e)" % (
+        shape, cout, ks, ks, stride, terms, err, err_lib))
+    assert err < (2e-6 if terms == 6 else 1e-4)
+    if terms == 6:
+        assert err < 4 * err_lib + 1e-7
 
 
-@pytest.mark.parametrize("case", list(um.FULL_CASES))
+@pytest.mark.parametrize("case", um.FULL_DETECTOR_CASES)
 def test_every_round3_route_switched_off_full_size(dev, models, case):
     """Every switch of DESIGN.md section 4.3 OFF at once (the round-2 defaults: library convolutions, separate linears and
-    LayerNorms, plain-store GEMM epilogues, msda_fwd_f32_buf / msda_bwd_f32_sorted): BASELINE-size model against the
+    LayerNorms, msda_fwd_f32_buf / msda_bwd_f32_sorted): BASELINE-size model against the
     reference goldens and, for cfg 2, the tracker's ids."""
     from trackformer_amd import _cabi, backbone, fused
     lib = _cabi.lib()
@@ -455,7 +464,7 @@ def test_every_round3_route_switched_off_full_size(dev, models, case):
                fused.set_ffn_fused, fused.set_linear_ln_fused, fused.set_stem_pool_fused, fused.set_pos_add_fused,
                fused.set_stem_conv_split, fused.set_heads_split]
     prev = [s(False) for s in setters]
-    opts = {b"linear_bufstore": 0, b"linear_deep": 0, b"direct9": 0}
+    opts = {b"direct9": 0}
     prev_opts = {k: lib.tf_msda_set_option(k, v) for k, v in opts.items()}
     try:
         model, out, res, feats, memory = _forward(case, models, dev, "graph_split_linear")
@@ -471,3 +480,114 @@ def test_every_round3_route_switched_off_full_size(dev, models, case):
             s(p)
         for k, v in prev_opts.items():
             lib.tf_msda_set_option(k, v)
+
+
+# ------------------------------------------------------------------ BASELINE cfg 1 / cfg 3 / cfg 5 at their quoted sizes (round 4:
+# tests/golden/make_golden_full.py cfg1_full / cfg3_full / cfg5_full / tracker_cfg5, from the reference's own classes on CPU)
+
+
+def run_cfg1(device):
+    """Plain DETR (detr.py:62-128): 100 object queries, coco classes, dense encoder / decoder with ffn 2048, one 480 x 640 frame."""
+    from trackformer_amd import config, factory
+    model, post, args = um.build("cfg1_full", factory.build_model, config.make_args, device=device)
+    model.to(device).eval()
+    img, _, target = um.model_inputs("cfg1_full", args.hidden_dim)
+    with torch.no_grad():
+        out, _, feats, memory, hs = model(img.to(device), target)
+        res = post['bbox'](out, torch.tensor([list(um.FULL_IMG_CFG1)], device=device))[0]
+    return model, out, res, feats, memory
+
+
+@pytest.mark.parametrize("split", [False, True], ids=["fp32_libraries", "split_product"])
+def test_cfg1_plain_detr_480x640_matches_reference(dev, split):
+    from trackformer_amd import fused
+    prev = fused.set_split_linear(split)
+    try:
+        model, out, res, feats, memory = run_cfg1(dev)
+    finally:
+        fused.set_split_linear(prev)
+    dbox, dlogit = _compare("cfg1_full", model, out, res, feats, memory, orig=um.FULL_IMG_CFG1)
+    print("cfg1_full / %s: max |d boxes| %.2e, max |d logits| %.2e" % ("split" if split else "library", dbox, dlogit))
+
+
+def _cfg5_model(dev):
+    from trackformer_amd import config, factory
+    model, post, args = um.build("cfg5_full", factory.build_model, config.make_args, device=dev)
+    model.to(dev).tracking()
+    return model, post, args
+
+
+def test_cfg5_mask_head_800x1333_matches_reference(dev):
+    """BASELINE cfg 5 (detr_segmentation.py:41-71 on the tracking detector): detector outputs, the mask logits of every 50th
+    query and the post-processed probabilities of the first three against the reference's classes on CPU."""
+    model, post, args = _cfg5_model(dev)
+    img, _, target = um.model_inputs("cfg5_full", args.hidden_dim)
+    with torch.no_grad():
+        out, _, feats, memory, hs = model(img.to(dev), um.to_device(target, dev), None)
+        sizes = torch.tensor([list(um.FULL_ORIG)], device=dev)
+        res = post['bbox'](out, sizes)
+        seg = post['segm'](res, out, sizes, torch.tensor([list(um.FULL_IMG)], device=dev), return_probs=True)
+    dbox, dlogit = _compare("cfg5_full", model, out, res[0], feats, memory)
+    z = np.load(os.path.join(GOLDEN, "full_cfg5_full.npz"))
+    assert list(out['pred_masks'].shape) == z['pred_masks_shape'].tolist()
+    pm = out['pred_masks'][:, ::um.FULL_MASK_QUERY_STRIDE].cpu().numpy()
+    scale = max(1.0, float(np.abs(z['pred_masks']).max()))
+    np.testing.assert_allclose(pm, z['pred_masks'], atol=1e-3 * scale)
+    np.testing.assert_allclose(seg[0]['masks'][:3, :, ::4, ::4].cpu().numpy(), z['post_masks'], atol=1e-3)
+    print("cfg5_full: max |d boxes| %.2e, max |d logits| %.2e, max |d mask logits| %.2e (scale %.1f)" % (
+        dbox, dlogit, float(np.abs(pm - z['pred_masks']).max()), scale))
+
+
+@pytest.mark.parametrize("lazy", [False, True], ids=["masks_for_every_query", "lazy_masks"])
+def test_cfg5_tracker_with_masks_800x1333_matches_reference(dev, lazy):
+    """The reference Tracker + mask head (tracker.py:521-547) over three 800 x 1333 frames: ids / frames / source queries exact,
+    boxes and scores within tolerance, the mask area every track owns within 2 % of the image (full_tracker_cfg5.npz)."""
+    from trackformer_amd import config
+    from trackformer_amd.tracker import Tracker
+    model, post, args = _cfg5_model(dev)
+    tracker = Tracker(model, post, config.tracker_cfg(), False, lazy_masks=lazy)
+    tracker.reset()
+    with torch.no_grad():
+        for blob in um.full_tracker_sequence(n_frames=3):
+            tracker.step(dict(blob, img=blob['img'].to(dev)))
+    results = tracker.get_results()
+    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg5.npz"))
+    rows, areas = [], []
+    for tid in sorted(results):
+        for f in sorted(results[tid]):
+            r = results[tid][f]
+            rows.append([tid, f, *r['bbox'].tolist(), float(r['score']), r['obj_ind']])
+            areas.append(int(np.asarray(r['mask']).sum()))
+            assert list(np.asarray(r['mask']).shape) == z["mask_shape"].tolist()
+    rows = np.array(rows, dtype=np.float64)
+    assert rows.shape == z["rows"].shape and int(z["num_tracks"]) == tracker.track_num
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])
+    np.testing.assert_allclose(rows[:, 2:6], z["rows"][:, 2:6], atol=1e-3 * max(um.FULL_ORIG))
+    np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
+    n_px = int(np.prod(z["mask_shape"]))
+    assert np.abs(np.array(areas) - z["mask_areas"]).max() <= 0.02 * n_px
+
+
+def test_cfg3_training_step_800x1333_batch2_matches_reference(dev):
+    """BASELINE cfg 3: one training step (engine.py:119-158, detr_tracking.py:39-183) of the full model at batch 2
+    (800 x 1333 + a padded 768 x 1280, 30 boxes per image, previous-frame pass, track-query augmentation, SetCriterion, backward
+    through tf_msda_backward_f32 at S = 22 223) against the reference on CPU: every loss, the weighted total, and the gradient
+    norm of EVERY parameter (full_cfg3_full.npz)."""
+    from trackformer_amd import config, factory
+    model, criterion, args = um.build_train(factory.build_model, config.make_args, device=dev, full=True)
+    model.to(dev)
+    criterion.to(dev)
+    samples, targets = um.train_batch(device=dev, full=True)
+    loss_dict, total, grads = um.train_step(model, criterion, samples, targets)
+    z = np.load(os.path.join(GOLDEN, "full_cfg3_full.npz"))
+    assert abs(_checksum(model) - float(z["weight_checksum"])) < 1e-6 * float(z["weight_checksum"])
+    assert sorted(loss_dict) == z["loss_keys"].tolist()
+    got = np.array([loss_dict[k] for k in sorted(loss_dict)])
+    np.testing.assert_allclose(got, z["loss_vals"], rtol=1e-3, atol=1e-3)
+    assert abs(total - float(z["total"])) <= 1e-3 * abs(float(z["total"]))
+    assert len(grads) == int(z["num_grads"]) and sorted(grads) == z["grad_keys"].tolist()
+    gn = np.array([grads[k] for k in z["grad_keys"].tolist()])
+    rel = np.abs(gn - z["grad_norms"]) / np.maximum(np.abs(z["grad_norms"]), 1e-6 * np.abs(z["grad_norms"]).max())
+    print("cfg3_full: total %.6f (reference %.6f), %d gradient norms, max relative difference %.2e (%s)" % (
+        total, float(z["total"]), len(gn), float(rel.max()), z["grad_keys"][int(rel.argmax())]))
+    np.testing.assert_allclose(gn, z["grad_norms"], rtol=5e-3, atol=1e-6 * float(np.abs(z["grad_norms"]).max()))

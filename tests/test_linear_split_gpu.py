@@ -1,5 +1,6 @@
-"""GPU (-m gpu): tf_linear_split_f32 -- nn.Linear as a bf16 split product (hi.hi + hi.mid + mid.hi, fp32 accumulate) on
-the matrix cores -- against a float64 reference, and the model / tracker goldens with the opt-in switched on."""
+"""GPU (-m gpu): tf_linear_split_f32 -- nn.Linear as a bf16 split product (six terms: the fp32-accurate default; three terms:
+the fast mode; fp32 accumulation) on the matrix cores -- against a float64 reference, and the model / tracker goldens with the
+routes switched on.  Every test runs for both term counts."""
 import pytest
 import torch
 
@@ -17,11 +18,13 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture()
-def split_on():
+@pytest.fixture(params=[6, 3], ids=["six_terms", "three_terms"])
+def split_on(request):
     from trackformer_amd import fused
     prev = fused.set_split_linear(True)
+    prev_terms = fused.set_split_terms(request.param)
     yield fused
+    fused.set_split_terms(prev_terms)
     fused.set_split_linear(prev)
 
 
@@ -49,8 +52,9 @@ def test_split_linear_matches_float64(dev, split_on, M, K, N, bias, relu):
         ref = ref + b.double()
     if relu:
         ref = ref.clamp_min(0)
-    # the dropped terms are < 2^-16 of each product: bound the error by that share of sum |x| |w| (+ fp32 accumulation)
-    bound = (x.abs().double() @ w.abs().double().t()) * 2.0 ** -15 + 1e-6
+    # the dropped terms are < 2^-16 (three terms) / < 2^-24 (six) of each product: bound the error by that share of
+    # sum |x| |w| (+ fp32 accumulation over K)
+    bound = (x.abs().double() @ w.abs().double().t()) * (2.0 ** -15 if split_on.split_terms() == 3 else 2.0 ** -20) + 1e-6
     err = (y.double() - ref).abs()
     assert bool((err <= bound).all()), float((err - bound).max())
     # and it is far closer to fp32 than plain bf16 would be
@@ -121,10 +125,12 @@ def test_split_linear_declines_what_it_cannot_do(dev, split_on):
     assert split_on.linear(x.double(), torch.randn(8, 48, device=dev).double()) is None
     from trackformer_amd import _cabi
     one = torch.zeros(64, device=dev)
-    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), 0, one.data_ptr(), 1, 48, 1, 0, 0)
+    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), 0, 0, one.data_ptr(), 1, 48, 1, 0, 0)
     assert rc == -2
-    rc = _cabi.lib().tf_linear_split_f32(0, one.data_ptr(), one.data_ptr(), 0, one.data_ptr(), 1, 32, 1, 0, 0)
+    rc = _cabi.lib().tf_linear_split_f32(0, one.data_ptr(), one.data_ptr(), 0, 0, one.data_ptr(), 1, 32, 1, 0, 0)
     assert rc == -1
+    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr() + 2, 0, one.data_ptr(), 1, 32, 1, 0, 0)
+    assert rc == -2                                                               # misaligned lo piece
     split_on.set_split_linear(False)
     assert split_on.linear(torch.randn(4, 32, device=dev), torch.randn(4, 32, device=dev)) is None   # switched off
 
@@ -159,8 +165,8 @@ def test_packed_linear_dispatch(dev, split_on):
 @pytest.mark.parametrize("M,K,N,bias,relu", SHAPES + [(66800, 64, 256, True, True), (16700, 512, 128, True, True)],
                          ids=["%dx%dx%d" % s[:3] for s in SHAPES] + ["conv_layer1", "conv_layer2"])
 def test_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, relu):
-    """linear_bufstore (stores through a buffer resource: no per-store branch, no vmcnt(0) between stores) and the
-    residual epilogue: bit-identical to the default epilogue / to the plain kernel + add; nothing written past Y."""
+    """The epilogue stores through a buffer resource (no per-store branch, no vmcnt(0) between stores; rows >= M / columns >= N
+    dropped by the bounds check): nothing is written past Y; the residual epilogue equals the plain kernel + add bit for bit."""
     from trackformer_amd import _cabi
     lib = _cabi.lib()
     g = torch.Generator().manual_seed(M + K + N)
@@ -168,53 +174,40 @@ def test_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, relu):
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev) if bias else None
     r = torch.randn(M, N, generator=g).to(dev)
-    prev = lib.tf_msda_set_option(b"linear_bufstore", 0)   # the plain-store epilogue
-    try:
-        base = split_on.linear(x, w, b, relu=relu)
-        base_res = split_on.linear(x, w, b, relu=relu, residual=r)
-        if K % 32 == 0:
-            plain = split_on.linear(x, w, b, relu=False) + r
-            assert torch.equal(base_res, plain.clamp_min(0) if relu else plain)
-    finally:
-        lib.tf_msda_set_option(b"linear_bufstore", prev)
+    got = split_on.linear(x, w, b, relu=relu)
+    got_res = split_on.linear(x, w, b, relu=relu, residual=r)
+    plain = split_on.linear(x, w, b, relu=False) + r
+    assert torch.equal(got_res, plain.clamp_min(0) if relu else plain)
     guard = torch.full((M + 300, N), 7.0, device=dev)       # the kernel writes into the first M rows of a larger buffer
-    prev = lib.tf_msda_set_option(b"linear_bufstore", 1)
-    try:
-        got = split_on.linear(x, w, b, relu=relu)
-        got_res = split_on.linear(x, w, b, relu=relu, residual=r)
-        hi, mid = split_on._split_weight(w)
-        rc = lib.tf_linear_split_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if b is None else b.data_ptr(),
-                                     guard.data_ptr(), M, K, N, 1 if relu else 0, torch.cuda.current_stream().cuda_stream)
-        assert rc == 0
-    finally:
-        lib.tf_msda_set_option(b"linear_bufstore", prev)
+    hi, mid, lo = split_on._split_weight(w)
+    rc = lib.tf_linear_split_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if lo is None else lo.data_ptr(),
+                                 0 if b is None else b.data_ptr(), guard.data_ptr(), M, K, N, 1 if relu else 0,
+                                 torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
     torch.cuda.synchronize()
-    assert torch.equal(got, base) and torch.equal(got_res, base_res)
+    assert torch.equal(guard[:M], got)
     assert torch.equal(guard[M:], torch.full((300, N), 7.0, device=dev))
 
 
 @pytest.mark.parametrize("M,K,N,bias,relu", [(400, 256, 256, True, False), (400, 256, 1024, True, True), (400, 1024, 256, True, False),
-                                              (800, 288, 288, True, False), (800, 1152, 288, False, False), (400, 256, 384, True, False)],
+                                              (800, 288, 288, True, False), (800, 1152, 288, False, False), (400, 256, 384, True, False),
+                                              (400, 96, 256, True, True)],
                          ids=lambda v: str(v))
-def test_deep_prefetch_linear_bit_identical(dev, split_on, M, K, N, bias, relu):
-    """Variant 7 (ring of 8 K-slices in registers, for the decoder's few-row linears): bit-identical to variant 5."""
-    from trackformer_amd import _cabi
-    lib = _cabi.lib()
+def test_few_rows_linear_kernels_agree(dev, split_on, monkeypatch, M, K, N, bias, relu):
+    """<= 4096 rows: the ring-of-8-slices kernel (K / 32 in {8, 9, 32, 36}) or the 64 x 64 block kernel; same products in the
+    same order as the packed kernel (bit-identical where K % 64 == 0), within the split product's bound of float64."""
     g = torch.Generator().manual_seed(M + K + N)
     x = torch.randn(M, K, generator=g).to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev) if bias else None
-    prev = lib.tf_msda_set_option(b"linear_deep", 0)
-    try:
-        base = split_on.linear(x, w, b, relu=relu)
-    finally:
-        lib.tf_msda_set_option(b"linear_deep", prev)
-    prev = lib.tf_msda_set_option(b"linear_deep", 1)
-    try:
-        got = split_on.linear(x, w, b, relu=relu)
-    finally:
-        lib.tf_msda_set_option(b"linear_deep", prev)
-    assert torch.equal(got, base)
+    got = split_on.linear(x, w, b, relu=relu)
+    ref = x.double() @ w.double().t() + (b.double() if bias else 0)
+    ref = ref.clamp_min(0) if relu else ref
+    bound = (x.abs().double() @ w.abs().double().t()) * (2.0 ** -15 if split_on.split_terms() == 3 else 2.0 ** -20) + 1e-6
+    assert bool(((got.double() - ref).abs() <= bound).all())
+    if K % 64 == 0:
+        monkeypatch.setattr(split_on, "_use_packed", lambda m, k, n: True)
+        assert torch.equal(split_on.linear(x, w, b, relu=relu), got)
 
 
 @pytest.mark.parametrize("rows,n", [(22223, 384), (400, 384), (400, 512), (5000, 256)])

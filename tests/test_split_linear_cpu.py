@@ -1,6 +1,7 @@
 """CPU: the numerical claim behind tf_linear_split_f32 -- every linear of the path computed as the bf16 split product
-hi.hi + hi.mid + mid.hi (fp32 accumulation), emulated with PyTorch on the CPU, keeps the model and the tracker inside
-the tolerances of the CPU parity suite (boxes 2e-5, logits 1e-4, track ids exact), while plain bf16 does not.  (The HIP kernel itself is checked on the GPU:
+(three terms hi.hi + hi.mid + mid.hi: the fast mode; six terms with a third piece: the default; fp32 accumulation), emulated
+with PyTorch on the CPU, keeps the model and the tracker inside the tolerances of the CPU parity suite (boxes 2e-5, logits 1e-4,
+track ids exact), while plain bf16 does not.  (The HIP kernel itself is checked on the GPU:
 tests/test_linear_split_gpu.py; the full sweep over all goldens: tools/experiments/bf16_split_linear.py.)"""
 import pytest
 import torch
@@ -12,17 +13,21 @@ from tests.test_models_cpu import host_op  # noqa: F401  (fixture: the product's
 
 def _pieces(t):
     hi = t.to(torch.bfloat16).float()
-    mid = (t - hi).to(torch.bfloat16).float()
-    return hi, mid
+    r = t - hi
+    mid = r.to(torch.bfloat16).float()
+    lo = (r - mid).to(torch.bfloat16).float()
+    return hi, mid, lo
 
 
 def _patch(monkeypatch, passes):
     def mm(x, w_t):
-        xh, xm = _pieces(x)
-        wh, wm = _pieces(w_t)
+        xh, xm, xl = _pieces(x)
+        wh, wm, wl = _pieces(w_t)
         out = xh @ wh
-        if passes == 3:
+        if passes >= 3:
             out = out + xh @ wm + xm @ wh
+        if passes == 6:
+            out = out + xm @ wm + xh @ wl + xl @ wh
         return out
 
     def linear(x, w, b=None):
@@ -37,20 +42,29 @@ def _patch(monkeypatch, passes):
     monkeypatch.setattr(torch, "_addmm_activation", addmm_activation)
 
 
-def test_weight_pieces_reconstruct_the_weight_to_16_bits():
+def test_weight_pieces_reconstruct_the_weight():
+    """(hi, mid): to 16 bits; (hi, mid, lo), the default: exactly."""
     from trackformer_amd import fused
     w = torch.randn(64, 96) * 3
-    hi, mid = fused._split_weight(w)
-    assert hi.dtype == mid.dtype == torch.bfloat16
+    assert fused.split_terms() == 6
+    hi, mid, lo = fused._split_weight(w)
+    assert hi.dtype == mid.dtype == lo.dtype == torch.bfloat16
     rel = ((hi.float() + mid.float() - w).abs() / w.abs().clamp_min(1e-30)).max()
     assert float(rel) < 2.0 ** -15
+    assert torch.equal(hi.double() + mid.double() + lo.double(), w.double())
     assert fused._split_weight(w)[0] is hi      # cached per tensor version
+    prev = fused.set_split_terms(3)
+    try:
+        assert fused._split_weight(w)[2] is None and fused._split_weight(w)[0] is hi    # the same cache entry, without lo
+    finally:
+        fused.set_split_terms(prev)
     w.add_(1.0)
     assert fused._split_weight(w)[0] is not hi  # an in-place update invalidates the cache entry
 
 
-def test_split_product_linears_keep_model_and_tracker_parity(host_op, monkeypatch):
-    _patch(monkeypatch, passes=3)
+@pytest.mark.parametrize("passes", [3, 6])
+def test_split_product_linears_keep_model_and_tracker_parity(host_op, monkeypatch, passes):
+    _patch(monkeypatch, passes=passes)
     case = "cfg2_deformable_tracking"
     model, out, res, feats = shared.run_case(case, device="cpu")
     # the CPU suite's own (tight) tolerances, 50x below the 1e-3 bar

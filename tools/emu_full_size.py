@@ -38,7 +38,7 @@ def main():
             fused.set_pos_add_fused(True)
             fused.set_stem_conv_split(True)
             fused.set_heads_split(True)
-            for k, v in ((b"linear_bufstore", 1), (b"linear_deep", 1), (b"direct9", 1)):
+            for k, v in ((b"direct9", 1),):
                 lib.tf_msda_set_option(k, v)
         with torch.no_grad():
             prev_features = None

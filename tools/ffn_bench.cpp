@@ -45,6 +45,8 @@ int main(int argc, char **argv)
 {
     const int M = argc > 1 ? atoi(argv[1]) : 22223, F = argc > 2 ? atoi(argv[2]) : 1024, D = argc > 4 ? atoi(argv[4]) : 256;
     if (argc > 3) tf_msda_set_option("ffn_ti", atoi(argv[3]));
+    const int T = getenv("TF_SPLIT_TERMS") && atoi(getenv("TF_SPLIT_TERMS")) == 3 ? 3 : 6;   // terms per split product (default 6)
+    printf("split product: %d terms\n", T);
     const int guard = 128;   // rows behind M that nothing may write
     std::mt19937 rng(11);
     std::normal_distribution<float> nrm(0.f, 1.f);
@@ -67,46 +69,48 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dY0, (size_t)M * D * 4));
     CK(hipMalloc(&dY1, (size_t)M * D * 4));
     CK(hipMalloc(&dY, (size_t)(M + guard) * D * 4));
-    CK(hipMalloc(&dP1, (size_t)tf_linear_packed_bytes(D, F)));
-    CK(hipMalloc(&dP2, (size_t)tf_linear_packed_bytes(F, D)));
+    CK(hipMalloc(&dP1, (size_t)tf_linear_packed_bytes(D, F, T)));
+    CK(hipMalloc(&dP2, (size_t)tf_linear_packed_bytes(F, D, T)));
     hipStream_t s;
     CK(hipStreamCreate(&s));
-    TF(tf_linear_pack_weight_f32(dW1, dP1, D, F, s));
-    TF(tf_linear_pack_weight_f32(dW2, dP2, F, D, s));
+    TF(tf_linear_pack_weight_f32(dW1, dP1, D, F, T, s));
+    TF(tf_linear_pack_weight_f32(dW2, dP2, F, D, T, s));
 
     // the separate kernels: tf_linear_packed_f32 where it applies (K % 64 == 0), else tf_linear_split_f32 (same bits)
-    auto split_of = [&](const std::vector<float> &W, unsigned short **dhi, unsigned short **dmid) {
-        std::vector<unsigned short> hi(W.size()), mid(W.size());
+    auto split_of = [&](const std::vector<float> &W, unsigned short **dhi, unsigned short **dmid, unsigned short **dlo) {
+        std::vector<unsigned short> pc[3];
+        for (auto &v : pc) v.resize(W.size());
         for (size_t i = 0; i < W.size(); ++i) {
-            unsigned u;
-            float f = W[i];
-            memcpy(&u, &f, 4);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            hi[i] = (unsigned short)(u >> 16);
-            unsigned hu = (unsigned)hi[i] << 16;
-            float hf;
-            memcpy(&hf, &hu, 4);
-            float r = W[i] - hf;
-            memcpy(&u, &r, 4);
-            u += 0x7FFFu + ((u >> 16) & 1u);
-            mid[i] = (unsigned short)(u >> 16);
+            float r = W[i];
+            for (int q = 0; q < 3; ++q) {   // round to nearest even, residual exact
+                unsigned u;
+                memcpy(&u, &r, 4);
+                u += 0x7FFFu + ((u >> 16) & 1u);
+                pc[q][i] = (unsigned short)(u >> 16);
+                unsigned hu = (unsigned)pc[q][i] << 16;
+                float hf;
+                memcpy(&hf, &hu, 4);
+                r -= hf;
+            }
         }
-        CK(hipMalloc(dhi, W.size() * 2));
-        CK(hipMalloc(dmid, W.size() * 2));
-        CK(hipMemcpy(*dhi, hi.data(), W.size() * 2, hipMemcpyHostToDevice));
-        CK(hipMemcpy(*dmid, mid.data(), W.size() * 2, hipMemcpyHostToDevice));
+        unsigned short **d[3] = {dhi, dmid, dlo};
+        for (int q = 0; q < 3; ++q) {
+            CK(hipMalloc(d[q], W.size() * 2));
+            CK(hipMemcpy(*d[q], pc[q].data(), W.size() * 2, hipMemcpyHostToDevice));
+        }
+        if (T == 3) *dlo = nullptr;   // three terms: no lo piece
     };
-    unsigned short *dW1hi, *dW1mid, *dW2hi, *dW2mid;
-    split_of(W1, &dW1hi, &dW1mid);
-    split_of(W2, &dW2hi, &dW2mid);
-    auto lin1 = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dW1hi, dW1mid, dB1, dH, M, D, F, 1, s) : tf_linear_packed_f32(dX, dP1, dB1, dH, M, D, F, 1, s); };
-    auto lin2 = [&]() { return (F % 64) ? tf_linear_split_f32(dH, dW2hi, dW2mid, dB2, dY0, M, F, D, 0, s) : tf_linear_packed_f32(dH, dP2, dB2, dY0, M, F, D, 0, s); };
+    unsigned short *dW1hi, *dW1mid, *dW1lo, *dW2hi, *dW2mid, *dW2lo;
+    split_of(W1, &dW1hi, &dW1mid, &dW1lo);
+    split_of(W2, &dW2hi, &dW2mid, &dW2lo);
+    auto lin1 = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dW1hi, dW1mid, dW1lo, dB1, dH, M, D, F, 1, s) : tf_linear_packed_f32(dX, dP1, dB1, dH, M, D, F, 1, T, s); };
+    auto lin2 = [&]() { return (F % 64) ? tf_linear_split_f32(dH, dW2hi, dW2mid, dW2lo, dB2, dY0, M, F, D, 0, s) : tf_linear_packed_f32(dH, dP2, dB2, dY0, M, F, D, 0, T, s); };
 
     // ---- 1. bit identity without the LayerNorm
     TF(lin1());
     TF(lin2());
     CK(hipMemsetAsync(dY, 0xFF, (size_t)(M + guard) * D * 4, s));
-    TF(tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, F, s));
+    TF(tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, F, T, s));
     CK(hipStreamSynchronize(s));
     std::vector<float> Y0((size_t)M * D), Y((size_t)(M + guard) * D);
     CK(hipMemcpy(Y0.data(), dY0, Y0.size() * 4, hipMemcpyDeviceToHost));
@@ -127,7 +131,7 @@ int main(int argc, char **argv)
            "(max |d| %.3g), words written behind row M: %lld\n", M, D, F, differ, Y0.size(), max_d, touched);
 
     // ---- 2. with the LayerNorm, against double precision on a sample of rows
-    TF(tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, dG, dBe, 1e-5f, dY, M, D, F, s));
+    TF(tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, dG, dBe, 1e-5f, dY, M, D, F, T, s));
     CK(hipStreamSynchronize(s));
     CK(hipMemcpy(Y.data(), dY, (size_t)M * D * 4, hipMemcpyDeviceToHost));
     double max_err = 0;
@@ -193,22 +197,22 @@ int main(int argc, char **argv)
         lin2();
         tf_add_layernorm_f32(dX, dY0, dG, dBe, dY1, M, D, 1e-5f, s);
     });
-    const double us_fused = time_graph([&] { tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, dG, dBe, 1e-5f, dY, M, D, F, s); });
-    const double us_fused_noln = time_graph([&] { tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, F, s); });
+    const double us_fused = time_graph([&] { tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, dG, dBe, 1e-5f, dY, M, D, F, T, s); });
+    const double us_fused_noln = time_graph([&] { tf_ffn_fused_f32(dX, dP1, dB1, dP2, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, F, T, s); });
     // the output projection + residual + LayerNorm (tf_linear_res_ln_f32) against tf_linear_split_f32-class GEMM + tf_add_layernorm_f32
     void *dPo;
     float *dWo;
     std::vector<float> Wo((size_t)D * D);
     for (auto &v : Wo) v = nrm(rng) * 0.0625f;
     up(&dWo, Wo);
-    CK(hipMalloc(&dPo, (size_t)tf_linear_packed_bytes(D, D)));
-    TF(tf_linear_pack_weight_f32(dWo, dPo, D, D, s));
-    unsigned short *dWohi, *dWomid;
-    split_of(Wo, &dWohi, &dWomid);
-    auto lino = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dWohi, dWomid, dB2, dY0, M, D, D, 0, s) : tf_linear_packed_f32(dX, dPo, dB2, dY0, M, D, D, 0, s); };
+    CK(hipMalloc(&dPo, (size_t)tf_linear_packed_bytes(D, D, T)));
+    TF(tf_linear_pack_weight_f32(dWo, dPo, D, D, T, s));
+    unsigned short *dWohi, *dWomid, *dWolo;
+    split_of(Wo, &dWohi, &dWomid, &dWolo);
+    auto lino = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dWohi, dWomid, dWolo, dB2, dY0, M, D, D, 0, s) : tf_linear_packed_f32(dX, dPo, dB2, dY0, M, D, D, 0, T, s); };
     TF(lino());
     CK(hipMemsetAsync(dY, 0xFF, (size_t)(M + guard) * D * 4, s));
-    TF(tf_linear_res_ln_f32(dX, dPo, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, D, s));
+    TF(tf_linear_res_ln_f32(dX, dPo, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, D, T, s));
     CK(hipStreamSynchronize(s));
     CK(hipMemcpy(Y0.data(), dY0, Y0.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(Y.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
@@ -226,7 +230,7 @@ int main(int argc, char **argv)
         lino();
         tf_add_layernorm_f32(dX, dY0, dG, dBe, dY1, M, D, 1e-5f, s);
     });
-    const double us_lin_fused = time_graph([&] { tf_linear_res_ln_f32(dX, dPo, dB2, dX, dG, dBe, 1e-5f, dY, M, D, D, s); });
+    const double us_lin_fused = time_graph([&] { tf_linear_res_ln_f32(dX, dPo, dB2, dX, dG, dBe, 1e-5f, dY, M, D, D, T, s); });
     printf("tf_linear_res_ln_f32 M=%d: outputs that differ from tf_linear_packed_f32 + x: %lld, words written behind row M: %lld\n"
            "  separate (packed linear, residual + LayerNorm): %.2f us;  fused: %.2f us = %.0f GB/s of x + residual + y\n",
            M, differ2, touched2, us_lin_sep, us_lin_fused, 3.0 * M * D * 4 / us_lin_fused * 1e-3);

@@ -1,10 +1,10 @@
 // tools/linear_bench.cpp -- standalone (no Python, no torch) parity + timing harness for tf_linear_split_f32
 // (include/tf_fused.h): Y[M, N] = X[M, K] . W[N, K]^T + bias as a bf16 split product on the matrix cores.
 //
-//   tools/bin/linear_bench [M K N [variant | packed | packedTI]]   (built by trackformer_amd/build.py; default 22223 256 256)
-//     variant: block shape of tf_linear_split_f32 (0..6); packed / packed2 / packed3 / packed4: tf_linear_packed_f32
-//     (weight packed once by tf_linear_pack_weight_f32; the digit forces the row tiles per block), whose output is
-//     also compared BIT FOR BIT with tf_linear_split_f32's
+//   tools/bin/linear_bench [M K N [packed | packedTI]]   (built by trackformer_amd/build.py; default 22223 256 256)
+//     packed / packed2 / packed3 / packed4: tf_linear_packed_f32 (weight packed once by tf_linear_pack_weight_f32; the digit
+//     forces the row tiles per block), whose output is also compared BIT FOR BIT with tf_linear_split_f32's
+//   TF_SPLIT_TERMS=3: the three-term product (default: six terms)
 //
 // Checks a sample of output rows (all columns, incl. the block edges) against a double-precision reference and
 // times 20 launches captured in one HIP graph.  Round-1 numbers: profiles/r01_split_gemm_experiment.txt.
@@ -51,9 +51,8 @@ int main(int argc, char **argv)
 {
     const int M = argc > 3 ? atoi(argv[1]) : 22223, K = argc > 3 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 256;
     const bool packed = argc > 4 && strncmp(argv[4], "packed", 6) == 0;
-    if (packed && argv[4][6] == 'a') tf_msda_set_option("linear_astat", atoi(argv[4] + 7));   // packeda3: activation-stationary
-    else if (packed && argv[4][6]) tf_msda_set_option("linear_stream_ti", atoi(argv[4] + 6));
-    if (argc > 4 && !packed) tf_msda_set_option("linear_variant", atoi(argv[4]));   // block shape / pipelining variant
+    if (packed && argv[4][6]) tf_msda_set_option("linear_stream_ti", atoi(argv[4] + 6));
+    const int T = getenv("TF_SPLIT_TERMS") && atoi(getenv("TF_SPLIT_TERMS")) == 3 ? 3 : 6;   // terms per split product
     if (K % 32) {
         fprintf(stderr, "K must be a multiple of 32\n");
         return 2;
@@ -64,13 +63,15 @@ int main(int argc, char **argv)
     for (auto &v : X) v = nrm(rng);
     for (auto &v : W) v = nrm(rng) * 0.0625f;   // ~ 1 / sqrt(K): activations stay O(1), as in the model
     for (auto &v : bias) v = nrm(rng);
-    std::vector<unsigned short> Whi(W.size()), Wmid(W.size());
+    std::vector<unsigned short> Whi(W.size()), Wmid(W.size()), Wlo(W.size());
     for (size_t i = 0; i < W.size(); ++i) {
         Whi[i] = bf16_rne(W[i]);
-        Wmid[i] = bf16_rne(W[i] - bf16_to_f32(Whi[i]));
+        const float r = W[i] - bf16_to_f32(Whi[i]);
+        Wmid[i] = bf16_rne(r);
+        Wlo[i] = bf16_rne(r - bf16_to_f32(Wmid[i]));
     }
     float *dX, *dB, *dY;
-    unsigned short *dWhi, *dWmid;
+    unsigned short *dWhi, *dWmid, *dWlo = nullptr;
     CK(hipMalloc(&dX, X.size() * 4));
     CK(hipMalloc(&dB, bias.size() * 4));
     CK(hipMalloc(&dY, Y.size() * 4));
@@ -80,6 +81,10 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dB, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dWhi, Whi.data(), W.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dWmid, Wmid.data(), W.size() * 2, hipMemcpyHostToDevice));
+    if (T == 6) {
+        CK(hipMalloc(&dWlo, W.size() * 2));
+        CK(hipMemcpy(dWlo, Wlo.data(), W.size() * 2, hipMemcpyHostToDevice));
+    }
     CK(hipMemset(dY, 0xFF, Y.size() * 4));
     hipStream_t stream;
     CK(hipStreamCreate(&stream));
@@ -87,7 +92,7 @@ int main(int argc, char **argv)
     float *dW = nullptr;
     long long not_identical = -1;
     if (packed) {
-        const int64_t bytes = tf_linear_packed_bytes(K, N);
+        const int64_t bytes = tf_linear_packed_bytes(K, N, T);
         if (bytes <= 0 || (K % 64)) {
             fprintf(stderr, "packed: K must be a multiple of 64\n");
             return 2;
@@ -95,19 +100,19 @@ int main(int argc, char **argv)
         CK(hipMalloc(&dWp, (size_t)bytes));
         CK(hipMalloc(&dW, W.size() * 4));
         CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
-        int prc = tf_linear_pack_weight_f32(dW, dWp, K, N, stream);
+        int prc = tf_linear_pack_weight_f32(dW, dWp, K, N, T, stream);
         if (prc != 0) {
             fprintf(stderr, "tf_linear_pack_weight_f32 failed: %s\n", tf_msda_strerror(prc));
             return 2;
         }
         // the unpacked kernel's output first: the packed one must reproduce it bit for bit
-        prc = tf_linear_split_f32(dX, dWhi, dWmid, dB, dY, M, K, N, 0, stream);
+        prc = tf_linear_split_f32(dX, dWhi, dWmid, dWlo, dB, dY, M, K, N, 0, stream);
         if (prc != 0) return 2;
         CK(hipStreamSynchronize(stream));
         std::vector<float> Y0(Y.size());
         CK(hipMemcpy(Y0.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
         CK(hipMemset(dY, 0xFF, Y.size() * 4));
-        prc = tf_linear_packed_f32(dX, dWp, dB, dY, M, K, N, 0, stream);
+        prc = tf_linear_packed_f32(dX, dWp, dB, dY, M, K, N, 0, T, stream);
         if (prc != 0) {
             fprintf(stderr, "tf_linear_packed_f32 failed: %s\n", tf_msda_strerror(prc));
             return 2;
@@ -119,8 +124,8 @@ int main(int argc, char **argv)
         CK(hipMemset(dY, 0xFF, Y.size() * 4));
     }
     auto run = [&]() {
-        return packed ? tf_linear_packed_f32(dX, dWp, dB, dY, M, K, N, 0, stream)
-                      : tf_linear_split_f32(dX, dWhi, dWmid, dB, dY, M, K, N, 0, stream);
+        return packed ? tf_linear_packed_f32(dX, dWp, dB, dY, M, K, N, 0, T, stream)
+                      : tf_linear_split_f32(dX, dWhi, dWmid, dWlo, dB, dY, M, K, N, 0, stream);
     };
     int rc = run();
     if (rc != 0) {
@@ -145,52 +150,12 @@ int main(int argc, char **argv)
             ++checked;
         }
     }
-    printf("%s variant %s M=%d K=%d N=%d: checked %lld outputs, max |err| %.3g (max |ref| %.3g), outside 1e-3: %lld\n",
-           packed ? "tf_linear_packed_f32" : "tf_linear_split_f32", argc > 4 ? argv[4] : "default", M, K, N, checked, max_err,
+    printf("%s (%d terms) %s M=%d K=%d N=%d: checked %lld outputs, max |err| %.3g (max |ref| %.3g), outside 1e-3: %lld\n",
+           packed ? "tf_linear_packed_f32" : "tf_linear_split_f32", T, argc > 4 ? argv[4] : "default", M, K, N, checked, max_err,
            max_ref, bad);
     if (packed) {
         printf("  outputs that differ from tf_linear_split_f32's bit pattern: %lld of %zu\n", not_identical, Y.size());
         if (not_identical) bad += not_identical;
-    }
-    if (packed && getenv("LINEAR_BENCH_TRACE")) {   // phase timestamps of the activation-stationary kernel (one launch)
-        const int nb = 4096;
-        unsigned long long *d_tr;
-        CK(hipMalloc(&d_tr, (size_t)nb * 16 * 8));
-        CK(hipMemset(d_tr, 0, (size_t)nb * 16 * 8));
-        tf_msda_debug_trace_buffer(d_tr);
-        run();
-        CK(hipStreamSynchronize(stream));
-        tf_msda_debug_trace_buffer(nullptr);
-        std::vector<unsigned long long> tr((size_t)nb * 16);
-        CK(hipMemcpy(tr.data(), d_tr, tr.size() * 8, hipMemcpyDeviceToHost));
-        unsigned long long t0 = ~0ull;
-        int used = 0;
-        for (int b = 0; b < nb; ++b)
-            if (tr[(size_t)b * 16]) {
-                t0 = std::min(t0, tr[(size_t)b * 16]);
-                used = b + 1;
-            }
-        static const char *names[14] = {"entry", "loads issued", "A converted", "barrier passed", "slice 0", "slice 1", "slice 3",
-                                        "slice 7 (col block 0)", "stores issued (col block 0)", "col block 1 done", "col block 2 done",
-                                        "col block 3 done", "all issued", "stores acknowledged"};
-        printf("  trace of %d blocks (us after the first block's entry; 100 MHz clock): mean / min / max over blocks\n", used);
-        for (int i = 0; i < 14; ++i) {
-            double sum = 0, mn = 1e30, mx = -1;
-            int n = 0;
-            for (int b = 0; b < used; ++b) {
-                const unsigned long long t = tr[(size_t)b * 16 + i];
-                if (!t) continue;
-                const double us = (double)(t - t0) * 0.01;
-                sum += us; mn = std::min(mn, us); mx = std::max(mx, us); ++n;
-            }
-            if (n) printf("    %-28s %7.2f %7.2f %7.2f   (%d blocks)\n", names[i], sum / n, mn, mx, n);
-        }
-        for (int b = 0; b < used; b += std::max(1, used / 6)) {
-            printf("    block %4d:", b);
-            for (int i = 0; i < 14; ++i) printf(" %6.2f", tr[(size_t)b * 16 + i] ? (double)(tr[(size_t)b * 16 + i] - t0) * 0.01 : -1.0);
-            printf("\n");
-        }
-        CK(hipFree(d_tr));
     }
     // ---- timing: 20 launches in one graph
     hipGraph_t graph;

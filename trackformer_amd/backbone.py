@@ -154,18 +154,26 @@ class _FoldCache:
             scale, _ = self._bn.scale_shift()
             return self._conv.weight * scale.reshape(-1, 1, 1, 1)
 
+    @staticmethod
+    def _published(t):
+        """A tensor built on the caller's current stream is about to be cached for EVERY stream (one lane per sequence, each on
+        its own HIP stream, share the model): wait for the building stream first (fused._publish_barrier), then hand it out."""
+        if t.is_cuda:
+            fused._publish_barrier(t.device)
+        return t
+
     @property
     def weight(self):
         if self._weight is None:
             w = self._scaled()
-            self._weight = w.contiguous(memory_format=torch.channels_last) if CHANNELS_LAST else w.contiguous()
+            self._weight = self._published(w.contiguous(memory_format=torch.channels_last) if CHANNELS_LAST else w.contiguous())
         return self._weight
 
     @property
     def weight2d(self):
         if self._weight2d is None and self._conv.kernel_size == (1, 1):
             w = self._scaled()
-            self._weight2d = w.reshape(w.shape[0], w.shape[1]).contiguous()
+            self._weight2d = self._published(w.reshape(w.shape[0], w.shape[1]).contiguous())
         return self._weight2d
 
     @property
@@ -173,7 +181,7 @@ class _FoldCache:
         if self._weight_taps is None and self._conv.kernel_size == (3, 3):
             w = self._scaled()
             # [Cout, 3, 3, Cin] -> [Cout, 9 * Cin]: the storage order of the channels_last weight (tap-major K)
-            self._weight_taps = w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous()
+            self._weight_taps = self._published(w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous())
         return self._weight_taps
 
     def get(self, conv: nn.Conv2d, bn: FrozenBatchNorm2d):
@@ -183,7 +191,7 @@ class _FoldCache:
         if key != self.key:
             with torch.no_grad():
                 _, shift = bn.scale_shift()
-                self.bias = shift.contiguous()
+                self.bias = self._published(shift.contiguous())
             self._conv, self._bn = conv, bn
             self._weight = self._weight2d = self._weight_taps = None
             self.key = key

@@ -13,9 +13,10 @@
 // stores: 91 MB of fp32 intermediate go out at ~1.5 TB/s and come back in for linear2.  Here the 1024-wide intermediate
 // never leaves the CU.
 //
-//   * Same arithmetic as the separate kernels (linear_split.hip / linear_stream.hip): every product is the three-term
-//     bf16 split x_hi.w_hi + x_hi.w_mid + x_mid.w_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, per accumulator
-//     in the order mid.hi, hi.mid, hi.hi, k ascending; the intermediate is rounded to fp32 (bias, ReLU) and split again,
+//   * Same arithmetic as the separate kernels (linear_split.hip / linear_stream.hip): every product is the bf16 split
+//     product of split_product.h (NP = 3 pieces / six terms: fp32-accurate, the default; NP = 2 / three terms: the fast mode)
+//     on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, per accumulator smallest terms first, k ascending (the numbers in
+//     this header are for NP = 2); the intermediate is rounded to fp32 (bias, ReLU) and split again,
 //     exactly what linear2 does with linear1's stored output.  Without the LayerNorm the result is bit-identical to
 //     tf_linear_packed_f32 (relu) -> tf_linear_packed_f32 -> + residual.
 //   * A block owns 32 TI rows (TI = 3: 96 rows, 232 blocks for 22 223 rows: one round on 256 CUs).  Its activation tile
@@ -46,16 +47,11 @@
 #include <type_traits>
 
 #include "msda_common.h"
+#include "split_product.h"
 #include "tf_fused.h"
 #include "tf_msda.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // Geometry per hidden size.  256: four waves, each two of the eight output tiles, hidden chunks of 128.  288 (the multi-frame
 // models: 9 output tiles): THREE waves of three tiles, hidden chunks of 96 -- the last chunk of a hidden width that is not a
@@ -74,7 +70,7 @@ struct Geo {
     static constexpr int U1 = KQ1 / 2;                 // weight units of GEMM 1 per chunk (two k-steps of one tile each)
     static constexpr int U2 = CH / 16;                 // weight units of GEMM 2 per chunk (one k-step of TJ tiles each)
     static constexpr int UPC = U1 + U2;                // 16 / 15
-    static constexpr int US = 2 * TJ > 4 ? 2 * TJ : 4; // 16-byte pieces per lane and unit
+    static constexpr int us(int np) { return np * (TJ > 2 ? TJ : 2); }   // 16-byte pieces per lane and unit
     static constexpr int RING = D == 256 ? 8 : 5;      // units in the ring (divides UPC: a unit's slot is a compile-time constant)
     static constexpr int AHEAD = RING - 2;             // prefetch distance
     static_assert(TJ * NW * 32 == D && KQ1 % 2 == 0 && UPC % RING == 0, "geometry");
@@ -92,12 +88,12 @@ __device__ __forceinline__ void static_for(F &&f)   // f(integral_constant<int, 
 }
 
 template <int D>
-constexpr size_t ffn_lds_bytes(int ti) { return (size_t)(32 * ti) * (Geo<D>::XS + Geo<D>::HS) * 2 * 2; }
+constexpr size_t ffn_lds_bytes(int ti, int np) { return (size_t)(32 * ti) * (Geo<D>::XS + Geo<D>::HS) * 2 * np; }
 
 // ---- the block's activation tile (32 TI rows x D) -> LDS as bf16 hi / mid.  All of its global loads are in flight before the
 // first conversion waits.  The caller issues the barrier.
-template <int D, int TI>
-__device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, int m0, unsigned short *sXhi, unsigned short *sXmid, int tid)
+template <int NP, int D, int TI>
+__device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, int m0, unsigned short *sX, int tid)   // sX: [NP][32 TI][XS]
 {
     using G = Geo<D>;
     constexpr int C4 = D / 4, NV = TI * 32 * C4 / G::NT;   // float4 per row / per thread
@@ -115,14 +111,10 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, i
     for (int it = 0; it < NV; ++it) {
         const int idx = it * G::NT + tid;
         const int row = idx / C4, c4 = idx - row * C4;
-        bf16x4 hi, mid;   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
+        bf16x4 pc[NP];   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
+        split4<NP>(xr[it], pc);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            hi[e] = (__bf16)xr[it][e];
-            mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
-        }
-        *reinterpret_cast<bf16x4 *>(&sXhi[row * G::XS + c4 * 4]) = hi;
-        *reinterpret_cast<bf16x4 *>(&sXmid[row * G::XS + c4 * 4]) = mid;
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(&sX[(p * TI * 32 + row) * G::XS + c4 * 4]) = pc[p];
     }
 }
 
@@ -215,7 +207,7 @@ __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][Geo<D>::T
                                                        (unsigned)((m0 + i * 32 + frow) * D + cbase + 32 * j + 8 * g) * 4u, 0, 0);
 }
 
-template <int D, int TI, bool LN>
+template <int NP, int D, int TI, bool LN>
 __global__ void __launch_bounds__(Geo<D>::NT, 1)
 ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, const float *__restrict__ b1,
                  const u32x4 *__restrict__ W2p, const float *__restrict__ b2, const float *R,
@@ -223,9 +215,10 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
 {
     using G = Geo<D>;
     constexpr int BM = TI * 32, TJ = G::TJ, NW = G::NW, XS = G::XS, HS = G::HS, RING = G::RING, UPC = G::UPC, U1 = G::U1, U2 = G::U2;
+    constexpr int US = G::us(NP);
     extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
-    unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * XS;
-    unsigned short *const sHhi = sXmid + BM * XS, *const sHmid = sHhi + BM * HS;
+    unsigned short *const sX = s_f;                      // [NP][BM][XS]
+    unsigned short *const sH = s_f + NP * BM * XS;       // [NP][BM][HS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
@@ -233,28 +226,28 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
     const int ntiles1 = (F + 255) / 256 * 8;   // hidden n-tiles the packed W1 holds (zero columns up to a multiple of 256)
 
     // ---- the weight stream.  Unit u of chunk c (UPC units per chunk, up to US x 16 bytes per lane each):
-    //   u < U1   GEMM 1: k-steps 2u, 2u + 1 (hi, mid each) of hidden n-tile NW c + wave of W1   [contiguous 4 KB]
-    //   u >= U1  GEMM 2: k-step U2 c + (u - U1) (hi, mid) of the wave's TJ output n-tiles of W2 (clamped to the last real one)
-    // packed layout (linear_stream.hip pack_weight_kernel): piece (n-tile t, k-step q, part p) at ((t KQ + q) 2 + p) 64 + lane
-    u32x4 ring[RING][G::US];
-    auto load_unit = [&](int c, auto uc, u32x4 (&dst)[G::US]) {
+    //   u < U1   GEMM 1: k-steps 2u, 2u + 1 (NP pieces each) of hidden n-tile NW c + wave of W1   [contiguous 2 NP KB]
+    //   u >= U1  GEMM 2: k-step U2 c + (u - U1) (NP pieces) of the wave's TJ output n-tiles of W2 (clamped to the last real one)
+    // packed layout (linear_stream.hip pack_weight_kernel): piece (n-tile t, k-step q, part p) at ((t KQ + q) NP + p) 64 + lane
+    u32x4 ring[RING][US];
+    auto load_unit = [&](int c, auto uc, u32x4 (&dst)[US]) {
         constexpr int u = decltype(uc)::value;
         if constexpr (u < U1) {
-            const u32x4 *base = W1p + ((size_t)min(c * NW + wave, ntiles1 - 1) * G::KQ1 * 2 + u * 4) * 64 + lane;
+            const u32x4 *base = W1p + ((size_t)min(c * NW + wave, ntiles1 - 1) * G::KQ1 * NP + u * 2 * NP) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dst[i] = base[i * 64];
+            for (int i = 0; i < 2 * NP; ++i) dst[i] = base[i * 64];
         } else {
             const int q = min(c * U2 + (u - U1), KQ2 - 1);
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) dst[j * 2 + p] = W2p[(((size_t)(TJ * wave + j) * KQ2 + q) * 2 + p) * 64 + lane];
+                for (int p = 0; p < NP; ++p) dst[j * NP + p] = W2p[(((size_t)(TJ * wave + j) * KQ2 + q) * NP + p) * 64 + lane];
         }
     };
     // the first units first (they have the longest way), then the whole activation tile
     static_for<G::AHEAD>([&](auto uc) { load_unit(0, uc, ring[decltype(uc)::value]); });
     __builtin_amdgcn_sched_barrier(0);
-    stage_rows<D, TI>(X, M, m0, sXhi, sXmid, tid);
+    stage_rows<NP, D, TI>(X, M, m0, sX, tid);
     __syncthreads();
 
     f32x16 accy[TI][TJ];
@@ -310,14 +303,14 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
         };
         // ---- GEMM 1: hidden[32 of this wave][BM rows] (transposed) = W1 tile . x^T.  One block per CU means one wave per
         // SIMD: nobody else covers the LDS latency, so the fragments of k-step st + 1 are read before the MFMAs of k-step st
-        bf16x8 xf[2][TI][2];   // [k-step parity][row tile][hi | mid]
+        bf16x8 xf[2][TI][NP];   // [k-step parity][row tile][piece]
         auto read_x = [&](auto stc) {
             constexpr int st = decltype(stc)::value;
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                xf[st & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sXhi[i * 32 * XS + xoff + st * 16]);
-                xf[st & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sXmid[i * 32 * XS + xoff + st * 16]);
-            }
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    xf[st & 1][i][p] = *reinterpret_cast<const bf16x8 *>(&sX[(p * BM + i * 32) * XS + xoff + st * 16]);
         };
         read_x(std::integral_constant<int, 0>{});
         static_for<G::KQ1>([&](auto stc) {
@@ -325,14 +318,17 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
             if constexpr ((st & 1) == 0) prefetch(std::integral_constant<int, st / 2>{});
             if constexpr (st + 1 < G::KQ1) read_x(std::integral_constant<int, st + 1>{});
             __builtin_amdgcn_sched_barrier(0);   // loads and reads stay at the head of the step (see linear_stream.hip)
-            const u32x4 (&cur)[G::US] = ring[(st / 2) % RING];
-            const bf16x8 w_hi = __builtin_bit_cast(bf16x8, cur[(st & 1) * 2 + 0]), w_mid = __builtin_bit_cast(bf16x8, cur[(st & 1) * 2 + 1]);
+            const u32x4 (&cur)[US] = ring[(st / 2) % RING];
+            bf16x8 wf[NP];
 #pragma unroll
-            for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, xf[st & 1][i][1], acch[i], 0, 0, 0);
+            for (int p = 0; p < NP; ++p) wf[p] = __builtin_bit_cast(bf16x8, cur[(st & 1) * NP + p]);
+            // the weight fragment is the A operand (transposed accumulators); x piece T::A[t] x weight piece T::B[t], smallest first
+            using T = SplitTerms<NP>;
 #pragma unroll
-            for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid, xf[st & 1][i][0], acch[i], 0, 0, 0);
+            for (int t = 0; t < T::N; ++t)
 #pragma unroll
-            for (int i = 0; i < TI; ++i) acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi, xf[st & 1][i][0], acch[i], 0, 0, 0);
+                for (int i = 0; i < TI; ++i)
+                    acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[T::B[t]], xf[st & 1][i][T::A[t]], acch[i], 0, 0, 0);
         });
 
         // ---- bias + ReLU + split -> the hidden tile in LDS.  C/D of the 32 x 32 MFMA with the weight as A: lane -> row
@@ -343,29 +339,29 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16x4 hi, mid;
+                f32x4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acch[i][4 * g + e] + b1v[g][e];
-                    t = (t > 0.f && hcol + 8 * g < F) ? t : 0.f;   // columns past the hidden width (last chunk only): zero
-                    hi[e] = (__bf16)t;
-                    mid[e] = (__bf16)(t - (float)hi[e]);
+                    const float t = acch[i][4 * g + e] + b1v[g][e];
+                    hv[e] = (t > 0.f && hcol + 8 * g < F) ? t : 0.f;   // columns past the hidden width (last chunk only): zero
                 }
+                bf16x4 pc[NP];
+                split4<NP>(hv, pc);
                 const int o = (i * 32 + frow) * HS + wave * 32 + 8 * g + 4 * (lane >> 5);
-                *reinterpret_cast<bf16x4 *>(&sHhi[o]) = hi;
-                *reinterpret_cast<bf16x4 *>(&sHmid[o]) = mid;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(&sH[p * BM * HS + o]) = pc[p];
             }
         __syncthreads();
 
         // ---- GEMM 2: y[32 TJ columns of this wave][BM rows] (transposed) += W2 tiles . hidden^T, k = this chunk
-        bf16x8 hf[2][TI][2];
+        bf16x8 hf[2][TI][NP];
         auto read_h = [&](auto vc) {
             constexpr int kv = decltype(vc)::value;   // k-step of the chunk
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                hf[kv & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sHhi[i * 32 * HS + hoff + kv * 16]);
-                hf[kv & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sHmid[i * 32 * HS + hoff + kv * 16]);
-            }
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    hf[kv & 1][i][p] = *reinterpret_cast<const bf16x8 *>(&sH[(p * BM + i * 32) * HS + hoff + kv * 16]);
         };
         read_h(std::integral_constant<int, 0>{});
         static_for<U2>([&](auto vc) {
@@ -373,39 +369,35 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
             prefetch(std::integral_constant<int, U1 + kv>{});
             if constexpr (kv + 1 < U2) read_h(std::integral_constant<int, kv + 1>{});
             __builtin_amdgcn_sched_barrier(0);
-            const u32x4 (&cur)[G::US] = ring[(U1 + kv) % RING];
-            bf16x8 w_hi[TJ], w_mid[TJ];
+            const u32x4 (&cur)[US] = ring[(U1 + kv) % RING];
+            bf16x8 wf[TJ][NP];
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                w_hi[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 0]);
-                w_mid[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 1]);
-            }
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+                for (int p = 0; p < NP; ++p) wf[j][p] = __builtin_bit_cast(bf16x8, cur[j * NP + p]);
+            using T = SplitTerms<NP>;
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], hf[kv & 1][i][1], accy[i][j], 0, 0, 0);
+            for (int t = 0; t < T::N; ++t)
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
+                for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid[j], hf[kv & 1][i][0], accy[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], hf[kv & 1][i][0], accy[i][j], 0, 0, 0);
+                    for (int j = 0; j < TJ; ++j)
+                        accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][T::B[t]], hf[kv & 1][i][T::A[t]], accy[i][j], 0, 0, 0);
         });
     }
 
     // ---- epilogue (the LayerNorm's exchange buffer aliases the hidden tile)
-    rows_epilogue<D, TI, LN>(accy, v, b2rs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sHhi), m0, wave, lane);
+    rows_epilogue<D, TI, LN>(accy, v, b2rs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sH), m0, wave, lane);
 }
 
-template <int D, int TI>
+template <int NP, int D, int TI>
 int launch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2, const float *b2, const float *res,
                const float *gamma, const float *beta, float eps, float *y, int M, int F, hipStream_t s)
 {
     const bool ln = gamma != nullptr;
-    const size_t lds = ffn_lds_bytes<D>(TI);
-    const void *fn = ln ? (const void *)&ffn_fused_kernel<D, TI, true> : (const void *)&ffn_fused_kernel<D, TI, false>;
+    constexpr size_t lds = ffn_lds_bytes<D>(TI, NP);
+    static_assert(lds <= 160 * 1024, "the two tiles do not fit the LDS of a CU");
+    const void *fn = ln ? (const void *)&ffn_fused_kernel<NP, D, TI, true> : (const void *)&ffn_fused_kernel<NP, D, TI, false>;
     static std::atomic<unsigned> raised[2];   // bit per device, per kernel
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -423,11 +415,11 @@ int launch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2
 // projection with the layer's residual add and norm1 (deformable_transformer.py:285-292 / ms_deform_attn.py:87).  The GEMM 2
 // half of the kernel above with the activation tile as its operand: D / 16 k-steps, each wave 32 TJ output columns.
 template <int D>
-constexpr size_t linln_lds_bytes(int ti) { return (size_t)(32 * ti) * Geo<D>::XS * 2 * 2; }
+constexpr size_t linln_lds_bytes(int ti, int np) { return (size_t)(32 * ti) * Geo<D>::XS * 2 * np; }
 constexpr int linln_min_blocks(int d, int ti) { return (d == 256 ? ti <= 2 : ti <= 1) ? 2 : 1; }   // resident blocks per CU the register budget is cut for
 constexpr int linln_ring(int ti) { return ti <= 2 ? 4 : 8; }          // weight units in flight + 2
 
-template <int D, int TI, bool LN>
+template <int NP, int D, int TI, bool LN>
 __global__ void __launch_bounds__(Geo<D>::NT, (linln_min_blocks(D, TI)))
 linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R,
                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *Y, int M)
@@ -435,19 +427,19 @@ linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, 
     using G = Geo<D>;
     constexpr int BM = TI * 32, TJ = G::TJ, XS = G::XS, KQ = G::KQ1;
     extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
-    unsigned short *const sXhi = s_f, *const sXmid = sXhi + BM * XS;
+    unsigned short *const sX = s_f;   // [NP][BM][XS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
-    // weight unit u = k-step u (hi, mid) of the wave's TJ output n-tiles; a ring as above, RING - 2 units ahead
+    // weight unit u = k-step u (NP pieces) of the wave's TJ output n-tiles; a ring as above, RING - 2 units ahead
     constexpr int RING = linln_ring(TI), AHEAD = RING - 2;
-    u32x4 ring[RING][2 * TJ];
-    auto load_unit = [&](auto uc, u32x4 (&dst)[2 * TJ]) {
+    u32x4 ring[RING][NP * TJ];
+    auto load_unit = [&](auto uc, u32x4 (&dst)[NP * TJ]) {
         constexpr int u = decltype(uc)::value;
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) dst[j * 2 + p] = Wp[(((size_t)(TJ * wave + j) * KQ + u) * 2 + p) * 64 + lane];
+            for (int p = 0; p < NP; ++p) dst[j * NP + p] = Wp[(((size_t)(TJ * wave + j) * KQ + u) * NP + p) * 64 + lane];
     };
     static_for<AHEAD>([&](auto uc) { load_unit(uc, ring[decltype(uc)::value]); });
     __builtin_amdgcn_sched_barrier(0);
@@ -457,7 +449,7 @@ linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, 
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : X), 0, R ? bytes : 0u, 0x00020000);
     const int frow = lane & 31, cbase = wave * (32 * TJ) + 4 * (lane >> 5);
     f32x4 v[TI][TJ][4];   // the residual rows (rows >= M return zeros), then the output values
-    stage_rows<D, TI>(X, M, m0, sXhi, sXmid, tid);
+    stage_rows<NP, D, TI>(X, M, m0, sX, tid);
     __syncthreads();
 
     f32x16 accy[TI][TJ];
@@ -468,14 +460,14 @@ linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) accy[i][j][e] = 0.f;
     const int xoff = frow * XS + (lane >> 5) * 8;
-    bf16x8 xf[2][TI][2];   // [k-step parity][row tile][hi | mid]: the fragments of step st + 1 are read before the MFMAs of st
+    bf16x8 xf[2][TI][NP];   // [k-step parity][row tile][piece]: the fragments of step st + 1 are read before the MFMAs of st
     auto read_x = [&](auto stc) {
         constexpr int st = decltype(stc)::value;
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            xf[st & 1][i][0] = *reinterpret_cast<const bf16x8 *>(&sXhi[i * 32 * XS + xoff + st * 16]);
-            xf[st & 1][i][1] = *reinterpret_cast<const bf16x8 *>(&sXmid[i * 32 * XS + xoff + st * 16]);
-        }
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+                xf[st & 1][i][p] = *reinterpret_cast<const bf16x8 *>(&sX[(p * BM + i * 32) * XS + xoff + st * 16]);
     };
     read_x(std::integral_constant<int, 0>{});
     static_for<KQ>([&](auto stc) {
@@ -493,36 +485,32 @@ linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, 
         }
         if constexpr (st + 1 < KQ) read_x(std::integral_constant<int, st + 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        const u32x4 (&cur)[2 * TJ] = ring[st % RING];
-        bf16x8 w_hi[TJ], w_mid[TJ];
+        const u32x4 (&cur)[NP * TJ] = ring[st % RING];
+        bf16x8 wf[TJ][NP];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            w_hi[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 0]);
-            w_mid[j] = __builtin_bit_cast(bf16x8, cur[j * 2 + 1]);
-        }
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+            for (int p = 0; p < NP; ++p) wf[j][p] = __builtin_bit_cast(bf16x8, cur[j * NP + p]);
+        using T = SplitTerms<NP>;
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], xf[st & 1][i][1], accy[i][j], 0, 0, 0);
+        for (int t = 0; t < T::N; ++t)
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_mid[j], xf[st & 1][i][0], accy[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w_hi[j], xf[st & 1][i][0], accy[i][j], 0, 0, 0);
+                for (int j = 0; j < TJ; ++j)
+                    accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][T::B[t]], xf[st & 1][i][T::A[t]], accy[i][j], 0, 0, 0);
     });
-    rows_epilogue<D, TI, LN>(accy, v, brs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sXhi), m0, wave, lane);
+    rows_epilogue<D, TI, LN>(accy, v, brs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sX), m0, wave, lane);
 }
 
-template <int D, int TI>
+template <int NP, int D, int TI>
 int launch_linln(const float *x, const u32x4 *w, const float *b, const float *res, const float *gamma, const float *beta, float eps,
                  float *y, int M, hipStream_t s)
 {
     const bool ln = gamma != nullptr;
-    const size_t lds = linln_lds_bytes<D>(TI);
-    const void *fn = ln ? (const void *)&linear_res_ln_kernel<D, TI, true> : (const void *)&linear_res_ln_kernel<D, TI, false>;
+    constexpr size_t lds = linln_lds_bytes<D>(TI, NP);
+    static_assert(lds <= 160 * 1024, "the activation tile does not fit the LDS of a CU");
+    const void *fn = ln ? (const void *)&linear_res_ln_kernel<NP, D, TI, true> : (const void *)&linear_res_ln_kernel<NP, D, TI, false>;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned> raised[2];   // bit per device, per kernel
         int dev = 0;
@@ -582,32 +570,35 @@ int linln_set_ti(int v)
 
 namespace {
 
-template <int D>
+template <int NP, int D>
 int dispatch_linln(const float *x, const u32x4 *w, const float *bias, const float *residual, const float *g, const float *b, float eps,
                    float *y, int M, hipStream_t s)
 {
-    // rows per block = 32 TI; automatic: few rows -> 32-row blocks (more of them), many -> 64 (two resident per CU)
+    // rows per block = 32 TI; automatic: few rows -> 32-row blocks (more of them), many -> 64 (two resident per CU with two
+    // pieces per operand; with three the 64-row tile is 99 KB of LDS: one block per CU)
     const int forced = linln_ti();
     switch (forced ? forced : (M < 4096 ? 1 : 2)) {
-    case 1: return launch_linln<D, 1>(x, w, bias, residual, g, b, eps, y, M, s);
-    case 3:   // 96 rows per block: hidden 256 only (at 288 the accumulators of three row tiles do not fit the register file)
-        if constexpr (D == 256) return launch_linln<D, 3>(x, w, bias, residual, g, b, eps, y, M, s);
-        else return launch_linln<D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
-    default: return launch_linln<D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
+    case 1: return launch_linln<NP, D, 1>(x, w, bias, residual, g, b, eps, y, M, s);
+    case 3:   // 96 rows per block: hidden 256 with two pieces only (at 288 the accumulators of three row tiles do not fit the
+              // register file, with three pieces the tile does not fit the LDS)
+        if constexpr (D == 256 && NP == 2) return launch_linln<NP, D, 3>(x, w, bias, residual, g, b, eps, y, M, s);
+        else return launch_linln<NP, D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
+    default: return launch_linln<NP, D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
     }
 }
 
-template <int D>
+template <int NP, int D>
 int dispatch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2, const float *b2, const float *residual,
                  const float *g, const float *b, float eps, float *y, int M, int F, hipStream_t s)
 {
     if (F < Geo<D>::CH || (F & 15)) return TF_MSDA_ERR_BAD_DIMS;   // at least one chunk; whole k-steps of GEMM 2
     switch (ffn_ti()) {
-    case 1: return launch_ffn<D, 1>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
-    case 2: return launch_ffn<D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
-    default:   // 96 rows per block: hidden 256 only (see dispatch_linln)
-        if constexpr (D == 256) return launch_ffn<D, 3>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
-        else return launch_ffn<D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    case 1: return launch_ffn<NP, D, 1>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    case 2: return launch_ffn<NP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    default:   // 96 rows per block: hidden 256 with two pieces only (see dispatch_linln; three pieces: 96 rows x (264 + 136) x 6 B
+               // = 225 KB of LDS)
+        if constexpr (D == 256 && NP == 2) return launch_ffn<NP, D, 3>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+        else return launch_ffn<NP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
     }
 }
 
@@ -615,28 +606,33 @@ int dispatch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *
 
 extern "C" int tf_linear_res_ln_f32(const float *x, const void *w_packed, const float *bias, const float *residual,
                                     const float *ln_weight, const float *ln_bias, float ln_eps, float *y, int64_t M, int K, int N,
-                                    void *stream)
+                                    int terms, void *stream)
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return TF_MSDA_ERR_NULL_POINTER;
-    if (M <= 0 || K != N || (K != 256 && K != 288) || (M + 128) * (int64_t)K * 4 > 0xFFFFFFFFLL) return TF_MSDA_ERR_BAD_DIMS;
+    const int np = split_pieces(terms);
+    if (M <= 0 || K != N || (K != 256 && K != 288) || (M + 128) * (int64_t)K * 4 > 0xFFFFFFFFLL || np == 0) return TF_MSDA_ERR_BAD_DIMS;
     uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y) |
                    reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(ln_weight) |
                    reinterpret_cast<uintptr_t>(ln_bias);
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *w = static_cast<const u32x4 *>(w_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return K == 256 ? dispatch_linln<256>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s)
-                    : dispatch_linln<288>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
+    if (np == 3)
+        return K == 256 ? dispatch_linln<3, 256>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s)
+                        : dispatch_linln<3, 288>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
+    return K == 256 ? dispatch_linln<2, 256>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s)
+                    : dispatch_linln<2, 288>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
 }
 
 extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const float *b1, const void *w2_packed, const float *b2,
                                 const float *residual, const float *ln_weight, const float *ln_bias, float ln_eps, float *y,
-                                int64_t M, int d_model, int d_ffn, void *stream)
+                                int64_t M, int d_model, int d_ffn, int terms, void *stream)
 {
     if (!x || !w1_packed || !w2_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return TF_MSDA_ERR_NULL_POINTER;
-    if (M <= 0 || (d_model != 256 && d_model != 288) || d_ffn <= 0 ||
+    const int np = split_pieces(terms);
+    if (M <= 0 || (d_model != 256 && d_model != 288) || d_ffn <= 0 || np == 0 ||
         (M + 128) * (int64_t)d_model * 4 > 0xFFFFFFFFLL)   // 32-bit buffer offsets, incl. the rows of the last block past M
         return TF_MSDA_ERR_BAD_DIMS;
     uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1_packed) | reinterpret_cast<uintptr_t>(w2_packed) |
@@ -645,6 +641,9 @@ extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const flo
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *w1 = static_cast<const u32x4 *>(w1_packed), *w2 = static_cast<const u32x4 *>(w2_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return d_model == 256 ? dispatch_ffn<256>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s)
-                          : dispatch_ffn<288>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
+    if (np == 3)
+        return d_model == 256 ? dispatch_ffn<3, 256>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s)
+                              : dispatch_ffn<3, 288>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
+    return d_model == 256 ? dispatch_ffn<2, 256>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s)
+                          : dispatch_ffn<2, 288>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
 }

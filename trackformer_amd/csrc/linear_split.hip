@@ -26,18 +26,14 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "msda_common.h"
+#include "split_product.h"
 #include "tf_fused.h"
 #include "tf_msda.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int BK = 32, THREADS = 256;
 constexpr int LDS_STRIDE = BK + 8;   // bf16 elements per LDS row: 80 bytes, keeps 16-byte alignment, spreads banks
@@ -68,18 +64,19 @@ __device__ __forceinline__ int stage_row(int q) { return (q & ~7) | ((q & 1) << 
 // (profiles/r02_split_gemm_astat_trace.txt: 10.5 us of store time per 96 x 256 tile).
 // XADD (tf_linear_split_add_f32): the activation is X + X2, added element-wise as the tile is staged -- the layers'
 // `with_pos_embed(src, pos)` in front of a projection (deformable_transformer.py:279-283) without its own pass over the tokens.
-template <int BM, int BN, bool RELU, bool PREFETCH, bool RESID, bool BUFST, bool XADD = false>
+template <int NP, int BM, int BN, bool RELU, bool PREFETCH, bool RESID, bool BUFST, bool XADD = false>
 __device__ __forceinline__ void
 split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, const float *__restrict__ R,
-                float *__restrict__ Y, int M, int K, int N, const float *__restrict__ X2 = nullptr)
+                const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo, const float *__restrict__ bias,
+                const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N, const float *__restrict__ X2 = nullptr)
 {
+    const unsigned short *const Wp[3] = {Whi, Wmid, Wlo};
     constexpr int TI = BM / 64, TJ = BN / 64;
     constexpr int XV = (BM * BK / 4) / THREADS;   // float4 of X per thread and slice
     constexpr int WV = (BN * BK / 8) / THREADS;   // 16-byte pieces of each weight tensor per thread and slice
     static_assert(XV >= 1 && WV >= 1, "tile too small for 256 threads");
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][BM * LDS_STRIDE];   // [hi | mid][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[2][BN * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned short sA[NP][BM * LDS_STRIDE];   // [hi | mid | lo][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[NP][BN * LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -93,7 +90,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 xr[XV];
-    u32x4 whr[WV], wmr[WV];
+    u32x4 wr[NP][WV];
     f32x4 xr2[XADD ? XV : 1];
     auto load_slice = [&](int k0) {
 #pragma unroll
@@ -114,8 +111,8 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
             const int row = stage_row(idx >> 2), c8 = idx & 3;
             const int grow = min(n0 + row, N - 1);
             const size_t g = (size_t)grow * K + k0 + c8 * 8;
-            whr[it] = *reinterpret_cast<const u32x4 *>(Whi + g);
-            wmr[it] = *reinterpret_cast<const u32x4 *>(Wmid + g);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) wr[q][it] = *reinterpret_cast<const u32x4 *>(Wp[q] + g);
         }
     };
     auto store_slice = [&]() {
@@ -123,23 +120,19 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            bf16x4 hi, mid;   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
+            bf16x4 pc[NP];   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
             f32x4 xv = xr[it];
             if constexpr (XADD) xv += xr2[it];
+            split4<NP>(xv, pc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)xv[e];
-                mid[e] = (__bf16)(xv[e] - (float)hi[e]);
-            }
-            *reinterpret_cast<bf16x4 *>(&sA[0][row * LDS_STRIDE + c4 * 4]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sA[1][row * LDS_STRIDE + c4 * 4]) = mid;
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 2), c8 = idx & 3;
-            *reinterpret_cast<u32x4 *>(&sB[0][row * LDS_STRIDE + c8 * 8]) = whr[it];
-            *reinterpret_cast<u32x4 *>(&sB[1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(&sB[q][row * LDS_STRIDE + c8 * 8]) = wr[q][it];
         }
     };
 
@@ -154,28 +147,20 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int koff = kk + (lane >> 5) * 8;
-            bf16x8 a_hi[TI], a_mid[TI], b_hi[TJ], b_mid[TJ];
+            bf16x8 af[TI][NP], bfr[TJ][NP];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
-                a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[0][r]);
-                a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[1][r]);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const bf16x8 *>(&sA[q][r]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
-                b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[0][r]);
-                b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[1][r]);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) bfr[j][q] = *reinterpret_cast<const bf16x8 *>(&sB[q][r]);
             }
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid[i], b_hi[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_mid[j], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
-                }
+            mfma_tiles<NP, TI, TJ>(acc, af, bfr);   // smallest terms first
         }
         __syncthreads();
     }
@@ -234,31 +219,31 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
         }
 }
 
-template <int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
+template <int NP, int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                  const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
-                  int M, int K, int N)
+                  const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                  const float *__restrict__ bias, float *__restrict__ Y, int M, int K, int N)
 {
-    split_gemm_body<BM, BN, RELU, PREFETCH, false, BUFST>(X, Whi, Wmid, bias, nullptr, Y, M, K, N);
+    split_gemm_body<NP, BM, BN, RELU, PREFETCH, false, BUFST>(X, Whi, Wmid, Wlo, bias, nullptr, Y, M, K, N);
 }
 
-template <int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
+template <int NP, int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_res_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                      const unsigned short *__restrict__ Wmid, const float *__restrict__ bias,
-                      const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N)
+                      const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                      const float *__restrict__ bias, const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N)
 {
-    split_gemm_body<BM, BN, RELU, PREFETCH, true, BUFST>(X, Whi, Wmid, bias, R, Y, M, K, N);
+    split_gemm_body<NP, BM, BN, RELU, PREFETCH, true, BUFST>(X, Whi, Wmid, Wlo, bias, R, Y, M, K, N);
 }
 
-template <int BM, int BN, bool PREFETCH, bool BUFST>
+template <int NP, int BM, int BN, bool PREFETCH, bool BUFST>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_add_kernel(const float *__restrict__ X, const float *__restrict__ X2, const unsigned short *__restrict__ Whi,
-                      const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
-                      int M, int K, int N)
+                      const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                      const float *__restrict__ bias, float *__restrict__ Y, int M, int K, int N)
 {
-    split_gemm_body<BM, BN, false, PREFETCH, false, BUFST, true>(X, Whi, Wmid, bias, nullptr, Y, M, K, N, X2);
+    split_gemm_body<NP, BM, BN, false, PREFETCH, false, BUFST, true>(X, Whi, Wmid, Wlo, bias, nullptr, Y, M, K, N, X2);
 }
 
 // ---- 3 x 3 convolution (padding 1, stride 1 or 2) on channels_last activations as the same split product: an
@@ -276,28 +261,30 @@ struct Conv3Args {
 };
 
 //
-// BUFLD (the default for inputs < 3 GiB; tf_msda_set_option("conv3_bufload", 0) / TF_CONV3_BUFLOAD=0 keeps the pointer loads):
-// the A rows and the weight pieces are fetched through buffer resources with 32-bit offsets.  A tap that falls outside the
+// The A rows and the weight pieces are fetched through buffer resources with 32-bit offsets.  A tap that falls outside the
 // image gets an offset beyond num_records and the hardware returns zeros, so nothing is selected AFTER the load: with
 // `v = *p; x = ok ? v : 0` the compiler placed the v_cndmask right behind each global_load (s_waitcnt vmcnt(0) between the
 // first A load and the remaining five of the slice, vmcnt(4) behind the second), i.e. the prefetch of slice s + 1 waited
 // for its own data BEFORE the MFMAs of slice s that were meant to cover it -- two exposed memory latencies per K-slice
 // (the ISA is quoted in DESIGN.md section 4.4).  The 64-bit address arithmetic (v_mad_i64 / v_mad_u64 chains per load)
-// goes away with it: per slice one uniform tap offset is added to per-thread constants.
-template <int BM, int BN, bool RELU, bool BUFLD, bool PIPE = false>
+// goes away with it: per slice one uniform tap offset is added to per-thread constants.  Inputs and weights have to lie below
+// the out-of-range marker (3 GiB; host check -- larger tensors are refused and the caller keeps the library convolution).
+// Measured and NOT kept (profiles/r03_conv3_bufload.txt, r03_conv3_ksplit.txt, r03_conv3_tile128.txt, r03_conv3_ahead2.txt,
+// r04_conv3_operands_ahead.txt): pointer loads (the defect above), a second LDS stage with one barrier per slice (1-10 % slower
+// at every layer), 128-row output tiles (+3 %), the loads issued two slices ahead with a second register set (+1.5 %), the
+// LDS operands read one k-step ahead of their MFMAs with two LDS stages (+7 % over the backbone).
+template <int NP, int BM, int BN, bool RELU>
 __global__ void __launch_bounds__(THREADS)
 split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                   const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
-                   const Conv3Args ca)
+                   const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                   const float *__restrict__ bias, float *__restrict__ Y, const Conv3Args ca)
 {
     constexpr int TI = BM / 64, TJ = BN / 64;
     constexpr int XV = (BM * BK / 4) / THREADS;
     constexpr int WV = (BN * BK / 8) / THREADS;
     static_assert(XV >= 1 && WV >= 1, "tile too small for 256 threads");
-    static_assert(!PIPE || BUFLD, "the pipelined schedule uses the buffer loads (dead loads past the last slice)");
-    constexpr int NST = PIPE ? 2 : 1;   // LDS stages
-    __shared__ __attribute__((aligned(16))) unsigned short sA[NST][2][BM * LDS_STRIDE];   // [stage][hi | mid][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[NST][2][BN * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned short sA[NP][BM * LDS_STRIDE];   // [hi | mid | lo][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[NP][BN * LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -312,8 +299,21 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // this thread's XV rows of the A tile: output pixel -> (image, top-left input pixel of its 3 x 3 window)
-    int ybase[XV], xbase[XV], ibase[XV];
+    int ybase[XV], xbase[XV];
     bool rowok[XV];
+    f32x4 xr[XV];
+    u32x4 wr[NP][WV];
+    // byte offsets of this thread's pieces at tap (0, 0), channel 0 / at k = 0 (wrap-around arithmetic: a border
+    // pixel's window starts in front of the image, the sum with a valid tap's offset is back inside)
+    constexpr unsigned OOB = 0xC0000000u;   // >= num_records of every resource below (sizes are checked by the host)
+    unsigned xoff[XV], woff[WV];
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(X), 0, (unsigned)((size_t)ca.nimg * ca.hin * ca.win * ca.cin * 4), 0x00020000);
+    const unsigned wbytes = (unsigned)((size_t)N * K * 2);
+    const __amdgpu_buffer_rsrc_t wrs[3] = {
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Whi), 0, wbytes, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Wmid), 0, wbytes, 0x00020000),
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(NP > 2 ? Wlo : Whi), 0, wbytes, 0x00020000)};
 #pragma unroll
     for (int it = 0; it < XV; ++it) {
         const int idx = it * THREADS + tid;
@@ -324,193 +324,90 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         const int yo = rem / ca.wout, xo = rem - yo * ca.wout;
         ybase[it] = yo * ca.stride - ca.pad;
         xbase[it] = xo * ca.stride - ca.pad;
-        ibase[it] = img * ca.hin;
+        xoff[it] = ((unsigned)((img * ca.hin + ybase[it]) * ca.win + xbase[it]) * (unsigned)ca.cin + (unsigned)((idx & 7) * 4)) * 4u;
     }
-    f32x4 xr[XV];
-    u32x4 whr[WV], wmr[WV];
-    // BUFLD: byte offsets of this thread's pieces at tap (0, 0), channel 0 / at k = 0 (wrap-around arithmetic: a border
-    // pixel's window starts in front of the image, the sum with a valid tap's offset is back inside)
-    constexpr unsigned OOB = 0xC0000000u;   // >= num_records of every resource below (sizes are checked by the host)
-    unsigned xoff[XV], woff[WV];
-    __amdgpu_buffer_rsrc_t xrs, whrs, wmrs;
-    if constexpr (BUFLD) {
-        xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0,
-                                                (unsigned)((size_t)ca.nimg * ca.hin * ca.win * ca.cin * 4), 0x00020000);
-        whrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Whi), 0, (unsigned)((size_t)N * K * 2), 0x00020000);
-        wmrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Wmid), 0, (unsigned)((size_t)N * K * 2), 0x00020000);
 #pragma unroll
-        for (int it = 0; it < XV; ++it)
-            xoff[it] = ((unsigned)((ibase[it] + ybase[it]) * ca.win + xbase[it]) * (unsigned)ca.cin
-                        + (unsigned)(((it * THREADS + tid) & 7) * 4)) * 4u;
-#pragma unroll
-        for (int it = 0; it < WV; ++it) {
-            const int idx = it * THREADS + tid;
-            woff[it] = ((unsigned)min(n0 + (stage_row(idx >> 2)), N - 1) * (unsigned)K + (unsigned)((idx & 3) * 8)) * 2u;
-        }
+    for (int it = 0; it < WV; ++it) {
+        const int idx = it * THREADS + tid;
+        woff[it] = ((unsigned)min(n0 + (stage_row(idx >> 2)), N - 1) * (unsigned)K + (unsigned)((idx & 3) * 8)) * 2u;
     }
-    // BUFLD walks the slices in order and steps (channel, dx, dy) of the NEXT slice instead of dividing k0 per slice
+    // the slices are walked in order: (channel, dx, dy) of the NEXT slice are stepped instead of dividing k0 per slice
     int nc0 = 0, ndx = 0, ndy = 0;
-    auto load_slice = [&](int k0, bool live = true) {   // !live (PIPE): past the last slice, every offset out of range
-        if constexpr (BUFLD) {
-            const int c0 = nc0, dx = ndx, dy = ndy;
-            nc0 += BK;
-            if (nc0 == ca.cin) {
-                nc0 = 0;
-                if (++ndx == ca.ks) {
-                    ndx = 0;
-                    ++ndy;
-                }
+    auto load_slice = [&](int k0) {
+        const int c0 = nc0, dx = ndx, dy = ndy;
+        nc0 += BK;
+        if (nc0 == ca.cin) {
+            nc0 = 0;
+            if (++ndx == ca.ks) {
+                ndx = 0;
+                ++ndy;
             }
-            const unsigned tapoff = (unsigned)((dy * ca.win + dx) * ca.cin + c0) * 4u;   // uniform
-            const unsigned dead = live ? 0u : OOB;   // OR-ed into every offset (all of them < OOB): straight-line code
-#pragma unroll
-            for (int it = 0; it < XV; ++it) {
-                const bool ok = rowok[it] && (unsigned)(ybase[it] + dy) < (unsigned)ca.hin
-                                && (unsigned)(xbase[it] + dx) < (unsigned)ca.win;
-                xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (ok ? xoff[it] + tapoff : OOB) | dead, 0, 0));
-            }
-#pragma unroll
-            for (int it = 0; it < WV; ++it) {
-                const unsigned o = (woff[it] + (unsigned)k0 * 2u) | dead;
-                whr[it] = __builtin_amdgcn_raw_buffer_load_b128(whrs, o, 0, 0);
-                wmr[it] = __builtin_amdgcn_raw_buffer_load_b128(wmrs, o, 0, 0);
-            }
-            return;
         }
-        const int tap = k0 / ca.cin, c0 = k0 - tap * ca.cin;   // uniform: the slice lies inside one tap
-        const int dy = tap / ca.ks, dx = tap - dy * ca.ks;
+        const unsigned tapoff = (unsigned)((dy * ca.win + dx) * ca.cin + c0) * 4u;   // uniform
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
-            const int idx = it * THREADS + tid;
-            const int c4 = idx & 7;
-            const int yi = ybase[it] + dy, xi = xbase[it] + dx;
-            const bool ok = rowok[it] && (unsigned)yi < (unsigned)ca.hin && (unsigned)xi < (unsigned)ca.win;
-            const size_t src = ((size_t)(ibase[it] + (ok ? yi : 0)) * ca.win + (ok ? xi : 0)) * ca.cin + c0 + c4 * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(X + src);   // (a valid address either way)
-            xr[it] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            const bool ok = rowok[it] && (unsigned)(ybase[it] + dy) < (unsigned)ca.hin && (unsigned)(xbase[it] + dx) < (unsigned)ca.win;
+            xr[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xoff[it] + tapoff : OOB, 0, 0));
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
-            const int idx = it * THREADS + tid;
-            const int row = stage_row(idx >> 2), c8 = idx & 3;
-            const int grow = min(n0 + row, N - 1);
-            const size_t g = (size_t)grow * K + k0 + c8 * 8;
-            whr[it] = *reinterpret_cast<const u32x4 *>(Whi + g);
-            wmr[it] = *reinterpret_cast<const u32x4 *>(Wmid + g);
+            const unsigned o = woff[it] + (unsigned)k0 * 2u;
+#pragma unroll
+            for (int q = 0; q < NP; ++q) wr[q][it] = __builtin_amdgcn_raw_buffer_load_b128(wrs[q], o, 0, 0);
         }
     };
-    auto store_slice = [&](int st = 0) {
+    auto store_slice = [&]() {
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            bf16x4 hi, mid;
+            bf16x4 pc[NP];
+            split4<NP>(xr[it], pc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)xr[it][e];
-                mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
-            }
-            *reinterpret_cast<bf16x4 *>(&sA[st][0][row * LDS_STRIDE + c4 * 4]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sA[st][1][row * LDS_STRIDE + c4 * 4]) = mid;
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 2), c8 = idx & 3;
-            *reinterpret_cast<u32x4 *>(&sB[st][0][row * LDS_STRIDE + c8 * 8]) = whr[it];
-            *reinterpret_cast<u32x4 *>(&sB[st][1][row * LDS_STRIDE + c8 * 8]) = wmr[it];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(&sB[q][row * LDS_STRIDE + c8 * 8]) = wr[q][it];
         }
     };
 
     const int kbeg = ca.kslices > 0 ? (int)blockIdx.z * ca.kslices * BK : 0;
     const int kend = ca.kslices > 0 ? min(K, kbeg + ca.kslices * BK) : K;
     if (ca.kslices > 0) Y += (size_t)blockIdx.z * M * N;   // this split's partial sums
-    if constexpr (BUFLD) {
+    {
         const int tap = kbeg / ca.cin;
         nc0 = kbeg - tap * ca.cin;
         ndy = tap / ca.ks;
         ndx = tap - ndy * ca.ks;
     }
-    struct Frags {
-        bf16x8 a_hi[TI], a_mid[TI], b_hi[TJ], b_mid[TJ];
-    };
-    auto read_frags = [&](Frags &f, int st, int kk) {   // the wave's operands of one 16-wide k-step from LDS stage `st`
-        const int koff = kk + (lane >> 5) * 8;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
-            f.a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[st][0][r]);
-            f.a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[st][1][r]);
-        }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
-            f.b_hi[j] = *reinterpret_cast<const bf16x8 *>(&sB[st][0][r]);
-            f.b_mid[j] = *reinterpret_cast<const bf16x8 *>(&sB[st][1][r]);
-        }
-    };
-    auto mfma_frags = [&](const Frags &f) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a_mid[i], f.b_hi[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a_hi[i], f.b_mid[j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a_hi[i], f.b_hi[j], acc[i][j], 0, 0, 0);
-            }
-    };
-    auto mfma_slice = [&]() {
+    load_slice(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        store_slice();
+        __syncthreads();
+        if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
-            Frags f;
-            read_frags(f, 0, kk);
-            mfma_frags(f);
+            const int koff = kk + (lane >> 5) * 8;
+            bf16x8 af[TI][NP], bfr[TJ][NP];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const bf16x8 *>(&sA[q][r]);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) bfr[j][q] = *reinterpret_cast<const bf16x8 *>(&sB[q][r]);
+            }
+            mfma_tiles<NP, TI, TJ>(acc, af, bfr);
         }
-    };
-    load_slice(kbeg);
-    if constexpr (PIPE) {
-        // EXPERIMENT (tf_msda_set_option("conv3_bufload", 2) / TF_CONV3_BUFLOAD=2; written after the last GPU minute of round 3,
-        // bit-identical on the emulator, NOT timed yet): the operands of a k-step are read from LDS one k-step AHEAD of
-        // the MFMAs that use them, into a second register set -- the counters of the default schedule show the waves a third
-        // of their time in s_waitcnt with neither memory latency, barrier count nor LDS store conflicts to blame
-        // (DESIGN.md section 4.4), which leaves the ds_read -> MFMA dependency inside the k-step.  Two LDS stages, ONE
-        // barrier per slice, placed between the two k-steps:
-        //     read (s, k-step 1) | MFMA (s, k-step 0) | stage slice s + 1 | issue the loads of s + 2 | barrier |
-        //     read (s + 1, k-step 0) | MFMA (s, k-step 1)
-        // Past the last slice the loads are dead (out-of-range offsets, zeros) and a stage of zeros is written: no branch
-        // in the loop, exact wait counts.  Same products in the same order per accumulator.
-        store_slice(0);
-        load_slice(kbeg + BK, kbeg + BK < kend);
         __syncthreads();
-        Frags f0, f1;
-        read_frags(f0, 0, 0);
-        int st = 0;
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            // (the sched_barriers pin the order: left alone, the scheduler sinks every ds_read to right in front of the
-            // MFMA that uses it -- shorter live ranges, and the schedule this variant exists to get away from)
-            read_frags(f1, st, 16);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_frags(f0);
-            store_slice(st ^ 1);
-            load_slice(k0 + 2 * BK, k0 + 2 * BK < kend);
-            __syncthreads();
-            read_frags(f0, st ^ 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_frags(f1);
-            __builtin_amdgcn_sched_barrier(0);
-            st ^= 1;
-        }
-    } else {
-        // Measured and NOT kept (profiles/r03_conv3_bufload.txt, r03_conv3_ksplit.txt, r03_conv3_tile128.txt, r03_conv3_ahead2.txt):
-        // a second LDS stage with one barrier per slice (1-10 % slower at every layer), 128-row output tiles (+3 %), the
-        // loads issued two slices ahead with a second register set (+1.5 %).
-        for (int k0 = kbeg; k0 < kend; k0 += BK) {
-            store_slice();
-            __syncthreads();
-            if (k0 + BK < kend) load_slice(k0 + BK);   // in flight during the MFMAs below
-            mfma_slice();
-            __syncthreads();
-        }
     }
     // ---- epilogue: buffer stores (rows >= M beyond num_records, columns >= N from 3 GiB)
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
@@ -574,17 +471,18 @@ conv_splitk_reduce_kernel(const float *__restrict__ part, const float *__restric
 // S = K / 32 is a template parameter (8, 9, 32, 36: hidden 256 / 288 and their FFN widths) so that the slice loop is
 // straight-line code: with run-time trip counts the compiler's wait-count pass loses track of how many loads are in
 // flight across the branches and falls back to vmcnt(0), which would wait for the refill just issued.
-template <bool RELU, int S>
+template <int NP, bool RELU, int S>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                       const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y,
-                       int M, int K, int N)
+                       const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                       const float *__restrict__ bias, float *__restrict__ Y, int M, int K, int N)
 {
     constexpr int BM = 64, BN = 64, PFD = 8;
     constexpr int XV = (BM * BK / 4) / THREADS;   // 2 float4 of X per thread and slice
     constexpr int WV = (BN * BK / 8) / THREADS;   // 1 16-byte piece of each weight tensor per thread and slice
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][2][BM * LDS_STRIDE];   // [buffer][hi | mid][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[2][2][BN * LDS_STRIDE];
+    const unsigned short *const Wp[3] = {Whi, Wmid, Wlo};
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][NP][BM * LDS_STRIDE];   // [buffer][hi | mid | lo][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][NP][BN * LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -594,7 +492,7 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     f32x4 xr[PFD][XV];
-    u32x4 whr[PFD][WV], wmr[PFD][WV];
+    u32x4 wr[PFD][NP][WV];
     const float *xp[XV];
     size_t wg[WV];
 #pragma unroll
@@ -614,10 +512,9 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
 #pragma unroll
         for (int it = 0; it < XV; ++it) xr[slot][it] = *reinterpret_cast<const f32x4 *>(xp[it] + s * BK);
 #pragma unroll
-        for (int it = 0; it < WV; ++it) {
-            whr[slot][it] = *reinterpret_cast<const u32x4 *>(Whi + wg[it] + s * BK);
-            wmr[slot][it] = *reinterpret_cast<const u32x4 *>(Wmid + wg[it] + s * BK);
-        }
+        for (int it = 0; it < WV; ++it)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) wr[slot][q][it] = *reinterpret_cast<const u32x4 *>(Wp[q] + wg[it] + s * BK);
     };
     auto store_slice = [&](auto slotc, int buf) {
         constexpr int slot = decltype(slotc)::value;
@@ -625,21 +522,17 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            bf16x4 hi, mid;   // v_cvt_pk_bf16_f32, round to nearest even
+            bf16x4 pc[NP];   // v_cvt_pk_bf16_f32, round to nearest even
+            split4<NP>(xr[slot][it], pc);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)xr[slot][it][e];
-                mid[e] = (__bf16)(xr[slot][it][e] - (float)hi[e]);
-            }
-            *reinterpret_cast<bf16x4 *>(&sA[buf][0][row * LDS_STRIDE + c4 * 4]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sA[buf][1][row * LDS_STRIDE + c4 * 4]) = mid;
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&sA[buf][q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 2), c8 = idx & 3;
-            *reinterpret_cast<u32x4 *>(&sB[buf][0][row * LDS_STRIDE + c8 * 8]) = whr[slot][it];
-            *reinterpret_cast<u32x4 *>(&sB[buf][1][row * LDS_STRIDE + c8 * 8]) = wmr[slot][it];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(&sB[buf][q][row * LDS_STRIDE + c8 * 8]) = wr[slot][q][it];
         }
     };
     auto each_slot = [&](auto &&f) {
@@ -670,13 +563,13 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
             for (int kk = 0; kk < BK; kk += 16) {
                 const int koff = kk + (lane >> 5) * 8;
                 const int ra = (wm + (lane & 31)) * LDS_STRIDE + koff, rb = (wn + (lane & 31)) * LDS_STRIDE + koff;
-                const bf16x8 a_hi = *reinterpret_cast<const bf16x8 *>(&sA[buf][0][ra]);
-                const bf16x8 a_mid = *reinterpret_cast<const bf16x8 *>(&sA[buf][1][ra]);
-                const bf16x8 b_hi = *reinterpret_cast<const bf16x8 *>(&sB[buf][0][rb]);
-                const bf16x8 b_mid = *reinterpret_cast<const bf16x8 *>(&sB[buf][1][rb]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid, b_hi, acc, 0, 0, 0);   // smallest terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_mid, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi, b_hi, acc, 0, 0, 0);
+                bf16x8 af[NP], bfr[NP];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    af[q] = *reinterpret_cast<const bf16x8 *>(&sA[buf][q][ra]);
+                    bfr[q] = *reinterpret_cast<const bf16x8 *>(&sB[buf][q][rb]);
+                }
+                mfma_terms<NP>(acc, af, bfr);   // smallest terms first
             }
             __syncthreads();
         }
@@ -714,447 +607,137 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
     }
 }
 
-// ---- weight-stationary variant (variant 6; K == 256, many rows; an experiment that was run and measured, see above): the 128 x 256 weight block of a column block stays in LDS for the
-// whole workgroup (hi + mid pieces: 128 KB, 16-byte pieces XOR-swizzled by row & 15 so that the 16 lanes that read 16
-// different rows at one k hit 16 different bank groups; staged once by LDS-DMA), the activations stream from global memory
-// straight into MFMA fragment layout (lane = row, 8 consecutive k: two 16-byte loads), are split in registers and never
-// touch LDS: no barrier in the main loop, every wave walks its own 16-row tiles with the next tile's loads in flight.
-// v_mfma_f32_16x16x32_bf16 with the WEIGHT fragment as A and the activation fragment as B: D[n][m], a lane ends up with
-// 4 consecutive n of one row m -> one 16-byte store per tile and lane.
-typedef __attribute__((ext_vector_type(4))) float f32x4w;
-constexpr int WS_K = 256, WS_BN = 128, WS_KS = WS_K / 32, WS_NT = WS_BN / 16;
-constexpr unsigned kWsOob = 0xFFFFFFF0u;
+// ---------------------------------------------------------------------------------------------------------------- host side
+// Tensors whose byte offsets stay below the buffer resources' out-of-range marker (3 GiB) take the buffer-store epilogue; anything
+// larger the plain stores (split_gemm_body<..., BUFST = false>).
+inline bool fits_bufstore(long long M, int N) { return (M + 256) * N * 4 < 0xC0000000LL; }
 
-// NSPLIT: the block's 8 column tiles are shared out over NSPLIT groups of 4 waves (NSPLIT = 2: 8 waves, each wave 4 column
-// tiles of every row tile of its group; the activations of a row tile are then loaded by 2 waves, the second time from L1).
-template <bool RELU, int NSPLIT>
-__global__ void __launch_bounds__(NSPLIT * 256)
-split_gemm_ws_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                     const unsigned short *__restrict__ Wmid, const float *__restrict__ bias, float *__restrict__ Y, int M,
-                     int N, int tiles_per_block, unsigned wbytes)
+template <int NP, int BM, int BN, bool PREFETCH>
+int launch_gemm(const float *x, const unsigned short *const (&w)[3], const float *bias, const float *res, float *y, int M, int K, int N,
+                int relu, hipStream_t s)
 {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char s_w[];   // [hi | mid][128 rows][32 pieces of 16 B]
-    constexpr int TENSOR_BYTES = WS_BN * WS_K * 2;   // 65536
-    constexpr int WAVES = 4 * NSPLIT, NTW = WS_NT / NSPLIT;   // column tiles per wave
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wrow = wave & 3, wcol = wave >> 2;   // row-tile lane of the wave, column group
-    const int n0 = blockIdx.x * WS_BN;
-    const int ntiles = (M + 15) >> 4;
-    const int tile0 = blockIdx.y * tiles_per_block;
-    if (tile0 >= ntiles) return;
-
-    const int lrow = lane & 15, kg = lane >> 4;
-    auto load_tile = [&](int tile, f32x4w (&xa)[WS_KS][2]) {
-        const int row = min(tile * 16 + lrow, M - 1);   // rows past M read the last row, never stored
-        const float *base = X + (size_t)row * WS_K + kg * 8;
-#pragma unroll
-        for (int ks = 0; ks < WS_KS; ++ks) {
-            xa[ks][0] = *reinterpret_cast<const f32x4w *>(base + ks * 32);
-            xa[ks][1] = *reinterpret_cast<const f32x4w *>(base + ks * 32 + 4);
+    const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
+    if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
+    auto go = [&](auto bufst) {
+        constexpr bool B = decltype(bufst)::value;
+        if (res) {
+            if (relu) hipLaunchKernelGGL((split_gemm_res_kernel<NP, BM, BN, true, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, res, y, M, K, N);
+            else hipLaunchKernelGGL((split_gemm_res_kernel<NP, BM, BN, false, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, res, y, M, K, N);
+        } else {
+            if (relu) hipLaunchKernelGGL((split_gemm_kernel<NP, BM, BN, true, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, y, M, K, N);
+            else hipLaunchKernelGGL((split_gemm_kernel<NP, BM, BN, false, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, y, M, K, N);
         }
     };
-    f32x4w xa[WS_KS][2], xn[WS_KS][2];
-    int t = wrow;
-    const bool any = t < tiles_per_block && tile0 + t < ntiles;
-    if (any) load_tile(tile0 + t, xa);   // the first tile's activations travel while the weights are staged
-
-    // ---- stage the weight block: 64 DMA wave-instructions of 1 KB per tensor
-    {
-        const __amdgpu_buffer_rsrc_t r_hi = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Whi), 0, wbytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t r_mid = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Wmid), 0, wbytes, 0x00020000);
-        for (int c = wave; c < TENSOR_BYTES / 1024; c += WAVES) {
-            const int pp = c * 64 + lane;            // physical 16-byte piece of the LDS image
-            const int row = pp >> 5, q = pp & 31;
-            const int logical = q ^ (row & 15);      // which 8 k of the row live there
-            const int grow = n0 + row;
-            const unsigned off = grow < N ? (unsigned)((grow * WS_K + logical * 8) * 2) : kWsOob;   // rows past N: zeros
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_hi, (__attribute__((address_space(3))) void *)(s_w + c * 1024), 16, off, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_mid, (__attribute__((address_space(3))) void *)(s_w + TENSOR_BYTES + c * 1024), 16,
-                                                     off, 0, 0, 0);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
-        __syncthreads();
-    }
-
-    const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)s_w) +
-                              (unsigned)(wcol * NTW) * 8192u;
-    for (; t < tiles_per_block && tile0 + t < ntiles; t += 4) {
-        const int tile = tile0 + t;
-        const bool has_next = t + 4 < tiles_per_block && tile + 4 < ntiles;
-        if (has_next) load_tile(tile + 4, xn);   // in flight during the MFMAs below
-        f32x4w acc[NTW];
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[j] = f32x4w{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < WS_KS; ++ks) {
-            bf16x8 xh, xm;   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                xh[e] = (__bf16)xa[ks][0][e];
-                xm[e] = (__bf16)(xa[ks][0][e] - (float)xh[e]);
-                xh[4 + e] = (__bf16)xa[ks][1][e];
-                xm[4 + e] = (__bf16)(xa[ks][1][e] - (float)xh[4 + e]);
-            }
-            // weight fragments of the wave's column tiles: row j * 16 + lrow, logical piece ks * 4 + kg, swizzled by the row
-            const unsigned a0 = lds_base + (unsigned)(lrow * 32 + ((ks * 4 + kg) ^ lrow)) * 16u;
-            bf16x8 wh[NTW], wm[NTW];
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                wh[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>((size_t)(a0 + j * 8192u));
-                wm[j] = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8 *>((size_t)(a0 + TENSOR_BYTES + j * 8192u));
-            }
-            // three passes over the column tiles: consecutive MFMAs never share an accumulator (smallest terms first)
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[j], xh, acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xm, acc[j], 0, 0, 0);
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh, acc[j], 0, 0, 0);
-        }
-        // ---- epilogue: D[n][m]: lane holds n = 4 * kg + 0..3 of column m = lrow
-        const int m = tile * 16 + lrow;
-        if (m < M) {
-#pragma unroll
-            for (int j = 0; j < NTW; ++j) {
-                const int n = n0 + (wcol * NTW + j) * 16 + kg * 4;
-                if (n < N) {   // N % 4 == 0 (host checked): the four columns exist together
-                    f32x4w v = acc[j];
-                    if (bias != nullptr) v += *reinterpret_cast<const f32x4w *>(bias + n);
-                    if (RELU) {
-                        v.x = fmaxf(v.x, 0.f);
-                        v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f);
-                        v.w = fmaxf(v.w, 0.f);
-                    }
-                    *reinterpret_cast<f32x4w *>(Y + (size_t)m * N + n) = v;
-                }
-            }
-        }
-        if (has_next) {
-#pragma unroll
-            for (int ks = 0; ks < WS_KS; ++ks) {
-                xa[ks][0] = xn[ks][0];
-                xa[ks][1] = xn[ks][1];
-            }
-        }
-    }
-}
-
-int ws_num_cus()
-{
-    static const int n = [] {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) {
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        }
-        return cus;
-    }();
-    return n;
-}
-
-int ws_nsplit()
-{
-    static const int v = [] { const char *e = getenv("TF_LINEAR_WS_SPLIT"); return e ? atoi(e) : 2; }();
-    return v == 1 ? 1 : 2;
-}
-
-// -> TF_MSDA_OK, an error, or 1 when the call does not qualify
-int launch_ws(const float *x, const unsigned short *wh, const unsigned short *wm, const float *bias, float *y, int M, int K, int N,
-              int relu, hipStream_t s)
-{
-    if (K != WS_K || (N & 3) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15)) || (reinterpret_cast<uintptr_t>(y) & 15) ||
-        (long long)N * K * 2 >= (1LL << 31))
-        return 1;
-    const int nblk = (N + WS_BN - 1) / WS_BN;
-    const int ntiles = (M + 15) / 16;
-    int mblk = ws_num_cus() / nblk;
-    if (mblk < 1) mblk = 1;
-    if (mblk > ntiles) mblk = ntiles;
-    const int tpb = (ntiles + mblk - 1) / mblk;
-    mblk = (ntiles + tpb - 1) / tpb;
-    const bool eight = ws_nsplit() == 2;
-    const size_t lds = 2 * (size_t)WS_BN * WS_K * 2;
-    const void *fn = relu ? (eight ? (const void *)&split_gemm_ws_kernel<true, 2> : (const void *)&split_gemm_ws_kernel<true, 1>)
-                          : (eight ? (const void *)&split_gemm_ws_kernel<false, 2> : (const void *)&split_gemm_ws_kernel<false, 1>);
-    {
-        static std::atomic<unsigned> raised[4];   // bit per device, per kernel
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        const int idx = (relu ? 2 : 0) + (eight ? 1 : 0);
-        if (dev >= 32 || !(raised[idx].load() & (1u << dev))) {
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return TF_MSDA_ERR_LAUNCH;
-            if (dev < 32) raised[idx].fetch_or(1u << dev);
-        }
-    }
-    unsigned wbytes = (unsigned)((long long)N * K * 2);
-    void *argv[] = {(void *)&x, (void *)&wh, (void *)&wm, (void *)&bias, (void *)&y, (void *)&M, (void *)&N, (void *)&tpb, (void *)&wbytes};
-    return hipLaunchKernel(fn, dim3((unsigned)nblk, (unsigned)mblk), dim3(eight ? 512 : 256), argv, lds, s) == hipSuccess
-               ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
-}
-
-std::atomic<int> g_deep{-1};       // -1: TF_LINEAR_DEEP (default 1 since round 3): variant 7 for every call with <= 4096 rows
-std::atomic<int> g_bufstore{-1};   // -1: TF_LINEAR_BUFSTORE (default 1 since round 3)
-std::atomic<int> g_conv3_bufload{-1};   // -1: TF_CONV3_BUFLOAD (default 1): buffer loads in split_conv3_kernel
-std::atomic<int> g_variant{-1};   // -1: TF_LINEAR_VARIANT or the default
-
-int variant()
-{
-    int v = g_variant.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("TF_LINEAR_VARIANT");
-        v = e ? atoi(e) : -2;   // -2: pick per shape
-        g_variant.store(v);
-    }
-    return v;
-}
-
-template <int BM, int BN, bool PREFETCH>
-int launch_variant(const float *x, const unsigned short *wh, const unsigned short *wm, const float *bias, const float *res,
-                   float *y, int M, int K, int N, int relu, hipStream_t s)
-{
-    const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
-    if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
-    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL) {   // buffer-store epilogue (tensors < 3 GiB)
-        if (res) {
-            if (relu)
-                hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, true, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
-            else
-                hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, false, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
-        } else {
-            if (relu)
-                hipLaunchKernelGGL((split_gemm_kernel<BM, BN, true, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, M, K, N);
-            else
-                hipLaunchKernelGGL((split_gemm_kernel<BM, BN, false, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, M, K, N);
-        }
-        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
-    }
-    if (res) {
-        if (relu)
-            hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, true, PREFETCH>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
-        else
-            hipLaunchKernelGGL((split_gemm_res_kernel<BM, BN, false, PREFETCH>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, res, y, M, K, N);
-        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
-    }
-    if (relu)
-        hipLaunchKernelGGL((split_gemm_kernel<BM, BN, true, PREFETCH>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, M, K, N);
-    else
-        hipLaunchKernelGGL((split_gemm_kernel<BM, BN, false, PREFETCH>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, M, K, N);
+    if (fits_bufstore(M, N)) go(std::true_type{});
+    else go(std::false_type{});
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-template <int BM, int BN, bool PREFETCH>
-int launch_add(const float *x, const float *x2, const unsigned short *wh, const unsigned short *wm, const float *bias, float *y, int M,
-               int K, int N, hipStream_t s)
+template <int NP, int BM, int BN, bool PREFETCH>
+int launch_add(const float *x, const float *x2, const unsigned short *const (&w)[3], const float *bias, float *y, int M, int K, int N,
+               hipStream_t s)
 {
     const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
-    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL)
-        hipLaunchKernelGGL((split_gemm_add_kernel<BM, BN, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, x2, wh, wm, bias, y, M, K, N);
+    if (fits_bufstore(M, N))
+        hipLaunchKernelGGL((split_gemm_add_kernel<NP, BM, BN, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, x2, w[0], w[1], w[2], bias, y, M, K, N);
     else
-        hipLaunchKernelGGL((split_gemm_add_kernel<BM, BN, PREFETCH, false>), grid, dim3(THREADS), 0, s, x, x2, wh, wm, bias, y, M, K, N);
+        hipLaunchKernelGGL((split_gemm_add_kernel<NP, BM, BN, PREFETCH, false>), grid, dim3(THREADS), 0, s, x, x2, w[0], w[1], w[2], bias, y, M, K, N);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-}  // namespace
-
-namespace tfm {
-int linear_bufstore()
+// the weight pieces of a call: (w_hi, w_mid) -> three terms, (w_hi, w_mid, w_lo) -> six; 16-byte aligned
+inline int weight_pieces(const void *w_hi, const void *w_mid, const void *w_lo, const unsigned short *(&w)[3])
 {
-    int v = g_bufstore.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("TF_LINEAR_BUFSTORE");
-        v = (e && e[0] == '0') ? 0 : 1;
-        g_bufstore.store(v);
-    }
-    return v;
-}
-int linear_deep()
-{
-    int v = g_deep.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("TF_LINEAR_DEEP");
-        v = (e && e[0] == '0') ? 0 : 1;
-        g_deep.store(v);
-    }
-    return v;
-}
-int conv3_bufload()
-{
-    int v = g_conv3_bufload.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("TF_CONV3_BUFLOAD");
-        v = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1;
-        g_conv3_bufload.store(v);
-    }
-    return v;
-}
-int conv3_bufload_set(int v)
-{
-    const int prev = conv3_bufload();
-    g_conv3_bufload.store(v < 0 ? 0 : v > 2 ? 2 : v);
-    return prev;
-}
-int linear_deep_set(int v)
-{
-    const int prev = linear_deep();
-    g_deep.store(v ? 1 : 0);
-    return prev;
-}
-int linear_bufstore_set(int v)
-{
-    const int prev = linear_bufstore();
-    g_bufstore.store(v ? 1 : 0);
-    return prev;
-}
-int linear_set_variant(int v)
-{
-    const int prev = variant();
-    g_variant.store(v);
-    return prev;
-}
-}  // namespace tfm
-
-namespace {
-int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, const float *res, float *y,
-                      int64_t M, int K, int N, int relu, void *stream);
+    if (!w_hi || !w_mid) return 0;
+    if ((reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_mid) | reinterpret_cast<uintptr_t>(w_lo)) & 15) return -1;
+    w[0] = static_cast<const unsigned short *>(w_hi);
+    w[1] = static_cast<const unsigned short *>(w_mid);
+    w[2] = static_cast<const unsigned short *>(w_lo);
+    return w_lo ? 3 : 2;
 }
 
-extern "C" int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
-                                   int64_t M, int K, int N, int relu, void *stream)
+// Block shape per call shape (measured in profiles/r02_split_gemm_variants.txt, r03_optin_linear_bufstore.txt):
+//   <= 4096 rows (the decoder)      the ring-of-8-slices kernel (64 x 64) when K / 32 is one of its unrolled trip counts and there
+//                                   is no residual, else 64 x 64 with register prefetch
+//   K >= 512 and N <= 256           128 x 64, prefetch
+//   256 < N < 512                   64 x 128, no prefetch
+//   else                            64 x 128, prefetch
+template <int NP>
+int linear_split_np(const float *x, const unsigned short *const (&w)[3], const float *bias, const float *res, float *y, int M, int K,
+                    int N, int relu, hipStream_t s)
 {
-    return linear_split_impl(x, w_hi, w_mid, bias, nullptr, y, M, K, N, relu, stream);
-}
-
-extern "C" int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias,
-                                       const float *residual, float *y, int64_t M, int K, int N, int relu, void *stream)
-{
-    if (!residual) return TF_MSDA_ERR_NULL_POINTER;
-    return linear_split_impl(x, w_hi, w_mid, bias, residual, y, M, K, N, relu, stream);
-}
-
-namespace {
-int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, const float *res, float *y,
-                      int64_t M, int K, int N, int relu, void *stream)
-{
-    if (!x || !w_hi || !w_mid || !y) return TF_MSDA_ERR_NULL_POINTER;
-    if (M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_mid)) & 15)
-        return TF_MSDA_ERR_BAD_DIMS;
-    const unsigned short *wh = static_cast<const unsigned short *>(w_hi), *wm = static_cast<const unsigned short *>(w_mid);
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    // block shape / pipelining variants (TF_LINEAR_VARIANT / tf_msda_set_option("linear_variant", v)); measured in
-    // profiles/r02_split_gemm_variants.txt
-    int var = variant();
-    if (var < 0) {
-        // per-shape choice from profiles/r02_split_gemm_variants.txt (22 223 x {256 -> 256, 256 -> 384, 256 -> 1024,
-        // 1024 -> 256}, 400 x 256 -> 256): few rows want many small blocks, a long K a narrow N block
-        // (variant 6, the weight-stationary kernel, measured no faster than variant 2 / 3 at the encoder shapes:
-        //  22.6 vs 21.4 us at 256 -> 256, 73.0 vs 74.5 us at 256 -> 1024 -- selectable, not the default)
-        if (M <= 4096) var = tfm::linear_deep() ? 7 : 5;
-        else if (K >= 512 && N <= 256) var = 4;
-        else if (N > 256 && N < 512) var = 3;
-        else var = 2;
-    }
-    if (var == 7) {   // ring of 8 K-slices in registers (few rows); no residual epilogue, tensors below 3 GiB
-        if (!res && (long long)(M + 256) * N * 4 < 0xC0000000LL) {
+    if (M <= 4096) {
+        if (!res && fits_bufstore(M, N)) {
             const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
             if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
             const int slices = K / BK;
-#define TF_DEEP(SS)                                                                                                            \
-    if (slices == SS) {                                                                                                        \
-        if (relu)                                                                                                              \
-            hipLaunchKernelGGL((split_gemm_deep_kernel<true, SS>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, (int)M, K, N);  \
-        else                                                                                                                   \
-            hipLaunchKernelGGL((split_gemm_deep_kernel<false, SS>), grid, dim3(THREADS), 0, s, x, wh, wm, bias, y, (int)M, K, N); \
-        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;                                              \
+#define TF_DEEP(SS)                                                                                                                      \
+    if (slices == SS) {                                                                                                                  \
+        if (relu)                                                                                                                        \
+            hipLaunchKernelGGL((split_gemm_deep_kernel<NP, true, SS>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, y, M, K, N);  \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((split_gemm_deep_kernel<NP, false, SS>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, y, M, K, N); \
+        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;                                                        \
     }
             TF_DEEP(8) TF_DEEP(9) TF_DEEP(32) TF_DEEP(36)
 #undef TF_DEEP
         }
-        var = 5;   // other K, a residual, or a tensor of 3 GiB: the default few-rows variant
+        return launch_gemm<NP, 64, 64, true>(x, w, bias, res, y, M, K, N, relu, s);
     }
-    if (var == 6) {
-        const int rc = res ? 1 : launch_ws(x, wh, wm, bias, y, (int)M, K, N, relu, s);   // (no residual epilogue there)
-        if (rc != 1) return rc;
-        var = 2;
-    }
-    switch (var) {
-    case 0: return launch_variant<128, 128, false>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);   // round 1
-    case 1: return launch_variant<128, 128, true>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
-    case 3: return launch_variant<64, 128, false>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
-    case 4: return launch_variant<128, 64, true>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
-    case 5: return launch_variant<64, 64, true>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
-    default: return launch_variant<64, 128, true>(x, wh, wm, bias, res, y, (int)M, K, N, relu, s);
-    }
+    if (K >= 512 && N <= 256) return launch_gemm<NP, 128, 64, true>(x, w, bias, res, y, M, K, N, relu, s);
+    if (N > 256 && N < 512) return launch_gemm<NP, 64, 128, false>(x, w, bias, res, y, M, K, N, relu, s);
+    return launch_gemm<NP, 64, 128, true>(x, w, bias, res, y, M, K, N, relu, s);
 }
-}  // namespace
 
-extern "C" int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const float *bias,
-                                       float *y, int64_t M, int K, int N, void *stream)
+int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, const float *res,
+                      float *y, int64_t M, int K, int N, int relu, void *stream)
 {
-    if (!x || !x2 || !w_hi || !w_mid || !y) return TF_MSDA_ERR_NULL_POINTER;
-    if (M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(w_hi) |
-         reinterpret_cast<uintptr_t>(w_mid)) & 15)
+    if (!x || !y) return TF_MSDA_ERR_NULL_POINTER;
+    const unsigned short *w[3];
+    const int np = weight_pieces(w_hi, w_mid, w_lo, w);
+    if (np == 0) return TF_MSDA_ERR_NULL_POINTER;
+    if (np < 0 || M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL || (reinterpret_cast<uintptr_t>(x) & 15))
         return TF_MSDA_ERR_BAD_DIMS;
-    const unsigned short *wh = static_cast<const unsigned short *>(w_hi), *wm = static_cast<const unsigned short *>(w_mid);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // the block shapes tf_linear_split_f32 picks for these calls: few rows -> 64 x 64, else 64 x 128 (prefetch as there)
-    if (M <= 4096) return launch_add<64, 64, true>(x, x2, wh, wm, bias, y, (int)M, K, N, s);
-    if (N > 256 && N < 512) return launch_add<64, 128, false>(x, x2, wh, wm, bias, y, (int)M, K, N, s);
-    return launch_add<64, 128, true>(x, x2, wh, wm, bias, y, (int)M, K, N, s);
+    return np == 3 ? linear_split_np<3>(x, w, bias, res, y, (int)M, K, N, relu, s)
+                   : linear_split_np<2>(x, w, bias, res, y, (int)M, K, N, relu, s);
 }
 
-namespace {
-int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg, int hin, int win,
-                    int cin, int cout, int stride, int ks, int relu, void *stream, int ksplit = 1, float *workspace = nullptr);
-}
-
-extern "C" int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
-                                     float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
-                                     void *stream)
+template <int NP>
+int conv_launch_np(const float *x, const unsigned short *const (&w)[3], const float *bias, float *out, const Conv3Args &ca, long long M,
+                   unsigned gz, int relu, hipStream_t s)
 {
-    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && !workspace)) return ksplit > 1 && !workspace ? TF_MSDA_ERR_NULL_POINTER : TF_MSDA_ERR_BAD_DIMS;
-    return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream, ksplit, workspace);
+    auto launch = [&](auto kern, unsigned bn) {
+        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((ca.cout + bn - 1) / bn), gz);
+        hipLaunchKernelGGL(kern, grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, out, ca);
+    };
+    if (ca.cout >= 128) {   // output tile 64 x 128 for the wide layers
+        relu ? launch(split_conv3_kernel<NP, 64, 128, true>, 128) : launch(split_conv3_kernel<NP, 64, 128, false>, 128);
+    } else {
+        relu ? launch(split_conv3_kernel<NP, 64, 64, true>, 64) : launch(split_conv3_kernel<NP, 64, 64, false>, 64);
+    }
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-extern "C" int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
-                                     float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
-                                     void *stream)
+int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y, int nimg,
+                    int hin, int win, int cin, int cout, int stride, int ks, int relu, void *stream, int ksplit = 1,
+                    float *workspace = nullptr)
 {
-    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && !workspace)) return ksplit > 1 && !workspace ? TF_MSDA_ERR_NULL_POINTER : TF_MSDA_ERR_BAD_DIMS;
-    return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream, ksplit, workspace);
-}
-
-extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg,
-                                    int hin, int win, int cin, int cout, int stride, int relu, void *stream)
-{
-    return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream);
-}
-
-extern "C" int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y,
-                                            int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream)
-{
-    return conv_split_impl(x, w_hi, w_mid, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream);
-}
-
-namespace {
-int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const float *bias, float *y, int nimg, int hin, int win,
-                    int cin, int cout, int stride, int ks, int relu, void *stream, int ksplit, float *workspace)
-{
-    if (!x || !w_hi || !w_mid || !y) return TF_MSDA_ERR_NULL_POINTER;
-    if (nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % BK) != 0 || (stride != 1 && stride != 2))
-        return TF_MSDA_ERR_BAD_DIMS;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_mid)) & 15)
+    if (!x || !y) return TF_MSDA_ERR_NULL_POINTER;
+    const unsigned short *w[3];
+    const int np = weight_pieces(w_hi, w_mid, w_lo, w);
+    if (np == 0) return TF_MSDA_ERR_NULL_POINTER;
+    if (np < 0 || nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % BK) != 0 || (stride != 1 && stride != 2) ||
+        (reinterpret_cast<uintptr_t>(x) & 15))
         return TF_MSDA_ERR_BAD_DIMS;
     const int pad = ks == 3 ? 1 : 0;
     Conv3Args ca{nimg, hin, win, cin, (hin + 2 * pad - ks) / stride + 1, (win + 2 * pad - ks) / stride + 1, cout, stride, ks, pad, 0};
     const long long M = (long long)nimg * ca.hout * ca.wout;
-    if (M <= 0 || (M + 256) * cout * 4 >= 0xC0000000LL || (long long)nimg * hin * win * cin * 4 >= (1LL << 40)) return TF_MSDA_ERR_BAD_DIMS;
-    const unsigned short *wh = static_cast<const unsigned short *>(w_hi), *wm = static_cast<const unsigned short *>(w_mid);
+    // every byte offset of the input, the weight pieces and the output below the out-of-range marker of the buffer resources
+    if (M <= 0 || (M + 256) * cout * 4 >= 0xC0000000LL || (long long)nimg * hin * win * cin * 4 >= 0xC0000000LL ||
+        (long long)cout * ks * ks * cin * 2 >= 0xC0000000LL)
+        return TF_MSDA_ERR_BAD_DIMS;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // split-K: z-slices of the K loop write partial sums to the workspace [ksplit][M][cout], a second pass adds them in order
     const int slices = ks * ks * cin / BK;
@@ -1171,24 +754,8 @@ int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const f
         kbias = nullptr;
         krelu = 0;
     }
-    // buffer loads need every offset below the out-of-range marker (3 GiB); larger inputs keep the pointer loads
-    const bool bufld = tfm::conv3_bufload() && (long long)nimg * hin * win * cin * 4 < 0xC0000000LL
-                       && (long long)cout * ks * ks * cin * 2 < 0xC0000000LL;
-    auto launch = [&](auto kern, unsigned bn) {
-        const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((cout + bn - 1) / bn), gz);
-        hipLaunchKernelGGL(kern, grid, dim3(THREADS), 0, s, x, wh, wm, kbias, out, ca);
-    };
-    const bool pipe = bufld && tfm::conv3_bufload() == 2;   // experiment: operands read one k-step ahead (see the kernel)
-    if (cout >= 128) {   // output tile 64 x 128 for the wide layers
-        if (pipe) krelu ? launch(split_conv3_kernel<64, 128, true, true, true>, 128) : launch(split_conv3_kernel<64, 128, false, true, true>, 128);
-        else if (bufld) krelu ? launch(split_conv3_kernel<64, 128, true, true>, 128) : launch(split_conv3_kernel<64, 128, false, true>, 128);
-        else krelu ? launch(split_conv3_kernel<64, 128, true, false>, 128) : launch(split_conv3_kernel<64, 128, false, false>, 128);
-    } else {
-        if (pipe) krelu ? launch(split_conv3_kernel<64, 64, true, true, true>, 64) : launch(split_conv3_kernel<64, 64, false, true, true>, 64);
-        else if (bufld) krelu ? launch(split_conv3_kernel<64, 64, true, true>, 64) : launch(split_conv3_kernel<64, 64, false, true>, 64);
-        else krelu ? launch(split_conv3_kernel<64, 64, true, false>, 64) : launch(split_conv3_kernel<64, 64, false, false>, 64);
-    }
-    if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    const int rc = np == 3 ? conv_launch_np<3>(x, w, kbias, out, ca, M, gz, krelu, s) : conv_launch_np<2>(x, w, kbias, out, ca, M, gz, krelu, s);
+    if (rc != TF_MSDA_OK) return rc;
     if (ksplit > 1) {
         const long long mn4 = M * cout / 4;
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, s, workspace, bias, y, mn4,
@@ -1197,4 +764,67 @@ int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const f
     }
     return TF_MSDA_OK;
 }
+
 }  // namespace
+
+extern "C" int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
+                                   int64_t M, int K, int N, int relu, void *stream)
+{
+    return linear_split_impl(x, w_hi, w_mid, w_lo, bias, nullptr, y, M, K, N, relu, stream);
+}
+
+extern "C" int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias,
+                                       const float *residual, float *y, int64_t M, int K, int N, int relu, void *stream)
+{
+    if (!residual) return TF_MSDA_ERR_NULL_POINTER;
+    return linear_split_impl(x, w_hi, w_mid, w_lo, bias, residual, y, M, K, N, relu, stream);
+}
+
+extern "C" int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const void *w_lo,
+                                       const float *bias, float *y, int64_t M, int K, int N, void *stream)
+{
+    if (!x || !x2 || !y) return TF_MSDA_ERR_NULL_POINTER;
+    const unsigned short *w[3];
+    const int np = weight_pieces(w_hi, w_mid, w_lo, w);
+    if (np == 0) return TF_MSDA_ERR_NULL_POINTER;
+    if (np < 0 || M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL ||
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2)) & 15))
+        return TF_MSDA_ERR_BAD_DIMS;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto go = [&](auto npc) {
+        constexpr int NP = decltype(npc)::value;
+        // the block shapes tf_linear_split_f32 picks for these calls: few rows -> 64 x 64, else 64 x 128 (prefetch as there)
+        if (M <= 4096) return launch_add<NP, 64, 64, true>(x, x2, w, bias, y, (int)M, K, N, s);
+        if (N > 256 && N < 512) return launch_add<NP, 64, 128, false>(x, x2, w, bias, y, (int)M, K, N, s);
+        return launch_add<NP, 64, 128, true>(x, x2, w, bias, y, (int)M, K, N, s);
+    };
+    return np == 3 ? go(std::integral_constant<int, 3>{}) : go(std::integral_constant<int, 2>{});
+}
+
+extern "C" int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
+                                     float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+                                     void *stream)
+{
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && !workspace)) return ksplit > 1 && !workspace ? TF_MSDA_ERR_NULL_POINTER : TF_MSDA_ERR_BAD_DIMS;
+    return conv_split_impl(x, w_hi, w_mid, w_lo, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream, ksplit, workspace);
+}
+
+extern "C" int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
+                                     float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+                                     void *stream)
+{
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && !workspace)) return ksplit > 1 && !workspace ? TF_MSDA_ERR_NULL_POINTER : TF_MSDA_ERR_BAD_DIMS;
+    return conv_split_impl(x, w_hi, w_mid, w_lo, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream, ksplit, workspace);
+}
+
+extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
+                                    int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream)
+{
+    return conv_split_impl(x, w_hi, w_mid, w_lo, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream);
+}
+
+extern "C" int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias,
+                                            float *y, int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream)
+{
+    return conv_split_impl(x, w_hi, w_mid, w_lo, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream);
+}

@@ -1,7 +1,8 @@
 // trackformer_amd/csrc/linear_stream.hip
 //
 // tf_linear_packed_f32 / tf_linear_pack_weight_f32 (include/tf_fused.h): the same arithmetic as tf_linear_split_f32
-// (linear_split.hip: Y = X . W^T + bias as x_hi.w_hi + x_hi.w_mid + x_mid.w_hi on v_mfma_f32_32x32x16_bf16; reference
+// (linear_split.hip: Y = X . W^T + bias as a bf16 split product on v_mfma_f32_32x32x16_bf16, six terms by default, three
+// in the fast mode -- split_product.h; the description below counts for the three-term form; reference
 // modules: models/ops/modules/ms_deform_attn.py:64-88, models/deformable_transformer.py:282-297), restructured around
 // what profiles/r02_split_gemm_mfma_*.json showed: the first kernel keeps the matrix pipes 23 % busy because both
 // operands make an LDS round trip per 32-wide K-slice between two barriers and a wave only owns 1 x 2 MFMA tiles
@@ -35,23 +36,20 @@
 #include <type_traits>
 
 #include "msda_common.h"
+#include "split_product.h"
 #include "tf_fused.h"
 #include "tf_msda.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int kThreads = 256, kSlice = 32;   // K per slice (two MFMA k-steps of 16)
 constexpr int kStride = kSlice + 8;          // bf16 per LDS row: 80 bytes (16-byte aligned, 8 rows cover all banks)
 constexpr int kTJ = 2;                       // MFMA column tiles per wave -> 4 waves x 2 x 32 = 256 columns per block
 constexpr int kBN = 4 * kTJ * 32;
 
-// ---- weight packing: one thread per (n-tile, k-step, lane) writes its hi and its mid piece
+// ---- weight packing: one thread per (n-tile, k-step, lane) writes its NP pieces: piece p of (n-tile t, k-step q) at
+// ((t KQ + q) NP + p) 64 + lane
+template <int NP>
 __global__ void __launch_bounds__(256)
 pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, int K, int N, long long total)
 {
@@ -67,20 +65,24 @@ pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, int K, 
         a = *reinterpret_cast<const f32x4 *>(W + (size_t)n * K + k);
         b = *reinterpret_cast<const f32x4 *>(W + (size_t)n * K + k + 4);
     }
-    bf16x8 hi, mid;   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
+    bf16x4 pa[NP], pb[NP];   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
+    split4<NP>(a, pa);
+    split4<NP>(b, pb);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hi[e] = (__bf16)a[e];
-        mid[e] = (__bf16)(a[e] - (float)hi[e]);
-        hi[4 + e] = (__bf16)b[e];
-        mid[4 + e] = (__bf16)(b[e] - (float)hi[4 + e]);
+    for (int p = 0; p < NP; ++p) {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = pa[p][e];
+            v[4 + e] = pb[p][e];
+        }
+        out[(tq * NP + p) * 64 + lane] = __builtin_bit_cast(u32x4, v);
     }
-    out[(tq * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hi);
-    out[(tq * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, mid);
 }
 
+template <int NP>
 struct WFrags {
-    u32x4 v[kTJ][2][2];   // [column tile][k-step of the slice][hi | mid]
+    u32x4 v[kTJ][2][NP];   // [column tile][k-step of the slice][hi | mid | lo]
 };
 
 constexpr int stream_min_waves(int ti) { return ti <= 3 ? 2 : 1; }   // blocks per CU the register budget is cut for
@@ -89,14 +91,14 @@ constexpr int stream_min_waves(int ti) { return ti <= 3 ? 2 : 1; }   // blocks p
 // (no per-store branch / wait): 57.9 -> 44.1 us at 22 223 x 256 -> 1024, 52.1 -> 39.4 us at 1024 -> 256, bit-identical
 // (profiles/r03_optin_linear_bufstore.txt).  A variant with transposed accumulators and 16-byte stores measured slower on the
 // first shape (58.6 us) and was removed.
-template <int TI, bool RELU, bool BUFST = false>
+template <int NP, int TI, bool RELU, bool BUFST = false>
 __global__ void __launch_bounds__(kThreads, (stream_min_waves(TI)))
 split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias,
                          float *__restrict__ Y, int M, int K, int N, int mblocks, int nblocks)
 {
     constexpr int BM = TI * 32;
     constexpr int XV = TI;   // float4 of X per thread and slice: BM * 8 / 256
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][2][BM * kStride];   // [buffer][hi | mid][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][NP][BM * kStride];   // [buffer][hi | mid | lo][row][k]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
@@ -133,33 +135,29 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
     auto store_x = [&](const f32x4 (&src)[XV], int buf) {
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
-            bf16x4 hi, mid;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)src[it][e];
-                mid[e] = (__bf16)(src[it][e] - (float)hi[e]);
-            }
+            bf16x4 pc[NP];
+            split4<NP>(src[it], pc);
             const int o = (it * 32 + arow) * kStride + ac4 * 4;
-            *reinterpret_cast<bf16x4 *>(&sA[buf][0][o]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sA[buf][1][o]) = mid;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(&sA[buf][p][o]) = pc[p];
         }
     };
     // ---- weights: the wave's two column tiles, fragment order (see pack_weight_kernel)
     const u32x4 *wp[kTJ];
 #pragma unroll
-    for (int j = 0; j < kTJ; ++j) wp[j] = Wp + ((size_t)(nb * 4 * kTJ + wave * kTJ + j) * KQ * 2) * 64 + lane;
-    auto load_w = [&](int s, WFrags &w) {
+    for (int j = 0; j < kTJ; ++j) wp[j] = Wp + ((size_t)(nb * 4 * kTJ + wave * kTJ + j) * KQ * NP) * 64 + lane;
+    auto load_w = [&](int s, WFrags<NP> &w) {
         const int q0 = min(s, S - 1) * 2;
 #pragma unroll
         for (int j = 0; j < kTJ; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int p = 0; p < 2; ++p) w.v[j][kk][p] = wp[j][((q0 + kk) * 2 + p) * 64];
+                for (int p = 0; p < NP; ++p) w.v[j][kk][p] = wp[j][((q0 + kk) * NP + p) * 64];
     };
 
     f32x4 xr[2][XV];   // slice s + 1 lives in xr[(s + 1) & 1], slice s + 2 in the other one
-    WFrags w0, w1;
+    WFrags<NP> w0, w1;
     {
         f32x4 first[XV];
         load_x(0, first);
@@ -171,7 +169,7 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
     __syncthreads();
 
     // one K-slice; PAR = s & 1 as a compile-time constant so that the register double buffers need no copies
-    auto slice = [&](int s, auto par, const WFrags &cur, WFrags &nxt) {
+    auto slice = [&](int s, auto par, const WFrags<NP> &cur, WFrags<NP> &nxt) {
         constexpr int PAR = decltype(par)::value;
         load_w(s + 1, nxt);   // in flight during the MFMAs below
         __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them to the end of the
@@ -179,35 +177,20 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int koff = kk * 16 + (lane >> 5) * 8;
-            bf16x8 a_hi[TI], a_mid[TI], b_hi[kTJ], b_mid[kTJ];
+            bf16x8 af[TI][NP], bfr[kTJ][NP];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int o = (i * 32 + (lane & 31)) * kStride + koff;
-                a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sA[PAR][0][o]);
-                a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sA[PAR][1][o]);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const bf16x8 *>(&sA[PAR][p][o]);
             }
 #pragma unroll
-            for (int j = 0; j < kTJ; ++j) {
-                b_hi[j] = __builtin_bit_cast(bf16x8, cur.v[j][kk][0]);
-                b_mid[j] = __builtin_bit_cast(bf16x8, cur.v[j][kk][1]);
-            }
-            // three passes over the tiles: consecutive MFMAs never share an accumulator; per accumulator the order is
-            // mid.hi, hi.mid, hi.hi (smallest terms first), as in linear_split.hip
+            for (int j = 0; j < kTJ; ++j)
 #pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < kTJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid[i], b_hi[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < kTJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_mid[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < kTJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+                for (int p = 0; p < NP; ++p) bfr[j][p] = __builtin_bit_cast(bf16x8, cur.v[j][kk][p]);
+            // term-major passes over the tiles: consecutive MFMAs never share an accumulator; per accumulator the order is
+            // smallest terms first, as in linear_split.hip
+            mfma_tiles<NP, TI, kTJ>(acc, af, bfr);
         }
         // slice s + 1 -> the LDS buffer nobody reads in this iteration (its readers passed the previous barrier),
         // then its registers take slice s + 3
@@ -264,179 +247,6 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
     }
 }
 
-// ---- activation-stationary variant for K == 256 (the encoder's hidden size): the block's whole activation tile
-// (32 TI rows x 256 k, split into bf16 hi / mid: 528-byte rows, conflict-free for the fragment reads) is staged in LDS
-// ONCE -- all of its global loads are issued back to back at kernel start, the most memory-level parallelism a block
-// can have -- and then every column block of the output is computed from it: no barrier after the staging one, the
-// waves run free, the only streams are the weight fragments (L2 -> registers, one K-slice ahead, across column-block
-// boundaries) and the output stores, which overlap with the next column block's matrix work.  For N = 1024 the
-// activations are read and split once instead of four times.  One block per CU (101 KB of LDS at TI = 3), one round:
-// 232 blocks for 22 223 rows.
-constexpr int kAK = 256, kAStride = kAK + 8, kASlices = kAK / kSlice;
-
-template <int TI, bool RELU>
-__global__ void __launch_bounds__(kThreads, 1)
-split_gemm_astat_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias,
-                        float *__restrict__ Y, int M, int N, int nblocks, unsigned long long *trace)
-{
-    // debug (tf_msda_debug_trace_buffer): 16 timestamps (s_memrealtime, 100 MHz) of wave 0 per block
-    auto stamp = [&](int i) {
-        if (trace != nullptr && threadIdx.x == 0) trace[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memrealtime();
-    };
-    stamp(0);
-    constexpr int BM = TI * 32, KQ = kAK >> 4;
-    constexpr int NV = BM * (kAK / 4) / kThreads;   // float4 per thread: a wave covers one row (1 KB) per step
-    extern __shared__ __attribute__((aligned(16))) unsigned short s_a[];   // [hi | mid][BM][kAStride]
-    unsigned short *const sHi = s_a, *const sMid = s_a + BM * kAStride;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BM;
-
-    // ---- weights of the first slice first (they have the longest way), then the whole activation tile
-    auto wptr = [&](int nb, int j) { return Wp + ((size_t)(nb * 4 * kTJ + wave * kTJ + j) * KQ * 2) * 64 + lane; };
-    auto load_w = [&](int nb, int sl, WFrags &w) {
-#pragma unroll
-        for (int j = 0; j < kTJ; ++j) {
-            const u32x4 *base = wptr(nb, j) + (size_t)sl * 4 * 64;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) w.v[j][kk][p] = base[(kk * 2 + p) * 64];
-        }
-    };
-    // Weight fragments: a ring of 4 register sets, loaded 3 K-slices ahead of their use (across column-block boundaries).
-    // One slice of prefetch distance left the waves waiting on L2 for 2/3 of their time (profiles/r02_split_gemm_packed_pmc.txt:
-    // SQ_WAIT_ANY 65 % of SQ_WAVE_CYCLES, 24 M TCP_PENDING_STALL_CYCLES): with 4 waves per CU and 8 KB per wave in flight the
-    // L2 -> L1 stream is latency bound (Little's law), so keep 24 KB per wave in flight instead.
-    // The column blocks are visited in an order rotated by the block id, so that neighbouring CUs do not ask the same L2
-    // lines for the same weight slice at the same moment.
-    const int rot = blockIdx.x % nblocks;
-    auto nb_at = [&](int v) { int nb = v + rot; return nb >= nblocks ? nb - nblocks : nb; };   // v-th column block visited
-    WFrags w[4];
-    load_w(nb_at(0), 0, w[0]);
-    load_w(nb_at(0), 1, w[1]);
-    load_w(nb_at(0), 2, w[2]);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        f32x4 xr[NV];
-#pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            const int row = it * 4 + wave;
-            const int grow = min(m0 + row, M - 1);   // rows past M read the last row, never stored
-            xr[it] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * kAK + lane * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // all NV loads in flight before the first conversion waits
-        stamp(1);
-#pragma unroll
-        for (int it = 0; it < NV; ++it) {
-            const int row = it * 4 + wave;
-            bf16x4 hi, mid;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                hi[e] = (__bf16)xr[it][e];
-                mid[e] = (__bf16)(xr[it][e] - (float)hi[e]);
-            }
-            *reinterpret_cast<bf16x4 *>(&sHi[row * kAStride + lane * 4]) = hi;
-            *reinterpret_cast<bf16x4 *>(&sMid[row * kAStride + lane * 4]) = mid;
-        }
-    }
-    stamp(2);
-    __syncthreads();
-    stamp(3);
-
-    const int arow = (lane & 31) * kAStride + (lane >> 5) * 8;
-    for (int v = 0; v < nblocks; ++v) {
-        const int nb = nb_at(v);
-        const int ncol0 = nb * kBN + wave * kTJ * 32;
-        f32x16 acc[TI][kTJ];
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < kTJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        const int nb_next = nb_at(min(v + 1, nblocks - 1));   // after the last block: a harmless reload
-        auto slice = [&](auto slc) {
-            constexpr int sl = decltype(slc)::value;
-            constexpr int ahead = sl + 3;
-            if constexpr (ahead < kASlices) load_w(nb, ahead, w[ahead & 3]);
-            else load_w(nb_next, ahead - kASlices, w[ahead & 3]);
-            __builtin_amdgcn_sched_barrier(0);   // keep the loads at the head of the slice (see split_gemm_stream_kernel)
-            const WFrags &cur = w[sl & 3];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int koff = sl * kSlice + kk * 16;
-                bf16x8 a_hi[TI], a_mid[TI], b_hi[kTJ], b_mid[kTJ];
-#pragma unroll
-                for (int i = 0; i < TI; ++i) {
-                    a_hi[i] = *reinterpret_cast<const bf16x8 *>(&sHi[i * 32 * kAStride + arow + koff]);
-                    a_mid[i] = *reinterpret_cast<const bf16x8 *>(&sMid[i * 32 * kAStride + arow + koff]);
-                }
-#pragma unroll
-                for (int j = 0; j < kTJ; ++j) {
-                    b_hi[j] = __builtin_bit_cast(bf16x8, cur.v[j][kk][0]);
-                    b_mid[j] = __builtin_bit_cast(bf16x8, cur.v[j][kk][1]);
-                }
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < kTJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_mid[i], b_hi[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < kTJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_mid[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < kTJ; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
-            }
-        };
-        static_assert(kASlices == 8, "the slice loop is written out for K = 256");
-        slice(std::integral_constant<int, 0>{});
-        if (v == 0) stamp(4);
-        slice(std::integral_constant<int, 1>{});
-        if (v == 0) stamp(5);
-        slice(std::integral_constant<int, 2>{});
-        slice(std::integral_constant<int, 3>{});
-        if (v == 0) stamp(6);
-        slice(std::integral_constant<int, 4>{});
-        slice(std::integral_constant<int, 5>{});
-        slice(std::integral_constant<int, 6>{});
-        slice(std::integral_constant<int, 7>{});   // the ring now holds slices 0..2 of the next column block
-        if (v == 0) stamp(7);
-        if (v == 1) stamp(9);
-        if (v == 2) stamp(10);
-        if (v == 3) stamp(11);
-        if (ncol0 >= N) continue;   // a wave whose columns lie past N (N % 256 != 0) computed zeros: nothing to store
-#pragma unroll
-        for (int j = 0; j < kTJ; ++j) {
-            const int col = ncol0 + j * 32 + (lane & 31);
-            if (col >= N) continue;
-            const float b = bias ? bias[col] : 0.f;
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (row < M) {
-                        float v = acc[i][j][e] + b;
-                        if (RELU) v = v > 0.f ? v : 0.f;
-                        Y[(size_t)row * N + col] = v;
-                    }
-                }
-        }
-        if (v == 0) stamp(8);
-    }
-    stamp(12);
-    if (trace != nullptr) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the stores have been acknowledged
-        stamp(13);
-    }
-}
-
 int num_cus()
 {
     static const int n = [] {
@@ -451,20 +261,6 @@ int num_cus()
 }
 
 std::atomic<int> g_ti{-1};   // -1: TF_LINEAR_STREAM_TI or automatic (0)
-std::atomic<unsigned long long *> g_trace{nullptr};   // tf_msda_debug_trace_buffer
-std::atomic<int> g_astat{-1};   // -1: TF_LINEAR_ASTAT or the default (0: off, 2..4: on with that many row tiles)
-
-int astat_ti()
-{
-    int v = g_astat.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char *e = getenv("TF_LINEAR_ASTAT");
-        v = e ? atoi(e) : 0;
-        if (v < 2 || v > 4) v = 0;
-        g_astat.store(v);
-    }
-    return v;
-}
 
 int forced_ti()
 {
@@ -478,9 +274,9 @@ int forced_ti()
     return v;
 }
 
-// rows per block = 32 TI.  Measured at 22 223 rows (profiles/r02_split_gemm_packed.txt): two row tiles (three blocks per
-// CU resident) win at K = 256 -- 59.3 / 67.3 / 84.2 us for TI = 2 / 3 / 4 at N = 1024 -- where a block's eight K-slices are
-// too short a loop to hide its own memory latency and the co-resident blocks have to; three win at K = 1024
+// rows per block = 32 TI.  Measured at 22 223 rows with three terms (profiles/r02_split_gemm_packed.txt): two row tiles (three
+// blocks per CU resident) win at K = 256 -- 59.3 / 67.3 / 84.2 us for TI = 2 / 3 / 4 at N = 1024 -- where a block's eight K-slices
+// are too short a loop to hide its own memory latency and the co-resident blocks have to; three win at K = 1024
 // (55.6 / 50.5 / 58.0 us), where the loop is long enough and the weight traffic per MFMA counts.
 int choose_ti(int K)
 {
@@ -489,60 +285,33 @@ int choose_ti(int K)
     return K >= 512 ? 3 : 2;
 }
 
-template <int TI>
+template <int NP, int TI>
 int launch_stream(const float *x, const u32x4 *wp, const float *bias, float *y, int M, int K, int N, int relu, hipStream_t s)
 {
     const int mblocks = (M + 32 * TI - 1) / (32 * TI), nblocks = (N + kBN - 1) / kBN;
     const long long grid = (long long)((mblocks + 7) / 8) * 8 * nblocks;
     if (grid > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
-    if (tfm::linear_bufstore() && (long long)(M + 256) * N * 4 < 0xC0000000LL) {   // buffer-store epilogue (tensors < 3 GiB)
+    if ((long long)(M + 256) * N * 4 < 0xC0000000LL) {   // buffer-store epilogue (tensors < 3 GiB)
         if (relu)
-            hipLaunchKernelGGL((split_gemm_stream_kernel<TI, true, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
+            hipLaunchKernelGGL((split_gemm_stream_kernel<NP, TI, true, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
                                M, K, N, mblocks, nblocks);
         else
-            hipLaunchKernelGGL((split_gemm_stream_kernel<TI, false, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
+            hipLaunchKernelGGL((split_gemm_stream_kernel<NP, TI, false, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
                                M, K, N, mblocks, nblocks);
         return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
     }
     if (relu)
-        hipLaunchKernelGGL((split_gemm_stream_kernel<TI, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y, M, K,
+        hipLaunchKernelGGL((split_gemm_stream_kernel<NP, TI, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y, M, K,
                            N, mblocks, nblocks);
     else
-        hipLaunchKernelGGL((split_gemm_stream_kernel<TI, false>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y, M, K,
+        hipLaunchKernelGGL((split_gemm_stream_kernel<NP, TI, false>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y, M, K,
                            N, mblocks, nblocks);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
-}
-
-template <int TI>
-int launch_astat(const float *x, const u32x4 *wp, const float *bias, float *y, int M, int N, int relu, hipStream_t s)
-{
-    const int mblocks = (M + 32 * TI - 1) / (32 * TI), nblocks = (N + kBN - 1) / kBN;
-    const size_t lds = 2 * (size_t)(32 * TI) * kAStride * 2;
-    const void *fn = relu ? (const void *)&split_gemm_astat_kernel<TI, true> : (const void *)&split_gemm_astat_kernel<TI, false>;
-    if (lds > 64 * 1024) {
-        static std::atomic<unsigned> raised[2];   // bit per device, per kernel
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 32 || !(raised[relu ? 1 : 0].load() & (1u << dev))) {
-            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return TF_MSDA_ERR_LAUNCH;
-            if (dev < 32) raised[relu ? 1 : 0].fetch_or(1u << dev);
-        }
-    }
-    unsigned long long *trace = g_trace.load(std::memory_order_relaxed);
-    void *argv[] = {(void *)&x, (void *)&wp, (void *)&bias, (void *)&y, (void *)&M, (void *)&N, (void *)&nblocks, (void *)&trace};
-    return hipLaunchKernel(fn, dim3((unsigned)mblocks), dim3(kThreads), argv, lds, s) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
 }  // namespace
 
 namespace tfm {
-void linear_set_trace(unsigned long long *device_buffer) { g_trace.store(device_buffer); }
-int linear_astat_set(int v)
-{
-    const int prev = astat_ti();
-    g_astat.store(v >= 2 && v <= 4 ? v : 0);
-    return prev;
-}
 int linear_stream_set_ti(int v)
 {
     const int prev = forced_ti();
@@ -551,46 +320,49 @@ int linear_stream_set_ti(int v)
 }
 }  // namespace tfm
 
-extern "C" int64_t tf_linear_packed_bytes(int K, int N)
+extern "C" int64_t tf_linear_packed_bytes(int K, int N, int terms)
 {
-    if (K <= 0 || N <= 0 || (K % 16) != 0) return -1;
+    const int np = split_pieces(terms);
+    if (K <= 0 || N <= 0 || (K % 16) != 0 || np == 0) return -1;
     const int64_t npad = ((int64_t)N + kBN - 1) / kBN * kBN;
-    return npad * K * 4;   // hi + mid bf16 per element
+    return npad * K * 2 * np;   // np bf16 pieces per element
 }
 
-extern "C" int tf_linear_pack_weight_f32(const float *w, void *packed, int K, int N, void *stream)
+extern "C" int tf_linear_pack_weight_f32(const float *w, void *packed, int K, int N, int terms, void *stream)
 {
     if (!w || !packed) return TF_MSDA_ERR_NULL_POINTER;
-    if (K <= 0 || N <= 0 || (K % 16) != 0) return TF_MSDA_ERR_BAD_DIMS;
+    const int np = split_pieces(terms);
+    if (K <= 0 || N <= 0 || (K % 16) != 0 || np == 0) return TF_MSDA_ERR_BAD_DIMS;
     if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(packed)) & 15) return TF_MSDA_ERR_BAD_DIMS;
     const long long ntiles = ((long long)N + kBN - 1) / kBN * (kBN / 32);
     const long long total = ntiles * (K >> 4) * 64;
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                       static_cast<u32x4 *>(packed), K, N, total);
+    if (np == 3)
+        hipLaunchKernelGGL(pack_weight_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                           static_cast<u32x4 *>(packed), K, N, total);
+    else
+        hipLaunchKernelGGL(pack_weight_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                           static_cast<u32x4 *>(packed), K, N, total);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
 extern "C" int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias, float *y, int64_t M, int K, int N,
-                                    int relu, void *stream)
+                                    int relu, int terms, void *stream)
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
-    if (M <= 0 || K <= 0 || N <= 0 || (K % 64) != 0 || M > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
+    const int np = split_pieces(terms);
+    if (M <= 0 || K <= 0 || N <= 0 || (K % 64) != 0 || M > 0x7fffffffLL || np == 0) return TF_MSDA_ERR_BAD_DIMS;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed)) & 15) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *wp = static_cast<const u32x4 *>(w_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (K == kAK) {
-        switch (astat_ti()) {
-        case 2: return launch_astat<2>(x, wp, bias, y, (int)M, N, relu, s);
-        case 3: return launch_astat<3>(x, wp, bias, y, (int)M, N, relu, s);
-        case 4: return launch_astat<4>(x, wp, bias, y, (int)M, N, relu, s);
-        default: break;
+    auto go = [&](auto npc) {
+        constexpr int NP = decltype(npc)::value;
+        switch (choose_ti(K)) {
+        case 2: return launch_stream<NP, 2>(x, wp, bias, y, (int)M, K, N, relu, s);
+        case 4: return launch_stream<NP, 4>(x, wp, bias, y, (int)M, K, N, relu, s);
+        default: return launch_stream<NP, 3>(x, wp, bias, y, (int)M, K, N, relu, s);
         }
-    }
-    switch (choose_ti(K)) {
-    case 2: return launch_stream<2>(x, wp, bias, y, (int)M, K, N, relu, s);
-    case 4: return launch_stream<4>(x, wp, bias, y, (int)M, K, N, relu, s);
-    default: return launch_stream<3>(x, wp, bias, y, (int)M, K, N, relu, s);
-    }
+    };
+    return np == 3 ? go(std::integral_constant<int, 3>{}) : go(std::integral_constant<int, 2>{});
 }

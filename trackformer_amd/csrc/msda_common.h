@@ -45,26 +45,11 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
 int pquad_set_option(const char *name, int value);   // -1: unknown name, else the previous value
 void pquad_set_trace(unsigned long long *device_buffer);
 
-// linear_split.hip: block shape / pipelining variant of tf_linear_split_f32; returns the previous one
-int linear_set_variant(int v);
-// linear_split.hip: buffer-store epilogue of the split GEMMs (0 / 1, default 1); the setter returns the previous value
-int linear_bufstore();
-int linear_bufstore_set(int v);
-// linear_split.hip: deep-prefetch kernel (variant 7) for calls with few rows (0 / 1, default 1)
-int linear_deep();
-int linear_deep_set(int v);
-// linear_split.hip: buffer loads (out-of-image taps read zeros from beyond num_records) in the 3 x 3 / strided 1 x 1
-// split-product convolution (0 / 1, default 1)
-int conv3_bufload();
-int conv3_bufload_set(int v);
 // ffn_fused.hip: row tiles per block of tf_ffn_fused_f32 (1..3, default 3); returns the previous value
 int ffn_set_ti(int v);
 int linln_set_ti(int v);   // tf_linear_res_ln_f32 (1..3; 0 = by row count)
 // linear_stream.hip: row tiles per block of tf_linear_packed_f32 (2..4; 0 = per shape); returns the previous value
 int linear_stream_set_ti(int v);
-// linear_stream.hip: activation-stationary kernel for K == 256 (0 = off, 2..4 = row tiles per block); returns the previous value
-int linear_astat_set(int v);
-void linear_set_trace(unsigned long long *device_buffer);   // debug timestamps of the activation-stationary kernel
 
 }  // namespace tfm
 

@@ -2999,7 +2999,6 @@ void tf_msda_debug_trace_buffer(void *device_buffer)
 {
     g_quad_trace.store(static_cast<unsigned long long *>(device_buffer));
     pquad_set_trace(static_cast<unsigned long long *>(device_buffer));
-    linear_set_trace(static_cast<unsigned long long *>(device_buffer));
 }
 
 int tf_msda_set_option(const char *name, int value)
@@ -3015,14 +3014,9 @@ int tf_msda_set_option(const char *name, int value)
         }
     if (strcmp(name, "bwd_sorted2") == 0) return g_bwd_sorted2.exchange(value < 0 ? -1 : (value ? 1 : 0));
     if (strcmp(name, "direct9") == 0) return g_direct9.exchange(value < 0 ? -1 : (value ? 1 : 0));
-    if (strcmp(name, "linear_bufstore") == 0) return linear_bufstore_set(value);
-    if (strcmp(name, "linear_deep") == 0) return linear_deep_set(value);
-    if (strcmp(name, "conv3_bufload") == 0) return conv3_bufload_set(value);
     if (strcmp(name, "ffn_ti") == 0) return ffn_set_ti(value);
     if (strcmp(name, "linln_ti") == 0) return linln_set_ti(value);
-    if (strcmp(name, "linear_variant") == 0) return linear_set_variant(value);
     if (strcmp(name, "linear_stream_ti") == 0) return linear_stream_set_ti(value);
-    if (strcmp(name, "linear_astat") == 0) return linear_astat_set(value);
     if (strncmp(name, "pquad", 5) == 0) {
         const int prev = pquad_set_option(name, value);
         return prev == -1 ? INT_MIN : prev;

@@ -2,9 +2,9 @@
 //
 // tf_stem_conv7x7_f32 (include/tf_fused.h): the backbone's first convolution -- 7 x 7, stride 2, padding 3, 3 -> 64 channels
 // (reference: models/backbone.py:93-104 -> torchvision resnet50.conv1, with the FrozenBatchNorm2d scale of :45-55 folded into
-// the weight by the caller) -- as an implicit GEMM on the matrix cores with the same three-term bf16 split as the linears
-// (x_hi.w_hi + x_hi.w_mid + x_mid.w_hi, fp32 accumulation).  OPT-IN (TF_STEM_CONV_SPLIT=1): written against the emulator, not
-// yet run on hardware; with it and the bottleneck routes of linear_split.hip no convolution of the backbone is left in MIOpen.
+// the weight by the caller) -- as an implicit GEMM on the matrix cores with the same bf16 split product as the linears
+// (split_product.h: six terms by default, three in the fast mode; fp32 accumulation).  With it and the bottleneck routes of
+// linear_split.hip no convolution of the backbone is left in MIOpen.
 //
 //   * GEMM view: M = output pixels, N = 64, K = 3 x 7 x 8 = 168 (-> 176 = 11 k-steps of 16): k = (c * 7 + ky) * 8 + kx with the
 //     7 taps of a kernel row padded to 8 (zero weight), so that a lane's 8 consecutive k of an MFMA fragment are 8 consecutive
@@ -27,23 +27,20 @@
 #include <stdint.h>
 
 #include "msda_common.h"
+#include "split_product.h"
 #include "tf_fused.h"
 #include "tf_msda.h"
 
 namespace {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 constexpr int kCout = 64, kKQ = 11;                  // 176 / 16 k-steps
 constexpr int kTH = 4, kTW = 32, kTilesPerBlock = 4; // output rows per block (one per wave), columns per tile, tiles per block
 constexpr int kPR = 2 * kTH + 5, kPW = 72;           // patch rows (13), floats per patch row (70 used)
 constexpr int kPatch = 3 * kPR * kPW;                // 2808 floats
 
-template <bool RELU>
+template <int NP, bool RELU>
 __global__ void __launch_bounds__(256)
 stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, float *Y, int H, int W,
                     int Ho, int Wo)
@@ -55,14 +52,14 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
     const int oy0 = blockIdx.y * kTH, n = blockIdx.z;
     const float *xin = X + (size_t)n * 3 * H * W;
 
-    // ---- the whole weight: fragment (n-tile t, k-step q, part p) at ((t KQ + q) 2 + p) 64 + lane (linear_stream.hip)
-    u32x4 wf[2][kKQ][2];
+    // ---- the whole weight: fragment (n-tile t, k-step q, part p) at ((t KQ + q) NP + p) 64 + lane (linear_stream.hip)
+    u32x4 wf[2][kKQ][NP];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int q = 0; q < kKQ; ++q)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) wf[t][q][p] = Wp[((size_t)(t * kKQ + q) * 2 + p) * 64 + lane];
+            for (int p = 0; p < NP; ++p) wf[t][q][p] = Wp[((size_t)(t * kKQ + q) * NP + p) * 64 + lane];
 
     const unsigned ybytes = (unsigned)((size_t)gridDim.z * Ho * Wo * kCout * 4);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, ybytes, 0x00020000);
@@ -145,21 +142,22 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xv[e] = half ? 0.f : xv[e];
             }
-            bf16x8 x_hi, x_mid;
+            bf16x8 xp[NP];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                x_hi[e] = (__bf16)xv[e];
-                x_mid[e] = (__bf16)(xv[e] - (float)x_hi[e]);
+                float r = xv[e];
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    xp[p][e] = (__bf16)r;
+                    if (p + 1 < NP) r -= (float)xp[p][e];
+                }
             }
+            using T = SplitTerms<NP>;   // x piece T::A[t] x weight piece T::B[t], smallest terms first
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[t][q][0]), x_mid, acc[t], 0, 0, 0);
+            for (int tt = 0; tt < T::N; ++tt)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[t][q][1]), x_hi, acc[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[t][q][0]), x_hi, acc[t], 0, 0, 0);
+                for (int t = 0; t < 2; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[t][q][T::B[tt]]), xp[T::A[tt]], acc[t], 0, 0, 0);
         }
         // ---- epilogue: lane -> pixel (oy, ox0 + m); registers 4 g .. 4 g + 3 of tile t -> channels 32 t + 8 g + 4 half + 0..3
         const int ox = ox0 + m;
@@ -188,10 +186,11 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
 }  // namespace
 
 extern "C" int tf_stem_conv7x7_f32(const float *x, const void *w_packed, const float *bias, float *y, int N, int H, int W, int relu,
-                                   void *stream)
+                                   int terms, void *stream)
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
-    if (N <= 0 || H <= 0 || W <= 0 || N > 65535) return TF_MSDA_ERR_BAD_DIMS;
+    const int np = split_pieces(terms);
+    if (N <= 0 || H <= 0 || W <= 0 || N > 65535 || np == 0) return TF_MSDA_ERR_BAD_DIMS;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if ((long long)N * Ho * Wo * kCout * 4 >= 0xC0000000LL || (long long)N * 3 * H * W >= (1LL << 31)) return TF_MSDA_ERR_BAD_DIMS;
     if ((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15)
@@ -200,9 +199,12 @@ extern "C" int tf_stem_conv7x7_f32(const float *x, const void *w_packed, const f
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *wp = static_cast<const u32x4 *>(w_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (relu)
-        hipLaunchKernelGGL(stem_conv7x7_kernel<true>, grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
-    else
-        hipLaunchKernelGGL(stem_conv7x7_kernel<false>, grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
+    if (np == 3) {
+        if (relu) hipLaunchKernelGGL((stem_conv7x7_kernel<3, true>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
+        else hipLaunchKernelGGL((stem_conv7x7_kernel<3, false>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
+    } else {
+        if (relu) hipLaunchKernelGGL((stem_conv7x7_kernel<2, true>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
+        else hipLaunchKernelGGL((stem_conv7x7_kernel<2, false>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
+    }
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }

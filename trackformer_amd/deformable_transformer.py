@@ -217,6 +217,8 @@ class DeformableTransformer(nn.Module):
             if (query_embed.is_cuda and torch.cuda.is_current_stream_capturing()) or len(cache) >= _KEEP_CACHE_ENTRIES:
                 return value   # never keep a buffer of a graph's memory pool; a full cache recomputes, it never evicts
             hit = (value, query_param)
+            if value.is_cuda:
+                fused._publish_barrier(value.device)   # built on this stream, read by every lane's stream
             cache[key] = hit
         return hit[0]
 
@@ -229,6 +231,11 @@ class DeformableTransformer(nn.Module):
                               for lvl, p in enumerate(pos_embeds)], 1)
         if self.training or torch.is_grad_enabled():
             return compute()
+        # Only the position-encoding module's own CACHED tensors (all-valid masks: one tensor per geometry, position_encoding.py
+        # marks them) are worth keying on: a padded batch gets fresh tensors on every call, each of which would pin its
+        # [N, S, C] result and its inputs for ever without being hit again (~90 MB per entry at batch 2, 800 x 1333).
+        if not all(getattr(p, "_tf_cached_geometry", False) for p in pos_embeds):
+            return compute()
         key = tuple((id(p), p._version) for p in pos_embeds) + (self.level_embed._version, self.level_embed.data_ptr())
         cache = self.__dict__.setdefault("_lvl_pos_cache", {})
         hit = cache.get(key)
@@ -237,6 +244,8 @@ class DeformableTransformer(nn.Module):
                 return compute()   # never keep a buffer of a graph's memory pool; a full cache recomputes, it never evicts
             # the inputs are kept alive next to the result: an id() in the key can then not be reused by another tensor
             hit = (compute(), list(pos_embeds))
+            if pos_embeds[0].is_cuda:
+                fused._publish_barrier(pos_embeds[0].device)   # built on this stream, read by every lane's stream
             cache[key] = hit
         return hit[0]
 

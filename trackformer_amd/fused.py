@@ -97,6 +97,28 @@ def set_split_linear(on):
     return prev
 
 
+# How many bf16 terms a product is made of (include/tf_fused.h, THE SPLIT PRODUCT): 6 = operands cut into (hi, mid, lo), all
+# 24 significand bits, dropped terms below 2^-24 of the product -- the reference's fp32 arithmetic in another summation
+# order; the DEFAULT.  3 = (hi, mid) pieces, products good to 2^-16: the fast mode (TF_SPLIT_TERMS=3 / set_split_terms(3)).
+# Why six is the default: the 64-frame reference-Tracker fixture (tests/golden/full_tracker_cfg2_64.npz) keeps the reference's
+# track ids for 59 frames under fp32 library GEMMs but only 14 under three terms (profiles/r04_id_parity_64.txt) -- boxes and
+# logits are inside 1e-3 either way, NMS decisions with IoU margins of 1e-4 are not.
+_split_terms = 3 if os.environ.get("TF_SPLIT_TERMS", "6") == "3" else 6
+
+
+def split_terms():
+    return _split_terms
+
+
+def set_split_terms(n):
+    """3 or 6 terms per split product (process-wide; cached weight images are kept per setting); returns the previous value."""
+    global _split_terms
+    if n not in (3, 6):
+        raise ValueError("split terms: 3 or 6")
+    prev, _split_terms = _split_terms, n
+    return prev
+
+
 # The same product with the weight packed once in matrix-core fragment order (tf_linear_packed_f32,
 # csrc/linear_stream.hip): bit-identical results.  Used where it measured faster (profiles/r02_split_gemm_packed.txt):
 # many rows and a wide output or a long K -- the FFN linears of the encoder (22 223 x 256 -> 1024: 76.2 -> 59.3 us,
@@ -129,49 +151,57 @@ def _publish_barrier(device):
 
 
 def _packed_weight(weight, rows):
-    """Fragment-order (hi, mid) image of `weight` (or of its row block `rows`), built by tf_linear_pack_weight_f32 and
-    cached on the tensor object with its version counter, like _split_weight below."""
+    """Fragment-order image (the bf16 pieces of the current split_terms()) of `weight` (or of its row block `rows`), built by
+    tf_linear_pack_weight_f32 and cached on the tensor object with its version counter, like _split_weight below."""
     cache = getattr(weight, "_tf_packed", None)
     if cache is None or cache[0] != weight._version:
         cache = (weight._version, {})
         weight._tf_packed = cache
-    hit = cache[1].get(rows)
+    terms = _split_terms
+    hit = cache[1].get((rows, terms))
     if hit is None:
         if torch.cuda.is_current_stream_capturing():
             return None   # never build a cached buffer inside a graph's memory pool: this call takes the unpacked kernel
         N, K = weight.shape
         a, b = (0, N) if rows is None else rows
-        nbytes = _cabi.lib().tf_linear_packed_bytes(K, b - a)
+        nbytes = _cabi.lib().tf_linear_packed_bytes(K, b - a, terms)
         if nbytes <= 0:
             return None
         w = weight.detach()
         with torch.cuda.device(weight.device):
             hit = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-            rc = _cabi.lib().tf_linear_pack_weight_f32(w.data_ptr() + a * K * 4, hit.data_ptr(), K, b - a,
+            rc = _cabi.lib().tf_linear_pack_weight_f32(w.data_ptr() + a * K * 4, hit.data_ptr(), K, b - a, terms,
                                                        _stream(weight.device))
         _cabi.check(rc, "tf_linear_pack_weight_f32")
         _publish_barrier(weight.device)
-        cache[1][rows] = hit
+        cache[1][(rows, terms)] = hit
     return hit
 
 
 def _split_weight(weight):
-    """(w_hi, w_mid) bf16 pieces of an fp32 weight.  Cached ON THE TENSOR OBJECT together with its version counter
+    """(w_hi, w_mid, w_lo) bf16 pieces of an fp32 weight (round to nearest even at every step; w_lo is None when
+    split_terms() == 3).  Cached ON THE TENSOR OBJECT together with its version counter
     (weights are constants in inference; an in-place update bumps the version).  Not keyed by data_ptr: a freed
     parameter's address is handed to the next model's parameters by the caching allocator, and a pointer-keyed cache
     then serves another tensor's pieces (seen as a golden failure when two test models were built one after the
     other).  Callers pass persistent tensors (module parameters, _CatProjection's concatenation), and use `rows=` of
     linear() for a row block instead of a temporary slice."""
     hit = getattr(weight, "_tf_split", None)
-    if hit is None or hit[0] != weight._version:
+    if hit is None or hit[0] != weight._version or (hit[3] is None and _split_terms == 6):
         w = weight.detach()
         hi = w.to(torch.bfloat16)
-        mid = (w - hi.float()).to(torch.bfloat16)
-        hit = (weight._version, hi.contiguous(), mid.contiguous())
+        r = w - hi.float()                      # exact in fp32
+        mid = r.to(torch.bfloat16)
+        lo = (r - mid.float()).to(torch.bfloat16).contiguous() if _split_terms == 6 else None
+        hit = (weight._version, hi.contiguous(), mid.contiguous(), lo)
         if w.is_cuda:
             _publish_barrier(w.device)
         weight._tf_split = hit
-    return hit[1], hit[2]
+    return hit[1], hit[2], (hit[3] if _split_terms == 6 else None)
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
 
 
 def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
@@ -206,22 +236,22 @@ def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
                 y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
                 rc = _cabi.lib().tf_linear_packed_f32(x2.data_ptr(), packed.data_ptr(),
                                                       0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0],
-                                                      K, N, 1 if relu else 0, _stream(x.device))
+                                                      K, N, 1 if relu else 0, _split_terms, _stream(x.device))
             _cabi.check(rc, "tf_linear_packed_f32")
             return y.view(*x.shape[:-1], N)
-    hi, mid = _split_weight(weight)
-    if rows is not None:
-        hi, mid = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]]   # views: a row block is contiguous
-    if (x2.data_ptr() | hi.data_ptr() | mid.data_ptr()) & 15:
+    hi, mid, lo = _split_weight(weight)
+    if rows is not None:   # views: a row block is contiguous
+        hi, mid, lo = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]], (None if lo is None else lo[rows[0]:rows[1]])
+    if (x2.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
         return None
     with torch.cuda.device(x.device):
         y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
         if residual is None:
-            rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(),
+            rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo),
                                                  0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0], K, N,
                                                  1 if relu else 0, _stream(x.device))
         else:
-            rc = _cabi.lib().tf_linear_split_res_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(),
+            rc = _cabi.lib().tf_linear_split_res_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo),
                                                      0 if bias is None else bias.data_ptr(), residual.data_ptr(),
                                                      y.data_ptr(), x2.shape[0], K, N, 1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_linear_split_f32")
@@ -289,7 +319,7 @@ def ffn(x, linear1, linear2, norm=None, residual=None):
         rc = _cabi.lib().tf_ffn_fused_f32(x2.data_ptr(), p1.data_ptr(), ptr(linear1.bias), p2.data_ptr(), ptr(linear2.bias),
                                           ptr(residual), 0 if norm is None else norm.weight.data_ptr(),
                                           0 if norm is None else norm.bias.data_ptr(), 0.0 if norm is None else float(norm.eps),
-                                          y.data_ptr(), M, D, F_, _stream(x.device))
+                                          y.data_ptr(), M, D, F_, _split_terms, _stream(x.device))
     _cabi.check(rc, "tf_ffn_fused_f32")
     return y.view(x.shape)
 
@@ -346,7 +376,7 @@ def linear_residual_norm(x, linear, residual, norm):
         y = torch.empty((M, D), dtype=torch.float32, device=x.device)
         rc = _cabi.lib().tf_linear_res_ln_f32(x2.data_ptr(), packed.data_ptr(), 0 if linear.bias is None else linear.bias.data_ptr(),
                                               residual.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
-                                              y.data_ptr(), M, D, D, _stream(x.device))
+                                              y.data_ptr(), M, D, D, _split_terms, _stream(x.device))
     _cabi.check(rc, "tf_linear_res_ln_f32")
     return y.view(x.shape)
 
@@ -385,19 +415,20 @@ def set_stem_conv_split(on):
 def _stem_packed(weight):
     """Packed [64, 176] image (k = (c * 7 + ky) * 8 + kx, zero padded) of a [64, 3, 7, 7] weight, cached on the tensor."""
     hit = getattr(weight, "_tf_stem_packed", None)
-    if hit is None or hit[0] != weight._version:
+    terms = _split_terms
+    if hit is None or hit[0] != (weight._version, terms):
         if torch.cuda.is_current_stream_capturing():
             return None
         w = weight.detach()
         w2 = torch.zeros((64, 176), dtype=torch.float32, device=w.device)
         w2[:, :168] = F.pad(w, (0, 1)).reshape(64, 168)
-        nbytes = _cabi.lib().tf_linear_packed_bytes(176, 64)
+        nbytes = _cabi.lib().tf_linear_packed_bytes(176, 64, terms)
         with torch.cuda.device(w.device):
             packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
-            rc = _cabi.lib().tf_linear_pack_weight_f32(w2.data_ptr(), packed.data_ptr(), 176, 64, _stream(w.device))
+            rc = _cabi.lib().tf_linear_pack_weight_f32(w2.data_ptr(), packed.data_ptr(), 176, 64, terms, _stream(w.device))
         _cabi.check(rc, "tf_linear_pack_weight_f32")
         _publish_barrier(w.device)
-        hit = (weight._version, packed)
+        hit = ((weight._version, terms), packed)
         weight._tf_stem_packed = hit
     return hit[1]
 
@@ -422,7 +453,7 @@ def stem_conv(x, weight, bias=None, relu=False):
     with torch.cuda.device(x.device):
         y = torch.empty((n, 64, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         rc = _cabi.lib().tf_stem_conv7x7_f32(x.data_ptr(), packed.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(),
-                                             n, h, w, 1 if relu else 0, _stream(x.device))
+                                             n, h, w, 1 if relu else 0, _split_terms, _stream(x.device))
     _cabi.check(rc, "tf_stem_conv7x7_f32")
     return y
 
@@ -505,14 +536,14 @@ def linear_add(x, x2, weight, bias=None, rows=None):
     a, b = x.reshape(-1, K), x2.reshape(-1, K)
     a = a if a.is_contiguous() else a.contiguous()
     b = b if b.is_contiguous() else b.contiguous()
-    hi, mid = _split_weight(weight)
+    hi, mid, lo = _split_weight(weight)
     if rows is not None:
-        hi, mid = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]]
-    if (a.data_ptr() | b.data_ptr() | hi.data_ptr() | mid.data_ptr()) & 15:
+        hi, mid, lo = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]], (None if lo is None else lo[rows[0]:rows[1]])
+    if (a.data_ptr() | b.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
         return None
     with torch.cuda.device(x.device):
         y = torch.empty((a.shape[0], N), dtype=torch.float32, device=x.device)
-        rc = _cabi.lib().tf_linear_split_add_f32(a.data_ptr(), b.data_ptr(), hi.data_ptr(), mid.data_ptr(),
+        rc = _cabi.lib().tf_linear_split_add_f32(a.data_ptr(), b.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo),
                                                  0 if bias is None else bias.data_ptr(), y.data_ptr(), a.shape[0], K, N,
                                                  _stream(x.device))
     _cabi.check(rc, "tf_linear_split_add_f32")
@@ -537,8 +568,8 @@ def conv3x3(x, w_taps, bias, relu, stride):
     if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
                                  and bias.device == x.device):
         return None
-    hi, mid = _split_weight(w_taps)
-    if (x.data_ptr() | hi.data_ptr() | mid.data_ptr()) & 15:
+    hi, mid, lo = _split_weight(w_taps)
+    if (x.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
         return None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
@@ -550,11 +581,11 @@ def conv3x3(x, w_taps, bias, relu, stride):
         if ksplit > 1:   # few output pixels under a long K: split the K loop over workgroups (deterministic second pass)
             ws = torch.empty((ksplit, n * ho * wo * cout), dtype=torch.float32, device=x.device)
             fn = _cabi.lib().tf_conv3x3_splitk_f32 if ks == 3 else _cabi.lib().tf_conv1x1_splitk_f32
-            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), ws.data_ptr(),
-                    ksplit, n, h, w, cin, cout, stride, 1 if relu else 0, _stream(x.device))
+            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), 0 if bias is None else bias.data_ptr(), y.data_ptr(),
+                    ws.data_ptr(), ksplit, n, h, w, cin, cout, stride, 1 if relu else 0, _stream(x.device))
         else:
             fn = _cabi.lib().tf_conv3x3_split_f32 if ks == 3 else _cabi.lib().tf_conv1x1_strided_split_f32
-            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(), n, h, w,
+            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), 0 if bias is None else bias.data_ptr(), y.data_ptr(), n, h, w,
                     cin, cout, stride, 1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_conv3x3_split_f32")
     return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
@@ -676,6 +707,8 @@ def input_proj_1x1(x, conv, gn):
     hit = getattr(conv, "_tf_w2d", None)   # persistent [Cout, Cin] view: the split pieces are cached on it
     if hit is None or hit[0] != conv.weight._version or hit[1].device != conv.weight.device:
         hit = (conv.weight._version, conv.weight.detach().reshape(cout, cin).contiguous())
+        if hit[1].is_cuda and hit[1].data_ptr() != conv.weight.data_ptr():   # a copy made on this stream: publish for the others
+            _publish_barrier(hit[1].device)
         conv._tf_w2d = hit
     y2 = None
     if conv1x1_wants_split_k(n * h * w, cin, cout):   # the coarse levels: 1050 / 4200 pixels under K = 2048 / 1024

@@ -54,6 +54,7 @@ class PositionEmbeddingSine(nn.Module):
             pos = self._cache.get(key)
             if pos is None:
                 pos = self._cache[key] = self._compute(mask)
+                pos._tf_cached_geometry = True   # one tensor per geometry: what downstream per-geometry caches may key on
             return pos
         return self._compute(mask)
 
@@ -95,6 +96,7 @@ class PositionEmbeddingSine3D(nn.Module):
             pos = self._cache.get(key)
             if pos is None:
                 pos = self._cache[key] = self._compute(mask)
+                pos._tf_cached_geometry = True   # one tensor per geometry: what downstream per-geometry caches may key on
             return pos
         return self._compute(mask)
 

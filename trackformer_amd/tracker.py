@@ -340,9 +340,14 @@ class Tracker:
             if host is None or host.shape[0] < packed_dev.shape[0]:
                 host = self.__dict__["_packed_host"] = torch.empty((max(1024, 2 * packed_dev.shape[0]), 6), dtype=torch.float32,
                                                                    pin_memory=True)
-            host[:packed_dev.shape[0]].copy_(packed_dev, non_blocking=True)
-            event = torch.cuda.Event()
-            event.record()
+            # the copy and its event go on the stream of packed_dev's device that the detector just ran on -- NOT on "the
+            # current device's current stream": with the model on cuda:1 and no torch.cuda.set_device, a bare
+            # event.record() lands on an idle stream of cuda:0, synchronize() returns at once and step_finish reads the
+            # pinned buffer before the copy has landed
+            with torch.cuda.device(packed_dev.device):
+                host[:packed_dev.shape[0]].copy_(packed_dev, non_blocking=True)
+                event = torch.cuda.Event()
+                event.record(torch.cuda.current_stream(packed_dev.device))
         return dict(blob=blob, outputs=outputs, features=features, hs_embeds=hs_embeds, results=results, result=result,
                     orig_size=orig_size, orig_hw=(orig_h, orig_w), num_prev_track=num_prev_track, device=device,
                     packed_dev=packed_dev, host=host, event=event)
