@@ -490,13 +490,20 @@ class Tracker:
             self._resolve_masks(outputs, results, orig_size, blob["size"].to(device))
         masks_host = None
         if 'masks' in result and self.tracks:
+            # tracker.py:521-532 of the reference: a pixel belongs to the track with the largest probability there, if that
+            # probability exceeds 0.5 -- `logical_and(probs > 0.5, index_map == probs.argmax(0))`.  Ownership is exclusive, so
+            # ONE label map (owning track or -1 per pixel) holds every track's mask: 2 bytes per pixel reach the host instead
+            # of one byte per pixel AND track (3.9 MB instead of ~290 MB per 1080 x 1800 frame with 150 tracks; cfg 5 went
+            # from 40 to ... ms per step, profiles/r04_bench_cfg5.json); the per-track boolean masks of the results are
+            # rebuilt from it when somebody reads them (`results`), bit-identical.
             probs = torch.stack([t.mask for t in self.tracks])
-            index_map = torch.arange(probs.size(0), device=probs.device)[:, None, None]
-            track_masks = torch.logical_and(probs > 0.5,
-                                            index_map.expand_as(probs) == probs.argmax(dim=0))
+            best, owner = probs.max(dim=0)            # ties: the first track, as argmax
+            label = torch.where(best > 0.5, owner, torch.full_like(owner, -1)).to(torch.int16)
+            index_map = torch.arange(probs.size(0), device=probs.device, dtype=torch.int16)[:, None, None]
+            track_masks = label[None] == index_map    # device-side per-track views (Track.mask keeps the reference's meaning)
             for i, track in enumerate(self.tracks):
                 track.mask = track_masks[i]
-            masks_host = track_masks.cpu().numpy()   # ONE copy for all tracks (the results hold a full-size mask per track)
+            masks_host = _LabelMap(label.cpu().numpy())
 
         if self.tracks:   # one stack + one numpy view for all tracks instead of three conversions per track
             if cur is None or cur[0].shape[0] != len(self.tracks):
@@ -518,7 +525,7 @@ class Tracker:
             # frame at 150 live tracks, off the per-frame path now)
             extras = None
             if any(t.mask is not None or t.attention_map is not None for t in self.tracks):
-                extras = [(masks_host[i] if (masks_host is not None and t.mask is not None) else
+                extras = [(masks_host.of(i) if (masks_host is not None and t.mask is not None) else
                            (t.mask.cpu().numpy() if t.mask is not None else None),
                            t.attention_map.cpu().numpy() if t.attention_map is not None else None)
                           for i, t in enumerate(self.tracks)]
@@ -585,7 +592,7 @@ class Tracker:
                 if extras is not None:
                     mask, amap = extras[i]
                     if mask is not None:
-                        entry['mask'] = mask
+                        entry['mask'] = mask.materialise() if isinstance(mask, _LabelMask) else mask
                     if amap is not None:
                         entry['attention_map'] = amap
         return self._results
@@ -598,6 +605,28 @@ class Tracker:
     def get_results(self):
         """{track_id: {frame_idx: {'bbox': xyxy px, 'score', 'obj_ind', ['mask'], ['attention_map']}}}"""
         return self.results
+
+
+class _LabelMap:
+    """One frame's mask ownership on the host: label[y, x] = index (into that frame's track list) of the track that owns the
+    pixel, -1 for none.  `of(i)` is a handle that turns into track i's boolean mask when the results are read."""
+    __slots__ = ("label",)
+
+    def __init__(self, label):
+        self.label = label
+
+    def of(self, i):
+        return _LabelMask(self, i)
+
+
+class _LabelMask:
+    __slots__ = ("map", "index")
+
+    def __init__(self, label_map, index):
+        self.map, self.index = label_map, index
+
+    def materialise(self):
+        return self.map.label == self.index     # bool [H, W], what `track_masks[i].cpu().numpy()` of the reference holds
 
 
 class _MaskRef:
