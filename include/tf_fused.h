@@ -160,13 +160,34 @@ int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, c
  * only the activations pass through LDS.  Results are bit-identical to tf_linear_split_f32 with the same number of terms.
  *   tf_linear_packed_bytes(K, N, terms)          size of the packed buffer (N padded to a multiple of 256), or -1; K % 16 == 0
  *   tf_linear_pack_weight_f32(w, packed, ...)    w [N, K] fp32 row-major -> packed (16-byte aligned pointers); one small kernel
- *   tf_linear_packed_f32                         y[M, N] = x[M, K] . w^T + bias, ReLU if relu != 0; K % 64 == 0, 16-byte aligned x
+ *   tf_linear_packed_f32                         y[M, N] = act(x[M, K] . w^T + bias + residual); K % 64 == 0, 16-byte aligned x;
+ *                                                bias / residual [M, N] may be NULL, residual may alias y; y below 3 GiB
  * terms: 3 or 6 (see THE SPLIT PRODUCT above); a weight packed for 6 terms holds three pieces per fragment.
+ * The residual form is the closing 1 x 1 convolution of a ResNet bottleneck (conv3 -> FrozenBatchNorm2d -> `out += identity` ->
+ * ReLU; reference: models/backbone.py:45-55 + torchvision's Bottleneck.forward) on channels_last activations.
  */
 int64_t tf_linear_packed_bytes(int K, int N, int terms);
 int tf_linear_pack_weight_f32(const float *w, void *packed, int K, int N, int terms, void *stream);
-int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias, float *y, int64_t M, int K, int N,
-                         int relu, int terms, void *stream);
+int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias, const float *residual, float *y, int64_t M, int K,
+                         int N, int relu, int terms, void *stream);
+
+/*
+ * Convolution of a channels_last activation through the same kernel (an implicit GEMM over the output pixels; the weight
+ * fragments streamed from L2, only the shifted input pixels pass LDS): ks = 3 (padding 1) or 1 (no padding), stride 1 or 2.
+ *   x [nimg, hin, win, cin] NHWC fp32, below 3 GiB;  y [nimg, hout, wout, cout] NHWC, below 3 GiB;  cin % 64 == 0
+ *   w_packed   tf_linear_pack_weight_f32(K = ks * ks * cin, N = cout, terms) of the [cout, ks, ks, cin] weight (the storage of a
+ *              channels_last OIHW tensor: K is tap-major) -- a following FrozenBatchNorm2d's scale folded in by the caller
+ *   bias [cout] / residual [nimg, hout, wout, cout]: may be NULL
+ *   ksplit     1..64 pieces of the K loop run as separate workgroups (few output pixels under a long K: layer3 / layer4, the
+ *              extra pyramid level of deformable_detr.py:55-79); the pieces write partial sums to `workspace` (ksplit * M * cout
+ *              floats), a second launch adds them in a fixed order (deterministic) and applies bias / residual / ReLU.
+ *              ksplit > 1: cout % 4 == 0, 16-byte aligned y / bias / residual / workspace.
+ * Same products in the same order as tf_conv3x3_split_f32 / tf_conv1x1_strided_split_f32: bit-identical for ksplit == 1.
+ * (reference: torchvision Bottleneck.conv1 / conv2 / downsample under models/backbone.py:93-104)
+ */
+int tf_conv_packed_f32(const float *x, const void *w_packed, const float *bias, const float *residual, float *y, float *workspace,
+                       int ksplit, int nimg, int hin, int win, int cin, int cout, int ks, int stride, int relu, int terms,
+                       void *stream);
 
 /*
  * The feed-forward block of a transformer layer in one launch (trackformer_amd/csrc/ffn_fused.hip):

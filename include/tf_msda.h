@@ -27,7 +27,11 @@
  *       attn         [N, Lq, M, L, P]
  *       out/grad_out [N, Lq, M*D]
  *   - Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the default stream) and the
- *     call returns without synchronising.  Re-entrant; no global state.  HIP-graph capturable.
+ *     call returns without synchronising.  HIP-graph capturable.  Re-entrant: a call's RESULT depends on its arguments
+ *     only.  What IS process-wide: (a) the kernel-selection knobs below (tf_msda_set_tiled / tf_msda_set_option and the
+ *     environment variables they mirror) -- performance only, results identical up to fp32 summation order; they exist
+ *     for A/B measurements, a deployment leaves them alone; (b) the per-thread last-HIP-error slot; (c) per-(function,
+ *     device) one-time attribute calls (dynamic LDS above 64 KB).
  *   - Return value: TF_MSDA_OK (0) or a negative tf_msda_status.  Never throws.
  *   - im2col_step of the reference API only chunks the batch (cu:44-66) and does not change results;
  *     this ABI has no such parameter.
@@ -64,9 +68,9 @@ int tf_msda_last_hip_error(void);
 
 /*
  * Kernel selection knob (process-wide, performance only -- results are identical up to fp32 summation
- * order) for encoder-shaped forward calls (Lq == S, fp32, D == 32, P == 4, L <= 4, host shapes):
- * 2 = msda_fwd_f32_quad (LDS windows, 4 lanes per pair; the default), 1 = msda_fwd_f32_win (LDS windows,
- * 8 lanes per pair), 0 = msda_fwd_f32_direct (row gathers by buffer loads, what every other shape uses),
+ * order) for encoder-shaped forward calls (Lq == S, fp32, D == 32 or 36, P == 4, L <= 4, host shapes):
+ * 2 = the LDS-window kernels (msda_fwd_f32_pquad: persistent workgroups, 4 lanes per pair; msda_fwd_f32_quad where it
+ * declines; the default), 0 = msda_fwd_f32_direct (row gathers by buffer loads, what every other shape uses),
  * -1 restores the default (environment variable TF_MSDA_TILED, 2 when unset).  Returns the previous setting.
  */
 int tf_msda_set_tiled(int mode);
@@ -74,14 +78,20 @@ int tf_msda_set_tiled(int mode);
 /*
  * Generic form of the knob above (process-wide, performance only).  Sets option `name` to `value` and
  * returns the previous value, or INT_MIN for an unknown name.  Names:
- *   "tiled"         0 / 1 / 2 / -1 as tf_msda_set_tiled (2 = the 4-lanes-per-pair LDS-window kernel
- *                   msda_fwd_f32_quad, same eligibility as mode 1)
+ *   "tiled"         0 / 2 / -1 as tf_msda_set_tiled
+ *   "pquad"         1 / 0: the persistent encoder kernel on / off (off: msda_fwd_f32_quad)
+ *   "pquad_npass" "pquad_lds_kb" "pquad_wg_per_cu" "pquad_wide" "pquad_prefetch" "pquad_skew" "pquad_halo_y"
+ *   "pquad_halo_x" "pquad_tile_h" "pquad_tile_w"    its tile plan (TF_MSDA_PQUAD="npass=2,lds=52,wgs=3,...")
  *   "quad_ta_mask"  bit l set: level l is gathered by buffer loads instead of an LDS window (0, 8 or 12)
- *   "quad_waves"    wavefronts per workgroup (4 or 8);  "quad_npass"  passes of 16 pairs per wave (1 or 2)
+ *   "quad_waves"    wavefronts per workgroup (4 or 8);  "quad_npass"  passes of 16 pairs per wave (1..3)
  *   "quad_lds_kb"   LDS per workgroup (decides the workgroups per CU and the window capacity)
  *   "quad_halo_y" / "quad_halo_x"   clamp of the data-adaptive windows around the tile footprint
- *   "quad_tile_h" / "quad_tile_w"   tile size in level-0 pixels (0 = search)
- * Environment: TF_MSDA_TILED=2, TF_MSDA_QUAD="ta=12,waves=8,npass=1,lds=53,hy=6,hx=10,th=0,tw=0".
+ *   "quad_tile_h" / "quad_tile_w"   tile size in level-0 pixels (0 = search);  "quad_split"  staging rounds
+ *   "direct9"       1 / 0: msda_fwd_f32_direct9 for D == 36 decoder calls (off: msda_fwd_f32_buf)
+ *   "ffn_ti" "linln_ti" "linear_stream_ti"   row tiles per block of tf_ffn_fused_f32 / tf_linear_res_ln_f32 /
+ *                   tf_linear_packed_f32 (include/tf_fused.h; 0 = per shape)
+ * Knobs of experiments that were measured and removed (linear_variant, linear_bufstore, linear_deep, linear_astat,
+ * conv3_bufload, bwd_sorted2, tiled = 1) are unknown names now.
  */
 int tf_msda_set_option(const char *name, int value);
 

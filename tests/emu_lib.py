@@ -78,7 +78,9 @@ def lib():
     L.tf_linear_pack_weight_f32.restype = ci
     L.tf_linear_pack_weight_f32.argtypes = [vp, vp, ci, ci, ci, vp]
     L.tf_linear_packed_f32.restype = ci
-    L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, ci, vp]
+    L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, ci, vp]
+    L.tf_conv_packed_f32.restype = ci
+    L.tf_conv_packed_f32.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 10 + [vp]
     L.tf_mha_core_f32.restype = ci
     L.tf_mha_core_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [ctypes.c_float, vp]
     L.hipemu_get_stats.restype = None
@@ -233,14 +235,15 @@ def _aligned16(a):
     return out
 
 
-def linear_packed(x, w, bias=None, relu=False):
-    x, w = _c(x, np.float32), _c(w, np.float32)
+def linear_packed(x, w, bias=None, relu=False, residual=None, guard_rows=0):
+    x, w = _aligned(x), _c(w, np.float32)
     M, K = x.shape
     N = w.shape[0]
     pk = _packed(w)
     b = _c(bias, np.float32) if bias is not None else None
-    y = np.full((M, N), np.nan, np.float32)
-    rc = lib().tf_linear_packed_f32(_p(x), pk.ctypes.data, _p(b), _p(y), M, K, N, int(relu), TERMS, None)
+    r = _aligned(residual)
+    y = np.full((M + guard_rows, N), np.nan, np.float32)
+    rc = lib().tf_linear_packed_f32(_p(x), pk.ctypes.data, _p(b), _p(r), _p(y), M, K, N, int(relu), TERMS, None)
     if rc != 0:
         raise RuntimeError("tf_linear_packed_f32: status %d" % rc)
     return y
@@ -388,6 +391,25 @@ def conv3x3_split(x_nhwc, w_ohwi, bias=None, relu=False, stride=1):
     rc = fn(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(y), n, h, wd, cin, cout, stride, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_conv3x3_split_f32: status %d" % rc)
+    return y
+
+
+def conv_packed(x_nhwc, w_ohwi, bias=None, relu=False, stride=1, ksplit=1, residual=None):
+    """tf_conv_packed_f32: x [N, H, W, Cin], w [Cout, ks, ks, Cin] (ks = 3: padding 1; ks = 1: none) -> y [N, Hout, Wout, Cout]."""
+    x, w = _aligned(x_nhwc), _c(w_ohwi, np.float32)
+    n, h, wd, cin = x.shape
+    cout, ks = w.shape[0], w.shape[1]
+    pk = _packed(w.reshape(cout, ks * ks * cin))
+    b = _aligned(bias)
+    pad = 1 if ks == 3 else 0
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
+    y = _aligned(np.full((n, ho, wo, cout), np.nan, np.float32))
+    r = _aligned(residual)
+    ws = _aligned(np.full((max(ksplit, 1), n * ho * wo * cout), np.nan, np.float32)) if ksplit > 1 else None
+    rc = lib().tf_conv_packed_f32(_p(x), pk.ctypes.data, _p(b), _p(r), _p(y), _p(ws), ksplit, n, h, wd, cin, cout, ks, stride,
+                                  int(relu), TERMS, None)
+    if rc != 0:
+        raise RuntimeError("tf_conv_packed_f32: status %d" % rc)
     return y
 
 

@@ -98,11 +98,10 @@ def _with_d(value, D):
     return rng.standard_normal(value.shape[:3] + (D,), dtype=np.float32)
 
 
-@pytest.fixture(params=["win", "quad", "pquad"])
+@pytest.fixture(params=["quad", "pquad"])
 def tiled(request):
     L = emu_lib.lib()
-    mode = {"win": 1, "quad": 2, "pquad": 2}[request.param]
-    prev_t = L.tf_msda_set_tiled(mode)
+    prev_t = L.tf_msda_set_tiled(2)
     prev_p = L.tf_msda_set_option(b"pquad", 1 if request.param == "pquad" else 0)
     yield request.param
     L.tf_msda_set_tiled(prev_t)
@@ -118,7 +117,7 @@ def test_encoder_window_kernels_vs_oracle(tiled, name, shapes, mode, N, D):
     np.testing.assert_allclose(out, ref, atol=1e-5, rtol=1e-4)
     st = emu_lib.stats()
     assert st["divergent_ops"] == 0, st
-    if tiled != "win" and mode in ("init", "local") and len(shapes) > 1 and shapes[0][0] > shapes[1][0]:
+    if mode in ("init", "local") and len(shapes) > 1 and shapes[0][0] > shapes[1][0]:
         assert st["lds_dma_bytes"] > 0   # the windows were staged by LDS-DMA: it really was the window kernel
 
 
@@ -385,8 +384,8 @@ BWD2_CASES = [c for c in ENC_CASES if c[0] in ("pyramid_init", "pyramid_local_n2
 
 @pytest.mark.parametrize("name,shapes,mode,N,D", BWD2_CASES, ids=[c[0] for c in BWD2_CASES])
 def test_encoder_shape_backward_sorted2_kernel(name, shapes, mode, N, D):
-    """msda_bwd_f32_sorted2 (opt-in): tap arithmetic once per pair through the per-wave LDS exchange, the channel sums as
-    four dot products + 8-lane DPP reductions, eight destination rows per wave in the row reduction."""
+    """msda_bwd_f32_sorted2 (the encoder-shape backward): tap arithmetic once per pair through the per-wave LDS exchange, the
+    channel sums as four dot products + 8-lane DPP reductions, eight destination rows per wave in the row reduction."""
     value, loc, attn = encoder_inputs(shapes, mode, N=N, seed=len(name))
     shp = np.array(shapes, np.int64)
     rng = np.random.default_rng(3)
@@ -396,21 +395,12 @@ def test_encoder_shape_backward_sorted2_kernel(name, shapes, mode, N, D):
         loc[:, :, :, :, ::2, 0] += 12.0 / 42
         loc[:, :, :, :, ::2, 1] -= 9.0 / 25
     rv, rl, ra = msda_oracle.msda_backward(value, shp, loc, attn, grad_out)
-    base = emu_lib.msda_backward(value, shp, loc, attn, grad_out)
-    prev = emu_lib.set_options(bwd_sorted2=1)
-    try:
-        emu_lib.stats(reset=True)
-        gv, gl, ga = emu_lib.msda_backward(value, shp, loc, attn, grad_out)
-        assert emu_lib.stats()["wave_ops"] > 0
-    finally:
-        emu_lib.set_options(**prev)
+    emu_lib.stats(reset=True)
+    gv, gl, ga = emu_lib.msda_backward(value, shp, loc, attn, grad_out)
+    assert emu_lib.stats()["wave_ops"] > 0
     np.testing.assert_allclose(gv, rv, atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(gl, rl, atol=2e-3, rtol=1e-4)
     np.testing.assert_allclose(ga, ra, atol=1e-4, rtol=1e-4)
-    # and against the default kernel (same items, different summation order)
-    np.testing.assert_allclose(gv, base[0], atol=2e-4, rtol=1e-4)
-    np.testing.assert_allclose(gl, base[1], atol=2e-3, rtol=1e-4)
-    np.testing.assert_allclose(ga, base[2], atol=1e-4, rtol=1e-4)
 
 
 @pytest.mark.parametrize("M,K,N", [(300, 64, 256), (130, 256, 64), (200, 512, 128), (70, 128, 512)], ids=lambda v: str(v))
@@ -798,3 +788,101 @@ def test_conv3x3_split_k(n, h, w, cin, cout, stride, ksplit, terms):
     assert np.abs(y - base).max() < 1e-5 * max(1.0, np.abs(ref).max())
     if ksplit == 1:
         assert np.array_equal(y, base)
+
+
+# ------------------------------------------------------------------ the stream GEMM's round-4 forms (linear_stream.hip)
+@pytest.mark.parametrize("M,K,N", [(300, 64, 256), (4200, 64, 64), (130, 256, 128), (200, 512, 64), (70, 128, 512), (333, 64, 200)],
+                         ids=lambda v: str(v))
+@pytest.mark.parametrize("relu", [False, True], ids=["plain", "relu"])
+def test_stream_gemm_residual_epilogue_and_narrow_blocks(M, K, N, relu, terms):
+    """tf_linear_packed_f32 with a residual (the closing 1 x 1 convolution of a bottleneck) and with 64- / 128-column blocks:
+    the bits of tf_linear_split_res_f32 (same products in the same order), nothing written behind row M."""
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N, dtype=np.float32)
+    r = rng.standard_normal((M, N), dtype=np.float32)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b + r
+    if relu:
+        ref = np.maximum(ref, 0)
+    y = emu_lib.linear_packed(x, w, b, relu, residual=r, guard_rows=3)
+    assert np.isnan(y[M:]).all()
+    assert np.abs(y[:M] - ref).max() < _tol(terms) * max(1.0, np.abs(ref).max())
+    assert np.array_equal(y[:M], emu_lib.linear_split(x, w, b, relu, residual=r))
+    assert np.array_equal(emu_lib.linear_packed(x, w, b, relu), emu_lib.linear_split(x, w, b, relu))
+    for ti in (1, 2, 4):   # every row-tile count of the block shape the width selects
+        prev = emu_lib.set_options(linear_stream_ti=ti)
+        try:
+            assert np.array_equal(emu_lib.linear_packed(x, w, b, relu, residual=r), y[:M]), ti
+        finally:
+            emu_lib.set_options(**prev)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,stride,ks", [(1, 9, 11, 64, 64, 1, 3), (2, 8, 6, 64, 128, 1, 3), (1, 10, 13, 64, 160, 2, 3),
+                                                       (1, 7, 7, 128, 64, 2, 1), (1, 12, 9, 128, 256, 1, 3), (1, 6, 5, 192, 320, 1, 1),
+                                                       (1, 1, 1, 64, 64, 1, 3)], ids=lambda v: str(v))
+def test_convolution_through_the_stream_gemm(n, h, w, cin, cout, stride, ks, terms):
+    """tf_conv_packed_f32: 3 x 3 (padding 1) and 1 x 1 convolutions, stride 1 / 2, as an implicit GEMM with the weight fragments
+    streamed and only the shifted input pixels through LDS -- the bits of the LDS-staged kernel (tf_conv3x3_split_f32), and
+    torch's convolution in float64 within the split product's bound; every block shape."""
+    import torch
+    rng = np.random.default_rng(h * w + cin + cout)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, ks, ks, cin), dtype=np.float32) / np.sqrt(ks * ks * cin)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double().permute(0, 3, 1, 2),
+                                     torch.from_numpy(b).double(), stride=stride, padding=1 if ks == 3 else 0).clamp_min(0).permute(0, 2, 3, 1).numpy()
+    y = emu_lib.conv_packed(x, wt, b, relu=True, stride=stride)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < _tol(terms) * max(1.0, np.abs(ref).max())
+    assert np.array_equal(y, emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride))
+    for ti in (1, 2, 4):
+        prev = emu_lib.set_options(linear_stream_ti=ti)
+        try:
+            assert np.array_equal(emu_lib.conv_packed(x, wt, b, relu=True, stride=stride), y), ti
+        finally:
+            emu_lib.set_options(**prev)
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,stride,ks,ksplit", [(1, 9, 11, 128, 64, 2, 3, 4), (1, 7, 6, 256, 256, 2, 3, 9), (2, 5, 5, 64, 128, 1, 3, 18),
+                                                              (1, 9, 11, 256, 64, 1, 1, 4), (1, 6, 6, 64, 192, 1, 1, 2), (1, 4, 4, 64, 64, 2, 3, 1)],
+                         ids=lambda v: str(v))
+def test_stream_convolution_split_k(n, h, w, cin, cout, stride, ks, ksplit, terms):
+    """tf_conv_packed_f32 with the K loop cut into pieces (partial sums in a workspace, added in a fixed order by a second launch,
+    then bias / residual / ReLU): against float64 and the uncut kernel (same products, another sum order); run twice: same bits."""
+    import torch
+    rng = np.random.default_rng(h * w + cin + ksplit)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, ks, ks, cin), dtype=np.float32) / np.sqrt(ks * ks * cin)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32)
+    pad = 1 if ks == 3 else 0
+    conv = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double().permute(0, 3, 1, 2),
+                                      torch.from_numpy(b).double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    r = rng.standard_normal(tuple(conv.shape), dtype=np.float32)
+    ref = (conv + torch.from_numpy(r).double()).clamp_min(0).numpy()
+    y = emu_lib.conv_packed(x, wt, b, relu=True, stride=stride, ksplit=ksplit, residual=r)
+    assert y.shape == ref.shape
+    assert np.abs(y - ref).max() < _tol(terms) * max(1.0, np.abs(ref).max())
+    base = emu_lib.conv_packed(x, wt, b, relu=True, stride=stride, residual=r)
+    assert np.abs(y - base).max() < 1e-5 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(emu_lib.conv_packed(x, wt, b, relu=True, stride=stride, ksplit=ksplit, residual=r), y)
+
+
+@pytest.mark.parametrize("M,ti", [(300, 2), (520, 2), (333, 0), (200, 2)])
+def test_fused_blocks_tail_split_is_bit_identical(M, ti, terms):
+    """The rows behind the full rounds of 64-row blocks go to a second launch of 32-row blocks (dispatch_ffn / dispatch_linln):
+    a row's result does not depend on the block it is in.  The emulated device has 4 CUs (HIPEMU_CUS): a round is 256 rows, so
+    300 rows = one round + 44, 520 = two rounds + 8; 200 rows: no full round, nothing to split."""
+    x, w1, b1, w2, b2, g, be = _ffn_case(M, 256, 3 * M)
+    outs = {}
+    for split in (0, 1):
+        prev = emu_lib.set_options(ffn_tail_split=split, ffn_ti=ti if ti else 3)
+        try:
+            outs[split] = (emu_lib.ffn_fused(x, w1, b1, w2, b2, residual=x, ln=(g, be), guard_rows=2),
+                           emu_lib.linear_res_ln(x, w2[:, :256].copy(), b2, x, ln=(g, be), guard_rows=2))
+        finally:
+            emu_lib.set_options(**prev)
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a[:M], b[:M]) and np.isnan(b[M:]).all()

@@ -154,54 +154,78 @@ def test_full_size_tracker_track_ids_bit_exact(dev, models, setup):
     np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
 
 
-def test_full_size_tracker_64_frame_sequence_against_reference(dev, models):
-    """the 64-frame 800x1333 sequence through Tracker.step in the bench set-up (tuned runtime, HIP graphs with
-    the bucketed track-query count, every default route) against the reference's own Tracker on CPU
-    (tests/golden/make_golden_full.py tracker64: 9 514 track ids, up to 1 980 simultaneous track queries).
-    The fixture records for the reference run (a) the smallest distance of any score to a score threshold: 0.35, no score
-    decision is near an edge, and (b) PER FRAME the smallest distance of any IoU an NMS pass looked at to its threshold.
-    With hundreds of near-identical random-weight boxes that distance drops below 1e-3 from frame 5 on and reaches 1e-7:
-    a pair that close to 0.9 is decided by the last bits of the boxes, which the 1e-3 tolerance does not pin.  So: every
-    frame whose NMS margin is >= 1e-3 must agree exactly; the following frames are compared until the first one that
-    differs (measured: 14 frames / 1 003 live tracks agree, frame 15 flips one suppression at a margin of 1.5e-4), at
-    least six must agree; every row of the agreeing frames must match in id / frame / source query, boxes and scores."""
+def _ids_until_divergence(models, dev, gold, n_frames, split, terms):
+    """Tracker.step over the 64-frame sequence in the bench set-up (tuned runtime, HIP graphs with the bucketed track-query
+    count) under one arithmetic set-up; -> (frames that agree with the reference from the start, the tracker)."""
     from trackformer_amd import config, fused, runtime
     from trackformer_amd.graphed import GraphedDetector
     from trackformer_amd.tracker import Tracker
-    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2_64.npz"))
-    assert float(z["min_score_margin"]) > 1e-2
-    margins = z["nms_iou_margin_per_frame"]
-    must = int(np.argmax(margins < 1e-3)) if (margins < 1e-3).any() else len(margins)   # frames that have to agree
-    n_run = 20
     model, post, args = models("cfg2_full")
     runtime.configure_inference(verbose=False)
-    prev_split = fused.set_split_linear(True)
+    prev_split, prev_terms = fused.set_split_linear(split), fused.set_split_terms(terms)
     try:
         tracker = Tracker(GraphedDetector(model), post, config.tracker_cfg(), False)
         tracker.reset()
         agree = 0
         with torch.no_grad():
-            for f, blob in enumerate(um.full_tracker_sequence(n_frames=n_run)):
+            for f, blob in enumerate(um.full_tracker_sequence(n_frames=n_frames)):
                 tracker.step(dict(blob, img=blob['img'].to(dev)))
-                ids = sorted(t.id for t in tracker.tracks)
-                gold_ids = sorted(int(r[0]) for r in z["rows"][z["rows"][:, 1] == f])
-                if ids != gold_ids:
+                if sorted(t.id for t in tracker.tracks) != gold[f]:
                     break
                 agree = f + 1
     finally:
         fused.set_split_linear(prev_split)
-    print("64-frame fixture: %d frames must agree (NMS margin >= 1e-3), %d of the %d frames run agree (%d live tracks); "
-          "NMS margin of the first differing frame: %.1e" % (must, agree, n_run, int(z["active_per_frame"][agree - 1]),
-                                                           margins[min(agree, len(margins) - 1)]))
-    assert agree >= max(must, 6), (agree, must, margins[:n_run].tolist())
+        fused.set_split_terms(prev_terms)
+    return agree, tracker
+
+
+def test_full_size_tracker_64_frame_sequence_against_reference(dev, models):
+    """the 64-frame 800x1333 sequence through Tracker.step against the reference's own Tracker on CPU
+    (tests/golden/make_golden_full.py tracker64: 9 514 track ids, up to 1 980 simultaneous track queries), run until the first
+    frame whose set of live ids differs (after that the track queries fed back differ: another sequence).
+
+    What decides ids here: the fixture records (a) that no score of any frame comes within 0.35 of a score threshold and
+    (b) PER FRAME the smallest distance of any IoU an NMS pass looked at to its threshold.  With hundreds of near-identical
+    random-weight boxes that margin is 1.3e-2 at frame 0, below 1e-3 from frame 4, 9.3e-6 at frame 24 and 5.7e-6 at frame 26.
+    Two fp32 implementations that agree on every box to 1.5e-6 (what this suite measures between the MI355X path and the
+    reference CPU path) agree on an IoU only to a few 1e-6: decisions with margins of that size are not pinned by ANY
+    fp32-accurate implementation -- the reference on another BLAS would not reproduce them either.
+
+    Measured on MI355X (profiles/r04_id_parity_64.txt, r04_pytest_64_frame.txt), frames that agree:
+        fp32 libraries (hipBLASLt / MIOpen)          64 (all) in one run, 59 in another (margin 1.4e-5 at frame 59)
+        six-term split product (the default)         26 in every run (margin 5.7e-6 at frame 26)
+        three-term split product (the fast mode)     14 in two runs (margin 6.8e-4 at frame 14), 32 in a third after the
+                                                     convolutions changed kernels (margin 2.0e-5)
+    i.e. products good to 2^-16 can flip a decision whose margin is 7e-4 -- forty times the margin fp32-class arithmetic
+    needs -- and whether they do depends on the kernel's summation order; that is why six terms are the default and the
+    three-term numbers are never the headline.  Asserted: the default agrees on every frame in front of the first one whose
+    NMS margin is below 2e-5 (24 frames), the three-term mode on every frame whose margin is at least 1e-3; every row of the
+    agreeing frames matches in id / frame / source query, boxes and scores."""
+    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2_64.npz"))
+    assert float(z["min_score_margin"]) > 1e-2
+    margins = z["nms_iou_margin_per_frame"]
+    rows = z["rows"]
+    n_run = 40
+    gold = [sorted(int(r[0]) for r in rows[rows[:, 1] == f]) for f in range(n_run)]
+
+    def first_below(thr):
+        return int(np.argmax(margins < thr)) if (margins < thr).any() else len(margins)
+    agree6, tracker = _ids_until_divergence(models, dev, gold, n_run, True, 6)
+    agree3, _ = _ids_until_divergence(models, dev, gold, n_run, True, 3)
+    print("64-frame fixture: six terms agree on %d frames (NMS margin of the first differing frame %.1e), three terms on %d "
+          "(%.1e); frames in front of the first margin < 2e-5: %d, < 1e-3: %d" % (
+              agree6, margins[min(agree6, len(margins) - 1)], agree3, margins[min(agree3, len(margins) - 1)],
+              first_below(2e-5), first_below(1e-3)))
+    assert agree6 >= first_below(2e-5), (agree6, margins[:n_run].tolist())
+    assert agree3 >= first_below(1e-3)
     results = tracker.get_results()
-    rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']), results[tid][f]['obj_ind']]
-                     for tid in sorted(results) for f in sorted(results[tid]) if f < agree], dtype=np.float64)
-    gold = z["rows"][z["rows"][:, 1] < agree]
-    assert rows.shape == gold.shape
-    np.testing.assert_array_equal(rows[:, [0, 1, 7]], gold[:, [0, 1, 7]])   # id, frame, source query
-    np.testing.assert_allclose(rows[:, 2:6], gold[:, 2:6], atol=1e-3 * max(um.FULL_ORIG))
-    np.testing.assert_allclose(rows[:, 6], gold[:, 6], atol=1e-3)
+    got = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']), results[tid][f]['obj_ind']]
+                    for tid in sorted(results) for f in sorted(results[tid]) if f < agree6], dtype=np.float64)
+    want = rows[rows[:, 1] < agree6]
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got[:, [0, 1, 7]], want[:, [0, 1, 7]])   # id, frame, source query
+    np.testing.assert_allclose(got[:, 2:6], want[:, 2:6], atol=1e-3 * max(um.FULL_ORIG))
+    np.testing.assert_allclose(got[:, 6], want[:, 6], atol=1e-3)
 
 
 # ------------------------------------------------------------------ the round-3 routes (defaults since their hardware validation:
@@ -437,11 +461,21 @@ def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
     taps = w.permute(0, 2, 3, 1).reshape(cout, ks * ks * shape[1]).contiguous()
     prev = fused.set_split_terms(terms)
     try:
-        y = fused.conv3x3(x, taps, b, True, stride)
+        y = fused.conv3x3(x, taps, b, True, stride)          # the stream GEMM (tf_conv_packed_f32), the default route
+        prev_stream = fused.set_conv_stream(False)
+        try:
+            y_block = fused.conv3x3(x, taps, b, True, stride)   # the LDS-staged block kernel (tf_conv3x3_split_f32)
+        finally:
+            fused.set_conv_stream(prev_stream)
         torch.cuda.synchronize()
     finally:
         fused.set_split_terms(prev)
-    assert y is not None
+    assert y is not None and y_block is not None
+    ho, wo = y.shape[2], y.shape[3]
+    if fused._conv_ksplit(shape[0] * ho * wo, ks * ks * shape[1], cout) == 1 or (ks == 1 and not fused.conv1x1_wants_split_k(shape[0] * ho * wo, shape[1], cout)):
+        assert torch.equal(y, y_block)                       # same products in the same order
+    else:
+        assert float((y - y_block).abs().max()) < 1e-5 * float(y_block.abs().max())   # the K pieces are cut elsewhere
     ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2))
     lib32 = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=ks // 2))
     scale = float(ref.abs().max())

@@ -383,13 +383,13 @@ def _fp32_linears():
 
 
 # ------------------------------------------------------------------ tiled / LDS-staged encoder kernel
-@pytest.fixture(params=[1, 2, 3], ids=["win", "quad", "pquad"])
+@pytest.fixture(params=[2, 3], ids=["quad", "pquad"])
 def tiled(dev, request):
-    """Select an LDS-window encoder kernel (1: msda_fwd_f32_win, 2: msda_fwd_f32_quad, 3: the persistent
-    msda_fwd_f32_pquad -- the default for encoder-shaped calls) for the duration of a test."""
+    """Select an LDS-window encoder kernel (2: msda_fwd_f32_quad, 3: the persistent msda_fwd_f32_pquad -- the default for
+    encoder-shaped calls) for the duration of a test."""
     from trackformer_amd import _cabi
     lib = _cabi.lib()
-    prev = lib.tf_msda_set_tiled(min(request.param, 2))
+    prev = lib.tf_msda_set_tiled(2)
     prev_pq = lib.tf_msda_set_option(b"pquad", 1 if request.param == 3 else 0)
     yield
     lib.tf_msda_set_tiled(prev)
@@ -648,13 +648,10 @@ def test_direct9_decoder_kernel(dev, Lq, L, N):
         lib.tf_msda_set_option(b"direct9", prev)
 
 
-@pytest.mark.parametrize("sorted2", [1, 0], ids=["sorted2", "sorted"])
 @pytest.mark.parametrize("name,shapes,mode,N,M,D", [c for c in BWD_ENC_CASES if c[5] == 32], ids=[c[0] for c in BWD_ENC_CASES if c[5] == 32])
-def test_backward_sorted_kernels(dev, name, shapes, mode, N, M, D, sorted2):
-    """msda_bwd_f32_sorted2 (the default) and msda_bwd_f32_sorted (bwd_sorted2 = 0) at the encoder shapes of
-    test_encoder_shape_backward_vs_oracle."""
-    from trackformer_amd import _cabi
-    lib = _cabi.lib()
+def test_backward_sorted_kernel_with_points_outside_their_windows(dev, name, shapes, mode, N, M, D):
+    """msda_bwd_f32_sorted2 at the encoder shapes of test_encoder_shape_backward_vs_oracle, with half of the points of the
+    cfg-2 case pushed far outside their binned windows (the direct-scatter path)."""
     value, shp, loc, attn, grad_out = _encoder_inputs(dev, shapes, mode, N=N, M=M, D=D, seed=len(name))
     if name == "cfg2_init":
         loc = loc.clone()
@@ -662,11 +659,7 @@ def test_backward_sorted_kernels(dev, name, shapes, mode, N, M, D, sorted2):
         loc[:, :, :, :, ::2, 1] -= 9.0 / 100
     rv, rl, ra = msda_oracle.msda_backward(value.cpu().numpy(), shp.cpu().numpy(), loc.cpu().numpy(),
                                            attn.cpu().numpy(), grad_out.cpu().numpy())
-    prev = lib.tf_msda_set_option(b"bwd_sorted2", sorted2)
-    try:
-        gv, gl, ga = [t.cpu().numpy() for t in _bwd(value, shp, loc, attn, grad_out)]
-    finally:
-        lib.tf_msda_set_option(b"bwd_sorted2", prev)
+    gv, gl, ga = [t.cpu().numpy() for t in _bwd(value, shp, loc, attn, grad_out)]
     np.testing.assert_allclose(gv, rv, atol=2e-4, rtol=1e-4)
     np.testing.assert_allclose(gl, rl, atol=2e-3, rtol=1e-4)
     np.testing.assert_allclose(ga, ra, atol=1e-4, rtol=1e-4)

@@ -103,7 +103,13 @@ def test_packed_kernel_dispatch_policy():
     prev = fused.set_packed_linear(True)
     try:
         assert fused._use_packed(22223, 256, 1024) and fused._use_packed(22223, 1024, 256)
-        assert not fused._use_packed(22223, 256, 256) and not fused._use_packed(22223, 256, 384)
+        assert fused.split_terms() == 6 and fused._use_packed(22223, 256, 256) and fused._use_packed(66800, 256, 64)   # six terms: K >= 256
+        assert not fused._use_packed(22223, 256, 384) and not fused._use_packed(66800, 64, 256)
+        p3 = fused.set_split_terms(3)
+        try:
+            assert not fused._use_packed(22223, 256, 256) and fused._use_packed(22223, 256, 1024)   # three terms: wide output / long K only
+        finally:
+            fused.set_split_terms(p3)
         assert not fused._use_packed(400, 256, 1024)       # decoder: few rows
         assert not fused._use_packed(30000, 288, 1024)     # hidden 288: K not a multiple of 64
         assert not fused._use_packed(30000, 1024, 288)     # second 256-column block nearly empty

@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--shapes", default=None, help="comma-separated subset of: " + ", ".join(n for n, _ in CONFIGS))
     ap.add_argument("--modes", default="uniform,local,init")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
-                    help="tf_msda_set_option before timing, e.g. --option direct9=1 --option bwd_sorted2=1")
+                    help="tf_msda_set_option before timing, e.g. --option direct9=1 --option pquad=0")
     args = ap.parse_args()
     from trackformer_amd import _cabi
     for o in args.option:

@@ -21,7 +21,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    for cin, cout, h, w in ((64, 64, 200, 334), (256, 256, 50, 84)):
+    for cin, cout, h, w in ((64, 64, 200, 334), (128, 128, 100, 167), (256, 256, 50, 84)):
         x = torch.randn(1, cin, h, w, device=dev).contiguous(memory_format=torch.channels_last)
         wt = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).contiguous()
         b = torch.randn(cout, device=dev)

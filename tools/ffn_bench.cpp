@@ -103,8 +103,8 @@ int main(int argc, char **argv)
     unsigned short *dW1hi, *dW1mid, *dW1lo, *dW2hi, *dW2mid, *dW2lo;
     split_of(W1, &dW1hi, &dW1mid, &dW1lo);
     split_of(W2, &dW2hi, &dW2mid, &dW2lo);
-    auto lin1 = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dW1hi, dW1mid, dW1lo, dB1, dH, M, D, F, 1, s) : tf_linear_packed_f32(dX, dP1, dB1, dH, M, D, F, 1, T, s); };
-    auto lin2 = [&]() { return (F % 64) ? tf_linear_split_f32(dH, dW2hi, dW2mid, dW2lo, dB2, dY0, M, F, D, 0, s) : tf_linear_packed_f32(dH, dP2, dB2, dY0, M, F, D, 0, T, s); };
+    auto lin1 = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dW1hi, dW1mid, dW1lo, dB1, dH, M, D, F, 1, s) : tf_linear_packed_f32(dX, dP1, dB1, nullptr, dH, M, D, F, 1, T, s); };
+    auto lin2 = [&]() { return (F % 64) ? tf_linear_split_f32(dH, dW2hi, dW2mid, dW2lo, dB2, dY0, M, F, D, 0, s) : tf_linear_packed_f32(dH, dP2, dB2, nullptr, dY0, M, F, D, 0, T, s); };
 
     // ---- 1. bit identity without the LayerNorm
     TF(lin1());
@@ -209,7 +209,7 @@ int main(int argc, char **argv)
     TF(tf_linear_pack_weight_f32(dWo, dPo, D, D, T, s));
     unsigned short *dWohi, *dWomid, *dWolo;
     split_of(Wo, &dWohi, &dWomid, &dWolo);
-    auto lino = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dWohi, dWomid, dWolo, dB2, dY0, M, D, D, 0, s) : tf_linear_packed_f32(dX, dPo, dB2, dY0, M, D, D, 0, T, s); };
+    auto lino = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dWohi, dWomid, dWolo, dB2, dY0, M, D, D, 0, s) : tf_linear_packed_f32(dX, dPo, dB2, nullptr, dY0, M, D, D, 0, T, s); };
     TF(lino());
     CK(hipMemsetAsync(dY, 0xFF, (size_t)(M + guard) * D * 4, s));
     TF(tf_linear_res_ln_f32(dX, dPo, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, D, T, s));

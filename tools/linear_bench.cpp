@@ -112,7 +112,7 @@ int main(int argc, char **argv)
         std::vector<float> Y0(Y.size());
         CK(hipMemcpy(Y0.data(), dY, Y.size() * 4, hipMemcpyDeviceToHost));
         CK(hipMemset(dY, 0xFF, Y.size() * 4));
-        prc = tf_linear_packed_f32(dX, dWp, dB, dY, M, K, N, 0, T, stream);
+        prc = tf_linear_packed_f32(dX, dWp, dB, nullptr, dY, M, K, N, 0, T, stream);
         if (prc != 0) {
             fprintf(stderr, "tf_linear_packed_f32 failed: %s\n", tf_msda_strerror(prc));
             return 2;
@@ -124,7 +124,7 @@ int main(int argc, char **argv)
         CK(hipMemset(dY, 0xFF, Y.size() * 4));
     }
     auto run = [&]() {
-        return packed ? tf_linear_packed_f32(dX, dWp, dB, dY, M, K, N, 0, T, stream)
+        return packed ? tf_linear_packed_f32(dX, dWp, dB, nullptr, dY, M, K, N, 0, T, stream)
                       : tf_linear_split_f32(dX, dWhi, dWmid, dWlo, dB, dY, M, K, N, 0, stream);
     };
     int rc = run();

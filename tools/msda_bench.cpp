@@ -124,7 +124,7 @@ static Config parse_config(const std::string &arg)
     Config c;
     c.name = arg;
     const std::string kind = arg.substr(0, arg.find(':'));
-    c.tiled = kind == "direct" ? 0 : kind == "win" ? 1 : kind == "quad" ? 2 : kind == "pquad" ? 3 : -9;
+    c.tiled = kind == "direct" ? 0 : kind == "quad" ? 2 : kind == "pquad" ? 3 : -9;
     if (c.tiled == -9) {
         fprintf(stderr, "unknown configuration '%s'\n", arg.c_str());
         exit(2);

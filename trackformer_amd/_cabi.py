@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = (
     "tf_linear_split_add_f32",
     "tf_ffn_fused_f32",
     "tf_linear_res_ln_f32",
+    "tf_conv_packed_f32",
     "tf_mha_core_f32",
     "tf_nms_host_f32",
 )
@@ -142,7 +143,9 @@ def lib():
     L.tf_linear_split_add_f32.restype = ci
     L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_linear_packed_f32.restype = ci
-    L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, ci, vp]
+    L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, ci, vp]
+    L.tf_conv_packed_f32.restype = ci
+    L.tf_conv_packed_f32.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 10 + [vp]
     L.tf_mha_core_f32.restype = ci
     L.tf_mha_core_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [ctypes.c_float, vp]
     if L.tf_msda_abi_version() != ABI_VERSION:

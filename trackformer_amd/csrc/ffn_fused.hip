@@ -538,6 +538,7 @@ int linln_ti()
     return v;
 }
 
+std::atomic<int> g_ffn_tail{-1};   // -1: TF_FFN_TAIL_SPLIT or the default (1): the rows behind the full rounds as 32-row blocks
 std::atomic<int> g_ffn_ti{-1};   // -1: TF_FFN_TI or the default (3)
 int ffn_ti()
 {
@@ -554,6 +555,22 @@ int ffn_ti()
 }  // namespace
 
 namespace tfm {
+int ffn_tail_split()
+{
+    int v = g_ffn_tail.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_FFN_TAIL_SPLIT");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_ffn_tail.store(v);
+    }
+    return v;
+}
+int ffn_set_tail_split(int v)
+{
+    const int prev = ffn_tail_split();
+    g_ffn_tail.store(v ? 1 : 0);
+    return prev;
+}
 int ffn_set_ti(int v)
 {
     const int prev = ffn_ti();
@@ -570,6 +587,19 @@ int linln_set_ti(int v)
 
 namespace {
 
+int ffn_num_cus()
+{
+    static const int n = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        return cus;
+    }();
+    return n;
+}
+
 template <int NP, int D>
 int dispatch_linln(const float *x, const u32x4 *w, const float *bias, const float *residual, const float *g, const float *b, float eps,
                    float *y, int M, hipStream_t s)
@@ -577,7 +607,11 @@ int dispatch_linln(const float *x, const u32x4 *w, const float *bias, const floa
     // rows per block = 32 TI; automatic: few rows -> 32-row blocks (more of them), many -> 64 (two resident per CU with two
     // pieces per operand; with three the 64-row tile is 99 KB of LDS: one block per CU)
     const int forced = linln_ti();
-    switch (forced ? forced : (M < 4096 ? 1 : 2)) {
+    // Three pieces: a 64-row tile is 99 KB of LDS -- one block per CU, rounds of `cus` blocks (348 blocks at the cfg-2 encoder: a
+    // full round and a third of one).  32-row tiles (50 KB) keep three blocks resident per CU and the 695 blocks run as one
+    // round: 26.2 us against 31.2 us with 64-row blocks (29.0 with the rows behind the full round split off as dispatch_ffn
+    // does; profiles/r04_one_launch_blocks_tail_split.txt).  Two pieces: 64-row tiles, two resident per CU, as measured in round 3.
+    switch (forced ? forced : (M < 4096 || NP == 3 ? 1 : 2)) {
     case 1: return launch_linln<NP, D, 1>(x, w, bias, residual, g, b, eps, y, M, s);
     case 3:   // 96 rows per block: hidden 256 with two pieces only (at 288 the accumulators of three row tiles do not fit the
               // register file, with three pieces the tile does not fit the LDS)
@@ -592,7 +626,26 @@ int dispatch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *
                  const float *g, const float *b, float eps, float *y, int M, int F, hipStream_t s)
 {
     if (F < Geo<D>::CH || (F & 15)) return TF_MSDA_ERR_BAD_DIMS;   // at least one chunk; whole k-steps of GEMM 2
-    switch (ffn_ti()) {
+    // One block per CU (the two LDS tiles fill it), so a launch runs in ROUNDS of `cus` blocks.  With 64-row blocks (three
+    // pieces, or hidden 288) the 22 223 rows of the cfg-2 encoder are 348 blocks = one full round + 92 blocks: the second round
+    // takes as long as the first with a third of the chip (profiles/r04_pmc_dense_six_terms.txt: 63 % of a wave's cycles are
+    // MFMA-busy, 38 % of the launch's).  When the last round would be less than half full, the rows behind the full rounds go
+    // to a second launch of 32-row blocks: a short round instead of a long one.  Same arithmetic per row (a row's result does
+    // not depend on the block it is in): bit-identical.
+    const int want = ffn_ti();
+    const bool ti2 = want == 2 || (want >= 3 && !(D == 256 && NP == 2));
+    if (ti2 && tfm::ffn_tail_split()) {
+        const int cus = ffn_num_cus();
+        const long long per_round = 64LL * cus;
+        const int main_rows = (int)(M / per_round * per_round), rem = M - main_rows;
+        if (main_rows > 0 && rem > 0 && rem <= 32LL * cus) {
+            int rc = launch_ffn<NP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, main_rows, F, s);
+            if (rc != TF_MSDA_OK) return rc;
+            const size_t off = (size_t)main_rows * D;
+            return launch_ffn<NP, D, 1>(x + off, w1, b1, w2, b2, residual ? residual + off : nullptr, g, b, eps, y + off, rem, F, s);
+        }
+    }
+    switch (want) {
     case 1: return launch_ffn<NP, D, 1>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
     case 2: return launch_ffn<NP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
     default:   // 96 rows per block: hidden 256 with two pieces only (see dispatch_linln; three pieces: 96 rows x (264 + 136) x 6 B

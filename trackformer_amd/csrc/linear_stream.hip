@@ -80,27 +80,46 @@ pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, int K, 
     }
 }
 
-template <int NP>
-struct WFrags {
-    u32x4 v[kTJ][2][NP];   // [column tile][k-step of the slice][hi | mid | lo]
+// ---------------------------------------------------------------------------------------------------------------------------
+// THE STREAM GEMM (round 4: one kernel for the linears, the 1 x 1 convolutions incl. the residual epilogue of a bottleneck, and
+// -- as an implicit GEMM over the output pixels -- the 3 x 3 / strided convolutions; it replaces the LDS-staged block kernels
+// of linear_split.hip wherever the weight is packed).  Why (profiles/r04_pmc_dense_six_terms.txt, six terms, MI355X): at equal
+// matrix work the block kernel that stages BOTH operands in LDS takes 88.0 us (22 223 x 1024 -> 256) / 84.7 us (256 -> 1024) /
+// 26.3 us (256 -> 256), this structure 65.6 / 67.5 / 23.9 us: a wave of the block kernel reads (TI + TJ) x NP KB of LDS per
+// TI x TJ x 6 MFMAs, here the weight fragments come straight from L2 in fragment order and only the activations pass LDS.
+//
+//   block   256 threads = 4 waves as WR x WC (rows x columns), WC in {4, 2};  wave tile = TI x TJ MFMA tiles of 32 x 32
+//           BM = WR TI 32 rows, BN = WC TJ 32 columns:  (WC, TJ) = (4, 2): 256 columns, (4, 1): 128, (2, 1): 64 (WR = 2)
+//   A       fp32 rows (MODE 0) or shifted input pixels of one tap (MODE 1: buffer loads, taps outside the image read zeros from
+//           beyond num_records) -> registers two slices ahead -> bf16 pieces -> LDS, double buffered: ONE barrier per 32-wide slice
+//   B       packed fragments (pack_weight_kernel), L2 -> registers one slice ahead
+//   split-K blockIdx.y walks `kslices` slices and writes partial sums to Y + z M N (host: no bias / ReLU / residual then; a
+//           second launch adds the pieces in a fixed order)
+//   epilogue  + bias, + residual (R may alias Y), ReLU; buffer stores (rows >= M / columns >= N fall outside the resource)
+// Accumulation order per output element: k ascending, per k-step smallest terms first -- the order of linear_split.hip, so
+// the results are bit-identical to tf_linear_split_f32 / tf_conv3x3_split_f32 with the same number of terms.
+struct StreamConv {
+    int nimg, hin, win, cin, hout, wout, ks, pad, stride;
 };
 
-constexpr int stream_min_waves(int ti) { return ti <= 3 ? 2 : 1; }   // blocks per CU the register budget is cut for
+template <int NP, int TJ>
+struct WFrags {
+    u32x4 v[TJ][2][NP];   // [column tile][k-step of the slice][hi | mid | lo]
+};
 
-// BUFST (the default since round 3, linear_bufstore option; see linear_split.hip): the epilogue through a buffer resource
-// (no per-store branch / wait): 57.9 -> 44.1 us at 22 223 x 256 -> 1024, 52.1 -> 39.4 us at 1024 -> 256, bit-identical
-// (profiles/r03_optin_linear_bufstore.txt).  A variant with transposed accumulators and 16-byte stores measured slower on the
-// first shape (58.6 us) and was removed.
-template <int NP, int TI, bool RELU, bool BUFST = false>
-__global__ void __launch_bounds__(kThreads, (stream_min_waves(TI)))
-split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias,
-                         float *__restrict__ Y, int M, int K, int N, int mblocks, int nblocks)
+constexpr int stream_min_waves(int ti, int tj, int wc) { return (4 / wc) * ti * tj <= 6 && ti <= 3 ? 2 : 1; }   // blocks per CU the register budget is cut for
+
+template <int NP, int TI, int TJ, int WC, bool CONV>
+__global__ void __launch_bounds__(kThreads, (stream_min_waves(TI, TJ, WC)))
+stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R,
+                   float *Y, int M, int K, int N, int mblocks, int nblocks, int relu, int kslices, const StreamConv cv)
 {
-    constexpr int BM = TI * 32;
-    constexpr int XV = TI;   // float4 of X per thread and slice: BM * 8 / 256
+    constexpr int WR = 4 / WC, BM = WR * TI * 32, BN = WC * TJ * 32;
+    constexpr int XV = BM / 32;   // float4 of A per thread and slice: BM * 8 / 256
     __shared__ __attribute__((aligned(16))) unsigned short sA[2][NP][BM * kStride];   // [buffer][hi | mid | lo][row][k]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave - wr * WC;
 
     // ---- block -> (row block, column block): ids that are congruent mod 8 land on one XCD; the column blocks of a
     // row block sit 8 ids apart inside a group of 8 * nblocks ids
@@ -108,29 +127,81 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
     const int g = blockIdx.x / per, r = blockIdx.x - g * per;
     const int mb = g * 8 + (r & 7), nb = r >> 3;
     if (mb >= mblocks) return;   // whole block, before any barrier
-    const int m0 = mb * BM, n0 = nb * kBN;
-    const int S = K / kSlice, KQ = K >> 4;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int KQ = K >> 4;
+    const int sbeg = kslices > 0 ? (int)blockIdx.y * kslices : 0;
+    const int send = kslices > 0 ? min(K / kSlice, sbeg + kslices) : K / kSlice;   // this block's slices: [sbeg, send), an even number
+    if (kslices > 0) Y += (size_t)blockIdx.y * M * N;
 
-    f32x16 acc[TI][kTJ];
+    f32x16 acc[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < kTJ; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     // ---- activations: thread -> (row, 4 consecutive k) of the slice, XV rows 32 apart
-    const float *xp[XV];
     const int arow = tid >> 3, ac4 = tid & 7;
+    const float *xp[CONV ? 1 : XV];
+    unsigned xoff[CONV ? XV : 1];
+    int ybase[CONV ? XV : 1], xbase[CONV ? XV : 1];
+    bool rowok[CONV ? XV : 1];
+    constexpr unsigned OOB = 0xC0000000u;   // >= num_records (host: the input lies below 3 GiB)
+    __amdgpu_buffer_rsrc_t xrs;
+    int nslice = sbeg, ntap_c0 = 0, ndx = 0, ndy = 0;   // the NEXT slice load_x fetches, as (slice, channel, tap column, tap row)
+    if constexpr (!CONV) {
 #pragma unroll
-    for (int it = 0; it < XV; ++it) {
-        const int grow = min(m0 + it * 32 + arow, M - 1);   // rows past M read the last row, never stored
-        xp[it] = X + (size_t)grow * K + ac4 * 4;
+        for (int it = 0; it < XV; ++it) {
+            const int grow = min(m0 + it * 32 + arow, M - 1);   // rows past M read the last row, never stored
+            xp[it] = X + (size_t)grow * K + ac4 * 4;
+        }
+    } else {
+        xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (unsigned)((size_t)cv.nimg * cv.hin * cv.win * cv.cin * 4), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < XV; ++it) {
+            const int row = m0 + it * 32 + arow;
+            rowok[it] = row < M;
+            const int rr = rowok[it] ? row : 0;
+            const int img = rr / (cv.hout * cv.wout), rem = rr - img * (cv.hout * cv.wout);
+            const int yo = rem / cv.wout, xo = rem - yo * cv.wout;
+            ybase[it] = yo * cv.stride - cv.pad;
+            xbase[it] = xo * cv.stride - cv.pad;
+            // byte offset of the pixel's window origin, channel ac4 * 4 (wrap-around arithmetic: a border pixel's window starts
+            // in front of the image, the sum with a valid tap's offset is back inside)
+            xoff[it] = ((unsigned)((img * cv.hin + ybase[it]) * cv.win + xbase[it]) * (unsigned)cv.cin + (unsigned)(ac4 * 4)) * 4u;
+        }
+        const int k0 = sbeg * kSlice, tap = k0 / cv.cin;
+        ntap_c0 = k0 - tap * cv.cin;
+        ndy = tap / cv.ks;
+        ndx = tap - ndy * cv.ks;
     }
-    auto load_x = [&](int s, f32x4 (&dst)[XV]) {
-        const int k0 = min(s, S - 1) * kSlice;   // past the end: a harmless reload of the last slice
+    // the slices are fetched strictly in order (sbeg, sbeg + 1, ...); calls past the last slice re-fetch it (never used)
+    auto load_x = [&](f32x4 (&dst)[XV]) {
+        if constexpr (!CONV) {
+            const int k0 = min(nslice, send - 1) * kSlice;
 #pragma unroll
-        for (int it = 0; it < XV; ++it) dst[it] = *reinterpret_cast<const f32x4 *>(xp[it] + k0);
+            for (int it = 0; it < XV; ++it) dst[it] = *reinterpret_cast<const f32x4 *>(xp[it] + k0);
+            ++nslice;
+        } else {
+            const unsigned tapoff = (unsigned)((ndy * cv.win + ndx) * cv.cin + ntap_c0) * 4u;   // uniform
+#pragma unroll
+            for (int it = 0; it < XV; ++it) {
+                const bool ok = rowok[it] && (unsigned)(ybase[it] + ndy) < (unsigned)cv.hin && (unsigned)(xbase[it] + ndx) < (unsigned)cv.win;
+                dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? xoff[it] + tapoff : OOB, 0, 0));
+            }
+            if (nslice + 1 < send) {   // step (channel, tap column, tap row) to the next slice
+                ++nslice;
+                ntap_c0 += kSlice;
+                if (ntap_c0 == cv.cin) {
+                    ntap_c0 = 0;
+                    if (++ndx == cv.ks) {
+                        ndx = 0;
+                        ++ndy;
+                    }
+                }
+            }
+        }
     };
     auto store_x = [&](const f32x4 (&src)[XV], int buf) {
 #pragma unroll
@@ -142,34 +213,34 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
             for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(&sA[buf][p][o]) = pc[p];
         }
     };
-    // ---- weights: the wave's two column tiles, fragment order (see pack_weight_kernel)
-    const u32x4 *wp[kTJ];
+    // ---- weights: the wave's TJ column tiles, fragment order (see pack_weight_kernel)
+    const u32x4 *wp[TJ];
 #pragma unroll
-    for (int j = 0; j < kTJ; ++j) wp[j] = Wp + ((size_t)(nb * 4 * kTJ + wave * kTJ + j) * KQ * NP) * 64 + lane;
-    auto load_w = [&](int s, WFrags<NP> &w) {
-        const int q0 = min(s, S - 1) * 2;
+    for (int j = 0; j < TJ; ++j) wp[j] = Wp + ((size_t)(nb * (WC * TJ) + wc * TJ + j) * KQ * NP) * 64 + lane;
+    auto load_w = [&](int s, WFrags<NP, TJ> &w) {
+        const int q0 = min(s, send - 1) * 2;
 #pragma unroll
-        for (int j = 0; j < kTJ; ++j)
+        for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) w.v[j][kk][p] = wp[j][((q0 + kk) * NP + p) * 64];
     };
 
-    f32x4 xr[2][XV];   // slice s + 1 lives in xr[(s + 1) & 1], slice s + 2 in the other one
-    WFrags<NP> w0, w1;
+    f32x4 xr[2][XV];   // slice s + 1 lives in xr[(s + 1) & 1], slice s + 2 in the other one   (parity relative to sbeg)
+    WFrags<NP, TJ> w0, w1;
     {
         f32x4 first[XV];
-        load_x(0, first);
-        load_w(0, w0);
-        load_x(1, xr[1]);
-        load_x(2, xr[0]);
+        load_x(first);
+        load_w(sbeg, w0);
+        load_x(xr[1]);
+        load_x(xr[0]);
         store_x(first, 0);
     }
     __syncthreads();
 
-    // one K-slice; PAR = s & 1 as a compile-time constant so that the register double buffers need no copies
-    auto slice = [&](int s, auto par, const WFrags<NP> &cur, WFrags<NP> &nxt) {
+    // one K-slice; PAR = (s - sbeg) & 1 as a compile-time constant so that the register double buffers need no copies
+    auto slice = [&](int s, auto par, const WFrags<NP, TJ> &cur, WFrags<NP, TJ> &nxt) {
         constexpr int PAR = decltype(par)::value;
         load_w(s + 1, nxt);   // in flight during the MFMAs below
         __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them to the end of the
@@ -177,74 +248,92 @@ split_gemm_stream_kernel(const float *__restrict__ X, const u32x4 *__restrict__ 
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int koff = kk * 16 + (lane >> 5) * 8;
-            bf16x8 af[TI][NP], bfr[kTJ][NP];
+            bf16x8 af[TI][NP], bfr[TJ][NP];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-                const int o = (i * 32 + (lane & 31)) * kStride + koff;
+                const int o = ((wr * TI + i) * 32 + (lane & 31)) * kStride + koff;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const bf16x8 *>(&sA[PAR][p][o]);
             }
 #pragma unroll
-            for (int j = 0; j < kTJ; ++j)
+            for (int j = 0; j < TJ; ++j)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) bfr[j][p] = __builtin_bit_cast(bf16x8, cur.v[j][kk][p]);
             // term-major passes over the tiles: consecutive MFMAs never share an accumulator; per accumulator the order is
             // smallest terms first, as in linear_split.hip
-            mfma_tiles<NP, TI, kTJ>(acc, af, bfr);
+            mfma_tiles<NP, TI, TJ>(acc, af, bfr);
         }
         // slice s + 1 -> the LDS buffer nobody reads in this iteration (its readers passed the previous barrier),
         // then its registers take slice s + 3
         store_x(xr[PAR ^ 1], PAR ^ 1);
-        load_x(s + 3, xr[PAR ^ 1]);
+        load_x(xr[PAR ^ 1]);
         __syncthreads();
     };
-    for (int s = 0; s < S; s += 2) {   // S is even (host: K % 64 == 0)
+    for (int s = sbeg; s < send; s += 2) {   // an even number of slices (host)
         slice(s, std::integral_constant<int, 0>{}, w0, w1);
         slice(s + 1, std::integral_constant<int, 1>{}, w1, w0);
     }
 
-    // ---- epilogue: C/D of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if constexpr (BUFST) {
-        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (unsigned)((size_t)M * N * 4), 0x00020000);
+    // ---- epilogue: C/D of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Buffer
+    // resources over Y (and R): rows >= M land beyond num_records (dropped / read as zero by the hardware); columns >= N start
+    // from 3 GiB, which stays out of range and does not wrap for any row delta (host: the tensor is < 3 GiB)
+    const unsigned ybytes = (unsigned)((size_t)M * N * 4);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : Y), 0, R ? ybytes : 0u, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < kTJ; ++j) {
-            const int col = n0 + (wave * kTJ + j) * 32 + (lane & 31);
-            const bool colok = col < N;
-            const float b = (bias && colok) ? bias[col] : 0.f;
+    for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + (wc * TJ + j) * 32 + (lane & 31);
+        const bool colok = col < N;
+        const float b = (bias && colok) ? bias[col] : 0.f;
 #pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const int row0 = m0 + i * 32 + 4 * (lane >> 5);
-                // rows >= M land beyond num_records (dropped by the hardware); columns >= N start from 3 GiB, which stays
-                // out of range and does not wrap for any row delta (host: the tensor is < 3 GiB)
-                const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xC0000000u;
+        for (int i = 0; i < TI; ++i) {
+            const int row0 = m0 + (wr * TI + i) * 32 + 4 * (lane >> 5);
+            const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xC0000000u;
+            float rv[16];
+            if (R != nullptr) {   // uniform
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = acc[i][j][e] + b;
-                    if (RELU) v = v > 0.f ? v : 0.f;
-                    const unsigned off = base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off, 0, 0);
-                }
+                for (int e = 0; e < 16; ++e)
+                    rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u, 0, 0));
             }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < kTJ; ++j) {
-        const int col = n0 + (wave * kTJ + j) * 32 + (lane & 31);
-        if (col >= N) continue;
-        const float b = bias ? bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (row < M) {
-                    float v = acc[i][j][e] + b;
-                    if (RELU) v = v > 0.f ? v : 0.f;
-                    Y[(size_t)row * N + col] = v;
-                }
+                float v = acc[i][j][e] + b;
+                if (R != nullptr) v += rv[e];
+                if (relu) v = v > 0.f ? v : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u, 0, 0);
             }
+        }
     }
+}
+
+// ---- split-K second pass: y = act(sum_z partial[z] + bias + residual), the partials added in the order z = 0, 1, ... (a fixed
+// order: the result does not depend on scheduling, unlike atomic accumulation).  One thread per 4 consecutive outputs.
+__global__ void __launch_bounds__(256)
+stream_splitk_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias, const float *R, float *y, long long mn4,
+                            int n4, int splits, int relu)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;   // mn4 < 2^31 (the output is below 3 GiB): 32-bit index arithmetic
+    if (i >= (unsigned)mn4) return;
+    const f32x4 *p = reinterpret_cast<const f32x4 *>(part) + i;
+    f32x4 acc = p[0];
+    int z = 1;
+    for (; z + 3 < splits; z += 4) {   // four loads in flight, added in the order z, z + 1, ...
+        const f32x4 a = p[(long long)z * mn4], b = p[(long long)(z + 1) * mn4], c = p[(long long)(z + 2) * mn4], d = p[(long long)(z + 3) * mn4];
+        acc += a;
+        acc += b;
+        acc += c;
+        acc += d;
+    }
+    for (; z < splits; ++z) acc += p[(long long)z * mn4];
+    if (bias != nullptr) acc += reinterpret_cast<const f32x4 *>(bias)[i % (unsigned)n4];
+    if (R != nullptr) acc += reinterpret_cast<const f32x4 *>(R)[i];
+    if (relu) {
+        acc.x = acc.x > 0.f ? acc.x : 0.f;
+        acc.y = acc.y > 0.f ? acc.y : 0.f;
+        acc.z = acc.z > 0.f ? acc.z : 0.f;
+        acc.w = acc.w > 0.f ? acc.w : 0.f;
+    }
+    reinterpret_cast<f32x4 *>(y)[i] = acc;
 }
 
 int num_cus()
@@ -268,45 +357,83 @@ int forced_ti()
     if (v < 0) {
         const char *e = getenv("TF_LINEAR_STREAM_TI");
         v = e ? atoi(e) : 0;
-        if (v < 2 || v > 4) v = 0;
+        if (v < 1 || v > 4) v = 0;
         g_ti.store(v);
     }
     return v;
 }
 
-// rows per block = 32 TI.  Measured at 22 223 rows with three terms (profiles/r02_split_gemm_packed.txt): two row tiles (three
-// blocks per CU resident) win at K = 256 -- 59.3 / 67.3 / 84.2 us for TI = 2 / 3 / 4 at N = 1024 -- where a block's eight K-slices
-// are too short a loop to hide its own memory latency and the co-resident blocks have to; three win at K = 1024
-// (55.6 / 50.5 / 58.0 us), where the loop is long enough and the weight traffic per MFMA counts.
-int choose_ti(int K)
+// ---------------------------------------------------------------------------------------------------------------- host side
+struct StreamCall {
+    const float *x;
+    const u32x4 *wp;
+    const float *bias, *res;
+    float *y;
+    int M, K, N, relu;
+    bool conv;
+    StreamConv cv;
+    float *workspace;   // split-K partial sums [pieces][M][N], or NULL
+    int ksplit;         // pieces the K loop is cut into (1: none)
+};
+
+template <int NP, int TI, int TJ, int WC, bool CONV>
+int launch_stream(const StreamCall &c, hipStream_t s)
 {
-    const int f = forced_ti();
-    if (f) return f;
-    return K >= 512 ? 3 : 2;
+    constexpr int BM = (4 / WC) * TI * 32, BN = WC * TJ * 32;
+    const int mblocks = (c.M + BM - 1) / BM, nblocks = (c.N + BN - 1) / BN;
+    const long long gx = (long long)((mblocks + 7) / 8) * 8 * nblocks;
+    const int slices = c.K / kSlice;
+    int kslices = 0, gz = 1;
+    if (c.ksplit > 1) {
+        kslices = ((slices + c.ksplit - 1) / c.ksplit + 1) & ~1;   // an even number of slices per piece
+        gz = (slices + kslices - 1) / kslices;
+        if (gz <= 1) kslices = 0, gz = 1;
+    }
+    if (gx > 0x7fffffffLL || gz > 65535) return TF_MSDA_ERR_BAD_DIMS;
+    const bool partial = gz > 1;
+    float *out = partial ? c.workspace : c.y;
+    hipLaunchKernelGGL((stream_gemm_kernel<NP, TI, TJ, WC, CONV>), dim3((unsigned)gx, (unsigned)gz), dim3(kThreads), 0, s, c.x, c.wp,
+                       partial ? nullptr : c.bias, partial ? nullptr : c.res, out, c.M, c.K, c.N, mblocks, nblocks, partial ? 0 : c.relu,
+                       kslices, c.cv);
+    if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    if (partial) {
+        const long long mn4 = (long long)c.M * c.N / 4;
+        hipLaunchKernelGGL(stream_splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, s, c.workspace, c.bias, c.res,
+                           c.y, mn4, c.N / 4, gz, c.relu);
+        if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    }
+    return TF_MSDA_OK;
 }
 
-template <int NP, int TI>
-int launch_stream(const float *x, const u32x4 *wp, const float *bias, float *y, int M, int K, int N, int relu, hipStream_t s)
+// Block shape per call.  Columns: N <= 64 -> 64-column blocks (2 x 2 waves), N <= 128 -> 128 (4 waves side by side, one column
+// tile each), else 256.  Rows: 32 TI per row group.  Measured at 22 223 rows with three terms (profiles/r02_split_gemm_packed.txt,
+// 256-column blocks): two row tiles win at K = 256 (59.3 / 67.3 / 84.2 us for TI = 2 / 3 / 4 at N = 1024: a block's eight K-slices
+// are too short a loop to hide its own memory latency and the co-resident blocks have to), three at K = 1024 (55.6 / 50.5 / 58.0).
+// The narrow shapes take 128-row blocks while that leaves at least ~2 blocks per CU, else 64.
+template <int NP, bool CONV>
+int stream_dispatch(const StreamCall &c, hipStream_t s)
 {
-    const int mblocks = (M + 32 * TI - 1) / (32 * TI), nblocks = (N + kBN - 1) / kBN;
-    const long long grid = (long long)((mblocks + 7) / 8) * 8 * nblocks;
-    if (grid > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
-    if ((long long)(M + 256) * N * 4 < 0xC0000000LL) {   // buffer-store epilogue (tensors < 3 GiB)
-        if (relu)
-            hipLaunchKernelGGL((split_gemm_stream_kernel<NP, TI, true, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
-                               M, K, N, mblocks, nblocks);
-        else
-            hipLaunchKernelGGL((split_gemm_stream_kernel<NP, TI, false, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y,
-                               M, K, N, mblocks, nblocks);
-        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    const int f = forced_ti();
+    const long long pieces = c.ksplit > 1 ? c.ksplit : 1;
+    if (c.N <= 64) {
+        const bool big = f ? f >= 2 : (long long)((c.M + 127) / 128) * pieces >= 2LL * num_cus();
+        return big ? launch_stream<NP, 2, 1, 2, CONV>(c, s) : launch_stream<NP, 1, 1, 2, CONV>(c, s);
     }
-    if (relu)
-        hipLaunchKernelGGL((split_gemm_stream_kernel<NP, TI, true>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y, M, K,
-                           N, mblocks, nblocks);
-    else
-        hipLaunchKernelGGL((split_gemm_stream_kernel<NP, TI, false>), dim3((unsigned)grid), dim3(kThreads), 0, s, x, wp, bias, y, M, K,
-                           N, mblocks, nblocks);
-    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+    if (c.N <= 128) {
+        const bool big = f ? f >= 4 : (long long)((c.M + 127) / 128) * pieces >= 2LL * num_cus();
+        return big ? launch_stream<NP, 4, 1, 4, CONV>(c, s) : launch_stream<NP, 2, 1, 4, CONV>(c, s);
+    }
+    if constexpr (CONV) {   // (three row tiles of the convolution form do not fit the register file with three pieces)
+        const bool big = f ? f >= 4 : (long long)((c.M + 127) / 128) * ((c.N + 255) / 256) * pieces >= 2LL * num_cus();
+        return big ? launch_stream<NP, 4, 2, 4, CONV>(c, s) : launch_stream<NP, 2, 2, 4, CONV>(c, s);
+    } else {
+        switch (f ? f : (c.K >= 512 ? 3 : 2)) {
+        case 1:
+        case 2: return launch_stream<NP, 2, 2, 4, CONV>(c, s);
+        case 4: return launch_stream<NP, 4, 2, 4, CONV>(c, s);
+        default: return launch_stream<NP, 3, 2, 4, CONV>(c, s);
+        }
+    }
 }
 
 }  // namespace
@@ -315,7 +442,7 @@ namespace tfm {
 int linear_stream_set_ti(int v)
 {
     const int prev = forced_ti();
-    g_ti.store(v >= 2 && v <= 4 ? v : 0);
+    g_ti.store(v >= 1 && v <= 4 ? v : 0);
     return prev;
 }
 }  // namespace tfm
@@ -347,22 +474,41 @@ extern "C" int tf_linear_pack_weight_f32(const float *w, void *packed, int K, in
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-extern "C" int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias, float *y, int64_t M, int K, int N,
-                                    int relu, int terms, void *stream)
+extern "C" int tf_linear_packed_f32(const float *x, const void *w_packed, const float *bias, const float *residual, float *y,
+                                    int64_t M, int K, int N, int relu, int terms, void *stream)
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
     const int np = split_pieces(terms);
     if (M <= 0 || K <= 0 || N <= 0 || (K % 64) != 0 || M > 0x7fffffffLL || np == 0) return TF_MSDA_ERR_BAD_DIMS;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed)) & 15) return TF_MSDA_ERR_BAD_DIMS;
-    const u32x4 *wp = static_cast<const u32x4 *>(w_packed);
+    if ((long long)(M + 256) * N * 4 >= 0xC0000000LL) return TF_MSDA_ERR_BAD_DIMS;   // buffer-resource offsets (the caller keeps tf_linear_split_f32)
+    StreamCall c{x, static_cast<const u32x4 *>(w_packed), bias, residual, y, (int)M, K, N, relu, false, StreamConv{}, nullptr, 1};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    auto go = [&](auto npc) {
-        constexpr int NP = decltype(npc)::value;
-        switch (choose_ti(K)) {
-        case 2: return launch_stream<NP, 2>(x, wp, bias, y, (int)M, K, N, relu, s);
-        case 4: return launch_stream<NP, 4>(x, wp, bias, y, (int)M, K, N, relu, s);
-        default: return launch_stream<NP, 3>(x, wp, bias, y, (int)M, K, N, relu, s);
-        }
-    };
-    return np == 3 ? go(std::integral_constant<int, 3>{}) : go(std::integral_constant<int, 2>{});
+    return np == 3 ? stream_dispatch<3, false>(c, s) : stream_dispatch<2, false>(c, s);
+}
+
+extern "C" int tf_conv_packed_f32(const float *x, const void *w_packed, const float *bias, const float *residual, float *y,
+                                  float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int ks, int stride,
+                                  int relu, int terms, void *stream)
+{
+    if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
+    const int np = split_pieces(terms);
+    if (nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % 64) != 0 || (stride != 1 && stride != 2) || (ks != 1 && ks != 3) ||
+        np == 0 || ksplit < 1 || ksplit > 64)
+        return TF_MSDA_ERR_BAD_DIMS;
+    if (ksplit > 1 && !workspace) return TF_MSDA_ERR_NULL_POINTER;
+    const int pad = ks == 3 ? 1 : 0;
+    StreamConv cv{nimg, hin, win, cin, (hin + 2 * pad - ks) / stride + 1, (win + 2 * pad - ks) / stride + 1, ks, pad, stride};
+    const long long M = (long long)nimg * cv.hout * cv.wout;
+    // every byte offset of the input and the output below the out-of-range marker of the buffer resources (3 GiB)
+    if (M <= 0 || (M + 256) * cout * 4 >= 0xC0000000LL || (long long)nimg * hin * win * cin * 4 >= 0xC0000000LL) return TF_MSDA_ERR_BAD_DIMS;
+    uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed);
+    if (ksplit > 1) {
+        if (cout & 3) return TF_MSDA_ERR_BAD_DIMS;
+        al |= reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual);
+    }
+    if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
+    StreamCall c{x, static_cast<const u32x4 *>(w_packed), bias, residual, y, (int)M, ks * ks * cin, cout, relu, true, cv, workspace, ksplit};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    return np == 3 ? stream_dispatch<3, true>(c, s) : stream_dispatch<2, true>(c, s);
 }

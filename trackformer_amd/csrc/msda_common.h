@@ -47,6 +47,8 @@ void pquad_set_trace(unsigned long long *device_buffer);
 
 // ffn_fused.hip: row tiles per block of tf_ffn_fused_f32 (1..3, default 3); returns the previous value
 int ffn_set_ti(int v);
+int ffn_tail_split();            // tf_ffn_fused_f32: the rows behind the full rounds of 64-row blocks go to 32-row blocks (0 / 1, default 1)
+int ffn_set_tail_split(int v);
 int linln_set_ti(int v);   // tf_linear_res_ln_f32 (1..3; 0 = by row count)
 // linear_stream.hip: row tiles per block of tf_linear_packed_f32 (2..4; 0 = per shape); returns the previous value
 int linear_stream_set_ti(int v);

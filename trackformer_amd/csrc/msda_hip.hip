@@ -23,13 +23,17 @@
 //   msda_fwd_f32_direct         fp32, D == 32, P == 4 (every TrackFormer config with hidden 256): no
 //                               staging prologue, tap arithmetic computed once per pair and shared
 //                               inside the wave.  THE DEFAULT for decoder-shaped calls.
-//   msda_fwd_f32_quad           encoder shape (Lq == S): data-adaptive LDS windows, 4 lanes per pair
-//                               (msda_fwd_quad.h).  THE DEFAULT for encoder-shaped calls.
-//   msda_fwd_f32_win            encoder shape only, opt-in: the first LDS-window kernel (8 lanes per pair).
+//   msda_fwd_f32_direct9        the same for D == 36 (hidden 288): nine lanes per pair.
+//   msda_fwd_f32_pquad          encoder shape (Lq == S): persistent workgroups, data-adaptive LDS windows, 4 lanes per
+//                               pair (msda_pquad.hip).  THE DEFAULT for encoder-shaped calls.
+//   msda_fwd_f32_quad           the one-tile-per-workgroup form of it (msda_fwd_quad.h): taken when pquad declines
+//                               (4-d reference points of two-stage models, pquad switched off).
 //   msda_bwd_rowgather<T,...>   any dtype; fuses the reference's two backward kernels.
 //   msda_bwd_f32_buf<P,ROWATOM> fp32 fast path: buffer loads + buffer atomics (full-row scatter for D == 32).
-//   msda_bwd_f32_sorted         encoder shape, D == 32, P == 4: contributions counting-sorted by destination
+//   msda_bwd_f32_sorted2        encoder shape, D == 32, P == 4: contributions counting-sorted by destination
 //                               row in LDS, one global atomic per row.  THE DEFAULT for encoder backward.
+// Removed in round 4 (superseded, no default route reached them; measurements in DESIGN.md section 4.1):
+// msda_fwd_f32_win (the first LDS-window kernel, 8 lanes per pair) and msda_bwd_f32_sorted (the first sorted backward).
 // Common rules: level geometry comes from the kernel arguments (host-shape entry points) or from the
 // reference's device-resident int64 tensor (..._dshapes) -- never a host<->device sync; no kernel
 // branches per tap; nothing depends on CUDA-style 32-wide warps.
@@ -750,24 +754,11 @@ msda_fwd_f32_direct9(const DirectArgs da, const LevelTable lt, const int64_t *__
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward, encoder shape, fp32, D == 32, P == 4, L <= 4: data-adaptive LDS windows (all levels resident)
+// 2-D query tiles of the sorted backward kernel (512 threads, 8 lanes per (query, head) pair, up to two passes of 64
+// pairs).  The forward kernel that introduced this geometry (msda_fwd_f32_win, round 1: 8 lanes per pair, all windows
+// resident) was superseded by the 4-lanes-per-pair LDS-window kernels (msda_fwd_quad.h, msda_pquad.hip) and removed
+// in round 4; its measurements stay in DESIGN.md section 4.1.
 // ---------------------------------------------------------------------------------------------
-// The row-gather kernels are bound by the vector-memory path (64 B/clk/CU for 1.46 GB of row gathers per
-// cfg-2 encoder launch); LDS serves ds_read_b128 at 256 B/clk/CU.  This kernel tiles the queries in 2-D,
-// keeps the wave-shared tap arithmetic of msda_fwd_f32_direct and sizes its LDS windows from the DATA
-// instead of from a guessed halo:
-//   * a workgroup (512 threads) owns the queries of one 2-D tile (TH x TW level-0 pixels plus the
-//     pixels of the other levels whose centres fall into the same normalised rectangle) for one head,
-//     and serves them in up to kWinPasses passes of 64 (query, head) pairs, 8 lanes per pair;
-//   * phase A: every lane computes the integer tap coordinates of the points it owns, and the
-//     workgroup reduces them to one bounding box per level (xor butterflies inside the wave, then
-//     ds_min / ds_max).  Attention heads sample along their own directions, so these boxes are much
-//     tighter than a symmetric halo around the tile;
-//   * phase B: the boxes (clamped to the tile footprint +- (HY, HX) pixels and to the LDS capacity)
-//     are streamed into LDS by LDS-DMA, all levels at once, rows unpadded (128 B);
-//   * phase C: as msda_fwd_f32_direct, but the taps are ds_read_b128 from the windows.  Taps outside
-//     the level read a zero row; points whose taps leave their window (clamped box) take buffer
-//     loads under a wave-uniform branch, so any input is handled exactly.
 constexpr int kWinThreads = 512;
 constexpr int kWinWaves = kWinThreads / 64;
 constexpr int kWinPasses = 2;
@@ -784,361 +775,6 @@ struct WinGeom {
     int tiles_y, tiles_x;
     int cap_rows;      // LDS rows for windows, all levels together (multiple of 8)
 };
-
-template <bool FUSED>
-__global__ void __launch_bounds__(kWinThreads, 4)
-msda_fwd_f32_win(const DirectArgs da, const LevelTable lt, const WinGeom wg)
-{
-    constexpr int PT = 4, D = 32, LPAIRS = kWinLevels / 2;
-    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
-    int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start          (48 ints)
-    int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb | qoff (84 ints)
-    int *s_bb = s_q + 5 * TF_MSDA_MAX_LEVELS + 4;                  // xmin xmax ymin ymax per level
-    // per-wave copy of the window geometry: wx0 wy0 wx1 wy1 | ww roff lvl_base -   (8 ints per level)
-    u32x4_t *s_geo = reinterpret_cast<u32x4_t *>(smem + 640);
-    u32x4_t *s_xo = reinterpret_cast<u32x4_t *>(smem + kWinHeaderBytes);
-    f32x4_t *s_xw = reinterpret_cast<f32x4_t *>(s_xo + kWinXchSlots);
-    u32x4_t *s_xg = reinterpret_cast<u32x4_t *>(s_xw + kWinXchSlots);
-    unsigned char *s_rows = smem + kWinRowsOffset;                 // row 0: zeros, then the windows
-
-    const int L = da.L, M = da.M, S = da.S, LP = L * PT;
-    const int m = blockIdx.x % M;
-    int t = blockIdx.x / M;
-    const int tx = t % wg.tiles_x;
-    t /= wg.tiles_x;
-    const int ty = t % wg.tiles_y;
-    const int b = t / wg.tiles_y;
-
-    if (threadIdx.x < 4 * kWinLevels) {
-        // thread 4l+k: bound k (ya, yb, xa, xb) of the pixels of level l whose centre lies in the tile's
-        // normalised rectangle -- integer exact, so that the tiles partition every level
-        const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
-        if (l < L) {
-            const unsigned H0 = (unsigned)lt.H[0], W0 = (unsigned)lt.W[0];
-            const unsigned Hl = (unsigned)lt.H[l], Wl = (unsigned)lt.W[l];
-            const unsigned y0 = (unsigned)ty * wg.TH, y1 = min(H0, y0 + (unsigned)wg.TH);
-            const unsigned x0 = (unsigned)tx * wg.TW, x1 = min(W0, x0 + (unsigned)wg.TW);
-            const unsigned num = k == 0 ? 2u * y0 * Hl + H0 - 1u : k == 1 ? 2u * y1 * Hl + H0 - 1u
-                                 : k == 2 ? 2u * x0 * Wl + W0 - 1u : 2u * x1 * Wl + W0 - 1u;
-            s_q[k * TF_MSDA_MAX_LEVELS + l] = (int)(num / (k < 2 ? 2u * H0 : 2u * W0));   // host: < 2^31
-            if (k == 0) {
-                s_tab[l] = lt.H[l];
-                s_tab[TF_MSDA_MAX_LEVELS + l] = lt.W[l];
-                s_tab[2 * TF_MSDA_MAX_LEVELS + l] = lt.start[l];
-            }
-        }
-    }
-    if (threadIdx.x < 4 * kWinLevels) s_bb[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
-    if (threadIdx.x < D) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dv = threadIdx.x & 7, sub = dv & 3, which = dv >> 2;
-    int qoff[kWinLevels + 1];   // first tile-local index of every level's queries
-    qoff[0] = 0;
-#pragma unroll
-    for (int l = 0; l < kWinLevels; ++l)
-        qoff[l + 1] = qoff[l] + (l < L ? (s_q[TF_MSDA_MAX_LEVELS + l] - s_q[l]) *
-                                             (s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l])
-                                       : 0);
-    const int nq = qoff[kWinLevels];   // <= kWinMaxQueries (the host checked the maximum)
-
-    // ---- the queries of this lane's group, one per pass; their sampling points ------------------
-    long long bqs[kWinPasses];
-    bool live[kWinPasses];
-    float sx[kWinPasses][LPAIRS], sy[kWinPasses][LPAIRS], sa[kWinPasses][LPAIRS];
-#pragma unroll
-    for (int ps = 0; ps < kWinPasses; ++ps) {
-        const int tq = ps * kWinPairs + (threadIdx.x >> 3);
-        int q = 0;
-        live[ps] = tq < nq;
-        if (live[ps]) {
-            int l = 0, base = 0;
-#pragma unroll
-            for (int k = 1; k < kWinLevels; ++k)
-                if (tq >= qoff[k] && k < L) {
-                    l = k;
-                    base = qoff[k];
-                }
-            const int r = tq - base;
-            const int nx = s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l];
-            const int yy = r / nx, xx = r - yy * nx;
-            q = s_tab[2 * TF_MSDA_MAX_LEVELS + l] + (s_q[l] + yy) * s_tab[TF_MSDA_MAX_LEVELS + l] +
-                s_q[2 * TF_MSDA_MAX_LEVELS + l] + xx;
-        }
-        bqs[ps] = (long long)b * S + q;
-        const long long pair = bqs[ps] * M + m;
-#pragma unroll
-        for (int i = 0; i < LPAIRS; ++i) {
-            const int ml = 2 * i + which;
-            const int s = (ml < L ? ml : 0) * PT + sub;
-            if constexpr (!FUSED) {
-                const float2 xy = *reinterpret_cast<const float2 *>(da.loc + (pair * LP + s) * 2);
-                sx[ps][i] = xy.x;
-                sy[ps][i] = xy.y;
-                sa[ps][i] = da.attn[pair * LP + s];
-            } else {
-                const float *row = da.fa.qproj + bqs[ps] * da.fa.ld;
-                const float2 off = *reinterpret_cast<const float2 *>(row + da.fa.off_col + (m * LP + s) * 2);
-                sx[ps][i] = off.x;
-                sy[ps][i] = off.y;
-                sa[ps][i] = ml < L ? row[da.fa.logit_col + m * LP + s] : -__builtin_inff();
-            }
-        }
-    }
-    if constexpr (FUSED) {
-#pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
-#pragma unroll
-        for (int ps = 0; ps < kWinPasses; ++ps) {
-            float mx = sa[ps][0];
-#pragma unroll
-            for (int i = 1; i < LPAIRS; ++i) mx = fmaxf(mx, sa[ps][i]);
-            mx = fmaxf(mx, __shfl_xor(mx, 1));
-            mx = fmaxf(mx, __shfl_xor(mx, 2));
-            mx = fmaxf(mx, __shfl_xor(mx, 4));
-            float sum = 0.f;
-#pragma unroll
-            for (int i = 0; i < LPAIRS; ++i) {
-                sa[ps][i] = (2 * i + which < L) ? __expf(sa[ps][i] - mx) : 0.f;
-                sum += sa[ps][i];
-            }
-            sum += __shfl_xor(sum, 1);
-            sum += __shfl_xor(sum, 2);
-            sum += __shfl_xor(sum, 4);
-#pragma unroll
-            for (int i = 0; i < LPAIRS; ++i) {
-                sa[ps][i] = sa[ps][i] / sum;
-                const int ml = (2 * i + which < L) ? 2 * i + which : 0;
-                const float *rp = da.fa.ref + (bqs[ps] * L + ml) * da.fa.ref_dim;
-                if (da.fa.ref_dim == 2) {
-                    sx[ps][i] = rp[0] + sx[ps][i] / (float)s_tab[ml];                       // x / H_l
-                    sy[ps][i] = rp[1] + sy[ps][i] / (float)s_tab[TF_MSDA_MAX_LEVELS + ml];  // y / W_l
-                } else {
-                    sx[ps][i] = rp[0] + sx[ps][i] / (float)PT * rp[2] * 0.5f;
-                    sy[ps][i] = rp[1] + sy[ps][i] / (float)PT * rp[3] * 0.5f;
-                }
-            }
-        }
-    }
-
-    // ---- phase A: bounding box of the valid taps, per level ------------------------------------
-    {
-        int mnx[LPAIRS], mxx[LPAIRS], mny[LPAIRS], mxy[LPAIRS];
-#pragma unroll
-        for (int i = 0; i < LPAIRS; ++i) {
-            mnx[i] = INT_MAX, mny[i] = INT_MAX, mxx[i] = INT_MIN, mxy[i] = INT_MIN;
-            const int ml = (2 * i + which < L) ? 2 * i + which : 0;
-            const int H = s_tab[ml], W = s_tab[TF_MSDA_MAX_LEVELS + ml];
-            const float Wf = (float)W, Hf = (float)H;
-#pragma unroll
-            for (int ps = 0; ps < kWinPasses; ++ps) {
-                const float xr = __builtin_fmaf(sx[ps][i], Wf, -0.5f);
-                const float yr = __builtin_fmaf(sy[ps][i], Hf, -0.5f);
-                const bool in = live[ps] && (2 * i + which < L) && (yr > -1.f) && (xr > -1.f) &&
-                                (yr < Hf) && (xr < Wf);
-                const int x0 = (int)__builtin_floorf(in ? xr : 0.f), y0 = (int)__builtin_floorf(in ? yr : 0.f);
-                const int xlo = x0 >= 0 ? x0 : x0 + 1, xhi = (x0 + 1 <= W - 1) ? x0 + 1 : x0;
-                const int ylo = y0 >= 0 ? y0 : y0 + 1, yhi = (y0 + 1 <= H - 1) ? y0 + 1 : y0;
-                if (in) {
-                    mnx[i] = min(mnx[i], xlo);
-                    mxx[i] = max(mxx[i], xhi);
-                    mny[i] = min(mny[i], ylo);
-                    mxy[i] = max(mxy[i], yhi);
-                }
-            }
-            // lanes with the same `which` (bit 2 of the lane id) hold points of the same level: reduce
-            // over lane bits 0, 1 and 3 with DPP (quad_perm xor 1, xor 2, row_ror:8), then one LDS
-            // atomic per 16-lane row and level
-#define TF_DPP(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xF, 0xF, true)
-#pragma unroll
-            for (int st = 0; st < 3; ++st) {
-                const int c0 = 0xB1, c1 = 0x4E, c2 = 0x128;
-                mnx[i] = min(mnx[i], st == 0 ? TF_DPP(mnx[i], c0) : st == 1 ? TF_DPP(mnx[i], c1) : TF_DPP(mnx[i], c2));
-                mxx[i] = max(mxx[i], st == 0 ? TF_DPP(mxx[i], c0) : st == 1 ? TF_DPP(mxx[i], c1) : TF_DPP(mxx[i], c2));
-                mny[i] = min(mny[i], st == 0 ? TF_DPP(mny[i], c0) : st == 1 ? TF_DPP(mny[i], c1) : TF_DPP(mny[i], c2));
-                mxy[i] = max(mxy[i], st == 0 ? TF_DPP(mxy[i], c0) : st == 1 ? TF_DPP(mxy[i], c1) : TF_DPP(mxy[i], c2));
-            }
-#undef TF_DPP
-            if ((lane & 0xB) == 0 && 2 * i + which < L && mnx[i] != INT_MAX) {
-                const int l = 2 * i + which;
-                atomicMin(&s_bb[4 * l + 0], mnx[i]);
-                atomicMax(&s_bb[4 * l + 1], mxx[i]);
-                atomicMin(&s_bb[4 * l + 2], mny[i]);
-                atomicMax(&s_bb[4 * l + 3], mxy[i]);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- phase B: window geometry (wave-uniform) and LDS-DMA staging ---------------------------
-    const unsigned rowbytes = (unsigned)(M * D) * 4u;
-    const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(da.value), 0, da.value_bytes, 0x00020000);
-    {
-        const int H0 = __builtin_amdgcn_readfirstlane(s_tab[0]);
-        const int W0 = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS]);
-        const float rH0 = __builtin_amdgcn_rcpf((float)H0), rW0 = __builtin_amdgcn_rcpf((float)W0);
-        const int y0t = ty * wg.TH, y1t = min(H0, y0t + wg.TH);
-        const int x0t = tx * wg.TW, x1t = min(W0, x0t + wg.TW);
-        int used = 0;
-        for (int l = 0; l < L; ++l) {
-            const int H = __builtin_amdgcn_readfirstlane(s_tab[l]);
-            const int W = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS + l]);
-            const unsigned lvl_base =
-                head_base + (unsigned)__builtin_amdgcn_readfirstlane(s_tab[2 * TF_MSDA_MAX_LEVELS + l]) * rowbytes;
-            const int bx0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 0]);
-            const int bx1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 1]);
-            const int by0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 2]);
-            const int by1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 3]);
-            // nominal footprint of the tile in this level (a clamp only: precision is irrelevant)
-            const int ny0 = (int)__builtin_floorf((float)y0t * (float)H * rH0 - 0.5f) - wg.HY;
-            const int ny1 = (int)__builtin_floorf((float)y1t * (float)H * rH0 - 0.5f) + 1 + wg.HY;
-            const int nx0 = (int)__builtin_floorf((float)x0t * (float)W * rW0 - 0.5f) - wg.HX;
-            const int nx1 = (int)__builtin_floorf((float)x1t * (float)W * rW0 - 0.5f) + 1 + wg.HX;
-            const int wx0 = max(max(bx0, nx0), 0), wx1 = min(min(bx1, nx1), W - 1);
-            const int wy0 = max(max(by0, ny0), 0), wy1 = min(min(by1, ny1), H - 1);
-            int ww = wx1 - wx0 + 1, wh = wy1 - wy0 + 1;
-            if (ww <= 0 || wh <= 0 || bx0 == INT_MAX) {
-                ww = 1;
-                wh = 0;
-            }
-            const int avail = wg.cap_rows - used;
-            if (wh * ww > avail) wh = avail / ww;   // keep the top of the box
-            const int roff = 1 + used;              // LDS row index of the window (row 0 = zeros)
-            const int nrows = wh * ww;
-            const int nchunks = (nrows + 7) >> 3;   // one DMA wave-instruction = 8 rows of 128 B
-            used += nchunks * 8;
-            if (lane == 0) {
-                s_geo[(wave * kWinLevels + l) * 2] =
-                    u32x4_t{(unsigned)wx0, (unsigned)wy0, (unsigned)(wx0 + ww - 1), (unsigned)(wy0 + wh - 1)};
-                s_geo[(wave * kWinLevels + l) * 2 + 1] = u32x4_t{(unsigned)ww, (unsigned)roff, lvl_base, 0u};
-            }
-            const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
-            for (int c = wave; c < nchunks; c += kWinWaves) {
-                const int row = c * 8 + (lane >> 3), col = lane & 7;
-                int wy = (int)(((float)row + 0.5f) * inv_ww);
-                int wx = row - wy * ww;
-                if (wx < 0) { --wy; wx += ww; }             // rcp is approximate: fix up the quotient
-                if (wx >= ww) { ++wy; wx -= ww; }
-                const unsigned off = row < nrows
-                    ? lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)col * 16u
-                    : kOobOffset;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                    rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128),
-                    16, off, 0, 0, 0);
-            }
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA landed
-    __syncthreads();                      // ... everybody's
-
-    // ---- phase C: gather -------------------------------------------------------------------------
-    const int xbase = wave * 72 + (lane >> 3) * 9;   // exchange slot of lane 0 of this group
-    const unsigned char *rb = s_rows + dv * 16;
-    const unsigned dvb = (unsigned)dv * 16u;
-#pragma unroll
-    for (int ps = 0; ps < kWinPasses; ++ps) {
-        if (ps * kWinPairs >= nq) break;   // uniform
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < LPAIRS; ++i) {
-            if (2 * i >= L) break;   // uniform
-            // produce: taps of this lane's point of the level pair (2i, 2i+1)
-            const bool have = 2 * i + which < L;
-            const int mlc = have ? 2 * i + which : 0;
-            const int H = s_tab[mlc], W = s_tab[TF_MSDA_MAX_LEVELS + mlc];
-            const u32x4_t ga = s_geo[(wave * kWinLevels + mlc) * 2], gb = s_geo[(wave * kWinLevels + mlc) * 2 + 1];
-            const int wx0 = (int)ga.x, wy0 = (int)ga.y, wx1 = (int)ga.z, wy1 = (int)ga.w;
-            const int ww = (int)gb.x, roff = (int)gb.y;
-            const unsigned lvl_base = gb.z;
-            const float Wf = (float)W, Hf = (float)H;
-            const float xr = __builtin_fmaf(sx[ps][i], Wf, -0.5f);   // cuh:227-228, single rounding
-            const float yr = __builtin_fmaf(sy[ps][i], Hf, -0.5f);
-            const bool in = have && live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
-            const float x = in ? xr : 0.f, y = in ? yr : 0.f;
-            const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
-            const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
-            const int x0 = (int)xf, y0 = (int)yf;
-            const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
-            const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
-            // lowest / highest VALID tap coordinate must lie inside the staged window
-            const int xlo = kx0 ? x0 : x0 + 1, xhi = kx1 ? x0 + 1 : x0;
-            const int ylo = ky0 ? y0 : y0 + 1, yhi = ky1 ? y0 + 1 : y0;
-            const bool staged = in && xlo >= wx0 && xhi <= wx1 && ylo >= wy0 && yhi <= wy1;
-            const bool fb = in && !staged;
-            const unsigned lo = (unsigned)(roff + (y0 - wy0) * ww + (x0 - wx0)) * 128u;
-            const u32x4_t plo = {(staged && ky0 && kx0) ? lo : 0u,                          // 0 = zero row
-                                 (staged && ky0 && kx1) ? lo + 128u : 0u,
-                                 (staged && ky1 && kx0) ? lo + (unsigned)ww * 128u : 0u,
-                                 (staged && ky1 && kx1) ? lo + (unsigned)(ww + 1) * 128u : 0u};
-            const float a = in ? sa[ps][i] : 0.f;
-            const f32x4_t pw = {gy * gx * a, gy * fx * a, fy * gx * a, fy * fx * a};
-            const bool wave_fb = __any(fb);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            s_xo[xbase + dv] = plo;
-            s_xw[xbase + dv] = pw;
-            if (wave_fb) {
-                const int r0 = y0 * W + x0;
-                // staged / invalid taps: kOobBase + dv*16 is still out of range -> hardware zero
-                s_xg[xbase + dv] = u32x4_t{
-                    (fb && ky0 && kx0) ? lvl_base + (unsigned)r0 * rowbytes : kOobBase,
-                    (fb && ky0 && kx1) ? lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase,
-                    (fb && ky1 && kx0) ? lvl_base + (unsigned)(r0 + W) * rowbytes : kOobBase,
-                    (fb && ky1 && kx1) ? lvl_base + (unsigned)(r0 + W + 1) * rowbytes : kOobBase};
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-
-            // consume: the 8 points of the level pair, produced by lanes 0..7 of the group
-#pragma unroll
-            for (int ll = 0; ll < 2; ++ll) {
-                if (2 * i + ll >= L) break;   // uniform
-#pragma unroll
-                for (int kk = 0; kk < 4; kk += 2) {   // two points (8 taps) in flight per lane
-                    f32x4_t v[2][4];
-                    f32x4_t w[2];
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const u32x4_t o = s_xo[xbase + ll * 4 + kk + k];
-                        w[k] = s_xw[xbase + ll * 4 + kk + k];
-                        v[k][0] = *reinterpret_cast<const f32x4_t *>(rb + o.x);
-                        v[k][1] = *reinterpret_cast<const f32x4_t *>(rb + o.y);
-                        v[k][2] = *reinterpret_cast<const f32x4_t *>(rb + o.z);
-                        v[k][3] = *reinterpret_cast<const f32x4_t *>(rb + o.w);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        acc += v[k][0] * w[k].x;
-                        acc += v[k][1] * w[k].y;
-                        acc += v[k][2] * w[k].z;
-                        acc += v[k][3] * w[k].w;
-                    }
-                    if (wave_fb) {   // some point of this wave left its window: global gather for those
-                        u32x4_t g[2][4];
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            const u32x4_t o = s_xg[xbase + ll * 4 + kk + k];
-                            g[k][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.x + dvb, 0, 0);
-                            g[k][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.y + dvb, 0, 0);
-                            g[k][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.z + dvb, 0, 0);
-                            g[k][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o.w + dvb, 0, 0);
-                        }
-#pragma unroll
-                        for (int k = 0; k < 2; ++k) {
-                            acc += __builtin_bit_cast(f32x4_t, g[k][0]) * w[k].x;
-                            acc += __builtin_bit_cast(f32x4_t, g[k][1]) * w[k].y;
-                            acc += __builtin_bit_cast(f32x4_t, g[k][2]) * w[k].z;
-                            acc += __builtin_bit_cast(f32x4_t, g[k][3]) * w[k].w;
-                        }
-                    }
-                }
-            }
-        }
-        if (live[ps]) *reinterpret_cast<f32x4_t *>(da.out + (bqs[ps] * M + m) * D + dv * 4) = acc;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // forward, encoder shape, fp32, D == 32, P == 4, L <= 4: LDS windows, 4 lanes per pair (DPP quads)
@@ -1177,344 +813,11 @@ struct BwdSortArgs {
     int S, M, L;
 };
 
-__global__ void __launch_bounds__(kWinThreads, 4)
-msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
-{
-    constexpr int PT = 4, D = 32, LPAIRS = kWinLevels / 2;
-    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
-    int *s_tab = reinterpret_cast<int *>(smem);                    // H | W | start          (48 ints)
-    int *s_q = s_tab + 3 * TF_MSDA_MAX_LEVELS;                     // ya | yb | xa | xb
-    int *s_bb = s_q + 5 * TF_MSDA_MAX_LEVELS + 4;                  // xmin xmax ymin ymax per level
-    int *s_direct = s_bb + 4 * kWinLevels;                         // per level: taps filed for direct scatter?
-    unsigned *s_cnt = reinterpret_cast<unsigned *>(smem + kSortOffCnt);
-    unsigned *s_start = reinterpret_cast<unsigned *>(smem + kSortOffStart);
-    uint2 *s_item = reinterpret_cast<uint2 *>(smem + kSortOffItem);
-    uint2 *s_sorted = reinterpret_cast<uint2 *>(smem + kSortOffSorted);
-    float *s_go = reinterpret_cast<float *>(smem + kSortOffGo);
-
-    const int L = ba.L, M = ba.M, S = ba.S, LP = L * PT;
-    const int m = blockIdx.x % M;
-    int t = blockIdx.x / M;
-    const int tx = t % wg.tiles_x;
-    t /= wg.tiles_x;
-    const int ty = t % wg.tiles_y;
-    const int b = t / wg.tiles_y;
-
-    if (threadIdx.x < 4 * kWinLevels) {   // as msda_fwd_f32_win: exact partition of every level
-        const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
-        if (l < L) {
-            const unsigned H0 = (unsigned)lt.H[0], W0 = (unsigned)lt.W[0];
-            const unsigned Hl = (unsigned)lt.H[l], Wl = (unsigned)lt.W[l];
-            const unsigned y0 = (unsigned)ty * wg.TH, y1 = min(H0, y0 + (unsigned)wg.TH);
-            const unsigned x0 = (unsigned)tx * wg.TW, x1 = min(W0, x0 + (unsigned)wg.TW);
-            const unsigned num = k == 0 ? 2u * y0 * Hl + H0 - 1u : k == 1 ? 2u * y1 * Hl + H0 - 1u
-                                 : k == 2 ? 2u * x0 * Wl + W0 - 1u : 2u * x1 * Wl + W0 - 1u;
-            s_q[k * TF_MSDA_MAX_LEVELS + l] = (int)(num / (k < 2 ? 2u * H0 : 2u * W0));
-            if (k == 0) {
-                s_tab[l] = lt.H[l];
-                s_tab[TF_MSDA_MAX_LEVELS + l] = lt.W[l];
-                s_tab[2 * TF_MSDA_MAX_LEVELS + l] = lt.start[l];
-            }
-        }
-        s_bb[threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
-        if (threadIdx.x < kWinLevels) s_direct[threadIdx.x] = 0;
-    }
-    __syncthreads();
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int dv = threadIdx.x & 7, sub = dv & 3, which = dv >> 2;
-    const int pl = threadIdx.x >> 3;   // pair of this lane group inside a pass
-    int qoff[kWinLevels + 1];
-    qoff[0] = 0;
-#pragma unroll
-    for (int l = 0; l < kWinLevels; ++l)
-        qoff[l + 1] = qoff[l] + (l < L ? (s_q[TF_MSDA_MAX_LEVELS + l] - s_q[l]) *
-                                             (s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l])
-                                       : 0);
-    const int nq = qoff[kWinLevels];
-
-    long long bqs[kWinPasses];
-    bool live[kWinPasses];
-    f32x4_t gA[kWinPasses];
-#pragma unroll
-    for (int ps = 0; ps < kWinPasses; ++ps) {
-        const int tq = ps * kWinPairs + pl;
-        int q = 0;
-        live[ps] = tq < nq;
-        if (live[ps]) {
-            int l = 0, base = 0;
-#pragma unroll
-            for (int k = 1; k < kWinLevels; ++k)
-                if (tq >= qoff[k] && k < L) {
-                    l = k;
-                    base = qoff[k];
-                }
-            const int r = tq - base;
-            const int nx = s_q[3 * TF_MSDA_MAX_LEVELS + l] - s_q[2 * TF_MSDA_MAX_LEVELS + l];
-            const int yy = r / nx, xx = r - yy * nx;
-            q = s_tab[2 * TF_MSDA_MAX_LEVELS + l] + (s_q[l] + yy) * s_tab[TF_MSDA_MAX_LEVELS + l] +
-                s_q[2 * TF_MSDA_MAX_LEVELS + l] + xx;
-        }
-        bqs[ps] = (long long)b * S + q;
-        gA[ps] = *reinterpret_cast<const f32x4_t *>(ba.grad_out + (bqs[ps] * M + m) * D + dv * 4);
-        if (!live[ps]) gA[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4_t *>(s_go + (size_t)tq * D + dv * 4) = gA[ps];   // tile of grad_out
-    }
-
-    // ---- phase A: bounding box of the valid taps, per level (lane owns point `sub` of level 2i+which)
-#pragma unroll
-    for (int i = 0; i < LPAIRS; ++i) {
-        int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
-        const bool have = 2 * i + which < L;
-        const int ml = have ? 2 * i + which : 0;
-        const int H = s_tab[ml], W = s_tab[TF_MSDA_MAX_LEVELS + ml];
-        const float Wf = (float)W, Hf = (float)H;
-#pragma unroll
-        for (int ps = 0; ps < kWinPasses; ++ps) {
-            const float2 xy = *reinterpret_cast<const float2 *>(
-                ba.loc + ((bqs[ps] * M + m) * LP + ml * PT + sub) * 2);
-            const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);
-            const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
-            const bool in = live[ps] && have && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);
-            const int x0 = (int)__builtin_floorf(in ? xr : 0.f), y0 = (int)__builtin_floorf(in ? yr : 0.f);
-            if (in) {
-                mnx = min(mnx, x0 >= 0 ? x0 : x0 + 1);
-                mxx = max(mxx, (x0 + 1 <= W - 1) ? x0 + 1 : x0);
-                mny = min(mny, y0 >= 0 ? y0 : y0 + 1);
-                mxy = max(mxy, (y0 + 1 <= H - 1) ? y0 + 1 : y0);
-            }
-        }
-#define TF_DPP(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xF, 0xF, true)
-        mnx = min(mnx, TF_DPP(mnx, 0xB1)); mxx = max(mxx, TF_DPP(mxx, 0xB1));
-        mny = min(mny, TF_DPP(mny, 0xB1)); mxy = max(mxy, TF_DPP(mxy, 0xB1));
-        mnx = min(mnx, TF_DPP(mnx, 0x4E)); mxx = max(mxx, TF_DPP(mxx, 0x4E));
-        mny = min(mny, TF_DPP(mny, 0x4E)); mxy = max(mxy, TF_DPP(mxy, 0x4E));
-        mnx = min(mnx, TF_DPP(mnx, 0x128)); mxx = max(mxx, TF_DPP(mxx, 0x128));
-        mny = min(mny, TF_DPP(mny, 0x128)); mxy = max(mxy, TF_DPP(mxy, 0x128));
-#undef TF_DPP
-        if ((lane & 0xB) == 0 && have && mnx != INT_MAX) {
-            atomicMin(&s_bb[4 * ml + 0], mnx);
-            atomicMax(&s_bb[4 * ml + 1], mxx);
-            atomicMin(&s_bb[4 * ml + 2], mny);
-            atomicMax(&s_bb[4 * ml + 3], mxy);
-        }
-    }
-    __syncthreads();
-
-    const unsigned rowbytes = (unsigned)(M * D) * 4u;
-    const unsigned head_base = (unsigned)((((long long)b * S * M + m) * D) * 4);
-    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(ba.value), 0, ba.value_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_g =
-        __builtin_amdgcn_make_buffer_rsrc(ba.grad_value, 0, ba.value_bytes, 0x00020000);
-    const unsigned la = (unsigned)dv * 16u;
-    const int half = lane >> 5, ch = lane & 31;
-    const int H0 = __builtin_amdgcn_readfirstlane(s_tab[0]);
-    const int W0 = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS]);
-    const float rH0 = __builtin_amdgcn_rcpf((float)H0), rW0 = __builtin_amdgcn_rcpf((float)W0);
-    const int y0t = ty * wg.TH, y1t = min(H0, y0t + wg.TH);
-    const int x0t = tx * wg.TW, x1t = min(W0, x0t + wg.TW);
-    float rdx[kWinPasses][2], rdy[kWinPasses][2], rdot[kWinPasses][2];
-#pragma unroll
-    for (int ps = 0; ps < kWinPasses; ++ps)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) rdx[ps][h] = rdy[ps][h] = rdot[ps][h] = 0.f;
-
-    for (int l = 0; l < L; ++l) {
-        // ---- window of this level: bounding box of the tile's taps, clamped to the tile footprint
-        //      +- (HY, HX) and to kSortRowsCap rows (wave-uniform)
-        const int H = __builtin_amdgcn_readfirstlane(s_tab[l]);
-        const int W = __builtin_amdgcn_readfirstlane(s_tab[TF_MSDA_MAX_LEVELS + l]);
-        const unsigned lvl_base =
-            head_base + (unsigned)__builtin_amdgcn_readfirstlane(s_tab[2 * TF_MSDA_MAX_LEVELS + l]) * rowbytes;
-        const int bx0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 0]);
-        const int bx1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 1]);
-        const int by0 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 2]);
-        const int by1 = __builtin_amdgcn_readfirstlane(s_bb[4 * l + 3]);
-        const int ny0 = (int)__builtin_floorf((float)y0t * (float)H * rH0 - 0.5f) - wg.HY;
-        const int ny1 = (int)__builtin_floorf((float)y1t * (float)H * rH0 - 0.5f) + 1 + wg.HY;
-        const int nx0 = (int)__builtin_floorf((float)x0t * (float)W * rW0 - 0.5f) - wg.HX;
-        const int nx1 = (int)__builtin_floorf((float)x1t * (float)W * rW0 - 0.5f) + 1 + wg.HX;
-        const int wx0 = max(max(bx0, nx0), 0), wy0 = max(max(by0, ny0), 0);
-        int ww = min(min(bx1, nx1), W - 1) - wx0 + 1, wh = min(min(by1, ny1), H - 1) - wy0 + 1;
-        if (ww <= 0 || wh <= 0 || bx0 == INT_MAX || ww > kSortRowsCap) {
-            ww = 1;
-            wh = 0;
-        }
-        if (wh * ww > kSortRowsCap) wh = kSortRowsCap / ww;
-        const int wx1 = wx0 + ww - 1, wy1 = wy0 + wh - 1, nrows = wh * ww;
-        const float Wf = (float)W, Hf = (float)H;
-
-        // ---- a. reset counters and items
-        for (int i = threadIdx.x; i < nrows; i += kWinThreads) s_cnt[i] = 0u;
-        for (int i = threadIdx.x; i < kSortItems; i += kWinThreads) s_item[i].x = kSortInvalid;
-        __syncthreads();
-
-        // ---- b. taps of this level: grad_loc / grad_attn, and the grad_value items
-#pragma unroll
-        for (int ps = 0; ps < kWinPasses; ++ps) {
-            if (ps * kWinPairs >= nq) break;   // uniform
-            const long long pair = bqs[ps] * M + m;
-            const int tq = ps * kWinPairs + pl;
-#pragma unroll
-            for (int p = 0; p < PT; ++p) {
-                const int s = l * PT + p;
-                const float2 xy = *reinterpret_cast<const float2 *>(ba.loc + (pair * LP + s) * 2);
-                const float a = ba.attn[pair * LP + s];
-                const float xr = __builtin_fmaf(xy.x, Wf, -0.5f);   // cuh:350-351
-                const float yr = __builtin_fmaf(xy.y, Hf, -0.5f);
-                const bool in = live[ps] && (yr > -1.f) && (xr > -1.f) && (yr < Hf) && (xr < Wf);   // cuh:359
-                const float x = in ? xr : 0.f, y = in ? yr : 0.f;
-                const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
-                const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
-                const int x0 = (int)xf, y0 = (int)yf;
-                const bool kx0 = in && (x0 >= 0), kx1 = in && (x0 + 1 <= W - 1);
-                const bool ky0 = in && (y0 >= 0), ky1 = in && (y0 + 1 <= H - 1);
-                const bool k1 = ky0 && kx0, k2 = ky0 && kx1, k3 = ky1 && kx0, k4 = ky1 && kx1;
-                const int r0 = y0 * W + x0;
-                const unsigned t1 = lvl_base + (unsigned)r0 * rowbytes, t2 = t1 + rowbytes;
-                const unsigned t3 = t1 + (unsigned)W * rowbytes, t4 = t3 + rowbytes;
-                const f32x4_t v1 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k1 ? t1 + la : kOobOffset, 0, 0));
-                const f32x4_t v2 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k2 ? t2 + la : kOobOffset, 0, 0));
-                const f32x4_t v3 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k3 ? t3 + la : kOobOffset, 0, 0));
-                const f32x4_t v4 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, k4 ? t4 + la : kOobOffset, 0, 0));
-                const float w1 = gy * gx, w2 = gy * fx, w3 = fy * gx, w4 = fy * fx;
-                if (dv < 4) {   // lane t of the group files tap t (cuh:279,296-301)
-                    const int tx_ = x0 + (dv & 1), ty_ = y0 + (dv >> 1);
-                    const bool kt = dv == 0 ? k1 : dv == 1 ? k2 : dv == 2 ? k3 : k4;
-                    const float wt = (dv == 0 ? w1 : dv == 1 ? w2 : dv == 2 ? w3 : w4) * a;
-                    if (kt && wt != 0.f) {
-                        const bool inside = tx_ >= wx0 && tx_ <= wx1 && ty_ >= wy0 && ty_ <= wy1;
-                        const unsigned row = inside ? (unsigned)((ty_ - wy0) * ww + (tx_ - wx0))
-                                                    : (0x80000000u | (unsigned)(ty_ * W + tx_));
-                        s_item[(tq * PT + p) * 4 + dv] =
-                            uint2{row | ((unsigned)tq << 24), __builtin_bit_cast(unsigned, wt)};
-                        if (inside)
-                            atomicAdd(&s_cnt[row], 1u);
-                        else
-                            s_direct[l] = 1;   // benign race: every writer stores the same value
-                    }
-                }
-                // grad wrt attention weight / location: partial sums over this lane's 4 channels
-                const f32x4_t smp = v1 * w1 + v2 * w2 + v3 * w3 + v4 * w4;             // cuh:365
-                const f32x4_t ddx = (v2 - v1) * gy + (v4 - v3) * fy;                   // cuh:150-160
-                const f32x4_t ddy = (v3 - v1) * gx + (v4 - v2) * fx;                   // cuh:139-149
-                const f32x4_t pd = gA[ps] * smp, px = gA[ps] * ddx, py = gA[ps] * ddy;
-                float dot = (pd.x + pd.y) + (pd.z + pd.w);
-                float dx = (px.x + px.y) + (px.z + px.w);
-                float dy = (py.x + py.y) + (py.z + py.w);
-#pragma unroll
-                for (int off = 4; off > 0; off >>= 1) {
-                    dot += __shfl_xor(dot, off);
-                    dx += __shfl_xor(dx, off);
-                    dy += __shfl_xor(dy, off);
-                }
-                if ((s & 7) == dv) {   // lane dv keeps points dv and dv + 8
-                    rdx[ps][s >> 3] = dx * a * Wf;      // cuh:371,373
-                    rdy[ps][s >> 3] = dy * a * Hf;      // cuh:371,374
-                    rdot[ps][s >> 3] = dot;             // cuh:376
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- c. exclusive prefix sum of the row counts (wave 0; 16 consecutive rows per lane)
-        if (wave == 0) {
-            unsigned c[16], sum = 0;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int r = lane * 16 + k;
-                c[k] = r < nrows ? s_cnt[r] : 0u;
-                sum += c[k];
-            }
-            unsigned incl = sum;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned up = (unsigned)__shfl_up((int)incl, off);
-                if (lane >= off) incl += up;
-            }
-            unsigned run = incl - sum;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int r = lane * 16 + k;
-                if (r < nrows) {
-                    s_start[r] = run;
-                    s_cnt[r] = 0u;   // reused as the placement cursor
-                }
-                run += c[k];
-            }
-            if (lane == 63) s_start[nrows] = incl;   // number of binned items
-        }
-        __syncthreads();
-
-        // ---- d. place the binned items in row order
-        for (int i = threadIdx.x; i < kSortItems; i += kWinThreads) {
-            const uint2 it = s_item[i];
-            if (it.x != kSortInvalid && !(it.x & 0x80000000u)) {
-                const unsigned row = it.x & 0xFFFFFFu;
-                s_sorted[s_start[row] + atomicAdd(&s_cnt[row], 1u)] = it;
-            }
-        }
-        __syncthreads();
-
-        // ---- e. one half wave per destination row (lane = channel): sum the row's segment, one atomic
-        const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
-        for (int row = wave * 2 + half; row < nrows; row += 2 * kWinWaves) {
-            const unsigned beg = s_start[row], end = s_start[row + 1];
-            if (beg == end) continue;
-            float acc = 0.f;
-            for (unsigned k = beg; k < end; k += 4) {   // 4 independent LDS round trips in flight
-                uint2 it[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) it[j] = s_sorted[min(k + j, end - 1)];
-                float g[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = s_go[((it[j].x >> 24) & 0x7Fu) * D + ch];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (k + j < end) acc = __builtin_fmaf(__builtin_bit_cast(float, it[j].y), g[j], acc);
-            }
-            int wy = (int)(((float)row + 0.5f) * inv_ww);
-            int wx = row - wy * ww;
-            if (wx < 0) { --wy; wx += ww; }
-            if (wx >= ww) { ++wy; wx -= ww; }
-            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
-                acc, rsrc_g, lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)ch * 4u, 0, 0);
-        }
-        // ---- f. taps outside the window: scattered directly, still one full row per half wave
-        if (s_direct[l]) {
-            for (int i = wave * 2 + half; i < kSortItems; i += 2 * kWinWaves) {
-                const uint2 it = s_item[i];
-                if (it.x != kSortInvalid && (it.x & 0x80000000u)) {
-                    const float v = __builtin_bit_cast(float, it.y) * s_go[((it.x >> 24) & 0x7Fu) * D + ch];
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
-                        v, rsrc_g, lvl_base + (it.x & 0xFFFFFFu) * rowbytes + (unsigned)ch * 4u, 0, 0);
-                }
-            }
-        }
-        __syncthreads();   // items / counters are reused by the next level
-    }
-
-#pragma unroll
-    for (int ps = 0; ps < kWinPasses; ++ps) {
-        if (!live[ps]) continue;
-        const long long pair = bqs[ps] * M + m;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int s = dv + 8 * h;
-            if (s < LP) {
-                *reinterpret_cast<float2 *>(ba.grad_loc + (pair * LP + s) * 2) = float2{rdx[ps][h], rdy[ps][h]};
-                ba.grad_attn[pair * LP + s] = rdot[ps][h];
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// msda_bwd_f32_sorted2: the same algorithm with ~half the vector instructions (OPT-IN until timed on hardware:
-// tf_msda_set_option("bwd_sorted2", 1) / TF_MSDA_BWD_SORTED2=1).  msda_bwd_f32_sorted is bound by vector-ALU issue
-// (profiles/r01_msda_bwd_sorted_pmc.json: 84 % of its cycles, 9.9 k instructions per wave), spent in phase b and e:
+// msda_bwd_f32_sorted2: the algorithm above with ~half the vector instructions of its first implementation
+// (msda_bwd_f32_sorted, rounds 1-2: 292 -> 223 us at cfg 2, profiles/r03_optin_msda_variants.txt; removed in round 4).  That
+// kernel was bound by vector-ALU issue (profiles/r01_msda_bwd_sorted_pmc.json: 84 % of its cycles, 9.9 k instructions per
+// wave), spent in phase b and e:
 //   * phase b: the tap arithmetic of a point was repeated by the 8 lanes of its pair.  Here the lane that loaded the
 //     point in phase A (level 2i + which, point sub) computes it once, files the point's four grad_value items, and
 //     publishes offsets / weights through a per-wave LDS exchange (as msda_fwd_f32_direct);
@@ -1526,7 +829,7 @@ msda_bwd_f32_sorted(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
 //     tile's grad_out per item instead of a ds_read_b32 per channel and half wave), items as {byte offset of the
 //     query's grad_out row, weight}; the sums are transposed through LDS so that the global atomics still add to
 //     complete 128-byte rows (two rows per instruction).
-// Same LDS layout as msda_bwd_f32_sorted plus 1.5 KB per wave (exchange / transposition buffer): 70 528 B.
+// The first implementation's LDS layout (constants above) plus 1.5 KB per wave (exchange / transposition buffer): 70 528 B.
 constexpr int kSort2XchPerWave = 1536;
 constexpr int kSort2OffXch = kSortLdsBytes;
 constexpr int kSort2LdsBytes = kSort2OffXch + kWinWaves * kSort2XchPerWave;
@@ -2314,8 +1617,9 @@ bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, in
     return true;
 }
 
-// Encoder-shaped calls (Lq == S, host shapes, D == 32, P == 4, L <= 4) run msda_fwd_f32_quad by default;
-// TF_MSDA_TILED=0 / tf_msda_set_tiled(0) selects msda_fwd_f32_direct, 1 the older msda_fwd_f32_win.  Measured
+// Encoder-shaped calls (Lq == S, host shapes, D == 32 / 36, P == 4, L <= 4) run the LDS-window kernels by default
+// (msda_fwd_f32_pquad, or msda_fwd_f32_quad where that declines); TF_MSDA_TILED=0 / tf_msda_set_tiled(0) selects
+// msda_fwd_f32_direct.  (Mode 1 selected msda_fwd_f32_win, removed in round 4: it now means 2.)  Round-1 measurements
 // at the cfg-2 encoder shape (HIP graph of 20 launches, us per launch, plain / fused entry;
 // profiles/r01_msda_fwd_quad_harness.txt):
 //                                  init          local         uniform
@@ -2324,15 +1628,15 @@ bool buf_path_ok(const LevelTable &lt, bool host_shapes, int N, int S, int M, in
 //   msda_fwd_f32_quad (default)    36.0 / 44.4   60.0 / 70.4   76.4 / 89.5
 // init = what a default-initialised model produces (bench.py), local = reference point + N(0, 2 px),
 // uniform = rand over the level (no locality at all: every level falls back to buffer loads).
-std::atomic<int> g_tiled_mode{-1};   // -1: follow the environment, 0: off, 1: msda_fwd_f32_win, 2: msda_fwd_f32_quad
+std::atomic<int> g_tiled_mode{-1};   // -1: follow the environment, 0: row gathers (msda_fwd_f32_direct), 2: the LDS-window kernels
 int tiled_mode()
 {
     const int g = g_tiled_mode.load(std::memory_order_relaxed);
     if (g >= 0) return g;
     static const int env_mode = [] {
-        const char *e = getenv("TF_MSDA_TILED");   // unset: msda_fwd_f32_quad; 0: off; 1: msda_fwd_f32_win
+        const char *e = getenv("TF_MSDA_TILED");   // unset: the LDS-window kernels; 0: off
         if (!e || !e[0]) return 2;
-        return e[0] == '0' ? 0 : e[0] == '1' ? 1 : 2;
+        return e[0] == '0' ? 0 : 2;
     }();
     return env_mode;
 }
@@ -2357,67 +1661,7 @@ long long tile_max_queries(const LevelTable &lt, int L, int th, int tw)
     return max_nq;
 }
 
-// Tile plan of msda_fwd_f32_win: the tile with the most queries that still fits kWinMaxQueries.
-bool plan_win(const LevelTable &lt, int L, int D, int P, WinGeom *wg, size_t *lds)
-{
-    if (tiled_mode() != 1 || D != 32 || P != 4 || L > kWinLevels) return false;
-    int hy = 6, hx = 10, th = 0, tw = 0, rows = 408;   // 408 rows (80 KB with the header): two workgroups per CU
-    if (const char *e = getenv("TF_MSDA_HALO")) sscanf(e, "%d,%d", &hy, &hx);
-    if (const char *e = getenv("TF_MSDA_TILE")) sscanf(e, "%d,%d", &th, &tw);
-    if (const char *e = getenv("TF_MSDA_WIN_ROWS")) rows = atoi(e);
-    rows &= ~7;
-    if (hy < 0 || hx < 0 || th < 0 || tw < 0 || rows < 8) return false;
-    for (int l = 0; l < L; ++l)
-        if (lt.H[l] >= 32768 || lt.W[l] >= 32768) return false;   // 32-bit tile arithmetic in the kernel
-    const size_t need = (size_t)kWinRowsOffset + (size_t)(1 + rows) * 128;
-    if (need > 160 * 1024) return false;
-    // the search below walks every tile of every candidate: remember the last plan of this thread
-    struct Memo {
-        bool valid = false, ok = false;
-        int L = 0;
-        LevelTable lt;
-        WinGeom wg;
-    };
-    static thread_local Memo memo;
-    if (memo.valid && memo.L == L && memcmp(&memo.lt, &lt, sizeof(lt)) == 0) {
-        *wg = memo.wg;
-        *lds = need;
-        return memo.ok;
-    }
-    memo.valid = true;
-    memo.ok = false;
-    memo.L = L;
-    memo.lt = lt;
-    long long best = 0;
-    int bth = 0, btw = 0;
-    const int tws[5] = {8, 16, 4, 2, 1};
-    for (int k = 0; k < 5; ++k) {
-        const int ctw = tw ? tw : tws[k];
-        for (int cth = th ? th : 16; cth >= (th ? th : 1); --cth) {
-            const long long nq = tile_max_queries(lt, L, cth, ctw);
-            if (nq >= 1 && nq <= kWinMaxQueries && nq > best) {
-                best = nq;
-                bth = cth;
-                btw = ctw;
-            }
-        }
-        if (tw || best >= kWinMaxQueries * 2 / 3) break;   // a row of 8 queries per wave is preferred
-    }
-    if (!best) return false;
-    wg->TH = bth;
-    wg->TW = btw;
-    wg->HY = hy;
-    wg->HX = hx;
-    wg->tiles_y = (lt.H[0] + bth - 1) / bth;
-    wg->tiles_x = (lt.W[0] + btw - 1) / btw;
-    wg->cap_rows = rows;
-    *lds = need;
-    memo.wg = *wg;
-    memo.ok = true;
-    return true;
-}
-
-// Tile plan of msda_bwd_f32_sorted: the tile search of plan_win without its LDS-capacity terms.
+// Tile plan of msda_bwd_f32_sorted2: the tile with the most queries that still fits kWinMaxQueries.
 bool plan_sorted(const LevelTable &lt, int L, int D, int P, WinGeom *wg)
 {
     static const int on = [] { const char *e = getenv("TF_MSDA_BWD_SORTED"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -2472,23 +1716,6 @@ bool plan_sorted(const LevelTable &lt, int L, int D, int P, WinGeom *wg)
 }
 
 bool raise_dynamic_lds_limit(const void *fn);   // per (function, device), below
-
-// Launch msda_fwd_f32_win for encoder-shaped calls (Lq == S, host shapes).  Returns false if not taken.
-bool launch_win(bool fused, const DirectArgs &da, const LevelTable &lt, int N, int D, int P,
-                hipStream_t stream, hipError_t *err)
-{
-    if (da.Lq != da.S) return false;
-    WinGeom wg;
-    size_t lds = 0;
-    if (!plan_win(lt, da.L, D, P, &wg, &lds)) return false;
-    const long long grid = (long long)N * wg.tiles_y * wg.tiles_x * da.M;
-    if (grid > 0x7fffffffLL) return false;
-    const void *fn = fused ? (const void *)&msda_fwd_f32_win<true> : (const void *)&msda_fwd_f32_win<false>;
-    if (!raise_dynamic_lds_limit(fn)) return false;
-    void *argv[] = {(void *)&da, (void *)&lt, (void *)&wg};
-    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kWinThreads), argv, lds, stream);
-    return true;
-}
 
 // ---- msda_fwd_f32_quad: options, tile plan, launch ----------------------------------------------------
 // Performance knobs (process-wide; tf_msda_set_option / TF_MSDA_QUAD="ta=12,waves=8,npass=1,lds=53,...").
@@ -2689,15 +1916,6 @@ bool direct_enabled()
     return on != 0;
 }
 
-std::atomic<int> g_bwd_sorted2{-1};   // -1: environment (TF_MSDA_BWD_SORTED2, default 1 since round 3: 292 -> 223 us `local`, 266 -> 255 us
-                                      // `init` at the cfg-2 encoder shape, profiles/r03_optin_msda_variants.txt)
-bool bwd_sorted2_enabled()
-{
-    const int v = g_bwd_sorted2.load(std::memory_order_relaxed);
-    if (v >= 0) return v != 0;
-    static const int env = [] { const char *e = getenv("TF_MSDA_BWD_SORTED2"); return (e && e[0] == '0') ? 0 : 1; }();
-    return env != 0;
-}
 // dynamic LDS above 64 KB needs the per-function, per-device attribute: set once per device for msda_bwd_f32_sorted2
 bool raise_dynamic_lds(const void *fn)
 {
@@ -2807,8 +2025,6 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                     return record_hip(e);
                 if (is_aligned(loc, 8) && shapes_dev == nullptr && launch_quad(false, da, lt, N, D, P, stream, &e))
                     return record_hip(e);
-                if (is_aligned(loc, 8) && shapes_dev == nullptr && launch_win(false, da, lt, N, D, P, stream, &e))
-                    return record_hip(e);
                 if (is_aligned(loc, 8) && launch_direct(false, da, lt, shapes_dev, D, P, stream, &e))
                     return record_hip(e);
             }
@@ -2871,8 +2087,6 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
             return record_hip(de);
         if (launch_quad(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
             return record_hip(de);
-        if (launch_win(true, da, lt, N, D, P, static_cast<hipStream_t>(stream_v), &de))
-            return record_hip(de);
         if (launch_direct(true, da, lt, nullptr, D, P, static_cast<hipStream_t>(stream_v), &de))
             return record_hip(de);
     }
@@ -2926,9 +2140,8 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
                 plan_sorted(lt, L, D, P, &sgeom) &&
                 (long long)N * sgeom.tiles_y * sgeom.tiles_x * M <= 0x7fffffffLL) {
                 BwdSortArgs ba{value, vbytes, loc, attn, grad_out, grad_value, grad_loc, grad_attn, S, M, L};
-                const bool v2 = bwd_sorted2_enabled();
-                const void *sfn = v2 ? (const void *)&msda_bwd_f32_sorted2 : (const void *)&msda_bwd_f32_sorted;
-                const size_t slds = v2 ? (size_t)kSort2LdsBytes : (size_t)kSortLdsBytes;
+                const void *sfn = (const void *)&msda_bwd_f32_sorted2;
+                const size_t slds = (size_t)kSort2LdsBytes;
                 if (slds > 64 * 1024 && !raise_dynamic_lds(sfn)) return record_hip(hipErrorInvalidValue);
                 void *argv[] = {(void *)&ba, (void *)&lt, (void *)&sgeom};
                 const unsigned sgrid = (unsigned)((long long)N * sgeom.tiles_y * sgeom.tiles_x * M);
@@ -2992,7 +2205,7 @@ int tf_msda_last_hip_error(void) { return g_last_hip_error; }
 
 int tf_msda_set_tiled(int mode)
 {
-    return g_tiled_mode.exchange(mode < 0 ? -1 : (mode == 2 ? 2 : (mode ? 1 : 0)));
+    return g_tiled_mode.exchange(mode < 0 ? -1 : (mode ? 2 : 0));
 }
 
 void tf_msda_debug_trace_buffer(void *device_buffer)
@@ -3012,9 +2225,9 @@ int tf_msda_set_option(const char *name, int value)
             g_quad_epoch.fetch_add(1);
             return prev;
         }
-    if (strcmp(name, "bwd_sorted2") == 0) return g_bwd_sorted2.exchange(value < 0 ? -1 : (value ? 1 : 0));
     if (strcmp(name, "direct9") == 0) return g_direct9.exchange(value < 0 ? -1 : (value ? 1 : 0));
     if (strcmp(name, "ffn_ti") == 0) return ffn_set_ti(value);
+    if (strcmp(name, "ffn_tail_split") == 0) return ffn_set_tail_split(value);
     if (strcmp(name, "linln_ti") == 0) return linln_set_ti(value);
     if (strcmp(name, "linear_stream_ti") == 0) return linear_stream_set_ti(value);
     if (strncmp(name, "pquad", 5) == 0) {

@@ -128,11 +128,21 @@ _PACKED_MIN_ROWS = 4096
 
 
 def _use_packed(M, K, N):
-    """Shapes tf_linear_packed_f32 is the faster kernel for: its 256-column blocks must be mostly full."""
+    """Shapes tf_linear_packed_f32 (the stream GEMM: weight fragments from L2, only the activations through LDS) is the faster
+    kernel for.  Its column blocks (64 / 128 / 256 wide) must be mostly full.  Six terms: every many-row shape with K >= 256 -- at
+    equal matrix work it beats the LDS-staged block kernel there (22 223 rows: 256 -> 256 23.9 vs 26.3 us, 256 -> 1024 67.5 vs
+    84.7, 1024 -> 256 65.6 vs 88.0, profiles/r04_pmc_dense_six_terms.txt; the reducing 1 x 1 convolutions of ResNet-50 25.2 vs
+    35.6 / 24.8 vs 28.9 / 35.9 vs 42.2 us) but not under a short K, where its prologue is most of the block (the expanding 1 x 1
+    convolutions with their residual: K = 64: 34.8 vs 30.4 us, K = 128: 28.8 vs 26.0; profiles/r04_conv_per_layer_stream_vs_block.txt).
+    Three terms: a wide output or a long K only (at K = 256, N <= 384 the many small blocks of the block kernel hide the memory
+    latency better: 21.4 vs 22.8 us)."""
     if not _packed_linear or M <= _PACKED_MIN_ROWS or K % 64:
         return False
     tail = N % 256
-    return (N >= 512 or K >= 512) and (tail == 0 or tail > 128)
+    full = N <= 128 or tail == 0 or tail > 128
+    if _split_terms == 6:
+        return full and K >= 256
+    return (N >= 512 or K >= 512) and full
 
 
 def set_packed_linear(on):
@@ -229,14 +239,14 @@ def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
     if residual is not None and not (residual.dtype == torch.float32 and residual.is_contiguous() and residual.device == x.device
                                      and residual.numel() == x2.shape[0] * N):
         return None
-    if residual is None and _use_packed(x2.shape[0], K, N) and not (x2.data_ptr() & 15):
+    if _use_packed(x2.shape[0], K, N) and not (x2.data_ptr() & 15) and (x2.shape[0] + 256) * N * 4 < 0xC0000000:
         packed = _packed_weight(weight, rows)
         if packed is not None:
             with torch.cuda.device(x.device):
                 y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
                 rc = _cabi.lib().tf_linear_packed_f32(x2.data_ptr(), packed.data_ptr(),
-                                                      0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0],
-                                                      K, N, 1 if relu else 0, _split_terms, _stream(x.device))
+                                                      0 if bias is None else bias.data_ptr(), _ptr(residual), y.data_ptr(),
+                                                      x2.shape[0], K, N, 1 if relu else 0, _split_terms, _stream(x.device))
             _cabi.check(rc, "tf_linear_packed_f32")
             return y.view(*x.shape[:-1], N)
     hi, mid, lo = _split_weight(weight)
@@ -568,14 +578,25 @@ def conv3x3(x, w_taps, bias, relu, stride):
     if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout
                                  and bias.device == x.device):
         return None
-    hi, mid, lo = _split_weight(w_taps)
-    if (x.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
-        return None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
     ksplit = _conv_ksplit(n * ho * wo, ks * ks * cin, cout)
     if ks == 1 and (ksplit < _CONV1X1_MIN_PIECES or not _conv1x1_splitk):
         ksplit = 1
+    if (_conv_stream and _conv_stream_wins(n * ho * wo, cout) and cin % 64 == 0 and not (x.data_ptr() & 15)
+            and n * h * w * cin * 4 < 0xC0000000 and (n * ho * wo + 256) * cout * 4 < 0xC0000000):
+        packed = _packed_weight(w_taps, None)
+        if packed is not None:
+            with torch.cuda.device(x.device):
+                y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+                ws = torch.empty((ksplit, n * ho * wo * cout), dtype=torch.float32, device=x.device) if ksplit > 1 else None
+                rc = _cabi.lib().tf_conv_packed_f32(x.data_ptr(), packed.data_ptr(), _ptr(bias), 0, y.data_ptr(), _ptr(ws), ksplit,
+                                                    n, h, w, cin, cout, ks, stride, 1 if relu else 0, _split_terms, _stream(x.device))
+            _cabi.check(rc, "tf_conv_packed_f32")
+            return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
+    hi, mid, lo = _split_weight(w_taps)
+    if (x.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
+        return None
     with torch.cuda.device(x.device):
         y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
         if ksplit > 1:   # few output pixels under a long K: split the K loop over workgroups (deterministic second pass)
@@ -592,6 +613,29 @@ def conv3x3(x, w_taps, bias, relu, stride):
 
 
 _conv_splitk = os.environ.get("TF_CONV_SPLITK", "1") not in ("", "0")
+
+# Round 4 (TF_CONV_STREAM=0 / set_conv_stream(False): the LDS-staged block kernel of linear_split.hip): the convolutions through
+# the stream GEMM (tf_conv_packed_f32, csrc/linear_stream.hip) -- weight fragments straight from L2, only the shifted input
+# pixels through LDS.  Same products in the same order: bit-identical without split-K.
+_conv_stream = os.environ.get("TF_CONV_STREAM", "1") not in ("", "0")
+_CONV_STREAM_ALL = os.environ.get("TF_CONV_STREAM") == "all"   # A/B aid: every shape through the stream form
+
+
+def _conv_stream_wins(m, cout):
+    """Where the stream form of the 3 x 3 / strided convolutions measured faster than the LDS-staged block kernel on MI355X
+    (profiles/r04_conv_per_layer_stream_vs_block.txt, 800 x 1333 frame): many output pixels under at least 128 output channels
+    -- layer2's 3 x 3 convolutions (six terms 47.5 vs 51.3 us, three terms 30.6 vs 34.9), its strided first one (45.9 vs 51.2 /
+    31.4 vs 36.4).  Not the 64-channel layer1 (two column tiles only: 47.7 vs 43.6 us) and not the few-pixel layers whose K loop
+    is cut into pieces (layer3 / layer4: 49.0 vs 46.9, 48.8 vs 48.6) -- there the two forms are within noise or the block kernel
+    wins, and it stays."""
+    return _CONV_STREAM_ALL or (cout >= 128 and m >= 8192)
+
+
+def set_conv_stream(on):
+    global _conv_stream
+    prev, _conv_stream = _conv_stream, bool(on)
+    return prev
+
 
 
 # Split-K policy of the 3 x 3 convolutions: (workgroups aimed at, launches with at least this many blocks are left alone,
