@@ -20,6 +20,9 @@ def _run(case, optin, fn=None):
                    fused.set_ffn_fused, fused.set_linear_ln_fused, fused.set_stem_pool_fused, fused.set_pos_add_fused,
                    fused.set_stem_conv_split, fused.set_heads_split]
         prev = [(s, s(bool(optin))) for s in setters]
+        # the stream form of the convolutions for EVERY shape (at the small test frame the default rule -- many output pixels
+        # under >= 128 channels -- would select it nowhere)
+        prev.append((fused.set_conv_stream, fused.set_conv_stream("all" if optin else False)))
         prev += [(lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
                  (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
         fused._LINLN_MIN_ROWS = 1

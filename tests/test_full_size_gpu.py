@@ -461,9 +461,10 @@ def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
     taps = w.permute(0, 2, 3, 1).reshape(cout, ks * ks * shape[1]).contiguous()
     prev = fused.set_split_terms(terms)
     try:
-        y = fused.conv3x3(x, taps, b, True, stride)          # the stream GEMM (tf_conv_packed_f32), the default route
-        prev_stream = fused.set_conv_stream(False)
+        prev_stream = fused.set_conv_stream("all")
         try:
+            y = fused.conv3x3(x, taps, b, True, stride)          # the stream GEMM (tf_conv_packed_f32)
+            fused.set_conv_stream(False)
             y_block = fused.conv3x3(x, taps, b, True, stride)   # the LDS-staged block kernel (tf_conv3x3_split_f32)
         finally:
             fused.set_conv_stream(prev_stream)

@@ -107,3 +107,45 @@ def test_gather_rows_equals_the_stack_for_every_mix_of_sources():
         assert torch.equal(_gather_rows(items), want), name
     scores = torch.rand(5, generator=g)
     assert torch.equal(_gather_rows([(scores, 4), (scores, 0)]), scores[[4, 0]])     # 1-d sources: the scores
+
+
+def test_rank_cpu_shares_follow_the_gpu_numa_map(monkeypatch):
+    """dist_utils._cpu_share: ranks whose GPUs share a NUMA node split that node's CPUs by their order among themselves, for any
+    GPU -> node mapping (contiguous, interleaved, uneven); an unknown node anywhere makes EVERY rank fall back to the even split,
+    so two ranks never end up on the same CPUs."""
+    from trackformer_amd import dist_utils as du
+    node_cpus = {0: set(range(0, 16)), 1: set(range(16, 32))}
+    monkeypatch.setattr(du, "_node_cpus", lambda n: node_cpus.get(n))
+    allowed = list(range(32))
+    for node_of in ([0, 0, 0, 0, 1, 1, 1, 1], [0, 1, 0, 1, 0, 1, 0, 1], [0, 0, 0, 0, 0, 0, 1, 1], [0, None, 0, 1, 1, 1, 0, 0]):
+        shares = [du._cpu_share(r, 8, allowed, node_of) for r in range(8)]
+        flat = [c for s in shares for c in s]
+        assert len(flat) == len(set(flat)) and all(shares), (node_of, shares)          # disjoint, nobody empty
+        if None not in node_of:
+            for r, s in enumerate(shares):
+                assert set(s) <= node_cpus[node_of[r]], (node_of, r, s)                # on the rank's own node
+            assert len(set(flat)) == 32                                                # every CPU of both nodes is used
+        else:
+            assert shares == [allowed[4 * r:4 * r + 4] for r in range(8)]              # everyone fell back together
+
+
+def test_host_nms_orders_nan_scores_first_and_keeps_input_order_among_ties():
+    """tf_nms_host_f32: stable descending order with NaN scores in front (torch.sort's placement); ties by input order."""
+    import ctypes
+
+    import numpy as np
+
+    from trackformer_amd import _cabi
+    try:
+        lib = _cabi.lib()
+    except RuntimeError:
+        import pytest
+        pytest.skip("libtf_msda.so not built")
+    boxes = np.array([[0, 0, 10, 10], [100, 100, 110, 110], [0, 0, 10, 10.5], [200, 200, 210, 210], [100, 100, 110, 111]], np.float32)
+    scores = np.array([0.5, float("nan"), float("inf"), 0.5, float("inf")], np.float32)
+    keep = np.zeros(5, np.int64)
+    n_keep = ctypes.c_int(0)
+    rc = lib.tf_nms_host_f32(boxes.ctypes.data, scores.ctypes.data, 5, ctypes.c_float(0.5), keep.ctypes.data, ctypes.byref(n_keep))
+    assert rc == 0
+    # order: NaN (1), then the two +inf in input order (2, 4), then the two 0.5 (0, 3); 4 overlaps 1 (IoU 0.91) and 0 overlaps 2
+    assert keep[:n_keep.value].tolist() == [1, 2, 3]

@@ -226,7 +226,14 @@ extern "C" int tf_nms_host_f32(const float *boxes, const float *scores, int n, f
     if (n < 0) return TF_MSDA_ERR_BAD_DIMS;
     std::vector<int> order((size_t)n);
     for (int i = 0; i < n; ++i) order[(size_t)i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+    // descending by score, ties in input order (tracker.py:493-495 relies on it for its +inf scores); a NaN score sorts in front
+    // of everything, as torch.sort(descending=True) places it -- `a > b` alone is not a strict weak ordering with NaNs (undefined
+    // behaviour in std::stable_sort)
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const float sa = scores[a], sb = scores[b];
+        const bool na = sa != sa, nb = sb != sb;
+        return na ? !nb : (!nb && sa > sb);
+    });
     std::vector<float> area((size_t)n);
     for (int i = 0; i < n; ++i) area[(size_t)i] = (boxes[4 * i + 2] - boxes[4 * i]) * (boxes[4 * i + 3] - boxes[4 * i + 1]);
     std::vector<char> dead((size_t)n, 0);

@@ -42,19 +42,40 @@ def _parse_cpulist(text):
     return cpus
 
 
-def _gpu_numa_cpus(local_rank):
-    """CPUs of the NUMA node the rank's GPU hangs off (sysfs), or None when the platform does not say."""
+def _gpu_numa_node(device_index):
+    """NUMA node the GPU hangs off (sysfs), or None when the platform does not say."""
     try:
-        props = torch.cuda.get_device_properties(local_rank)
+        props = torch.cuda.get_device_properties(device_index)
         bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
         with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
             node = int(f.read())
-        if node < 0:
-            return None
-        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
-            return _parse_cpulist(f.read())
+        return node if node >= 0 else None
     except (OSError, AttributeError, ValueError, RuntimeError, AssertionError):
         return None
+
+
+def _node_cpus(node):
+    try:
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            return _parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return None
+
+
+def _cpu_share(local_rank, local_world, allowed, node_of):
+    """The CPU slice of `local_rank`.  node_of: NUMA node of every local rank's GPU (None where unknown).  Every rank computes the
+    same table from sysfs, so the ranks agree without a collective: when ALL nodes are known, the ranks whose GPUs share a node
+    split that node's CPUs by their order among themselves (whatever the GPU -> node mapping looks like: contiguous, interleaved,
+    uneven); when any is unknown, every rank falls back to an even split of the allowed CPUs by local rank."""
+    if all(n is not None for n in node_of):
+        mine = node_of[local_rank]
+        cpus = _node_cpus(mine)
+        pool = sorted(set(allowed) & cpus) if cpus else []
+        peers = [r for r in range(local_world) if node_of[r] == mine]
+        if pool and len(pool) >= len(peers):
+            k = peers.index(local_rank)
+            return pool[len(pool) * k // len(peers):len(pool) * (k + 1) // len(peers)]
+    return allowed[len(allowed) * local_rank // local_world:len(allowed) * (local_rank + 1) // local_world]
 
 
 def pin_rank_to_cpus(local_rank, local_world, max_threads=16):
@@ -65,18 +86,13 @@ def pin_rank_to_cpus(local_rank, local_world, max_threads=16):
     if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
         return []
     allowed = sorted(os.sched_getaffinity(0))
-    node = _gpu_numa_cpus(local_rank) if torch.cuda.is_available() else None
-    pool = sorted(set(allowed) & node) if node else allowed
-    if node and len(pool) * 2 >= len(allowed) // max(1, local_world):
-        # ranks that share the node split it: rank order inside the node = local_rank order (even split assumed)
-        nodes = max(1, round(len(allowed) / max(1, len(pool))))
-        per_node = max(1, local_world // nodes)
-        k = local_rank % per_node
-        share = pool[len(pool) * k // per_node:len(pool) * (k + 1) // per_node]
-    else:
-        share = allowed[len(allowed) * local_rank // local_world:len(allowed) * (local_rank + 1) // local_world]
+    have = torch.cuda.is_available() and torch.cuda.device_count() >= local_world
+    node_of = [_gpu_numa_node(r) if have else None for r in range(local_world)]
+    share = _cpu_share(local_rank, local_world, allowed, node_of)
     if not share:
         return []
+    # (call this before anything starts a thread pool: sched_setaffinity(0) moves the calling thread, and the threads created
+    # afterwards inherit its mask -- bench.py and engine.py call it right after reading the rank environment)
     os.sched_setaffinity(0, share)
     torch.set_num_threads(max(1, min(max_threads, len(share))))
     return share

@@ -618,7 +618,7 @@ _conv_splitk = os.environ.get("TF_CONV_SPLITK", "1") not in ("", "0")
 # the stream GEMM (tf_conv_packed_f32, csrc/linear_stream.hip) -- weight fragments straight from L2, only the shifted input
 # pixels through LDS.  Same products in the same order: bit-identical without split-K.
 _conv_stream = os.environ.get("TF_CONV_STREAM", "1") not in ("", "0")
-_CONV_STREAM_ALL = os.environ.get("TF_CONV_STREAM") == "all"   # A/B aid: every shape through the stream form
+_CONV_STREAM_ALL = os.environ.get("TF_CONV_STREAM") == "all"   # A/B aid / tests: every shape through the stream form
 
 
 def _conv_stream_wins(m, cout):
@@ -632,8 +632,10 @@ def _conv_stream_wins(m, cout):
 
 
 def set_conv_stream(on):
-    global _conv_stream
-    prev, _conv_stream = _conv_stream, bool(on)
+    """True: where it measured faster (the default); "all": every shape (tests, A/B); False: never.  Returns the previous setting."""
+    global _conv_stream, _CONV_STREAM_ALL
+    prev = "all" if (_conv_stream and _CONV_STREAM_ALL) else _conv_stream
+    _conv_stream, _CONV_STREAM_ALL = bool(on), on == "all"
     return prev
 
 
