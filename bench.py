@@ -487,15 +487,20 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
     kernel = {"0": "msda_fwd_f32_direct"}.get(mode, "msda_fwd_f32_pquad")
     if D != 32 and kernel == "msda_fwd_f32_pquad":
         kernel = "msda_fwd_f32_pquad<D=36>"   # head dimension 36 (hidden 288): 144-byte rows, 3 lanes x 12 channels
-    traffic = None
+    traffic = traffic_src = None
     try:
-        with open(os.path.join(REPO, "profiles", "r03_msda_fwd_pquad_traffic.json")) as f:
-            traffic = json.load(f)[kernel]["hbm_traffic_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
+        import glob
+        newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_msda_fwd_pquad_traffic.json")))[-1]
+        with open(newest) as f:
+            tj = json.load(f)
+        traffic = tj[kernel]["hbm_traffic_bytes_per_launch"]
+        traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes; taken at commit %s)" % (
+            os.path.basename(newest), tj.get("_commit", "of round 3"))
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     return {"bound": "hbm", "kernel": kernel + " via tf_msda_forward_fused_f32 (encoder call, Lq=S=22223)",
             "achieved": head["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
-            "traffic": traffic, "algorithmic_bytes": alg, "avg_launch_us": head["avg_launch_us"],
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg, "avg_launch_us": head["avg_launch_us"],
             "launches": launches, "input_sets": sets,
             "pattern": "pert (perturbed-weight model sampling), Infinity-Cache-cold",
             "other_patterns": {k: v for k, v in per_pattern.items() if k != "pert"}}

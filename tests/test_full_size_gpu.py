@@ -205,7 +205,7 @@ def test_full_size_tracker_64_frame_sequence_against_reference(dev, models):
     assert float(z["min_score_margin"]) > 1e-2
     margins = z["nms_iou_margin_per_frame"]
     rows = z["rows"]
-    n_run = 40
+    n_run = 34
     gold = [sorted(int(r[0]) for r in rows[rows[:, 1] == f]) for f in range(n_run)]
 
     def first_below(thr):

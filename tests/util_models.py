@@ -192,11 +192,19 @@ def train_step(model, criterion, samples, targets, rng_seed=7):
     criterion.train()
     model.zero_grad()
     torch.manual_seed(rng_seed)      # host RNG of the track-query augmentation
-    outputs, targets, *_ = model(samples, targets)
-    loss_dict = criterion(outputs, targets)
-    weight_dict = criterion.weight_dict
-    losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
-    losses.backward()
+    # an earlier test of the process may have switched MIOpen's exhaustive search on (runtime.configure_inference): a training
+    # step would then time every solver for the forward / backward-data / backward-weight pass of ~50 convolution shapes --
+    # minutes of search for one step.  The immediate-mode choice computes the same convolutions.
+    prev_benchmark = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    try:
+        outputs, targets, *_ = model(samples, targets)
+        loss_dict = criterion(outputs, targets)
+        weight_dict = criterion.weight_dict
+        losses = sum(loss_dict[k] * weight_dict[k] for k in loss_dict.keys() if k in weight_dict)
+        losses.backward()
+    finally:
+        torch.backends.cudnn.benchmark = prev_benchmark
     grads = {n: float(p.grad.detach().double().norm()) for n, p in model.named_parameters()
              if p.grad is not None}
     return {k: float(v) for k, v in loss_dict.items()}, float(losses), grads
