@@ -341,7 +341,7 @@ static inline void hipemu_buffer_load_lds(const hipemu_buffer_rsrc &r, LdsPtr ld
 #define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds, size, voff, soff, imm, aux) \
     hipemu_buffer_load_lds((r), (lds), (size), (voff), (soff), (imm), __LINE__)
 
-// ---- MFMA (gfx950 bf16 shapes): executed once per wave by the emulator with the hardware's fragment layout ---
+// ---- MFMA (gfx950 bf16 shapes + the 32 x 32 x 16 fp16 one): executed once per wave by the emulator with the hardware's fragment layout ---
 template <class AB, class CD>
 static inline CD hipemu_mfma(int kind, AB a, AB b, CD c, unsigned site)
 {
@@ -352,5 +352,6 @@ static inline CD hipemu_mfma(int kind, AB a, AB b, CD c, unsigned site)
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma(::hipemu::kOpMfma32x32x16Bf16, (a), (b), (c), __LINE__)
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma(::hipemu::kOpMfma16x16x32Bf16, (a), (b), (c), __LINE__)
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma(::hipemu::kOpMfma32x32x16F16, (a), (b), (c), __LINE__)
 
 #endif  // TF_HIPEMU_HIP_RUNTIME_H_

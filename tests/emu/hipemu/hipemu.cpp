@@ -133,6 +133,28 @@ float bf16_to_float(uint16_t b)
     return f;
 }
 
+float f16_to_float(uint16_t h)   // IEEE binary16 incl. subnormals, infinities and NaNs
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) {
+            u = sign;
+        } else {   // subnormal: m * 2^-24
+            float f = (float)m * (1.0f / 16777216.0f);
+            memcpy(&u, &f, 4);
+            u |= sign;
+        }
+    } else if (e == 31) {
+        u = sign | 0x7f800000u | (m << 13);
+    } else {
+        u = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
 // Executes one wave operation for the lanes in `grp` (all at the same site and kind).
 void exec_group(Engine *e, Fiber **wave_lanes, int nlanes, const std::vector<int> &grp)
 {
@@ -184,9 +206,10 @@ void exec_group(Engine *e, Fiber **wave_lanes, int nlanes, const std::vector<int
         break;
     }
     case kOpMfma32x32x16Bf16:
+    case kOpMfma32x32x16F16:
     case kOpMfma16x16x32Bf16: {
-        // in: 8 bf16 of A, in2: 8 bf16 of B, in3: C (16 or 4 floats), out: D.  All 64 lanes must be active.
-        const bool big = first->kind == kOpMfma32x32x16Bf16;
+        // in: 8 bf16 (fp16) of A, in2: 8 of B, in3: C (16 or 4 floats), out: D.  All 64 lanes must be active.
+        const bool big = first->kind != kOpMfma16x16x32Bf16, half = first->kind == kOpMfma32x32x16F16;
         const int MN = big ? 32 : 16, K = big ? 16 : 32, NR = big ? 16 : 4;
         if ((int)grp.size() != kWave) {
             fprintf(stderr, "hipemu: MFMA with %zu active lanes\n", grp.size());
@@ -198,8 +221,8 @@ void exec_group(Engine *e, Fiber **wave_lanes, int nlanes, const std::vector<int
             const uint16_t *b = (const uint16_t *)wave_lanes[l]->req->in2;
             const int rc = l % MN, k0 = 8 * (l / MN);
             for (int i = 0; i < 8; ++i) {
-                A[rc][k0 + i] = bf16_to_float(a[i]);
-                B[rc][k0 + i] = bf16_to_float(b[i]);
+                A[rc][k0 + i] = half ? f16_to_float(a[i]) : bf16_to_float(a[i]);
+                B[rc][k0 + i] = half ? f16_to_float(b[i]) : bf16_to_float(b[i]);
             }
         }
         for (int l = 0; l < kWave; ++l) {
@@ -208,7 +231,7 @@ void exec_group(Engine *e, Fiber **wave_lanes, int nlanes, const std::vector<int
             const int col = l % MN;
             for (int r = 0; r < NR; ++r) {
                 const int row = big ? (r & 3) + 8 * (r >> 2) + 4 * (l >> 5) : 4 * (l >> 4) + r;
-                double acc = 0.0;   // products of bf16 pairs are exact in fp32; the sum is rounded once here
+                double acc = 0.0;   // products of bf16 / fp16 pairs are exact in fp32; the sum is rounded once here
                 for (int k = 0; k < K; ++k) acc += (double)A[row][k] * (double)B[col][k];
                 d[r] = (float)((double)c[r] + acc);
             }

@@ -50,6 +50,7 @@ enum OpKind : int {
     kOpVote,           // out (uint64) = ballot of (in != 0); aux out: exec mask
     kOpMfma32x32x16Bf16,
     kOpMfma16x16x32Bf16,
+    kOpMfma32x32x16F16,
     kOpLdsDma,         // in: 16/4 bytes of data fetched by the lane; lds base = first active lane's pointer
     kOpLdsTrack16,     // in: the lane's 32-bit LDS address of a ds_read_b128; accounting only (HIPEMU_LDS_TRACK=1)
 };

@@ -165,9 +165,9 @@ TERMS = 6   # terms per split product of the wrappers below (include/tf_fused.h:
 
 
 def set_terms(n):
-    """3 or 6; returns the previous value."""
+    """3, 6 (bf16 pieces) or 16 (fp16 pieces, three terms); returns the previous value."""
     global TERMS
-    assert n in (3, 6)
+    assert n in (3, 6, 16)
     prev, TERMS = TERMS, n
     return prev
 
@@ -186,7 +186,7 @@ def bf16_split(w, terms=None):
     hi = to_bf16(w)
     r = w - to_f32(hi)
     mid = to_bf16(r)
-    lo = to_bf16(r - to_f32(mid)) if (terms or TERMS) == 6 else None
+    lo = to_bf16(r - to_f32(mid)) if (terms or TERMS) != 3 else None
     return hi, mid, lo
 
 

@@ -545,6 +545,17 @@ def test_cfg1_plain_detr_480x640_matches_reference(dev, split):
     print("cfg1_full / %s: max |d boxes| %.2e, max |d logits| %.2e" % ("split" if split else "library", dbox, dlogit))
 
 
+@pytest.fixture
+def no_solver_search():
+    """The mask head's convolutions have one batch size per number of masks asked for; with `cudnn.benchmark` left on by an
+    earlier `runtime.configure_inference` MIOpen times its solvers for each of them (the three cfg-5 tests took 500 s of the
+    GPU suite: profiles/r04_pytest_durations.txt).  Correctness does not depend on the solver."""
+    prev = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = False
+    yield
+    torch.backends.cudnn.benchmark = prev
+
+
 def _cfg5_model(dev):
     from trackformer_amd import config, factory
     model, post, args = um.build("cfg5_full", factory.build_model, config.make_args, device=dev)
@@ -557,6 +568,7 @@ def test_cfg5_mask_head_800x1333_matches_reference(dev):
     query and the post-processed probabilities of the first three against the reference's classes on CPU."""
     model, post, args = _cfg5_model(dev)
     img, _, target = um.model_inputs("cfg5_full", args.hidden_dim)
+    torch.backends.cudnn.benchmark = False   # see no_solver_search (this function is also called by the CPU suite: no fixture)
     with torch.no_grad():
         out, _, feats, memory, hs = model(img.to(dev), um.to_device(target, dev), None)
         sizes = torch.tensor([list(um.FULL_ORIG)], device=dev)
@@ -574,7 +586,7 @@ def test_cfg5_mask_head_800x1333_matches_reference(dev):
 
 
 @pytest.mark.parametrize("lazy", [False, True], ids=["masks_for_every_query", "lazy_masks"])
-def test_cfg5_tracker_with_masks_800x1333_matches_reference(dev, lazy):
+def test_cfg5_tracker_with_masks_800x1333_matches_reference(dev, lazy, no_solver_search):
     """The reference Tracker + mask head (tracker.py:521-547) over three 800 x 1333 frames: ids / frames / source queries exact,
     boxes and scores within tolerance, the mask area every track owns within 2 % of the image (full_tracker_cfg5.npz)."""
     from trackformer_amd import config

@@ -70,7 +70,7 @@ struct Geo {
     static constexpr int U1 = KQ1 / 2;                 // weight units of GEMM 1 per chunk (two k-steps of one tile each)
     static constexpr int U2 = CH / 16;                 // weight units of GEMM 2 per chunk (one k-step of TJ tiles each)
     static constexpr int UPC = U1 + U2;                // 16 / 15
-    static constexpr int us(int np) { return np * (TJ > 2 ? TJ : 2); }   // 16-byte pieces per lane and unit
+    static constexpr int us(int nb) { return nb * (TJ > 2 ? TJ : 2); }   // 16-byte pieces per lane and unit (nb weight pieces)
     static constexpr int RING = D == 256 ? 8 : 5;      // units in the ring (divides UPC: a unit's slot is a compile-time constant)
     static constexpr int AHEAD = RING - 2;             // prefetch distance
     static_assert(TJ * NW * 32 == D && KQ1 % 2 == 0 && UPC % RING == 0, "geometry");
@@ -88,12 +88,12 @@ __device__ __forceinline__ void static_for(F &&f)   // f(integral_constant<int, 
 }
 
 template <int D>
-constexpr size_t ffn_lds_bytes(int ti, int np) { return (size_t)(32 * ti) * (Geo<D>::XS + Geo<D>::HS) * 2 * np; }
+constexpr size_t ffn_lds_bytes(int ti, int na) { return (size_t)(32 * ti) * (Geo<D>::XS + Geo<D>::HS) * 2 * na; }   // na activation pieces
 
-// ---- the block's activation tile (32 TI rows x D) -> LDS as bf16 hi / mid.  All of its global loads are in flight before the
+// ---- the block's activation tile (32 TI rows x D) -> LDS as its 16-bit pieces.  All of its global loads are in flight before the
 // first conversion waits.  The caller issues the barrier.
-template <int NP, int D, int TI>
-__device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, int m0, unsigned short *sX, int tid)   // sX: [NP][32 TI][XS]
+template <int SP, int D, int TI>
+__device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, int m0, unsigned short *sX, int tid)   // sX: [NA][32 TI][XS]
 {
     using G = Geo<D>;
     constexpr int C4 = D / 4, NV = TI * 32 * C4 / G::NT;   // float4 per row / per thread
@@ -111,10 +111,10 @@ __device__ __forceinline__ void stage_rows(const float *__restrict__ X, int M, i
     for (int it = 0; it < NV; ++it) {
         const int idx = it * G::NT + tid;
         const int row = idx / C4, c4 = idx - row * C4;
-        bf16x4 pc[NP];   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
-        split4<NP>(xr[it], pc);
+        u32x2 pc[Split<SP>::NA];   // round to nearest even, as torch's .to(bfloat16) / .to(float16)
+        split4<SP>(xr[it], pc);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(&sX[(p * TI * 32 + row) * G::XS + c4 * 4]) = pc[p];
+        for (int p = 0; p < Split<SP>::NA; ++p) *reinterpret_cast<u32x2 *>(&sX[(p * TI * 32 + row) * G::XS + c4 * 4]) = pc[p];
     }
 }
 
@@ -130,9 +130,10 @@ __device__ __forceinline__ float wave_partials(const float *s, int stride)
 // row m0 + 32 i + (lane & 31); registers 4 g .. 4 g + 3 of tile j -> columns 32 TJ wave + 32 j + 8 g + 4 (lane >> 5) + 0..3);
 // v: the residual values in the same layout on entry.  sRed: [2 passes][NW waves][BM] floats of LDS that alias a tile every
 // wave has finished reading once it reaches the first barrier in here.  Rows >= M: stores are dropped by the buffer resource.
-template <int D, int TI, bool LN>
+// F16 (the fp16 scheme of split_product.h): the accumulators are multiplied by their output channel's power of two (r: D floats).
+template <int D, int TI, bool LN, bool F16>
 __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][Geo<D>::TJ], f32x4 (&v)[TI][Geo<D>::TJ][4],
-                                              const __amdgpu_buffer_rsrc_t b2rs, const float *__restrict__ gamma,
+                                              const __amdgpu_buffer_rsrc_t b2rs, const float *__restrict__ r, const float *__restrict__ gamma,
                                               const float *__restrict__ beta, float eps, const __amdgpu_buffer_rsrc_t yrs, float *sRed,
                                               int m0, int wave, int lane)
 {
@@ -144,10 +145,13 @@ __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][Geo<D>::T
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b2rs, (unsigned)(cbase + 32 * j + 8 * g) * 4u, 0, 0));
+            f32x4 rv = {1.f, 1.f, 1.f, 1.f};
+            if constexpr (F16) rv = *reinterpret_cast<const f32x4 *>(r + cbase + 32 * j + 8 * g);
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[i][j][g][e] = (accy[i][j][4 * g + e] + b[e]) + v[i][j][g][e];
+                for (int e = 0; e < 4; ++e)
+                    v[i][j][g][e] = (F16 ? __builtin_fmaf(accy[i][j][4 * g + e], rv[e], b[e]) : accy[i][j][4 * g + e] + b[e]) + v[i][j][g][e];
         }
     if constexpr (LN) {
         // two-pass statistics over the D columns of a row: 16 TJ values in this lane, as many in lane ^ 32, the rest in the
@@ -207,7 +211,7 @@ __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][Geo<D>::T
                                                        (unsigned)((m0 + i * 32 + frow) * D + cbase + 32 * j + 8 * g) * 4u, 0, 0);
 }
 
-template <int NP, int D, int TI, bool LN>
+template <int SP, int D, int TI, bool LN>
 __global__ void __launch_bounds__(Geo<D>::NT, 1)
 ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, const float *__restrict__ b1,
                  const u32x4 *__restrict__ W2p, const float *__restrict__ b2, const float *R,
@@ -215,10 +219,11 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
 {
     using G = Geo<D>;
     constexpr int BM = TI * 32, TJ = G::TJ, NW = G::NW, XS = G::XS, HS = G::HS, RING = G::RING, UPC = G::UPC, U1 = G::U1, U2 = G::U2;
-    constexpr int US = G::us(NP);
+    constexpr int NA = Split<SP>::NA, NB = Split<SP>::NB, US = G::us(NB);
+    constexpr bool F16 = Split<SP>::F16;
     extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
-    unsigned short *const sX = s_f;                      // [NP][BM][XS]
-    unsigned short *const sH = s_f + NP * BM * XS;       // [NP][BM][HS]
+    unsigned short *const sX = s_f;                      // [NA][BM][XS]
+    unsigned short *const sH = s_f + NA * BM * XS;       // [NA][BM][HS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
@@ -233,21 +238,21 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
     auto load_unit = [&](int c, auto uc, u32x4 (&dst)[US]) {
         constexpr int u = decltype(uc)::value;
         if constexpr (u < U1) {
-            const u32x4 *base = W1p + ((size_t)min(c * NW + wave, ntiles1 - 1) * G::KQ1 * NP + u * 2 * NP) * 64 + lane;
+            const u32x4 *base = W1p + ((size_t)min(c * NW + wave, ntiles1 - 1) * G::KQ1 * NB + u * 2 * NB) * 64 + lane;
 #pragma unroll
-            for (int i = 0; i < 2 * NP; ++i) dst[i] = base[i * 64];
+            for (int i = 0; i < 2 * NB; ++i) dst[i] = base[i * 64];
         } else {
             const int q = min(c * U2 + (u - U1), KQ2 - 1);
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) dst[j * NP + p] = W2p[(((size_t)(TJ * wave + j) * KQ2 + q) * NP + p) * 64 + lane];
+                for (int p = 0; p < NB; ++p) dst[j * NB + p] = W2p[(((size_t)(TJ * wave + j) * KQ2 + q) * NB + p) * 64 + lane];
         }
     };
     // the first units first (they have the longest way), then the whole activation tile
     static_for<G::AHEAD>([&](auto uc) { load_unit(0, uc, ring[decltype(uc)::value]); });
     __builtin_amdgcn_sched_barrier(0);
-    stage_rows<NP, D, TI>(X, M, m0, sX, tid);
+    stage_rows<SP, D, TI>(X, M, m0, sX, tid);
     __syncthreads();
 
     f32x16 accy[TI][TJ];
@@ -258,6 +263,9 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
 #pragma unroll
             for (int e = 0; e < 16; ++e) accy[i][j][e] = 0.f;
 
+    // fp16 scheme: the per-channel powers of two lie behind the fragments of each packed weight (linear_stream.hip)
+    const float *const r1 = reinterpret_cast<const float *>(W1p + (size_t)ntiles1 * G::KQ1 * NB * 64);            // ntiles1 * 32 floats
+    const float *const r2 = reinterpret_cast<const float *>(W2p + (size_t)((D + 255) / 256 * 8) * KQ2 * NB * 64);   // >= D floats
     const int frow = (lane & 31), fk = (lane >> 5) * 8;   // fragment: lane -> (row of the tile, first of 8 consecutive k)
     const int xoff = frow * XS + fk, hoff = frow * HS + fk;
 
@@ -273,11 +281,15 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
     for (int c = 0; c < nchunks; ++c) {
         const int cn = min(c + 1, nchunks - 1);   // after the last chunk: a harmless reload
         // this chunk's hidden bias, 4 consecutive columns per register group (transposed tile, see below)
-        f32x4 b1v[4];
+        f32x4 b1v[4], r1v[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
+            r1v[g] = f32x4{1.f, 1.f, 1.f, 1.f};
             b1v[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                    b1rs, (unsigned)(c * G::CH + wave * 32 + 8 * g + 4 * (lane >> 5)) * 4u, 0, 0));
+            if constexpr (F16)   // columns past the hidden width (last chunk of hidden 288): any in-range entry, the value is zeroed below
+                r1v[g] = *reinterpret_cast<const f32x4 *>(r1 + min(c * G::CH + wave * 32 + 8 * g + 4 * (lane >> 5), ntiles1 * 32 - 4));
+        }
         if (c == nchunks - 1) {
             // the residual rows: in flight during the last chunk.  Lane -> output row m0 + 32 i + (lane & 31); registers
             // 4 g .. 4 g + 3 of tile j -> columns 32 TJ wave + 32 j + 8 g + 4 (lane >> 5) + 0..3; rows >= M return zeros
@@ -303,14 +315,14 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
         };
         // ---- GEMM 1: hidden[32 of this wave][BM rows] (transposed) = W1 tile . x^T.  One block per CU means one wave per
         // SIMD: nobody else covers the LDS latency, so the fragments of k-step st + 1 are read before the MFMAs of k-step st
-        bf16x8 xf[2][TI][NP];   // [k-step parity][row tile][piece]
+        u32x4 xf[2][TI][NA];   // [k-step parity][row tile][piece]
         auto read_x = [&](auto stc) {
             constexpr int st = decltype(stc)::value;
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    xf[st & 1][i][p] = *reinterpret_cast<const bf16x8 *>(&sX[(p * BM + i * 32) * XS + xoff + st * 16]);
+                for (int p = 0; p < NA; ++p)
+                    xf[st & 1][i][p] = *reinterpret_cast<const u32x4 *>(&sX[(p * BM + i * 32) * XS + xoff + st * 16]);
         };
         read_x(std::integral_constant<int, 0>{});
         static_for<G::KQ1>([&](auto stc) {
@@ -319,16 +331,15 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
             if constexpr (st + 1 < G::KQ1) read_x(std::integral_constant<int, st + 1>{});
             __builtin_amdgcn_sched_barrier(0);   // loads and reads stay at the head of the step (see linear_stream.hip)
             const u32x4 (&cur)[US] = ring[(st / 2) % RING];
-            bf16x8 wf[NP];
+            u32x4 wf[NB];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) wf[p] = __builtin_bit_cast(bf16x8, cur[(st & 1) * NP + p]);
+            for (int p = 0; p < NB; ++p) wf[p] = cur[(st & 1) * NB + p];
             // the weight fragment is the A operand (transposed accumulators); x piece T::A[t] x weight piece T::B[t], smallest first
-            using T = SplitTerms<NP>;
+            using T = Split<SP>;
 #pragma unroll
             for (int t = 0; t < T::N; ++t)
 #pragma unroll
-                for (int i = 0; i < TI; ++i)
-                    acch[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[T::B[t]], xf[st & 1][i][T::A[t]], acch[i], 0, 0, 0);
+                for (int i = 0; i < TI; ++i) acch[i] = mfma16<SP>(wf[T::B[t]], xf[st & 1][i][T::A[t]], acch[i]);
         });
 
         // ---- bias + ReLU + split -> the hidden tile in LDS.  C/D of the 32 x 32 MFMA with the weight as A: lane -> row
@@ -342,26 +353,26 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
                 f32x4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = acch[i][4 * g + e] + b1v[g][e];
+                    const float t = F16 ? __builtin_fmaf(acch[i][4 * g + e], r1v[g][e], b1v[g][e]) : acch[i][4 * g + e] + b1v[g][e];
                     hv[e] = (t > 0.f && hcol + 8 * g < F) ? t : 0.f;   // columns past the hidden width (last chunk only): zero
                 }
-                bf16x4 pc[NP];
-                split4<NP>(hv, pc);
+                u32x2 pc[NA];
+                split4<SP>(hv, pc);
                 const int o = (i * 32 + frow) * HS + wave * 32 + 8 * g + 4 * (lane >> 5);
 #pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(&sH[p * BM * HS + o]) = pc[p];
+                for (int p = 0; p < NA; ++p) *reinterpret_cast<u32x2 *>(&sH[p * BM * HS + o]) = pc[p];
             }
         __syncthreads();
 
         // ---- GEMM 2: y[32 TJ columns of this wave][BM rows] (transposed) += W2 tiles . hidden^T, k = this chunk
-        bf16x8 hf[2][TI][NP];
+        u32x4 hf[2][TI][NA];
         auto read_h = [&](auto vc) {
             constexpr int kv = decltype(vc)::value;   // k-step of the chunk
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    hf[kv & 1][i][p] = *reinterpret_cast<const bf16x8 *>(&sH[(p * BM + i * 32) * HS + hoff + kv * 16]);
+                for (int p = 0; p < NA; ++p)
+                    hf[kv & 1][i][p] = *reinterpret_cast<const u32x4 *>(&sH[(p * BM + i * 32) * HS + hoff + kv * 16]);
         };
         read_h(std::integral_constant<int, 0>{});
         static_for<U2>([&](auto vc) {
@@ -370,34 +381,27 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
             if constexpr (kv + 1 < U2) read_h(std::integral_constant<int, kv + 1>{});
             __builtin_amdgcn_sched_barrier(0);
             const u32x4 (&cur)[US] = ring[(U1 + kv) % RING];
-            bf16x8 wf[TJ][NP];
+            u32x4 wf[TJ][NB];
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) wf[j][p] = __builtin_bit_cast(bf16x8, cur[j * NP + p]);
-            using T = SplitTerms<NP>;
-#pragma unroll
-            for (int t = 0; t < T::N; ++t)
-#pragma unroll
-                for (int i = 0; i < TI; ++i)
-#pragma unroll
-                    for (int j = 0; j < TJ; ++j)
-                        accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][T::B[t]], hf[kv & 1][i][T::A[t]], accy[i][j], 0, 0, 0);
+                for (int p = 0; p < NB; ++p) wf[j][p] = cur[j * NB + p];
+            mfma_tiles<SP, TI, TJ, false>(accy, hf[kv & 1], wf);
         });
     }
 
     // ---- epilogue (the LayerNorm's exchange buffer aliases the hidden tile)
-    rows_epilogue<D, TI, LN>(accy, v, b2rs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sH), m0, wave, lane);
+    rows_epilogue<D, TI, LN, F16>(accy, v, b2rs, r2, gamma, beta, eps, yrs, reinterpret_cast<float *>(sH), m0, wave, lane);
 }
 
-template <int NP, int D, int TI>
+template <int SP, int D, int TI>
 int launch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2, const float *b2, const float *res,
                const float *gamma, const float *beta, float eps, float *y, int M, int F, hipStream_t s)
 {
     const bool ln = gamma != nullptr;
-    constexpr size_t lds = ffn_lds_bytes<D>(TI, NP);
+    constexpr size_t lds = ffn_lds_bytes<D>(TI, Split<SP>::NA);
     static_assert(lds <= 160 * 1024, "the two tiles do not fit the LDS of a CU");
-    const void *fn = ln ? (const void *)&ffn_fused_kernel<NP, D, TI, true> : (const void *)&ffn_fused_kernel<NP, D, TI, false>;
+    const void *fn = ln ? (const void *)&ffn_fused_kernel<SP, D, TI, true> : (const void *)&ffn_fused_kernel<SP, D, TI, false>;
     static std::atomic<unsigned> raised[2];   // bit per device, per kernel
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -415,31 +419,31 @@ int launch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2
 // projection with the layer's residual add and norm1 (deformable_transformer.py:285-292 / ms_deform_attn.py:87).  The GEMM 2
 // half of the kernel above with the activation tile as its operand: D / 16 k-steps, each wave 32 TJ output columns.
 template <int D>
-constexpr size_t linln_lds_bytes(int ti, int np) { return (size_t)(32 * ti) * Geo<D>::XS * 2 * np; }
+constexpr size_t linln_lds_bytes(int ti, int na) { return (size_t)(32 * ti) * Geo<D>::XS * 2 * na; }
 constexpr int linln_min_blocks(int d, int ti) { return (d == 256 ? ti <= 2 : ti <= 1) ? 2 : 1; }   // resident blocks per CU the register budget is cut for
 constexpr int linln_ring(int ti) { return ti <= 2 ? 4 : 8; }          // weight units in flight + 2
 
-template <int NP, int D, int TI, bool LN>
+template <int SP, int D, int TI, bool LN>
 __global__ void __launch_bounds__(Geo<D>::NT, (linln_min_blocks(D, TI)))
 linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R,
                      const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float *Y, int M)
 {
     using G = Geo<D>;
-    constexpr int BM = TI * 32, TJ = G::TJ, XS = G::XS, KQ = G::KQ1;
+    constexpr int BM = TI * 32, TJ = G::TJ, XS = G::XS, KQ = G::KQ1, NA = Split<SP>::NA, NB = Split<SP>::NB;
     extern __shared__ __attribute__((aligned(16))) unsigned short s_f[];
-    unsigned short *const sX = s_f;   // [NP][BM][XS]
+    unsigned short *const sX = s_f;   // [NA][BM][XS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m0 = blockIdx.x * BM;
     // weight unit u = k-step u (NP pieces) of the wave's TJ output n-tiles; a ring as above, RING - 2 units ahead
     constexpr int RING = linln_ring(TI), AHEAD = RING - 2;
-    u32x4 ring[RING][NP * TJ];
-    auto load_unit = [&](auto uc, u32x4 (&dst)[NP * TJ]) {
+    u32x4 ring[RING][NB * TJ];
+    auto load_unit = [&](auto uc, u32x4 (&dst)[NB * TJ]) {
         constexpr int u = decltype(uc)::value;
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) dst[j * NP + p] = Wp[(((size_t)(TJ * wave + j) * KQ + u) * NP + p) * 64 + lane];
+            for (int p = 0; p < NB; ++p) dst[j * NB + p] = Wp[(((size_t)(TJ * wave + j) * KQ + u) * NB + p) * 64 + lane];
     };
     static_for<AHEAD>([&](auto uc) { load_unit(uc, ring[decltype(uc)::value]); });
     __builtin_amdgcn_sched_barrier(0);
@@ -449,7 +453,7 @@ linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, 
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : X), 0, R ? bytes : 0u, 0x00020000);
     const int frow = lane & 31, cbase = wave * (32 * TJ) + 4 * (lane >> 5);
     f32x4 v[TI][TJ][4];   // the residual rows (rows >= M return zeros), then the output values
-    stage_rows<NP, D, TI>(X, M, m0, sX, tid);
+    stage_rows<SP, D, TI>(X, M, m0, sX, tid);
     __syncthreads();
 
     f32x16 accy[TI][TJ];
@@ -460,14 +464,14 @@ linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) accy[i][j][e] = 0.f;
     const int xoff = frow * XS + (lane >> 5) * 8;
-    bf16x8 xf[2][TI][NP];   // [k-step parity][row tile][piece]: the fragments of step st + 1 are read before the MFMAs of st
+    u32x4 xf[2][TI][NA];   // [k-step parity][row tile][piece]: the fragments of step st + 1 are read before the MFMAs of st
     auto read_x = [&](auto stc) {
         constexpr int st = decltype(stc)::value;
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
-                xf[st & 1][i][p] = *reinterpret_cast<const bf16x8 *>(&sX[(p * BM + i * 32) * XS + xoff + st * 16]);
+            for (int p = 0; p < NA; ++p)
+                xf[st & 1][i][p] = *reinterpret_cast<const u32x4 *>(&sX[(p * BM + i * 32) * XS + xoff + st * 16]);
     };
     read_x(std::integral_constant<int, 0>{});
     static_for<KQ>([&](auto stc) {
@@ -485,32 +489,26 @@ linear_res_ln_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, 
         }
         if constexpr (st + 1 < KQ) read_x(std::integral_constant<int, st + 1>{});
         __builtin_amdgcn_sched_barrier(0);
-        const u32x4 (&cur)[NP * TJ] = ring[st % RING];
-        bf16x8 wf[TJ][NP];
+        const u32x4 (&cur)[NB * TJ] = ring[st % RING];
+        u32x4 wf[TJ][NB];
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) wf[j][p] = __builtin_bit_cast(bf16x8, cur[j * NP + p]);
-        using T = SplitTerms<NP>;
-#pragma unroll
-        for (int t = 0; t < T::N; ++t)
-#pragma unroll
-            for (int i = 0; i < TI; ++i)
-#pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    accy[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][T::B[t]], xf[st & 1][i][T::A[t]], accy[i][j], 0, 0, 0);
+            for (int p = 0; p < NB; ++p) wf[j][p] = cur[j * NB + p];
+        mfma_tiles<SP, TI, TJ, false>(accy, xf[st & 1], wf);
     });
-    rows_epilogue<D, TI, LN>(accy, v, brs, gamma, beta, eps, yrs, reinterpret_cast<float *>(sX), m0, wave, lane);
+    const float *const r = reinterpret_cast<const float *>(Wp + (size_t)((D + 255) / 256 * 8) * KQ * NB * 64);   // fp16 scheme: see ffn_fused_kernel
+    rows_epilogue<D, TI, LN, Split<SP>::F16>(accy, v, brs, r, gamma, beta, eps, yrs, reinterpret_cast<float *>(sX), m0, wave, lane);
 }
 
-template <int NP, int D, int TI>
+template <int SP, int D, int TI>
 int launch_linln(const float *x, const u32x4 *w, const float *b, const float *res, const float *gamma, const float *beta, float eps,
                  float *y, int M, hipStream_t s)
 {
     const bool ln = gamma != nullptr;
-    constexpr size_t lds = linln_lds_bytes<D>(TI, NP);
+    constexpr size_t lds = linln_lds_bytes<D>(TI, Split<SP>::NA);
     static_assert(lds <= 160 * 1024, "the activation tile does not fit the LDS of a CU");
-    const void *fn = ln ? (const void *)&linear_res_ln_kernel<NP, D, TI, true> : (const void *)&linear_res_ln_kernel<NP, D, TI, false>;
+    const void *fn = ln ? (const void *)&linear_res_ln_kernel<SP, D, TI, true> : (const void *)&linear_res_ln_kernel<SP, D, TI, false>;
     if (lds > 64 * 1024) {
         static std::atomic<unsigned> raised[2];   // bit per device, per kernel
         int dev = 0;
@@ -600,28 +598,28 @@ int ffn_num_cus()
     return n;
 }
 
-template <int NP, int D>
+template <int SP, int D>
 int dispatch_linln(const float *x, const u32x4 *w, const float *bias, const float *residual, const float *g, const float *b, float eps,
                    float *y, int M, hipStream_t s)
 {
     // rows per block = 32 TI; automatic: few rows -> 32-row blocks (more of them), many -> 64 (two resident per CU with two
-    // pieces per operand; with three the 64-row tile is 99 KB of LDS: one block per CU)
+    // activation pieces; with three the 64-row tile is 99 KB of LDS: one block per CU)
     const int forced = linln_ti();
     // Three pieces: a 64-row tile is 99 KB of LDS -- one block per CU, rounds of `cus` blocks (348 blocks at the cfg-2 encoder: a
     // full round and a third of one).  32-row tiles (50 KB) keep three blocks resident per CU and the 695 blocks run as one
     // round: 26.2 us against 31.2 us with 64-row blocks (29.0 with the rows behind the full round split off as dispatch_ffn
     // does; profiles/r04_one_launch_blocks_tail_split.txt).  Two pieces: 64-row tiles, two resident per CU, as measured in round 3.
-    switch (forced ? forced : (M < 4096 || NP == 3 ? 1 : 2)) {
-    case 1: return launch_linln<NP, D, 1>(x, w, bias, residual, g, b, eps, y, M, s);
-    case 3:   // 96 rows per block: hidden 256 with two pieces only (at 288 the accumulators of three row tiles do not fit the
-              // register file, with three pieces the tile does not fit the LDS)
-        if constexpr (D == 256 && NP == 2) return launch_linln<NP, D, 3>(x, w, bias, residual, g, b, eps, y, M, s);
-        else return launch_linln<NP, D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
-    default: return launch_linln<NP, D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
+    switch (forced ? forced : (M < 4096 || Split<SP>::NA == 3 ? 1 : 2)) {
+    case 1: return launch_linln<SP, D, 1>(x, w, bias, residual, g, b, eps, y, M, s);
+    case 3:   // 96 rows per block: hidden 256 with two bf16 pieces only (at 288 the accumulators of three row tiles do not fit the
+              // register file, with three pieces the tile does not fit the LDS / the weight ring does not fit the registers)
+        if constexpr (D == 256 && SP == 2) return launch_linln<SP, D, 3>(x, w, bias, residual, g, b, eps, y, M, s);
+        else return launch_linln<SP, D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
+    default: return launch_linln<SP, D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
     }
 }
 
-template <int NP, int D>
+template <int SP, int D>
 int dispatch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2, const float *b2, const float *residual,
                  const float *g, const float *b, float eps, float *y, int M, int F, hipStream_t s)
 {
@@ -632,26 +630,49 @@ int dispatch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *
     // MFMA-busy, 38 % of the launch's).  When the last round would be less than half full, the rows behind the full rounds go
     // to a second launch of 32-row blocks: a short round instead of a long one.  Same arithmetic per row (a row's result does
     // not depend on the block it is in): bit-identical.
+    constexpr bool three_tiles = D == 256 && SP == 2;   // 96 rows per block: two bf16 pieces only (three weight pieces: the ring of
+                                                        // weight units does not leave room for a third row tile's accumulators)
     const int want = ffn_ti();
-    const bool ti2 = want == 2 || (want >= 3 && !(D == 256 && NP == 2));
+    const bool ti2 = want == 2 || (want >= 3 && !three_tiles);
     if (ti2 && tfm::ffn_tail_split()) {
         const int cus = ffn_num_cus();
         const long long per_round = 64LL * cus;
         const int main_rows = (int)(M / per_round * per_round), rem = M - main_rows;
         if (main_rows > 0 && rem > 0 && rem <= 32LL * cus) {
-            int rc = launch_ffn<NP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, main_rows, F, s);
+            int rc = launch_ffn<SP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, main_rows, F, s);
             if (rc != TF_MSDA_OK) return rc;
             const size_t off = (size_t)main_rows * D;
-            return launch_ffn<NP, D, 1>(x + off, w1, b1, w2, b2, residual ? residual + off : nullptr, g, b, eps, y + off, rem, F, s);
+            return launch_ffn<SP, D, 1>(x + off, w1, b1, w2, b2, residual ? residual + off : nullptr, g, b, eps, y + off, rem, F, s);
         }
     }
     switch (want) {
-    case 1: return launch_ffn<NP, D, 1>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
-    case 2: return launch_ffn<NP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
-    default:   // 96 rows per block: hidden 256 with two pieces only (see dispatch_linln; three pieces: 96 rows x (264 + 136) x 6 B
-               // = 225 KB of LDS)
-        if constexpr (D == 256 && NP == 2) return launch_ffn<NP, D, 3>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
-        else return launch_ffn<NP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    case 1: return launch_ffn<SP, D, 1>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    case 2: return launch_ffn<SP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    default:
+        if constexpr (three_tiles) return launch_ffn<SP, D, 3>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+        else return launch_ffn<SP, D, 2>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    }
+}
+
+template <int D>
+int dispatch_linln_scheme(int sp, const float *x, const u32x4 *w, const float *bias, const float *residual, const float *g, const float *b,
+                          float eps, float *y, int M, hipStream_t s)
+{
+    switch (sp) {
+    case 2: return dispatch_linln<2, D>(x, w, bias, residual, g, b, eps, y, M, s);
+    case 3: return dispatch_linln<3, D>(x, w, bias, residual, g, b, eps, y, M, s);
+    default: return dispatch_linln<16, D>(x, w, bias, residual, g, b, eps, y, M, s);
+    }
+}
+
+template <int D>
+int dispatch_ffn_scheme(int sp, const float *x, const u32x4 *w1, const float *b1, const u32x4 *w2, const float *b2, const float *residual,
+                        const float *g, const float *b, float eps, float *y, int M, int F, hipStream_t s)
+{
+    switch (sp) {
+    case 2: return dispatch_ffn<2, D>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    case 3: return dispatch_ffn<3, D>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
+    default: return dispatch_ffn<16, D>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
     }
 }
 
@@ -663,19 +684,16 @@ extern "C" int tf_linear_res_ln_f32(const float *x, const void *w_packed, const 
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return TF_MSDA_ERR_NULL_POINTER;
-    const int np = split_pieces(terms);
-    if (M <= 0 || K != N || (K != 256 && K != 288) || (M + 128) * (int64_t)K * 4 > 0xFFFFFFFFLL || np == 0) return TF_MSDA_ERR_BAD_DIMS;
+    const int sp = split_scheme(terms);
+    if (M <= 0 || K != N || (K != 256 && K != 288) || (M + 128) * (int64_t)K * 4 > 0xFFFFFFFFLL || sp == 0) return TF_MSDA_ERR_BAD_DIMS;
     uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y) |
                    reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(ln_weight) |
                    reinterpret_cast<uintptr_t>(ln_bias);
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *w = static_cast<const u32x4 *>(w_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (np == 3)
-        return K == 256 ? dispatch_linln<3, 256>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s)
-                        : dispatch_linln<3, 288>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
-    return K == 256 ? dispatch_linln<2, 256>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s)
-                    : dispatch_linln<2, 288>(x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
+    return K == 256 ? dispatch_linln_scheme<256>(sp, x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s)
+                    : dispatch_linln_scheme<288>(sp, x, w, bias, residual, ln_weight, ln_bias, ln_eps, y, (int)M, s);
 }
 
 extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const float *b1, const void *w2_packed, const float *b2,
@@ -684,8 +702,8 @@ extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const flo
 {
     if (!x || !w1_packed || !w2_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return TF_MSDA_ERR_NULL_POINTER;
-    const int np = split_pieces(terms);
-    if (M <= 0 || (d_model != 256 && d_model != 288) || d_ffn <= 0 || np == 0 ||
+    const int sp = split_scheme(terms);
+    if (M <= 0 || (d_model != 256 && d_model != 288) || d_ffn <= 0 || sp == 0 ||
         (M + 128) * (int64_t)d_model * 4 > 0xFFFFFFFFLL)   // 32-bit buffer offsets, incl. the rows of the last block past M
         return TF_MSDA_ERR_BAD_DIMS;
     uintptr_t al = reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w1_packed) | reinterpret_cast<uintptr_t>(w2_packed) |
@@ -694,9 +712,6 @@ extern "C" int tf_ffn_fused_f32(const float *x, const void *w1_packed, const flo
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *w1 = static_cast<const u32x4 *>(w1_packed), *w2 = static_cast<const u32x4 *>(w2_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (np == 3)
-        return d_model == 256 ? dispatch_ffn<3, 256>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s)
-                              : dispatch_ffn<3, 288>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
-    return d_model == 256 ? dispatch_ffn<2, 256>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s)
-                          : dispatch_ffn<2, 288>(x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
+    return d_model == 256 ? dispatch_ffn_scheme<256>(sp, x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s)
+                          : dispatch_ffn_scheme<288>(sp, x, w1, b1, w2, b2, residual, ln_weight, ln_bias, ln_eps, y, (int)M, d_ffn, s);
 }

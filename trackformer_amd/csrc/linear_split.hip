@@ -120,12 +120,12 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            bf16x4 pc[NP];   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
+            u32x2 pc[NP];   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
             f32x4 xv = xr[it];
             if constexpr (XADD) xv += xr2[it];
             split4<NP>(xv, pc);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
@@ -147,18 +147,18 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int koff = kk + (lane >> 5) * 8;
-            bf16x8 af[TI][NP], bfr[TJ][NP];
+            u32x4 af[TI][NP], bfr[TJ][NP];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const bf16x8 *>(&sA[q][r]);
+                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const u32x4 *>(&sA[q][r]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) bfr[j][q] = *reinterpret_cast<const bf16x8 *>(&sB[q][r]);
+                for (int q = 0; q < NP; ++q) bfr[j][q] = *reinterpret_cast<const u32x4 *>(&sB[q][r]);
             }
             mfma_tiles<NP, TI, TJ>(acc, af, bfr);   // smallest terms first
         }
@@ -361,10 +361,10 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            bf16x4 pc[NP];
+            u32x2 pc[NP];
             split4<NP>(xr[it], pc);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
@@ -392,18 +392,18 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int koff = kk + (lane >> 5) * 8;
-            bf16x8 af[TI][NP], bfr[TJ][NP];
+            u32x4 af[TI][NP], bfr[TJ][NP];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const bf16x8 *>(&sA[q][r]);
+                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const u32x4 *>(&sA[q][r]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) bfr[j][q] = *reinterpret_cast<const bf16x8 *>(&sB[q][r]);
+                for (int q = 0; q < NP; ++q) bfr[j][q] = *reinterpret_cast<const u32x4 *>(&sB[q][r]);
             }
             mfma_tiles<NP, TI, TJ>(acc, af, bfr);
         }
@@ -522,10 +522,10 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            bf16x4 pc[NP];   // v_cvt_pk_bf16_f32, round to nearest even
+            u32x2 pc[NP];   // v_cvt_pk_bf16_f32, round to nearest even
             split4<NP>(xr[slot][it], pc);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<bf16x4 *>(&sA[buf][q][row * LDS_STRIDE + c4 * 4]) = pc[q];
+            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(&sA[buf][q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
@@ -563,11 +563,11 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
             for (int kk = 0; kk < BK; kk += 16) {
                 const int koff = kk + (lane >> 5) * 8;
                 const int ra = (wm + (lane & 31)) * LDS_STRIDE + koff, rb = (wn + (lane & 31)) * LDS_STRIDE + koff;
-                bf16x8 af[NP], bfr[NP];
+                u32x4 af[NP], bfr[NP];
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
-                    af[q] = *reinterpret_cast<const bf16x8 *>(&sA[buf][q][ra]);
-                    bfr[q] = *reinterpret_cast<const bf16x8 *>(&sB[buf][q][rb]);
+                    af[q] = *reinterpret_cast<const u32x4 *>(&sA[buf][q][ra]);
+                    bfr[q] = *reinterpret_cast<const u32x4 *>(&sB[buf][q][rb]);
                 }
                 mfma_terms<NP>(acc, af, bfr);   // smallest terms first
             }

@@ -47,12 +47,27 @@ constexpr int kStride = kSlice + 8;          // bf16 per LDS row: 80 bytes (16-b
 constexpr int kTJ = 2;                       // MFMA column tiles per wave -> 4 waves x 2 x 32 = 256 columns per block
 constexpr int kBN = 4 * kTJ * 32;
 
-// ---- weight packing: one thread per (n-tile, k-step, lane) writes its NP pieces: piece p of (n-tile t, k-step q) at
-// ((t KQ + q) NP + p) 64 + lane
-template <int NP>
+// ---- weight packing: one thread per (n-tile, k-step, lane) writes its NB pieces: piece p of (n-tile t, k-step q) at
+// ((t KQ + q) NB + p) 64 + lane.  fp16 scheme: behind the fragments lie npad floats r_n = 1 / (kActScale t_n) (the epilogue's
+// factor per output channel, split_product.h), written by pack_scale_kernel before this kernel runs.
 __global__ void __launch_bounds__(256)
-pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, int K, int N, long long total)
+pack_scale_kernel(const float *__restrict__ W, float *__restrict__ rs, int K, int N, int npad)
 {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;   // one wave per output channel
+    if (n >= npad) return;
+    float amax = 0.f;
+    if (n < N)
+        for (int k = lane; k < K; k += 64) amax = fmaxf(amax, fabsf(W[(size_t)n * K + k]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) amax = fmaxf(amax, __shfl_xor(amax, d));
+    if (lane == 0) rs[n] = 1.f / (kActScale * weight_scale_for(amax));
+}
+
+template <int SP>
+__global__ void __launch_bounds__(256)
+pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, const float *__restrict__ rs, int K, int N, long long total)
+{
+    constexpr int NB = Split<SP>::NB;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int KQ = K >> 4;
@@ -64,19 +79,19 @@ pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, int K, 
     if (n < N) {   // rows past N (padding up to a whole block of columns): zeros
         a = *reinterpret_cast<const f32x4 *>(W + (size_t)n * K + k);
         b = *reinterpret_cast<const f32x4 *>(W + (size_t)n * K + k + 4);
-    }
-    bf16x4 pa[NP], pb[NP];   // v_cvt_pk_bf16_f32: round to nearest even, as torch's .to(bfloat16)
-    split4<NP>(a, pa);
-    split4<NP>(b, pb);
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        bf16x8 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = pa[p][e];
-            v[4 + e] = pb[p][e];
+        if constexpr (Split<SP>::F16) {
+            const float tn = 1.f / (kActScale * rs[n]);   // powers of two: exact
+            a *= tn;
+            b *= tn;
         }
-        out[(tq * NP + p) * 64 + lane] = __builtin_bit_cast(u32x4, v);
+    }
+    u32x2 pa[NB], pb[NB];   // round to nearest even, as torch's .to(bfloat16) / .to(float16)
+    split4_weight<SP>(a, pa);
+    split4_weight<SP>(b, pb);
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        const u32x4 v = {pa[p].x, pa[p].y, pb[p].x, pb[p].y};
+        out[(tq * NB + p) * 64 + lane] = v;
     }
 }
 
@@ -102,21 +117,21 @@ struct StreamConv {
     int nimg, hin, win, cin, hout, wout, ks, pad, stride;
 };
 
-template <int NP, int TJ>
+template <int NB, int TJ>
 struct WFrags {
-    u32x4 v[TJ][2][NP];   // [column tile][k-step of the slice][hi | mid | lo]
+    u32x4 v[TJ][2][NB];   // [column tile][k-step of the slice][weight piece]
 };
 
 constexpr int stream_min_waves(int ti, int tj, int wc) { return (4 / wc) * ti * tj <= 6 && ti <= 3 ? 2 : 1; }   // blocks per CU the register budget is cut for
 
-template <int NP, int TI, int TJ, int WC, bool CONV>
+template <int SP, int TI, int TJ, int WC, bool CONV>
 __global__ void __launch_bounds__(kThreads, (stream_min_waves(TI, TJ, WC)))
 stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R,
                    float *Y, int M, int K, int N, int mblocks, int nblocks, int relu, int kslices, const StreamConv cv)
 {
-    constexpr int WR = 4 / WC, BM = WR * TI * 32, BN = WC * TJ * 32;
+    constexpr int WR = 4 / WC, BM = WR * TI * 32, BN = WC * TJ * 32, NA = Split<SP>::NA, NB = Split<SP>::NB;
     constexpr int XV = BM / 32;   // float4 of A per thread and slice: BM * 8 / 256
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][NP][BM * kStride];   // [buffer][hi | mid | lo][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][NA][BM * kStride];   // [buffer][activation piece][row][k]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WC, wc = wave - wr * WC;
@@ -206,29 +221,29 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
     auto store_x = [&](const f32x4 (&src)[XV], int buf) {
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
-            bf16x4 pc[NP];
-            split4<NP>(src[it], pc);
+            u32x2 pc[NA];
+            split4<SP>(src[it], pc);
             const int o = (it * 32 + arow) * kStride + ac4 * 4;
 #pragma unroll
-            for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4 *>(&sA[buf][p][o]) = pc[p];
+            for (int p = 0; p < NA; ++p) *reinterpret_cast<u32x2 *>(&sA[buf][p][o]) = pc[p];
         }
     };
     // ---- weights: the wave's TJ column tiles, fragment order (see pack_weight_kernel)
     const u32x4 *wp[TJ];
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) wp[j] = Wp + ((size_t)(nb * (WC * TJ) + wc * TJ + j) * KQ * NP) * 64 + lane;
-    auto load_w = [&](int s, WFrags<NP, TJ> &w) {
+    for (int j = 0; j < TJ; ++j) wp[j] = Wp + ((size_t)(nb * (WC * TJ) + wc * TJ + j) * KQ * NB) * 64 + lane;
+    auto load_w = [&](int s, WFrags<NB, TJ> &w) {
         const int q0 = min(s, send - 1) * 2;
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) w.v[j][kk][p] = wp[j][((q0 + kk) * NP + p) * 64];
+                for (int p = 0; p < NB; ++p) w.v[j][kk][p] = wp[j][((q0 + kk) * NB + p) * 64];
     };
 
     f32x4 xr[2][XV];   // slice s + 1 lives in xr[(s + 1) & 1], slice s + 2 in the other one   (parity relative to sbeg)
-    WFrags<NP, TJ> w0, w1;
+    WFrags<NB, TJ> w0, w1;
     {
         f32x4 first[XV];
         load_x(first);
@@ -240,7 +255,7 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
     __syncthreads();
 
     // one K-slice; PAR = (s - sbeg) & 1 as a compile-time constant so that the register double buffers need no copies
-    auto slice = [&](int s, auto par, const WFrags<NP, TJ> &cur, WFrags<NP, TJ> &nxt) {
+    auto slice = [&](int s, auto par, const WFrags<NB, TJ> &cur, WFrags<NB, TJ> &nxt) {
         constexpr int PAR = decltype(par)::value;
         load_w(s + 1, nxt);   // in flight during the MFMAs below
         __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them to the end of the
@@ -248,20 +263,20 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int koff = kk * 16 + (lane >> 5) * 8;
-            bf16x8 af[TI][NP], bfr[TJ][NP];
+            u32x4 af[TI][NA], bfr[TJ][NB];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int o = ((wr * TI + i) * 32 + (lane & 31)) * kStride + koff;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) af[i][p] = *reinterpret_cast<const bf16x8 *>(&sA[PAR][p][o]);
+                for (int p = 0; p < NA; ++p) af[i][p] = *reinterpret_cast<const u32x4 *>(&sA[PAR][p][o]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) bfr[j][p] = __builtin_bit_cast(bf16x8, cur.v[j][kk][p]);
+                for (int p = 0; p < NB; ++p) bfr[j][p] = cur.v[j][kk][p];
             // term-major passes over the tiles: consecutive MFMAs never share an accumulator; per accumulator the order is
             // smallest terms first, as in linear_split.hip
-            mfma_tiles<NP, TI, TJ>(acc, af, bfr);
+            mfma_tiles<SP, TI, TJ>(acc, af, bfr);
         }
         // slice s + 1 -> the LDS buffer nobody reads in this iteration (its readers passed the previous barrier),
         // then its registers take slice s + 3
@@ -285,6 +300,8 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
         const int col = n0 + (wc * TJ + j) * 32 + (lane & 31);
         const bool colok = col < N;
         const float b = (bias && colok) ? bias[col] : 0.f;
+        float rsc = 1.f;   // fp16 scheme: the output channel's power of two (behind the fragments of the packed weight)
+        if constexpr (Split<SP>::F16) rsc = reinterpret_cast<const float *>(Wp + (size_t)((N + kBN - 1) / kBN * (kBN / 32)) * KQ * NB * 64)[colok ? col : 0];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             const int row0 = m0 + (wr * TI + i) * 32 + 4 * (lane >> 5);
@@ -297,7 +314,7 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] + b;
+                float v = Split<SP>::F16 ? __builtin_fmaf(acc[i][j][e], rsc, b) : acc[i][j][e] + b;
                 if (R != nullptr) v += rv[e];
                 if (relu) v = v > 0.f ? v : 0.f;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u, 0, 0);
@@ -376,7 +393,7 @@ struct StreamCall {
     int ksplit;         // pieces the K loop is cut into (1: none)
 };
 
-template <int NP, int TI, int TJ, int WC, bool CONV>
+template <int SP, int TI, int TJ, int WC, bool CONV>
 int launch_stream(const StreamCall &c, hipStream_t s)
 {
     constexpr int BM = (4 / WC) * TI * 32, BN = WC * TJ * 32;
@@ -392,7 +409,7 @@ int launch_stream(const StreamCall &c, hipStream_t s)
     if (gx > 0x7fffffffLL || gz > 65535) return TF_MSDA_ERR_BAD_DIMS;
     const bool partial = gz > 1;
     float *out = partial ? c.workspace : c.y;
-    hipLaunchKernelGGL((stream_gemm_kernel<NP, TI, TJ, WC, CONV>), dim3((unsigned)gx, (unsigned)gz), dim3(kThreads), 0, s, c.x, c.wp,
+    hipLaunchKernelGGL((stream_gemm_kernel<SP, TI, TJ, WC, CONV>), dim3((unsigned)gx, (unsigned)gz), dim3(kThreads), 0, s, c.x, c.wp,
                        partial ? nullptr : c.bias, partial ? nullptr : c.res, out, c.M, c.K, c.N, mblocks, nblocks, partial ? 0 : c.relu,
                        kslices, c.cv);
     if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
@@ -410,28 +427,28 @@ int launch_stream(const StreamCall &c, hipStream_t s)
 // 256-column blocks): two row tiles win at K = 256 (59.3 / 67.3 / 84.2 us for TI = 2 / 3 / 4 at N = 1024: a block's eight K-slices
 // are too short a loop to hide its own memory latency and the co-resident blocks have to), three at K = 1024 (55.6 / 50.5 / 58.0).
 // The narrow shapes take 128-row blocks while that leaves at least ~2 blocks per CU, else 64.
-template <int NP, bool CONV>
+template <int SP, bool CONV>
 int stream_dispatch(const StreamCall &c, hipStream_t s)
 {
     const int f = forced_ti();
     const long long pieces = c.ksplit > 1 ? c.ksplit : 1;
     if (c.N <= 64) {
         const bool big = f ? f >= 2 : (long long)((c.M + 127) / 128) * pieces >= 2LL * num_cus();
-        return big ? launch_stream<NP, 2, 1, 2, CONV>(c, s) : launch_stream<NP, 1, 1, 2, CONV>(c, s);
+        return big ? launch_stream<SP, 2, 1, 2, CONV>(c, s) : launch_stream<SP, 1, 1, 2, CONV>(c, s);
     }
     if (c.N <= 128) {
         const bool big = f ? f >= 4 : (long long)((c.M + 127) / 128) * pieces >= 2LL * num_cus();
-        return big ? launch_stream<NP, 4, 1, 4, CONV>(c, s) : launch_stream<NP, 2, 1, 4, CONV>(c, s);
+        return big ? launch_stream<SP, 4, 1, 4, CONV>(c, s) : launch_stream<SP, 2, 1, 4, CONV>(c, s);
     }
     if constexpr (CONV) {   // (three row tiles of the convolution form do not fit the register file with three pieces)
         const bool big = f ? f >= 4 : (long long)((c.M + 127) / 128) * ((c.N + 255) / 256) * pieces >= 2LL * num_cus();
-        return big ? launch_stream<NP, 4, 2, 4, CONV>(c, s) : launch_stream<NP, 2, 2, 4, CONV>(c, s);
+        return big ? launch_stream<SP, 4, 2, 4, CONV>(c, s) : launch_stream<SP, 2, 2, 4, CONV>(c, s);
     } else {
         switch (f ? f : (c.K >= 512 ? 3 : 2)) {
         case 1:
-        case 2: return launch_stream<NP, 2, 2, 4, CONV>(c, s);
-        case 4: return launch_stream<NP, 4, 2, 4, CONV>(c, s);
-        default: return launch_stream<NP, 3, 2, 4, CONV>(c, s);
+        case 2: return launch_stream<SP, 2, 2, 4, CONV>(c, s);
+        case 4: return launch_stream<SP, 4, 2, 4, CONV>(c, s);
+        default: return launch_stream<SP, 3, 2, 4, CONV>(c, s);
         }
     }
 }
@@ -447,30 +464,45 @@ int linear_stream_set_ti(int v)
 }
 }  // namespace tfm
 
+template <bool CONV>
+int stream_dispatch_scheme(int sp, const StreamCall &c, hipStream_t s)
+{
+    switch (sp) {
+    case 2: return stream_dispatch<2, CONV>(c, s);
+    case 3: return stream_dispatch<3, CONV>(c, s);
+    default: return stream_dispatch<16, CONV>(c, s);
+    }
+}
+
 extern "C" int64_t tf_linear_packed_bytes(int K, int N, int terms)
 {
-    const int np = split_pieces(terms);
-    if (K <= 0 || N <= 0 || (K % 16) != 0 || np == 0) return -1;
+    const int sp = split_scheme(terms);
+    if (K <= 0 || N <= 0 || (K % 16) != 0 || sp == 0) return -1;
     const int64_t npad = ((int64_t)N + kBN - 1) / kBN * kBN;
-    return npad * K * 2 * np;   // np bf16 pieces per element
+    return npad * K * 2 * scheme_pieces_b(sp) + (sp == 16 ? npad * 4 : 0);   // 16-bit pieces per element [+ a float per output channel]
 }
 
 extern "C" int tf_linear_pack_weight_f32(const float *w, void *packed, int K, int N, int terms, void *stream)
 {
     if (!w || !packed) return TF_MSDA_ERR_NULL_POINTER;
-    const int np = split_pieces(terms);
-    if (K <= 0 || N <= 0 || (K % 16) != 0 || np == 0) return TF_MSDA_ERR_BAD_DIMS;
+    const int sp = split_scheme(terms);
+    if (K <= 0 || N <= 0 || (K % 16) != 0 || sp == 0) return TF_MSDA_ERR_BAD_DIMS;
     if ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(packed)) & 15) return TF_MSDA_ERR_BAD_DIMS;
-    const long long ntiles = ((long long)N + kBN - 1) / kBN * (kBN / 32);
+    const long long npad = ((long long)N + kBN - 1) / kBN * kBN;
+    const long long ntiles = npad / 32;
     const long long total = ntiles * (K >> 4) * 64;
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
-    if (np == 3)
-        hipLaunchKernelGGL(pack_weight_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                           static_cast<u32x4 *>(packed), K, N, total);
-    else
-        hipLaunchKernelGGL(pack_weight_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                           static_cast<u32x4 *>(packed), K, N, total);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    u32x4 *out = static_cast<u32x4 *>(packed);
+    float *rs = reinterpret_cast<float *>(out + total * scheme_pieces_b(sp));   // fp16 scheme only
+    switch (sp) {
+    case 2: hipLaunchKernelGGL(pack_weight_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, w, out, (const float *)nullptr, K, N, total); break;
+    case 3: hipLaunchKernelGGL(pack_weight_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, w, out, (const float *)nullptr, K, N, total); break;
+    default:
+        hipLaunchKernelGGL(pack_scale_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, w, rs, K, N, (int)npad);
+        hipLaunchKernelGGL(pack_weight_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, s, w, out, (const float *)rs, K, N, total);
+    }
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
@@ -478,13 +510,12 @@ extern "C" int tf_linear_packed_f32(const float *x, const void *w_packed, const 
                                     int64_t M, int K, int N, int relu, int terms, void *stream)
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
-    const int np = split_pieces(terms);
-    if (M <= 0 || K <= 0 || N <= 0 || (K % 64) != 0 || M > 0x7fffffffLL || np == 0) return TF_MSDA_ERR_BAD_DIMS;
+    const int sp = split_scheme(terms);
+    if (M <= 0 || K <= 0 || N <= 0 || (K % 64) != 0 || M > 0x7fffffffLL || sp == 0) return TF_MSDA_ERR_BAD_DIMS;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed)) & 15) return TF_MSDA_ERR_BAD_DIMS;
     if ((long long)(M + 256) * N * 4 >= 0xC0000000LL) return TF_MSDA_ERR_BAD_DIMS;   // buffer-resource offsets (the caller keeps tf_linear_split_f32)
     StreamCall c{x, static_cast<const u32x4 *>(w_packed), bias, residual, y, (int)M, K, N, relu, false, StreamConv{}, nullptr, 1};
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return np == 3 ? stream_dispatch<3, false>(c, s) : stream_dispatch<2, false>(c, s);
+    return stream_dispatch_scheme<false>(sp, c, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tf_conv_packed_f32(const float *x, const void *w_packed, const float *bias, const float *residual, float *y,
@@ -492,9 +523,9 @@ extern "C" int tf_conv_packed_f32(const float *x, const void *w_packed, const fl
                                   int relu, int terms, void *stream)
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
-    const int np = split_pieces(terms);
+    const int sp = split_scheme(terms);
     if (nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % 64) != 0 || (stride != 1 && stride != 2) || (ks != 1 && ks != 3) ||
-        np == 0 || ksplit < 1 || ksplit > 64)
+        sp == 0 || ksplit < 1 || ksplit > 64)
         return TF_MSDA_ERR_BAD_DIMS;
     if (ksplit > 1 && !workspace) return TF_MSDA_ERR_NULL_POINTER;
     const int pad = ks == 3 ? 1 : 0;
@@ -509,6 +540,5 @@ extern "C" int tf_conv_packed_f32(const float *x, const void *w_packed, const fl
     }
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     StreamCall c{x, static_cast<const u32x4 *>(w_packed), bias, residual, y, (int)M, ks * ks * cin, cout, relu, true, cv, workspace, ksplit};
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    return np == 3 ? stream_dispatch<3, true>(c, s) : stream_dispatch<2, true>(c, s);
+    return stream_dispatch_scheme<true>(sp, c, static_cast<hipStream_t>(stream));
 }

@@ -1,6 +1,6 @@
-// trackformer_amd/csrc/split_product.h -- the bf16 split product shared by the matrix-core kernels of this library
-// (linear_split.hip, linear_stream.hip, ffn_fused.hip, stem_conv.hip): fp32 operands cut into bf16 pieces, the product formed
-// from v_mfma_f32_32x32x16_bf16 terms with fp32 accumulation.  Reference arithmetic: fp32 everywhere
+// trackformer_amd/csrc/split_product.h -- the split product shared by the matrix-core kernels of this library
+// (linear_split.hip, linear_stream.hip, ffn_fused.hip, stem_conv.hip): fp32 operands cut into 16-bit pieces, the product formed
+// from v_mfma_f32_32x32x16_{bf16,f16} terms with fp32 accumulation.  Reference arithmetic: fp32 everywhere
 // (models/ops/src/cuda/ms_deform_attn_cuda.cu:69 AT_DISPATCH_FLOATING_TYPES on fp32 tensors; nn.Linear / Conv2d of
 // models/deformable_transformer.py, models/backbone.py; no autocast anywhere in the reference).
 #ifndef TF_SPLIT_PRODUCT_H_
@@ -12,71 +12,157 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 8 pieces of one kind: an MFMA operand fragment
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // 4 pieces of one kind
 
-// ---- the split product, generic in the number of bf16 PIECES per operand (NP):
-//   NP = 2 (hi, mid):     three terms  a_mid.b_hi + a_hi.b_mid + a_hi.b_hi                 dropped terms < 2^-16 of the product
-//   NP = 3 (hi, mid, lo): six terms    a_lo.b_hi + a_hi.b_lo + a_mid.b_mid + a_mid.b_hi + a_hi.b_mid + a_hi.b_hi
-// Three bf16 pieces (round to nearest even at every step) carry all 24 significand bits of an fp32 number (hi 8, mid 8, lo 8; the
+// ---- the split product, generic in the SCHEME SP (the template parameter of every kernel that uses it):
+//   SP = 2   bf16 (hi, mid) per operand:     three terms  a_mid.b_hi + a_hi.b_mid + a_hi.b_hi            dropped terms < 2^-16 of the product
+//   SP = 3   bf16 (hi, mid, lo) per operand: six terms    a_lo.b_hi + a_hi.b_lo + a_mid.b_mid + a_mid.b_hi + a_hi.b_mid + a_hi.b_hi
+//   SP = 16  fp16 (hi, lo) activations x fp16 (hi, lo, hi 2^-11) weights: three terms  a_lo.b_hs + a_hi.b_lo + a_hi.b_hi
+//
+// bf16, three pieces (round to nearest even at every step) carry all 24 significand bits of an fp32 number (hi 8, mid 8, lo 8; the
 // residuals x - hi and (x - hi) - mid are exact in fp32), and the six products kept are all those of weight >= 2^-16; the dropped
-// ones (mid.lo, lo.mid, lo.lo) are below 2^-24 of |a||b| -- half an ulp of the fp32 product the reference rounds to
-// (ms_deform_attn_cuda.cu:69 and every nn.Linear / Conv2d of the path are fp32).  With fp32 accumulation on the matrix cores the
-// six-term product is fp32 arithmetic in a different summation order; it is the DEFAULT (fused.set_split_terms(6)), the
-// three-term product the opt-in fast mode: on the 64-frame reference-Tracker fixture fp32 keeps the reference's track ids for 59
-// frames, the three-term product for 14 (profiles/r04_id_parity_64.txt).  Terms are issued smallest first.
-template <int NP> struct SplitTerms;
-template <> struct SplitTerms<2> {
-    static constexpr int N = 3;
+// ones (mid.lo, lo.mid, lo.lo) are below 2^-24 of |a||b| -- half an ulp of the fp32 product the reference rounds to.  With fp32
+// accumulation on the matrix cores the six-term product is fp32 arithmetic in a different summation order.  The three-term bf16
+// product is the opt-in fast mode: on the 64-frame reference-Tracker fixture fp32 keeps the reference's track ids for 59 frames,
+// the three-term bf16 product for 14 (profiles/r04_id_parity_64.txt).
+//
+// fp16 (round 4): an fp16 piece carries 11 significand bits, so TWO pieces (hi = rne16(x), lo = rne16(x - hi), the residual
+// exact in fp32) carry 22 bits + the sign of lo: |x - hi - lo| <= 2^-23 |x| -- one bit short of fp32's own rounding -- and the
+// only product dropped (lo.lo) is below 2^-22 of |a||b|.  Three MFMAs instead of six.  What fp16 lacks is exponent range (5 bits):
+//   * the lo piece of a small number would fall into the subnormals.  It is therefore stored SCALED: lo' = rne16((x - hi) 2^11)
+//     has the magnitude of hi's last place times 2^11, normal whenever hi is, and its partner in the product is the weight's hi
+//     piece times 2^-11 (the third weight piece `hs`, exact: a power of two; made once when the weight is packed);
+//   * weights are scaled per OUTPUT CHANNEL by the power of two t_n that puts the channel's largest |w| into [2^13, 2^14) (exact;
+//     a weight 2^-17 times the channel's largest still has all its bits, smaller ones an absolute error of 2^-39 of the largest);
+//     the epilogue multiplies the accumulator by r_n = 1 / (kActScale t_n), again a power of two;
+//   * activations are scaled by kActScale = 2^-4: |x| up to 1.0e6 is representable, |x| below 2^-10 has an absolute error of
+//     2^-32 (hi subnormal, lo' picks up the residual).  An activation beyond 1.0e6 becomes inf -> (inf - inf) = NaN in lo': the
+//     output row is NaN, loudly, instead of silently saturated.
+// Measured against float64 on random operands (tools/experiments/f16_split.py): max |err| / sum |x||w| = 3.7e-8 for the
+// representation alone (fp32 rounding of the SUM, which the reference's sgemm has as well: 2.4e-7), six-term bf16 3.3e-9,
+// three-term bf16 2.2e-6.  Terms are issued smallest first.
+template <int SP> struct Split;
+template <> struct Split<2> {
+    static constexpr bool F16 = false;
+    static constexpr int NA = 2, NB = 2, N = 3;
     static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0};
 };
-template <> struct SplitTerms<3> {
-    static constexpr int N = 6;
+template <> struct Split<3> {
+    static constexpr bool F16 = false;
+    static constexpr int NA = 3, NB = 3, N = 6;
     static constexpr int A[6] = {2, 0, 1, 1, 0, 0}, B[6] = {0, 2, 1, 0, 1, 0};
 };
+template <> struct Split<16> {
+    static constexpr bool F16 = true;
+    static constexpr int NA = 2, NB = 3, N = 3;
+    static constexpr int A[3] = {1, 0, 0}, B[3] = {2, 1, 0};
+};
 
-// x[0..3] -> NP bf16x4 pieces (v_cvt_pk_bf16_f32, round to nearest even)
-template <int NP>
-__device__ __forceinline__ void split4(const f32x4 &x, bf16x4 (&p)[NP])
+constexpr float kActScale = 0.0625f;        // fp16 scheme: activations are split as x 2^-4
+constexpr float kLoScale = 2048.f;          // ... and the lo piece as (x 2^-4 - hi) 2^11
+constexpr float kInvLoScale = 1.f / 2048.f;
+
+// x[0..3] of an ACTIVATION -> NA pieces of 4 (bf16: v_cvt_pk_bf16_f32; fp16: v_cvt_f16_f32 -- both round to nearest even)
+template <int SP>
+__device__ __forceinline__ void split4(const f32x4 &x, u32x2 (&p)[Split<SP>::NA])
 {
+    if constexpr (Split<SP>::F16) {
+        f16x4 h, l;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float r = x[e];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            p[q][e] = (__bf16)r;
-            if (q + 1 < NP) r -= (float)p[q][e];
+        for (int e = 0; e < 4; ++e) {
+            const float xs = x[e] * kActScale;
+            h[e] = (_Float16)xs;
+            l[e] = (_Float16)((xs - (float)h[e]) * kLoScale);
         }
+        p[0] = __builtin_bit_cast(u32x2, h);
+        p[1] = __builtin_bit_cast(u32x2, l);
+    } else {
+        bf16x4 q[Split<SP>::NA];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r = x[e];
+#pragma unroll
+            for (int i = 0; i < Split<SP>::NA; ++i) {
+                q[i][e] = (__bf16)r;
+                if (i + 1 < Split<SP>::NA) r -= (float)q[i][e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < Split<SP>::NA; ++i) p[i] = __builtin_bit_cast(u32x2, q[i]);
     }
 }
 
-// acc += a . b over the pieces, smallest terms first (one 32 x 32 x 16 MFMA per term)
-template <int NP>
-__device__ __forceinline__ void mfma_terms(f32x16 &acc, const bf16x8 (&a)[NP], const bf16x8 (&b)[NP])
+// w[0..3] of a WEIGHT (fp16 scheme: already multiplied by its channel's t_n) -> NB pieces of 4
+template <int SP>
+__device__ __forceinline__ void split4_weight(const f32x4 &w, u32x2 (&p)[Split<SP>::NB])
 {
-    using T = SplitTerms<NP>;
+    if constexpr (Split<SP>::F16) {
+        f16x4 h, l, s;
 #pragma unroll
-    for (int t = 0; t < T::N; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[T::A[t]], b[T::B[t]], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) {
+            h[e] = (_Float16)w[e];
+            l[e] = (_Float16)(w[e] - (float)h[e]);
+            s[e] = (_Float16)((float)h[e] * kInvLoScale);
+        }
+        p[0] = __builtin_bit_cast(u32x2, h);
+        p[1] = __builtin_bit_cast(u32x2, l);
+        p[2] = __builtin_bit_cast(u32x2, s);
+    } else {
+        split4<SP>(w, p);
+    }
+}
+
+// the power of two that puts `amax` (the largest |w| of an output channel) into [2^13, 2^14); 1 for an all-zero / non-finite channel
+__device__ __forceinline__ float weight_scale_for(float amax)
+{
+    if (!(amax > 0.f) || !(amax < 3.0e38f)) return 1.f;
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu) - 127;   // floor(log2 amax) for normal numbers
+    int s = 13 - e;
+    s = s < -100 ? -100 : (s > 100 ? 100 : s);
+    return __builtin_bit_cast(float, (unsigned)(s + 127) << 23);
+}
+
+// one term: acc += a . b (32 x 32 x 16) on the scheme's element type
+template <int SP>
+__device__ __forceinline__ f32x16 mfma16(const u32x4 &a, const u32x4 &b, const f32x16 &acc)
+{
+    if constexpr (Split<SP>::F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// acc += x . w over the pieces, smallest terms first (one 32 x 32 x 16 MFMA per term); XA: the activation fragment is the MFMA's
+// A operand (rows of the accumulator tile = activation rows), else the weight fragment is (transposed tile)
+template <int SP, bool XA = true>
+__device__ __forceinline__ void mfma_terms(f32x16 &acc, const u32x4 (&x)[Split<SP>::NA], const u32x4 (&w)[Split<SP>::NB])
+{
+    using T = Split<SP>;
+#pragma unroll
+    for (int t = 0; t < T::N; ++t) acc = XA ? mfma16<SP>(x[T::A[t]], w[T::B[t]], acc) : mfma16<SP>(w[T::B[t]], x[T::A[t]], acc);
 }
 
 // the same for a wave's TI x TJ tiles, term-major: consecutive MFMAs never share an accumulator; per accumulator the order is
 // still smallest term first, k ascending
-template <int NP, int TI, int TJ>
-__device__ __forceinline__ void mfma_tiles(f32x16 (&acc)[TI][TJ], const bf16x8 (&a)[TI][NP], const bf16x8 (&b)[TJ][NP])
+template <int SP, int TI, int TJ, bool XA = true>
+__device__ __forceinline__ void mfma_tiles(f32x16 (&acc)[TI][TJ], const u32x4 (&x)[TI][Split<SP>::NA], const u32x4 (&w)[TJ][Split<SP>::NB])
 {
-    using T = SplitTerms<NP>;
+    using T = Split<SP>;
 #pragma unroll
     for (int t = 0; t < T::N; ++t)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][T::A[t]], b[j][T::B[t]], acc[i][j], 0, 0, 0);
+                acc[i][j] = XA ? mfma16<SP>(x[i][T::A[t]], w[j][T::B[t]], acc[i][j]) : mfma16<SP>(w[j][T::B[t]], x[i][T::A[t]], acc[i][j]);
 }
 
-// `terms` argument of the C ABI (3 or 6) -> pieces per operand, or 0
-inline int split_pieces(int terms) { return terms == 3 ? 2 : terms == 6 ? 3 : 0; }
+// `terms` argument of the C ABI -> scheme: 3 / 6 bf16 terms, 16 = fp16 pieces (three terms); 0: unknown
+inline int split_scheme(int terms) { return terms == 3 ? 2 : terms == 6 ? 3 : terms == 16 ? 16 : 0; }
+inline int scheme_pieces_b(int sp) { return sp == 16 ? 3 : sp; }   // 16-bit weight pieces per element
 
 }  // namespace
 

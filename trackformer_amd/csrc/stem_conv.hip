@@ -26,6 +26,8 @@
 
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "msda_common.h"
 #include "split_product.h"
 #include "tf_fused.h"
@@ -40,7 +42,7 @@ constexpr int kTH = 4, kTW = 32, kTilesPerBlock = 4; // output rows per block (o
 constexpr int kPR = 2 * kTH + 5, kPW = 72;           // patch rows (13), floats per patch row (70 used)
 constexpr int kPatch = 3 * kPR * kPW;                // 2808 floats
 
-template <int NP, bool RELU>
+template <int SP, bool RELU>
 __global__ void __launch_bounds__(256)
 stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, float *Y, int H, int W,
                     int Ho, int Wo)
@@ -52,24 +54,30 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
     const int oy0 = blockIdx.y * kTH, n = blockIdx.z;
     const float *xin = X + (size_t)n * 3 * H * W;
 
-    // ---- the whole weight: fragment (n-tile t, k-step q, part p) at ((t KQ + q) NP + p) 64 + lane (linear_stream.hip)
-    u32x4 wf[2][kKQ][NP];
+    // ---- the whole weight: fragment (n-tile t, k-step q, part p) at ((t KQ + q) NB + p) 64 + lane (linear_stream.hip)
+    constexpr int NA = Split<SP>::NA, NB = Split<SP>::NB;
+    u32x4 wf[2][kKQ][NB];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int q = 0; q < kKQ; ++q)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) wf[t][q][p] = Wp[((size_t)(t * kKQ + q) * NP + p) * 64 + lane];
+            for (int p = 0; p < NB; ++p) wf[t][q][p] = Wp[((size_t)(t * kKQ + q) * NB + p) * 64 + lane];
 
     const unsigned ybytes = (unsigned)((size_t)gridDim.z * Ho * Wo * kCout * 4);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, ybytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(bias ? bias : X), 0, bias ? kCout * 4u : 0u, 0x00020000);
-    f32x4 bv[2][4];   // bias of the lane's channels: tile t, group g -> channels 32 t + 8 g + 4 half + 0..3
+    f32x4 bv[2][4], rv[2][4];   // bias [and, fp16 scheme, power of two] of the lane's channels: tile t, group g -> channels 32 t + 8 g + 4 half + 0..3
+    // the packed weight is padded to 256 output channels (8 n-tiles); its per-channel factors lie behind the fragments
+    const float *const rsc = reinterpret_cast<const float *>(Wp + (size_t)8 * kKQ * NB * 64);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
+        for (int g = 0; g < 4; ++g) {
             bv[t][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, (unsigned)(32 * t + 8 * g + 4 * half) * 4u, 0, 0));
+            rv[t][g] = f32x4{1.f, 1.f, 1.f, 1.f};
+            if constexpr (Split<SP>::F16) rv[t][g] = *reinterpret_cast<const f32x4 *>(rsc + 32 * t + 8 * g + 4 * half);
+        }
 
     const int oy = oy0 + wave;
     // ---- patch staging: rows 2 oy0 - 3 .. + 12, columns 2 ox0 - 3 .. + 71 of the three planes, zeros outside the image.
@@ -142,22 +150,17 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xv[e] = half ? 0.f : xv[e];
             }
-            bf16x8 xp[NP];
+            u32x2 plo[NA], phi[NA];
+            split4<SP>(f32x4{xv[0], xv[1], xv[2], xv[3]}, plo);
+            split4<SP>(f32x4{xv[4], xv[5], xv[6], xv[7]}, phi);
+            u32x4 xp[NA];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float r = xv[e];
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    xp[p][e] = (__bf16)r;
-                    if (p + 1 < NP) r -= (float)xp[p][e];
-                }
-            }
-            using T = SplitTerms<NP>;   // x piece T::A[t] x weight piece T::B[t], smallest terms first
+            for (int p = 0; p < NA; ++p) xp[p] = u32x4{plo[p].x, plo[p].y, phi[p].x, phi[p].y};
+            using T = Split<SP>;   // x piece T::A[t] x weight piece T::B[t], smallest terms first
 #pragma unroll
             for (int tt = 0; tt < T::N; ++tt)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[t][q][T::B[tt]]), xp[T::A[tt]], acc[t], 0, 0, 0);
+                for (int t = 0; t < 2; ++t) acc[t] = mfma16<SP>(wf[t][q][T::B[tt]], xp[T::A[tt]], acc[t]);
         }
         // ---- epilogue: lane -> pixel (oy, ox0 + m); registers 4 g .. 4 g + 3 of tile t -> channels 32 t + 8 g + 4 half + 0..3
         const int ox = ox0 + m;
@@ -167,8 +170,10 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 v = {acc[t][4 * g] + bv[t][g].x, acc[t][4 * g + 1] + bv[t][g].y, acc[t][4 * g + 2] + bv[t][g].z,
-                           acc[t][4 * g + 3] + bv[t][g].w};
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = Split<SP>::F16 ? __builtin_fmaf(acc[t][4 * g + e], rv[t][g][e], bv[t][g][e]) : acc[t][4 * g + e] + bv[t][g][e];
                 if (RELU) {
                     v.x = v.x > 0.f ? v.x : 0.f;
                     v.y = v.y > 0.f ? v.y : 0.f;
@@ -189,8 +194,8 @@ extern "C" int tf_stem_conv7x7_f32(const float *x, const void *w_packed, const f
                                    int terms, void *stream)
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
-    const int np = split_pieces(terms);
-    if (N <= 0 || H <= 0 || W <= 0 || N > 65535 || np == 0) return TF_MSDA_ERR_BAD_DIMS;
+    const int sp = split_scheme(terms);
+    if (N <= 0 || H <= 0 || W <= 0 || N > 65535 || sp == 0) return TF_MSDA_ERR_BAD_DIMS;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     if ((long long)N * Ho * Wo * kCout * 4 >= 0xC0000000LL || (long long)N * 3 * H * W >= (1LL << 31)) return TF_MSDA_ERR_BAD_DIMS;
     if ((reinterpret_cast<uintptr_t>(w_packed) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(bias)) & 15)
@@ -199,12 +204,13 @@ extern "C" int tf_stem_conv7x7_f32(const float *x, const void *w_packed, const f
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
     const u32x4 *wp = static_cast<const u32x4 *>(w_packed);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (np == 3) {
-        if (relu) hipLaunchKernelGGL((stem_conv7x7_kernel<3, true>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
-        else hipLaunchKernelGGL((stem_conv7x7_kernel<3, false>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
-    } else {
-        if (relu) hipLaunchKernelGGL((stem_conv7x7_kernel<2, true>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
-        else hipLaunchKernelGGL((stem_conv7x7_kernel<2, false>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
-    }
+    auto go = [&](auto spc) {
+        constexpr int SP = decltype(spc)::value;
+        if (relu) hipLaunchKernelGGL((stem_conv7x7_kernel<SP, true>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
+        else hipLaunchKernelGGL((stem_conv7x7_kernel<SP, false>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
+    };
+    if (sp == 2) go(std::integral_constant<int, 2>{});
+    else if (sp == 3) go(std::integral_constant<int, 3>{});
+    else go(std::integral_constant<int, 16>{});
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
