@@ -67,27 +67,38 @@ int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta,
                           int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream);
 
 /*
- * THE SPLIT PRODUCT (every matrix-core kernel below).  fp32 operands are cut into bf16 pieces (round to nearest even):
- *   hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid)          (the residuals are exact in fp32)
- * and a product x . w is formed from v_mfma_f32_32x32x16_bf16 terms with fp32 accumulation, smallest terms first:
- *   six terms   (pieces hi, mid, lo):  x_lo.w_hi + x_hi.w_lo + x_mid.w_mid + x_mid.w_hi + x_hi.w_mid + x_hi.w_hi
- *               The three pieces carry all 24 significand bits; the dropped terms are below 2^-24 |x||w| -- the arithmetic of the
- *               reference (fp32 nn.Linear / Conv2d; models/ops/src/cuda/ms_deform_attn_cuda.cu:69 dispatches on fp32) in another
- *               summation order.  THE DEFAULT of trackformer_amd (fused.set_split_terms(6)).
- *   three terms (pieces hi, mid):      x_mid.w_hi + x_hi.w_mid + x_hi.w_hi      relative error of a product < 2^-16: boxes / logits
- *               stay inside the 1e-3 parity bar, but track ids leave the reference's earlier than fp32 does (frame 14 instead of
- *               59 of the 64-frame fixture, profiles/r04_id_parity_64.txt): the opt-in fast mode.
- * Entry points that take the weight as separate piece tensors (`w_hi`, `w_mid`, `w_lo`: bf16 [N, K] each, split once by the
- * caller) select by `w_lo`: NULL -> three terms, else six.  Entry points that take a PACKED weight select by `terms` (3 or 6),
- * which must be the value the weight was packed with.  x is split the same way inside the kernels.
+ * THE SPLIT PRODUCT (every matrix-core kernel below; trackformer_amd/csrc/split_product.h).  fp32 operands are cut into 16-bit
+ * pieces (round to nearest even, residuals exact in fp32) and a product x . w is formed from v_mfma_f32_32x32x16_{bf16,f16}
+ * terms with fp32 accumulation, smallest terms first.  The reference computes these layers in fp32 (nn.Linear / Conv2d;
+ * models/ops/src/cuda/ms_deform_attn_cuda.cu:69 dispatches on fp32 tensors, no autocast anywhere).
+ *   terms = 6   bf16 pieces hi, mid, lo of both operands:  x_lo.w_hi + x_hi.w_lo + x_mid.w_mid + x_mid.w_hi + x_hi.w_mid + x_hi.w_hi
+ *               The three pieces carry all 24 significand bits; the dropped terms are below 2^-24 |x||w|: fp32 arithmetic in
+ *               another summation order.
+ *   terms = 16  fp16 pieces:  activation  xh = f16(x / 16),  xl = f16((x / 16 - xh) 2^11)
+ *                             weight      wh = f16(w t_n),   wl = f16(w t_n - wh),   ws = f16(wh 2^-11)
+ *               three terms  xl.ws + xh.wl + xh.wh,  result times r_n = 16 / t_n.  Two fp16 pieces carry 22 significand bits + the
+ *               sign of the lower one (error of an operand <= 2^-23 of it); the only dropped product (lo.lo) is below 2^-22 |x||w|.
+ *               t_n: the power of two that puts the largest |w| of output channel n into [2^13, 2^14) -- with the lower
+ *               activation piece stored times 2^11 nothing falls into fp16's subnormals (|x| < 1.0e6; beyond that the row becomes
+ *               NaN instead of saturating).  Half the matrix work of terms = 6 at fp32-class accuracy (against float64 on random
+ *               operands: 3.7e-8 of sum |x||w| for the representation; the fp32 rounding of the sum itself is 2.4e-7).
+ *   terms = 3   bf16 pieces hi, mid:  x_mid.w_hi + x_hi.w_mid + x_hi.w_hi   relative error of a product < 2^-16: boxes / logits stay
+ *               inside the 1e-3 parity bar, but track ids leave the reference's earlier than fp32 does (frame 14 instead of 59 of
+ *               the 64-frame fixture, profiles/r04_id_parity_64.txt): the opt-in fast mode.
+ * Entry points that take the weight as separate piece tensors (16-bit [N, K] each, made once by the caller) select by which are
+ * given:  (w_hi, w_mid)                       bf16 hi, mid                   -> three terms
+ *         (w_hi, w_mid, w_lo)                 bf16 hi, mid, lo               -> six terms
+ *         (w_hi, w_mid, w_lo, w_scale)        fp16 wh, wl, ws + r_n [N] fp32 -> the fp16 product
+ * Entry points that take a PACKED weight select by `terms` (3, 6 or 16), which must be the value the weight was packed with
+ * (tf_linear_pack_weight_f32 computes t_n / r_n itself).  x is split inside the kernels.
  */
 
 /*
  * y[M, N] = x[M, K] . w[N, K]^T + bias[N] (bias may be NULL), ReLU if relu != 0; fp32 in and out, row-major.
- * K % 32 == 0, 16-byte aligned x / w_hi / w_mid / w_lo.  (trackformer_amd/csrc/linear_split.hip)
+ * K % 32 == 0, 16-byte aligned x / w_hi / w_mid / w_lo; w_lo, w_scale: see THE SPLIT PRODUCT.  (trackformer_amd/csrc/linear_split.hip)
  */
-int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                        int64_t M, int K, int N, int relu, void *stream);
+int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, const float *bias,
+                        float *y, int64_t M, int K, int N, int relu, void *stream);
 
 /*
  * The same product with a residual in the epilogue: y = act(x . w^T + bias + residual), residual [M, N] fp32 (may alias y).
@@ -95,7 +106,7 @@ int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, con
  * reference: models/backbone.py:45-55 + torchvision's Bottleneck.forward): on channels_last activations a stride-1 1 x 1
  * convolution IS this GEMM with M = N_img * H * W rows, the BN scale folded into w and its shift as bias.
  */
-int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias,
+int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, const float *bias,
                             const float *residual, float *y, int64_t M, int K, int N, int relu, void *stream);
 
 /*
@@ -106,25 +117,26 @@ int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid,
  * For torchvision's Bottleneck.conv2 + FrozenBatchNorm2d + ReLU (BN scale folded into w, shift as bias).  Input, output and
  * weight pieces below 3 GiB each (buffer-resource offsets), else TF_MSDA_ERR_BAD_DIMS.
  */
-int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                         int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, const float *bias,
+                         float *y, int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
 /* The same convolution with the K loop (9 Cin) cut into `ksplit` pieces that run as separate workgroups -- for few output
  * pixels under a long K (the extra pyramid level of deformable_detr.py:55-79: 2048 -> 256 at 13 x 21; layer4's 3 x 3
  * convolutions).  The pieces write partial sums to `workspace` (ksplit * N*Hout*Wout * cout floats, 16-byte aligned), a second
  * launch adds them in a fixed order (deterministic, unlike atomics) and applies bias / ReLU.  ksplit in 1..64 (1: no workspace
  * needed, identical to tf_conv3x3_split_f32); cout % 4 == 0 and 16-byte aligned y / bias when ksplit > 1. */
-int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                          float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, const float *bias,
+                          float *y, float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
                           void *stream);
 /* The same kernel for a strided 1 x 1 convolution without padding (w [Cout, Cin]): the projections of the identity branch
  * (torchvision Bottleneck.downsample, stride 2) -- the rows of the GEMM are every stride-th pixel. */
-int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                                 int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream);
+int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale,
+                                 const float *bias, float *y, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+                                 void *stream);
 /* The 1 x 1 convolution (stride 1 or 2, w [Cout, Cin]) with the K loop (Cin) cut into `ksplit` pieces, as tf_conv3x3_splitk_f32:
  * ResNet-50's reducing 1 x 1 convolutions of layer3 / layer4 (torchvision Bottleneck.conv1: 1024 -> 256 at 50 x 84, 2048 -> 512 at
  * 25 x 42 for an 800 x 1333 frame) are 132 / 68 workgroups of 32 / 64 K-slices -- fewer than the chip has CUs. */
-int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                          float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, const float *bias,
+                          float *y, float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
                           void *stream);
 
 /*
@@ -151,18 +163,19 @@ int tf_bias_relu_maxpool_f32(const float *x, const float *bias, float *out, int 
 /* y[M, N] = (x + x2)[M, K] . w^T + bias: tf_linear_split_f32 with an element-wise add in front, done as the activation tile is
  * staged -- `with_pos_embed(src, pos)` + a projection (models/deformable_transformer.py:279-283, ms_deform_attn.py:67-72)
  * without a separate pass over the tokens.  Bit-identical to adding first. */
-int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const void *w_lo,
+int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale,
                             const float *bias, float *y, int64_t M, int K, int N, void *stream);
 
 /*
  * The same product with the weight in PACKED form (trackformer_amd/csrc/linear_stream.hip): the weight is split into
  * its bf16 pieces once and stored in matrix-core fragment order, so that the GEMM streams it from L2 into registers and
  * only the activations pass through LDS.  Results are bit-identical to tf_linear_split_f32 with the same number of terms.
- *   tf_linear_packed_bytes(K, N, terms)          size of the packed buffer (N padded to a multiple of 256), or -1; K % 16 == 0
+ *   tf_linear_packed_bytes(K, N, terms)          size of the packed buffer (N padded to a multiple of 256; terms = 16: + a float
+ *                                                per padded output channel behind the fragments), or -1; K % 16 == 0
  *   tf_linear_pack_weight_f32(w, packed, ...)    w [N, K] fp32 row-major -> packed (16-byte aligned pointers); one small kernel
  *   tf_linear_packed_f32                         y[M, N] = act(x[M, K] . w^T + bias + residual); K % 64 == 0, 16-byte aligned x;
  *                                                bias / residual [M, N] may be NULL, residual may alias y; y below 3 GiB
- * terms: 3 or 6 (see THE SPLIT PRODUCT above); a weight packed for 6 terms holds three pieces per fragment.
+ * terms: 3, 6 or 16 (see THE SPLIT PRODUCT above); a weight packed for 6 / 16 holds three pieces per fragment.
  * The residual form is the closing 1 x 1 convolution of a ResNet bottleneck (conv3 -> FrozenBatchNorm2d -> `out += identity` ->
  * ReLU; reference: models/backbone.py:45-55 + torchvision's Bottleneck.forward) on channels_last activations.
  */

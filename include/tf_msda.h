@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define TF_MSDA_ABI_VERSION 2
+#define TF_MSDA_ABI_VERSION 3
 #define TF_MSDA_MAX_LEVELS 16
 
 typedef enum tf_msda_status {

@@ -60,19 +60,19 @@ def lib():
     L.tf_ffn_fused_f32.restype = ci
     L.tf_ffn_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_add_f32.restype = ci
-    L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_linear_split_f32.restype = ci
-    L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci
-    L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_conv3x3_splitk_f32.restype = ci
-    L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv3x3_split_f32.restype = ci
-    L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_conv1x1_splitk_f32.restype = ci
-    L.tf_conv1x1_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.tf_conv1x1_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv1x1_strided_split_f32.restype = ci
-    L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_linear_packed_bytes.restype = ctypes.c_int64
     L.tf_linear_packed_bytes.argtypes = [ci, ci, ci]
     L.tf_linear_pack_weight_f32.restype = ci
@@ -190,23 +190,40 @@ def bf16_split(w, terms=None):
     return hi, mid, lo
 
 
+def f16_split(w):
+    """w [N, K] (fp32) -> (wh, wl, ws, r): the fp16 scheme of include/tf_fused.h as uint16 bit patterns + the channels' factors
+    r_n = 16 / t_n (what fused._split_weight hands the kernels for split_terms() == 16)."""
+    w = w.astype(np.float32)
+    amax = np.abs(w).max(axis=1)
+    _, e = np.frexp(amax)                       # amax = m 2^e, m in [0.5, 1)
+    t = np.ldexp(np.float32(1), np.clip(14 - e, -100, 100)).astype(np.float32)
+    t = np.where((amax > 0) & (amax < 3.0e38), t, np.float32(1)).astype(np.float32)
+    ws = (w * t[:, None]).astype(np.float32)
+    hi = ws.astype(np.float16)
+    lo = (ws - hi.astype(np.float32)).astype(np.float16)
+    hs = (hi.astype(np.float32) * np.float32(1.0 / 2048.0)).astype(np.float16)
+    return hi.view(np.uint16), lo.view(np.uint16), hs.view(np.uint16), (np.float32(16) / t).astype(np.float32)
+
+
 def _pieces(w2d, terms=None):
-    """16-byte aligned contiguous piece arrays of a [N, K] weight."""
-    return tuple(None if p is None else _aligned16(np.ascontiguousarray(p)) for p in bf16_split(w2d, terms))
+    """16-byte aligned contiguous piece arrays of a [N, K] weight -> (p0, p1, p2 | None, scale | None)."""
+    if (terms or TERMS) == 16:
+        return tuple(_aligned16(np.ascontiguousarray(p)) for p in f16_split(w2d))
+    return tuple(None if p is None else _aligned16(np.ascontiguousarray(p)) for p in bf16_split(w2d, terms)) + (None,)
 
 
 def linear_split(x, w, bias=None, relu=False, residual=None):
     x, w = _c(x, np.float32), _c(w, np.float32)
     M, K = x.shape
     N = w.shape[0]
-    hi, mid, lo = _pieces(w)
+    hi, mid, lo, sc = _pieces(w)
     b = _c(bias, np.float32) if bias is not None else None
     y = np.full((M, N), np.nan, np.float32)
     if residual is not None:
         r = _c(residual, np.float32)
-        rc = lib().tf_linear_split_res_f32(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(r), _p(y), M, K, N, int(relu), None)
+        rc = lib().tf_linear_split_res_f32(_p(x), _p(hi), _p(mid), _p(lo), _p(sc), _p(b), _p(r), _p(y), M, K, N, int(relu), None)
     else:
-        rc = lib().tf_linear_split_f32(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(y), M, K, N, int(relu), None)
+        rc = lib().tf_linear_split_f32(_p(x), _p(hi), _p(mid), _p(lo), _p(sc), _p(b), _p(y), M, K, N, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_linear_split_f32: status %d" % rc)
     return y
@@ -217,10 +234,10 @@ def linear_split_add(x, x2, w, bias=None):
     x, x2, w = _aligned(x), _aligned(x2), _c(w, np.float32)
     M, K = x.shape
     N = w.shape[0]
-    hi, mid, lo = _pieces(w)
+    hi, mid, lo, sc = _pieces(w)
     b = _aligned(bias)
     y = np.full((M, N), np.nan, np.float32)
-    rc = lib().tf_linear_split_add_f32(_p(x), _p(x2), _p(hi), _p(mid), _p(lo), _p(b), _p(y), M, K, N, None)
+    rc = lib().tf_linear_split_add_f32(_p(x), _p(x2), _p(hi), _p(mid), _p(lo), _p(sc), _p(b), _p(y), M, K, N, None)
     if rc != 0:
         raise RuntimeError("tf_linear_split_add_f32: status %d" % rc)
     return y
@@ -382,13 +399,13 @@ def conv3x3_split(x_nhwc, w_ohwi, bias=None, relu=False, stride=1):
     n, h, wd, cin = x.shape
     cout, ks = w.shape[0], w.shape[1]
     x = _aligned(x)
-    hi, mid, lo = _pieces(w.reshape(cout, ks * ks * cin))
+    hi, mid, lo, sc = _pieces(w.reshape(cout, ks * ks * cin))
     b = _c(bias, np.float32) if bias is not None else None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
     y = np.full((n, ho, wo, cout), np.nan, np.float32)
     fn = lib().tf_conv3x3_split_f32 if ks == 3 else lib().tf_conv1x1_strided_split_f32
-    rc = fn(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(y), n, h, wd, cin, cout, stride, int(relu), None)
+    rc = fn(_p(x), _p(hi), _p(mid), _p(lo), _p(sc), _p(b), _p(y), n, h, wd, cin, cout, stride, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_conv3x3_split_f32: status %d" % rc)
     return y
@@ -419,14 +436,14 @@ def conv3x3_splitk(x_nhwc, w_ohwi, bias=None, relu=False, stride=1, ksplit=4):
     x, w = _aligned(x_nhwc), _c(w_ohwi, np.float32)
     n, h, wd, cin = x.shape
     cout, ks = w.shape[0], w.shape[1]
-    hi, mid, lo = _pieces(w.reshape(cout, ks * ks * cin))
+    hi, mid, lo, sc = _pieces(w.reshape(cout, ks * ks * cin))
     b = _aligned(bias)
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
     y = _aligned(np.full((n, ho, wo, cout), np.nan, np.float32))
     ws = _aligned(np.full((max(ksplit, 1), n * ho * wo * cout), np.nan, np.float32))
     fn = lib().tf_conv3x3_splitk_f32 if ks == 3 else lib().tf_conv1x1_splitk_f32
-    rc = fn(_p(x), _p(hi), _p(mid), _p(lo), _p(b), _p(y), _p(ws), ksplit, n, h, wd, cin, cout, stride, int(relu), None)
+    rc = fn(_p(x), _p(hi), _p(mid), _p(lo), _p(sc), _p(b), _p(y), _p(ws), ksplit, n, h, wd, cin, cout, stride, int(relu), None)
     if rc != 0:
         raise RuntimeError("tf_conv%dx%d_splitk_f32: status %d" % (ks, ks, rc))
     return y

@@ -13,7 +13,7 @@ from tests.util_emu_gpu_path import gpu_path_on_emulator
 pytestmark = pytest.mark.skipif(not emu_lib.available(), reason="needs a host clang++ (ROCm's llvm) to build the emulated library")
 
 
-def _run(case, optin, fn=None):
+def _run(case, optin, fn=None, terms=None):
     from trackformer_amd import backbone, fused
     with gpu_path_on_emulator() as lib:
         setters = [backbone.set_conv1x1_split, backbone.set_conv3x3_split, fused.set_input_proj_fused, fused.set_box_refine_fused,
@@ -23,6 +23,8 @@ def _run(case, optin, fn=None):
         # the stream form of the convolutions for EVERY shape (at the small test frame the default rule -- many output pixels
         # under >= 128 channels -- would select it nowhere)
         prev.append((fused.set_conv_stream, fused.set_conv_stream("all" if optin else False)))
+        if terms is not None:
+            prev.append((fused.set_split_terms, fused.set_split_terms(terms)))
         prev += [(lambda v: setattr(fused, "_LINLN_MIN_ROWS", v), fused._LINLN_MIN_ROWS),
                  (lambda v: setattr(fused, "_FFN_FUSED_MIN_ROWS", v), fused._FFN_FUSED_MIN_ROWS)]
         fused._LINLN_MIN_ROWS = 1
@@ -72,6 +74,20 @@ def test_gpu_inference_path_on_the_emulator_matches_reference(optin):
         float(np.abs(out['pred_logits'].numpy() - z['pred_logits']).max())))
 
 
+@pytest.mark.parametrize("case", ["cfg2_deformable_tracking", "cfg4_multi_frame_tracking"])
+def test_gpu_inference_path_with_fp16_pieces_matches_reference(case):
+    """The same path with every split product as the fp16 product (fused.set_split_terms(16): two fp16 pieces per activation, three
+    per weight, three MFMAs per product -- include/tf_fused.h) against the reference goldens, at the tolerance the six-term
+    product meets; hidden 256 and 288."""
+    model, out, res, feats, calls = _run(case, True, terms=16)
+    assert calls.get("tf_ffn_fused_f32", 0) >= 12 and calls.get("tf_linear_res_ln_f32", 0) >= 18 and calls.get("tf_conv_packed_f32", 0) >= 21
+    shared.compare_to_golden(case, model, out, res, feats, box_tol=2e-5, logit_tol=1e-4)
+    z = np.load(shared.os.path.join(shared.GOLDEN, "model_%s.npz" % case))
+    print("fp16 pieces, %s: max |d boxes| %.2e  max |d logits| %.2e" % (
+        case, float(np.abs(out['pred_boxes'].numpy() - z['pred_boxes']).max()),
+        float(np.abs(out['pred_logits'].numpy() - z['pred_logits']).max())))
+
+
 def test_multi_frame_model_hidden_288_on_the_emulator():
     """cfg 4's model family (hidden 288: head dimension 36, two frames x 4 levels in the decoder, GroupNorm with 9 channels
     per group) through the GPU path with every opt-in route: msda_fwd_f32_pquad<.., 36>, msda_fwd_f32_direct9, the
@@ -84,10 +100,11 @@ def test_multi_frame_model_hidden_288_on_the_emulator():
     assert calls.get("tf_ffn_fused_f32", 0) >= 12 and calls.get("tf_linear_res_ln_f32", 0) >= 18 and calls.get("tf_add_layernorm_f32", 0) == 0
 
 
-def test_tracker_sequence_ids_on_the_emulator_with_every_opt_in_route():
+@pytest.mark.parametrize("terms", [6, 16], ids=["six_terms", "fp16_pieces"])
+def test_tracker_sequence_ids_on_the_emulator_with_every_opt_in_route(terms):
     """Six frames of Tracker.step through the emulated GPU path, all opt-in routes on: track ids / frames / source queries
     equal the reference golden bit for bit (the decisions hang on scores next to thresholds)."""
-    tracker, rows, active, inactive, calls = _run("cfg2_deformable_tracking", True, fn=lambda: shared.run_tracker(False))
+    tracker, rows, active, inactive, calls = _run("cfg2_deformable_tracking", True, fn=lambda: shared.run_tracker(False), terms=terms)
     shared.compare_tracker_to_golden(False, tracker, rows, active, inactive, box_tol_px=0.05)
     assert calls.get("tf_conv_packed_f32", 0) >= (17 + 3) * 6 and calls.get("tf_box_refine_f32") == 36
 

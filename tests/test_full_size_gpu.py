@@ -400,7 +400,7 @@ def test_conv3x3_split_k(dev, shape, cout, stride, ksplit):
     w = (torch.randn(cout, shape[1], 3, 3, generator=g) / (3 * shape[1] ** 0.5)).to(dev)
     b = torch.randn(cout, generator=g).to(dev)
     taps = w.permute(0, 2, 3, 1).reshape(cout, 9 * shape[1]).contiguous()
-    hi, mid, lo = fused._split_weight(taps)
+    hi, mid, lo, wsc = fused._split_weight(taps)
     n, cin, h, wd = shape
     ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
     outs = []
@@ -408,7 +408,7 @@ def test_conv3x3_split_k(dev, shape, cout, stride, ksplit):
         y = torch.full((n, ho, wo, cout), float("nan"), device=dev)
         ws = torch.empty((ksplit, n * ho * wo * cout), device=dev)
         rc = _cabi.lib().tf_conv3x3_splitk_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if lo is None else lo.data_ptr(),
-                                               b.data_ptr(), y.data_ptr(), ws.data_ptr(), ksplit, n, h, wd, cin, cout, stride, 1, fused._stream(dev))
+                                               0 if wsc is None else wsc.data_ptr(), b.data_ptr(), y.data_ptr(), ws.data_ptr(), ksplit, n, h, wd, cin, cout, stride, 1, fused._stream(dev))
         _cabi.check(rc, "tf_conv3x3_splitk_f32")
         outs.append(y)
     ref = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)).permute(0, 2, 3, 1)

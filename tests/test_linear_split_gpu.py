@@ -125,12 +125,14 @@ def test_split_linear_declines_what_it_cannot_do(dev, split_on):
     assert split_on.linear(x.double(), torch.randn(8, 48, device=dev).double()) is None
     from trackformer_amd import _cabi
     one = torch.zeros(64, device=dev)
-    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), 0, 0, one.data_ptr(), 1, 48, 1, 0, 0)
+    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), 0, 0, 0, one.data_ptr(), 1, 48, 1, 0, 0)
     assert rc == -2
-    rc = _cabi.lib().tf_linear_split_f32(0, one.data_ptr(), one.data_ptr(), 0, 0, one.data_ptr(), 1, 32, 1, 0, 0)
+    rc = _cabi.lib().tf_linear_split_f32(0, one.data_ptr(), one.data_ptr(), 0, 0, 0, one.data_ptr(), 1, 32, 1, 0, 0)
     assert rc == -1
-    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr() + 2, 0, one.data_ptr(), 1, 32, 1, 0, 0)
+    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr() + 2, 0, 0, one.data_ptr(), 1, 32, 1, 0, 0)
     assert rc == -2                                                               # misaligned lo piece
+    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), 0, one.data_ptr(), 0, one.data_ptr(), 1, 32, 1, 0, 0)
+    assert rc == -1                                                               # fp16 pieces (w_scale given) without the third piece
     split_on.set_split_linear(False)
     assert split_on.linear(torch.randn(4, 32, device=dev), torch.randn(4, 32, device=dev)) is None   # switched off
 
@@ -182,8 +184,9 @@ def test_buffer_store_epilogue_and_residual(dev, split_on, M, K, N, bias, relu):
     plain = split_on.linear(x, w, b, relu=False) + r
     assert torch.equal(got_res, plain.clamp_min(0) if relu else plain)
     guard = torch.full((M + 300, N), 7.0, device=dev)       # the kernel writes into the first M rows of a larger buffer
-    hi, mid, lo = split_on._split_weight(w)
+    hi, mid, lo, wsc = split_on._split_weight(w)
     rc = lib.tf_linear_split_f32(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), 0 if lo is None else lo.data_ptr(),
+                                 0 if wsc is None else wsc.data_ptr(),
                                  0 if b is None else b.data_ptr(), guard.data_ptr(), M, K, N, 1 if relu else 0,
                                  torch.cuda.current_stream().cuda_stream)
     assert rc == 0

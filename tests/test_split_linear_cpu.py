@@ -47,8 +47,8 @@ def test_weight_pieces_reconstruct_the_weight():
     from trackformer_amd import fused
     w = torch.randn(64, 96) * 3
     assert fused.split_terms() == 6
-    hi, mid, lo = fused._split_weight(w)
-    assert hi.dtype == mid.dtype == lo.dtype == torch.bfloat16
+    hi, mid, lo, none = fused._split_weight(w)
+    assert hi.dtype == mid.dtype == lo.dtype == torch.bfloat16 and none is None
     rel = ((hi.float() + mid.float() - w).abs() / w.abs().clamp_min(1e-30)).max()
     assert float(rel) < 2.0 ** -15
     assert torch.equal(hi.double() + mid.double() + lo.double(), w.double())
@@ -60,6 +60,25 @@ def test_weight_pieces_reconstruct_the_weight():
         fused.set_split_terms(prev)
     w.add_(1.0)
     assert fused._split_weight(w)[0] is not hi  # an in-place update invalidates the cache entry
+    # fp16 pieces: w t_n = wh + wl to 2^-23 of it, ws = wh 2^-11 exactly, scale = 16 / t_n, the largest |w t_n| of a row in [2^13, 2^14)
+    w[3] *= 1e-4
+    w[5] *= 300.0
+    prev = fused.set_split_terms(16)
+    try:
+        wh, wl, ws, sc = fused._split_weight(w)
+        assert wh.dtype == wl.dtype == ws.dtype == torch.float16 and sc.dtype == torch.float32 and sc.shape == (64,)
+        t = 16.0 / sc.double()
+        assert torch.equal(torch.log2(t), torch.log2(t).round())                      # powers of two
+        scaled = w.double() * t[:, None]
+        amax = scaled.abs().amax(1)
+        assert bool(((amax >= 2.0 ** 13) & (amax < 2.0 ** 14)).all())
+        err = (wh.double() + wl.double() - scaled).abs()
+        assert bool((err <= scaled.abs() * 2.0 ** -22 + 2.0 ** -25).all())
+        assert torch.equal(ws.double() * 2048.0, wh.double()) or float((ws.double() * 2048.0 - wh.double()).abs().max()) <= 2.0 ** -13
+        assert fused._split_weight(w)[0] is wh
+    finally:
+        fused.set_split_terms(prev)
+    assert fused._split_weight(w)[0].dtype == torch.bfloat16
 
 
 @pytest.mark.parametrize("passes", [3, 6])

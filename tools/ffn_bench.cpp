@@ -45,7 +45,8 @@ int main(int argc, char **argv)
 {
     const int M = argc > 1 ? atoi(argv[1]) : 22223, F = argc > 2 ? atoi(argv[2]) : 1024, D = argc > 4 ? atoi(argv[4]) : 256;
     if (argc > 3) tf_msda_set_option("ffn_ti", atoi(argv[3]));
-    const int T = getenv("TF_SPLIT_TERMS") && atoi(getenv("TF_SPLIT_TERMS")) == 3 ? 3 : 6;   // terms per split product (default 6)
+    const int Tenv = getenv("TF_SPLIT_TERMS") ? atoi(getenv("TF_SPLIT_TERMS")) : 6;
+    const int T = Tenv == 3 ? 3 : Tenv == 16 ? 16 : 6;   // the split product (include/tf_fused.h; default six bf16 terms)
     printf("split product: %d terms\n", T);
     const int guard = 128;   // rows behind M that nothing may write
     std::mt19937 rng(11);
@@ -77,20 +78,44 @@ int main(int argc, char **argv)
     TF(tf_linear_pack_weight_f32(dW2, dP2, F, D, T, s));
 
     // the separate kernels: tf_linear_packed_f32 where it applies (K % 64 == 0), else tf_linear_split_f32 (same bits)
-    auto split_of = [&](const std::vector<float> &W, unsigned short **dhi, unsigned short **dmid, unsigned short **dlo) {
+    auto split_of = [&](const std::vector<float> &W, int n_out, unsigned short **dhi, unsigned short **dmid, unsigned short **dlo, float **dsc) {
         std::vector<unsigned short> pc[3];
         for (auto &v : pc) v.resize(W.size());
-        for (size_t i = 0; i < W.size(); ++i) {
-            float r = W[i];
-            for (int q = 0; q < 3; ++q) {   // round to nearest even, residual exact
-                unsigned u;
-                memcpy(&u, &r, 4);
-                u += 0x7FFFu + ((u >> 16) & 1u);
-                pc[q][i] = (unsigned short)(u >> 16);
-                unsigned hu = (unsigned)pc[q][i] << 16;
-                float hf;
-                memcpy(&hf, &hu, 4);
-                r -= hf;
+        const size_t kk = W.size() / (size_t)n_out;
+        std::vector<float> sc((size_t)n_out, 1.f);
+        *dsc = nullptr;
+        if (T == 16) {   // fp16 pieces wh, wl, wh 2^-11 of w t_n + the channels' factors 16 / t_n
+            for (int n = 0; n < n_out; ++n) {
+                float amax = 0.f;
+                for (size_t k = 0; k < kk; ++k) amax = std::max(amax, std::fabs(W[n * kk + k]));
+                int e = 0;
+                (void)std::frexp(amax, &e);
+                const float tn = amax > 0.f ? std::ldexp(1.f, 14 - e) : 1.f;
+                sc[n] = 16.f / tn;
+                for (size_t k = 0; k < kk; ++k) {
+                    const size_t i = n * kk + k;
+                    const float ws = W[i] * tn;
+                    const _Float16 h = (_Float16)ws, l = (_Float16)(ws - (float)h), s2 = (_Float16)((float)h * (1.f / 2048.f));
+                    memcpy(&pc[0][i], &h, 2);
+                    memcpy(&pc[1][i], &l, 2);
+                    memcpy(&pc[2][i], &s2, 2);
+                }
+            }
+            CK(hipMalloc(dsc, sc.size() * 4));
+            CK(hipMemcpy(*dsc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice));
+        } else {
+            for (size_t i = 0; i < W.size(); ++i) {
+                float r = W[i];
+                for (int q = 0; q < 3; ++q) {   // round to nearest even, residual exact
+                    unsigned u;
+                    memcpy(&u, &r, 4);
+                    u += 0x7FFFu + ((u >> 16) & 1u);
+                    pc[q][i] = (unsigned short)(u >> 16);
+                    unsigned hu = (unsigned)pc[q][i] << 16;
+                    float hf;
+                    memcpy(&hf, &hu, 4);
+                    r -= hf;
+                }
             }
         }
         unsigned short **d[3] = {dhi, dmid, dlo};
@@ -101,10 +126,11 @@ int main(int argc, char **argv)
         if (T == 3) *dlo = nullptr;   // three terms: no lo piece
     };
     unsigned short *dW1hi, *dW1mid, *dW1lo, *dW2hi, *dW2mid, *dW2lo;
-    split_of(W1, &dW1hi, &dW1mid, &dW1lo);
-    split_of(W2, &dW2hi, &dW2mid, &dW2lo);
-    auto lin1 = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dW1hi, dW1mid, dW1lo, dB1, dH, M, D, F, 1, s) : tf_linear_packed_f32(dX, dP1, dB1, nullptr, dH, M, D, F, 1, T, s); };
-    auto lin2 = [&]() { return (F % 64) ? tf_linear_split_f32(dH, dW2hi, dW2mid, dW2lo, dB2, dY0, M, F, D, 0, s) : tf_linear_packed_f32(dH, dP2, dB2, nullptr, dY0, M, F, D, 0, T, s); };
+    float *dW1sc, *dW2sc, *dWosc;
+    split_of(W1, F, &dW1hi, &dW1mid, &dW1lo, &dW1sc);
+    split_of(W2, D, &dW2hi, &dW2mid, &dW2lo, &dW2sc);
+    auto lin1 = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dW1hi, dW1mid, dW1lo, dW1sc, dB1, dH, M, D, F, 1, s) : tf_linear_packed_f32(dX, dP1, dB1, nullptr, dH, M, D, F, 1, T, s); };
+    auto lin2 = [&]() { return (F % 64) ? tf_linear_split_f32(dH, dW2hi, dW2mid, dW2lo, dW2sc, dB2, dY0, M, F, D, 0, s) : tf_linear_packed_f32(dH, dP2, dB2, nullptr, dY0, M, F, D, 0, T, s); };
 
     // ---- 1. bit identity without the LayerNorm
     TF(lin1());
@@ -208,8 +234,8 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dPo, (size_t)tf_linear_packed_bytes(D, D, T)));
     TF(tf_linear_pack_weight_f32(dWo, dPo, D, D, T, s));
     unsigned short *dWohi, *dWomid, *dWolo;
-    split_of(Wo, &dWohi, &dWomid, &dWolo);
-    auto lino = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dWohi, dWomid, dWolo, dB2, dY0, M, D, D, 0, s) : tf_linear_packed_f32(dX, dPo, dB2, nullptr, dY0, M, D, D, 0, T, s); };
+    split_of(Wo, D, &dWohi, &dWomid, &dWolo, &dWosc);
+    auto lino = [&]() { return (D % 64) ? tf_linear_split_f32(dX, dWohi, dWomid, dWolo, dWosc, dB2, dY0, M, D, D, 0, s) : tf_linear_packed_f32(dX, dPo, dB2, nullptr, dY0, M, D, D, 0, T, s); };
     TF(lino());
     CK(hipMemsetAsync(dY, 0xFF, (size_t)(M + guard) * D * 4, s));
     TF(tf_linear_res_ln_f32(dX, dPo, dB2, dX, nullptr, nullptr, 0.f, dY, M, D, D, T, s));

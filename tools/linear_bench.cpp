@@ -4,7 +4,7 @@
 //   tools/bin/linear_bench [M K N [packed | packedTI]]   (built by trackformer_amd/build.py; default 22223 256 256)
 //     packed / packed2 / packed3 / packed4: tf_linear_packed_f32 (weight packed once by tf_linear_pack_weight_f32; the digit
 //     forces the row tiles per block), whose output is also compared BIT FOR BIT with tf_linear_split_f32's
-//   TF_SPLIT_TERMS=3: the three-term product (default: six terms)
+//   TF_SPLIT_TERMS=3: the three-term bf16 product, =16: fp16 pieces (default: six bf16 terms)
 //
 // Checks a sample of output rows (all columns, incl. the block edges) against a double-precision reference and
 // times 20 launches captured in one HIP graph.  Round-1 numbers: profiles/r01_split_gemm_experiment.txt.
@@ -52,7 +52,8 @@ int main(int argc, char **argv)
     const int M = argc > 3 ? atoi(argv[1]) : 22223, K = argc > 3 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 256;
     const bool packed = argc > 4 && strncmp(argv[4], "packed", 6) == 0;
     if (packed && argv[4][6]) tf_msda_set_option("linear_stream_ti", atoi(argv[4] + 6));
-    const int T = getenv("TF_SPLIT_TERMS") && atoi(getenv("TF_SPLIT_TERMS")) == 3 ? 3 : 6;   // terms per split product
+    const int Tenv = getenv("TF_SPLIT_TERMS") ? atoi(getenv("TF_SPLIT_TERMS")) : 6;
+    const int T = Tenv == 3 ? 3 : Tenv == 16 ? 16 : 6;   // the split product (include/tf_fused.h)
     if (K % 32) {
         fprintf(stderr, "K must be a multiple of 32\n");
         return 2;
@@ -64,13 +65,33 @@ int main(int argc, char **argv)
     for (auto &v : W) v = nrm(rng) * 0.0625f;   // ~ 1 / sqrt(K): activations stay O(1), as in the model
     for (auto &v : bias) v = nrm(rng);
     std::vector<unsigned short> Whi(W.size()), Wmid(W.size()), Wlo(W.size());
-    for (size_t i = 0; i < W.size(); ++i) {
-        Whi[i] = bf16_rne(W[i]);
-        const float r = W[i] - bf16_to_f32(Whi[i]);
-        Wmid[i] = bf16_rne(r);
-        Wlo[i] = bf16_rne(r - bf16_to_f32(Wmid[i]));
+    std::vector<float> Wsc(N, 1.f);
+    if (T == 16) {   // fp16 pieces wh, wl, wh 2^-11 of w t_n + the channels' factors 16 / t_n
+        for (int n = 0; n < N; ++n) {
+            float amax = 0.f;
+            for (int k = 0; k < K; ++k) amax = std::max(amax, std::fabs(W[(size_t)n * K + k]));
+            int e = 0;
+            (void)std::frexp(amax, &e);   // amax = m 2^e, m in [0.5, 1)
+            const float tn = amax > 0.f ? std::ldexp(1.f, 14 - e) : 1.f;
+            Wsc[n] = 16.f / tn;
+            for (int k = 0; k < K; ++k) {
+                const size_t i = (size_t)n * K + k;
+                const float ws = W[i] * tn;
+                const _Float16 h = (_Float16)ws, l = (_Float16)(ws - (float)h), s = (_Float16)((float)h * (1.f / 2048.f));
+                memcpy(&Whi[i], &h, 2);
+                memcpy(&Wmid[i], &l, 2);
+                memcpy(&Wlo[i], &s, 2);
+            }
+        }
+    } else {
+        for (size_t i = 0; i < W.size(); ++i) {
+            Whi[i] = bf16_rne(W[i]);
+            const float r = W[i] - bf16_to_f32(Whi[i]);
+            Wmid[i] = bf16_rne(r);
+            Wlo[i] = bf16_rne(r - bf16_to_f32(Wmid[i]));
+        }
     }
-    float *dX, *dB, *dY;
+    float *dX, *dB, *dY, *dWsc = nullptr;
     unsigned short *dWhi, *dWmid, *dWlo = nullptr;
     CK(hipMalloc(&dX, X.size() * 4));
     CK(hipMalloc(&dB, bias.size() * 4));
@@ -81,9 +102,13 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dB, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dWhi, Whi.data(), W.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dWmid, Wmid.data(), W.size() * 2, hipMemcpyHostToDevice));
-    if (T == 6) {
+    if (T != 3) {
         CK(hipMalloc(&dWlo, W.size() * 2));
         CK(hipMemcpy(dWlo, Wlo.data(), W.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (T == 16) {
+        CK(hipMalloc(&dWsc, Wsc.size() * 4));
+        CK(hipMemcpy(dWsc, Wsc.data(), Wsc.size() * 4, hipMemcpyHostToDevice));
     }
     CK(hipMemset(dY, 0xFF, Y.size() * 4));
     hipStream_t stream;
@@ -106,7 +131,7 @@ int main(int argc, char **argv)
             return 2;
         }
         // the unpacked kernel's output first: the packed one must reproduce it bit for bit
-        prc = tf_linear_split_f32(dX, dWhi, dWmid, dWlo, dB, dY, M, K, N, 0, stream);
+        prc = tf_linear_split_f32(dX, dWhi, dWmid, dWlo, dWsc, dB, dY, M, K, N, 0, stream);
         if (prc != 0) return 2;
         CK(hipStreamSynchronize(stream));
         std::vector<float> Y0(Y.size());
@@ -125,7 +150,7 @@ int main(int argc, char **argv)
     }
     auto run = [&]() {
         return packed ? tf_linear_packed_f32(dX, dWp, dB, nullptr, dY, M, K, N, 0, T, stream)
-                      : tf_linear_split_f32(dX, dWhi, dWmid, dWlo, dB, dY, M, K, N, 0, stream);
+                      : tf_linear_split_f32(dX, dWhi, dWmid, dWlo, dWsc, dB, dY, M, K, N, 0, stream);
     };
     int rc = run();
     if (rc != 0) {

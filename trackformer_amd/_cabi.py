@@ -54,7 +54,7 @@ EXPORTED_SYMBOLS = (
     "tf_nms_host_f32",
 )
 
-ABI_VERSION = 2   # 2: the split-product entry points take w_lo / terms (include/tf_fused.h)
+ABI_VERSION = 3   # 3: the split-product entry points take w_lo / w_scale / terms (include/tf_fused.h)
 
 _lib = None
 
@@ -121,17 +121,17 @@ def lib():
     L.tf_groupnorm_nhwc_f32.restype = ci
     L.tf_groupnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
     L.tf_linear_split_f32.restype = ci
-    L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci
-    L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
+    L.tf_linear_split_res_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_conv3x3_splitk_f32.restype = ci
-    L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.tf_conv3x3_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv3x3_split_f32.restype = ci
-    L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv3x3_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_conv1x1_splitk_f32.restype = ci
-    L.tf_conv1x1_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.tf_conv1x1_splitk_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_conv1x1_strided_split_f32.restype = ci
-    L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
+    L.tf_conv1x1_strided_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.tf_linear_packed_bytes.restype = ctypes.c_int64
     L.tf_linear_packed_bytes.argtypes = [ci, ci, ci]
     L.tf_linear_pack_weight_f32.restype = ci
@@ -141,7 +141,7 @@ def lib():
     L.tf_ffn_fused_f32.restype = ci
     L.tf_ffn_fused_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_add_f32.restype = ci
-    L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
+    L.tf_linear_split_add_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, vp]
     L.tf_linear_packed_f32.restype = ci
     L.tf_linear_packed_f32.argtypes = [vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, ci, vp]
     L.tf_conv_packed_f32.restype = ci

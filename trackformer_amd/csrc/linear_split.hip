@@ -64,19 +64,24 @@ __device__ __forceinline__ int stage_row(int q) { return (q & ~7) | ((q & 1) << 
 // (profiles/r02_split_gemm_astat_trace.txt: 10.5 us of store time per 96 x 256 tile).
 // XADD (tf_linear_split_add_f32): the activation is X + X2, added element-wise as the tile is staged -- the layers'
 // `with_pos_embed(src, pos)` in front of a projection (deformable_transformer.py:279-283) without its own pass over the tokens.
-template <int NP, int BM, int BN, bool RELU, bool PREFETCH, bool RESID, bool BUFST, bool XADD = false>
+// SP: the scheme of split_product.h (2 / 3: bf16 pieces, Wsc unused; 16: fp16 pieces -- Whi / Wmid / Wlo hold the weight's hi, lo and
+// hi 2^-11 pieces and Wsc the output channels' powers of two).
+template <int SP, int BM, int BN, bool RELU, bool PREFETCH, bool RESID, bool BUFST, bool XADD = false>
 __device__ __forceinline__ void
 split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo, const float *__restrict__ bias,
-                const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N, const float *__restrict__ X2 = nullptr)
+                const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo, const float *__restrict__ Wsc,
+                const float *__restrict__ bias, const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N,
+                const float *__restrict__ X2 = nullptr)
 {
+    constexpr int NA = Split<SP>::NA, NB = Split<SP>::NB;
+    constexpr bool F16 = Split<SP>::F16;
     const unsigned short *const Wp[3] = {Whi, Wmid, Wlo};
     constexpr int TI = BM / 64, TJ = BN / 64;
     constexpr int XV = (BM * BK / 4) / THREADS;   // float4 of X per thread and slice
     constexpr int WV = (BN * BK / 8) / THREADS;   // 16-byte pieces of each weight tensor per thread and slice
     static_assert(XV >= 1 && WV >= 1, "tile too small for 256 threads");
-    __shared__ __attribute__((aligned(16))) unsigned short sA[NP][BM * LDS_STRIDE];   // [hi | mid | lo][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[NP][BN * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned short sA[NA][BM * LDS_STRIDE];   // [activation piece][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[NB][BN * LDS_STRIDE];   // [weight piece][row][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -90,7 +95,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 xr[XV];
-    u32x4 wr[NP][WV];
+    u32x4 wr[NB][WV];
     f32x4 xr2[XADD ? XV : 1];
     auto load_slice = [&](int k0) {
 #pragma unroll
@@ -112,7 +117,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
             const int grow = min(n0 + row, N - 1);
             const size_t g = (size_t)grow * K + k0 + c8 * 8;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) wr[q][it] = *reinterpret_cast<const u32x4 *>(Wp[q] + g);
+            for (int q = 0; q < NB; ++q) wr[q][it] = *reinterpret_cast<const u32x4 *>(Wp[q] + g);
         }
     };
     auto store_slice = [&]() {
@@ -120,19 +125,19 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            u32x2 pc[NP];   // hardware conversion (v_cvt_pk_bf16_f32, round to nearest even)
+            u32x2 pc[NA];   // hardware conversion (round to nearest even)
             f32x4 xv = xr[it];
             if constexpr (XADD) xv += xr2[it];
-            split4<NP>(xv, pc);
+            split4<SP>(xv, pc);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
+            for (int q = 0; q < NA; ++q) *reinterpret_cast<u32x2 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 2), c8 = idx & 3;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(&sB[q][row * LDS_STRIDE + c8 * 8]) = wr[q][it];
+            for (int q = 0; q < NB; ++q) *reinterpret_cast<u32x4 *>(&sB[q][row * LDS_STRIDE + c8 * 8]) = wr[q][it];
         }
     };
 
@@ -147,20 +152,20 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int koff = kk + (lane >> 5) * 8;
-            u32x4 af[TI][NP], bfr[TJ][NP];
+            u32x4 af[TI][NA], bfr[TJ][NB];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const u32x4 *>(&sA[q][r]);
+                for (int q = 0; q < NA; ++q) af[i][q] = *reinterpret_cast<const u32x4 *>(&sA[q][r]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) bfr[j][q] = *reinterpret_cast<const u32x4 *>(&sB[q][r]);
+                for (int q = 0; q < NB; ++q) bfr[j][q] = *reinterpret_cast<const u32x4 *>(&sB[q][r]);
             }
-            mfma_tiles<NP, TI, TJ>(acc, af, bfr);   // smallest terms first
+            mfma_tiles<SP, TI, TJ>(acc, af, bfr);   // smallest terms first
         }
         __syncthreads();
     }
@@ -176,6 +181,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
                 const int col = n0 + wn + j * 32 + (lane & 31);
                 const bool colok = col < N;
                 const float b = (bias && colok) ? bias[col] : 0.f;
+                const float rsc = (F16 && colok) ? Wsc[col] : 1.f;
                 const int row0 = m0 + wm + i * 32 + 4 * (lane >> 5);
                 // rows >= M: (row * N + col) * 4 >= num_records -> dropped; columns >= N start from 3 GiB, which stays out
                 // of range and does not wrap for any row delta (host: the tensor is < 3 GiB)
@@ -190,7 +196,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r] + b;
+                    float v = F16 ? __builtin_fmaf(acc[i][j][r], rsc, b) : acc[i][j][r] + b;
                     if constexpr (RESID) v += rv[r];
                     if (RELU) v = v > 0.f ? v : 0.f;
                     const unsigned off = base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u;
@@ -206,11 +212,12 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
             const int col = n0 + wn + j * 32 + (lane & 31);
             if (col >= N) continue;
             const float b = bias ? bias[col] : 0.f;
+            const float rsc = F16 ? Wsc[col] : 1.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < M) {
-                    float v = acc[i][j][r] + b;
+                    float v = F16 ? __builtin_fmaf(acc[i][j][r], rsc, b) : acc[i][j][r] + b;
                     if constexpr (RESID) v += R[(size_t)row * N + col];
                     if (RELU) v = v > 0.f ? v : 0.f;
                     Y[(size_t)row * N + col] = v;
@@ -219,31 +226,31 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
         }
 }
 
-template <int NP, int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
+template <int SP, int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                  const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                  const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo, const float *__restrict__ Wsc,
                   const float *__restrict__ bias, float *__restrict__ Y, int M, int K, int N)
 {
-    split_gemm_body<NP, BM, BN, RELU, PREFETCH, false, BUFST>(X, Whi, Wmid, Wlo, bias, nullptr, Y, M, K, N);
+    split_gemm_body<SP, BM, BN, RELU, PREFETCH, false, BUFST>(X, Whi, Wmid, Wlo, Wsc, bias, nullptr, Y, M, K, N);
 }
 
-template <int NP, int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
+template <int SP, int BM, int BN, bool RELU, bool PREFETCH, bool BUFST = false>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_res_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                      const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                      const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo, const float *__restrict__ Wsc,
                       const float *__restrict__ bias, const float *__restrict__ R, float *__restrict__ Y, int M, int K, int N)
 {
-    split_gemm_body<NP, BM, BN, RELU, PREFETCH, true, BUFST>(X, Whi, Wmid, Wlo, bias, R, Y, M, K, N);
+    split_gemm_body<SP, BM, BN, RELU, PREFETCH, true, BUFST>(X, Whi, Wmid, Wlo, Wsc, bias, R, Y, M, K, N);
 }
 
-template <int NP, int BM, int BN, bool PREFETCH, bool BUFST>
+template <int SP, int BM, int BN, bool PREFETCH, bool BUFST>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_add_kernel(const float *__restrict__ X, const float *__restrict__ X2, const unsigned short *__restrict__ Whi,
-                      const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                      const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo, const float *__restrict__ Wsc,
                       const float *__restrict__ bias, float *__restrict__ Y, int M, int K, int N)
 {
-    split_gemm_body<NP, BM, BN, false, PREFETCH, false, BUFST, true>(X, Whi, Wmid, Wlo, bias, nullptr, Y, M, K, N, X2);
+    split_gemm_body<SP, BM, BN, false, PREFETCH, false, BUFST, true>(X, Whi, Wmid, Wlo, Wsc, bias, nullptr, Y, M, K, N, X2);
 }
 
 // ---- 3 x 3 convolution (padding 1, stride 1 or 2) on channels_last activations as the same split product: an
@@ -273,18 +280,20 @@ struct Conv3Args {
 // r04_conv3_operands_ahead.txt): pointer loads (the defect above), a second LDS stage with one barrier per slice (1-10 % slower
 // at every layer), 128-row output tiles (+3 %), the loads issued two slices ahead with a second register set (+1.5 %), the
 // LDS operands read one k-step ahead of their MFMAs with two LDS stages (+7 % over the backbone).
-template <int NP, int BM, int BN, bool RELU>
+template <int SP, int BM, int BN, bool RELU>
 __global__ void __launch_bounds__(THREADS)
 split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                   const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                   const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo, const float *__restrict__ Wsc,
                    const float *__restrict__ bias, float *__restrict__ Y, const Conv3Args ca)
 {
+    constexpr int NA = Split<SP>::NA, NB = Split<SP>::NB;
+    constexpr bool F16 = Split<SP>::F16;
     constexpr int TI = BM / 64, TJ = BN / 64;
     constexpr int XV = (BM * BK / 4) / THREADS;
     constexpr int WV = (BN * BK / 8) / THREADS;
     static_assert(XV >= 1 && WV >= 1, "tile too small for 256 threads");
-    __shared__ __attribute__((aligned(16))) unsigned short sA[NP][BM * LDS_STRIDE];   // [hi | mid | lo][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[NP][BN * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned short sA[NA][BM * LDS_STRIDE];   // [activation piece][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[NB][BN * LDS_STRIDE];   // [weight piece][row][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -302,7 +311,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
     int ybase[XV], xbase[XV];
     bool rowok[XV];
     f32x4 xr[XV];
-    u32x4 wr[NP][WV];
+    u32x4 wr[NB][WV];
     // byte offsets of this thread's pieces at tap (0, 0), channel 0 / at k = 0 (wrap-around arithmetic: a border
     // pixel's window starts in front of the image, the sum with a valid tap's offset is back inside)
     constexpr unsigned OOB = 0xC0000000u;   // >= num_records of every resource below (sizes are checked by the host)
@@ -313,7 +322,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
     const __amdgpu_buffer_rsrc_t wrs[3] = {
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Whi), 0, wbytes, 0x00020000),
         __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(Wmid), 0, wbytes, 0x00020000),
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(NP > 2 ? Wlo : Whi), 0, wbytes, 0x00020000)};
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short *>(NB > 2 ? Wlo : Whi), 0, wbytes, 0x00020000)};
 #pragma unroll
     for (int it = 0; it < XV; ++it) {
         const int idx = it * THREADS + tid;
@@ -353,7 +362,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         for (int it = 0; it < WV; ++it) {
             const unsigned o = woff[it] + (unsigned)k0 * 2u;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) wr[q][it] = __builtin_amdgcn_raw_buffer_load_b128(wrs[q], o, 0, 0);
+            for (int q = 0; q < NB; ++q) wr[q][it] = __builtin_amdgcn_raw_buffer_load_b128(wrs[q], o, 0, 0);
         }
     };
     auto store_slice = [&]() {
@@ -361,17 +370,17 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            u32x2 pc[NP];
-            split4<NP>(xr[it], pc);
+            u32x2 pc[NA];
+            split4<SP>(xr[it], pc);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
+            for (int q = 0; q < NA; ++q) *reinterpret_cast<u32x2 *>(&sA[q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 2), c8 = idx & 3;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(&sB[q][row * LDS_STRIDE + c8 * 8]) = wr[q][it];
+            for (int q = 0; q < NB; ++q) *reinterpret_cast<u32x4 *>(&sB[q][row * LDS_STRIDE + c8 * 8]) = wr[q][it];
         }
     };
 
@@ -392,20 +401,20 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int koff = kk + (lane >> 5) * 8;
-            u32x4 af[TI][NP], bfr[TJ][NP];
+            u32x4 af[TI][NA], bfr[TJ][NB];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
                 const int r = (wm + i * 32 + (lane & 31)) * LDS_STRIDE + koff;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) af[i][q] = *reinterpret_cast<const u32x4 *>(&sA[q][r]);
+                for (int q = 0; q < NA; ++q) af[i][q] = *reinterpret_cast<const u32x4 *>(&sA[q][r]);
             }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
                 const int r = (wn + j * 32 + (lane & 31)) * LDS_STRIDE + koff;
 #pragma unroll
-                for (int q = 0; q < NP; ++q) bfr[j][q] = *reinterpret_cast<const u32x4 *>(&sB[q][r]);
+                for (int q = 0; q < NB; ++q) bfr[j][q] = *reinterpret_cast<const u32x4 *>(&sB[q][r]);
             }
-            mfma_tiles<NP, TI, TJ>(acc, af, bfr);
+            mfma_tiles<SP, TI, TJ>(acc, af, bfr);
         }
         __syncthreads();
     }
@@ -418,11 +427,12 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
             const int col = n0 + wn + j * 32 + (lane & 31);
             const bool colok = col < N;
             const float b = (bias && colok) ? bias[col] : 0.f;
+            const float rsc = (F16 && colok) ? Wsc[col] : 1.f;   // (split-K partial sums carry the factor too)
             const int row0 = m0 + wm + i * 32 + 4 * (lane >> 5);
             const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xC0000000u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = acc[i][j][r] + b;
+                float v = F16 ? __builtin_fmaf(acc[i][j][r], rsc, b) : acc[i][j][r] + b;
                 if (RELU) v = v > 0.f ? v : 0.f;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
                                                       base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
@@ -471,18 +481,19 @@ conv_splitk_reduce_kernel(const float *__restrict__ part, const float *__restric
 // S = K / 32 is a template parameter (8, 9, 32, 36: hidden 256 / 288 and their FFN widths) so that the slice loop is
 // straight-line code: with run-time trip counts the compiler's wait-count pass loses track of how many loads are in
 // flight across the branches and falls back to vmcnt(0), which would wait for the refill just issued.
-template <int NP, bool RELU, int S>
+template <int SP, bool RELU, int S>
 __global__ void __launch_bounds__(THREADS)
 split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
-                       const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo,
+                       const unsigned short *__restrict__ Wmid, const unsigned short *__restrict__ Wlo, const float *__restrict__ Wsc,
                        const float *__restrict__ bias, float *__restrict__ Y, int M, int K, int N)
 {
+    constexpr int NA = Split<SP>::NA, NB = Split<SP>::NB;
     constexpr int BM = 64, BN = 64, PFD = 8;
     constexpr int XV = (BM * BK / 4) / THREADS;   // 2 float4 of X per thread and slice
     constexpr int WV = (BN * BK / 8) / THREADS;   // 1 16-byte piece of each weight tensor per thread and slice
     const unsigned short *const Wp[3] = {Whi, Wmid, Wlo};
-    __shared__ __attribute__((aligned(16))) unsigned short sA[2][NP][BM * LDS_STRIDE];   // [buffer][hi | mid | lo][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short sB[2][NP][BN * LDS_STRIDE];
+    __shared__ __attribute__((aligned(16))) unsigned short sA[2][NA][BM * LDS_STRIDE];   // [buffer][activation piece][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short sB[2][NB][BN * LDS_STRIDE];   // [buffer][weight piece][row][k]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
@@ -492,7 +503,7 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     f32x4 xr[PFD][XV];
-    u32x4 wr[PFD][NP][WV];
+    u32x4 wr[PFD][NB][WV];
     const float *xp[XV];
     size_t wg[WV];
 #pragma unroll
@@ -514,7 +525,7 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
 #pragma unroll
         for (int it = 0; it < WV; ++it)
 #pragma unroll
-            for (int q = 0; q < NP; ++q) wr[slot][q][it] = *reinterpret_cast<const u32x4 *>(Wp[q] + wg[it] + s * BK);
+            for (int q = 0; q < NB; ++q) wr[slot][q][it] = *reinterpret_cast<const u32x4 *>(Wp[q] + wg[it] + s * BK);
     };
     auto store_slice = [&](auto slotc, int buf) {
         constexpr int slot = decltype(slotc)::value;
@@ -522,17 +533,17 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
         for (int it = 0; it < XV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 3), c4 = idx & 7;
-            u32x2 pc[NP];   // v_cvt_pk_bf16_f32, round to nearest even
-            split4<NP>(xr[slot][it], pc);
+            u32x2 pc[NA];   // round to nearest even
+            split4<SP>(xr[slot][it], pc);
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2 *>(&sA[buf][q][row * LDS_STRIDE + c4 * 4]) = pc[q];
+            for (int q = 0; q < NA; ++q) *reinterpret_cast<u32x2 *>(&sA[buf][q][row * LDS_STRIDE + c4 * 4]) = pc[q];
         }
 #pragma unroll
         for (int it = 0; it < WV; ++it) {
             const int idx = it * THREADS + tid;
             const int row = stage_row(idx >> 2), c8 = idx & 3;
 #pragma unroll
-            for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x4 *>(&sB[buf][q][row * LDS_STRIDE + c8 * 8]) = wr[slot][q][it];
+            for (int q = 0; q < NB; ++q) *reinterpret_cast<u32x4 *>(&sB[buf][q][row * LDS_STRIDE + c8 * 8]) = wr[slot][q][it];
         }
     };
     auto each_slot = [&](auto &&f) {
@@ -563,13 +574,12 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
             for (int kk = 0; kk < BK; kk += 16) {
                 const int koff = kk + (lane >> 5) * 8;
                 const int ra = (wm + (lane & 31)) * LDS_STRIDE + koff, rb = (wn + (lane & 31)) * LDS_STRIDE + koff;
-                u32x4 af[NP], bfr[NP];
+                u32x4 af[NA], bfr[NB];
 #pragma unroll
-                for (int q = 0; q < NP; ++q) {
-                    af[q] = *reinterpret_cast<const u32x4 *>(&sA[buf][q][ra]);
-                    bfr[q] = *reinterpret_cast<const u32x4 *>(&sB[buf][q][rb]);
-                }
-                mfma_terms<NP>(acc, af, bfr);   // smallest terms first
+                for (int q = 0; q < NA; ++q) af[q] = *reinterpret_cast<const u32x4 *>(&sA[buf][q][ra]);
+#pragma unroll
+                for (int q = 0; q < NB; ++q) bfr[q] = *reinterpret_cast<const u32x4 *>(&sB[buf][q][rb]);
+                mfma_terms<SP>(acc, af, bfr);   // smallest terms first
             }
             __syncthreads();
         }
@@ -596,11 +606,12 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
     const int col = n0 + wn + (lane & 31);
     const bool colok = col < N;
     const float b = (bias && colok) ? bias[col] : 0.f;
+    const float rsc = (Split<SP>::F16 && colok) ? Wsc[col] : 1.f;
     const int row0 = m0 + wm + 4 * (lane >> 5);
     const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : 0xC0000000u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        float v = acc[r] + b;
+        float v = Split<SP>::F16 ? __builtin_fmaf(acc[r], rsc, b) : acc[r] + b;
         if (RELU) v = v > 0.f ? v : 0.f;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
                                               base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
@@ -612,20 +623,25 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
 // larger the plain stores (split_gemm_body<..., BUFST = false>).
 inline bool fits_bufstore(long long M, int N) { return (M + 256) * N * 4 < 0xC0000000LL; }
 
-template <int NP, int BM, int BN, bool PREFETCH>
-int launch_gemm(const float *x, const unsigned short *const (&w)[3], const float *bias, const float *res, float *y, int M, int K, int N,
-                int relu, hipStream_t s)
+// the weight of a call: its 16-bit pieces (hi, mid [, lo] bf16; or, fp16 scheme: hi, lo, hi 2^-11) [+ the output channels' powers of two]
+struct Weight {
+    const unsigned short *p[3];
+    const float *scale;
+};
+
+template <int SP, int BM, int BN, bool PREFETCH>
+int launch_gemm(const float *x, const Weight &w, const float *bias, const float *res, float *y, int M, int K, int N, int relu, hipStream_t s)
 {
     const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
     auto go = [&](auto bufst) {
         constexpr bool B = decltype(bufst)::value;
         if (res) {
-            if (relu) hipLaunchKernelGGL((split_gemm_res_kernel<NP, BM, BN, true, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, res, y, M, K, N);
-            else hipLaunchKernelGGL((split_gemm_res_kernel<NP, BM, BN, false, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, res, y, M, K, N);
+            if (relu) hipLaunchKernelGGL((split_gemm_res_kernel<SP, BM, BN, true, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w.p[0], w.p[1], w.p[2], w.scale, bias, res, y, M, K, N);
+            else hipLaunchKernelGGL((split_gemm_res_kernel<SP, BM, BN, false, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w.p[0], w.p[1], w.p[2], w.scale, bias, res, y, M, K, N);
         } else {
-            if (relu) hipLaunchKernelGGL((split_gemm_kernel<NP, BM, BN, true, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, y, M, K, N);
-            else hipLaunchKernelGGL((split_gemm_kernel<NP, BM, BN, false, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, y, M, K, N);
+            if (relu) hipLaunchKernelGGL((split_gemm_kernel<SP, BM, BN, true, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w.p[0], w.p[1], w.p[2], w.scale, bias, y, M, K, N);
+            else hipLaunchKernelGGL((split_gemm_kernel<SP, BM, BN, false, PREFETCH, B>), grid, dim3(THREADS), 0, s, x, w.p[0], w.p[1], w.p[2], w.scale, bias, y, M, K, N);
         }
     };
     if (fits_bufstore(M, N)) go(std::true_type{});
@@ -633,28 +649,41 @@ int launch_gemm(const float *x, const unsigned short *const (&w)[3], const float
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-template <int NP, int BM, int BN, bool PREFETCH>
-int launch_add(const float *x, const float *x2, const unsigned short *const (&w)[3], const float *bias, float *y, int M, int K, int N,
-               hipStream_t s)
+template <int SP, int BM, int BN, bool PREFETCH>
+int launch_add(const float *x, const float *x2, const Weight &w, const float *bias, float *y, int M, int K, int N, hipStream_t s)
 {
     const dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((N + BN - 1) / BN));
     if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
     if (fits_bufstore(M, N))
-        hipLaunchKernelGGL((split_gemm_add_kernel<NP, BM, BN, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, x2, w[0], w[1], w[2], bias, y, M, K, N);
+        hipLaunchKernelGGL((split_gemm_add_kernel<SP, BM, BN, PREFETCH, true>), grid, dim3(THREADS), 0, s, x, x2, w.p[0], w.p[1], w.p[2], w.scale, bias, y, M, K, N);
     else
-        hipLaunchKernelGGL((split_gemm_add_kernel<NP, BM, BN, PREFETCH, false>), grid, dim3(THREADS), 0, s, x, x2, w[0], w[1], w[2], bias, y, M, K, N);
+        hipLaunchKernelGGL((split_gemm_add_kernel<SP, BM, BN, PREFETCH, false>), grid, dim3(THREADS), 0, s, x, x2, w.p[0], w.p[1], w.p[2], w.scale, bias, y, M, K, N);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-// the weight pieces of a call: (w_hi, w_mid) -> three terms, (w_hi, w_mid, w_lo) -> six; 16-byte aligned
-inline int weight_pieces(const void *w_hi, const void *w_mid, const void *w_lo, const unsigned short *(&w)[3])
+// The weight arguments of the C ABI -> scheme (split_product.h): (w_hi, w_mid) -> 2 (three bf16 terms), (w_hi, w_mid, w_lo) -> 3
+// (six), (w_hi, w_mid, w_lo, w_scale) -> 16 (fp16 pieces hi, lo, hi 2^-11 + the channels' factors); 0: a missing piece, -1:
+// misaligned (16 bytes)
+inline int weight_scheme(const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, Weight &w)
 {
-    if (!w_hi || !w_mid) return 0;
+    if (!w_hi || !w_mid || (w_scale && !w_lo)) return 0;
     if ((reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_mid) | reinterpret_cast<uintptr_t>(w_lo)) & 15) return -1;
-    w[0] = static_cast<const unsigned short *>(w_hi);
-    w[1] = static_cast<const unsigned short *>(w_mid);
-    w[2] = static_cast<const unsigned short *>(w_lo);
-    return w_lo ? 3 : 2;
+    w.p[0] = static_cast<const unsigned short *>(w_hi);
+    w.p[1] = static_cast<const unsigned short *>(w_mid);
+    w.p[2] = static_cast<const unsigned short *>(w_lo);
+    w.scale = w_scale;
+    return w_scale ? 16 : (w_lo ? 3 : 2);
+}
+
+// f(integral_constant<int, SP>) for the run-time scheme sp
+template <class F>
+int with_scheme(int sp, F &&f)
+{
+    switch (sp) {
+    case 2: return f(std::integral_constant<int, 2>{});
+    case 3: return f(std::integral_constant<int, 3>{});
+    default: return f(std::integral_constant<int, 16>{});
+    }
 }
 
 // Block shape per call shape (measured in profiles/r02_split_gemm_variants.txt, r03_optin_linear_bufstore.txt):
@@ -663,72 +692,71 @@ inline int weight_pieces(const void *w_hi, const void *w_mid, const void *w_lo, 
 //   K >= 512 and N <= 256           128 x 64, prefetch
 //   256 < N < 512                   64 x 128, no prefetch
 //   else                            64 x 128, prefetch
-template <int NP>
-int linear_split_np(const float *x, const unsigned short *const (&w)[3], const float *bias, const float *res, float *y, int M, int K,
-                    int N, int relu, hipStream_t s)
+template <int SP>
+int linear_split_sp(const float *x, const Weight &w, const float *bias, const float *res, float *y, int M, int K, int N, int relu,
+                    hipStream_t s)
 {
     if (M <= 4096) {
         if (!res && fits_bufstore(M, N)) {
             const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64));
             if (grid.y > 65535u) return TF_MSDA_ERR_BAD_DIMS;
             const int slices = K / BK;
-#define TF_DEEP(SS)                                                                                                                      \
-    if (slices == SS) {                                                                                                                  \
-        if (relu)                                                                                                                        \
-            hipLaunchKernelGGL((split_gemm_deep_kernel<NP, true, SS>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, y, M, K, N);  \
-        else                                                                                                                             \
-            hipLaunchKernelGGL((split_gemm_deep_kernel<NP, false, SS>), grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, y, M, K, N); \
-        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;                                                        \
+#define TF_DEEP(SS)                                                                                                                               \
+    if (slices == SS) {                                                                                                                           \
+        if (relu)                                                                                                                                 \
+            hipLaunchKernelGGL((split_gemm_deep_kernel<SP, true, SS>), grid, dim3(THREADS), 0, s, x, w.p[0], w.p[1], w.p[2], w.scale, bias, y, M, K, N);  \
+        else                                                                                                                                      \
+            hipLaunchKernelGGL((split_gemm_deep_kernel<SP, false, SS>), grid, dim3(THREADS), 0, s, x, w.p[0], w.p[1], w.p[2], w.scale, bias, y, M, K, N); \
+        return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;                                                                 \
     }
             TF_DEEP(8) TF_DEEP(9) TF_DEEP(32) TF_DEEP(36)
 #undef TF_DEEP
         }
-        return launch_gemm<NP, 64, 64, true>(x, w, bias, res, y, M, K, N, relu, s);
+        return launch_gemm<SP, 64, 64, true>(x, w, bias, res, y, M, K, N, relu, s);
     }
-    if (K >= 512 && N <= 256) return launch_gemm<NP, 128, 64, true>(x, w, bias, res, y, M, K, N, relu, s);
-    if (N > 256 && N < 512) return launch_gemm<NP, 64, 128, false>(x, w, bias, res, y, M, K, N, relu, s);
-    return launch_gemm<NP, 64, 128, true>(x, w, bias, res, y, M, K, N, relu, s);
+    if (K >= 512 && N <= 256) return launch_gemm<SP, 128, 64, true>(x, w, bias, res, y, M, K, N, relu, s);
+    if (N > 256 && N < 512) return launch_gemm<SP, 64, 128, false>(x, w, bias, res, y, M, K, N, relu, s);
+    return launch_gemm<SP, 64, 128, true>(x, w, bias, res, y, M, K, N, relu, s);
 }
 
-int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, const float *res,
-                      float *y, int64_t M, int K, int N, int relu, void *stream)
+int linear_split_impl(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, const float *bias,
+                      const float *res, float *y, int64_t M, int K, int N, int relu, void *stream)
 {
     if (!x || !y) return TF_MSDA_ERR_NULL_POINTER;
-    const unsigned short *w[3];
-    const int np = weight_pieces(w_hi, w_mid, w_lo, w);
-    if (np == 0) return TF_MSDA_ERR_NULL_POINTER;
-    if (np < 0 || M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL || (reinterpret_cast<uintptr_t>(x) & 15))
+    Weight w;
+    const int sp = weight_scheme(w_hi, w_mid, w_lo, w_scale, w);
+    if (sp == 0) return TF_MSDA_ERR_NULL_POINTER;
+    if (sp < 0 || M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL || (reinterpret_cast<uintptr_t>(x) & 15))
         return TF_MSDA_ERR_BAD_DIMS;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    return np == 3 ? linear_split_np<3>(x, w, bias, res, y, (int)M, K, N, relu, s)
-                   : linear_split_np<2>(x, w, bias, res, y, (int)M, K, N, relu, s);
+    return with_scheme(sp, [&](auto spc) { return linear_split_sp<decltype(spc)::value>(x, w, bias, res, y, (int)M, K, N, relu, s); });
 }
 
-template <int NP>
-int conv_launch_np(const float *x, const unsigned short *const (&w)[3], const float *bias, float *out, const Conv3Args &ca, long long M,
-                   unsigned gz, int relu, hipStream_t s)
+template <int SP>
+int conv_launch_sp(const float *x, const Weight &w, const float *bias, float *out, const Conv3Args &ca, long long M, unsigned gz, int relu,
+                   hipStream_t s)
 {
     auto launch = [&](auto kern, unsigned bn) {
         const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((ca.cout + bn - 1) / bn), gz);
-        hipLaunchKernelGGL(kern, grid, dim3(THREADS), 0, s, x, w[0], w[1], w[2], bias, out, ca);
+        hipLaunchKernelGGL(kern, grid, dim3(THREADS), 0, s, x, w.p[0], w.p[1], w.p[2], w.scale, bias, out, ca);
     };
     if (ca.cout >= 128) {   // output tile 64 x 128 for the wide layers
-        relu ? launch(split_conv3_kernel<NP, 64, 128, true>, 128) : launch(split_conv3_kernel<NP, 64, 128, false>, 128);
+        relu ? launch(split_conv3_kernel<SP, 64, 128, true>, 128) : launch(split_conv3_kernel<SP, 64, 128, false>, 128);
     } else {
-        relu ? launch(split_conv3_kernel<NP, 64, 64, true>, 64) : launch(split_conv3_kernel<NP, 64, 64, false>, 64);
+        relu ? launch(split_conv3_kernel<SP, 64, 64, true>, 64) : launch(split_conv3_kernel<SP, 64, 64, false>, 64);
     }
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y, int nimg,
-                    int hin, int win, int cin, int cout, int stride, int ks, int relu, void *stream, int ksplit = 1,
+int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, const float *bias,
+                    float *y, int nimg, int hin, int win, int cin, int cout, int stride, int ks, int relu, void *stream, int ksplit = 1,
                     float *workspace = nullptr)
 {
     if (!x || !y) return TF_MSDA_ERR_NULL_POINTER;
-    const unsigned short *w[3];
-    const int np = weight_pieces(w_hi, w_mid, w_lo, w);
-    if (np == 0) return TF_MSDA_ERR_NULL_POINTER;
-    if (np < 0 || nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % BK) != 0 || (stride != 1 && stride != 2) ||
+    Weight w;
+    const int sp = weight_scheme(w_hi, w_mid, w_lo, w_scale, w);
+    if (sp == 0) return TF_MSDA_ERR_NULL_POINTER;
+    if (sp < 0 || nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % BK) != 0 || (stride != 1 && stride != 2) ||
         (reinterpret_cast<uintptr_t>(x) & 15))
         return TF_MSDA_ERR_BAD_DIMS;
     const int pad = ks == 3 ? 1 : 0;
@@ -754,7 +782,7 @@ int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const v
         kbias = nullptr;
         krelu = 0;
     }
-    const int rc = np == 3 ? conv_launch_np<3>(x, w, kbias, out, ca, M, gz, krelu, s) : conv_launch_np<2>(x, w, kbias, out, ca, M, gz, krelu, s);
+    const int rc = with_scheme(sp, [&](auto spc) { return conv_launch_sp<decltype(spc)::value>(x, w, kbias, out, ca, M, gz, krelu, s); });
     if (rc != TF_MSDA_OK) return rc;
     if (ksplit > 1) {
         const long long mn4 = M * cout / 4;
@@ -767,64 +795,67 @@ int conv_split_impl(const float *x, const void *w_hi, const void *w_mid, const v
 
 }  // namespace
 
-extern "C" int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                                   int64_t M, int K, int N, int relu, void *stream)
+extern "C" int tf_linear_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale,
+                                   const float *bias, float *y, int64_t M, int K, int N, int relu, void *stream)
 {
-    return linear_split_impl(x, w_hi, w_mid, w_lo, bias, nullptr, y, M, K, N, relu, stream);
+    return linear_split_impl(x, w_hi, w_mid, w_lo, w_scale, bias, nullptr, y, M, K, N, relu, stream);
 }
 
-extern "C" int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias,
-                                       const float *residual, float *y, int64_t M, int K, int N, int relu, void *stream)
+extern "C" int tf_linear_split_res_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale,
+                                       const float *bias, const float *residual, float *y, int64_t M, int K, int N, int relu, void *stream)
 {
     if (!residual) return TF_MSDA_ERR_NULL_POINTER;
-    return linear_split_impl(x, w_hi, w_mid, w_lo, bias, residual, y, M, K, N, relu, stream);
+    return linear_split_impl(x, w_hi, w_mid, w_lo, w_scale, bias, residual, y, M, K, N, relu, stream);
 }
 
 extern "C" int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, const void *w_mid, const void *w_lo,
-                                       const float *bias, float *y, int64_t M, int K, int N, void *stream)
+                                       const float *w_scale, const float *bias, float *y, int64_t M, int K, int N, void *stream)
 {
     if (!x || !x2 || !y) return TF_MSDA_ERR_NULL_POINTER;
-    const unsigned short *w[3];
-    const int np = weight_pieces(w_hi, w_mid, w_lo, w);
-    if (np == 0) return TF_MSDA_ERR_NULL_POINTER;
-    if (np < 0 || M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL ||
+    Weight w;
+    const int sp = weight_scheme(w_hi, w_mid, w_lo, w_scale, w);
+    if (sp == 0) return TF_MSDA_ERR_NULL_POINTER;
+    if (sp < 0 || M <= 0 || K <= 0 || N <= 0 || (K % BK) != 0 || M > 0x7fffffffLL ||
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2)) & 15))
         return TF_MSDA_ERR_BAD_DIMS;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    auto go = [&](auto npc) {
-        constexpr int NP = decltype(npc)::value;
-        // the block shapes tf_linear_split_f32 picks for these calls: few rows -> 64 x 64, else 64 x 128 (prefetch as there)
-        if (M <= 4096) return launch_add<NP, 64, 64, true>(x, x2, w, bias, y, (int)M, K, N, s);
-        if (N > 256 && N < 512) return launch_add<NP, 64, 128, false>(x, x2, w, bias, y, (int)M, K, N, s);
-        return launch_add<NP, 64, 128, true>(x, x2, w, bias, y, (int)M, K, N, s);
-    };
-    return np == 3 ? go(std::integral_constant<int, 3>{}) : go(std::integral_constant<int, 2>{});
+    return with_scheme(sp, [&](auto spc) {
+        constexpr int SP = decltype(spc)::value;
+        // block shapes as linear_split_sp (no deep-prefetch form of the add kernel)
+        if (M <= 4096) return launch_add<SP, 64, 64, true>(x, x2, w, bias, y, (int)M, K, N, s);
+        if (N > 256 && N < 512) return launch_add<SP, 64, 128, false>(x, x2, w, bias, y, (int)M, K, N, s);
+        return launch_add<SP, 64, 128, true>(x, x2, w, bias, y, (int)M, K, N, s);
+    });
 }
 
-extern "C" int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                                     float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
-                                     void *stream)
+extern "C" int tf_conv3x3_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale,
+                                     const float *bias, float *y, float *workspace, int ksplit, int nimg, int hin, int win, int cin,
+                                     int cout, int stride, int relu, void *stream)
 {
-    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && !workspace)) return ksplit > 1 && !workspace ? TF_MSDA_ERR_NULL_POINTER : TF_MSDA_ERR_BAD_DIMS;
-    return conv_split_impl(x, w_hi, w_mid, w_lo, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream, ksplit, workspace);
+    if (ksplit > 1 && !workspace) return TF_MSDA_ERR_NULL_POINTER;
+    if (ksplit < 1 || ksplit > 64) return TF_MSDA_ERR_BAD_DIMS;
+    return conv_split_impl(x, w_hi, w_mid, w_lo, w_scale, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream, ksplit, workspace);
 }
 
-extern "C" int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                                     float *workspace, int ksplit, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
-                                     void *stream)
+extern "C" int tf_conv1x1_splitk_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale,
+                                     const float *bias, float *y, float *workspace, int ksplit, int nimg, int hin, int win, int cin,
+                                     int cout, int stride, int relu, void *stream)
 {
-    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && !workspace)) return ksplit > 1 && !workspace ? TF_MSDA_ERR_NULL_POINTER : TF_MSDA_ERR_BAD_DIMS;
-    return conv_split_impl(x, w_hi, w_mid, w_lo, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream, ksplit, workspace);
+    if (ksplit > 1 && !workspace) return TF_MSDA_ERR_NULL_POINTER;
+    if (ksplit < 1 || ksplit > 64) return TF_MSDA_ERR_BAD_DIMS;
+    return conv_split_impl(x, w_hi, w_mid, w_lo, w_scale, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream, ksplit, workspace);
 }
 
-extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias, float *y,
-                                    int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream)
+extern "C" int tf_conv3x3_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale,
+                                    const float *bias, float *y, int nimg, int hin, int win, int cin, int cout, int stride, int relu,
+                                    void *stream)
 {
-    return conv_split_impl(x, w_hi, w_mid, w_lo, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream);
+    return conv_split_impl(x, w_hi, w_mid, w_lo, w_scale, bias, y, nimg, hin, win, cin, cout, stride, 3, relu, stream);
 }
 
-extern "C" int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *bias,
-                                            float *y, int nimg, int hin, int win, int cin, int cout, int stride, int relu, void *stream)
+extern "C" int tf_conv1x1_strided_split_f32(const float *x, const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale,
+                                            const float *bias, float *y, int nimg, int hin, int win, int cin, int cout, int stride,
+                                            int relu, void *stream)
 {
-    return conv_split_impl(x, w_hi, w_mid, w_lo, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream);
+    return conv_split_impl(x, w_hi, w_mid, w_lo, w_scale, bias, y, nimg, hin, win, cin, cout, stride, 1, relu, stream);
 }

@@ -97,13 +97,26 @@ def set_split_linear(on):
     return prev
 
 
-# How many bf16 terms a product is made of (include/tf_fused.h, THE SPLIT PRODUCT): 6 = operands cut into (hi, mid, lo), all
-# 24 significand bits, dropped terms below 2^-24 of the product -- the reference's fp32 arithmetic in another summation
-# order; the DEFAULT.  3 = (hi, mid) pieces, products good to 2^-16: the fast mode (TF_SPLIT_TERMS=3 / set_split_terms(3)).
-# Why six is the default: the 64-frame reference-Tracker fixture (tests/golden/full_tracker_cfg2_64.npz) keeps the reference's
-# track ids for 59 frames under fp32 library GEMMs but only 14 under three terms (profiles/r04_id_parity_64.txt) -- boxes and
-# logits are inside 1e-3 either way, NMS decisions with IoU margins of 1e-4 are not.
-_split_terms = 3 if os.environ.get("TF_SPLIT_TERMS", "6") == "3" else 6
+# The arithmetic of a split product (include/tf_fused.h, THE SPLIT PRODUCT; csrc/split_product.h):
+#   6   bf16 pieces (hi, mid, lo) per operand, six terms: all 24 significand bits, dropped terms below 2^-24 of the product -- the
+#       reference's fp32 arithmetic in another summation order.
+#   16  fp16 pieces: (hi, lo) of the activation x (hi, lo, hi 2^-11) of the weight, THREE terms: 22 + 1 significand bits, the only
+#       dropped product below 2^-22; weights scaled per output channel and the lo piece stored times 2^11 so that nothing falls
+#       into fp16's subnormals.  Half the matrix work of 6.
+#   3   bf16 pieces (hi, mid), three terms, products good to 2^-16: the fast mode.
+# Why not 3 by default: the 64-frame reference-Tracker fixture (tests/golden/full_tracker_cfg2_64.npz) keeps the reference's
+# track ids for 59 frames under fp32 library GEMMs but only 14 under three bf16 terms (profiles/r04_id_parity_64.txt) -- boxes
+# and logits are inside 1e-3 either way, NMS decisions with IoU margins of 1e-4 are not.
+def _parse_terms(v):
+    v = str(v).strip().lower()
+    if v in ("3", "6", "16"):
+        return int(v)
+    if v in ("f16", "fp16", "half"):
+        return 16
+    raise ValueError("split terms: 3, 6 or 16 (fp16 pieces)")
+
+
+_split_terms = _parse_terms(os.environ.get("TF_SPLIT_TERMS", "6"))
 
 
 def split_terms():
@@ -111,10 +124,10 @@ def split_terms():
 
 
 def set_split_terms(n):
-    """3 or 6 terms per split product (process-wide; cached weight images are kept per setting); returns the previous value."""
+    """3 / 6 (bf16 pieces) or 16 (fp16 pieces, three terms) per split product (process-wide; cached weight images are kept per
+    setting); returns the previous value."""
     global _split_terms
-    if n not in (3, 6):
-        raise ValueError("split terms: 3 or 6")
+    n = _parse_terms(n)
     prev, _split_terms = _split_terms, n
     return prev
 
@@ -140,7 +153,7 @@ def _use_packed(M, K, N):
         return False
     tail = N % 256
     full = N <= 128 or tail == 0 or tail > 128
-    if _split_terms == 6:
+    if _split_terms != 3:   # (fp16 pieces: the weight traffic of six terms -- three pieces --, its policy until measured separately)
         return full and K >= 256
     return (N >= 512 or K >= 512) and full
 
@@ -189,13 +202,34 @@ def _packed_weight(weight, rows):
 
 
 def _split_weight(weight):
-    """(w_hi, w_mid, w_lo) bf16 pieces of an fp32 weight (round to nearest even at every step; w_lo is None when
-    split_terms() == 3).  Cached ON THE TENSOR OBJECT together with its version counter
+    """The 16-bit pieces of an fp32 weight [N, K] for the kernels that take them as separate tensors (include/tf_fused.h, THE
+    SPLIT PRODUCT) -> (p0, p1, p2, scale):
+      split_terms() 3 / 6   bf16 hi, mid, lo (lo None for three terms), scale None
+      split_terms() 16      fp16 wh = f16(w t_n), wl = f16(w t_n - wh), ws = f16(wh 2^-11) and scale[n] = 16 / t_n (fp32), t_n the
+                            power of two that puts the largest |w| of output channel n into [2^13, 2^14)
+    (round to nearest even at every step).  Cached ON THE TENSOR OBJECT together with its version counter
     (weights are constants in inference; an in-place update bumps the version).  Not keyed by data_ptr: a freed
     parameter's address is handed to the next model's parameters by the caching allocator, and a pointer-keyed cache
     then serves another tensor's pieces (seen as a golden failure when two test models were built one after the
     other).  Callers pass persistent tensors (module parameters, _CatProjection's concatenation), and use `rows=` of
     linear() for a row block instead of a temporary slice."""
+    if _split_terms == 16:
+        hit = getattr(weight, "_tf_split_f16", None)
+        if hit is None or hit[0] != weight._version:
+            w = weight.detach()
+            amax = w.abs().amax(dim=1)
+            _, e = torch.frexp(amax)                                   # amax = m 2^e with m in [0.5, 1): floor(log2 amax) = e - 1
+            t = torch.ldexp(torch.ones_like(amax), torch.clamp(14 - e, -100, 100))
+            t = torch.where((amax > 0) & (amax < 3.0e38), t, torch.ones_like(t))
+            ws = w * t[:, None]                                        # exact: powers of two
+            hi = ws.to(torch.float16)
+            lo = (ws - hi.float()).to(torch.float16)
+            hs = (hi.float() * (1.0 / 2048.0)).to(torch.float16)
+            hit = (weight._version, hi.contiguous(), lo.contiguous(), hs.contiguous(), (16.0 / t).contiguous())
+            if w.is_cuda:
+                _publish_barrier(w.device)
+            weight._tf_split_f16 = hit
+        return hit[1], hit[2], hit[3], hit[4]
     hit = getattr(weight, "_tf_split", None)
     if hit is None or hit[0] != weight._version or (hit[3] is None and _split_terms == 6):
         w = weight.detach()
@@ -207,7 +241,12 @@ def _split_weight(weight):
         if w.is_cuda:
             _publish_barrier(w.device)
         weight._tf_split = hit
-    return hit[1], hit[2], (hit[3] if _split_terms == 6 else None)
+    return hit[1], hit[2], (hit[3] if _split_terms == 6 else None), None
+
+
+def _rows_of(pieces, rows):
+    """The row block `rows` = (a, b) of _split_weight's pieces (views: a row block is contiguous)."""
+    return tuple(None if p is None else p[rows[0]:rows[1]] for p in pieces)
 
 
 def _ptr(t):
@@ -249,19 +288,20 @@ def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
                                                       x2.shape[0], K, N, 1 if relu else 0, _split_terms, _stream(x.device))
             _cabi.check(rc, "tf_linear_packed_f32")
             return y.view(*x.shape[:-1], N)
-    hi, mid, lo = _split_weight(weight)
-    if rows is not None:   # views: a row block is contiguous
-        hi, mid, lo = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]], (None if lo is None else lo[rows[0]:rows[1]])
+    pieces = _split_weight(weight)
+    if rows is not None:
+        pieces = _rows_of(pieces, rows)
+    hi, mid, lo, wsc = pieces
     if (x2.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
         return None
     with torch.cuda.device(x.device):
         y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
         if residual is None:
-            rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo),
+            rc = _cabi.lib().tf_linear_split_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), _ptr(wsc),
                                                  0 if bias is None else bias.data_ptr(), y.data_ptr(), x2.shape[0], K, N,
                                                  1 if relu else 0, _stream(x.device))
         else:
-            rc = _cabi.lib().tf_linear_split_res_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo),
+            rc = _cabi.lib().tf_linear_split_res_f32(x2.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), _ptr(wsc),
                                                      0 if bias is None else bias.data_ptr(), residual.data_ptr(),
                                                      y.data_ptr(), x2.shape[0], K, N, 1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_linear_split_f32")
@@ -546,14 +586,15 @@ def linear_add(x, x2, weight, bias=None, rows=None):
     a, b = x.reshape(-1, K), x2.reshape(-1, K)
     a = a if a.is_contiguous() else a.contiguous()
     b = b if b.is_contiguous() else b.contiguous()
-    hi, mid, lo = _split_weight(weight)
+    pieces = _split_weight(weight)
     if rows is not None:
-        hi, mid, lo = hi[rows[0]:rows[1]], mid[rows[0]:rows[1]], (None if lo is None else lo[rows[0]:rows[1]])
+        pieces = _rows_of(pieces, rows)
+    hi, mid, lo, wsc = pieces
     if (a.data_ptr() | b.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
         return None
     with torch.cuda.device(x.device):
         y = torch.empty((a.shape[0], N), dtype=torch.float32, device=x.device)
-        rc = _cabi.lib().tf_linear_split_add_f32(a.data_ptr(), b.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo),
+        rc = _cabi.lib().tf_linear_split_add_f32(a.data_ptr(), b.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), _ptr(wsc),
                                                  0 if bias is None else bias.data_ptr(), y.data_ptr(), a.shape[0], K, N,
                                                  _stream(x.device))
     _cabi.check(rc, "tf_linear_split_add_f32")
@@ -594,7 +635,7 @@ def conv3x3(x, w_taps, bias, relu, stride):
                                                     n, h, w, cin, cout, ks, stride, 1 if relu else 0, _split_terms, _stream(x.device))
             _cabi.check(rc, "tf_conv_packed_f32")
             return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
-    hi, mid, lo = _split_weight(w_taps)
+    hi, mid, lo, wsc = _split_weight(w_taps)
     if (x.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
         return None
     with torch.cuda.device(x.device):
@@ -602,12 +643,12 @@ def conv3x3(x, w_taps, bias, relu, stride):
         if ksplit > 1:   # few output pixels under a long K: split the K loop over workgroups (deterministic second pass)
             ws = torch.empty((ksplit, n * ho * wo * cout), dtype=torch.float32, device=x.device)
             fn = _cabi.lib().tf_conv3x3_splitk_f32 if ks == 3 else _cabi.lib().tf_conv1x1_splitk_f32
-            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), 0 if bias is None else bias.data_ptr(), y.data_ptr(),
+            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), _ptr(wsc), 0 if bias is None else bias.data_ptr(), y.data_ptr(),
                     ws.data_ptr(), ksplit, n, h, w, cin, cout, stride, 1 if relu else 0, _stream(x.device))
         else:
             fn = _cabi.lib().tf_conv3x3_split_f32 if ks == 3 else _cabi.lib().tf_conv1x1_strided_split_f32
-            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), 0 if bias is None else bias.data_ptr(), y.data_ptr(), n, h, w,
-                    cin, cout, stride, 1 if relu else 0, _stream(x.device))
+            rc = fn(x.data_ptr(), hi.data_ptr(), mid.data_ptr(), _ptr(lo), _ptr(wsc), 0 if bias is None else bias.data_ptr(), y.data_ptr(),
+                    n, h, w, cin, cout, stride, 1 if relu else 0, _stream(x.device))
     _cabi.check(rc, "tf_conv3x3_split_f32")
     return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
 
