@@ -52,13 +52,15 @@ The JSON line also carries
                    timed beside it; rank 0, N=1 only, a bounded sample.
   single_sequence_fps / multi_sequence_fps -- cfg2/4/5: the same steps with ONE sequence per GPU (no overlap of one
                    sequence's host-side association with another's forward) / with --sequences interleaved.
-  precision     -- `value` is measured with the DEFAULT arithmetic: every dense layer as the SIX-term bf16 split product on the
-                   matrix cores (operands cut into hi / mid / lo bf16 pieces = all 24 significand bits, dropped terms < 2^-24 of a
-                   product, fp32 accumulation: fp32 arithmetic in another summation order; include/tf_fused.h).  Beside it:
-                   fp32_exact_fps / single_sequence_fp32_exact_fps (every matrix product in the fp32 LIBRARIES: hipBLASLt linears,
-                   MIOpen convolutions; 3 sequences / one sequence) and split3_fps (the three-term fast mode, products good to 2^-16:
-                   NOT the reference's precision -- it loses the reference's track ids at frame 14 of the 64-frame fixture where
-                   fp32 holds 59, profiles/r04_id_parity_64.txt -- reported, never the headline).
+  precision     -- `value` is measured with the DEFAULT arithmetic of the package (fused.split_terms(); `dtype` and
+                   `precision.value_measured_with` name it): every dense layer as a split product on the matrix cores with fp32
+                   accumulation (include/tf_fused.h) -- the fp16 product (two / three fp16 pieces per operand, three MFMAs, fp32-class
+                   accuracy) or the six-term bf16 product (all 24 significand bits).  Beside it: fp32_exact_fps /
+                   single_sequence_fp32_exact_fps (every matrix product in the fp32 LIBRARIES: hipBLASLt linears, MIOpen
+                   convolutions; 3 sequences / one sequence), the other fp32-class product (split6_fps / split_f16_fps) and
+                   split3_fps (the three-term bf16 fast mode, products good to 2^-16: NOT the reference's precision -- it loses the
+                   reference's track ids at frame 14 of the 64-frame fixture where fp32 holds 59, profiles/r04_id_parity_64.txt --
+                   reported, never the headline).
   association   -- what the association leg did in four untimed steps (survivors, initialised, alive).
   parity        -- cfg2: in-run check against the committed reference goldens (max |d boxes|, max |d logits|, ids equal).
   mfma_utilisation -- "live": the dense kernels of the frame timed HERE with HIP events at their cfg-2 shapes, as fp32-equivalent
@@ -149,9 +151,10 @@ def parse_args():
                     help="encoder / decoder linears as bf16 split products on the matrix cores "
                          "(tf_linear_split_f32; same as TF_SPLIT_LINEAR=1)")
     ap.add_argument("--no-split-linear", dest="split_linear", action="store_false")
-    ap.add_argument("--split-terms", type=int, choices=(3, 6), default=None,
-                    help="terms per split product: 6 (default; fp32-accurate) or 3 (fast mode, products good to 2^-16)")
-    ap.add_argument("--no-split3", action="store_true", help="skip the extra measurement in the three-term fast mode")
+    ap.add_argument("--split-terms", type=int, choices=(3, 6, 16), default=None,
+                    help="the split product (include/tf_fused.h): 6 bf16 terms, 16 = fp16 pieces (three terms, fp32-class accuracy) "
+                         "or 3 bf16 terms (fast mode, products good to 2^-16); default: the package's (fused.split_terms())")
+    ap.add_argument("--no-split3", action="store_true", help="skip the extra measurements with the other split products")
     ap.add_argument("--conv1x1-split", dest="conv1x1_split", action="store_true", default=None,
                     help="the backbone's stride-1 1x1 convolutions through the split-product GEMM with the "
                          "FrozenBN / identity / ReLU epilogue (the default; --no-conv1x1-split = TF_CONV1X1_SPLIT=0)")
@@ -509,6 +512,20 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
 MFMA_PEAK_BF16 = 2.5e15   # dense bf16 flop/s of the matrix cores (MI355X_MICROARCH.md)
 
 
+# split product (fused.split_terms()) -> (short name, key of its side leg in the line, `dtype` text)
+_ARITH = {
+    6: ("six-term bf16 split product", "split6_fps",
+        "f32 (dense layers as the six-term bf16 split product on MFMA: hi / mid / lo pieces carry all 24 significand bits, dropped terms "
+        "< 2^-24 of a product, f32 accumulate -- fp32 arithmetic in another summation order)"),
+    16: ("fp16 split product (three terms)", "split_f16_fps",
+         "f32 (dense layers as the fp16 split product on MFMA: two fp16 pieces per activation, three per weight scaled per output "
+         "channel -- 22 + 1 significand bits per operand, the one dropped product < 2^-22 --, three terms, f32 accumulate)"),
+    3: ("three-term bf16 split product", "split3_fps",
+        "f32 storage, products good to 2^-16 (three-term bf16 split product on MFMA, f32 accumulate): the fast mode, NOT the "
+        "reference's precision"),
+}
+
+
 def measure_dense_kernels(device, hidden=256):
     """The dense kernels of a cfg-2 frame, timed HERE (HIP events around 20 launches replayed from one HIP graph on the launch
     stream) at the shapes the frame runs them: fp32-equivalent TFLOP/s and matrix-pipe utilisation = 2 M K N x terms /
@@ -516,7 +533,7 @@ def measure_dense_kernels(device, hidden=256):
     Live, unlike the PMC figures next to it (which need their own rocprofv3 pass and are committed with their commit)."""
     import torch.nn as nn
     from trackformer_amd import fused
-    terms = fused.split_terms()
+    terms = 3 if fused.split_terms() == 16 else fused.split_terms()   # MFMAs per product
     g = torch.Generator().manual_seed(0)
     rows = 22223
     out = {}
@@ -562,7 +579,7 @@ def measure_dense_kernels(device, hidden=256):
         if fused.linear(x1, w1, None, relu=True, residual=r1) is not None:
             out["conv 1x1 64 -> 256 + identity + ReLU at 200 x 334"] = timed(lambda: fused.linear(x1, w1, None, relu=True, residual=r1),
                                                                              2.0 * 66800 * 64 * 256)
-    return {"terms": terms, "peak": "2.5 PFLOP/s dense bf16", "kernels": out}
+    return {"terms": terms, "split_product": _ARITH[fused.split_terms()][0], "peak": "2.5 PFLOP/s dense bf16 / fp16", "kernels": out}
 
 
 def committed_mfma_utilisation():
@@ -844,7 +861,8 @@ def main():
             print(json.dumps(measure_roofline(device, head_dim=hd, patterns=("pert", "init", "local"))))
         return
     model, criterion, post, margs = build_model(cfg, device)
-    single = fp32_exact = fp32_exact_single = split3 = association = multi = None
+    single = fp32_exact = fp32_exact_single = association = multi = None
+    other_arith = {}
     n_seq = 1
     if cfg["kind"] == "track":
         model.tracking()
@@ -879,17 +897,21 @@ def main():
                     fp32_exact_single = args.steps * rf * world / ef
             finally:
                 fused.set_split_linear(prev_split)
-        if fused.split_linear_enabled() and fused.split_terms() == 6 and not args.no_split3:
-            # ... and in the three-term fast mode (reported beside the headline, never as the headline)
-            prev_terms = fused.set_split_terms(3)
-            try:
-                e3, r3 = run_tracking(cfg, args, device, world, model, post, margs, max(1, args.sequences), seeds)
-                split3 = {"sequences_per_gpu": max(1, args.sequences), "value": round(args.steps * r3 * world / e3, 3)}
-                if args.sequences > 1 and not args.no_single_sequence:
-                    e3, r3 = run_tracking(cfg, args, device, world, model, post, margs, 1, seeds)
-                    split3["single_sequence"] = round(args.steps * r3 * world / e3, 3)
-            finally:
-                fused.set_split_terms(prev_terms)
+        if fused.split_linear_enabled() and not args.no_split3:
+            # ... and with the other split products (reported beside the headline, never as the headline)
+            for alt in (6, 16, 3):
+                if alt == fused.split_terms():
+                    continue
+                prev_terms = fused.set_split_terms(alt)
+                try:
+                    e3, r3 = run_tracking(cfg, args, device, world, model, post, margs, max(1, args.sequences), seeds)
+                    leg = {"sequences_per_gpu": max(1, args.sequences), "value": round(args.steps * r3 * world / e3, 3)}
+                    if args.sequences > 1 and not args.no_single_sequence:
+                        e3, r3 = run_tracking(cfg, args, device, world, model, post, margs, 1, seeds)
+                        leg["single_sequence"] = round(args.steps * r3 * world / e3, 3)
+                    other_arith[_ARITH[alt][1]] = leg
+                finally:
+                    fused.set_split_terms(prev_terms)
     elif cfg["kind"] == "detect":
         model.eval()
         elapsed, reps = run_detect(cfg, args, device, world, model, post)
@@ -930,12 +952,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / steps_timed, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if not fused.split_linear_enabled() or train
-                     else ("f32 (dense layers as the six-term bf16 split product on MFMA: hi / mid / lo pieces carry all 24 significand "
-                           "bits, dropped terms < 2^-24 of a product, f32 accumulate -- fp32 arithmetic in another summation order)"
-                           if fused.split_terms() == 6 else
-                           "f32 storage, products good to 2^-16 (three-term bf16 split product on MFMA, f32 accumulate): the fast mode, "
-                           "NOT the reference's precision"),
+            "dtype": "f32" if not fused.split_linear_enabled() or train else _ARITH[fused.split_terms()][2],
             "data": "synthetic", "per_gpu": round(value / world, 3),
             "timed_repeats": reps, "steps_timed": steps_timed, "timed_seconds": round(elapsed, 3),
             "config": {"workload": cfg["name"] + ", seeded random-init weights, frames "
@@ -944,7 +961,7 @@ def main():
                        "global_batch": world * (2 if train else 1),
                        "parallelism": ("DDP x%d (RCCL all-reduce)" if train else "sequence-sharded x%d") % world,
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
-                       "linears": ("bf16 split product, %d terms, f32 accumulate (own kernels)" % fused.split_terms())
+                       "linears": (_ARITH[fused.split_terms()][0] + ", f32 accumulate (own kernels)")
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",
                        **({"routes": _active_optins(_backbone, fused)} if not train and _active_optins(_backbone, fused) else {}),
                        **({"ffn": "one launch per feed-forward block (tf_ffn_fused_f32)"} if fused.ffn_fused_enabled() and not train else {}),
@@ -956,14 +973,15 @@ def main():
             "multi_sequence_fps": None if multi is None else {"sequences_per_gpu": max(1, args.sequences), "value": round(multi, 3)},
             "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
             "single_sequence_fp32_exact_fps": None if fp32_exact_single is None else round(fp32_exact_single, 3),
-            "split3_fps": split3,
+            **{_ARITH[a][1]: other_arith.get(_ARITH[a][1]) for a in (6, 16, 3) if a != fused.split_terms() or not fused.split_linear_enabled()},
             "precision": None if train else {
-                "value_measured_with": ("six-term split product (fp32-accurate), own kernels" if fused.split_terms() == 6 else
-                                        "three-term split product (2^-16 per product), own kernels") if fused.split_linear_enabled()
+                "value_measured_with": (_ARITH[fused.split_terms()][0] + ", own kernels") if fused.split_linear_enabled()
                                        else "fp32 libraries (hipBLASLt, MIOpen)",
                 "fp32_exact_fps": "fp32 libraries (hipBLASLt linears, MIOpen convolutions), --sequences per GPU",
                 "single_sequence_fp32_exact_fps": "the same with one sequence per GPU",
-                "split3_fps": "three-term fast mode; not the reference's precision (profiles/r04_id_parity_64.txt)"},
+                "split6_fps": "six-term bf16 split product: all 24 significand bits of both operands",
+                "split_f16_fps": "fp16 split product: three MFMAs per product, 22 + 1 significand bits per operand (include/tf_fused.h)",
+                "split3_fps": "three-term bf16 fast mode; not the reference's precision (profiles/r04_id_parity_64.txt)"},
             "association": association, "parity": parity, "ranks": ranks, "mfma_utilisation": mfma,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -50,6 +50,10 @@ def models(dev):
     return get
 
 
+SETUPS = ["eager", "graph_tuned", "graph_split_linear", "graph_split3", "graph_f16"]
+_SPLIT_SETUPS = {"graph_split_linear": 6, "graph_split3": 3, "graph_f16": 16}   # set-up -> split product (include/tf_fused.h)
+
+
 def _forward(case, models, dev, setup):
     from trackformer_amd import fused, runtime
     from trackformer_amd.graphed import GraphedDetector
@@ -57,8 +61,8 @@ def _forward(case, models, dev, setup):
     img, prev, target = um.model_inputs(case, args.hidden_dim)
     img, prev, target = img.to(dev), prev.to(dev), um.to_device(target, dev)
     detector = model
-    prev_split = fused.set_split_linear(setup in ("graph_split_linear", "graph_split3"))
-    prev_terms = fused.set_split_terms(3 if setup == "graph_split3" else 6)
+    prev_split = fused.set_split_linear(setup in _SPLIT_SETUPS)
+    prev_terms = fused.set_split_terms(_SPLIT_SETUPS.get(setup, 6))
     try:
         if setup != "eager":
             runtime.configure_inference(verbose=False)
@@ -104,7 +108,7 @@ def _compare(case, model, out, res, feats, memory, box_tol=1e-3, logit_tol=1e-3,
         float(np.abs(out['pred_logits'].cpu().numpy() - z['pred_logits']).max())
 
 
-@pytest.mark.parametrize("setup", ["eager", "graph_tuned", "graph_split_linear", "graph_split3"])
+@pytest.mark.parametrize("setup", SETUPS)
 @pytest.mark.parametrize("case", um.FULL_DETECTOR_CASES)
 def test_full_size_model_matches_reference_cpu_path(dev, models, case, setup):
     model, out, res, feats, memory = _forward(case, models, dev, setup)
@@ -118,8 +122,8 @@ def _run_tracker(models, dev, setup):
     from trackformer_amd.tracker import Tracker
     model, post, args = models("cfg2_full")
     detector = model
-    prev_split = fused.set_split_linear(setup in ("graph_split_linear", "graph_split3"))
-    prev_terms = fused.set_split_terms(3 if setup == "graph_split3" else 6)
+    prev_split = fused.set_split_linear(setup in _SPLIT_SETUPS)
+    prev_terms = fused.set_split_terms(_SPLIT_SETUPS.get(setup, 6))
     try:
         if setup != "eager":
             runtime.configure_inference(verbose=False)
@@ -141,7 +145,7 @@ def _run_tracker(models, dev, setup):
     return tracker, rows, active
 
 
-@pytest.mark.parametrize("setup", ["eager", "graph_tuned", "graph_split_linear", "graph_split3"])
+@pytest.mark.parametrize("setup", SETUPS)
 def test_full_size_tracker_track_ids_bit_exact(dev, models, setup):
     tracker, rows, active = _run_tracker(models, dev, setup)
     z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2.npz"))
@@ -152,6 +156,11 @@ def test_full_size_tracker_track_ids_bit_exact(dev, models, setup):
     np.testing.assert_array_equal(rows[:, [0, 1, 7]], z["rows"][:, [0, 1, 7]])   # id, frame, source query
     np.testing.assert_allclose(rows[:, 2:6], z["rows"][:, 2:6], atol=1e-3 * max(um.FULL_ORIG))
     np.testing.assert_allclose(rows[:, 6], z["rows"][:, 6], atol=1e-3)
+
+
+def fused_default_terms():
+    from trackformer_amd import fused
+    return fused.split_terms()
 
 
 def _ids_until_divergence(models, dev, gold, n_frames, split, terms):
@@ -212,12 +221,16 @@ def test_full_size_tracker_64_frame_sequence_against_reference(dev, models):
         return int(np.argmax(margins < thr)) if (margins < thr).any() else len(margins)
     agree6, tracker = _ids_until_divergence(models, dev, gold, n_run, True, 6)
     agree3, _ = _ids_until_divergence(models, dev, gold, n_run, True, 3)
-    print("64-frame fixture: six terms agree on %d frames (NMS margin of the first differing frame %.1e), three terms on %d "
-          "(%.1e); frames in front of the first margin < 2e-5: %d, < 1e-3: %d" % (
-              agree6, margins[min(agree6, len(margins) - 1)], agree3, margins[min(agree3, len(margins) - 1)],
-              first_below(2e-5), first_below(1e-3)))
+    agree16, tracker16 = _ids_until_divergence(models, dev, gold, n_run, True, 16)
+    print("64-frame fixture: six terms agree on %d frames (NMS margin of the first differing frame %.1e), fp16 pieces on %d (%.1e), "
+          "three terms on %d (%.1e); frames in front of the first margin < 2e-5: %d, < 1e-3: %d" % (
+              agree6, margins[min(agree6, len(margins) - 1)], agree16, margins[min(agree16, len(margins) - 1)],
+              agree3, margins[min(agree3, len(margins) - 1)], first_below(2e-5), first_below(1e-3)))
     assert agree6 >= first_below(2e-5), (agree6, margins[:n_run].tolist())
+    assert agree16 >= first_below(2e-5), (agree16, margins[:n_run].tolist())   # the fp16 product is held to the six-term bar
     assert agree3 >= first_below(1e-3)
+    if fused_default_terms() == 16:
+        agree6, tracker = agree16, tracker16
     results = tracker.get_results()
     got = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']), results[tid][f]['obj_ind']]
                     for tid in sorted(results) for f in sorted(results[tid]) if f < agree6], dtype=np.float64)
@@ -445,7 +458,7 @@ def test_conv1x1_split_k(dev, shape, cout, stride):
         assert torch.equal(y1, y0)                     # two pieces do not pay for a 1 x 1 convolution: left alone
 
 
-@pytest.mark.parametrize("terms", [6, 3], ids=["six_terms", "three_terms"])
+@pytest.mark.parametrize("terms", [6, 3, 16], ids=["six_terms", "three_terms", "fp16_pieces"])
 @pytest.mark.parametrize("shape,cout,ks,stride", [((1, 64, 200, 334), 64, 3, 1), ((1, 256, 100, 167), 256, 3, 2), ((1, 512, 25, 42), 512, 3, 1),
                                                   ((2, 128, 37, 53), 160, 3, 1), ((1, 1024, 50, 84), 2048, 1, 2)])
 def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
@@ -483,8 +496,8 @@ def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
     err, err_lib = float((y.double() - ref).abs().max()) / scale, float((lib32.double() - ref).abs().max()) / scale
     print("conv %s -> %d, %d x %d / %d, %d terms: max err / max |y| %.2e (library fp32 convolution: %.2e)" % (
         shape, cout, ks, ks, stride, terms, err, err_lib))
-    assert err < (2e-6 if terms == 6 else 1e-4)
-    if terms == 6:
+    assert err < (1e-4 if terms == 3 else 2e-6)
+    if terms != 3:
         assert err < 4 * err_lib + 1e-7
 
 

@@ -8,6 +8,7 @@ and the NMS margin the fixture recorded for that frame.
 Set-ups:
   fp32_library       fused.set_split_linear(False): hipBLASLt / MIOpen fp32 for every dense layer
   split3             the three-term bf16 split product everywhere (round-3 default)
+  split16            the fp16 split product (three terms; include/tf_fused.h)
   split3_heads_fp32  three-term products, but class_embed / bbox_embed (the decision-critical tail) through the fp32 library
   split6             the six-term (hi / mid / lo) split product everywhere: fp32-accurate products (dropped terms < 2^-24)
 Once two runs differ in one id, the track queries fed back differ and everything after is a different sequence: only the
@@ -46,11 +47,11 @@ def run(setup, n_frames, dev):
         prev["heads"] = fused.set_heads_split(False)
         if hasattr(fused, "set_split_terms"):
             prev["terms"] = fused.set_split_terms(3)
-    elif setup == "split6":
+    elif setup in ("split6", "split16"):
         if not hasattr(fused, "set_split_terms"):
             return None
         prev["split"] = fused.set_split_linear(True)
-        prev["terms"] = fused.set_split_terms(6)
+        prev["terms"] = fused.set_split_terms(6 if setup == "split6" else 16)
     else:
         raise ValueError(setup)
     try:
@@ -81,7 +82,7 @@ def first_diff(a, b):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
-    ap.add_argument("--setups", default="fp32_library,split3,split3_heads_fp32,split6")
+    ap.add_argument("--setups", default="fp32_library,split16,split6,split3")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     z = np.load(os.path.join(REPO, "tests", "golden", "full_tracker_cfg2_64.npz"))
