@@ -75,8 +75,9 @@ int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta,
  *               The three pieces carry all 24 significand bits; the dropped terms are below 2^-24 |x||w|: fp32 arithmetic in
  *               another summation order.
  *   terms = 16  fp16 pieces:  activation  xh = f16(x / 16),  xl = f16((x / 16 - xh) 2^11)
- *                             weight      wh = f16(w t_n),   wl = f16(w t_n - wh),   ws = f16(wh 2^-11)
- *               three terms  xl.ws + xh.wl + xh.wh,  result times r_n = 16 / t_n.  Two fp16 pieces carry 22 significand bits + the
+ *                             weight      wh = f16(w t_n),   wl = f16(w t_n - wh)
+ *               three terms  xl.(wh 2^-11) + xh.wl + xh.wh,  result times r_n = 16 / t_n  (wh 2^-11 is formed in registers from the
+ *               wh fragment: exact).  Two fp16 pieces carry 22 significand bits + the
  *               sign of the lower one (error of an operand <= 2^-23 of it); the only dropped product (lo.lo) is below 2^-22 |x||w|.
  *               t_n: the power of two that puts the largest |w| of output channel n into [2^13, 2^14) -- with the lower
  *               activation piece stored times 2^11 nothing falls into fp16's subnormals (|x| < 1.0e6; beyond that the row becomes
@@ -88,7 +89,7 @@ int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta,
  * Entry points that take the weight as separate piece tensors (16-bit [N, K] each, made once by the caller) select by which are
  * given:  (w_hi, w_mid)                       bf16 hi, mid                   -> three terms
  *         (w_hi, w_mid, w_lo)                 bf16 hi, mid, lo               -> six terms
- *         (w_hi, w_mid, w_lo, w_scale)        fp16 wh, wl, ws + r_n [N] fp32 -> the fp16 product
+ *         (w_hi, w_mid, NULL, w_scale)        fp16 wh, wl + r_n [N] fp32     -> the fp16 product
  * Entry points that take a PACKED weight select by `terms` (3, 6 or 16), which must be the value the weight was packed with
  * (tf_linear_pack_weight_f32 computes t_n / r_n itself).  x is split inside the kernels.
  */
@@ -175,7 +176,7 @@ int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, c
  *   tf_linear_pack_weight_f32(w, packed, ...)    w [N, K] fp32 row-major -> packed (16-byte aligned pointers); one small kernel
  *   tf_linear_packed_f32                         y[M, N] = act(x[M, K] . w^T + bias + residual); K % 64 == 0, 16-byte aligned x;
  *                                                bias / residual [M, N] may be NULL, residual may alias y; y below 3 GiB
- * terms: 3, 6 or 16 (see THE SPLIT PRODUCT above); a weight packed for 6 / 16 holds three pieces per fragment.
+ * terms: 3, 6 or 16 (see THE SPLIT PRODUCT above); a weight packed for 6 holds three pieces per fragment, else two.
  * The residual form is the closing 1 x 1 convolution of a ResNet bottleneck (conv3 -> FrozenBatchNorm2d -> `out += identity` ->
  * ReLU; reference: models/backbone.py:45-55 + torchvision's Bottleneck.forward) on channels_last activations.
  */

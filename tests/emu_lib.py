@@ -191,7 +191,7 @@ def bf16_split(w, terms=None):
 
 
 def f16_split(w):
-    """w [N, K] (fp32) -> (wh, wl, ws, r): the fp16 scheme of include/tf_fused.h as uint16 bit patterns + the channels' factors
+    """w [N, K] (fp32) -> (wh, wl, None, r): the fp16 scheme of include/tf_fused.h as uint16 bit patterns + the channels' factors
     r_n = 16 / t_n (what fused._split_weight hands the kernels for split_terms() == 16)."""
     w = w.astype(np.float32)
     amax = np.abs(w).max(axis=1)
@@ -201,14 +201,13 @@ def f16_split(w):
     ws = (w * t[:, None]).astype(np.float32)
     hi = ws.astype(np.float16)
     lo = (ws - hi.astype(np.float32)).astype(np.float16)
-    hs = (hi.astype(np.float32) * np.float32(1.0 / 2048.0)).astype(np.float16)
-    return hi.view(np.uint16), lo.view(np.uint16), hs.view(np.uint16), (np.float32(16) / t).astype(np.float32)
+    return hi.view(np.uint16), lo.view(np.uint16), None, (np.float32(16) / t).astype(np.float32)
 
 
 def _pieces(w2d, terms=None):
     """16-byte aligned contiguous piece arrays of a [N, K] weight -> (p0, p1, p2 | None, scale | None)."""
     if (terms or TERMS) == 16:
-        return tuple(_aligned16(np.ascontiguousarray(p)) for p in f16_split(w2d))
+        return tuple(None if p is None else _aligned16(np.ascontiguousarray(p)) for p in f16_split(w2d))
     return tuple(None if p is None else _aligned16(np.ascontiguousarray(p)) for p in bf16_split(w2d, terms)) + (None,)
 
 

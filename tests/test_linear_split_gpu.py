@@ -131,8 +131,8 @@ def test_split_linear_declines_what_it_cannot_do(dev, split_on):
     assert rc == -1
     rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr() + 2, 0, 0, one.data_ptr(), 1, 32, 1, 0, 0)
     assert rc == -2                                                               # misaligned lo piece
-    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), 0, one.data_ptr(), 0, one.data_ptr(), 1, 32, 1, 0, 0)
-    assert rc == -1                                                               # fp16 pieces (w_scale given) without the third piece
+    rc = _cabi.lib().tf_linear_split_f32(one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr(), one.data_ptr(), 0, one.data_ptr(), 1, 32, 1, 0, 0)
+    assert rc == -2                                                               # fp16 pieces (w_scale given) take two pieces, not three
     split_on.set_split_linear(False)
     assert split_on.linear(torch.randn(4, 32, device=dev), torch.randn(4, 32, device=dev)) is None   # switched off
 

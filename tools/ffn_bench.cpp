@@ -84,7 +84,7 @@ int main(int argc, char **argv)
         const size_t kk = W.size() / (size_t)n_out;
         std::vector<float> sc((size_t)n_out, 1.f);
         *dsc = nullptr;
-        if (T == 16) {   // fp16 pieces wh, wl, wh 2^-11 of w t_n + the channels' factors 16 / t_n
+        if (T == 16) {   // fp16 pieces wh, wl of w t_n + the channels' factors 16 / t_n
             for (int n = 0; n < n_out; ++n) {
                 float amax = 0.f;
                 for (size_t k = 0; k < kk; ++k) amax = std::max(amax, std::fabs(W[n * kk + k]));
@@ -95,10 +95,9 @@ int main(int argc, char **argv)
                 for (size_t k = 0; k < kk; ++k) {
                     const size_t i = n * kk + k;
                     const float ws = W[i] * tn;
-                    const _Float16 h = (_Float16)ws, l = (_Float16)(ws - (float)h), s2 = (_Float16)((float)h * (1.f / 2048.f));
+                    const _Float16 h = (_Float16)ws, l = (_Float16)(ws - (float)h);
                     memcpy(&pc[0][i], &h, 2);
                     memcpy(&pc[1][i], &l, 2);
-                    memcpy(&pc[2][i], &s2, 2);
                 }
             }
             CK(hipMalloc(dsc, sc.size() * 4));
@@ -123,7 +122,7 @@ int main(int argc, char **argv)
             CK(hipMalloc(d[q], W.size() * 2));
             CK(hipMemcpy(*d[q], pc[q].data(), W.size() * 2, hipMemcpyHostToDevice));
         }
-        if (T == 3) *dlo = nullptr;   // three terms: no lo piece
+        if (T != 6) *dlo = nullptr;   // three bf16 terms / fp16 pieces: no third piece
     };
     unsigned short *dW1hi, *dW1mid, *dW1lo, *dW2hi, *dW2mid, *dW2lo;
     float *dW1sc, *dW2sc, *dWosc;

@@ -302,11 +302,11 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
                         v[i][j][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                                    rrs, (unsigned)((m0 + i * 32 + frow) * D + cbase + 32 * j + 8 * g) * 4u, 0, 0));
         }
-        f32x16 acch[TI];
+        f32x16 acch[TI][1];   // ([.][1]: the tile-array form mfma_tiles takes)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acch[i][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acch[i][0][e] = 0.f;
 
         auto prefetch = [&](auto uc) {
             constexpr int ahead = decltype(uc)::value + G::AHEAD;
@@ -331,15 +331,11 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
             if constexpr (st + 1 < G::KQ1) read_x(std::integral_constant<int, st + 1>{});
             __builtin_amdgcn_sched_barrier(0);   // loads and reads stay at the head of the step (see linear_stream.hip)
             const u32x4 (&cur)[US] = ring[(st / 2) % RING];
-            u32x4 wf[NB];
+            u32x4 wf[1][NB];
 #pragma unroll
-            for (int p = 0; p < NB; ++p) wf[p] = cur[(st & 1) * NB + p];
-            // the weight fragment is the A operand (transposed accumulators); x piece T::A[t] x weight piece T::B[t], smallest first
-            using T = Split<SP>;
-#pragma unroll
-            for (int t = 0; t < T::N; ++t)
-#pragma unroll
-                for (int i = 0; i < TI; ++i) acch[i] = mfma16<SP>(wf[T::B[t]], xf[st & 1][i][T::A[t]], acch[i]);
+            for (int p = 0; p < NB; ++p) wf[0][p] = cur[(st & 1) * NB + p];
+            // the weight fragment is the A operand (transposed accumulators); x piece T::A[t] x weight operand T::B[t], smallest first
+            mfma_tiles<SP, TI, 1, false>(acch, xf[st & 1], wf);
         });
 
         // ---- bias + ReLU + split -> the hidden tile in LDS.  C/D of the 32 x 32 MFMA with the weight as A: lane -> row
@@ -353,7 +349,7 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
                 f32x4 hv;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = F16 ? __builtin_fmaf(acch[i][4 * g + e], r1v[g][e], b1v[g][e]) : acch[i][4 * g + e] + b1v[g][e];
+                    const float t = F16 ? __builtin_fmaf(acch[i][0][4 * g + e], r1v[g][e], b1v[g][e]) : acch[i][0][4 * g + e] + b1v[g][e];
                     hv[e] = (t > 0.f && hcol + 8 * g < F) ? t : 0.f;   // columns past the hidden width (last chunk only): zero
                 }
                 u32x2 pc[NA];
@@ -613,7 +609,7 @@ int dispatch_linln(const float *x, const u32x4 *w, const float *bias, const floa
     case 1: return launch_linln<SP, D, 1>(x, w, bias, residual, g, b, eps, y, M, s);
     case 3:   // 96 rows per block: hidden 256 with two bf16 pieces only (at 288 the accumulators of three row tiles do not fit the
               // register file, with three pieces the tile does not fit the LDS / the weight ring does not fit the registers)
-        if constexpr (D == 256 && SP == 2) return launch_linln<SP, D, 3>(x, w, bias, residual, g, b, eps, y, M, s);
+        if constexpr (D == 256 && Split<SP>::NB == 2) return launch_linln<SP, D, 3>(x, w, bias, residual, g, b, eps, y, M, s);
         else return launch_linln<SP, D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
     default: return launch_linln<SP, D, 2>(x, w, bias, residual, g, b, eps, y, M, s);
     }
@@ -630,8 +626,8 @@ int dispatch_ffn(const float *x, const u32x4 *w1, const float *b1, const u32x4 *
     // MFMA-busy, 38 % of the launch's).  When the last round would be less than half full, the rows behind the full rounds go
     // to a second launch of 32-row blocks: a short round instead of a long one.  Same arithmetic per row (a row's result does
     // not depend on the block it is in): bit-identical.
-    constexpr bool three_tiles = D == 256 && SP == 2;   // 96 rows per block: two bf16 pieces only (three weight pieces: the ring of
-                                                        // weight units does not leave room for a third row tile's accumulators)
+    constexpr bool three_tiles = D == 256 && Split<SP>::NB == 2;   // 96 rows per block: two stored weight pieces only (with three the
+                                                                   // ring of weight units leaves no room for a third row tile's accumulators)
     const int want = ffn_ti();
     const bool ti2 = want == 2 || (want >= 3 && !three_tiles);
     if (ti2 && tfm::ffn_tail_split()) {

@@ -64,8 +64,8 @@ __device__ __forceinline__ int stage_row(int q) { return (q & ~7) | ((q & 1) << 
 // (profiles/r02_split_gemm_astat_trace.txt: 10.5 us of store time per 96 x 256 tile).
 // XADD (tf_linear_split_add_f32): the activation is X + X2, added element-wise as the tile is staged -- the layers'
 // `with_pos_embed(src, pos)` in front of a projection (deformable_transformer.py:279-283) without its own pass over the tokens.
-// SP: the scheme of split_product.h (2 / 3: bf16 pieces, Wsc unused; 16: fp16 pieces -- Whi / Wmid / Wlo hold the weight's hi, lo and
-// hi 2^-11 pieces and Wsc the output channels' powers of two).
+// SP: the scheme of split_product.h (2 / 3: bf16 pieces, Wsc unused; 16: fp16 pieces -- Whi / Wmid hold the weight's hi and lo pieces,
+// Wlo is unused, Wsc the output channels' powers of two).
 template <int SP, int BM, int BN, bool RELU, bool PREFETCH, bool RESID, bool BUFST, bool XADD = false>
 __device__ __forceinline__ void
 split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ Whi,
@@ -623,7 +623,7 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
 // larger the plain stores (split_gemm_body<..., BUFST = false>).
 inline bool fits_bufstore(long long M, int N) { return (M + 256) * N * 4 < 0xC0000000LL; }
 
-// the weight of a call: its 16-bit pieces (hi, mid [, lo] bf16; or, fp16 scheme: hi, lo, hi 2^-11) [+ the output channels' powers of two]
+// the weight of a call: its 16-bit pieces (hi, mid [, lo] bf16; or, fp16 scheme: hi, lo) [+ the output channels' powers of two]
 struct Weight {
     const unsigned short *p[3];
     const float *scale;
@@ -662,11 +662,12 @@ int launch_add(const float *x, const float *x2, const Weight &w, const float *bi
 }
 
 // The weight arguments of the C ABI -> scheme (split_product.h): (w_hi, w_mid) -> 2 (three bf16 terms), (w_hi, w_mid, w_lo) -> 3
-// (six), (w_hi, w_mid, w_lo, w_scale) -> 16 (fp16 pieces hi, lo, hi 2^-11 + the channels' factors); 0: a missing piece, -1:
-// misaligned (16 bytes)
+// (six), (w_hi, w_mid, NULL, w_scale) -> 16 (fp16 pieces hi, lo + the channels' factors); 0: a missing piece, -1: misaligned
+// (16 bytes) or a third piece beside w_scale
 inline int weight_scheme(const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, Weight &w)
 {
-    if (!w_hi || !w_mid || (w_scale && !w_lo)) return 0;
+    if (!w_hi || !w_mid) return 0;
+    if (w_scale && w_lo) return -1;
     if ((reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_mid) | reinterpret_cast<uintptr_t>(w_lo)) & 15) return -1;
     w.p[0] = static_cast<const unsigned short *>(w_hi);
     w.p[1] = static_cast<const unsigned short *>(w_mid);

@@ -22,7 +22,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // 4 pieces of
 // ---- the split product, generic in the SCHEME SP (the template parameter of every kernel that uses it):
 //   SP = 2   bf16 (hi, mid) per operand:     three terms  a_mid.b_hi + a_hi.b_mid + a_hi.b_hi            dropped terms < 2^-16 of the product
 //   SP = 3   bf16 (hi, mid, lo) per operand: six terms    a_lo.b_hi + a_hi.b_lo + a_mid.b_mid + a_mid.b_hi + a_hi.b_mid + a_hi.b_hi
-//   SP = 16  fp16 (hi, lo) activations x fp16 (hi, lo, hi 2^-11) weights: three terms  a_lo.b_hs + a_hi.b_lo + a_hi.b_hi
+//   SP = 16  fp16 (hi, lo) of both operands, three terms  a_lo.(b_hi 2^-11) + a_hi.b_lo + a_hi.b_hi
 //
 // bf16, three pieces (round to nearest even at every step) carry all 24 significand bits of an fp32 number (hi 8, mid 8, lo 8; the
 // residuals x - hi and (x - hi) - mid are exact in fp32), and the six products kept are all those of weight >= 2^-16; the dropped
@@ -36,7 +36,10 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // 4 pieces of
 // only product dropped (lo.lo) is below 2^-22 of |a||b|.  Three MFMAs instead of six.  What fp16 lacks is exponent range (5 bits):
 //   * the lo piece of a small number would fall into the subnormals.  It is therefore stored SCALED: lo' = rne16((x - hi) 2^11)
 //     has the magnitude of hi's last place times 2^11, normal whenever hi is, and its partner in the product is the weight's hi
-//     piece times 2^-11 (the third weight piece `hs`, exact: a power of two; made once when the weight is packed);
+//     piece times 2^-11 -- made in registers from the hi fragment right before its MFMA (v_pk_mul_f16 by a power of two: exact; four
+//     instructions per fragment, which serves every row tile of the wave), so a weight is stored as TWO pieces like the
+//     three-term bf16 product's (the first version of this scheme stored the third operand: 1.5x the weight traffic and a
+//     third more fragment registers -- 99.7 against 71.2 us in the fused feed-forward block, profiles/r04_f16_first_harness.txt);
 //   * weights are scaled per OUTPUT CHANNEL by the power of two t_n that puts the channel's largest |w| into [2^13, 2^14) (exact;
 //     a weight 2^-17 times the channel's largest still has all its bits, smaller ones an absolute error of 2^-39 of the largest);
 //     the epilogue multiplies the accumulator by r_n = 1 / (kActScale t_n), again a power of two;
@@ -47,19 +50,21 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // 4 pieces of
 // representation alone (fp32 rounding of the SUM, which the reference's sgemm has as well: 2.4e-7), six-term bf16 3.3e-9,
 // three-term bf16 2.2e-6.  Terms are issued smallest first.
 template <int SP> struct Split;
+// NA / NB: pieces of an activation / of a weight as STORED (LDS, packed image, piece tensors); NBX: weight operands of the terms (B
+// indexes them): the stored pieces [+ the one expand_weight() derives]
 template <> struct Split<2> {
     static constexpr bool F16 = false;
-    static constexpr int NA = 2, NB = 2, N = 3;
+    static constexpr int NA = 2, NB = 2, NBX = 2, N = 3;
     static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0};
 };
 template <> struct Split<3> {
     static constexpr bool F16 = false;
-    static constexpr int NA = 3, NB = 3, N = 6;
+    static constexpr int NA = 3, NB = 3, NBX = 3, N = 6;
     static constexpr int A[6] = {2, 0, 1, 1, 0, 0}, B[6] = {0, 2, 1, 0, 1, 0};
 };
 template <> struct Split<16> {
     static constexpr bool F16 = true;
-    static constexpr int NA = 2, NB = 3, N = 3;
+    static constexpr int NA = 2, NB = 2, NBX = 3, N = 3;
     static constexpr int A[3] = {1, 0, 0}, B[3] = {2, 1, 0};
 };
 
@@ -102,18 +107,28 @@ template <int SP>
 __device__ __forceinline__ void split4_weight(const f32x4 &w, u32x2 (&p)[Split<SP>::NB])
 {
     if constexpr (Split<SP>::F16) {
-        f16x4 h, l, s;
+        f16x4 h, l;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             h[e] = (_Float16)w[e];
             l[e] = (_Float16)(w[e] - (float)h[e]);
-            s[e] = (_Float16)((float)h[e] * kInvLoScale);
         }
         p[0] = __builtin_bit_cast(u32x2, h);
         p[1] = __builtin_bit_cast(u32x2, l);
-        p[2] = __builtin_bit_cast(u32x2, s);
     } else {
         split4<SP>(w, p);
+    }
+}
+
+// the weight operands of the terms from the stored pieces of a fragment: fp16 scheme: + hi 2^-11 (exact; v_pk_mul_f16 x 4)
+template <int SP>
+__device__ __forceinline__ void expand_weight(const u32x4 (&w)[Split<SP>::NB], u32x4 (&wx)[Split<SP>::NBX])
+{
+#pragma unroll
+    for (int p = 0; p < Split<SP>::NB; ++p) wx[p] = w[p];
+    if constexpr (Split<SP>::F16) {
+        const f16x8 h = __builtin_bit_cast(f16x8, w[0]);
+        wx[2] = __builtin_bit_cast(u32x4, h * (_Float16)kInvLoScale);
     }
 }
 
@@ -141,8 +156,10 @@ template <int SP, bool XA = true>
 __device__ __forceinline__ void mfma_terms(f32x16 &acc, const u32x4 (&x)[Split<SP>::NA], const u32x4 (&w)[Split<SP>::NB])
 {
     using T = Split<SP>;
+    u32x4 wx[T::NBX];
+    expand_weight<SP>(w, wx);
 #pragma unroll
-    for (int t = 0; t < T::N; ++t) acc = XA ? mfma16<SP>(x[T::A[t]], w[T::B[t]], acc) : mfma16<SP>(w[T::B[t]], x[T::A[t]], acc);
+    for (int t = 0; t < T::N; ++t) acc = XA ? mfma16<SP>(x[T::A[t]], wx[T::B[t]], acc) : mfma16<SP>(wx[T::B[t]], x[T::A[t]], acc);
 }
 
 // the same for a wave's TI x TJ tiles, term-major: consecutive MFMAs never share an accumulator; per accumulator the order is
@@ -151,18 +168,21 @@ template <int SP, int TI, int TJ, bool XA = true>
 __device__ __forceinline__ void mfma_tiles(f32x16 (&acc)[TI][TJ], const u32x4 (&x)[TI][Split<SP>::NA], const u32x4 (&w)[TJ][Split<SP>::NB])
 {
     using T = Split<SP>;
+    u32x4 wx[TJ][T::NBX];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) expand_weight<SP>(w[j], wx[j]);
 #pragma unroll
     for (int t = 0; t < T::N; ++t)
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
-                acc[i][j] = XA ? mfma16<SP>(x[i][T::A[t]], w[j][T::B[t]], acc[i][j]) : mfma16<SP>(w[j][T::B[t]], x[i][T::A[t]], acc[i][j]);
+                acc[i][j] = XA ? mfma16<SP>(x[i][T::A[t]], wx[j][T::B[t]], acc[i][j]) : mfma16<SP>(wx[j][T::B[t]], x[i][T::A[t]], acc[i][j]);
 }
 
 // `terms` argument of the C ABI -> scheme: 3 / 6 bf16 terms, 16 = fp16 pieces (three terms); 0: unknown
 inline int split_scheme(int terms) { return terms == 3 ? 2 : terms == 6 ? 3 : terms == 16 ? 16 : 0; }
-inline int scheme_pieces_b(int sp) { return sp == 16 ? 3 : sp; }   // 16-bit weight pieces per element
+inline int scheme_pieces_b(int sp) { return sp == 16 ? 2 : sp; }   // 16-bit weight pieces stored per element
 
 }  // namespace
 

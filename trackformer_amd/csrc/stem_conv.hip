@@ -156,11 +156,14 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
             u32x4 xp[NA];
 #pragma unroll
             for (int p = 0; p < NA; ++p) xp[p] = u32x4{plo[p].x, plo[p].y, phi[p].x, phi[p].y};
-            using T = Split<SP>;   // x piece T::A[t] x weight piece T::B[t], smallest terms first
+            using T = Split<SP>;   // x piece T::A[t] x weight operand T::B[t], smallest terms first
+            u32x4 wx[2][T::NBX];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) expand_weight<SP>(wf[t][q], wx[t]);
 #pragma unroll
             for (int tt = 0; tt < T::N; ++tt)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) acc[t] = mfma16<SP>(wf[t][q][T::B[tt]], xp[T::A[tt]], acc[t]);
+                for (int t = 0; t < 2; ++t) acc[t] = mfma16<SP>(wx[t][T::B[tt]], xp[T::A[tt]], acc[t]);
         }
         // ---- epilogue: lane -> pixel (oy, ox0 + m); registers 4 g .. 4 g + 3 of tile t -> channels 32 t + 8 g + 4 half + 0..3
         const int ox = ox0 + m;

@@ -205,8 +205,8 @@ def _split_weight(weight):
     """The 16-bit pieces of an fp32 weight [N, K] for the kernels that take them as separate tensors (include/tf_fused.h, THE
     SPLIT PRODUCT) -> (p0, p1, p2, scale):
       split_terms() 3 / 6   bf16 hi, mid, lo (lo None for three terms), scale None
-      split_terms() 16      fp16 wh = f16(w t_n), wl = f16(w t_n - wh), ws = f16(wh 2^-11) and scale[n] = 16 / t_n (fp32), t_n the
-                            power of two that puts the largest |w| of output channel n into [2^13, 2^14)
+      split_terms() 16      fp16 wh = f16(w t_n), wl = f16(w t_n - wh), None, and scale[n] = 16 / t_n (fp32), t_n the power of two
+                            that puts the largest |w| of output channel n into [2^13, 2^14)
     (round to nearest even at every step).  Cached ON THE TENSOR OBJECT together with its version counter
     (weights are constants in inference; an in-place update bumps the version).  Not keyed by data_ptr: a freed
     parameter's address is handed to the next model's parameters by the caching allocator, and a pointer-keyed cache
@@ -219,13 +219,13 @@ def _split_weight(weight):
             w = weight.detach()
             amax = w.abs().amax(dim=1)
             _, e = torch.frexp(amax)                                   # amax = m 2^e with m in [0.5, 1): floor(log2 amax) = e - 1
-            t = torch.ldexp(torch.ones_like(amax), torch.clamp(14 - e, -100, 100))
+            # 2^(14 - e) from its exponent bits (torch.ldexp goes through pow(), which is not exact on every device)
+            t = ((torch.clamp(14 - e, -100, 100).to(torch.int32) + 127) << 23).view(torch.float32)
             t = torch.where((amax > 0) & (amax < 3.0e38), t, torch.ones_like(t))
             ws = w * t[:, None]                                        # exact: powers of two
             hi = ws.to(torch.float16)
             lo = (ws - hi.float()).to(torch.float16)
-            hs = (hi.float() * (1.0 / 2048.0)).to(torch.float16)
-            hit = (weight._version, hi.contiguous(), lo.contiguous(), hs.contiguous(), (16.0 / t).contiguous())
+            hit = (weight._version, hi.contiguous(), lo.contiguous(), None, (16.0 / t).contiguous())
             if w.is_cuda:
                 _publish_barrier(w.device)
             weight._tf_split_f16 = hit
