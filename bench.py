@@ -359,17 +359,20 @@ def measure_parity(device):
             model.to(device).tracking()
             cache[case] = (model, post, margs)
         return cache[case]
+    from trackformer_amd import fused
     case = "cfg2_full"
-    model, out, res, feats, memory = T._forward(case, models, device, "graph_split_linear")
+    # the set-up of tests/test_full_size_gpu.py that matches the arithmetic `value` is measured with
+    setup = {16: "graph_split_linear", 6: "graph_split6", 3: "graph_split3"}[fused.split_terms()] if fused.split_linear_enabled() else "graph_tuned"
+    model, out, res, feats, memory = T._forward(case, models, device, setup)
     z = np.load(os.path.join(T.GOLDEN, "full_%s.npz" % case))
     dbox = float(np.abs(out['pred_boxes'].cpu().numpy() - z['pred_boxes']).max())
     dlogit = float(np.abs(out['pred_logits'].cpu().numpy() - z['pred_logits']).max())
-    tracker, rows, active = T._run_tracker(models, device, "graph_split_linear")
+    tracker, rows, active = T._run_tracker(models, device, setup)
     zt = np.load(os.path.join(T.GOLDEN, "full_tracker_cfg2.npz"))
     ids_equal = bool(rows.shape == zt["rows"].shape and np.array_equal(rows[:, [0, 1, 7]], zt["rows"][:, [0, 1, 7]])
                      and int(zt["num_tracks"]) == tracker.track_num and zt["active_per_frame"].tolist() == active)
     return {"against": "reference CPU path goldens (tests/golden/full_cfg2_full.npz, full_tracker_cfg2.npz), perturbed weights, 800x1333",
-            "max_abs_boxes": dbox, "max_abs_logits": dlogit, "tolerance": 1e-3,
+            "setup": setup, "max_abs_boxes": dbox, "max_abs_logits": dlogit, "tolerance": 1e-3,
             "ids_equal": ids_equal, "tracker_frames": int(len(active)), "track_rows": int(rows.shape[0])}
 
 

@@ -50,8 +50,9 @@ def models(dev):
     return get
 
 
-SETUPS = ["eager", "graph_tuned", "graph_split_linear", "graph_split3", "graph_f16"]
-_SPLIT_SETUPS = {"graph_split_linear": 6, "graph_split3": 3, "graph_f16": 16}   # set-up -> split product (include/tf_fused.h)
+SETUPS = ["eager", "graph_tuned", "graph_split_linear", "graph_split6", "graph_split3"]
+# set-up -> split product (include/tf_fused.h); "graph_split_linear" is the bench set-up: the package's default product (fp16 pieces)
+_SPLIT_SETUPS = {"graph_split_linear": 16, "graph_split6": 6, "graph_split3": 3}
 
 
 def _forward(case, models, dev, setup):

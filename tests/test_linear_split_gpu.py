@@ -150,7 +150,7 @@ def test_model_and_tracker_goldens_hold_with_split_linears(dev, split_on):
 def test_packed_linear_dispatch(dev, split_on):
     """Only the shapes the packed kernel measured faster on go to it (trackformer_amd/fused.py: _use_packed)."""
     assert split_on._use_packed(22223, 256, 1024) and split_on._use_packed(22223, 1024, 256)
-    six = split_on.split_terms() != 3     # (the fp16 pieces follow the six-term policy)
+    six = split_on.split_terms() == 6     # (the fp16 pieces store two weight pieces: the three-term policy)
     assert split_on._use_packed(22223, 256, 256) == six        # six terms: every many-row shape with K >= 256
     assert not split_on._use_packed(22223, 256, 384)           # the second 256-column block would be half empty
     assert not split_on._use_packed(66800, 64, 256)            # a short K: the block kernel

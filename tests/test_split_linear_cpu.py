@@ -43,10 +43,11 @@ def _patch(monkeypatch, passes):
 
 
 def test_weight_pieces_reconstruct_the_weight():
-    """(hi, mid): to 16 bits; (hi, mid, lo), the default: exactly."""
+    """bf16 (hi, mid): to 16 bits; (hi, mid, lo): exactly; the default, fp16 (hi, lo) of the channel-scaled weight: to 2^-23."""
     from trackformer_amd import fused
     w = torch.randn(64, 96) * 3
-    assert fused.split_terms() == 6
+    assert fused.split_terms() == 16     # the package's default product
+    prev6 = fused.set_split_terms(6)
     hi, mid, lo, none = fused._split_weight(w)
     assert hi.dtype == mid.dtype == lo.dtype == torch.bfloat16 and none is None
     rel = ((hi.float() + mid.float() - w).abs() / w.abs().clamp_min(1e-30)).max()
@@ -78,6 +79,7 @@ def test_weight_pieces_reconstruct_the_weight():
     finally:
         fused.set_split_terms(prev)
     assert fused._split_weight(w)[0].dtype == torch.bfloat16
+    assert fused.set_split_terms(prev6) == 6 and fused._split_weight(w)[0].dtype == torch.float16
 
 
 @pytest.mark.parametrize("passes", [3, 6])
@@ -104,6 +106,7 @@ def test_split_pieces_are_cached_on_the_tensor_not_by_address():
     freed parameter's memory to the next model) must not share split pieces."""
     import torch
     from trackformer_amd import fused
+    prev = fused.set_split_terms(6)      # bf16 pieces: the hi piece is simply the weight rounded to bf16
     a = torch.randn(8, 32)
     hi_a = fused._split_weight(a)[0].clone()
     b = torch.empty(0)
@@ -111,6 +114,7 @@ def test_split_pieces_are_cached_on_the_tensor_not_by_address():
     with torch.no_grad():
         a.mul_(0).add_(torch.randn(8, 32))                  # new values at the old address
     hi_b = fused._split_weight(b)[0]
+    fused.set_split_terms(prev)
     assert torch.equal(hi_b, b.to(torch.bfloat16)) and not torch.equal(hi_b, hi_a)
 
 
@@ -121,13 +125,18 @@ def test_packed_kernel_dispatch_policy():
     prev = fused.set_packed_linear(True)
     try:
         assert fused._use_packed(22223, 256, 1024) and fused._use_packed(22223, 1024, 256)
-        assert fused.split_terms() == 6 and fused._use_packed(22223, 256, 256) and fused._use_packed(66800, 256, 64)   # six terms: K >= 256
         assert not fused._use_packed(22223, 256, 384) and not fused._use_packed(66800, 64, 256)
-        p3 = fused.set_split_terms(3)
+        for two_pieces in (16, 3):     # fp16 pieces (the default) / three bf16 terms: a wide output or a long K only
+            p = fused.set_split_terms(two_pieces)
+            try:
+                assert not fused._use_packed(22223, 256, 256) and fused._use_packed(22223, 256, 1024) and fused._use_packed(16700, 512, 128)
+            finally:
+                fused.set_split_terms(p)
+        p6 = fused.set_split_terms(6)
         try:
-            assert not fused._use_packed(22223, 256, 256) and fused._use_packed(22223, 256, 1024)   # three terms: wide output / long K only
+            assert fused._use_packed(22223, 256, 256) and fused._use_packed(66800, 256, 64)   # six terms: K >= 256
         finally:
-            fused.set_split_terms(p3)
+            fused.set_split_terms(p6)
         assert not fused._use_packed(400, 256, 1024)       # decoder: few rows
         assert not fused._use_packed(30000, 288, 1024)     # hidden 288: K not a multiple of 64
         assert not fused._use_packed(30000, 1024, 288)     # second 256-column block nearly empty

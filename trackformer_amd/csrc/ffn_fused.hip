@@ -605,7 +605,8 @@ int dispatch_linln(const float *x, const u32x4 *w, const float *bias, const floa
     // full round and a third of one).  32-row tiles (50 KB) keep three blocks resident per CU and the 695 blocks run as one
     // round: 26.2 us against 31.2 us with 64-row blocks (29.0 with the rows behind the full round split off as dispatch_ffn
     // does; profiles/r04_one_launch_blocks_tail_split.txt).  Two pieces: 64-row tiles, two resident per CU, as measured in round 3.
-    switch (forced ? forced : (M < 4096 || Split<SP>::NA == 3 ? 1 : 2)) {
+    // fp16 pieces, hidden 256: 96-row blocks (20.1 us against 21.1 / 22.6 with 32 / 64 rows; profiles/r04_f16_harness.txt)
+    switch (forced ? forced : (M < 4096 || Split<SP>::NA == 3 ? 1 : (SP == 16 && D == 256 ? 3 : 2))) {
     case 1: return launch_linln<SP, D, 1>(x, w, bias, residual, g, b, eps, y, M, s);
     case 3:   // 96 rows per block: hidden 256 with two bf16 pieces only (at 288 the accumulators of three row tiles do not fit the
               // register file, with three pieces the tile does not fit the LDS / the weight ring does not fit the registers)

@@ -444,7 +444,9 @@ int stream_dispatch(const StreamCall &c, hipStream_t s)
         const bool big = f ? f >= 4 : (long long)((c.M + 127) / 128) * ((c.N + 255) / 256) * pieces >= 2LL * num_cus();
         return big ? launch_stream<SP, 4, 2, 4, CONV>(c, s) : launch_stream<SP, 2, 2, 4, CONV>(c, s);
     } else {
-        switch (f ? f : (c.K >= 512 ? 3 : 2)) {
+        // (fp16 pieces: three row tiles at every K -- 22 223 rows: 256 -> 1024 48.8 vs 51.3 us, 1024 -> 256 43.2 vs 50.5, 256 -> 256
+        // 18.2 vs 18.6; profiles/r04_f16_harness.txt)
+        switch (f ? f : (c.K >= 512 || SP == 16 ? 3 : 2)) {
         case 1:
         case 2: return launch_stream<SP, 2, 2, 4, CONV>(c, s);
         case 4: return launch_stream<SP, 4, 2, 4, CONV>(c, s);

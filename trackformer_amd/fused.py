@@ -102,7 +102,10 @@ def set_split_linear(on):
 #       reference's fp32 arithmetic in another summation order.
 #   16  fp16 pieces: (hi, lo) of the activation x (hi, lo, hi 2^-11) of the weight, THREE terms: 22 + 1 significand bits, the only
 #       dropped product below 2^-22; weights scaled per output channel and the lo piece stored times 2^11 so that nothing falls
-#       into fp16's subnormals.  Half the matrix work of 6.
+#       into fp16's subnormals.  Half the matrix work of 6 at fp32-class accuracy: THE DEFAULT (round 4).  MI355X, cfg 2: 396.9
+#       frames/s against 295.6 with six terms (410.3 with three bf16 terms, 193.9 on the fp32 libraries); full-size logits 1.2e-5 /
+#       boxes 5.4e-7 from the reference (six terms: 1.6e-5 / 5.4e-7); the reference's track ids on all 64 frames of the 64-frame
+#       fixture in both runs (six terms: 26 frames, the fp32 libraries 59 / 26): profiles/r04_id_parity_64_with_fp16.txt.
 #   3   bf16 pieces (hi, mid), three terms, products good to 2^-16: the fast mode.
 # Why not 3 by default: the 64-frame reference-Tracker fixture (tests/golden/full_tracker_cfg2_64.npz) keeps the reference's
 # track ids for 59 frames under fp32 library GEMMs but only 14 under three bf16 terms (profiles/r04_id_parity_64.txt) -- boxes
@@ -116,7 +119,7 @@ def _parse_terms(v):
     raise ValueError("split terms: 3, 6 or 16 (fp16 pieces)")
 
 
-_split_terms = _parse_terms(os.environ.get("TF_SPLIT_TERMS", "6"))
+_split_terms = _parse_terms(os.environ.get("TF_SPLIT_TERMS", "16"))
 
 
 def split_terms():
@@ -153,8 +156,11 @@ def _use_packed(M, K, N):
         return False
     tail = N % 256
     full = N <= 128 or tail == 0 or tail > 128
-    if _split_terms != 3:   # (fp16 pieces: the weight traffic of six terms -- three pieces --, its policy until measured separately)
+    if _split_terms == 6:
         return full and K >= 256
+    # two stored weight pieces (three bf16 terms, fp16 pieces): the same kernels at the same cost -- measured with the fp16 pieces
+    # too (profiles/r04_f16_harness.txt: 22 223 x 256 -> 256 18.4 vs 18.7 us, 16 700 x 512 -> 128 16.1 vs 21.6, 66 800 x 64 -> 256
+    # 20.8 vs 19.3, 16 700 x 128 -> 512 17.3 vs 17.4)
     return (N >= 512 or K >= 512) and full
 
 
@@ -669,7 +675,9 @@ def _conv_stream_wins(m, cout):
     31.4 vs 36.4).  Not the 64-channel layer1 (two column tiles only: 47.7 vs 43.6 us) and not the few-pixel layers whose K loop
     is cut into pieces (layer3 / layer4: 49.0 vs 46.9, 48.8 vs 48.6) -- there the two forms are within noise or the block kernel
     wins, and it stays."""
-    return _CONV_STREAM_ALL or (cout >= 128 and m >= 8192)
+    # fp16 pieces: every shape (per frame 1321 us with the stream form everywhere against 1362 with the block kernels,
+    # profiles/r04_f16_conv_per_layer.txt)
+    return _CONV_STREAM_ALL or _split_terms == 16 or (cout >= 128 and m >= 8192)
 
 
 def set_conv_stream(on):
