@@ -601,11 +601,13 @@ def committed_mfma_utilisation():
     frame = {k: round(v["mfma_util"], 3) for k, v in d.get("mfma_frame", {}).items() if "mfma_util" in v}
     harness = {}
     for key, kern, label in (("mfma_ffn", "ffn_fused_kernel", "tf_ffn_fused_f32 22223x256x1024"),
-                             ("mfma_lin1", "split_gemm_stream_kernel", "tf_linear_packed_f32 22223x256->1024"),
-                             ("mfma_lin2", "split_gemm_kernel", "tf_linear_split_f32 22223x256->256")):
-        try:
-            harness[label] = round(d[key][kern]["mfma_util"], 3)
-        except (KeyError, TypeError):
+                             ("mfma_lin1", "stream_gemm_kernel", "tf_linear_packed_f32 22223x256->1024"),
+                             ("mfma_lin2", "gemm_kernel", "tf_linear_packed_f32 / tf_linear_split_f32 22223x256->256")):
+        try:   # the kernel of that harness run that spent the most time (its name carries the template arguments)
+            hits = [v for k, v in d[key].items() if kern in k and isinstance(v, dict) and "mfma_util" in v]
+            if hits:
+                harness[label] = round(max(hits, key=lambda v: v.get("dispatch_ns_total", 0))["mfma_util"], 3)
+        except (KeyError, TypeError, AttributeError):
             pass
     return {"source": "profiles/%s (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, own pass)" % os.path.basename(files[-1]),
             "source_commit": d.get("_commit", "before round 4 (three-term kernels of round 3)"), "terms": d.get("_terms", 3),

@@ -12,8 +12,9 @@
  *                          :360-361): residual add + LayerNorm in one pass
  *
  *   tf_linear_split_f32    nn.Linear (+ ReLU) of the encoder / decoder (ms_deform_attn.py:64-88,
- *                          deformable_transformer.py:282-297) as a bf16 split product on the matrix cores (six terms:
- *                          fp32-accurate, the default; three terms: the fast mode -- THE SPLIT PRODUCT below)
+ *                          deformable_transformer.py:282-297) as a split product on the matrix cores (fp16 pieces, three terms:
+ *                          fp32-class, what trackformer_amd uses by default; six bf16 terms; three bf16 terms: the fast mode --
+ *                          THE SPLIT PRODUCT below)
  *   tf_linear_packed_f32   the same product with the weight packed once in fragment order (+ tf_linear_pack_weight_f32)
  *   tf_ffn_fused_f32       linear1 -> ReLU -> linear2 -> + residual -> LayerNorm of a transformer layer in one launch
  *   tf_linear_res_ln_f32   linear (256 -> 256) -> + residual -> LayerNorm in one launch (output projection + norm1)

@@ -45,8 +45,8 @@ int main(int argc, char **argv)
 {
     const int M = argc > 1 ? atoi(argv[1]) : 22223, F = argc > 2 ? atoi(argv[2]) : 1024, D = argc > 4 ? atoi(argv[4]) : 256;
     if (argc > 3) tf_msda_set_option("ffn_ti", atoi(argv[3]));
-    const int Tenv = getenv("TF_SPLIT_TERMS") ? atoi(getenv("TF_SPLIT_TERMS")) : 6;
-    const int T = Tenv == 3 ? 3 : Tenv == 16 ? 16 : 6;   // the split product (include/tf_fused.h; default six bf16 terms)
+    const int Tenv = getenv("TF_SPLIT_TERMS") ? atoi(getenv("TF_SPLIT_TERMS")) : 16;
+    const int T = Tenv == 3 ? 3 : Tenv == 6 ? 6 : 16;   // the split product (include/tf_fused.h; default: fp16 pieces)
     printf("split product: %d terms\n", T);
     const int guard = 128;   // rows behind M that nothing may write
     std::mt19937 rng(11);
