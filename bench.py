@@ -439,7 +439,7 @@ def measure_roofline_backward(device, launches=10):
     ms = time_launches(lambda: msda.ms_deform_attn_backward(value, shapes, loc, attn, grad_out, 64), launches)
     alg = algorithmic_bytes(N=2, S=S, M=8, D=32, L=4, Lq=S, P=4, backward=True)
     gbs = alg / ms / 1e6
-    return {"bound": "hbm", "kernel": "msda_bwd_f32_sorted (encoder call of a bs-2 training step, N=2, Lq=S=22223)",
+    return {"bound": "hbm", "kernel": "msda_bwd_f32_sorted2 (encoder call of a bs-2 training step, N=2, Lq=S=22223)",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": None, "algorithmic_bytes": alg, "avg_launch_us": round(ms * 1e3, 2), "launches": launches,
             "pattern": "local (reference point + N(0, 2 px))"}
