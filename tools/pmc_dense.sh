@@ -7,7 +7,7 @@
 # (GRBM_GUI_ACTIVE / duration).
 set -u
 TAG=$1
-TERMS=${2:-6}
+TERMS=${2:-16}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -36,7 +36,7 @@ agg = collections.OrderedDict()
 for path in open(sys.argv[1]).read().split():
     for r in csv.DictReader(open(path)):
         n = r.get("Kernel_Name", "")
-        if not any(k in n for k in ("split_", "ffn_fused", "linear_res_ln", "stem_conv", "conv_splitk")):
+        if not any(k in n for k in ("split_", "stream_", "ffn_fused", "linear_res_ln", "stem_conv", "conv_splitk")):
             continue
         n = re.sub(r"\(anonymous namespace\)::", "", n)
         n = re.sub(r"\(.*$", "", n).replace("void ", "")

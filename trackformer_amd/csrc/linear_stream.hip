@@ -111,6 +111,17 @@ pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, const f
 //   split-K blockIdx.y walks `kslices` slices and writes partial sums to Y + z M N (host: no bias / ReLU / residual then; a
 //           second launch adds the pieces in a fixed order)
 //   epilogue  + bias, + residual (R may alias Y), ReLU; buffer stores (rows >= M / columns >= N fall outside the resource)
+// Measured and NOT kept (round 4, fp16 pieces; profiles/r04_pmc_dense_fp16.txt has the counters that prompted them: 7 vector
+// instructions per MFMA in the convolution form, waves issuing 37 % / issue-stalled 30 % / parked 33 % of their cycles):
+//   * the weight fragments three slices ahead in a ring of four register stages for the convolution form (one or two blocks per
+//     CU, each walking a long K): 1363 against 1326 us of backbone convolutions per frame, every 3 x 3 layer 1-2 us slower -- the
+//     weight latency is not what those launches wait for (profiles/r04_stream_conv_weight_ring.txt);
+//   * the split of slice s + 1 placed in front of slice s's MFMAs with sched_group_barrier asking for one MFMA, then a few
+//     vector instructions, and so on: the compiler interleaves the LDS reads but leaves most of the split behind the MFMAs;
+//     1340 us per frame, the linears 3-8 % slower (profiles/r04_stream_interleave.txt).
+// What the counters point at instead is the split itself: in the convolution form every input pixel is cut into pieces once per
+// tap and column block (up to 18 times); the producing kernel's epilogue could write the pieces once (4 bytes per element, like
+// fp32) and this kernel would copy them to LDS.  DESIGN.md section 9.
 // Accumulation order per output element: k ascending, per k-step smallest terms first -- the order of linear_split.hip, so
 // the results are bit-identical to tf_linear_split_f32 / tf_conv3x3_split_f32 with the same number of terms.
 struct StreamConv {
