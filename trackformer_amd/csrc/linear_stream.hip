@@ -119,9 +119,12 @@ pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, const f
 //   * the split of slice s + 1 placed in front of slice s's MFMAs with sched_group_barrier asking for one MFMA, then a few
 //     vector instructions, and so on: the compiler interleaves the LDS reads but leaves most of the split behind the MFMAs;
 //     1340 us per frame, the linears 3-8 % slower (profiles/r04_stream_interleave.txt).
-// What the counters point at instead is the split itself: in the convolution form every input pixel is cut into pieces once per
-// tap and column block (up to 18 times); the producing kernel's epilogue could write the pieces once (4 bytes per element, like
-// fp32) and this kernel would copy them to LDS.  DESIGN.md section 9.
+// The obvious suspect after that, the split itself (every input pixel of a convolution is cut into pieces once per tap and column
+// block), was then ABLATED before anything was built on it (raw bits to LDS instead of the pieces: wrong results, right amount of
+// loads / LDS traffic / MFMAs; profiles/r04_stream_conv_ablate_split.txt): the 3 x 3 convolutions go from 33-34 us to 28-32, the
+// backbone's convolutions from 1350 to 1272 us per frame, the 1024 -> 256 linear from 46.8 to 42.4 us -- the split is 6-17 % of
+// these launches, not the two thirds its share of the instruction count suggests.  What a slice of this kernel waits for is not
+// instruction issue; the next step is a phase trace (s_memrealtime stamps per slice, as for the encoder kernel), DESIGN.md section 9.
 // Accumulation order per output element: k ascending, per k-step smallest terms first -- the order of linear_split.hip, so
 // the results are bit-identical to tf_linear_split_f32 / tf_conv3x3_split_f32 with the same number of terms.
 struct StreamConv {
