@@ -131,6 +131,25 @@ struct StreamConv {
     int nimg, hin, win, cin, hout, wout, ks, pad, stride;
 };
 
+// PHASE TRACE (tools/build_stream_trace.py builds a separate library with -DTF_STREAM_TRACE; libtf_msda.so never contains it):
+// wave 0 of the first kTraceBlocks blocks stamps the shader clock (s_memtime) at six points of each of its first kTraceSlices
+// K-slices into a buffer the harness hands over with tf_debug_stream_trace_buffer (tools/stream_trace.py reads it):
+//   0 slice start (behind the barrier of the previous one)   1 weight loads issued   2 LDS fragments of both k-steps read
+//   3 MFMAs issued   4 next slice split and written to LDS, its global loads issued   5 barrier passed
+#ifdef TF_STREAM_TRACE
+constexpr int kTraceBlocks = 64, kTraceSlices = 40, kTracePoints = 6;
+__device__ unsigned long long *g_stream_trace = nullptr;
+#define TF_TRACE(slot, pt)                                                                                         \
+    do {                                                                                                           \
+        if (g_stream_trace && threadIdx.x == 0 && blockIdx.x < kTraceBlocks && blockIdx.y == 0 && (slot) < kTraceSlices) \
+            g_stream_trace[((size_t)blockIdx.x * kTraceSlices + (slot)) * kTracePoints + (pt)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define TF_TRACE(slot, pt) \
+    do {                   \
+    } while (0)
+#endif
+
 template <int NB, int TJ>
 struct WFrags {
     u32x4 v[TJ][2][NB];   // [column tile][k-step of the slice][weight piece]
@@ -271,9 +290,11 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
     // one K-slice; PAR = (s - sbeg) & 1 as a compile-time constant so that the register double buffers need no copies
     auto slice = [&](int s, auto par, const WFrags<NB, TJ> &cur, WFrags<NB, TJ> &nxt) {
         constexpr int PAR = decltype(par)::value;
+        TF_TRACE(s - sbeg, 0);
         load_w(s + 1, nxt);   // in flight during the MFMAs below
         __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them to the end of the
                                              // slice to shorten live ranges, and the next slice starts by waiting for L2
+        TF_TRACE(s - sbeg, 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int koff = kk * 16 + (lane >> 5) * 8;
@@ -291,12 +312,22 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
             // term-major passes over the tiles: consecutive MFMAs never share an accumulator; per accumulator the order is
             // smallest terms first, as in linear_split.hip
             mfma_tiles<SP, TI, TJ>(acc, af, bfr);
+#ifdef TF_STREAM_TRACE
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk == 0) TF_TRACE(s - sbeg, 2);   // (the first k-step's MFMAs are issued: its LDS reads have returned)
+#endif
         }
+        TF_TRACE(s - sbeg, 3);
         // slice s + 1 -> the LDS buffer nobody reads in this iteration (its readers passed the previous barrier),
         // then its registers take slice s + 3
         store_x(xr[PAR ^ 1], PAR ^ 1);
         load_x(xr[PAR ^ 1]);
+#ifdef TF_STREAM_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        TF_TRACE(s - sbeg, 4);
         __syncthreads();
+        TF_TRACE(s - sbeg, 5);
     };
     for (int s = sbeg; s < send; s += 2) {   // an even number of slices (host)
         slice(s, std::integral_constant<int, 0>{}, w0, w1);
@@ -489,6 +520,17 @@ int stream_dispatch_scheme(int sp, const StreamCall &c, hipStream_t s)
     default: return stream_dispatch<16, CONV>(c, s);
     }
 }
+
+#ifdef TF_STREAM_TRACE
+extern "C" int tf_debug_stream_trace_buffer(void *device_buffer, int *blocks, int *slices, int *points)
+{
+    unsigned long long *p = static_cast<unsigned long long *>(device_buffer);
+    if (blocks) *blocks = kTraceBlocks;
+    if (slices) *slices = kTraceSlices;
+    if (points) *points = kTracePoints;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stream_trace), &p, sizeof(p)) == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+#endif
 
 extern "C" int64_t tf_linear_packed_bytes(int K, int N, int terms)
 {
