@@ -119,6 +119,8 @@ pack_weight_kernel(const float *__restrict__ W, u32x4 *__restrict__ out, const f
 //   * the split of slice s + 1 placed in front of slice s's MFMAs with sched_group_barrier asking for one MFMA, then a few
 //     vector instructions, and so on: the compiler interleaves the LDS reads but leaves most of the split behind the MFMAs;
 //     1340 us per frame, the linears 3-8 % slower (profiles/r04_stream_interleave.txt).
+//   * 128-row blocks for every convolution (more independent accumulators per wave; TF_LINEAR_STREAM_TI=4): 1570 against 1309 us
+//     per frame -- half the blocks, and the split-K policy does not make up for it (profiles/r04_stream_conv_row_tiles.txt).
 // The obvious suspect after that, the split itself (every input pixel of a convolution is cut into pieces once per tap and column
 // block), was then ABLATED before anything was built on it (raw bits to LDS instead of the pieces: wrong results, right amount of
 // loads / LDS traffic / MFMAs; profiles/r04_stream_conv_ablate_split.txt): the 3 x 3 convolutions go from 33-34 us to 28-32, the
