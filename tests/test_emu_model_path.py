@@ -96,6 +96,38 @@ def test_tracker_sequence_ids_on_the_emulator_with_every_opt_in_route():
     assert calls.get("tf_conv_packed_f32", 0) >= (17 + 3) * 6 and calls.get("tf_box_refine_f32") == 36
 
 
+def test_mask_head_through_the_split_product_convolutions():
+    """MaskHeadSmallConv's GPU inference route (detr_segmentation.py: lay2 .. lay5 through fused.conv3x3 on channels_last
+    activations -- lay2's 264 input channels padded to 288 --, their GroupNorms through tf_groupnorm_nhwc_f32) against the same
+    module's PyTorch path (reference: models/detr_segmentation.py:105-157), hidden 256 + 8 heads, three queries."""
+    from trackformer_amd import detr_segmentation as ds
+    torch.manual_seed(0)
+    head = ds.MaskHeadSmallConv(264, [1024, 512, 256], 256).eval()
+    for m in head.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            torch.nn.init.normal_(m.bias, 0, 0.1)
+        if isinstance(m, torch.nn.GroupNorm):
+            torch.nn.init.normal_(m.weight, 1, 0.2)
+            torch.nn.init.normal_(m.bias, 0, 0.2)
+    B, Q, h, w = 1, 3, 5, 7
+    x, bm = torch.randn(B, 256, h, w), torch.rand(B, Q, 8, h, w)
+    fpns = [torch.randn(B, 1024, 2 * h, 2 * w) * 0.3, torch.randn(B, 512, 4 * h, 4 * w) * 0.3, torch.randn(B, 256, 8 * h, 8 * w) * 0.3]
+    with torch.no_grad():
+        ref = head(x, bm, fpns)
+        with gpu_path_on_emulator() as lib:
+            got = head(x, bm, fpns)
+            calls = dict(lib.calls)
+            prev = ds.set_mask_head_split(False)
+            try:
+                off = head(x, bm, fpns)
+            finally:
+                ds.set_mask_head_split(prev)
+    n_conv = sum(calls.get(k, 0) for k in ("tf_conv3x3_split_f32", "tf_conv3x3_splitk_f32", "tf_conv_packed_f32"))
+    assert n_conv == 4 and calls.get("tf_groupnorm_nhwc_f32") == 4, calls
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(off, ref)     # switched off: the library path
+
+
 def test_training_step_through_the_emulated_kernels():
     """One training step (padded two-image batch, previous-frame pass, track-query augmentation, SetCriterion, backward)
     with MSDeformAttnFunction running the HIP kernels under the emulator -- forward msda_fwd_f32_pquad / _direct, backward

@@ -20,6 +20,7 @@ Differences, all result-preserving:
 """
 import contextlib
 import io
+import os
 import threading
 from collections import defaultdict
 from typing import List, Optional
@@ -146,6 +147,17 @@ class DeformableDETRSegmTracking(DETRSegmBase, DETRTrackingBase, DeformableDETR)
         DETRSegmBase.__init__(self, **mask_kwargs)
 
 
+_mask_head_split = os.environ.get("TF_MASK_HEAD_SPLIT", "1") != "0"
+
+
+def set_mask_head_split(on):
+    """The mask head's 3 x 3 convolutions through the split-product kernels in the GPU inference path (process-wide); returns the
+    previous setting."""
+    global _mask_head_split
+    prev, _mask_head_split = _mask_head_split, bool(on)
+    return prev
+
+
 class MaskHeadSmallConv(nn.Module):
     """Small FPN-style convolutional head with GroupNorm: [image features | attention maps] at stride
     16 (deformable; 32 for plain DETR) -> one mask logit map per query at the stride of fpns[2]."""
@@ -183,11 +195,51 @@ class MaskHeadSmallConv(nn.Module):
             return fpn + x
         return (x.view(fpn.size(0), num_queries, *x.shape[1:]) + fpn[:, None]).flatten(0, 1)
 
+    # ---- the GPU inference route (round 4; TF_MASK_HEAD_SPLIT=0 / set_mask_head_split(False) switches it off): lay2 .. lay5 --
+    # 97 % of the head's flops, ~17 of the 20.6 ms of a cfg-5 step in the library convolutions -- through the split-product
+    # convolution kernels (fused.conv3x3: the fp16 product by default) on channels_last activations, their GroupNorms through
+    # tf_groupnorm_nhwc_f32.  lay2's 264 input channels are padded to 288 with zeros (the kernels take Cin % 32 == 0); lay1
+    # (8 attention channels per query after the decomposition below) and out_lay (16 -> 1) stay in the library.  A layer the
+    # kernels decline (tensor beyond their 3 GiB offsets: more than ~310 queries at 200 x 334) takes the library path.
+    @staticmethod
+    def _taps(conv, cin_pad):
+        """[Cout, 9 * cin_pad] tap-major weight of a 3 x 3 convolution (zero columns for the padded input channels), cached on the
+        module with the weight's version."""
+        hit = getattr(conv, "_tf_taps", None)
+        if hit is None or hit[0] != (conv.weight._version, cin_pad) or hit[1].device != conv.weight.device:
+            w = conv.weight.detach()
+            cout, cin = w.shape[:2]
+            taps = w.new_zeros(cout, 3, 3, cin_pad)
+            taps[..., :cin] = w.permute(0, 2, 3, 1)
+            hit = ((conv.weight._version, cin_pad), taps.reshape(cout, 9 * cin_pad).contiguous())
+            conv._tf_taps = hit
+        return hit[1]
+
+    def _conv_gn_relu(self, x, conv, gn):
+        """relu(gn(conv(x))) for a channels_last x [N, Cin(_pad), H, W]; -> channels_last [N, Cout, H, W]."""
+        from . import fused
+        cin_pad = x.shape[1]
+        y = fused.conv3x3(x, self._taps(conv, cin_pad), conv.bias, False, 1)
+        if y is None:     # declined (size / alignment): the library convolution on the unpadded channels
+            y = F.conv2d(x[:, :conv.in_channels], conv.weight, conv.bias, padding=1).contiguous(memory_format=torch.channels_last)
+        n, c, h, w = y.shape
+        z = fused.groupnorm_nhwc(y.permute(0, 2, 3, 1).reshape(n * h * w, c), n, gn)
+        if z is None:
+            return F.relu(gn(y))
+        return z.relu_().view(n, h, w, c).permute(0, 3, 1, 2)
+
+    def _split_route(self, x):
+        from . import fused
+        return (_mask_head_split and fused.split_linear_enabled() and x.is_cuda and x.dtype == torch.float32
+                and not torch.is_grad_enabled() and self.lay2.in_channels <= 288 and self.lay3.in_channels % 32 == 0
+                and self.lay4.in_channels % 32 == 0 and self.lay5.in_channels % 32 == 0)
+
     def forward(self, x: Tensor, bbox_mask: Tensor, fpns: List[Tensor]):
         """x [B,C,h,w] projected image features, bbox_mask [B,Q,heads,h,w], fpns 3 x [B,C_k,H_k,W_k]
         (coarse to fine) -> [B*Q, 1, H_2, W_2]."""
         num_queries = bbox_mask.shape[1]
         c_img = x.shape[1]
+        split = self._split_route(x)
         # lay1 over cat([x repeated per query, attention maps]) == lay1_img(x) + lay1_att(maps):
         # the image part (and the bias) once per image, the attention part per query
         w = self.lay1.weight
@@ -195,6 +247,17 @@ class MaskHeadSmallConv(nn.Module):
         y_att = F.conv2d(bbox_mask.flatten(0, 1), w[:, c_img:], None, padding=1)     # [B*Q, dim, h, w]
         x = (y_att.view(x.shape[0], num_queries, *y_att.shape[1:]) + y_img[:, None]).flatten(0, 1)
         x = F.relu(self.gn1(x))
+        if split:
+            n, c, h, wd = x.shape
+            cin_pad = -(-c // 32) * 32
+            xp = x.new_zeros(n, h, wd, cin_pad)                                      # channels innermost, zero tail
+            xp[..., :c] = x.permute(0, 2, 3, 1)
+            x = self._conv_gn_relu(xp.permute(0, 3, 1, 2), self.lay2, self.gn2)
+            for adapter, conv, gn, fpn in ((self.adapter1, self.lay3, self.gn3, fpns[0]), (self.adapter2, self.lay4, self.gn4, fpns[1]),
+                                           (self.adapter3, self.lay5, self.gn5, fpns[2])):
+                x = self._merge(x, adapter(fpn).contiguous(memory_format=torch.channels_last), num_queries)
+                x = self._conv_gn_relu(x.contiguous(memory_format=torch.channels_last), conv, gn)
+            return self.out_lay(x)
         x = F.relu(self.gn2(self.lay2(x)))
 
         x = self._merge(x, self.adapter1(fpns[0]), num_queries)
