@@ -148,6 +148,7 @@ class DeformableDETRSegmTracking(DETRSegmBase, DETRTrackingBase, DeformableDETR)
 
 
 _mask_head_split = os.environ.get("TF_MASK_HEAD_SPLIT", "1") != "0"
+_SPLIT_QUERY_CHUNK = 128
 
 
 def set_mask_head_split(on):
@@ -240,6 +241,11 @@ class MaskHeadSmallConv(nn.Module):
         num_queries = bbox_mask.shape[1]
         c_img = x.shape[1]
         split = self._split_route(x)
+        if split and x.shape[0] == 1 and num_queries > _SPLIT_QUERY_CHUNK:
+            # queries are independent: chunks keep every activation of the route below the kernels' 3 GiB offsets (the finest
+            # level is 8.6 MB per query and channel group at 800 x 1333) and bound the head's memory
+            return torch.cat([self.forward(x, bbox_mask[:, q0:q0 + _SPLIT_QUERY_CHUNK], fpns)
+                              for q0 in range(0, num_queries, _SPLIT_QUERY_CHUNK)], 0)
         # lay1 over cat([x repeated per query, attention maps]) == lay1_img(x) + lay1_att(maps):
         # the image part (and the bias) once per image, the attention part per query
         w = self.lay1.weight

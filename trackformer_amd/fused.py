@@ -641,6 +641,9 @@ def conv3x3(x, w_taps, bias, relu, stride):
                                                     n, h, w, cin, cout, ks, stride, 1 if relu else 0, _split_terms, _stream(x.device))
             _cabi.check(rc, "tf_conv_packed_f32")
             return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
+    # the block kernels address input, output and weight pieces through buffer resources: every byte offset below 3 GiB
+    if (n * h * w * cin * 4 >= 0xC0000000 or (n * ho * wo + 256) * cout * 4 >= 0xC0000000 or cout * ks * ks * cin * 2 >= 0xC0000000):
+        return None
     hi, mid, lo, wsc = _split_weight(w_taps)
     if (x.data_ptr() | hi.data_ptr() | mid.data_ptr() | _ptr(lo)) & 15:
         return None
