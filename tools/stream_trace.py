@@ -4,8 +4,10 @@ tools/build_stream_trace.py): where a K-slice of a block spends its time.
 
     python tools/build_stream_trace.py && python tools/stream_trace.py      (on the GPU box)
 
-Wave 0 of the first 64 blocks stamps s_memtime at six points of each of its first 40 slices; printed: the median over blocks and
-slices (the first two and the last slice of a block left out) of each phase, in clock ticks and as a share of the slice, for a
+Wave 0 of the first 64 blocks stamps s_memtime at three points of each slice -- where the LDS counter is drained anyway -- and keeps
+the stamps of slices 4 .. 7 in registers until the block ends (version 2; version 1 stamped six points straight to memory and doubled
+the launch time: profiles/r04_stream_phase_trace.txt); printed: the median over blocks and slices of each phase, in clock ticks and as
+a share of the slice, for a
 3 x 3 convolution of layer2 (128 -> 128 at 100 x 167), one of layer1 (64 -> 64 at 200 x 334) and the 1024 -> 256 linear at 22 223
 rows; beside it the launch's duration by HIP events, which calibrates the tick."""
 import ctypes
@@ -21,8 +23,8 @@ import torch  # noqa: E402
 
 from trackformer_amd import _cabi, fused  # noqa: E402
 
-PHASES = ["weight loads issued", "LDS fragments read, first k-step's MFMAs issued", "second k-step's MFMAs issued",
-          "next slice: split, LDS writes, global loads issued", "barrier"]
+PHASES = ["matrix phase: next weights requested, LDS fragments read, MFMAs issued", "staging: next slice split, LDS writes, global loads issued",
+          "barrier"]
 
 
 def trace(name, fn, iters=5):
@@ -44,21 +46,21 @@ def trace(name, fn, iters=5):
     lib.tf_debug_stream_trace_buffer(None, None, None, None)
     us = e0.elapsed_time(e1) * 1e3 / iters
     t = buf.cpu().numpy().reshape(b.value, s.value, p.value).astype(np.float64)
-    ok = (t > 0).all(axis=2)                          # slices this block ran
-    n_sl = ok.sum(axis=1)
-    blocks = np.nonzero(n_sl >= 4)[0]
+    blocks = np.nonzero((t > 0).all(axis=(1, 2)))[0]  # blocks that ran all traced slices
+    if len(blocks) == 0:
+        print("== %s: %.1f us per launch; no block ran the traced slices (K too short)" % (name, us))
+        return us, None
+    # slice sl: points 0, 1, 2 and the start of slice sl + 1 (point 0 of the next row) -> three phases for all but the last traced slice
     d = []
     for bl in blocks:
-        for sl in range(2, int(n_sl[bl]) - 1):
-            d.append(np.diff(t[bl, sl]))
+        for sl in range(s.value - 1):
+            d.append([t[bl, sl, 1] - t[bl, sl, 0], t[bl, sl, 2] - t[bl, sl, 1], t[bl, sl + 1, 0] - t[bl, sl, 2]])
     d = np.array(d)
-    total = np.array([t[bl, int(n_sl[bl]) - 1, -1] - t[bl, 0, 0] for bl in blocks])
-    print("== %s: %.1f us per launch (events, incl. launch gaps), %d traced blocks, %d slices each, first stamp to last %.0f ticks (median)"
-          % (name, us, len(blocks), int(np.median(n_sl[blocks])), float(np.median(total))))
     med = np.median(d, axis=0)
+    print("== %s: %.1f us per launch (events, incl. launch gaps), %d traced blocks" % (name, us, len(blocks)))
     for ph, m in zip(PHASES, med):
-        print("   %-55s %8.0f ticks  %5.1f %%" % (ph, m, 100 * m / med.sum()))
-    print("   %-55s %8.0f ticks" % ("slice", med.sum()))
+        print("   %-75s %8.0f ticks  %5.1f %%" % (ph, m, 100 * m / med.sum()))
+    print("   %-75s %8.0f ticks" % ("slice", med.sum()))
     return us, med
 
 

@@ -14,7 +14,8 @@
 // never leaves the CU.
 //
 //   * Same arithmetic as the separate kernels (linear_split.hip / linear_stream.hip): every product is the bf16 split
-//     product of split_product.h (NP = 3 pieces / six terms: fp32-accurate, the default; NP = 2 / three terms: the fast mode)
+//     product of split_product.h (scheme SP: 16 = fp16 pieces, three terms, fp32-class: what trackformer_amd uses by default; 3 = six
+//     bf16 terms; 2 = three bf16 terms, the fast mode)
 //     on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, per accumulator smallest terms first, k ascending (the numbers in
 //     this header are for NP = 2); the intermediate is rounded to fp32 (bias, ReLU) and split again,
 //     exactly what linear2 does with linear1's stored output.  Without the LayerNorm the result is bit-identical to

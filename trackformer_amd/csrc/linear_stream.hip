@@ -1,7 +1,7 @@
 // trackformer_amd/csrc/linear_stream.hip
 //
 // tf_linear_packed_f32 / tf_linear_pack_weight_f32 (include/tf_fused.h): the same arithmetic as tf_linear_split_f32
-// (linear_split.hip: Y = X . W^T + bias as a bf16 split product on v_mfma_f32_32x32x16_bf16, six terms by default, three
+// (linear_split.hip: Y = X . W^T + bias as a split product on v_mfma_f32_32x32x16_{f16,bf16} -- fp16 pieces, six bf16 terms or three
 // in the fast mode -- split_product.h; the description below counts for the three-term form; reference
 // modules: models/ops/modules/ms_deform_attn.py:64-88, models/deformable_transformer.py:282-297), restructured around
 // what profiles/r02_split_gemm_mfma_*.json showed: the first kernel keeps the matrix pipes 23 % busy because both
@@ -133,19 +133,31 @@ struct StreamConv {
     int nimg, hin, win, cin, hout, wout, ks, pad, stride;
 };
 
-// PHASE TRACE (tools/build_stream_trace.py builds a separate library with -DTF_STREAM_TRACE; libtf_msda.so never contains it):
-// wave 0 of the first kTraceBlocks blocks stamps the shader clock (s_memtime) at six points of each of its first kTraceSlices
-// K-slices into a buffer the harness hands over with tf_debug_stream_trace_buffer (tools/stream_trace.py reads it):
-//   0 slice start (behind the barrier of the previous one)   1 weight loads issued   2 LDS fragments of both k-steps read
-//   3 MFMAs issued   4 next slice split and written to LDS, its global loads issued   5 barrier passed
+// PHASE TRACE (tools/build_stream_trace.py builds a separate library with -DTF_STREAM_TRACE; libtf_msda.so never contains it).
+// Version 2.  The first version (six stamps per slice, each written to memory at once: profiles/r04_stream_phase_trace.txt) doubled
+// the launch time -- reading s_memtime waits for lgkmcnt(0), i.e. for the LDS reads in flight, and every stamp was a store with
+// its address arithmetic.  Here wave 0 of the first kTraceBlocks blocks stamps THREE points per slice, each at a place where the
+// LDS counter is drained anyway, keeps the stamps of slices kTraceFirst .. kTraceFirst + 3 in scalar registers and writes them once,
+// behind the epilogue:
+//   0 slice start (the barrier of the previous slice passed)   1 this slice's MFMAs issued (weight loads of the next slice issued
+//   before them, LDS fragments read)   2 next slice split, written to LDS, its global loads issued: in front of the barrier
+// so that 0 -> 1 is the matrix phase, 1 -> 2 the staging phase and 2 -> next 0 the wait at the barrier.
 #ifdef TF_STREAM_TRACE
-constexpr int kTraceBlocks = 64, kTraceSlices = 40, kTracePoints = 6;
+constexpr int kTraceBlocks = 64, kTraceSlices = 4, kTracePoints = 3, kTraceFirst = 4;
 __device__ unsigned long long *g_stream_trace = nullptr;
-#define TF_TRACE(slot, pt)                                                                                         \
-    do {                                                                                                           \
-        if (g_stream_trace && threadIdx.x == 0 && blockIdx.x < kTraceBlocks && blockIdx.y == 0 && (slot) < kTraceSlices) \
-            g_stream_trace[((size_t)blockIdx.x * kTraceSlices + (slot)) * kTracePoints + (pt)] = __builtin_readcyclecounter(); \
-    } while (0)
+struct TraceRegs {
+    unsigned long long t[kTraceSlices][kTracePoints];
+};
+template <int PT>
+__device__ __forceinline__ void trace_stamp(TraceRegs &r, int slot)
+{
+    const unsigned long long c = __builtin_readcyclecounter();
+    if (slot == kTraceFirst) r.t[0][PT] = c;
+    else if (slot == kTraceFirst + 1) r.t[1][PT] = c;
+    else if (slot == kTraceFirst + 2) r.t[2][PT] = c;
+    else if (slot == kTraceFirst + 3) r.t[3][PT] = c;
+}
+#define TF_TRACE(slot, pt) trace_stamp<pt>(trace_regs, (slot))
 #else
 #define TF_TRACE(slot, pt) \
     do {                   \
@@ -277,6 +289,9 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
                 for (int p = 0; p < NB; ++p) w.v[j][kk][p] = wp[j][((q0 + kk) * NB + p) * 64];
     };
 
+#ifdef TF_STREAM_TRACE
+    TraceRegs trace_regs = {};
+#endif
     f32x4 xr[2][XV];   // slice s + 1 lives in xr[(s + 1) & 1], slice s + 2 in the other one   (parity relative to sbeg)
     WFrags<NB, TJ> w0, w1;
     {
@@ -296,7 +311,6 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
         load_w(s + 1, nxt);   // in flight during the MFMAs below
         __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them to the end of the
                                              // slice to shorten live ranges, and the next slice starts by waiting for L2
-        TF_TRACE(s - sbeg, 1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int koff = kk * 16 + (lane >> 5) * 8;
@@ -314,12 +328,11 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
             // term-major passes over the tiles: consecutive MFMAs never share an accumulator; per accumulator the order is
             // smallest terms first, as in linear_split.hip
             mfma_tiles<SP, TI, TJ>(acc, af, bfr);
-#ifdef TF_STREAM_TRACE
-            __builtin_amdgcn_sched_barrier(0);
-            if (kk == 0) TF_TRACE(s - sbeg, 2);   // (the first k-step's MFMAs are issued: its LDS reads have returned)
-#endif
         }
-        TF_TRACE(s - sbeg, 3);
+#ifdef TF_STREAM_TRACE
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        TF_TRACE(s - sbeg, 1);
         // slice s + 1 -> the LDS buffer nobody reads in this iteration (its readers passed the previous barrier),
         // then its registers take slice s + 3
         store_x(xr[PAR ^ 1], PAR ^ 1);
@@ -327,9 +340,8 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
 #ifdef TF_STREAM_TRACE
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        TF_TRACE(s - sbeg, 4);
+        TF_TRACE(s - sbeg, 2);
         __syncthreads();
-        TF_TRACE(s - sbeg, 5);
     };
     for (int s = sbeg; s < send; s += 2) {   // an even number of slices (host)
         slice(s, std::integral_constant<int, 0>{}, w0, w1);
@@ -368,6 +380,14 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
             }
         }
     }
+#ifdef TF_STREAM_TRACE
+    if (g_stream_trace && threadIdx.x == 0 && blockIdx.x < kTraceBlocks && blockIdx.y == 0)
+#pragma unroll
+        for (int sl = 0; sl < kTraceSlices; ++sl)
+#pragma unroll
+            for (int pt = 0; pt < kTracePoints; ++pt)
+                g_stream_trace[((size_t)blockIdx.x * kTraceSlices + sl) * kTracePoints + pt] = trace_regs.t[sl][pt];
+#endif
 }
 
 // ---- split-K second pass: y = act(sum_z partial[z] + bias + residual), the partials added in the order z = 0, 1, ... (a fixed

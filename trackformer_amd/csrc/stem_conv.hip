@@ -3,7 +3,7 @@
 // tf_stem_conv7x7_f32 (include/tf_fused.h): the backbone's first convolution -- 7 x 7, stride 2, padding 3, 3 -> 64 channels
 // (reference: models/backbone.py:93-104 -> torchvision resnet50.conv1, with the FrozenBatchNorm2d scale of :45-55 folded into
 // the weight by the caller) -- as an implicit GEMM on the matrix cores with the same bf16 split product as the linears
-// (split_product.h: six terms by default, three in the fast mode; fp32 accumulation).  With it and the bottleneck routes of
+// (split_product.h: fp16 pieces, six bf16 terms, or three in the fast mode; fp32 accumulation).  With it and the bottleneck routes of
 // linear_split.hip no convolution of the backbone is left in MIOpen.
 //
 //   * GEMM view: M = output pixels, N = 64, K = 3 x 7 x 8 = 168 (-> 176 = 11 k-steps of 16): k = (c * 7 + ky) * 8 + kx with the
