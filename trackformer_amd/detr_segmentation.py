@@ -213,6 +213,9 @@ class MaskHeadSmallConv(nn.Module):
             taps = w.new_zeros(cout, 3, 3, cin_pad)
             taps[..., :cin] = w.permute(0, 2, 3, 1)
             hit = ((conv.weight._version, cin_pad), taps.reshape(cout, 9 * cin_pad).contiguous())
+            if w.is_cuda:
+                from . import fused
+                fused._publish_barrier(w.device)   # built on this stream, read by every sequence's stream from now on
             conv._tf_taps = hit
         return hit[1]
 
