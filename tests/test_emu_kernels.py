@@ -328,6 +328,45 @@ def test_six_term_product_is_fp32_accurate():
     assert err[6] < 2 * sgemm and err[3] > 8 * err[6]
 
 
+@pytest.mark.parametrize("xs,ws", [(1.0, 0.05), (1e-3, 0.05), (300.0, 0.05), (1.0, 1e-4), (1.0, 30.0)],
+                         ids=["x1", "x1e-3", "x300", "w1e-4", "w30"])
+def test_fp16_product_is_fp32_class_whatever_the_magnitudes(xs, ws):
+    """The claim behind the DEFAULT (include/tf_fused.h, terms = 16): two fp16 pieces per operand with the lower activation piece
+    stored times 2^11 and the weights scaled per output channel are fp32-class over the magnitudes a network produces -- small and
+    large activations, small and large weights, output channels whose scales differ by 1e5, rows of activations that differ by 1e4
+    -- where plain fp16 pieces would fall into the subnormals (tools/experiments/f16_split.py).  Error against float64,
+    normalised per output by sum |x||w|: within a factor of two of numpy's sgemm, through the packed kernel and the piece-tensor
+    kernel (which must agree bit for bit)."""
+    rng = np.random.default_rng(11)
+    M, K, N = 150, 256, 192
+    x = (rng.standard_normal((M, K)) * xs).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * ws).astype(np.float32)
+    w[::7] *= 1e-3          # channels of very different scale (FrozenBN folded into a convolution)
+    w[3::11] *= 100.0
+    x[::5] *= 1e-2          # rows of very different scale
+    x[2::9] *= 1e2
+    ref = x.astype(np.float64) @ w.astype(np.float64).T
+    scale = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T
+    prev = emu_lib.set_terms(16)
+    try:
+        packed = emu_lib.linear_packed(x, w)
+        pieces = emu_lib.linear_split(x, w)
+    finally:
+        emu_lib.set_terms(prev)
+    assert np.array_equal(packed, pieces)
+    err = float((np.abs(packed - ref) / scale).max())
+    sgemm = float((np.abs((x @ w.T).astype(np.float64) - ref) / scale).max())
+    # the scheme's floor: an activation below 2^-10 is represented to an ABSOLUTE 2^-32 (split_product.h), i.e. an output carries
+    # up to 2^-32 sum_k |w_nk| that does not shrink with the row -- harmless next to O(1) rows, visible relative to a row of 1e-5s
+    floor = 2.0 ** -31 * np.abs(w).astype(np.float64).sum(1)[None, :]
+    excess = float(((np.abs(packed - ref) - floor) / scale).max())
+    print("x ~ %g, w ~ %g: max |err| / sum |x||w|: fp16 product %.2e (beyond the absolute floor: %.2e), numpy sgemm %.2e" % (
+        xs, ws, err, excess, sgemm))
+    assert np.isfinite(packed).all() and excess < 2 * sgemm
+    if xs >= 1.0:
+        assert err < 2 * sgemm      # every |x| of these cases is above 2^-10 up to the rows scaled down by 1e-2 ... still above it
+
+
 @pytest.mark.parametrize("Lq,Lk,H,D,masked", [(100, 100, 8, 32, False), (57, 130, 8, 36, True), (33, 33, 4, 16, True), (40, 40, 2, 64, False)])
 def test_query_self_attention_kernel(Lq, Lk, H, D, masked):
     rng = np.random.default_rng(Lq + D)
