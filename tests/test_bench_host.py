@@ -1,0 +1,55 @@
+"""CPU (-m "not gpu"): the host-side pieces of bench.py that must not break between GPU runs -- its arguments, the table of split
+products it reports (`dtype`, side legs), and the committed counter / traffic passes it folds into the line (profiles/)."""
+import glob
+import json
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+import bench  # noqa: E402
+
+
+def test_arguments_and_defaults(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse_args()
+    assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0 and a.config == "cfg2" and a.split_terms is None
+    for t in ("3", "6", "16"):
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--split-terms", t, "--config", "cfg4", "--no-split3"])
+        a = bench.parse_args()
+        assert a.split_terms == int(t) and a.config == "cfg4" and a.no_split3
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--split-terms", "5"])
+    with pytest.raises(SystemExit):
+        bench.parse_args()
+
+
+def test_every_split_product_has_a_name_a_leg_and_a_dtype_text():
+    from trackformer_amd import fused
+    assert set(bench._ARITH) == {3, 6, 16} and fused.split_terms() in bench._ARITH
+    legs = [v[1] for v in bench._ARITH.values()]
+    assert len(set(legs)) == 3 and all(leg.endswith("_fps") for leg in legs)
+    assert "fp16" in bench._ARITH[16][2] and "six-term" in bench._ARITH[6][2] and "NOT the reference's precision" in bench._ARITH[3][2]
+    prev = fused.set_split_terms(6)
+    try:
+        assert fused.split_terms() == 6
+    finally:
+        fused.set_split_terms(prev)
+
+
+def test_committed_counter_passes_are_readable():
+    """bench.py folds the newest profiles/rNN_mfma_utilisation.json and rNN_msda_fwd_pquad_traffic.json into its line."""
+    m = bench.committed_mfma_utilisation()
+    assert m is not None and m["terms"] in (3, 6, 16) and "source_commit" in m
+    assert m["harness"], m            # the harness kernels were found under their current names
+    assert all(0.0 <= v <= 1.0 for v in m["harness"].values())
+    frame = m["per_kernel_in_an_eager_cfg2_frame"]
+    assert frame and max(frame.values()) <= 1.0 and any("ffn_fused" in k for k in frame)
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_msda_fwd_pquad_traffic.json")))
+    assert files
+    with open(files[-1]) as f:
+        t = json.load(f)
+    pq = t["msda_fwd_f32_pquad"]
+    algorithmic = 4 * (22223 * 8 * 32 + 3 * 22223 * 8 * 4 * 4 + 22223 * 8 * 32)      # SURVEY 8(d) at the cfg-2 encoder call
+    assert algorithmic == 79647232 and algorithmic <= pq["hbm_traffic_bytes_per_launch"] < 2 * algorithmic
