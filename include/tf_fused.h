@@ -66,6 +66,9 @@ int tf_box_refine_f32(const float *delta, const float *ref, float *out, int64_t 
  */
 int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
                           int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream);
+/* The same followed by ReLU in the same pass: `F.relu(gn(conv(x)))` of the mask head (reference: models/detr_segmentation.py:142-156). */
+int tf_groupnorm_relu_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
+                               int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream);
 
 /*
  * THE SPLIT PRODUCT (every matrix-core kernel below; trackformer_amd/csrc/split_product.h).  fp32 operands are cut into 16-bit

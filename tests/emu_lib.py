@@ -53,8 +53,9 @@ def lib():
     L.tf_bias_relu_maxpool_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_box_refine_f32.restype = ci
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
-    L.tf_groupnorm_nhwc_f32.restype = ci
-    L.tf_groupnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
+    for fn in (L.tf_groupnorm_nhwc_f32, L.tf_groupnorm_relu_nhwc_f32):
+        fn.restype = ci
+        fn.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
     L.tf_linear_res_ln_f32.restype = ci
     L.tf_linear_res_ln_f32.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_float, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_ffn_fused_f32.restype = ci
@@ -448,13 +449,14 @@ def conv3x3_splitk(x_nhwc, w_ohwi, bias=None, relu=False, stride=1, ksplit=4):
     return y
 
 
-def groupnorm_nhwc(x, gamma, beta, G, eps=1e-5):
-    """x [N, HW, C] -> GroupNorm over (HW, C / G) per image and group."""
+def groupnorm_nhwc(x, gamma, beta, G, eps=1e-5, relu=False):
+    """x [N, HW, C] -> GroupNorm over (HW, C / G) per image and group [+ ReLU: tf_groupnorm_relu_nhwc_f32]."""
     x, gamma, beta = _c(x, np.float32), _c(gamma, np.float32), _c(beta, np.float32)
     n, hw, c = x.shape
     out = np.full(x.shape, np.nan, np.float32)
     ws = np.full(2 * n * G, np.nan, np.float64)
-    rc = lib().tf_groupnorm_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(out), _p(ws), n, hw, c, G, ctypes.c_float(eps), hw * c, hw * c, None)
+    fn = lib().tf_groupnorm_relu_nhwc_f32 if relu else lib().tf_groupnorm_nhwc_f32
+    rc = fn(_p(x), _p(gamma), _p(beta), _p(out), _p(ws), n, hw, c, G, ctypes.c_float(eps), hw * c, hw * c, None)
     if rc != 0:
         raise RuntimeError("tf_groupnorm_nhwc_f32: status %d" % rc)
     return out

@@ -535,7 +535,9 @@ def test_groupnorm_nhwc(n, hw, c, g):
     mean = xr.mean(axis=(1, 3), keepdims=True)
     var = xr.var(axis=(1, 3), keepdims=True)
     ref = ((xr - mean) / np.sqrt(var + 1e-5)).reshape(n, hw, c) * ga + be
-    np.testing.assert_allclose(emu_lib.groupnorm_nhwc(x, ga, be, g), ref, atol=2e-5, rtol=1e-5)
+    got = emu_lib.groupnorm_nhwc(x, ga, be, g)
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=1e-5)
+    assert np.array_equal(emu_lib.groupnorm_nhwc(x, ga, be, g, relu=True), np.maximum(got, 0))   # tf_groupnorm_relu_nhwc_f32: the same pass + ReLU
 
 
 @pytest.mark.parametrize("ref_dim", [2, 4])

@@ -123,7 +123,7 @@ def test_mask_head_through_the_split_product_convolutions():
             finally:
                 ds.set_mask_head_split(prev)
     n_conv = sum(calls.get(k, 0) for k in ("tf_conv3x3_split_f32", "tf_conv3x3_splitk_f32", "tf_conv_packed_f32"))
-    assert n_conv == 4 and calls.get("tf_groupnorm_nhwc_f32") == 4, calls
+    assert n_conv == 4 and calls.get("tf_groupnorm_relu_nhwc_f32") == 4, calls   # GroupNorm + ReLU in one pass each
     assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
     assert torch.equal(off, ref)     # switched off: the library path
 

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = (
     "tf_bias_act_f32",
     "tf_add_layernorm_f32",
     "tf_groupnorm_nhwc_f32",
+    "tf_groupnorm_relu_nhwc_f32",
     "tf_box_refine_f32",
     "tf_bias_relu_maxpool_f32",
     "tf_stem_conv7x7_f32",
@@ -118,8 +119,9 @@ def lib():
     L.tf_bias_relu_maxpool_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_box_refine_f32.restype = ci
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
-    L.tf_groupnorm_nhwc_f32.restype = ci
-    L.tf_groupnorm_nhwc_f32.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
+    for fn in (L.tf_groupnorm_nhwc_f32, L.tf_groupnorm_relu_nhwc_f32):
+        fn.restype = ci
+        fn.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
     L.tf_linear_split_f32.restype = ci
     L.tf_linear_split_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ci, ci, ci, vp]
     L.tf_linear_split_res_f32.restype = ci

@@ -182,6 +182,7 @@ groupnorm_stats_kernel(const float *__restrict__ x, double *__restrict__ ws, int
     for (int i = threadIdx.x; i < 2 * G; i += blockDim.x) atomicAdd(&ws[(long long)n * 2 * G + i], s_stat[i]);
 }
 
+template <bool RELU>
 __global__ void __launch_bounds__(256)
 groupnorm_apply_kernel(const float *__restrict__ x, const double *__restrict__ ws, const float *__restrict__ gamma,
                        const float *__restrict__ beta, float *__restrict__ out, int HW, int C, int G, float eps,
@@ -213,6 +214,12 @@ groupnorm_apply_kernel(const float *__restrict__ x, const double *__restrict__ w
         y.y = (v.y - s_mean[g1]) * s_rstd[g1] * ga.y + be.y;
         y.z = (v.z - s_mean[g2]) * s_rstd[g2] * ga.z + be.z;
         y.w = (v.w - s_mean[g3]) * s_rstd[g3] * ga.w + be.w;
+        if (RELU) {
+            y.x = y.x > 0.f ? y.x : 0.f;
+            y.y = y.y > 0.f ? y.y : 0.f;
+            y.z = y.z > 0.f ? y.z : 0.f;
+            y.w = y.w > 0.f ? y.w : 0.f;
+        }
         op[i] = y;
     }
 }
@@ -316,8 +323,8 @@ int tf_box_refine_f32(const float *delta, const float *ref, float *out, int64_t 
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
-                          int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream)
+static int groupnorm_nhwc_impl(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N, int HW,
+                               int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, bool relu, void *stream)
 {
     if (!x || !gamma || !beta || !out || !workspace) return TF_MSDA_ERR_NULL_POINTER;
     if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 256 || C > 1024 || (C % G) != 0 || (C & 3) || N > 65535)
@@ -333,10 +340,27 @@ int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta,
                        (long long)x_image_stride);
     long long ablocks = ((long long)HW * (C / 4) + 255) / 256;
     if (ablocks > 256 * 8) ablocks = 256 * 8;
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3((unsigned)ablocks, (unsigned)N), dim3(256), 0, s, x,
-                       (const double *)workspace, gamma, beta, out, HW, C, G, eps, (long long)x_image_stride,
-                       (long long)out_image_stride);
+    if (relu)
+        hipLaunchKernelGGL(groupnorm_apply_kernel<true>, dim3((unsigned)ablocks, (unsigned)N), dim3(256), 0, s, x,
+                           (const double *)workspace, gamma, beta, out, HW, C, G, eps, (long long)x_image_stride,
+                           (long long)out_image_stride);
+    else
+        hipLaunchKernelGGL(groupnorm_apply_kernel<false>, dim3((unsigned)ablocks, (unsigned)N), dim3(256), 0, s, x,
+                           (const double *)workspace, gamma, beta, out, HW, C, G, eps, (long long)x_image_stride,
+                           (long long)out_image_stride);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
+                          int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream)
+{
+    return groupnorm_nhwc_impl(x, gamma, beta, out, workspace, N, HW, C, G, eps, x_image_stride, out_image_stride, false, stream);
+}
+
+int tf_groupnorm_relu_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
+                               int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream)
+{
+    return groupnorm_nhwc_impl(x, gamma, beta, out, workspace, N, HW, C, G, eps, x_image_stride, out_image_stride, true, stream);
 }
 
 int tf_bias_act_f32(float *x, const float *bias, const float *residual, int64_t n, int C, int relu,

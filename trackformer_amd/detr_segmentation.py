@@ -227,10 +227,10 @@ class MaskHeadSmallConv(nn.Module):
         if y is None:     # declined (size / alignment): the library convolution on the unpadded channels
             y = F.conv2d(x[:, :conv.in_channels], conv.weight, conv.bias, padding=1).contiguous(memory_format=torch.channels_last)
         n, c, h, w = y.shape
-        z = fused.groupnorm_nhwc(y.permute(0, 2, 3, 1).reshape(n * h * w, c), n, gn)
+        z = fused.groupnorm_nhwc(y.permute(0, 2, 3, 1).reshape(n * h * w, c), n, gn, relu=True)   # GroupNorm + ReLU in one pass
         if z is None:
             return F.relu(gn(y))
-        return z.relu_().view(n, h, w, c).permute(0, 3, 1, 2)
+        return z.view(n, h, w, c).permute(0, 3, 1, 2)
 
     def _split_route(self, x):
         from . import fused

@@ -755,9 +755,9 @@ def set_input_proj_fused(on):
     return prev
 
 
-def groupnorm_nhwc(x2, n_img, gn):
-    """GroupNorm of x2 [n_img * HW, C] (channels innermost) with nn.GroupNorm `gn`'s parameters; returns a new tensor of the
-    same shape or None when the kernel does not apply."""
+def groupnorm_nhwc(x2, n_img, gn, relu=False):
+    """GroupNorm [+ ReLU] of x2 [n_img * HW, C] (channels innermost) with nn.GroupNorm `gn`'s parameters; returns a new tensor of
+    the same shape or None when the kernel does not apply."""
     if not (x2.is_cuda and x2.dtype == torch.float32 and x2.dim() == 2 and x2.is_contiguous()
             and gn.weight is not None and gn.bias is not None and gn.weight.device == x2.device):
         return None
@@ -768,9 +768,9 @@ def groupnorm_nhwc(x2, n_img, gn):
     with torch.cuda.device(x2.device):
         out = torch.empty_like(x2)
         ws = torch.empty(2 * n_img * gn.num_groups, dtype=torch.float64, device=x2.device)
-        rc = _cabi.lib().tf_groupnorm_nhwc_f32(x2.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(), out.data_ptr(),
-                                               ws.data_ptr(), n_img, hw, c, gn.num_groups, float(gn.eps), hw * c, hw * c,
-                                               _stream(x2.device))
+        fn = _cabi.lib().tf_groupnorm_relu_nhwc_f32 if relu else _cabi.lib().tf_groupnorm_nhwc_f32
+        rc = fn(x2.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(), out.data_ptr(), ws.data_ptr(), n_img, hw, c, gn.num_groups,
+                float(gn.eps), hw * c, hw * c, _stream(x2.device))
     _cabi.check(rc, "tf_groupnorm_nhwc_f32")
     return out
 
