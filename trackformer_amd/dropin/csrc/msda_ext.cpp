@@ -1,0 +1,153 @@
+// trackformer_amd/dropin/csrc/msda_ext.cpp -- `MultiScaleDeformableAttention` as a COMPILED torch extension over the C ABI of
+// libtf_msda.so (include/tf_msda.h): the form the reference ships its operator in (models/ops/setup.py:30-66 builds a pybind11 module
+// of this name; models/ops/src/vision.cpp:4-7 exports ms_deform_attn_forward / ms_deform_attn_backward; the only consumer is
+// `import MultiScaleDeformableAttention as MSDA` in models/ops/functions/ms_deform_attn_func.py:11).  No kernels in here: tensor
+// checks, output allocation, the current HIP stream, and the calls into the library.  Same signatures, argument meaning and error
+// behaviour (a c10::Error / RuntimeError) as the reference's functions, plus what its CPU branch lacks: host tensors run the
+// library's host operator instead of raising "Not implemented on the CPU".
+#include <torch/extension.h>
+
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+
+#include <vector>
+
+#include "tf_msda.h"
+
+namespace {
+
+struct Dims {
+    int N, S, M, D, L, Lq, P;
+};
+
+Dims check_inputs(const at::Tensor &value, const at::Tensor &spatial_shapes, const at::Tensor &sampling_loc,
+                  const at::Tensor &attn_weight, int64_t im2col_step)
+{
+    TORCH_CHECK(value.is_contiguous(), "value tensor has to be contiguous");
+    TORCH_CHECK(spatial_shapes.is_contiguous(), "spatial_shapes tensor has to be contiguous");
+    TORCH_CHECK(sampling_loc.is_contiguous(), "sampling_loc tensor has to be contiguous");
+    TORCH_CHECK(attn_weight.is_contiguous(), "attn_weight tensor has to be contiguous");
+    TORCH_CHECK(value.dim() == 4 && sampling_loc.dim() == 6 && attn_weight.dim() == 5 && spatial_shapes.dim() == 2 &&
+                    spatial_shapes.size(1) == 2,
+                "expected value [N,S,M,D], spatial_shapes [L,2], sampling_loc [N,Lq,M,L,P,2], attn_weight [N,Lq,M,L,P]");
+    TORCH_CHECK(spatial_shapes.scalar_type() == at::kLong, "spatial_shapes must be int64");
+    TORCH_CHECK(value.scalar_type() == at::kFloat || value.scalar_type() == at::kDouble, "value must be float32 or float64");
+    TORCH_CHECK(sampling_loc.scalar_type() == value.scalar_type() && attn_weight.scalar_type() == value.scalar_type(),
+                "value, sampling_loc and attn_weight must have one dtype");
+    TORCH_CHECK(sampling_loc.device() == value.device() && attn_weight.device() == value.device(),
+                "value, sampling_loc and attn_weight must be on one device");
+    Dims d;
+    d.N = (int)value.size(0);
+    d.S = (int)value.size(1);
+    d.M = (int)value.size(2);
+    d.D = (int)value.size(3);
+    d.L = (int)spatial_shapes.size(0);
+    d.Lq = (int)sampling_loc.size(1);
+    d.P = (int)sampling_loc.size(4);
+    TORCH_CHECK(sampling_loc.size(0) == d.N && sampling_loc.size(2) == d.M && sampling_loc.size(3) == d.L && sampling_loc.size(5) == 2 &&
+                    attn_weight.size(0) == d.N && attn_weight.size(1) == d.Lq && attn_weight.size(2) == d.M && attn_weight.size(3) == d.L &&
+                    attn_weight.size(4) == d.P,
+                "inconsistent tensor shapes");
+    // the reference processes the batch in chunks of im2col_step and requires it to divide the batch (cu:37-39); results never
+    // depended on it, the check is kept so that a call the reference rejects is rejected here too
+    const int64_t step = std::min<int64_t>(d.N, im2col_step);
+    TORCH_CHECK(step > 0 && d.N % step == 0, "batch(", d.N, ") must divide im2col_step(", step, ")");
+    return d;
+}
+
+void raise_on(int rc, const char *what)
+{
+    TORCH_CHECK(rc == TF_MSDA_OK, what, " failed: ", tf_msda_strerror(rc), " (status ", rc, ", hipError ", tf_msda_last_hip_error(), ")");
+}
+
+// the level shapes for the host-shape entry points: a CPU copy of a CPU tensor is free; a device tensor goes to the *_dshapes entries
+const int64_t *host_shapes(const at::Tensor &spatial_shapes) { return spatial_shapes.data_ptr<int64_t>(); }
+
+}  // namespace
+
+at::Tensor ms_deform_attn_forward(const at::Tensor &value, const at::Tensor &spatial_shapes, const at::Tensor &sampling_loc,
+                                  const at::Tensor &attn_weight, const int64_t im2col_step)
+{
+    const Dims d = check_inputs(value, spatial_shapes, sampling_loc, attn_weight, im2col_step);
+    at::Tensor out = at::empty({d.N, d.Lq, d.M * d.D}, value.options());
+    const bool f32 = value.scalar_type() == at::kFloat;
+    int rc;
+    if (!value.is_cuda()) {   // host tensors: the library's host operator (synchronous)
+        TORCH_CHECK(!spatial_shapes.is_cuda(), "spatial_shapes must be a host tensor for host inputs");
+        rc = f32 ? tf_msda_forward_host_f32(value.data_ptr<float>(), host_shapes(spatial_shapes), sampling_loc.data_ptr<float>(),
+                                            attn_weight.data_ptr<float>(), out.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P)
+                 : tf_msda_forward_host_f64(value.data_ptr<double>(), host_shapes(spatial_shapes), sampling_loc.data_ptr<double>(),
+                                            attn_weight.data_ptr<double>(), out.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P);
+        raise_on(rc, "ms_deform_attn_forward");
+        return out;
+    }
+    // (PyTorch on ROCm presents HIP devices under the CUDA device type: the masquerading guard / stream are the ones that match)
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
+    void *stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    const int64_t *shp = spatial_shapes.data_ptr<int64_t>();
+    if (spatial_shapes.is_cuda())   // the reference's device-resident shapes: read inside the kernel, no synchronisation
+        rc = f32 ? tf_msda_forward_f32_dshapes(value.data_ptr<float>(), shp, sampling_loc.data_ptr<float>(), attn_weight.data_ptr<float>(),
+                                               out.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, stream)
+                 : tf_msda_forward_f64_dshapes(value.data_ptr<double>(), shp, sampling_loc.data_ptr<double>(),
+                                               attn_weight.data_ptr<double>(), out.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, stream);
+    else
+        rc = f32 ? tf_msda_forward_f32(value.data_ptr<float>(), shp, sampling_loc.data_ptr<float>(), attn_weight.data_ptr<float>(),
+                                       out.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, stream)
+                 : tf_msda_forward_f64(value.data_ptr<double>(), shp, sampling_loc.data_ptr<double>(), attn_weight.data_ptr<double>(),
+                                       out.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P, stream);
+    raise_on(rc, "ms_deform_attn_forward");
+    return out;
+}
+
+std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor &value, const at::Tensor &spatial_shapes, const at::Tensor &sampling_loc,
+                                                const at::Tensor &attn_weight, const at::Tensor &grad_output, const int64_t im2col_step)
+{
+    const Dims d = check_inputs(value, spatial_shapes, sampling_loc, attn_weight, im2col_step);
+    TORCH_CHECK(grad_output.device() == value.device() && grad_output.scalar_type() == value.scalar_type() &&
+                    grad_output.numel() == (int64_t)d.N * d.Lq * d.M * d.D,
+                "grad_output must be a tensor of shape [N, Lq, M*D] on value's device with value's dtype");
+    const at::Tensor go = grad_output.contiguous();   // autograd may hand over a strided view
+    at::Tensor gv = at::empty_like(value), gl = at::empty_like(sampling_loc), ga = at::empty_like(attn_weight);
+    const bool f32 = value.scalar_type() == at::kFloat;
+    int rc;
+    if (!value.is_cuda()) {
+        TORCH_CHECK(!spatial_shapes.is_cuda(), "spatial_shapes must be a host tensor for host inputs");
+        rc = f32 ? tf_msda_backward_host_f32(value.data_ptr<float>(), host_shapes(spatial_shapes), sampling_loc.data_ptr<float>(),
+                                             attn_weight.data_ptr<float>(), go.data_ptr<float>(), gv.data_ptr<float>(), gl.data_ptr<float>(),
+                                             ga.data_ptr<float>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P)
+                 : tf_msda_backward_host_f64(value.data_ptr<double>(), host_shapes(spatial_shapes), sampling_loc.data_ptr<double>(),
+                                             attn_weight.data_ptr<double>(), go.data_ptr<double>(), gv.data_ptr<double>(),
+                                             gl.data_ptr<double>(), ga.data_ptr<double>(), d.N, d.S, d.M, d.D, d.L, d.Lq, d.P);
+        raise_on(rc, "ms_deform_attn_backward");
+        return {gv, gl, ga};
+    }
+    // (PyTorch on ROCm presents HIP devices under the CUDA device type: the masquerading guard / stream are the ones that match)
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(value.device());
+    void *stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    const int64_t *shp = spatial_shapes.data_ptr<int64_t>();
+    if (spatial_shapes.is_cuda())
+        rc = f32 ? tf_msda_backward_f32_dshapes(value.data_ptr<float>(), shp, sampling_loc.data_ptr<float>(), attn_weight.data_ptr<float>(),
+                                                go.data_ptr<float>(), gv.data_ptr<float>(), gl.data_ptr<float>(), ga.data_ptr<float>(), d.N, d.S,
+                                                d.M, d.D, d.L, d.Lq, d.P, stream)
+                 : tf_msda_backward_f64_dshapes(value.data_ptr<double>(), shp, sampling_loc.data_ptr<double>(), attn_weight.data_ptr<double>(),
+                                                go.data_ptr<double>(), gv.data_ptr<double>(), gl.data_ptr<double>(), ga.data_ptr<double>(), d.N,
+                                                d.S, d.M, d.D, d.L, d.Lq, d.P, stream);
+    else
+        rc = f32 ? tf_msda_backward_f32(value.data_ptr<float>(), shp, sampling_loc.data_ptr<float>(), attn_weight.data_ptr<float>(),
+                                        go.data_ptr<float>(), gv.data_ptr<float>(), gl.data_ptr<float>(), ga.data_ptr<float>(), d.N, d.S, d.M, d.D,
+                                        d.L, d.Lq, d.P, stream)
+                 : tf_msda_backward_f64(value.data_ptr<double>(), shp, sampling_loc.data_ptr<double>(), attn_weight.data_ptr<double>(),
+                                        go.data_ptr<double>(), gv.data_ptr<double>(), gl.data_ptr<double>(), ga.data_ptr<double>(), d.N, d.S, d.M,
+                                        d.D, d.L, d.Lq, d.P, stream);
+    raise_on(rc, "ms_deform_attn_backward");
+    return {gv, gl, ga};
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "MultiScaleDeformableAttention for AMD Instinct MI355X: the reference's plugin API over libtf_msda.so";
+    m.def("ms_deform_attn_forward", &ms_deform_attn_forward, "ms_deform_attn_forward", py::arg("value"), py::arg("spatial_shapes"),
+          py::arg("sampling_loc"), py::arg("attn_weight"), py::arg("im2col_step") = 64);
+    m.def("ms_deform_attn_backward", &ms_deform_attn_backward, "ms_deform_attn_backward", py::arg("value"), py::arg("spatial_shapes"),
+          py::arg("sampling_loc"), py::arg("attn_weight"), py::arg("grad_output"), py::arg("im2col_step") = 64);
+}
