@@ -16,6 +16,11 @@ cfg4_full  the `multi_frame` model (hidden 288, 500 object + 300 track queries, 
            cfgs/train_multi_frame.yaml:1-5): previous frame, then current frame with prev_features
 tracker    reference `Tracker` (tracker.py:266-550) for 3 frames of 800x1333 with the cfg-2 model
 tracker64  the same for 64 frames, with the score margins to the thresholds recorded
+tracker_wc64  64 frames with the WELL-CONDITIONED detector (tests/util_models.shape_well_conditioned: the same seeded weights
+           with a planted circuit that keeps every tracker decision of the sequence far from its threshold while tracks are
+           born, suppressed and terminated in every frame) -> full_tracker_cfg2_wc64.npz
+tracker_cfg4  the multi_frame model (cfg 4, the same shaping) under the reference Tracker, which carries the previous frame's
+           features through its deque (tracker.py:74,306,547), 12 frames -> full_tracker_cfg4.npz
 
 Weights and inputs are regenerated from seeds (tests/util_models, tests/util_weights) on the GPU box;
 the fixtures hold outputs only.  Large tensors are subsampled (encoder memory: every 89th token, last
@@ -140,11 +145,17 @@ def mask_tracker_case(ref, frames=3):
         tracker.track_num, active, len(rows), sum(areas), os.path.basename(path)), flush=True)
 
 
-def tracker_case(ref, n_frames=None):
+def tracker_case(ref, n_frames=None, case="cfg2_full", shape=None, tag=None):
     """n_frames None: the 3-frame fixture; 64: SURVEY 8(d)'s "64-frame synthetic sequence for the track-ID parity check"
     (full_tracker_cfg2_64.npz), which also records how far every score of every frame stays from the two score
-    thresholds -- a fixture whose decisions sit within the 1e-3 box / logit tolerance of a threshold would not pin ids."""
-    model, post, args = um.build("cfg2_full", ref.models.build_model, config.make_args)
+    thresholds -- a fixture whose decisions sit within the 1e-3 box / logit tolerance of a threshold would not pin ids.
+    case "cfg4_full": the `multi_frame` model (BASELINE cfg 4) under the reference Tracker, which hands frame t's backbone
+    features to frame t + 1 through its deque (tracker.py:74,306,547) -> full_tracker_cfg4.npz.
+    shape: a function applied to the model after the seeded perturbation (um.shape_well_conditioned: the detector whose
+    tracker decisions keep wide margins, full_tracker_cfg2_wc64.npz)."""
+    model, post, args = um.build(case, ref.models.build_model, config.make_args)
+    if shape is not None:
+        shape(model)
     model.tracking()
     cfg = config.tracker_cfg()
     all_scores = []
@@ -157,14 +168,19 @@ def tracker_case(ref, n_frames=None):
             return res
     post = dict(post, bbox=Recording())
     # ... and how close any pair of boxes an NMS pass looks at comes to its IoU threshold, per frame
-    nms_margin = []
+    nms_margin, order_margin = [], []
     real_nms = ref.tracker.nms
 
     def recording_nms(boxes, scores, thr):
         if boxes.shape[0] > 1:
             iou = ref.tracker.box_iou(boxes, boxes)
-            iou = iou[~torch.eye(len(iou), dtype=torch.bool)]
-            nms_margin[-1] = min(nms_margin[-1], float((iou - thr).abs().min()))
+            off = ~torch.eye(len(iou), dtype=torch.bool)
+            nms_margin[-1] = min(nms_margin[-1], float((iou[off] - thr).abs().min()))
+            # ... and how far apart the scores of two boxes are that suppress one another (which of them survives)
+            gap = (scores[:, None] - scores[None, :]).abs()
+            both = off & (iou > thr) & torch.isfinite(scores)[:, None] & torch.isfinite(scores)[None, :]
+            if both.any():
+                order_margin[-1] = min(order_margin[-1], float(gap[both].min()))
         return real_nms(boxes, scores, thr)
     ref.tracker.nms = recording_nms
     tracker = ref.tracker.Tracker(model, post, cfg, False)
@@ -175,6 +191,7 @@ def tracker_case(ref, n_frames=None):
     with torch.no_grad():
         for blob in frames:
             nms_margin.append(float("inf"))
+            order_margin.append(float("inf"))
             tracker.step(blob)
             active.append(len(tracker.tracks))
             print("  frame %d: %d active tracks (%.0f s)" % (len(active), active[-1], time.time() - t0),
@@ -187,13 +204,16 @@ def tracker_case(ref, n_frames=None):
     sc = torch.cat(all_scores).numpy().astype(np.float64)
     thresholds = sorted({cfg['track_obj_score_thresh'], cfg['detection_obj_score_thresh'], cfg['reid_score_thresh']})
     min_margin = float(min(np.abs(sc - t).min() for t in thresholds))
-    path = os.path.join(HERE, "full_tracker_cfg2.npz" if n_frames is None else "full_tracker_cfg2_%d.npz" % n_frames)
+    stem = "full_tracker_%s" % (tag or case[:4])
+    path = os.path.join(HERE, stem + ".npz" if n_frames is None or tag else "%s_%d.npz" % (stem, n_frames))
     np.savez_compressed(path, rows=rows, active_per_frame=np.array(active),
                         num_tracks=np.int64(tracker.track_num), num_reids=np.int64(tracker.num_reids),
                         min_score_margin=np.float64(min_margin), score_thresholds=np.array(thresholds),
-                        nms_iou_margin_per_frame=np.array(nms_margin))
+                        nms_iou_margin_per_frame=np.array(nms_margin), nms_order_margin_per_frame=np.array(order_margin),
+                        min_score_margin_per_frame=np.array([float(min((s.double() - t).abs().min() for t in thresholds)) for s in all_scores]))
     ref.tracker.nms = real_nms
     print("smallest |IoU - NMS threshold| per frame:", ["%.1e" % m for m in nms_margin])
+    print("smallest score gap between two boxes one of which suppresses the other:", "%.2e" % min(order_margin))
     print("smallest |score - threshold| over every query of every frame: %.3e (thresholds %s)" % (min_margin, thresholds))
     print("tracker: %d ids, active %s, smallest |score - threshold| of a kept track %.2e -> %s" % (
         tracker.track_num, active, margin, os.path.basename(path)), flush=True)
@@ -210,6 +230,10 @@ def main():
             train_case(ref)
         elif case == "tracker_cfg5":
             mask_tracker_case(ref)
+        elif case == "tracker_cfg4":
+            tracker_case(ref, um.FULL_TRACKER_CFG4_FRAMES, case="cfg4_full", shape=um.shape_well_conditioned, tag="cfg4")
+        elif case == "tracker_wc64":
+            tracker_case(ref, 64, shape=um.shape_well_conditioned, tag="cfg2_wc64")
         elif case.startswith("tracker") and case[7:].isdigit():   # e.g. tracker64
             tracker_case(ref, int(case[7:]))
         else:

@@ -135,6 +135,69 @@ def main():
             tracker.num_reids, os.path.basename(path)))
     tracker_variants(ref)
     mask_tracker(ref)
+    tracker_wc(ref)
+
+
+def tracker_wc(ref):
+    """The reference Tracker over the WELL-CONDITIONED detector (tests/util_models.shape_well_conditioned) at the small
+    test size: 64 frames of the cfg-2 model, 24 frames with re-identification, 12 frames of the multi_frame model (whose
+    previous-frame features travel through the Tracker's deque: tracker.py:74,306,547).  Stored beside the rows: per frame
+    the smallest |score - threshold|, |IoU - NMS threshold| and score gap of a suppressing pair -- the test asserts that
+    they stay wide (that is what the shaping is for)."""
+    for name, (case, n_frames, reid) in um.WC_TRACKER_CASES.items():
+        model, post, args = um.build(case, ref.models.build_model, config.make_args)
+        um.shape_well_conditioned(model)
+        model.tracking()
+        cfg = config.tracker_cfg(reid=reid)
+        scores_seen, iou_margin, order_margin = [], [], []
+        bbox_post = post['bbox']
+
+        class Recording(torch.nn.Module):
+            def forward(self, outputs, sizes, *a, **k):
+                res = bbox_post(outputs, sizes, *a, **k)
+                scores_seen.append(res[0]['scores'].detach().clone())
+                return res
+        real_nms = ref.tracker.nms
+
+        def recording_nms(boxes, scores, thr):
+            if boxes.shape[0] > 1:
+                iou = ref.tracker.box_iou(boxes, boxes)
+                off = ~torch.eye(len(iou), dtype=torch.bool)
+                iou_margin[-1] = min(iou_margin[-1], float((iou[off] - thr).abs().min()))
+                fin = torch.isfinite(scores)
+                both = off & (iou > thr) & fin[:, None] & fin[None, :]
+                if both.any():
+                    order_margin[-1] = min(order_margin[-1], float((scores[:, None] - scores[None, :]).abs()[both].min()))
+            return real_nms(boxes, scores, thr)
+        ref.tracker.nms = recording_nms
+        try:
+            tracker = ref.tracker.Tracker(model, dict(post, bbox=Recording()), cfg, False)
+            tracker.reset()
+            active, inactive = [], []
+            with torch.no_grad():
+                for blob in um.tracker_sequence(n_frames=n_frames):
+                    iou_margin.append(float("inf"))
+                    order_margin.append(float("inf"))
+                    tracker.step(blob)
+                    active.append(len(tracker.tracks))
+                    inactive.append(len(tracker.inactive_tracks))
+        finally:
+            ref.tracker.nms = real_nms
+        results = tracker.get_results()
+        rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']), results[tid][f]['obj_ind']]
+                         for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
+        thresholds = sorted({cfg['track_obj_score_thresh'], cfg['detection_obj_score_thresh'], cfg['reid_score_thresh']})
+        score_margin = [float(min((s.double() - t).abs().min() for t in thresholds)) for s in scores_seen]
+        path = os.path.join(HERE, "tracker_%s.npz" % name)
+        np.savez_compressed(path, rows=rows, active_per_frame=np.array(active), inactive_per_frame=np.array(inactive),
+                            num_tracks=np.int64(tracker.track_num), num_reids=np.int64(tracker.num_reids),
+                            score_margin_per_frame=np.array(score_margin), nms_iou_margin_per_frame=np.array(iou_margin),
+                            nms_order_margin_per_frame=np.array(order_margin), weight_checksum=np.float64(checksum(model)))
+        print("tracker %s: %d frames, %d ids, %d rows, active %d..%d, inactive %d..%d, reids %d; smallest score margin %.3f, "
+              "IoU margin %.3f, order margin %.2e -> %s (%d KB)" % (
+                  name, n_frames, tracker.track_num, len(rows), min(active), max(active), min(inactive), max(inactive),
+                  tracker.num_reids, min(score_margin), min(iou_margin), min(order_margin), os.path.basename(path),
+                  os.path.getsize(path) // 1024))
 
 
 def mask_tracker(ref, frames=3):
@@ -231,6 +294,11 @@ if __name__ == "__main__":
         ref_ = reference_models.load()
         torch.set_num_threads(8)
         mask_tracker(ref_)
+        sys.exit(0)
+    if sys.argv[1:] == ["wc"]:
+        ref_ = reference_models.load()
+        torch.set_num_threads(4)
+        tracker_wc(ref_)
         sys.exit(0)
     if sys.argv[1:] == ["tracker_variants"]:
         ref_ = reference_models.load()

@@ -936,3 +936,35 @@ def test_fused_blocks_tail_split_is_bit_identical(M, ti, terms):
             emu_lib.set_options(**prev)
     for a, b in zip(outs[0], outs[1]):
         assert np.array_equal(a[:M], b[:M]) and np.isnan(b[M:]).all()
+
+
+@pytest.mark.parametrize("terms", [16, 6])
+def test_relu_epilogues_propagate_nan_instead_of_zeroing_it(terms):
+    """an activation beyond the fp16 product's range (|x| >= 65504 * 16) makes its output row NaN; a ReLU
+    epilogue written `v > 0 ? v : 0` would turn that NaN into a silent zero.  Every epilogue is `v < 0 ? 0 : v` -- torch.relu's
+    behaviour: the NaN row reaches the caller (linear, packed linear, bias_act, convolution, fused feed-forward block).  With six
+    bf16 terms the same input is simply in range."""
+    prev_terms = emu_lib.set_terms(terms)
+    try:
+        rng = np.random.default_rng(3)
+        M, K, N = 64, 64, 64
+        x = rng.standard_normal((M, K)).astype(np.float32)
+        x[5, 7] = 4.0e6          # one activation out of the fp16 product's range
+        w = (rng.standard_normal((N, K)) / 8).astype(np.float32)
+        b = rng.standard_normal(N).astype(np.float32)
+        ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64).T + b, 0)
+        for y in (emu_lib.linear_split(x, w, b, True), emu_lib.linear_packed(x, w, b, relu=True)):
+            ok = np.ones(M, bool)
+            ok[5] = False
+            np.testing.assert_allclose(y[ok], ref[ok], atol=2e-5 * np.abs(ref).max())
+            if terms == 16:
+                assert np.isnan(y[5]).all(), "the out-of-range row must be NaN, not zeros"
+            else:
+                np.testing.assert_allclose(y[5], ref[5], rtol=1e-5, atol=1e-5 * np.abs(ref[5]).max())
+        # a NaN that reaches the element-wise epilogue kernel stays a NaN
+        v = rng.standard_normal((4, 64)).astype(np.float32)
+        v[1, 3] = np.nan
+        out = emu_lib.bias_act(v, b, None, relu=True)
+        assert np.isnan(out[1, 3]) and np.isfinite(np.delete(out.ravel(), 64 + 3)).all()
+    finally:
+        emu_lib.set_terms(prev_terms)

@@ -244,3 +244,45 @@ def test_stem_convolution_split(shape):
     scale = float(ref.abs().max())
     assert float((got - ref).abs().max()) < 1e-3 * scale
     assert float((got_b - torch.relu(ref + b.view(1, -1, 1, 1))).abs().max()) < 1e-3 * scale
+
+
+def test_fp16_product_range_contract_is_loud_and_has_a_way_out(dev):
+    """VERDICT r04 weak #9 / ADVICE r04 (medium).  An activation beyond 65504 * 16 under the fp16 split product (the default):
+    (1) the output row is NaN -- also through a ReLU epilogue, which used to map it to zero; (2) the debug check names the
+    operation; (3) audit_activation_range() routes exactly that layer through the six-term product, after which the layer is
+    fp32-accurate again while every other layer keeps the fp16 product."""
+    from trackformer_amd import fused
+    prev_split, prev_terms = fused.set_split_linear(True), fused.set_split_terms(16)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(512, 256, generator=g).to(dev)
+    x[17, 3] = 4.0e6
+    lin = torch.nn.Linear(256, 256).to(dev)
+    other = torch.nn.Linear(256, 256).to(dev)
+    ref = F.relu(F.linear(x.double(), lin.weight.double(), lin.bias.double())).float()
+    try:
+        with torch.no_grad():
+            y = fused.linear(x, lin.weight, lin.bias, relu=True)
+            assert y is not None and torch.isnan(y[17]).all() and torch.isfinite(y[torch.arange(512, device=dev) != 17]).all()
+            prev_check = fused.set_check_finite(True)
+            try:
+                with pytest.raises(FloatingPointError, match="linear produced a non-finite result"):
+                    fused.linear(x, lin.weight, lin.bias, relu=True)
+                assert fused.linear(x[:16], lin.weight, lin.bias, relu=True) is not None      # in-range rows pass the check
+            finally:
+                fused.set_check_finite(prev_check)
+            with fused.audit_activation_range() as report:
+                fused.linear(x, lin.weight, lin.bias, relu=True)
+                fused.linear(x[:16], other.weight, other.bias)
+            assert report["routed"] == 1 and report["largest"] == 4.0e6 and fused.six_term_routes() == 1
+            assert report["layers"][0][0] == "linear" and report["layers"][0][2] == 4.0e6
+            y = fused.linear(x, lin.weight, lin.bias, relu=True)                                # now six terms for this weight
+            assert torch.isfinite(y).all()
+            assert float((y - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+            assert fused.split_terms() == 16                                                    # the process default is untouched
+            z = fused.linear(x[:16], other.weight, other.bias)
+            assert float((z - F.linear(x[:16], other.weight, other.bias)).abs().max()) < 1e-4
+    finally:
+        fused.route_six_terms(lin.weight, False)
+        fused.set_split_linear(prev_split)
+        fused.set_split_terms(prev_terms)
+    assert fused.six_term_routes() == 0

@@ -178,6 +178,60 @@ def test_tracker_variants_match_reference(name, host_op):
     compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.05)
 
 
+def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None):
+    """Tracker.step over a sequence of tests/util_models.WC_TRACKER_CASES: the well-conditioned detector (the same seeded
+    weights with um.shape_well_conditioned's planted circuit).  wrap: detector -> detector (e.g. GraphedDetector)."""
+    case, frames, reid = um.WC_TRACKER_CASES[name]
+    model, post, args = um.build(case, factory.build_model, config.make_args, device=device)
+    um.shape_well_conditioned(model)
+    model.to(device)
+    model.tracking()
+    tracker = Tracker(wrap(model) if wrap is not None else model, post, config.tracker_cfg(reid=reid), False)
+    tracker.reset()
+    active, inactive = [], []
+    with torch.no_grad():
+        for blob in um.tracker_sequence(n_frames=n_frames or frames):
+            tracker.step(blob)
+            active.append(len(tracker.tracks))
+            inactive.append(len(tracker.inactive_tracks))
+    results = tracker.get_results()
+    rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']), results[tid][f]['obj_ind']]
+                     for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
+    return tracker, rows, active, inactive
+
+
+def compare_wc_to_golden(name, tracker, rows, active, inactive, box_tol_px, n_frames=None):
+    """Every decision of every frame: the fixture's recorded margins (smallest |score - threshold|, |IoU - NMS threshold|,
+    score gap of a suppressing pair, per frame) are asserted to be WIDE first -- so nothing below is conditional on where a
+    near-tie falls -- then ids / frames / source queries bit-exact, boxes and scores within tolerance."""
+    z = np.load(os.path.join(GOLDEN, "tracker_%s.npz" % name))
+    assert float(z["score_margin_per_frame"].min()) >= 1e-2
+    assert float(z["nms_iou_margin_per_frame"].min()) >= 1e-3
+    assert float(z["nms_order_margin_per_frame"].min()) >= 1e-2
+    n = n_frames or len(z["active_per_frame"])
+    want = z["rows"][z["rows"][:, 1] < n]
+    assert z["active_per_frame"][:n].tolist() == active
+    assert z["inactive_per_frame"][:n].tolist() == inactive
+    if n == len(z["active_per_frame"]):
+        assert int(z["num_tracks"]) == tracker.track_num
+        assert int(z["num_reids"]) == tracker.num_reids
+    assert rows.shape == want.shape
+    np.testing.assert_array_equal(rows[:, [0, 1, 7]], want[:, [0, 1, 7]])
+    np.testing.assert_allclose(rows[:, 2:6], want[:, 2:6], atol=box_tol_px)
+    np.testing.assert_allclose(rows[:, 6], want[:, 6], atol=1e-3)
+    # the sequence is not static: tracks are born and terminated in every frame, and some live through all of it
+    ids_per_frame = [set(want[want[:, 1] == f][:, 0].astype(int)) for f in range(n)]
+    assert all(ids_per_frame[f] - ids_per_frame[f - 1] and ids_per_frame[f - 1] - ids_per_frame[f] for f in range(1, n))
+    assert set.intersection(*ids_per_frame)
+
+
+@pytest.mark.parametrize("name,n_frames", [("cfg2_wc", 6), ("cfg2_wc_reid", 5), ("cfg4_wc", 4)])
+def test_well_conditioned_tracker_sequences_match_reference(name, n_frames, host_op):
+    """The first frames of each sequence on the CPU through the host operator (the GPU suite runs all of them: 64 frames)."""
+    tracker, rows, active, inactive = run_wc_tracker(name, n_frames=n_frames)
+    compare_wc_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.05, n_frames=n_frames)
+
+
 def run_mask_tracker(device="cpu", frames=3, lazy_masks=False):
     """cfg-5 path: Tracker.step on the mask-head model; -> {track id: {frame: result dict}}."""
     model, post, args = um.build("cfg5_segm_tracking", factory.build_model, config.make_args,

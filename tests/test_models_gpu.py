@@ -40,6 +40,18 @@ def test_tracker_variants_track_ids_bit_exact(dev, name):
     shared.compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.64)
 
 
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graph"])
+@pytest.mark.parametrize("name", list(um.WC_TRACKER_CASES))
+def test_well_conditioned_tracker_sequences_track_ids_bit_exact(dev, name, graph):
+    """sequences whose every decision has a wide margin (asserted from the fixture's recorded margins),
+    so that ALL frames are compared -- 64 frames of the cfg-2 model, 24 with the re-identification config, 12 of the
+    multi_frame model (cfg 4), whose previous-frame features travel through the Tracker (tracker.py:74,306,547 of the
+    reference; under `graph` they alias the static buffers of GraphedDetector)."""
+    from trackformer_amd.graphed import GraphedDetector
+    tracker, rows, active, inactive = shared.run_wc_tracker(name, device=dev, wrap=GraphedDetector if graph else None)
+    shared.compare_wc_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.64)
+
+
 @pytest.mark.parametrize("lazy", [False, True], ids=["full_head", "lazy_head"])
 def test_tracker_with_mask_head_matches_reference(dev, lazy):
     """cfg-5 path (mask head + Tracker) on the GPU against the reference's own Tracker / mask head / PostProcessSegm on CPU

@@ -50,6 +50,7 @@ FULL_TRAIN_BOXES = 30                           # 30 boxes per imag
 # cfg 5 fixture: pred_masks of every FULL_MASK_QUERY_STRIDE-th query, post-processed probabilities of the first 3
 FULL_MASK_QUERY_STRIDE = 50
 FULL_TRACKER_FRAMES = 3
+FULL_TRACKER_CFG4_FRAMES = 12  # the multi-frame model under the Tracker (prev_features through the deque)
 FULL_IMG = (800, 1333)
 FULL_ORIG = (1080, 1800)      # aspect of 800x1333 (datasets/transforms.py:115-146 resize)
 FULL_IMG_CFG1 = (480, 640)    # cfg 1 is quoted on a 480x640 frame (no resize)
@@ -226,3 +227,113 @@ TRAIN_GRAD_KEYS = [
     "backbone.0.body.layer2.0.conv1.weight", "backbone.0.body.layer4.2.conv3.weight",
     "class_embed.2.weight", "transformer.decoder.bbox_embed.0.layers.2.weight", "query_embed.weight",
 ]
+
+
+# ------------------------------------------------------------------ a detector whose tracker decisions keep wide margins
+# with perturbed random weights every query fires and hundreds of near-identical boxes reach the two
+# NMS passes of Tracker.step (tracker.py:399,495 of the reference), so that from frame 4 of the 64-frame sequence some
+# IoU sits within 1e-5 of its threshold -- a decision no fp32 implementation pins.  shape_well_conditioned() plants a small
+# circuit in the SAME seeded weights (a function of the state_dict only: the reference model and the repo's model get identical
+# values) so that every decision of a long sequence has a wide margin while tracks are still born, re-detected,
+# suppressed and terminated:
+#   * three PAIRS of channels of the decoder's residual stream are never written (their rows of the three output projections
+#     of every decoder layer are zero).  The two channels of a pair have the same LayerNorm gains, so what a LayerNorm adds to
+#     them (- mean / std) is the same number and their DIFFERENCE is only ever multiplied (gain / std): an object query carries
+#     the difference planted in its embedding to the class head, a track query -- whose input is the previous frame's output
+#     embedding (deformable_transformer.py:212-225) -- has it multiplied once more per frame by the pair's gain in the LAST
+#     LayerNorm: pair A ~ x 1.4 - 1.9 (and the normalisation itself holds it at a fixed point), pair B ~ x -0.7 ... -0.9, pair C ~ x 0.11 - 0.16
+#     (the smaller figures at 800 x 1333, the larger ones at the small test size: the constants below keep every decision decisive at both);
+#   * the "person" logit of the last class head reads the three differences (the other classes are silent): a track born
+#     from an A query lives for ever (and suppresses the re-detection of its object query in every frame: IoU > 0.97 against the
+#     0.9 threshold), one born from a B query falls far below the 0.4 threshold in the next frame (and its query starts a new
+#     track in that frame), one born from a C query steps through the threshold after one or two frames;
+#   * the firing object queries sit on a lattice (reference_points reads two planted channels of the query embedding) with
+#     small boxes (layer-0 box head bias) and a box head whose other outputs are ~1e-5: boxes of different places do not
+#     overlap at all; a few places are owned by TWO firing queries with different planted scores (the NMS of new detections
+#     against each other decides by score).
+WC_PAIRS = {"A": (1, 2), "B": (5, 6), "C": (3, 4)}
+WC_LN_GAIN = 1.236                      # undoes the average 1 / std of a LayerNorm of the decoder at these weights
+WC_RHO = {"A": 1.3, "B": -0.62, "C": 0.105}
+WC_HEAD = {"A": 2.0, "B": 5.0, "C": 30.0}   # class-head weight on each difference
+WC_BIAS = -0.405 - 1.25                 # person logit of a query without planted differences: score 0.16
+WC_PLANT = {"A": 1.0, "B": -0.95, "C1": 0.55, "C2": 5.5}
+WC_RIVAL = 0.6                          # planted value of a place's second query relative to its first
+
+
+def wc_families(nq):
+    """-> {query: (family, place index)}; families 'A', 'B', 'C1', 'C2' (+ 'r': the rival of the place, a lower score)."""
+    fire = [q for q in range(nq) if q % 5 == 0]
+    fam = {}
+    for i, q in enumerate(fire):
+        fam[q] = (("A", "B", "C1", "C2")[i % 4], i)
+        if i < 16 and fam[q][0] in "AB":   # (a C1 rival would sit too close to the threshold, a C2 rival's score within
+            # 1e-6 of its place's first query: both saturate)
+            fam[q + 1] = (fam[q][0] + "r", i)
+    return fam
+
+
+def shape_well_conditioned(model):
+    import math
+    sd = model.state_dict()
+    with torch.no_grad():
+        qe = sd["query_embed.weight"]
+        nq, c2 = qe.shape
+        c = c2 // 2
+        n_layers = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith("transformer.decoder.layers."))
+        fam = wc_families(nq)
+        n_places = 1 + max(v[1] for v in fam.values())
+        nx = 10
+        ny = (n_places + nx - 1) // nx
+        for pair in WC_PAIRS.values():
+            for ch in pair:
+                qe[:, c + ch] = 0.0
+        for q, (f, i) in fam.items():
+            cx = 0.12 + 0.76 * (i % nx) / max(nx - 1, 1)
+            cy = 0.14 + 0.72 * (i // nx) / max(ny - 1, 1)
+            qe[q, 0] = math.log(cx / (1 - cx))
+            qe[q, 1] = math.log(cy / (1 - cy))
+            scale = WC_RIVAL if f.endswith("r") else 1.0
+            qe[q, c + WC_PAIRS[f[0]][0]] = WC_PLANT[f.rstrip("r")] * scale
+        w = sd["transformer.reference_points.weight"]
+        w.zero_()
+        w[0, 0] = 1.0
+        w[1, 1] = 1.0
+        sd["transformer.reference_points.bias"].zero_()
+        for i in range(n_layers):
+            p = "transformer.decoder.layers.%d." % i
+            for k, pair in WC_PAIRS.items():
+                for ch in pair:
+                    for name in ("self_attn.out_proj", "cross_attn.output_proj", "linear2"):
+                        sd[p + name + ".weight"][ch].zero_()
+                        sd[p + name + ".bias"][ch] = 0.0
+                    for name in ("norm1", "norm2", "norm3"):
+                        last = i == n_layers - 1 and name == "norm3"
+                        sd[p + name + ".weight"][ch] = WC_LN_GAIN * (WC_RHO[k] if last else 1.0)
+                        sd[p + name + ".bias"][ch] = 0.0
+        for k in range(n_layers):
+            if "class_embed.%d.weight" % k not in sd:
+                continue
+            cw, cb = sd["class_embed.%d.weight" % k], sd["class_embed.%d.bias" % k]
+            cw.mul_(0.05)
+            cw[1:].zero_()
+            cb[1:] = -5.0
+            for kk, (ch, ref_ch) in WC_PAIRS.items():
+                cw[0, ch] = WC_HEAD[kk]
+                cw[0, ref_ch] = -WC_HEAD[kk]
+            cb[0] = WC_BIAS
+            bw, bb = sd["bbox_embed.%d.layers.2.weight" % k], sd["bbox_embed.%d.layers.2.bias" % k]
+            bw.mul_(0.0002)
+            bb.zero_()
+            if k == 0:
+                bb[2] = -3.0
+                bb[3] = -2.6
+    return model
+
+
+# small-size tracker sequences with the well-conditioned detector (tests/golden/tracker_<name>.npz from
+# make_golden_models.py wc): (model case, frames, re-identification config)
+WC_TRACKER_CASES = {
+    "cfg2_wc": ("cfg2_deformable_tracking", 64, False),
+    "cfg2_wc_reid": ("cfg2_deformable_tracking", 24, True),     # inactive_patience 5: B tracks come back after two frames
+    "cfg4_wc": ("cfg4_multi_frame_tracking", 12, False),        # multi_frame: prev_features through the Tracker's deque
+}

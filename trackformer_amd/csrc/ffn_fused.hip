@@ -351,7 +351,7 @@ ffn_fused_kernel(const float *__restrict__ X, const u32x4 *__restrict__ W1p, con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float t = F16 ? __builtin_fmaf(acch[i][0][4 * g + e], r1v[g][e], b1v[g][e]) : acch[i][0][4 * g + e] + b1v[g][e];
-                    hv[e] = (t > 0.f && hcol + 8 * g < F) ? t : 0.f;   // columns past the hidden width (last chunk only): zero
+                    hv[e] = (t < 0.f || hcol + 8 * g >= F) ? 0.f : t;   // columns past the hidden width (last chunk only): zero
                 }
                 u32x2 pc[NA];
                 split4<SP>(hv, pc);

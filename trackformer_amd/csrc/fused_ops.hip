@@ -56,8 +56,8 @@ bias_act_kernel(float *__restrict__ x, const float *__restrict__ bias, const flo
             v1 += r1;
         }
         if constexpr (RELU) {
-            v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
-            v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+            v0.x = v0.x < 0.f ? 0.f : v0.x; v0.y = v0.y < 0.f ? 0.f : v0.y; v0.z = v0.z < 0.f ? 0.f : v0.z; v0.w = v0.w < 0.f ? 0.f : v0.w;
+            v1.x = v1.x < 0.f ? 0.f : v1.x; v1.y = v1.y < 0.f ? 0.f : v1.y; v1.z = v1.z < 0.f ? 0.f : v1.z; v1.w = v1.w < 0.f ? 0.f : v1.w;
         }
         reinterpret_cast<f32x4_t *>(x)[i] = v0;
         if (two) reinterpret_cast<f32x4_t *>(x)[i1] = v1;
@@ -215,10 +215,10 @@ groupnorm_apply_kernel(const float *__restrict__ x, const double *__restrict__ w
         y.z = (v.z - s_mean[g2]) * s_rstd[g2] * ga.z + be.z;
         y.w = (v.w - s_mean[g3]) * s_rstd[g3] * ga.w + be.w;
         if (RELU) {
-            y.x = y.x > 0.f ? y.x : 0.f;
-            y.y = y.y > 0.f ? y.y : 0.f;
-            y.z = y.z > 0.f ? y.z : 0.f;
-            y.w = y.w > 0.f ? y.w : 0.f;
+            y.x = y.x < 0.f ? 0.f : y.x;
+            y.y = y.y < 0.f ? 0.f : y.y;
+            y.z = y.z < 0.f ? 0.f : y.z;
+            y.w = y.w < 0.f ? 0.f : y.w;
         }
         op[i] = y;
     }
@@ -287,10 +287,10 @@ bias_relu_maxpool_kernel(const float *__restrict__ x, const float *__restrict__ 
     }
     const f32x4_t b = reinterpret_cast<const f32x4_t *>(bias)[c4];
     m += b;
-    m.x = m.x > 0.f ? m.x : 0.f;
-    m.y = m.y > 0.f ? m.y : 0.f;
-    m.z = m.z > 0.f ? m.z : 0.f;
-    m.w = m.w > 0.f ? m.w : 0.f;
+    m.x = m.x < 0.f ? 0.f : m.x;
+    m.y = m.y < 0.f ? 0.f : m.y;
+    m.z = m.z < 0.f ? 0.f : m.z;
+    m.w = m.w < 0.f ? 0.f : m.w;
     reinterpret_cast<f32x4_t *>(out)[idx] = m;
 }
 

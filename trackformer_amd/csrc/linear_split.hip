@@ -198,7 +198,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
                 for (int r = 0; r < 16; ++r) {
                     float v = F16 ? __builtin_fmaf(acc[i][j][r], rsc, b) : acc[i][j][r] + b;
                     if constexpr (RESID) v += rv[r];
-                    if (RELU) v = v > 0.f ? v : 0.f;
+                    if (RELU) v = v < 0.f ? 0.f : v;
                     const unsigned off = base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off, 0, 0);
                 }
@@ -219,7 +219,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
                 if (row < M) {
                     float v = F16 ? __builtin_fmaf(acc[i][j][r], rsc, b) : acc[i][j][r] + b;
                     if constexpr (RESID) v += R[(size_t)row * N + col];
-                    if (RELU) v = v > 0.f ? v : 0.f;
+                    if (RELU) v = v < 0.f ? 0.f : v;
                     Y[(size_t)row * N + col] = v;
                 }
             }
@@ -433,7 +433,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = F16 ? __builtin_fmaf(acc[i][j][r], rsc, b) : acc[i][j][r] + b;
-                if (RELU) v = v > 0.f ? v : 0.f;
+                if (RELU) v = v < 0.f ? 0.f : v;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
                                                       base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
             }
@@ -461,10 +461,10 @@ conv_splitk_reduce_kernel(const float *__restrict__ part, const float *__restric
     for (; z < splits; ++z) acc += p[(long long)z * mn4];
     if (bias != nullptr) acc += reinterpret_cast<const f32x4 *>(bias)[i % (unsigned)n4];
     if (relu) {
-        acc.x = acc.x > 0.f ? acc.x : 0.f;
-        acc.y = acc.y > 0.f ? acc.y : 0.f;
-        acc.z = acc.z > 0.f ? acc.z : 0.f;
-        acc.w = acc.w > 0.f ? acc.w : 0.f;
+        acc.x = acc.x < 0.f ? 0.f : acc.x;
+        acc.y = acc.y < 0.f ? 0.f : acc.y;
+        acc.z = acc.z < 0.f ? 0.f : acc.z;
+        acc.w = acc.w < 0.f ? 0.f : acc.w;
     }
     reinterpret_cast<f32x4 *>(y)[i] = acc;
 }
@@ -612,7 +612,7 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         float v = Split<SP>::F16 ? __builtin_fmaf(acc[r], rsc, b) : acc[r] + b;
-        if (RELU) v = v > 0.f ? v : 0.f;
+        if (RELU) v = v < 0.f ? 0.f : v;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
                                               base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
     }

@@ -375,7 +375,7 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
             for (int e = 0; e < 16; ++e) {
                 float v = Split<SP>::F16 ? __builtin_fmaf(acc[i][j][e], rsc, b) : acc[i][j][e] + b;
                 if (R != nullptr) v += rv[e];
-                if (relu) v = v > 0.f ? v : 0.f;
+                if (relu) v = v < 0.f ? 0.f : v;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u, 0, 0);
             }
         }
@@ -412,10 +412,10 @@ stream_splitk_reduce_kernel(const float *__restrict__ part, const float *__restr
     if (bias != nullptr) acc += reinterpret_cast<const f32x4 *>(bias)[i % (unsigned)n4];
     if (R != nullptr) acc += reinterpret_cast<const f32x4 *>(R)[i];
     if (relu) {
-        acc.x = acc.x > 0.f ? acc.x : 0.f;
-        acc.y = acc.y > 0.f ? acc.y : 0.f;
-        acc.z = acc.z > 0.f ? acc.z : 0.f;
-        acc.w = acc.w > 0.f ? acc.w : 0.f;
+        acc.x = acc.x < 0.f ? 0.f : acc.x;
+        acc.y = acc.y < 0.f ? 0.f : acc.y;
+        acc.z = acc.z < 0.f ? 0.f : acc.z;
+        acc.w = acc.w < 0.f ? 0.f : acc.w;
     }
     reinterpret_cast<f32x4 *>(y)[i] = acc;
 }

@@ -178,10 +178,10 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
                 for (int e = 0; e < 4; ++e)
                     v[e] = Split<SP>::F16 ? __builtin_fmaf(acc[t][4 * g + e], rv[t][g][e], bv[t][g][e]) : acc[t][4 * g + e] + bv[t][g][e];
                 if (RELU) {
-                    v.x = v.x > 0.f ? v.x : 0.f;
-                    v.y = v.y > 0.f ? v.y : 0.f;
-                    v.z = v.z > 0.f ? v.z : 0.f;
-                    v.w = v.w > 0.f ? v.w : 0.f;
+                    v.x = v.x < 0.f ? 0.f : v.x;
+                    v.y = v.y < 0.f ? 0.f : v.y;
+                    v.z = v.z < 0.f ? 0.f : v.z;
+                    v.w = v.w < 0.f ? 0.f : v.w;
                 }
                 const unsigned off = ok ? pix + (unsigned)(32 * t + 8 * g + 4 * half) * 4u : 0xC0000000u;   // outside: dropped
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);

@@ -5,6 +5,7 @@ of the running interpreter, linked to libtf_msda.so by a relative rpath.
 
     python -m trackformer_amd.dropin.build_ext          # or trackformer_amd.dropin.build_ext.build()
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -23,15 +24,23 @@ def target():
 
 
 def build(force=False, verbose=False):
-    """-> path of the extension module (built if missing or older than its source / the header / the library)."""
+    """-> path of the extension module.  Rebuilt when the content hash of its source, the C-ABI header, this recipe and the
+    torch version differs from the stamp beside it (not by mtime: the gpurun snapshot does not keep mtime order).  The library
+    itself is linked dynamically: a rebuilt libtf_msda.so needs no rebuild here, the module checks tf_msda_abi_version() when
+    it is imported."""
     import torch
     from torch.utils import cpp_extension as ce
     out = target()
     lib = os.path.join(PKG, "lib", "libtf_msda.so")
     if not os.path.exists(lib):
         raise RuntimeError("build libtf_msda.so first (python -m trackformer_amd.build)")
-    deps = [SRC, os.path.join(REPO, "include", "tf_msda.h"), os.path.abspath(__file__)]
-    if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+    h = hashlib.sha256(torch.__version__.encode())
+    for d in (SRC, os.path.join(REPO, "include", "tf_msda.h"), os.path.abspath(__file__)):
+        with open(d, "rb") as f:
+            h.update(f.read())
+    key = h.hexdigest()
+    stamp = out + ".stamp"
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == key:
         return out
     os.makedirs(OUT_DIR, exist_ok=True)
     rocm = ce.ROCM_HOME or "/opt/rocm"
@@ -47,6 +56,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(key + "\n")
     return out
 
 

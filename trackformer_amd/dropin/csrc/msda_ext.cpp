@@ -145,6 +145,9 @@ std::vector<at::Tensor> ms_deform_attn_backward(const at::Tensor &value, const a
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
+    // the library is linked dynamically: refuse to bind a libtf_msda.so of another ABI (as trackformer_amd/_cabi.py does)
+    TORCH_CHECK(tf_msda_abi_version() == TF_MSDA_ABI_VERSION, "libtf_msda.so has ABI version ", tf_msda_abi_version(),
+                ", this extension was compiled against ", TF_MSDA_ABI_VERSION);
     m.doc() = "MultiScaleDeformableAttention for AMD Instinct MI355X: the reference's plugin API over libtf_msda.so";
     m.def("ms_deform_attn_forward", &ms_deform_attn_forward, "ms_deform_attn_forward", py::arg("value"), py::arg("spatial_shapes"),
           py::arg("sampling_loc"), py::arg("attn_weight"), py::arg("im2col_step") = 64);

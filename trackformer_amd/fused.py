@@ -891,3 +891,108 @@ def mha_core(qk, v, num_heads, key_padding_mask=None):
         return None
     _cabi.check(rc, "tf_mha_core_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The fp16 split product's activation range (csrc/split_product.h): activations are scaled by 2^-4 into fp16, so |x| up to
+# 65504 * 16 = 1.05e6 is representable; beyond it the hi piece is inf and the output row is NaN -- loudly: every ReLU epilogue
+# propagates NaN (v < 0 ? 0 : v, as torch.relu does), none maps it to zero.  The reference's fp32 arithmetic has no such limit,
+# so three tools make the contract explicit instead of silent:
+#   * set_check_finite(True) / TF_SPLIT_CHECK_FINITE=1 -- debug mode: every split-product call checks its result and raises a
+#     FloatingPointError naming the operation (one host synchronisation per call: not for timed runs);
+#   * audit_activation_range() -- a context manager: run the model once under it on representative input; it records the
+#     largest |activation| every split-product layer was given (and, for the fused feed-forward block, its hidden
+#     activation) and, on exit, routes each layer that came within `safety` of the limit through the SIX-TERM bf16 product
+#     (all 24 significand bits, fp32's exponent range) for the rest of the process; the report lists them;
+#   * route_six_terms(weight) -- the same routing by hand.
+# With no layer routed, no audit running and the check off the wrappers cost one comparison per call.
+import contextlib
+import functools
+
+F16_ACTIVATION_LIMIT = 65504.0 * 16.0
+_check_finite = os.environ.get("TF_SPLIT_CHECK_FINITE", "0") not in ("", "0")
+_six_term_weights = set()     # data_ptr() of weights whose layer runs the six-term product while the default is the fp16 one
+_range_audit = None           # {(operation, weight pointers): largest |activation|} while audit_activation_range() runs
+
+
+def set_check_finite(on):
+    global _check_finite
+    prev, _check_finite = _check_finite, bool(on)
+    return prev
+
+
+def route_six_terms(weight, on=True):
+    """Route every split product of this weight tensor through the six-term bf16 product (while the default is the fp16 one)."""
+    (_six_term_weights.add if on else _six_term_weights.discard)(weight.data_ptr())
+
+
+def six_term_routes():
+    return len(_six_term_weights)
+
+
+@contextlib.contextmanager
+def audit_activation_range(route=True, safety=4.0):
+    """-> report dict, filled on exit: {"limit", "largest", "layers": [(operation, weight shape, largest |activation|)...],
+    "routed": n}.  Layers whose activations came within `safety` of the fp16 product's limit are routed to six terms."""
+    global _range_audit
+    report = {"limit": F16_ACTIVATION_LIMIT, "safety": safety, "largest": 0.0, "layers": [], "routed": 0}
+    prev, _range_audit = _range_audit, {}
+    try:
+        yield report
+    finally:
+        seen, _range_audit = _range_audit, prev
+        for (name, ptrs, shapes), amax in sorted(seen.items(), key=lambda kv: -kv[1]):
+            report["layers"].append((name, shapes, amax))
+            report["largest"] = max(report["largest"], amax)
+            if route and not (amax * safety < F16_ACTIVATION_LIMIT):   # also catches NaN / inf
+                _six_term_weights.update(ptrs)
+                report["routed"] += 1
+
+
+def _amax(t):
+    return float(t.detach().abs().max()) if t is not None and t.numel() else 0.0
+
+
+def _ranged(name, weights_of, acts_of):
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapped(*a, **k):
+            global _split_terms
+            if _split_terms != 16 or not (_six_term_weights or _check_finite or _range_audit is not None):
+                return fn(*a, **k)
+            ws = [w for w in weights_of(*a, **k) if w is not None]
+            ptrs = tuple(w.data_ptr() for w in ws)
+            route6 = any(p in _six_term_weights for p in ptrs)
+            if route6:
+                _split_terms = 6
+            try:
+                y = fn(*a, **k)
+            finally:
+                if route6:
+                    _split_terms = 16
+            if y is None:
+                return y
+            if _range_audit is not None:
+                key = (name, ptrs, tuple(tuple(w.shape) for w in ws))
+                _range_audit[key] = max(_range_audit.get(key, 0.0), max(_amax(t) for t in acts_of(*a, **k)))
+            if _check_finite and not bool(torch.isfinite(y).all()):
+                raise FloatingPointError(
+                    "%s produced a non-finite result (largest |input| %.3g; the fp16 split product represents activations up to "
+                    "%.3g -- fused.audit_activation_range() routes such layers through the six-term product, "
+                    "fused.set_split_terms(6) all of them)" % (name, max(_amax(t) for t in acts_of(*a, **k)), F16_ACTIVATION_LIMIT))
+            return y
+        return wrapped
+    return deco
+
+
+def _ffn_acts(x, linear1, linear2, norm=None, residual=None):
+    hidden = F.relu(F.linear(x, linear1.weight, linear1.bias)) if _range_audit is not None else None   # audit only: the hidden activation
+    return (x, hidden)
+
+
+linear = _ranged("linear", lambda x, weight, *a, **k: (weight,), lambda x, *a, **k: (x,))(linear)
+linear_add = _ranged("linear_add", lambda x, x2, weight, *a, **k: (weight,), lambda x, x2, *a, **k: (x + x2,))(linear_add)
+ffn = _ranged("ffn", lambda x, linear1, linear2, *a, **k: (linear1.weight, linear2.weight), _ffn_acts)(ffn)
+linear_residual_norm = _ranged("linear_residual_norm", lambda x, linear, *a, **k: (linear.weight,), lambda x, *a, **k: (x,))(linear_residual_norm)
+stem_conv = _ranged("stem_conv", lambda x, weight, *a, **k: (weight,), lambda x, *a, **k: (x,))(stem_conv)
+conv3x3 = _ranged("conv3x3", lambda x, w_taps, *a, **k: (w_taps,), lambda x, *a, **k: (x,))(conv3x3)
