@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+from tests.util_msda import discontinuity_mask
 from trackformer_amd import dropin, msda
 
 pytestmark = pytest.mark.gpu
@@ -58,11 +59,13 @@ def test_compiled_module_on_device_reproduces_the_reference_goldens(ext, dev, pa
     want = z["out"].reshape(out.shape)
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=(1e-5 if f32 else 1e-12) * max(1.0, float(np.abs(want).max())))
     go = t("grad_out").reshape(out.shape).to(dev)
-    gv, gl, ga = ext.ms_deform_attn_backward(value, shapes, loc, attn, go, 64)
-    tol = 2e-4 if f32 else 1e-10     # fp32: atomics reorder sums of up to thousands of terms
-    for got, key in ((gv, "grad_value"), (gl, "grad_loc"), (ga, "grad_attn")):
-        w = z[key].reshape(got.shape)
-        np.testing.assert_allclose(got.cpu().numpy(), w, atol=tol * max(1.0, float(np.abs(w).max())))
+    gv, gl, ga = [g.cpu().numpy() for g in ext.ms_deform_attn_backward(value, shapes, loc, attn, go, 64)]
+    atol, rtol = (1e-5, 1e-4) if f32 else (1e-12, 1e-10)          # the bars of tests/test_msda_gpu.py::test_backward_golden
+    np.testing.assert_allclose(gv, z["grad_value"].reshape(gv.shape), atol=atol * 2, rtol=rtol)
+    np.testing.assert_allclose(ga, z["grad_attn"].reshape(ga.shape), atol=atol * 10, rtol=rtol)
+    keep = ~discontinuity_mask(z["loc"], z["shapes"])             # sampling points ON a pixel boundary: the one-sided derivative is a convention
+    np.testing.assert_allclose(gl[keep], z["grad_loc"].reshape(gl.shape)[keep], atol=atol * 10, rtol=rtol)
+    assert np.all(gl[~keep] == 0)                                 # CUDA semantics at the boundary (cuh:359-362)
     # the same library entry points as the ctypes form of the module
     assert torch.equal(out, msda.ms_deform_attn_forward(value, shapes, loc, attn, 64))
 

@@ -1,0 +1,488 @@
+// trackformer_amd/csrc/msda_pquad2.h -- msda_fwd_f32_pquad2: the persistent encoder forward kernel, second version.
+// Included by msda_pquad.hip inside its anonymous namespace (shares PquadGeom, the tile plan, the launch code and the
+// gather helpers of msda_quad_dev.h).  D == 32, P == 4, L <= 4, 16-byte aligned inputs, two passes of 64 (query, head)
+// pairs per tile -- the cfg-2 / cfg-3 / cfg-5 encoder; everything else stays on msda_fwd_f32_pquad.
+//
+// Why a second version.  Four rounds of measurements say the first version's time is the ~3700
+// instructions a wave executes per tile (without ANY gather it still takes 35 of its 45 us), of which the gathers' own are
+// ~1000.  Same tiles, same windows, same LDS layout, same gather -- but the ~2700 other instructions are cut to ~700:
+//
+//   * LANE j OF A QUAD OWNS LEVEL j (not point j of every level).  The 16-byte loads already deliver a level's four points
+//     to one lane: the three 4 x 4 DPP transposes per pass (and the reference-point broadcasts) disappear, every lane does the
+//     tap arithmetic of its own four points with ITS level's constants held in registers, and the gather of level l
+//     broadcasts from lane l of the quad (quad_perm [l,l,l,l]) instead of from lane `point`.
+//   * the tap arithmetic of a point is done ONCE (the first version did it for the bounding boxes and again in every
+//     level pass): floor coordinates as one packed int16 pair, the four weights, and -- after the window geometry -- the two
+//     LDS row addresses are kept in registers (7 per point).
+//   * bounding boxes as packed int16 min / max (v_pk_min_i16 / v_pk_max_i16): all four levels are reduced at once (each
+//     lane carries its own level), two DPP row rotations + two ds_bpermute steps, one 8-byte LDS store per level and wave.
+//   * window geometry per LANE (every lane works out its own level's window from the four waves' boxes; the few
+//     wave-uniform numbers the LDS-DMA loops need are read back with v_readlane): no geometry table, one barrier fewer.
+//   * LDS-DMA source offsets: 64 lanes compute the offsets of 64 window rows (8 DMA instructions' worth) at once and hand
+//     them to the issuing lanes by ds_bpermute, instead of ~14 vector instructions in front of every DMA instruction.
+//   * the tile's query list (tile-local index -> query) is worked out by 128 threads once per tile and read back from LDS,
+//     not decoded with two divisions per lane and pass.
+//   * ONE fallback path: a point outside its window and a level whose window does not fit are the same case (no staged
+//     address -> buffer loads for exactly those points, under a wave-uniform branch).
+//
+// Arithmetic: SURVEY.md Appendix A; reference ms_deform_im2col_cuda.cuh:227-237 (pixel mapping, in-range rule), :24-67
+// (bilinear taps with zero padding); fused prologue ms_deform_attn.py:69-86.  Results equal the first version's up to the
+// order of two multiplications per weight and of the softmax sum (1 ulp each).
+#ifndef TF_MSDA_PQUAD2_H_
+#define TF_MSDA_PQUAD2_H_
+
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+
+// LDS header of version 2 (ints; <= kPqHdrBytes / 4 = 512)
+constexpr int kP2OffQ = 16;               // [2 parities][4 levels][ya, yb, xa, xb]: the tile's queries of each level
+constexpr int kP2OffNom = kP2OffQ + 32;   // [2][4 levels][ny0, ny1, nx0, nx1]: nominal footprints (the window clamp)
+constexpr int kP2OffBb = kP2OffNom + 32;  // [2][4 waves][4 levels][min, max]: packed int16 pairs (x | y << 16)
+constexpr int kP2OffNq = kP2OffBb + 64;   // [2]: queries of the tile
+constexpr int kP2OffQi = kP2OffNq + 2;    // [2][128]: b * S + q of the tile's k-th query, -1 behind the last
+static_assert((kP2OffQi + 256) * 4 <= kPqHdrBytes, "LDS header of msda_fwd_f32_pquad2");
+
+constexpr int kP2Sentinel = (int)0x80008000u;   // packed floor coordinates of a point that is not in range: (-32768, -32768)
+
+__device__ __forceinline__ int p2_pack16(int x, int y)   // -> x | y << 16 (both in int16 range)
+{
+    return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(x, y));
+}
+__device__ __forceinline__ int p2_pkmin(int a, int b)
+{
+    return __builtin_bit_cast(int, __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
+}
+__device__ __forceinline__ int p2_pkmax(int a, int b)
+{
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
+}
+__device__ __forceinline__ int p2_lo16(int p) { return (int)(short)(p & 0xFFFF); }
+__device__ __forceinline__ int p2_hi16(int p) { return p >> 16; }
+// lane i <- lane i ^ MASK (MASK = 16 / 32: across the DPP rows of the wave); bp = 4 * (lane ^ MASK)
+__device__ __forceinline__ int p2_bperm(int bp, int v) { return __builtin_amdgcn_ds_bpermute(bp, v); }
+
+template <bool FUSED>
+__global__ void __launch_bounds__(kPqThreads, 3)
+msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
+{
+    constexpr int NP = 2, PT = 4, D = 32, NL = 4, PAIRS = kPqPairs;
+    constexpr unsigned ROWB = D * 4;
+    extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
+    int *s_tab = reinterpret_cast<int *>(smem);   // [H0..3 | W0..3 | start0..3]
+    int *s_q = s_tab + kP2OffQ;
+    int *s_nom = s_tab + kP2OffNom;
+    int *s_bb = s_tab + kP2OffBb;
+    int *s_nq = s_tab + kP2OffNq;
+    int *s_qi = s_tab + kP2OffQi;
+    unsigned char *s_rows = smem + kPqHdrBytes;   // rows 0, 1: zeros; the windows start at row 2
+
+    const int L = da.L, M = da.M, S = da.S, LP = L * PT;
+    const int G = (int)gridDim.x;
+    int item = (int)blockIdx.x;
+    if (item >= pg.n_items) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = threadIdx.x & 3;            // the level this lane owns
+    const int quad = threadIdx.x >> 2;
+    const int hsel = (quad >> 2) & 1;
+    const unsigned rbA = (unsigned)(hsel * 64 + sub * 16), rbB = (unsigned)((1 - hsel) * 64 + sub * 16);
+    const unsigned lds_rows = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)s_rows);
+    const unsigned ldsA = lds_rows + rbA, ldsB = lds_rows + rbB;
+    const int bp16 = 4 * (lane ^ 16), bp32 = 4 * (lane ^ 32), bp8 = 4 * (lane >> 3);
+    const unsigned long long lanes_of_level0 = 0x1111111111111111ull;
+
+    auto stamp = [&](int i) {
+        if (pg.trace != nullptr && threadIdx.x == 0 && i < 16)
+            pg.trace[(size_t)blockIdx.x * 16 + i] = __builtin_amdgcn_s_memrealtime();
+    };
+    auto decode_item = [&](int it, int &b, int &ty, int &tx, int &m) {
+        m = it % M;
+        int t = it / M;
+        tx = t % pg.tiles_x;
+        t /= pg.tiles_x;
+        ty = t % pg.tiles_y;
+        b = t / pg.tiles_y;
+    };
+    // ---- per-tile tables.  Step 1 (threads 0..15): query partition + nominal footprints of every level ------------------
+    auto tables_1 = [&](int par, int ty, int tx) {
+        if (threadIdx.x < 4 * NL) {
+            const int l = threadIdx.x >> 2, k = threadIdx.x & 3;
+            int qv = 0, nv = 0;
+            if (l < L) {
+                const unsigned H0 = (unsigned)lt.H[0], W0 = (unsigned)lt.W[0];
+                const unsigned Hl = (unsigned)lt.H[l], Wl = (unsigned)lt.W[l];
+                const unsigned y0 = (unsigned)ty * pg.TH, y1 = min(H0, y0 + (unsigned)pg.TH);
+                const unsigned x0 = (unsigned)tx * pg.TW, x1 = min(W0, x0 + (unsigned)pg.TW);
+                qv = k == 0 ? tfq_tile_bound(y0, Hl, H0) : k == 1 ? tfq_tile_bound(y1, Hl, H0)
+                     : k == 2 ? tfq_tile_bound(x0, Wl, W0) : tfq_tile_bound(x1, Wl, W0);
+                int lo, hi;
+                if (k < 2)
+                    tfq_nominal((int)y0, (int)y1, (int)Hl, 1.f / (float)H0, pg.HY, &lo, &hi);
+                else
+                    tfq_nominal((int)x0, (int)x1, (int)Wl, 1.f / (float)W0, pg.HX, &lo, &hi);
+                nv = (k & 1) ? hi : lo;
+            }
+            s_q[(par * 4 + l) * 4 + k] = qv;       // a level the call does not have: an empty range
+            s_nom[(par * 4 + l) * 4 + k] = nv;
+        }
+    };
+    // ---- step 2 (threads 0..127, one barrier after step 1): the tile's query list -----------------------------------------
+    auto tables_2 = [&](int par, int b) {
+        if (threadIdx.x < NP * PAIRS) {
+            const int tq = (int)threadIdx.x;
+            const int *q4 = s_q + par * 16;
+            int qoff = 0, q = -1;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const int ya = q4[4 * l], yb = q4[4 * l + 1], xa = q4[4 * l + 2], xb = q4[4 * l + 3];
+                const int nx = xb - xa, n = (yb - ya) * nx;
+                const int rr = tq - qoff;
+                if (rr >= 0 && rr < n) {
+                    // rr / nx: (rr + 0.5) / nx is at least 0.5 / nx away from an integer, far more than the float error
+                    const int yy = (int)(((float)rr + 0.5f) * __builtin_amdgcn_rcpf((float)nx));
+                    const int xx = rr - yy * nx;
+                    q = b * S + s_tab[8 + l] + (ya + yy) * s_tab[4 + l] + xa + xx;
+                }
+                qoff += n;
+            }
+            s_qi[par * (NP * PAIRS) + tq] = q;
+            if (tq == 0) s_nq[par] = qoff;   // <= NP * PAIRS (the host checked the maximum)
+        }
+    };
+
+    if (threadIdx.x < NL) {
+        const int l = threadIdx.x;
+        s_tab[l] = l < L ? lt.H[l] : 1;
+        s_tab[4 + l] = l < L ? lt.W[l] : 1;
+        s_tab[8 + l] = l < L ? lt.start[l] : 0;
+    }
+    if (threadIdx.x < 2 * D) reinterpret_cast<float *>(s_rows)[threadIdx.x] = 0.f;   // rows 0, 1
+    int cb, cty, ctx, cm;
+    decode_item(item, cb, cty, ctx, cm);
+    tables_1(0, cty, ctx);
+    stamp(0);
+    __syncthreads();
+    tables_2(0, cb);
+
+    // wave-uniform level constants (LDS-DMA loops) and this lane's own level
+    int Hs[NL], Ws[NL], starts[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        Hs[l] = __builtin_amdgcn_readfirstlane(s_tab[l]);
+        Ws[l] = __builtin_amdgcn_readfirstlane(s_tab[4 + l]);
+        starts[l] = __builtin_amdgcn_readfirstlane(s_tab[8 + l]);
+    }
+    const bool lvalid = sub < L;
+    const int my_H = s_tab[sub], my_W = s_tab[4 + sub], my_start = s_tab[8 + sub];
+    const float my_Hf = (float)my_H, my_Wf = (float)my_W;
+    const float my_inv_h = __builtin_amdgcn_rcpf(my_Hf), my_inv_w = __builtin_amdgcn_rcpf(my_Wf);
+    const unsigned lsub = (unsigned)(lvalid ? sub : 0);
+    const unsigned rowbytes = (unsigned)(M * D) * 4u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(da.value), 0, da.value_bytes, 0x00020000);
+    __syncthreads();   // the first tile's query list is visible
+
+    // ---- a tile's points: per pass the four points of this lane's level --------------------------------------------------
+    int pk[NP][PT];               // packed floor coordinates (x0 | y0 << 16), kP2Sentinel: not in range
+    float w[NP][PT][4];           // bilinear weights x attention weight
+    unsigned a0[NP][PT], a1[NP][PT];   // LDS byte offsets of the rows (y0, x0) / (y0 + 1, x0); 0: not staged (rows 0, 1 are zeros)
+    unsigned pair32[NP];          // (b * S + q) * M + m
+    bool live[NP];
+    int nq = 0;
+
+    // loads -> softmax / locations (fused entry) -> tap arithmetic -> bounding boxes (filed in s_bb[par])
+    auto prologue = [&](int par, int m) {
+        nq = __builtin_amdgcn_readfirstlane(s_nq[par]);
+        f32x4_t xy0[NP], xy1[NP], a4[NP];
+        float2 rp[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            const int bqs = s_qi[par * (NP * PAIRS) + ps * PAIRS + quad];
+            live[ps] = bqs >= 0;
+            const unsigned bq = live[ps] ? (unsigned)bqs : 0u;
+            pair32[ps] = bq * (unsigned)M + (unsigned)m;
+            if constexpr (!FUSED) {
+                const unsigned pr = pair32[ps] * (unsigned)LP + lsub * (unsigned)PT;
+                xy0[ps] = ldg_f4(da.loc, pr * 8u);
+                xy1[ps] = ldg_f4(da.loc, pr * 8u + 16u);
+                a4[ps] = ldg_f4(da.attn, pr * 4u);
+                rp[ps] = float2{0.f, 0.f};
+            } else {
+                const unsigned row = bq * (unsigned)da.fa.ld;
+                const unsigned s = (unsigned)(m * LP) + lsub * (unsigned)PT;
+                xy0[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.off_col + s * 2u) * 4u);
+                xy1[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.off_col + s * 2u) * 4u + 16u);
+                a4[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.logit_col + s) * 4u);
+                rp[ps] = ldg_f2(da.fa.ref, (bq * (unsigned)L + lsub) * 8u);   // ref_dim == 2: this level's reference point
+            }
+        }
+        int mn = 0x7FFF7FFF, mx = kP2Sentinel;   // packed int16 (x, y) bounding box of this lane's in-range points
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            float sx[PT] = {xy0[ps].x, xy0[ps].z, xy1[ps].x, xy1[ps].z};
+            float sy[PT] = {xy0[ps].y, xy0[ps].w, xy1[ps].y, xy1[ps].w};
+            float sa[PT] = {a4[ps].x, a4[ps].y, a4[ps].z, a4[ps].w};
+            if constexpr (FUSED && !(kPqAblate & 16)) {
+#pragma clang fp contract(off)   // keep the reference's operation order (no fused multiply-add)
+                // softmax over the pair's L * P logits (ms_deform_attn.py:70-71): this lane's four, then across the quad
+#pragma unroll
+                for (int k = 0; k < PT; ++k) sa[k] = lvalid ? sa[k] : -__builtin_inff();
+                float m4 = fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3]));
+                m4 = fmaxf(m4, dpp_f<kDppQuadXor1>(m4));
+                m4 = fmaxf(m4, dpp_f<kDppQuadXor2>(m4));
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < PT; ++k) {
+                    sa[k] = lvalid ? __expf(sa[k] - m4) : 0.f;
+                    sum += sa[k];
+                }
+                sum += dpp_f<kDppQuadXor1>(sum);
+                sum += dpp_f<kDppQuadXor2>(sum);
+                const float inv_sum = __builtin_amdgcn_rcpf(sum);   // (v_rcp_f32, 1 ulp: as in the first version)
+#pragma unroll
+                for (int k = 0; k < PT; ++k) {
+                    sa[k] = sa[k] * inv_sum;
+                    sx[k] = rp[ps].x + sx[k] * my_inv_h;   // x / H_l (as the reference writes it: ms_deform_attn.py:78-79)
+                    sy[k] = rp[ps].y + sy[k] * my_inv_w;   // y / W_l
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                const float xr = __builtin_fmaf(sx[k], my_Wf, -0.5f);   // cuh:227-228 with one rounding (see make_tap, msda_hip.hip)
+                const float yr = __builtin_fmaf(sy[k], my_Hf, -0.5f);
+                const bool in = live[ps] && lvalid && (yr > -1.f) && (xr > -1.f) && (yr < my_Hf) && (xr < my_Wf);
+                const float x = in ? xr : 0.f, y = in ? yr : 0.f;
+                const float xf = __builtin_floorf(x), yf = __builtin_floorf(y);
+                const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
+                const float a = in ? sa[k] : 0.f;
+                const float ga = gy * a, fa = fy * a;
+                w[ps][k][0] = ga * gx;
+                w[ps][k][1] = ga * fx;
+                w[ps][k][2] = fa * gx;
+                w[ps][k][3] = fa * fx;
+                const int p = p2_pack16((int)xf, (int)yf);
+                pk[ps][k] = in ? p : kP2Sentinel;
+                if constexpr ((kPqAblate & 4) == 0) {
+                    mn = p2_pkmin(mn, in ? p : 0x7FFF7FFF);
+                    mx = p2_pkmax(mx, in ? p : kP2Sentinel);
+                }
+            }
+        }
+        if constexpr ((kPqAblate & 4) != 0) {   // the whole level: the geometry clamps it to the nominal footprint
+            mn = p2_pack16(-1, -1);
+            mx = p2_pack16(my_W, my_H);
+        }
+        // lanes of one level: the 16 quads of the wave (two rotations inside a DPP row, then across the four rows)
+        mn = p2_pkmin(mn, dpp_i<kDppRowRor4>(mn));
+        mx = p2_pkmax(mx, dpp_i<kDppRowRor4>(mx));
+        mn = p2_pkmin(mn, dpp_i<kDppRowRor8>(mn));
+        mx = p2_pkmax(mx, dpp_i<kDppRowRor8>(mx));
+        mn = p2_pkmin(mn, p2_bperm(bp16, mn));
+        mx = p2_pkmax(mx, p2_bperm(bp16, mx));
+        mn = p2_pkmin(mn, p2_bperm(bp32, mn));
+        mx = p2_pkmax(mx, p2_bperm(bp32, mx));
+        if (lane < NL) {
+            int2 *slot = reinterpret_cast<int2 *>(s_bb + ((par * 4 + wave) * 4 + lane) * 2);
+            *slot = int2{mn, mx};
+        }
+    };
+
+    prologue(0, cm);
+    stamp(2);
+
+    int par = 0;
+    int iter = 0;
+    while (true) {
+        const int next_item = item + G;
+        const bool has_next = next_item < pg.n_items;   // uniform
+        int nb = 0, nty = 0, ntx = 0, nm = 0;
+        if (has_next) decode_item(next_item, nb, nty, ntx, nm);
+
+        __syncthreads();   // B0: the tile's bounding boxes are filed; every wave is done with the previous tile's windows
+        if (iter == 0) stamp(3);
+
+        // ---- window geometry, per lane for its own level (msda_quad_geom.h tfq_window) ----------------------------------
+        int g_wx0, g_wy0, g_limx, g_limy, g_ww, g_rows, g_roff;
+        {
+            const int2 *bb = reinterpret_cast<const int2 *>(s_bb + par * 32) + sub;   // + 4 * wave
+            const int2 b0 = bb[0], b1 = bb[4], b2 = bb[8], b3 = bb[12];
+            const int4 nom = *reinterpret_cast<const int4 *>(s_nom + (par * 4 + sub) * 4);   // ny0, ny1, nx0, nx1
+            const int mn = p2_pkmin(p2_pkmin(b0.x, b1.x), p2_pkmin(b2.x, b3.x));
+            const int mx = p2_pkmax(p2_pkmax(b0.y, b1.y), p2_pkmax(b2.y, b3.y));
+            const int bx0 = p2_lo16(mn), by0 = p2_hi16(mn), bx1 = p2_lo16(mx), by1 = p2_hi16(mx);
+            const int wx0 = tfq_max(bx0, nom.z), wx1 = tfq_min(bx1, nom.w - 1) + 1;
+            const int wy0 = tfq_max(by0, nom.x), wy1 = tfq_min(by1, nom.y - 1) + 1;
+            const bool some = lvalid && bx0 <= bx1 && by0 <= by1 && wx0 < wx1 && wy0 < wy1;
+            const int ww = some ? wx1 - wx0 + 1 : 0, wh = some ? wy1 - wy0 + 1 : 0;
+            const int rows = ww * wh, rows8 = (rows + 7) & ~7;
+            // round 0: level 0 alone; round 1: levels 1..3 packed one behind the other, all or nothing per level
+            const int cap = pg.cap_rows;
+            const int r1 = dpp_i<0x55>(rows), r2 = dpp_i<0xAA>(rows), r3 = dpp_i<0xFF>(rows);
+            const int e1 = dpp_i<0x55>(rows8), e2 = dpp_i<0xAA>(rows8);
+            const bool fit1 = r1 <= cap;
+            const int u2 = fit1 ? e1 : 0;
+            const bool fit2 = r2 <= cap - u2;
+            const int u3 = u2 + (fit2 ? e2 : 0);
+            const bool fit3 = r3 <= cap - u3;
+            const bool fit = sub == 0 ? rows <= cap : sub == 1 ? fit1 : sub == 2 ? fit2 : fit3;
+            const bool stage = some && fit;
+            g_roff = 2 + (sub == 2 ? u2 : sub == 3 ? u3 : 0);
+            g_wx0 = stage ? wx0 : kQuadFar;
+            g_wy0 = stage ? wy0 : kQuadFar;
+            g_ww = stage ? ww : 0;
+            g_rows = stage ? rows : 0;
+            g_limx = stage ? ww - 2 : 0;
+            g_limy = stage ? wh - 2 : 0;
+        }
+        const unsigned g_pitchb = (unsigned)g_ww * ROWB;
+        const unsigned g_roffb = (unsigned)g_roff * ROWB;   // (relative to s_rows: the gather adds ldsA / ldsB)
+        // what the LDS-DMA loops need, wave-uniform: lane l of the wave owns level l
+        int u_wx0[NL], u_wy0[NL], u_ww[NL], u_rows[NL], u_roff[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            u_wx0[l] = __builtin_amdgcn_readlane(g_wx0, l);
+            u_wy0[l] = __builtin_amdgcn_readlane(g_wy0, l);
+            u_ww[l] = __builtin_amdgcn_readlane(g_ww, l);
+            u_rows[l] = __builtin_amdgcn_readlane(g_rows, l);
+            u_roff[l] = __builtin_amdgcn_readlane(g_roff, l);
+        }
+
+        // ---- LDS row addresses of every point; which (pass, level) have points that are not staged --------------------------
+        unsigned long long ngm[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            ngm[ps] = 0ull;
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                const int p = pk[ps][k];
+                const int dx = p2_lo16(p) - g_wx0, dy = p2_hi16(p) - g_wy0;
+                const bool staged = (unsigned)dx <= (unsigned)g_limx && (unsigned)dy <= (unsigned)g_limy;
+                const unsigned lo = g_roffb + (unsigned)dy * g_pitchb + ((unsigned)dx << 7);
+                a0[ps][k] = staged ? lo : 0u;                  // rows 0, 1 are zeros
+                a1[ps][k] = staged ? lo + g_pitchb : 0u;
+                ngm[ps] |= __ballot(p != kP2Sentinel && !staged);
+            }
+        }
+        const unsigned head_base = (unsigned)((((long long)cb * S * M + cm) * D) * 4);
+        const unsigned my_lvl_base = head_base + (unsigned)my_start * rowbytes;
+
+        // ---- staging: 64 lanes work out the source offsets of 64 window rows (8 DMA instructions), ds_bpermute hands each
+        //      DMA lane its row's offset; a DMA wave-instruction moves 8 rows of 128 B.  Pixels outside the level (extended
+        //      coordinates -1 / size) get an out-of-range offset: the hardware writes zeros.
+        auto stage_level = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            const int nrows = u_rows[l];
+            if (nrows <= 0) return;   // uniform
+            const int nchunks = (nrows + 7) >> 3;
+            const int H = Hs[l], W = Ws[l], ww = u_ww[l], wx0 = u_wx0[l], wy0 = u_wy0[l], roff = u_roff[l];
+            const unsigned lvl_base = head_base + (unsigned)starts[l] * rowbytes;
+            const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
+            constexpr int NW = kPqThreads / 64;
+            for (int c0 = wave; c0 < nchunks; c0 += 8 * NW) {   // this wave's chunks c0, c0 + NW, ...: 8 per group
+                const int r = (c0 + NW * (lane >> 3)) * 8 + (lane & 7);   // the window row this lane resolves
+                const int wy = (int)(((float)r + 0.5f) * inv_ww);         // r / ww (r < 2^16: exact, see tables_2)
+                const int wx = r - wy * ww;
+                const int py = wy0 + wy, px = wx0 + wx;                    // extended coordinates: may be -1 or size
+                const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
+                const unsigned off = ok ? lvl_base + (unsigned)(py * W + px) * rowbytes : kOobBase;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int c = c0 + NW * g;
+                    if (c >= nchunks) break;   // uniform
+                    const unsigned src = (unsigned)__builtin_amdgcn_ds_bpermute(bp8 + 32 * g, (int)off) + (unsigned)(lane & 7) * 16u;
+                    if constexpr (!(kPqAblate & 2))
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128), 16, src, 0, 0, 0);
+                }
+            }
+        };
+
+        f32x4_t accA[NP], accB[NP];
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            accA[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            accB[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- one level: the staged points from LDS, the others (if the wave has any) by buffer loads --------------------------
+        auto gather_level = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            if (l >= L) return;   // uniform
+#pragma unroll
+            for (int ps = 0; ps < NP; ++ps) {
+                if (ps * PAIRS >= nq) continue;   // uniform
+                if constexpr ((kPqAblate & 1) != 0) {
+#pragma unroll
+                    for (int k = 0; k < PT; ++k) accA[ps].x += (float)(a0[ps][k] + a1[ps][k]) * w[ps][k][0];   // keeps the records alive
+                } else {
+#pragma unroll
+                    for (int k = 0; k < PT; ++k)
+                        quad_taps_lds<l>(a0[ps][k], a1[ps][k], w[ps][k], ldsA, ldsB, accA[ps], accB[ps]);
+                }
+                if constexpr ((kPqAblate & 32) != 0) continue;
+                if ((ngm[ps] & (lanes_of_level0 << l)) == 0ull) continue;   // uniform: every point of this level and pass was staged
+#pragma unroll
+                for (int k = 0; k < PT; ++k) {
+                    const int p = pk[ps][k];
+                    const int x0 = p2_lo16(p), y0 = p2_hi16(p);
+                    const bool need = p != kP2Sentinel && a0[ps][k] == 0u;   // in range, not staged (a staged row offset is >= 256)
+                    const bool kx0 = need && (x0 >= 0), kx1 = need && (x0 + 1 <= my_W - 1);
+                    const bool ky0 = (y0 >= 0), ky1 = (y0 + 1 <= my_H - 1);
+                    const int r0 = y0 * my_W + x0;
+                    // staged / invalid taps: kOobBase + (lane offset < 128) is still out of range -> hardware zero
+                    const unsigned g4[4] = {(ky0 && kx0) ? my_lvl_base + (unsigned)r0 * rowbytes : kOobBase,
+                                            (ky0 && kx1) ? my_lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase,
+                                            (ky1 && kx0) ? my_lvl_base + (unsigned)(r0 + my_W) * rowbytes : kOobBase,
+                                            (ky1 && kx1) ? my_lvl_base + (unsigned)(r0 + my_W + 1) * rowbytes : kOobBase};
+                    quad_taps_global<l>(rsrc, g4, w[ps][k], rbA, rbB, accA[ps], accB[ps]);
+                }
+            }
+        };
+
+        // ---- round 0: level 0 ----
+        stage_level(std::integral_constant<int, 0>{});
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA landed
+        __syncthreads();                      // B1: ... everybody's
+        if (iter == 0) stamp(4);
+        if (has_next) tables_1(par ^ 1, nty, ntx);   // off the staging path; visible after B2
+        if (iter == 0) stamp(5);
+        gather_level(std::integral_constant<int, 0>{});
+        if (iter == 0) stamp(6);
+
+        // ---- round 1: levels 1..3 in the same rows ----
+        __syncthreads();   // B2: every wave is done reading level 0's window
+        if (iter == 0) stamp(11);
+        if (has_next) tables_2(par ^ 1, nb);   // visible after B3
+        stage_level(std::integral_constant<int, 1>{});
+        stage_level(std::integral_constant<int, 2>{});
+        stage_level(std::integral_constant<int, 3>{});
+        if (iter == 0) stamp(12);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        if (iter == 0) stamp(13);
+        __syncthreads();   // B3
+        if (iter == 0) stamp(7);
+        gather_level(std::integral_constant<int, 1>{});
+        gather_level(std::integral_constant<int, 2>{});
+        gather_level(std::integral_constant<int, 3>{});
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps)
+            if (live[ps] && (!(kPqAblate & 8) || accA[ps].x == 12345.678f)) {
+                float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(da.out) + (size_t)(pair32[ps] * (unsigned)(D * 4)));
+                *reinterpret_cast<f32x4_t *>(o + rbA / 4) = accA[ps];
+                *reinterpret_cast<f32x4_t *>(o + rbB / 4) = accB[ps];
+            }
+        if (iter == 0) stamp(8);
+        if (!has_next) break;
+
+        // ---- the next tile: its points, prologue arithmetic and bounding boxes ----
+        cb = nb;
+        cm = nm;
+        prologue(par ^ 1, nm);
+        if (iter == 0) stamp(9);
+        item = next_item;
+        par ^= 1;
+        ++iter;
+    }
+    stamp(10);
+}
+
+#endif  // TF_MSDA_PQUAD2_H_
