@@ -153,6 +153,15 @@ static inline void hipLaunchKernelGGL(void (*k)(P...), dim3 grid, dim3 block, si
 #define __builtin_amdgcn_readlane(v, l) ::hipemu::shuffle_from((v), (int)(l), (v), __LINE__)
 #define __builtin_amdgcn_mov_dpp(v, ctrl, rm, bm, bc) ::hipemu::mov_dpp((v), (v), (ctrl), (rm), (bm), (bc), __LINE__)
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) ::hipemu::mov_dpp((old), (v), (ctrl), (rm), (bm), (bc), __LINE__)
+// ds_bpermute_b32: lane i <- v of lane (addr_i / 4) mod 64
+#define __builtin_amdgcn_ds_bpermute(addr, v) ::hipemu::shuffle_from((int)(v), (int)((((unsigned)(addr)) >> 2) & 63u), (int)(v), __LINE__)
+typedef short hipemu_s16x2 __attribute__((ext_vector_type(2)));
+static inline hipemu_s16x2 hipemu_cvt_pk_i16(int a, int b)   // v_cvt_pk_i16_i32: {sat16(a), sat16(b)}
+{
+    auto sat = [](int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); };
+    return hipemu_s16x2{sat(a), sat(b)};
+}
+#define __builtin_amdgcn_cvt_pk_i16(a, b) hipemu_cvt_pk_i16((a), (b))
 
 static inline int __lane_id() { return ::hipemu::lane_id(); }
 static inline bool hipemu_any(bool p, unsigned site) { return ::hipemu::ballot(p, nullptr, site) != 0; }

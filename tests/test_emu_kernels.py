@@ -98,14 +98,18 @@ def _with_d(value, D):
     return rng.standard_normal(value.shape[:3] + (D,), dtype=np.float32)
 
 
-@pytest.fixture(params=["quad", "pquad"])
+@pytest.fixture(params=["quad", "pquad", "pquad_v1"])
 def tiled(request):
+    """quad: one tile per workgroup; pquad: the persistent kernel (version 2 where it applies: msda_pquad2.h); pquad_v1: the
+    first version everywhere."""
     L = emu_lib.lib()
     prev_t = L.tf_msda_set_tiled(2)
-    prev_p = L.tf_msda_set_option(b"pquad", 1 if request.param == "pquad" else 0)
+    prev_p = L.tf_msda_set_option(b"pquad", 0 if request.param == "quad" else 1)
+    prev_v = L.tf_msda_set_option(b"pquad_v2", 0 if request.param == "pquad_v1" else 1)
     yield request.param
     L.tf_msda_set_tiled(prev_t)
     L.tf_msda_set_option(b"pquad", prev_p)
+    L.tf_msda_set_option(b"pquad_v2", prev_v)
 
 
 @pytest.mark.parametrize("name,shapes,mode,N,D", ENC_CASES, ids=[c[0] for c in ENC_CASES])
@@ -142,7 +146,10 @@ def _fused_case(shapes, N, D, seed, M=8, P=4, spread=2.0):
 
 PQUAD_VARIANTS = [dict(), dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pquad_wg_per_cu=2),
                   dict(pquad_wide=0), dict(pquad_lds_kb=24),
-                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1)]
+                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1),
+                  # version 2 (the default where it applies) under other plans, and version 1 at the default plan
+                  dict(pquad_v2=0), dict(pquad_v2=0, pquad_lds_kb=24), dict(pquad_wg_per_cu=1), dict(pquad_halo_y=2, pquad_halo_x=2),
+                  dict(pquad_lds_kb=12)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items()) or "default"

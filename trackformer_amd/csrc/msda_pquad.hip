@@ -771,13 +771,16 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
     stamp(10);
 }
 
+#include "msda_pquad2.h"
+
 // ---- options, tile plan, launch ------------------------------------------------------------------------------
-enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoCount };
+enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoV2, kPoCount };
 const char *const kPqOptNames[kPoCount] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
                                            "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew",
-                                           "pquad"};
-const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on"};
-constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1};   // 3 x 52 KB = 156 KB of the CU's 160
+                                           "pquad", "pquad_v2"};
+const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on", "v2"};
+// v2: msda_fwd_f32_pquad2 (msda_pquad2.h) where it applies (D == 32, two passes, 16-byte aligned inputs)
+constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 1};   // 3 x 52 KB = 156 KB of the CU's 160
 std::atomic<int> g_pq_opt[kPoCount];
 std::atomic<int> g_pq_epoch{0};
 std::atomic<unsigned long long *> g_pq_trace{nullptr};
@@ -834,6 +837,7 @@ struct PqPlan {
     size_t lds;
     int ta_mask, npass, wgs, pf;
     bool wide;
+    bool v2;
 };
 
 int pq_num_cus()
@@ -936,6 +940,7 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     r.geom.skew = o[kPoSkew];
     r.geom.cus = pq_num_cus();
     r.wide = o[kPoWide] != 0;
+    r.v2 = o[kPoV2] != 0;
     r.ta_mask = ta;
     r.npass = npass;
     r.wgs = wgs;
@@ -996,8 +1001,10 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
                da.fa.logit_col % 4 == 0;
     else
         wide = wide && ((uintptr_t)da.loc % 16 == 0) && ((uintptr_t)da.attn % 16 == 0);
-    const void *fn = D == 36 ? (fused ? pq_kernel_d36<true>(wide) : pq_kernel_d36<false>(wide))
-                             : (fused ? pq_kernel<true>(pl.npass, wide) : pq_kernel<false>(pl.npass, wide));
+    const bool v2 = pl.v2 && D == 32 && pl.npass == 2 && wide && pl.ta_mask == 0;
+    const void *fn = v2 ? (fused ? (const void *)&msda_fwd_f32_pquad2<true> : (const void *)&msda_fwd_f32_pquad2<false>)
+                     : D == 36 ? (fused ? pq_kernel_d36<true>(wide) : pq_kernel_d36<false>(wide))
+                               : (fused ? pq_kernel<true>(pl.npass, wide) : pq_kernel<false>(pl.npass, wide));
     // the dynamic-LDS limit is a per-function, per-device attribute: cheap, set on every first (function, device)
     struct Raised { const void *fn; int dev; };
     static std::atomic<int> n_raised{0};

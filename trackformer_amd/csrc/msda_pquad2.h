@@ -36,11 +36,21 @@ typedef short s16x2_t __attribute__((ext_vector_type(2)));
 // LDS header of version 2 (ints; <= kPqHdrBytes / 4 = 512)
 constexpr int kP2OffQ = 16;               // [2 parities][4 levels][ya, yb, xa, xb]: the tile's queries of each level
 constexpr int kP2OffNom = kP2OffQ + 32;   // [2][4 levels][ny0, ny1, nx0, nx1]: nominal footprints (the window clamp)
-constexpr int kP2OffBb = kP2OffNom + 32;  // [2][4 waves][4 levels][min, max]: packed int16 pairs (x | y << 16)
+constexpr int kP2OffBb = kP2OffNom + 48;  // [2][4 waves][4 levels][min, max]: packed int16 pairs (x | y << 16)
 constexpr int kP2OffNq = kP2OffBb + 64;   // [2]: queries of the tile
 constexpr int kP2OffQi = kP2OffNq + 2;    // [2][128]: b * S + q of the tile's k-th query, -1 behind the last
 static_assert((kP2OffQi + 256) * 4 <= kPqHdrBytes, "LDS header of msda_fwd_f32_pquad2");
 
+// staging of the windows: LDS-DMA (buffer_load ... lds), or buffer loads into registers + ds_write_b128 (TF_P2_STAGE_LDS=0)
+#ifndef TF_P2_STAGE_LDS
+#define TF_P2_STAGE_LDS 1
+#endif
+constexpr bool kP2StageByLds = TF_P2_STAGE_LDS != 0;
+// experiment: level 0 (the largest window) is not staged at all -- its taps go by buffer loads (the texture path)
+#ifndef TF_P2_L0_BY_LOADS
+#define TF_P2_L0_BY_LOADS 0
+#endif
+constexpr bool kP2Level0ByLoads = TF_P2_L0_BY_LOADS != 0;
 constexpr int kP2Sentinel = (int)0x80008000u;   // packed floor coordinates of a point that is not in range: (-32768, -32768)
 
 __device__ __forceinline__ int p2_pack16(int x, int y)   // -> x | y << 16 (both in int16 range)
@@ -59,6 +69,56 @@ __device__ __forceinline__ int p2_lo16(int p) { return (int)(short)(p & 0xFFFF);
 __device__ __forceinline__ int p2_hi16(int p) { return p >> 16; }
 // lane i <- lane i ^ MASK (MASK = 16 / 32: across the DPP rows of the wave); bp = 4 * (lane ^ MASK)
 __device__ __forceinline__ int p2_bperm(int bp, int v) { return __builtin_amdgcn_ds_bpermute(bp, v); }
+
+// One point's four taps from LDS windows, one window row (two taps, four 16-byte reads) at a time: half the registers in
+// flight of quad_taps_lds (msda_quad_dev.h), same sums in the same order.
+template <int K>
+__device__ __forceinline__ void quad_taps_lds_rows(unsigned a0, unsigned a1, const float (&w)[4], unsigned ldsA, unsigned ldsB,
+                                                   f32x4_t &accA, f32x4_t &accB)
+{
+    constexpr int C = K * 0x55;   // quad_perm [K,K,K,K]
+    {
+        const unsigned p0a = dpp_u<C>(a0) + ldsA, p0b = dpp_u<C>(a0) + ldsB;
+        const float W0 = dpp_f<C>(w[0]), W1 = dpp_f<C>(w[1]);
+        const f32x4_t v00a = lds_read16(p0a), v01a = lds_read16(p0a + 128u);
+        const f32x4_t v00b = lds_read16(p0b), v01b = lds_read16(p0b + 128u);
+        accA += v00a * W0;
+        accB += v00b * W0;
+        accA += v01a * W1;
+        accB += v01b * W1;
+    }
+    {
+        const unsigned p1a = dpp_u<C>(a1) + ldsA, p1b = dpp_u<C>(a1) + ldsB;
+        const float W2 = dpp_f<C>(w[2]), W3 = dpp_f<C>(w[3]);
+        const f32x4_t v10a = lds_read16(p1a), v11a = lds_read16(p1a + 128u);
+        const f32x4_t v10b = lds_read16(p1b), v11b = lds_read16(p1b + 128u);
+        accA += v10a * W2;
+        accB += v10b * W2;
+        accA += v11a * W3;
+        accB += v11b * W3;
+    }
+}
+
+// ... and by buffer loads (the points that are not staged), two taps at a time.
+template <int K>
+__device__ __forceinline__ void quad_taps_global_rows(const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&g)[4], const float (&w)[4],
+                                                      unsigned rbA, unsigned rbB, f32x4_t &accA, f32x4_t &accB)
+{
+    constexpr int C = K * 0x55;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const unsigned G0 = dpp_u<C>(g[2 * h]), G1 = dpp_u<C>(g[2 * h + 1]);
+        const float W0 = dpp_f<C>(w[2 * h]), W1 = dpp_f<C>(w[2 * h + 1]);
+        const u32x4_t v0a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G0 + rbA, 0, 0);
+        const u32x4_t v0b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G0 + rbB, 0, 0);
+        const u32x4_t v1a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G1 + rbA, 0, 0);
+        const u32x4_t v1b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G1 + rbB, 0, 0);
+        accA += __builtin_bit_cast(f32x4_t, v0a) * W0;
+        accB += __builtin_bit_cast(f32x4_t, v0b) * W0;
+        accA += __builtin_bit_cast(f32x4_t, v1a) * W1;
+        accB += __builtin_bit_cast(f32x4_t, v1b) * W1;
+    }
+}
 
 template <bool FUSED>
 __global__ void __launch_bounds__(kPqThreads, 3)
@@ -80,6 +140,11 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
     int item = (int)blockIdx.x;
     if (item >= pg.n_items) return;
 
+    if (pg.skew > 0) {
+        // de-phase the workgroups that share a CU (observed placement: workgroup b is the (b / cus)-th of its CU)
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((item / pg.cus) * pg.skew);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = threadIdx.x & 3;            // the level this lane owns
@@ -314,9 +379,10 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
             const int wy0 = tfq_max(by0, nom.x), wy1 = tfq_min(by1, nom.y - 1) + 1;
             const bool some = lvalid && bx0 <= bx1 && by0 <= by1 && wx0 < wx1 && wy0 < wy1;
             const int ww = some ? wx1 - wx0 + 1 : 0, wh = some ? wy1 - wy0 + 1 : 0;
-            const int rows = ww * wh, rows8 = (rows + 7) & ~7;
+            const int rows = ww * wh;
             // round 0: level 0 alone; round 1: levels 1..3 packed one behind the other, all or nothing per level
             const int cap = pg.cap_rows;
+            const int rows8 = (rows + 7) & ~7;
             const int r1 = dpp_i<0x55>(rows), r2 = dpp_i<0xAA>(rows), r3 = dpp_i<0xFF>(rows);
             const int e1 = dpp_i<0x55>(rows8), e2 = dpp_i<0xAA>(rows8);
             const bool fit1 = r1 <= cap;
@@ -324,7 +390,7 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
             const bool fit2 = r2 <= cap - u2;
             const int u3 = u2 + (fit2 ? e2 : 0);
             const bool fit3 = r3 <= cap - u3;
-            const bool fit = sub == 0 ? rows <= cap : sub == 1 ? fit1 : sub == 2 ? fit2 : fit3;
+            const bool fit = sub == 0 ? (rows <= cap && !kP2Level0ByLoads) : sub == 1 ? fit1 : sub == 2 ? fit2 : fit3;
             const bool stage = some && fit;
             g_roff = 2 + (sub == 2 ? u2 : sub == 3 ? u3 : 0);
             g_wx0 = stage ? wx0 : kQuadFar;
@@ -385,14 +451,33 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
                 const int py = wy0 + wy, px = wx0 + wx;                    // extended coordinates: may be -1 or size
                 const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
                 const unsigned off = ok ? lvl_base + (unsigned)(py * W + px) * rowbytes : kOobBase;
+                if constexpr (kP2StageByLds) {
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {
-                    const int c = c0 + NW * g;
-                    if (c >= nchunks) break;   // uniform
-                    const unsigned src = (unsigned)__builtin_amdgcn_ds_bpermute(bp8 + 32 * g, (int)off) + (unsigned)(lane & 7) * 16u;
-                    if constexpr (!(kPqAblate & 2))
-                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                            rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128), 16, src, 0, 0, 0);
+                    for (int g = 0; g < 8; ++g) {
+                        const int c = c0 + NW * g;
+                        if (c >= nchunks) break;   // uniform
+                        const unsigned src = (unsigned)__builtin_amdgcn_ds_bpermute(bp8 + 32 * g, (int)off) + (unsigned)(lane & 7) * 16u;
+                        if constexpr (!(kPqAblate & 2))
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128), 16, src, 0, 0, 0);
+                    }
+                } else {
+                    // through registers: 8 buffer loads in flight, then 8 ds_write_b128 (an LDS-DMA instruction costs its wave
+                    // 100-185 cycles of issue inside a busy phase, MI355X_MICROARCH.md; a load + a store far less)
+                    u32x4_t v[8];
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int c = c0 + NW * g;
+                        const unsigned src = (unsigned)__builtin_amdgcn_ds_bpermute(bp8 + 32 * g, (int)off) + (unsigned)(lane & 7) * 16u;
+                        if (c < nchunks)   // uniform
+                            v[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src, 0, 0);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) {
+                        const int c = c0 + NW * g;
+                        if (c < nchunks)   // uniform
+                            *reinterpret_cast<u32x4_t *>(s_rows + (size_t)(roff + c * 8) * 128 + (size_t)lane * 16) = v[g];
+                    }
                 }
             }
         };
