@@ -383,17 +383,19 @@ def _fp32_linears():
 
 
 # ------------------------------------------------------------------ tiled / LDS-staged encoder kernel
-@pytest.fixture(params=[2, 3], ids=["quad", "pquad"])
+@pytest.fixture(params=[2, 3, 4], ids=["quad", "pquad", "pquad_v1"])
 def tiled(dev, request):
-    """Select an LDS-window encoder kernel (2: msda_fwd_f32_quad, 3: the persistent msda_fwd_f32_pquad -- the default for
-    encoder-shaped calls) for the duration of a test."""
+    """Select an LDS-window encoder kernel (2: msda_fwd_f32_quad, 3: the persistent kernel -- the default for encoder-shaped
+    calls: msda_fwd_f32_pquad2 where it applies, 4: its first version msda_fwd_f32_pquad everywhere) for the duration of a test."""
     from trackformer_amd import _cabi
     lib = _cabi.lib()
     prev = lib.tf_msda_set_tiled(2)
-    prev_pq = lib.tf_msda_set_option(b"pquad", 1 if request.param == 3 else 0)
+    prev_pq = lib.tf_msda_set_option(b"pquad", 0 if request.param == 2 else 1)
+    prev_v2 = lib.tf_msda_set_option(b"pquad_v2", 0 if request.param == 4 else 1)
     yield
     lib.tf_msda_set_tiled(prev)
     lib.tf_msda_set_option(b"pquad", prev_pq)
+    lib.tf_msda_set_option(b"pquad_v2", prev_v2)
 
 
 def _encoder_inputs(dev, shapes, mode, N=1, M=8, D=32, seed=0):
@@ -457,7 +459,11 @@ def test_tiled_kernel_matches_rowgather_kernel(dev, tiled):
 
 PQUAD_VARIANTS = [dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pquad_wg_per_cu=2),
                   dict(pquad_prefetch=2, pquad_wg_per_cu=2), dict(pquad_wide=0), dict(pquad_lds_kb=24),
-                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1), dict(pquad_skew=100)]
+                  dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1), dict(pquad_skew=100),
+                  # round 5: msda_fwd_f32_pquad2 (msda_pquad2.h) is the default where it applies (D == 32, two passes, 16-byte
+                  # loads) -- the first version at the default plan, and the second under other plans
+                  dict(pquad_v2=0), dict(pquad_v2=0, pquad_lds_kb=24), dict(pquad_wg_per_cu=1), dict(pquad_halo_y=2, pquad_halo_x=2),
+                  dict(pquad_lds_kb=12), dict(pquad_skew=150, pquad_wg_per_cu=2)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items())
