@@ -155,6 +155,8 @@ static inline void hipLaunchKernelGGL(void (*k)(P...), dim3 grid, dim3 block, si
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) ::hipemu::mov_dpp((old), (v), (ctrl), (rm), (bm), (bc), __LINE__)
 // ds_bpermute_b32: lane i <- v of lane (addr_i / 4) mod 64
 #define __builtin_amdgcn_ds_bpermute(addr, v) ::hipemu::shuffle_from((int)(v), (int)((((unsigned)(addr)) >> 2) & 63u), (int)(v), __LINE__)
+// ds_swizzle_b32, bit-mask mode (pattern bit 15 == 0): inside each group of 32 lanes, lane i <- lane ((i & and) | or) ^ xor
+#define __builtin_amdgcn_ds_swizzle(v, pat) ::hipemu::shuffle_from((int)(v), (::hipemu::lane_id() & 32) | (((((::hipemu::lane_id() & 31) & ((pat) & 31)) | (((pat) >> 5) & 31)) ^ (((pat) >> 10) & 31)) & 31), (int)(v), __LINE__)
 typedef short hipemu_s16x2 __attribute__((ext_vector_type(2)));
 static inline hipemu_s16x2 hipemu_cvt_pk_i16(int a, int b)   // v_cvt_pk_i16_i32: {sat16(a), sat16(b)}
 {

@@ -149,7 +149,9 @@ PQUAD_VARIANTS = [dict(), dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npa
                   dict(pquad_tile_h=4, pquad_tile_w=16, pquad_wg_per_cu=1),
                   # version 2 (the default where it applies) under other plans, and version 1 at the default plan
                   dict(pquad_v2=0), dict(pquad_v2=0, pquad_lds_kb=24), dict(pquad_wg_per_cu=1), dict(pquad_halo_y=2, pquad_halo_x=2),
-                  dict(pquad_lds_kb=12)]
+                  dict(pquad_lds_kb=12),
+                  # eight-wave workgroups of version 2: one pass of 128 pairs, two workgroups per CU
+                  dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78), dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=1, pquad_lds_kb=30)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items()) or "default"

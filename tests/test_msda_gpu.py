@@ -463,7 +463,9 @@ PQUAD_VARIANTS = [dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pq
                   # round 5: msda_fwd_f32_pquad2 (msda_pquad2.h) is the default where it applies (D == 32, two passes, 16-byte
                   # loads) -- the first version at the default plan, and the second under other plans
                   dict(pquad_v2=0), dict(pquad_v2=0, pquad_lds_kb=24), dict(pquad_wg_per_cu=1), dict(pquad_halo_y=2, pquad_halo_x=2),
-                  dict(pquad_lds_kb=12), dict(pquad_skew=150, pquad_wg_per_cu=2)]
+                  dict(pquad_lds_kb=12), dict(pquad_skew=150, pquad_wg_per_cu=2),
+                  # eight-wave workgroups of version 2: one pass of 128 pairs, two workgroups per CU
+                  dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78), dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=1, pquad_lds_kb=30)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items())

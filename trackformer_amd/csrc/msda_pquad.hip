@@ -774,13 +774,14 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 #include "msda_pquad2.h"
 
 // ---- options, tile plan, launch ------------------------------------------------------------------------------
-enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoV2, kPoCount };
+enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoV2, kPoWaves, kPoCount };
 const char *const kPqOptNames[kPoCount] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
                                            "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew",
-                                           "pquad", "pquad_v2"};
-const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on", "v2"};
+                                           "pquad", "pquad_v2", "pquad_waves"};
+const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on", "v2", "waves"};
 // v2: msda_fwd_f32_pquad2 (msda_pquad2.h) where it applies (D == 32, two passes, 16-byte aligned inputs)
-constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 1};   // 3 x 52 KB = 156 KB of the CU's 160
+// waves: 4, or 8 (version 2 only: one pass of 128 pairs, two workgroups per CU -- use with lds=78)
+constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 1, 4};   // 3 x 52 KB = 156 KB of the CU's 160
 std::atomic<int> g_pq_opt[kPoCount];
 std::atomic<int> g_pq_epoch{0};
 std::atomic<unsigned long long *> g_pq_trace{nullptr};
@@ -838,6 +839,7 @@ struct PqPlan {
     int ta_mask, npass, wgs, pf;
     bool wide;
     bool v2;
+    int waves;
 };
 
 int pq_num_cus()
@@ -863,7 +865,10 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     const int epoch = g_pq_epoch.load(std::memory_order_relaxed);
     const int ta = 0, npass = o[kPoNpass], pf = o[kPoPrefetch];
     if (npass < 1 || npass > 3 || pf != 0 || o[kPoWgPerCu] < 1 || o[kPoSkew] < 0) return false;   // pquad_prefetch = 2: removed
-    const int wgs = o[kPoWgPerCu] < pq_max_wgs(npass, pf) ? o[kPoWgPerCu] : pq_max_wgs(npass, pf);
+    // eight-wave workgroups (version 2 only, one pass of 128 pairs): two workgroups per CU (<= 128 registers)
+    const int waves = (o[kPoV2] && D == 32 && o[kPoWaves] == 8 && npass == 1) ? 8 : 4;
+    const int max_wgs = waves == 8 ? 2 : pq_max_wgs(npass, pf);
+    const int wgs = o[kPoWgPerCu] < max_wgs ? o[kPoWgPerCu] : max_wgs;
     if (o[kPoLdsKb] < 8 || o[kPoLdsKb] > 160 || o[kPoHaloY] < 0 || o[kPoHaloX] < 0 || o[kPoTileH] < 0 || o[kPoTileW] < 0)
         return false;
     for (int l = 0; l < L; ++l)
@@ -893,7 +898,7 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     memo.D = D;
     memo.epoch = epoch;
     memo.lt = lt;
-    const long long cap_q = (long long)kPqPairs * npass;
+    const long long cap_q = (long long)(16 * waves) * npass;
     const long long slots = (long long)pq_num_cus() * wgs;
     int bth = 0, btw = 0;
     if (o[kPoTileH] > 0 && o[kPoTileW] > 0) {
@@ -941,6 +946,7 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     r.geom.cus = pq_num_cus();
     r.wide = o[kPoWide] != 0;
     r.v2 = o[kPoV2] != 0;
+    r.waves = waves;
     r.ta_mask = ta;
     r.npass = npass;
     r.wgs = wgs;
@@ -1001,8 +1007,10 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
                da.fa.logit_col % 4 == 0;
     else
         wide = wide && ((uintptr_t)da.loc % 16 == 0) && ((uintptr_t)da.attn % 16 == 0);
-    const bool v2 = pl.v2 && D == 32 && pl.npass == 2 && wide && pl.ta_mask == 0;
-    const void *fn = v2 ? (fused ? (const void *)&msda_fwd_f32_pquad2<true> : (const void *)&msda_fwd_f32_pquad2<false>)
+    const bool v2 = pl.v2 && D == 32 && wide && pl.ta_mask == 0 && ((pl.waves == 4 && pl.npass == 2) || (pl.waves == 8 && pl.npass == 1));
+    if (pl.waves == 8 && !v2) return false;   // (the plan was made for eight-wave workgroups: only version 2 has them)
+    const void *fn = v2 ? (pl.waves == 8 ? (fused ? (const void *)&msda_fwd_f32_pquad2<true, 8, 1> : (const void *)&msda_fwd_f32_pquad2<false, 8, 1>)
+                                         : (fused ? (const void *)&msda_fwd_f32_pquad2<true, 4, 2> : (const void *)&msda_fwd_f32_pquad2<false, 4, 2>))
                      : D == 36 ? (fused ? pq_kernel_d36<true>(wide) : pq_kernel_d36<false>(wide))
                                : (fused ? pq_kernel<true>(pl.npass, wide) : pq_kernel<false>(pl.npass, wide));
     // the dynamic-LDS limit is a per-function, per-device attribute: cheap, set on every first (function, device)
@@ -1028,7 +1036,7 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
     }
     pl.geom.trace = g_pq_trace.load(std::memory_order_relaxed);
     void *argv[] = {(void *)&da, (void *)&lt, (void *)&pl.geom};
-    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kPqThreads), argv, pl.lds, stream);
+    *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(64 * pl.waves), argv, pl.lds, stream);
     return true;
 }
 

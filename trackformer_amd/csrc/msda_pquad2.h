@@ -120,11 +120,14 @@ __device__ __forceinline__ void quad_taps_global_rows(const __amdgpu_buffer_rsrc
     }
 }
 
-template <bool FUSED>
-__global__ void __launch_bounds__(kPqThreads, 3)
+// WAVES x NP: 4 waves x 2 passes of 64 pairs (three workgroups per CU, <= 168 registers), or 8 waves x 1 pass of 128 pairs (two
+// workgroups per CU with twice the LDS each, <= 128 registers: 16 instead of 12 waves per CU, half the work per wave and tile)
+template <bool FUSED, int WAVES, int NP>
+__global__ void __launch_bounds__(64 * WAVES, (WAVES == 8 ? 4 : 3))
 msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 {
-    constexpr int NP = 2, PT = 4, D = 32, NL = 4, PAIRS = kPqPairs;
+    static_assert((WAVES == 4 && NP == 2) || (WAVES == 8 && NP == 1), "128 (query, head) pairs per tile");
+    constexpr int PT = 4, D = 32, NL = 4, PAIRS = 16 * WAVES;
     constexpr unsigned ROWB = D * 4;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
     int *s_tab = reinterpret_cast<int *>(smem);   // [H0..3 | W0..3 | start0..3]
@@ -153,7 +156,7 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
     const unsigned rbA = (unsigned)(hsel * 64 + sub * 16), rbB = (unsigned)((1 - hsel) * 64 + sub * 16);
     const unsigned lds_rows = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)s_rows);
     const unsigned ldsA = lds_rows + rbA, ldsB = lds_rows + rbB;
-    const int bp16 = 4 * (lane ^ 16), bp32 = 4 * (lane ^ 32), bp8 = 4 * (lane >> 3);
+    const int bp16 = 4 * (lane ^ 16), bp32 = 4 * (lane ^ 32);
     const unsigned long long lanes_of_level0 = 0x1111111111111111ull;
 
     auto stamp = [&](int i) {
@@ -347,7 +350,7 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         mn = p2_pkmin(mn, p2_bperm(bp32, mn));
         mx = p2_pkmax(mx, p2_bperm(bp32, mx));
         if (lane < NL) {
-            int2 *slot = reinterpret_cast<int2 *>(s_bb + ((par * 4 + wave) * 4 + lane) * 2);
+            int2 *slot = reinterpret_cast<int2 *>(s_bb + ((par * WAVES + wave) * 4 + lane) * 2);
             *slot = int2{mn, mx};
         }
     };
@@ -369,11 +372,15 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         // ---- window geometry, per lane for its own level (msda_quad_geom.h tfq_window) ----------------------------------
         int g_wx0, g_wy0, g_limx, g_limy, g_ww, g_rows, g_roff;
         {
-            const int2 *bb = reinterpret_cast<const int2 *>(s_bb + par * 32) + sub;   // + 4 * wave
-            const int2 b0 = bb[0], b1 = bb[4], b2 = bb[8], b3 = bb[12];
+            const int2 *bb = reinterpret_cast<const int2 *>(s_bb + par * WAVES * 8) + sub;   // + 4 * wave
             const int4 nom = *reinterpret_cast<const int4 *>(s_nom + (par * 4 + sub) * 4);   // ny0, ny1, nx0, nx1
-            const int mn = p2_pkmin(p2_pkmin(b0.x, b1.x), p2_pkmin(b2.x, b3.x));
-            const int mx = p2_pkmax(p2_pkmax(b0.y, b1.y), p2_pkmax(b2.y, b3.y));
+            int mn = 0x7FFF7FFF, mx = kP2Sentinel;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) {
+                const int2 b = bb[4 * wv];
+                mn = p2_pkmin(mn, b.x);
+                mx = p2_pkmax(mx, b.y);
+            }
             const int bx0 = p2_lo16(mn), by0 = p2_hi16(mn), bx1 = p2_lo16(mx), by1 = p2_hi16(mx);
             const int wx0 = tfq_max(bx0, nom.z), wx1 = tfq_min(bx1, nom.w - 1) + 1;
             const int wy0 = tfq_max(by0, nom.x), wy1 = tfq_min(by1, nom.y - 1) + 1;
@@ -443,23 +450,35 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
             const int H = Hs[l], W = Ws[l], ww = u_ww[l], wx0 = u_wx0[l], wy0 = u_wy0[l], roff = u_roff[l];
             const unsigned lvl_base = head_base + (unsigned)starts[l] * rowbytes;
             const float inv_ww = __builtin_amdgcn_rcpf((float)ww);
-            constexpr int NW = kPqThreads / 64;
+            constexpr int NW = WAVES;
             for (int c0 = wave; c0 < nchunks; c0 += 8 * NW) {   // this wave's chunks c0, c0 + NW, ...: 8 per group
-                const int r = (c0 + NW * (lane >> 3)) * 8 + (lane & 7);   // the window row this lane resolves
+                // lane j resolves row (j >> 3) of chunk c0 + NW * (j & 7): the DMA lanes of row a (lanes 8 a .. 8 a + 7) then find
+                // chunk g's offset in lane 8 a + g -- a broadcast inside their group of 8 (ds_swizzle, no address register)
+                const int r = (c0 + NW * (lane & 7)) * 8 + (lane >> 3);   // the window row this lane resolves
                 const int wy = (int)(((float)r + 0.5f) * inv_ww);         // r / ww (r < 2^16: exact, see tables_2)
                 const int wx = r - wy * ww;
                 const int py = wy0 + wy, px = wx0 + wx;                    // extended coordinates: may be -1 or size
                 const bool ok = r < nrows && (unsigned)py < (unsigned)H && (unsigned)px < (unsigned)W;
                 const unsigned off = ok ? lvl_base + (unsigned)(py * W + px) * rowbytes : kOobBase;
                 if constexpr (kP2StageByLds) {
+                    // all eight broadcasts first (one LDS round trip for the group, not one per DMA instruction)
+                    unsigned src[8];
+                    src[0] = (unsigned)__builtin_amdgcn_ds_swizzle((int)off, 0x18 | (0 << 5));
+                    src[1] = (unsigned)__builtin_amdgcn_ds_swizzle((int)off, 0x18 | (1 << 5));
+                    src[2] = (unsigned)__builtin_amdgcn_ds_swizzle((int)off, 0x18 | (2 << 5));
+                    src[3] = (unsigned)__builtin_amdgcn_ds_swizzle((int)off, 0x18 | (3 << 5));
+                    src[4] = (unsigned)__builtin_amdgcn_ds_swizzle((int)off, 0x18 | (4 << 5));
+                    src[5] = (unsigned)__builtin_amdgcn_ds_swizzle((int)off, 0x18 | (5 << 5));
+                    src[6] = (unsigned)__builtin_amdgcn_ds_swizzle((int)off, 0x18 | (6 << 5));
+                    src[7] = (unsigned)__builtin_amdgcn_ds_swizzle((int)off, 0x18 | (7 << 5));
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
                         const int c = c0 + NW * g;
                         if (c >= nchunks) break;   // uniform
-                        const unsigned src = (unsigned)__builtin_amdgcn_ds_bpermute(bp8 + 32 * g, (int)off) + (unsigned)(lane & 7) * 16u;
                         if constexpr (!(kPqAblate & 2))
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                                rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128), 16, src, 0, 0, 0);
+                                rsrc, (__attribute__((address_space(3))) void *)(s_rows + (size_t)(roff + c * 8) * 128), 16,
+                                src[g] + (unsigned)(lane & 7) * 16u, 0, 0, 0);
                     }
                 } else {
                     // through registers: 8 buffer loads in flight, then 8 ds_write_b128 (an LDS-DMA instruction costs its wave
@@ -468,7 +487,7 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
 #pragma unroll
                     for (int g = 0; g < 8; ++g) {
                         const int c = c0 + NW * g;
-                        const unsigned src = (unsigned)__builtin_amdgcn_ds_bpermute(bp8 + 32 * g, (int)off) + (unsigned)(lane & 7) * 16u;
+                        const unsigned src = (unsigned)__builtin_amdgcn_ds_bpermute(4 * ((lane & 0x38) | g), (int)off) + (unsigned)(lane & 7) * 16u;
                         if (c < nchunks)   // uniform
                             v[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, src, 0, 0);
                     }
