@@ -523,8 +523,11 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
     # HBM traffic of the same kernel / shape / pattern from the PMC counters: collected offline (rocprofv3
     # --pmc needs its own passes) and committed together with the method; see the file's "_how"
     mode = os.environ.get("TF_MSDA_TILED", "2")[:1] or "2"   # the library's kernel choice for this shape
-    kernel = {"0": "msda_fwd_f32_direct"}.get(mode, "msda_fwd_f32_pquad")
-    if D != 32 and kernel == "msda_fwd_f32_pquad":
+    # (round 5: msda_fwd_f32_pquad2, the second version of the persistent kernel, where it applies: D == 32)
+    kernel = {"0": "msda_fwd_f32_direct"}.get(mode, "msda_fwd_f32_pquad2")
+    if "v2=0" in os.environ.get("TF_MSDA_PQUAD", ""):
+        kernel = "msda_fwd_f32_pquad"
+    if D != 32 and kernel.startswith("msda_fwd_f32_pquad"):
         kernel = "msda_fwd_f32_pquad<D=36>"   # head dimension 36 (hidden 288): 144-byte rows, 3 lanes x 12 channels
     traffic = traffic_src = None
     try:
