@@ -134,6 +134,8 @@ def parse_args():
                          "fresh process so that the leg gets torch's default one-thread-per-core set-up")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-single-sequence", action="store_true")
+    ap.add_argument("--no-prepare", action="store_true",
+                    help="do not run the next frame's image-only half ahead of the association (Tracker.step_prepare)")
     ap.add_argument("--no-fp32-exact", action="store_true",
                     help="skip the second measurement with every matrix product in fp32 (hipBLASLt / library convolutions)")
     ap.add_argument("--no-parity", action="store_true",
@@ -808,13 +810,18 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
             while any(done[s] < per_seq[s] for s in range(n_seq)):
                 for s in range(n_seq):
                     with torch.cuda.stream(streams[s]):
+                        nxt = frames[(s + issued[s]) % len(frames)] if issued[s] < per_seq[s] else None
                         if handles[s] is not None:
+                            if nxt is not None and not args.no_prepare:
+                                # the image-only half of the next frame (backbone, encoder) goes to the GPU BEFORE the host
+                                # associates this one: Tracker.step_prepare -- a single sequence no longer leaves the GPU idle
+                                trackers[s].step_prepare(nxt)
                             trackers[s].step_finish(handles[s])
                             handles[s] = None
                             done[s] += 1
-                        if issued[s] < per_seq[s]:
+                        if nxt is not None:
                             seeder.seed(trackers[s])
-                            handles[s] = trackers[s].step_async(frames[(s + issued[s]) % len(frames)])
+                            handles[s] = trackers[s].step_async(nxt)
                             issued[s] += 1
         for st in streams:
             st.synchronize()
@@ -1027,6 +1034,9 @@ def main():
                        "global_batch": world * (2 if train else 1),
                        "parallelism": ("DDP x%d (RCCL all-reduce)" if train else "sequence-sharded x%d") % world,
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
+                       **({"pipelined": "the next frame's backbone + encoder are enqueued before the host associates the current "
+                                        "frame (Tracker.step_prepare; results those of step())"}
+                          if cfg["kind"] == "track" and not args.no_prepare else {}),
                        "linears": (_ARITH[fused.split_terms()][0] + ", f32 accumulate (own kernels)")
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",
                        **({"routes": _active_optins(_backbone, fused)} if not train and _active_optins(_backbone, fused) else {}),

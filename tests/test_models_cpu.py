@@ -178,9 +178,11 @@ def test_tracker_variants_match_reference(name, host_op):
     compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.05)
 
 
-def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None):
+def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None, prepare=False):
     """Tracker.step over a sequence of tests/util_models.WC_TRACKER_CASES: the well-conditioned detector (the same seeded
-    weights with um.shape_well_conditioned's planted circuit).  wrap: detector -> detector (e.g. GraphedDetector)."""
+    weights with um.shape_well_conditioned's planted circuit).  wrap: detector -> detector (e.g. GraphedDetector).
+    prepare: the pipelined form -- step_async(t), step_prepare(t + 1), step_finish(t): the image-only half of the next
+    frame is enqueued before this frame's association runs (Tracker.step_prepare)."""
     case, frames, reid = um.WC_TRACKER_CASES[name]
     model, post, args = um.build(case, factory.build_model, config.make_args, device=device)
     um.shape_well_conditioned(model)
@@ -189,11 +191,25 @@ def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None):
     tracker = Tracker(wrap(model) if wrap is not None else model, post, config.tracker_cfg(reid=reid), False)
     tracker.reset()
     active, inactive = [], []
+    blobs = um.tracker_sequence(n_frames=n_frames or frames)
     with torch.no_grad():
-        for blob in um.tracker_sequence(n_frames=n_frames or frames):
-            tracker.step(blob)
-            active.append(len(tracker.tracks))
-            inactive.append(len(tracker.inactive_tracks))
+        if prepare:
+            prepared = 0
+            handle = tracker.step_async(blobs[0])
+            for i in range(len(blobs)):
+                if i + 1 < len(blobs):
+                    prepared += bool(tracker.step_prepare(blobs[i + 1]))
+                tracker.step_finish(handle)
+                active.append(len(tracker.tracks))
+                inactive.append(len(tracker.inactive_tracks))
+                if i + 1 < len(blobs):
+                    handle = tracker.step_async(blobs[i + 1])
+            tracker.frames_prepared = prepared
+        else:
+            for blob in blobs:
+                tracker.step(blob)
+                active.append(len(tracker.tracks))
+                inactive.append(len(tracker.inactive_tracks))
     results = tracker.get_results()
     rows = np.array([[tid, f, *results[tid][f]['bbox'].tolist(), float(results[tid][f]['score']), results[tid][f]['obj_ind']]
                      for tid in sorted(results) for f in sorted(results[tid])], dtype=np.float64)
@@ -230,6 +246,28 @@ def test_well_conditioned_tracker_sequences_match_reference(name, n_frames, host
     """The first frames of each sequence on the CPU through the host operator (the GPU suite runs all of them: 64 frames)."""
     tracker, rows, active, inactive = run_wc_tracker(name, n_frames=n_frames)
     compare_wc_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.05, n_frames=n_frames)
+
+
+def test_image_only_half_of_the_forward_can_run_ahead(host_op):
+    """encode_frame() + forward(encoded=...) is forward(): same tensors bit for bit, with and without track queries; and a
+    Tracker that runs the next frame's image-only half before it associates the current frame (step_prepare) files exactly
+    the tracks of the plain step() loop.  (Round 5: the single-sequence headline no longer waits for the host.)"""
+    model, post, args = um.build("cfg2_deformable_tracking", factory.build_model, config.make_args)
+    model.tracking()
+    img, prev, target = um.model_inputs("cfg2_deformable_tracking", args.hidden_dim)
+    with torch.no_grad():
+        for tgt in (None, target):
+            want = model(img, None if tgt is None else [dict(t) for t in tgt], None)
+            enc = model.encode_frame(img, None)
+            got = model(img, None if tgt is None else [dict(t) for t in tgt], None, encoded=enc)
+            for k in ("pred_logits", "pred_boxes", "hs_embed"):
+                assert torch.equal(got[0][k], want[0][k])
+            assert torch.equal(got[4], want[4]) and all(torch.equal(a, b) for a, b in zip(got[3], want[3]))
+    plain = run_wc_tracker("cfg2_wc", n_frames=5)
+    ahead = run_wc_tracker("cfg2_wc", n_frames=5, prepare=True)
+    assert ahead[0].frames_prepared == 4
+    np.testing.assert_array_equal(plain[1], ahead[1])
+    assert plain[2] == ahead[2] and plain[3] == ahead[3]
 
 
 def run_mask_tracker(device="cpu", frames=3, lazy_masks=False):

@@ -132,6 +132,12 @@ bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 
 // Replaces the ATen path behind the reference's `input_proj` (models/deformable_detr.py:73-90: Conv2d + GroupNorm(32, 256)),
 // which for channels_last inputs is a layout copy + RowwiseMoments over only N * 32 rows + a parameter kernel + an
 // element-wise kernel (0.2 ms per frame, profiles/r02_e2e_eager_per_frame.txt).
+__global__ void __launch_bounds__(256) groupnorm_zero_kernel(double *__restrict__ ws, unsigned n)
+{
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) ws[i] = 0.0;
+}
+
 constexpr int kGnRowsPerBlock = 64;   // 261 workgroups for the largest level at 800 x 1333 (16 700 pixels)
 
 __global__ void __launch_bounds__(256)
@@ -334,7 +340,16 @@ static int groupnorm_nhwc_impl(const float *x, const float *gamma, const float *
     if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || !aligned16(out) || (reinterpret_cast<uintptr_t>(workspace) & 7))
         return TF_MSDA_ERR_BAD_DIMS;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(workspace, 0, sizeof(double) * 2 * (size_t)N * G, s) != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    // the statistics are accumulated by atomics: zeros first -- by a KERNEL, not hipMemsetAsync.  Inside a captured HIP graph
+    // the memset node was seen (ROCm 7.2, MI355X; round 5, profiles/r05_graph_memset_groupnorm.txt) to land AFTER the
+    // statistics kernel's atomics in about one replay out of a hundred when the graph was launched right behind device-to-
+    // device copies: the 48-pixel level of a small frame then normalised with garbage statistics (inf) -- one NaN frame in a
+    // 64-frame sequence.  Kernel -> kernel order inside a graph is an ordinary dependency edge.
+    {
+        const unsigned n_ws = 2u * (unsigned)N * (unsigned)G;
+        hipLaunchKernelGGL(groupnorm_zero_kernel, dim3((n_ws + 255) / 256), dim3(256), 0, s, workspace, n_ws);
+        if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    }
     const unsigned sblocks = (unsigned)((HW + kGnRowsPerBlock - 1) / kGnRowsPerBlock);
     hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(sblocks, (unsigned)N), dim3(256), 0, s, x, workspace, HW, C, G,
                        (long long)x_image_stride);

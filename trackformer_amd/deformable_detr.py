@@ -101,13 +101,30 @@ class DeformableDETR(DETR):
             y = self.merge_features[level](torch.cat([y, self._input_proj(level, prev_x)], dim=1))
         return y
 
-    def forward(self, samples: NestedTensor, targets: list = None, prev_features=None):
+    def forward(self, samples: NestedTensor, targets: list = None, prev_features=None, encoded=None):
         """samples: NestedTensor / list of images / [B,3,H,W] tensor.  targets (tracking): list of
         dicts with `track_query_hs_embeds` [T,C] and `track_query_boxes` [T,4].  prev_features: the
         `features_all` returned for the previous frame (multi-frame attention).
+        encoded: what encode_frame(samples, prev_features) returned for THIS frame (optional; not in the reference): the
+        image-only half -- backbone, input projections, encoder -- is then not run again.
 
         Returns (out, targets, features_all, memory, hs) as deformable_detr.py:275; `out` holds
         pred_logits [B,Q,C], pred_boxes [B,Q,4] (cxcywh, [0,1]), hs_embed [B,Q,hidden], aux_outputs."""
+        if encoded is None:
+            encoded = self.encode_frame(samples, prev_features)
+        features_all, src_shapes, enc = encoded["features_all"], encoded["src_shapes"], encoded["enc"]
+
+        query_embeds = None if self.two_stage else self.query_embed.weight
+        hs, memory, init_reference, inter_references, enc_outputs_class, enc_outputs_coord_unact = \
+            self.transformer.decode(enc, query_embeds, targets)
+        return self._heads(hs, memory, init_reference, inter_references, enc_outputs_class, enc_outputs_coord_unact,
+                           targets, features_all, src_shapes)
+
+    def encode_frame(self, samples, prev_features=None):
+        """Everything of forward() that depends on the image (and, with multi-frame attention, the previous frame's features)
+        only: backbone, input projections, position encodings, the encoder (deformable_detr.py:124-223 +
+        deformable_transformer.py:133-173 of the reference).  The track queries of `targets` enter afterwards (the decoder),
+        so a tracker can run this half for frame t + 1 while it still associates frame t (Tracker.step_prepare)."""
         if not isinstance(samples, NestedTensor):
             samples = nested_tensor_from_tensor_list(samples)
         features_all, pos = self.backbone(samples)
@@ -143,10 +160,11 @@ class DeformableDETR(DETR):
                 mask_list.append(mask)
                 pos_list.append(pos_l[:, frame] if per_frame_pos else pos_l)
 
-        query_embeds = None if self.two_stage else self.query_embed.weight
-        hs, memory, init_reference, inter_references, enc_outputs_class, enc_outputs_coord_unact = \
-            self.transformer(src_list, mask_list, pos_list, query_embeds, targets)
+        return {"features_all": features_all, "src_shapes": [tuple(s.shape[-2:]) for s in src_list],
+                "enc": self.transformer.encode(src_list, mask_list, pos_list)}
 
+    def _heads(self, hs, memory, init_reference, inter_references, enc_outputs_class, enc_outputs_coord_unact, targets,
+               features_all, src_shapes):
         reuse_refinement = (self.with_box_refine and not self.two_stage and not self.training
                             and not torch.is_grad_enabled()
                             and inter_references.shape[0] == hs.shape[0])
@@ -185,8 +203,7 @@ class DeformableDETR(DETR):
         # encoder memory re-sliced into per-level [B, C, H, W] views
         batch_size, _, channels = memory.shape
         memory_slices, offset = [], 0
-        for src in src_list:
-            h, w = src.shape[-2:]
+        for h, w in src_shapes:
             memory_slices.append(memory[:, offset:offset + h * w].permute(0, 2, 1).view(
                 batch_size, channels, h, w))
             offset += h * w

@@ -250,8 +250,12 @@ class DeformableTransformer(nn.Module):
         return hit[0]
 
     def forward(self, srcs, masks, pos_embeds, query_embed=None, targets=None):
-        assert self.two_stage or query_embed is not None
+        return self.decode(self.encode(srcs, masks, pos_embeds), query_embed, targets)
 
+    def encode(self, srcs, masks, pos_embeds):
+        """The part of forward() that depends on the IMAGE only (deformable_transformer.py:133-173 of the reference: flatten,
+        level embedding, encoder) -> the state decode() needs.  Tracker.step_prepare runs it for frame t + 1 while the host
+        still associates frame t: the track queries enter in decode()."""
         shapes = tuple((int(s.shape[2]), int(s.shape[3])) for s in srcs)
         device = srcs[0].device
         src_flatten = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
@@ -284,6 +288,14 @@ class DeformableTransformer(nn.Module):
             memory = self.encoder(src_flatten, spatial_shapes, valid_ratios, lvl_pos_embed_flatten,
                                   mask_flatten, unit_ratios=unpadded)
 
+        return {"memory": memory, "spatial_shapes": spatial_shapes, "valid_ratios": valid_ratios,
+                "mask_flatten": mask_flatten, "device": device}
+
+    def decode(self, enc, query_embed=None, targets=None):
+        """The rest of forward() (deformable_transformer.py:175-246 of the reference): object + track queries, decoder."""
+        assert self.two_stage or query_embed is not None
+        memory, spatial_shapes, valid_ratios = enc["memory"], enc["spatial_shapes"], enc["valid_ratios"]
+        mask_flatten, device = enc["mask_flatten"], enc["device"]
         # decoder inputs
         bs, _, c = memory.shape
         query_attn_mask = None

@@ -44,7 +44,7 @@ class DETRTrackingBase(nn.Module):
             false_negative_prob=self._track_query_false_negative_prob,
             num_queries=self.num_queries)
 
-    def forward(self, samples: NestedTensor, targets: list = None, prev_features=None):
+    def forward(self, samples: NestedTensor, targets: list = None, prev_features=None, encoded=None):
         if targets is not None and not self._tracking:
             prev_targets = [target['prev_target'] for target in targets]
             if self.training:
@@ -83,6 +83,8 @@ class DETRTrackingBase(nn.Module):
                     target['track_query_boxes'] = torch.zeros(0, 4, device=device)
                     target['track_query_match_ids'] = torch.zeros(0, dtype=torch.long,
                                                                   device=device)
+        if encoded is not None:   # (Tracker.step_prepare: the image-only half of this frame has already run)
+            return super().forward(samples, targets, prev_features, encoded=encoded)
         return super().forward(samples, targets, prev_features)
 
 

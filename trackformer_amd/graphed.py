@@ -28,6 +28,12 @@ track queries (zero embedding, a fixed box) that are masked out as keys of the d
 the real queries see what they would see without them (up to the summation order of the attention) -- and drops the
 fillers' rows from the outputs.  Everything else in the decoder is per query.  `bucket=1` switches it off.
 
+Two graphs (round 5).  For the single-frame models without a mask head the forward is captured in two halves: A = backbone +
+input projections + encoder, which depends on the image only, and B = decoder + heads, which also takes the track queries.
+`prepare(img)` replays A for a frame whose track queries are not known yet -- Tracker.step_prepare calls it for frame
+t + 1 before it associates frame t, so that the GPU never waits for the host in a single sequence -- and the following
+call with that tensor replays B alone.  Without prepare() a call replays A and B back to back: same kernels as one graph.
+
 Threads: bench.py and INTEGRATION.md run one tracker thread (own HIP stream) per sequence against one
 shared model.  Captures are serialised by a process-wide lock and run in `thread_local` capture mode
 with a private memory pool, so other threads may keep replaying / running eagerly meanwhile.  The
@@ -53,6 +59,8 @@ class GraphedDetector:
         self.bucket = max(1, int(bucket))
         self._graphs = OrderedDict()
         self._seen = {}
+        self._enc = {}            # (image shape, device) -> the image-only half as its own graph (prepare(), module docstring)
+        self._prepared = None     # (image tensor, its _enc entry) of the last prepare()
 
     def __getattr__(self, name):  # only called for attributes GraphedDetector itself lacks
         return getattr(self.model, name)
@@ -78,7 +86,48 @@ class GraphedDetector:
         return [NestedTensor(f.tensors.clone(), None if f.mask is None else f.mask.clone())
                 for f in features]
 
+    # ------------------------------------------------------------------ the forward in two graphs (models without a second
+    # frame / mask head): A = backbone + input projections + encoder (the image only), B = decoder + heads (+ the track queries)
+    def _splittable(self):
+        m = self.model
+        return hasattr(m, "encode_frame") and not self._multi_frame() and not hasattr(m, "mask_head")
+
+    def _capture_encoder(self, img):
+        entry = {"img": img.clone()}
+        dev = img.device
+        with _CAPTURE_LOCK:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    warm = self.model.encode_frame(entry["img"], None)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            del warm
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                entry["state"] = self.model.encode_frame(entry["img"], None)
+        entry["graph"] = graph
+        return entry
+
+    def prepare(self, img, prev_features=None):
+        """Enqueue the IMAGE-ONLY half of the forward (backbone, input projections, encoder) for `img` on the current stream
+        and return True; the next call of the detector with this very tensor then runs the decoder half only.  A tracker
+        calls it for frame t + 1 before it associates frame t (Tracker.step_prepare): the GPU works on the next frame while
+        the host decides about this one.  False: nothing was enqueued (not a model / input this applies to, or the graph of
+        this image shape does not exist yet -- it is captured by the ordinary calls)."""
+        if not (self._splittable() and self._capturable(img, None, prev_features)):
+            return False
+        a = self._enc.get((tuple(img.shape), img.device))
+        if a is None:
+            return False
+        a["img"].copy_(img, non_blocking=True)
+        a["graph"].replay()
+        self._prepared = (img, a)
+        return True
+
     def _capture(self, img, target, prev_features):
+        if self._splittable():
+            return self._capture_decoder(img, target)
         entry = {"img": img.clone()}
         static_target = None
         if target is not None:
@@ -121,6 +170,39 @@ class GraphedDetector:
                             d.mask.copy_(s.mask)
                     out = (out[0], out[1], dst, out[3], out[4])
                 entry["out"] = out
+        entry["graph"] = graph
+        return entry
+
+    def _capture_decoder(self, img, target):
+        akey = (tuple(img.shape), img.device)
+        a = self._enc.get(akey)
+        if a is None:
+            a = self._enc[akey] = self._capture_encoder(img)
+        entry = {"enc": a, "prev": None}
+        static_target = None
+        if target is not None:
+            entry["boxes"] = target[0]['track_query_boxes'].clone()
+            entry["hs"] = target[0]['track_query_hs_embeds'].clone()
+            static_target = [{'track_query_boxes': entry["boxes"], 'track_query_hs_embeds': entry["hs"],
+                              'image_id': target[0].get('image_id')}]
+            if 'track_query_filler' in target[0]:
+                entry["filler"] = target[0]['track_query_filler'].clone()
+                static_target[0]['track_query_filler'] = entry["filler"]
+        entry["target"] = static_target
+        dev = img.device
+        with _CAPTURE_LOCK:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                a["img"].copy_(img)
+                a["graph"].replay()      # the state the decoder half reads (static buffers of the encoder graph)
+                for _ in range(2):
+                    warm = self.model(a["img"], static_target, None, encoded=a["state"])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            del warm
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                entry["out"] = self.model(a["img"], static_target, None, encoded=a["state"])
         entry["graph"] = graph
         return entry
 
@@ -181,6 +263,7 @@ class GraphedDetector:
             # capture a shape the second time it shows up (one-off shapes are not worth a graph)
             self._seen[key] = self._seen.get(key, 0) + 1
             if self._seen[key] < 2:
+                self._prepared = None
                 return self.model(img, caller_target, prev_features)
             entry = self._capture(img, target, prev_features)
             self._graphs[key] = entry
@@ -188,12 +271,19 @@ class GraphedDetector:
                 self._graphs.popitem(last=False)   # least recently used
         else:
             self._graphs.move_to_end(key)
-        entry["img"].copy_(img, non_blocking=True)
         if target is not None:
             entry["boxes"].copy_(target[0]['track_query_boxes'], non_blocking=True)
             entry["hs"].copy_(target[0]['track_query_hs_embeds'], non_blocking=True)
             if "filler" in entry:
                 entry["filler"].copy_(target[0]['track_query_filler'], non_blocking=True)
+        if "enc" in entry:   # two graphs: the image-only half unless prepare() already ran it for this very tensor
+            a = entry["enc"]
+            prepared, self._prepared = self._prepared, None
+            if prepared is None or prepared[0] is not img or prepared[1] is not a:
+                a["img"].copy_(img, non_blocking=True)
+                a["graph"].replay()
+        else:
+            entry["img"].copy_(img, non_blocking=True)
         if entry["prev"] is not None:
             self._feed_prev(entry, prev_features)
         entry["graph"].replay()

@@ -271,6 +271,28 @@ class Tracker:
         'dets' [1,K,4] xyxy public detections} as produced by the reference's sequence datasets."""
         self.step_finish(self.step_async(blob))
 
+    def step_prepare(self, blob):
+        """Optional, BEFORE step_finish of the previous frame: enqueue the image-only half of `blob`'s forward (backbone,
+        input projections, encoder -- GraphedDetector.prepare, or the model's encode_frame) so that the GPU works on this
+        frame while the host still associates the previous one; the following step_async(blob) / step(blob) of the SAME
+        blob then runs the decoder half only.  Results are those of step(): the image-only half does not depend on the
+        tracks.  Returns whether anything was enqueued (multi-frame and mask-head models: no -- their first half needs the
+        previous frame's features / feeds the mask head)."""
+        det = self.obj_detector
+        img = blob['img'].to(self.device, non_blocking=True)
+        prep = getattr(det, "prepare", None)
+        self._prepared = None
+        if prep is not None:
+            if prep(img, None):
+                self._prepared = (blob['img'], img, None)
+                return True
+            return False
+        if (hasattr(det, "encode_frame") and not getattr(det, "multi_frame_attention", False) and not hasattr(det, "mask_head")
+                and not det.training and not torch.is_grad_enabled()):
+            self._prepared = (blob['img'], img, det.encode_frame(img, None))
+            return True
+        return False
+
     def step_async(self, blob):
         """First half of step(): builds the track queries, ENQUEUES the detector forward, the post-processing and the frame's
         single device -> host copy on the current stream, and returns without waiting for any of it.  step_finish(handle)
@@ -291,7 +313,12 @@ class Tracker:
             track.last_pos.append(track._pos)
 
         device = self.device
-        img = blob['img'].to(device, non_blocking=True)
+        prepared, self._prepared = getattr(self, "_prepared", None), None
+        encoded = None
+        if prepared is not None and prepared[0] is blob['img']:
+            img, encoded = prepared[1], prepared[2]     # step_prepare(blob) ran the image-only half for this very frame
+        else:
+            img = blob['img'].to(device, non_blocking=True)
         orig_size_host = blob['orig_size'].detach().cpu()
         orig_size = orig_size_host.to(device, non_blocking=True)
         orig_h, orig_w = int(orig_size_host[0, 0]), int(orig_size_host[0, 1])
@@ -313,6 +340,8 @@ class Tracker:
             from .detr_segmentation import lazy_mask_scope
             with lazy_mask_scope():
                 outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
+        elif encoded is not None:
+            outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0], encoded=encoded)
         else:
             outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
         hs_embeds = outputs['hs_embed'][0]
