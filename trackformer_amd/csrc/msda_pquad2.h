@@ -371,6 +371,7 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
 
         // ---- window geometry, per lane for its own level (msda_quad_geom.h tfq_window) ----------------------------------
         int g_wx0, g_wy0, g_limx, g_limy, g_ww, g_rows, g_roff;
+        bool late3;
         {
             const int2 *bb = reinterpret_cast<const int2 *>(s_bb + par * WAVES * 8) + sub;   // + 4 * wave
             const int4 nom = *reinterpret_cast<const int4 *>(s_nom + (par * 4 + sub) * 4);   // ny0, ny1, nx0, nx1
@@ -397,9 +398,12 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
             const bool fit2 = r2 <= cap - u2;
             const int u3 = u2 + (fit2 ? e2 : 0);
             const bool fit3 = r3 <= cap - u3;
-            const bool fit = sub == 0 ? (rows <= cap && !kP2Level0ByLoads) : sub == 1 ? fit1 : sub == 2 ? fit2 : fit3;
+            // level 3 does not fit behind levels 1 and 2 but would on its own (headline pattern: the four diagonal heads): a THIRD
+            // round of its own instead of buffer loads for every one of its points
+            late3 = !fit3 && r3 <= cap && r3 > 0;
+            const bool fit = sub == 0 ? (rows <= cap && !kP2Level0ByLoads) : sub == 1 ? fit1 : sub == 2 ? fit2 : (fit3 || late3);
             const bool stage = some && fit;
-            g_roff = 2 + (sub == 2 ? u2 : sub == 3 ? u3 : 0);
+            g_roff = 2 + (sub == 2 ? u2 : sub == 3 ? (late3 ? 0 : u3) : 0);
             g_wx0 = stage ? wx0 : kQuadFar;
             g_wy0 = stage ? wy0 : kQuadFar;
             g_ww = stage ? ww : 0;
@@ -556,9 +560,10 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         __syncthreads();   // B2: every wave is done reading level 0's window
         if (iter == 0) stamp(11);
         if (has_next) tables_2(par ^ 1, nb);   // visible after B3
+        const bool third_round = __builtin_amdgcn_readfirstlane((int)late3) != 0;   // (the same in every lane)
         stage_level(std::integral_constant<int, 1>{});
         stage_level(std::integral_constant<int, 2>{});
-        stage_level(std::integral_constant<int, 3>{});
+        if (!third_round) stage_level(std::integral_constant<int, 3>{});
         if (iter == 0) stamp(12);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         if (iter == 0) stamp(13);
@@ -566,6 +571,12 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         if (iter == 0) stamp(7);
         gather_level(std::integral_constant<int, 1>{});
         gather_level(std::integral_constant<int, 2>{});
+        if (third_round) {   // ---- round 2: level 3 on its own ----
+            __syncthreads();
+            stage_level(std::integral_constant<int, 3>{});
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+        }
         gather_level(std::integral_constant<int, 3>{});
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps)
