@@ -364,5 +364,14 @@ static inline CD hipemu_mfma(int kind, AB a, AB b, CD c, unsigned site)
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu_mfma(::hipemu::kOpMfma32x32x16Bf16, (a), (b), (c), __LINE__)
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hipemu_mfma(::hipemu::kOpMfma16x16x32Bf16, (a), (b), (c), __LINE__)
 #define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) hipemu_mfma(::hipemu::kOpMfma32x32x16F16, (a), (b), (c), __LINE__)
+template <class CD>
+static inline CD hipemu_mfma_f32(float a, float b, CD c, unsigned site)
+{
+    CD d;
+    ::hipemu::OpReq q{::hipemu::kOpMfma16x16x4F32, site, &a, &d, 0, 0, 0, &b, &c};
+    ::hipemu::wave_op(q);
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) hipemu_mfma_f32((float)(a), (float)(b), (c), __LINE__)
 
 #endif  // TF_HIPEMU_HIP_RUNTIME_H_

@@ -1,6 +1,7 @@
 // tests/emu/hipemu/hipemu.cpp -- the fiber engine of the SIMT emulator (see hipemu.h).  TEST INFRASTRUCTURE.
 #include "hipemu.h"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <sys/mman.h>
@@ -236,6 +237,29 @@ void exec_group(Engine *e, Fiber **wave_lanes, int nlanes, const std::vector<int
                 d[r] = (float)((double)c[r] + acc);
             }
             memcpy(wave_lanes[l]->req->out, d, sizeof(float) * NR);
+        }
+        break;
+    }
+    case kOpMfma16x16x4F32: {
+        // v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulation (modelled as the fused chain over k = 0 .. 3)
+        if ((int)grp.size() != kWave) {
+            fprintf(stderr, "hipemu: MFMA with %zu active lanes\n", grp.size());
+            abort();
+        }
+        float A[16][4], B[16][4];
+        for (int l = 0; l < kWave; ++l) {
+            A[l % 16][l / 16] = *(const float *)wave_lanes[l]->req->in;
+            B[l % 16][l / 16] = *(const float *)wave_lanes[l]->req->in2;
+        }
+        for (int l = 0; l < kWave; ++l) {
+            const float *c = (const float *)wave_lanes[l]->req->in3;
+            float d[4];
+            for (int r = 0; r < 4; ++r) {
+                float acc = c[r];
+                for (int k = 0; k < 4; ++k) acc = fmaf(A[4 * (l >> 4) + r][k], B[l % 16][k], acc);
+                d[r] = acc;
+            }
+            memcpy(wave_lanes[l]->req->out, d, sizeof(d));
         }
         break;
     }

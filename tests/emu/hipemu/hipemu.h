@@ -51,6 +51,7 @@ enum OpKind : int {
     kOpMfma32x32x16Bf16,
     kOpMfma16x16x32Bf16,
     kOpMfma32x32x16F16,
+    kOpMfma16x16x4F32,  // in / in2: ONE float of A (row lane % 16, k lane / 16) / of B (column lane % 16, k lane / 16); in3 / out: 4 floats
     kOpLdsDma,         // in: 16/4 bytes of data fetched by the lane; lds base = first active lane's pointer
     kOpLdsTrack16,     // in: the lane's 32-bit LDS address of a ds_read_b128; accounting only (HIPEMU_LDS_TRACK=1)
 };

@@ -376,8 +376,13 @@ def test_fp16_product_is_fp32_class_whatever_the_magnitudes(xs, ws):
         assert err < 2 * sgemm      # every |x| of these cases is above 2^-10 up to the rows scaled down by 1e-2 ... still above it
 
 
-@pytest.mark.parametrize("Lq,Lk,H,D,masked", [(100, 100, 8, 32, False), (57, 130, 8, 36, True), (33, 33, 4, 16, True), (40, 40, 2, 64, False)])
-def test_query_self_attention_kernel(Lq, Lk, H, D, masked):
+@pytest.mark.parametrize("mfma", [1, 2, 0], ids=["matrix_cores", "matrix_cores_lds_staged", "vector"])
+@pytest.mark.parametrize("Lq,Lk,H,D,masked", [(100, 100, 8, 32, False), (57, 130, 8, 36, True), (33, 33, 4, 16, True), (40, 40, 2, 64, False),
+                                              (280, 90, 8, 36, True), (17, 1, 2, 32, False),
+                                              (20, 600, 2, 32, True), (18, 300, 2, 64, True), (20, 530, 1, 36, False)])
+def test_query_self_attention_kernel(Lq, Lk, H, D, masked, mfma):
+    """tf_mha_core_f32: the fp32 matrix-core kernel (round 5: v_mfma_f32_16x16x4_f32 for q k^T and P V) and the vector kernel it
+    replaced, against float64 numpy.  (280 queries x 8 heads x 2 images = more workgroups than CUs: 64-key chunks, one buffer.)"""
     rng = np.random.default_rng(Lq + D)
     N = 2
     q = rng.standard_normal((N, Lq, H, D), dtype=np.float32)
@@ -395,8 +400,17 @@ def test_query_self_attention_kernel(Lq, Lk, H, D, masked):
     p = np.exp(s - s.max(-1, keepdims=True))
     p /= p.sum(-1, keepdims=True)
     ref = np.einsum("nhlj,njhd->nlhd", p, v.astype(np.float64))
-    base = emu_lib.mha_core(q, k, v, scale, mask)
-    np.testing.assert_allclose(base, ref, atol=2e-5, rtol=1e-4)
+    prev = emu_lib.set_options(mha_mfma=mfma)
+    try:
+        base = emu_lib.mha_core(q, k, v, scale, mask)
+        np.testing.assert_allclose(base, ref, atol=2e-5, rtol=1e-4)
+        if masked:   # a row whose keys are all masked gives zeros (both kernels), not NaN
+            mask[1, :] = 1
+            out = emu_lib.mha_core(q, k, v, scale, mask)
+            assert np.array_equal(out[1], np.zeros_like(out[1]))
+            np.testing.assert_allclose(out[0], ref[0], atol=2e-5, rtol=1e-4)
+    finally:
+        emu_lib.set_options(**prev)
 
 
 # ---- kernels first written against this emulator (defaults since their hardware validation in round 3) --------------------------------------------------------------

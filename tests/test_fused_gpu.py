@@ -77,9 +77,20 @@ def test_residual_norm_dispatch(dev):
 
 @pytest.mark.parametrize("n,length,heads,d,masked", [(1, 400, 8, 32, False), (1, 800, 8, 36, False),
                                                      (2, 77, 8, 32, True), (1, 7, 4, 64, False), (1, 1030, 8, 32, True)])
-def test_mha_core_matches_torch_reference(dev, n, length, heads, d, masked):
+@pytest.mark.parametrize("mfma", [1, 2, 0], ids=["matrix_cores", "matrix_cores_lds_staged", "vector"])
+def test_mha_core_matches_torch_reference(dev, n, length, heads, d, masked, mfma):
     """tf_mha_core_f32 (decoder query self-attention, deformable_transformer.py:364-383) against the plain fp32
-    formulation softmax(q k^T / sqrt(d)) v evaluated in float64."""
+    formulation softmax(q k^T / sqrt(d)) v evaluated in float64: the fp32 matrix-core kernel (the default since round 5)
+    and the vector kernel it replaced."""
+    from trackformer_amd import _cabi, fused
+    prev = _cabi.lib().tf_msda_set_option(b"mha_mfma", mfma)
+    try:
+        _mha_case(dev, n, length, heads, d, masked)
+    finally:
+        _cabi.lib().tf_msda_set_option(b"mha_mfma", prev)
+
+
+def _mha_case(dev, n, length, heads, d, masked):
     from trackformer_amd import fused
     g = torch.Generator().manual_seed(length)
     e = heads * d

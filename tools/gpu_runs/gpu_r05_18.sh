@@ -1,0 +1,5 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r18
+timeout 600 python -m pytest tests/test_fused_gpu.py -q -k "mha or self_attention" 2>&1 | tail -8 > gpurun_out/r18/mha_tests.txt
+timeout 300 python tools/bench_mha.py > gpurun_out/r18/bench_mha.txt 2>&1
+cat gpurun_out/r18/*.txt
