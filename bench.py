@@ -815,7 +815,7 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
                             if nxt is not None and not args.no_prepare:
                                 # the image-only half of the next frame (backbone, encoder) goes to the GPU BEFORE the host
                                 # associates this one: Tracker.step_prepare -- a single sequence no longer leaves the GPU idle
-                                trackers[s].step_prepare(nxt)
+                                trackers[s].step_prepare(nxt, image_ready=not args.host_frames)   # (device frames: resident since before the run)
                             trackers[s].step_finish(handles[s])
                             handles[s] = None
                             done[s] += 1
@@ -1035,7 +1035,8 @@ def main():
                        "parallelism": ("DDP x%d (RCCL all-reduce)" if train else "sequence-sharded x%d") % world,
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
                        **({"pipelined": "the next frame's backbone + encoder are enqueued before the host associates the current "
-                                        "frame (Tracker.step_prepare; results those of step())"}
+                                        "frame, on a side stream next to the current frame's decoder half (Tracker.step_prepare; "
+                                        "results those of step())"}
                           if cfg["kind"] == "track" and not args.no_prepare else {}),
                        "linears": (_ARITH[fused.split_terms()][0] + ", f32 accumulate (own kernels)")
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",

@@ -32,7 +32,11 @@ Two graphs (round 5).  For the single-frame models without a mask head the forwa
 input projections + encoder, which depends on the image only, and B = decoder + heads, which also takes the track queries.
 `prepare(img)` replays A for a frame whose track queries are not known yet -- Tracker.step_prepare calls it for frame
 t + 1 before it associates frame t, so that the GPU never waits for the host in a single sequence -- and the following
-call with that tensor replays B alone.  Without prepare() a call replays A and B back to back: same kernels as one graph.
+call with the tensor it returned replays B alone.  Without prepare() a call replays A and B back to back: same kernels as one
+graph.  prepare() runs A on a SIDE stream of the wrapper and into one of TWO sets of static buffers (used alternately), so that
+A of frame t + 1 (53 convolutions and the encoder: large launches) shares the GPU with B of frame t (the decoder: ~150 launches of
+a few microseconds on 300-400 rows, which leave most of the chip idle) instead of queueing behind it; B waits for its A by an
+event, A waits by an event for the B that last read its buffers.  The arithmetic of a frame is unchanged.
 
 Threads: bench.py and INTEGRATION.md run one tracker thread (own HIP stream) per sequence against one
 shared model.  Captures are serialised by a process-wide lock and run in `thread_local` capture mode
@@ -53,14 +57,16 @@ class GraphedDetector:
     # the latest set (Tracker with prev_frame_dist > 1) has to clone them -- Tracker.step checks this attribute
     features_alias_static_buffers = True
 
-    def __init__(self, model, max_graphs=16, bucket=16):
+    def __init__(self, model, max_graphs=32, bucket=16):
         self.model = model
         self.max_graphs = max_graphs
         self.bucket = max(1, int(bucket))
         self._graphs = OrderedDict()
         self._seen = {}
-        self._enc = {}            # (image shape, device) -> the image-only half as its own graph (prepare(), module docstring)
-        self._prepared = None     # (image tensor, its _enc entry) of the last prepare()
+        self._enc = {}            # (image shape, device) -> [slot 0, slot 1]: the image-only half as its own graph, two sets of buffers
+        self._prepared = None     # (static image tensor, slot index) of the last prepare()
+        self._slot = 0            # the slot the last forward read: prepare() fills the other one
+        self._side = {}           # device -> the stream prepare() runs the image-only half on
 
     def __getattr__(self, name):  # only called for attributes GraphedDetector itself lacks
         return getattr(self.model, name)
@@ -92,42 +98,80 @@ class GraphedDetector:
         m = self.model
         return hasattr(m, "encode_frame") and not self._multi_frame() and not hasattr(m, "mask_head")
 
-    def _capture_encoder(self, img):
-        entry = {"img": img.clone()}
-        dev = img.device
+    def _side_stream(self, dev):
+        st = self._side.get(dev)
+        if st is None:
+            st = self._side[dev] = torch.cuda.Stream(dev)
+        return st
+
+    def _capture_encoder(self, img, dev):
+        """One slot of the image-only half: static image, static results, the graph (captured ON the side stream: library
+        workspaces that PyTorch keys by capture stream are then not the ones of the decoder graphs it runs next to), and the
+        events that order it against the decoder graphs reading its results."""
+        side = self._side_stream(dev)
+        cur = torch.cuda.current_stream(dev)
+        entry = {"done": torch.cuda.Event(), "free": torch.cuda.Event(), "ran": False, "read": False}
         with _CAPTURE_LOCK:
-            side = torch.cuda.Stream(dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
+            side.wait_stream(cur)
             with torch.cuda.stream(side):
+                entry["img"] = img.to(dev, copy=True)
                 for _ in range(2):
                     warm = self.model.encode_frame(entry["img"], None)
-            torch.cuda.current_stream(dev).wait_stream(side)
+            cur.wait_stream(side)
             del warm
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 entry["state"] = self.model.encode_frame(entry["img"], None)
         entry["graph"] = graph
         return entry
 
-    def prepare(self, img, prev_features=None):
-        """Enqueue the IMAGE-ONLY half of the forward (backbone, input projections, encoder) for `img` on the current stream
-        and return True; the next call of the detector with this very tensor then runs the decoder half only.  A tracker
-        calls it for frame t + 1 before it associates frame t (Tracker.step_prepare): the GPU works on the next frame while
-        the host decides about this one.  False: nothing was enqueued (not a model / input this applies to, or the graph of
-        this image shape does not exist yet -- it is captured by the ordinary calls)."""
-        if not (self._splittable() and self._capturable(img, None, prev_features)):
-            return False
-        a = self._enc.get((tuple(img.shape), img.device))
-        if a is None:
-            return False
-        a["img"].copy_(img, non_blocking=True)
-        a["graph"].replay()
-        self._prepared = (img, a)
-        return True
+    def prepare(self, img, prev_features=None, device=None, image_ready=False):
+        """Enqueue the IMAGE-ONLY half of the forward (backbone, input projections, encoder) for `img` and return the static
+        device tensor that now holds the image: calling the detector with THAT tensor then runs the decoder half only.  A
+        tracker calls it for frame t + 1 before it associates frame t (Tracker.step_prepare): the GPU works on the next frame
+        while the host decides about this one, and -- the half runs on the wrapper's side stream -- next to the decoder
+        half of frame t, which on its own leaves most of the chip idle.
+        `img`: a host tensor (copied to `device` on the side stream) or a device tensor; the side stream waits for the work
+        enqueued so far on the current stream before it reads a device tensor unless `image_ready` says the tensor is
+        complete already (frames resident on the device before the sequence started: waiting would queue this frame's
+        image-only half behind the previous frame's decoder half).
+        None: nothing was enqueued (not a model / input this applies to, or the graph of this image shape does not exist
+        yet -- it is captured by the ordinary calls)."""
+        m = self.model
+        if not self._splittable() or torch.is_grad_enabled() or m.training or not getattr(m, "_tracking", True):
+            return None
+        if not torch.is_tensor(img) or img.dim() != 4 or img.shape[0] != 1:
+            return None
+        dev = img.device if img.is_cuda else (torch.device(device) if device is not None else None)
+        if dev is None or dev.type != "cuda":
+            return None
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        slots = self._enc.get((tuple(img.shape), dev))
+        if slots is None:
+            return None
+        i = 1 - self._slot
+        if slots[i] is None:
+            slots[i] = self._capture_encoder(img, dev)
+        a = slots[i]
+        side, cur = self._side_stream(dev), torch.cuda.current_stream(dev)
+        if img.is_cuda and not image_ready:
+            side.wait_stream(cur)
+        if a["read"]:
+            side.wait_event(a["free"])      # the decoder half that last read this slot's results is done with them
+        with torch.cuda.stream(side):
+            a["img"].copy_(img, non_blocking=True)
+            a["graph"].replay()
+            a["done"].record(side)
+        if img.is_cuda:
+            img.record_stream(side)
+        a["ran"] = True
+        self._prepared = (a["img"], i)
+        return a["img"]
 
-    def _capture(self, img, target, prev_features):
+    def _capture(self, img, target, prev_features, slot=0):
         if self._splittable():
-            return self._capture_decoder(img, target)
+            return self._capture_decoder(img, target, slot)
         entry = {"img": img.clone()}
         static_target = None
         if target is not None:
@@ -173,11 +217,13 @@ class GraphedDetector:
         entry["graph"] = graph
         return entry
 
-    def _capture_decoder(self, img, target):
+    def _capture_decoder(self, img, target, slot):
         akey = (tuple(img.shape), img.device)
-        a = self._enc.get(akey)
-        if a is None:
-            a = self._enc[akey] = self._capture_encoder(img)
+        torch.cuda.synchronize(img.device)   # (a prepared image-only half of this slot may be in flight on the side stream)
+        slots = self._enc.setdefault(akey, [None, None])
+        if slots[slot] is None:
+            slots[slot] = self._capture_encoder(img, img.device)
+        a = slots[slot]
         entry = {"enc": a, "prev": None}
         static_target = None
         if target is not None:
@@ -256,16 +302,28 @@ class GraphedDetector:
             target, n_real, n_pad = self._bucketed(target)
         n_track = n_pad
         lazy = getattr(self.model, "lazy_masks_active", None)
+        prepared, self._prepared = self._prepared, None
+        slot = prepared[1] if prepared is not None and prepared[0] is img else 0   # the buffers prepare() filled for this very tensor
+        if prepared is not None and prepared[0] is not img:
+            prepared = None
+        if prepared is not None:   # `img` IS the slot's static image: the side stream fills it (and the encoder results)
+            torch.cuda.current_stream(img.device).wait_event(self._enc[(tuple(img.shape), img.device)][slot]["done"])
         key = (tuple(img.shape), n_track, img.device, bool(multi and prev_features is not None),
-               bool(lazy()) if lazy is not None else False)   # a graph with and one without the mask head are different graphs
+               bool(lazy()) if lazy is not None else False,   # a graph with and one without the mask head are different graphs
+               slot)                                          # the decoder half reads ONE slot's static buffers
         entry = self._graphs.get(key)
         if entry is None:
             # capture a shape the second time it shows up (one-off shapes are not worth a graph)
             self._seen[key] = self._seen.get(key, 0) + 1
             if self._seen[key] < 2:
-                self._prepared = None
-                return self.model(img, caller_target, prev_features)
-            entry = self._capture(img, target, prev_features)
+                res = self.model(img, caller_target, prev_features)
+                if prepared is not None:   # the eager forward read the slot's static image: prepare() must not overwrite it yet
+                    a = self._enc[(tuple(img.shape), img.device)][slot]
+                    a["free"].record(torch.cuda.current_stream(img.device))
+                    a["read"] = True
+                    self._slot = slot
+                return res
+            entry = self._capture(img, target, prev_features, slot)
             self._graphs[key] = entry
             while len(self._graphs) > self.max_graphs:
                 self._graphs.popitem(last=False)   # least recently used
@@ -278,8 +336,10 @@ class GraphedDetector:
                 entry["filler"].copy_(target[0]['track_query_filler'], non_blocking=True)
         if "enc" in entry:   # two graphs: the image-only half unless prepare() already ran it for this very tensor
             a = entry["enc"]
-            prepared, self._prepared = self._prepared, None
-            if prepared is None or prepared[0] is not img or prepared[1] is not a:
+            cur = torch.cuda.current_stream(img.device)
+            if a["ran"]:
+                cur.wait_event(a["done"])   # the side stream's last run into this slot (the one prepare() started, or a stale one)
+            if prepared is None:
                 a["img"].copy_(img, non_blocking=True)
                 a["graph"].replay()
         else:
@@ -287,6 +347,10 @@ class GraphedDetector:
         if entry["prev"] is not None:
             self._feed_prev(entry, prev_features)
         entry["graph"].replay()
+        if "enc" in entry:
+            a["free"].record(cur)
+            a["read"] = True
+            self._slot = slot
         out, tgt, features, memory, hs = entry["out"]
         # what the tracker keeps across frames must not alias the static buffers (see the module docstring)
         out = dict(out)

@@ -271,7 +271,7 @@ class Tracker:
         'dets' [1,K,4] xyxy public detections} as produced by the reference's sequence datasets."""
         self.step_finish(self.step_async(blob))
 
-    def step_prepare(self, blob):
+    def step_prepare(self, blob, image_ready=False):
         """Optional, BEFORE step_finish of the previous frame: enqueue the image-only half of `blob`'s forward (backbone,
         input projections, encoder -- GraphedDetector.prepare, or the model's encode_frame) so that the GPU works on this
         frame while the host still associates the previous one; the following step_async(blob) / step(blob) of the SAME
@@ -279,14 +279,17 @@ class Tracker:
         tracks.  Returns whether anything was enqueued (multi-frame and mask-head models: no -- their first half needs the
         previous frame's features / feeds the mask head)."""
         det = self.obj_detector
-        img = blob['img'].to(self.device, non_blocking=True)
         prep = getattr(det, "prepare", None)
         self._prepared = None
         if prep is not None:
-            if prep(img, None):
+            # GraphedDetector: the half runs on the wrapper's side stream, NEXT TO the previous frame's decoder half (a host
+            # image is uploaded on that stream too); `image_ready`: a device-resident blob['img'] is complete already
+            img = prep(blob['img'], None, device=self.device, image_ready=image_ready)
+            if img is not None:
                 self._prepared = (blob['img'], img, None)
                 return True
             return False
+        img = blob['img'].to(self.device, non_blocking=True)
         if (hasattr(det, "encode_frame") and not getattr(det, "multi_frame_attention", False) and not hasattr(det, "mask_head")
                 and not det.training and not torch.is_grad_enabled()):
             self._prepared = (blob['img'], img, det.encode_frame(img, None))
