@@ -127,6 +127,17 @@ def test_rank_cpu_shares_follow_the_gpu_numa_map(monkeypatch):
             assert len(set(flat)) == 32                                                # every CPU of both nodes is used
         else:
             assert shares == [allowed[4 * r:4 * r + 4] for r in range(8)]              # everyone fell back together
+    # a cpuset that covers node 0 only (a container): node 1's ranks have no CPU of their own node -- the fallback is decided on the
+    # whole table, so EVERY rank takes the even split (deciding per rank let node 0's ranks keep node slices that overlapped it)
+    allowed = list(range(16))
+    for node_of in ([0, 0, 0, 0, 1, 1, 1, 1], [0, 1, 0, 1, 0, 1, 0, 1]):
+        shares = [du._cpu_share(r, 8, allowed, node_of) for r in range(8)]
+        assert shares == [allowed[2 * r:2 * r + 2] for r in range(8)], (node_of, shares)
+    # node 1 has CPUs, but fewer than ranks: the same
+    allowed = list(range(16)) + [16, 17]
+    shares = [du._cpu_share(r, 8, allowed, [0, 0, 0, 0, 1, 1, 1, 1]) for r in range(8)]
+    flat = [c for s in shares for c in s]
+    assert len(flat) == len(set(flat)) and all(shares) and shares[0] == allowed[0:2]
 
 
 def test_host_nms_orders_nan_scores_first_and_keeps_input_order_among_ties():

@@ -213,6 +213,8 @@ class MaskHeadSmallConv(nn.Module):
             taps = w.new_zeros(cout, 3, 3, cin_pad)
             taps[..., :cin] = w.permute(0, 2, 3, 1)
             hit = ((conv.weight._version, cin_pad), taps.reshape(cout, 9 * cin_pad).contiguous())
+            if w.is_cuda and torch.cuda.is_current_stream_capturing():
+                return hit[1]   # built inside a graph's memory pool: part of that graph, never a cached buffer
             if w.is_cuda:
                 from . import fused
                 fused._publish_barrier(w.device)   # built on this stream, read by every sequence's stream from now on
@@ -244,17 +246,28 @@ class MaskHeadSmallConv(nn.Module):
         num_queries = bbox_mask.shape[1]
         c_img = x.shape[1]
         split = self._split_route(x)
-        if split and x.shape[0] == 1 and num_queries > _SPLIT_QUERY_CHUNK:
-            # queries are independent: chunks keep every activation of the route below the kernels' 3 GiB offsets (the finest
-            # level is 8.6 MB per query and channel group at 800 x 1333) and bound the head's memory
-            return torch.cat([self.forward(x, bbox_mask[:, q0:q0 + _SPLIT_QUERY_CHUNK], fpns)
-                              for q0 in range(0, num_queries, _SPLIT_QUERY_CHUNK)], 0)
-        # lay1 over cat([x repeated per query, attention maps]) == lay1_img(x) + lay1_att(maps):
-        # the image part (and the bias) once per image, the attention part per query
-        w = self.lay1.weight
-        y_img = F.conv2d(x, w[:, :c_img], self.lay1.bias, padding=1)                 # [B, dim, h, w]
-        y_att = F.conv2d(bbox_mask.flatten(0, 1), w[:, c_img:], None, padding=1)     # [B*Q, dim, h, w]
-        x = (y_att.view(x.shape[0], num_queries, *y_att.shape[1:]) + y_img[:, None]).flatten(0, 1)
+        # What does not depend on the query is computed ONCE per image: lay1 over cat([x repeated per query, attention maps])
+        # == lay1_img(x) + lay1_att(maps) -- the image part (and the bias) here, the attention part per query below -- and
+        # the three adapter convolutions of the backbone features
+        y_img = F.conv2d(x, self.lay1.weight[:, :c_img], self.lay1.bias, padding=1)                 # [B, dim, h, w]
+        feats = [self.adapter1(fpns[0]), self.adapter2(fpns[1]), self.adapter3(fpns[2])]
+        if split:
+            feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
+            if x.shape[0] * num_queries > _SPLIT_QUERY_CHUNK:
+                # (image, query) pairs are independent: chunks of one image's queries keep every activation of the route below
+                # the kernels' 3 GiB offsets (the finest level is 8.6 MB per query and channel group at 800 x 1333) and bound
+                # the head's memory, for any batch size
+                return torch.cat([self._per_query(y_img[b:b + 1], bbox_mask[b:b + 1, q0:q0 + _SPLIT_QUERY_CHUNK],
+                                                  [f[b:b + 1] for f in feats], c_img, True)
+                                  for b in range(x.shape[0]) for q0 in range(0, num_queries, _SPLIT_QUERY_CHUNK)], 0)
+        return self._per_query(y_img, bbox_mask, feats, c_img, split)
+
+    def _per_query(self, y_img, bbox_mask, feats, c_img, split):
+        """The per-query part of the head: y_img [B, dim, h, w] (lay1's image part), bbox_mask [B, Q', heads, h, w],
+        feats 3 x [B, C_k, H_k, W_k] (the adapters' outputs) -> [B * Q', 1, H_2, W_2]."""
+        batch, num_queries = bbox_mask.shape[:2]
+        y_att = F.conv2d(bbox_mask.flatten(0, 1), self.lay1.weight[:, c_img:], None, padding=1)     # [B*Q', dim, h, w]
+        x = (y_att.view(batch, num_queries, *y_att.shape[1:]) + y_img[:, None]).flatten(0, 1)
         x = F.relu(self.gn1(x))
         if split:
             n, c, h, wd = x.shape
@@ -262,18 +275,16 @@ class MaskHeadSmallConv(nn.Module):
             xp = x.new_zeros(n, h, wd, cin_pad)                                      # channels innermost, zero tail
             xp[..., :c] = x.permute(0, 2, 3, 1)
             x = self._conv_gn_relu(xp.permute(0, 3, 1, 2), self.lay2, self.gn2)
-            for adapter, conv, gn, fpn in ((self.adapter1, self.lay3, self.gn3, fpns[0]), (self.adapter2, self.lay4, self.gn4, fpns[1]),
-                                           (self.adapter3, self.lay5, self.gn5, fpns[2])):
-                x = self._merge(x, adapter(fpn).contiguous(memory_format=torch.channels_last), num_queries)
+            for conv, gn, feat in ((self.lay3, self.gn3, feats[0]), (self.lay4, self.gn4, feats[1]), (self.lay5, self.gn5, feats[2])):
+                x = self._merge(x, feat, num_queries)
                 x = self._conv_gn_relu(x.contiguous(memory_format=torch.channels_last), conv, gn)
             return self.out_lay(x)
         x = F.relu(self.gn2(self.lay2(x)))
-
-        x = self._merge(x, self.adapter1(fpns[0]), num_queries)
+        x = self._merge(x, feats[0], num_queries)
         x = F.relu(self.gn3(self.lay3(x)))
-        x = self._merge(x, self.adapter2(fpns[1]), num_queries)
+        x = self._merge(x, feats[1], num_queries)
         x = F.relu(self.gn4(self.lay4(x)))
-        x = self._merge(x, self.adapter3(fpns[2]), num_queries)
+        x = self._merge(x, feats[2], num_queries)
         x = F.relu(self.gn5(self.lay5(x)))
         return self.out_lay(x)
 

@@ -64,15 +64,21 @@ def _node_cpus(node):
 
 def _cpu_share(local_rank, local_world, allowed, node_of):
     """The CPU slice of `local_rank`.  node_of: NUMA node of every local rank's GPU (None where unknown).  Every rank computes the
-    same table from sysfs, so the ranks agree without a collective: when ALL nodes are known, the ranks whose GPUs share a node
-    split that node's CPUs by their order among themselves (whatever the GPU -> node mapping looks like: contiguous, interleaved,
-    uneven); when any is unknown, every rank falls back to an even split of the allowed CPUs by local rank."""
+    same table from sysfs, so the ranks agree without a collective: when ALL nodes are known AND every node in use has at least
+    one allowed CPU per rank on it, the ranks whose GPUs share a node split that node's CPUs by their order among themselves
+    (whatever the GPU -> node mapping looks like: contiguous, interleaved, uneven).  Otherwise -- a node unknown, or a node
+    whose allowed CPUs do not go round (a container cpuset that covers one node only) -- EVERY rank takes the even split of
+    the allowed CPUs by local rank: the decision is made on the whole table, never per rank, so slices cannot overlap."""
     if all(n is not None for n in node_of):
-        mine = node_of[local_rank]
-        cpus = _node_cpus(mine)
-        pool = sorted(set(allowed) & cpus) if cpus else []
-        peers = [r for r in range(local_world) if node_of[r] == mine]
-        if pool and len(pool) >= len(peers):
+        pools, ok = {}, True
+        for node in sorted(set(node_of)):
+            cpus = _node_cpus(node)
+            pools[node] = sorted(set(allowed) & cpus) if cpus else []
+            ok = ok and len(pools[node]) >= sum(1 for n in node_of if n == node)
+        if ok:
+            mine = node_of[local_rank]
+            pool = pools[mine]
+            peers = [r for r in range(local_world) if node_of[r] == mine]
             k = peers.index(local_rank)
             return pool[len(pool) * k // len(peers):len(pool) * (k + 1) // len(peers)]
     return allowed[len(allowed) * local_rank // local_world:len(allowed) * (local_rank + 1) // local_world]

@@ -232,6 +232,8 @@ def _split_weight(weight):
             hi = ws.to(torch.float16)
             lo = (ws - hi.float()).to(torch.float16)
             hit = (weight._version, hi.contiguous(), lo.contiguous(), None, (16.0 / t).contiguous())
+            if w.is_cuda and torch.cuda.is_current_stream_capturing():
+                return hit[1], hit[2], hit[3], hit[4]   # built inside a graph's memory pool: part of the graph, never a cached buffer
             if w.is_cuda:
                 _publish_barrier(w.device)
             weight._tf_split_f16 = hit
@@ -244,6 +246,8 @@ def _split_weight(weight):
         mid = r.to(torch.bfloat16)
         lo = (r - mid.float()).to(torch.bfloat16).contiguous() if _split_terms == 6 else None
         hit = (weight._version, hi.contiguous(), mid.contiguous(), lo)
+        if w.is_cuda and torch.cuda.is_current_stream_capturing():
+            return hit[1], hit[2], (hit[3] if _split_terms == 6 else None), None   # (as above: not cached)
         if w.is_cuda:
             _publish_barrier(w.device)
         weight._tf_split = hit

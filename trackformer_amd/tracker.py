@@ -526,7 +526,8 @@ class Tracker:
             # probability exceeds 0.5 -- `logical_and(probs > 0.5, index_map == probs.argmax(0))`.  Ownership is exclusive, so
             # ONE label map (owning track or -1 per pixel) holds every track's mask: 2 bytes per pixel reach the host instead
             # of one byte per pixel AND track (3.9 MB instead of ~290 MB per 1080 x 1800 frame with 150 tracks; cfg 5 went
-            # from 40 to ... ms per step, profiles/r04_bench_cfg5.json); the per-track boolean masks of the results are
+            # from 40.0 to 21.1 ms per step together with the mask head's split-product route, profiles/r03_bench_cfg5.json ->
+            # r04_bench_cfg5.json); the per-track boolean masks of the results are
             # rebuilt from it when somebody reads them (`results`), bit-identical.
             probs = torch.stack([t.mask for t in self.tracks])
             best, owner = probs.max(dim=0)            # ties: the first track, as argmax
