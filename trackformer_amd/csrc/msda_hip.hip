@@ -761,7 +761,13 @@ msda_fwd_f32_direct9(const DirectArgs da, const LevelTable lt, const int64_t *__
 // ---------------------------------------------------------------------------------------------
 constexpr int kWinThreads = 512;
 constexpr int kWinWaves = kWinThreads / 64;
-constexpr int kWinPasses = 2;
+#ifndef TF_BWD_PASSES
+#define TF_BWD_PASSES 2   // tools/build_variant.py --source msda_hip.hip -DTF_BWD_PASSES=4: 256-query tiles (experiment)
+#endif
+#ifndef TF_BWD_ABLATE
+#define TF_BWD_ABLATE 0   // timing ablations of msda_bwd_f32_sorted2 (tools only): 1 no global atomics, 2 no value gathers, 4 no sort / reduce
+#endif
+constexpr int kWinPasses = TF_BWD_PASSES;
 constexpr int kWinPairs = kWinThreads / 8;               // (query, head) pairs per pass
 constexpr int kWinMaxQueries = kWinPasses * kWinPairs;   // queries per tile
 constexpr int kWinLevels = 4;
@@ -797,7 +803,10 @@ struct WinGeom {
 // full rows.  grad_loc / grad_attn as in the row kernels.
 constexpr int kSortRowsCap = 1024;                      // destination rows binned per level and tile
 constexpr int kSortItems = kWinMaxQueries * 4 * 4;      // taps per level: queries x points x taps
-constexpr unsigned kSortInvalid = 0xFFFFFFFFu;          // item key: [31] direct scatter, [30:24] query, [23:0] row
+constexpr unsigned kSortInvalid = 0xFFFFFFFFu;          // item key: [31] direct scatter, [30:23] query, [22:0] row
+constexpr int kSortQueryShift = 23;
+constexpr unsigned kSortRowMask = (1u << kSortQueryShift) - 1u, kSortQueryMask = 0xFFu;
+static_assert(kWinMaxQueries <= 256, "item key: 8 bits of query");
 constexpr int kSortOffCnt = 768;                                     // u32[kSortRowsCap]
 constexpr int kSortOffStart = kSortOffCnt + 4 * kSortRowsCap;        // u32[kSortRowsCap + 1]
 constexpr int kSortOffItem = kSortOffStart + 4224;                   // {key, weight}[kSortItems]
@@ -834,7 +843,7 @@ constexpr int kSort2XchPerWave = 1536;
 constexpr int kSort2OffXch = kSortLdsBytes;
 constexpr int kSort2LdsBytes = kSort2OffXch + kWinWaves * kSort2XchPerWave;
 
-__global__ void __launch_bounds__(kWinThreads, 4)
+__global__ void __launch_bounds__(kWinThreads, (kWinPasses > 2 ? 2 : 4))
 msda_bwd_f32_sorted2(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg)
 {
     constexpr int PT = 4, D = 32, LPAIRS = kWinLevels / 2;
@@ -1058,7 +1067,7 @@ msda_bwd_f32_sorted2(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg
                         const unsigned row = inside ? (unsigned)((ty_ - wy0) * ww + (tx_ - wx0))
                                                     : (0x80000000u | (unsigned)(ty_ * W + tx_));
                         s_item[(tq * PT + sub) * 4 + tp] =
-                            uint2{row | ((unsigned)tq << 24), __builtin_bit_cast(unsigned, wt)};
+                            uint2{row | ((unsigned)tq << kSortQueryShift), __builtin_bit_cast(unsigned, wt)};
                         if (inside)
                             atomicAdd(&s_cnt[row], 1u);
                         else
@@ -1074,10 +1083,12 @@ msda_bwd_f32_sorted2(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg
                 const u32x4_t o = xch[p * 3 + 0];
                 const f32x4_t w = __builtin_bit_cast(f32x4_t, xch[p * 3 + 1]);
                 const f32x4_t f = __builtin_bit_cast(f32x4_t, xch[p * 3 + 2]);
-                const f32x4_t v1 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.x + la, 0, 0));
-                const f32x4_t v2 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.y + la, 0, 0));
-                const f32x4_t v3 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.z + la, 0, 0));
-                const f32x4_t v4 = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.w + la, 0, 0));
+                const bool gather = !(TF_BWD_ABLATE & 2);
+                const f32x4_t vz = __builtin_bit_cast(f32x4_t, o);   // (ablation 2: no loads, the arithmetic stays)
+                const f32x4_t v1 = gather ? __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.x + la, 0, 0)) : vz;
+                const f32x4_t v2 = gather ? __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.y + la, 0, 0)) : vz;
+                const f32x4_t v3 = gather ? __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.z + la, 0, 0)) : vz;
+                const f32x4_t v4 = gather ? __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, o.w + la, 0, 0)) : vz;
                 // s_t = <grad_out, value row of tap t>: this lane's 4 channels, then the 8 lanes of the pair
                 const f32x4_t g = gA[ps];
                 float s1 = (g.x * v1.x + g.y * v1.y) + (g.z * v1.z + g.w * v1.w);
@@ -1103,6 +1114,7 @@ msda_bwd_f32_sorted2(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg
         }
         __syncthreads();
 
+        if (TF_BWD_ABLATE & 4) continue;   // (ablation 4: no sort, no row reduction, no atomics; uniform)
         // ---- c. exclusive prefix sum of the row counts (wave 0; 16 consecutive rows per lane)
         if (wave == 0) {
             unsigned c[16], sum = 0;
@@ -1136,8 +1148,8 @@ msda_bwd_f32_sorted2(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg
         for (int i = threadIdx.x; i < kSortItems; i += kWinThreads) {
             const uint2 it = s_item[i];
             if (it.x != kSortInvalid && !(it.x & 0x80000000u)) {
-                const unsigned row = it.x & 0xFFFFFFu;
-                s_sorted[s_start[row] + atomicAdd(&s_cnt[row], 1u)] = uint2{((it.x >> 24) & 0x7Fu) * (unsigned)(D * 4), it.y};
+                const unsigned row = it.x & kSortRowMask;
+                s_sorted[s_start[row] + atomicAdd(&s_cnt[row], 1u)] = uint2{((it.x >> kSortQueryShift) & kSortQueryMask) * (unsigned)(D * 4), it.y};
             }
         }
         __syncthreads();
@@ -1177,8 +1189,11 @@ msda_bwd_f32_sorted2(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg
                     int wx = rowj - wy * ww;
                     if (wx < 0) { --wy; wx += ww; }
                     if (wx >= ww) { ++wy; wx -= ww; }
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
-                        v, rsrc_g, lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)ch * 4u, 0, 0);
+                    if (!(TF_BWD_ABLATE & 1))
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                            v, rsrc_g, lvl_base + (unsigned)((wy0 + wy) * W + wx0 + wx) * rowbytes + (unsigned)ch * 4u, 0, 0);
+                    else if (v == 12345.678f)   // (ablation: keep the sum alive)
+                        s_tr[rr * D + ch] = v;
                 }
             }
         }
@@ -1187,9 +1202,10 @@ msda_bwd_f32_sorted2(const BwdSortArgs ba, const LevelTable lt, const WinGeom wg
             for (int i = wave * 2 + half; i < kSortItems; i += 2 * kWinWaves) {
                 const uint2 it = s_item[i];
                 if (it.x != kSortInvalid && (it.x & 0x80000000u)) {
-                    const float v = __builtin_bit_cast(float, it.y) * s_go[((it.x >> 24) & 0x7Fu) * D + ch];
-                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
-                        v, rsrc_g, lvl_base + (it.x & 0xFFFFFFu) * rowbytes + (unsigned)ch * 4u, 0, 0);
+                    const float v = __builtin_bit_cast(float, it.y) * s_go[((it.x >> kSortQueryShift) & kSortQueryMask) * D + ch];
+                    if (!(TF_BWD_ABLATE & 1))
+                        __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(
+                            v, rsrc_g, lvl_base + (it.x & kSortRowMask) * rowbytes + (unsigned)ch * 4u, 0, 0);
                 }
             }
         }
@@ -1667,7 +1683,7 @@ bool plan_sorted(const LevelTable &lt, int L, int D, int P, WinGeom *wg)
     static const int on = [] { const char *e = getenv("TF_MSDA_BWD_SORTED"); return (e && e[0] == '0') ? 0 : 1; }();
     if (!on || D != 32 || P != 4 || L > kWinLevels) return false;
     for (int l = 0; l < L; ++l)
-        if (lt.H[l] >= 32768 || lt.W[l] >= 32768 || (long long)lt.H[l] * lt.W[l] >= (1 << 24)) return false;
+        if (lt.H[l] >= 32768 || lt.W[l] >= 32768 || (long long)lt.H[l] * lt.W[l] >= (1 << kSortQueryShift)) return false;
     struct Memo {
         bool valid = false, ok = false;
         int L = 0;
@@ -1716,6 +1732,11 @@ bool plan_sorted(const LevelTable &lt, int L, int D, int P, WinGeom *wg)
 }
 
 bool raise_dynamic_lds_limit(const void *fn);   // per (function, device), below
+
+// ---------------------------------------------------------------------------------------------
+// backward, encoder shape, fp32, D == 32, P == 4, L <= 4: two dense products on the matrix cores around the tap phase (round 5)
+// ---------------------------------------------------------------------------------------------
+#include "msda_bwd_mm.h"
 
 // ---- msda_fwd_f32_quad: options, tile plan, launch ----------------------------------------------------
 // Performance knobs (process-wide; tf_msda_set_option / TF_MSDA_QUAD="ta=12,waves=8,npass=1,lds=53,...").
@@ -2136,6 +2157,18 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
             buf_path_ok(lt, shapes_host != nullptr, N, S, M, D, L) && is_aligned(grad_value, 16)) {
             const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
             WinGeom sgeom;
+            const int mm_pairs = bwd_mm_pairs();
+            if (mm_pairs && shapes_host && Lq == S && is_aligned(loc, 8) && is_aligned(grad_loc, 8) &&
+                plan_mm(lt, L, D, P, mm_pairs, bwd_mm_rows() > 0 ? bwd_mm_rows() : 256, &sgeom) &&
+                (long long)N * sgeom.tiles_y * sgeom.tiles_x * M <= 0x7fffffffLL) {
+                BwdSortArgs ba{value, vbytes, loc, attn, grad_out, grad_value, grad_loc, grad_attn, S, M, L};
+                const void *mfn = mm_pairs == 64 ? (const void *)&msda_bwd_f32_mm<64> : (const void *)&msda_bwd_f32_mm<32>;
+                const size_t mlds = mm_lds_bytes(mm_pairs, sgeom.cap_rows);
+                if (mlds > 64 * 1024 && !raise_dynamic_lds_limit(mfn)) return record_hip(hipErrorInvalidValue);
+                void *argv[] = {(void *)&ba, (void *)&lt, (void *)&sgeom};
+                const unsigned mgrid = (unsigned)((long long)N * sgeom.tiles_y * sgeom.tiles_x * M);
+                return record_hip(hipLaunchKernel(mfn, dim3(mgrid), dim3(mm_pairs * 4), argv, mlds, stream));
+            }
             if (shapes_host && Lq == S && is_aligned(loc, 8) && is_aligned(grad_loc, 8) &&
                 plan_sorted(lt, L, D, P, &sgeom) &&
                 (long long)N * sgeom.tiles_y * sgeom.tiles_x * M <= 0x7fffffffLL) {
@@ -2226,6 +2259,16 @@ int tf_msda_set_option(const char *name, int value)
             return prev;
         }
     if (strcmp(name, "direct9") == 0) return g_direct9.exchange(value < 0 ? -1 : (value ? 1 : 0));
+    if (strcmp(name, "bwd_mm") == 0) {   // 0: msda_bwd_f32_sorted2, 32 / 64: msda_bwd_f32_mm with that many pairs per tile
+        const int prev = bwd_mm_pairs();
+        g_bwd_mm.store(value == 0 || value == 32 || value == 64 ? value : 32);
+        return prev;
+    }
+    if (strcmp(name, "bwd_mm_rows") == 0) {   // LDS rows of a tile's windows (0: the default)
+        const int prev = bwd_mm_rows();
+        g_bwd_mm_rows.store(value >= 16 && value <= kMmMaxRows ? value : 0);
+        return prev;
+    }
     if (strcmp(name, "ffn_ti") == 0) return ffn_set_ti(value);
     if (strcmp(name, "ffn_tail_split") == 0) return ffn_set_tail_split(value);
     if (strcmp(name, "linln_ti") == 0) return linln_set_ti(value);
