@@ -453,24 +453,10 @@ BWD2_CASES = [c for c in ENC_CASES if c[0] in ("pyramid_init", "pyramid_local_n2
                                                "tiny_levels", "one_level", "coarse_first")]
 
 
-BWD_KERNELS = {"mm32": dict(bwd_mm=32), "mm64": dict(bwd_mm=64), "mm32_rows_48": dict(bwd_mm=32, bwd_mm_rows=48), "sorted2": dict(bwd_mm=0)}
-
-
-@pytest.mark.parametrize("kernel", list(BWD_KERNELS))
 @pytest.mark.parametrize("name,shapes,mode,N,D", BWD2_CASES, ids=[c[0] for c in BWD2_CASES])
-def test_encoder_shape_backward_sorted2_kernel(name, shapes, mode, N, D, kernel):
-    """The encoder-shape backward kernels against the oracle.  msda_bwd_f32_mm (round 5, the default with 32 pairs per tile): S = V GO^T
-    and GV = Wt GO as fp32 matrix-core products around the tap phase -- also with 64 pairs, and with LDS rows for 48 window rows
-    only (most taps then take the per-lane path through global memory).  msda_bwd_f32_sorted2: tap arithmetic once per pair through
-    the per-wave LDS exchange, the channel sums as four dot products + 8-lane DPP reductions, eight destination rows per wave."""
-    prev = emu_lib.set_options(**BWD_KERNELS[kernel])
-    try:
-        _encoder_backward_case(name, shapes, mode, N, D)
-    finally:
-        emu_lib.set_options(**prev)
-
-
-def _encoder_backward_case(name, shapes, mode, N, D):
+def test_encoder_shape_backward_sorted2_kernel(name, shapes, mode, N, D):
+    """msda_bwd_f32_sorted2 (the encoder-shape backward): tap arithmetic once per pair through the per-wave LDS exchange, the
+    channel sums as four dot products + 8-lane DPP reductions, eight destination rows per wave in the row reduction."""
     value, loc, attn = encoder_inputs(shapes, mode, N=N, seed=len(name))
     shp = np.array(shapes, np.int64)
     rng = np.random.default_rng(3)

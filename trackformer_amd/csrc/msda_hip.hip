@@ -1733,11 +1733,6 @@ bool plan_sorted(const LevelTable &lt, int L, int D, int P, WinGeom *wg)
 
 bool raise_dynamic_lds_limit(const void *fn);   // per (function, device), below
 
-// ---------------------------------------------------------------------------------------------
-// backward, encoder shape, fp32, D == 32, P == 4, L <= 4: two dense products on the matrix cores around the tap phase (round 5)
-// ---------------------------------------------------------------------------------------------
-#include "msda_bwd_mm.h"
-
 // ---- msda_fwd_f32_quad: options, tile plan, launch ----------------------------------------------------
 // Performance knobs (process-wide; tf_msda_set_option / TF_MSDA_QUAD="ta=12,waves=8,npass=1,lds=53,...").
 enum QuadOpt { kQoTaMask, kQoWaves, kQoNpass, kQoLdsKb, kQoHaloY, kQoHaloX, kQoTileH, kQoTileW, kQoSplit, kQoCount };
@@ -2157,18 +2152,6 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
             buf_path_ok(lt, shapes_host != nullptr, N, S, M, D, L) && is_aligned(grad_value, 16)) {
             const unsigned vbytes = (unsigned)((long long)N * S * M * D * 4);
             WinGeom sgeom;
-            const int mm_pairs = bwd_mm_pairs();
-            if (mm_pairs && shapes_host && Lq == S && is_aligned(loc, 8) && is_aligned(grad_loc, 8) &&
-                plan_mm(lt, L, D, P, mm_pairs, bwd_mm_rows() > 0 ? bwd_mm_rows() : 256, &sgeom) &&
-                (long long)N * sgeom.tiles_y * sgeom.tiles_x * M <= 0x7fffffffLL) {
-                BwdSortArgs ba{value, vbytes, loc, attn, grad_out, grad_value, grad_loc, grad_attn, S, M, L};
-                const void *mfn = mm_pairs == 64 ? (const void *)&msda_bwd_f32_mm<64> : (const void *)&msda_bwd_f32_mm<32>;
-                const size_t mlds = mm_lds_bytes(mm_pairs, sgeom.cap_rows);
-                if (mlds > 64 * 1024 && !raise_dynamic_lds_limit(mfn)) return record_hip(hipErrorInvalidValue);
-                void *argv[] = {(void *)&ba, (void *)&lt, (void *)&sgeom};
-                const unsigned mgrid = (unsigned)((long long)N * sgeom.tiles_y * sgeom.tiles_x * M);
-                return record_hip(hipLaunchKernel(mfn, dim3(mgrid), dim3(mm_pairs * 4), argv, mlds, stream));
-            }
             if (shapes_host && Lq == S && is_aligned(loc, 8) && is_aligned(grad_loc, 8) &&
                 plan_sorted(lt, L, D, P, &sgeom) &&
                 (long long)N * sgeom.tiles_y * sgeom.tiles_x * M <= 0x7fffffffLL) {
@@ -2259,16 +2242,6 @@ int tf_msda_set_option(const char *name, int value)
             return prev;
         }
     if (strcmp(name, "direct9") == 0) return g_direct9.exchange(value < 0 ? -1 : (value ? 1 : 0));
-    if (strcmp(name, "bwd_mm") == 0) {   // 0: msda_bwd_f32_sorted2, 32 / 64: msda_bwd_f32_mm with that many pairs per tile
-        const int prev = bwd_mm_pairs();
-        g_bwd_mm.store(value == 0 || value == 32 || value == 64 ? value : 32);
-        return prev;
-    }
-    if (strcmp(name, "bwd_mm_rows") == 0) {   // LDS rows of a tile's windows (0: the default)
-        const int prev = bwd_mm_rows();
-        g_bwd_mm_rows.store(value >= 16 && value <= kMmMaxRows ? value : 0);
-        return prev;
-    }
     if (strcmp(name, "ffn_ti") == 0) return ffn_set_ti(value);
     if (strcmp(name, "ffn_tail_split") == 0) return ffn_set_tail_split(value);
     if (strcmp(name, "linln_ti") == 0) return linln_set_ti(value);
