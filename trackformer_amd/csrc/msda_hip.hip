@@ -2121,6 +2121,12 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
     return record_hip(e);
 }
 
+template <typename W>
+__global__ void __launch_bounds__(256) zero_words_kernel(W *__restrict__ p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (size_t)gridDim.x * 256u) p[i] = W(0);
+}
+
 template <typename T>
 int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *shapes_dev,
                   const T *loc, const T *attn, const T *grad_out, T *grad_value, T *grad_loc,
@@ -2143,8 +2149,23 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
     int rc = make_plan<T>(N, M, D, L, Lq, P, 6, aligned, &pl);
     if (rc != TF_MSDA_OK) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    rc = record_hip(hipMemsetAsync(grad_value, 0, sizeof(T) * (size_t)N * S * M * D, stream));
-    if (rc != TF_MSDA_OK) return rc;
+    // grad_value is accumulated by atomics: zeros first -- by a KERNEL, not hipMemsetAsync.  Inside a captured HIP graph a memset
+    // node in front of a kernel node was seen NOT to be ordered before that kernel's atomics on ROCm 7.2 (the group-norm
+    // statistics of the two-graph detector, profiles/r05_graph_memset_groupnorm.txt; and this very call: a captured backward
+    // replayed onto uninitialised memory, tests/test_dropin_compiled_gpu.py).  Kernel -> kernel order is an ordinary edge.
+    {
+        const size_t bytes = sizeof(T) * (size_t)N * S * M * D;
+        const bool wide = bytes % 16 == 0 && is_aligned(grad_value, 16);
+        const size_t n = wide ? bytes / 16 : bytes / 4;   // (T is float or double: a multiple of 4 bytes)
+        size_t blocks = (n + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;   // grid-stride above 8192 workgroups
+        if (wide)
+            hipLaunchKernelGGL(zero_words_kernel<u32x4_t>, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<u32x4_t *>(grad_value), n);
+        else
+            hipLaunchKernelGGL(zero_words_kernel<unsigned>, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<unsigned *>(grad_value), n);
+        rc = record_hip(hipGetLastError());
+        if (rc != TF_MSDA_OK) return rc;
+    }
     const long long total_pairs = (long long)N * Lq * M;
     const bool pow2 = (pl.DV & (pl.DV - 1)) == 0 && pl.DV <= 64;
     if constexpr (sizeof(T) == 4) {
