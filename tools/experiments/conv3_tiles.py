@@ -19,16 +19,24 @@ from tools.bench_conv import time_it  # noqa: E402
 
 
 def main():
+    import argparse
+    from trackformer_amd import _cabi
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ti", type=int, default=0, help="row tiles per block (tf_msda_set_option linear_stream_ti): 2 = 64-row blocks, 4 = 128-row blocks")
+    args = ap.parse_args()
+    if args.ti:
+        _cabi.lib().tf_msda_set_option(b"linear_stream_ti", args.ti)
+    rows_per_block = 128 if args.ti >= 4 else 64
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     cin = cout = 128
     wt = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).contiguous()
     b = torch.randn(cout, device=dev)
-    print("rows  pieces  blocks  us/launch  us/block*256  ns/(block slice)*256")
+    print("%d-row blocks\nrows  pieces  blocks  us/launch  us/block*256  ns/(block slice)*256" % rows_per_block)
     for pieces in (2, 1):
         fused._conv_ksplit = lambda m, k, c, p=pieces: p
         for blocks in (128, 256, 384, 512, 528, 640, 768, 1024, 1056, 2048):
-            rows = blocks // pieces * 64
+            rows = blocks // pieces * rows_per_block
             x = torch.randn(1, cin, rows // 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
             with torch.no_grad():
                 y = fused.conv3x3(x, wt, b, True, 1)
