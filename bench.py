@@ -57,10 +57,8 @@ The JSON line also carries
                    accumulation (include/tf_fused.h) -- the fp16 product (two / three fp16 pieces per operand, three MFMAs, fp32-class
                    accuracy) or the six-term bf16 product (all 24 significand bits).  Beside it: fp32_exact_fps /
                    single_sequence_fp32_exact_fps (every matrix product in the fp32 LIBRARIES: hipBLASLt linears, MIOpen
-                   convolutions; 3 sequences / one sequence), the other fp32-class product (split6_fps / split_f16_fps) and
-                   split3_fps (the three-term bf16 fast mode, products good to 2^-16: NOT the reference's precision -- it loses the
-                   reference's track ids at frame 14 of the 64-frame fixture where fp32 holds 59, profiles/r04_id_parity_64.txt --
-                   reported, never the headline).
+                   convolutions; 3 sequences / one sequence) and the other fp32-class product (split6_fps / split_f16_fps).
+                   (The three-term bf16 fast mode of rounds 2-4 and its split3_fps leg were removed in round 5.)
   association   -- what the association leg did in four untimed steps (survivors, initialised, alive).
   parity        -- cfg2: in-run check against the committed reference goldens (max |d boxes|, max |d logits|, ids equal).
   mfma_utilisation -- "live": the dense kernels of the frame timed HERE with HIP events at their cfg-2 shapes, as fp32-equivalent
@@ -153,10 +151,11 @@ def parse_args():
                     help="encoder / decoder linears as bf16 split products on the matrix cores "
                          "(tf_linear_split_f32; same as TF_SPLIT_LINEAR=1)")
     ap.add_argument("--no-split-linear", dest="split_linear", action="store_false")
-    ap.add_argument("--split-terms", type=int, choices=(3, 6, 16), default=None,
-                    help="the split product (include/tf_fused.h): 6 bf16 terms, 16 = fp16 pieces (three terms, fp32-class accuracy) "
-                         "or 3 bf16 terms (fast mode, products good to 2^-16); default: the package's (fused.split_terms())")
-    ap.add_argument("--no-split3", action="store_true", help="skip the extra measurements with the other split products")
+    ap.add_argument("--split-terms", type=int, choices=(6, 16), default=None,
+                    help="the split product (include/tf_fused.h): 6 bf16 terms or 16 = fp16 pieces (three terms, fp32-class accuracy); "
+                         "default: the package's (fused.split_terms())")
+    ap.add_argument("--no-split3", action="store_true",
+                    help="skip the extra measurement with the other split product (the flag's name is from the rounds that had three)")
     ap.add_argument("--conv1x1-split", dest="conv1x1_split", action="store_true", default=None,
                     help="the backbone's stride-1 1x1 convolutions through the split-product GEMM with the "
                          "FrozenBN / identity / ReLU epilogue (the default; --no-conv1x1-split = TF_CONV1X1_SPLIT=0)")
@@ -397,7 +396,7 @@ def measure_parity(device):
     from trackformer_amd import fused
     case = "cfg2_full"
     # the set-up of tests/test_full_size_gpu.py that matches the arithmetic `value` is measured with
-    setup = {16: "graph_split_linear", 6: "graph_split6", 3: "graph_split3"}[fused.split_terms()] if fused.split_linear_enabled() else "graph_tuned"
+    setup = {16: "graph_split_linear", 6: "graph_split6"}[fused.split_terms()] if fused.split_linear_enabled() else "graph_tuned"
     model, out, res, feats, memory = T._forward(case, models, device, setup)
     z = np.load(os.path.join(T.GOLDEN, "full_%s.npz" % case))
     dbox = float(np.abs(out['pred_boxes'].cpu().numpy() - z['pred_boxes']).max())
@@ -561,9 +560,6 @@ _ARITH = {
     16: ("fp16 split product (three terms)", "split_f16_fps",
          "f32 (dense layers as the fp16 split product on MFMA: two fp16 pieces per activation, three per weight scaled per output "
          "channel -- 22 + 1 significand bits per operand, the one dropped product < 2^-22 --, three terms, f32 accumulate)"),
-    3: ("three-term bf16 split product", "split3_fps",
-        "f32 storage, products good to 2^-16 (three-term bf16 split product on MFMA, f32 accumulate): the fast mode, NOT the "
-        "reference's precision"),
 }
 
 
@@ -967,7 +963,7 @@ def main():
                 fused.set_split_linear(prev_split)
         if fused.split_linear_enabled() and not args.no_split3:
             # ... and with the other split products (reported beside the headline, never as the headline)
-            for alt in (6, 16, 3):
+            for alt in (6, 16):
                 if alt == fused.split_terms():
                     continue
                 prev_terms = fused.set_split_terms(alt)
@@ -1050,15 +1046,14 @@ def main():
             "multi_sequence_fps": None if multi is None else {"sequences_per_gpu": max(1, args.sequences), "value": round(multi, 3)},
             "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
             "single_sequence_fp32_exact_fps": None if fp32_exact_single is None else round(fp32_exact_single, 3),
-            **{_ARITH[a][1]: other_arith.get(_ARITH[a][1]) for a in (6, 16, 3) if a != fused.split_terms() or not fused.split_linear_enabled()},
+            **{_ARITH[a][1]: other_arith.get(_ARITH[a][1]) for a in (6, 16) if a != fused.split_terms() or not fused.split_linear_enabled()},
             "precision": None if train else {
                 "value_measured_with": (_ARITH[fused.split_terms()][0] + ", own kernels") if fused.split_linear_enabled()
                                        else "fp32 libraries (hipBLASLt, MIOpen)",
                 "fp32_exact_fps": "fp32 libraries (hipBLASLt linears, MIOpen convolutions), --sequences per GPU",
                 "single_sequence_fp32_exact_fps": "the same with one sequence per GPU",
                 "split6_fps": "six-term bf16 split product: all 24 significand bits of both operands",
-                "split_f16_fps": "fp16 split product: three MFMAs per product, 22 + 1 significand bits per operand (include/tf_fused.h)",
-                "split3_fps": "three-term bf16 fast mode; not the reference's precision (profiles/r04_id_parity_64.txt)"},
+                "split_f16_fps": "fp16 split product: three MFMAs per product, 22 + 1 significand bits per operand (include/tf_fused.h)"},
             "association": association, "parity": parity, "ranks": ranks, "mfma_utilisation": mfma,
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }

@@ -13,8 +13,7 @@
  *
  *   tf_linear_split_f32    nn.Linear (+ ReLU) of the encoder / decoder (ms_deform_attn.py:64-88,
  *                          deformable_transformer.py:282-297) as a split product on the matrix cores (fp16 pieces, three terms:
- *                          fp32-class, what trackformer_amd uses by default; six bf16 terms; three bf16 terms: the fast mode --
- *                          THE SPLIT PRODUCT below)
+ *                          fp32-class, what trackformer_amd uses by default; or six bf16 terms -- THE SPLIT PRODUCT below)
  *   tf_linear_packed_f32   the same product with the weight packed once in fragment order (+ tf_linear_pack_weight_f32)
  *   tf_ffn_fused_f32       linear1 -> ReLU -> linear2 -> + residual -> LayerNorm of a transformer layer in one launch
  *   tf_linear_res_ln_f32   linear (256 -> 256) -> + residual -> LayerNorm in one launch (output projection + norm1)
@@ -87,14 +86,13 @@ int tf_groupnorm_relu_nhwc_f32(const float *x, const float *gamma, const float *
  *               activation piece stored times 2^11 nothing falls into fp16's subnormals (|x| < 1.0e6; beyond that the row becomes
  *               NaN instead of saturating).  Half the matrix work of terms = 6 at fp32-class accuracy (against float64 on random
  *               operands: 3.7e-8 of sum |x||w| for the representation; the fp32 rounding of the sum itself is 2.4e-7).
- *   terms = 3   bf16 pieces hi, mid:  x_mid.w_hi + x_hi.w_mid + x_hi.w_hi   relative error of a product < 2^-16: boxes / logits stay
- *               inside the 1e-3 parity bar, but track ids leave the reference's earlier than fp32 does (frame 14 instead of 59 of
- *               the 64-frame fixture, profiles/r04_id_parity_64.txt): the opt-in fast mode.
+ *   (terms = 3, two bf16 pieces and three terms with products good to 2^-16 -- the "fast mode" of rounds 2-4 -- was REMOVED in
+ *   round 5: the fp16 product runs at the same speed with fp32-class accuracy, and three bf16 terms lost the reference's track ids
+ *   at frame 14 of the 64-frame fixture, profiles/r04_id_parity_64.txt.  terms = 3 / (w_hi, w_mid) alone is TF_MSDA_ERR_BAD_DIMS.)
  * Entry points that take the weight as separate piece tensors (16-bit [N, K] each, made once by the caller) select by which are
- * given:  (w_hi, w_mid)                       bf16 hi, mid                   -> three terms
- *         (w_hi, w_mid, w_lo)                 bf16 hi, mid, lo               -> six terms
+ * given:  (w_hi, w_mid, w_lo)                 bf16 hi, mid, lo               -> six terms
  *         (w_hi, w_mid, NULL, w_scale)        fp16 wh, wl + r_n [N] fp32     -> the fp16 product
- * Entry points that take a PACKED weight select by `terms` (3, 6 or 16), which must be the value the weight was packed with
+ * Entry points that take a PACKED weight select by `terms` (6 or 16), which must be the value the weight was packed with
  * (tf_linear_pack_weight_f32 computes t_n / r_n itself).  x is split inside the kernels.
  */
 
@@ -180,7 +178,7 @@ int tf_linear_split_add_f32(const float *x, const float *x2, const void *w_hi, c
  *   tf_linear_pack_weight_f32(w, packed, ...)    w [N, K] fp32 row-major -> packed (16-byte aligned pointers); one small kernel
  *   tf_linear_packed_f32                         y[M, N] = act(x[M, K] . w^T + bias + residual); K % 64 == 0, 16-byte aligned x;
  *                                                bias / residual [M, N] may be NULL, residual may alias y; y below 3 GiB
- * terms: 3, 6 or 16 (see THE SPLIT PRODUCT above); a weight packed for 6 holds three pieces per fragment, else two.
+ * terms: 6 or 16 (see THE SPLIT PRODUCT above); a weight packed for 6 holds three pieces per fragment, for 16 two.
  * The residual form is the closing 1 x 1 convolution of a ResNet bottleneck (conv3 -> FrozenBatchNorm2d -> `out += identity` ->
  * ReLU; reference: models/backbone.py:45-55 + torchvision's Bottleneck.forward) on channels_last activations.
  */

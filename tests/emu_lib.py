@@ -162,20 +162,20 @@ def msda_backward(value, shapes, loc, attn, grad_out, dshapes=False):
     return gv, gl, ga
 
 
-TERMS = 6   # terms per split product of the wrappers below (include/tf_fused.h: 6 = the default, 3 = the fast mode)
+TERMS = 6   # terms per split product of the wrappers below (include/tf_fused.h: 6 bf16 terms, or 16 = fp16 pieces)
 
 
 def set_terms(n):
-    """3, 6 (bf16 pieces) or 16 (fp16 pieces, three terms); returns the previous value."""
+    """6 (bf16 pieces) or 16 (fp16 pieces, three terms); returns the previous value."""
     global TERMS
-    assert n in (3, 6, 16)
+    assert n in (6, 16)
     prev, TERMS = TERMS, n
     return prev
 
 
 def bf16_split(w, terms=None):
     """w (fp32) -> (hi, mid, lo) as uint16 bit patterns of bf16, round to nearest even at every step (what fused.py hands the
-    kernel); lo is None for three terms."""
+    kernel)."""
     def to_bf16(x):
         u = x.astype(np.float32).view(np.uint32).astype(np.uint64)
         r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
@@ -187,7 +187,7 @@ def bf16_split(w, terms=None):
     hi = to_bf16(w)
     r = w - to_f32(hi)
     mid = to_bf16(r)
-    lo = to_bf16(r - to_f32(mid)) if (terms or TERMS) != 3 else None
+    lo = to_bf16(r - to_f32(mid))
     return hi, mid, lo
 
 

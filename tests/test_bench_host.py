@@ -16,21 +16,24 @@ def test_arguments_and_defaults(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse_args()
     assert a.gpus == 1 and a.steps > 0 and a.warmup >= 0 and a.config == "cfg2" and a.split_terms is None
-    for t in ("3", "6", "16"):
+    for t in ("6", "16"):
         monkeypatch.setattr(sys, "argv", ["bench.py", "--split-terms", t, "--config", "cfg4", "--no-split3"])
         a = bench.parse_args()
         assert a.split_terms == int(t) and a.config == "cfg4" and a.no_split3
-    monkeypatch.setattr(sys, "argv", ["bench.py", "--split-terms", "5"])
-    with pytest.raises(SystemExit):
-        bench.parse_args()
+    for t in ("5", "3"):   # 3: the three-term bf16 mode was removed in round 5
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--split-terms", t])
+        with pytest.raises(SystemExit):
+            bench.parse_args()
 
 
 def test_every_split_product_has_a_name_a_leg_and_a_dtype_text():
     from trackformer_amd import fused
-    assert set(bench._ARITH) == {3, 6, 16} and fused.split_terms() in bench._ARITH
+    assert set(bench._ARITH) == {6, 16} and fused.split_terms() in bench._ARITH
     legs = [v[1] for v in bench._ARITH.values()]
-    assert len(set(legs)) == 3 and all(leg.endswith("_fps") for leg in legs)
-    assert "fp16" in bench._ARITH[16][2] and "six-term" in bench._ARITH[6][2] and "NOT the reference's precision" in bench._ARITH[3][2]
+    assert len(set(legs)) == 2 and all(leg.endswith("_fps") for leg in legs)
+    assert "fp16" in bench._ARITH[16][2] and "six-term" in bench._ARITH[6][2]
+    with pytest.raises(ValueError, match="removed in round 5"):
+        fused.set_split_terms(3)
     prev = fused.set_split_terms(6)
     try:
         assert fused.split_terms() == 6
@@ -41,7 +44,7 @@ def test_every_split_product_has_a_name_a_leg_and_a_dtype_text():
 def test_committed_counter_passes_are_readable():
     """bench.py folds the newest profiles/rNN_mfma_utilisation.json and rNN_msda_fwd_pquad_traffic.json into its line."""
     m = bench.committed_mfma_utilisation()
-    assert m is not None and m["terms"] in (3, 6, 16) and "source_commit" in m
+    assert m is not None and m["terms"] in (3, 6, 16) and "source_commit" in m   # (3: a counter pass committed before round 4)
     assert m["harness"], m            # the harness kernels were found under their current names
     assert all(0.0 <= v <= 1.0 for v in m["harness"].values())
     frame = m["per_kernel_in_an_eager_cfg2_frame"]

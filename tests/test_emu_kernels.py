@@ -253,10 +253,10 @@ def test_bias_act_and_add_layernorm():
         np.testing.assert_allclose(emu_lib.add_layernorm(x, res, g, be), ref, atol=2e-5, rtol=1e-5)
 
 
-@pytest.fixture(params=[6, 3, 16], ids=["six_terms", "three_terms", "fp16_pieces"])
+@pytest.fixture(params=[6, 16], ids=["six_terms", "fp16_pieces"])
 def terms(request):
-    """The split product (include/tf_fused.h): six bf16 terms, three (the fast mode), or fp16 pieces.  Every case runs for the
-    package's default product; for the other two every third case (by a hash of its name) unless TF_EMU_ALL_SCHEMES=1 -- the
+    """The split product (include/tf_fused.h): six bf16 terms or fp16 pieces (the three-term bf16 mode was removed in round 5).
+    Every case runs for the package's default product; for the other one every third case (by a hash of its name) unless TF_EMU_ALL_SCHEMES=1 -- the
     kernels are the same templates, and the emulator takes seconds per case."""
     import os
     import zlib
@@ -270,9 +270,8 @@ def terms(request):
 
 
 def _tol(terms):
-    """Relative error of a split-product GEMM against float64: six bf16 terms and the fp16 pieces sit at fp32 round-off, three bf16
-    terms at 2^-16 per product."""
-    return 1e-4 if terms == 3 else 2e-6
+    """Relative error of a split-product GEMM against float64: six bf16 terms and the fp16 pieces sit at fp32 round-off."""
+    return 2e-6
 
 
 LINEAR_SHAPES = [(200, 256, 256), (333, 256, 384), (130, 256, 1024), (130, 1024, 256), (400, 288, 288), (70, 64, 96)]
@@ -281,8 +280,8 @@ LINEAR_SHAPES = [(200, 256, 256), (333, 256, 384), (130, 256, 1024), (130, 1024,
 @pytest.mark.parametrize("M,K,N", LINEAR_SHAPES, ids=["%dx%dx%d" % s for s in LINEAR_SHAPES])
 @pytest.mark.parametrize("relu", [False, True], ids=["plain", "relu"])
 def test_split_product_linear_on_emulated_matrix_cores(M, K, N, relu, terms):
-    """tf_linear_split_f32 (LDS-staged operands) and tf_linear_packed_f32 (weight fragments in MFMA order): the six- and the
-    three-term split product on the emulated v_mfma_f32_32x32x16_bf16 against a float64 product.  A wrong fragment layout
+    """tf_linear_split_f32 (LDS-staged operands) and tf_linear_packed_f32 (weight fragments in MFMA order): the six-term bf16 and
+    the fp16 split product on the emulated v_mfma_f32_32x32x16_bf16 / _f16 against a float64 product.  A wrong fragment layout
     anywhere gives errors of order 1; a wrong piece pairing in the six-term form errors of 2^-16."""
     rng = np.random.default_rng(M + K + N)
     x = rng.standard_normal((M, K), dtype=np.float32)
@@ -315,8 +314,7 @@ def test_split_product_linear_block_shapes(M, K, N, terms):
 
 def test_six_term_product_is_fp32_accurate():
     """The claim behind the default: with (hi, mid, lo) pieces and six terms the result is as close to the exact product as an
-    fp32 GEMM is (here: numpy's sgemm), an order of magnitude closer than the three-term form; and the three pieces
-    reconstruct the operand exactly."""
+    fp32 GEMM is (here: numpy's sgemm), and so is the fp16 product; the three bf16 pieces reconstruct the operand exactly."""
     rng = np.random.default_rng(3)
     x = (rng.standard_normal((256, 1024), dtype=np.float32) * np.exp(rng.standard_normal((256, 1024)) * 2).astype(np.float32))
     w = (rng.standard_normal((256, 1024), dtype=np.float32) / 32).astype(np.float32)
@@ -326,15 +324,15 @@ def test_six_term_product_is_fp32_accurate():
     ref = x.astype(np.float64) @ w.astype(np.float64).T
     scale = np.abs(x).astype(np.float64) @ np.abs(w).astype(np.float64).T     # sum |x||w|: what rounding errors scale with
     err = {}
-    for t in (6, 3):
+    for t in (6, 16):
         prev = emu_lib.set_terms(t)
         try:
             err[t] = (np.abs(emu_lib.linear_split(x, w) - ref) / scale).max()
         finally:
             emu_lib.set_terms(prev)
     sgemm = (np.abs(x @ w.T - ref) / scale).max()
-    print("max |err| / sum |x||w|: six terms %.2e, three terms %.2e, numpy sgemm %.2e" % (err[6], err[3], sgemm))
-    assert err[6] < 2 * sgemm and err[3] > 8 * err[6]
+    print("max |err| / sum |x||w|: six terms %.2e, fp16 pieces %.2e, numpy sgemm %.2e" % (err[6], err[16], sgemm))
+    assert err[6] < 2 * sgemm and err[16] < 2 * sgemm
 
 
 @pytest.mark.parametrize("xs,ws", [(1.0, 0.05), (1e-3, 0.05), (300.0, 0.05), (1.0, 1e-4), (1.0, 30.0)],
@@ -690,14 +688,14 @@ def test_one_launch_blocks_validate_their_arguments():
     assert lin(M=0) == BAD and lin(K=320, N=320) == BAD and lin(N=128) == BAD and lin(K=288) == BAD   # square, 256 or 288
     assert lin(x=p(buf) + 4) == BAD and lin(r=p(buf) + 8) == BAD   # not 16-byte aligned
     assert lin(M=(1 << 22)) == BAD                      # 32-bit buffer offsets
-    assert lin(T=4) == BAD and lin(T=0) == BAD          # terms: 3 or 6
+    assert lin(T=4) == BAD and lin(T=0) == BAD and lin(T=3) == BAD   # terms: 6 or 16 (3 was removed in round 5)
     ffn = lambda x=p(buf), a=p(w1), c=p(w2), out=p(y), M=64, D=256, F=128, g=None, be=None, T=emu_lib.TERMS: \
         L.tf_ffn_fused_f32(x, a, None, c, None, None, g, be, f0, out, M, D, F, T, None)
     assert ffn() == 0
     assert ffn(x=None) == NULLP and ffn(a=None) == NULLP and ffn(c=None) == NULLP and ffn(out=None) == NULLP
     assert ffn(be=p(buf)) == NULLP
     assert ffn(M=-1) == BAD and ffn(D=128) == BAD and ffn(F=64) == BAD and ffn(F=200) == BAD   # F: >= one chunk, multiple of 16
-    assert ffn(out=p(y) + 4) == BAD and ffn(T=5) == BAD
+    assert ffn(out=p(y) + 4) == BAD and ffn(T=5) == BAD and ffn(T=3) == BAD
 
 
 @pytest.mark.parametrize("n,h,w,c", [(1, 20, 33, 64), (2, 7, 8, 8), (1, 1, 1, 4), (1, 2, 5, 12)], ids=lambda v: str(v))

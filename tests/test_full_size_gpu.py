@@ -50,9 +50,9 @@ def models(dev):
     return get
 
 
-SETUPS = ["eager", "graph_tuned", "graph_split_linear", "graph_split6", "graph_split3"]
+SETUPS = ["eager", "graph_tuned", "graph_split_linear", "graph_split6"]
 # set-up -> split product (include/tf_fused.h); "graph_split_linear" is the bench set-up: the package's default product (fp16 pieces)
-_SPLIT_SETUPS = {"graph_split_linear": 16, "graph_split6": 6, "graph_split3": 3}
+_SPLIT_SETUPS = {"graph_split_linear": 16, "graph_split6": 6}
 
 
 def _forward(case, models, dev, setup):
@@ -205,13 +205,12 @@ def test_full_size_tracker_64_frame_sequence_against_reference(dev, models):
         fp32 libraries (hipBLASLt / MIOpen)          64 (all) in one run, 59 in another (margin 1.4e-5 at frame 59)
         six-term split product                       26 in every run (margin 5.7e-6 at frame 26)
         fp16 split product (the default since r4)    all 64 in both runs of profiles/r04_id_parity_64_with_fp16.txt
-        three-term split product (the fast mode)     14 in two runs (margin 6.8e-4 at frame 14), 32 in a third after the
-                                                     convolutions changed kernels (margin 2.0e-5)
-    i.e. products good to 2^-16 can flip a decision whose margin is 7e-4 -- forty times the margin fp32-class arithmetic
-    needs -- and whether they do depends on the kernel's summation order; that is why the default is a product with
-    fp32-class accuracy (the fp16 pieces: 22 + 1 significand bits; six bf16 terms: all 24) and the three-term numbers are never
-    the headline.  Asserted: the default and the six-term product agree on every frame in front of the first one whose NMS margin
-    is below 2e-5 (24 frames), the three-term mode on every frame whose margin is at least 1e-3; every row of the agreeing
+        three-term bf16 split product (rounds 2-4)   14 in two runs (margin 6.8e-4 at frame 14), 32 in a third after the
+                                                     convolutions changed kernels (margin 2.0e-5) -- REMOVED in round 5
+    i.e. products good to 2^-16 flipped a decision whose margin was 7e-4 -- forty times the margin fp32-class arithmetic
+    needs -- and whether they did depended on the kernel's summation order; that is why the products the library has are
+    fp32-class (the fp16 pieces: 22 + 1 significand bits; six bf16 terms: all 24).  Asserted: the default and the six-term
+    product agree on every frame in front of the first one whose NMS margin is below 2e-5 (24 frames); every row of the agreeing
     frames matches in id / frame / source query, boxes and scores.  (The fixture whose decisions ARE pinned -- every margin
     >= 0.08 -- is test_full_size_well_conditioned_64_frames_every_id below: all 64 frames, every set-up.)"""
     z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2_64.npz"))
@@ -224,15 +223,12 @@ def test_full_size_tracker_64_frame_sequence_against_reference(dev, models):
     def first_below(thr):
         return int(np.argmax(margins < thr)) if (margins < thr).any() else len(margins)
     agree6, tracker = _ids_until_divergence(models, dev, gold, n_run, True, 6)
-    agree3, _ = _ids_until_divergence(models, dev, gold, n_run, True, 3)
     agree16, tracker16 = _ids_until_divergence(models, dev, gold, n_run, True, 16)
-    print("64-frame fixture: six terms agree on %d frames (NMS margin of the first differing frame %.1e), fp16 pieces on %d (%.1e), "
-          "three terms on %d (%.1e); frames in front of the first margin < 2e-5: %d, < 1e-3: %d" % (
-              agree6, margins[min(agree6, len(margins) - 1)], agree16, margins[min(agree16, len(margins) - 1)],
-              agree3, margins[min(agree3, len(margins) - 1)], first_below(2e-5), first_below(1e-3)))
+    print("64-frame fixture: six terms agree on %d frames (NMS margin of the first differing frame %.1e), fp16 pieces on %d (%.1e); "
+          "frames in front of the first margin < 2e-5: %d" % (
+              agree6, margins[min(agree6, len(margins) - 1)], agree16, margins[min(agree16, len(margins) - 1)], first_below(2e-5)))
     assert agree6 >= first_below(2e-5), (agree6, margins[:n_run].tolist())
     assert agree16 >= first_below(2e-5), (agree16, margins[:n_run].tolist())   # the fp16 product is held to the six-term bar
-    assert agree3 >= first_below(1e-3)
     if fused_default_terms() == 16:
         agree6, tracker = agree16, tracker16
     results = tracker.get_results()
@@ -548,14 +544,14 @@ def test_conv1x1_split_k(dev, shape, cout, stride):
         assert torch.equal(y1, y0)                     # two pieces do not pay for a 1 x 1 convolution: left alone
 
 
-@pytest.mark.parametrize("terms", [6, 3, 16], ids=["six_terms", "three_terms", "fp16_pieces"])
+@pytest.mark.parametrize("terms", [6, 16], ids=["six_terms", "fp16_pieces"])
 @pytest.mark.parametrize("shape,cout,ks,stride", [((1, 64, 200, 334), 64, 3, 1), ((1, 256, 100, 167), 256, 3, 2), ((1, 512, 25, 42), 512, 3, 1),
                                                   ((2, 128, 37, 53), 160, 3, 1), ((1, 1024, 50, 84), 2048, 1, 2)])
 def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
     """split_conv3_kernel (buffer-resource fetches: a tap outside the image reads zeros from beyond num_records; DESIGN.md
     section 4.4) at ResNet-50's shapes of the 800 x 1333 frame -- borders on all four sides, the last row block partial, the
-    split-K pieces fused.conv3x3 chooses -- against a float64 convolution: six terms at fp32 round-off (the library's fp32
-    convolution is no closer), three terms at 2^-16 per product."""
+    split-K pieces fused.conv3x3 chooses -- against a float64 convolution: both products at fp32 round-off (the library's fp32
+    convolution is no closer)."""
     from trackformer_amd import fused
     g = torch.Generator().manual_seed(shape[1] + cout)
     x = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
@@ -586,9 +582,8 @@ def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
     err, err_lib = float((y.double() - ref).abs().max()) / scale, float((lib32.double() - ref).abs().max()) / scale
     print("conv %s -> %d, %d x %d / %d, %d terms: max err / max |y| %.2e (library fp32 convolution: %.2e)" % (
         shape, cout, ks, ks, stride, terms, err, err_lib))
-    assert err < (1e-4 if terms == 3 else 2e-6)
-    if terms != 3:
-        assert err < 4 * err_lib + 1e-7
+    assert err < 2e-6
+    assert err < 4 * err_lib + 1e-7
 
 
 @pytest.mark.parametrize("case", um.FULL_DETECTOR_CASES)

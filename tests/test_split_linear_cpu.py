@@ -1,5 +1,6 @@
-"""CPU: the numerical claim behind tf_linear_split_f32 -- every linear of the path computed as the bf16 split product
-(three terms hi.hi + hi.mid + mid.hi: the fast mode; six terms with a third piece: the default; fp32 accumulation), emulated
+"""CPU: the numerical claim behind tf_linear_split_f32 -- every linear of the path computed as the six-term bf16 split product
+(three pieces per operand, fp32 accumulation; the three-term form of rounds 2-4 -- hi.hi + hi.mid + mid.hi -- passes the same
+bars and is kept here as the weaker of the two emulations although the library no longer has it), emulated
 with PyTorch on the CPU, keeps the model and the tracker inside the tolerances of the CPU parity suite (boxes 2e-5, logits 1e-4,
 track ids exact), while plain bf16 does not.  (The HIP kernel itself is checked on the GPU:
 tests/test_linear_split_gpu.py; the full sweep over all goldens: tools/experiments/bf16_split_linear.py.)"""
@@ -54,11 +55,9 @@ def test_weight_pieces_reconstruct_the_weight():
     assert float(rel) < 2.0 ** -15
     assert torch.equal(hi.double() + mid.double() + lo.double(), w.double())
     assert fused._split_weight(w)[0] is hi      # cached per tensor version
-    prev = fused.set_split_terms(3)
-    try:
-        assert fused._split_weight(w)[2] is None and fused._split_weight(w)[0] is hi    # the same cache entry, without lo
-    finally:
-        fused.set_split_terms(prev)
+    import pytest
+    with pytest.raises(ValueError, match="removed in round 5"):   # the three-term bf16 mode
+        fused.set_split_terms(3)
     w.add_(1.0)
     assert fused._split_weight(w)[0] is not hi  # an in-place update invalidates the cache entry
     # fp16 pieces: w t_n = wh + wl to 2^-23 of it, scale = 16 / t_n, the largest |w t_n| of a row in [2^13, 2^14)
@@ -126,12 +125,11 @@ def test_packed_kernel_dispatch_policy():
     try:
         assert fused._use_packed(22223, 256, 1024) and fused._use_packed(22223, 1024, 256)
         assert not fused._use_packed(22223, 256, 384) and not fused._use_packed(66800, 64, 256)
-        for two_pieces in (16, 3):     # fp16 pieces (the default) / three bf16 terms: a wide output or a long K only
-            p = fused.set_split_terms(two_pieces)
-            try:
-                assert not fused._use_packed(22223, 256, 256) and fused._use_packed(22223, 256, 1024) and fused._use_packed(16700, 512, 128)
-            finally:
-                fused.set_split_terms(p)
+        p = fused.set_split_terms(16)     # fp16 pieces (the default; two stored weight pieces): a wide output or a long K only
+        try:
+            assert not fused._use_packed(22223, 256, 256) and fused._use_packed(22223, 256, 1024) and fused._use_packed(16700, 512, 128)
+        finally:
+            fused.set_split_terms(p)
         p6 = fused.set_split_terms(6)
         try:
             assert fused._use_packed(22223, 256, 256) and fused._use_packed(66800, 256, 64)   # six terms: K >= 256

@@ -46,7 +46,7 @@ int main(int argc, char **argv)
     const int M = argc > 1 ? atoi(argv[1]) : 22223, F = argc > 2 ? atoi(argv[2]) : 1024, D = argc > 4 ? atoi(argv[4]) : 256;
     if (argc > 3) tf_msda_set_option("ffn_ti", atoi(argv[3]));
     const int Tenv = getenv("TF_SPLIT_TERMS") ? atoi(getenv("TF_SPLIT_TERMS")) : 16;
-    const int T = Tenv == 3 ? 3 : Tenv == 6 ? 6 : 16;   // the split product (include/tf_fused.h; default: fp16 pieces)
+    const int T = Tenv == 6 ? 6 : 16;   // the split product (include/tf_fused.h; default: fp16 pieces)
     printf("split product: %d terms\n", T);
     const int guard = 128;   // rows behind M that nothing may write
     std::mt19937 rng(11);
@@ -122,7 +122,7 @@ int main(int argc, char **argv)
             CK(hipMalloc(d[q], W.size() * 2));
             CK(hipMemcpy(*d[q], pc[q].data(), W.size() * 2, hipMemcpyHostToDevice));
         }
-        if (T != 6) *dlo = nullptr;   // three bf16 terms / fp16 pieces: no third piece
+        if (T != 6) *dlo = nullptr;   // fp16 pieces: no third piece
     };
     unsigned short *dW1hi, *dW1mid, *dW1lo, *dW2hi, *dW2mid, *dW2lo;
     float *dW1sc, *dW2sc, *dWosc;

@@ -38,15 +38,8 @@ def run(setup, n_frames, dev):
     prev = {}
     if setup == "fp32_library":
         prev["split"] = fused.set_split_linear(False)
-    elif setup == "split3":
-        prev["split"] = fused.set_split_linear(True)
-        if hasattr(fused, "set_split_terms"):
-            prev["terms"] = fused.set_split_terms(3)
-    elif setup == "split3_heads_fp32":
-        prev["split"] = fused.set_split_linear(True)
-        prev["heads"] = fused.set_heads_split(False)
-        if hasattr(fused, "set_split_terms"):
-            prev["terms"] = fused.set_split_terms(3)
+    elif setup in ("split3", "split3_heads_fp32"):
+        raise ValueError("the three-term bf16 product was removed in round 5 (its results: profiles/r04_id_parity_64.txt)")
     elif setup in ("split6", "split16"):
         if not hasattr(fused, "set_split_terms"):
             return None
@@ -82,7 +75,7 @@ def first_diff(a, b):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=64)
-    ap.add_argument("--setups", default="fp32_library,split16,split6,split3")
+    ap.add_argument("--setups", default="fp32_library,split16,split6")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     z = np.load(os.path.join(REPO, "tests", "golden", "full_tracker_cfg2_64.npz"))

@@ -4,7 +4,7 @@
 //   tools/bin/linear_bench [M K N [packed | packedTI]]   (built by trackformer_amd/build.py; default 22223 256 256)
 //     packed / packed2 / packed3 / packed4: tf_linear_packed_f32 (weight packed once by tf_linear_pack_weight_f32; the digit
 //     forces the row tiles per block), whose output is also compared BIT FOR BIT with tf_linear_split_f32's
-//   TF_SPLIT_TERMS=6: six bf16 terms, =3: the three-term bf16 product (default: 16, fp16 pieces)
+//   TF_SPLIT_TERMS=6: six bf16 terms (default: 16, fp16 pieces; the three-term bf16 product of rounds 2-4 is gone)
 //
 // Checks a sample of output rows (all columns, incl. the block edges) against a double-precision reference and
 // times 20 launches captured in one HIP graph.  Round-1 numbers: profiles/r01_split_gemm_experiment.txt.
@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     const bool packed = argc > 4 && strncmp(argv[4], "packed", 6) == 0;
     if (packed && argv[4][6]) tf_msda_set_option("linear_stream_ti", atoi(argv[4] + 6));
     const int Tenv = getenv("TF_SPLIT_TERMS") ? atoi(getenv("TF_SPLIT_TERMS")) : 16;
-    const int T = Tenv == 3 ? 3 : Tenv == 6 ? 6 : 16;   // the split product (include/tf_fused.h; default: fp16 pieces)
+    const int T = Tenv == 6 ? 6 : 16;   // the split product (include/tf_fused.h; default: fp16 pieces)
     if (K % 32) {
         fprintf(stderr, "K must be a multiple of 32\n");
         return 2;

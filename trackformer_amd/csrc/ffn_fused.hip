@@ -657,7 +657,6 @@ int dispatch_linln_scheme(int sp, const float *x, const u32x4 *w, const float *b
                           float eps, float *y, int M, hipStream_t s)
 {
     switch (sp) {
-    case 2: return dispatch_linln<2, D>(x, w, bias, residual, g, b, eps, y, M, s);
     case 3: return dispatch_linln<3, D>(x, w, bias, residual, g, b, eps, y, M, s);
     default: return dispatch_linln<16, D>(x, w, bias, residual, g, b, eps, y, M, s);
     }
@@ -668,7 +667,6 @@ int dispatch_ffn_scheme(int sp, const float *x, const u32x4 *w1, const float *b1
                         const float *g, const float *b, float eps, float *y, int M, int F, hipStream_t s)
 {
     switch (sp) {
-    case 2: return dispatch_ffn<2, D>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
     case 3: return dispatch_ffn<3, D>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
     default: return dispatch_ffn<16, D>(x, w1, b1, w2, b2, residual, g, b, eps, y, M, F, s);
     }

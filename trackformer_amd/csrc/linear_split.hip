@@ -661,9 +661,9 @@ int launch_add(const float *x, const float *x2, const Weight &w, const float *bi
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
-// The weight arguments of the C ABI -> scheme (split_product.h): (w_hi, w_mid) -> 2 (three bf16 terms), (w_hi, w_mid, w_lo) -> 3
-// (six), (w_hi, w_mid, NULL, w_scale) -> 16 (fp16 pieces hi, lo + the channels' factors); 0: a missing piece, -1: misaligned
-// (16 bytes) or a third piece beside w_scale
+// The weight arguments of the C ABI -> scheme (split_product.h): (w_hi, w_mid, w_lo) -> 3 (six bf16 terms), (w_hi, w_mid, NULL,
+// w_scale) -> 16 (fp16 pieces hi, lo + the channels' factors); 0: a missing piece, -1: misaligned (16 bytes), a third piece
+// beside w_scale, or neither (two bf16 pieces alone were the three-term product of rounds 2-4, removed in round 5)
 inline int weight_scheme(const void *w_hi, const void *w_mid, const void *w_lo, const float *w_scale, Weight &w)
 {
     if (!w_hi || !w_mid) return 0;
@@ -673,7 +673,8 @@ inline int weight_scheme(const void *w_hi, const void *w_mid, const void *w_lo, 
     w.p[1] = static_cast<const unsigned short *>(w_mid);
     w.p[2] = static_cast<const unsigned short *>(w_lo);
     w.scale = w_scale;
-    return w_scale ? 16 : (w_lo ? 3 : 2);
+    if (!w_scale && !w_lo) return -1;   // (hi, mid) alone was the three-term bf16 product: removed in round 5
+    return w_scale ? 16 : 3;
 }
 
 // f(integral_constant<int, SP>) for the run-time scheme sp
@@ -681,7 +682,6 @@ template <class F>
 int with_scheme(int sp, F &&f)
 {
     switch (sp) {
-    case 2: return f(std::integral_constant<int, 2>{});
     case 3: return f(std::integral_constant<int, 3>{});
     default: return f(std::integral_constant<int, 16>{});
     }

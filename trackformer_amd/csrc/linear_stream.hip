@@ -537,7 +537,6 @@ template <bool CONV>
 int stream_dispatch_scheme(int sp, const StreamCall &c, hipStream_t s)
 {
     switch (sp) {
-    case 2: return stream_dispatch<2, CONV>(c, s);
     case 3: return stream_dispatch<3, CONV>(c, s);
     default: return stream_dispatch<16, CONV>(c, s);
     }
@@ -577,7 +576,6 @@ extern "C" int tf_linear_pack_weight_f32(const float *w, void *packed, int K, in
     u32x4 *out = static_cast<u32x4 *>(packed);
     float *rs = reinterpret_cast<float *>(out + total * scheme_pieces_b(sp));   // fp16 scheme only
     switch (sp) {
-    case 2: hipLaunchKernelGGL(pack_weight_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, s, w, out, (const float *)nullptr, K, N, total); break;
     case 3: hipLaunchKernelGGL(pack_weight_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, s, w, out, (const float *)nullptr, K, N, total); break;
     default:
         hipLaunchKernelGGL(pack_scale_kernel, dim3((unsigned)((npad + 3) / 4)), dim3(256), 0, s, w, rs, K, N, (int)npad);

@@ -52,11 +52,6 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // 4 pieces of
 template <int SP> struct Split;
 // NA / NB: pieces of an activation / of a weight as STORED (LDS, packed image, piece tensors); NBX: weight operands of the terms (B
 // indexes them): the stored pieces [+ the one expand_weight() derives]
-template <> struct Split<2> {
-    static constexpr bool F16 = false;
-    static constexpr int NA = 2, NB = 2, NBX = 2, N = 3;
-    static constexpr int A[3] = {1, 0, 0}, B[3] = {0, 1, 0};
-};
 template <> struct Split<3> {
     static constexpr bool F16 = false;
     static constexpr int NA = 3, NB = 3, NBX = 3, N = 6;
@@ -180,8 +175,9 @@ __device__ __forceinline__ void mfma_tiles(f32x16 (&acc)[TI][TJ], const u32x4 (&
                 acc[i][j] = XA ? mfma16<SP>(x[i][T::A[t]], wx[j][T::B[t]], acc[i][j]) : mfma16<SP>(wx[j][T::B[t]], x[i][T::A[t]], acc[i][j]);
 }
 
-// `terms` argument of the C ABI -> scheme: 3 / 6 bf16 terms, 16 = fp16 pieces (three terms); 0: unknown
-inline int split_scheme(int terms) { return terms == 3 ? 2 : terms == 6 ? 3 : terms == 16 ? 16 : 0; }
+// `terms` argument of the C ABI -> scheme: 6 bf16 terms (three pieces per operand), 16 = fp16 pieces (three terms); 0: unknown.
+// (The three-term bf16 product -- two pieces, products good to 2^-16 -- of rounds 2-4 was removed in round 5: terms == 3 is unknown.)
+inline int split_scheme(int terms) { return terms == 6 ? 3 : terms == 16 ? 16 : 0; }
 inline int scheme_pieces_b(int sp) { return sp == 16 ? 2 : sp; }   // 16-bit weight pieces stored per element
 
 }  // namespace

@@ -212,8 +212,7 @@ extern "C" int tf_stem_conv7x7_f32(const float *x, const void *w_packed, const f
         if (relu) hipLaunchKernelGGL((stem_conv7x7_kernel<SP, true>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
         else hipLaunchKernelGGL((stem_conv7x7_kernel<SP, false>), grid, dim3(256), 0, s, x, wp, bias, y, H, W, Ho, Wo);
     };
-    if (sp == 2) go(std::integral_constant<int, 2>{});
-    else if (sp == 3) go(std::integral_constant<int, 3>{});
+    if (sp == 3) go(std::integral_constant<int, 3>{});
     else go(std::integral_constant<int, 16>{});
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }

@@ -106,17 +106,19 @@ def set_split_linear(on):
 #       frames/s against 295.6 with six terms (410.3 with three bf16 terms, 193.9 on the fp32 libraries); full-size logits 1.2e-5 /
 #       boxes 5.4e-7 from the reference (six terms: 1.6e-5 / 5.4e-7); the reference's track ids on all 64 frames of the 64-frame
 #       fixture in both runs (six terms: 26 frames, the fp32 libraries 59 / 26): profiles/r04_id_parity_64_with_fp16.txt.
-#   3   bf16 pieces (hi, mid), three terms, products good to 2^-16: the fast mode.
-# Why not 3 by default: the 64-frame reference-Tracker fixture (tests/golden/full_tracker_cfg2_64.npz) keeps the reference's
-# track ids for 59 frames under fp32 library GEMMs but only 14 under three bf16 terms (profiles/r04_id_parity_64.txt) -- boxes
-# and logits are inside 1e-3 either way, NMS decisions with IoU margins of 1e-4 are not.
+# (3 = bf16 pieces (hi, mid), three terms, products good to 2^-16 -- the "fast mode" of rounds 2-4 -- was REMOVED in round 5: the
+# fp16 product runs at the same speed, and the 64-frame reference-Tracker fixture keeps the reference's track ids for 59 frames
+# under fp32 library GEMMs but only 14 under three bf16 terms, profiles/r04_id_parity_64.txt.)
 def _parse_terms(v):
     v = str(v).strip().lower()
-    if v in ("3", "6", "16"):
+    if v in ("6", "16"):
         return int(v)
     if v in ("f16", "fp16", "half"):
         return 16
-    raise ValueError("split terms: 3, 6 or 16 (fp16 pieces)")
+    if v == "3":
+        raise ValueError("split terms 3 (the three-term bf16 fast mode) was removed in round 5: use 16 (fp16 pieces, the default: "
+                         "same speed, fp32-class accuracy) or 6 (six bf16 terms)")
+    raise ValueError("split terms: 6 or 16 (fp16 pieces)")
 
 
 _split_terms = _parse_terms(os.environ.get("TF_SPLIT_TERMS", "16"))
@@ -127,7 +129,7 @@ def split_terms():
 
 
 def set_split_terms(n):
-    """3 / 6 (bf16 pieces) or 16 (fp16 pieces, three terms) per split product (process-wide; cached weight images are kept per
+    """6 (bf16 pieces, six terms) or 16 (fp16 pieces, three terms) per split product (process-wide; cached weight images are kept per
     setting); returns the previous value."""
     global _split_terms
     n = _parse_terms(n)
@@ -150,16 +152,15 @@ def _use_packed(M, K, N):
     84.7, 1024 -> 256 65.6 vs 88.0, profiles/r04_pmc_dense_six_terms.txt; the reducing 1 x 1 convolutions of ResNet-50 25.2 vs
     35.6 / 24.8 vs 28.9 / 35.9 vs 42.2 us) but not under a short K, where its prologue is most of the block (the expanding 1 x 1
     convolutions with their residual: K = 64: 34.8 vs 30.4 us, K = 128: 28.8 vs 26.0; profiles/r04_conv_per_layer_stream_vs_block.txt).
-    Three terms: a wide output or a long K only (at K = 256, N <= 384 the many small blocks of the block kernel hide the memory
-    latency better: 21.4 vs 22.8 us)."""
+    Two stored weight pieces (the fp16 product): a wide output or a long K only (at K = 256, N <= 384 the many small blocks of the
+    block kernel hide the memory latency better: 21.4 vs 22.8 us)."""
     if not _packed_linear or M <= _PACKED_MIN_ROWS or K % 64:
         return False
     tail = N % 256
     full = N <= 128 or tail == 0 or tail > 128
     if _split_terms == 6:
         return full and K >= 256
-    # two stored weight pieces (three bf16 terms, fp16 pieces): the same kernels at the same cost -- measured with the fp16 pieces
-    # too (profiles/r04_f16_harness.txt: 22 223 x 256 -> 256 18.4 vs 18.7 us, 16 700 x 512 -> 128 16.1 vs 21.6, 66 800 x 64 -> 256
+    # two stored weight pieces (fp16 pieces; measured: profiles/r04_f16_harness.txt: 22 223 x 256 -> 256 18.4 vs 18.7 us, 16 700 x 512 -> 128 16.1 vs 21.6, 66 800 x 64 -> 256
     # 20.8 vs 19.3, 16 700 x 128 -> 512 17.3 vs 17.4)
     return (N >= 512 or K >= 512) and full
 
@@ -210,7 +211,7 @@ def _packed_weight(weight, rows):
 def _split_weight(weight):
     """The 16-bit pieces of an fp32 weight [N, K] for the kernels that take them as separate tensors (include/tf_fused.h, THE
     SPLIT PRODUCT) -> (p0, p1, p2, scale):
-      split_terms() 3 / 6   bf16 hi, mid, lo (lo None for three terms), scale None
+      split_terms() 6       bf16 hi, mid, lo; scale None
       split_terms() 16      fp16 wh = f16(w t_n), wl = f16(w t_n - wh), None, and scale[n] = 16 / t_n (fp32), t_n the power of two
                             that puts the largest |w| of output channel n into [2^13, 2^14)
     (round to nearest even at every step).  Cached ON THE TENSOR OBJECT together with its version counter
@@ -239,19 +240,19 @@ def _split_weight(weight):
             weight._tf_split_f16 = hit
         return hit[1], hit[2], hit[3], hit[4]
     hit = getattr(weight, "_tf_split", None)
-    if hit is None or hit[0] != weight._version or (hit[3] is None and _split_terms == 6):
+    if hit is None or hit[0] != weight._version:
         w = weight.detach()
         hi = w.to(torch.bfloat16)
         r = w - hi.float()                      # exact in fp32
         mid = r.to(torch.bfloat16)
-        lo = (r - mid.float()).to(torch.bfloat16).contiguous() if _split_terms == 6 else None
+        lo = (r - mid.float()).to(torch.bfloat16).contiguous()
         hit = (weight._version, hi.contiguous(), mid.contiguous(), lo)
         if w.is_cuda and torch.cuda.is_current_stream_capturing():
-            return hit[1], hit[2], (hit[3] if _split_terms == 6 else None), None   # (as above: not cached)
+            return hit[1], hit[2], hit[3], None   # (as above: not cached)
         if w.is_cuda:
             _publish_barrier(w.device)
         weight._tf_split = hit
-    return hit[1], hit[2], (hit[3] if _split_terms == 6 else None), None
+    return hit[1], hit[2], hit[3], None
 
 
 def _rows_of(pieces, rows):
@@ -536,8 +537,8 @@ def bias_relu_maxpool(x, bias):
 
 # DEFAULT since round 3 (TF_HEADS_SPLIT=0 / set_heads_split(False) switches it off; +2.9 % frames/s on its own,
 # profiles/r03_optin_single_routes.txt): the small head GEMMs (box-regression MLPs, class heads: 400 rows) through
-# the split-product kernels as well instead of hipBLASLt -- 24 launches per frame; the class logits then carry the three-term
-# product's ~1e-5 relative error like everything else (tools/experiments/bf16_split_linear.py: parity and track ids hold).
+# the split-product kernels as well instead of hipBLASLt -- 24 launches per frame; the class logits then carry the split
+# product's fp32-class error like everything else (parity and track ids: tests/test_full_size_gpu.py).
 _heads_split = os.environ.get("TF_HEADS_SPLIT", "1") != "0"
 
 
