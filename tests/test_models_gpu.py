@@ -218,6 +218,53 @@ def test_two_sequences_on_two_threads_match_sequential(dev):
                 assert a[1] == b[1] and max(abs(x - y) for x, y in zip(a[0], b[0])) < 1e-2
 
 
+def test_graphed_detector_prepare_on_the_side_stream_in_any_order(dev):
+    """GraphedDetector.prepare (round 5: the image-only half on a side stream, into alternating buffers) outside the tidy
+    prepare -> call -> prepare -> call of the tracker: a prepared frame that is never used, two prepares in a row, an ordinary
+    call between prepare and its use, host and device images, the frames where the decoder graph of a slot does not exist yet
+    (eager on the slot's static image) -- every output equals the eager forward of that image with those track queries."""
+    from trackformer_amd import config, factory
+    from trackformer_amd.graphed import GraphedDetector
+    model, post, args = um.build("cfg2_deformable_tracking", factory.build_model, config.make_args, device=dev)
+    model.to(dev).tracking()
+    graphed = GraphedDetector(model, bucket=16)
+    g = torch.Generator().manual_seed(11)
+    imgs_host = [torch.randn(1, 3, 160, 192, generator=g) for _ in range(5)]
+    imgs = [t.to(dev) for t in imgs_host]
+    target = [{'track_query_hs_embeds': torch.randn(7, 256, generator=g).to(dev),
+               'track_query_boxes': (torch.rand(7, 4, generator=g) * 0.5 + 0.2).to(dev), 'image_id': torch.tensor([1], device=dev)}]
+    tol = {'pred_logits': 2e-4, 'hs_embed': 2e-4, 'pred_boxes': 1e-5}   # see test_graphed_detector_equals_eager
+
+    def check(out, i, what):
+        eager, _, _, _, _ = model(imgs[i], [dict(target[0])], None)
+        for k in tol:
+            assert torch.allclose(eager[k], out[k], atol=tol[k], rtol=1e-5), (what, i, k, float((eager[k] - out[k]).abs().max()))
+
+    with torch.no_grad():
+        assert graphed.prepare(imgs[0]) is None                       # no graph of this shape yet: nothing to enqueue
+        for _ in range(3):                                            # ordinary calls: slot 0's two graphs are captured
+            check(graphed(imgs[0], [dict(target[0])], None)[0], 0, "ordinary")
+        for rep in range(3):                                          # the decoder graph of slot 1: eager once, captured, replayed
+            p = graphed.prepare(imgs[1], image_ready=True)
+            assert p is not None and p.is_cuda
+            check(graphed(p, [dict(target[0])], None)[0], 1, "prepared %d" % rep)
+            p = graphed.prepare(imgs_host[2], device=dev)             # a HOST image: uploaded on the side stream
+            assert p is not None
+            check(graphed(p, [dict(target[0])], None)[0], 2, "prepared from host %d" % rep)
+        p3 = graphed.prepare(imgs[3])                                 # (device image, not declared ready: the side stream waits)
+        check(graphed(imgs[4], [dict(target[0])], None)[0], 4, "ordinary call while a prepared frame waits")
+        assert graphed._prepared is None                              # ... which forgets the preparation (the tensor was another one)
+        check(graphed(p3, [dict(target[0])], None)[0], 3, "the slot's static image, no longer prepared: the half runs again")
+        graphed.prepare(imgs[1], image_ready=True)                    # two prepares in a row: the second one wins
+        p = graphed.prepare(imgs[2], image_ready=True)
+        check(graphed(p, [dict(target[0])], None)[0], 2, "second of two prepares")
+        p = graphed.prepare(imgs[0], image_ready=True)                # prepared, never used; then the tidy order again
+        for i in (1, 2, 3, 4):
+            p = graphed.prepare(imgs[i], image_ready=True)
+            check(graphed(p, [dict(target[0])], None)[0], i, "alternating")
+    torch.cuda.synchronize()
+
+
 def test_graphed_detector_buckets_the_track_query_count(dev):
     """Frames with 3, 5, 9, 16 and 17 track queries share two graphs (buckets of 16); the filler track queries are masked
     as self-attention keys and their rows dropped: outputs equal the eager forward on the real queries."""

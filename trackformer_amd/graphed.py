@@ -308,6 +308,11 @@ class GraphedDetector:
             prepared = None
         if prepared is not None:   # `img` IS the slot's static image: the side stream fills it (and the encoder results)
             torch.cuda.current_stream(img.device).wait_event(self._enc[(tuple(img.shape), img.device)][slot]["done"])
+        else:
+            # a static image prepare() handed out earlier, used after its preparation was forgotten: the side stream wrote it
+            for a in self._enc.get((tuple(img.shape), img.device)) or ():
+                if a is not None and a["img"] is img and a["ran"]:
+                    torch.cuda.current_stream(img.device).wait_event(a["done"])
         key = (tuple(img.shape), n_track, img.device, bool(multi and prev_features is not None),
                bool(lazy()) if lazy is not None else False,   # a graph with and one without the mask head are different graphs
                slot)                                          # the decoder half reads ONE slot's static buffers
