@@ -56,3 +56,21 @@ def test_committed_counter_passes_are_readable():
     pq = t.get("msda_fwd_f32_pquad2") or t["msda_fwd_f32_pquad"]   # round 5: the second version of the kernel
     algorithmic = 4 * (22223 * 8 * 32 + 3 * 22223 * 8 * 4 * 4 + 22223 * 8 * 32)      # SURVEY 8(d) at the cfg-2 encoder call
     assert algorithmic == 79647232 and algorithmic <= pq["hbm_traffic_bytes_per_launch"] < 2 * algorithmic
+
+
+def test_every_rank_gets_its_own_library_caches(monkeypatch, tmp_path):
+    """bench.per_rank_caches (round 5): MIOpen's user database / kernel cache and the TunableOp results file are per rank -- eight
+    ranks of a first run writing one find-db serialise on its lock -- and a path the caller already set is left alone."""
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    for var in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR", "PYTORCH_TUNABLEOP_FILENAME"):
+        monkeypatch.delenv(var, raising=False)
+    base3 = bench.per_rank_caches(3)
+    got3 = {v: os.environ[v] for v in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR", "PYTORCH_TUNABLEOP_FILENAME")}
+    assert base3.endswith("tf_bench_rank3") and all(p.startswith(base3) for p in got3.values())
+    assert os.path.isdir(got3["MIOPEN_USER_DB_PATH"]) and os.path.isdir(got3["MIOPEN_CUSTOM_CACHE_DIR"])
+    for var in got3:
+        monkeypatch.delenv(var)
+    monkeypatch.setenv("MIOPEN_USER_DB_PATH", "/somewhere/else")
+    base5 = bench.per_rank_caches(5)
+    assert os.environ["MIOPEN_USER_DB_PATH"] == "/somewhere/else"          # the caller's choice stands
+    assert os.environ["MIOPEN_CUSTOM_CACHE_DIR"].startswith(base5) and base5 != base3
