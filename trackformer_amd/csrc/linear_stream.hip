@@ -44,6 +44,9 @@ namespace {
 
 constexpr int kThreads = 256, kSlice = 32;   // K per slice (two MFMA k-steps of 16)
 constexpr int kStride = kSlice + 8;          // bf16 per LDS row: 80 bytes (16-byte aligned, 8 rows cover all banks)
+#ifndef TF_STREAM_ABLATE
+#define TF_STREAM_ABLATE 0   // timing ablations of stream_gemm_kernel (tools only): 1 no activation split, 2 no MFMAs
+#endif
 constexpr int kTJ = 2;                       // MFMA column tiles per wave -> 4 waves x 2 x 32 = 256 columns per block
 constexpr int kBN = 4 * kTJ * 32;
 
@@ -269,7 +272,12 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             u32x2 pc[NA];
+#if TF_STREAM_ABLATE & 1   // timing ablation (tools/build_variant.py --source linear_stream.hip): no fp32 -> pieces conversion, the bits as they are
+#pragma unroll
+            for (int p = 0; p < NA; ++p) pc[p] = u32x2{__builtin_bit_cast(unsigned, src[it].x) + (unsigned)p, __builtin_bit_cast(unsigned, src[it].z)};
+#else
             split4<SP>(src[it], pc);
+#endif
             const int o = (it * 32 + arow) * kStride + ac4 * 4;
 #pragma unroll
             for (int p = 0; p < NA; ++p) *reinterpret_cast<u32x2 *>(&sA[buf][p][o]) = pc[p];
@@ -327,7 +335,14 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
                 for (int p = 0; p < NB; ++p) bfr[j][p] = cur.v[j][kk][p];
             // term-major passes over the tiles: consecutive MFMAs never share an accumulator; per accumulator the order is
             // smallest terms first, as in linear_split.hip
+#if TF_STREAM_ABLATE & 2   // timing ablation: no matrix instructions (the operands stay alive through one add)
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j][kk] += __builtin_bit_cast(float, af[i][0].x ^ bfr[j][0].x);
+#else
             mfma_tiles<SP, TI, TJ>(acc, af, bfr);
+#endif
         }
 #ifdef TF_STREAM_TRACE
         __builtin_amdgcn_sched_barrier(0);
