@@ -519,6 +519,8 @@ int stream_dispatch(const StreamCall &c, hipStream_t s)
         return big ? launch_stream<SP, 2, 1, 2, CONV>(c, s) : launch_stream<SP, 1, 1, 2, CONV>(c, s);
     }
     if (c.N <= 128) {
+        // (round 5, measured and removed: 128 x 128 blocks as 2 x 2 waves of 64 x 64 -- half the LDS re-reads of the activations per
+        // MFMA, twice the weight fragments per wave: 150.6 us against 146.9 at 131 072 rows, profiles/r05_conv3_tiles_2x2_waves.txt)
         const bool big = f ? f >= 4 : (long long)((c.M + 127) / 128) * pieces >= 2LL * num_cus();
         return big ? launch_stream<SP, 4, 1, 4, CONV>(c, s) : launch_stream<SP, 2, 1, 4, CONV>(c, s);
     }
