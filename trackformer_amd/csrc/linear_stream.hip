@@ -44,6 +44,9 @@ namespace {
 
 constexpr int kThreads = 256, kSlice = 32;   // K per slice (two MFMA k-steps of 16)
 constexpr int kStride = kSlice + 8;          // bf16 per LDS row: 80 bytes (16-byte aligned, 8 rows cover all banks)
+#ifndef TF_STREAM_XDEPTH
+#define TF_STREAM_XDEPTH 2   // register stages of activations ahead in the convolution form (4: measured in round 5, no gain; tools/build_variant.py for A/B)
+#endif
 #ifndef TF_STREAM_ABLATE
 #define TF_STREAM_ABLATE 0   // timing ablations of stream_gemm_kernel (tools only): 1 no activation split, 2 no MFMAs
 #endif
@@ -300,21 +303,30 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
 #ifdef TF_STREAM_TRACE
     TraceRegs trace_regs = {};
 #endif
-    f32x4 xr[2][XV];   // slice s + 1 lives in xr[(s + 1) & 1], slice s + 2 in the other one   (parity relative to sbeg)
+    // The activations of the slices AHEAD live in a ring of DX register stages: slice s + 1 in xr[(s + 1 - sbeg) % DX], ..., slice
+    // s + DX in xr[(s - sbeg) % DX].  Two stages.  The phase trace of round 5 (profiles/r05_stream_phase_trace.txt) shows the
+    // convolution form spending 806 of the 1660 cycles of a slice (128 -> 128 3 x 3) in its staging phase; FOUR stages
+    // (-DTF_STREAM_XDEPTH=4) were measured against that and do not help -- 1360 against 1322 us per frame over ResNet-50's
+    // convolutions, 37.9 against 31.6 us for layer1's 3 x 3 (fewer resident blocks), profiles/r05_stream_xdepth.txt: the phase is
+    // not waiting for those loads.
+    constexpr int DX = CONV ? TF_STREAM_XDEPTH : 2;
+    static_assert(DX == 2 || DX == 4, "ring of 2 or 4 register stages");
+    f32x4 xr[DX][XV];
     WFrags<NB, TJ> w0, w1;
     {
         f32x4 first[XV];
         load_x(first);
         load_w(sbeg, w0);
-        load_x(xr[1]);
-        load_x(xr[0]);
+#pragma unroll
+        for (int d = 1; d <= DX; ++d) load_x(xr[d % DX]);
         store_x(first, 0);
     }
     __syncthreads();
 
-    // one K-slice; PAR = (s - sbeg) & 1 as a compile-time constant so that the register double buffers need no copies
-    auto slice = [&](int s, auto par, const WFrags<NB, TJ> &cur, WFrags<NB, TJ> &nxt) {
-        constexpr int PAR = decltype(par)::value;
+    // one K-slice; PAR = (s - sbeg) & 1 (the LDS buffer it reads) and XS = (s + 1 - sbeg) % DX (the register stage that holds
+    // slice s + 1) as compile-time constants so that the register buffers need no copies
+    auto slice = [&](int s, auto par, auto xs, const WFrags<NB, TJ> &cur, WFrags<NB, TJ> &nxt) {
+        constexpr int PAR = decltype(par)::value, XS = decltype(xs)::value;
         TF_TRACE(s - sbeg, 0);
         load_w(s + 1, nxt);   // in flight during the MFMAs below
         __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them to the end of the
@@ -349,18 +361,30 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
 #endif
         TF_TRACE(s - sbeg, 1);
         // slice s + 1 -> the LDS buffer nobody reads in this iteration (its readers passed the previous barrier),
-        // then its registers take slice s + 3
-        store_x(xr[PAR ^ 1], PAR ^ 1);
-        load_x(xr[PAR ^ 1]);
+        // then its registers take slice s + 1 + DX
+        store_x(xr[XS], PAR ^ 1);
+        load_x(xr[XS]);
 #ifdef TF_STREAM_TRACE
         __builtin_amdgcn_sched_barrier(0);
 #endif
         TF_TRACE(s - sbeg, 2);
         __syncthreads();
     };
-    for (int s = sbeg; s < send; s += 2) {   // an even number of slices (host)
-        slice(s, std::integral_constant<int, 0>{}, w0, w1);
-        slice(s + 1, std::integral_constant<int, 1>{}, w1, w0);
+    using std::integral_constant;
+    if constexpr (DX == 2) {
+        for (int s = sbeg; s < send; s += 2) {   // an even number of slices (host)
+            slice(s, integral_constant<int, 0>{}, integral_constant<int, 1>{}, w0, w1);
+            slice(s + 1, integral_constant<int, 1>{}, integral_constant<int, 0>{}, w1, w0);
+        }
+    } else {
+        for (int s = sbeg; s < send; s += 4) {   // an even number of slices (host): the second pair may be absent (block-uniform)
+            slice(s, integral_constant<int, 0>{}, integral_constant<int, 1>{}, w0, w1);
+            slice(s + 1, integral_constant<int, 1>{}, integral_constant<int, 2>{}, w1, w0);
+            if (s + 2 < send) {
+                slice(s + 2, integral_constant<int, 0>{}, integral_constant<int, 3>{}, w0, w1);
+                slice(s + 3, integral_constant<int, 1>{}, integral_constant<int, 0>{}, w1, w0);
+            }
+        }
     }
 
     // ---- epilogue: C/D of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  Buffer
