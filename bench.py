@@ -50,6 +50,9 @@ The JSON line also carries
                    pure-CPU MSDeformAttn path (grid_sample, oracle/msda_grid_sample.py: "kind":
                    "reference-restated"); the C port of the kernels' arithmetic (oracle/msda_ref.c)
                    timed beside it; rank 0, N=1 only, a bounded sample.
+  step_only_fps / host_frames_fps -- one sequence, (1) plain Tracker.step() per frame without step_prepare: what an unmodified
+                   src/track.py loop of the reference gets from the drop-in; (2) the pipelined loop with the frames in pinned
+                   host memory, the upload inside the timed step.  `value` is the pipelined loop on HBM-resident frames.
   single_sequence_fps / multi_sequence_fps -- cfg2/4/5: the same steps with ONE sequence per GPU (no overlap of one
                    sequence's host-side association with another's forward) / with --sequences interleaved.
   precision     -- `value` is measured with the DEFAULT arithmetic of the package (fused.split_terms(); `dtype` and
@@ -377,7 +380,7 @@ def association_stats(model, post, seeder, frames, steps=4):
             "tracks_alive_after_step": alive}
 
 
-def measure_parity(device):
+def measure_parity(device, pipelined=True):
     """In-run parity of the product path against the committed goldens of the reference's own classes (tests/golden/
     full_cfg2_full.npz, full_tracker_cfg2.npz; generated by tests/golden/make_golden_full.py from /root/reference on CPU): the
     800 x 1333 cfg-2 model with the parity tests' perturbed weights in the bench set-up (tuned runtime, HIP graph, every
@@ -405,9 +408,30 @@ def measure_parity(device):
     zt = np.load(os.path.join(T.GOLDEN, "full_tracker_cfg2.npz"))
     ids_equal = bool(rows.shape == zt["rows"].shape and np.array_equal(rows[:, [0, 1, 7]], zt["rows"][:, [0, 1, 7]])
                      and int(zt["num_tracks"]) == tracker.track_num and zt["active_per_frame"].tolist() == active)
-    return {"against": "reference CPU path goldens (tests/golden/full_cfg2_full.npz, full_tracker_cfg2.npz), perturbed weights, 800x1333",
+    line = {"against": "reference CPU path goldens (tests/golden/full_cfg2_full.npz, full_tracker_cfg2.npz), perturbed weights, 800x1333",
             "setup": setup, "max_abs_boxes": dbox, "max_abs_logits": dlogit, "tolerance": 1e-3,
             "ids_equal": ids_equal, "tracker_frames": int(len(active)), "track_rows": int(rows.shape[0])}
+    if pipelined and setup in T._SPLIT_SETUPS:
+        # THE PATH `value` IS TIMED ON (VERDICT r05 task 1b): step_async / step_prepare / step_finish with the image-only half of
+        # the next frame on the side stream, two graphs, over the 64-frame well-conditioned 800x1333 sequence against the
+        # reference's own Tracker (full_tracker_cfg2_wc64.npz): ids of every frame, and that the frames really were prepared
+        zw = np.load(os.path.join(T.GOLDEN, "full_tracker_cfg2_wc64.npz"))
+        n = len(zw["active_per_frame"])
+        tr, rw, act, prepared = T._run_wc_tracker_pipelined(case, device, setup, n, host_frames=False)
+        same_shape = rw.shape == zw["rows"].shape
+        line["path"] = "pipelined"
+        line["pipelined"] = {
+            "against": "tests/golden/full_tracker_cfg2_wc64.npz (the reference's Tracker on CPU, well-conditioned 64-frame sequence, 800x1333)",
+            "loop": "step_async(t) -> step_prepare(t+1) -> step_finish(t), frames resident in HBM: the loop run_tracking times",
+            "frames": int(n), "frames_prepared": int(prepared), "track_rows": int(rw.shape[0]),
+            "ids_equal": bool(same_shape and np.array_equal(rw[:, [0, 1, 7]], zw["rows"][:, [0, 1, 7]])
+                              and int(zw["num_tracks"]) == tr.track_num and zw["active_per_frame"].tolist() == act),
+            "max_abs_boxes_px": float(np.abs(rw[:, 2:6] - zw["rows"][:, 2:6]).max()) if same_shape else None,
+            "max_abs_scores": float(np.abs(rw[:, 6] - zw["rows"][:, 6]).max()) if same_shape else None}
+        line["ids_equal"] = bool(line["ids_equal"] and line["pipelined"]["ids_equal"])
+    else:
+        line["path"] = "step"
+    return line
 
 
 def make_frames(device, size, n=4, host=False):
@@ -473,7 +497,7 @@ def measure_roofline_backward(device, launches=10):
     ms = time_launches(lambda: msda.ms_deform_attn_backward(value, shapes, loc, attn, grad_out, 64), launches)
     alg = algorithmic_bytes(N=2, S=S, M=8, D=32, L=4, Lq=S, P=4, backward=True)
     gbs = alg / ms / 1e6
-    return {"bound": "hbm", "kernel": "msda_bwd_f32_sorted2 (encoder call of a bs-2 training step, N=2, Lq=S=22223)",
+    return {"bound": "hbm", "kernel": msda.last_kernel() + " (encoder call of a bs-2 training step, N=2, Lq=S=22223)",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
             "traffic": None, "algorithmic_bytes": alg, "avg_launch_us": round(ms * 1e3, 2), "launches": launches,
             "pattern": "local (reference point + N(0, 2 px))"}
@@ -518,25 +542,24 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
             end.synchronize()
         us = start.elapsed_time(end) * 1e3 / launches
         per_pattern[pattern] = {"avg_launch_us": round(us, 2), "GBps": round(alg / (us * 1e-6) / 1e9, 1),
-                                "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                                "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "kernel": msda.last_kernel()}   # what the library dispatched for this thread's last call
         del graph, inputs
     head = per_pattern["pert"]
     # HBM traffic of the same kernel / shape / pattern from the PMC counters: collected offline (rocprofv3
     # --pmc needs its own passes) and committed together with the method; see the file's "_how"
-    mode = os.environ.get("TF_MSDA_TILED", "2")[:1] or "2"   # the library's kernel choice for this shape
-    # (round 5: msda_fwd_f32_pquad2, the second version of the persistent kernel, where it applies: D == 32)
-    kernel = {"0": "msda_fwd_f32_direct"}.get(mode, "msda_fwd_f32_pquad2")
-    if "v2=0" in os.environ.get("TF_MSDA_PQUAD", ""):
-        kernel = "msda_fwd_f32_pquad"
-    if D != 32 and kernel.startswith("msda_fwd_f32_pquad"):
-        kernel = "msda_fwd_f32_pquad<D=36>"   # head dimension 36 (hidden 288): 144-byte rows, 3 lanes x 12 channels
+    # the kernel the LIBRARY dispatched for these calls (tf_msda_last_kernel), not what the options suggest
+    kernel = head["kernel"]
+    family = kernel.split("<")[0]   # the key of the committed counter passes
+    if D != 32 and family == "msda_fwd_f32_pquad":
+        family = "msda_fwd_f32_pquad<D=36>"
     traffic = traffic_src = None
     try:
         import glob
         newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_msda_fwd_pquad_traffic.json")))[-1]
         with open(newest) as f:
             tj = json.load(f)
-        traffic = tj[kernel]["hbm_traffic_bytes_per_launch"]
+        traffic = tj[family]["hbm_traffic_bytes_per_launch"]
         traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes; taken at commit %s)" % (
             os.path.basename(newest), tj.get("_commit", "of round 3"))
     except (OSError, KeyError, ValueError, IndexError):
@@ -920,7 +943,7 @@ def main():
             print(json.dumps(measure_roofline(device, head_dim=hd, patterns=("pert", "init", "local"))))
         return
     model, criterion, post, margs = build_model(cfg, device)
-    single = fp32_exact = fp32_exact_single = association = multi = None
+    single = fp32_exact = fp32_exact_single = association = multi = step_only = host_frames_fps = None
     other_arith = {}
     n_seq = 1
     if cfg["kind"] == "track":
@@ -943,6 +966,19 @@ def main():
                 em, rm = run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds)
                 multi = args.steps * rm * world / em
             n_seq = 1
+        if not args.no_prepare and not args.no_single_sequence and not args.host_frames:
+            # ... and the two figures a caller of the reference's own loop gets (VERDICT r05 task 1c): (1) plain Tracker.step()
+            # per frame, no step_prepare -- what an unmodified src/track.py:130-134 drives; (2) the pipelined loop with the frames
+            # in pinned HOST memory, the 12.8 MB upload inside the timed step (tracker.py:283-284 of the reference uploads too)
+            import copy
+            a_step = copy.copy(args)
+            a_step.no_prepare = True
+            es, rs = run_tracking(cfg, a_step, device, world, model, post, margs, 1, seeds)
+            step_only = args.steps * rs * world / es
+            a_host = copy.copy(args)
+            a_host.host_frames = True
+            eh, rh = run_tracking(cfg, a_host, device, world, model, post, margs, 1, seeds)
+            host_frames_fps = args.steps * rh * world / eh
         if seeds is not None and rank == 0:
             association = association_stats(model, post, TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds),
                                             make_frames(device, cfg["size"]))
@@ -989,7 +1025,7 @@ def main():
         if not args.no_roofline and margs.deformable:
             roofline = measure_roofline(device, train=train, head_dim=margs.hidden_dim // margs.nheads)
         if args.config == "cfg2" and not args.no_parity and not args.no_graph:
-            parity = measure_parity(device)
+            parity = measure_parity(device, pipelined=not args.no_prepare)
         if not train and margs.deformable:
             mfma = {"live": measure_dense_kernels(device, margs.hidden_dim) if fused.split_linear_enabled() else None,
                     "pmc": committed_mfma_utilisation()}
@@ -1044,6 +1080,8 @@ def main():
                           if "segm" in post and os.environ.get("TF_LAZY_MASKS", "1") != "0" and not train else {})},
             "single_sequence_fps": None if single is None else round(single, 3),
             "multi_sequence_fps": None if multi is None else {"sequences_per_gpu": max(1, args.sequences), "value": round(multi, 3)},
+            "step_only_fps": None if step_only is None else round(step_only, 3),
+            "host_frames_fps": None if host_frames_fps is None else round(host_frames_fps, 3),
             "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
             "single_sequence_fp32_exact_fps": None if fp32_exact_single is None else round(fp32_exact_single, 3),
             **{_ARITH[a][1]: other_arith.get(_ARITH[a][1]) for a in (6, 16) if a != fused.split_terms() or not fused.split_linear_enabled()},

@@ -67,6 +67,13 @@ const char *tf_msda_strerror(int status);
 int tf_msda_last_hip_error(void);
 
 /*
+ * Name of the device kernel the most recent forward / backward call of THIS thread enqueued (e.g.
+ * "msda_fwd_f32_pquad2<fused,4w,2p>"), "" before the first call.  The string is static.  Measurement aid: bench.py labels
+ * its roofline with what the library dispatched instead of inferring it from the options.
+ */
+const char *tf_msda_last_kernel(void);
+
+/*
  * Kernel selection knob (process-wide, performance only -- results are identical up to fp32 summation
  * order) for encoder-shaped forward calls (Lq == S, fp32, D == 32 or 36, P == 4, L <= 4, host shapes):
  * 2 = the LDS-window kernels (msda_fwd_f32_pquad: persistent workgroups, 4 lanes per pair; msda_fwd_f32_quad where it

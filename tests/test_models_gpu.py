@@ -64,6 +64,91 @@ def test_pipelined_tracker_runs_the_next_frames_encoder_under_the_association(de
     assert tracker.frames_prepared >= (63 if not graph else 40)   # graph: a new track-query bucket is captured on its second sight
 
 
+def _small_detector(dev):
+    from trackformer_amd import config, factory
+    model, post, args = um.build("cfg2_deformable_tracking", factory.build_model, config.make_args, device=dev)
+    model.to(dev).tracking()
+    return model
+
+
+def test_range_audit_and_routes_work_with_graphed_detector(dev):
+    """graph replays call none of fused's wrappers -- (1) under an audit / the finite check the wrapper runs
+    the model eagerly, so the audit sees every layer (it used to report `largest 0`); (2) a route added after capture drops the
+    graphs (fused.route_epoch), the next calls capture again; (3) capturing with the finite check on raises a clear error
+    instead of synchronising inside the capture."""
+    from trackformer_amd import fused
+    from trackformer_amd.graphed import GraphedDetector
+    prev_split, prev_terms = fused.set_split_linear(True), fused.set_split_terms(16)
+    model = _small_detector(dev)
+    det = GraphedDetector(model)
+    img = um.tracker_sequence()[0]['img'].to(dev)
+    try:
+        with torch.no_grad():
+            for _ in range(3):
+                out0, *_ = det(img, None, None)
+            assert len(det._graphs) == 1
+            with fused.audit_activation_range(route=False) as report:
+                out1, *_ = det(img, None, None)            # eager under the audit
+            assert report["largest"] > 0 and len(report["layers"]) > 10 and report["routed"] == 0
+            assert torch.allclose(out0['pred_boxes'], out1['pred_boxes'], atol=1e-5)
+            w = model.transformer.encoder.layers[0].linear1.weight
+            fused.route_six_terms(w)
+            try:
+                out2, *_ = det(img, None, None)
+                assert len(det._graphs) == 0                # dropped: captured under another epoch
+                out2, *_ = det(img, None, None)
+                assert len(det._graphs) == 1                # ... and captured again, with the routed layer
+                assert torch.allclose(out0['pred_boxes'], out2['pred_boxes'], atol=1e-4)
+            finally:
+                fused.route_six_terms(w, False)
+            prev = fused.set_check_finite(True)
+            try:
+                g = torch.cuda.CUDAGraph()
+                x = torch.randn(64, 256, device=dev)
+                lin = torch.nn.Linear(256, 256).to(dev)
+                fused.linear(x, lin.weight, lin.bias)
+                with pytest.raises(RuntimeError, match="cannot run while a HIP graph is being captured"):
+                    with torch.cuda.graph(g):
+                        fused.linear(x, lin.weight, lin.bias)
+            finally:
+                fused.set_check_finite(prev)
+    finally:
+        fused.set_split_linear(prev_split)
+        fused.set_split_terms(prev_terms)
+    assert fused.six_term_routes() == 0
+
+
+def test_graphed_detector_prepare_twice_and_eager_fallbacks(dev):
+    """(1) two prepare() calls without a forward in between fill the same slot -- the tensor of the FIRST call
+    must not be taken for "prepared" (it would silently decode the second image's encoder state): it is encoded from its
+    contents; (2) a call that cannot be replayed (gradients on) with a prepared tensor waits for the side stream before the
+    eager forward reads the image."""
+    from trackformer_amd.graphed import GraphedDetector
+    model = _small_detector(dev)
+    det = GraphedDetector(model)
+    frames = [b['img'].to(dev) for b in um.tracker_sequence()[:3]]
+    with torch.no_grad():
+        for _ in range(3):
+            det(frames[0], None, None)                      # the graphs of this shape exist
+        want = [model(f, None, None)[0]['pred_boxes'].clone() for f in frames]
+        p1 = det.prepare(frames[1], image_ready=True)
+        p2 = det.prepare(frames[2], image_ready=True)
+        assert p1 is not None and p2 is not None and p1 is not p2 and p1.data_ptr() == p2.data_ptr()
+        out, *_ = det(p2, None, None)
+        assert torch.allclose(out['pred_boxes'], want[2], atol=1e-5)
+        p1 = det.prepare(frames[1], image_ready=True)
+        p2 = det.prepare(frames[2], image_ready=True)
+        out, *_ = det(p1, None, None)                       # the stale alias: holds frame 2 now, and is decoded as what it holds
+        assert torch.allclose(out['pred_boxes'], want[2], atol=1e-5)
+        p = det.prepare(frames[1], image_ready=True)
+    with torch.enable_grad():
+        out, *_ = det(p, None, None)                        # not replayable: eager, after the side stream's write of `p`
+    assert torch.allclose(out['pred_boxes'].detach(), want[1], atol=1e-5)
+    with torch.no_grad():
+        out, *_ = det(frames[0], None, None)
+    assert torch.allclose(out['pred_boxes'], want[0], atol=1e-5)
+
+
 @pytest.mark.parametrize("lazy", [False, True], ids=["full_head", "lazy_head"])
 def test_tracker_with_mask_head_matches_reference(dev, lazy):
     """cfg-5 path (mask head + Tracker) on the GPU against the reference's own Tracker / mask head / PostProcessSegm on CPU

@@ -135,8 +135,9 @@ static Config parse_config(const std::string &arg)
     static const char *pkeys[][2] = {{"wide", "pquad_wide"}, {"npass", "pquad_npass"}, {"lds", "pquad_lds_kb"},
                                      {"hy", "pquad_halo_y"}, {"hx", "pquad_halo_x"}, {"th", "pquad_tile_h"},
                                      {"tw", "pquad_tile_w"}, {"wgs", "pquad_wg_per_cu"}, {"pf", "pquad_prefetch"},
-                                     {"skew", "pquad_skew"}, {"v2", "pquad_v2"}, {"waves", "pquad_waves"}};
-    const size_t nkeys = c.tiled == 3 ? 12 : 9;
+                                     {"skew", "pquad_skew"}, {"v2", "pquad_v2"}, {"waves", "pquad_waves"},
+                                     {"hm", "pquad_headmix"}, {"prio", "pquad_prio"}};
+    const size_t nkeys = c.tiled == 3 ? 14 : 9;
     const char *(*keys)[2] = c.tiled == 3 ? pkeys : qkeys;
     size_t pos = arg.find(':');
     while (pos != std::string::npos && pos + 1 < arg.size()) {
@@ -157,10 +158,11 @@ static void apply(const Config &c)
                                   "quad_halo_x",  "quad_tile_h", "quad_tile_w", "quad_split"};
     static const int defaults[] = {0, 4, 3, 40, 6, 10, 0, 0, 1};   // = kQuadOptDefaults of the library
     static const char *pnames[] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
-                                   "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew", "pquad_v2", "pquad_waves"};
-    static const int pdefaults[] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 4};   // = kPqOptDefaults of the library
+                                   "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew", "pquad_v2", "pquad_waves",
+                                   "pquad_headmix", "pquad_prio"};
+    static const int pdefaults[] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 4, 0, 0};   // = kPqOptDefaults of the library
     for (int i = 0; i < 9; ++i) tf_msda_set_option(names[i], defaults[i]);
-    for (int i = 0; i < 12; ++i) tf_msda_set_option(pnames[i], pdefaults[i]);
+    for (int i = 0; i < 14; ++i) tf_msda_set_option(pnames[i], pdefaults[i]);
     for (auto &o : c.opts) tf_msda_set_option(o.first.c_str(), o.second);
     tf_msda_set_option("pquad", c.tiled == 3 ? 1 : 0);
     tf_msda_set_option("tiled", c.tiled == 3 ? 2 : c.tiled);
@@ -169,13 +171,17 @@ static void apply(const Config &c)
 int main(int argc, char **argv)
 {
     int iters = 20, N = 1, fused = 1, trace = 0, sets = 1;
-    std::string patterns = "init,local,uniform";
+    std::string patterns = "init,local,uniform", trace_dump;
     std::vector<Config> cfgs;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--iters") && i + 1 < argc) iters = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--n") && i + 1 < argc) N = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--fused") && i + 1 < argc) fused = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--trace")) trace = 1;
+        else if (!strcmp(argv[i], "--trace-dump") && i + 1 < argc) {   // raw stamps of every workgroup, one CSV row each
+            trace = 1;
+            trace_dump = argv[++i];
+        }
         else if (!strcmp(argv[i], "--sets") && i + 1 < argc) sets = std::max(1, atoi(argv[++i]));   // rotate over K copies of
         // the tensors (K x 80..114 MB): with K >= 4 the working set exceeds the 256 MiB Infinity Cache, every launch reads HBM
         else if (!strcmp(argv[i], "--patterns") && i + 1 < argc) patterns = argv[++i];
@@ -309,6 +315,20 @@ int main(int argc, char **argv)
                                                      "DMA L1-3 landed (own)"};
                     const char **names = c.tiled == 3 ? pnames : qnames;
                     printf("  trace of %zu workgroups (us after the first workgroup's entry; 100 MHz clock):\n", nwg);
+                    if (!trace_dump.empty()) {
+                        // block, then 16 stamps in 10 ns ticks after the earliest entry (0 = not stamped); appended per run
+                        FILE *f = fopen(trace_dump.c_str(), "a");
+                        if (f) {
+                            fprintf(f, "# %s %s %s\n", mode.c_str(), fz ? "fused" : "plain", c.name.c_str());
+                            for (size_t w = 0; w < nwg; ++w) {
+                                fprintf(f, "%zu", w);
+                                for (int i = 0; i < 16; ++i)
+                                    fprintf(f, ",%lld", tr[w * 16 + i] ? (long long)(tr[w * 16 + i] - t0) : -1LL);
+                                fprintf(f, "\n");
+                            }
+                            fclose(f);
+                        }
+                    }
                     static const int qorder[14] = {0, 1, 12, 13, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
                     static const int porder[14] = {0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 7, 8, 9, 10};
                     const int *order = c.tiled == 3 ? porder : qorder;

@@ -14,6 +14,7 @@ EXPORTED_SYMBOLS = (
     "tf_msda_abi_version",
     "tf_msda_strerror",
     "tf_msda_last_hip_error",
+    "tf_msda_last_kernel",
     "tf_msda_set_tiled",
     "tf_msda_set_option",
     "tf_msda_debug_trace_buffer",
@@ -84,6 +85,8 @@ def lib():
     L.tf_msda_strerror.argtypes = [ci]
     L.tf_msda_last_hip_error.restype = ci
     L.tf_msda_last_hip_error.argtypes = []
+    L.tf_msda_last_kernel.restype = ctypes.c_char_p
+    L.tf_msda_last_kernel.argtypes = []
     L.tf_msda_set_tiled.restype = ci
     L.tf_msda_set_tiled.argtypes = [ci]
     L.tf_msda_set_option.restype = ci

@@ -173,7 +173,7 @@ class _FoldCache:
     def weight2d(self):
         if self._weight2d is None and self._conv.kernel_size == (1, 1):
             w = self._scaled()
-            self._weight2d = self._published(w.reshape(w.shape[0], w.shape[1]).contiguous())
+            self._weight2d = fused.inherit_route(self._published(w.reshape(w.shape[0], w.shape[1]).contiguous()), self._conv.weight)
         return self._weight2d
 
     @property
@@ -181,7 +181,8 @@ class _FoldCache:
         if self._weight_taps is None and self._conv.kernel_size == (3, 3):
             w = self._scaled()
             # [Cout, 3, 3, Cin] -> [Cout, 9 * Cin]: the storage order of the channels_last weight (tap-major K)
-            self._weight_taps = self._published(w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous())
+            self._weight_taps = fused.inherit_route(self._published(w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * w.shape[1]).contiguous()),
+                                                    self._conv.weight)
         return self._weight_taps
 
     def get(self, conv: nn.Conv2d, bn: FrozenBatchNorm2d):
@@ -193,6 +194,10 @@ class _FoldCache:
                 _, shift = bn.scale_shift()
                 self.bias = self._published(shift.contiguous())
             self._conv, self._bn = conv, bn
+            # a six-term route (fused.route_six_terms / audit_activation_range) lives on the image it was given for: the images
+            # re-created for changed weights inherit it through the convolution's parameter
+            if any(fused._routed(t) for t in (self._weight2d, self._weight_taps) if t is not None):
+                fused.route_six_terms(conv.weight)
             self._weight = self._weight2d = self._weight_taps = None
             self.key = key
         return self.bias

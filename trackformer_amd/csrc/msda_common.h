@@ -38,6 +38,9 @@ struct DirectArgs {
     long long nlq;             // N * Lq
 };
 
+// the kernel the calling thread dispatched last (tf_msda_last_kernel, include/tf_msda.h); `name` must be a string literal
+void note_kernel(const char *name);
+
 // msda_pquad.hip: the persistent LDS-window encoder forward (msda_fwd_f32_pquad).  launch_pquad returns
 // false when the call does not qualify (the caller falls through to the next kernel).
 bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N, int D, int P, hipStream_t stream,

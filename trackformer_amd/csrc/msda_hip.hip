@@ -67,6 +67,7 @@ struct alignas(sizeof(T) * VEC) Pack {
 };
 
 thread_local int g_last_hip_error = 0;
+thread_local const char *g_last_kernel = "";
 
 // ---------------------------------------------------------------------------------------------
 // device helpers
@@ -1922,6 +1923,7 @@ bool launch_quad(bool fused, const DirectArgs &da, const LevelTable &lt, int N, 
     qp.geom.trace = g_quad_trace.load(std::memory_order_relaxed);
     void *argv[] = {(void *)&da, (void *)&lt, (void *)&qp.geom};
     *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(qp.waves * 64), argv, qp.lds, stream);
+    note_kernel(fused ? "msda_fwd_f32_quad<fused>" : "msda_fwd_f32_quad<plain>");
     return true;
 }
 
@@ -1977,6 +1979,7 @@ bool launch_direct(bool fused, const DirectArgs &da, const LevelTable &lt, const
         const long long grid9 = (da.nlq + ppb - 1) / ppb * da.M;
         if (grid9 > 0x7fffffffLL) return false;
         *err = launch(fn, (unsigned)grid9, 0, stream, da, lt, shapes_dev);
+        note_kernel(fused ? "msda_fwd_f32_direct9<fused>" : "msda_fwd_f32_direct9<plain>");
         return true;
     }
     if (D != 32) return false;
@@ -1994,6 +1997,7 @@ bool launch_direct(bool fused, const DirectArgs &da, const LevelTable &lt, const
     const long long grid = chunks * da.M;
     if (grid > 0x7fffffffLL) return false;
     *err = launch(fn, (unsigned)grid, 0, stream, da, lt, shapes_dev);
+    note_kernel(fused ? "msda_fwd_f32_direct<fused>" : "msda_fwd_f32_direct<plain>");
     return true;
 }
 
@@ -2053,6 +2057,7 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
             const unsigned grid = none.head_major ? head_major_grid(N, Lq, M, pl.ppb) : pl.grid;
             e = launch(fn, grid, pl.lds, stream, value, vbytes, loc, attn, out, lt, shapes_dev,
                        S, M, D, L, Lq, total_pairs, pl.ppb, pl.DV, none);
+            note_kernel("msda_fwd_f32_buf<plain>");
             return record_hip(e);
         }
     }
@@ -2060,6 +2065,7 @@ int forward_impl(const T *value, const int64_t *shapes_host, const int64_t *shap
                                  : (const void *)&msda_fwd_rowgather<T, 1>;
     e = launch(fn, pl.grid, pl.lds, stream, value, loc, attn, out, lt, shapes_dev, S, M, D, L, Lq,
                P, total_pairs, pl.ppb, pl.DV);
+    note_kernel(sizeof(T) == 4 ? "msda_fwd_rowgather<f32>" : "msda_fwd_rowgather<f64>");
     return record_hip(e);
 }
 
@@ -2118,6 +2124,7 @@ int forward_fused_impl(const float *value, const int64_t *shapes_host, const flo
     const hipError_t e = launch(fn, grid, pl.lds, static_cast<hipStream_t>(stream_v), value,
                                 vbytes, nul, nul, out, lt, nod, S, M, D, L, Lq, total_pairs, pl.ppb,
                                 pl.DV, fa);
+    note_kernel("msda_fwd_f32_buf<fused>");
     return record_hip(e);
 }
 
@@ -2182,6 +2189,7 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
                 if (slds > 64 * 1024 && !raise_dynamic_lds(sfn)) return record_hip(hipErrorInvalidValue);
                 void *argv[] = {(void *)&ba, (void *)&lt, (void *)&sgeom};
                 const unsigned sgrid = (unsigned)((long long)N * sgeom.tiles_y * sgeom.tiles_x * M);
+                note_kernel("msda_bwd_f32_sorted2");
                 return record_hip(hipLaunchKernel(sfn, dim3(sgrid), dim3(kWinThreads), argv, slds, stream));
             }
             static const int rowatom_on = [] { const char *e = getenv("TF_MSDA_BWD_ROWATOM"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -2200,6 +2208,7 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
                                          value, vbytes, loc, attn, grad_out, grad_value, grad_loc,
                                          grad_attn, lt, shapes_dev, S, M, D, L, Lq, total_pairs,
                                          pl.ppb, pl.DV);
+            note_kernel(rowatom ? "msda_bwd_f32_buf<rowatom>" : "msda_bwd_f32_buf");
             return record_hip(be);
         }
     }
@@ -2213,10 +2222,15 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
     const hipError_t e = launch(fn, pl.grid, pl.lds, stream, value, loc, attn, grad_out, grad_value,
                                 grad_loc, grad_attn, lt, shapes_dev, S, M, D, L, Lq, P, total_pairs,
                                 pl.ppb, pl.DV);
+    note_kernel(sizeof(T) == 4 ? "msda_bwd_rowgather<f32>" : "msda_bwd_rowgather<f64>");
     return record_hip(e);
 }
 
 }  // namespace
+
+namespace tfm {
+void note_kernel(const char *name) { g_last_kernel = name; }
+}  // namespace tfm
 
 // ---------------------------------------------------------------------------------------------
 // C ABI (include/tf_msda.h)
@@ -2224,6 +2238,8 @@ int backward_impl(const T *value, const int64_t *shapes_host, const int64_t *sha
 extern "C" {
 
 int tf_msda_abi_version(void) { return TF_MSDA_ABI_VERSION; }
+
+const char *tf_msda_last_kernel(void) { return g_last_kernel; }
 
 const char *tf_msda_strerror(int status)
 {

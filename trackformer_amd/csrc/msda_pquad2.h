@@ -121,12 +121,14 @@ __device__ __forceinline__ void quad_taps_global_rows(const __amdgpu_buffer_rsrc
 }
 
 // WAVES x NP: 4 waves x 2 passes of 64 pairs (three workgroups per CU, <= 168 registers), or 8 waves x 1 pass of 128 pairs (two
-// workgroups per CU with twice the LDS each, <= 128 registers: 16 instead of 12 waves per CU, half the work per wave and tile)
+// workgroups per CU with twice the LDS each, <= 128 registers: 16 instead of 12 waves per CU, half the work per wave and tile),
+// or 4 waves x 1 pass: tiles of 64 pairs, four workgroups per CU (<= 128 registers, 39 KB of LDS each) -- more tiles in flight per
+// CU against a per-tile chain of latencies that does not shrink with the tile
 template <bool FUSED, int WAVES, int NP>
-__global__ void __launch_bounds__(64 * WAVES, (WAVES == 8 ? 4 : 3))
+__global__ void __launch_bounds__(64 * WAVES, ((WAVES == 8 || NP == 1) ? 4 : 3))
 msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 {
-    static_assert((WAVES == 4 && NP == 2) || (WAVES == 8 && NP == 1), "128 (query, head) pairs per tile");
+    static_assert((WAVES == 4 && NP == 2) || (WAVES == 8 && NP == 1) || (WAVES == 4 && NP == 1), "64 or 128 (query, head) pairs per tile");
     constexpr int PT = 4, D = 32, NL = 4, PAIRS = 16 * WAVES;
     constexpr unsigned ROWB = D * 4;
     extern __shared__ __attribute__((aligned(128))) unsigned char smem[];
@@ -148,6 +150,14 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)((item / pg.cus) * pg.skew);
         while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(8);
     }
+    if (pg.prio != 0) {
+        // static priorities by the workgroup's slot on its CU: workgroups that share a CU otherwise move through their phases
+        // in lock-step (fair arbitration keeps them aligned), front ends and gathers never overlap
+        const int slot = item / pg.cus;
+        const int pr = pg.prio == 1 ? 2 - slot : slot;
+        if (pr >= 2) __builtin_amdgcn_s_setprio(3);
+        else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int sub = threadIdx.x & 3;            // the level this lane owns
@@ -166,6 +176,11 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
     auto decode_item = [&](int it, int &b, int &ty, int &tx, int &m) {
         m = it % M;
         int t = it / M;
+        // which head: for every tile t the map i % M -> m stays a bijection.  0: workgroup b (XCD b % 8) always works on head
+        // b % 8 -- the heads whose windows are larger (the diagonal directions of the default bias grid) then own whole XCDs
+        const int per = pg.cus >= 8 ? pg.cus >> 3 : 1;   // tiles per round of `cus` items
+        if (pg.headmix == 1) m = (m + t + t / per) % M;
+        else if (pg.headmix == 2) m ^= (t / per) & 1;
         tx = t % pg.tiles_x;
         t /= pg.tiles_x;
         ty = t % pg.tiles_y;

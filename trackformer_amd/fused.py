@@ -3,6 +3,7 @@
 Used by the inference path only (eval mode, gradients disabled) on GPU tensors; everywhere else the
 callers keep the plain PyTorch formulation (these helpers return None when they do not apply)."""
 import os
+import threading
 
 import torch
 import torch.nn.functional as F
@@ -122,10 +123,17 @@ def _parse_terms(v):
 
 
 _split_terms = _parse_terms(os.environ.get("TF_SPLIT_TERMS", "16"))
+_tls = threading.local()   # .terms: a routed layer's six-term product, for the CALLING thread only (see _ranged)
 
 
 def split_terms():
     return _split_terms
+
+
+def _terms():
+    """The split product of the call being made: the calling thread's override (a layer routed to six terms) or the process-wide
+    setting.  Every kernel call and every weight-image cache of this module reads it through here."""
+    return getattr(_tls, "terms", None) or _split_terms
 
 
 def set_split_terms(n):
@@ -158,7 +166,7 @@ def _use_packed(M, K, N):
         return False
     tail = N % 256
     full = N <= 128 or tail == 0 or tail > 128
-    if _split_terms == 6:
+    if _terms() == 6:
         return full and K >= 256
     # two stored weight pieces (fp16 pieces; measured: profiles/r04_f16_harness.txt: 22 223 x 256 -> 256 18.4 vs 18.7 us, 16 700 x 512 -> 128 16.1 vs 21.6, 66 800 x 64 -> 256
     # 20.8 vs 19.3, 16 700 x 128 -> 512 17.3 vs 17.4)
@@ -187,7 +195,7 @@ def _packed_weight(weight, rows):
     if cache is None or cache[0] != weight._version:
         cache = (weight._version, {})
         weight._tf_packed = cache
-    terms = _split_terms
+    terms = _terms()
     hit = cache[1].get((rows, terms))
     if hit is None:
         if torch.cuda.is_current_stream_capturing():
@@ -220,7 +228,7 @@ def _split_weight(weight):
     then serves another tensor's pieces (seen as a golden failure when two test models were built one after the
     other).  Callers pass persistent tensors (module parameters, _CatProjection's concatenation), and use `rows=` of
     linear() for a row block instead of a temporary slice."""
-    if _split_terms == 16:
+    if _terms() == 16:
         hit = getattr(weight, "_tf_split_f16", None)
         if hit is None or hit[0] != weight._version:
             w = weight.detach()
@@ -296,7 +304,7 @@ def linear(x, weight, bias=None, relu=False, rows=None, residual=None):
                 y = torch.empty((x2.shape[0], N), dtype=torch.float32, device=x.device)
                 rc = _cabi.lib().tf_linear_packed_f32(x2.data_ptr(), packed.data_ptr(),
                                                       0 if bias is None else bias.data_ptr(), _ptr(residual), y.data_ptr(),
-                                                      x2.shape[0], K, N, 1 if relu else 0, _split_terms, _stream(x.device))
+                                                      x2.shape[0], K, N, 1 if relu else 0, _terms(), _stream(x.device))
             _cabi.check(rc, "tf_linear_packed_f32")
             return y.view(*x.shape[:-1], N)
     pieces = _split_weight(weight)
@@ -380,7 +388,7 @@ def ffn(x, linear1, linear2, norm=None, residual=None):
         rc = _cabi.lib().tf_ffn_fused_f32(x2.data_ptr(), p1.data_ptr(), ptr(linear1.bias), p2.data_ptr(), ptr(linear2.bias),
                                           ptr(residual), 0 if norm is None else norm.weight.data_ptr(),
                                           0 if norm is None else norm.bias.data_ptr(), 0.0 if norm is None else float(norm.eps),
-                                          y.data_ptr(), M, D, F_, _split_terms, _stream(x.device))
+                                          y.data_ptr(), M, D, F_, _terms(), _stream(x.device))
     _cabi.check(rc, "tf_ffn_fused_f32")
     return y.view(x.shape)
 
@@ -437,7 +445,7 @@ def linear_residual_norm(x, linear, residual, norm):
         y = torch.empty((M, D), dtype=torch.float32, device=x.device)
         rc = _cabi.lib().tf_linear_res_ln_f32(x2.data_ptr(), packed.data_ptr(), 0 if linear.bias is None else linear.bias.data_ptr(),
                                               residual.data_ptr(), norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps),
-                                              y.data_ptr(), M, D, D, _split_terms, _stream(x.device))
+                                              y.data_ptr(), M, D, D, _terms(), _stream(x.device))
     _cabi.check(rc, "tf_linear_res_ln_f32")
     return y.view(x.shape)
 
@@ -476,7 +484,7 @@ def set_stem_conv_split(on):
 def _stem_packed(weight):
     """Packed [64, 176] image (k = (c * 7 + ky) * 8 + kx, zero padded) of a [64, 3, 7, 7] weight, cached on the tensor."""
     hit = getattr(weight, "_tf_stem_packed", None)
-    terms = _split_terms
+    terms = _terms()
     if hit is None or hit[0] != (weight._version, terms):
         if torch.cuda.is_current_stream_capturing():
             return None
@@ -514,7 +522,7 @@ def stem_conv(x, weight, bias=None, relu=False):
     with torch.cuda.device(x.device):
         y = torch.empty((n, 64, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         rc = _cabi.lib().tf_stem_conv7x7_f32(x.data_ptr(), packed.data_ptr(), 0 if bias is None else bias.data_ptr(), y.data_ptr(),
-                                             n, h, w, 1 if relu else 0, _split_terms, _stream(x.device))
+                                             n, h, w, 1 if relu else 0, _terms(), _stream(x.device))
     _cabi.check(rc, "tf_stem_conv7x7_f32")
     return y
 
@@ -643,7 +651,7 @@ def conv3x3(x, w_taps, bias, relu, stride):
                 y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
                 ws = torch.empty((ksplit, n * ho * wo * cout), dtype=torch.float32, device=x.device) if ksplit > 1 else None
                 rc = _cabi.lib().tf_conv_packed_f32(x.data_ptr(), packed.data_ptr(), _ptr(bias), 0, y.data_ptr(), _ptr(ws), ksplit,
-                                                    n, h, w, cin, cout, ks, stride, 1 if relu else 0, _split_terms, _stream(x.device))
+                                                    n, h, w, cin, cout, ks, stride, 1 if relu else 0, _terms(), _stream(x.device))
             _cabi.check(rc, "tf_conv_packed_f32")
             return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
     # the block kernels address input, output and weight pieces through buffer resources: every byte offset below 3 GiB
@@ -685,7 +693,7 @@ def _conv_stream_wins(m, cout):
     wins, and it stays."""
     # fp16 pieces: every shape (per frame 1321 us with the stream form everywhere against 1362 with the block kernels,
     # profiles/r04_f16_conv_per_layer.txt)
-    return _CONV_STREAM_ALL or _split_terms == 16 or (cout >= 128 and m >= 8192)
+    return _CONV_STREAM_ALL or _terms() == 16 or (cout >= 128 and m >= 8192)
 
 
 def set_conv_stream(on):
@@ -793,7 +801,9 @@ def input_proj_1x1(x, conv, gn):
         cout, cin = conv.out_channels, conv.in_channels
         hit = getattr(conv, "_tf_wtaps", None)   # persistent [Cout, 9 * Cin] tap-major image: the split pieces are cached on it
         if hit is None or hit[0] != conv.weight._version or hit[1].device != conv.weight.device:
+            prev_img = None if hit is None else hit[1]
             hit = (conv.weight._version, conv.weight.detach().permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous())
+            inherit_route(hit[1], conv.weight, prev_img)
             conv._tf_wtaps = hit
         y = conv3x3(x, hit[1], conv.bias, False, 2)
         if y is None:
@@ -809,7 +819,9 @@ def input_proj_1x1(x, conv, gn):
     cout = conv.out_channels
     hit = getattr(conv, "_tf_w2d", None)   # persistent [Cout, Cin] view: the split pieces are cached on it
     if hit is None or hit[0] != conv.weight._version or hit[1].device != conv.weight.device:
+        prev_img = None if hit is None else hit[1]
         hit = (conv.weight._version, conv.weight.detach().reshape(cout, cin).contiguous())
+        inherit_route(hit[1], conv.weight, prev_img)
         if hit[1].is_cuda and hit[1].data_ptr() != conv.weight.data_ptr():   # a copy made on this stream: publish for the others
             _publish_barrier(hit[1].device)
         conv._tf_w2d = hit
@@ -916,41 +928,82 @@ import functools
 
 F16_ACTIVATION_LIMIT = 65504.0 * 16.0
 _check_finite = os.environ.get("TF_SPLIT_CHECK_FINITE", "0") not in ("", "0")
-_six_term_weights = set()     # data_ptr() of weights whose layer runs the six-term product while the default is the fp16 one
-_range_audit = None           # {(operation, weight pointers): largest |activation|} while audit_activation_range() runs
+_n_six_term_routes = 0        # weights marked `_tf_six_terms` (their layers run the six-term product while the default is the fp16 one)
+_range_audit = None           # {(operation, ids of the weights): [weights, shapes, largest |activation|]} while audit_activation_range() runs
+_route_epoch = 0              # bumped whenever a route / the check / an audit changes what a forward enqueues: GraphedDetector
+                              # drops the HIP graphs it captured under another epoch (kernels are baked into a graph)
+
+# HIP graphs (graphed.GraphedDetector, the default path of bench.py and dist_utils.track_sequences): a replay calls none of the
+# wrappers below, so (1) an audit or the finite check sees nothing inside a graph -- GraphedDetector therefore runs EAGERLY while
+# either is active (debug_checks_active()), and a capture attempted with one of them on raises instead of synchronising inside
+# the capture; (2) a route added after a graph was captured would not reach it -- route_epoch() is part of what a graph was
+# captured under, a change drops the graphs and they are captured again with the routed kernels.  Run the audit BEFORE timing.
+
+
+def route_epoch():
+    return _route_epoch
+
+
+def debug_checks_active():
+    """An activation-range audit is running or the finite check is on: forwards must run eagerly (not from a captured graph)."""
+    return _check_finite or _range_audit is not None
 
 
 def set_check_finite(on):
-    global _check_finite
+    global _check_finite, _route_epoch
     prev, _check_finite = _check_finite, bool(on)
+    if prev != _check_finite:
+        _route_epoch += 1
     return prev
 
 
+def _routed(weight):
+    return getattr(weight, "_tf_six_terms", False)
+
+
 def route_six_terms(weight, on=True):
-    """Route every split product of this weight tensor through the six-term bf16 product (while the default is the fp16 one)."""
-    (_six_term_weights.add if on else _six_term_weights.discard)(weight.data_ptr())
+    """Route every split product of this weight tensor through the six-term bf16 product (while the default is the fp16 one).
+    The mark lives ON THE TENSOR OBJECT (like the cached pieces: an address can be freed and handed to another weight) and is
+    inherited by the images derived from it (inherit_route: a convolution's tap-major / 2-d image, re-created when the weight
+    changes)."""
+    global _n_six_term_routes, _route_epoch
+    if bool(_routed(weight)) != bool(on):
+        weight._tf_six_terms = bool(on)
+        _n_six_term_routes += 1 if on else -1
+        _route_epoch += 1
+
+
+def inherit_route(new, *sources):
+    """`new` is an image derived from `sources` (the parameter, the image it replaces): it runs six terms if one of them does."""
+    if any(src is not None and _routed(src) for src in sources) and not _routed(new):
+        route_six_terms(new)
+    return new
 
 
 def six_term_routes():
-    return len(_six_term_weights)
+    return _n_six_term_routes
 
 
 @contextlib.contextmanager
 def audit_activation_range(route=True, safety=4.0):
     """-> report dict, filled on exit: {"limit", "largest", "layers": [(operation, weight shape, largest |activation|)...],
-    "routed": n}.  Layers whose activations came within `safety` of the fp16 product's limit are routed to six terms."""
-    global _range_audit
+    "routed": n}.  Layers whose activations came within `safety` of the fp16 product's limit are routed to six terms.
+    Forwards under the audit run eagerly (GraphedDetector steps aside); graphs captured before it are dropped if it routes."""
+    global _range_audit, _route_epoch
     report = {"limit": F16_ACTIVATION_LIMIT, "safety": safety, "largest": 0.0, "layers": [], "routed": 0}
     prev, _range_audit = _range_audit, {}
+    _route_epoch += 1
     try:
         yield report
     finally:
         seen, _range_audit = _range_audit, prev
-        for (name, ptrs, shapes), amax in sorted(seen.items(), key=lambda kv: -kv[1]):
+        _route_epoch += 1
+        for (name, _ids), (ws, shapes, amax) in sorted(seen.items(), key=lambda kv: -kv[1][2]):
             report["layers"].append((name, shapes, amax))
             report["largest"] = max(report["largest"], amax)
             if route and not (amax * safety < F16_ACTIVATION_LIMIT):   # also catches NaN / inf
-                _six_term_weights.update(ptrs)
+                for w in ws:
+                    route_six_terms(w)
                 report["routed"] += 1
 
 
@@ -962,24 +1015,28 @@ def _ranged(name, weights_of, acts_of):
     def deco(fn):
         @functools.wraps(fn)
         def wrapped(*a, **k):
-            global _split_terms
-            if _split_terms != 16 or not (_six_term_weights or _check_finite or _range_audit is not None):
+            if _split_terms != 16 or not (_n_six_term_routes or _check_finite or _range_audit is not None):
                 return fn(*a, **k)
             ws = [w for w in weights_of(*a, **k) if w is not None]
-            ptrs = tuple(w.data_ptr() for w in ws)
-            route6 = any(p in _six_term_weights for p in ptrs)
+            checks = _check_finite or _range_audit is not None
+            if checks and ws and ws[0].is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("fused.%s: an activation-range audit / the finite check (set_check_finite, TF_SPLIT_CHECK_FINITE) "
+                                   "reads results on the host and cannot run while a HIP graph is being captured -- run the model "
+                                   "eagerly under them (GraphedDetector does so by itself), then capture" % name)
+            route6 = any(_routed(w) for w in ws)
             if route6:
-                _split_terms = 6
+                _tls.terms = 6     # this thread's calls only: another tracker thread of the same model keeps its own arithmetic
             try:
                 y = fn(*a, **k)
             finally:
                 if route6:
-                    _split_terms = 16
+                    _tls.terms = None
             if y is None:
                 return y
             if _range_audit is not None:
-                key = (name, ptrs, tuple(tuple(w.shape) for w in ws))
-                _range_audit[key] = max(_range_audit.get(key, 0.0), max(_amax(t) for t in acts_of(*a, **k)))
+                key = (name, tuple(id(w) for w in ws))
+                rec = _range_audit.setdefault(key, [ws, tuple(tuple(w.shape) for w in ws), 0.0])   # (holds the weights: ids stay unique)
+                rec[2] = max(rec[2], max(_amax(t) for t in acts_of(*a, **k)))
             if _check_finite and not bool(torch.isfinite(y).all()):
                 raise FloatingPointError(
                     "%s produced a non-finite result (largest |input| %.3g; the fp16 split product represents activations up to "

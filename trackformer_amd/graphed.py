@@ -18,8 +18,14 @@ buffers are what the call returns as `features` -- so the tracker hands them bac
 and no copy is needed then (a caller that passes anything else gets a copy-in before the replay).
 
 Aliasing contract: `out['pred_logits' | 'pred_boxes' | 'hs_embed']` are cloned (the tracker keeps them
-across frames); `features` (see above), `memory`, `hs` and `out['aux_outputs']` alias static buffers of
-the entry and are valid until the next call with the same key.
+across frames); `features` (see above), `memory`, `hs` and `out['aux_outputs']` alias static buffers and are valid
+until the next call with the same key -- or, for the two-graph models, until the SECOND following prepare() (the image-only
+half writes `features` / `memory` into one of two alternating slots, whatever the key).
+
+Debug modes and routes of the split product (fused.audit_activation_range, fused.set_check_finite, fused.route_six_terms):
+graph replays call none of fused's Python wrappers, so while an audit or the finite check is active the wrapper runs the
+model EAGERLY, and graphs captured under another fused.route_epoch() are dropped (the routed kernels are baked into a graph
+at capture time: a route added later forces a new capture).
 
 Bucketed track-query count: in real tracking the number of track queries changes from frame to frame, and every
 count would be its own graph.  The wrapper therefore rounds the count up to a multiple of `bucket` (16) with FILLER
@@ -64,17 +70,33 @@ class GraphedDetector:
         self._graphs = OrderedDict()
         self._seen = {}
         self._enc = {}            # (image shape, device) -> [slot 0, slot 1]: the image-only half as its own graph, two sets of buffers
-        self._prepared = None     # (static image tensor, slot index) of the last prepare()
+        self._prepared = None     # (static image tensor, slot index, generation) of the last prepare()
         self._slot = 0            # the slot the last forward read: prepare() fills the other one
         self._side = {}           # device -> the stream prepare() runs the image-only half on
+        self._generation = 0      # prepare() calls so far: a static image is only "prepared" for the call that follows ITS prepare()
+        self._epoch = None        # fused.route_epoch() the graphs were captured under
 
     def __getattr__(self, name):  # only called for attributes GraphedDetector itself lacks
         return getattr(self.model, name)
 
     # ------------------------------------------------------------------
+    def _sync_epoch(self):
+        """Graphs bake the kernels of the fused routes they were captured under: drop them when the routes changed."""
+        from . import fused
+        epoch = fused.route_epoch()
+        if epoch != self._epoch:
+            if self._graphs or self._enc:
+                torch.cuda.synchronize()
+                self._graphs.clear()
+                self._enc.clear()
+                self._seen.clear()
+                self._prepared = None
+            self._epoch = epoch
+
     def _capturable(self, img, target, prev_features):
+        from . import fused
         m = self.model
-        if torch.is_grad_enabled() or m.training or not getattr(m, "_tracking", True):
+        if torch.is_grad_enabled() or m.training or not getattr(m, "_tracking", True) or fused.debug_checks_active():
             return False
         if not torch.is_tensor(img) or not img.is_cuda or img.dim() != 4 or img.shape[0] != 1:
             return False
@@ -137,8 +159,11 @@ class GraphedDetector:
         image-only half behind the previous frame's decoder half).
         None: nothing was enqueued (not a model / input this applies to, or the graph of this image shape does not exist
         yet -- it is captured by the ordinary calls)."""
+        from . import fused
         m = self.model
-        if not self._splittable() or torch.is_grad_enabled() or m.training or not getattr(m, "_tracking", True):
+        self._sync_epoch()
+        if (not self._splittable() or torch.is_grad_enabled() or m.training or not getattr(m, "_tracking", True)
+                or fused.debug_checks_active()):
             return None
         if not torch.is_tensor(img) or img.dim() != 4 or img.shape[0] != 1:
             return None
@@ -166,8 +191,14 @@ class GraphedDetector:
         if img.is_cuda:
             img.record_stream(side)
         a["ran"] = True
-        self._prepared = (a["img"], i)
-        return a["img"]
+        self._generation += 1
+        a["generation"] = self._generation   # the slot holds THIS preparation until the next one into it
+        # a fresh alias per preparation: two prepare() calls in a row fill the same slot, and only the tensor the LAST one
+        # returned stands for "the image-only half of what this tensor holds has run" (the earlier alias now holds the later image
+        # and is treated as any device image: encoded again from its contents)
+        alias = a["img"].view(a["img"].shape)
+        self._prepared = (alias, i, self._generation)
+        return alias
 
     def _capture(self, img, target, prev_features, slot=0):
         if self._splittable():
@@ -252,6 +283,18 @@ class GraphedDetector:
         entry["graph"] = graph
         return entry
 
+    def _evict_encoders(self, keep=4):
+        """The image-only graphs (two slots per image shape, each with its own pool of backbone + encoder activations) live as
+        long as a decoder graph references them; beyond that only the `keep` most recently captured shapes stay -- a data set with
+        many resolutions must not grow device memory without bound."""
+        used = {id(e["enc"]) for e in self._graphs.values() if "enc" in e}
+        idle = [k for k, slots in self._enc.items() if not any(a is not None and id(a) in used for a in slots)]
+        for k in idle[:max(0, len(idle) - keep)]:
+            if self._prepared is not None and (tuple(self._prepared[0].shape), self._prepared[0].device) == k:
+                continue
+            torch.cuda.synchronize(k[1])
+            del self._enc[k]
+
     def _feed_prev(self, entry, prev_features):
         """Copy-in of the previous frame's features unless they ARE the entry's static buffers."""
         for d, s in zip(entry["prev"], prev_features):
@@ -292,9 +335,38 @@ class GraphedDetector:
             out['aux_outputs'] = [{k: cut(v, 1) for k, v in a.items()} for a in out['aux_outputs']]
         return out, cut(hs, 2)
 
+    def _wait_static_image(self, img):
+        """`img` may be a static image prepare() handed out (now or earlier): the side stream wrote it -- the current stream
+        must not read it before that run is done."""
+        if not (torch.is_tensor(img) and img.is_cuda):
+            return
+        for a in self._enc.get((tuple(img.shape), img.device)) or ():
+            if a is not None and a["ran"] and a["img"].data_ptr() == img.data_ptr():
+                torch.cuda.current_stream(img.device).wait_event(a["done"])
+
+    def _mark_read(self, img, slot):
+        """An eager forward on the current stream read slot `slot`'s static image: prepare() must not overwrite it before."""
+        a = self._enc[(tuple(img.shape), img.device)][slot]
+        a["free"].record(torch.cuda.current_stream(img.device))
+        a["read"] = True
+        self._slot = slot
+
     def __call__(self, img, target=None, prev_features=None):
+        self._sync_epoch()
+        prepared, self._prepared = self._prepared, None
+        # prepared for THIS call: the very tensor of the LAST prepare(), and nothing has been prepared into that slot since (two
+        # prepare() calls in a row fill the same slot and return the same tensor: only the second image's state is in it)
+        if prepared is not None:
+            slots = self._enc.get((tuple(prepared[0].shape), prepared[0].device))
+            if (prepared[0] is not img or slots is None or slots[prepared[1]] is None
+                    or slots[prepared[1]].get("generation") != prepared[2]):
+                prepared = None
         if not self._capturable(img, target, prev_features):
-            return self.model(img, target, prev_features)
+            self._wait_static_image(img)   # (also consumes the preparation: the eager forward encodes the image itself)
+            res = self.model(img, target, prev_features)
+            if prepared is not None:
+                self._mark_read(img, prepared[1])
+            return res
         multi = self._multi_frame()
         n_real = n_pad = 0
         caller_target = target
@@ -302,36 +374,26 @@ class GraphedDetector:
             target, n_real, n_pad = self._bucketed(target)
         n_track = n_pad
         lazy = getattr(self.model, "lazy_masks_active", None)
-        prepared, self._prepared = self._prepared, None
-        slot = prepared[1] if prepared is not None and prepared[0] is img else 0   # the buffers prepare() filled for this very tensor
-        if prepared is not None and prepared[0] is not img:
-            prepared = None
-        if prepared is not None:   # `img` IS the slot's static image: the side stream fills it (and the encoder results)
-            torch.cuda.current_stream(img.device).wait_event(self._enc[(tuple(img.shape), img.device)][slot]["done"])
-        else:
-            # a static image prepare() handed out earlier, used after its preparation was forgotten: the side stream wrote it
-            for a in self._enc.get((tuple(img.shape), img.device)) or ():
-                if a is not None and a["img"] is img and a["ran"]:
-                    torch.cuda.current_stream(img.device).wait_event(a["done"])
+        slot = prepared[1] if prepared is not None else 0   # the buffers prepare() filled for this very tensor
+        self._wait_static_image(img)   # the slot's run, or a static image used after its preparation was forgotten
         key = (tuple(img.shape), n_track, img.device, bool(multi and prev_features is not None),
                bool(lazy()) if lazy is not None else False,   # a graph with and one without the mask head are different graphs
                slot)                                          # the decoder half reads ONE slot's static buffers
         entry = self._graphs.get(key)
         if entry is None:
             # capture a shape the second time it shows up (one-off shapes are not worth a graph)
-            self._seen[key] = self._seen.get(key, 0) + 1
-            if self._seen[key] < 2:
+            seen_key = key[:-1]   # without the slot: a bucket seen on one slot is captured at its first sight on the other
+            self._seen[seen_key] = self._seen.get(seen_key, 0) + 1
+            if self._seen[seen_key] < 2:
                 res = self.model(img, caller_target, prev_features)
                 if prepared is not None:   # the eager forward read the slot's static image: prepare() must not overwrite it yet
-                    a = self._enc[(tuple(img.shape), img.device)][slot]
-                    a["free"].record(torch.cuda.current_stream(img.device))
-                    a["read"] = True
-                    self._slot = slot
+                    self._mark_read(img, slot)
                 return res
             entry = self._capture(img, target, prev_features, slot)
             self._graphs[key] = entry
             while len(self._graphs) > self.max_graphs:
                 self._graphs.popitem(last=False)   # least recently used
+            self._evict_encoders()
         else:
             self._graphs.move_to_end(key)
         if target is not None:

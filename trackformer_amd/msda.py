@@ -118,6 +118,12 @@ def _shape_args(spatial_shapes, value):
     return "_dshapes", ctypes.c_void_p(ss.data_ptr()), ss
 
 
+def last_kernel():
+    """Name of the device kernel this thread's most recent operator call enqueued (tf_msda_last_kernel, include/tf_msda.h):
+    what the library dispatched, not what the options suggest -- bench.py labels its roofline with it."""
+    return _cabi.lib().tf_msda_last_kernel().decode()
+
+
 def ms_deform_attn_forward(value, spatial_shapes, sampling_loc, attn_weight, im2col_step=64):
     """value[N,S,M,D], spatial_shapes[L,2] i64, sampling_loc[N,Lq,M,L,P,2], attn_weight[N,Lq,M,L,P]
     -> output[N,Lq,M*D].   Same contract as the reference's MSDA.ms_deform_attn_forward
