@@ -151,7 +151,11 @@ PQUAD_VARIANTS = [dict(), dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npa
                   dict(pquad_v2=0), dict(pquad_v2=0, pquad_lds_kb=24), dict(pquad_wg_per_cu=1), dict(pquad_halo_y=2, pquad_halo_x=2),
                   dict(pquad_lds_kb=12),
                   # eight-wave workgroups of version 2: one pass of 128 pairs, two workgroups per CU
-                  dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78), dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=1, pquad_lds_kb=30)]
+                  dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78), dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=1, pquad_lds_kb=30),
+                  # round 6: the conflict-free gather (lanes of a quad split by tap column), small windows (the buffer-load path of the
+                  # same lane mapping), eight waves; the other output-store policies and the rotated head map
+                  dict(pquad_cf=1), dict(pquad_cf=1, pquad_lds_kb=12), dict(pquad_cf=1, pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78),
+                  dict(pquad_store=0, pquad_headmix=1, pquad_ldnt=1), dict(pquad_store=2, pquad_headmix=2, pquad_prio=2)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items()) or "default"
@@ -772,30 +776,37 @@ def test_linear_with_add_prologue_is_bit_identical(M, K, N, terms):
 
 def test_lds_bank_conflict_model_on_the_encoder_kernel():
     """HIPEMU_LDS_TRACK=1: the emulator's ds_read_b128 bank model (four fixed 16-lane groups, 64 banks, broadcast) counts the
-    LDS cycles of the LDS-window kernel's gathers.  Hardware counters of round 2 put 34 % of that kernel's LDS cycles down
-    to bank conflicts (profiles/r02_msda_fwd_pquad_pmc.json); the model gives 6.0 cycles per gather = 33 %
-    (tools/lds_conflict_study.py).  Here: a small pyramid in a fresh process, the ratio must lie between conflict-free
-    (4) and the two-way level (8), and the result must not depend on the accounting."""
+    LDS cycles of the LDS-window kernel's gathers.  Rounds 2-5: hardware counters put 34-35 % of the encoder kernel's LDS cycles
+    down to bank conflicts (profiles/r02_msda_fwd_pquad_pmc.json, r05_msda_fwd_pquad2_pmc.json) and the model agreed (6.0 cycles
+    per gather, tools/lds_conflict_study.py).  Round 6: msda_fwd_f32_pquad2's gather splits a quad's lanes by tap COLUMN
+    (x0 / x0 + 1: neighbouring LDS rows, opposite parities whatever the data) and rotates the piece order over the quads of an
+    LDS cycle -- every gather instruction is conflict-free BY CONSTRUCTION: exactly 4 cycles, on any sampling pattern (option
+    pquad_cf; on MI355X SQ_LDS_BANK_CONFLICT went 3.59 M -> 0 per launch and the launch time did not improve, so it is not the
+    default: profiles/r06_msda_pquad2_conflict_free.txt).  The result must not depend on the accounting."""
     import os
     import subprocess
     import sys
     code = (
+        "import os\n"
         "import numpy as np\n"
         "from tests import emu_lib\n"
         "from tests.test_emu_kernels import _fused_case, PYR\n"
+        "emu_lib.set_options(pquad_cf=int(os.environ['CF']))\n"
         "value, refp, qproj, _, _ = _fused_case(PYR, 1, 32, seed=3, spread=0.8)\n"
         "out = emu_lib.msda_forward_fused(value, np.array(PYR, np.int64), refp, qproj, 8, len(PYR), 4)\n"
         "st = emu_lib.stats()\n"
         "print('RESULT', st['lds_b128_reads'], st['lds_b128_cycles'], float(np.abs(out).sum()))\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for track in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_LDS_TRACK=track), capture_output=True, text=True, cwd=root)
+    for track, cf in (("1", "1"), ("0", "1"), ("1", "0")):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HIPEMU_LDS_TRACK=track, CF=cf), capture_output=True, text=True, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
-        res[track] = [float(v) for v in r.stdout.split("RESULT")[1].split()]
-    reads, cycles, checksum = res["1"]
-    assert reads > 1000 and 4.0 <= cycles / reads <= 8.0, (reads, cycles)
-    assert res["0"][0] == 0 and res["0"][2] == checksum
+        res[track, cf] = [float(v) for v in r.stdout.split("RESULT")[1].split()]
+    reads, cycles, checksum = res["1", "1"]
+    assert reads > 1000 and cycles == 4.0 * reads, (reads, cycles)           # option pquad_cf: conflict-free by construction
+    assert res["0", "1"][0] == 0 and res["0", "1"][2] == checksum
+    reads, cycles, _ = res["1", "0"]                                          # the default gather: between conflict-free and two-way
+    assert reads > 1000 and 4.0 < cycles / reads <= 8.0, (reads, cycles)
 
 
 @pytest.mark.parametrize("n,h,w", [(1, 37, 70), (2, 16, 19), (1, 8, 300), (1, 5, 5), (1, 1, 1)], ids=lambda v: str(v))

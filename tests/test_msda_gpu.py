@@ -465,7 +465,11 @@ PQUAD_VARIANTS = [dict(pquad_npass=1, pquad_wg_per_cu=4), dict(pquad_npass=3, pq
                   dict(pquad_v2=0), dict(pquad_v2=0, pquad_lds_kb=24), dict(pquad_wg_per_cu=1), dict(pquad_halo_y=2, pquad_halo_x=2),
                   dict(pquad_lds_kb=12), dict(pquad_skew=150, pquad_wg_per_cu=2),
                   # eight-wave workgroups of version 2: one pass of 128 pairs, two workgroups per CU
-                  dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78), dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=1, pquad_lds_kb=30)]
+                  dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78), dict(pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=1, pquad_lds_kb=30),
+                  # round 6: the conflict-free gather (+ its buffer-load path under small windows, + eight waves), the output-store
+                  # policies (nt is the default), non-temporal point loads, the rotated head maps, static priorities
+                  dict(pquad_cf=1), dict(pquad_cf=1, pquad_lds_kb=12), dict(pquad_cf=1, pquad_waves=8, pquad_npass=1, pquad_wg_per_cu=2, pquad_lds_kb=78),
+                  dict(pquad_store=0, pquad_headmix=1, pquad_ldnt=1), dict(pquad_store=2, pquad_headmix=2, pquad_prio=2), dict(pquad_store=3, pquad_prio=1)]
 
 
 @pytest.mark.parametrize("opts", PQUAD_VARIANTS, ids=["-".join("%s%d" % (k[6:], v) for k, v in o.items())

@@ -5,7 +5,7 @@ addresses; MI355X_MICROARCH.md section LDS).  Runs the fused encoder entry on a 
 windows and lane mapping do not depend on the level sizes) with the perturbed-model offset pattern and prints LDS cycles
 per gather instruction: 4.0 = conflict-free.
 
-    HIPEMU_LDS_TRACK=1 python tools/lds_conflict_study.py [option=value ...]     e.g. pquad_swap=1
+    HIPEMU_LDS_TRACK=1 python tools/lds_conflict_study.py [option=value ...]     e.g. pquad_cf=1 (the conflict-free gather: 4.00)
 """
 import os
 import sys

@@ -136,8 +136,8 @@ static Config parse_config(const std::string &arg)
                                      {"hy", "pquad_halo_y"}, {"hx", "pquad_halo_x"}, {"th", "pquad_tile_h"},
                                      {"tw", "pquad_tile_w"}, {"wgs", "pquad_wg_per_cu"}, {"pf", "pquad_prefetch"},
                                      {"skew", "pquad_skew"}, {"v2", "pquad_v2"}, {"waves", "pquad_waves"},
-                                     {"hm", "pquad_headmix"}, {"prio", "pquad_prio"}};
-    const size_t nkeys = c.tiled == 3 ? 14 : 9;
+                                     {"hm", "pquad_headmix"}, {"prio", "pquad_prio"}, {"st", "pquad_store"}, {"ldnt", "pquad_ldnt"}, {"ti", "pquad_trace_iter"}, {"cf", "pquad_cf"}};
+    const size_t nkeys = c.tiled == 3 ? 18 : 9;
     const char *(*keys)[2] = c.tiled == 3 ? pkeys : qkeys;
     size_t pos = arg.find(':');
     while (pos != std::string::npos && pos + 1 < arg.size()) {
@@ -159,10 +159,10 @@ static void apply(const Config &c)
     static const int defaults[] = {0, 4, 3, 40, 6, 10, 0, 0, 1};   // = kQuadOptDefaults of the library
     static const char *pnames[] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
                                    "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew", "pquad_v2", "pquad_waves",
-                                   "pquad_headmix", "pquad_prio"};
-    static const int pdefaults[] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 4, 0, 0};   // = kPqOptDefaults of the library
+                                   "pquad_headmix", "pquad_prio", "pquad_store", "pquad_ldnt", "pquad_trace_iter", "pquad_cf"};
+    static const int pdefaults[] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 4, 0, 0, 1, 0, 0, 0};   // = kPqOptDefaults of the library
     for (int i = 0; i < 9; ++i) tf_msda_set_option(names[i], defaults[i]);
-    for (int i = 0; i < 14; ++i) tf_msda_set_option(pnames[i], pdefaults[i]);
+    for (int i = 0; i < 18; ++i) tf_msda_set_option(pnames[i], pdefaults[i]);
     for (auto &o : c.opts) tf_msda_set_option(o.first.c_str(), o.second);
     tf_msda_set_option("pquad", c.tiled == 3 ? 1 : 0);
     tf_msda_set_option("tiled", c.tiled == 3 ? 2 : c.tiled);

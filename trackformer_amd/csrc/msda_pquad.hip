@@ -87,6 +87,11 @@ struct PquadGeom {
     int cus;           // compute units of the device (workgroup b is the (b / cus)-th of its CU)
     int headmix;       // version 2: how item i maps to (tile, head) -- 0: head = i % M (workgroup b, XCD b % 8, always works on head
                        // b % 8); 1: rotated by the tile index; 2: the low bit of the head flips with every round of `cus` items
+    int store;         // version 2: cache policy of the output stores -- 0: plain (the lines stay dirty in L2 until the end of the
+                       // kernel writes them back), 1: nt, 2: sc1 (write-through), 3: sc0 sc1
+    int cf;            // version 2: the conflict-free gather (msda_pquad2.h quad_taps_lds_cf; 4 waves x 2 passes and 8 waves x 1 pass)
+    int ldnt;          // version 2: the point loads (read once) are non-temporal
+    int trace_iter;    // debug: which tile of a workgroup (0 or 1) the phase stamps 3..8, 11..13 belong to
     int prio;          // version 2: static wave priority by the workgroup's slot on its CU (0: none, 1: first-dispatched highest,
                        // 2: last-dispatched highest)
     unsigned long long *trace;   // debug: 16 timestamps (s_memrealtime, 100 MHz) per workgroup, or null
@@ -779,14 +784,14 @@ msda_fwd_f32_pquad(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 
 // ---- options, tile plan, launch ------------------------------------------------------------------------------
 enum PqOpt { kPoWide, kPoNpass, kPoLdsKb, kPoHaloY, kPoHaloX, kPoTileH, kPoTileW, kPoWgPerCu, kPoPrefetch, kPoSkew, kPoEnable, kPoV2, kPoWaves,
-             kPoHeadMix, kPoPrio, kPoCount };
+             kPoHeadMix, kPoPrio, kPoStore, kPoLdNt, kPoTraceIter, kPoCf, kPoCount };
 const char *const kPqOptNames[kPoCount] = {"pquad_wide", "pquad_npass", "pquad_lds_kb", "pquad_halo_y", "pquad_halo_x",
                                            "pquad_tile_h",  "pquad_tile_w", "pquad_wg_per_cu", "pquad_prefetch", "pquad_skew",
-                                           "pquad", "pquad_v2", "pquad_waves", "pquad_headmix", "pquad_prio"};
-const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on", "v2", "waves", "hm", "prio"};
+                                           "pquad", "pquad_v2", "pquad_waves", "pquad_headmix", "pquad_prio", "pquad_store", "pquad_ldnt", "pquad_trace_iter", "pquad_cf"};
+const char *const kPqEnvKeys[kPoCount] = {"wide", "npass", "lds", "hy", "hx", "th", "tw", "wgs", "pf", "skew", "on", "v2", "waves", "hm", "prio", "st", "ldnt", "ti", "cf"};
 // v2: msda_fwd_f32_pquad2 (msda_pquad2.h) where it applies (D == 32, two passes, 16-byte aligned inputs)
 // waves: 4, or 8 (version 2 only: one pass of 128 pairs, two workgroups per CU -- use with lds=78)
-constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 1, 4, 0, 0};   // 3 x 52 KB = 156 KB of the CU's 160
+constexpr int kPqOptDefaults[kPoCount] = {1, 2, 52, 6, 10, 0, 0, 3, 0, 0, 1, 1, 4, 0, 0, 1, 0, 0, 0};   // 3 x 52 KB = 156 KB of the CU's 160
 std::atomic<int> g_pq_opt[kPoCount];
 std::atomic<int> g_pq_epoch{0};
 std::atomic<unsigned long long *> g_pq_trace{nullptr};
@@ -951,6 +956,10 @@ bool pq_plan(const LevelTable &lt, int L, int M, int N, int D, PqPlan *out)
     r.geom.cus = pq_num_cus();
     r.geom.headmix = (o[kPoHeadMix] == 1 || (o[kPoHeadMix] == 2 && M % 2 == 0)) ? o[kPoHeadMix] : 0;
     r.geom.prio = (o[kPoPrio] == 1 || o[kPoPrio] == 2) ? o[kPoPrio] : 0;
+    r.geom.store = (o[kPoStore] >= 0 && o[kPoStore] <= 3) ? o[kPoStore] : 0;
+    r.geom.ldnt = o[kPoLdNt] != 0;
+    r.geom.cf = o[kPoCf] != 0 && !(waves == 4 && npass == 1);
+    r.geom.trace_iter = o[kPoTraceIter] == 1 ? 1 : 0;
     r.wide = o[kPoWide] != 0;
     r.v2 = o[kPoV2] != 0;
     r.waves = waves;
@@ -1016,7 +1025,10 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
         wide = wide && ((uintptr_t)da.loc % 16 == 0) && ((uintptr_t)da.attn % 16 == 0);
     const bool v2 = pl.v2 && D == 32 && wide && pl.ta_mask == 0 && ((pl.waves == 4 && pl.npass <= 2) || (pl.waves == 8 && pl.npass == 1));
     if (pl.waves == 8 && !v2) return false;   // (the plan was made for eight-wave workgroups: only version 2 has them)
-    const void *fn = v2 ? (pl.waves == 8 ? (fused ? (const void *)&msda_fwd_f32_pquad2<true, 8, 1> : (const void *)&msda_fwd_f32_pquad2<false, 8, 1>)
+    const bool cf = v2 && pl.geom.cf != 0;
+    const void *fn = cf ? (pl.waves == 8 ? (fused ? (const void *)&msda_fwd_f32_pquad2<true, 8, 1, true> : (const void *)&msda_fwd_f32_pquad2<false, 8, 1, true>)
+                                         : (fused ? (const void *)&msda_fwd_f32_pquad2<true, 4, 2, true> : (const void *)&msda_fwd_f32_pquad2<false, 4, 2, true>))
+                     : v2 ? (pl.waves == 8 ? (fused ? (const void *)&msda_fwd_f32_pquad2<true, 8, 1> : (const void *)&msda_fwd_f32_pquad2<false, 8, 1>)
                            : pl.npass == 1 ? (fused ? (const void *)&msda_fwd_f32_pquad2<true, 4, 1> : (const void *)&msda_fwd_f32_pquad2<false, 4, 1>)
                                            : (fused ? (const void *)&msda_fwd_f32_pquad2<true, 4, 2> : (const void *)&msda_fwd_f32_pquad2<false, 4, 2>))
                      : D == 36 ? (fused ? pq_kernel_d36<true>(wide) : pq_kernel_d36<false>(wide))
@@ -1045,7 +1057,9 @@ bool launch_pquad(bool fused, const DirectArgs &da, const LevelTable &lt, int N,
     pl.geom.trace = g_pq_trace.load(std::memory_order_relaxed);
     void *argv[] = {(void *)&da, (void *)&lt, (void *)&pl.geom};
     *err = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(64 * pl.waves), argv, pl.lds, stream);
-    note_kernel(v2 ? (pl.waves == 8 ? (fused ? "msda_fwd_f32_pquad2<fused,8w,1p>" : "msda_fwd_f32_pquad2<plain,8w,1p>")
+    note_kernel(cf ? (pl.waves == 8 ? (fused ? "msda_fwd_f32_pquad2<fused,8w,1p,cf>" : "msda_fwd_f32_pquad2<plain,8w,1p,cf>")
+                                    : (fused ? "msda_fwd_f32_pquad2<fused,4w,2p,cf>" : "msda_fwd_f32_pquad2<plain,4w,2p,cf>"))
+                : v2 ? (pl.waves == 8 ? (fused ? "msda_fwd_f32_pquad2<fused,8w,1p>" : "msda_fwd_f32_pquad2<plain,8w,1p>")
                       : pl.npass == 1 ? (fused ? "msda_fwd_f32_pquad2<fused,4w,1p>" : "msda_fwd_f32_pquad2<plain,4w,1p>")
                                       : (fused ? "msda_fwd_f32_pquad2<fused,4w,2p>" : "msda_fwd_f32_pquad2<plain,4w,2p>"))
                    : D == 36 ? (fused ? "msda_fwd_f32_pquad<fused,D=36>" : "msda_fwd_f32_pquad<plain,D=36>")

@@ -120,14 +120,89 @@ __device__ __forceinline__ void quad_taps_global_rows(const __amdgpu_buffer_rsrc
     }
 }
 
+__device__ __forceinline__ f32x4_t ldg_f4_nt(const float *base, unsigned byte_off)
+{
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4_t *>(reinterpret_cast<const char *>(base) + (size_t)byte_off));
+}
+
+// ---- the conflict-free gather (TF_P2_CF) ---------------------------------------------------------------------------------------
+// A ds_read_b128 is served in four LDS cycles of 16 lanes -- the quads {0, 3, 5, 6}, {1, 2, 4, 7} of each half wave
+// (MI355X_MICROARCH.md, LDS) -- and is conflict-free when those 16 lanes hit 16 different 16-byte slots (address / 16 mod 16).
+// A (pixel, head) row is 128 bytes = 8 slots; which 8 is decided by the parity of its LDS row, i.e. by the data: with a quad
+// reading a half row of ONE tap per instruction, two quads of a cycle collide whenever their rows have the same parity (1.75
+// cycles per cycle for random parities; measured share of conflict cycles 35 %).  But the two taps (y, x0) and (y, x0 + 1) of a
+// sampling point are ALWAYS neighbouring LDS rows: opposite parities.  So the lanes of a quad split by tap COLUMN instead of by
+// half row -- lane s of the quad reads column s & 1, half s >> 1, one 16-byte piece per instruction -- and a quad then covers
+// the slots {c, c + 4, c + 8, c + 12} whatever the parity, c the piece index of that instruction.  The four quads of an LDS cycle
+// take the pieces in four different orders (piece = instruction ^ g, g the quad's place in its cycle): every slot exactly once.
+// Price: a lane accumulates 16 channels (4 pieces of ONE column) instead of 8, the two columns are added across lanes (sub ^ 1)
+// once per tile, and the gather spends 8 instead of 4 address additions and a select per weight pair.
+// The weights of a point travel as (gy a, fy a, fx) -- three registers instead of four products: the lane forms the two it needs,
+// (gy a) c and (fy a) c with c = fx or 1 - fx by its column (the same two roundings as the products formed in the prologue).
+template <int K>
+__device__ __forceinline__ void quad_taps_lds_cf(unsigned a0, unsigned a1, const float (&w)[3], const unsigned (&C)[4], bool col,
+                                                 f32x4_t (&acc)[4])
+{
+    constexpr int Q = K * 0x55;   // quad_perm [K,K,K,K]
+    const float ga = dpp_f<Q>(w[0]), fa = dpp_f<Q>(w[1]), fx = dpp_f<Q>(w[2]);
+    const float cx = col ? fx : 1.f - fx;
+    const float W0 = ga * cx, W1 = fa * cx;   // rows y0 / y0 + 1 of this lane's column
+    f32x4_t v0[4], v1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v0[t] = lds_read16(dpp_u<Q>(a0) + C[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v1[t] = lds_read16(dpp_u<Q>(a1) + C[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] += v0[t] * W0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] += v1[t] * W1;
+}
+// ... and by buffer loads (points that are not staged).  g[t]: byte offset of tap t's row (y0 x0, y0 x0+1, y1 x0, y1 x0+1) held by
+// lane K; R[t]: this lane's byte offset of instruction t's piece inside a row (without the column).
+template <int K>
+__device__ __forceinline__ void quad_taps_global_cf(const __amdgpu_buffer_rsrc_t rsrc, const unsigned (&g)[4], const float (&w)[3],
+                                                    const unsigned (&R)[4], bool col, f32x4_t (&acc)[4])
+{
+    constexpr int Q = K * 0x55;
+    const unsigned g0 = dpp_u<Q>(g[0]), g1 = dpp_u<Q>(g[1]), g2 = dpp_u<Q>(g[2]), g3 = dpp_u<Q>(g[3]);
+    const float ga = dpp_f<Q>(w[0]), fa = dpp_f<Q>(w[1]), fx = dpp_f<Q>(w[2]);
+    const unsigned G0 = col ? g1 : g0, G1 = col ? g3 : g2;
+    const float cx = col ? fx : 1.f - fx;
+    const float W0 = ga * cx, W1 = fa * cx;
+    u32x4_t v0[4], v1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v0[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G0 + R[t], 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v1[t] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, G1 + R[t], 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] += __builtin_bit_cast(f32x4_t, v0[t]) * W0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] += __builtin_bit_cast(f32x4_t, v1[t]) * W1;
+}
+
+// 16-byte output store through a buffer descriptor with a cache policy (PquadGeom::store; gfx940+ aux bits: 1 = sc0, 2 = nt, 16 = sc1)
+__device__ __forceinline__ void p2_store16(const __amdgpu_buffer_rsrc_t orsrc, unsigned byte_off, f32x4_t v, int mode)
+{
+    const u32x4_t u = __builtin_bit_cast(u32x4_t, v);
+    if (mode == 1) __builtin_amdgcn_raw_buffer_store_b128(u, orsrc, byte_off, 0, 2);
+    else if (mode == 2) __builtin_amdgcn_raw_buffer_store_b128(u, orsrc, byte_off, 0, 16);
+    else if (mode == 3) __builtin_amdgcn_raw_buffer_store_b128(u, orsrc, byte_off, 0, 17);
+    else __builtin_amdgcn_raw_buffer_store_b128(u, orsrc, byte_off, 0, 0);
+}
+
 // WAVES x NP: 4 waves x 2 passes of 64 pairs (three workgroups per CU, <= 168 registers), or 8 waves x 1 pass of 128 pairs (two
 // workgroups per CU with twice the LDS each, <= 128 registers: 16 instead of 12 waves per CU, half the work per wave and tile),
 // or 4 waves x 1 pass: tiles of 64 pairs, four workgroups per CU (<= 128 registers, 39 KB of LDS each) -- more tiles in flight per
 // CU against a per-tile chain of latencies that does not shrink with the tile
-template <bool FUSED, int WAVES, int NP>
+// CF: the conflict-free gather (quad_taps_lds_cf above; option pquad_cf).  Measured on MI355X (profiles/r06_msda_pquad2_conflict_free.txt):
+// SQ_LDS_BANK_CONFLICT 3.59 M -> 0, LDS-active cycles 10.27 M -> 6.68 M per launch, vector instructions 9.72 M -> 10.95 M -- and the
+// launch takes 39.7 instead of 38.1 us: the LDS pipe was not what bounds the kernel; the vector ALUs' extra 12 % cost more than the
+// conflicts did.  Kept as an option (and as the emulator's proof that the layout IS conflict-free), not the default.
+template <bool FUSED, int WAVES, int NP, bool CF = false>
 __global__ void __launch_bounds__(64 * WAVES, ((WAVES == 8 || NP == 1) ? 4 : 3))
 msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg)
 {
+    constexpr bool kP2ConflictFree = CF;
     static_assert((WAVES == 4 && NP == 2) || (WAVES == 8 && NP == 1) || (WAVES == 4 && NP == 1), "64 or 128 (query, head) pairs per tile");
     constexpr int PT = 4, D = 32, NL = 4, PAIRS = 16 * WAVES;
     constexpr unsigned ROWB = D * 4;
@@ -166,6 +241,14 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
     const unsigned rbA = (unsigned)(hsel * 64 + sub * 16), rbB = (unsigned)((1 - hsel) * 64 + sub * 16);
     const unsigned lds_rows = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char *)s_rows);
     const unsigned ldsA = lds_rows + rbA, ldsB = lds_rows + rbB;
+    // conflict-free gather: column (x0 / x0 + 1) and half row of this lane, the quad's place g in its LDS cycle ({0, 3, 5, 6} /
+    // {1, 2, 4, 7}: (quad & 7) >> 1), this lane's piece of instruction t: t ^ g
+    const bool cf_col = (sub & 1) != 0;
+    const unsigned cf_g = (unsigned)((quad & 7) >> 1);
+    unsigned cfC[4];
+    const unsigned cf_base = lds_rows + (cf_col ? 128u : 0u);   // cfC[t] - cf_base: the piece's byte offset inside a (pixel, head) row
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cfC[t] = cf_base + (unsigned)((sub >> 1) * 64) + 16u * ((unsigned)t ^ cf_g);
     const int bp16 = 4 * (lane ^ 16), bp32 = 4 * (lane ^ 32);
     const unsigned long long lanes_of_level0 = 0x1111111111111111ull;
 
@@ -263,41 +346,67 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
     const unsigned rowbytes = (unsigned)(M * D) * 4u;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(da.value), 0, da.value_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        da.out, 0, (unsigned)(da.nlq * M * D * 4), 0x00020000);
     __syncthreads();   // the first tile's query list is visible
 
     // ---- a tile's points: per pass the four points of this lane's level --------------------------------------------------
     int pk[NP][PT];               // packed floor coordinates (x0 | y0 << 16), kP2Sentinel: not in range
-    float w[NP][PT][4];           // bilinear weights x attention weight
+    float w[NP][PT][kP2ConflictFree ? 3 : 4];   // bilinear weights x attention weight; conflict-free gather: (gy a, fy a, fx)
     unsigned a0[NP][PT], a1[NP][PT];   // LDS byte offsets of the rows (y0, x0) / (y0 + 1, x0); 0: not staged (rows 0, 1 are zeros)
     unsigned pair32[NP];          // (b * S + q) * M + m
     bool live[NP];
     int nq = 0;
 
-    // loads -> softmax / locations (fused entry) -> tap arithmetic -> bounding boxes (filed in s_bb[par])
-    auto prologue = [&](int par, int m) {
-        nq = __builtin_amdgcn_readfirstlane(s_nq[par]);
-        f32x4_t xy0[NP], xy1[NP], a4[NP];
-        float2 rp[NP];
+    // A tile's prologue in two halves: (1) the loads into xy0 / xy1 / a4 / rp and the tile's pair indices, (2) softmax / locations
+    // (fused entry) -> tap arithmetic -> bounding boxes (filed in s_bb[par]).  (Measured in round 6 and removed: a pass-major tail that
+    // issues the next tile's loads while the second pass still gathers -- the order alone changes nothing, 39.0 vs 38.7 us, and the
+    // loads held across the gather cost 21 / 74 spilled registers: 43.7 / 70.9 us, profiles/r06_msda_pquad2_early_loads.txt.)
+    f32x4_t xy0[NP], xy1[NP], a4[NP];
+    float2 rp[NP];
+    unsigned n_pair32[NP];
+    bool n_live[NP];
+    auto prologue_loads = [&](int par, int m) {
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
             const int bqs = s_qi[par * (NP * PAIRS) + ps * PAIRS + quad];
-            live[ps] = bqs >= 0;
-            const unsigned bq = live[ps] ? (unsigned)bqs : 0u;
-            pair32[ps] = bq * (unsigned)M + (unsigned)m;
+            n_live[ps] = bqs >= 0;
+            const unsigned bq = n_live[ps] ? (unsigned)bqs : 0u;
+            n_pair32[ps] = bq * (unsigned)M + (unsigned)m;
             if constexpr (!FUSED) {
-                const unsigned pr = pair32[ps] * (unsigned)LP + lsub * (unsigned)PT;
-                xy0[ps] = ldg_f4(da.loc, pr * 8u);
-                xy1[ps] = ldg_f4(da.loc, pr * 8u + 16u);
-                a4[ps] = ldg_f4(da.attn, pr * 4u);
+                const unsigned pr = n_pair32[ps] * (unsigned)LP + lsub * (unsigned)PT;
+                if (pg.ldnt) {
+                    xy0[ps] = ldg_f4_nt(da.loc, pr * 8u);
+                    xy1[ps] = ldg_f4_nt(da.loc, pr * 8u + 16u);
+                    a4[ps] = ldg_f4_nt(da.attn, pr * 4u);
+                } else {
+                    xy0[ps] = ldg_f4(da.loc, pr * 8u);
+                    xy1[ps] = ldg_f4(da.loc, pr * 8u + 16u);
+                    a4[ps] = ldg_f4(da.attn, pr * 4u);
+                }
                 rp[ps] = float2{0.f, 0.f};
             } else {
                 const unsigned row = bq * (unsigned)da.fa.ld;
                 const unsigned s = (unsigned)(m * LP) + lsub * (unsigned)PT;
-                xy0[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.off_col + s * 2u) * 4u);
-                xy1[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.off_col + s * 2u) * 4u + 16u);
-                a4[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.logit_col + s) * 4u);
+                if (pg.ldnt) {   // read once: do not displace the value rows (re-read by the neighbouring tiles) from L2
+                    xy0[ps] = ldg_f4_nt(da.fa.qproj, (row + (unsigned)da.fa.off_col + s * 2u) * 4u);
+                    xy1[ps] = ldg_f4_nt(da.fa.qproj, (row + (unsigned)da.fa.off_col + s * 2u) * 4u + 16u);
+                    a4[ps] = ldg_f4_nt(da.fa.qproj, (row + (unsigned)da.fa.logit_col + s) * 4u);
+                } else {
+                    xy0[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.off_col + s * 2u) * 4u);
+                    xy1[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.off_col + s * 2u) * 4u + 16u);
+                    a4[ps] = ldg_f4(da.fa.qproj, (row + (unsigned)da.fa.logit_col + s) * 4u);
+                }
                 rp[ps] = ldg_f2(da.fa.ref, (bq * (unsigned)L + lsub) * 8u);   // ref_dim == 2: this level's reference point
             }
+        }
+    };
+    auto prologue_math = [&](int par) {
+        nq = __builtin_amdgcn_readfirstlane(s_nq[par]);
+#pragma unroll
+        for (int ps = 0; ps < NP; ++ps) {
+            live[ps] = n_live[ps];
+            pair32[ps] = n_pair32[ps];
         }
         int mn = 0x7FFF7FFF, mx = kP2Sentinel;   // packed int16 (x, y) bounding box of this lane's in-range points
 #pragma unroll
@@ -339,10 +448,16 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
                 const float fx = x - xf, fy = y - yf, gx = 1.f - fx, gy = 1.f - fy;
                 const float a = in ? sa[k] : 0.f;
                 const float ga = gy * a, fa = fy * a;
-                w[ps][k][0] = ga * gx;
-                w[ps][k][1] = ga * fx;
-                w[ps][k][2] = fa * gx;
-                w[ps][k][3] = fa * fx;
+                if constexpr (kP2ConflictFree) {
+                    w[ps][k][0] = ga;
+                    w[ps][k][1] = fa;
+                    w[ps][k][2] = fx;
+                } else {
+                    w[ps][k][0] = ga * gx;
+                    w[ps][k][1] = ga * fx;
+                    w[ps][k][2] = fa * gx;
+                    w[ps][k][3] = fa * fx;
+                }
                 const int p = p2_pack16((int)xf, (int)yf);
                 pk[ps][k] = in ? p : kP2Sentinel;
                 if constexpr ((kPqAblate & 4) == 0) {
@@ -370,7 +485,8 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         }
     };
 
-    prologue(0, cm);
+    prologue_loads(0, cm);
+    prologue_math(0);
     stamp(2);
 
     int par = 0;
@@ -382,7 +498,7 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         if (has_next) decode_item(next_item, nb, nty, ntx, nm);
 
         __syncthreads();   // B0: the tile's bounding boxes are filed; every wave is done with the previous tile's windows
-        if (iter == 0) stamp(3);
+        if (iter == pg.trace_iter) stamp(3);
 
         // ---- window geometry, per lane for its own level (msda_quad_geom.h tfq_window) ----------------------------------
         int g_wx0, g_wy0, g_limx, g_limy, g_ww, g_rows, g_roff;
@@ -521,25 +637,33 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         };
 
         f32x4_t accA[NP], accB[NP];
+        f32x4_t acc4[kP2ConflictFree ? NP : 1][4];   // conflict-free gather: instruction t's piece (t ^ g) of this lane's column
 #pragma unroll
         for (int ps = 0; ps < NP; ++ps) {
             accA[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             accB[ps] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if constexpr (kP2ConflictFree) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc4[ps][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
         }
         // ---- one level: the staged points from LDS, the others (if the wave has any) by buffer loads --------------------------
-        auto gather_level = [&](auto lc) {
+        auto gather_lp = [&](auto lc, auto pc) {   // one level, one pass (both compile-time: the records are register arrays)
             constexpr int l = decltype(lc)::value;
+            constexpr int ps = decltype(pc)::value;
             if (l >= L) return;   // uniform
-#pragma unroll
-            for (int ps = 0; ps < NP; ++ps) {
+            if constexpr (ps < NP) {
+              do {
                 if (ps * PAIRS >= nq) continue;   // uniform
                 if constexpr ((kPqAblate & 1) != 0) {
 #pragma unroll
                     for (int k = 0; k < PT; ++k) accA[ps].x += (float)(a0[ps][k] + a1[ps][k]) * w[ps][k][0];   // keeps the records alive
                 } else {
 #pragma unroll
-                    for (int k = 0; k < PT; ++k)
-                        quad_taps_lds<l>(a0[ps][k], a1[ps][k], w[ps][k], ldsA, ldsB, accA[ps], accB[ps]);
+                    for (int k = 0; k < PT; ++k) {
+                        if constexpr (kP2ConflictFree) quad_taps_lds_cf<l>(a0[ps][k], a1[ps][k], w[ps][k], cfC, cf_col, acc4[ps]);
+                        else quad_taps_lds<l>(a0[ps][k], a1[ps][k], w[ps][k], ldsA, ldsB, accA[ps], accB[ps]);
+                    }
                 }
                 if constexpr ((kPqAblate & 32) != 0) continue;
                 if ((ngm[ps] & (lanes_of_level0 << l)) == 0ull) continue;   // uniform: every point of this level and pass was staged
@@ -556,34 +680,43 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
                                             (ky0 && kx1) ? my_lvl_base + (unsigned)(r0 + 1) * rowbytes : kOobBase,
                                             (ky1 && kx0) ? my_lvl_base + (unsigned)(r0 + my_W) * rowbytes : kOobBase,
                                             (ky1 && kx1) ? my_lvl_base + (unsigned)(r0 + my_W + 1) * rowbytes : kOobBase};
-                    quad_taps_global<l>(rsrc, g4, w[ps][k], rbA, rbB, accA[ps], accB[ps]);
+                    if constexpr (kP2ConflictFree) {
+                        const unsigned cfR[4] = {cfC[0] - cf_base, cfC[1] - cf_base, cfC[2] - cf_base, cfC[3] - cf_base};
+                        quad_taps_global_cf<l>(rsrc, g4, w[ps][k], cfR, cf_col, acc4[ps]);
+                    }
+                    else quad_taps_global<l>(rsrc, g4, w[ps][k], rbA, rbB, accA[ps], accB[ps]);
                 }
+              } while (false);
             }
+        };
+        auto gather_level = [&](auto lc) {   // one level, every pass
+            gather_lp(lc, std::integral_constant<int, 0>{});
+            gather_lp(lc, std::integral_constant<int, 1>{});
         };
 
         // ---- round 0: level 0 ----
         stage_level(std::integral_constant<int, 0>{});
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's DMA landed
         __syncthreads();                      // B1: ... everybody's
-        if (iter == 0) stamp(4);
+        if (iter == pg.trace_iter) stamp(4);
         if (has_next) tables_1(par ^ 1, nty, ntx);   // off the staging path; visible after B2
-        if (iter == 0) stamp(5);
+        if (iter == pg.trace_iter) stamp(5);
         gather_level(std::integral_constant<int, 0>{});
-        if (iter == 0) stamp(6);
+        if (iter == pg.trace_iter) stamp(6);
 
         // ---- round 1: levels 1..3 in the same rows ----
         __syncthreads();   // B2: every wave is done reading level 0's window
-        if (iter == 0) stamp(11);
+        if (iter == pg.trace_iter) stamp(11);
         if (has_next) tables_2(par ^ 1, nb);   // visible after B3
         const bool third_round = __builtin_amdgcn_readfirstlane((int)late3) != 0;   // (the same in every lane)
         stage_level(std::integral_constant<int, 1>{});
         stage_level(std::integral_constant<int, 2>{});
         if (!third_round) stage_level(std::integral_constant<int, 3>{});
-        if (iter == 0) stamp(12);
+        if (iter == pg.trace_iter) stamp(12);
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        if (iter == 0) stamp(13);
+        if (iter == pg.trace_iter) stamp(13);
         __syncthreads();   // B3
-        if (iter == 0) stamp(7);
+        if (iter == pg.trace_iter) stamp(7);
         gather_level(std::integral_constant<int, 1>{});
         gather_level(std::integral_constant<int, 2>{});
         if (third_round) {   // ---- round 2: level 3 on its own ----
@@ -594,19 +727,42 @@ msda_fwd_f32_pquad2(const DirectArgs da, const LevelTable lt, const PquadGeom pg
         }
         gather_level(std::integral_constant<int, 3>{});
 #pragma unroll
-        for (int ps = 0; ps < NP; ++ps)
-            if (live[ps] && (!(kPqAblate & 8) || accA[ps].x == 12345.678f)) {
-                float *o = reinterpret_cast<float *>(reinterpret_cast<char *>(da.out) + (size_t)(pair32[ps] * (unsigned)(D * 4)));
-                *reinterpret_cast<f32x4_t *>(o + rbA / 4) = accA[ps];
-                *reinterpret_cast<f32x4_t *>(o + rbB / 4) = accB[ps];
+        for (int ps = 0; ps < NP; ++ps) {
+            if constexpr (kP2ConflictFree) {
+                // the two columns of a pair sit in the lanes sub and sub ^ 1 (same half row, same piece order): a lane sends the partner
+                // the two pieces the partner stores and adds what it receives to the two it stores itself
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4_t mine = cf_col ? acc4[ps][2 + j] : acc4[ps][j];
+                    const f32x4_t yours = cf_col ? acc4[ps][j] : acc4[ps][2 + j];
+                    f32x4_t sum;
+                    sum.x = mine.x + dpp_f<kDppQuadXor1>(yours.x);
+                    sum.y = mine.y + dpp_f<kDppQuadXor1>(yours.y);
+                    sum.z = mine.z + dpp_f<kDppQuadXor1>(yours.z);
+                    sum.w = mine.w + dpp_f<kDppQuadXor1>(yours.w);
+                    (j == 0 ? accA[ps] : accB[ps]) = sum;
+                }
             }
-        if (iter == 0) stamp(8);
+            if (live[ps] && (!(kPqAblate & 8) || accA[ps].x == 12345.678f)) {
+                const unsigned ob = pair32[ps] * (unsigned)(D * 4);
+                if constexpr (kP2ConflictFree) {
+                    p2_store16(orsrc, ob + (cf_col ? cfC[2] : cfC[0]) - cf_base, accA[ps], pg.store);
+                    p2_store16(orsrc, ob + (cf_col ? cfC[3] : cfC[1]) - cf_base, accB[ps], pg.store);
+                } else {
+                    p2_store16(orsrc, ob + rbA, accA[ps], pg.store);
+                    p2_store16(orsrc, ob + rbB, accB[ps], pg.store);
+                }
+            }
+        }
+        if (iter == pg.trace_iter) stamp(8);
         if (!has_next) break;
 
         // ---- the next tile: its points, prologue arithmetic and bounding boxes ----
         cb = nb;
         cm = nm;
-        prologue(par ^ 1, nm);
+        if (iter == 0) stamp(14);
+        prologue_loads(par ^ 1, nm);
+        prologue_math(par ^ 1);
         if (iter == 0) stamp(9);
         item = next_item;
         par ^= 1;
