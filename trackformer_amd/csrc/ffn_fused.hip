@@ -209,7 +209,7 @@ __device__ __forceinline__ void rows_epilogue(const f32x16 (&accy)[TI][Geo<D>::T
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[i][j][g]), yrs,
-                                                       (unsigned)((m0 + i * 32 + frow) * D + cbase + 32 * j + 8 * g) * 4u, 0, 0);
+                                                       (unsigned)((m0 + i * 32 + frow) * D + cbase + 32 * j + 8 * g) * 4u, 0, tfm::kStoreAux);
 }
 
 template <int SP, int D, int TI, bool LN>

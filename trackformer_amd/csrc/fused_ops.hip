@@ -59,8 +59,8 @@ bias_act_kernel(float *__restrict__ x, const float *__restrict__ bias, const flo
             v0.x = v0.x < 0.f ? 0.f : v0.x; v0.y = v0.y < 0.f ? 0.f : v0.y; v0.z = v0.z < 0.f ? 0.f : v0.z; v0.w = v0.w < 0.f ? 0.f : v0.w;
             v1.x = v1.x < 0.f ? 0.f : v1.x; v1.y = v1.y < 0.f ? 0.f : v1.y; v1.z = v1.z < 0.f ? 0.f : v1.z; v1.w = v1.w < 0.f ? 0.f : v1.w;
         }
-        reinterpret_cast<f32x4_t *>(x)[i] = v0;
-        if (two) reinterpret_cast<f32x4_t *>(x)[i1] = v1;
+        tfm::stream_store(reinterpret_cast<f32x4_t *>(x) + i, v0);
+        if (two) tfm::stream_store(reinterpret_cast<f32x4_t *>(x) + i1, v1);
     }
 }
 
@@ -115,7 +115,7 @@ add_layernorm_kernel(const float *__restrict__ x, const float *__restrict__ res,
             if (j < C4) {
                 const f32x4_t g = reinterpret_cast<const f32x4_t *>(gamma)[j];
                 const f32x4_t b = reinterpret_cast<const f32x4_t *>(beta)[j];
-                orow[j] = (v[k] - mean) * rstd * g + b;
+                tfm::stream_store(orow + j, (v[k] - mean) * rstd * g + b);
             }
         }
     }
@@ -226,7 +226,7 @@ groupnorm_apply_kernel(const float *__restrict__ x, const double *__restrict__ w
             y.z = y.z < 0.f ? 0.f : y.z;
             y.w = y.w < 0.f ? 0.f : y.w;
         }
-        op[i] = y;
+        tfm::stream_store(op + i, y);
     }
 }
 

@@ -200,7 +200,7 @@ split_gemm_body(const float *__restrict__ X, const unsigned short *__restrict__ 
                     if constexpr (RESID) v += rv[r];
                     if (RELU) v = v < 0.f ? 0.f : v;
                     const unsigned off = base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off, 0, tfm::kStoreAux);
                 }
             }
         return;
@@ -435,7 +435,7 @@ split_conv3_kernel(const float *__restrict__ X, const unsigned short *__restrict
                 float v = F16 ? __builtin_fmaf(acc[i][j][r], rsc, b) : acc[i][j][r] + b;
                 if (RELU) v = v < 0.f ? 0.f : v;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
-                                                      base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
+                                                      base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, tfm::kStoreAux);
             }
         }
 }
@@ -614,7 +614,7 @@ split_gemm_deep_kernel(const float *__restrict__ X, const unsigned short *__rest
         float v = Split<SP>::F16 ? __builtin_fmaf(acc[r], rsc, b) : acc[r] + b;
         if (RELU) v = v < 0.f ? 0.f : v;
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs,
-                                              base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, 0);
+                                              base + (unsigned)(((r & 3) + 8 * (r >> 2)) * N) * 4u, 0, tfm::kStoreAux);
     }
 }
 

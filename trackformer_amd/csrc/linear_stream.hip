@@ -415,7 +415,7 @@ stream_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, co
                 float v = Split<SP>::F16 ? __builtin_fmaf(acc[i][j][e], rsc, b) : acc[i][j][e] + b;
                 if (R != nullptr) v += rv[e];
                 if (relu) v = v < 0.f ? 0.f : v;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u, 0, tfm::kStoreAux);
             }
         }
     }
@@ -456,7 +456,7 @@ stream_splitk_reduce_kernel(const float *__restrict__ part, const float *__restr
         acc.z = acc.z < 0.f ? 0.f : acc.z;
         acc.w = acc.w < 0.f ? 0.f : acc.w;
     }
-    reinterpret_cast<f32x4 *>(y)[i] = acc;
+    tfm::stream_store(reinterpret_cast<f32x4 *>(y) + i, acc);
 }
 
 int num_cus()

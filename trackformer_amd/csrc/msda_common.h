@@ -17,6 +17,22 @@ struct LevelTable {
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// Cache policy of the output stores of the dense / element-wise kernels (buffer-store aux bits on gfx940+: 1 = sc0, 2 = nt, 16 = sc1).
+// Measured in round 6 (profiles/r06_nt_stores.txt): non-temporal stores make an ISOLATED streaming kernel faster (the dirty output
+// otherwise waits for the write-back at the end of the kernel: msda_fwd_f32_pquad2 40.6 -> 38.1 us in the harness), but in the frame
+// every output is the next kernel's input, and with nt stores in all dense kernels the frame is SLOWER (335 vs 348 frames/s): the
+// consumer then misses the caches.  Plain stores stay the default; the macro is the A/B switch (tools/build_variant_all.py).
+#ifndef TF_STORE_AUX
+#define TF_STORE_AUX 0
+#endif
+constexpr int kStoreAux = TF_STORE_AUX;
+template <typename V>
+__device__ __forceinline__ void stream_store(V *p, V v)
+{
+    if constexpr (kStoreAux == 2) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
 constexpr unsigned kOobOffset = 0xFFFFFFF0u;  // >= num_records for every supported tensor
 constexpr unsigned kOobBase = 0xFFFFFF00u;    // ... and so is kOobBase + (lane slice offset < 0xF0)
 

@@ -184,7 +184,7 @@ stem_conv7x7_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
                     v.w = v.w < 0.f ? 0.f : v.w;
                 }
                 const unsigned off = ok ? pix + (unsigned)(32 * t + 8 * g + 4 * half) * 4u : 0xC0000000u;   // outside: dropped
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yrs, off, 0, tfm::kStoreAux);
             }
         if (has_next) store_patch(ox0 + kTW, pv, sP[(tile + 1) & 1]);   // the buffer of the previous tile: every wave is past it
         __syncthreads();
