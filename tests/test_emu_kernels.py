@@ -914,18 +914,60 @@ def test_convolution_through_the_stream_gemm(n, h, w, cin, cout, stride, ks, ter
     b = rng.standard_normal(cout, dtype=np.float32)
     ref = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double().permute(0, 3, 1, 2),
                                      torch.from_numpy(b).double(), stride=stride, padding=1 if ks == 3 else 0).clamp_min(0).permute(0, 2, 3, 1).numpy()
-    y = emu_lib.conv_packed(x, wt, b, relu=True, stride=stride)
+    prev_halo = emu_lib.set_options(conv_halo=0)   # the stream form (the halo form of the stride-1 3 x 3 layers: next test)
+    try:
+        y = emu_lib.conv_packed(x, wt, b, relu=True, stride=stride)
+        assert y.shape == ref.shape
+        assert np.abs(y - ref).max() < _tol(terms) * max(1.0, np.abs(ref).max())
+        assert np.array_equal(y, emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride))
+        for ti in (1, 2, 4):
+            prev = emu_lib.set_options(linear_stream_ti=ti)
+            try:
+                assert np.array_equal(emu_lib.conv_packed(x, wt, b, relu=True, stride=stride), y), ti
+            finally:
+                emu_lib.set_options(**prev)
+        st = emu_lib.stats()
+        assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+    finally:
+        emu_lib.set_options(**prev_halo)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,ksplit", [(1, 9, 11, 64, 64, 1), (2, 8, 6, 64, 128, 1), (1, 12, 9, 128, 256, 1), (1, 1, 1, 64, 64, 1),
+                                                    (1, 17, 19, 64, 96, 1), (2, 5, 5, 128, 128, 3), (1, 16, 8, 256, 64, 4), (1, 7, 23, 128, 320, 2)],
+                         ids=lambda v: str(v))
+def test_convolution_3x3_halo_form(n, h, w, cin, cout, ksplit, terms):
+    """The halo form of the stride-1 3 x 3 convolution (conv3x3_halo_kernel, round 6): a block stages the halo of its patch of output
+    pixels once per 32-channel slice and runs all nine taps from it.  Against torch's convolution in float64 within the split
+    product's bound -- images that are not multiples of the patch, one pixel, several images, residual + ReLU, the channel loop cut
+    into pieces -- and against the stream form (the same products in another fp32 order); every block shape gives the same bits
+    (the order per output element does not depend on the patch), nothing is read from inactive lanes."""
+    import torch
+    rng = np.random.default_rng(h * w + cin + cout + ksplit)
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, 3, 3, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32)
+    conv = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double().permute(0, 3, 1, 2),
+                                      torch.from_numpy(b).double(), stride=1, padding=1).permute(0, 2, 3, 1)
+    r = rng.standard_normal(tuple(conv.shape), dtype=np.float32)
+    ref = (conv + torch.from_numpy(r).double()).clamp_min(0).numpy()
+    assert emu_lib.set_options(conv_halo=1)["conv_halo"] == 1   # the default
+    y = emu_lib.conv_packed(x, wt, b, relu=True, stride=1, ksplit=ksplit, residual=r)
     assert y.shape == ref.shape
     assert np.abs(y - ref).max() < _tol(terms) * max(1.0, np.abs(ref).max())
-    assert np.array_equal(y, emu_lib.conv3x3_split(x, wt, b, relu=True, stride=stride))
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
     for ti in (1, 2, 4):
         prev = emu_lib.set_options(linear_stream_ti=ti)
         try:
-            assert np.array_equal(emu_lib.conv_packed(x, wt, b, relu=True, stride=stride), y), ti
+            assert np.array_equal(emu_lib.conv_packed(x, wt, b, relu=True, stride=1, ksplit=ksplit, residual=r), y), ti
         finally:
             emu_lib.set_options(**prev)
-    st = emu_lib.stats()
-    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+    prev = emu_lib.set_options(conv_halo=0)
+    try:
+        stream = emu_lib.conv_packed(x, wt, b, relu=True, stride=1, ksplit=ksplit, residual=r)
+    finally:
+        emu_lib.set_options(**prev)
+    assert np.abs(y - stream).max() <= 4e-6 * max(1.0, np.abs(ref).max())   # same products, another summation order
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout,stride,ks,ksplit", [(1, 9, 11, 128, 64, 2, 3, 4), (1, 7, 6, 256, 256, 2, 3, 9), (2, 5, 5, 64, 128, 1, 3, 18),

@@ -47,6 +47,9 @@ constexpr int kStride = kSlice + 8;          // bf16 per LDS row: 80 bytes (16-b
 #ifndef TF_STREAM_XDEPTH
 #define TF_STREAM_XDEPTH 2   // register stages of activations ahead in the convolution form (4: measured in round 5, no gain; tools/build_variant.py for A/B)
 #endif
+#ifndef TF_HALO_ABLATE
+#define TF_HALO_ABLATE 0     // timing ablations of conv3x3_halo_kernel (tools only): 1 weights from L1, 2 no re-staging, 4 no MFMAs
+#endif
 #ifndef TF_STREAM_ABLATE
 #define TF_STREAM_ABLATE 0   // timing ablations of stream_gemm_kernel (tools only): 1 no activation split, 2 no MFMAs
 #endif
@@ -459,6 +462,235 @@ stream_splitk_reduce_kernel(const float *__restrict__ part, const float *__restr
     tfm::stream_store(reinterpret_cast<f32x4 *>(y) + i, acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// THE HALO FORM OF THE 3 x 3 CONVOLUTION (round 6; stride 1, padding 1: sixteen of ResNet-50's convolutions).
+// The stream form above treats a 3 x 3 convolution as a GEMM over K = 9 Cin in tap-major order: every (tap, 32-channel slice) fetches
+// the block's shifted input pixels again, splits them into pieces again and writes them to LDS again -- nine times the work per input
+// value, and per slice only TI x TJ x 2 x terms MFMAs stand against it: the phase trace of round 5 has a slice of the 128 -> 128
+// layer spend 806 of its 1660 cycles staging and 704 in a "matrix phase" that holds 384 cycles of MFMAs
+// (profiles/r05_stream_phase_trace.txt); the ablation without MFMAs runs 80 % as long as the kernel (r05_stream_gemm_ablations.txt).
+// Here a block owns a PATCH of PH x 8 output pixels and walks the input channels in slices of 32: per slice it stages the patch's HALO
+// ((PH + 2) x 10 input pixels, 1.4-1.6 pixels per output pixel instead of 9) once -- global -> registers -> pieces -> LDS, double
+// buffered, one barrier per slice -- and runs all NINE taps from it: the A fragment of tap (dy, dx) is the same LDS tile read at a
+// constant offset (an immediate of ds_read_b128), the B fragments are the packed weight's k-steps (tap Cin + c) / 16, prefetched one tap
+// ahead.  18 x TI x TJ x terms MFMAs per barrier instead of 2 x TI x TJ x terms.
+//   block   256 threads = 4 waves as WR x WC; BM = WR TI 32 output pixels = a patch of PH = BM / 8 rows x 8 columns, BN = WC TJ 32 channels
+//   rows    tile row r of the block <-> patch pixel (r / 8, r % 8); a wave's tile i covers patch rows 4 (wr TI + i) .. + 3
+//   split-K blockIdx.y walks `cslices` channel slices (all nine taps of each) and writes partial sums to Y + z M N (second pass: the
+//           stream form's reduce kernel)
+// Summation order per output element: channel slice, tap, k-step, smallest term first (the stream form: tap, channel) -- the same
+// products, another fp32 order.
+template <int SP, int TI, int TJ, int WC>
+__global__ void __launch_bounds__(kThreads, (TI * TJ <= 2 ? 2 : 1))
+conv3x3_halo_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R, float *Y,
+                    int N, int nblocks, int npatches, int tiles_x, int tiles_y, int relu, int cslices, const StreamConv cv)
+{
+    constexpr int WR = 4 / WC, BM = WR * TI * 32, PW = 8, PH = BM / PW, HW = PW + 2, HH = PH + 2, HP = HH * HW;
+    constexpr int NA = Split<SP>::NA, NB = Split<SP>::NB;
+    constexpr int XV = (HP * 8 + kThreads - 1) / kThreads;   // float4 of the halo per thread and slice
+    __shared__ __attribute__((aligned(16))) unsigned short sH[2][NA][HP * kStride];   // [buffer][activation piece][halo pixel][k]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave - wr * WC;
+
+    // block -> (patch, column block): the column blocks of a patch sit 8 ids apart (ids congruent mod 8 share an XCD and its L2)
+    const int per = 8 * nblocks;
+    const int g = blockIdx.x / per, r = blockIdx.x - g * per;
+    const int pid = g * 8 + (r & 7), nb = r >> 3;
+    if (pid >= npatches) return;   // whole block, before any barrier
+    const int tx = pid % tiles_x, t2 = pid / tiles_x, ty = t2 % tiles_y, img = t2 / tiles_y;
+    const int y0 = ty * PH, x0 = tx * PW;
+    const int H = cv.hin, W = cv.win, Cin = cv.cin;   // stride 1, padding 1: the output has the input's size
+    const int nsl = Cin / kSlice;
+    const int cbeg = cslices > 0 ? (int)blockIdx.y * cslices : 0;
+    const int cend = cslices > 0 ? min(nsl, cbeg + cslices) : nsl;
+    const long long Mtot = (long long)cv.nimg * H * W;
+    if (cslices > 0) Y += (size_t)blockIdx.y * Mtot * N;
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // ---- the halo: thread -> float4 f = tid + 256 it of (halo pixel f >> 3, channels 4 (f & 7) ..); pixels outside the image (and
+    // the slots behind the last halo pixel) read zeros from beyond num_records
+    constexpr unsigned OOB = 0xC0000000u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (unsigned)((size_t)cv.nimg * H * W * Cin * 4), 0x00020000);
+    unsigned xoff[XV];
+    int lds_o[XV];
+#pragma unroll
+    for (int it = 0; it < XV; ++it) {
+        const int f = tid + kThreads * it;
+        const int hp = f >> 3, c4 = f & 7;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        xoff[it] = ok ? ((unsigned)((img * H + iy) * W + ix) * (unsigned)Cin + (unsigned)(c4 * 4)) * 4u : OOB;
+        lds_o[it] = hp < HP ? hp * kStride + c4 * 4 : -1;
+    }
+    auto load_x = [&](int cs, f32x4 (&dst)[XV]) {
+        const unsigned coff = (unsigned)(min(cs, cend - 1) * kSlice) * 4u;   // (calls past the last slice re-fetch it: never used)
+#pragma unroll
+        for (int it = 0; it < XV; ++it)
+            dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff[it] == OOB ? OOB : xoff[it] + coff, 0, 0));
+    };
+    auto store_x = [&](const f32x4 (&src)[XV], int buf) {
+#pragma unroll
+        for (int it = 0; it < XV; ++it) {
+            if (XV * kThreads > HP * 8 && lds_o[it] < 0) continue;
+            u32x2 pc[NA];
+            split4<SP>(src[it], pc);
+#pragma unroll
+            for (int p = 0; p < NA; ++p) *reinterpret_cast<u32x2 *>(&sH[buf][p][lds_o[it]]) = pc[p];
+        }
+    };
+    // ---- weights: the wave's TJ column tiles in fragment order; k-step of (tap, channel slice cs, kk): tap Cin / 16 + 2 cs + kk
+    const int KQ = (9 * Cin) >> 4, tapq = Cin >> 4;
+    const u32x4 *wp[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) wp[j] = Wp + ((size_t)(nb * (WC * TJ) + wc * TJ + j) * KQ * NB) * 64 + lane;
+    auto load_w = [&](int cs, int tap, WFrags<NB, TJ> &w) {
+#if TF_HALO_ABLATE & 1   // timing ablation (tools/build_variant.py --source linear_stream.hip): the same 4 KB of weights every time (L1-resident)
+        const int q0 = 0 * (tap + cs);
+#else
+        const int q0 = tap * tapq + 2 * min(cs, cend - 1);
+#endif
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int p = 0; p < NB; ++p) w.v[j][kk][p] = wp[j][((q0 + kk) * NB + p) * 64];
+    };
+    // ---- A fragments: lane -> (tile row lane & 31 = patch pixel (row >> 3, row & 7), k group lane >> 5)
+    int abase[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int prow = (wr * TI + i) * 4 + ((lane & 31) >> 3), pcol = lane & 7;
+        abase[i] = (prow * HW + pcol) * kStride + (lane >> 5) * 8;   // halo pixel of tap (0, 0); tap (dy, dx): + (dy HW + dx) kStride
+    }
+
+    // The tap loop is software-pipelined by hand (one wave per SIMD at these grid sizes: nothing else hides a latency).  A slice is 18
+    // steps (tap, k-step); in program order step s issues the LDS reads of step s + 1 (two register sets of A fragments) and, at the
+    // first k-step of a tap, the weight fragments of tap + 2 (a ring of three sets: 9 taps = 3 turns, the next slice's taps 0 / 1 land
+    // where this slice's did), THEN its own MFMAs -- the compiler's s_waitcnt counts let the younger requests stay in flight.
+    f32x4 xr[XV];
+    WFrags<NB, TJ> wr3[3];
+    u32x4 af[2][TI][NA];
+    auto read_a = [&](int buf, int step, u32x4 (&dst)[TI][NA]) {   // step = 2 tap + kk (compile-time at every call)
+        const int tap = step >> 1, kk = step & 1;
+        const int toff = ((tap / 3) * HW + (tap % 3)) * kStride + kk * 16;
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int p = 0; p < NA; ++p) dst[i][p] = *reinterpret_cast<const u32x4 *>(&sH[buf][p][abase[i] + toff]);
+    };
+    {
+        f32x4 first[XV];
+        load_x(cbeg, first);
+        load_w(cbeg, 0, wr3[0]);
+        load_w(cbeg, 1, wr3[1]);
+        load_x(cbeg + 1, xr);
+        store_x(first, 0);
+    }
+    __syncthreads();
+
+    for (int cs = cbeg; cs < cend; ++cs) {
+        const int buf = (cs - cbeg) & 1;
+        read_a(buf, 0, af[0]);
+        auto step = [&](auto sc) {
+            constexpr int st = decltype(sc)::value, tap = st >> 1, kk = st & 1;
+            if constexpr (st < 17) read_a(buf, st + 1, af[(st + 1) & 1]);
+            if constexpr (kk == 0) {
+                if constexpr (tap + 2 < 9) load_w(cs, tap + 2, wr3[(tap + 2) % 3]);
+                else load_w(cs + 1, tap + 2 - 9, wr3[(tap + 2) % 3]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the requests stay in front of this step's MFMAs
+            u32x4 bfr[TJ][NB];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int p = 0; p < NB; ++p) bfr[j][p] = wr3[tap % 3].v[j][kk][p];
+#if TF_HALO_ABLATE & 4   // timing ablation: no matrix instructions (the operands stay alive through one add)
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) acc[i][j][kk] += __builtin_bit_cast(float, af[st & 1][i][0].x ^ bfr[j][0].x);
+#else
+            mfma_tiles<SP, TI, TJ>(acc, af[st & 1], bfr);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using std::integral_constant;
+        step(integral_constant<int, 0>{});
+        step(integral_constant<int, 1>{});
+        step(integral_constant<int, 2>{});
+        step(integral_constant<int, 3>{});
+        step(integral_constant<int, 4>{});
+        step(integral_constant<int, 5>{});
+        step(integral_constant<int, 6>{});
+        step(integral_constant<int, 7>{});
+        step(integral_constant<int, 8>{});
+        step(integral_constant<int, 9>{});
+        step(integral_constant<int, 10>{});
+        step(integral_constant<int, 11>{});
+        step(integral_constant<int, 12>{});
+        step(integral_constant<int, 13>{});
+        step(integral_constant<int, 14>{});
+        step(integral_constant<int, 15>{});
+        step(integral_constant<int, 16>{});
+        step(integral_constant<int, 17>{});
+        // the next slice -> the other LDS buffer (its readers passed the previous barrier), its registers take the slice after it
+#if !(TF_HALO_ABLATE & 2)   // timing ablation 2: the halo is staged once (every slice reads the first one)
+        if (cs + 1 < cend) {
+            store_x(xr, buf ^ 1);
+            load_x(cs + 2, xr);
+        }
+#endif
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); row -> patch pixel ->
+    // image pixel; pixels of the patch outside the image and columns >= N go beyond num_records (dropped by the hardware)
+    const unsigned ybytes = (unsigned)((size_t)Mtot * N * 4);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : Y), 0, R ? ybytes : 0u, 0x00020000);
+    const int n0 = nb * (WC * TJ * 32);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + (wc * TJ + j) * 32 + (lane & 31);
+        const bool colok = col < N;
+        const float b = (bias && colok) ? bias[col] : 0.f;
+        float rsc = 1.f;   // fp16 scheme: the output channel's power of two (behind the fragments of the packed weight)
+        if constexpr (Split<SP>::F16) rsc = reinterpret_cast<const float *>(Wp + (size_t)((N + kBN - 1) / kBN * (kBN / 32)) * KQ * NB * 64)[colok ? col : 0];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            unsigned off[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (wr * TI + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int oy = y0 + (row >> 3), ox = x0 + (row & 7);
+                off[e] = (colok && oy < H && ox < W) ? (unsigned)(((img * H + oy) * W + ox) * N + col) * 4u : OOB;
+            }
+            float rv[16];
+            if (R != nullptr) {   // uniform
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, off[e], 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = Split<SP>::F16 ? __builtin_fmaf(acc[i][j][e], rsc, b) : acc[i][j][e] + b;
+                if (R != nullptr) v += rv[e];
+                if (relu) v = v < 0.f ? 0.f : v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, off[e], 0, tfm::kStoreAux);
+            }
+        }
+    }
+}
+
 int num_cus()
 {
     static const int n = [] {
@@ -563,9 +795,71 @@ int stream_dispatch(const StreamCall &c, hipStream_t s)
     }
 }
 
+// ---- the halo form: block shape per call (as stream_dispatch: 64 / 128 / 256 columns; 64-pixel patches, 128 where that still leaves
+// about two blocks per CU)
+std::atomic<int> g_halo{-1};   // -1: TF_CONV_HALO or the default (1)
+bool halo_enabled()
+{
+    int v = g_halo.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_CONV_HALO");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_halo.store(v);
+    }
+    return v != 0;
+}
+
+template <int SP, int TI, int TJ, int WC>
+int launch_halo(const StreamCall &c, hipStream_t s)
+{
+    constexpr int BM = (4 / WC) * TI * 32, BN = WC * TJ * 32, PH = BM / 8;
+    const int tiles_x = (c.cv.win + 7) / 8, tiles_y = (c.cv.hin + PH - 1) / PH;
+    const long long npatches = (long long)c.cv.nimg * tiles_y * tiles_x;
+    const int nblocks = (c.N + BN - 1) / BN;
+    const long long gx = (npatches + 7) / 8 * 8 * nblocks;
+    const int nsl = c.cv.cin / kSlice;
+    int cslices = 0, gz = 1;
+    if (c.ksplit > 1) {
+        cslices = (nsl + c.ksplit - 1) / c.ksplit;
+        gz = (nsl + cslices - 1) / cslices;
+        if (gz <= 1) cslices = 0, gz = 1;
+    }
+    if (gx > 0x7fffffffLL || gz > 65535 || npatches > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
+    const bool partial = gz > 1;
+    float *out = partial ? c.workspace : c.y;
+    hipLaunchKernelGGL((conv3x3_halo_kernel<SP, TI, TJ, WC>), dim3((unsigned)gx, (unsigned)gz), dim3(kThreads), 0, s, c.x, c.wp,
+                       partial ? nullptr : c.bias, partial ? nullptr : c.res, out, c.N, nblocks, (int)npatches, tiles_x, tiles_y,
+                       partial ? 0 : c.relu, cslices, c.cv);
+    if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    if (partial) {
+        const long long mn4 = (long long)c.M * c.N / 4;
+        hipLaunchKernelGGL(stream_splitk_reduce_kernel, dim3((unsigned)((mn4 + 255) / 256)), dim3(256), 0, s, c.workspace, c.bias, c.res,
+                           c.y, mn4, c.N / 4, gz, c.relu);
+        if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    }
+    return TF_MSDA_OK;
+}
+
+template <int SP>
+int halo_dispatch(const StreamCall &c, hipStream_t s)
+{
+    const int f = forced_ti();
+    const long long pieces = c.ksplit > 1 ? c.ksplit : 1;
+    const bool big = (long long)((c.M + 127) / 128) * ((c.N + 255) / 256) * pieces >= 2LL * num_cus();
+    if (c.N <= 64) return (f ? f >= 2 : big) ? launch_halo<SP, 2, 1, 2>(c, s) : launch_halo<SP, 1, 1, 2>(c, s);
+    if (c.N <= 128) return (f ? f >= 4 : big) ? launch_halo<SP, 4, 1, 4>(c, s) : launch_halo<SP, 2, 1, 4>(c, s);
+    return launch_halo<SP, 2, 2, 4>(c, s);
+}
+
 }  // namespace
 
 namespace tfm {
+int conv_halo_set(int v)
+{
+    const int prev = halo_enabled() ? 1 : 0;
+    g_halo.store(v != 0 ? 1 : 0);
+    return prev;
+}
 int linear_stream_set_ti(int v)
 {
     const int prev = forced_ti();
@@ -659,5 +953,7 @@ extern "C" int tf_conv_packed_f32(const float *x, const void *w_packed, const fl
     }
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     StreamCall c{x, static_cast<const u32x4 *>(w_packed), bias, residual, y, (int)M, ks * ks * cin, cout, relu, true, cv, workspace, ksplit};
+    if (ks == 3 && stride == 1 && halo_enabled())   // the halo form: every input pixel staged once per channel slice, not once per tap
+        return sp == 3 ? halo_dispatch<3>(c, static_cast<hipStream_t>(stream)) : halo_dispatch<16>(c, static_cast<hipStream_t>(stream));
     return stream_dispatch_scheme<true>(sp, c, static_cast<hipStream_t>(stream));
 }

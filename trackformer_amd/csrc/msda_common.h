@@ -71,6 +71,8 @@ int ffn_set_tail_split(int v);
 int linln_set_ti(int v);   // tf_linear_res_ln_f32 (1..3; 0 = by row count)
 // linear_stream.hip: row tiles per block of tf_linear_packed_f32 (2..4; 0 = per shape); returns the previous value
 int linear_stream_set_ti(int v);
+// linear_stream.hip: 1 = the halo form of the stride-1 3 x 3 convolutions (default), 0 = the stream form; returns the previous value
+int conv_halo_set(int v);
 // mha_core.hip: 1 = the matrix-core kernel (default), 0 = the vector kernel of round 4; returns the previous value
 int mha_set_mfma(int v);
 

@@ -640,7 +640,8 @@ def conv3x3(x, w_taps, bias, relu, stride):
         return None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
-    ksplit = _conv_ksplit(n * ho * wo, ks * ks * cin, cout)
+    halo = ks == 3 and stride == 1 and _conv_halo   # (the halo form of the stream route: its own split policy)
+    ksplit = _conv_ksplit(n * ho * wo, ks * ks * cin, cout, _HALO_KSPLIT_POLICY if halo else None)
     if ks == 1 and (ksplit < _CONV1X1_MIN_PIECES or not _conv1x1_splitk):
         ksplit = 1
     if (_conv_stream and _conv_stream_wins(n * ho * wo, cout) and cin % 64 == 0 and not (x.data_ptr() & 15)
@@ -739,14 +740,30 @@ def set_conv1x1_splitk(on):
     return prev
 
 
-def _conv_ksplit(m, k, cout):
+# The halo form of the stride-1 3 x 3 convolutions (csrc/linear_stream.hip conv3x3_halo_kernel, round 6; TF_CONV_HALO=0 /
+# set_conv_halo(False): the stream form): a block stages the halo of its patch once per channel slice and runs all nine taps from it.
+# Its blocks carry 18 x the matrix work per barrier of the stream form's, so it wants fewer, longer pieces: swept on the MI355X
+# (profiles/r06_conv3_halo.txt).
+_conv_halo = os.environ.get("TF_CONV_HALO", "1") not in ("", "0")
+_HALO_KSPLIT_POLICY = tuple(int(v) for v in os.environ.get("TF_CONV_HALO_KSPLIT_POLICY", "512,300,9,32").split(","))
+
+
+def set_conv_halo(on):
+    """Switch the halo form of the stride-1 3 x 3 convolutions on or off (process-wide, also inside the library); returns the previous setting."""
+    global _conv_halo
+    prev, _conv_halo = _conv_halo, bool(on)
+    _cabi.lib().tf_msda_set_option(b"conv_halo", 1 if on else 0)
+    return prev
+
+
+def _conv_ksplit(m, k, cout, policy=None):
     """Pieces the K loop (k = 9 Cin or Cin) of a split-product convolution is cut into: 1 unless the launch would leave most of the chip
     with one workgroup or none while every one of them walks a long K (at 800 x 1333: layer2's stride-1 layers 261
     workgroups of 36 K-slices -> 2 pieces, layer3 132 of 72 -> 5, layer4 68 of 144 -> 11, the extra pyramid level 10 of
     576 -> 64)."""
     if not _conv_splitk or cout % 4:
         return 1
-    target, alone, per_piece, min_slices = _KSPLIT_POLICY
+    target, alone, per_piece, min_slices = policy or _KSPLIT_POLICY
     blocks = -(-m // 64) * -(-cout // (128 if cout >= 128 else 64))
     slices = k // 32
     if blocks >= alone or slices < min_slices:
