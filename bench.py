@@ -888,6 +888,7 @@ def run_training(cfg, args, device, world, rank, model, criterion, margs):
             tg = [dict(t, prev_target=dict(t['prev_target'])) for t in targets]   # forward mutates targets
             engine.train_step(ddp, criterion, optimizer, samples, tg, clip_max_norm=margs.clip_max_norm)
     run_set(args.warmup)
+    engine.settle_heap()   # (as engine.train_one_epoch does after its first steps: no oldest-generation collector pass inside a step)
     return timed_repeats(run_set, args.steps, world, device, args.min_seconds)
 
 

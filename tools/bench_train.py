@@ -87,6 +87,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    engine.settle_heap()
     du.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -156,8 +156,9 @@ class SetCriterion(nn.Module):
         assert loss in loss_map, f'do you really want to compute {loss} loss?'
         return loss_map[loss](outputs, targets, indices, num_boxes, **kwargs)
 
-    def _extra_losses(self, outputs, targets, num_boxes, suffix):
-        indices = self.matcher(outputs, targets)
+    def _extra_losses(self, outputs, targets, num_boxes, suffix, indices=None):
+        if indices is None:
+            indices = self.matcher(outputs, targets)
         out = {}
         for loss in self.losses:
             if loss == 'masks':  # too costly on intermediate outputs
@@ -169,7 +170,14 @@ class SetCriterion(nn.Module):
 
     def forward(self, outputs, targets):
         outputs_without_aux = {k: v for k, v in outputs.items() if k != 'aux_outputs'}
-        indices = self.matcher(outputs_without_aux, targets)
+        aux_list = list(outputs.get('aux_outputs', []))
+        # the final layer and the auxiliary layers are matched against the same targets: one device pass + one host copy for all of
+        # them (matcher.match_many; the reference calls its matcher once per layer, detr.py:266-289 -- same assignments)
+        if aux_list and hasattr(self.matcher, "match_many"):
+            all_indices = self.matcher.match_many([outputs_without_aux] + aux_list, targets)
+            indices, aux_indices = all_indices[0], all_indices[1:]
+        else:
+            indices, aux_indices = self.matcher(outputs_without_aux, targets), [None] * len(aux_list)
 
         # number of target boxes averaged over all ranks (the one scalar all-reduce of the loss)
         num_boxes = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float,
@@ -181,8 +189,8 @@ class SetCriterion(nn.Module):
         losses = {}
         for loss in self.losses:
             losses.update(self.get_loss(loss, outputs, targets, indices, num_boxes))
-        for i, aux_outputs in enumerate(outputs.get('aux_outputs', [])):
-            losses.update(self._extra_losses(aux_outputs, targets, num_boxes, f'_{i}'))
+        for i, aux_outputs in enumerate(aux_list):
+            losses.update(self._extra_losses(aux_outputs, targets, num_boxes, f'_{i}', aux_indices[i]))
         if 'enc_outputs' in outputs:
             bin_targets = copy.deepcopy(targets)
             for bt in bin_targets:
