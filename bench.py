@@ -497,9 +497,20 @@ def measure_roofline_backward(device, launches=10):
     ms = time_launches(lambda: msda.ms_deform_attn_backward(value, shapes, loc, attn, grad_out, 64), launches)
     alg = algorithmic_bytes(N=2, S=S, M=8, D=32, L=4, Lq=S, P=4, backward=True)
     gbs = alg / ms / 1e6
-    return {"bound": "hbm", "kernel": msda.last_kernel() + " (encoder call of a bs-2 training step, N=2, Lq=S=22223)",
+    kernel = msda.last_kernel()
+    traffic = traffic_src = None   # the committed counter pass of the same kernel / shape / pattern (rocprofv3 --pmc needs its own runs)
+    try:
+        import glob
+        newest = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_msda_bwd_sorted2_traffic.json")))[-1]
+        with open(newest) as f:
+            tj = json.load(f)
+        traffic = tj[kernel]["hbm_traffic_bytes_per_launch"]
+        traffic_src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, own passes; taken at commit %s)" % (os.path.basename(newest), tj.get("_commit"))
+    except (OSError, KeyError, ValueError, IndexError):
+        pass
+    return {"bound": "hbm", "kernel": kernel + " (encoder call of a bs-2 training step, N=2, Lq=S=22223)",
             "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": None, "algorithmic_bytes": alg, "avg_launch_us": round(ms * 1e3, 2), "launches": launches,
+            "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg, "avg_launch_us": round(ms * 1e3, 2), "launches": launches,
             "pattern": "local (reference point + N(0, 2 px))"}
 
 
