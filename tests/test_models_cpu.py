@@ -270,18 +270,33 @@ def test_image_only_half_of_the_forward_can_run_ahead(host_op):
     assert plain[2] == ahead[2] and plain[3] == ahead[3]
 
 
-def run_mask_tracker(device="cpu", frames=3, lazy_masks=False):
-    """cfg-5 path: Tracker.step on the mask-head model; -> {track id: {frame: result dict}}."""
+def run_mask_tracker(device="cpu", frames=3, lazy_masks=False, wrap=None, prepare=False):
+    """cfg-5 path: Tracker.step on the mask-head model; -> {track id: {frame: result dict}}.  wrap: detector -> detector
+    (GraphedDetector); prepare: the pipelined loop -- step_async(t), step_prepare(t + 1), step_finish(t)."""
     model, post, args = um.build("cfg5_segm_tracking", factory.build_model, config.make_args,
                                  device=device)
     model.to(device)
     model.tracking()
-    tracker = Tracker(model, post, config.tracker_cfg(), False, lazy_masks=lazy_masks)
+    tracker = Tracker(wrap(model) if wrap is not None else model, post, config.tracker_cfg(), False, lazy_masks=lazy_masks)
     tracker.reset()
+    blobs = um.tracker_sequence(n_frames=frames) if frames > 3 else um.tracker_sequence()[:frames]
     with torch.no_grad():
-        for blob in um.tracker_sequence()[:frames]:
-            tracker.step(blob)
-    return tracker.get_results()
+        if prepare:
+            prepared = 0
+            handle = tracker.step_async(blobs[0])
+            for i in range(len(blobs)):
+                if i + 1 < len(blobs):
+                    prepared += bool(tracker.step_prepare(blobs[i + 1]))
+                tracker.step_finish(handle)
+                if i + 1 < len(blobs):
+                    handle = tracker.step_async(blobs[i + 1])
+            tracker.frames_prepared = prepared
+        else:
+            for blob in blobs:
+                tracker.step(blob)
+    tracker_results = tracker.get_results()
+    run_mask_tracker.last_tracker = tracker
+    return tracker_results
 
 
 def compare_mask_tracker_to_golden(results, box_tol_px=0.05, area_tol=0.02):

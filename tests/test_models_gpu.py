@@ -158,6 +158,30 @@ def test_tracker_with_mask_head_matches_reference(dev, lazy):
     shared.compare_mask_tracker_to_golden(shared.run_mask_tracker(device=dev, lazy_masks=lazy), box_tol_px=0.64)
 
 
+def test_pipelined_mask_tracker_equals_the_plain_loop(dev):
+    """Round 6: the mask-head model under GraphedDetector's two graphs with the image-only half of the next
+    frame prepared ahead (Tracker.step_prepare) -- the loop `bench.py --config cfg5` times -- against the plain eager loop over
+    the same 12 frames: same track ids / frames / source queries, boxes and scores, the same masks up to the ties of a
+    random-weight head; and the frames really were prepared."""
+    import numpy as np
+    from trackformer_amd.graphed import GraphedDetector
+    plain = shared.run_mask_tracker(device=dev, frames=12, lazy_masks=True)
+    piped = shared.run_mask_tracker(device=dev, frames=12, lazy_masks=True, wrap=GraphedDetector, prepare=True)
+    assert shared.run_mask_tracker.last_tracker.frames_prepared >= 7   # (the graphs of a shape exist from its second sight on)
+    assert sorted(plain) == sorted(piped)
+    n_px = n_diff = 0
+    for tid in plain:
+        assert sorted(plain[tid]) == sorted(piped[tid])
+        for f in plain[tid]:
+            a, b = plain[tid][f], piped[tid][f]
+            assert a['obj_ind'] == b['obj_ind']
+            np.testing.assert_allclose(a['bbox'], b['bbox'], atol=5e-3)
+            np.testing.assert_allclose(a['score'], b['score'], atol=1e-5)
+            n_px += a['mask'].size
+            n_diff += int((a['mask'] != b['mask']).sum())
+    assert n_px > 0 and n_diff <= 2e-3 * n_px, (n_diff, n_px)
+
+
 def test_lazy_mask_head_gives_the_same_tracks(dev):
     """Lazy mask head (Tracker's default; lazy_masks=False runs the head for every query inside the detector): the head runs
     for the surviving tracks' queries only; same track ids as the full head, boxes and scores up to the run-to-run noise

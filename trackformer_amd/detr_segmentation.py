@@ -78,8 +78,13 @@ class DETRSegmBase(nn.Module):
         self.mask_head = MaskHeadSmallConv(self.hidden_dim + nheads, self.fpn_channels,
                                            self.hidden_dim)
 
-    def forward(self, samples: NestedTensor, targets: list = None, prev_features=None):
-        out, targets, features, memory, hs = super().forward(samples, targets, prev_features)
+    def forward(self, samples: NestedTensor, targets: list = None, prev_features=None, encoded=None):
+        # encoded: what encode_frame() returned for this frame (the image-only half ran ahead: GraphedDetector.prepare /
+        # Tracker.step_prepare); everything the mask head reads -- features, encoder memory -- is part of it
+        if encoded is not None:
+            out, targets, features, memory, hs = super().forward(samples, targets, prev_features, encoded=encoded)
+        else:
+            out, targets, features, memory, hs = super().forward(samples, targets, prev_features)
 
         if isinstance(memory, list):   # deformable: per-level encoder memory
             src, mask = features[-2].decompose()

@@ -34,7 +34,7 @@ track queries (zero embedding, a fixed box) that are masked out as keys of the d
 the real queries see what they would see without them (up to the summation order of the attention) -- and drops the
 fillers' rows from the outputs.  Everything else in the decoder is per query.  `bucket=1` switches it off.
 
-Two graphs (round 5).  For the single-frame models without a mask head the forward is captured in two halves: A = backbone +
+Two graphs (round 5; with a mask head since round 6).  For the single-frame models the forward is captured in two halves: A = backbone +
 input projections + encoder, which depends on the image only, and B = decoder + heads, which also takes the track queries.
 `prepare(img)` replays A for a frame whose track queries are not known yet -- Tracker.step_prepare calls it for frame
 t + 1 before it associates frame t, so that the GPU never waits for the host in a single sequence -- and the following
@@ -118,7 +118,9 @@ class GraphedDetector:
     # frame / mask head): A = backbone + input projections + encoder (the image only), B = decoder + heads (+ the track queries)
     def _splittable(self):
         m = self.model
-        return hasattr(m, "encode_frame") and not self._multi_frame() and not hasattr(m, "mask_head")
+        # (a mask head reads the features and the encoder memory: both are results of the image-only half, DETRSegmBase.forward
+        # takes them through `encoded=` since round 6)
+        return hasattr(m, "encode_frame") and not self._multi_frame()
 
     def _side_stream(self, dev):
         st = self._side.get(dev)

@@ -276,8 +276,8 @@ class Tracker:
         input projections, encoder -- GraphedDetector.prepare, or the model's encode_frame) so that the GPU works on this
         frame while the host still associates the previous one; the following step_async(blob) / step(blob) of the SAME
         blob then runs the decoder half only.  Results are those of step(): the image-only half does not depend on the
-        tracks.  Returns whether anything was enqueued (multi-frame and mask-head models: no -- their first half needs the
-        previous frame's features / feeds the mask head)."""
+        tracks.  Returns whether anything was enqueued (multi-frame models: no -- their first half needs the previous frame's
+        features)."""
         det = self.obj_detector
         prep = getattr(det, "prepare", None)
         self._prepared = None
@@ -290,7 +290,7 @@ class Tracker:
                 return True
             return False
         img = blob['img'].to(self.device, non_blocking=True)
-        if (hasattr(det, "encode_frame") and not getattr(det, "multi_frame_attention", False) and not hasattr(det, "mask_head")
+        if (hasattr(det, "encode_frame") and not getattr(det, "multi_frame_attention", False)
                 and not det.training and not torch.is_grad_enabled()):
             self._prepared = (blob['img'], img, det.encode_frame(img, None))
             return True
@@ -342,7 +342,10 @@ class Tracker:
         if self._lazy_masks:
             from .detr_segmentation import lazy_mask_scope
             with lazy_mask_scope():
-                outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
+                if encoded is not None:
+                    outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0], encoded=encoded)
+                else:
+                    outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
         elif encoded is not None:
             outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0], encoded=encoded)
         else:
