@@ -900,6 +900,33 @@ def test_stream_gemm_residual_epilogue_and_narrow_blocks(M, K, N, relu, terms):
             emu_lib.set_options(**prev)
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,K,N,relu", [(130, 64, 64, False), (300, 256, 256, True), (70, 128, 96, False), (513, 192, 384, True)],
+                         ids=lambda v: str(v))
+def test_lds_dma_gemm_is_bit_identical(M, K, N, relu, mode, terms):
+    """The LDS-DMA GEMM behind tf_linear_packed_f32 (dma_gemm_kernel, round 6; option linear_dma = block shape): both operands
+    global -> LDS by LDS-DMA into a ring of K-slices with counted s_waitcnt vmcnt, the A fragments read as fp32 from an XOR-swizzled
+    image and cut into pieces in registers.  Every block shape / ring depth: the bits of tf_linear_split_res_f32 (same products, same
+    order), with bias, residual and ReLU, ragged M and N, nothing written behind row M; the emulator lands a DMA only at the
+    s_waitcnt that covers it, so a read in front of its wait would see poisoned LDS."""
+    rng = np.random.default_rng(M + K + N + mode)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N, dtype=np.float32)
+    r = rng.standard_normal((M, N), dtype=np.float32)
+    prev = emu_lib.set_options(linear_dma=mode)
+    try:
+        y = emu_lib.linear_packed(x, w, b, relu, residual=r, guard_rows=3)
+        y0 = emu_lib.linear_packed(x, w, None, relu)
+    finally:
+        emu_lib.set_options(**prev)
+    assert np.isnan(y[M:]).all()
+    assert np.array_equal(y[:M], emu_lib.linear_split(x, w, b, relu, residual=r))
+    assert np.array_equal(y0, emu_lib.linear_split(x, w, None, relu))
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,stride,ks", [(1, 9, 11, 64, 64, 1, 3), (2, 8, 6, 64, 128, 1, 3), (1, 10, 13, 64, 160, 2, 3),
                                                        (1, 7, 7, 128, 64, 2, 1), (1, 12, 9, 128, 256, 1, 3), (1, 6, 5, 192, 320, 1, 1),
                                                        (1, 1, 1, 64, 64, 1, 3)], ids=lambda v: str(v))

@@ -463,6 +463,183 @@ stream_splitk_reduce_kernel(const float *__restrict__ part, const float *__restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// THE LDS-DMA GEMM (round 6).  Every dense kernel of the frame moves its operands from L2 / HBM at 5-6 TB/s whatever its shape
+// (256 -> 256 linear: 22.7 MB of rows + 128 KB of weights x 696 blocks in 18.6 us; 256 -> 384: 179 MB in 31 us; the 3 x 3 layers:
+// ~160 MB in 32 us; the fused FFN: 464 MB of weight re-reads in 74 us): not a bandwidth limit -- the memory-level parallelism of the
+// structure.  A wave of the stream form holds its fetches in REGISTERS (one slice of rows two slices ahead, one set of weight
+// fragments one slice ahead: 8-16 KB in flight per wave, ~50 KB per CU), and 50 KB per CU over ~2 us of loaded latency is 6 TB/s.
+// Here nothing is fetched into registers: both operands go global -> LDS by LDS-DMA (buffer_load ... lds) into a ring of STAGES
+// slices per block, (STAGES - 1) slices in flight behind counted s_waitcnt vmcnt -- the bytes in flight are bounded by LDS, not by
+// the register file.
+//   block   256 threads = 4 waves splitting the ROWS: wave w owns rows 32 TI w .. + 32 TI - 1 and ALL BN = 32 TJ columns
+//   A       raw fp32 rows of the slice (BM x 128 B), each wave fetches ITS rows (4 TI DMA instructions of 8 rows x 128 B) and is the
+//           only one to read them: no barrier for A, no split pass through LDS -- the wave reads its MFMA A fragments as fp32 (two
+//           ds_read_b128 per row tile and k-step) and cuts them into pieces in registers right in front of the MFMAs (every input
+//           value is split exactly once).  LDS image: row r, 16-byte piece c at r * 8 + (c ^ ((r >> 1) & 7)) -- the XOR is applied to
+//           the SOURCE offset of the DMA lane (the LDS side of an LDS-DMA is lane-linear); the 16 rows of an LDS cycle of
+//           ds_read_b128 then hit 16 different slots
+//   B       the packed weight fragments of the block's TJ column tiles (TJ x 2 k-steps x NB pieces x 1 KB per slice, in fragment order:
+//           the B fragment read is base + 16 lane, conflict-free), fetched once per BLOCK (its four waves share them; each issues a
+//           quarter of the DMA instructions) -- a quarter of the stream form's weight traffic per row
+//   loop    wait for this wave's part of slice s (vmcnt counted so that the younger slices stay in flight) -> s_barrier (slice s is
+//           complete for everybody, and everybody is done reading slice s - 1) -> refill the slot of slice s - 1 with slice
+//           s + STAGES - 1 -> MFMAs of slice s.  One barrier per slice, raw (a __syncthreads() would drain the DMA queue).
+// Accumulation order per output element: that of linear_split.hip / the stream form (k ascending, per k-step smallest terms first):
+// bit-identical results.
+template <int SP, int TI, int TJ, int STAGES>
+__global__ void __launch_bounds__(kThreads, (TI * TJ <= 4 ? 2 : 1))
+dma_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R, float *Y,
+                int M, int K, int N, int mblocks, int nblocks, int relu)
+{
+    constexpr int BM = 4 * TI * 32, BN = TJ * 32, NA = Split<SP>::NA, NB = Split<SP>::NB;
+    constexpr int A_BYTES = BM * 128, B_BYTES = TJ * 2 * NB * 1024, STAGE = A_BYTES + B_BYTES;
+    constexpr int A_INSTR = 4 * TI;                 // DMA instructions per wave and slice for its rows (8 rows each)
+    constexpr int B_INSTR = TJ * 2 * NB / 4;        // ... and its quarter of the weight fragments
+    static_assert((TJ * 2 * NB) % 4 == 0, "the weight fragments of a slice are dealt to four waves");
+    constexpr int PER = A_INSTR + B_INSTR;          // DMA instructions per wave and slice
+    static_assert(STAGES >= 2 && STAGES <= 4 && (STAGES - 2) * PER < 64, "ring of 2..4 slices; s_waitcnt vmcnt holds 6 bits");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // ONE shared array (a second one makes hipcc drain the DMAs)
+    unsigned char *const lds0 = smem;   // (lambdas take the pointer: naming the __shared__ array itself inside one fails the host pass)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int per = 8 * nblocks;
+    const int g = blockIdx.x / per, r = blockIdx.x - g * per;
+    const int mb = g * 8 + (r & 7), nb = r >> 3;
+    if (mb >= mblocks) return;   // whole block, before any barrier
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int KQ = K >> 4, nsl = K / kSlice;
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    constexpr unsigned OOB = 0xC0000000u;   // >= num_records (host: the tensors lie below 3 GiB)
+    // ---- A: DMA instruction a of this wave covers its rows 8 a .. 8 a + 7 (tile-local row rl = 32 TI wave + 8 a + (lane >> 3)); the lane
+    // fetches the piece that belongs at LDS position lane & 7 of that row: piece (lane & 7) ^ ((rl >> 1) & 7)
+    unsigned a_src[A_INSTR];
+#pragma unroll
+    for (int a = 0; a < A_INSTR; ++a) {
+        const int rl = 32 * TI * wave + 8 * a + (lane >> 3);
+        const int row = m0 + rl;
+        const int c = (lane & 7) ^ ((rl >> 1) & 7);
+        a_src[a] = row < M ? ((unsigned)row * (unsigned)K + (unsigned)(c * 4)) * 4u : OOB;
+    }
+    // ---- B: fragment f = 4 b + wave of the slice's TJ * 2 * NB (b < B_INSTR), f = (j * 2 + kk) * NB + p
+    unsigned b_src[B_INSTR];
+#pragma unroll
+    for (int b = 0; b < B_INSTR; ++b) {
+        const int f = 4 * b + wave, p = f % NB, jk = f / NB, kk = jk & 1, j = jk >> 1;
+        b_src[b] = (unsigned)((((size_t)(nb * TJ + j) * KQ + kk) * NB + p) * 1024) + (unsigned)lane * 16u;   // + slice * 2 * NB * 1024
+    }
+    // slice s of both operands -> ring slot `slot`: this wave's rows of A, its quarter of the weight fragments.  (The source offset goes
+    // through a LOCAL: with an array element written directly into the builtin's argument -- a_src[a] + koff -- hipcc's host pass (ROCm 7.2)
+    // drops the whole kernel template without a diagnostic: undefined stubs when the library is linked.  Found by bisection.)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (unsigned)((size_t)M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<u32x4 *>(Wp), 0, (unsigned)((size_t)((N + kBN - 1) / kBN * (kBN / 32)) * KQ * NB * 1024), 0x00020000);
+#define TF_DMA_ISSUE(S_, SLOT_)                                                                                                          \
+    do {                                                                                                                                 \
+        unsigned char *base_ = lds0 + (SLOT_) * STAGE;                                                                                    \
+        const unsigned koff_ = (unsigned)(S_) * (kSlice * 4u), woff_ = (unsigned)(S_) * (2u * NB * 1024u);                                \
+        _Pragma("unroll") for (int a = 0; a < A_INSTR; ++a) {                                                                            \
+            const unsigned v_ = a_src[a] == OOB ? OOB : a_src[a] + koff_;   /* (a local: see above) */                                    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void *)(base_ + (32 * TI * wave + 8 * a) * 128), \
+                                                     16, v_, 0, 0, 0);                                                                    \
+        }                                                                                                                                \
+        _Pragma("unroll") for (int b = 0; b < B_INSTR; ++b) {                                                                            \
+            const unsigned v_ = b_src[b] + woff_;                                                                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void *)(base_ + A_BYTES + (4 * b + wave) * 1024), \
+                                                     16, v_, 0, 0, 0);                                                                    \
+        }                                                                                                                                \
+    } while (0)
+    // ---- A fragment addresses: lane -> (row lane & 31 of its tile, k group lane >> 5): fp32 k = 16 kk + 8 (lane >> 5) .. + 7 = the pieces
+    // c0 = 4 kk + 2 (lane >> 5) and c0 + 1, at the positions c ^ ((row >> 1) & 7) of the row
+    int a_off[TI][2];   // byte offsets (inside a stage) of the two pieces of k-step 0; k-step 1: ^ 64
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int rl = 32 * TI * wave + 32 * i + (lane & 31);
+        const int sw = (rl >> 1) & 7, c0 = 2 * (lane >> 5);
+        a_off[i][0] = rl * 128 + ((c0 ^ sw) << 4);
+        a_off[i][1] = rl * 128 + (((c0 + 1) ^ sw) << 4);
+    }
+
+    // ---- prologue: STAGES - 1 slices in flight
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nsl) TF_DMA_ISSUE(s, s);
+
+    for (int s = 0; s < nsl; ++s) {
+        const int slot = s % STAGES;
+        // this wave's part of slice s has landed: the slices issued after it (at most STAGES - 2, fewer at the end) may stay in flight
+        const int younger = min(STAGES - 2, nsl - 1 - s);
+        if (younger >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * PER) & 0xF) | (((2 * PER) >> 4) << 14));
+        else if (younger == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | (PER & 0xF) | ((PER >> 4) << 14));
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();   // slice s is complete for every wave; every wave is done with slice s - 1
+        if (s + STAGES - 1 < nsl) TF_DMA_ISSUE(s + STAGES - 1, (s + STAGES - 1) % STAGES);
+        const unsigned char *st = smem + slot * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 af[TI][NA], bfr[TJ][NB];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const f32x4 lo = *reinterpret_cast<const f32x4 *>(st + (a_off[i][0] ^ (kk * 64)));
+                const f32x4 hi = *reinterpret_cast<const f32x4 *>(st + (a_off[i][1] ^ (kk * 64)));
+                u32x2 pl[NA], ph[NA];
+                split4<SP>(lo, pl);
+                split4<SP>(hi, ph);
+#pragma unroll
+                for (int p = 0; p < NA; ++p) af[i][p] = u32x4{pl[p].x, pl[p].y, ph[p].x, ph[p].y};
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+#pragma unroll
+                for (int p = 0; p < NB; ++p)
+                    bfr[j][p] = *reinterpret_cast<const u32x4 *>(st + A_BYTES + ((j * 2 + kk) * NB + p) * 1024 + lane * 16);
+            mfma_tiles<SP, TI, TJ>(acc, af, bfr);
+        }
+    }
+
+    // ---- epilogue (as the stream form): C/D of the 32 x 32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const unsigned ybytes = (unsigned)((size_t)M * N * 4);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(Y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(R ? R : Y), 0, R ? ybytes : 0u, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int col = n0 + j * 32 + (lane & 31);
+        const bool colok = col < N;
+        const float b = (bias && colok) ? bias[col] : 0.f;
+        float rsc = 1.f;
+        if constexpr (Split<SP>::F16) rsc = reinterpret_cast<const float *>(Wp + (size_t)((N + kBN - 1) / kBN * (kBN / 32)) * KQ * NB * 64)[colok ? col : 0];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int row0 = m0 + (wave * TI + i) * 32 + 4 * (lane >> 5);
+            const unsigned base = colok ? (unsigned)(row0 * N + col) * 4u : OOB;
+            float rv[16];
+            if (R != nullptr) {   // uniform
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u, 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = Split<SP>::F16 ? __builtin_fmaf(acc[i][j][e], rsc, b) : acc[i][j][e] + b;
+                if (R != nullptr) v += rv[e];
+                if (relu) v = v < 0.f ? 0.f : v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), yrs, base + (unsigned)(((e & 3) + 8 * (e >> 2)) * N) * 4u, 0, tfm::kStoreAux);
+            }
+        }
+    }
+}
+
+#undef TF_DMA_ISSUE
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // THE HALO FORM OF THE 3 x 3 CONVOLUTION (round 6; stride 1, padding 1: sixteen of ResNet-50's convolutions).
 // The stream form above treats a 3 x 3 convolution as a GEMM over K = 9 Cin in tap-major order: every (tap, 32-channel slice) fetches
 // the block's shifted input pixels again, splits them into pieces again and writes them to LDS again -- nine times the work per input
@@ -851,9 +1028,65 @@ int halo_dispatch(const StreamCall &c, hipStream_t s)
     return launch_halo<SP, 2, 2, 4>(c, s);
 }
 
+// ---- the LDS-DMA GEMM: shape per call.  g_dma: -1 = TF_LINEAR_DMA or the default, 0 = off (the stream form), 1..4 = a fixed shape
+// (1: 128 x 128, 2 slices; 2: 128 x 64, 3 slices; 3: 128 x 128, 3 slices; 4: 256 x 128, 2 slices), 9 = per call shape
+std::atomic<int> g_dma{-1};
+int dma_mode()
+{
+    int v = g_dma.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("TF_LINEAR_DMA");
+        v = e ? atoi(e) : 0;
+        if (v < 0 || v > 9) v = 0;
+        g_dma.store(v);
+    }
+    return v;
+}
+
+template <int SP, int TI, int TJ, int STAGES>
+int launch_dma(const StreamCall &c, hipStream_t s)
+{
+    constexpr int BM = 4 * TI * 32, BN = TJ * 32, NB = Split<SP>::NB;
+    constexpr size_t lds = (size_t)STAGES * (BM * 128 + TJ * 2 * NB * 1024);
+    static_assert(lds <= 160 * 1024, "LDS of a CU");
+    const int mblocks = (c.M + BM - 1) / BM, nblocks = (c.N + BN - 1) / BN;
+    const long long gx = (long long)((mblocks + 7) / 8) * 8 * nblocks;
+    if (gx > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
+    const void *fn = (const void *)&dma_gemm_kernel<SP, TI, TJ, STAGES>;
+    static std::atomic<unsigned long long> raised{0};   // bit d: device d has the dynamic-LDS attribute of THIS instantiation
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(raised.load(std::memory_order_acquire) & bit)) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+        raised.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((dma_gemm_kernel<SP, TI, TJ, STAGES>), dim3((unsigned)gx), dim3(kThreads), lds, s, c.x, c.wp, c.bias, c.res, c.y,
+                       c.M, c.K, c.N, mblocks, nblocks, c.relu);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+template <int SP>
+int dma_dispatch(int mode, const StreamCall &c, hipStream_t s)
+{
+    if (mode == 9) mode = c.N <= 64 ? 2 : 1;
+    switch (mode) {
+    case 2: return launch_dma<SP, 1, 2, 3>(c, s);
+    case 3: return launch_dma<SP, 1, 4, 3>(c, s);
+    case 4: return launch_dma<SP, 2, 4, 2>(c, s);
+    default: return launch_dma<SP, 1, 4, 2>(c, s);
+    }
+}
+
 }  // namespace
 
 namespace tfm {
+int linear_dma_set(int v)
+{
+    const int prev = dma_mode();
+    g_dma.store(v >= 0 && v <= 9 ? v : 0);
+    return prev;
+}
 int conv_halo_set(int v)
 {
     const int prev = halo_enabled() ? 1 : 0;
@@ -928,6 +1161,9 @@ extern "C" int tf_linear_packed_f32(const float *x, const void *w_packed, const 
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_packed)) & 15) return TF_MSDA_ERR_BAD_DIMS;
     if ((long long)(M + 256) * N * 4 >= 0xC0000000LL) return TF_MSDA_ERR_BAD_DIMS;   // buffer-resource offsets (the caller keeps tf_linear_split_f32)
     StreamCall c{x, static_cast<const u32x4 *>(w_packed), bias, residual, y, (int)M, K, N, relu, false, StreamConv{}, nullptr, 1};
+    if (const int mode = dma_mode())   // the LDS-DMA GEMM (both operands global -> LDS by DMA, a ring of slices in flight)
+        if ((long long)M * K * 4 < 0xC0000000LL)
+            return sp == 3 ? dma_dispatch<3>(mode, c, static_cast<hipStream_t>(stream)) : dma_dispatch<16>(mode, c, static_cast<hipStream_t>(stream));
     return stream_dispatch_scheme<false>(sp, c, static_cast<hipStream_t>(stream));
 }
 

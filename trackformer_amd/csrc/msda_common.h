@@ -73,6 +73,8 @@ int linln_set_ti(int v);   // tf_linear_res_ln_f32 (1..3; 0 = by row count)
 int linear_stream_set_ti(int v);
 // linear_stream.hip: 1 = the halo form of the stride-1 3 x 3 convolutions (default), 0 = the stream form; returns the previous value
 int conv_halo_set(int v);
+// linear_stream.hip: the LDS-DMA GEMM behind tf_linear_packed_f32: 0 = off (the stream form), 1..4 = a fixed block shape, 9 = per call
+int linear_dma_set(int v);
 // mha_core.hip: 1 = the matrix-core kernel (default), 0 = the vector kernel of round 4; returns the previous value
 int mha_set_mfma(int v);
 

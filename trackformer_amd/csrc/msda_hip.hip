@@ -2284,6 +2284,7 @@ int tf_msda_set_option(const char *name, int value)
     if (strcmp(name, "linln_ti") == 0) return linln_set_ti(value);
     if (strcmp(name, "linear_stream_ti") == 0) return linear_stream_set_ti(value);
     if (strcmp(name, "conv_halo") == 0) return conv_halo_set(value);
+    if (strcmp(name, "linear_dma") == 0) return linear_dma_set(value);
     if (strcmp(name, "mha_mfma") == 0) return mha_set_mfma(value);
     if (strncmp(name, "pquad", 5) == 0) {
         const int prev = pquad_set_option(name, value);
