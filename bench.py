@@ -514,7 +514,8 @@ def measure_roofline_backward(device, launches=10):
             "pattern": "local (reference point + N(0, 2 px))"}
 
 
-def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patterns=("pert", "init", "local")):
+def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patterns=("pert", "init", "local"),
+                     warm_replays=3, timed_replays=8):
     """HIP-event timing of the MSDeformAttn forward kernel at the cfg-2 encoder call shape, THROUGH THE
     FUSED ENTRY the model calls (tf_msda_forward_fused_f32), on the sampling pattern of the
     perturbed-weight parity model, rotating over `sets` input sets (4 x 80 MB > the 256 MiB Infinity
@@ -544,14 +545,16 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
                 for i in range(launches):
                     value, qproj = inputs[i % sets]
                     msda.ms_deform_attn_forward_fused(value, shapes, ref, qproj, M, L, P)
-            graph.replay()
+            for _ in range(warm_replays):   # (clocks and caches in their steady state: one 2 ms replay alone read 41-44 us on
+                graph.replay()              # boxes where ten of them read 38)
             stream.synchronize()
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             start.record(stream)
-            graph.replay()
+            for _ in range(timed_replays):
+                graph.replay()
             end.record(stream)
             end.synchronize()
-        us = start.elapsed_time(end) * 1e3 / launches
+        us = start.elapsed_time(end) * 1e3 / (launches * timed_replays)
         per_pattern[pattern] = {"avg_launch_us": round(us, 2), "GBps": round(alg / (us * 1e-6) / 1e9, 1),
                                 "frac": round(alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                 "kernel": msda.last_kernel()}   # what the library dispatched for this thread's last call
@@ -578,7 +581,7 @@ def measure_roofline(device, launches=48, sets=4, train=False, head_dim=32, patt
     return {"bound": "hbm", "kernel": kernel + " via tf_msda_forward_fused_f32 (encoder call, Lq=S=22223)",
             "achieved": head["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": head["frac"],
             "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": alg, "avg_launch_us": head["avg_launch_us"],
-            "launches": launches, "input_sets": sets,
+            "launches": launches * timed_replays, "launches_per_graph": launches, "warm_replays": warm_replays, "input_sets": sets,
             "pattern": "pert (perturbed-weight model sampling), Infinity-Cache-cold",
             "other_patterns": {k: v for k, v in per_pattern.items() if k != "pert"}}
 

@@ -2,7 +2,7 @@
 pybind11 torch extension over the C ABI of libtf_msda.so -- what the reference ships as models/ops/src/vision.cpp:4-7 + setup.py) on
 host tensors: the reference's two functions with its signatures, against the oracle's goldens and the ctypes binding, and the
 reference's error behaviour (a RuntimeError for what ms_deform_attn_cuda.cu:26-39 asserts).  The device branch is exercised by the
-same module on the GPU box (tools/gpu_runs/gpu_r05_01.sh); nothing in the package routes through this form."""
+same module on the GPU box (tests/test_dropin_compiled_gpu.py); nothing in the package routes through this form."""
 import glob
 import os
 

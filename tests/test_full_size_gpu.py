@@ -613,21 +613,30 @@ def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
     prev = fused.set_split_terms(terms)
     try:
         prev_stream = fused.set_conv_stream("all")
+        prev_halo = fused.set_conv_halo(False)
         try:
-            y = fused.conv3x3(x, taps, b, True, stride)          # the stream GEMM (tf_conv_packed_f32)
+            y = fused.conv3x3(x, taps, b, True, stride)          # the stream GEMM (tf_conv_packed_f32), tap-major K
+            fused.set_conv_halo(True)
+            y_halo = fused.conv3x3(x, taps, b, True, stride)     # (stride-1 3 x 3 only) the halo form: channel-slice-major K
             fused.set_conv_stream(False)
             y_block = fused.conv3x3(x, taps, b, True, stride)   # the LDS-staged block kernel (tf_conv3x3_split_f32)
         finally:
+            fused.set_conv_halo(prev_halo)
             fused.set_conv_stream(prev_stream)
         torch.cuda.synchronize()
     finally:
         fused.set_split_terms(prev)
-    assert y is not None and y_block is not None
+    assert y is not None and y_block is not None and y_halo is not None
     ho, wo = y.shape[2], y.shape[3]
     if fused._conv_ksplit(shape[0] * ho * wo, ks * ks * shape[1], cout) == 1 or (ks == 1 and not fused.conv1x1_wants_split_k(shape[0] * ho * wo, shape[1], cout)):
         assert torch.equal(y, y_block)                       # same products in the same order
     else:
         assert float((y - y_block).abs().max()) < 1e-5 * float(y_block.abs().max())   # the K pieces are cut elsewhere
+    if ks == 3 and stride == 1:   # same products, the nine taps of a 32-channel slice before the next slice
+        assert float((y_halo - y_block).abs().max()) < 1e-5 * float(y_block.abs().max())
+        y = y_halo                # ... and it is the default: the one held against float64 below
+    else:
+        assert torch.equal(y_halo, y)
     ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=ks // 2))
     lib32 = torch.relu(torch.nn.functional.conv2d(x, w, b, stride=stride, padding=ks // 2))
     scale = float(ref.abs().max())

@@ -3,6 +3,7 @@ the HIP MSDeformAttn -> heads -> Tracker) against goldens from the reference CPU
 
 Tolerances are north_star's: boxes / logits within 1e-3 (fp32), track-id assignment bit-exact.
 """
+import numpy as np
 import pytest
 import torch
 
@@ -250,6 +251,40 @@ def test_training_step_matches_reference_cpu_path(dev):
     """cfg 3 path on the GPU: HIP MSDeformAttn forward AND backward inside a real training step."""
     loss_dict, total, grads = shared.run_train_step(device=dev)
     shared.compare_train_to_golden(loss_dict, total, grads, rtol=2e-3)
+
+
+def test_training_fold_of_the_backbone_equals_the_module_graph(dev):
+    """backbone.set_train_fold (round 6): in a training step the frozen stem + layer1 and the no-grad previous-frame pass take the
+    inference kernels, layer2-4 fold the FrozenBN scale into the weight (an autograd op on the weight) and run shift / residual /
+    ReLU as one in-place pass (_BiasAct).  Same losses and gradient norms as the reference's module graph (mul, add, add, ReLU
+    over the feature maps) to fp32 round-off, and the modes really are taken."""
+    from trackformer_amd import backbone
+    calls = []
+    orig = backbone._BiasAct.forward
+
+    def counting(ctx, y, shift, residual, relu):
+        calls.append(y.is_contiguous(memory_format=torch.channels_last))
+        return orig(ctx, y, shift, residual, relu)
+    backbone._BiasAct.forward = staticmethod(counting)
+    try:
+        prev = backbone.set_train_fold(True)
+        try:
+            loss_a, total_a, grads_a = shared.run_train_step(device=dev)
+            n_fold = len(calls)
+            backbone.set_train_fold(False)
+            loss_b, total_b, grads_b = shared.run_train_step(device=dev)
+        finally:
+            backbone.set_train_fold(prev)
+    finally:
+        backbone._BiasAct.forward = orig
+    # ResNet-50: layer2-4 hold 13 bottlenecks = 39 convolutions + 3 projections of the identity branch; one pass with a graph
+    assert n_fold == 42 and len(calls) == n_fold and all(calls), (n_fold, len(calls))
+    assert sorted(loss_a) == sorted(loss_b) and sorted(grads_a) == sorted(grads_b)
+    for k in loss_a:
+        assert abs(loss_a[k] - loss_b[k]) <= 2e-4 * max(1.0, abs(loss_b[k])), (k, loss_a[k], loss_b[k])
+    assert abs(total_a - total_b) <= 2e-4 * abs(total_b)
+    ga, gb = np.array([grads_a[k] for k in sorted(grads_a)]), np.array([grads_b[k] for k in sorted(grads_b)])
+    np.testing.assert_allclose(ga, gb, rtol=2e-3, atol=1e-6 * float(np.abs(gb).max()))
 
 
 def test_training_step_with_mask_head_matches_reference_cpu_path(dev):

@@ -207,11 +207,90 @@ def _inference_mode(module: nn.Module) -> bool:
     return (not module.training) and (not torch.is_grad_enabled())
 
 
+# Round 6 (TF_TRAIN_FOLD=0 / set_train_fold(False): the reference's module graph -- convolution, FrozenBN as mul + add, residual
+# add, ReLU, each an autograd op over the whole feature map): the conv + FrozenBN pairs of a TRAINING step.  Measured on the cfg-3
+# step (profiles/r06_train_step_breakdown.txt): ~17 ms of a 96 ms step were element-wise passes, most of them these.
+#   * no graph is recorded (the previous-frame pass of DETRTrackingBase.forward runs under no_grad in training mode,
+#     detr_tracking.py:219-277; the backbone has no dropout): the inference kernels, as in eval mode;
+#   * a frozen block whose input carries no graph (stem + layer1: backbone.py:66-69 of the reference freezes everything outside
+#     layer2-4): the inference kernels as well -- nothing there is differentiated;
+#   * a trainable block: the BN scale folded into the weight as an autograd op on the WEIGHT (Cout x Cin x k x k, not the feature map),
+#     the library convolution, then shift / residual / ReLU in ONE in-place pass whose backward is one threshold pass (_BiasAct).
+_train_fold = _os.environ.get("TF_TRAIN_FOLD", "1") != "0"
+
+
+def set_train_fold(on: bool) -> bool:
+    global _train_fold
+    prev, _train_fold = _train_fold, bool(on)
+    return prev
+
+
+def _frozen(module: nn.Module) -> bool:
+    f = module.__dict__.get("_tf_frozen")
+    if f is None or f[0] != _frozen_epoch[0]:
+        f = (_frozen_epoch[0], not any(p.requires_grad for p in module.parameters()))
+        module.__dict__["_tf_frozen"] = f
+    return f[1]
+
+
+_frozen_epoch = [0]   # bump (backbone.refresh_frozen()) after changing requires_grad of backbone parameters by hand
+
+
+def refresh_frozen():
+    _frozen_epoch[0] += 1
+
+
+def _fold_mode(module: nn.Module, x) -> int:
+    """0: the module graph; 1: the inference kernels (folded BN, fused epilogues, split products); 2: training with the fold as an
+    autograd op on the weight and the fused epilogue pass."""
+    if not torch.is_grad_enabled():
+        return 1 if (not module.training or (_train_fold and x.is_cuda)) else 0
+    if not (module.training and _train_fold and x.is_cuda and CHANNELS_LAST):
+        return 0   # (eval mode with gradients -- gradient checks, saliency -- keeps the module graph)
+    if not x.requires_grad and _frozen(module):
+        return 1
+    return 2
+
+
+class _BiasAct(torch.autograd.Function):
+    """y <- act(y + shift[c] (+ residual)) in place on a convolution's output (tf_bias_act_f32); backward: one threshold pass,
+    the same gradient to the convolution output and to the residual (shift is a buffer of the FrozenBN)."""
+
+    @staticmethod
+    def forward(ctx, y, shift, residual, relu):
+        out = fused.bias_act_(y, shift, residual, relu)
+        if out is None:   # layout / alignment the kernel does not take: the same arithmetic by ATen, still in place
+            y.add_(shift.reshape(1, -1, 1, 1))
+            if residual is not None:
+                y.add_(residual)
+            if relu:
+                y.relu_()
+        ctx.mark_dirty(y)
+        ctx.relu = relu
+        ctx.has_res = residual is not None
+        if relu:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.relu:
+            (y,) = ctx.saved_tensors
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        return g, None, (g if ctx.has_res else None), None
+
+
 def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, fold: bool,
              residual=None):
     """conv -> frozen BN (-> + residual) (-> ReLU).  Inference on the GPU: one library convolution with
     the BN scale folded into its weights, then ONE fused pass for shift / residual / ReLU."""
-    if fold and isinstance(bn, FrozenBatchNorm2d):
+    if fold == 2 and isinstance(bn, FrozenBatchNorm2d) and x.is_cuda:
+        scale, shift = bn.scale_shift()
+        y = F.conv2d(x, conv.weight * scale.reshape(-1, 1, 1, 1), None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if y.requires_grad:
+            return _BiasAct.apply(y, shift, residual, relu)
+        fold = 0   # (nothing here is differentiated and the block is not frozen either: cannot happen for a trainable weight)
+    if fold == 1 and isinstance(bn, FrozenBatchNorm2d):
         b = cache.get(conv, bn)
         if x.is_cuda:
             split_ok = _split_route_allowed(conv)   # False: this shape keeps the library convolution (TF_CONV_SPLIT_SKIP)
@@ -246,6 +325,8 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
         if residual is not None:
             y = y.add_(residual)
         return F.relu_(y) if relu else y
+    if fold == 2 and not x.is_cuda:
+        fold = 0
     x = bn(conv(x))
     if residual is not None:
         x = x + residual
@@ -304,7 +385,7 @@ class Bottleneck(nn.Module):
         self._folds = [_FoldCache() for _ in range(4)]
 
     def forward(self, x):
-        fold = _inference_mode(self)
+        fold = _fold_mode(self, x)
         out = _conv_bn(x, self.conv1, self.bn1, self._folds[0], True, fold)
         out = _conv_bn(out, self.conv2, self.bn2, self._folds[1], True, fold)
         if self.downsample is not None:
@@ -363,11 +444,12 @@ class ResNet(nn.Module):
         return nn.Sequential(*layers)
 
     def stem(self, x):
-        if _inference_mode(self):
+        fold = _fold_mode(self.conv1, x) if self.training else int(_inference_mode(self))
+        if fold == 1:
             pooled = _stem_pooled(x, self.conv1, self.bn1, self.maxpool, self._stem_fold)
             if pooled is not None:
                 return pooled
-        x = _conv_bn(x, self.conv1, self.bn1, self._stem_fold, True, _inference_mode(self))
+        x = _conv_bn(x, self.conv1, self.bn1, self._stem_fold, True, fold)
         return self.maxpool(x)
 
     def forward(self, x):
@@ -407,8 +489,9 @@ class IntermediateLayerGetter(nn.ModuleDict):
 
     def forward(self, x):
         out = OrderedDict()
-        fold = _inference_mode(self)
-        fused_stem = fold and all(k in self for k in ("conv1", "bn1", "relu"))
+        # (the stem: the mode of ITS convolution -- frozen by the reference, so the inference kernels in a training step too)
+        fold = _fold_mode(self["conv1"], x) if (self.training and "conv1" in self) else int(_inference_mode(self))
+        fused_stem = fold == 1 and all(k in self for k in ("conv1", "bn1", "relu"))
         # opt-in: the stem's shift + ReLU + pooling in one pass (only when nobody asked for the intermediate maps)
         pooled_stem = (fused_stem and "maxpool" in self
                        and not any(k in self.return_layers for k in ("conv1", "bn1", "relu", "maxpool")))
@@ -421,7 +504,7 @@ class IntermediateLayerGetter(nn.ModuleDict):
                 if pooled is not None:
                     x, skip = pooled, ("maxpool",)
                     continue
-                x = _conv_bn(x, self["conv1"], self["bn1"], self._fold, True, True)
+                x = _conv_bn(x, self["conv1"], self["bn1"], self._fold, True, 1)
             else:
                 x = module(x)
             if name in self.return_layers:
@@ -447,7 +530,7 @@ class BackboneBase(nn.Module):
 
     def forward(self, tensor_list: NestedTensor):
         x = tensor_list.tensors
-        if _inference_mode(self) and x.is_cuda and CHANNELS_LAST:
+        if (_inference_mode(self) or (_train_fold and self.training)) and x.is_cuda and CHANNELS_LAST:
             x = x.contiguous(memory_format=torch.channels_last)
         xs = self.body(x)
         m = tensor_list.mask

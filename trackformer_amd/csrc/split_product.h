@@ -20,16 +20,15 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // 8 pieces of
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // 4 pieces of one kind
 
 // ---- the split product, generic in the SCHEME SP (the template parameter of every kernel that uses it):
-//   SP = 2   bf16 (hi, mid) per operand:     three terms  a_mid.b_hi + a_hi.b_mid + a_hi.b_hi            dropped terms < 2^-16 of the product
 //   SP = 3   bf16 (hi, mid, lo) per operand: six terms    a_lo.b_hi + a_hi.b_lo + a_mid.b_mid + a_mid.b_hi + a_hi.b_mid + a_hi.b_hi
-//   SP = 16  fp16 (hi, lo) of both operands, three terms  a_lo.(b_hi 2^-11) + a_hi.b_lo + a_hi.b_hi
+//   SP = 16  fp16 (hi, lo) of both operands, three terms  a_lo.(b_hi 2^-11) + a_hi.b_lo + a_hi.b_hi      (the default)
+// Both are fp32-class; nothing cheaper exists in this library (the two-piece bf16 scheme -- three terms, product error < 2^-16 -- kept
+// the reference's track ids for 14 of 64 frames where fp32 keeps 59, profiles/r04_id_parity_64.txt, and was deleted in round 5).
 //
 // bf16, three pieces (round to nearest even at every step) carry all 24 significand bits of an fp32 number (hi 8, mid 8, lo 8; the
 // residuals x - hi and (x - hi) - mid are exact in fp32), and the six products kept are all those of weight >= 2^-16; the dropped
 // ones (mid.lo, lo.mid, lo.lo) are below 2^-24 of |a||b| -- half an ulp of the fp32 product the reference rounds to.  With fp32
-// accumulation on the matrix cores the six-term product is fp32 arithmetic in a different summation order.  The three-term bf16
-// product is the opt-in fast mode: on the 64-frame reference-Tracker fixture fp32 keeps the reference's track ids for 59 frames,
-// the three-term bf16 product for 14 (profiles/r04_id_parity_64.txt).
+// accumulation on the matrix cores the six-term product is fp32 arithmetic in a different summation order.
 //
 // fp16 (round 4): an fp16 piece carries 11 significand bits, so TWO pieces (hi = rne16(x), lo = rne16(x - hi), the residual
 // exact in fp32) carry 22 bits + the sign of lo: |x - hi - lo| <= 2^-23 |x| -- one bit short of fp32's own rounding -- and the
@@ -37,8 +36,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // 4 pieces of
 //   * the lo piece of a small number would fall into the subnormals.  It is therefore stored SCALED: lo' = rne16((x - hi) 2^11)
 //     has the magnitude of hi's last place times 2^11, normal whenever hi is, and its partner in the product is the weight's hi
 //     piece times 2^-11 -- made in registers from the hi fragment right before its MFMA (v_pk_mul_f16 by a power of two: exact; four
-//     instructions per fragment, which serves every row tile of the wave), so a weight is stored as TWO pieces like the
-//     three-term bf16 product's (the first version of this scheme stored the third operand: 1.5x the weight traffic and a
+//     instructions per fragment, which serves every row tile of the wave), so a weight is stored as TWO pieces (the first version of this scheme stored the third operand: 1.5x the weight traffic and a
 //     third more fragment registers -- 99.7 against 71.2 us in the fused feed-forward block, profiles/r04_f16_first_harness.txt);
 //   * weights are scaled per OUTPUT CHANNEL by the power of two t_n that puts the channel's largest |w| into [2^13, 2^14) (exact;
 //     a weight 2^-17 times the channel's largest still has all its bits, smaller ones an absolute error of 2^-39 of the largest);
@@ -47,8 +45,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;   // 4 pieces of
 //     2^-32 (hi subnormal, lo' picks up the residual).  An activation beyond 1.0e6 becomes inf -> (inf - inf) = NaN in lo': the
 //     output row is NaN, loudly, instead of silently saturated.
 // Measured against float64 on random operands (tools/experiments/f16_split.py): max |err| / sum |x||w| = 3.7e-8 for the
-// representation alone (fp32 rounding of the SUM, which the reference's sgemm has as well: 2.4e-7), six-term bf16 3.3e-9,
-// three-term bf16 2.2e-6.  Terms are issued smallest first.
+// representation alone (fp32 rounding of the SUM, which the reference's sgemm has as well: 2.4e-7), six-term bf16 3.3e-9.
+// Terms are issued smallest first.
 template <int SP> struct Split;
 // NA / NB: pieces of an activation / of a weight as STORED (LDS, packed image, piece tensors); NBX: weight operands of the terms (B
 // indexes them): the stored pieces [+ the one expand_weight() derives]

@@ -640,12 +640,13 @@ def conv3x3(x, w_taps, bias, relu, stride):
         return None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
-    halo = ks == 3 and stride == 1 and _conv_halo   # (the halo form of the stream route: its own split policy)
+    stream_route = (_conv_stream and _conv_stream_wins(n * ho * wo, cout) and cin % 64 == 0 and not (x.data_ptr() & 15)
+                    and n * h * w * cin * 4 < 0xC0000000 and (n * ho * wo + 256) * cout * 4 < 0xC0000000)
+    halo = ks == 3 and stride == 1 and _conv_halo and stream_route   # (the halo form of the stream route: its own split policy)
     ksplit = _conv_ksplit(n * ho * wo, ks * ks * cin, cout, _HALO_KSPLIT_POLICY if halo else None)
     if ks == 1 and (ksplit < _CONV1X1_MIN_PIECES or not _conv1x1_splitk):
         ksplit = 1
-    if (_conv_stream and _conv_stream_wins(n * ho * wo, cout) and cin % 64 == 0 and not (x.data_ptr() & 15)
-            and n * h * w * cin * 4 < 0xC0000000 and (n * ho * wo + 256) * cout * 4 < 0xC0000000):
+    if stream_route:
         packed = _packed_weight(w_taps, None)
         if packed is not None:
             with torch.cuda.device(x.device):
