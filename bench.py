@@ -50,9 +50,12 @@ The JSON line also carries
                    pure-CPU MSDeformAttn path (grid_sample, oracle/msda_grid_sample.py: "kind":
                    "reference-restated"); the C port of the kernels' arithmetic (oracle/msda_ref.c)
                    timed beside it; rank 0, N=1 only, a bounded sample.
-  step_only_fps / host_frames_fps -- one sequence, (1) plain Tracker.step() per frame without step_prepare: what an unmodified
-                   src/track.py loop of the reference gets from the drop-in; (2) the pipelined loop with the frames in pinned
-                   host memory, the upload inside the timed step.  `value` is the pipelined loop on HBM-resident frames.
+  step_only_fps / host_frames_fps / plain_step_fps -- one sequence: (1) step_finish(step_async(blob)) per frame, no look-ahead
+                   (= Tracker.step with tracker.deferred = False; HBM frames); (2) the pipelined loop with the frames in pinned
+                   host memory, the upload inside the timed step; (3) the reference's own loop, `for blob in frames:
+                   tracker.step(blob)` (src/track.py:130-134) on host frames -- what an UNMODIFIED caller gets: with the deferred
+                   association of Tracker.step (round 6, default) and with tracker.deferred = False.  `value` is the pipelined
+                   loop on HBM-resident frames.
   single_sequence_fps / multi_sequence_fps -- cfg2/4/5: the same steps with ONE sequence per GPU (no overlap of one
                    sequence's host-side association with another's forward) / with --sequences interleaved.
   precision     -- `value` is measured with the DEFAULT arithmetic of the package (fused.split_terms(); `dtype` and
@@ -124,7 +127,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default: 120 (cfg 1/2/4), 24 (cfg 5), 6 (cfg 3)")
-    ap.add_argument("--warmup", type=int, default=None, help="default: 8 (cfg 1/2/4/5), 2 (cfg 3)")
+    ap.add_argument("--warmup", type=int, default=None, help="default: 8 (cfg 1/2/4), 4 (cfg 3, cfg 5)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2")
     ap.add_argument("--min-seconds", type=float, default=2.0,
                     help="repeat the K-step set until this much timed work has accumulated")
@@ -178,7 +181,7 @@ def parse_args():
     if args.steps is None:
         args.steps = 6 if train else 24 if heavy else 120
     if args.warmup is None:
-        args.warmup = 2 if train else 4 if heavy else 8
+        args.warmup = 4 if train else 4 if heavy else 8   # (training: 2 steps left a one-off ~0.6 s stall of the first process on a fresh box inside the timed region, profiles/r06_train_step_breakdown.txt)
     return args
 
 
@@ -831,6 +834,8 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
     sequential.  (Round 2 used one thread per sequence: with the association leg at work they serialise on the GIL and
     four threads are slower than one, profiles/r03_sequences_sweep.txt.)"""
     trackers = [build_tracker(model, post, use_graph=not args.no_graph) for _ in range(n_seq)]
+    # (the look-ahead policy of dist_utils.track_sequences: not for multi-frame models with several sequences in flight)
+    look_ahead = not args.no_prepare and (n_seq == 1 or not getattr(model, "multi_frame_attention", False))
     seeder = TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds)
     frames = make_frames(device, cfg["size"], host=args.host_frames)
     streams = [torch.cuda.Stream(device) for _ in range(n_seq)]
@@ -845,7 +850,7 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
                     with torch.cuda.stream(streams[s]):
                         nxt = frames[(s + issued[s]) % len(frames)] if issued[s] < per_seq[s] else None
                         if handles[s] is not None:
-                            if nxt is not None and not args.no_prepare:
+                            if nxt is not None and look_ahead:
                                 # the image-only half of the next frame (backbone, encoder) goes to the GPU BEFORE the host
                                 # associates this one: Tracker.step_prepare -- a single sequence no longer leaves the GPU idle
                                 trackers[s].step_prepare(nxt, image_ready=not args.host_frames)   # (device frames: resident since before the run)
@@ -865,6 +870,43 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
     torch.cuda.synchronize()
     from trackformer_amd import runtime
     runtime.settle_heap()   # model, trackers and graphs exist: the cyclic collector need not walk them again
+    return timed_repeats(run_set, args.steps, world, device, args.min_seconds)
+
+
+def run_plain_step(cfg, args, device, world, model, post, margs, seeds=None, deferred=True):
+    """The reference's own loop, src/track.py:130-134: `for frame_data in seq_loader: tracker.step(frame_data)` -- ONE call per
+    frame, frames arriving in (pinned) host memory as a DataLoader hands them over, nothing else touches the tracker.  With the
+    deferred association of Tracker.step (round 6) this loop runs the pipelined schedule by itself.  The benchmark's re-seeding
+    (exactly cfg["tracks"] track queries in every step) happens where it does in run_tracking: inside the step, after the previous
+    frame's association and before this frame's track queries are built (a subclass hook; the call per frame stays step())."""
+    from trackformer_amd import config, runtime
+    from trackformer_amd.graphed import GraphedDetector
+    from trackformer_amd.tracker import Tracker
+    seeder = TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds)
+
+    class SeededTracker(Tracker):
+        def step_async(self, blob):
+            seeder.seed(self)
+            return super().step_async(blob)
+    detector = model if args.no_graph else GraphedDetector(model, bucket=1)
+    tracker = SeededTracker(detector, post, config.tracker_cfg(), False)
+    tracker.reset()
+    tracker.deferred = bool(deferred)
+    frames = make_frames(device, cfg["size"], host=True)
+    stream = torch.cuda.Stream(device)
+    count = [0]
+
+    def run_set(steps):
+        torch.cuda.set_device(device)
+        with torch.no_grad(), torch.cuda.stream(stream):
+            for _ in range(steps):
+                tracker.step(frames[count[0] % len(frames)])
+                count[0] += 1
+            tracker._flush_deferred()   # the last frame's association belongs to the timed region
+        stream.synchronize()
+    run_set(max(4, args.warmup))
+    torch.cuda.synchronize()
+    runtime.settle_heap()
     return timed_repeats(run_set, args.steps, world, device, args.min_seconds)
 
 
@@ -958,7 +1000,7 @@ def main():
             print(json.dumps(measure_roofline(device, head_dim=hd, patterns=("pert", "init", "local"))))
         return
     model, criterion, post, margs = build_model(cfg, device)
-    single = fp32_exact = fp32_exact_single = association = multi = step_only = host_frames_fps = None
+    single = fp32_exact = fp32_exact_single = association = multi = step_only = host_frames_fps = plain_step = None
     other_arith = {}
     n_seq = 1
     if cfg["kind"] == "track":
@@ -994,6 +1036,13 @@ def main():
             a_host.host_frames = True
             eh, rh = run_tracking(cfg, a_host, device, world, model, post, margs, 1, seeds)
             host_frames_fps = args.steps * rh * world / eh
+            # (3) the reference's own loop itself: tracker.step(blob) per frame on host frames, association deferred into the next
+            # step (the default) and not (tracker.deferred = False: step() returns after its association, as in round 5)
+            ep, rp = run_plain_step(cfg, args, device, world, model, post, margs, seeds, deferred=True)
+            es2, rs2 = run_plain_step(cfg, args, device, world, model, post, margs, seeds, deferred=False)
+            plain_step = {"deferred_association": round(args.steps * rp * world / ep, 3),
+                          "association_before_return": round(args.steps * rs2 * world / es2, 3),
+                          "loop": "for blob in frames: tracker.step(blob) -- src/track.py:130-134 of the reference; frames in pinned host memory"}
         if seeds is not None and rank == 0:
             association = association_stats(model, post, TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds),
                                             make_frames(device, cfg["size"]))
@@ -1097,6 +1146,7 @@ def main():
             "multi_sequence_fps": None if multi is None else {"sequences_per_gpu": max(1, args.sequences), "value": round(multi, 3)},
             "step_only_fps": None if step_only is None else round(step_only, 3),
             "host_frames_fps": None if host_frames_fps is None else round(host_frames_fps, 3),
+            "plain_step_fps": plain_step,
             "fp32_exact_fps": None if fp32_exact is None else round(fp32_exact, 3),
             "single_sequence_fp32_exact_fps": None if fp32_exact_single is None else round(fp32_exact_single, 3),
             **{_ARITH[a][1]: other_arith.get(_ARITH[a][1]) for a in (6, 16) if a != fused.split_terms() or not fused.split_linear_enabled()},

@@ -316,7 +316,7 @@ def test_full_size_well_conditioned_64_frames_every_id(dev, setup):
     _compare_wc(z, tracker, rows, active)
 
 
-def _run_wc_tracker_pipelined(case, dev, setup, n_frames, host_frames=False):
+def _run_wc_tracker_pipelined(case, dev, setup, n_frames, host_frames=False, unobserved=False):
     """The loop `bench.py` TIMES (run_tracking): step_async(t) -> step_prepare(t + 1) -> step_finish(t), the image-only half
     of frame t + 1 on GraphedDetector's side stream into alternating buffers while the host associates frame t.  Frames
     resident in HBM before the sequence starts (`image_ready`, the driver's line) or in pinned host memory (uploaded on the
@@ -337,14 +337,30 @@ def _run_wc_tracker_pipelined(case, dev, setup, n_frames, host_frames=False):
         torch.cuda.synchronize(dev)
         active, prepared = [], 0
         with torch.no_grad():
-            handle = tracker.step_async(blobs[0])
-            for i in range(len(blobs)):
-                if i + 1 < len(blobs):
-                    prepared += bool(tracker.step_prepare(blobs[i + 1], image_ready=not host_frames))
-                tracker.step_finish(handle)
-                active.append(len(tracker.tracks))
-                if i + 1 < len(blobs):
-                    handle = tracker.step_async(blobs[i + 1])
+            if unobserved:
+                # the reference's own loop (src/track.py:130-134): step() per frame and nothing else -- Tracker.step defers the
+                # association of frame t into step(t + 1), after the image-only half of frame t + 1 has been enqueued
+                orig_prepare = tracker.step_prepare
+
+                def counting_prepare(blob, **kw):
+                    nonlocal prepared
+                    ok = orig_prepare(blob, **kw)
+                    prepared += bool(ok)
+                    return ok
+                tracker.step_prepare = counting_prepare
+                for blob in blobs:
+                    tracker.step(blob)
+                    assert tracker.__dict__.get("_deferred_handle") is not None
+                active = None
+            else:
+                handle = tracker.step_async(blobs[0])
+                for i in range(len(blobs)):
+                    if i + 1 < len(blobs):
+                        prepared += bool(tracker.step_prepare(blobs[i + 1], image_ready=not host_frames))
+                    tracker.step_finish(handle)
+                    active.append(len(tracker.tracks))
+                    if i + 1 < len(blobs):
+                        handle = tracker.step_async(blobs[i + 1])
         torch.cuda.synchronize(dev)
     finally:
         fused.set_split_linear(prev_split)
@@ -366,6 +382,30 @@ def test_full_size_pipelined_tracker_64_frames_every_id(dev, frames):
                                                                 host_frames=frames == "host_frames")
     _compare_wc(z, tracker, rows, active)
     assert prepared >= 60, prepared
+
+
+def test_full_size_unobserved_step_loop_64_frames_every_id(dev):
+    """Round 6: what an UNMODIFIED reference caller gets -- `for blob in sequence: tracker.step(blob)` with host frames, as
+    src/track.py:130-134 drives it -- runs the pipelined schedule by itself (deferred association, Tracker.step): all 64 frames
+    of the well-conditioned sequence at 800x1333, every id, and the frames really were prepared ahead."""
+    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2_wc64.npz"))
+    n = len(z["active_per_frame"])
+    tracker, rows, _, prepared = _run_wc_tracker_pipelined("cfg2_full", dev, "graph_split_linear", n, host_frames=True, unobserved=True)
+    _compare_wc(z, tracker, rows, z["active_per_frame"].tolist())
+    assert prepared >= 60, prepared
+
+
+@pytest.mark.parametrize("loop", ["pipelined", "unobserved"])
+def test_full_size_multi_frame_tracker_prepared_ahead_matches_reference(dev, loop):
+    """Round 6: BASELINE cfg 4 with the image-only half of frame t + 1 (backbone, the encoder over frame t + 1 and over frame t's
+    backbone features) prepared ahead on the side stream -- the loop `bench.py --config cfg4` times, and the plain step() loop
+    with its deferred association -- 12 frames at 800x1333 against the reference's Tracker."""
+    z = np.load(os.path.join(GOLDEN, "full_tracker_cfg4.npz"))
+    n = len(z["active_per_frame"])
+    tracker, rows, active, prepared = _run_wc_tracker_pipelined("cfg4_full", dev, "graph_split_linear", n, host_frames=(loop == "unobserved"),
+                                                                unobserved=(loop == "unobserved"))
+    _compare_wc(z, tracker, rows, active if active is not None else z["active_per_frame"].tolist())
+    assert prepared >= n - 4, prepared   # (the first frame attends to itself; the graphs of a shape exist from its second sight on)
 
 
 @pytest.mark.parametrize("setup", ["eager", "graph_split_linear", "graph_tuned"])

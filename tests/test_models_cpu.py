@@ -178,7 +178,7 @@ def test_tracker_variants_match_reference(name, host_op):
     compare_variant_to_golden(name, tracker, rows, active, inactive, box_tol_px=0.05)
 
 
-def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None, prepare=False):
+def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None, prepare=False, unobserved=False):
     """Tracker.step over a sequence of tests/util_models.WC_TRACKER_CASES: the well-conditioned detector (the same seeded
     weights with um.shape_well_conditioned's planted circuit).  wrap: detector -> detector (e.g. GraphedDetector).
     prepare: the pipelined form -- step_async(t), step_prepare(t + 1), step_finish(t): the image-only half of the next
@@ -193,7 +193,23 @@ def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None, prepare=False):
     active, inactive = [], []
     blobs = um.tracker_sequence(n_frames=n_frames or frames)
     with torch.no_grad():
-        if prepare:
+        if unobserved:
+            # the reference's loop (src/track.py:130-134): step() per frame, nobody looks at the tracker in between -- the
+            # deferred association of Tracker.step (round 6) is outstanding after every step and runs inside the next one
+            outstanding = prepared = 0
+            orig_prepare = tracker.step_prepare
+
+            def counting_prepare(blob, **kw):
+                nonlocal prepared
+                ok = orig_prepare(blob, **kw)
+                prepared += bool(ok)
+                return ok
+            tracker.step_prepare = counting_prepare
+            for blob in blobs:
+                tracker.step(blob)
+                outstanding += tracker.__dict__.get("_deferred_handle") is not None
+            tracker.steps_outstanding, tracker.frames_prepared = outstanding, prepared
+        elif prepare:
             prepared = 0
             handle = tracker.step_async(blobs[0])
             for i in range(len(blobs)):
@@ -268,6 +284,48 @@ def test_image_only_half_of_the_forward_can_run_ahead(host_op):
     assert ahead[0].frames_prepared == 4
     np.testing.assert_array_equal(plain[1], ahead[1])
     assert plain[2] == ahead[2] and plain[3] == ahead[3]
+
+
+@pytest.mark.parametrize("name,n_frames", [("cfg2_wc", 5), ("cfg4_wc", 4)])
+def test_unobserved_step_loop_defers_the_association_and_files_the_same_tracks(name, n_frames, host_op):
+    """Round 6: `for blob in sequence: tracker.step(blob)` -- the reference's own loop, src/track.py:130-134 -- leaves every
+    frame's association outstanding until the next step() (which first enqueues ITS image-only half) or until somebody reads
+    the tracker; tracks, frames, boxes and scores are those of the step-by-step loop, bit for bit, and of the reference."""
+    plain = run_wc_tracker(name, n_frames=n_frames)
+    lazy = run_wc_tracker(name, n_frames=n_frames, unobserved=True)
+    assert lazy[0].steps_outstanding == n_frames and lazy[0].frames_prepared == n_frames - 1
+    np.testing.assert_array_equal(plain[1], lazy[1])
+    assert lazy[0].track_num == plain[0].track_num and lazy[0].num_reids == plain[0].num_reids
+    assert lazy[0].frame_index == plain[0].frame_index == n_frames
+    # state read or written from outside runs the outstanding association first
+    tracker = lazy[0]
+    blob = um.tracker_sequence(n_frames=n_frames + 1)[n_frames]
+    with torch.no_grad():
+        tracker.step(blob)
+    assert tracker.__dict__["_deferred_handle"] is not None
+    n_tracks = len(tracker.tracks)
+    assert tracker.__dict__["_deferred_handle"] is None and tracker.frame_index == n_frames + 1 and n_tracks > 0
+    with torch.no_grad():
+        tracker.step(blob)
+    tracker.tracks = []                      # (bench.py's re-seeding: a write must not be overwritten by the older frame)
+    assert tracker.__dict__["_deferred_handle"] is None and tracker.tracks == []
+    tracker.deferred = False
+    with torch.no_grad():
+        tracker.step(blob)
+    assert tracker.__dict__.get("_deferred_handle") is None
+
+
+def test_image_only_half_of_a_multi_frame_model_can_run_ahead(host_op):
+    """Round 6: the multi_frame model (cfg 4).  Its first half reads the previous frame's BACKBONE features (deformable_detr.py:
+    133-221 of the reference) -- results of the previous frame's first half, known when step_prepare(t + 1) runs between
+    step_async(t) and step_finish(t) (Tracker._upcoming_prev_features).  Every frame but the first (which attends to itself)
+    is prepared; tracks are those of the plain loop and of the reference's Tracker."""
+    plain = run_wc_tracker("cfg4_wc", n_frames=4)
+    ahead = run_wc_tracker("cfg4_wc", n_frames=4, prepare=True)
+    assert ahead[0].frames_prepared == 3
+    np.testing.assert_array_equal(plain[1], ahead[1])
+    assert plain[2] == ahead[2] and plain[3] == ahead[3]
+    compare_wc_to_golden("cfg4_wc", ahead[0], ahead[1], ahead[2], ahead[3], box_tol_px=0.05, n_frames=4)
 
 
 def run_mask_tracker(device="cpu", frames=3, lazy_masks=False, wrap=None, prepare=False):

@@ -217,6 +217,7 @@ def _inference_mode(module: nn.Module) -> bool:
 #   * a trainable block: the BN scale folded into the weight as an autograd op on the WEIGHT (Cout x Cin x k x k, not the feature map),
 #     the library convolution, then shift / residual / ReLU in ONE in-place pass whose backward is one threshold pass (_BiasAct).
 _train_fold = _os.environ.get("TF_TRAIN_FOLD", "1") != "0"
+_TRAIN_NOGRAD_LIBRARY = _os.environ.get("TF_TRAIN_FOLD", "1") == "lib"
 
 
 def set_train_fold(on: bool) -> bool:
@@ -290,10 +291,15 @@ def _conv_bn(x, conv: nn.Conv2d, bn: nn.Module, cache: _FoldCache, relu: bool, f
         if y.requires_grad:
             return _BiasAct.apply(y, shift, residual, relu)
         fold = 0   # (nothing here is differentiated and the block is not frozen either: cannot happen for a trainable weight)
+    if fold == 1 and isinstance(bn, FrozenBatchNorm2d) and conv.training and x.is_cuda and not getattr(fused._tls, "one_stream", 0):
+        with fused.one_stream():   # a training step: images rebuilt per step, one stream
+            return _conv_bn(x, conv, bn, cache, relu, fold, residual)
     if fold == 1 and isinstance(bn, FrozenBatchNorm2d):
         b = cache.get(conv, bn)
         if x.is_cuda:
             split_ok = _split_route_allowed(conv)   # False: this shape keeps the library convolution (TF_CONV_SPLIT_SKIP)
+            if _TRAIN_NOGRAD_LIBRARY and conv.training and conv.weight.requires_grad:
+                split_ok = False   # (A/B aid: a trainable layer's packed image is rebuilt after every optimiser step)
             if (split_ok and _conv1x1_split and cache.weight2d is not None and residual is None and conv.stride == (1, 1)
                     and conv.padding == (0, 0) and conv.groups == 1 and CHANNELS_LAST
                     and fused.conv1x1_wants_split_k(x.shape[0] * x.shape[2] * x.shape[3], conv.in_channels, conv.out_channels)):

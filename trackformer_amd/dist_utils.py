@@ -183,13 +183,17 @@ def track_sequences(make_tracker, sequences, device, interleave=1):
     pending = [None] * lanes       # handle of the frame in flight
     nothing = object()
     ahead = [nothing] * lanes      # the blob behind the frame in flight, once it has been looked at (None: the sequence ended)
+    # look-ahead policy (measured on MI355X, profiles/r06_bench_cfg4_*.json): with several sequences in flight the other lanes
+    # already fill the GPU while one associates; for the multi-frame models -- whose image-only half is two encoder passes -- a
+    # second stream per lane then costs more than it gains (3 lanes: 191 frames/s without, 170 with; 1 lane: 111 -> 151 with)
+    look_ahead = lanes == 1 or not getattr(getattr(trackers[0], "obj_detector", None), "multi_frame_attention", False)
 
     def advance(k):
         """Finish the lane's frame in flight, then launch its next frame (of the same or, at its end, the next sequence)."""
         if pending[k] is not None:
             if lane_seq[k] is not None and ahead[k] is nothing:
                 ahead[k] = next(lane_seq[k][1], None)
-                if ahead[k] is not None and hasattr(trackers[k], "step_prepare"):
+                if ahead[k] is not None and look_ahead and hasattr(trackers[k], "step_prepare"):
                     trackers[k].step_prepare(ahead[k])   # GPU: the next frame's backbone + encoder; host: this frame's association
             trackers[k].step_finish(pending[k])
             pending[k] = None

@@ -184,8 +184,24 @@ def _publish_barrier(device):
     """Cached weight images are built on the caller's current stream and then published on the tensor for EVERY stream
     (one tracker thread per sequence, each on its own HIP stream, share one model): wait for the building stream before
     publishing, so that a second thread's first GEMM cannot read a half-written image.  Once per weight."""
+    if getattr(_tls, "one_stream", 0) and os.environ.get("TF_TRAIN_PUBLISH_BARRIER") != "1":
+        return   # (a training step: the images are rebuilt every step for the stream that uses them next, see one_stream())
     if not torch.cuda.is_current_stream_capturing():
         torch.cuda.current_stream(device).synchronize()
+
+
+class one_stream:
+    """with fused.one_stream(): weight images built inside are used by the calling thread's current stream only -- no host
+    synchronisation when they are published.  The previous-frame pass of a TRAINING step (no_grad, inference kernels: backbone.
+    _fold_mode) rebuilds the images of every trainable convolution after every optimiser step; ~80 stream synchronisations per
+    step otherwise."""
+
+    def __enter__(self):
+        _tls.one_stream = getattr(_tls, "one_stream", 0) + 1
+
+    def __exit__(self, *exc):
+        _tls.one_stream -= 1
+        return False
 
 
 def _packed_weight(weight, rows):

@@ -120,7 +120,18 @@ class GraphedDetector:
         m = self.model
         # (a mask head reads the features and the encoder memory: both are results of the image-only half, DETRSegmBase.forward
         # takes them through `encoded=` since round 6)
-        return hasattr(m, "encode_frame") and not self._multi_frame()
+        # (multi-frame models, round 6: the previous frame's BACKBONE features are results of the previous frame's image-only half --
+        # the first half of frame t + 1 depends on the images t + 1 and t only; the first frame of a sequence, which attends to
+        # itself, keeps the single graph)
+        return hasattr(m, "encode_frame")
+
+    def _split_call(self, prev_features):
+        return self._splittable() and (not self._multi_frame() or prev_features is not None)
+
+    _PREV_LEVELS = 3   # encode_frame reads prev_features[-3:] (deformable_detr.py:133 of the reference)
+
+    def _prev_tail(self, prev_features):
+        return list(prev_features)[-self._PREV_LEVELS:]
 
     def _side_stream(self, dev):
         st = self._side.get(dev)
@@ -139,13 +150,18 @@ class GraphedDetector:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 entry["img"] = img.to(dev, copy=True)
+                entry["prev"] = None
                 for _ in range(2):
-                    warm = self.model.encode_frame(entry["img"], None)
+                    warm = self.model.encode_frame(entry["img"], entry["prev"])
+                    if self._multi_frame() and entry["prev"] is None:
+                        # static copies of the previous frame's features this slot's graph reads: filled before every replay from
+                        # wherever they are (the other slot's results, a caller's tensors) -- _feed_prev
+                        entry["prev"] = self._clone_features(self._prev_tail(warm["features_all"]))
             cur.wait_stream(side)
             del warm
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-                entry["state"] = self.model.encode_frame(entry["img"], None)
+                entry["state"] = self.model.encode_frame(entry["img"], entry["prev"])
         entry["graph"] = graph
         return entry
 
@@ -174,6 +190,9 @@ class GraphedDetector:
             return None
         if dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
+        multi = self._multi_frame()
+        if multi and prev_features is None:
+            return None   # the first frame of a sequence attends to itself: the single graph of __call__
         slots = self._enc.get((tuple(img.shape), dev))
         if slots is None:
             return None
@@ -182,14 +201,21 @@ class GraphedDetector:
             slots[i] = self._capture_encoder(img, dev)
         a = slots[i]
         side, cur = self._side_stream(dev), torch.cuda.current_stream(dev)
-        if img.is_cuda and not image_ready:
+        # the previous frame's features: results of the other slot's run on the side stream (ordered by the stream), or somebody
+        # else's tensors, produced on the current stream
+        foreign_prev = multi and not self._is_slot_result(slots[1 - i], prev_features)
+        if (img.is_cuda and not image_ready) or foreign_prev:
             side.wait_stream(cur)
         if a["read"]:
             side.wait_event(a["free"])      # the decoder half that last read this slot's results is done with them
         with torch.cuda.stream(side):
             a["img"].copy_(img, non_blocking=True)
+            if multi:
+                self._feed_prev(a, self._prev_tail(prev_features))
             a["graph"].replay()
             a["done"].record(side)
+        if multi:
+            a["prev_id"] = self._prev_id(prev_features)
         if img.is_cuda:
             img.record_stream(side)
         a["ran"] = True
@@ -203,8 +229,8 @@ class GraphedDetector:
         return alias
 
     def _capture(self, img, target, prev_features, slot=0):
-        if self._splittable():
-            return self._capture_decoder(img, target, slot)
+        if self._split_call(prev_features):
+            return self._capture_decoder(img, target, slot, prev_features)
         entry = {"img": img.clone()}
         static_target = None
         if target is not None:
@@ -250,7 +276,19 @@ class GraphedDetector:
         entry["graph"] = graph
         return entry
 
-    def _capture_decoder(self, img, target, slot):
+    @staticmethod
+    def _prev_id(prev_features):
+        """What identifies a set of previous-frame features for "the image-only half prepare() ran used THESE"."""
+        t = list(prev_features)[-1].tensors
+        return (t.data_ptr(), t._version)
+
+    @staticmethod
+    def _is_slot_result(a, prev_features):
+        if a is None or "state" not in a:
+            return False
+        return list(prev_features)[-1].tensors.data_ptr() == a["state"]["features_all"][-1].tensors.data_ptr()
+
+    def _capture_decoder(self, img, target, slot, prev_features=None):
         akey = (tuple(img.shape), img.device)
         torch.cuda.synchronize(img.device)   # (a prepared image-only half of this slot may be in flight on the side stream)
         slots = self._enc.setdefault(akey, [None, None])
@@ -274,6 +312,8 @@ class GraphedDetector:
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 a["img"].copy_(img)
+                if a["prev"] is not None:
+                    self._feed_prev(a, self._prev_tail(prev_features))
                 a["graph"].replay()      # the state the decoder half reads (static buffers of the encoder graph)
                 for _ in range(2):
                     warm = self.model(a["img"], static_target, None, encoded=a["state"])
@@ -363,6 +403,9 @@ class GraphedDetector:
             if (prepared[0] is not img or slots is None or slots[prepared[1]] is None
                     or slots[prepared[1]].get("generation") != prepared[2]):
                 prepared = None
+            elif self._multi_frame() and (prev_features is None
+                                          or slots[prepared[1]].get("prev_id") != self._prev_id(prev_features)):
+                prepared = None   # prepared against other previous-frame features than this call's: encoded again below
         if not self._capturable(img, target, prev_features):
             self._wait_static_image(img)   # (also consumes the preparation: the eager forward encodes the image itself)
             res = self.model(img, target, prev_features)
@@ -410,6 +453,8 @@ class GraphedDetector:
                 cur.wait_event(a["done"])   # the side stream's last run into this slot (the one prepare() started, or a stale one)
             if prepared is None:
                 a["img"].copy_(img, non_blocking=True)
+                if a["prev"] is not None:
+                    self._feed_prev(a, self._prev_tail(prev_features))
                 a["graph"].replay()
         else:
             entry["img"].copy_(img, non_blocking=True)

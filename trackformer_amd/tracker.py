@@ -73,6 +73,11 @@ class Tracker:
 
         self._logger = logger if logger is not None else (lambda *log_strs: None)
         self._verbose = verbose
+        # DEFAULT since round 6 (TF_DEFERRED_STEP=0 / tracker.deferred = False: step() returns after its association, as the
+        # reference's does): step() returns once the frame's GPU work is ENQUEUED and runs the frame's association at the start of
+        # the next step(), after that frame's image-only half has been enqueued (see step()).
+        self.deferred = os.environ.get("TF_DEFERRED_STEP", "1") != "0" and not generate_attention_maps   # (the attention hooks
+        # file the maps of the LAST forward: the next frame's image-only half must not run before this frame's are read)
 
     # ------------------------------------------------------------------ state
     @property
@@ -104,9 +109,12 @@ class Tracker:
         return torch.stack([_HsHistory._row(it) for it in items], dim=0)
 
     def reset(self, hard=True):
+        self._flush_deferred()   # (a frame whose association is still outstanding belongs to the results a soft reset keeps)
         self.tracks = []
         self.inactive_tracks = []
         self._prev_features = deque([None], maxlen=self.prev_frame_dist)
+        self._inflight_features = None
+        self._prepared = None
         if hard:
             self.track_num = 0
             self._results = {}
@@ -268,33 +276,85 @@ class Tracker:
     # ------------------------------------------------------------------ one frame
     def step(self, blob):
         """Process one frame.  blob: {'img' [1,3,H,W], 'orig_size' [1,2] (h,w), 'size' [1,2],
-        'dets' [1,K,4] xyxy public detections} as produced by the reference's sequence datasets."""
-        self.step_finish(self.step_async(blob))
+        'dets' [1,K,4] xyxy public detections} as produced by the reference's sequence datasets.
+
+        Deferred association (round 6, default; `tracker.deferred = False` / TF_DEFERRED_STEP=0: everything before returning).
+        The reference's loop is `for frame_data in seq_loader: tracker.step(frame_data)` (src/track.py:130-134): nothing reads the
+        tracker between two steps.  step(t) therefore returns when frame t's forward, post-processing and device -> host copy are
+        ENQUEUED; step(t + 1) first enqueues the image-only half of frame t + 1 (step_prepare: backbone + encoder need no tracks),
+        THEN waits for frame t's copy and associates it on the host -- while the GPU is already on frame t + 1 -- and then
+        enqueues frame t + 1's decoder half with the track queries that association produced.  Same operations on the same
+        data in the same order per frame as step_finish(step_async(blob)); the schedule is the pipelined loop's
+        (step_async(t) -> step_prepare(t + 1) -> step_finish(t)) without the caller knowing the next frame in advance.  Every
+        read of the tracker's state from outside (tracks, inactive_tracks, track_num, frame_index, num_reids, results /
+        get_results(), reset()) first runs the outstanding association, so an observer never sees the difference."""
+        if not self.deferred:
+            self.step_finish(self.step_async(blob))
+            return
+        d = self.__dict__
+        d["_busy"] = True
+        try:
+            handle = d.get("_deferred_handle")
+            if handle is not None:
+                self.step_prepare(blob)          # frame t + 1's image-only half: next to frame t's decoder half and association
+                d["_deferred_handle"] = None
+                self.step_finish(handle)
+            d["_deferred_handle"] = self.step_async(blob)
+        finally:
+            d["_busy"] = False
+
+    def _flush_deferred(self):
+        """Run the association a deferred step() left outstanding (no-op otherwise)."""
+        d = self.__dict__
+        handle = d.get("_deferred_handle")
+        if handle is None or d.get("_busy"):
+            return
+        d["_deferred_handle"] = None
+        d["_busy"] = True
+        try:
+            self.step_finish(handle)
+        finally:
+            d["_busy"] = False
 
     def step_prepare(self, blob, image_ready=False):
         """Optional, BEFORE step_finish of the previous frame: enqueue the image-only half of `blob`'s forward (backbone,
         input projections, encoder -- GraphedDetector.prepare, or the model's encode_frame) so that the GPU works on this
         frame while the host still associates the previous one; the following step_async(blob) / step(blob) of the SAME
         blob then runs the decoder half only.  Results are those of step(): the image-only half does not depend on the
-        tracks.  Returns whether anything was enqueued (multi-frame models: no -- their first half needs the previous frame's
-        features)."""
+        tracks.  Multi-frame models (round 6): their first half also reads the previous frame's BACKBONE features -- results of
+        the previous frame's first half, so they are known here as well (_upcoming_prev_features).  Returns whether anything was
+        enqueued (not for the first frame of a multi-frame sequence, which attends to itself)."""
         det = self.obj_detector
         prep = getattr(det, "prepare", None)
         self._prepared = None
+        multi = bool(getattr(det, "multi_frame_attention", False))
+        prev = self._upcoming_prev_features() if multi else None
+        if multi and prev is None:
+            return False
         if prep is not None:
             # GraphedDetector: the half runs on the wrapper's side stream, NEXT TO the previous frame's decoder half (a host
             # image is uploaded on that stream too); `image_ready`: a device-resident blob['img'] is complete already
-            img = prep(blob['img'], None, device=self.device, image_ready=image_ready)
+            img = prep(blob['img'], prev, device=self.device, image_ready=image_ready)
             if img is not None:
                 self._prepared = (blob['img'], img, None)
                 return True
             return False
         img = blob['img'].to(self.device, non_blocking=True)
-        if (hasattr(det, "encode_frame") and not getattr(det, "multi_frame_attention", False)
-                and not det.training and not torch.is_grad_enabled()):
-            self._prepared = (blob['img'], img, det.encode_frame(img, None))
+        if hasattr(det, "encode_frame") and not det.training and not torch.is_grad_enabled():
+            self._prepared = (blob['img'], img, det.encode_frame(img, prev), prev)
             return True
         return False
+
+    def _upcoming_prev_features(self):
+        """`self._prev_features[0]` as the NEXT step_async will see it: step_prepare runs between step_async(t) and
+        step_finish(t), and it is step_finish(t) that files frame t's features (tracker.py:331 of the reference appends them at
+        the end of step)."""
+        inflight = self.__dict__.get("_inflight_features")
+        if inflight is None:
+            return self._prev_features[0]
+        future = deque(self._prev_features, maxlen=self.prev_frame_dist)
+        future.append(inflight)   # (distance 1: the in-flight features themselves, aliases of the detector's buffers as they are
+        return future[0]          # in step(); a longer distance reads an older entry, which step_finish made its own)
 
     def step_async(self, blob):
         """First half of step(): builds the track queries, ENQUEUES the detector forward, the post-processing and the frame's
@@ -318,7 +378,7 @@ class Tracker:
         device = self.device
         prepared, self._prepared = getattr(self, "_prepared", None), None
         encoded = None
-        if prepared is not None and prepared[0] is blob['img']:
+        if prepared is not None and prepared[0] is blob['img'] and (len(prepared) < 4 or prepared[3] is self._prev_features[0]):
             img, encoded = prepared[1], prepared[2]     # step_prepare(blob) ran the image-only half for this very frame
         else:
             img = blob['img'].to(device, non_blocking=True)
@@ -383,6 +443,7 @@ class Tracker:
                 host[:packed_dev.shape[0]].copy_(packed_dev, non_blocking=True)
                 event = torch.cuda.Event()
                 event.record(torch.cuda.current_stream(packed_dev.device))
+        self._inflight_features = features   # (filed by step_finish; step_prepare of the next frame reads them before that)
         return dict(blob=blob, outputs=outputs, features=features, hs_embeds=hs_embeds, results=results, result=result,
                     orig_size=orig_size, orig_hw=(orig_h, orig_w), num_prev_track=num_prev_track, device=device,
                     packed_dev=packed_dev, host=host, event=event)
@@ -576,6 +637,7 @@ class Tracker:
             # are exactly what the next call wants back; older slots of the deque must own their data
             features = self.obj_detector._clone_features(features)
         self._prev_features.append(features)
+        self._inflight_features = None
         if self.reid_sim_only:
             self.tracks_to_inactive(self.tracks)
 
@@ -618,6 +680,7 @@ class Tracker:
     def results(self):
         """{track_id: {frame_idx: {'bbox': xyxy px, 'score', 'obj_ind', ['mask'], ['attention_map']}}} (tracker.py:523-541 of
         the reference): the frames filed since the last access are merged in here."""
+        self._flush_deferred()
         pending, self._pending_results = self._pending_results, []
         for frame, ids, pos, scores, obj_inds, extras in pending:
             for i, tid in enumerate(ids):
@@ -641,6 +704,30 @@ class Tracker:
     def get_results(self):
         """{track_id: {frame_idx: {'bbox': xyxy px, 'score', 'obj_ind', ['mask'], ['attention_map']}}}"""
         return self.results
+
+
+def _guarded_state(name):
+    """Tracker state that a deferred step() (see Tracker.step) may not have brought up to date yet: reading it from outside a
+    step first runs the outstanding association."""
+    key = "_state_" + name
+
+    def get(self):
+        d = self.__dict__
+        if d.get("_deferred_handle") is not None and not d.get("_busy"):
+            self._flush_deferred()
+        return d[key]
+
+    def put(self, value):
+        d = self.__dict__
+        if d.get("_deferred_handle") is not None and not d.get("_busy"):
+            self._flush_deferred()   # (a write from outside -- re-seeding the tracks -- must not be overwritten by the older frame)
+        d[key] = value
+    return property(get, put)
+
+
+for _name in ("tracks", "inactive_tracks", "track_num", "frame_index", "num_reids"):
+    setattr(Tracker, _name, _guarded_state(_name))
+del _name
 
 
 class _LabelMap:
