@@ -57,6 +57,19 @@ int tf_add_layernorm_f32(const float *x, const float *res, const float *gamma, c
 int tf_box_refine_f32(const float *delta, const float *ref, float *out, int64_t rows, int ref_dim, float eps, void *stream);
 
 /*
+ * The per-frame post-processing of the tracker in one pass (reference: models/deformable_detr.py DeformablePostProcess.forward
+ * -- sigmoid, best class and its score, boxes cxcywh -> xyxy scaled to the image -- followed by models/tracker.py:300-303
+ * clip_boxes_to_image and the stacking of what the association reads).  logits [Q, C], boxes [Q, 4] (cx, cy, w, h in [0, 1]),
+ * out [Q, 6] = (x0, y0, x1, y1, score, label as float):
+ *   score = max_c sigmoid(logits[q, c]), label = the first c that attains it;
+ *   x0 = (cx - 0.5 w) img_w, y0 = (cy - 0.5 h) img_h, x1 = (cx + 0.5 w) img_w, y1 = (cy + 0.5 h) img_h, every operation rounded
+ *   on its own (no fused multiply-add: the arithmetic of the separate ATen kernels), then, if clip != 0, clamped to [0, img_w] /
+ *   [0, img_h].  Replaces ~17 element-wise launches on [Q, 4] tensors per frame.
+ */
+int tf_postprocess_pack_f32(const float *logits, const float *boxes, float *out, int64_t Q, int C, float img_h, float img_w,
+                            int clip, void *stream);
+
+/*
  * GroupNorm of a channels-innermost activation: x [N, HW, C] (row n starts at x + n * x_image_stride floats; the storage of
  * a channels_last NCHW tensor or a token-major projection output), G groups of C / G consecutive channels, statistics
  * per (image, group) with the biased variance and eps inside the square root (torch.nn.GroupNorm); out may alias x.

@@ -53,6 +53,8 @@ def lib():
     L.tf_bias_relu_maxpool_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, vp]
     L.tf_box_refine_f32.restype = ci
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
+    L.tf_postprocess_pack_f32.restype = ci
+    L.tf_postprocess_pack_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, ctypes.c_float, ci, vp]
     for fn in (L.tf_groupnorm_nhwc_f32, L.tf_groupnorm_relu_nhwc_f32):
         fn.restype = ci
         fn.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
@@ -459,6 +461,17 @@ def groupnorm_nhwc(x, gamma, beta, G, eps=1e-5, relu=False):
     rc = fn(_p(x), _p(gamma), _p(beta), _p(out), _p(ws), n, hw, c, G, ctypes.c_float(eps), hw * c, hw * c, None)
     if rc != 0:
         raise RuntimeError("tf_groupnorm_nhwc_f32: status %d" % rc)
+    return out
+
+
+def postprocess_pack(logits, boxes, img_h, img_w, clip=True):
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    out = np.empty((logits.shape[0], 6), dtype=np.float32)
+    rc = lib().tf_postprocess_pack_f32(_p(logits), _p(boxes), _p(out), logits.shape[0], logits.shape[1], ctypes.c_float(img_h),
+                                       ctypes.c_float(img_w), 1 if clip else 0, None)
+    if rc != 0:
+        raise RuntimeError("tf_postprocess_pack_f32: status %d" % rc)
     return out
 
 

@@ -580,6 +580,31 @@ def test_box_refine_fused(ref_dim):
     np.testing.assert_allclose(emu_lib.box_refine(delta, ref), 1 / (1 + np.exp(-v)), atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("classes,clip", [(1, True), (20, True), (3, False)])
+def test_postprocess_pack_fused(classes, clip):
+    """tf_postprocess_pack_f32 (round 6) against the module chain it replaces in the tracker: DeformablePostProcess.forward
+    (sigmoid, best class, boxes cxcywh -> xyxy scaled to the image), clip_boxes_to_image, the stacking of boxes / score / label.
+    Boxes bit for bit (the same operations, each rounded on its own), labels equal (first class that attains the maximum, ties
+    included), scores to an ulp of the exponential."""
+    import torch
+    from trackformer_amd.box_ops import clip_boxes_to_image
+    from trackformer_amd.deformable_detr import DeformablePostProcess
+    g = torch.Generator().manual_seed(classes)
+    q, h, w = 403, 1080.0, 1920.0
+    logits = torch.randn(1, q, classes, generator=g) * 3
+    if classes > 1:
+        logits[0, :7, 1] = logits[0, :7, 0]            # ties: the first class wins
+        logits[0, 7:12] = 40.0                         # saturated sigmoids: all classes tie at 1.0
+    boxes = torch.rand(1, q, 4, generator=g)
+    boxes[0, :20, 2:] *= 3                             # boxes that overflow the image on every side
+    res = DeformablePostProcess()({'pred_logits': logits, 'pred_boxes': boxes}, torch.tensor([[int(h), int(w)]]))[0]
+    want_boxes = clip_boxes_to_image(res['boxes'], (int(h), int(w))) if clip else res['boxes']
+    got = emu_lib.postprocess_pack(logits[0].numpy(), boxes[0].numpy(), h, w, clip)
+    assert np.array_equal(got[:, :4], want_boxes.numpy())
+    assert np.array_equal(got[:, 5].astype(np.int64), res['labels'].numpy())
+    np.testing.assert_allclose(got[:, 4], res['scores'].numpy(), rtol=3e-7, atol=0)
+
+
 # ------------------------------------------------------------------ one-launch feed-forward block (opt-in, ffn_fused.hip)
 def _ffn_case(M, F, seed, D=256):
     rng = np.random.default_rng(seed)

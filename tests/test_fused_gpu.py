@@ -297,3 +297,34 @@ def test_fp16_product_range_contract_is_loud_and_has_a_way_out(dev):
         fused.set_split_linear(prev_split)
         fused.set_split_terms(prev_terms)
     assert fused.six_term_routes() == 0
+
+
+@pytest.mark.parametrize("classes,clip", [(1, True), (20, True), (3, False)])
+def test_postprocess_pack_equals_the_module_chain(dev, classes, clip):
+    """tf_postprocess_pack_f32 (round 6: what Tracker.step_async enqueues after the detector for a model without a mask head)
+    against the chain it replaces ON THE DEVICE -- DeformablePostProcess.forward, clip_boxes_to_image, the stacking -- boxes bit
+    for bit, labels equal (ties: the first class), scores to an ulp of the exponential; and the switch."""
+    from trackformer_amd import fused
+    from trackformer_amd.box_ops import clip_boxes_to_image
+    from trackformer_amd.deformable_detr import DeformablePostProcess
+    g = torch.Generator().manual_seed(classes)
+    q, h, w = 400, 1080, 1920
+    logits = torch.randn(1, q, classes, generator=g) * 3
+    if classes > 1:
+        logits[0, :7, 1] = logits[0, :7, 0]
+        logits[0, 7:12] = 40.0
+    boxes = torch.rand(1, q, 4, generator=g)
+    boxes[0, :20, 2:] *= 3
+    logits, boxes = logits.to(dev), boxes.to(dev)
+    res = DeformablePostProcess()({'pred_logits': logits, 'pred_boxes': boxes}, torch.tensor([[h, w]], device=dev))[0]
+    want_boxes = clip_boxes_to_image(res['boxes'], (h, w)) if clip else res['boxes']
+    got = fused.postprocess_pack(logits[0], boxes[0], h, w, clip)
+    assert got is not None and got.shape == (q, 6)
+    assert torch.equal(got[:, :4], want_boxes)
+    assert torch.equal(got[:, 5].long(), res['labels'])
+    assert torch.allclose(got[:, 4], res['scores'], rtol=3e-7, atol=0)
+    prev = fused.set_postprocess_fused(False)
+    try:
+        assert fused.postprocess_pack(logits[0], boxes[0], h, w, clip) is None
+    finally:
+        fused.set_postprocess_fused(prev)

@@ -163,6 +163,53 @@ def test_graphed_detector_prepare_twice_and_eager_fallbacks(dev):
     assert torch.allclose(out['pred_boxes'], want[0], atol=1e-5)
 
 
+def test_graphed_multi_frame_prepare_with_foreign_and_mismatched_previous_features(dev):
+    """Round 6, GraphedDetector.prepare for multi-frame models: (1) the previous frame's features may be anybody's tensors
+    (cloned: not a slot's results) -- they are copied into the slot's static buffers after the side stream has waited for the
+    stream that produced them; (2) a preparation made against OTHER previous-frame features than the following call's is
+    discarded and the image-only half runs again with the call's; (3) the ordinary chain prepare(features of the last call) ->
+    call replays the decoder half only.  Every output equals the eager forward's."""
+    from trackformer_amd import config, factory
+    from trackformer_amd.graphed import GraphedDetector
+    model, post, args = um.build("cfg4_multi_frame_tracking", factory.build_model, config.make_args, device=dev)
+    model.to(dev).tracking()
+    det = GraphedDetector(model)
+    frames = [b['img'].to(dev) for b in um.tracker_sequence(n_frames=6)]
+
+    def close(a, b):
+        return torch.allclose(a['pred_boxes'], b['pred_boxes'], atol=1e-5) and torch.allclose(a['pred_logits'], b['pred_logits'], atol=1e-4)
+    with torch.no_grad():
+        feats = [model(f, None, None)[2] for f in frames]                       # every frame's own backbone features (eager)
+        want = {(i, j): model(frames[i], None, feats[j])[0] for i, j in [(1, 0), (2, 1), (3, 0), (3, 2), (4, 3), (5, 4)]}
+        want = {k: {n: v[n].clone() for n in ('pred_boxes', 'pred_logits')} for k, v in want.items()}
+        prev = None
+        for i in range(3):                                                      # frames 0-2: the graphs of this shape come to exist
+            out, _, prev, _, _ = det(frames[i], None, prev)
+        assert close(out, want[(2, 1)])
+        # (1) foreign previous features
+        foreign = det._clone_features(feats[2])
+        p = det.prepare(frames[3], foreign, image_ready=True)
+        assert p is not None
+        out, _, prev3, _, _ = det(p, None, foreign)
+        assert close(out, want[(3, 2)])
+        # (2) prepared against frame 2's features, called with frame 0's
+        p = det.prepare(frames[3], foreign, image_ready=True)
+        other = det._clone_features(feats[0])
+        out, _, _, _, _ = det(p, None, other)
+        assert close(out, want[(3, 0)])
+        # (3) the tracker's chain: the features the last call returned (a slot's static buffers) go into the next prepare
+        out, _, prev3, _, _ = det(frames[3], None, det._clone_features(feats[2]))
+        for i in (4, 5):
+            p = det.prepare(frames[i], prev3, image_ready=True)
+            assert p is not None
+            gen = det._generation
+            out, _, prev3, _, _ = det(p, None, prev3)
+            assert det._generation == gen                                       # nothing was prepared again inside the call
+            assert close(out, want[(i, i - 1)]), i
+        # the first frame of a sequence (no previous features) is never prepared
+        assert det.prepare(frames[0], None, image_ready=True) is None
+
+
 @pytest.mark.parametrize("lazy", [False, True], ids=["full_head", "lazy_head"])
 def test_tracker_with_mask_head_matches_reference(dev, lazy):
     """cfg-5 path (mask head + Tracker) on the GPU against the reference's own Tracker / mask head / PostProcessSegm on CPU

@@ -253,6 +253,31 @@ box_refine_kernel(const float *__restrict__ delta, const float *__restrict__ ref
     out[i] = 1.f / (1.f + expf(-v));
 }
 
+// ---- the tracker's per-frame post-processing (include/tf_fused.h tf_postprocess_pack_f32): one thread per query
+__global__ void __launch_bounds__(256)
+postprocess_pack_kernel(const float *__restrict__ logits, const float *__restrict__ boxes, float *__restrict__ out, long long Q,
+                        int C, float img_h, float img_w, int clip)
+{
+#pragma clang fp contract(off)
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    float best = 1.f / (1.f + expf(-logits[q * C]));
+    int label = 0;
+    for (int c = 1; c < C; ++c) {
+        const float s = 1.f / (1.f + expf(-logits[q * C + c]));
+        if (s > best) { best = s; label = c; }   // (the first class that attains the maximum, as torch.max)
+    }
+    const float4 b = *reinterpret_cast<const float4 *>(boxes + q * 4);
+    const float hw = 0.5f * b.z, hh = 0.5f * b.w;
+    float x0 = (b.x - hw) * img_w, y0 = (b.y - hh) * img_h, x1 = (b.x + hw) * img_w, y1 = (b.y + hh) * img_h;
+    if (clip) {
+        x0 = fminf(fmaxf(x0, 0.f), img_w); x1 = fminf(fmaxf(x1, 0.f), img_w);
+        y0 = fminf(fmaxf(y0, 0.f), img_h); y1 = fminf(fmaxf(y1, 0.f), img_h);
+    }
+    float *o = out + q * 6;
+    o[0] = x0; o[1] = y0; o[2] = x1; o[3] = y1; o[4] = best; o[5] = (float)label;
+}
+
 // ---- out = maxpool3x3/s2/p1(relu(x + bias[c])) on channels_last activations: the stem of the backbone after its 7 x 7
 // convolution (reference: models/backbone.py:45-55 FrozenBatchNorm2d shift, torchvision ResNet.relu + .maxpool).  x + bias and
 // ReLU are monotone per channel, so max_i relu(x_i + b) == relu(max_i(x_i) + b) bit for bit: ONE pass reads the convolution's
@@ -326,6 +351,18 @@ int tf_box_refine_f32(const float *delta, const float *ref, float *out, int64_t 
     if (blocks > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
     hipLaunchKernelGGL(box_refine_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), delta, ref,
                        out, (long long)rows, ref_dim, eps);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+int tf_postprocess_pack_f32(const float *logits, const float *boxes, float *out, int64_t Q, int C, float img_h, float img_w,
+                            int clip, void *stream)
+{
+    if (!logits || !boxes || !out) return TF_MSDA_ERR_NULL_POINTER;
+    if (Q <= 0 || C <= 0 || Q > (1LL << 31)) return TF_MSDA_ERR_BAD_DIMS;
+    if (reinterpret_cast<uintptr_t>(boxes) & 15) return TF_MSDA_ERR_BAD_DIMS;
+    const long long blocks = (Q + 255) / 256;
+    hipLaunchKernelGGL(postprocess_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), logits, boxes,
+                       out, (long long)Q, C, img_h, img_w, clip);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 

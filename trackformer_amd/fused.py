@@ -901,6 +901,34 @@ def box_refine(delta, reference_points):
     return out
 
 
+# DEFAULT since round 6 (TF_POSTPROCESS_FUSED=0 / set_postprocess_fused(False): the post-processor module + clip + cat, ~17
+# element-wise ATen launches on [queries, 4] tensors outside the HIP graph, every frame): what the tracker's association reads
+# -- scaled, clipped xyxy boxes, best score, label -- in ONE launch (tf_postprocess_pack_f32).
+_postprocess_fused = os.environ.get("TF_POSTPROCESS_FUSED", "1") != "0"
+
+
+def set_postprocess_fused(on):
+    global _postprocess_fused
+    prev, _postprocess_fused = _postprocess_fused, bool(on)
+    return prev
+
+
+def postprocess_pack(logits, boxes, img_h, img_w, clip):
+    """[Q, 6] = (x0, y0, x1, y1, score, label) of DeformablePostProcess + clip_boxes_to_image for ONE image: logits [Q, C],
+    boxes [Q, 4] cxcywh in [0, 1]; the arithmetic of the separate ATen kernels, operation by operation.  None when not applicable."""
+    if not (_postprocess_fused and logits.is_cuda and logits.dtype == torch.float32 and boxes.dtype == torch.float32
+            and logits.dim() == 2 and boxes.dim() == 2 and boxes.shape == (logits.shape[0], 4) and logits.shape[0] > 0
+            and logits.shape[1] > 0 and logits.is_contiguous() and boxes.is_contiguous() and boxes.device == logits.device
+            and boxes.data_ptr() % 16 == 0):
+        return None
+    with torch.cuda.device(logits.device):
+        out = torch.empty((logits.shape[0], 6), dtype=torch.float32, device=logits.device)
+        rc = _cabi.lib().tf_postprocess_pack_f32(logits.data_ptr(), boxes.data_ptr(), out.data_ptr(), logits.shape[0], logits.shape[1],
+                                                 float(img_h), float(img_w), 1 if clip else 0, _stream(logits.device))
+    _cabi.check(rc, "tf_postprocess_pack_f32")
+    return out
+
+
 def module_linear(module, x, inference):
     """module(x) for an nn.Linear: the split product on the GPU inference path when enabled, else the module."""
     if inference and _split_linear:

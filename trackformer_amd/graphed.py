@@ -208,6 +208,11 @@ class GraphedDetector:
             side.wait_stream(cur)
         if a["read"]:
             side.wait_event(a["free"])      # the decoder half that last read this slot's results is done with them
+        if multi and not foreign_prev and slots[1 - i]["ran"]:
+            # the other slot's results are this run's previous-frame features: written by its last image-only run -- on the side
+            # stream when it was prepared (ordered by the stream: the wait is free), on the CALLER's stream when it was not
+            # (the first frames of a sequence, a bucket's first sight)
+            side.wait_event(slots[1 - i]["done"])
         with torch.cuda.stream(side):
             a["img"].copy_(img, non_blocking=True)
             if multi:
@@ -456,6 +461,8 @@ class GraphedDetector:
                 if a["prev"] is not None:
                     self._feed_prev(a, self._prev_tail(prev_features))
                 a["graph"].replay()
+                a["done"].record(cur)       # (this slot's results now come from a run on the caller's stream: prepare() of the
+                a["ran"] = True             # other slot, which reads them as previous-frame features, waits for this event)
         else:
             entry["img"].copy_(img, non_blocking=True)
         if entry["prev"] is not None:

@@ -383,7 +383,7 @@ class Tracker:
         else:
             img = blob['img'].to(device, non_blocking=True)
         orig_size_host = blob['orig_size'].detach().cpu()
-        orig_size = orig_size_host.to(device, non_blocking=True)
+        orig_size = None   # (its device copy: made when a post-processor module is called, not for the fused post-processing)
         orig_h, orig_w = int(orig_size_host[0, 0]), int(orig_size_host[0, 1])
 
         target = None
@@ -412,8 +412,22 @@ class Tracker:
             outputs, _, features, _, _ = self.obj_detector(img, target, self._prev_features[0])
         hs_embeds = outputs['hs_embed'][0]
 
-        results = self.obj_detector_post['bbox'](outputs, orig_size)
-        result = results[0]
+        packed_dev = None
+        post = self.obj_detector_post['bbox']
+        if ("segm" not in self.obj_detector_post and type(post).__name__ == "DeformablePostProcess"
+                and type(post).__module__.startswith("trackformer_amd.") and outputs['pred_logits'].shape[0] == 1):
+            # sigmoid + best class + box scaling (DeformablePostProcess.forward), clip_boxes_to_image and the stacking below in
+            # ONE launch (fused.postprocess_pack: the same operations, each rounded on its own); nothing else of the
+            # post-processor's result is read for a model without a mask head
+            from . import fused
+            packed_dev = fused.postprocess_pack(outputs['pred_logits'][0], outputs['pred_boxes'][0], orig_h, orig_w,
+                                                clip=not self.obj_detector.overflow_boxes)
+        if packed_dev is not None:
+            results, result = None, {}
+        else:
+            orig_size = orig_size_host.to(device, non_blocking=True)
+            results = self.obj_detector_post['bbox'](outputs, orig_size)
+            result = results[0]
         if "segm" in self.obj_detector_post:
             # The reference resizes the masks of ALL queries to the original image size here (tracker.py:315-319:
             # 400 x 800 x 1333 floats per frame) and then keeps those of the surviving tracks.  A query's mask
@@ -422,13 +436,13 @@ class Tracker:
             # the step (_resolve_masks) -- same values, a fraction of the work.
             result['masks'] = _MaskRows(len(result['scores']))
 
-        boxes_dev = result['boxes']
-        if not self.obj_detector.overflow_boxes:
-            boxes_dev = clip_boxes_to_image(boxes_dev, (orig_h, orig_w))
-
-        # the frame's single device -> host transfer: enqueued here, awaited in step_finish
-        packed_dev = torch.cat([boxes_dev, result['scores'][:, None],
-                                result['labels'][:, None].to(boxes_dev.dtype)], dim=1)
+        if packed_dev is None:
+            boxes_dev = result['boxes']
+            if not self.obj_detector.overflow_boxes:
+                boxes_dev = clip_boxes_to_image(boxes_dev, (orig_h, orig_w))
+            packed_dev = torch.cat([boxes_dev, result['scores'][:, None],
+                                    result['labels'][:, None].to(boxes_dev.dtype)], dim=1)
+        # packed_dev: the frame's single device -> host transfer: enqueued here, awaited in step_finish
         event = host = None
         if packed_dev.device.type == "cuda":
             host = self.__dict__.get("_packed_host")
@@ -559,6 +573,8 @@ class Tracker:
         gather = sel.to(device, non_blocking=True) if (det_masks is not None or det_maps is not None) else None
         aux_results = None
         if self._verbose:
+            if orig_size is None:
+                orig_size = blob['orig_size'].detach().to(device)
             aux_results = [self.obj_detector_post['bbox'](out, orig_size)[0]
                            for out in outputs['aux_outputs']]
         first_obj_row = hs_embeds.shape[0] - nq          # the new tracks reference their rows of this frame's embeddings
