@@ -83,6 +83,27 @@ int tf_groupnorm_relu_nhwc_f32(const float *x, const float *gamma, const float *
                                int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream);
 
 /*
+ * The FPN merge of the mask head in one pass (reference: models/detr_segmentation.py:142-156 `_expand(adapter(fpn), Q) +
+ * F.interpolate(x, size=fpn.shape[-2:], mode="nearest")`): out[n, y, x, c] = low[n, ys, xs, c] + fpn[n / q_per_image, y, x, c] with
+ * ys = min(floorf(y * (float)h / H), h - 1), xs likewise (torch's legacy "nearest" index).  low [N, h, w, C], fpn [N / q_per_image, H,
+ * W, C], out [N, H, W, C] -- the storage of channels_last NCHW tensors; C % 4 == 0, 16-byte aligned.  The reference's two passes
+ * write and re-read the up-sampled tensor (1.1 GB per 128 queries at the finest level of an 800 x 1333 frame).
+ */
+int tf_upsample_add_nhwc_f32(const float *low, const float *fpn, float *out, int N, int q_per_image, int h, int w, int H, int W, int C,
+                             void *stream);
+
+/*
+ * The end of the mask head in one pass over the last hidden activation (reference: models/detr_segmentation.py:157-160
+ * `out_lay(F.relu(gn5(x)))`, a 3 x 3 convolution to ONE channel, padding 1): statistics of x [N, H, W, C] per (image, group) as
+ * tf_groupnorm_nhwc_f32 computes them (workspace: 2 * N * G doubles, zeroed by the call), then out[n, y, x] = bias + sum over the
+ * 3 x 3 taps and C channels of relu(gn(x))[n, y + dy, x + dx, c] * weight[(dy, dx), c] in fp32 (zero outside the image); the
+ * normalised activation is never written.  weight [9, C] tap-major (the [1, C, 3, 3] weight permuted to [3, 3, C]); C in {16, 32},
+ * G divides C; 16-byte aligned pointers.
+ */
+int tf_groupnorm_relu_conv3x3_c1_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *weight, float bias,
+                                          float *out, double *workspace, int N, int H, int W, int C, int G, float eps, void *stream);
+
+/*
  * THE SPLIT PRODUCT (every matrix-core kernel below; trackformer_amd/csrc/split_product.h).  fp32 operands are cut into 16-bit
  * pieces (round to nearest even, residuals exact in fp32) and a product x . w is formed from v_mfma_f32_32x32x16_{bf16,f16}
  * terms with fp32 accumulation, smallest terms first.  The reference computes these layers in fp32 (nn.Linear / Conv2d;

@@ -55,6 +55,10 @@ def lib():
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_postprocess_pack_f32.restype = ci
     L.tf_postprocess_pack_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, ctypes.c_float, ci, vp]
+    L.tf_upsample_add_nhwc_f32.restype = ci
+    L.tf_upsample_add_nhwc_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
+    L.tf_groupnorm_relu_conv3x3_c1_nhwc_f32.restype = ci
+    L.tf_groupnorm_relu_conv3x3_c1_nhwc_f32.argtypes = [vp, vp, vp, vp, ctypes.c_float, vp, vp, ci, ci, ci, ci, ci, ctypes.c_float, vp]
     for fn in (L.tf_groupnorm_nhwc_f32, L.tf_groupnorm_relu_nhwc_f32):
         fn.restype = ci
         fn.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ctypes.c_float, ctypes.c_int64, ctypes.c_int64, vp]
@@ -472,6 +476,34 @@ def postprocess_pack(logits, boxes, img_h, img_w, clip=True):
                                        ctypes.c_float(img_w), 1 if clip else 0, None)
     if rc != 0:
         raise RuntimeError("tf_postprocess_pack_f32: status %d" % rc)
+    return out
+
+
+def upsample_add(low, fpn, q_per_image):
+    """low [N, h, w, C], fpn [N / q_per_image, H, W, C] (channels innermost) -> [N, H, W, C]."""
+    low = np.ascontiguousarray(low, dtype=np.float32)
+    fpn = np.ascontiguousarray(fpn, dtype=np.float32)
+    n, h, w, c = low.shape
+    _, H, W, _ = fpn.shape
+    out = np.empty((n, H, W, c), dtype=np.float32)
+    rc = lib().tf_upsample_add_nhwc_f32(_p(low), _p(fpn), _p(out), n, q_per_image, h, w, H, W, c, None)
+    if rc != 0:
+        raise RuntimeError("tf_upsample_add_nhwc_f32: status %d" % rc)
+    return out
+
+
+def groupnorm_relu_conv3x3_c1(x, gamma, beta, weight, bias, groups, eps=1e-5):
+    """x [N, H, W, C], weight [9, C] tap-major -> [N, H, W]."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    gamma, beta = np.ascontiguousarray(gamma, dtype=np.float32), np.ascontiguousarray(beta, dtype=np.float32)
+    weight = np.ascontiguousarray(weight, dtype=np.float32)
+    n, H, W, c = x.shape
+    out = np.empty((n, H, W), dtype=np.float32)
+    ws = np.empty(2 * n * groups, dtype=np.float64)
+    rc = lib().tf_groupnorm_relu_conv3x3_c1_nhwc_f32(_p(x), _p(gamma), _p(beta), _p(weight), ctypes.c_float(bias), _p(out), _p(ws), n, H, W,
+                                                     c, groups, ctypes.c_float(eps), None)
+    if rc != 0:
+        raise RuntimeError("tf_groupnorm_relu_conv3x3_c1_nhwc_f32: status %d" % rc)
     return out
 
 

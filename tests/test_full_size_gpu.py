@@ -638,7 +638,8 @@ def test_conv1x1_split_k(dev, shape, cout, stride):
 
 @pytest.mark.parametrize("terms", [6, 16], ids=["six_terms", "fp16_pieces"])
 @pytest.mark.parametrize("shape,cout,ks,stride", [((1, 64, 200, 334), 64, 3, 1), ((1, 256, 100, 167), 256, 3, 2), ((1, 512, 25, 42), 512, 3, 1),
-                                                  ((2, 128, 37, 53), 160, 3, 1), ((1, 1024, 50, 84), 2048, 1, 2)])
+                                                  ((2, 128, 37, 53), 160, 3, 1), ((1, 1024, 50, 84), 2048, 1, 2),
+                                                  ((3, 32, 100, 167), 16, 3, 1), ((2, 288, 25, 42), 128, 3, 1)])   # (the mask head's lay5 / lay2: halo form only)
 def test_conv3x3_split_at_resnet_shapes(dev, shape, cout, ks, stride, terms):
     """split_conv3_kernel (buffer-resource fetches: a tap outside the image reads zeros from beyond num_records; DESIGN.md
     section 4.4) at ResNet-50's shapes of the 800 x 1333 frame -- borders on all four sides, the last row block partial, the

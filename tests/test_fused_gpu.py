@@ -328,3 +328,41 @@ def test_postprocess_pack_equals_the_module_chain(dev, classes, clip):
         assert fused.postprocess_pack(logits[0], boxes[0], h, w, clip) is None
     finally:
         fused.set_postprocess_fused(prev)
+
+
+@pytest.mark.parametrize("shape,out_size,qpi", [((6, 32, 25, 42), (50, 84), 3), ((4, 64, 50, 84), (100, 167), 4), ((2, 16, 100, 167), (200, 334), 1)])
+def test_upsample_add_equals_interpolate_plus_add(dev, shape, out_size, qpi):
+    """tf_upsample_add_nhwc_f32 (round 6, the mask head's FPN merge) against detr_segmentation.MaskHeadSmallConv._merge on the
+    device, bit for bit (84 -> 167 columns: the nearest index is not x / 2)."""
+    from trackformer_amd import fused
+    from trackformer_amd.detr_segmentation import MaskHeadSmallConv
+    g = torch.Generator().manual_seed(shape[1])
+    low = torch.randn(*shape, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    fpn = torch.randn(shape[0] // qpi, shape[1], *out_size, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    want = MaskHeadSmallConv._merge(low, fpn, qpi)
+    got = fused.upsample_add(low, fpn, qpi)
+    assert got is not None and got.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("c,groups,hw,n", [(16, 8, (200, 334), 5), (32, 8, (37, 65), 3), (16, 8, (9, 37), 2)])
+def test_groupnorm_relu_conv_to_one_channel(dev, c, groups, hw, n):
+    """tf_groupnorm_relu_conv3x3_c1_nhwc_f32 (round 6, the end of the mask head: out_lay(relu(gn5(x)))) against the modules in
+    float64 on the device, and against the library's own GroupNorm kernel + fp32 convolution at the same tolerance."""
+    from trackformer_amd import fused
+    g = torch.Generator().manual_seed(c + groups)
+    x = (torch.randn(n, c, *hw, generator=g) * 2 + 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    gn = torch.nn.GroupNorm(groups, c).to(dev)
+    conv = torch.nn.Conv2d(c, 1, 3, padding=1).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(c, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(c, generator=g) * 0.2)
+        want = torch.nn.functional.conv2d(torch.relu(torch.nn.functional.group_norm(x.double(), groups, gn.weight.double(), gn.bias.double(), gn.eps)),
+                                          conv.weight.double(), conv.bias.double(), padding=1)
+        lib32 = conv(torch.relu(gn(x)))
+        got = fused.groupnorm_relu_conv3x3_c1(x, gn, conv)
+    assert got is not None and got.shape == (n, 1, *hw)
+    scale = float(want.abs().max())
+    err, err_lib = float((got.double() - want).abs().max()) / scale, float((lib32.double() - want).abs().max()) / scale
+    print("gn + relu + conv %d -> 1 at %s: max err / max |y| %.2e (library fp32 modules: %.2e)" % (c, hw, err, err_lib))
+    assert err < 2e-6 and err < 4 * err_lib + 1e-7

@@ -230,6 +230,87 @@ groupnorm_apply_kernel(const float *__restrict__ x, const double *__restrict__ w
     }
 }
 
+// ---- the FPN merge of the mask head (include/tf_fused.h tf_upsample_add_nhwc_f32): one thread per (output pixel, 4 channels)
+__global__ void __launch_bounds__(256)
+upsample_add_nhwc_kernel(const float *__restrict__ low, const float *__restrict__ fpn, float *__restrict__ out, int q_per_image,
+                         int h, int w, int H, int W, int C4, float sy, float sx, long long total)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % C4);
+        const long long p = i / C4;
+        const int x = (int)(p % W);
+        const long long q = p / W;
+        const int y = (int)(q % H);
+        const int n = (int)(q / H);
+        const int ys = min((int)floorf((float)y * sy), h - 1), xs = min((int)floorf((float)x * sx), w - 1);
+        const f32x4_t a = reinterpret_cast<const f32x4_t *>(low)[(((long long)n * h + ys) * w + xs) * C4 + c];
+        const f32x4_t b = reinterpret_cast<const f32x4_t *>(fpn)[(((long long)(n / q_per_image) * H + y) * W + x) * C4 + c];
+        reinterpret_cast<f32x4_t *>(out)[i] = a + b;
+    }
+}
+
+// ---- GroupNorm + ReLU + 3 x 3 convolution to one channel (include/tf_fused.h tf_groupnorm_relu_conv3x3_c1_nhwc_f32): a workgroup
+// owns 8 x 32 output pixels of one image; their 10 x 34 halo is normalised on its way into LDS (zeros outside the image: the
+// convolution pads the NORMALISED activation), one thread per output pixel.  A pixel's channels sit 4 floats apart from the next
+// pixel's (pitch C + 4): the 16 lanes of a ds_read_b128 cycle read neighbouring pixels, 20 (36) banks apart -- no two on a bank.
+template <int C>
+__global__ void __launch_bounds__(256)
+gn_relu_conv3x3_c1_kernel(const float *__restrict__ x, const double *__restrict__ ws, const float *__restrict__ gamma,
+                          const float *__restrict__ beta, const float *__restrict__ weight, float bias, float *__restrict__ out, int H,
+                          int W, int G, float eps)
+{
+    constexpr int TY = 8, TX = 32, HY = TY + 2, HX = TX + 2, C4 = C / 4, PITCH = C + 4;
+    __shared__ __attribute__((aligned(16))) float s_in[HY * HX * PITCH];
+    __shared__ __attribute__((aligned(16))) float s_w[9 * C];
+    __shared__ float s_mean[C], s_rstd[C];   // per CHANNEL (its group's statistics)
+    const int n = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * TX;
+    const int cpg = C / G;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const double cnt = (double)H * (double)W * (double)cpg;
+        const double mean = ws[(long long)n * 2 * G + 2 * g] / cnt;
+        double var = ws[(long long)n * 2 * G + 2 * g + 1] / cnt - mean * mean;   // biased, as torch.nn.GroupNorm
+        if (var < 0.0) var = 0.0;
+        s_mean[c] = (float)mean;
+        s_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    for (int i = threadIdx.x; i < 9 * C; i += blockDim.x) s_w[i] = weight[i];
+    __syncthreads();
+    const f32x4_t *xp = reinterpret_cast<const f32x4_t *>(x + (long long)n * H * W * C);
+    for (int i = threadIdx.x; i < HY * HX * C4; i += blockDim.x) {
+        const int q = i % C4, pix = i / C4;
+        const int py = y0 - 1 + pix / HX, px = x0 - 1 + pix % HX;
+        f32x4_t y = {0.f, 0.f, 0.f, 0.f};
+        if (py >= 0 && py < H && px >= 0 && px < W) {
+            const f32x4_t v = xp[((long long)py * W + px) * C4 + q];
+            const f32x4_t ga = reinterpret_cast<const f32x4_t *>(gamma)[q], be = reinterpret_cast<const f32x4_t *>(beta)[q];
+            // the expression of groupnorm_apply_kernel, operation by operation
+            y.x = (v.x - s_mean[4 * q]) * s_rstd[4 * q] * ga.x + be.x;
+            y.y = (v.y - s_mean[4 * q + 1]) * s_rstd[4 * q + 1] * ga.y + be.y;
+            y.z = (v.z - s_mean[4 * q + 2]) * s_rstd[4 * q + 2] * ga.z + be.z;
+            y.w = (v.w - s_mean[4 * q + 3]) * s_rstd[4 * q + 3] * ga.w + be.w;
+            y.x = y.x < 0.f ? 0.f : y.x;
+            y.y = y.y < 0.f ? 0.f : y.y;
+            y.z = y.z < 0.f ? 0.f : y.z;
+            y.w = y.w < 0.f ? 0.f : y.w;
+        }
+        *reinterpret_cast<f32x4_t *>(&s_in[pix * PITCH + 4 * q]) = y;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int oy = y0 + ty, ox = x0 + tx;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float *ip = &s_in[((ty + t / 3) * HX + tx + t % 3) * PITCH];
+#pragma unroll
+        for (int q = 0; q < C4; ++q)
+            acc += *reinterpret_cast<const f32x4_t *>(ip + 4 * q) * *reinterpret_cast<const f32x4_t *>(&s_w[t * C + 4 * q]);
+    }
+    if (oy < H && ox < W) out[((long long)n * H + oy) * W + ox] = ((acc.x + acc.y) + (acc.z + acc.w)) + bias;
+}
+
 // ---- iterative box refinement of the decoder (models/deformable_transformer.py:331-343 of the reference):
 //   ref_dim 4: new = sigmoid(delta + inverse_sigmoid(ref))
 //   ref_dim 2: new[:2] = sigmoid(delta[:2] + inverse_sigmoid(ref)), new[2:] = sigmoid(delta[2:])
@@ -363,6 +444,45 @@ int tf_postprocess_pack_f32(const float *logits, const float *boxes, float *out,
     const long long blocks = (Q + 255) / 256;
     hipLaunchKernelGGL(postprocess_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), logits, boxes,
                        out, (long long)Q, C, img_h, img_w, clip);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+int tf_upsample_add_nhwc_f32(const float *low, const float *fpn, float *out, int N, int q_per_image, int h, int w, int H, int W, int C,
+                             void *stream)
+{
+    if (!low || !fpn || !out) return TF_MSDA_ERR_NULL_POINTER;
+    if (N <= 0 || q_per_image <= 0 || (N % q_per_image) || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3))
+        return TF_MSDA_ERR_BAD_DIMS;
+    if (!aligned16(low) || !aligned16(fpn) || !aligned16(out)) return TF_MSDA_ERR_BAD_DIMS;
+    const long long total = (long long)N * H * W * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(upsample_add_nhwc_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), low, fpn, out,
+                       q_per_image, h, w, H, W, C / 4, (float)h / (float)H, (float)w / (float)W, total);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+int tf_groupnorm_relu_conv3x3_c1_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *weight, float bias,
+                                          float *out, double *workspace, int N, int H, int W, int C, int G, float eps, void *stream)
+{
+    if (!x || !gamma || !beta || !weight || !out || !workspace) return TF_MSDA_ERR_NULL_POINTER;
+    if (N <= 0 || N > 65535 || H <= 0 || W <= 0 || (C != 16 && C != 32) || G <= 0 || (C % G) != 0) return TF_MSDA_ERR_BAD_DIMS;
+    if ((long long)H * W >= (1LL << 31)) return TF_MSDA_ERR_BAD_DIMS;
+    if (!aligned16(x) || !aligned16(gamma) || !aligned16(beta) || (reinterpret_cast<uintptr_t>(workspace) & 7)) return TF_MSDA_ERR_BAD_DIMS;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int HW = H * W;
+    const unsigned n_ws = 2u * (unsigned)N * (unsigned)G;
+    hipLaunchKernelGGL(groupnorm_zero_kernel, dim3((n_ws + 255) / 256), dim3(256), 0, s, workspace, n_ws);   // (a kernel, not a memset node)
+    if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    const unsigned sblocks = (unsigned)((HW + kGnRowsPerBlock - 1) / kGnRowsPerBlock);
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(sblocks, (unsigned)N), dim3(256), 0, s, x, workspace, HW, C, G, (long long)HW * C);
+    const dim3 grid((unsigned)((W + 31) / 32), (unsigned)((H + 7) / 8), (unsigned)N);
+    if (C == 16)
+        hipLaunchKernelGGL(gn_relu_conv3x3_c1_kernel<16>, grid, dim3(256), 0, s, x, (const double *)workspace, gamma, beta, weight, bias,
+                           out, H, W, G, eps);
+    else
+        hipLaunchKernelGGL(gn_relu_conv3x3_c1_kernel<32>, grid, dim3(256), 0, s, x, (const double *)workspace, gamma, beta, weight, bias,
+                           out, H, W, G, eps);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 

@@ -1023,6 +1023,12 @@ int halo_dispatch(const StreamCall &c, hipStream_t s)
     const int f = forced_ti();
     const long long pieces = c.ksplit > 1 ? c.ksplit : 1;
     const bool big = (long long)((c.M + 127) / 128) * ((c.N + 255) / 256) * pieces >= 2LL * num_cus();
+    // (<= 32 output channels -- the mask head's lay4 / lay5: 32 / 16 at up to 200 x 334 pixels per query --: one column tile, the four
+    // waves split the rows; the 64-column shapes leave two of the four waves multiplying padding)
+    // 128-row blocks whatever the launch size: at Cin <= 64 a block's life is one or two slices -- cold halo, nine taps of weight
+    // fragments from L2, epilogue -- and two resident blocks per CU overlap that better than one of twice the rows (MI355X, 128
+    // queries: 32 -> 16 at 200 x 334 902 vs 1 101 us, 64 -> 32 at 100 x 167 402 vs 515; tools/experiments/mask_head_convs.py)
+    if (c.N <= 32) return (f >= 2) ? launch_halo<SP, 2, 1, 1>(c, s) : launch_halo<SP, 1, 1, 1>(c, s);
     if (c.N <= 64) return (f ? f >= 2 : big) ? launch_halo<SP, 2, 1, 2>(c, s) : launch_halo<SP, 1, 1, 2>(c, s);
     if (c.N <= 128) return (f ? f >= 4 : big) ? launch_halo<SP, 4, 1, 4>(c, s) : launch_halo<SP, 2, 1, 4>(c, s);
     return launch_halo<SP, 2, 2, 4>(c, s);
@@ -1173,8 +1179,11 @@ extern "C" int tf_conv_packed_f32(const float *x, const void *w_packed, const fl
 {
     if (!x || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
     const int sp = split_scheme(terms);
-    if (nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % 64) != 0 || (stride != 1 && stride != 2) || (ks != 1 && ks != 3) ||
-        sp == 0 || ksplit < 1 || ksplit > 64)
+    // (the stream form walks pairs of 32-deep slices: Cin % 64; the halo form -- stride-1 3 x 3 -- any number of them: Cin % 32, which
+    // the mask head's lay2 (288 channels) and lay5 (32) need)
+    const bool halo = ks == 3 && stride == 1 && halo_enabled();
+    if (nimg <= 0 || hin <= 0 || win <= 0 || cin <= 0 || cout <= 0 || (cin % (halo ? 32 : 64)) != 0 || (stride != 1 && stride != 2) ||
+        (ks != 1 && ks != 3) || sp == 0 || ksplit < 1 || ksplit > 64)
         return TF_MSDA_ERR_BAD_DIMS;
     if (ksplit > 1 && !workspace) return TF_MSDA_ERR_NULL_POINTER;
     const int pad = ks == 3 ? 1 : 0;
@@ -1189,7 +1198,7 @@ extern "C" int tf_conv_packed_f32(const float *x, const void *w_packed, const fl
     }
     if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
     StreamCall c{x, static_cast<const u32x4 *>(w_packed), bias, residual, y, (int)M, ks * ks * cin, cout, relu, true, cv, workspace, ksplit};
-    if (ks == 3 && stride == 1 && halo_enabled())   // the halo form: every input pixel staged once per channel slice, not once per tap
+    if (halo)   // the halo form: every input pixel staged once per channel slice, not once per tap
         return sp == 3 ? halo_dispatch<3>(c, static_cast<hipStream_t>(stream)) : halo_dispatch<16>(c, static_cast<hipStream_t>(stream));
     return stream_dispatch_scheme<true>(sp, c, static_cast<hipStream_t>(stream));
 }

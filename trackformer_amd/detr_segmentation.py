@@ -164,6 +164,17 @@ def set_mask_head_split(on):
     return prev
 
 
+# DEFAULT since round 6 (TF_MASK_HEAD_FUSED_TAIL=0 / set_mask_head_fused_tail(False)): the FPN merges and the end of the mask head
+# through their own one-pass kernels (fused.upsample_add, fused.groupnorm_relu_conv3x3_c1) on the split-product route.
+_mask_head_fused_tail = os.environ.get("TF_MASK_HEAD_FUSED_TAIL", "1") != "0"
+
+
+def set_mask_head_fused_tail(on):
+    global _mask_head_fused_tail
+    prev, _mask_head_fused_tail = _mask_head_fused_tail, bool(on)
+    return prev
+
+
 class MaskHeadSmallConv(nn.Module):
     """Small FPN-style convolutional head with GroupNorm: [image features | attention maps] at stride
     16 (deformable; 32 for plain DETR) -> one mask logit map per query at the stride of fpns[2]."""
@@ -275,14 +286,26 @@ class MaskHeadSmallConv(nn.Module):
         x = (y_att.view(batch, num_queries, *y_att.shape[1:]) + y_img[:, None]).flatten(0, 1)
         x = F.relu(self.gn1(x))
         if split:
+            from . import fused
             n, c, h, wd = x.shape
             cin_pad = -(-c // 32) * 32
             xp = x.new_zeros(n, h, wd, cin_pad)                                      # channels innermost, zero tail
             xp[..., :c] = x.permute(0, 2, 3, 1)
             x = self._conv_gn_relu(xp.permute(0, 3, 1, 2), self.lay2, self.gn2)
             for conv, gn, feat in ((self.lay3, self.gn3, feats[0]), (self.lay4, self.gn4, feats[1]), (self.lay5, self.gn5, feats[2])):
-                x = self._merge(x, feat, num_queries)
-                x = self._conv_gn_relu(x.contiguous(memory_format=torch.channels_last), conv, gn)
+                # round 6: nearest up-sampling + the broadcast add of the adapter's output in ONE pass (tf_upsample_add_nhwc_f32; the
+                # two ATen passes write and re-read the up-sampled tensor: 1.1 GB per 128 queries at the finest level)
+                merged = fused.upsample_add(x, feat, num_queries) if _mask_head_fused_tail else None
+                x = merged if merged is not None else self._merge(x, feat, num_queries).contiguous(memory_format=torch.channels_last)
+                if conv is self.lay5 and _mask_head_fused_tail:
+                    # ... and the end of the head -- gn5 + ReLU + out_lay (16 -> 1) -- in one pass over lay5's raw output
+                    # (tf_groupnorm_relu_conv3x3_c1_nhwc_f32): the normalised activation is never written, no library convolution
+                    # (MIOpen ran a Winograd kernel between two layout transposes here: ~0.65 ms per 128 queries)
+                    y = fused.conv3x3(x, self._taps(conv, conv.in_channels), conv.bias, False, 1)
+                    out = None if y is None else fused.groupnorm_relu_conv3x3_c1(y, gn, self.out_lay)
+                    if out is not None:
+                        return out
+                x = self._conv_gn_relu(x, conv, gn)
             return self.out_lay(x)
         x = F.relu(self.gn2(self.lay2(x)))
         x = self._merge(x, feats[0], num_queries)

@@ -656,7 +656,9 @@ def conv3x3(x, w_taps, bias, relu, stride):
         return None
     pad = 1 if ks == 3 else 0
     ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
-    stream_route = (_conv_stream and _conv_stream_wins(n * ho * wo, cout) and cin % 64 == 0 and not (x.data_ptr() & 15)
+    # (the stream form takes Cin % 64; its halo form -- stride-1 3 x 3 -- Cin % 32: the mask head's 288- and 32-channel layers)
+    cin_ok = cin % 64 == 0 or (ks == 3 and stride == 1 and _conv_halo and cin % 32 == 0)
+    stream_route = (_conv_stream and _conv_stream_wins(n * ho * wo, cout) and cin_ok and not (x.data_ptr() & 15)
                     and n * h * w * cin * 4 < 0xC0000000 and (n * ho * wo + 256) * cout * 4 < 0xC0000000)
     halo = ks == 3 and stride == 1 and _conv_halo and stream_route   # (the halo form of the stream route: its own split policy)
     ksplit = _conv_ksplit(n * ho * wo, ks * ks * cin, cout, _HALO_KSPLIT_POLICY if halo else None)
@@ -819,6 +821,53 @@ def groupnorm_nhwc(x2, n_img, gn, relu=False):
         rc = fn(x2.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(), out.data_ptr(), ws.data_ptr(), n_img, hw, c, gn.num_groups,
                 float(gn.eps), hw * c, hw * c, _stream(x2.device))
     _cabi.check(rc, "tf_groupnorm_nhwc_f32")
+    return out
+
+
+def upsample_add(low, fpn, q_per_image):
+    """The mask head's FPN merge (detr_segmentation._merge) in one pass: F.interpolate(low, size=fpn.shape[-2:], mode="nearest") +
+    fpn broadcast over the queries of its image.  low [N, C, h, w], fpn [N / q_per_image, C, H, W], both channels_last -> [N, C, H, W]
+    channels_last, bit-identical to the two ATen passes; None when not applicable."""
+    if not (low.is_cuda and low.dtype == torch.float32 and fpn.dtype == torch.float32 and low.dim() == 4 and fpn.dim() == 4
+            and fpn.device == low.device and low.shape[1] == fpn.shape[1] and low.shape[1] % 4 == 0 and q_per_image > 0
+            and low.shape[0] == fpn.shape[0] * q_per_image and low.is_contiguous(memory_format=torch.channels_last)
+            and fpn.is_contiguous(memory_format=torch.channels_last) and not ((low.data_ptr() | fpn.data_ptr()) & 15)):
+        return None
+    n, c, h, w = low.shape
+    H, W = fpn.shape[-2:]
+    if n * H * W * c >= 1 << 33:
+        return None
+    with torch.cuda.device(low.device):
+        out = torch.empty((n, H, W, c), dtype=torch.float32, device=low.device)
+        rc = _cabi.lib().tf_upsample_add_nhwc_f32(low.data_ptr(), fpn.data_ptr(), out.data_ptr(), n, q_per_image, h, w, H, W, c, _stream(low.device))
+    _cabi.check(rc, "tf_upsample_add_nhwc_f32")
+    return out.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
+
+
+def groupnorm_relu_conv3x3_c1(x, gn, conv):
+    """conv(relu(gn(x))) for a 3 x 3 / padding 1 convolution to ONE channel (the mask head's out_lay behind gn5) of a channels_last
+    x [N, C, H, W], C in {16, 32}: the normalised activation is never written.  -> [N, 1, H, W]; None when not applicable."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and x.shape[1] in (16, 32) and gn.num_channels == x.shape[1] and gn.weight is not None and gn.bias is not None
+            and conv.out_channels == 1 and conv.in_channels == x.shape[1] and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and x.shape[0] <= 65535
+            and gn.weight.device == x.device and conv.weight.device == x.device and not (x.data_ptr() & 15)):
+        return None
+    n, c, H, W = x.shape
+    hit = getattr(conv, "_tf_c1_taps", None)   # [9, C] tap-major + the bias as a Python float (one synchronising read per weight version)
+    key = (conv.weight._version, None if conv.bias is None else conv.bias._version, conv.weight.device)
+    if hit is None or hit[0] != key:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        hit = conv._tf_c1_taps = (key, conv.weight.detach()[0].permute(1, 2, 0).reshape(9, c).contiguous(),
+                                  0.0 if conv.bias is None else float(conv.bias.detach()))
+    with torch.cuda.device(x.device):
+        out = torch.empty((n, 1, H, W), dtype=torch.float32, device=x.device)
+        ws = torch.empty(2 * n * gn.num_groups, dtype=torch.float64, device=x.device)
+        rc = _cabi.lib().tf_groupnorm_relu_conv3x3_c1_nhwc_f32(x.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(), hit[1].data_ptr(), hit[2],
+                                                               out.data_ptr(), ws.data_ptr(), n, H, W, c, gn.num_groups, float(gn.eps),
+                                                               _stream(x.device))
+    _cabi.check(rc, "tf_groupnorm_relu_conv3x3_c1_nhwc_f32")
     return out
 
 
