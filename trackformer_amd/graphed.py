@@ -103,6 +103,12 @@ class GraphedDetector:
         if target is not None and (len(target) != 1
                                    or 'track_query_hs_embeds' not in target[0]):
             return False
+        if prev_features is not None and self._multi_frame():
+            # the graphs are captured for all-valid padding masks (batch 1: no padding, nested.all_valid_mask); previous-frame
+            # features with a real mask (a caller's own, padded) take the eager path
+            from .nested import is_all_valid
+            if any(f.mask is not None and not is_all_valid(f.mask) for f in prev_features):
+                return False
         return True   # prev_features: fed through static buffers (multi-frame models), ignored by the others
 
     def _multi_frame(self):
@@ -110,8 +116,12 @@ class GraphedDetector:
 
     @staticmethod
     def _clone_features(features):
-        from .nested import NestedTensor
-        return [NestedTensor(f.tensors.clone(), None if f.mask is None else f.mask.clone())
+        """Owned copies of a frame's features.  An all-valid padding mask (nested.all_valid_mask: a shared constant TAGGED so that
+        consumers skip the mask-dependent work -- valid ratios, reference points, masked_fill -- without a device read) is kept as it
+        is: a clone would lose the tag, and every replay of a multi-frame graph would recompute 16 linspace / cumsum chains and
+        mask-fill the encoder's tensors for the previous frame (round 6: ~1 ms of a 6.5 ms cfg-4 frame)."""
+        from .nested import NestedTensor, is_all_valid
+        return [NestedTensor(f.tensors.clone(), None if f.mask is None else (f.mask if is_all_valid(f.mask) else f.mask.clone()))
                 for f in features]
 
     # ------------------------------------------------------------------ the forward in two graphs (models without a second
@@ -272,9 +282,10 @@ class GraphedDetector:
                 out = self.model(entry["img"], static_target, entry["prev"])
                 if multi:
                     dst = entry["prev"] if entry["prev"] is not None else entry["prev_out"]
+                    from .nested import is_all_valid
                     for d, s in zip(dst, out[2]):
                         d.tensors.copy_(s.tensors)
-                        if d.mask is not None and s.mask is not None:
+                        if d.mask is not None and s.mask is not None and not is_all_valid(d.mask):
                             d.mask.copy_(s.mask)
                     out = (out[0], out[1], dst, out[3], out[4])
                 entry["out"] = out
@@ -344,10 +355,11 @@ class GraphedDetector:
 
     def _feed_prev(self, entry, prev_features):
         """Copy-in of the previous frame's features unless they ARE the entry's static buffers."""
+        from .nested import is_all_valid
         for d, s in zip(entry["prev"], prev_features):
             if d.tensors.data_ptr() != s.tensors.data_ptr():
                 d.tensors.copy_(s.tensors, non_blocking=True)
-                if d.mask is not None and s.mask is not None:
+                if d.mask is not None and s.mask is not None and not is_all_valid(d.mask):   # (_capturable: all-valid in, all-valid here)
                     d.mask.copy_(s.mask, non_blocking=True)
 
     def _bucketed(self, target):
