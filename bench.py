@@ -966,7 +966,7 @@ def main():
     _cabi.lib()   # fail loudly if the HIP library is missing
     train = cfg["kind"] == "train"
     if train:
-        torch.backends.cudnn.benchmark = True
+        runtime.configure_training()
     else:
         runtime.configure_inference(tune=os.environ.get("TF_TUNE", "0") == "1",
                                     miopen_find=os.environ.get("TF_MIOPEN_FIND", "1") == "1",

@@ -64,6 +64,16 @@ def configure_inference(tune=False, miopen_find=True, tunable_file=None, verbose
                   ("loaded" if ok else "REJECTED (validator mismatch)", path), file=sys.stderr)
 
 
+def configure_training():
+    """The training step (engine.train_step) runs its linears in hipBLASLt / rocBLAS and its convolutions in MIOpen, forward and
+    backward, in fp32: MIOpen times its solvers per configuration on first use (as for inference).  PyTorch TunableOp is NOT
+    switched on here: tuned on an MI355X for the GEMM shapes of the BASELINE cfg-3 step (tools/gpu_runs/gpu_r06_34.sh) it picked
+    solutions that are slower inside the step than hipBLASLt's own heuristics -- 95.7 against 84.8 ms per step (the 44 446 x 256 ->
+    1024 forward GEMM: 190 us for the tuner's choice, 152 us for the default's)."""
+    if torch.cuda.is_available():
+        torch.backends.cudnn.benchmark = True
+
+
 def settle_heap():
     """Call once the model, the trackers and the HIP graphs exist (after the warm-up frames).  The association leg creates and
     drops a few hundred small objects per frame (Track, deque, per-row tensors), which makes CPython's cyclic collector run
