@@ -104,6 +104,19 @@ int tf_groupnorm_relu_conv3x3_c1_nhwc_f32(const float *x, const float *gamma, co
                                           float *out, double *workspace, int N, int H, int W, int C, int G, float eps, void *stream);
 
 /*
+ * The tracker's mask post-processing in one pass (reference: models/detr_segmentation.py PostProcessSegm.forward -- bilinear resize
+ * of the mask logits to the padded batch size, sigmoid, crop of the padding, nearest resize to the original image size -- followed by
+ * models/tracker.py:521-532: a pixel belongs to the track with the largest probability there if that probability exceeds the
+ * threshold).  logits [n, h, w] (mask-head outputs of n queries), order [n_tracks]: the row of `logits` that is track i's mask (-1: the
+ * track has none); label [out_h, out_w] int16: the owning track's index or -1.  Per output pixel: its nearest source pixel in the
+ * (img_h, img_w) crop of the (pad_h, pad_w) grid (torch's legacy "nearest" index), there the bilinear sample of every track's logits
+ * (align_corners = False, torch's arithmetic operation by operation), its sigmoid; ties go to the first track, as torch.max.
+ * The reference's chain writes and re-reads n full-size fp32 maps (~0.9 GB per frame at 100 tracks and 1080 x 1920).
+ */
+int tf_mask_label_map_f32(const float *logits, const int *order, int16_t *label, int n_tracks, int h, int w, int pad_h, int pad_w, int img_h,
+                          int img_w, int out_h, int out_w, float threshold, void *stream);
+
+/*
  * THE SPLIT PRODUCT (every matrix-core kernel below; trackformer_amd/csrc/split_product.h).  fp32 operands are cut into 16-bit
  * pieces (round to nearest even, residuals exact in fp32) and a product x . w is formed from v_mfma_f32_32x32x16_{bf16,f16}
  * terms with fp32 accumulation, smallest terms first.  The reference computes these layers in fp32 (nn.Linear / Conv2d;

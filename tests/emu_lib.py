@@ -55,6 +55,8 @@ def lib():
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_postprocess_pack_f32.restype = ci
     L.tf_postprocess_pack_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, ctypes.c_float, ci, vp]
+    L.tf_mask_label_map_f32.restype = ci
+    L.tf_mask_label_map_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]
     L.tf_upsample_add_nhwc_f32.restype = ci
     L.tf_upsample_add_nhwc_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_groupnorm_relu_conv3x3_c1_nhwc_f32.restype = ci
@@ -477,6 +479,19 @@ def postprocess_pack(logits, boxes, img_h, img_w, clip=True):
     if rc != 0:
         raise RuntimeError("tf_postprocess_pack_f32: status %d" % rc)
     return out
+
+
+def mask_label_map(logits, order, pad, img, out, threshold=0.5):
+    """logits [n, h, w], order [n_tracks] (row of logits or -1) -> int16 [out_h, out_w]."""
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    n, h, w = logits.shape
+    label = np.empty(tuple(out), dtype=np.int16)
+    rc = lib().tf_mask_label_map_f32(_p(logits), _p(order), _p(label), len(order), h, w, pad[0], pad[1], img[0], img[1], out[0], out[1],
+                                     ctypes.c_float(threshold), None)
+    if rc != 0:
+        raise RuntimeError("tf_mask_label_map_f32: status %d" % rc)
+    return label
 
 
 def upsample_add(low, fpn, q_per_image):

@@ -619,6 +619,36 @@ def test_upsample_add_fused(shape, out_size, qpi):
     assert np.array_equal(got, want.permute(0, 2, 3, 1).numpy())
 
 
+@pytest.mark.parametrize("lowres,pad,img,out", [((12, 20), (48, 80), (48, 80), (48, 80)), ((10, 17), (40, 67), (37, 61), (54, 96)),
+                                                 ((25, 42), (100, 167), (100, 160), (67, 107))])
+def test_mask_label_map_fused(lowres, pad, img, out):
+    """tf_mask_label_map_f32 (round 6) against the chain it replaces in the tracker: PostProcessSegm (bilinear to the padded size,
+    sigmoid, crop, nearest to the original size) -> stack -> max over the tracks -> threshold.  Same label map: pixels where the
+    two best tracks are closer than fp32 round-off (the CPU's and the kernel's exponentials differ in the last bit) excepted --
+    and there are none to speak of."""
+    import torch
+    from trackformer_amd.detr_segmentation import PostProcessSegm
+    g = torch.Generator().manual_seed(lowres[0])
+    n = 7
+    logits = torch.randn(1, n, *lowres, generator=g) * 3
+    logits[0, 5] = logits[0, 2]                        # a tie between two tracks everywhere: the first wins
+    order = [3, 0, -1, 6, 2, 5, 1]                     # track i -> row of logits (-1: no mask)
+    seg = PostProcessSegm()([{}], {'pred_masks': logits}, torch.tensor([list(out)]), torch.tensor([list(img)]), return_probs=True)[0]['masks'].squeeze(1)
+    # PostProcessSegm resizes to the PADDED BATCH size = the largest `size` of the batch: here the one image's own (pad == img
+    # unless the caller pads); the kernel takes both, so feed the module the padded size by hand for the cropped case
+    if pad != img:
+        cur = torch.nn.functional.interpolate(logits, size=pad, mode="bilinear", align_corners=False)[0].sigmoid()
+        seg = torch.nn.functional.interpolate(cur[:, :img[0], :img[1]].unsqueeze(1), size=out, mode="nearest").squeeze(1)
+    probs = torch.stack([seg[r] if r >= 0 else torch.full(out, -1.0) for r in order])
+    best, owner = probs.max(dim=0)
+    want = torch.where(best > 0.5, owner, torch.full_like(owner, -1)).to(torch.int16).numpy()
+    got = emu_lib.mask_label_map(logits[0].numpy(), order, pad, img, out)
+    assert got.shape == want.shape
+    assert (got != want).mean() < 1e-3
+    assert set(np.unique(got).tolist()) <= {-1, 0, 1, 3, 4, 6}     # track 2 has no mask; track 5's row equals track 4's: the first wins
+    assert (got == 4).any()
+
+
 @pytest.mark.parametrize("c,groups,hw", [(16, 8, (9, 37)), (32, 8, (17, 33)), (16, 4, (8, 32))])
 def test_groupnorm_relu_conv_to_one_channel_fused(c, groups, hw):
     """tf_groupnorm_relu_conv3x3_c1_nhwc_f32 (round 6: the end of the mask head, out_lay(relu(gn5(x)))) against torch in float64:

@@ -366,3 +366,28 @@ def test_groupnorm_relu_conv_to_one_channel(dev, c, groups, hw, n):
     err, err_lib = float((got.double() - want).abs().max()) / scale, float((lib32.double() - want).abs().max()) / scale
     print("gn + relu + conv %d -> 1 at %s: max err / max |y| %.2e (library fp32 modules: %.2e)" % (c, hw, err, err_lib))
     assert err < 2e-6 and err < 4 * err_lib + 1e-7
+
+
+@pytest.mark.parametrize("lowres,img,out,n", [((200, 334), (800, 1333), (1080, 1800), 100), ((25, 42), (100, 160), (67, 107), 7)])
+def test_mask_label_map_equals_the_module_chain(dev, lowres, img, out, n):
+    """tf_mask_label_map_f32 (round 6) against PostProcessSegm + stack + max + threshold on the device: the same ownership map up
+    to pixels where the two best tracks differ by fp32 round-off; a track without a mask never owns a pixel, ties go to the
+    first track."""
+    from trackformer_amd import fused
+    from trackformer_amd.detr_segmentation import PostProcessSegm
+    g = torch.Generator().manual_seed(n)
+    logits = (torch.randn(1, n, *lowres, generator=g) * 3).to(dev)
+    logits[0, n - 2] = logits[0, 1]
+    order = torch.randperm(n, generator=g).tolist()
+    order[0] = -1
+    seg = PostProcessSegm()([{}], {'pred_masks': logits}, torch.tensor([list(out)]), torch.tensor([list(img)]), return_probs=True)[0]['masks'].squeeze(1)
+    probs = torch.stack([seg[r] if r >= 0 else torch.full(out, -1.0, device=dev) for r in order])
+    best, owner = probs.max(dim=0)
+    want = torch.where(best > 0.5, owner, torch.full_like(owner, -1)).to(torch.int16)
+    got = fused.mask_label_map(logits[0].contiguous(), order, img, img, out)
+    assert got is not None and got.shape == want.shape and got.dtype == torch.int16
+    assert float((got != want).float().mean()) < 1e-4
+    assert not bool((got == 0).any())                                                      # track 0 has no mask
+    first, second = sorted((order.index(1), order.index(n - 2))) if 1 in order and (n - 2) in order else (None, None)
+    if first is not None:
+        assert not bool((got == second).any())                                             # equal rows: the first track wins

@@ -249,6 +249,36 @@ def test_pipelined_mask_tracker_equals_the_plain_loop(dev):
     assert n_px > 0 and n_diff <= 2e-3 * n_px, (n_diff, n_px)
 
 
+def test_fused_mask_post_processing_gives_the_same_masks(dev):
+    """Round 6: the tracker's mask post-processing in one launch (Tracker._label_map_fused -> tf_mask_label_map_f32) against the
+    module chain (PostProcessSegm, stack, max, threshold; fused.set_postprocess_fused(False)) over 6 frames of the mask tracker:
+    same tracks, the same covered pixels, every track's area within 2 % of the image (which of two random-weight tracks owns a
+    pixel flips with the run-to-run noise of the mask head's library convolutions: compared as in the tests around this one;
+    tests/test_fused_gpu.py::test_mask_label_map_equals_the_module_chain holds the kernel against the chain on the SAME logits)."""
+    import numpy as np
+    from trackformer_amd import fused
+    on = shared.run_mask_tracker(device=dev, frames=6, lazy_masks=True)
+    prev = fused.set_postprocess_fused(False)
+    try:
+        off = shared.run_mask_tracker(device=dev, frames=6, lazy_masks=True)
+    finally:
+        fused.set_postprocess_fused(prev)
+    assert sorted(on) == sorted(off)
+    cover_a, cover_b = {}, {}
+    for tid in on:
+        assert sorted(on[tid]) == sorted(off[tid])
+        for f in on[tid]:
+            a, b = on[tid][f], off[tid][f]
+            assert a['obj_ind'] == b['obj_ind']
+            np.testing.assert_allclose(a['bbox'], b['bbox'], atol=5e-3)
+            assert abs(int(a['mask'].sum()) - int(b['mask'].sum())) <= 0.02 * a['mask'].size
+            cover_a[f] = cover_a.get(f, 0) | a['mask']
+            cover_b[f] = cover_b.get(f, 0) | b['mask']
+    n_px = sum(u.size for u in cover_a.values())
+    n_diff = sum(int((cover_a[f] != cover_b[f]).sum()) for f in cover_a)
+    assert n_px > 0 and n_diff <= 2e-3 * n_px, (n_diff, n_px)
+
+
 def test_lazy_mask_head_gives_the_same_tracks(dev):
     """Lazy mask head (Tracker's default; lazy_masks=False runs the head for every query inside the detector): the head runs
     for the surviving tracks' queries only; same track ids as the full head, boxes and scores up to the run-to-run noise

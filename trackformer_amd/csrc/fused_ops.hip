@@ -311,6 +311,37 @@ gn_relu_conv3x3_c1_kernel(const float *__restrict__ x, const double *__restrict_
     if (oy < H && ox < W) out[((long long)n * H + oy) * W + ox] = ((acc.x + acc.y) + (acc.z + acc.w)) + bias;
 }
 
+// ---- the tracker's mask post-processing (include/tf_fused.h tf_mask_label_map_f32): one thread per output pixel, a loop over the tracks
+__global__ void __launch_bounds__(256)
+mask_label_map_kernel(const float *__restrict__ logits, const int *__restrict__ order, short *__restrict__ label, int n_tracks, int h, int w,
+                      int pad_h, int pad_w, int img_h, int img_w, int out_h, int out_w, float threshold)
+{
+#pragma clang fp contract(off)
+    const int ox = blockIdx.x * 32 + (threadIdx.x & 31), oy = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (ox >= out_w || oy >= out_h) return;
+    // nearest: the source pixel in the cropped (img_h, img_w) grid (upsample_nearest2d: min(floorf(dst * scale), in - 1))
+    const int py = min((int)floorf((float)oy * ((float)img_h / (float)out_h)), img_h - 1);
+    const int px = min((int)floorf((float)ox * ((float)img_w / (float)out_w)), img_w - 1);
+    // bilinear, align_corners = False (upsample_bilinear2d): source index = max(scale (dst + 0.5) - 0.5, 0)
+    const float ry = (float)h / (float)pad_h, rx = (float)w / (float)pad_w;
+    const float sy = fmaxf(ry * ((float)py + 0.5f) - 0.5f, 0.f), sx = fmaxf(rx * ((float)px + 0.5f) - 0.5f, 0.f);
+    const int y1 = (int)sy, x1 = (int)sx;
+    const int yp = (y1 < h - 1) ? 1 : 0, xp = (x1 < w - 1) ? 1 : 0;
+    const float ly1 = sy - (float)y1, ly0 = 1.f - ly1, lx1 = sx - (float)x1, lx0 = 1.f - lx1;
+    const int o00 = y1 * w + x1, o01 = o00 + xp, o10 = o00 + yp * w, o11 = o10 + xp;
+    float best = -1.f;
+    int owner = -1;
+    for (int t = 0; t < n_tracks; ++t) {
+        const int row = order[t];   // uniform
+        if (row < 0) continue;
+        const float *p = logits + (long long)row * h * w;
+        const float v = ly0 * (lx0 * p[o00] + lx1 * p[o01]) + ly1 * (lx0 * p[o10] + lx1 * p[o11]);
+        const float prob = 1.f / (1.f + expf(-v));
+        if (prob > best) { best = prob; owner = t; }   // ties: the first track (torch.max)
+    }
+    label[(long long)oy * out_w + ox] = (short)((owner >= 0 && best > threshold) ? owner : -1);
+}
+
 // ---- iterative box refinement of the decoder (models/deformable_transformer.py:331-343 of the reference):
 //   ref_dim 4: new = sigmoid(delta + inverse_sigmoid(ref))
 //   ref_dim 2: new[:2] = sigmoid(delta[:2] + inverse_sigmoid(ref)), new[2:] = sigmoid(delta[2:])
@@ -483,6 +514,19 @@ int tf_groupnorm_relu_conv3x3_c1_nhwc_f32(const float *x, const float *gamma, co
     else
         hipLaunchKernelGGL(gn_relu_conv3x3_c1_kernel<32>, grid, dim3(256), 0, s, x, (const double *)workspace, gamma, beta, weight, bias,
                            out, H, W, G, eps);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
+int tf_mask_label_map_f32(const float *logits, const int *order, int16_t *label, int n_tracks, int h, int w, int pad_h, int pad_w, int img_h,
+                          int img_w, int out_h, int out_w, float threshold, void *stream)
+{
+    if (!logits || !order || !label) return TF_MSDA_ERR_NULL_POINTER;
+    if (n_tracks <= 0 || n_tracks > 32767 || h <= 0 || w <= 0 || pad_h <= 0 || pad_w <= 0 || img_h <= 0 || img_w <= 0 || img_h > pad_h ||
+        img_w > pad_w || out_h <= 0 || out_w <= 0)
+        return TF_MSDA_ERR_BAD_DIMS;
+    const dim3 grid((unsigned)((out_w + 31) / 32), (unsigned)((out_h + 7) / 8));
+    hipLaunchKernelGGL(mask_label_map_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), logits, order, reinterpret_cast<short *>(label),
+                       n_tracks, h, w, pad_h, pad_w, img_h, img_w, out_h, out_w, threshold);
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 

@@ -824,6 +824,26 @@ def groupnorm_nhwc(x2, n_img, gn, relu=False):
     return out
 
 
+def mask_label_map(logits, order, pad_hw, img_hw, out_hw, threshold=0.5):
+    """The tracker's mask post-processing in one launch (tf_mask_label_map_f32): logits [n, h, w] fp32 on the GPU (mask-head outputs),
+    order: per track the row of `logits` that is its mask (-1: none) -> int16 [out_h, out_w], the owning track per pixel or -1.
+    None when not applicable."""
+    if not (_postprocess_fused and logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 3 and logits.is_contiguous()
+            and 0 < len(order) <= 32767 and logits.numel() > 0):
+        return None
+    n, h, w = logits.shape
+    if any(r >= n for r in order) or img_hw[0] > pad_hw[0] or img_hw[1] > pad_hw[1]:
+        return None
+    with torch.cuda.device(logits.device):
+        order_dev = torch.tensor(list(order), dtype=torch.int32).to(logits.device, non_blocking=True)
+        label = torch.empty((int(out_hw[0]), int(out_hw[1])), dtype=torch.int16, device=logits.device)
+        rc = _cabi.lib().tf_mask_label_map_f32(logits.data_ptr(), order_dev.data_ptr(), label.data_ptr(), len(order), h, w, int(pad_hw[0]),
+                                               int(pad_hw[1]), int(img_hw[0]), int(img_hw[1]), int(out_hw[0]), int(out_hw[1]), float(threshold),
+                                               _stream(logits.device))
+    _cabi.check(rc, "tf_mask_label_map_f32")
+    return label
+
+
 def upsample_add(low, fpn, q_per_image):
     """The mask head's FPN merge (detr_segmentation._merge) in one pass: F.interpolate(low, size=fpn.shape[-2:], mode="nearest") +
     fpn broadcast over the queries of its image.  low [N, C, h, w], fpn [N / q_per_image, C, H, W], both channels_last -> [N, C, H, W]

@@ -598,10 +598,19 @@ class Tracker:
             cur = self._keep_after_nms(cur[0], cur[1], rank, self.detection_nms_thresh, 'detection_nms_thresh')   # always win
 
         # ---------------------------------------------------------------- results
+        label = None
         if 'masks' in result:
-            self._resolve_masks(outputs, results, orig_size, blob["size"].to(device))
+            label = self._label_map_fused(outputs, blob, orig_h, orig_w)   # (round 6) None: the module chain below
+            if label is None:
+                self._resolve_masks(outputs, results, orig_size, blob["size"].to(device))
         masks_host = None
-        if 'masks' in result and self.tracks:
+        if label is not None and self.tracks:
+            index_map = torch.arange(len(self.tracks), device=label.device, dtype=torch.int16)[:, None, None]
+            track_masks = label[None] == index_map    # device-side per-track views (Track.mask keeps the reference's meaning)
+            for i, track in enumerate(self.tracks):
+                track.mask = track_masks[i]
+            masks_host = _LabelMap(label.cpu().numpy())
+        elif 'masks' in result and self.tracks:
             # tracker.py:521-532 of the reference: a pixel belongs to the track with the largest probability there, if that
             # probability exceeds 0.5 -- `logical_and(probs > 0.5, index_map == probs.argmax(0))`.  Ownership is exclusive, so
             # ONE label map (owning track or -1 per pixel) holds every track's mask: 2 bytes per pixel reach the host instead
@@ -656,6 +665,38 @@ class Tracker:
         self._inflight_features = None
         if self.reid_sim_only:
             self.tracks_to_inactive(self.tracks)
+
+    def _label_map_fused(self, outputs, blob, orig_h, orig_w):
+        """The frame's mask ownership map (int16 [orig_h, orig_w]: index into self.tracks or -1) straight from the mask head's
+        low-resolution logits -- PostProcessSegm's bilinear resize / sigmoid / crop / nearest resize and the reference's per-pixel
+        argmax over the tracks (tracker.py:521-532) in ONE launch (fused.mask_label_map) instead of ~10 passes over one full-size
+        fp32 map per track.  Lazy mask head on the GPU with the package's own PostProcessSegm only; None otherwise."""
+        post = self.obj_detector_post.get('segm')
+        if (not self.tracks or 'pred_masks' in outputs or 'mask_context' not in outputs or post is None
+                or type(post).__name__ != "PostProcessSegm" or not type(post).__module__.startswith("trackformer_amd.")
+                or getattr(post, "threshold", None) != 0.5 or not outputs['hs_embed'].is_cuda
+                or not all(isinstance(t.mask, _MaskRef) for t in self.tracks)):
+            return None
+        from . import fused
+        if not fused._postprocess_fused:
+            return None
+        refs = sorted({t.mask.row for t in self.tracks})
+        module = getattr(self.obj_detector, "model", self.obj_detector)
+        hs = outputs['hs_embed']
+        padded = refs + [refs[-1]] * (-len(refs) % 32)     # (as _resolve_masks: the convolution library tunes per shape)
+        idx = torch.tensor(padded, dtype=torch.long, device=hs.device)
+        with torch.no_grad():
+            rows = module.mask_rows(outputs['mask_context'], hs.index_select(1, idx))[0]   # [n_padded, H, W]
+        pos = {row: k for k, row in enumerate(refs)}
+        size = blob["size"].detach().cpu().reshape(-1).tolist()                            # the (un-padded) size of this image
+        label = fused.mask_label_map(rows.contiguous(), [pos[t.mask.row] for t in self.tracks], (int(size[0]), int(size[1])),
+                                     (int(size[0]), int(size[1])), (orig_h, orig_w))
+        if label is None:
+            return None
+        for t in self.inactive_tracks:      # references of tracks that left the active set are never read
+            if isinstance(t.mask, _MaskRef):
+                t.mask = None
+        return label
 
     def _resolve_masks(self, outputs, results, orig_size, size):
         """Turn the _MaskRef placeholders of this frame into mask probabilities at the original image size:
