@@ -282,15 +282,34 @@ class MaskHeadSmallConv(nn.Module):
         """The per-query part of the head: y_img [B, dim, h, w] (lay1's image part), bbox_mask [B, Q', heads, h, w],
         feats 3 x [B, C_k, H_k, W_k] (the adapters' outputs) -> [B * Q', 1, H_2, W_2]."""
         batch, num_queries = bbox_mask.shape[:2]
-        y_att = F.conv2d(bbox_mask.flatten(0, 1), self.lay1.weight[:, c_img:], None, padding=1)     # [B*Q', dim, h, w]
-        x = (y_att.view(batch, num_queries, *y_att.shape[1:]) + y_img[:, None]).flatten(0, 1)
-        x = F.relu(self.gn1(x))
+        xp = None
+        if split and _mask_head_fused_tail:
+            # round 6: the front of the per-query part channels-innermost from the start -- lay1's attention part (library
+            # convolution, NHWC in and out), + its image part broadcast over the queries (fused.upsample_add at equal sizes: one
+            # coalesced pass), GroupNorm + ReLU in the library's own two passes -- instead of NCHW element-wise passes, ATen's
+            # GroupNorm, a ReLU pass and a strided permute-copy into the padded buffer
+            from . import fused
+            y_att = F.conv2d(bbox_mask.flatten(0, 1).contiguous(memory_format=torch.channels_last), self.lay1.weight[:, c_img:], None, padding=1)
+            y_att = y_att.contiguous(memory_format=torch.channels_last)
+            z = fused.upsample_add(y_att, y_img.contiguous(memory_format=torch.channels_last), num_queries)
+            if z is not None:
+                n, c, h, wd = z.shape
+                z2 = fused.groupnorm_nhwc(z.permute(0, 2, 3, 1).reshape(n * h * wd, c), n, self.gn1, relu=True)
+                if z2 is not None:
+                    cin_pad = -(-c // 32) * 32
+                    xp = z2.new_zeros(n, h, wd, cin_pad)                             # channels innermost, zero tail
+                    xp[..., :c] = z2.view(n, h, wd, c)
+        if xp is None:
+            y_att = F.conv2d(bbox_mask.flatten(0, 1), self.lay1.weight[:, c_img:], None, padding=1)     # [B*Q', dim, h, w]
+            x = (y_att.view(batch, num_queries, *y_att.shape[1:]) + y_img[:, None]).flatten(0, 1)
+            x = F.relu(self.gn1(x))
         if split:
             from . import fused
-            n, c, h, wd = x.shape
-            cin_pad = -(-c // 32) * 32
-            xp = x.new_zeros(n, h, wd, cin_pad)                                      # channels innermost, zero tail
-            xp[..., :c] = x.permute(0, 2, 3, 1)
+            if xp is None:
+                n, c, h, wd = x.shape
+                cin_pad = -(-c // 32) * 32
+                xp = x.new_zeros(n, h, wd, cin_pad)                                  # channels innermost, zero tail
+                xp[..., :c] = x.permute(0, 2, 3, 1)
             x = self._conv_gn_relu(xp.permute(0, 3, 1, 2), self.lay2, self.gn2)
             for conv, gn, feat in ((self.lay3, self.gn3, feats[0]), (self.lay4, self.gn4, feats[1]), (self.lay5, self.gn5, feats[2])):
                 # round 6: nearest up-sampling + the broadcast add of the adapter's output in ONE pass (tf_upsample_add_nhwc_f32; the
