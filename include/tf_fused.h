@@ -78,6 +78,9 @@ int tf_postprocess_pack_f32(const float *logits, const float *boxes, float *out,
  */
 int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
                           int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream);
+/* The statistics pass alone: workspace[n][g] = (sum, sum of squares) of x's group g of image n, as doubles -- for a consumer that applies
+ * the normalisation in its own fetch (tf_conv3x3_merge_packed_f32). */
+int tf_groupnorm_stats_nhwc_f32(const float *x, double *workspace, int N, int HW, int C, int G, int64_t x_image_stride, void *stream);
 /* The same followed by ReLU in the same pass: `F.relu(gn(conv(x)))` of the mask head (reference: models/detr_segmentation.py:142-156). */
 int tf_groupnorm_relu_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
                                int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream);
@@ -91,6 +94,19 @@ int tf_groupnorm_relu_nhwc_f32(const float *x, const float *gamma, const float *
  */
 int tf_upsample_add_nhwc_f32(const float *low, const float *fpn, float *out, int N, int q_per_image, int h, int w, int H, int W, int C,
                              void *stream);
+
+/*
+ * A 3 x 3 / padding 1 convolution (split product, halo form) whose input is the mask head's FPN merge, computed in the convolution's
+ * fetch and never written (reference: models/detr_segmentation.py:142-156 `x = adapter(fpn) + F.interpolate(x, size=fpn.shape[-2:])`,
+ * `x = lay(x)`): input pixel (y, x), channel c of image n = act(low[n, ys, xs, c]) + fpn[n / q_per_image, y, x, c], (ys, xs) torch's
+ * legacy nearest index.  act = identity when gn_workspace is NULL; else relu(GroupNorm(low)) from RAW statistics (the 2 * nimg * groups
+ * doubles tf_groupnorm_*'s statistics pass leaves: sum | sum of squares per (image, group) over lh * lw * cin / groups values) -- the
+ * previous layer's GroupNorm + ReLU folded in as well.  low [nimg, lh, lw, cin], fpn [nimg / q_per_image, H, W, cin], y [nimg, H, W,
+ * cout]; cin % 32 == 0, cin <= 320; w_packed: tf_linear_pack_weight_f32 of the [cout, 9 * cin] tap-major weight.
+ */
+int tf_conv3x3_merge_packed_f32(const float *low, const float *fpn, const double *gn_workspace, const float *gamma, const float *beta,
+                                int groups, float eps, const void *w_packed, const float *bias, float *y, int nimg, int q_per_image, int lh,
+                                int lw, int H, int W, int cin, int cout, int relu, int terms, void *stream);
 
 /*
  * The end of the mask head in one pass over the last hidden activation (reference: models/detr_segmentation.py:157-160

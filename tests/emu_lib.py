@@ -55,6 +55,10 @@ def lib():
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_postprocess_pack_f32.restype = ci
     L.tf_postprocess_pack_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, ctypes.c_float, ci, vp]
+    L.tf_groupnorm_stats_nhwc_f32.restype = ci
+    L.tf_groupnorm_stats_nhwc_f32.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_int64, vp]
+    L.tf_conv3x3_merge_packed_f32.restype = ci
+    L.tf_conv3x3_merge_packed_f32.argtypes = [vp, vp, vp, vp, vp, ci, ctypes.c_float, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_mask_label_map_f32.restype = ci
     L.tf_mask_label_map_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]
     L.tf_upsample_add_nhwc_f32.restype = ci
@@ -435,6 +439,31 @@ def conv_packed(x_nhwc, w_ohwi, bias=None, relu=False, stride=1, ksplit=1, resid
                                   int(relu), TERMS, None)
     if rc != 0:
         raise RuntimeError("tf_conv_packed_f32: status %d" % rc)
+    return y
+
+
+def conv3x3_merged(low_nhwc, fpn_nhwc, q_per_image, w_ohwi, bias=None, relu=False, gn=None):
+    """tf_conv3x3_merge_packed_f32: low [N, h, w, Cin], fpn [N / q_per_image, H, W, Cin], w [Cout, 3, 3, Cin] -> y [N, H, W, Cout];
+    gn = (gamma, beta, groups, eps): relu(GroupNorm(low)) is applied in the fetch, from the statistics pass's raw sums."""
+    low, fpn, w = _aligned(low_nhwc), _aligned(fpn_nhwc), _c(w_ohwi, np.float32)
+    n, lh, lw, cin = low.shape
+    _, H, W, _ = fpn.shape
+    cout = w.shape[0]
+    pk = _packed(w.reshape(cout, 9 * cin))
+    b = _aligned(bias)
+    y = _aligned(np.full((n, H, W, cout), np.nan, np.float32))
+    ws = gamma = beta = None
+    groups, eps = 1, 0.0
+    if gn is not None:
+        gamma, beta, groups, eps = _aligned(gn[0]), _aligned(gn[1]), int(gn[2]), float(gn[3])
+        ws = np.empty(2 * n * groups, dtype=np.float64)
+        rc = lib().tf_groupnorm_stats_nhwc_f32(_p(low), _p(ws), n, lh * lw, cin, groups, lh * lw * cin, None)
+        if rc != 0:
+            raise RuntimeError("tf_groupnorm_stats_nhwc_f32: status %d" % rc)
+    rc = lib().tf_conv3x3_merge_packed_f32(_p(low), _p(fpn), _p(ws), _p(gamma), _p(beta), groups, ctypes.c_float(eps), pk.ctypes.data, _p(b),
+                                           _p(y), n, q_per_image, lh, lw, H, W, cin, cout, int(relu), TERMS, None)
+    if rc != 0:
+        raise RuntimeError("tf_conv3x3_merge_packed_f32: status %d" % rc)
     return y
 
 

@@ -1088,6 +1088,39 @@ def test_convolution_3x3_halo_form(n, h, w, cin, cout, ksplit, terms):
     assert np.abs(y - stream).max() <= 4e-6 * max(1.0, np.abs(ref).max())   # same products, another summation order
 
 
+@pytest.mark.parametrize("n,qpi,low,out,cin,cout,norm", [(4, 2, (5, 7), (10, 14), 32, 16, True), (3, 3, (6, 21), (12, 41), 64, 32, True),
+                                                          (2, 1, (4, 5), (8, 10), 128, 64, False), (2, 2, (3, 4), (6, 8), 288, 128, True)],
+                         ids=lambda v: str(v))
+def test_convolution_3x3_with_the_fpn_merge_in_its_fetch(n, qpi, low, out, cin, cout, norm, terms):
+    """tf_conv3x3_merge_packed_f32 (round 6, the mask head's FPN levels): conv(relu(gn(low)) up-sampled (nearest) + fpn broadcast over
+    the queries of an image) with the merge -- and the previous layer's GroupNorm + ReLU -- computed in the convolution's fetch.
+    Against the unfused chain of the SAME library (groupnorm, upsample_add, the halo convolution): the same products of the same
+    values -- bit for bit -- and against torch in float64 within the split product's bound."""
+    import torch
+    rng = np.random.default_rng(n * cin + cout)
+    lo = (rng.standard_normal((n, *low, cin), dtype=np.float32) * 2 + 0.3).astype(np.float32)
+    fpn = rng.standard_normal((n // qpi, *out, cin), dtype=np.float32)
+    wt = (rng.standard_normal((cout, 3, 3, cin), dtype=np.float32) / np.sqrt(9 * cin)).astype(np.float32)
+    b = rng.standard_normal(cout, dtype=np.float32)
+    groups = 8
+    gamma = (rng.random(cin, dtype=np.float32) + 0.5).astype(np.float32)
+    beta = (rng.standard_normal(cin, dtype=np.float32) * 0.2).astype(np.float32)
+    got = emu_lib.conv3x3_merged(lo, fpn, qpi, wt, b, relu=False, gn=(gamma, beta, groups, 1e-5) if norm else None)
+    act = emu_lib.groupnorm_nhwc(lo.reshape(n, low[0] * low[1], cin), gamma, beta, groups, relu=True).reshape(lo.shape) if norm else lo
+    merged = emu_lib.upsample_add(act, fpn, qpi)
+    chain = emu_lib.conv_packed(merged, wt, b, relu=False, stride=1)
+    assert got.shape == chain.shape and np.array_equal(got, chain)
+    t = torch.from_numpy(lo).double().permute(0, 3, 1, 2)
+    if norm:
+        t = torch.relu(torch.nn.functional.group_norm(t, groups, torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5))
+    t = torch.nn.functional.interpolate(t, size=out, mode="nearest")
+    t = (t.view(n // qpi, qpi, *t.shape[1:]) + torch.from_numpy(fpn).double().permute(0, 3, 1, 2)[:, None]).flatten(0, 1)
+    ref = torch.nn.functional.conv2d(t, torch.from_numpy(wt).double().permute(0, 3, 1, 2), torch.from_numpy(b).double(), padding=1).permute(0, 2, 3, 1).numpy()
+    assert np.abs(got - ref).max() < _tol(terms) * max(1.0, np.abs(ref).max())
+    st = emu_lib.stats()
+    assert st["divergent_ops"] == 0 and st["inactive_reads"] == 0
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,stride,ks,ksplit", [(1, 9, 11, 128, 64, 2, 3, 4), (1, 7, 6, 256, 256, 2, 3, 9), (2, 5, 5, 64, 128, 1, 3, 18),
                                                               (1, 9, 11, 256, 64, 1, 1, 4), (1, 6, 6, 64, 192, 1, 1, 2), (1, 4, 4, 64, 64, 2, 3, 1)],
                          ids=lambda v: str(v))

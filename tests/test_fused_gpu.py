@@ -391,3 +391,39 @@ def test_mask_label_map_equals_the_module_chain(dev, lowres, img, out, n):
     first, second = sorted((order.index(1), order.index(n - 2))) if 1 in order and (n - 2) in order else (None, None)
     if first is not None:
         assert not bool((got == second).any())                                             # equal rows: the first track wins
+
+
+@pytest.mark.parametrize("n,qpi,low,out,cin,cout,norm", [(6, 3, (50, 84), (100, 167), 64, 32, True), (4, 4, (100, 167), (200, 334), 32, 16, True),
+                                                          (4, 2, (25, 42), (50, 84), 128, 64, True), (2, 1, (13, 21), (25, 42), 288, 128, False)])
+def test_conv3x3_merged_equals_the_pass_by_pass_chain(dev, n, qpi, low, out, cin, cout, norm):
+    """tf_conv3x3_merge_packed_f32 (round 6: the mask head's FPN levels with the merge and the previous layer's GroupNorm + ReLU in the
+    convolution's fetch) against the chain it replaces on the device -- fused.groupnorm_nhwc(relu), fused.upsample_add,
+    fused.conv3x3 -- at the head's shapes: the same products of the same values in (possibly) another fp32 order, and against torch in float64 within the split product's bound."""
+    from trackformer_amd import fused
+    g = torch.Generator().manual_seed(cin + cout)
+    lo = (torch.randn(n, cin, *low, generator=g) * 2 + 0.3).to(dev).contiguous(memory_format=torch.channels_last)
+    fpn = torch.randn(n // qpi, cin, *out, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    taps = (torch.randn(cout, 3, 3, cin, generator=g) / (9 * cin) ** 0.5).to(dev).reshape(cout, 9 * cin).contiguous()
+    b = torch.randn(cout, generator=g).to(dev)
+    gn = torch.nn.GroupNorm(8, cin).to(dev)
+    with torch.no_grad():
+        gn.weight.copy_(torch.rand(cin, generator=g) + 0.5)
+        gn.bias.copy_(torch.randn(cin, generator=g) * 0.2)
+        ws = fused.groupnorm_stats(lo, gn) if norm else None
+        got = fused.conv3x3_merged(lo, fpn, qpi, taps, b, gn=gn if norm else None, ws=ws)
+        assert got is not None and got.shape == (n, cout, *out)
+        act = lo
+        if norm:
+            z = fused.groupnorm_nhwc(lo.permute(0, 2, 3, 1).reshape(n * low[0] * low[1], cin), n, gn, relu=True)
+            act = z.view(n, *low, cin).permute(0, 3, 1, 2)
+        merged = fused.upsample_add(act, fpn, qpi)
+        chain = fused.conv3x3(merged, taps, b, False, 1)
+        ref = lo.double()
+        if norm:
+            ref = torch.relu(torch.nn.functional.group_norm(ref, 8, gn.weight.double(), gn.bias.double(), gn.eps))
+        ref = torch.nn.functional.interpolate(ref, size=out, mode="nearest")
+        ref = (ref.view(n // qpi, qpi, *ref.shape[1:]) + fpn.double()[:, None]).flatten(0, 1)
+        ref = torch.nn.functional.conv2d(ref, taps.view(cout, 3, 3, cin).permute(0, 3, 1, 2).double(), b.double(), padding=1)
+    scale = float(ref.abs().max())
+    assert float((got - chain).abs().max()) <= 4e-6 * scale   # (the chain's convolution may cut its K loop into pieces: another fp32 order)
+    assert float((got.double() - ref).abs().max()) < 3e-6 * scale

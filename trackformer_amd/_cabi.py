@@ -40,6 +40,8 @@ EXPORTED_SYMBOLS = (
     "tf_postprocess_pack_f32",
     "tf_upsample_add_nhwc_f32",
     "tf_mask_label_map_f32",
+    "tf_conv3x3_merge_packed_f32",
+    "tf_groupnorm_stats_nhwc_f32",
     "tf_groupnorm_relu_conv3x3_c1_nhwc_f32",
     "tf_bias_relu_maxpool_f32",
     "tf_stem_conv7x7_f32",
@@ -128,6 +130,10 @@ def lib():
     L.tf_box_refine_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, vp]
     L.tf_postprocess_pack_f32.restype = ci
     L.tf_postprocess_pack_f32.argtypes = [vp, vp, vp, ctypes.c_int64, ci, ctypes.c_float, ctypes.c_float, ci, vp]
+    L.tf_groupnorm_stats_nhwc_f32.restype = ci
+    L.tf_groupnorm_stats_nhwc_f32.argtypes = [vp, vp, ci, ci, ci, ci, ctypes.c_int64, vp]
+    L.tf_conv3x3_merge_packed_f32.restype = ci
+    L.tf_conv3x3_merge_packed_f32.argtypes = [vp, vp, vp, vp, vp, ci, ctypes.c_float, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp]
     L.tf_mask_label_map_f32.restype = ci
     L.tf_mask_label_map_f32.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, ci, ctypes.c_float, vp]
     L.tf_upsample_add_nhwc_f32.restype = ci

@@ -567,6 +567,21 @@ static int groupnorm_nhwc_impl(const float *x, const float *gamma, const float *
     return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
 }
 
+int tf_groupnorm_stats_nhwc_f32(const float *x, double *workspace, int N, int HW, int C, int G, int64_t x_image_stride, void *stream)
+{
+    if (!x || !workspace) return TF_MSDA_ERR_NULL_POINTER;
+    if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 256 || C > 1024 || (C % G) != 0 || (C & 3) || N > 65535) return TF_MSDA_ERR_BAD_DIMS;
+    if (x_image_stride < (int64_t)HW * C || (x_image_stride & 3) || !aligned16(x) || (reinterpret_cast<uintptr_t>(workspace) & 7))
+        return TF_MSDA_ERR_BAD_DIMS;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned n_ws = 2u * (unsigned)N * (unsigned)G;
+    hipLaunchKernelGGL(groupnorm_zero_kernel, dim3((n_ws + 255) / 256), dim3(256), 0, s, workspace, n_ws);   // (a kernel, not a memset node)
+    if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
+    const unsigned sblocks = (unsigned)((HW + kGnRowsPerBlock - 1) / kGnRowsPerBlock);
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(sblocks, (unsigned)N), dim3(256), 0, s, x, workspace, HW, C, G, (long long)x_image_stride);
+    return hipGetLastError() == hipSuccess ? TF_MSDA_OK : TF_MSDA_ERR_LAUNCH;
+}
+
 int tf_groupnorm_nhwc_f32(const float *x, const float *gamma, const float *beta, float *out, double *workspace, int N,
                           int HW, int C, int G, float eps, int64_t x_image_stride, int64_t out_image_stride, void *stream)
 {

@@ -657,10 +657,24 @@ dma_gemm_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const
 //           stream form's reduce kernel)
 // Summation order per output element: channel slice, tap, k-step, smallest term first (the stream form: tap, channel) -- the same
 // products, another fp32 order.
-template <int SP, int TI, int TJ, int WC>
+// MRG (round 6, the mask head's FPN levels -- reference: models/detr_segmentation.py:142-156 `x = adapter(fpn) + interpolate(x)`, then
+// lay(x)): the convolution's input is never materialised.  X is the PREVIOUS layer's output at its own (lower) resolution [nimg, lh, lw,
+// Cin]; the value of input pixel (iy, ix), channel c is  act(X[img, ys, xs, c]) + fpn[img / qpi, iy, ix, c]  with (ys, xs) torch's
+// legacy nearest index (min(floorf(iy (float)lh / H), lh - 1)) and act = identity or, with `ws`, relu(GroupNorm(X)) from the raw
+// statistics of tf_groupnorm's workspace (sum | sum of squares per (image, group)) in the expression of groupnorm_apply_kernel.
+struct HaloMerge {
+    const float *fpn;
+    const double *ws;       // NULL: X is taken as it is
+    const float *gamma, *beta;
+    int qpi, lh, lw, G;
+    float eps;
+};
+
+template <int SP, int TI, int TJ, int WC, bool MRG = false>
 __global__ void __launch_bounds__(kThreads, (TI * TJ <= 2 ? 2 : 1))
 conv3x3_halo_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, const float *__restrict__ bias, const float *R, float *Y,
-                    int N, int nblocks, int npatches, int tiles_x, int tiles_y, int relu, int cslices, const StreamConv cv)
+                    int N, int nblocks, int npatches, int tiles_x, int tiles_y, int relu, int cslices, const StreamConv cv,
+                    const HaloMerge mg = HaloMerge{})
 {
     constexpr int WR = 4 / WC, BM = WR * TI * 32, PW = 8, PH = BM / PW, HW = PW + 2, HH = PH + 2, HP = HH * HW;
     constexpr int NA = Split<SP>::NA, NB = Split<SP>::NB;
@@ -695,9 +709,30 @@ conv3x3_halo_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
     // ---- the halo: thread -> float4 f = tid + 256 it of (halo pixel f >> 3, channels 4 (f & 7) ..); pixels outside the image (and
     // the slots behind the last halo pixel) read zeros from beyond num_records
     constexpr unsigned OOB = 0xC0000000u;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (unsigned)((size_t)cv.nimg * H * W * Cin * 4), 0x00020000);
-    unsigned xoff[XV];
+    constexpr int kMrgC = MRG ? 320 : 1;   // MRG: Cin <= 320 (host)
+    __shared__ float s_gn[MRG ? 4 : 1][kMrgC];   // MRG with statistics: mean | rstd | gamma | beta per input channel of this block's image
+    const size_t xbytes = MRG ? (size_t)cv.nimg * mg.lh * mg.lw * Cin * 4 : (size_t)cv.nimg * H * W * Cin * 4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), 0, (unsigned)xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(MRG ? mg.fpn : X), 0, MRG ? (unsigned)((size_t)(cv.nimg / mg.qpi) * H * W * Cin * 4) : 0u, 0x00020000);
+    unsigned xoff[XV], foff[MRG ? XV : 1];
     int lds_o[XV];
+    if constexpr (MRG) {
+        if (mg.ws != nullptr) {   // uniform
+            const int cpg = Cin / mg.G;
+            for (int c = tid; c < Cin; c += kThreads) {
+                const int g = c / cpg;
+                const double cnt = (double)mg.lh * (double)mg.lw * (double)cpg;
+                const double mean = mg.ws[(long long)img * 2 * mg.G + 2 * g] / cnt;
+                double var = mg.ws[(long long)img * 2 * mg.G + 2 * g + 1] / cnt - mean * mean;   // biased, as torch.nn.GroupNorm
+                if (var < 0.0) var = 0.0;
+                s_gn[0][c] = (float)mean;
+                s_gn[1][c] = (float)(1.0 / sqrt(var + (double)mg.eps));
+                s_gn[2][c] = mg.gamma[c];
+                s_gn[3][c] = mg.beta[c];
+            }
+        }
+    }
 #pragma unroll
     for (int it = 0; it < XV; ++it) {
         const int f = tid + kThreads * it;
@@ -705,21 +740,53 @@ conv3x3_halo_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
         const int hy = hp / HW, hx = hp - hy * HW;
         const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
         const bool ok = hp < HP && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        xoff[it] = ok ? ((unsigned)((img * H + iy) * W + ix) * (unsigned)Cin + (unsigned)(c4 * 4)) * 4u : OOB;
+        if constexpr (MRG) {
+            const int ys = min((int)floorf((float)iy * ((float)mg.lh / (float)H)), mg.lh - 1);
+            const int xs = min((int)floorf((float)ix * ((float)mg.lw / (float)W)), mg.lw - 1);
+            xoff[it] = ok ? ((unsigned)((img * mg.lh + ys) * mg.lw + xs) * (unsigned)Cin + (unsigned)(c4 * 4)) * 4u : OOB;
+            foff[it] = ok ? ((unsigned)(((img / mg.qpi) * H + iy) * W + ix) * (unsigned)Cin + (unsigned)(c4 * 4)) * 4u : OOB;
+        } else {
+            xoff[it] = ok ? ((unsigned)((img * H + iy) * W + ix) * (unsigned)Cin + (unsigned)(c4 * 4)) * 4u : OOB;
+        }
         lds_o[it] = hp < HP ? hp * kStride + c4 * 4 : -1;
     }
-    auto load_x = [&](int cs, f32x4 (&dst)[XV]) {
+    // (MRG: a slice's registers hold the low-resolution value and the fpn value: XV more f32x4; they meet in store_x)
+    struct XRegs {
+        f32x4 v[XV];
+        f32x4 f[MRG ? XV : 1];
+    };
+    auto load_x = [&](int cs, XRegs &dst) {
         const unsigned coff = (unsigned)(min(cs, cend - 1) * kSlice) * 4u;   // (calls past the last slice re-fetch it: never used)
 #pragma unroll
-        for (int it = 0; it < XV; ++it)
-            dst[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff[it] == OOB ? OOB : xoff[it] + coff, 0, 0));
+        for (int it = 0; it < XV; ++it) {
+            dst.v[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff[it] == OOB ? OOB : xoff[it] + coff, 0, 0));
+            if constexpr (MRG)
+                dst.f[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(frs, foff[it] == OOB ? OOB : foff[it] + coff, 0, 0));
+        }
     };
-    auto store_x = [&](const f32x4 (&src)[XV], int buf) {
+    auto store_x = [&](const XRegs &src, int buf, int cs) {
 #pragma unroll
         for (int it = 0; it < XV; ++it) {
             if (XV * kThreads > HP * 8 && lds_o[it] < 0) continue;
+            f32x4 v = src.v[it];
+            if constexpr (MRG) {
+                if (mg.ws != nullptr && xoff[it] != OOB) {   // (outside the image the MERGED tensor is zero: the convolution's padding)
+                    const int c = min(cs, cend - 1) * kSlice + ((tid + kThreads * it) & 7) * 4;
+                    const f32x4 mean = *reinterpret_cast<const f32x4 *>(&s_gn[0][c]), rstd = *reinterpret_cast<const f32x4 *>(&s_gn[1][c]);
+                    const f32x4 ga = *reinterpret_cast<const f32x4 *>(&s_gn[2][c]), be = *reinterpret_cast<const f32x4 *>(&s_gn[3][c]);
+                    v.x = (v.x - mean.x) * rstd.x * ga.x + be.x;
+                    v.y = (v.y - mean.y) * rstd.y * ga.y + be.y;
+                    v.z = (v.z - mean.z) * rstd.z * ga.z + be.z;
+                    v.w = (v.w - mean.w) * rstd.w * ga.w + be.w;
+                    v.x = v.x < 0.f ? 0.f : v.x;
+                    v.y = v.y < 0.f ? 0.f : v.y;
+                    v.z = v.z < 0.f ? 0.f : v.z;
+                    v.w = v.w < 0.f ? 0.f : v.w;
+                }
+                v += src.f[it];
+            }
             u32x2 pc[NA];
-            split4<SP>(src[it], pc);
+            split4<SP>(v, pc);
 #pragma unroll
             for (int p = 0; p < NA; ++p) *reinterpret_cast<u32x2 *>(&sH[buf][p][lds_o[it]]) = pc[p];
         }
@@ -754,7 +821,7 @@ conv3x3_halo_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
     // steps (tap, k-step); in program order step s issues the LDS reads of step s + 1 (two register sets of A fragments) and, at the
     // first k-step of a tap, the weight fragments of tap + 2 (a ring of three sets: 9 taps = 3 turns, the next slice's taps 0 / 1 land
     // where this slice's did), THEN its own MFMAs -- the compiler's s_waitcnt counts let the younger requests stay in flight.
-    f32x4 xr[XV];
+    XRegs xr;
     WFrags<NB, TJ> wr3[3];
     u32x4 af[2][TI][NA];
     auto read_a = [&](int buf, int step, u32x4 (&dst)[TI][NA]) {   // step = 2 tap + kk (compile-time at every call)
@@ -766,12 +833,13 @@ conv3x3_halo_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
             for (int p = 0; p < NA; ++p) dst[i][p] = *reinterpret_cast<const u32x4 *>(&sH[buf][p][abase[i] + toff]);
     };
     {
-        f32x4 first[XV];
+        XRegs first;
         load_x(cbeg, first);
         load_w(cbeg, 0, wr3[0]);
         load_w(cbeg, 1, wr3[1]);
         load_x(cbeg + 1, xr);
-        store_x(first, 0);
+        if constexpr (MRG) __syncthreads();   // s_gn
+        store_x(first, 0, cbeg);
     }
     __syncthreads();
 
@@ -823,7 +891,7 @@ conv3x3_halo_kernel(const float *__restrict__ X, const u32x4 *__restrict__ Wp, c
         // the next slice -> the other LDS buffer (its readers passed the previous barrier), its registers take the slice after it
 #if !(TF_HALO_ABLATE & 2)   // timing ablation 2: the halo is staged once (every slice reads the first one)
         if (cs + 1 < cend) {
-            store_x(xr, buf ^ 1);
+            store_x(xr, buf ^ 1, cs + 1);
             load_x(cs + 2, xr);
         }
 #endif
@@ -986,8 +1054,8 @@ bool halo_enabled()
     return v != 0;
 }
 
-template <int SP, int TI, int TJ, int WC>
-int launch_halo(const StreamCall &c, hipStream_t s)
+template <int SP, int TI, int TJ, int WC, bool MRG = false>
+int launch_halo(const StreamCall &c, hipStream_t s, const HaloMerge mg = HaloMerge{})
 {
     constexpr int BM = (4 / WC) * TI * 32, BN = WC * TJ * 32, PH = BM / 8;
     const int tiles_x = (c.cv.win + 7) / 8, tiles_y = (c.cv.hin + PH - 1) / PH;
@@ -1004,9 +1072,9 @@ int launch_halo(const StreamCall &c, hipStream_t s)
     if (gx > 0x7fffffffLL || gz > 65535 || npatches > 0x7fffffffLL) return TF_MSDA_ERR_BAD_DIMS;
     const bool partial = gz > 1;
     float *out = partial ? c.workspace : c.y;
-    hipLaunchKernelGGL((conv3x3_halo_kernel<SP, TI, TJ, WC>), dim3((unsigned)gx, (unsigned)gz), dim3(kThreads), 0, s, c.x, c.wp,
+    hipLaunchKernelGGL((conv3x3_halo_kernel<SP, TI, TJ, WC, MRG>), dim3((unsigned)gx, (unsigned)gz), dim3(kThreads), 0, s, c.x, c.wp,
                        partial ? nullptr : c.bias, partial ? nullptr : c.res, out, c.N, nblocks, (int)npatches, tiles_x, tiles_y,
-                       partial ? 0 : c.relu, cslices, c.cv);
+                       partial ? 0 : c.relu, cslices, c.cv, mg);
     if (hipGetLastError() != hipSuccess) return TF_MSDA_ERR_LAUNCH;
     if (partial) {
         const long long mn4 = (long long)c.M * c.N / 4;
@@ -1032,6 +1100,16 @@ int halo_dispatch(const StreamCall &c, hipStream_t s)
     if (c.N <= 64) return (f ? f >= 2 : big) ? launch_halo<SP, 2, 1, 2>(c, s) : launch_halo<SP, 1, 1, 2>(c, s);
     if (c.N <= 128) return (f ? f >= 4 : big) ? launch_halo<SP, 4, 1, 4>(c, s) : launch_halo<SP, 2, 1, 4>(c, s);
     return launch_halo<SP, 2, 2, 4>(c, s);
+}
+
+// the merged form (MRG): the mask head's shapes only -- one column tile of 32 (lay4 / lay5), 64 (lay3) or 128 channels
+template <int SP>
+int halo_dispatch_merge(const StreamCall &c, hipStream_t s, const HaloMerge &mg)
+{
+    if (c.N <= 32) return launch_halo<SP, 1, 1, 1, true>(c, s, mg);
+    if (c.N <= 64) return launch_halo<SP, 2, 1, 2, true>(c, s, mg);
+    if (c.N <= 128) return launch_halo<SP, 2, 1, 4, true>(c, s, mg);
+    return launch_halo<SP, 2, 2, 4, true>(c, s, mg);
 }
 
 // ---- the LDS-DMA GEMM: shape per call.  g_dma: -1 = TF_LINEAR_DMA or the default, 0 = off (the stream form), 1..4 = a fixed shape
@@ -1114,6 +1192,30 @@ int stream_dispatch_scheme(int sp, const StreamCall &c, hipStream_t s)
     case 3: return stream_dispatch<3, CONV>(c, s);
     default: return stream_dispatch<16, CONV>(c, s);
     }
+}
+
+extern "C" int tf_conv3x3_merge_packed_f32(const float *low, const float *fpn, const double *gn_workspace, const float *gamma,
+                                           const float *beta, int groups, float eps, const void *w_packed, const float *bias, float *y, int nimg,
+                                           int q_per_image, int lh, int lw, int H, int W, int cin, int cout, int relu, int terms, void *stream)
+{
+    if (!low || !fpn || !w_packed || !y) return TF_MSDA_ERR_NULL_POINTER;
+    if (gn_workspace && (!gamma || !beta)) return TF_MSDA_ERR_NULL_POINTER;
+    const int sp = split_scheme(terms);
+    if (nimg <= 0 || q_per_image <= 0 || (nimg % q_per_image) || lh <= 0 || lw <= 0 || H <= 0 || W <= 0 || cin <= 0 || cin > 320 || (cin % 32) != 0 ||
+        cout <= 0 || sp == 0 || (gn_workspace && (groups <= 0 || (cin % groups) != 0)))
+        return TF_MSDA_ERR_BAD_DIMS;
+    const long long M = (long long)nimg * H * W;
+    if ((M + 256) * cout * 4 >= 0xC0000000LL || (long long)nimg * lh * lw * cin * 4 >= 0xC0000000LL ||
+        (long long)(nimg / q_per_image) * H * W * cin * 4 >= 0xC0000000LL)
+        return TF_MSDA_ERR_BAD_DIMS;
+    uintptr_t al = reinterpret_cast<uintptr_t>(low) | reinterpret_cast<uintptr_t>(fpn) | reinterpret_cast<uintptr_t>(w_packed);
+    if (gn_workspace) al |= reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta);
+    if (al & 15) return TF_MSDA_ERR_BAD_DIMS;
+    StreamConv cv{nimg, H, W, cin, H, W, 3, 1, 1};
+    StreamCall c{low, static_cast<const u32x4 *>(w_packed), bias, nullptr, y, (int)M, 9 * cin, cout, relu, true, cv, nullptr, 1};
+    const HaloMerge mg{fpn, gn_workspace, gamma, beta, q_per_image, lh, lw, gn_workspace ? groups : 1, eps};
+    return sp == 3 ? halo_dispatch_merge<3>(c, static_cast<hipStream_t>(stream), mg)
+                   : halo_dispatch_merge<16>(c, static_cast<hipStream_t>(stream), mg);
 }
 
 #ifdef TF_STREAM_TRACE

@@ -237,6 +237,28 @@ class MaskHeadSmallConv(nn.Module):
             conv._tf_taps = hit
         return hit[1]
 
+    def _merged_levels(self, xp, feats, num_queries):
+        """lay2 .. out_lay with NO intermediate activation written in normalised or up-sampled form (round 6): every convolution
+        leaves its RAW output and one statistics pass over it; the next convolution applies GroupNorm + ReLU, the nearest
+        up-sampling and the adapter's broadcast add in its own fetch (fused.conv3x3_merged), the last one feeds gn5 + ReLU +
+        out_lay (fused.groupnorm_relu_conv3x3_c1).  Per level that is a read of the low-resolution tensor instead of a
+        normalise pass (read + write), a merge pass (read + 4x write) and a read of the merged tensor.  None: a kernel declined
+        (the caller runs the pass-by-pass route)."""
+        from . import fused
+        y = fused.conv3x3(xp, self._taps(self.lay2, xp.shape[1]), self.lay2.bias, False, 1)
+        if y is None:
+            return None
+        gn_prev = self.gn2
+        for conv, gn, feat in ((self.lay3, self.gn3, feats[0]), (self.lay4, self.gn4, feats[1]), (self.lay5, self.gn5, feats[2])):
+            ws = fused.groupnorm_stats(y, gn_prev)
+            if ws is None:
+                return None
+            y = fused.conv3x3_merged(y, feat, num_queries, self._taps(conv, conv.in_channels), conv.bias, gn=gn_prev, ws=ws)
+            if y is None:
+                return None
+            gn_prev = gn
+        return fused.groupnorm_relu_conv3x3_c1(y, self.gn5, self.out_lay)
+
     def _conv_gn_relu(self, x, conv, gn):
         """relu(gn(conv(x))) for a channels_last x [N, Cin(_pad), H, W]; -> channels_last [N, Cout, H, W]."""
         from . import fused
@@ -310,6 +332,10 @@ class MaskHeadSmallConv(nn.Module):
                 cin_pad = -(-c // 32) * 32
                 xp = x.new_zeros(n, h, wd, cin_pad)                                  # channels innermost, zero tail
                 xp[..., :c] = x.permute(0, 2, 3, 1)
+            if _mask_head_fused_tail:
+                out = self._merged_levels(xp.permute(0, 3, 1, 2), feats, num_queries)
+                if out is not None:
+                    return out
             x = self._conv_gn_relu(xp.permute(0, 3, 1, 2), self.lay2, self.gn2)
             for conv, gn, feat in ((self.lay3, self.gn3, feats[0]), (self.lay4, self.gn4, feats[1]), (self.lay5, self.gn5, feats[2])):
                 # round 6: nearest up-sampling + the broadcast add of the adapter's output in ONE pass (tf_upsample_add_nhwc_f32; the

@@ -864,6 +864,55 @@ def upsample_add(low, fpn, q_per_image):
     return out.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
 
 
+def groupnorm_stats(x, gn):
+    """The statistics pass of GroupNorm alone for a channels_last x [N, C, H, W]: 2 * N * groups doubles (sum | sum of squares per image
+    and group) for a consumer that normalises in its own fetch (conv3x3_merged).  None when not applicable."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and gn.num_channels == x.shape[1] and x.shape[1] % 4 == 0 and x.shape[1] <= 1024 and gn.num_groups <= 256
+            and x.shape[0] <= 65535 and not (x.data_ptr() & 15)):
+        return None
+    n, c, h, w = x.shape
+    with torch.cuda.device(x.device):
+        ws = torch.empty(2 * n * gn.num_groups, dtype=torch.float64, device=x.device)
+        rc = _cabi.lib().tf_groupnorm_stats_nhwc_f32(x.data_ptr(), ws.data_ptr(), n, h * w, c, gn.num_groups, h * w * c, _stream(x.device))
+    _cabi.check(rc, "tf_groupnorm_stats_nhwc_f32")
+    return ws
+
+
+def conv3x3_merged(low, fpn, q_per_image, w_taps, bias, gn=None, ws=None):
+    """3 x 3 / padding 1 convolution over  act(low) up-sampled (nearest) to fpn's size + fpn broadcast over the q_per_image queries of
+    its image  -- the mask head's FPN merge -- computed in the convolution's fetch (tf_conv3x3_merge_packed_f32): the merged tensor is
+    never written.  act = relu(gn(low)) from `ws` (groupnorm_stats of low) when gn is given, else identity.  low [N, Cin, h, w], fpn
+    [N / q_per_image, Cin, H, W] channels_last, w_taps [Cout, 9 * Cin] tap-major (a persistent tensor).  -> [N, Cout, H, W] channels_last,
+    or None when not applicable."""
+    if not (_split_linear and _conv_halo and low.is_cuda and low.dtype == torch.float32 and fpn.dtype == torch.float32 and low.dim() == 4
+            and fpn.dim() == 4 and fpn.device == low.device and low.shape[1] == fpn.shape[1] and q_per_image > 0
+            and low.shape[0] == fpn.shape[0] * q_per_image and low.is_contiguous(memory_format=torch.channels_last)
+            and fpn.is_contiguous(memory_format=torch.channels_last) and w_taps.dtype == torch.float32 and w_taps.dim() == 2
+            and w_taps.is_contiguous() and w_taps.device == low.device and not ((low.data_ptr() | fpn.data_ptr()) & 15)):
+        return None
+    n, cin, lh, lw = low.shape
+    H, W = fpn.shape[-2:]
+    cout = w_taps.shape[0]
+    if w_taps.shape[1] != 9 * cin or cin % 32 or cin > 320 or (gn is not None and (ws is None or gn.num_channels != cin or gn.weight is None)):
+        return None
+    if bias is not None and not (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout and bias.device == low.device):
+        return None
+    if (n * H * W + 256) * cout * 4 >= 0xC0000000 or n * lh * lw * cin * 4 >= 0xC0000000 or fpn.numel() * 4 >= 0xC0000000:
+        return None
+    packed = _packed_weight(w_taps, None)
+    if packed is None:
+        return None
+    with torch.cuda.device(low.device):
+        y = torch.empty((n, H, W, cout), dtype=torch.float32, device=low.device)
+        rc = _cabi.lib().tf_conv3x3_merge_packed_f32(
+            low.data_ptr(), fpn.data_ptr(), 0 if gn is None else ws.data_ptr(), 0 if gn is None else gn.weight.data_ptr(),
+            0 if gn is None else gn.bias.data_ptr(), 1 if gn is None else gn.num_groups, 0.0 if gn is None else float(gn.eps), packed.data_ptr(),
+            _ptr(bias), y.data_ptr(), n, q_per_image, lh, lw, H, W, cin, cout, 0, _terms(), _stream(low.device))
+    _cabi.check(rc, "tf_conv3x3_merge_packed_f32")
+    return y.permute(0, 3, 1, 2)   # NCHW shape over NHWC storage = channels_last
+
+
 def groupnorm_relu_conv3x3_c1(x, gn, conv):
     """conv(relu(gn(x))) for a 3 x 3 / padding 1 convolution to ONE channel (the mask head's out_lay behind gn5) of a channels_last
     x [N, C, H, W], C in {16, 32}: the normalised activation is never written.  -> [N, 1, H, W]; None when not applicable."""
