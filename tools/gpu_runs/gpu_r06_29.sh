@@ -1,6 +1,6 @@
 # Round 6, calls 29 / 38: where do the 14.5 (call 29) / 10.0 ms (call 38) of a cfg-5 frame go?  rocprofv3 kernel statistics of bench.py --config cfg5 (side legs off)
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/r06_38
+O=$GRAFT_REPO_ROOT/gpurun_out/r06_40
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python $GRAFT_REPO_ROOT/bench.py --config cfg5 --no-cpu-baseline --no-split3 --no-fp32-exact --no-parity --no-roofline --sequences 1 --no-single-sequence --steps 24 --warmup 4 --min-seconds 4 > $O/prof.log 2>&1
