@@ -286,7 +286,7 @@ def test_image_only_half_of_the_forward_can_run_ahead(host_op):
     assert plain[2] == ahead[2] and plain[3] == ahead[3]
 
 
-@pytest.mark.parametrize("name,n_frames", [("cfg2_wc", 5), ("cfg4_wc", 4)])
+@pytest.mark.parametrize("name,n_frames", [("cfg2_wc", 5), ("cfg4_wc", 4), ("cfg2_wc_reid", 6)])
 def test_unobserved_step_loop_defers_the_association_and_files_the_same_tracks(name, n_frames, host_op):
     """Round 6: `for blob in sequence: tracker.step(blob)` -- the reference's own loop, src/track.py:130-134 -- leaves every
     frame's association outstanding until the next step() (which first enqueues ITS image-only half) or until somebody reads
