@@ -462,6 +462,35 @@ def test_training_step_with_mask_head_matches_reference(host_op):
     compare_train_to_golden(loss_dict, total, grads, rtol=2e-4, fixture="train_cfg5_masks_small.npz")
 
 
+def test_criterion_layers_at_once_equals_the_loop_over_the_layers(host_op):
+    """Round 6: SetCriterion computes the class / cardinality / box losses of the final + five auxiliary decoder layers in one chain of
+    kernels with a leading layer dimension (criterion._layers_at_once) instead of looping (models/detr.py:266-289 of the reference):
+    the same values to fp32 round-off, the same gradients."""
+    from trackformer_amd import criterion as crit_mod
+    model, criterion, args = um.build_train(factory.build_model, config.make_args)
+    samples, targets = um.train_batch()
+    got = {}
+    for on in (True, False):
+        prev = crit_mod.set_layers_at_once(on)
+        try:
+            torch.manual_seed(7)
+            model.zero_grad()
+            outputs, tg, *_ = model(samples, [dict(t, prev_target=dict(t['prev_target'])) for t in targets])
+            loss_dict = criterion(outputs, tg)
+            total = sum(loss_dict[k] * criterion.weight_dict[k] for k in loss_dict if k in criterion.weight_dict)
+            total.backward()
+            got[on] = ({k: float(v) for k, v in loss_dict.items()},
+                       {n: float(p.grad.norm()) for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            crit_mod.set_layers_at_once(prev)
+    assert sorted(got[True][0]) == sorted(got[False][0]) and len(got[True][0]) >= 13   # (the small model: 3 decoder layers; BASELINE: 6 -> 25)
+    for k, v in got[False][0].items():
+        assert abs(got[True][0][k] - v) <= 2e-6 * max(1.0, abs(v)), (k, got[True][0][k], v)
+    assert sorted(got[True][1]) == sorted(got[False][1])
+    for n, v in got[False][1].items():
+        assert abs(got[True][1][n] - v) <= 1e-4 * max(abs(v), 1e-6 * max(got[False][1].values())), n
+
+
 def test_engine_train_step_reproduces_reference_loss_and_updates_weights(host_op):
     """engine.train_step (engine.py:119-158 body) + build_optimizer (train.py:93-120 groups)."""
     from trackformer_amd import engine

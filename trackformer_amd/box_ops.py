@@ -59,6 +59,19 @@ def generalized_box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
     return iou - (hull - union) / hull
 
 
+def generalized_box_iou_pairs(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    """GIoU of boxes1[i] with boxes2[i] ([N, 4] xyxy each -> [N]): the diagonal of generalized_box_iou, operation by operation, without
+    the N x N matrix the reference builds to take its diagonal (models/detr.py:320-323)."""
+    area1, area2 = box_area(boxes1), box_area(boxes2)
+    wh = (torch.min(boxes1[:, 2:], boxes2[:, 2:]) - torch.max(boxes1[:, :2], boxes2[:, :2])).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]
+    union = area1 + area2 - inter
+    iou = inter / union
+    wh = (torch.max(boxes1[:, 2:], boxes2[:, 2:]) - torch.min(boxes1[:, :2], boxes2[:, :2])).clamp(min=0)
+    hull = wh[:, 0] * wh[:, 1]
+    return iou - (hull - union) / hull
+
+
 def clip_boxes_to_image(boxes: Tensor, size) -> Tensor:
     """Clamp xyxy boxes into an image of size (h, w)."""
     h, w = size

@@ -4,6 +4,7 @@ Same surface as the reference's SetCriterion (models/detr.py:139-443) and its he
 (util/misc.py:448-463 accuracy, :522-571 dice / sigmoid focal loss).
 """
 import copy
+import os
 
 import torch
 import torch.distributed as dist
@@ -49,6 +50,21 @@ def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: f
         loss = torch.stack([l[m].mean(0) for l, m in zip(loss, query_mask)])
         return loss.sum() / num_boxes
     return loss.mean(1).sum() / num_boxes
+
+
+# DEFAULT since round 6 (TF_CRITERION_LAYERS_AT_ONCE=0 / set_layers_at_once(False): the reference's loop over the decoder layers)
+_LAYERS_AT_ONCE = os.environ.get("TF_CRITERION_LAYERS_AT_ONCE", "1") != "0"
+
+
+def set_layers_at_once(on):
+    global _LAYERS_AT_ONCE
+    prev, _LAYERS_AT_ONCE = _LAYERS_AT_ONCE, bool(on)
+    return prev
+
+
+def counts_match(indices, aux_indices):
+    n = sum(len(src) for src, _ in indices)
+    return all(sum(len(src) for src, _ in ind) == n for ind in aux_indices)
 
 
 class SetCriterion(nn.Module):
@@ -149,6 +165,76 @@ class SetCriterion(nn.Module):
         return {"loss_mask": sigmoid_focal_loss(src_masks, target_masks, num_boxes),
                 "loss_dice": dice_loss(src_masks, target_masks, num_boxes)}
 
+    def _layers_at_once(self, layer_outputs, targets, all_indices, num_boxes):
+        """The class (focal), cardinality and box losses of the final + auxiliary decoder layers computed TOGETHER (round 6): the
+        layers' predictions are stacked [L, B, Q, ...] and every loss is one chain of kernels with a leading layer dimension instead
+        of L chains (the reference loops over the layers, models/detr.py:266-289: ~70 launches forward and ~100 backward per layer on
+        [B, Q] tensors; 7.6 ms of a cfg-3 step sat in the criterion).  The arithmetic per element is that of loss_labels_focal /
+        loss_cardinality / loss_boxes; the GIoU of the matched pairs is computed for the pairs (box_ops.generalized_box_iou_pairs: the
+        diagonal the reference takes of an N x N matrix).  -> {key: 0-d tensor} with the reference's keys (`loss_ce`, `loss_ce_0`, ...),
+        or None when the layers cannot be stacked (the caller loops)."""
+        L = len(layer_outputs)
+        logits = [o['pred_logits'] for o in layer_outputs]
+        boxes = [o['pred_boxes'] for o in layer_outputs]
+        if any(t.shape != logits[0].shape for t in logits) or any(t.shape != boxes[0].shape for t in boxes):
+            return None
+        counts = [sum(len(src) for src, _ in ind) for ind in all_indices]
+        if len(set(counts)) != 1:
+            return None
+        logits, boxes = torch.stack(logits), torch.stack(boxes)          # [L, B, Q, C], [L, B, Q, 4]
+        dev = logits.device
+        B, Q, C = logits.shape[1:]
+        # (layer, image, query) of every matched prediction and its target's (image, index), layer by layer in the order the
+        # per-layer losses concatenate them
+        lay = torch.cat([torch.full((counts[0],), l, dtype=torch.int64) for l in range(L)])
+        bat = torch.cat([torch.full_like(src, i) for ind in all_indices for i, (src, _) in enumerate(ind)])
+        qry = torch.cat([src for ind in all_indices for (src, _) in ind])
+        tgt_of = [torch.cat([t_idx + off for (_, t_idx), off in zip(ind, self._offsets(targets))]) for ind in all_indices]
+        tgt = torch.cat(tgt_of)
+        lay, bat, qry, tgt = (t.to(dev, non_blocking=True) for t in (lay, bat, qry, tgt))
+        all_labels = torch.cat([t["labels"] for t in targets])
+        all_boxes = torch.cat([t["boxes"] for t in targets])
+        losses = {}
+        suffix = [''] + ['_%d' % i for i in range(L - 1)]
+        if 'labels' in self.losses:
+            classes = torch.full((L, B, Q), self.num_classes, dtype=torch.int64, device=dev)
+            matched = all_labels[tgt]
+            classes[lay, bat, qry] = matched
+            onehot = torch.zeros(L, B, Q, C + 1, dtype=logits.dtype, device=dev)
+            onehot.scatter_(3, classes.unsqueeze(-1), 1)
+            per_elem = sigmoid_focal_loss(logits, onehot[..., :-1], num_boxes, alpha=self.focal_alpha, gamma=self.focal_gamma,
+                                          reduction=False)
+            loss_ce = per_elem.mean(2).sum((1, 2)) / num_boxes * Q                       # [L]
+            for l in range(L):
+                losses['loss_ce' + suffix[l]] = loss_ce[l]
+            n0 = counts[0]
+            losses['class_error'] = 100 - accuracy(logits[0][bat[:n0], qry[:n0]], matched[:n0])[0]
+        if 'cardinality' in self.losses:
+            with torch.no_grad():
+                tgt_lengths = torch.as_tensor([len(v["labels"]) for v in targets], device=dev).float()
+                card_pred = (logits.argmax(-1) != C - 1).sum(2).float()                  # [L, B]
+                card = (card_pred - tgt_lengths[None]).abs().mean(1)
+            for l in range(L):
+                losses['cardinality_error' + suffix[l]] = card[l]
+        if 'boxes' in self.losses:
+            src_boxes = boxes[lay, bat, qry]                                             # [L * n, 4]
+            target_boxes = all_boxes[tgt]
+            loss_bbox = F.l1_loss(src_boxes, target_boxes, reduction='none').view(L, -1).sum(1) / num_boxes
+            a, b = box_ops.box_cxcywh_to_xyxy(src_boxes), box_ops.box_cxcywh_to_xyxy(target_boxes)
+            loss_giou = (1 - box_ops.generalized_box_iou_pairs(a, b)).view(L, -1).sum(1) / num_boxes
+            for l in range(L):
+                losses['loss_bbox' + suffix[l]] = loss_bbox[l]
+                losses['loss_giou' + suffix[l]] = loss_giou[l]
+        return losses
+
+    @staticmethod
+    def _offsets(targets):
+        off, out = 0, []
+        for t in targets:
+            out.append(off)
+            off += len(t["labels"])
+        return out
+
     def get_loss(self, loss, outputs, targets, indices, num_boxes, **kwargs):
         loss_map = {'labels': self.loss_labels_focal if self.focal_loss else self.loss_labels,
                     'cardinality': self.loss_cardinality, 'boxes': self.loss_boxes,
@@ -186,11 +272,18 @@ class SetCriterion(nn.Module):
             dist.all_reduce(num_boxes)
         num_boxes = torch.clamp(num_boxes / _world_size(), min=1).item()
 
-        losses = {}
-        for loss in self.losses:
-            losses.update(self.get_loss(loss, outputs, targets, indices, num_boxes))
-        for i, aux_outputs in enumerate(aux_list):
-            losses.update(self._extra_losses(aux_outputs, targets, num_boxes, f'_{i}', aux_indices[i]))
+        losses = None
+        if (_LAYERS_AT_ONCE and self.focal_loss and aux_list and all(ix is not None for ix in aux_indices) and counts_match(indices, aux_indices)
+                and all(loss in ('labels', 'cardinality', 'boxes', 'masks') for loss in self.losses)):
+            losses = self._layers_at_once([outputs_without_aux] + aux_list, targets, [indices] + list(aux_indices), num_boxes)
+            if losses is not None and 'masks' in self.losses:   # (the final layer only, as in the loop)
+                losses.update(self.get_loss('masks', outputs, targets, indices, num_boxes))
+        if losses is None:
+            losses = {}
+            for loss in self.losses:
+                losses.update(self.get_loss(loss, outputs, targets, indices, num_boxes))
+            for i, aux_outputs in enumerate(aux_list):
+                losses.update(self._extra_losses(aux_outputs, targets, num_boxes, f'_{i}', aux_indices[i]))
         if 'enc_outputs' in outputs:
             bin_targets = copy.deepcopy(targets)
             for bt in bin_targets:
