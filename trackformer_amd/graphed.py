@@ -403,6 +403,15 @@ class GraphedDetector:
             if a is not None and a["ran"] and a["img"].data_ptr() == img.data_ptr():
                 torch.cuda.current_stream(img.device).wait_event(a["done"])
 
+    def state_read(self, device=None):
+        """A consumer outside the detector call has just ENQUEUED a read of the last call's aliased results (`features`, `memory`,
+        out['mask_context']: static buffers of the slot that call decoded) on the current stream -- the tracker's lazy mask head runs
+        after the association.  prepare() must not overwrite that slot before this read: the slot's `free` event moves behind it."""
+        for slots in self._enc.values():
+            a = slots[self._slot]
+            if a is not None and a["read"] and (device is None or a["img"].device == torch.device(device)):
+                a["free"].record(torch.cuda.current_stream(a["img"].device))
+
     def _mark_read(self, img, slot):
         """An eager forward on the current stream read slot `slot`'s static image: prepare() must not overwrite it before."""
         a = self._enc[(tuple(img.shape), img.device)][slot]

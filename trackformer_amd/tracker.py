@@ -609,7 +609,10 @@ class Tracker:
             track_masks = label[None] == index_map    # device-side per-track views (Track.mask keeps the reference's meaning)
             for i, track in enumerate(self.tracks):
                 track.mask = track_masks[i]
-            masks_host = _LabelMap(label.cpu().numpy())
+            # the copy to the host is enqueued, not waited for.  (Measured and not kept: the mask head on a stream of its own, so that
+            # the next frame's decoder half does not queue behind it -- 110.9 against 119.9 frames/s, three sequences 105.7 against
+            # 129.5: the head's large launches next to the decoder half's small ones slow the chain more than the queueing did)
+            masks_host = _LabelMap(label)
         elif 'masks' in result and self.tracks:
             # tracker.py:521-532 of the reference: a pixel belongs to the track with the largest probability there, if that
             # probability exceeds 0.5 -- `logical_and(probs > 0.5, index_map == probs.argmax(0))`.  Ownership is exclusive, so
@@ -625,7 +628,7 @@ class Tracker:
             track_masks = label[None] == index_map    # device-side per-track views (Track.mask keeps the reference's meaning)
             for i, track in enumerate(self.tracks):
                 track.mask = track_masks[i]
-            masks_host = _LabelMap(label.cpu().numpy())
+            masks_host = _LabelMap(label)
 
         if self.tracks:   # one stack + one numpy view for all tracks instead of three conversions per track
             if cur is None or cur[0].shape[0] != len(self.tracks):
@@ -666,6 +669,14 @@ class Tracker:
         if self.reid_sim_only:
             self.tracks_to_inactive(self.tracks)
 
+    def _context_read(self, device):
+        """The lazy mask head has just been enqueued: it reads the detector's aliased buffers (GraphedDetector: the slot the frame
+        was decoded from) AFTER the detector call returned -- tell the wrapper, or the next-but-one frame's image-only half, prepared
+        on the side stream, could overwrite them while the head is still running (nothing on the host waits for the head any more)."""
+        fn = getattr(self.obj_detector, "state_read", None)
+        if fn is not None:
+            fn(device)
+
     def _label_map_fused(self, outputs, blob, orig_h, orig_w):
         """The frame's mask ownership map (int16 [orig_h, orig_w]: index into self.tracks or -1) straight from the mask head's
         low-resolution logits -- PostProcessSegm's bilinear resize / sigmoid / crop / nearest resize and the reference's per-pixel
@@ -684,11 +695,12 @@ class Tracker:
         module = getattr(self.obj_detector, "model", self.obj_detector)
         hs = outputs['hs_embed']
         padded = refs + [refs[-1]] * (-len(refs) % 32)     # (as _resolve_masks: the convolution library tunes per shape)
-        idx = torch.tensor(padded, dtype=torch.long, device=hs.device)
-        with torch.no_grad():
-            rows = module.mask_rows(outputs['mask_context'], hs.index_select(1, idx))[0]   # [n_padded, H, W]
         pos = {row: k for k, row in enumerate(refs)}
         size = blob["size"].detach().cpu().reshape(-1).tolist()                            # the (un-padded) size of this image
+        idx = torch.tensor(padded, dtype=torch.long).to(hs.device, non_blocking=True)
+        with torch.no_grad():
+            rows = module.mask_rows(outputs['mask_context'], hs.index_select(1, idx))[0]   # [n_padded, H, W]
+        self._context_read(hs.device)
         label = fused.mask_label_map(rows.contiguous(), [pos[t.mask.row] for t in self.tracks], (int(size[0]), int(size[1])),
                                      (int(size[0]), int(size[1])), (orig_h, orig_w))
         if label is None:
@@ -712,6 +724,7 @@ class Tracker:
             idx = torch.tensor(padded, dtype=torch.long, device=hs.device)
             with torch.no_grad():
                 rows = module.mask_rows(outputs['mask_context'], hs.index_select(1, idx))[:, :len(refs)]
+            self._context_read(hs.device)
             seg = self.obj_detector_post['segm']([{}], {'pred_masks': rows}, orig_size, size,
                                                  return_probs=True)[0]['masks'].squeeze(dim=1)
             by_row = {row: seg[k] for k, row in enumerate(refs)}
@@ -789,11 +802,50 @@ del _name
 
 class _LabelMap:
     """One frame's mask ownership on the host: label[y, x] = index (into that frame's track list) of the track that owns the
-    pixel, -1 for none.  `of(i)` is a handle that turns into track i's boolean mask when the results are read."""
-    __slots__ = ("label",)
+    pixel, -1 for none.  `of(i)` is a handle that turns into track i's boolean mask when the results are read.
+
+    Round 6: built from the DEVICE map without waiting for it -- the copy into pinned host memory is enqueued behind the mask head
+    on the tracker's stream and an event is recorded; `label` waits for that event when somebody first reads it (the results, at
+    the end of the sequence in the reference's loop).  step_finish used to block on this copy: with ~100 live tracks the host sat
+    idle for the whole mask head (~4 ms of a 9 ms cfg-5 frame) before it could enqueue the next frame's decoder half.  At most
+    `_MAX_PINNED` frames keep their pinned buffer; older ones are moved to ordinary memory (their copies finished long ago)."""
+    __slots__ = ("_label", "_pinned", "_event")
+    _MAX_PINNED = 8
+    _outstanding = None   # deque of maps that still hold a pinned buffer (process-wide: pinned memory is a shared resource)
 
     def __init__(self, label):
-        self.label = label
+        self._pinned = self._event = None
+        if torch.is_tensor(label) and label.is_cuda:
+            with torch.cuda.device(label.device):
+                self._pinned = torch.empty(label.shape, dtype=label.dtype, pin_memory=True)
+                self._pinned.copy_(label, non_blocking=True)
+                self._event = torch.cuda.Event()
+                self._event.record(torch.cuda.current_stream(label.device))
+            self._label = None
+            if _LabelMap._outstanding is None:
+                _LabelMap._outstanding = deque()
+            q = _LabelMap._outstanding
+            q.append(self)
+            while len(q) > self._MAX_PINNED:
+                q.popleft()._settle()
+        else:
+            self._label = label.cpu().numpy() if torch.is_tensor(label) else label
+
+    def _settle(self):
+        if self._label is None:
+            self._event.synchronize()
+            self._label = self._pinned.numpy().copy()
+            self._pinned = self._event = None
+
+    @property
+    def label(self):
+        if self._label is None:
+            self._settle()
+            try:
+                _LabelMap._outstanding.remove(self)
+            except (ValueError, AttributeError):
+                pass
+        return self._label
 
     def of(self, i):
         return _LabelMask(self, i)
