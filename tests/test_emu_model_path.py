@@ -117,14 +117,27 @@ def test_mask_head_through_the_split_product_convolutions():
         with gpu_path_on_emulator() as lib:
             got = head(x, bm, fpns)
             calls = dict(lib.calls)
+            lib.calls.clear()
+            prev_tail = ds.set_mask_head_fused_tail(False)      # the pass-by-pass route of rounds 4-5
+            try:
+                passes = head(x, bm, fpns)
+                calls_passes = dict(lib.calls)
+            finally:
+                ds.set_mask_head_fused_tail(prev_tail)
             prev = ds.set_mask_head_split(False)
             try:
                 off = head(x, bm, fpns)
             finally:
                 ds.set_mask_head_split(prev)
-    n_conv = sum(calls.get(k, 0) for k in ("tf_conv3x3_split_f32", "tf_conv3x3_splitk_f32", "tf_conv_packed_f32"))
-    assert n_conv == 4 and calls.get("tf_groupnorm_relu_nhwc_f32") == 4, calls   # GroupNorm + ReLU in one pass each
-    assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    # round 6 (the default): lay2 as a convolution, lay3 .. lay5 with the FPN merge and the previous GroupNorm + ReLU in their fetch
+    # (statistics passes only), gn5 + ReLU + out_lay in one pass, the front's GroupNorm + ReLU through the library's own kernel
+    assert calls.get("tf_conv_packed_f32", 0) + calls.get("tf_conv3x3_split_f32", 0) == 1 and calls.get("tf_conv3x3_merge_packed_f32") == 3, calls
+    assert calls.get("tf_groupnorm_stats_nhwc_f32") == 3 and calls.get("tf_groupnorm_relu_conv3x3_c1_nhwc_f32") == 1, calls
+    assert calls.get("tf_groupnorm_relu_nhwc_f32") == 1 and calls.get("tf_upsample_add_nhwc_f32") == 1, calls
+    n_conv = sum(calls_passes.get(k, 0) for k in ("tf_conv3x3_split_f32", "tf_conv3x3_splitk_f32", "tf_conv_packed_f32"))
+    assert n_conv == 4 and calls_passes.get("tf_groupnorm_relu_nhwc_f32") == 4, calls_passes   # GroupNorm + ReLU in one pass each
+    for out in (got, passes):
+        assert out.shape == ref.shape and float((out - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
     assert torch.equal(off, ref)     # switched off: the library path
 
 
