@@ -785,7 +785,10 @@ def _guarded_state(name):
         d = self.__dict__
         if d.get("_deferred_handle") is not None and not d.get("_busy"):
             self._flush_deferred()
-        return d[key]
+        try:
+            return d[key]
+        except KeyError:
+            raise AttributeError("%r object has no attribute %r (set by reset())" % (type(self).__name__, name)) from None
 
     def put(self, value):
         d = self.__dict__
