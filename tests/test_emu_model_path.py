@@ -131,7 +131,8 @@ def test_mask_head_through_the_split_product_convolutions():
                 ds.set_mask_head_split(prev)
     # round 6 (the default): lay2 as a convolution, lay3 .. lay5 with the FPN merge and the previous GroupNorm + ReLU in their fetch
     # (statistics passes only), gn5 + ReLU + out_lay in one pass, the front's GroupNorm + ReLU through the library's own kernel
-    assert calls.get("tf_conv_packed_f32", 0) + calls.get("tf_conv3x3_split_f32", 0) == 1 and calls.get("tf_conv3x3_merge_packed_f32") == 3, calls
+    # (+ lay1's image part, once per image)
+    assert calls.get("tf_conv_packed_f32", 0) + calls.get("tf_conv3x3_split_f32", 0) == 2 and calls.get("tf_conv3x3_merge_packed_f32") == 3, calls
     assert calls.get("tf_groupnorm_stats_nhwc_f32") == 3 and calls.get("tf_groupnorm_relu_conv3x3_c1_nhwc_f32") == 1, calls
     assert calls.get("tf_groupnorm_relu_nhwc_f32") == 1 and calls.get("tf_upsample_add_nhwc_f32") == 1, calls
     n_conv = sum(calls_passes.get(k, 0) for k in ("tf_conv3x3_split_f32", "tf_conv3x3_splitk_f32", "tf_conv_packed_f32"))

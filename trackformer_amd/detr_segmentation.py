@@ -259,6 +259,23 @@ class MaskHeadSmallConv(nn.Module):
             gn_prev = gn
         return fused.groupnorm_relu_conv3x3_c1(y, self.gn5, self.out_lay)
 
+    def _taps_part(self, c0, c1):
+        """[Cout, 9 * (c1 - c0)] tap-major weight of lay1 restricted to its input channels c0 .. c1 (the image part of the decomposition in
+        forward()), cached on the module with the weight's version."""
+        conv = self.lay1
+        hit = getattr(conv, "_tf_taps_part", None)
+        key = (conv.weight._version, c0, c1)
+        if hit is None or hit[0] != key or hit[1].device != conv.weight.device:
+            w = conv.weight.detach()[:, c0:c1]
+            hit = (key, w.permute(0, 2, 3, 1).reshape(w.shape[0], 9 * (c1 - c0)).contiguous())
+            if w.is_cuda and torch.cuda.is_current_stream_capturing():
+                return hit[1]   # built inside a graph's memory pool: part of that graph, never a cached buffer
+            if w.is_cuda:
+                from . import fused
+                fused._publish_barrier(w.device)
+            conv._tf_taps_part = hit
+        return hit[1]
+
     def _conv_gn_relu(self, x, conv, gn):
         """relu(gn(conv(x))) for a channels_last x [N, Cin(_pad), H, W]; -> channels_last [N, Cout, H, W]."""
         from . import fused
@@ -287,7 +304,14 @@ class MaskHeadSmallConv(nn.Module):
         # What does not depend on the query is computed ONCE per image: lay1 over cat([x repeated per query, attention maps])
         # == lay1_img(x) + lay1_att(maps) -- the image part (and the bias) here, the attention part per query below -- and
         # the three adapter convolutions of the backbone features
-        y_img = F.conv2d(x, self.lay1.weight[:, :c_img], self.lay1.bias, padding=1)                 # [B, dim, h, w]
+        y_img = None
+        if split and _mask_head_fused_tail and c_img % 32 == 0:
+            # lay1's image part through the split-product convolution as well (the library picked a grouped-convolution kernel that
+            # ran this 1 050-pixel, 256 -> 264 layer at ~5 TFLOP/s: 0.27 ms per frame)
+            from . import fused
+            y_img = fused.conv3x3(x.contiguous(memory_format=torch.channels_last), self._taps_part(0, c_img), self.lay1.bias, False, 1)
+        if y_img is None:
+            y_img = F.conv2d(x, self.lay1.weight[:, :c_img], self.lay1.bias, padding=1)             # [B, dim, h, w]
         feats = [self.adapter1(fpns[0]), self.adapter2(fpns[1]), self.adapter3(fpns[2])]
         if split:
             feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
