@@ -79,6 +79,7 @@ class _GeometryCache:
         t = self._ones.get(key)
         if t is None:
             t = self._ones[key] = torch.ones(bs, n_levels, 2, dtype=torch.float32, device=device)
+            t._tf_unit = True   # (consumers skip the multiplication by exactly 1.0: DeformableTransformerDecoder.forward)
         return t
 
     def encoder_reference_points(self, shapes, valid_ratios, unit_ratios):
@@ -538,8 +539,12 @@ class DeformableTransformerDecoder(nn.Module):
         output = tgt
         intermediate = []
         intermediate_reference_points = []
+        unit = getattr(src_valid_ratios, "_tf_unit", False)   # all-valid masks: the ratios are the cached tensor of ones
         for lid, layer in enumerate(self.layers):
-            if reference_points.shape[-1] == 4:
+            if unit:
+                # x * 1.0 is x: the reference's concatenation + multiplication (deformable_transformer.py:343-348) are a broadcast view
+                reference_points_input = reference_points[:, :, None].expand(-1, -1, src_valid_ratios.shape[1], -1)
+            elif reference_points.shape[-1] == 4:
                 reference_points_input = reference_points[:, :, None] \
                     * torch.cat([src_valid_ratios, src_valid_ratios], -1)[:, None]
             else:
