@@ -140,6 +140,8 @@ def parse_args():
     ap.add_argument("--no-single-sequence", action="store_true")
     ap.add_argument("--no-prepare", action="store_true",
                     help="do not run the next frame's image-only half ahead of the association (Tracker.step_prepare)")
+    ap.add_argument("--look-ahead", type=int, default=2,
+                    help="frames whose image-only half may be enqueued ahead of the frame being associated (capped by Tracker.look_ahead)")
     ap.add_argument("--no-fp32-exact", action="store_true",
                     help="skip the second measurement with every matrix product in fp32 (hipBLASLt / library convolutions)")
     ap.add_argument("--no-parity", action="store_true",
@@ -275,13 +277,21 @@ def build_model(cfg, device):
     return model, criterion, post, margs
 
 
-def build_tracker(model, post, use_graph):
+def sequence_stream(device, lanes=1, lane=0):
+    """The stream a sequence's tracker runs on (dist_utils.sequence_stream, what track_sequences uses: high priority for a single
+    sequence -- the decoder half and the post-processing, ~150 small launches the host waits for, are dispatched ahead of the
+    image-only halves GraphedDetector runs on its side streams --, normal priority for interleaved sequences)."""
+    from trackformer_amd.dist_utils import sequence_stream as make
+    return make(device, lanes, lane)
+
+
+def build_tracker(model, post, use_graph, lanes=1, lane=0):
     from trackformer_amd import config
     from trackformer_amd.tracker import Tracker
     detector = model
     if use_graph:
         from trackformer_amd.graphed import GraphedDetector
-        detector = GraphedDetector(model, bucket=1)   # the benchmark's track-query count is fixed: no filler queries
+        detector = GraphedDetector(model, bucket=1, lanes=lanes, lane=lane)   # the benchmark's track-query count is fixed: no filler queries
     tracker = Tracker(detector, post, config.tracker_cfg(), False)
     tracker.reset()
     return tracker
@@ -420,12 +430,15 @@ def measure_parity(device, pipelined=True):
         # reference's own Tracker (full_tracker_cfg2_wc64.npz): ids of every frame, and that the frames really were prepared
         zw = np.load(os.path.join(T.GOLDEN, "full_tracker_cfg2_wc64.npz"))
         n = len(zw["active_per_frame"])
-        tr, rw, act, prepared = T._run_wc_tracker_pipelined(case, device, setup, n, host_frames=False)
+        with torch.cuda.stream(sequence_stream(device)):   # (the high-priority stream the timed loop runs on)
+            tr, rw, act, prepared = T._run_wc_tracker_pipelined(case, device, setup, n, host_frames=False)
         same_shape = rw.shape == zw["rows"].shape
         line["path"] = "pipelined"
         line["pipelined"] = {
             "against": "tests/golden/full_tracker_cfg2_wc64.npz (the reference's Tracker on CPU, well-conditioned 64-frame sequence, 800x1333)",
-            "loop": "step_async(t) -> step_prepare(t+1) -> step_finish(t), frames resident in HBM: the loop run_tracking times",
+            "loop": "step_async(t) -> step_prepare(t+1, t+2) -> step_finish(t), frames resident in HBM, on a high-priority stream: "
+                    "the loop run_tracking times",
+            "look_ahead": int(tr.look_ahead),
             "frames": int(n), "frames_prepared": int(prepared), "track_rows": int(rw.shape[0]),
             "ids_equal": bool(same_shape and np.array_equal(rw[:, [0, 1, 7]], zw["rows"][:, [0, 1, 7]])
                               and int(zw["num_tracks"]) == tr.track_num and zw["active_per_frame"].tolist() == act),
@@ -833,16 +846,17 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
     one sequence's forward runs on the GPU the host does another one's association; frames of one sequence stay strictly
     sequential.  (Round 2 used one thread per sequence: with the association leg at work they serialise on the GIL and
     four threads are slower than one, profiles/r03_sequences_sweep.txt.)"""
-    trackers = [build_tracker(model, post, use_graph=not args.no_graph) for _ in range(n_seq)]
+    trackers = [build_tracker(model, post, use_graph=not args.no_graph, lanes=n_seq, lane=k) for k in range(n_seq)]
     # (the look-ahead policy of dist_utils.track_sequences: not for multi-frame models with several sequences in flight)
     look_ahead = not args.no_prepare and (n_seq == 1 or not getattr(model, "multi_frame_attention", False))
+    depth = min(trackers[0].look_ahead, args.look_ahead) if look_ahead else 0
     seeder = TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds)
     frames = make_frames(device, cfg["size"], host=args.host_frames)
-    streams = [torch.cuda.Stream(device) for _ in range(n_seq)]
+    streams = [sequence_stream(device, n_seq, k) for k in range(n_seq)]
 
     def run_set(steps):
         per_seq = [steps // n_seq + (1 if i < steps % n_seq else 0) for i in range(n_seq)]
-        handles, issued, done = [None] * n_seq, [0] * n_seq, [0] * n_seq
+        handles, issued, done, ahead = [None] * n_seq, [0] * n_seq, [0] * n_seq, [0] * n_seq
         torch.cuda.set_device(device)
         with torch.no_grad():
             while any(done[s] < per_seq[s] for s in range(n_seq)):
@@ -850,10 +864,14 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
                     with torch.cuda.stream(streams[s]):
                         nxt = frames[(s + issued[s]) % len(frames)] if issued[s] < per_seq[s] else None
                         if handles[s] is not None:
-                            if nxt is not None and look_ahead:
-                                # the image-only half of the next frame (backbone, encoder) goes to the GPU BEFORE the host
-                                # associates this one: Tracker.step_prepare -- a single sequence no longer leaves the GPU idle
-                                trackers[s].step_prepare(nxt, image_ready=not args.host_frames)   # (device frames: resident since before the run)
+                            # the image-only halves of the next frames (backbone, encoder) go to the GPU BEFORE the host associates
+                            # this one: Tracker.step_prepare -- a single sequence no longer leaves the GPU idle; up to
+                            # `depth` frames ahead (Tracker.look_ahead: 2 with graphs -- the halves of t + 1 and t + 2 share the chip)
+                            while ahead[s] < depth and issued[s] + ahead[s] < per_seq[s]:
+                                blob = frames[(s + issued[s] + ahead[s]) % len(frames)]
+                                if not trackers[s].step_prepare(blob, image_ready=not args.host_frames):   # (device frames: resident since before the run)
+                                    break
+                                ahead[s] += 1
                             trackers[s].step_finish(handles[s])
                             handles[s] = None
                             done[s] += 1
@@ -861,12 +879,13 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
                             seeder.seed(trackers[s])
                             handles[s] = trackers[s].step_async(nxt)
                             issued[s] += 1
+                            ahead[s] = max(0, ahead[s] - 1)
         for st in streams:
             st.synchronize()
 
     # warm-up (MIOpen find mode and the host-side caches are filled here; >= 4 steps per sequence: both HIP graphs of a
     # multi-frame model), then time
-    run_set(n_seq * max(4, (args.warmup + n_seq - 1) // n_seq))
+    run_set(n_seq * max(10, (args.warmup + n_seq - 1) // n_seq))   # (>= 10: every slot's pair of graphs exists before the timed region)
     torch.cuda.synchronize()
     from trackformer_amd import runtime
     runtime.settle_heap()   # model, trackers and graphs exist: the cyclic collector need not walk them again
@@ -893,7 +912,7 @@ def run_plain_step(cfg, args, device, world, model, post, margs, seeds=None, def
     tracker.reset()
     tracker.deferred = bool(deferred)
     frames = make_frames(device, cfg["size"], host=True)
-    stream = torch.cuda.Stream(device)
+    stream = sequence_stream(device)
     count = [0]
 
     def run_set(steps):
@@ -1130,9 +1149,10 @@ def main():
                        "global_batch": world * (2 if train else 1),
                        "parallelism": ("DDP x%d (RCCL all-reduce)" if train else "sequence-sharded x%d") % world,
                        "sequences_per_gpu": n_seq, "hip_graph": not args.no_graph and not train,
-                       **({"pipelined": "the next frame's backbone + encoder are enqueued before the host associates the current "
-                                        "frame, on a side stream next to the current frame's decoder half (Tracker.step_prepare; "
-                                        "results those of step())"}
+                       **({"pipelined": "the backbone + encoder of the next frames (Tracker.look_ahead: two for a single-frame model "
+                                        "without a mask head, else one) are enqueued before the host associates the current frame, "
+                                        "on side streams next to the current frame's decoder half (Tracker.step_prepare; results "
+                                        "those of step()); the sequence runs on a high-priority stream (dist_utils.sequence_stream)"}
                           if cfg["kind"] == "track" and not args.no_prepare else {}),
                        "linears": (_ARITH[fused.split_terms()][0] + ", f32 accumulate (own kernels)")
                                   if fused.split_linear_enabled() and not train else "f32 (hipBLASLt)",

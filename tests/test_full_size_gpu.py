@@ -316,9 +316,10 @@ def test_full_size_well_conditioned_64_frames_every_id(dev, setup):
     _compare_wc(z, tracker, rows, active)
 
 
-def _run_wc_tracker_pipelined(case, dev, setup, n_frames, host_frames=False, unobserved=False):
-    """The loop `bench.py` TIMES (run_tracking): step_async(t) -> step_prepare(t + 1) -> step_finish(t), the image-only half
-    of frame t + 1 on GraphedDetector's side stream into alternating buffers while the host associates frame t.  Frames
+def _run_wc_tracker_pipelined(case, dev, setup, n_frames, host_frames=False, unobserved=False, depth=None):
+    """The loop `bench.py` TIMES (run_tracking): step_async(t) -> step_prepare(t + 1, t + 2) -> step_finish(t), the image-only
+    halves of the next frames on GraphedDetector's side streams into its rotating buffers while the host associates frame t
+    (depth: frames ahead; None = Tracker.look_ahead, the policy of the timed loop).  Frames
     resident in HBM before the sequence starts (`image_ready`, the driver's line) or in pinned host memory (uploaded on the
     side stream inside the step, as the reference's step does: tracker.py:283-284).  -> (tracker, rows, active, prepared)."""
     from trackformer_amd import config, fused, runtime
@@ -353,14 +354,8 @@ def _run_wc_tracker_pipelined(case, dev, setup, n_frames, host_frames=False, uno
                     assert tracker.__dict__.get("_deferred_handle") is not None
                 active = None
             else:
-                handle = tracker.step_async(blobs[0])
-                for i in range(len(blobs)):
-                    if i + 1 < len(blobs):
-                        prepared += bool(tracker.step_prepare(blobs[i + 1], image_ready=not host_frames))
-                    tracker.step_finish(handle)
-                    active.append(len(tracker.tracks))
-                    if i + 1 < len(blobs):
-                        handle = tracker.step_async(blobs[i + 1])
+                prepared = um.pipelined_loop(tracker, blobs, depth=depth, on_finish=lambda i: active.append(len(tracker.tracks)),
+                                             image_ready=not host_frames)
         torch.cuda.synchronize(dev)
     finally:
         fused.set_split_linear(prev_split)
@@ -371,7 +366,7 @@ def _run_wc_tracker_pipelined(case, dev, setup, n_frames, host_frames=False, uno
     return tracker, rows, active, prepared
 
 
-@pytest.mark.parametrize("frames", ["hbm_frames", "host_frames"])
+@pytest.mark.parametrize("frames", ["hbm_frames", "host_frames", "hbm_frames_one_ahead"])
 def test_full_size_pipelined_tracker_64_frames_every_id(dev, frames):
     """VERDICT r05 task 1(a): the configuration `bench.py`'s `value` is measured in -- 800x1333, graph_split_linear (the fp16
     split product), two graphs, the image-only half of the next frame prepared on the side stream -- over all 64 frames of the
@@ -379,9 +374,11 @@ def test_full_size_pipelined_tracker_64_frames_every_id(dev, frames):
     and at least 60 of the 63 possible frames really were prepared (the first ones run before the graphs exist)."""
     z = np.load(os.path.join(GOLDEN, "full_tracker_cfg2_wc64.npz"))
     tracker, rows, active, prepared = _run_wc_tracker_pipelined("cfg2_full", dev, "graph_split_linear", len(z["active_per_frame"]),
-                                                                host_frames=frames == "host_frames")
+                                                                host_frames=frames == "host_frames",
+                                                                depth=1 if frames.endswith("one_ahead") else None)
     _compare_wc(z, tracker, rows, active)
     assert prepared >= 60, prepared
+    assert tracker.look_ahead == 2   # (two frames ahead is the timed loop's policy for this model: round 6)
 
 
 def test_full_size_unobserved_step_loop_64_frames_every_id(dev):

@@ -181,8 +181,9 @@ def test_tracker_variants_match_reference(name, host_op):
 def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None, prepare=False, unobserved=False):
     """Tracker.step over a sequence of tests/util_models.WC_TRACKER_CASES: the well-conditioned detector (the same seeded
     weights with um.shape_well_conditioned's planted circuit).  wrap: detector -> detector (e.g. GraphedDetector).
-    prepare: the pipelined form -- step_async(t), step_prepare(t + 1), step_finish(t): the image-only half of the next
-    frame is enqueued before this frame's association runs (Tracker.step_prepare)."""
+    prepare: the pipelined form -- step_async(t), step_prepare(t + 1 ..), step_finish(t): the image-only half of the next
+    frame(s) is enqueued before this frame's association runs (Tracker.step_prepare; True: as many frames ahead as
+    Tracker.look_ahead says, an int: that many -- tests/util_models.pipelined_loop)."""
     case, frames, reid = um.WC_TRACKER_CASES[name]
     model, post, args = um.build(case, factory.build_model, config.make_args, device=device)
     um.shape_well_conditioned(model)
@@ -210,17 +211,11 @@ def run_wc_tracker(name, device="cpu", wrap=None, n_frames=None, prepare=False, 
                 outstanding += tracker.__dict__.get("_deferred_handle") is not None
             tracker.steps_outstanding, tracker.frames_prepared = outstanding, prepared
         elif prepare:
-            prepared = 0
-            handle = tracker.step_async(blobs[0])
-            for i in range(len(blobs)):
-                if i + 1 < len(blobs):
-                    prepared += bool(tracker.step_prepare(blobs[i + 1]))
-                tracker.step_finish(handle)
+            def counts(i):
                 active.append(len(tracker.tracks))
                 inactive.append(len(tracker.inactive_tracks))
-                if i + 1 < len(blobs):
-                    handle = tracker.step_async(blobs[i + 1])
-            tracker.frames_prepared = prepared
+            tracker.frames_prepared = um.pipelined_loop(tracker, blobs, depth=None if prepare is True else int(prepare),
+                                                        on_finish=counts)
         else:
             for blob in blobs:
                 tracker.step(blob)
@@ -340,15 +335,7 @@ def run_mask_tracker(device="cpu", frames=3, lazy_masks=False, wrap=None, prepar
     blobs = um.tracker_sequence(n_frames=frames) if frames > 3 else um.tracker_sequence()[:frames]
     with torch.no_grad():
         if prepare:
-            prepared = 0
-            handle = tracker.step_async(blobs[0])
-            for i in range(len(blobs)):
-                if i + 1 < len(blobs):
-                    prepared += bool(tracker.step_prepare(blobs[i + 1]))
-                tracker.step_finish(handle)
-                if i + 1 < len(blobs):
-                    handle = tracker.step_async(blobs[i + 1])
-            tracker.frames_prepared = prepared
+            tracker.frames_prepared = um.pipelined_loop(tracker, blobs, depth=None if prepare is True else int(prepare))
         else:
             for blob in blobs:
                 tracker.step(blob)

@@ -337,3 +337,26 @@ WC_TRACKER_CASES = {
     "cfg2_wc_reid": ("cfg2_deformable_tracking", 24, True),     # inactive_patience 5: B tracks come back after two frames
     "cfg4_wc": ("cfg4_multi_frame_tracking", 12, False),        # multi_frame: prev_features through the Tracker's deque
 }
+
+
+def pipelined_loop(tracker, blobs, depth=None, on_finish=None, **prepare_kw):
+    """The loop `bench.py` times (run_tracking) and dist_utils.track_sequences runs: step_async(t) -> step_prepare(t + 1 ..
+    t + depth) -> step_finish(t).  depth: frames whose image-only half may be enqueued ahead of the frame being associated
+    (default: the tracker's own policy, Tracker.look_ahead -- 2 under GraphedDetector with a single-frame model, otherwise 1).
+    on_finish(i): called after frame i's association.  -> number of frames that really were prepared."""
+    depth = int(getattr(tracker, "look_ahead", 1)) if depth is None else int(depth)
+    prepared, upto = 0, 0           # upto: the highest frame index step_prepare accepted
+    handle = tracker.step_async(blobs[0])
+    for i in range(len(blobs)):
+        upto = max(upto, i)
+        while upto < min(i + depth, len(blobs) - 1):
+            if not tracker.step_prepare(blobs[upto + 1], **prepare_kw):
+                break
+            upto += 1
+            prepared += 1
+        tracker.step_finish(handle)
+        if on_finish is not None:
+            on_finish(i)
+        if i + 1 < len(blobs):
+            handle = tracker.step_async(blobs[i + 1])
+    return prepared

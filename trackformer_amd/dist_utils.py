@@ -7,6 +7,8 @@ runs on "gloo" for the CPU tests.
 """
 import os
 
+from collections import deque
+
 import torch
 import torch.distributed as dist
 
@@ -159,6 +161,32 @@ def gather_results(local_results):
     return out
 
 
+# streams of interleaved lanes, as indices into PyTorch's normal-priority stream pool (runtime.pool_stream): lane k's tracker runs on
+# stream LANE_MAINS[k], its GraphedDetector's side stream is LANE_SIDES[k] (TF_LANE_MAINS / TF_LANE_SIDES: comma-separated, A/B aid)
+# (a second side stream: + 16).  Three lanes of cfg 2 on MI355X: 392 frames/s with this layout, the best of 48 (structured + seeded
+# random: 232 - 392, tools/gpu_runs/gpu_r06_56.sh; streams bound to their hardware queues in a fixed order first, runtime.bind_streams).
+LANE_MAINS = tuple(int(x) for x in os.environ.get("TF_LANE_MAINS", "4,3,7,0,1,2,5,6").split(","))
+LANE_SIDES = tuple(int(x) for x in os.environ.get("TF_LANE_SIDES", "1,14,6,10,12,9,13,8").split(","))
+
+
+def sequence_stream(device, lanes=1, lane=0):
+    """A stream for one sequence's tracker.  ONE sequence in flight: HIGH priority (TF_SEQ_STREAM_PRIORITY overrides).  What runs on
+    it -- the decoder half of a frame, the post-processing, the result rows' way to the host: ~150 launches of a few microseconds
+    that the host waits for before it can associate -- competes with the image-only halves of the coming frames, which
+    GraphedDetector runs on normal-priority side streams and which nobody waits for yet.  cfg 2 on MI355X with two frames of
+    look-ahead: 349.6 -> 374.7 frames/s (tools/gpu_runs/gpu_r06_48.sh).  SEVERAL sequences interleaved: normal priority -- every
+    lane's decoder half in front of every lane's image-only half starves the latter (three lanes: 426 frames/s normal, 253 high;
+    cfg 5: 130 / 102).  The streams are fixed members of PyTorch's pool (runtime.pool_stream: which streams decides the rate)."""
+    from .runtime import bind_streams, pool_stream
+    bind_streams(device)
+    default = "-1" if lanes == 1 else "0"
+    priority = int(os.environ.get("TF_SEQ_STREAM_PRIORITY", default))
+    if lanes == 1:
+        # stream 0 of the high-priority pool: the placement GraphedDetector's side streams were measured against
+        return pool_stream(device, int(os.environ.get("TF_SEQ_STREAM_INDEX", "0")), priority)
+    return pool_stream(device, LANE_MAINS[lane % len(LANE_MAINS)], priority)
+
+
 def track_sequences(make_tracker, sequences, device, interleave=1):
     """Track this rank's share of `sequences` (each an iterable of blobs) and merge the per-sequence
     results of all ranks: {sequence index: tracker results}.  No collective inside the loop.
@@ -167,34 +195,49 @@ def track_sequences(make_tracker, sequences, device, interleave=1):
     stream: Tracker.step_async enqueues a frame's forward and returns, step_finish runs its association, so one sequence's
     host work overlaps another's GPU work (cfg 2 on MI355X with ~100 live tracks: 149 -> 263 frames/s at 3).  Frames
     of one sequence stay strictly sequential and the results are those of interleave = 1.
-    Inside a sequence the lane looks one frame ahead: Tracker.step_prepare(next blob) enqueues the image-only half of the next
-    frame's forward before step_finish associates the frame in flight (round 5: one sequence 236 -> 351 frames/s; a no-op for
+    Inside a sequence the lane looks ahead (Tracker.look_ahead frames): Tracker.step_prepare(blob) enqueues the image-only half of
+    the coming frames' forward before step_finish associates the frame in flight (round 5: one sequence 236 -> 351 frames/s; a no-op for
     the models it does not apply to)."""
     rank = dist.get_rank() if is_distributed() else 0
     world = dist.get_world_size() if is_distributed() else 1
     mine = [(idx, seq) for idx, seq in enumerate(sequences) if idx % world == rank]
     lanes = max(1, min(int(interleave), len(mine) or 1))
     trackers = [make_tracker(device) for _ in range(lanes)]
+    for k, t in enumerate(trackers):   # (GraphedDetector: the schedule of the prepared image-only halves depends on the number of lanes)
+        set_lanes = getattr(getattr(t, "obj_detector", None), "set_lanes", None)
+        if set_lanes is not None and type(t.obj_detector).__name__ == "GraphedDetector":
+            set_lanes(lanes, k)
     on_gpu = torch.cuda.is_available() and torch.device(device).type == "cuda"
-    streams = [torch.cuda.Stream(device) for _ in range(lanes)] if on_gpu and lanes > 1 else [None] * lanes
+    streams = [sequence_stream(device, lanes, k) for k in range(lanes)] if on_gpu else [None] * lanes
     local = {}
     todo = iter(mine)
     lane_seq = [None] * lanes      # (sequence index, frame iterator) of the lane
     pending = [None] * lanes       # handle of the frame in flight
-    nothing = object()
-    ahead = [nothing] * lanes      # the blob behind the frame in flight, once it has been looked at (None: the sequence ended)
+    # blobs of the lane's sequence already taken from its iterator, oldest first: [0 .. prepared[k]) have had step_prepare
+    ahead = [deque() for _ in range(lanes)]
+    prepared = [0] * lanes
     # look-ahead policy (measured on MI355X, profiles/r06_bench_cfg4_*.json): with several sequences in flight the other lanes
     # already fill the GPU while one associates; for the multi-frame models -- whose image-only half is two encoder passes -- a
     # second stream per lane then costs more than it gains (3 lanes: 191 frames/s without, 170 with; 1 lane: 111 -> 151 with)
     look_ahead = lanes == 1 or not getattr(getattr(trackers[0], "obj_detector", None), "multi_frame_attention", False)
+    # frames ahead (Tracker.look_ahead: 2 with HIP graphs and a single-frame model -- the image-only halves of frames t + 1 and
+    # t + 2 share the chip, round 6 --, otherwise 1)
+    depth = int(getattr(trackers[0], "look_ahead", 1)) if look_ahead and hasattr(trackers[0], "step_prepare") else 0
 
     def advance(k):
         """Finish the lane's frame in flight, then launch its next frame (of the same or, at its end, the next sequence)."""
         if pending[k] is not None:
-            if lane_seq[k] is not None and ahead[k] is nothing:
-                ahead[k] = next(lane_seq[k][1], None)
-                if ahead[k] is not None and look_ahead and hasattr(trackers[k], "step_prepare"):
-                    trackers[k].step_prepare(ahead[k])   # GPU: the next frame's backbone + encoder; host: this frame's association
+            if lane_seq[k] is not None:
+                while len(ahead[k]) < depth:
+                    blob = next(lane_seq[k][1], None)
+                    if blob is None:
+                        break
+                    ahead[k].append(blob)
+                while prepared[k] < len(ahead[k]):
+                    # GPU: the next frames' backbone + encoder; host: this frame's association
+                    if not trackers[k].step_prepare(ahead[k][prepared[k]]):
+                        break
+                    prepared[k] += 1
             trackers[k].step_finish(pending[k])
             pending[k] = None
         while True:
@@ -204,11 +247,13 @@ def track_sequences(make_tracker, sequences, device, interleave=1):
                     return False
                 trackers[k].reset()
                 lane_seq[k] = (nxt[0], iter(nxt[1]))
-                ahead[k] = nothing
-            if ahead[k] is nothing:
-                blob = next(lane_seq[k][1], None)
+                ahead[k].clear()
+                prepared[k] = 0
+            if ahead[k]:
+                blob = ahead[k].popleft()
+                prepared[k] = max(0, prepared[k] - 1)
             else:
-                blob, ahead[k] = ahead[k], nothing
+                blob = next(lane_seq[k][1], None)
             if blob is not None:
                 pending[k] = trackers[k].step_async(blob)
                 return True

@@ -62,19 +62,71 @@ class GraphedDetector:
     # `features` of a multi-frame replay are the entry's static buffers (module docstring): a caller that keeps more than
     # the latest set (Tracker with prev_frame_dist > 1) has to clone them -- Tracker.step checks this attribute
     features_alias_static_buffers = True
+    # The schedule of the prepared image-only halves (round 6; instance attributes, chosen in __init__ by the model):
+    #   SLOTS         sets of image-only buffers, handed out round-robin (slot i runs -- and was captured -- on side stream i % SIDE_STREAMS)
+    #   LOOKAHEAD     frames that may be prepared and not yet decoded (SLOTS >= LOOKAHEAD + 1: the slot being decoded, the prepared
+    #                 ones and the next one to fill are distinct)
+    #   SIDE_STREAMS  streams the halves run on: streams SIDE_FIRST, SIDE_FIRST + SIDE_SPACING, ... of PyTorch's pool (_side_stream)
+    # WIDE (4 / 2 / 2, spaced) for single-frame models without a mask head: the image-only halves of frames t + 1 and t + 2 are in
+    # flight together while frame t is decoded -- one such half leaves the chip part idle (small grids at the end of the backbone,
+    # ~120 dependent launches), two of them share it: 2.10 instead of 2.67 ms per half (tools/experiments/two_image_halves.py).
+    # cfg 2 on MI355X with the sequence on a high-priority stream (dist_utils.sequence_stream): 348 -> 375 frames/s, host frames
+    # 326 -> 371, the reference's own step() loop 325 -> 358 (tools/gpu_runs/gpu_r06_48.sh).  WHICH streams decides
+    # (runtime.pool_stream): side streams (1, 5) or (0, 4) or (3, 7) of the pool next to high-priority stream 0: 378 frames/s,
+    # (2, 6): 234, (1, 2): 350 (tools/experiments/stream_queue_map.py, profiles/r06_stream_queue_map.txt).
+    # NARROW (2 / 1 / 1: the schedule of round 5) for the others: a mask-head model loses 10 % with four slots (cfg 5: 118 -> 105
+    # frames/s, three slots 110 -- each slot holds the full-resolution backbone features the mask head reads, four of them no longer
+    # stay in the 256 MB Infinity Cache; gpu_r06_49.sh); a multi-frame model's next-but-one frame needs features no call has
+    # returned yet, and four slots alone cost it 1.5 % (cfg 4: 180.5 -> 177.7).
+    WIDE = (4, 2, 2)
+    NARROW = (2, 1, 1)
 
-    def __init__(self, model, max_graphs=32, bucket=16):
+    def __init__(self, model, max_graphs=32, bucket=16, lanes=1, lane=0):
+        """lanes / lane: how many sequences the process tracks at once on this device (dist_utils.track_sequences' interleave; each
+        with its own wrapper) and which of them this wrapper serves: decides WHICH streams of PyTorch's pool the image-only halves
+        run on (_side_stream)."""
         self.model = model
         self.max_graphs = max_graphs
         self.bucket = max(1, int(bucket))
+        self._configure(lanes, lane)
         self._graphs = OrderedDict()
         self._seen = {}
-        self._enc = {}            # (image shape, device) -> [slot 0, slot 1]: the image-only half as its own graph, two sets of buffers
-        self._prepared = None     # (static image tensor, slot index, generation) of the last prepare()
-        self._slot = 0            # the slot the last forward read: prepare() fills the other one
-        self._side = {}           # device -> the stream prepare() runs the image-only half on
+        self._enc = {}            # (image shape, device) -> [slot 0 .. slot K-1]: the image-only half as its own graph, K sets of buffers
+        self._fifo = []           # outstanding preparations, oldest first: (static image alias, slot index, generation)
+        self._slot = 0            # the slot the last forward read
+        self._last_alloc = self.SLOTS - 1   # the slot handed out last (prepare() or an unprepared call): the next one is + 1 mod K
+        self._side = {}           # device -> the streams prepare() runs the image-only halves on (slot i: stream i % SIDE_STREAMS)
         self._generation = 0      # prepare() calls so far: a static image is only "prepared" for the call that follows ITS prepare()
         self._epoch = None        # fused.route_epoch() the graphs were captured under
+
+    def _configure(self, lanes, lane=0):
+        import os
+        # (TF_GRAPH_*: A/B switches of the schedule, tools/gpu_runs/gpu_r06_44.sh ... _49.sh)
+        self.SLOTS, self.LOOKAHEAD, self.SIDE_STREAMS = self._schedule_for(lanes)
+        self._lanes, self._lane = max(1, int(lanes)), int(lane)
+        self.SIDE_SPACING = max(1, int(os.environ.get("TF_GRAPH_SIDE_SPACING", "4")))
+        self.SIDE_FIRST = int(os.environ.get("TF_GRAPH_SIDE_FIRST", "1"))
+
+    def set_lanes(self, lanes, lane=0):
+        """dist_utils.track_sequences: `lanes` sequences are tracked at once, each through its own wrapper (see __init__)."""
+        if ((self.SLOTS, self.LOOKAHEAD, self.SIDE_STREAMS) != self._schedule_for(lanes) or (lanes > 1) != (self._lanes > 1)
+                or (lanes > 1 and lane != self._lane)):
+            if self._graphs or self._enc:
+                torch.cuda.synchronize()
+                self._graphs.clear()
+                self._enc.clear()
+                self._seen.clear()
+            self._fifo, self._slot, self._side = [], 0, {}
+            self._configure(lanes, lane)
+            self._last_alloc = self.SLOTS - 1
+
+    def _schedule_for(self, lanes):
+        import os
+        wide = not self._multi_frame() and not hasattr(self.model, "lazy_masks_active")
+        slots, look_ahead, side_streams = self.WIDE if wide else self.NARROW
+        look_ahead = max(1, int(os.environ.get("TF_GRAPH_LOOKAHEAD", look_ahead)))
+        return (max(look_ahead + 1, int(os.environ.get("TF_GRAPH_SLOTS", slots))), look_ahead,
+                max(1, int(os.environ.get("TF_GRAPH_SIDE_STREAMS", side_streams))))
 
     def __getattr__(self, name):  # only called for attributes GraphedDetector itself lacks
         return getattr(self.model, name)
@@ -90,7 +142,7 @@ class GraphedDetector:
                 self._graphs.clear()
                 self._enc.clear()
                 self._seen.clear()
-                self._prepared = None
+                self._fifo = []
             self._epoch = epoch
 
     def _capturable(self, img, target, prev_features):
@@ -143,19 +195,62 @@ class GraphedDetector:
     def _prev_tail(self, prev_features):
         return list(prev_features)[-self._PREV_LEVELS:]
 
-    def _side_stream(self, dev):
+    def _side_stream(self, dev, slot=0):
         st = self._side.get(dev)
         if st is None:
-            st = self._side[dev] = torch.cuda.Stream(dev)
-        return st
+            # fixed members of PyTorch's stream pool (runtime.pool_stream: which streams decides the rate): normal-priority streams
+            # SIDE_FIRST, SIDE_FIRST + SIDE_SPACING, ... -- (1, 5) next to a sequence on high-priority stream 0
+            # (dist_utils.sequence_stream) is the measured-good placement
+            # (several lanes: each wrapper its own streams, dist_utils.LANE_SIDES -- lanes on one side stream would run their
+            # image-only halves one after the other: three lanes 313 frames/s; a seeded search over layouts, gpu_r06_53.sh:
+            # WIDE 391 - 427 frames/s on every layout tried, NARROW 357 - 362 on 34 of 35)
+            from .runtime import bind_streams, pool_stream
+            bind_streams(dev)
+            if self._lanes > 1:
+                from .dist_utils import LANE_SIDES
+                first = LANE_SIDES[self._lane % len(LANE_SIDES)]
+                st = tuple(pool_stream(dev, (first + 16 * k) % 32) for k in range(self.SIDE_STREAMS))
+            else:
+                st = tuple(pool_stream(dev, (self.SIDE_FIRST + k * self.SIDE_SPACING) % 32) for k in range(self.SIDE_STREAMS))
+            self._side[dev] = st
+        return st[slot % self.SIDE_STREAMS]
 
-    def _capture_encoder(self, img, dev):
+    def _next_slot(self):
+        """Round-robin over the slots, skipping the one the last call decoded (its results may still be read: the lazy mask head,
+        a multi-frame model's previous-frame features) and those of outstanding preparations -- at most 1 + LOOKAHEAD < SLOTS."""
+        busy = {self._slot} | {e[1] for e in self._fifo}
+        i = self._last_alloc
+        for _ in range(self.SLOTS):
+            i = (i + 1) % self.SLOTS
+            if i not in busy:
+                break
+        self._last_alloc = i
+        return i
+
+    def _take_prepared(self, img, prev_features):
+        """The outstanding preparation `img` stands for (-> its slot index) or None.  Preparations are consumed in order: a call
+        with the tensor of a later one drops the earlier ones, a call with any other image drops them all (a sequence that ended
+        early, a caller that changed its mind) -- a dropped static image that is passed in later is an ordinary device image."""
+        hit = next((n for n, e in enumerate(self._fifo) if e[0] is img), None)
+        if hit is None:
+            self._fifo = []
+            return None
+        alias, slot, generation = self._fifo[hit]
+        del self._fifo[:hit + 1]
+        slots = self._enc.get((tuple(alias.shape), alias.device))
+        if slots is None or slots[slot] is None or slots[slot].get("generation") != generation:
+            return None
+        if self._multi_frame() and (prev_features is None or slots[slot].get("prev_id") != self._prev_id(prev_features)):
+            return None   # prepared against other previous-frame features than this call's: encoded again
+        return slot
+
+    def _capture_encoder(self, img, dev, slot=0):
         """One slot of the image-only half: static image, static results, the graph (captured ON the side stream: library
         workspaces that PyTorch keys by capture stream are then not the ones of the decoder graphs it runs next to), and the
         events that order it against the decoder graphs reading its results."""
-        side = self._side_stream(dev)
+        side = self._side_stream(dev, slot)
         cur = torch.cuda.current_stream(dev)
-        entry = {"done": torch.cuda.Event(), "free": torch.cuda.Event(), "ran": False, "read": False}
+        entry = {"done": torch.cuda.Event(), "free": torch.cuda.Event(), "ran": False, "read": False, "stream": side}
         with _CAPTURE_LOCK:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
@@ -206,23 +301,30 @@ class GraphedDetector:
         slots = self._enc.get((tuple(img.shape), dev))
         if slots is None:
             return None
-        i = 1 - self._slot
+        # at most LOOKAHEAD frames prepared and not decoded yet (the round-robin of the slots relies on it); a multi-frame model one:
+        # frame t + 2's image-only half reads frame t + 1's backbone features, which no call has returned yet
+        self._fifo = [e for e in self._fifo if e[0].device == dev and tuple(e[0].shape) == tuple(img.shape)]
+        if len(self._fifo) >= (1 if multi else self.LOOKAHEAD):
+            return None
+        i = self._next_slot()
         if slots[i] is None:
-            slots[i] = self._capture_encoder(img, dev)
+            slots[i] = self._capture_encoder(img, dev, i)
         a = slots[i]
-        side, cur = self._side_stream(dev), torch.cuda.current_stream(dev)
-        # the previous frame's features: results of the other slot's run on the side stream (ordered by the stream), or somebody
-        # else's tensors, produced on the current stream
-        foreign_prev = multi and not self._is_slot_result(slots[1 - i], prev_features)
+        side, cur = a["stream"], torch.cuda.current_stream(dev)
+        # the previous frame's features: results of another slot's run (ordered by that run's `done` event), or somebody else's
+        # tensors, produced on the current stream
+        src = next((b for b in slots if b is not None and b is not a and self._is_slot_result(b, prev_features)), None) if multi else None
+        foreign_prev = multi and src is None
         if (img.is_cuda and not image_ready) or foreign_prev:
             side.wait_stream(cur)
         if a["read"]:
-            side.wait_event(a["free"])      # the decoder half that last read this slot's results is done with them
-        if multi and not foreign_prev and slots[1 - i]["ran"]:
-            # the other slot's results are this run's previous-frame features: written by its last image-only run -- on the side
-            # stream when it was prepared (ordered by the stream: the wait is free), on the CALLER's stream when it was not
-            # (the first frames of a sequence, a bucket's first sight)
-            side.wait_event(slots[1 - i]["done"])
+            side.wait_event(a["free"])      # the decoder half (or the lazy mask head) that last read this slot's results is done with them
+        if a["ran"]:
+            side.wait_event(a["done"])      # (a run into this slot on the CALLER's stream: an unprepared call)
+        if src is not None and src["ran"]:
+            # that slot's results are this run's previous-frame features: written by its last image-only run -- on a side stream
+            # when it was prepared, on the CALLER's stream when it was not (the first frames of a sequence, a bucket's first sight)
+            side.wait_event(src["done"])
         with torch.cuda.stream(side):
             a["img"].copy_(img, non_blocking=True)
             if multi:
@@ -236,11 +338,10 @@ class GraphedDetector:
         a["ran"] = True
         self._generation += 1
         a["generation"] = self._generation   # the slot holds THIS preparation until the next one into it
-        # a fresh alias per preparation: two prepare() calls in a row fill the same slot, and only the tensor the LAST one
-        # returned stands for "the image-only half of what this tensor holds has run" (the earlier alias now holds the later image
-        # and is treated as any device image: encoded again from its contents)
+        # a fresh alias per preparation: it stands for "the image-only half of what this tensor holds has run" until the call that
+        # decodes it (or a later preparation into the same slot: the generation)
         alias = a["img"].view(a["img"].shape)
-        self._prepared = (alias, i, self._generation)
+        self._fifo.append((alias, i, self._generation))
         return alias
 
     def _capture(self, img, target, prev_features, slot=0):
@@ -307,9 +408,9 @@ class GraphedDetector:
     def _capture_decoder(self, img, target, slot, prev_features=None):
         akey = (tuple(img.shape), img.device)
         torch.cuda.synchronize(img.device)   # (a prepared image-only half of this slot may be in flight on the side stream)
-        slots = self._enc.setdefault(akey, [None, None])
+        slots = self._enc.setdefault(akey, [None] * self.SLOTS)
         if slots[slot] is None:
-            slots[slot] = self._capture_encoder(img, img.device)
+            slots[slot] = self._capture_encoder(img, img.device, slot)
         a = slots[slot]
         entry = {"enc": a, "prev": None}
         static_target = None
@@ -348,7 +449,7 @@ class GraphedDetector:
         used = {id(e["enc"]) for e in self._graphs.values() if "enc" in e}
         idle = [k for k, slots in self._enc.items() if not any(a is not None and id(a) in used for a in slots)]
         for k in idle[:max(0, len(idle) - keep)]:
-            if self._prepared is not None and (tuple(self._prepared[0].shape), self._prepared[0].device) == k:
+            if any((tuple(e[0].shape), e[0].device) == k for e in self._fifo):
                 continue
             torch.cuda.synchronize(k[1])
             del self._enc[k]
@@ -421,22 +522,12 @@ class GraphedDetector:
 
     def __call__(self, img, target=None, prev_features=None):
         self._sync_epoch()
-        prepared, self._prepared = self._prepared, None
-        # prepared for THIS call: the very tensor of the LAST prepare(), and nothing has been prepared into that slot since (two
-        # prepare() calls in a row fill the same slot and return the same tensor: only the second image's state is in it)
-        if prepared is not None:
-            slots = self._enc.get((tuple(prepared[0].shape), prepared[0].device))
-            if (prepared[0] is not img or slots is None or slots[prepared[1]] is None
-                    or slots[prepared[1]].get("generation") != prepared[2]):
-                prepared = None
-            elif self._multi_frame() and (prev_features is None
-                                          or slots[prepared[1]].get("prev_id") != self._prev_id(prev_features)):
-                prepared = None   # prepared against other previous-frame features than this call's: encoded again below
+        prepared = self._take_prepared(img, prev_features)   # the slot prepare() filled for this very tensor, or None
         if not self._capturable(img, target, prev_features):
             self._wait_static_image(img)   # (also consumes the preparation: the eager forward encodes the image itself)
             res = self.model(img, target, prev_features)
             if prepared is not None:
-                self._mark_read(img, prepared[1])
+                self._mark_read(img, prepared)
             return res
         multi = self._multi_frame()
         n_real = n_pad = 0
@@ -445,7 +536,9 @@ class GraphedDetector:
             target, n_real, n_pad = self._bucketed(target)
         n_track = n_pad
         lazy = getattr(self.model, "lazy_masks_active", None)
-        slot = prepared[1] if prepared is not None else 0   # the buffers prepare() filled for this very tensor
+        # the buffers prepare() filled for this very tensor; an unprepared call decodes slot 0 (no preparation is outstanding then:
+        # _take_prepared dropped them)
+        slot = prepared if prepared is not None else 0
         self._wait_static_image(img)   # the slot's run, or a static image used after its preparation was forgotten
         key = (tuple(img.shape), n_track, img.device, bool(multi and prev_features is not None),
                bool(lazy()) if lazy is not None else False,   # a graph with and one without the mask head are different graphs

@@ -85,3 +85,49 @@ def settle_heap():
     gc.collect()
     gc.freeze()
 
+
+
+_BOUND = set()
+
+
+def bind_streams(device):
+    """Touch every stream of PyTorch's two pools for `device` once, in a fixed order (normal 0, high 0, normal 1, high 1, ...).
+    The HIP runtime binds a stream to one of its hardware queues when the stream first does something, and which streams end up
+    together decides the rate of the pipelined frame loop (pool_stream): with the binding left to whoever uses a stream first, three
+    interleaved lanes on the SAME streams ran at 427 frames/s in a process that started with them and at 294 in one that had
+    tracked a single sequence before (bench.py's legs; tools/gpu_runs/gpu_r06_54.sh).  Once per device and process; a few hundred
+    microseconds."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device in _BOUND:
+        return
+    _BOUND.add(device)
+    scratch = torch.zeros(64, device=device)
+    torch.cuda.synchronize(device)
+    for i in range(32):
+        for priority in (0, -1):
+            with torch.cuda.stream(pool_stream(device, i, priority)):
+                scratch[2 * i + (priority != 0)].zero_()
+    torch.cuda.synchronize(device)
+
+
+def pool_stream(device, index, priority=0):
+    """THE stream number `index` of PyTorch's stream pool for `device` and `priority` (0 normal, -1 high; 32 streams per pool, all
+    created together at the device's first stream request and handed out round-robin; StreamId = index << 5 | type).
+
+    Why pick by index (round 6, MI355X, ROCm 7.2): which hardware queue a HIP stream sits on is fixed when the stream is created,
+    and the rate of the pipelined frame loop -- the decoder half of frame t on the sequence's stream next to the image-only halves
+    of frames t + 1 and t + 2 on two side streams -- depends on WHICH streams: same schedule, same kernels, 378 frames/s with the
+    sequence on high-priority stream 0 and the side streams on normal streams (1, 5); 234 with the side streams on (2, 6); 233 with
+    the sequence on high-priority stream 1 (tools/experiments/stream_queue_map.py, profiles/r06_stream_queue_map.txt).  Taking
+    "the next stream of the pool" made every leg of bench.py depend on how many streams the process had drawn before it
+    (284 / 308 / 331 / 368 frames/s for one schedule, tools/gpu_runs/gpu_r06_44.sh).  Falls back to the pool's next stream when the
+    index never shows up (another StreamId layout)."""
+    device = torch.device(device)
+    stream = None
+    for _ in range(64):
+        stream = torch.cuda.Stream(device, priority=priority)
+        if (int(stream.stream_id) >> 5) == index:
+            break
+    return stream

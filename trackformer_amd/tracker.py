@@ -326,24 +326,38 @@ class Tracker:
         enqueued (not for the first frame of a multi-frame sequence, which attends to itself)."""
         det = self.obj_detector
         prep = getattr(det, "prepare", None)
-        self._prepared = None
+        pending = self.__dict__.get("_prepared") or []
         multi = bool(getattr(det, "multi_frame_attention", False))
+        if multi and pending:
+            return False   # the frame after a prepared one: its previous-frame features are those of a frame not yet decoded
         prev = self._upcoming_prev_features() if multi else None
         if multi and prev is None:
+            self._prepared = []
             return False
         if prep is not None:
-            # GraphedDetector: the half runs on the wrapper's side stream, NEXT TO the previous frame's decoder half (a host
-            # image is uploaded on that stream too); `image_ready`: a device-resident blob['img'] is complete already
+            # GraphedDetector: the half runs on one of the wrapper's side streams, NEXT TO the previous frame's decoder half (a host
+            # image is uploaded on that stream too); `image_ready`: a device-resident blob['img'] is complete already.  Up to
+            # GraphedDetector.LOOKAHEAD frames may be prepared and not yet stepped (round 6: the image-only halves of frames
+            # t + 1 and t + 2 share the chip); one more is refused (None)
             img = prep(blob['img'], prev, device=self.device, image_ready=image_ready)
             if img is not None:
-                self._prepared = (blob['img'], img, None)
+                self._prepared = pending + [(blob['img'], img, None)]
                 return True
             return False
         img = blob['img'].to(self.device, non_blocking=True)
         if hasattr(det, "encode_frame") and not det.training and not torch.is_grad_enabled():
-            self._prepared = (blob['img'], img, det.encode_frame(img, prev), prev)
+            self._prepared = [(blob['img'], img, det.encode_frame(img, prev), prev)]   # (without graphs: one frame ahead)
             return True
         return False
+
+    @property
+    def look_ahead(self):
+        """How many frames step_prepare may run ahead of step_async: GraphedDetector.LOOKAHEAD with graphs and a single-frame
+        model, otherwise 1 (a multi-frame model's image-only half needs the previous frame's backbone features)."""
+        det = self.obj_detector
+        if bool(getattr(det, "multi_frame_attention", False)) or not hasattr(det, "prepare"):
+            return 1
+        return int(getattr(det, "LOOKAHEAD", 1))
 
     def _upcoming_prev_features(self):
         """`self._prev_features[0]` as the NEXT step_async will see it: step_prepare runs between step_async(t) and
@@ -376,7 +390,11 @@ class Tracker:
             track.last_pos.append(track._pos)
 
         device = self.device
-        prepared, self._prepared = getattr(self, "_prepared", None), None
+        # the preparation of THIS blob, if any (step_prepare; in order: earlier ones of other blobs are dropped with it)
+        pending = self.__dict__.get("_prepared") or []
+        hit = next((n for n, e in enumerate(pending) if e[0] is blob['img']), None)
+        prepared = pending[hit] if hit is not None else None
+        self._prepared = pending[hit + 1:] if hit is not None else []
         encoded = None
         if prepared is not None and prepared[0] is blob['img'] and (len(prepared) < 4 or prepared[3] is self._prev_features[0]):
             img, encoded = prepared[1], prepared[2]     # step_prepare(blob) ran the image-only half for this very frame
@@ -445,10 +463,7 @@ class Tracker:
         # packed_dev: the frame's single device -> host transfer: enqueued here, awaited in step_finish
         event = host = None
         if packed_dev.device.type == "cuda":
-            host = self.__dict__.get("_packed_host")
-            if host is None or host.shape[0] < packed_dev.shape[0]:
-                host = self.__dict__["_packed_host"] = torch.empty((max(1024, 2 * packed_dev.shape[0]), 6), dtype=torch.float32,
-                                                                   pin_memory=True)
+            host = self._pinned_rows(packed_dev.shape[0])
             # the copy and its event go on the stream of packed_dev's device that the detector just ran on -- NOT on "the
             # current device's current stream": with the model on cuda:1 and no torch.cuda.set_device, a bare
             # event.record() lands on an idle stream of cuda:0, synchronize() returns at once and step_finish reads the
@@ -461,6 +476,16 @@ class Tracker:
         return dict(blob=blob, outputs=outputs, features=features, hs_embeds=hs_embeds, results=results, result=result,
                     orig_size=orig_size, orig_hw=(orig_h, orig_w), num_prev_track=num_prev_track, device=device,
                     packed_dev=packed_dev, host=host, event=event)
+
+    def _pinned_rows(self, n):
+        """The tracker's pinned host buffer for a frame's [n, 6] result rows (grown when needed; reused by every frame:
+        step_finish clones what it reads).  (Round 6 also had the post-processing kernel write the rows straight into this buffer --
+        pinned memory is mapped into the device's address space -- instead of device rows + an asynchronous copy: ids identical,
+        no change of any rate, tools/gpu_runs/gpu_r06_45.sh; not kept.)"""
+        host = self.__dict__.get("_packed_host")
+        if host is None or host.shape[0] < n:
+            host = self.__dict__["_packed_host"] = torch.empty((max(1024, 2 * n), 6), dtype=torch.float32, pin_memory=True)
+        return host
 
     def step_finish(self, st):
         """Second half of step(): waits for the frame's device -> host copy and runs the association on the host."""
