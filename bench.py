@@ -277,12 +277,12 @@ def build_model(cfg, device):
     return model, criterion, post, margs
 
 
-def sequence_stream(device, lanes=1, lane=0):
+def sequence_stream(device, lanes=1, lane=0, narrow=False):
     """The stream a sequence's tracker runs on (dist_utils.sequence_stream, what track_sequences uses: high priority for a single
     sequence -- the decoder half and the post-processing, ~150 small launches the host waits for, are dispatched ahead of the
     image-only halves GraphedDetector runs on its side streams --, normal priority for interleaved sequences)."""
     from trackformer_amd.dist_utils import sequence_stream as make
-    return make(device, lanes, lane)
+    return make(device, lanes, lane, narrow)
 
 
 def build_tracker(model, post, use_graph, lanes=1, lane=0):
@@ -852,7 +852,8 @@ def run_tracking(cfg, args, device, world, model, post, margs, n_seq, seeds=None
     depth = min(trackers[0].look_ahead, args.look_ahead) if look_ahead else 0
     seeder = TrackSeeder(device, margs.hidden_dim, cfg["tracks"], cfg["size"], seeds=seeds)
     frames = make_frames(device, cfg["size"], host=args.host_frames)
-    streams = [sequence_stream(device, n_seq, k) for k in range(n_seq)]
+    narrow = bool(getattr(model, "multi_frame_attention", False))   # (the lanes' streams: dist_utils.LANE_MAINS_NARROW)
+    streams = [sequence_stream(device, n_seq, k, narrow) for k in range(n_seq)]
 
     def run_set(steps):
         per_seq = [steps // n_seq + (1 if i < steps % n_seq else 0) for i in range(n_seq)]

@@ -167,9 +167,14 @@ def gather_results(local_results):
 # random: 232 - 392, tools/gpu_runs/gpu_r06_56.sh; streams bound to their hardware queues in a fixed order first, runtime.bind_streams).
 LANE_MAINS = tuple(int(x) for x in os.environ.get("TF_LANE_MAINS", "4,3,7,0,1,2,5,6").split(","))
 LANE_SIDES = tuple(int(x) for x in os.environ.get("TF_LANE_SIDES", "1,14,6,10,12,9,13,8").split(","))
+# ... and the single side stream of a NARROW wrapper (mask-head / multi-frame models; TF_LANE_SIDES_NARROW)
+LANE_SIDES_NARROW = tuple(int(x) for x in os.environ.get("TF_LANE_SIDES_NARROW", "1,14,6,10,12,9,13,8").split(","))
+# ... and the lanes' own streams for a multi-frame model (no look-ahead with several lanes: only these streams matter; cfg 4, three
+# lanes: 144 - 216 frames/s over 22 layouts, tools/gpu_runs/gpu_r06_58.sh; a mask-head model does best on LANE_MAINS: cfg 5 124.7)
+LANE_MAINS_NARROW = tuple(int(x) for x in os.environ.get("TF_LANE_MAINS_NARROW", "4,3,10,8,9,0,1,2").split(","))
 
 
-def sequence_stream(device, lanes=1, lane=0):
+def sequence_stream(device, lanes=1, lane=0, narrow=False):
     """A stream for one sequence's tracker.  ONE sequence in flight: HIGH priority (TF_SEQ_STREAM_PRIORITY overrides).  What runs on
     it -- the decoder half of a frame, the post-processing, the result rows' way to the host: ~150 launches of a few microseconds
     that the host waits for before it can associate -- competes with the image-only halves of the coming frames, which
@@ -184,7 +189,8 @@ def sequence_stream(device, lanes=1, lane=0):
     if lanes == 1:
         # stream 0 of the high-priority pool: the placement GraphedDetector's side streams were measured against
         return pool_stream(device, int(os.environ.get("TF_SEQ_STREAM_INDEX", "0")), priority)
-    return pool_stream(device, LANE_MAINS[lane % len(LANE_MAINS)], priority)
+    table = LANE_MAINS_NARROW if narrow else LANE_MAINS   # (narrow: a multi-frame model)
+    return pool_stream(device, table[lane % len(table)], priority)
 
 
 def track_sequences(make_tracker, sequences, device, interleave=1):
@@ -208,7 +214,8 @@ def track_sequences(make_tracker, sequences, device, interleave=1):
         if set_lanes is not None and type(t.obj_detector).__name__ == "GraphedDetector":
             set_lanes(lanes, k)
     on_gpu = torch.cuda.is_available() and torch.device(device).type == "cuda"
-    streams = [sequence_stream(device, lanes, k) for k in range(lanes)] if on_gpu else [None] * lanes
+    narrow = bool(getattr(getattr(trackers[0], "obj_detector", None), "multi_frame_attention", False))
+    streams = [sequence_stream(device, lanes, k, narrow) for k in range(lanes)] if on_gpu else [None] * lanes
     local = {}
     todo = iter(mine)
     lane_seq = [None] * lanes      # (sequence index, frame iterator) of the lane

@@ -207,8 +207,9 @@ class GraphedDetector:
             from .runtime import bind_streams, pool_stream
             bind_streams(dev)
             if self._lanes > 1:
-                from .dist_utils import LANE_SIDES
-                first = LANE_SIDES[self._lane % len(LANE_SIDES)]
+                from .dist_utils import LANE_SIDES, LANE_SIDES_NARROW
+                table = LANE_SIDES if self.SIDE_STREAMS > 1 else LANE_SIDES_NARROW
+                first = table[self._lane % len(table)]
                 st = tuple(pool_stream(dev, (first + 16 * k) % 32) for k in range(self.SIDE_STREAMS))
             else:
                 st = tuple(pool_stream(dev, (self.SIDE_FIRST + k * self.SIDE_SPACING) % 32) for k in range(self.SIDE_STREAMS))
