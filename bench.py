@@ -216,6 +216,8 @@ def init_distributed(args):
             return rank, 0, world
         torch.cuda.set_device(local_rank)
         du.pin_rank_to_cpus(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        from trackformer_amd import runtime
+        runtime.bind_streams(torch.device("cuda", local_rank))   # (before RCCL creates its own streams: see main())
         du.init_from_env(backend="nccl", device=torch.device("cuda", local_rank))  # nccl == RCCL
         verify_ranks(world, torch.device("cuda", local_rank))
     return rank, local_rank, world
@@ -984,6 +986,9 @@ def main():
     torch.cuda.set_device(device)
     from trackformer_amd import _cabi, fused, runtime
     _cabi.lib()   # fail loudly if the HIP library is missing
+    # PyTorch's pool streams get their hardware queues here, in a fixed order, before anything else of this process (the tracker
+    # loops, RCCL's own streams at the first collective) uses a stream: the rate of the pipelined loop depends on it
+    runtime.bind_streams(device)
     train = cfg["kind"] == "train"
     if train:
         runtime.configure_training()
