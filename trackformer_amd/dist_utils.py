@@ -267,6 +267,12 @@ def track_sequences(make_tracker, sequences, device, interleave=1):
             local[lane_seq[k][0]] = trackers[k].get_results()
             lane_seq[k] = None
 
+    if on_gpu:
+        # frames the caller already put on the device were produced on ITS stream: the lanes' streams start behind that work
+        # (frames produced while iterating are enqueued on the lane's stream: the iterators are advanced under it)
+        caller = torch.cuda.current_stream(device)
+        for st in streams:
+            st.wait_stream(caller)
     with torch.no_grad():
         busy = [True] * lanes
         while any(busy):
@@ -278,6 +284,9 @@ def track_sequences(make_tracker, sequences, device, interleave=1):
                         busy[k] = advance(k)
                 else:
                     busy[k] = advance(k)
+    if on_gpu:
+        for st in streams:   # (and whatever the caller does next on its stream comes after the lanes' work)
+            caller.wait_stream(st)
     merged = {}
     for part in gather_results(local):
         merged.update(part)
