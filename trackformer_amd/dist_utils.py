@@ -163,10 +163,10 @@ def gather_results(local_results):
 
 # streams of interleaved lanes, as indices into PyTorch's normal-priority stream pool (runtime.pool_stream): lane k's tracker runs on
 # stream LANE_MAINS[k], its GraphedDetector's side stream is LANE_SIDES[k] (TF_LANE_MAINS / TF_LANE_SIDES: comma-separated, A/B aid)
-# (a second side stream: + 16).  Three lanes of cfg 2 on MI355X: 392 frames/s with this layout, the best of 48 (structured + seeded
-# random: 232 - 392, tools/gpu_runs/gpu_r06_56.sh; streams bound to their hardware queues in a fixed order first, runtime.bind_streams).
-LANE_MAINS = tuple(int(x) for x in os.environ.get("TF_LANE_MAINS", "4,3,7,0,1,2,5,6").split(","))
-LANE_SIDES = tuple(int(x) for x in os.environ.get("TF_LANE_SIDES", "1,14,6,10,12,9,13,8").split(","))
+# (a second side stream: + 16).  Three lanes of cfg 2 on MI355X: 424 frames/s with this layout, the best of 13 under the binding order
+# of runtime.bind_streams (334 - 424, tools/gpu_runs/gpu_r06_61.sh; under the interleaved order: 48 layouts, 232 - 392, gpu_r06_56.sh).
+LANE_MAINS = tuple(int(x) for x in os.environ.get("TF_LANE_MAINS", "5,4,3,0,1,2,6,7").split(","))
+LANE_SIDES = tuple(int(x) for x in os.environ.get("TF_LANE_SIDES", "1,2,6,10,12,9,13,8").split(","))
 # ... and the single side stream of a NARROW wrapper (mask-head / multi-frame models; TF_LANE_SIDES_NARROW)
 LANE_SIDES_NARROW = tuple(int(x) for x in os.environ.get("TF_LANE_SIDES_NARROW", "1,14,6,10,12,9,13,8").split(","))
 # ... and the lanes' own streams for a multi-frame model (no look-ahead with several lanes: only these streams matter; cfg 4, three

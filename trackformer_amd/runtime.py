@@ -91,7 +91,7 @@ _BOUND = set()
 
 
 def bind_streams(device):
-    """Touch every stream of PyTorch's two pools for `device` once, in a fixed order (normal 0, high 0, normal 1, high 1, ...).
+    """Touch every stream of PyTorch's two pools for `device` once, in a fixed order (normal 0 ... 31, then high 0 ... 31).
     The HIP runtime binds a stream to one of its hardware queues when the stream first does something, and which streams end up
     together decides the rate of the pipelined frame loop (pool_stream): with the binding left to whoever uses a stream first, three
     interleaved lanes on the SAME streams ran at 427 frames/s in a process that started with them and at 294 in one that had
@@ -105,10 +105,20 @@ def bind_streams(device):
     _BOUND.add(device)
     scratch = torch.zeros(64, device=device)
     torch.cuda.synchronize(device)
-    for i in range(32):
-        for priority in (0, -1):
-            with torch.cuda.stream(pool_stream(device, i, priority)):
-                scratch[2 * i + (priority != 0)].zero_()
+    # the order matters too (tools/gpu_runs/gpu_r06_61.sh): all normal-priority streams first, then the high-priority ones -- a single
+    # sequence reads the same 375 frames/s as with the two pools interleaved, three lanes reach 424 instead of 392; high-priority
+    # streams first: a single sequence drops to 235; the interleaved order backwards: 350 / <= 323
+    order = os.environ.get("TF_BIND_ORDER", "normal_first")
+    pairs = [(i, priority) for i in range(32) for priority in (0, -1)]
+    if order == "normal_first":
+        pairs = [(i, 0) for i in range(32)] + [(i, -1) for i in range(32)]
+    elif order == "high_first":
+        pairs = [(i, -1) for i in range(32)] + [(i, 0) for i in range(32)]
+    elif order == "reverse":
+        pairs = pairs[::-1]
+    for i, priority in pairs:
+        with torch.cuda.stream(pool_stream(device, i, priority)):
+            scratch[2 * i + (priority != 0)].zero_()
     torch.cuda.synchronize(device)
 
 
