@@ -80,6 +80,10 @@ def main():
         cases.append(("high[%d], sides pool[1], pool[%d], 2 ahead" % (h, 1 + nq), high[h], (pool[1], pool[1 + nq]), 4, 2))
     for r in range(nq):
         cases.append(("normal pool[2], sides pool[%d], pool[%d], 2 ahead" % (r, r + nq), pool[2], (pool[r], pool[r + nq]), 4, 2))
+    null = torch.cuda.default_stream(device)     # what a caller who never sets a stream runs on
+    cases.append(("default (null) stream, sides pool[1], pool[5], 2 ahead", null, (pool[1], pool[5]), 4, 2))
+    cases.append(("default (null) stream, sides pool[1], pool[5], 1 ahead", null, (pool[1], pool[5]), 4, 1))
+    cases.append(("default (null) stream, 1 side stream pool[1] (NARROW)", null, (pool[1],), 2, 1))
     if a.cases:
         keep = {int(x) for x in a.cases.split(",")}
         cases = [c for i, c in enumerate(cases) if i in keep]
