@@ -24,7 +24,7 @@ class _Masks:
 
 
 def test_schedule_by_model_family(monkeypatch):
-    for k in ("TF_GRAPH_SLOTS", "TF_GRAPH_LOOKAHEAD", "TF_GRAPH_SIDE_STREAMS"):
+    for k in ("TF_GRAPH_SLOTS", "TF_GRAPH_LOOKAHEAD", "TF_GRAPH_SIDE_STREAMS", "GPU_MAX_HW_QUEUES"):
         monkeypatch.delenv(k, raising=False)
     wide = GraphedDetector(_Plain())
     assert (wide.SLOTS, wide.LOOKAHEAD, wide.SIDE_STREAMS) == GraphedDetector.WIDE == (4, 2, 2)
@@ -39,6 +39,21 @@ def test_schedule_by_model_family(monkeypatch):
     monkeypatch.setenv("TF_GRAPH_SLOTS", "2")
     forced = GraphedDetector(_Plain())
     assert forced.LOOKAHEAD == 3 and forced.SLOTS == 4   # (never fewer slots than frames in flight: decoded + prepared)
+
+
+def test_schedule_falls_back_when_the_runtime_has_another_number_of_hardware_queues(monkeypatch):
+    """The placement tables were measured with the HIP runtime's default of 4 hardware queues: with another GPU_MAX_HW_QUEUES every
+    model keeps round 5's schedule (runtime.placement_tuned)."""
+    for k in ("TF_GRAPH_SLOTS", "TF_GRAPH_LOOKAHEAD", "TF_GRAPH_SIDE_STREAMS"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
+    assert not runtime.placement_tuned()
+    det = GraphedDetector(_Plain())
+    assert (det.SLOTS, det.LOOKAHEAD, det.SIDE_STREAMS) == GraphedDetector.NARROW
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "4")
+    assert runtime.placement_tuned()
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES")
+    assert runtime.placement_tuned() and GraphedDetector(_Plain()).SLOTS == 4
 
 
 def test_slots_rotate_past_the_decoded_and_the_prepared_ones():

@@ -182,7 +182,9 @@ def sequence_stream(device, lanes=1, lane=0, narrow=False):
     look-ahead: 349.6 -> 374.7 frames/s (tools/gpu_runs/gpu_r06_48.sh).  SEVERAL sequences interleaved: normal priority -- every
     lane's decoder half in front of every lane's image-only half starves the latter (three lanes: 426 frames/s normal, 253 high;
     cfg 5: 130 / 102).  The streams are fixed members of PyTorch's pool (runtime.pool_stream: which streams decides the rate)."""
-    from .runtime import bind_streams, pool_stream
+    from .runtime import bind_streams, placement_tuned, pool_stream
+    if not placement_tuned():   # (another number of hardware queues than the tables were measured with: round 5's way)
+        return torch.cuda.Stream(device, priority=int(os.environ.get("TF_SEQ_STREAM_PRIORITY", "0")))
     bind_streams(device)
     default = "-1" if lanes == 1 else "0"
     priority = int(os.environ.get("TF_SEQ_STREAM_PRIORITY", default))

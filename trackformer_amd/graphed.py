@@ -122,7 +122,8 @@ class GraphedDetector:
 
     def _schedule_for(self, lanes):
         import os
-        wide = not self._multi_frame() and not hasattr(self.model, "lazy_masks_active")
+        from .runtime import placement_tuned
+        wide = not self._multi_frame() and not hasattr(self.model, "lazy_masks_active") and placement_tuned()
         slots, look_ahead, side_streams = self.WIDE if wide else self.NARROW
         look_ahead = max(1, int(os.environ.get("TF_GRAPH_LOOKAHEAD", look_ahead)))
         return (max(look_ahead + 1, int(os.environ.get("TF_GRAPH_SLOTS", slots))), look_ahead,
@@ -204,7 +205,10 @@ class GraphedDetector:
             # (several lanes: each wrapper its own streams, dist_utils.LANE_SIDES -- lanes on one side stream would run their
             # image-only halves one after the other: three lanes 313 frames/s; a seeded search over layouts, gpu_r06_53.sh:
             # WIDE 391 - 427 frames/s on every layout tried, NARROW 357 - 362 on 34 of 35)
-            from .runtime import bind_streams, pool_stream
+            from .runtime import bind_streams, placement_tuned, pool_stream
+            if not placement_tuned():   # (another number of hardware queues than the tables were measured with: round 5's way)
+                st = self._side[dev] = tuple(torch.cuda.Stream(dev) for _ in range(self.SIDE_STREAMS))
+                return st[slot % self.SIDE_STREAMS]
             bind_streams(dev)
             if self._lanes > 1:
                 from .dist_utils import LANE_SIDES, LANE_SIDES_NARROW

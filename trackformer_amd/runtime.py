@@ -87,6 +87,14 @@ def settle_heap():
 
 
 
+def placement_tuned():
+    """The stream placement of round 6 (pool_stream / bind_streams, dist_utils.sequence_stream, GraphedDetector's WIDE schedule) was
+    measured with the HIP runtime's default of 4 hardware queues per priority; with another GPU_MAX_HW_QUEUES the same tables read
+    155 - 292 frames/s instead of 375 (profiles/r06_stream_queue_map.txt, section 14).  False then: the callers keep round 5's
+    schedule (one side stream, the pool's next streams, normal priority: 349 frames/s wherever the streams sit)."""
+    return os.environ.get("GPU_MAX_HW_QUEUES", "4").strip() == "4"
+
+
 _BOUND = set()
 
 
